@@ -1,0 +1,558 @@
+// cull_project.hip -- frustum culling + 3D->2D EWA covariance projection, forward/backward.
+//
+// Replaces global_culling_kernel (gaussian.cu:1182-1336), global_culling_backward_kernel
+// (:1371-1576), world2camera (:49-99) and jacobian (:10-47) of the reference, and provides the
+// fused first/last stages of the frame path (gs_frame_forward / gs_frame_backward): projection
+// + activations + tile-rectangle count + per-block pair sums in ONE pass over the Gaussians.
+//
+// This file is compiled with -ffp-contract=off and evaluates every expression in the
+// reference's source order, so that depth bits and tile rectangles (the integer inputs of the
+// sort) are bit-identical to oracle/gs_oracle.c.  The stage is HBM-bound (40 B in, <=60 B out,
+// ~300 flops per Gaussian); losing FMA contraction costs nothing measurable.
+#include "gs_common.h"
+#include "gs_frame_layout.h"
+
+namespace {
+
+struct Cam {
+    float rot[9];
+    float tran[3];
+};
+
+__device__ __forceinline__ void world_to_camera(const float p[3], const Cam &cam, float pc[3]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        pc[i] = cam.rot[i * 3 + 0] * p[0] + cam.rot[i * 3 + 1] * p[1] + cam.rot[i * 3 + 2] * p[2] +
+                cam.tran[i];
+}
+
+__device__ __forceinline__ void quat_to_R(float w, float x, float y, float z, float R[9]) {
+    R[0] = 1 - 2 * y * y - 2 * z * z;
+    R[1] = 2 * x * y - 2 * z * w;
+    R[2] = 2 * x * z + 2 * y * w;
+    R[3] = 2 * x * y + 2 * z * w;
+    R[4] = 1 - 2 * x * x - 2 * z * z;
+    R[5] = 2 * y * z - 2 * x * w;
+    R[6] = 2 * x * z - 2 * y * w;
+    R[7] = 2 * y * z + 2 * x * w;
+    R[8] = 1 - 2 * x * x - 2 * y * y;
+}
+
+__device__ __forceinline__ void mm3(const float A[9], const float B[9], float C[9]) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float s = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s += A[r * 3 + k] * B[k * 3 + c];
+            C[r * 3 + c] = s;
+        }
+}
+__device__ __forceinline__ void mm3_nt(const float A[9], const float B[9], float C[9]) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float s = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s += A[r * 3 + k] * B[c * 3 + k];
+            C[r * 3 + c] = s;
+        }
+}
+
+// Rows 0,1 of J*W (row 2 of the Jacobian never reaches the 2x2 covariance).  JW is 3x3 with
+// row 2 left zero so the 3x3 products below have the reference's shape; the compiler drops
+// the dead row.
+__device__ __forceinline__ void jacobian_rows(const float pc[3], float J[9]) {
+    float u0 = pc[0], u1 = pc[1], u2 = pc[2];
+    J[0] = 1 / u2;
+    J[1] = 0;
+    J[2] = -u0 / (u2 * u2);
+    J[3] = 0;
+    J[4] = 1 / u2;
+    J[5] = -u1 / (u2 * u2);
+    J[6] = 0;
+    J[7] = 0;
+    J[8] = 0;
+}
+
+// Returns false when culled.  pos_i = (x/z, y/z, |p_c|), cov = (S00, S01, S10, S11).
+__device__ __forceinline__ bool project(const float p[3], const float q[4], const float s[3],
+                                        const Cam &cam, float near_plane, float half_w, float half_h,
+                                        float pos_i[3], float cov[4]) {
+    float pc[3];
+    world_to_camera(p, cam, pc);
+    if (pc[2] <= near_plane) return false;
+    pos_i[0] = pc[0] / pc[2];
+    pos_i[1] = pc[1] / pc[2];
+    pos_i[2] = sqrtf(pc[0] * pc[0] + pc[1] * pc[1] + pc[2] * pc[2]);
+    if (fabsf(pos_i[0]) >= half_w || fabsf(pos_i[1]) >= half_h) return false;
+    float R[9], S[9] = {s[0], 0, 0, 0, s[1], 0, 0, 0, s[2]}, RS[9], RSSR[9], J[9], JW[9], JWC[9], JWCWJ[9];
+    quat_to_R(q[0], q[1], q[2], q[3], R);
+    mm3(R, S, RS);
+    mm3_nt(RS, RS, RSSR);
+    jacobian_rows(pc, J);
+    mm3(J, cam.rot, JW);
+    mm3(JW, RSSR, JWC);
+    mm3_nt(JWC, JW, JWCWJ);
+    cov[0] = JWCWJ[0];
+    cov[1] = JWCWJ[1];
+    cov[2] = JWCWJ[3];
+    cov[3] = JWCWJ[4];
+    return true;
+}
+
+// Backward of `project` w.r.t. (p, q_hat, s_hat) given dL/dpos_i and dL/dcov
+// (gaussian.cu:1393-1575; the dependence of J on p is dropped exactly as there).
+__device__ __forceinline__ void project_backward(const float p[3], const float q[4], const float s[3],
+                                                 const Cam &cam, const float gi[3], const float g2[4],
+                                                 float gp[3], float gq[4], float gs[3]) {
+    float pc[3];
+    world_to_camera(p, cam, pc);
+    float r = sqrtf(pc[0] * pc[0] + pc[1] * pc[1] + pc[2] * pc[2]);
+    float gc[3];
+    gc[0] = gi[0] / pc[2] + gi[2] * pc[0] / r;
+    gc[1] = gi[1] / pc[2] + gi[2] * pc[1] / r;
+    gc[2] = -gi[0] * pc[0] / (pc[2] * pc[2]) - gi[1] * pc[1] / (pc[2] * pc[2]) + gi[2] * pc[2] / r;
+#pragma unroll
+    for (int ir = 0; ir < 3; ++ir) {
+        float a = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) a += cam.rot[k * 3 + ir] * gc[k];
+        gp[ir] = a;
+    }
+    float J[9], JW[9];
+    jacobian_rows(pc, J);
+    mm3(J, cam.rot, JW);
+    float g3[9];
+#pragma unroll
+    for (int ir = 0; ir < 3; ++ir)
+#pragma unroll
+        for (int ic = 0; ic < 3; ++ic) {
+            float a = 0;
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int ij = 0; ij < 2; ++ij) a += g2[ii * 2 + ij] * JW[ii * 3 + ir] * JW[ij * 3 + ic];
+            g3[ir * 3 + ic] = a;
+        }
+    float R[9], S[9] = {s[0], 0, 0, 0, s[1], 0, 0, 0, s[2]}, RS[9], gRS[9];
+    quat_to_R(q[0], q[1], q[2], q[3], R);
+    mm3(R, S, RS);
+#pragma unroll
+    for (int ir = 0; ir < 3; ++ir)
+#pragma unroll
+        for (int ic = 0; ic < 3; ++ic) {
+            float a = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) a += (g3[k * 3 + ir] + g3[ir * 3 + k]) * RS[k * 3 + ic];
+            gRS[ir * 3 + ic] = a;
+        }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        gs[i] = gRS[0 * 3 + i] * R[0 * 3 + i] + gRS[1 * 3 + i] * R[1 * 3 + i] + gRS[2 * 3 + i] * R[2 * 3 + i];
+    const float sx = s[0], sy = s[1], sz = s[2];
+    const float qr = q[0], qi = q[1], qj = q[2], qk = q[3];
+    const float c_qr[9] = {0, -2 * sy * qk, 2 * sz * qj, 2 * sx * qk, 0, -2 * sz * qi, -2 * sx * qj, 2 * sy * qi, 0};
+    const float c_qi[9] = {0, 2 * sy * qj, 2 * sz * qk, 2 * sx * qj, -4 * sy * qi, -2 * sz * qr,
+                           2 * sx * qk, 2 * sy * qr, -4 * sz * qi};
+    const float c_qj[9] = {-4 * sx * qj, 2 * sy * qi, 2 * sz * qr, 2 * sx * qi, 0, 2 * sz * qk,
+                           -2 * sx * qr, 2 * sy * qk, -4 * sz * qj};
+    const float c_qk[9] = {-4 * sx * qk, -2 * sy * qr, 2 * sz * qi, 2 * sx * qr, -4 * sy * qk, 2 * sz * qj,
+                           2 * sx * qi, 2 * sy * qj, 0};
+    float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        a0 += c_qr[i] * gRS[i];
+        a1 += c_qi[i] * gRS[i];
+        a2 += c_qj[i] * gRS[i];
+        a3 += c_qk[i] * gRS[i];
+    }
+    gq[0] = a0;
+    gq[1] = a1;
+    gq[2] = a2;
+    gq[3] = a3;
+}
+
+__device__ __forceinline__ void load3(const float *base, int64_t i, float v[3]) {
+    v[0] = base[i * 3 + 0];
+    v[1] = base[i * 3 + 1];
+    v[2] = base[i * 3 + 2];
+}
+
+// ---------------------------------------------------------------- reference-API kernels
+__global__ void __launch_bounds__(256) global_culling_kernel(
+    const float *__restrict__ pos, const float4 *__restrict__ quat, const float *__restrict__ scale,
+    const float *__restrict__ rot, const float *__restrict__ tran, int64_t n, float near_plane,
+    float half_w, float half_h, float *__restrict__ res_pos, float4 *__restrict__ res_cov,
+    int64_t *__restrict__ mask) {
+    Cam cam;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) cam.rot[i] = rot[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) cam.tran[i] = tran[i];
+    for (int64_t pid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pid < n;
+         pid += (int64_t)gridDim.x * blockDim.x) {
+        float p[3], s[3], pi[3], cv[4];
+        load3(pos, pid, p);
+        load3(scale, pid, s);
+        float4 q4 = quat[pid];
+        float q[4] = {q4.x, q4.y, q4.z, q4.w};
+        if (!project(p, q, s, cam, near_plane, half_w, half_h, pi, cv)) continue;
+        mask[pid] = 1;
+        res_pos[pid * 3 + 0] = pi[0];
+        res_pos[pid * 3 + 1] = pi[1];
+        res_pos[pid * 3 + 2] = pi[2];
+        res_cov[pid] = make_float4(cv[0], cv[1], cv[2], cv[3]);
+    }
+}
+
+__global__ void __launch_bounds__(256) global_culling_backward_kernel(
+    const float *__restrict__ pos, const float4 *__restrict__ quat, const float *__restrict__ scale,
+    const float *__restrict__ rot, const float *__restrict__ tran, int64_t n,
+    const float *__restrict__ gradout_pos, const float4 *__restrict__ gradout_cov,
+    const int64_t *__restrict__ mask, float *__restrict__ gin_pos, float4 *__restrict__ gin_quat,
+    float *__restrict__ gin_scale) {
+    Cam cam;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) cam.rot[i] = rot[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) cam.tran[i] = tran[i];
+    for (int64_t pid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pid < n;
+         pid += (int64_t)gridDim.x * blockDim.x) {
+        if (mask[pid] == 0) continue;
+        float p[3], s[3], gi[3], gp[3], gq[4], gs[3];
+        load3(pos, pid, p);
+        load3(scale, pid, s);
+        load3(gradout_pos, pid, gi);
+        float4 q4 = quat[pid], c4 = gradout_cov[pid];
+        float q[4] = {q4.x, q4.y, q4.z, q4.w}, g2[4] = {c4.x, c4.y, c4.z, c4.w};
+        project_backward(p, q, s, cam, gi, g2, gp, gq, gs);
+        gin_pos[pid * 3 + 0] = gp[0];
+        gin_pos[pid * 3 + 1] = gp[1];
+        gin_pos[pid * 3 + 2] = gp[2];
+        gin_quat[pid] = make_float4(gq[0], gq[1], gq[2], gq[3]);
+        gin_scale[pid * 3 + 0] = gs[0];
+        gin_scale[pid * 3 + 1] = gs[1];
+        gin_scale[pid * 3 + 2] = gs[2];
+    }
+}
+
+__global__ void __launch_bounds__(256) world2camera_kernel(const float *__restrict__ pos,
+                                                          const float *__restrict__ rot,
+                                                          const float *__restrict__ tran,
+                                                          float *__restrict__ res, int64_t B) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {
+        float p[3];
+        load3(pos, i, p);
+        res[i * 3 + 0] = p[0] * rot[0] + p[1] * rot[1] + p[2] * rot[2] + tran[0];
+        res[i * 3 + 1] = p[0] * rot[3] + p[1] * rot[4] + p[2] * rot[5] + tran[1];
+        res[i * 3 + 2] = p[0] * rot[6] + p[1] * rot[7] + p[2] * rot[8] + tran[2];
+    }
+}
+
+__global__ void __launch_bounds__(256) world2camera_backward_kernel(const float *__restrict__ grad_out,
+                                                                   const float *__restrict__ rot,
+                                                                   float *__restrict__ grad_inp, int64_t B) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {
+        float g[3];
+        load3(grad_out, i, g);
+        grad_inp[i * 3 + 0] = g[0] * rot[0] + g[1] * rot[3] + g[2] * rot[6];
+        grad_inp[i * 3 + 1] = g[0] * rot[1] + g[1] * rot[4] + g[2] * rot[7];
+        grad_inp[i * 3 + 2] = g[0] * rot[2] + g[1] * rot[5] + g[2] * rot[8];
+    }
+}
+
+__global__ void __launch_bounds__(256) jacobian_kernel(const float *__restrict__ pos_cam,
+                                                      float *__restrict__ jac, int64_t B) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {
+        float u[3];
+        load3(pos_cam, i, u);
+        float *J = jac + i * 9;
+        J[0] = 1 / u[2];
+        J[1] = 0;
+        J[2] = -u[0] / (u[2] * u[2]);
+        J[3] = 0;
+        J[4] = 1 / u[2];
+        J[5] = -u[1] / (u[2] * u[2]);
+        float rs = 1.0f / sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+        J[6] = rs * u[0];
+        J[7] = rs * u[1];
+        J[8] = rs * u[2];
+    }
+}
+
+// ---------------------------------------------------------------- fused frame stage S1
+// One thread per Gaussian: activations -> project -> tile rectangle -> per-Gaussian record.
+// Per-block sum of tiles_touched goes to block_sums[blockIdx.x] (input of the scan stage).
+struct ProjectParams {
+    Cam cam;
+    float near_plane, half_w, half_h;
+    float tlog;  // -2*logf(thresh), computed on the host
+    float tlx, tly, leftmost, topmost;
+    uint32_t ntx, nty;
+    int32_t scale_act;
+    int32_t color_dim;
+};
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Tile rectangle of calc_tile_info_kernel3 (gaussian.cu:226-242); count = 0 if det <= 0.
+__device__ __forceinline__ uint32_t tile_rect(float cx, float cy, const float cv[4], const ProjectParams &P,
+                                              uint32_t &y0, uint32_t &y1, uint32_t &x0, uint32_t &x1) {
+    float det = (cv[0] * cv[3] - cv[1] * cv[2]);
+    y0 = y1 = x0 = x1 = 0;
+    if (det <= 0) return 0;
+    float ai = (float)(cv[3] / (det + 1e-14));
+    float di = (float)(cv[0] / (det + 1e-14));
+    float shift_x = sqrtf(di * P.tlog * det);
+    float shift_y = sqrtf(ai * P.tlog * det);
+    float bbx_right = cx + shift_x, bbx_left = cx - shift_x;
+    float bbx_top = cy - shift_y, bbx_bottom = cy + shift_y;
+    y0 = gs_f2u_sat(fmaxf((bbx_top - P.topmost) / P.tly, 0));
+    y1 = gs_f2u_sat((bbx_bottom - P.topmost) / P.tly + 1);
+    x0 = gs_f2u_sat(fmaxf((bbx_left - P.leftmost) / P.tlx, 0));
+    x1 = gs_f2u_sat((bbx_right - P.leftmost) / P.tlx + 1);
+    if (y1 > P.nty) y1 = P.nty;
+    if (x1 > P.ntx) x1 = P.ntx;
+    if (y0 > y1) y0 = y1;
+    if (x0 > x1) x0 = x1;
+    return (y1 - y0) * (x1 - x0);
+}
+
+__device__ __forceinline__ void activate(const float qraw[4], const float sraw[3], int scale_act,
+                                         float q[4], float s[3]) {
+    float nr = sqrtf(qraw[0] * qraw[0] + qraw[1] * qraw[1] + qraw[2] * qraw[2] + qraw[3] * qraw[3]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[k] = qraw[k] / nr;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s[k] = scale_act == 0 ? fabsf(sraw[k]) + 1e-4f : expf(sraw[k]);
+}
+
+__global__ void __launch_bounds__(256) frame_project_kernel(
+    const float *__restrict__ pos, const float4 *__restrict__ quat, const float *__restrict__ scale,
+    const float *__restrict__ opa, const float *__restrict__ rgb, int64_t n, ProjectParams P,
+    float4 *__restrict__ rec_geom, float4 *__restrict__ rec_cov, float4 *__restrict__ rec_color,
+    uint32_t *__restrict__ tiles_touched, uint2 *__restrict__ rects, uint32_t *__restrict__ block_sums,
+    unsigned long long *__restrict__ counters) {
+    const int64_t pid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t cnt = 0, vis = 0;
+    if (pid < n) {
+        float p[3], sraw[3], q[4], s[3], pi[3], cv[4];
+        load3(pos, pid, p);
+        load3(scale, pid, sraw);
+        float4 q4 = quat[pid];
+        float qraw[4] = {q4.x, q4.y, q4.z, q4.w};
+        activate(qraw, sraw, P.scale_act, q, s);
+        float4 g = make_float4(0, 0, 0, 0), c = make_float4(0, 0, 0, 0), col = make_float4(0, 0, 0, 0);
+        uint2 rc = make_uint2(0, 0);
+        if (project(p, q, s, P.cam, P.near_plane, P.half_w, P.half_h, pi, cv)) {
+            vis = 1;
+            uint32_t y0, y1, x0, x1;
+            cnt = tile_rect(pi[0], pi[1], cv, P, y0, y1, x0, x1);
+            rc = make_uint2(y0 | (y1 << 16), x0 | (x1 << 16));
+            g = make_float4(pi[0], pi[1], pi[2], sigmoid_f(opa[pid]));
+            c = make_float4(cv[0], cv[1], cv[2], cv[3]);
+            if (P.color_dim == 3)
+                col = make_float4(sigmoid_f(rgb[pid * 3 + 0]), sigmoid_f(rgb[pid * 3 + 1]),
+                                  sigmoid_f(rgb[pid * 3 + 2]), 0.0f);
+        }
+        rec_geom[pid] = g;
+        rec_cov[pid] = c;
+        if (P.color_dim == 3) rec_color[pid] = col;
+        tiles_touched[pid] = cnt;
+        rects[pid] = rc;
+    }
+    // block sum of cnt (and of the visible flag) -> one store / one atomic per block
+    __shared__ uint32_t s_cnt[4], s_vis[4];
+    uint32_t wsum = gs_wave_sum_u32(cnt), wvis = gs_wave_sum_u32(vis);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s_cnt[wave] = wsum;
+        s_vis[wave] = wvis;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        block_sums[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        uint32_t v = s_vis[0] + s_vis[1] + s_vis[2] + s_vis[3];
+        if (v) atomicAdd(&counters[GS_CNT_VISIBLE], (unsigned long long)v);
+    }
+}
+
+// ---------------------------------------------------------------- fused frame stage B2
+// dgeom[N][12] = (dx, dy, da, db, dc, dd, dopa, dr, dg, db, -, -) accumulated by the raster
+// backward.  Writes dL/d(raw parameters); culled Gaussians get zeros.
+__global__ void __launch_bounds__(256) frame_project_backward_kernel(
+    const float *__restrict__ pos, const float4 *__restrict__ quat, const float *__restrict__ scale,
+    const float *__restrict__ rgb, int64_t n, ProjectParams P, const float4 *__restrict__ rec_geom,
+    const float4 *__restrict__ rec_color, const float4 *__restrict__ dgeom, float *__restrict__ grad_pos,
+    float4 *__restrict__ grad_quat, float *__restrict__ grad_scale, float *__restrict__ grad_opa,
+    float *__restrict__ grad_rgb) {
+    const int64_t pid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pid >= n) return;
+    const float4 g = rec_geom[pid];
+    float gp[3] = {0, 0, 0}, gqr[4] = {0, 0, 0, 0}, gsr[3] = {0, 0, 0}, gopa = 0, gcol[3] = {0, 0, 0};
+    if (g.z != 0.0f) {  // visible (depth > near > 0)
+        const float4 d0 = dgeom[pid * 3 + 0], d1 = dgeom[pid * 3 + 1], d2 = dgeom[pid * 3 + 2];
+        float p[3], sraw[3], q[4], s[3];
+        load3(pos, pid, p);
+        load3(scale, pid, sraw);
+        float4 q4 = quat[pid];
+        float qraw[4] = {q4.x, q4.y, q4.z, q4.w};
+        activate(qraw, sraw, P.scale_act, q, s);
+        float gi[3] = {d0.x, d0.y, 0.0f}, g2[4] = {d0.z, d0.w, d1.x, d1.y}, gq[4], gs[3];
+        project_backward(p, q, s, P.cam, gi, g2, gp, gq, gs);
+        // q_hat = q / |q|  ->  dq = (dq_hat - q_hat (q_hat . dq_hat)) / |q|
+        float nr = sqrtf(qraw[0] * qraw[0] + qraw[1] * qraw[1] + qraw[2] * qraw[2] + qraw[3] * qraw[3]);
+        float dt = q[0] * gq[0] + q[1] * gq[1] + q[2] * gq[2] + q[3] * gq[3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gqr[k] = (gq[k] - q[k] * dt) / nr;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (P.scale_act == 0)  // |s| + 1e-4 : d/ds = sign(s)
+                gsr[k] = sraw[k] > 0 ? gs[k] : (sraw[k] < 0 ? -gs[k] : 0.0f);
+            else  // trunc_exp backward (renderer.py:97-100): g * exp(clamp(x, -1, 1))
+                gsr[k] = gs[k] * expf(fminf(fmaxf(sraw[k], -1.0f), 1.0f));
+        }
+        gopa = d1.z * g.w * (1.0f - g.w);
+        if (P.color_dim == 3) {
+            const float4 c = rec_color[pid];
+            gcol[0] = d1.w * c.x * (1.0f - c.x);
+            gcol[1] = d2.x * c.y * (1.0f - c.y);
+            gcol[2] = d2.y * c.z * (1.0f - c.z);
+        }
+    }
+    grad_pos[pid * 3 + 0] = gp[0];
+    grad_pos[pid * 3 + 1] = gp[1];
+    grad_pos[pid * 3 + 2] = gp[2];
+    grad_quat[pid] = make_float4(gqr[0], gqr[1], gqr[2], gqr[3]);
+    grad_scale[pid * 3 + 0] = gsr[0];
+    grad_scale[pid * 3 + 1] = gsr[1];
+    grad_scale[pid * 3 + 2] = gsr[2];
+    grad_opa[pid] = gopa;
+    if (P.color_dim == 3) {
+        grad_rgb[pid * 3 + 0] = gcol[0];
+        grad_rgb[pid * 3 + 1] = gcol[1];
+        grad_rgb[pid * 3 + 2] = gcol[2];
+    }
+    (void)rgb;
+}
+
+inline int grid_for(int64_t n, int block) {
+    int64_t g = gs_div_up(n, block);
+    if (g > 8192) g = 8192;  // 256 CUs x 8 blocks x 4: grid-stride beyond that
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+// ================================================================= C ABI (section A)
+extern "C" int gs_world2camera(const float *pos, const float *rot, const float *tran, float *res, int64_t B,
+                               gs_stream_t stream) {
+    GS_CHECK_ARG(B >= 0, "B < 0");
+    if (B == 0) return 0;
+    GS_CHECK_ARG(pos && rot && tran && res, "null pointer");
+    hipLaunchKernelGGL(world2camera_kernel, dim3(grid_for(B, 256)), dim3(256), 0, (hipStream_t)stream, pos, rot,
+                       tran, res, B);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gs_world2camera_backward(const float *grad_out, const float *rot, float *grad_inp, int64_t B,
+                                        gs_stream_t stream) {
+    GS_CHECK_ARG(B >= 0, "B < 0");
+    if (B == 0) return 0;
+    GS_CHECK_ARG(grad_out && rot && grad_inp, "null pointer");
+    hipLaunchKernelGGL(world2camera_backward_kernel, dim3(grid_for(B, 256)), dim3(256), 0, (hipStream_t)stream,
+                       grad_out, rot, grad_inp, B);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gs_jacobian(const float *pos_cam, float *jac, int64_t B, gs_stream_t stream) {
+    GS_CHECK_ARG(B >= 0, "B < 0");
+    if (B == 0) return 0;
+    GS_CHECK_ARG(pos_cam && jac, "null pointer");
+    hipLaunchKernelGGL(jacobian_kernel, dim3(grid_for(B, 256)), dim3(256), 0, (hipStream_t)stream, pos_cam, jac, B);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gs_global_culling(const float *pos, const float *quat, const float *scale, const float *rot,
+                                 const float *tran, int64_t N, float near_plane, float half_width,
+                                 float half_height, float *res_pos, float *res_cov, int64_t *culling_mask,
+                                 gs_stream_t stream) {
+    GS_CHECK_ARG(N >= 0, "N < 0");
+    if (N == 0) return 0;
+    GS_CHECK_ARG(pos && quat && scale && rot && tran && res_pos && res_cov && culling_mask, "null pointer");
+    GS_CHECK_ARG(((uintptr_t)quat & 15) == 0 && ((uintptr_t)res_cov & 15) == 0, "quat/res_cov must be 16-byte aligned");
+    hipLaunchKernelGGL(global_culling_kernel, dim3(grid_for(N, 256)), dim3(256), 0, (hipStream_t)stream, pos,
+                       (const float4 *)quat, scale, rot, tran, N, near_plane, half_width, half_height, res_pos,
+                       (float4 *)res_cov, culling_mask);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gs_global_culling_backward(const float *pos, const float *quat, const float *scale,
+                                          const float *rot, const float *tran, int64_t N,
+                                          const float *gradout_pos, const float *gradout_cov,
+                                          const int64_t *culling_mask, float *gradinput_pos,
+                                          float *gradinput_quat, float *gradinput_scale, gs_stream_t stream) {
+    GS_CHECK_ARG(N >= 0, "N < 0");
+    if (N == 0) return 0;
+    GS_CHECK_ARG(pos && quat && scale && rot && tran && gradout_pos && gradout_cov && culling_mask &&
+                     gradinput_pos && gradinput_quat && gradinput_scale,
+                 "null pointer");
+    GS_CHECK_ARG(((uintptr_t)quat & 15) == 0 && ((uintptr_t)gradout_cov & 15) == 0 &&
+                     ((uintptr_t)gradinput_quat & 15) == 0,
+                 "quat/gradout_cov/gradinput_quat must be 16-byte aligned");
+    hipLaunchKernelGGL(global_culling_backward_kernel, dim3(grid_for(N, 256)), dim3(256), 0, (hipStream_t)stream,
+                       pos, (const float4 *)quat, scale, rot, tran, N, gradout_pos, (const float4 *)gradout_cov,
+                       culling_mask, gradinput_pos, (float4 *)gradinput_quat, gradinput_scale);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+// ================================================================= frame stages (internal)
+static ProjectParams make_params(const gs_frame *f) {
+    ProjectParams P;
+    for (int i = 0; i < 9; ++i) P.cam.rot[i] = f->rot[i];
+    for (int i = 0; i < 3; ++i) P.cam.tran[i] = f->tran[i];
+    P.near_plane = f->near_plane;
+    P.half_w = f->half_width;
+    P.half_h = f->half_height;
+    P.tlog = -2 * logf(f->thresh);
+    gs_frame_geom G = gs_frame_geometry(f);
+    P.tlx = G.tlx;
+    P.tly = G.tly;
+    P.leftmost = G.leftmost;
+    P.topmost = G.topmost;
+    P.ntx = (uint32_t)G.ntx;
+    P.nty = (uint32_t)G.nty;
+    P.scale_act = f->scale_activation;
+    P.color_dim = f->color_dim;
+    return P;
+}
+
+int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream) {
+    ProjectParams P = make_params(f);
+    int nblk = (int)gs_div_up(f->N, 256);
+    hipLaunchKernelGGL(frame_project_kernel, dim3(nblk), dim3(256), 0, stream, f->pos, (const float4 *)f->quat,
+                       f->scale, f->opa, f->rgb, f->N, P, ws.rec_geom, ws.rec_cov, ws.rec_color,
+                       ws.tiles_touched, ws.rects, ws.block_sums, ws.counters);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+int gs_stage_project_backward(const gs_frame *f, const gs_frame_ws &ws, float *grad_pos, float *grad_quat,
+                              float *grad_scale, float *grad_opa, float *grad_rgb, hipStream_t stream) {
+    ProjectParams P = make_params(f);
+    int nblk = (int)gs_div_up(f->N, 256);
+    hipLaunchKernelGGL(frame_project_backward_kernel, dim3(nblk), dim3(256), 0, stream, f->pos,
+                       (const float4 *)f->quat, f->scale, f->rgb, f->N, P, ws.rec_geom, ws.rec_color,
+                       (const float4 *)ws.dgeom, grad_pos, (float4 *)grad_quat, grad_scale, grad_opa, grad_rgb);
+    GS_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,99 @@
+// gs_common.h -- shared host/device helpers for libgs_amd (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/gs_abi.h"
+
+#define GS_WAVE 64
+#define GS_TILE 16
+
+// ---- error plumbing ------------------------------------------------------------------
+void gs_set_error(const char *fmt, ...);
+
+#define GS_CHECK_ARG(cond, what)                                   \
+    do {                                                           \
+        if (!(cond)) {                                             \
+            gs_set_error("%s: invalid argument: %s", __func__, what); \
+            return GS_E_INVALID;                                   \
+        }                                                          \
+    } while (0)
+
+#define GS_CHECK_LAUNCH()                                                         \
+    do {                                                                          \
+        hipError_t e_ = hipGetLastError();                                        \
+        if (e_ != hipSuccess) {                                                   \
+            gs_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e_)); \
+            return (int)e_;                                                       \
+        }                                                                         \
+    } while (0)
+
+#define GS_HIP(call)                                                              \
+    do {                                                                          \
+        hipError_t e_ = (call);                                                   \
+        if (e_ != hipSuccess) {                                                   \
+            gs_set_error("%s: %s failed: %s", __func__, #call, hipGetErrorString(e_)); \
+            return (int)e_;                                                       \
+        }                                                                         \
+    } while (0)
+
+static inline int64_t gs_div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t gs_align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+// ---- device helpers ---------------------------------------------------------------------
+#ifdef __HIPCC__
+
+// float -> uint32 with the saturating semantics of the reference's `(uint32_t)float`
+// conversions in calc_tile_info_kernel3 (gaussian.cu:241-242): NaN/negative -> 0.
+__device__ __forceinline__ uint32_t gs_f2u_sat(float v) {
+    if (!(v > 0.0f)) return 0u;
+    if (v >= 4294967296.0f) return 0xffffffffu;
+    return (uint32_t)v;
+}
+
+// wave64 helpers
+__device__ __forceinline__ int gs_lane() { return (int)__lane_id(); }
+
+__device__ __forceinline__ float gs_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t gs_wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// inclusive prefix sum across the 64 lanes of a wave
+__device__ __forceinline__ uint32_t gs_wave_incl_scan_u32(uint32_t v) {
+    const int lane = gs_lane();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// DPP full-wave shift right by one lane (gfx9 `wave_shr:1`): lane l receives src[l-1];
+// lane 0 keeps `old`.
+__device__ __forceinline__ float gs_wave_shr1(float old, float src) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src),
+                                           0x138, 0xf, 0xf, false));
+}
+
+// 2^x on the transcendental unit (v_exp_f32)
+__device__ __forceinline__ float gs_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float gs_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+#define GS_LOG2E 1.4426950408889634f
+#define GS_LN2 0.6931471805599453f
+
+// Early-stop test of the reference: `if (accum < 0.0001) break;` compares the float
+// promoted to double against the double literal (gaussian.cu:906); 0.0001f is the largest
+// float below 0.0001, so the test is exactly `accum <= 0.0001f`.
+#define GS_T_STOP 0.0001f
+
+#endif  // __HIPCC__

@@ -1,0 +1,194 @@
+// gs_frame.hip -- host orchestration of the fused frame path + error plumbing.
+//
+// gs_frame_forward issues, on ONE stream and with NO host synchronisation:
+//   memset(counters) -> S1 project+count -> S3 scan block sums -> S4 emit keys -> S5 radix sort
+//   (3 launches x ceil((32+tile_bits)/8) passes) -> S6 tile ranges -> S7 raster forward.
+// The number of (tile, Gaussian) pairs M lives in device memory only; every later stage is
+// launched with a capacity-sized grid and idles past M.  The reference needs >= 8 blocking
+// host syncs for the same work.
+#include <stdarg.h>
+#include <string.h>
+
+#include "gs_common.h"
+#include "gs_frame_layout.h"
+
+static thread_local char g_err[512] = "";
+
+void gs_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *gs_last_error(void) { return g_err; }
+extern "C" int gs_abi_version(void) { return GS_ABI_VERSION; }
+extern "C" int gs_culling(void) { return 0; }  // gaussian.cu:6-8 prints "hellow"; nothing to compute
+
+static int tile_bits(int n_tiles) {
+    int b = 0;
+    while ((1 << b) < n_tiles) ++b;
+    return b < 1 ? 1 : b;
+}
+
+static int validate(const gs_frame *f) {
+    GS_CHECK_ARG(f != nullptr, "frame is null");
+    GS_CHECK_ARG(f->N >= 0 && f->N < (1ll << 31), "N out of range");
+    GS_CHECK_ARG(f->color_dim == 3 || f->color_dim == 27, "color_dim must be 3 or 27");
+    GS_CHECK_ARG(f->scale_activation == 0 || f->scale_activation == 1, "scale_activation must be 0 (abs) or 1 (exp)");
+    GS_CHECK_ARG(f->width > 0 && f->height > 0, "empty image");
+    GS_CHECK_ARG(f->width <= 65535 * 16 && f->height <= 65535 * 16, "image too large");
+    GS_CHECK_ARG(f->max_pairs > 0 && f->max_pairs < (1ll << 32), "max_pairs out of range");
+    GS_CHECK_ARG(f->N == 0 || (f->pos && f->quat && f->scale && f->opa && f->rgb), "null scene pointer");
+    GS_CHECK_ARG(((uintptr_t)f->quat & 15) == 0, "quat must be 16-byte aligned");
+    GS_CHECK_ARG(f->workspace != nullptr && ((uintptr_t)f->workspace & 255) == 0, "workspace null or not 256-byte aligned");
+    GS_CHECK_ARG(f->thresh > 0.f && f->thresh < 1.f, "thresh must be in (0,1)");
+    const size_t need = gs_frame_workspace_bytes(f->N, f->max_pairs, f->width, f->height, f->color_dim, f->training);
+    if (f->workspace_bytes < need) {
+        gs_set_error("gs_frame: workspace too small (%zu < %zu bytes)", f->workspace_bytes, need);
+        return GS_E_CAPACITY;
+    }
+    return 0;
+}
+
+extern "C" size_t gs_frame_workspace_bytes(int64_t N, int64_t max_pairs, int32_t width, int32_t height,
+                                           int32_t color_dim, int32_t training) {
+    if (N < 0 || max_pairs < 0 || width <= 0 || height <= 0) return 0;
+    return gs_frame_carve(nullptr, N, max_pairs, width, height, color_dim, training).total_bytes;
+}
+
+static void sorted_buffers(const gs_frame *f, const gs_frame_ws &ws, const uint64_t **keys, const uint32_t **ids) {
+    gs_frame_geom G = gs_frame_geometry(f);
+    const int npass = (32 + tile_bits(G.n_tiles) + 7) / 8;
+    *keys = (npass & 1) ? ws.keys_b : ws.keys_a;
+    *ids = (npass & 1) ? ws.vals_b : ws.vals_a;
+}
+
+struct StageTimer {
+    hipEvent_t ev[GS_N_STAGES + 1];
+    int n = 0;
+    bool on;
+    hipStream_t s;
+    StageTimer(bool enabled, hipStream_t stream) : on(enabled), s(stream) {
+        if (on)
+            for (auto &e : ev) hipEventCreate(&e);
+    }
+    ~StageTimer() {
+        if (on)
+            for (auto &e : ev) hipEventDestroy(e);
+    }
+    void mark() {
+        if (on && n <= GS_N_STAGES) hipEventRecord(ev[n++], s);
+    }
+    // ms[i] = ev[i+1] - ev[i]; ms[last] = total
+    int finish(float *ms, int n_stages) {
+        if (!on) return 0;
+        GS_HIP(hipEventSynchronize(ev[n - 1]));
+        for (int i = 0; i + 1 < n && i < n_stages - 1; ++i) hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]);
+        hipEventElapsedTime(&ms[n_stages - 1], ev[0], ev[n - 1]);
+        return 0;
+    }
+};
+
+static int frame_forward_impl(const gs_frame *f, hipStream_t s, float *stage_ms) {
+    int rc = validate(f);
+    if (rc) return rc;
+    GS_CHECK_ARG(!f->training || f->image_padded, "training needs image_padded");
+    GS_CHECK_ARG(f->image || f->image_padded, "no output image");
+    gs_frame_ws ws = gs_frame_carve(f->workspace, f->N, f->max_pairs, f->width, f->height, f->color_dim, f->training);
+    gs_frame_geom G = gs_frame_geometry(f);
+    StageTimer tm(stage_ms != nullptr, s);
+    tm.mark();
+    GS_HIP(hipMemsetAsync(ws.counters, 0, sizeof(unsigned long long) * GS_CNT_N, s));
+    if (f->N > 0 && (rc = gs_stage_project(f, ws, s))) return rc;
+    tm.mark();
+    if (f->N > 0 && (rc = gs_stage_scan_emit(f, ws, s))) return rc;
+    tm.mark();
+    if (f->N > 0) {
+        int in1 = 0;
+        rc = gs_sort_pairs(ws.keys_a, ws.vals_a, ws.keys_b, ws.vals_b, (const uint32_t *)(ws.counters + GS_CNT_PAIRS),
+                           f->max_pairs, 32 + tile_bits(G.n_tiles), ws.sort_tmp, ws.sort_tmp_bytes, &in1, s);
+        if (rc) return rc;
+    }
+    tm.mark();
+    const uint64_t *skeys;
+    const uint32_t *sids;
+    sorted_buffers(f, ws, &skeys, &sids);
+    if ((rc = gs_stage_tile_ranges(f, ws, skeys, s))) return rc;
+    tm.mark();
+    if ((rc = gs_stage_raster_forward(f, ws, sids, s))) return rc;
+    tm.mark();
+    return tm.finish(stage_ms, GS_N_STAGES);
+}
+
+extern "C" int gs_frame_forward(const gs_frame *f, gs_stream_t stream) {
+    return frame_forward_impl(f, (hipStream_t)stream, nullptr);
+}
+
+extern "C" int gs_frame_forward_profile(const gs_frame *f, float *stage_ms_host, gs_stream_t stream) {
+    GS_CHECK_ARG(stage_ms_host != nullptr, "stage_ms_host is null");
+    return frame_forward_impl(f, (hipStream_t)stream, stage_ms_host);
+}
+
+static int frame_backward_impl(const gs_frame *f, const float *grad_image, float *grad_pos, float *grad_quat,
+                               float *grad_scale, float *grad_opa, float *grad_rgb, hipStream_t s, float *stage_ms) {
+    int rc = validate(f);
+    if (rc) return rc;
+    GS_CHECK_ARG(f->training && f->image_padded, "gs_frame_backward needs a training forward (image_padded kept)");
+    GS_CHECK_ARG(grad_image && grad_pos && grad_quat && grad_scale && grad_opa && grad_rgb, "null pointer");
+    GS_CHECK_ARG(((uintptr_t)grad_quat & 15) == 0, "grad_quat must be 16-byte aligned");
+    if (f->N == 0) return 0;
+    gs_frame_ws ws = gs_frame_carve(f->workspace, f->N, f->max_pairs, f->width, f->height, f->color_dim, 1);
+    const uint64_t *skeys;
+    const uint32_t *sids;
+    sorted_buffers(f, ws, &skeys, &sids);
+    StageTimer tm(stage_ms != nullptr, s);
+    tm.mark();
+    if ((rc = gs_stage_raster_backward(f, ws, sids, grad_image, grad_rgb, s))) return rc;
+    tm.mark();
+    if ((rc = gs_stage_project_backward(f, ws, grad_pos, grad_quat, grad_scale, grad_opa, grad_rgb, s))) return rc;
+    tm.mark();
+    return tm.finish(stage_ms, 3);
+}
+
+extern "C" int gs_frame_backward(const gs_frame *f, const float *grad_image, float *grad_pos, float *grad_quat,
+                                 float *grad_scale, float *grad_opa, float *grad_rgb, gs_stream_t stream) {
+    return frame_backward_impl(f, grad_image, grad_pos, grad_quat, grad_scale, grad_opa, grad_rgb,
+                               (hipStream_t)stream, nullptr);
+}
+
+extern "C" int gs_frame_backward_profile(const gs_frame *f, const float *grad_image, float *grad_pos,
+                                         float *grad_quat, float *grad_scale, float *grad_opa, float *grad_rgb,
+                                         float *stage_ms_host, gs_stream_t stream) {
+    GS_CHECK_ARG(stage_ms_host != nullptr, "stage_ms_host is null");
+    return frame_backward_impl(f, grad_image, grad_pos, grad_quat, grad_scale, grad_opa, grad_rgb,
+                               (hipStream_t)stream, stage_ms_host);
+}
+
+extern "C" int gs_frame_stats_async(const gs_frame *f, int64_t *stats_host, gs_stream_t stream) {
+    int rc = validate(f);
+    if (rc) return rc;
+    GS_CHECK_ARG(stats_host != nullptr, "stats_host is null");
+    gs_frame_ws ws = gs_frame_carve(f->workspace, f->N, f->max_pairs, f->width, f->height, f->color_dim, f->training);
+    GS_HIP(hipMemcpyAsync(stats_host, ws.counters, sizeof(int64_t) * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int gs_frame_debug_views(const gs_frame *f, const uint64_t **sorted_keys, const uint32_t **sorted_ids,
+                                    const int32_t **tile_ranges, const float **rec_geom, const float **rec_cov,
+                                    const float **rec_color, const uint32_t **tiles_touched) {
+    int rc = validate(f);
+    if (rc) return rc;
+    gs_frame_ws ws = gs_frame_carve(f->workspace, f->N, f->max_pairs, f->width, f->height, f->color_dim, f->training);
+    const uint64_t *skeys;
+    const uint32_t *sids;
+    sorted_buffers(f, ws, &skeys, &sids);
+    if (sorted_keys) *sorted_keys = skeys;
+    if (sorted_ids) *sorted_ids = sids;
+    if (tile_ranges) *tile_ranges = ws.tile_ranges;
+    if (rec_geom) *rec_geom = (const float *)ws.rec_geom;
+    if (rec_cov) *rec_cov = (const float *)ws.rec_cov;
+    if (rec_color) *rec_color = (const float *)ws.rec_color;
+    if (tiles_touched) *tiles_touched = ws.tiles_touched;
+    return 0;
+}

@@ -1,0 +1,115 @@
+// gs_frame_layout.h -- workspace carving for the fused frame path (host side, shared by stages).
+#pragma once
+#include "gs_common.h"
+
+enum { GS_CNT_VISIBLE = 0, GS_CNT_PAIRS = 1, GS_CNT_OVERFLOW = 2, GS_CNT_BUCKETS = 3, GS_CNT_N = 8 };
+
+#define GS_BUCKET 64          // Gaussians per backward bucket (= wavefront size)
+#define GS_SORT_TILE 2048     // keys per radix-sort workgroup (256 threads x 8)
+
+struct gs_frame_geom {
+    int padW, padH, ntx, nty, n_tiles, crop_top, crop_left;
+    float tlx, tly, leftmost, topmost;
+};
+
+// Integer geometry of splatter.Tiles (splatter.py:259-272).
+static inline gs_frame_geom gs_frame_geometry_i(int W, int H) {
+    gs_frame_geom G;
+    G.padW = (W + GS_TILE - 1) / GS_TILE * GS_TILE;
+    G.padH = (H + GS_TILE - 1) / GS_TILE * GS_TILE;
+    G.ntx = G.padW / GS_TILE;
+    G.nty = G.padH / GS_TILE;
+    G.n_tiles = G.ntx * G.nty;
+    G.crop_top = (G.padH - H) / 2;
+    G.crop_left = (G.padW - W) / 2;
+    G.tlx = G.tly = G.leftmost = G.topmost = 0.f;
+    return G;
+}
+static inline gs_frame_geom gs_frame_geometry(const gs_frame *f) {
+    gs_frame_geom G = gs_frame_geometry_i(f->width, f->height);
+    G.tlx = f->tile_length_x;
+    G.tly = f->tile_length_y;
+    G.leftmost = f->leftmost;
+    G.topmost = f->topmost;
+    return G;
+}
+
+struct gs_frame_ws {
+    unsigned long long *counters;  // [GS_CNT_N]
+    float4 *rec_geom;              // [N] (x, y, depth, opacity)
+    float4 *rec_cov;               // [N] (a, b, c, d)
+    float4 *rec_color;             // [N] (r, g, b, -)  (color_dim == 3 only)
+    uint32_t *tiles_touched;       // [N]
+    uint2 *rects;                  // [N] (y0 | y1 << 16, x0 | x1 << 16)
+    uint32_t *block_sums;          // [ceil(N/256)]
+    uint32_t *block_offsets;       // [ceil(N/256)]
+    uint64_t *keys_a, *keys_b;     // [max_pairs]
+    uint32_t *vals_a, *vals_b;     // [max_pairs]
+    void *sort_tmp;
+    size_t sort_tmp_bytes;
+    int32_t *tile_ranges;          // [T][2]
+    // training only
+    uint32_t *tile_nproc;          // [T] Gaussians processed by the forward (multiple of the chunk)
+    uint32_t *bucket_offsets;      // [T+1] exclusive scan of ceil(nproc/64)
+    float4 *ckpt;                  // [max_buckets][256] (T, Cr, Cg, Cb) at bucket starts
+    float *dgeom;                  // [N][12]
+    int64_t max_buckets;
+    size_t total_bytes;
+};
+
+static inline int64_t gs_max_buckets(int64_t max_pairs, int n_tiles) {
+    return max_pairs / GS_BUCKET + n_tiles + 1;
+}
+
+// Carves `base` (may be NULL to only compute the size).
+static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pairs, int W, int H, int color_dim,
+                                         int training) {
+    gs_frame_ws ws;
+    gs_frame_geom G = gs_frame_geometry_i(W, H);
+    size_t off = 0;
+    auto take = [&](size_t bytes) -> void * {
+        void *p = base ? (void *)((char *)base + off) : nullptr;
+        off += gs_align_up(bytes ? bytes : 1, 256);
+        return p;
+    };
+    const int64_t nblk = gs_div_up(N > 0 ? N : 1, 256);
+    ws.counters = (unsigned long long *)take(sizeof(unsigned long long) * GS_CNT_N);
+    ws.rec_geom = (float4 *)take(sizeof(float4) * N);
+    ws.rec_cov = (float4 *)take(sizeof(float4) * N);
+    ws.rec_color = (float4 *)take(color_dim == 3 ? sizeof(float4) * N : 0);
+    ws.tiles_touched = (uint32_t *)take(sizeof(uint32_t) * N);
+    ws.rects = (uint2 *)take(sizeof(uint2) * N);
+    ws.block_sums = (uint32_t *)take(sizeof(uint32_t) * nblk);
+    ws.block_offsets = (uint32_t *)take(sizeof(uint32_t) * nblk);
+    ws.keys_a = (uint64_t *)take(sizeof(uint64_t) * max_pairs);
+    ws.keys_b = (uint64_t *)take(sizeof(uint64_t) * max_pairs);
+    ws.vals_a = (uint32_t *)take(sizeof(uint32_t) * max_pairs);
+    ws.vals_b = (uint32_t *)take(sizeof(uint32_t) * max_pairs);
+    ws.sort_tmp_bytes = gs_sort_pairs_tmp_bytes(max_pairs);
+    ws.sort_tmp = take(ws.sort_tmp_bytes);
+    ws.tile_ranges = (int32_t *)take(sizeof(int32_t) * 2 * G.n_tiles);
+    ws.max_buckets = gs_max_buckets(max_pairs, G.n_tiles);
+    if (training) {
+        ws.tile_nproc = (uint32_t *)take(sizeof(uint32_t) * G.n_tiles);
+        ws.bucket_offsets = (uint32_t *)take(sizeof(uint32_t) * (G.n_tiles + 1));
+        ws.ckpt = (float4 *)take(sizeof(float4) * 256 * (size_t)ws.max_buckets);
+        ws.dgeom = (float *)take(sizeof(float) * 12 * N);
+    } else {
+        ws.tile_nproc = nullptr;
+        ws.bucket_offsets = nullptr;
+        ws.ckpt = nullptr;
+        ws.dgeom = nullptr;
+    }
+    ws.total_bytes = off;
+    return ws;
+}
+
+// stage entry points (defined across the .hip files)
+int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream);
+int gs_stage_project_backward(const gs_frame *f, const gs_frame_ws &ws, float *grad_pos, float *grad_quat,
+                              float *grad_scale, float *grad_opa, float *grad_rgb, hipStream_t stream);
+int gs_stage_scan_emit(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream);
+int gs_stage_tile_ranges(const gs_frame *f, const gs_frame_ws &ws, const uint64_t *sorted_keys, hipStream_t stream);
+int gs_stage_raster_forward(const gs_frame *f, const gs_frame_ws &ws, const uint32_t *sorted_ids, hipStream_t stream);
+int gs_stage_raster_backward(const gs_frame *f, const gs_frame_ws &ws, const uint32_t *sorted_ids,
+                             const float *grad_image, float *grad_rgb, hipStream_t stream);

@@ -1,0 +1,465 @@
+// raster_bwd.hip -- tile rasterizer backward as a 64-lane systolic pipeline.
+//
+// Replaces draw_backward_kernel (gaussian.cu:440-803).  The reference keeps one pixel per
+// thread and, for EVERY Gaussian, reduces 10 (no SH) or 34 (SH) gradient terms across the
+// warp with 5-step shuffle trees plus shared-memory atomics -- the reduction is most of its
+// runtime.  Here the roles are swapped:
+//
+//   * one wave64 owns one BUCKET of 64 consecutive Gaussians of a tile's sorted list; lane l
+//     keeps Gaussian l's parameters AND its gradient accumulators in registers;
+//   * the tile's 256 pixels stream through the lanes: at step t lane l handles pixel t - l.
+//     A pixel's running state (transmittance T, remaining colour R = C_final - C_run, dL/dC,
+//     pixel centre) moves from lane l to lane l+1 with one DPP `wave_shr:1` per register;
+//     lane 0 is fed from LDS (broadcast read of the staged per-pixel state);
+//   * therefore NO cross-lane reduction and NO atomics inside the loop: after 256+63 steps
+//     every lane holds the complete sum over the tile's pixels for its Gaussian.
+//
+// Buckets are independent because the forward pass (or its replay for the reference-API
+// entry point) checkpointed every pixel's (T, C_run) at each bucket boundary, so the grid is
+// one wave per (tile, bucket): long tiles are spread over many CUs instead of serialising
+// one workgroup (the reference's per-tile loop).  Gradient identities used (A.8 of SURVEY.md):
+//   s = dL/dalpha * alpha,  u = -ln G
+//   dL/dx = ln2 (2A' Sx - B' Sy),            Sx = sum s dx, Sy = sum s dy
+//   dL/da = (-Syy + 2 d Su)/Pn, dL/db = (Sxy - 2 c Su)/Pn, dL/dc = (Sxy - 2 b Su)/Pn,
+//   dL/dd = (-Sxx + 2 a Su)/Pn,              Sxx = sum s dx^2, ..., Su = sum s u
+// which is the reference's dP1_d{a,b,c,d} (gaussian.cu:610-621) with the per-Gaussian
+// constants factored out of the pixel loop.
+#include "raster_common.h"
+
+int gs_raster_forward_ref(const RasterSrc &S, const RasterGeom &G, const int32_t *accum, float *res, int use_sh,
+                          int sigmoid, int weight_normalize, float4 *ckpt, uint32_t *tile_nproc,
+                          hipStream_t stream);
+
+namespace {
+
+// exclusive scan of ceil(nproc/64) over tiles -> bucket_offsets[T+1], total -> *n_buckets
+__global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t *__restrict__ tile_nproc, int n_tiles,
+                                                          uint32_t *__restrict__ bucket_offsets,
+                                                          unsigned long long *__restrict__ n_buckets) {
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = 0; base < n_tiles; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < n_tiles ? (tile_nproc[i] + GS_BUCKET - 1) / GS_BUCKET : 0;
+        const uint32_t incl = gs_wave_incl_scan_u32(v);
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) woff += w < wave ? s_wave[w] : 0;
+        const uint32_t carry = s_carry;
+        if (i < n_tiles) bucket_offsets[i] = carry + woff + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = carry + woff + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        bucket_offsets[n_tiles] = s_carry;
+        *n_buckets = s_carry;
+    }
+}
+
+struct BwdOut {
+    // FRAME: atomically accumulated per-Gaussian sums
+    float *dgeom;     // [N][12]
+    float *grad_sh;   // [N][27] (SH only)
+    // REF: one row per pair
+    float *grad_pos, *grad_rgb, *grad_opa, *grad_cov;
+};
+
+struct BwdIn {
+    const float *c_final;     // padded image [padH,padW,3]
+    const float *grad;        // FRAME: dL/d(cropped, clamped image) [H,W,3]; REF: [padH,padW,3]
+    const float4 *ckpt;
+    const uint32_t *tile_nproc;
+    const uint32_t *bucket_offsets;  // [T+1]
+    const int32_t *ranges;           // FRAME: [T][2]; REF: accum [T+1]
+};
+
+template <int CDIM>
+struct PixState {  // what travels from lane to lane
+    float T, R0, R1, R2, g0, g1, g2, px, py;
+    float sh[CDIM == 27 ? 9 : 1];
+};
+
+template <int CDIM, bool FRAME>
+__global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
+    constexpr int NF = CDIM == 27 ? 5 : 3;  // float4 feed records per pixel
+    __shared__ float4 s_feed[4][NF][256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t n_tiles = (uint32_t)(G.ntx * G.nty);
+    const uint32_t kb = blockIdx.x * 4 + wave;
+    if (kb >= I.bucket_offsets[n_tiles]) return;  // whole wave exits; no block-level barrier below
+
+    // bucket -> (tile, local bucket): last tile with bucket_offsets[t] <= kb
+    uint32_t lo = 0, hi = n_tiles;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (I.bucket_offsets[mid] <= kb) lo = mid; else hi = mid;
+    }
+    const uint32_t tile = lo, b = kb - I.bucket_offsets[tile];
+    const uint32_t tx = tile % (uint32_t)G.ntx, ty = tile / (uint32_t)G.ntx;
+    const uint32_t start = (uint32_t)(FRAME ? I.ranges[2 * tile] : I.ranges[tile]);
+    const uint32_t nproc = I.tile_nproc[tile];
+    const uint32_t jloc = b * GS_BUCKET + lane;
+    const bool gvalid = jloc < nproc;
+    const uint32_t j = start + jloc;
+
+    // ---- stage the 256 pixel states of this bucket into the wave's LDS slice
+    const float4 *ck = I.ckpt + raster_ckpt_slot(start, tile, b) * 256;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int p = r * 64 + lane;
+        const uint32_t id_x = tx * 16 + (p & 15), id_y = ty * 16 + (p >> 4);
+        const float4 c = ck[p];
+        const float *cf = I.c_final + ((size_t)id_y * G.padW + id_x) * 3;
+        const float f0 = cf[0], f1 = cf[1], f2 = cf[2];
+        float g0, g1, g2;
+        if (FRAME) {  // grad w.r.t. the clamped + cropped output (splatter.py:652-653)
+            const int ox = (int)id_x - G.crop_left, oy = (int)id_y - G.crop_top;
+            const bool in = ox >= 0 && ox < G.width && oy >= 0 && oy < G.height;
+            const float *gp = I.grad + ((size_t)(in ? oy : 0) * G.width + (in ? ox : 0)) * 3;
+            g0 = (in && f0 >= 0.f && f0 <= 1.f) ? gp[0] : 0.f;
+            g1 = (in && f1 >= 0.f && f1 <= 1.f) ? gp[1] : 0.f;
+            g2 = (in && f2 >= 0.f && f2 <= 1.f) ? gp[2] : 0.f;
+        } else {
+            const float *gp = I.grad + ((size_t)id_y * G.padW + id_x) * 3;
+            g0 = gp[0];
+            g1 = gp[1];
+            g2 = gp[2];
+        }
+        const float px = raster_pixel_coord(id_x, G.padW, G.focal_x);
+        const float py = raster_pixel_coord(id_y, G.padH, G.focal_y);
+        s_feed[wave][0][p] = make_float4(c.x, f0 - c.y, f1 - c.z, f2 - c.w);
+        s_feed[wave][1][p] = make_float4(g0, g1, g2, px);
+        if (CDIM == 27) {
+            float SH[9];
+            raster_pixel_sh(id_x, id_y, G, SH);
+            s_feed[wave][2][p] = make_float4(py, SH[0], SH[1], SH[2]);
+            s_feed[wave][3][p] = make_float4(SH[3], SH[4], SH[5], SH[6]);
+            s_feed[wave][4][p] = make_float4(SH[7], SH[8], 0.f, 0.f);
+        } else {
+            s_feed[wave][2][p] = make_float4(py, 0.f, 0.f, 0.f);
+        }
+    }
+
+    // ---- this lane's Gaussian
+    GaussianRec g = {0, 0, 0, 0, 0, 0, 0};
+    float col0 = 0, col1 = 0, col2 = 0;
+    float coef[CDIM == 27 ? 27 : 1];
+    uint32_t gid = 0;
+    if (gvalid) {
+        gid = raster_load<FRAME>(S, j, g);
+        if (CDIM == 3) {
+            raster_load_rgb<FRAME>(S, j, gid, col0, col1, col2);
+        } else {
+            const float *src = raster_sh_ptr<FRAME>(S, j, gid);
+#pragma unroll
+            for (int q = 0; q < 27; ++q) coef[q] = src[q];
+        }
+    } else if (CDIM == 27) {
+#pragma unroll
+        for (int q = 0; q < 27; ++q) coef[q] = 0.f;
+    }
+    float cA = 0, cB = 0, cC = 0;
+    if (gvalid) raster_conic(g, cA, cB, cC);
+    const float opa = gvalid ? g.opa : 0.f;  // opacity 0 => alpha 0 => state passes through unchanged
+
+    // gradient accumulators
+    float Sx = 0, Sy = 0, Sxx = 0, Sxy = 0, Syy = 0, Su = 0, Sopa = 0, Sc0 = 0, Sc1 = 0, Sc2 = 0;
+    float Ssh[CDIM == 27 ? 27 : 1];
+    if (CDIM == 27) {
+#pragma unroll
+        for (int q = 0; q < 27; ++q) Ssh[q] = 0.f;
+    }
+
+    __builtin_amdgcn_wave_barrier();
+    // outgoing state of the previous step (T = 0 means "no pixel here")
+    float oT = 0, oR0 = 0, oR1 = 0, oR2 = 0, og0 = 0, og1 = 0, og2 = 0, opx = 0, opy = 0;
+    float osh[CDIM == 27 ? 9 : 1];
+    if (CDIM == 27) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) osh[q] = 0.f;
+    }
+
+    for (int t = 0; t < 256 + GS_BUCKET - 1; ++t) {
+        // feed for lane 0 (broadcast LDS reads; beyond the last pixel feed T = 0)
+        const int tp = t < 256 ? t : 255;
+        const float4 f0 = s_feed[wave][0][tp], f1 = s_feed[wave][1][tp], f2 = s_feed[wave][2][tp];
+        const float fT = t < 256 ? f0.x : 0.f;
+        // state entering this lane: lane l-1's output of the previous step; lane 0 takes the feed
+        const float T = gs_wave_shr1(fT, oT);
+        float R0 = gs_wave_shr1(f0.y, oR0), R1 = gs_wave_shr1(f0.z, oR1), R2 = gs_wave_shr1(f0.w, oR2);
+        const float g0 = gs_wave_shr1(f1.x, og0), g1 = gs_wave_shr1(f1.y, og1), g2 = gs_wave_shr1(f1.z, og2);
+        const float px = gs_wave_shr1(f1.w, opx), py = gs_wave_shr1(f2.x, opy);
+        float sh[CDIM == 27 ? 9 : 1];
+        if (CDIM == 27) {
+            const float4 f3 = s_feed[wave][CDIM == 27 ? 3 : 0][tp], f4 = s_feed[wave][CDIM == 27 ? 4 : 0][tp];
+            sh[0] = gs_wave_shr1(f2.y, osh[0]);
+            sh[1] = gs_wave_shr1(f2.z, osh[1]);
+            sh[2] = gs_wave_shr1(f2.w, osh[2]);
+            sh[3] = gs_wave_shr1(f3.x, osh[3]);
+            sh[4] = gs_wave_shr1(f3.y, osh[4]);
+            sh[5] = gs_wave_shr1(f3.z, osh[5]);
+            sh[6] = gs_wave_shr1(f3.w, osh[6]);
+            sh[7] = gs_wave_shr1(f4.x, osh[7]);
+            sh[8] = gs_wave_shr1(f4.y, osh[8]);
+        }
+
+        const float dx = px - g.x, dy = py - g.y;
+        const float dxx = dx * dx, dxy = dx * dy, dyy = dy * dy;
+        const float q = cA * dxx - cB * dxy + cC * dyy;
+        const float Gv = gs_exp2(-q);
+        const bool live = T > GS_T_STOP;
+        const float alpha = live ? Gv * opa : 0.f;
+        const float w = alpha * T;
+        if (CDIM == 27) {
+            float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                v0 += sh[k] * coef[k];
+                v1 += sh[k] * coef[9 + k];
+                v2 += sh[k] * coef[18 + k];
+            }
+            col0 = gs_rcp(1.0f + __expf(-v0));
+            col1 = gs_rcp(1.0f + __expf(-v1));
+            col2 = gs_rcp(1.0f + __expf(-v2));
+        }
+        // remaining colour AFTER this Gaussian (the reference's cur_out - color, :719)
+        R0 -= col0 * w;
+        R1 -= col1 * w;
+        R2 -= col2 * w;
+        const float one_m = 1.0f - alpha;
+        float d_alpha = T * (g0 * col0 + g1 * col1 + g2 * col2) - (g0 * R0 + g1 * R1 + g2 * R2) * gs_rcp(one_m + 1e-7f);
+        d_alpha = live ? d_alpha : 0.f;
+        if (CDIM == 27) {
+            const float D0 = g0 * w * (col0 * (1.0f - col0)), D1 = g1 * w * (col1 * (1.0f - col1)),
+                        D2 = g2 * w * (col2 * (1.0f - col2));
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                Ssh[k] += D0 * sh[k];
+                Ssh[9 + k] += D1 * sh[k];
+                Ssh[18 + k] += D2 * sh[k];
+            }
+        } else {
+            Sc0 += g0 * w;
+            Sc1 += g1 * w;
+            Sc2 += g2 * w;
+        }
+        Sopa += d_alpha * Gv;
+        const float s = d_alpha * alpha;
+        const float u = q * GS_LN2;
+        Sx += s * dx;
+        Sy += s * dy;
+        Sxx += s * dxx;
+        Sxy += s * dxy;
+        Syy += s * dyy;
+        Su += s * u;
+        // outgoing state
+        oT = T * one_m;
+        oR0 = R0;
+        oR1 = R1;
+        oR2 = R2;
+        og0 = g0;
+        og1 = g1;
+        og2 = g2;
+        opx = px;
+        opy = py;
+        if (CDIM == 27) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) osh[k] = sh[k];
+        }
+    }
+
+    if (!gvalid) return;
+    const float det = raster_det(g.a, g.b, g.c, g.d);
+    const float iPn = 1.0f / (2.0f * det + 1e-14f);
+    const float gx = GS_LN2 * (2.0f * cA * Sx - cB * Sy);
+    const float gy = GS_LN2 * (2.0f * cC * Sy - cB * Sx);
+    const float ga = iPn * (-Syy + 2.0f * g.d * Su);
+    const float gb = iPn * (Sxy - 2.0f * g.c * Su);
+    const float gc = iPn * (Sxy - 2.0f * g.b * Su);
+    const float gd = iPn * (-Sxx + 2.0f * g.a * Su);
+    if (FRAME) {
+        float *dg = O.dgeom + (size_t)gid * 12;
+        unsafeAtomicAdd(dg + 0, gx);
+        unsafeAtomicAdd(dg + 1, gy);
+        unsafeAtomicAdd(dg + 2, ga);
+        unsafeAtomicAdd(dg + 3, gb);
+        unsafeAtomicAdd(dg + 4, gc);
+        unsafeAtomicAdd(dg + 5, gd);
+        unsafeAtomicAdd(dg + 6, Sopa);
+        if (CDIM == 3) {
+            unsafeAtomicAdd(dg + 7, Sc0);
+            unsafeAtomicAdd(dg + 8, Sc1);
+            unsafeAtomicAdd(dg + 9, Sc2);
+        } else {
+            float *gs = O.grad_sh + (size_t)gid * 27;
+#pragma unroll
+            for (int k = 0; k < 27; ++k) unsafeAtomicAdd(gs + k, Ssh[k]);
+        }
+    } else {
+        O.grad_pos[(size_t)j * 3 + 0] = gx;
+        O.grad_pos[(size_t)j * 3 + 1] = gy;
+        O.grad_opa[j] = Sopa;
+        reinterpret_cast<float4 *>(O.grad_cov)[j] = make_float4(ga, gb, gc, gd);
+        if (CDIM == 3) {
+            O.grad_rgb[(size_t)j * 3 + 0] = Sc0;
+            O.grad_rgb[(size_t)j * 3 + 1] = Sc1;
+            O.grad_rgb[(size_t)j * 3 + 2] = Sc2;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 27; ++k) O.grad_rgb[(size_t)j * 27 + k] = Ssh[k];
+        }
+    }
+}
+
+template <int CDIM, bool FRAME>
+void launch_bwd(const RasterSrc &S, const RasterGeom &G, const BwdIn &I, const BwdOut &O, int64_t max_buckets,
+                hipStream_t stream) {
+    const int grid = (int)gs_div_up(max_buckets > 0 ? max_buckets : 1, 4);
+    hipLaunchKernelGGL((raster_backward_kernel<CDIM, FRAME>), dim3(grid), dim3(256), 0, stream, S, G, I, O);
+}
+
+struct RefWs {
+    uint32_t *tile_nproc, *bucket_offsets;
+    unsigned long long *n_buckets;
+    float4 *ckpt;
+    int64_t max_buckets;
+    size_t bytes;
+};
+RefWs carve_ref(void *base, int64_t M, int32_t h, int32_t w) {
+    RefWs r;
+    const int n_tiles = (w / 16) * (h / 16);
+    size_t off = 0;
+    auto take = [&](size_t bytes) -> void * {
+        void *p = base ? (void *)((char *)base + off) : nullptr;
+        off += gs_align_up(bytes ? bytes : 1, 256);
+        return p;
+    };
+    r.max_buckets = gs_max_buckets(M, n_tiles);
+    r.tile_nproc = (uint32_t *)take(sizeof(uint32_t) * n_tiles);
+    r.bucket_offsets = (uint32_t *)take(sizeof(uint32_t) * (n_tiles + 1));
+    r.n_buckets = (unsigned long long *)take(sizeof(unsigned long long));
+    r.ckpt = (float4 *)take(sizeof(float4) * 256 * (size_t)r.max_buckets);
+    r.bytes = off;
+    return r;
+}
+
+}  // namespace
+
+extern "C" size_t gs_draw_backward_workspace_bytes(int64_t M, int32_t h, int32_t w) {
+    if (M < 0 || h <= 0 || w <= 0) return 0;
+    return carve_ref(nullptr, M, h, w).bytes;
+}
+
+extern "C" int gs_draw_backward(const float *pos, const float *rgb, const float *opa, const float *cov,
+                                const int32_t *tile_n_point_accum, const float *output, const float *grad_output,
+                                float *grad_pos, float *grad_rgb, float *grad_opa, float *grad_cov, int32_t h,
+                                int32_t w, int64_t M, float focal_x, float focal_y, int weight_normalize,
+                                int sigmoid, int fast, const float *rays_o, const float *lefttop_pos,
+                                const float *vec_dx, const float *vec_dy, int use_sh_coeff, void *workspace,
+                                size_t workspace_bytes, gs_stream_t stream) {
+    (void)fast;
+    (void)weight_normalize;  // the reference backward ignores it as well (gaussian.cu:440-803)
+    GS_CHECK_ARG(h > 0 && w > 0 && (h % 16) == 0 && (w % 16) == 0, "h, w must be positive multiples of 16");
+    GS_CHECK_ARG(M >= 0, "M < 0");
+    if (sigmoid) {
+        gs_set_error("gs_draw_backward: sigmoid=True (alpha squashing) is not implemented; the reference pipeline "
+                     "always passes False (splatter.py:627)");
+        return GS_E_UNSUPPORTED;
+    }
+    if (M == 0) return 0;
+    GS_CHECK_ARG(pos && rgb && opa && cov && tile_n_point_accum && output && grad_output && grad_pos && grad_rgb &&
+                     grad_opa && grad_cov,
+                 "null pointer");
+    GS_CHECK_ARG(((uintptr_t)cov & 15) == 0 && ((uintptr_t)grad_cov & 15) == 0, "cov/grad_cov must be 16-byte aligned");
+    GS_CHECK_ARG(workspace && workspace_bytes >= gs_draw_backward_workspace_bytes(M, h, w), "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    RefWs ws = carve_ref(workspace, M, h, w);
+    RasterSrc S = {};
+    S.pos = pos;
+    S.rgb = rgb;
+    S.opa = opa;
+    S.cov = cov;
+    RasterGeom G = {};
+    G.padW = w;
+    G.padH = h;
+    G.ntx = w / 16;
+    G.nty = h / 16;
+    G.focal_x = focal_x;
+    G.focal_y = focal_y;
+    if (use_sh_coeff) {
+        GS_CHECK_ARG(rays_o && lefttop_pos && vec_dx && vec_dy, "SH needs the ray basis");
+        float hb[12];
+        GS_HIP(hipMemcpyAsync(hb + 0, rays_o, 12, hipMemcpyDeviceToHost, s));
+        GS_HIP(hipMemcpyAsync(hb + 3, lefttop_pos, 12, hipMemcpyDeviceToHost, s));
+        GS_HIP(hipMemcpyAsync(hb + 6, vec_dx, 12, hipMemcpyDeviceToHost, s));
+        GS_HIP(hipMemcpyAsync(hb + 9, vec_dy, 12, hipMemcpyDeviceToHost, s));
+        GS_HIP(hipStreamSynchronize(s));
+        for (int i = 0; i < 3; ++i) {
+            G.rays_o[i] = hb[i];
+            G.lefttop[i] = hb[3 + i];
+            G.vdx[i] = hb[6 + i];
+            G.vdy[i] = hb[9 + i];
+        }
+    }
+    // 1. replay the forward to checkpoint (T, C_run) at every bucket boundary
+    int rc = gs_raster_forward_ref(S, G, tile_n_point_accum, nullptr, use_sh_coeff, 0, 0, ws.ckpt, ws.tile_nproc, s);
+    if (rc) return rc;
+    // 2. bucket work list
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, s, ws.tile_nproc, G.ntx * G.nty,
+                       ws.bucket_offsets, ws.n_buckets);
+    // 3. systolic backward, one wave per bucket, one output row per pair
+    BwdIn I = {output, grad_output, ws.ckpt, ws.tile_nproc, ws.bucket_offsets, tile_n_point_accum};
+    BwdOut O = {nullptr, nullptr, grad_pos, grad_rgb, grad_opa, grad_cov};
+    if (use_sh_coeff)
+        launch_bwd<27, false>(S, G, I, O, ws.max_buckets, s);
+    else
+        launch_bwd<3, false>(S, G, I, O, ws.max_buckets, s);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+int gs_stage_raster_backward(const gs_frame *f, const gs_frame_ws &ws, const uint32_t *sorted_ids,
+                             const float *grad_image, float *grad_rgb, hipStream_t stream) {
+    gs_frame_geom FG = gs_frame_geometry(f);
+    RasterSrc S = {};
+    S.ids = sorted_ids;
+    S.geom = ws.rec_geom;
+    S.cov4 = ws.rec_cov;
+    S.color4 = ws.rec_color;
+    S.sh = f->rgb;
+    RasterGeom G = {};
+    G.padW = FG.padW;
+    G.padH = FG.padH;
+    G.ntx = FG.ntx;
+    G.nty = FG.nty;
+    G.width = f->width;
+    G.height = f->height;
+    G.crop_top = FG.crop_top;
+    G.crop_left = FG.crop_left;
+    G.focal_x = f->focal_x;
+    G.focal_y = f->focal_y;
+    for (int i = 0; i < 3; ++i) {
+        G.rays_o[i] = f->rays_o[i];
+        G.lefttop[i] = f->lefttop[i];
+        G.vdx[i] = f->vec_dx[i];
+        G.vdy[i] = f->vec_dy[i];
+    }
+    GS_HIP(hipMemsetAsync(ws.dgeom, 0, sizeof(float) * 12 * (size_t)f->N, stream));
+    if (f->color_dim == 27) GS_HIP(hipMemsetAsync(grad_rgb, 0, sizeof(float) * 27 * (size_t)f->N, stream));
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, ws.tile_nproc, FG.n_tiles,
+                       ws.bucket_offsets, ws.counters + GS_CNT_BUCKETS);
+    BwdIn I = {f->image_padded, grad_image, ws.ckpt, ws.tile_nproc, ws.bucket_offsets, ws.tile_ranges};
+    BwdOut O = {ws.dgeom, grad_rgb, nullptr, nullptr, nullptr, nullptr};
+    if (f->color_dim == 27)
+        launch_bwd<27, true>(S, G, I, O, ws.max_buckets, stream);
+    else
+        launch_bwd<3, true>(S, G, I, O, ws.max_buckets, stream);
+    GS_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,129 @@
+// raster_common.h -- shared pieces of the tile rasterizer forward/backward kernels.
+#pragma once
+#include "gs_common.h"
+#include "gs_frame_layout.h"
+
+// Where the Gaussians of a tile's sorted list live.
+//  FRAME = true : sorted Gaussian ids + N-indexed records written by stage S1 (no sorted
+//                 attribute copies exist; gathers hit L2 / Infinity Cache).
+//  FRAME = false: the reference API -- attributes already gathered in sorted order
+//                 (pos[M,3], rgb[M,D], opa[M], cov[M,2,2]; gaussian.cu:806-813).
+struct RasterSrc {
+    const uint32_t *ids;
+    const float4 *geom;    // (x, y, depth, opacity)
+    const float4 *cov4;    // (a, b, c, d)
+    const float4 *color4;  // (r, g, b, -)
+    const float *sh;       // raw rgb parameter [N,27] (SH coefficients)
+    const float *pos, *rgb, *opa, *cov;
+};
+
+struct RasterGeom {
+    int32_t padW, padH, ntx, nty;
+    int32_t width, height, crop_top, crop_left;  // un-padded output (frame path)
+    float focal_x, focal_y;
+    float rays_o[3], lefttop[3], vdx[3], vdy[3];
+};
+
+struct GaussianRec {
+    float x, y, a, b, c, d, opa;
+};
+
+template <bool FRAME>
+__device__ __forceinline__ uint32_t raster_load(const RasterSrc &S, uint32_t j, GaussianRec &g) {
+    if (FRAME) {
+        const uint32_t id = S.ids[j];
+        const float4 ge = S.geom[id], cv = S.cov4[id];
+        g.x = ge.x;
+        g.y = ge.y;
+        g.opa = ge.w;
+        g.a = cv.x;
+        g.b = cv.y;
+        g.c = cv.z;
+        g.d = cv.w;
+        return id;
+    } else {
+        g.x = S.pos[(size_t)j * 3 + 0];
+        g.y = S.pos[(size_t)j * 3 + 1];
+        g.opa = S.opa[j];
+        const float4 cv = reinterpret_cast<const float4 *>(S.cov)[j];
+        g.a = cv.x;
+        g.b = cv.y;
+        g.c = cv.z;
+        g.d = cv.w;
+        return j;
+    }
+}
+
+template <bool FRAME>
+__device__ __forceinline__ void raster_load_rgb(const RasterSrc &S, uint32_t j, uint32_t id, float &r, float &g,
+                                                float &b) {
+    if (FRAME) {
+        const float4 c = S.color4[id];
+        r = c.x;
+        g = c.y;
+        b = c.z;
+    } else {
+        r = S.rgb[(size_t)j * 3 + 0];
+        g = S.rgb[(size_t)j * 3 + 1];
+        b = S.rgb[(size_t)j * 3 + 2];
+    }
+}
+
+template <bool FRAME>
+__device__ __forceinline__ const float *raster_sh_ptr(const RasterSrc &S, uint32_t j, uint32_t id) {
+    return FRAME ? S.sh + (size_t)id * 27 : S.rgb + (size_t)j * 27;
+}
+
+// det = a*d - b*c without FMA contraction: the reference (and the oracle) round both products
+// before subtracting; for needle-like footprints (a*d ~ b*c) a contracted det differs by many
+// ulps and that difference is amplified into the exponent.
+__device__ __forceinline__ float raster_det(float a, float b, float c, float d) {
+#pragma clang fp contract(off)
+    return a * d - b * c;
+}
+
+// Conic in log2 units: G = 2^-(A dx^2 - B dx dy + C dy^2) == exp(-(d dx^2-(b+c)dx dy+a dy^2)/(2det+1e-14))
+// (gaussian.cu:916-923).  Hoists the reference's per-pixel fp64 division to once per Gaussian.
+__device__ __forceinline__ void raster_conic(const GaussianRec &g, float &A, float &B, float &C) {
+    const float det = raster_det(g.a, g.b, g.c, g.d);
+    const float k = GS_LOG2E / (2.0f * det + 1e-14f);
+    A = g.d * k;
+    B = (g.b + g.c) * k;
+    C = g.a * k;
+}
+
+// Pixel centre in normalised image units (gaussian.cu:839-840: double arithmetic, then float).
+__device__ __forceinline__ float raster_pixel_coord(uint32_t id, int32_t padded, float focal) {
+    return (float)(((double)id + 0.5 - (double)((uint32_t)padded / 2)) / (double)focal);
+}
+
+// Per-pixel SH basis (gaussian.cu:849-861, 405-426), same promotions as the reference.
+__device__ __forceinline__ void raster_pixel_sh(uint32_t id_x, uint32_t id_y, const RasterGeom &G, float SH[9]) {
+    float dir[3], nrm = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        dir[i] = G.lefttop[i] + id_x * G.vdx[i] + id_y * G.vdy[i] - G.rays_o[i];
+        nrm += dir[i] * dir[i];
+    }
+    nrm = sqrtf(nrm);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dir[i] = (float)(dir[i] / (nrm + 1e-7));
+    const float x = dir[0], y = dir[1], z = dir[2];
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    SH[0] = 0.28209479177387814f;
+    SH[1] = -0.4886025119029199f * y;
+    SH[2] = 0.4886025119029199f * z;
+    SH[3] = -0.4886025119029199f * x;
+    SH[4] = 1.0925484305920792f * xy;
+    SH[5] = -1.0925484305920792f * yz;
+    SH[6] = (float)(0.31539156525252005f * (2.0 * zz - xx - yy));
+    SH[7] = -1.0925484305920792f * xz;
+    SH[8] = 0.5462742152960396f * (xx - yy);
+}
+
+// Checkpoint slot of local bucket b of a tile whose sorted list starts at `start`:
+// floor(start/64) + tile + b.  Slots of different tiles never overlap and the total is
+// <= M/64 + T, so no scan is needed before the forward pass.
+__device__ __forceinline__ size_t raster_ckpt_slot(uint32_t start, uint32_t tile, uint32_t b) {
+    return (size_t)(start / GS_BUCKET) + tile + b;
+}

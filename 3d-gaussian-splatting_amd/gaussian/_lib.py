@@ -1,0 +1,94 @@
+"""ctypes loader for libgs_amd.so (the C ABI in include/gs_abi.h).
+
+There is NO CPU fallback: if the shared library is missing or cannot be loaded, importing
+``gaussian`` raises.  The library is built in-tree by ``gs_build.build()`` /
+``__graft_entry__.build()``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libgs_amd.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"libgs_amd.so not found at {LIB_PATH}: build it with `python __graft_entry__.py` "
+        "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the rasterizer.")
+
+lib = C.CDLL(LIB_PATH)
+
+vp, i64, i32, f32, ci, sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_int, C.c_size_t
+
+
+class GsFrame(C.Structure):
+    """Mirror of ``struct gs_frame`` (include/gs_abi.h)."""
+
+    _fields_ = [
+        ("N", i64), ("color_dim", i32), ("scale_activation", i32),
+        ("pos", vp), ("quat", vp), ("scale", vp), ("opa", vp), ("rgb", vp),
+        ("rot", f32 * 9), ("tran", f32 * 3),
+        ("near_plane", f32), ("half_width", f32), ("half_height", f32),
+        ("width", i32), ("height", i32),
+        ("focal_x", f32), ("focal_y", f32),
+        ("tile_length_x", f32), ("tile_length_y", f32), ("leftmost", f32), ("topmost", f32),
+        ("thresh", f32),
+        ("rays_o", f32 * 3), ("lefttop", f32 * 3), ("vec_dx", f32 * 3), ("vec_dy", f32 * 3),
+        ("max_pairs", i64), ("workspace", vp), ("workspace_bytes", sz),
+        ("image", vp), ("image_padded", vp),
+        ("training", i32), ("reserved", i32),
+    ]
+
+
+def _sig(name, restype, *argtypes):
+    fn = getattr(lib, name)
+    fn.restype = restype
+    fn.argtypes = list(argtypes)
+    return fn
+
+
+gs_last_error = _sig("gs_last_error", C.c_char_p)
+gs_abi_version = _sig("gs_abi_version", ci)
+gs_culling = _sig("gs_culling", ci)
+gs_world2camera = _sig("gs_world2camera", ci, vp, vp, vp, vp, i64, vp)
+gs_world2camera_backward = _sig("gs_world2camera_backward", ci, vp, vp, vp, i64, vp)
+gs_jacobian = _sig("gs_jacobian", ci, vp, vp, i64, vp)
+gs_global_culling = _sig("gs_global_culling", ci, vp, vp, vp, vp, vp, i64, f32, f32, f32, vp, vp, vp, vp)
+gs_global_culling_backward = _sig("gs_global_culling_backward", ci, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp,
+                                  vp, vp)
+gs_calc_tile_list = _sig("gs_calc_tile_list", ci, vp, vp, i64, vp, vp, vp, vp, vp, vp, i64, f32, ci, f32, f32,
+                         i32, i32, f32, f32, vp)
+gs_gather_gaussians = _sig("gs_gather_gaussians", ci, vp, vp, vp, vp, i64, i64, i64, vp)
+gs_draw = _sig("gs_draw", ci, vp, vp, vp, vp, vp, vp, i32, i32, i64, f32, f32, ci, ci, ci, vp, vp, vp, vp, ci, vp)
+gs_draw_backward_workspace_bytes = _sig("gs_draw_backward_workspace_bytes", sz, i64, i32, i32)
+gs_draw_backward = _sig("gs_draw_backward", ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, f32, f32,
+                        ci, ci, ci, vp, vp, vp, vp, ci, vp, sz, vp)
+gs_sort_pairs_tmp_bytes = _sig("gs_sort_pairs_tmp_bytes", sz, i64)
+gs_sort_pairs = _sig("gs_sort_pairs", ci, vp, vp, vp, vp, vp, i64, ci, vp, sz, C.POINTER(ci), vp)
+gs_frame_workspace_bytes = _sig("gs_frame_workspace_bytes", sz, i64, i64, i32, i32, i32, i32)
+gs_frame_forward = _sig("gs_frame_forward", ci, C.POINTER(GsFrame), vp)
+gs_frame_backward = _sig("gs_frame_backward", ci, C.POINTER(GsFrame), vp, vp, vp, vp, vp, vp, vp)
+gs_frame_forward_profile = _sig("gs_frame_forward_profile", ci, C.POINTER(GsFrame), C.POINTER(f32), vp)
+gs_frame_backward_profile = _sig("gs_frame_backward_profile", ci, C.POINTER(GsFrame), vp, vp, vp, vp, vp, vp,
+                                 C.POINTER(f32), vp)
+gs_frame_stats_async = _sig("gs_frame_stats_async", ci, C.POINTER(GsFrame), vp, vp)
+gs_frame_debug_views = _sig("gs_frame_debug_views", ci, C.POINTER(GsFrame), C.POINTER(vp), C.POINTER(vp),
+                            C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp))
+
+# Every symbol include/gs_abi.h declares (checked by tests/test_abi.py without a GPU).
+EXPORTS = [
+    "gs_last_error", "gs_abi_version", "gs_culling", "gs_world2camera", "gs_world2camera_backward",
+    "gs_jacobian", "gs_global_culling", "gs_global_culling_backward", "gs_calc_tile_list",
+    "gs_gather_gaussians", "gs_draw", "gs_draw_backward_workspace_bytes", "gs_draw_backward",
+    "gs_sort_pairs_tmp_bytes", "gs_sort_pairs", "gs_frame_workspace_bytes", "gs_frame_forward",
+    "gs_frame_stats_async", "gs_frame_debug_views", "gs_frame_backward", "gs_frame_forward_profile",
+    "gs_frame_backward_profile",
+]
+
+
+def check(rc: int, what: str):
+    """Map the C return convention onto the reference's: a Python RuntimeError."""
+    if rc != 0:
+        msg = gs_last_error()
+        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,65 @@
+"""Build recipe for libgs_amd.so (hipcc, gfx950 only, in-tree).
+
+``python gs_build.py`` or ``build()``: every ``csrc/*.hip`` is compiled to an object with
+``hipcc --offload-arch=gfx950 -O3`` and linked into ``csrc/libgs_amd.so``.  Files whose results
+feed the integer side of the pipeline (depth bits, tile rectangles) are compiled with
+``-ffp-contract=off`` so they match the oracle bit for bit (see cull_project.hip).
+No torch / pybind dependency: the library is a plain C ABI (include/gs_abi.h).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(CSRC, "libgs_amd.so")
+
+SOURCES = {
+    "cull_project.hip": ["-ffp-contract=off"],
+    "binning.hip": ["-ffp-contract=off"],
+    "radix_sort.hip": [],
+    "raster_fwd.hip": [],
+    "raster_bwd.hip": [],
+    "gs_frame.hip": [],
+}
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall",
+          "-Wno-unused-function", "-munsafe-fp-atomics"]
+HEADERS = ["gs_common.h", "gs_frame_layout.h", "raster_common.h", os.path.join("..", "..", "include", "gs_abi.h")]
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    objs, jobs = [], []
+    for src, extra in SOURCES.items():
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs):
+            jobs.append([hipcc, *COMMON, *extra, "-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            list(ex.map(run, jobs))
+    if force or jobs or _stale(LIB, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

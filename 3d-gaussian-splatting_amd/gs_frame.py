@@ -1,0 +1,229 @@
+"""Fused MI355X frame path: host-side mirror of ``Splatter.forward`` (splatter.py:513-655).
+
+``FrameRenderer`` owns one workspace (a torch uint8 tensor living in HBM) and drives
+``gs_frame_forward`` / ``gs_frame_backward`` of libgs_amd.so: cull + project + activations +
+tile counting, scan + key emission, device radix sort on (tile, depth) keys, tile ranges and
+the 16x16-tile compositing forward/backward -- one C call per direction, no host
+synchronisation, no T x MAXP table, no sorted attribute copies.  ``render`` is the autograd
+entry point (raw parameters in, clamped + cropped image out, exactly what
+``Splatter.forward`` returns).
+
+Semantics follow the reference with train.py's defaults (cudaculling=1,
+tile_culling_method="prob2", fast_drawing=1, render_weight_normalize=False); the known
+reference defects listed in SURVEY.md section 0 (per-tile cap MAXP, float32 sort key, racy
+reductions) are not reproduced.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from gaussian import _lib
+from gs_geometry import RayBasis, TileGrid
+
+SCALE_ACT = {"abs": 0, "exp": 1}
+
+
+@dataclass
+class FrameStats:
+    visible: int  # V: Gaussians surviving frustum culling
+    pairs: int  # M: (tile, Gaussian) pairs after duplication (clamped to capacity)
+    overflow: int  # 0, or the true M when it exceeded the workspace capacity
+    buckets: int  # 64-Gaussian buckets processed by the last backward
+
+
+class FrameRenderer:
+    def __init__(self, device="cuda", max_pairs: int = 1 << 20, training: bool = False,
+                 thresh: float = 0.05, scale_activation: str = "abs", auto_grow: bool = True):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("FrameRenderer needs a HIP device; there is no CPU fallback")
+        self.max_pairs = int(max_pairs)
+        self.training = bool(training)
+        self.thresh = float(thresh)
+        self.scale_activation = SCALE_ACT[scale_activation]
+        self.auto_grow = auto_grow
+        self._ws: Optional[torch.Tensor] = None
+        self._stats_host = torch.zeros(4, dtype=torch.int64).pin_memory()
+        self._frame: Optional[_lib.GsFrame] = None
+        self._keep = None
+
+    # ------------------------------------------------------------------ frame descriptor
+    def _describe(self, pos, quat, scale, opa, rgb, camera, training) -> _lib.GsFrame:
+        n = int(pos.shape[0])
+        color_dim = int(rgb.shape[1]) if rgb.dim() == 2 else 1
+        if color_dim not in (3, 27):
+            raise RuntimeError(f"rgb must be [N,3] or [N,27], got {tuple(rgb.shape)}")
+        for name, t, cols in (("pos", pos, 3), ("quat", quat, 4), ("scale", scale, 3), ("opa", opa, None),
+                              ("rgb", rgb, color_dim)):
+            if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+                raise RuntimeError(f"{name} must be a contiguous float32 HIP tensor")
+            if t.shape[0] != n or (cols is not None and (t.dim() != 2 or t.shape[1] != cols)):
+                raise RuntimeError(f"{name} has shape {tuple(t.shape)}, expected [{n},{cols}]")
+        grid = TileGrid(int(camera.width), int(camera.height), float(camera.focal_x), float(camera.focal_y))
+        half_w, half_h = grid.frustum_half_extents()
+        rays = RayBasis.from_camera(camera.rot, camera.tran, grid.padded_height, grid.padded_width, grid.focal_x,
+                                    grid.focal_y)
+        f = _lib.GsFrame()
+        f.N, f.color_dim, f.scale_activation = n, color_dim, self.scale_activation
+        f.pos, f.quat, f.scale, f.opa, f.rgb = (t.data_ptr() for t in (pos, quat, scale, opa, rgb))
+        f.rot = (C.c_float * 9)(*np.asarray(camera.rot, np.float32).reshape(9))
+        f.tran = (C.c_float * 3)(*np.asarray(camera.tran, np.float32).reshape(3))
+        f.near_plane, f.half_width, f.half_height = float(camera.near), half_w, half_h
+        f.width, f.height = grid.width, grid.height
+        f.focal_x, f.focal_y = grid.focal_x, grid.focal_y
+        f.tile_length_x, f.tile_length_y = grid.tile_geo_length_x, grid.tile_geo_length_y
+        f.leftmost, f.topmost = grid.leftmost, grid.topmost
+        f.thresh = self.thresh
+        f.rays_o = (C.c_float * 3)(*rays.rays_o)
+        f.lefttop = (C.c_float * 3)(*rays.lefttop)
+        f.vec_dx = (C.c_float * 3)(*rays.dx)
+        f.vec_dy = (C.c_float * 3)(*rays.dy)
+        f.max_pairs = self.max_pairs
+        f.training = int(training)
+        need = _lib.gs_frame_workspace_bytes(n, self.max_pairs, grid.width, grid.height, color_dim, int(training))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(int(need) + 256, dtype=torch.uint8, device=self.device)
+        base = self._ws.data_ptr()
+        f.workspace = (base + 255) // 256 * 256
+        f.workspace_bytes = self._ws.numel() - (f.workspace - base)
+        self._grid = grid
+        return f
+
+    # ------------------------------------------------------------------ low-level API
+    def forward(self, pos, quat, scale, opa, rgb, camera, training: Optional[bool] = None):
+        """Raw parameters -> (image [H,W,3] clamped+cropped, padded raw image or None)."""
+        training = self.training if training is None else training
+        stream = torch.cuda.current_stream().cuda_stream
+        while True:
+            f = self._describe(pos, quat, scale, opa, rgb, camera, training)
+            g = self._grid
+            image = torch.empty(g.height, g.width, 3, device=self.device, dtype=torch.float32)
+            padded = torch.empty(g.padded_height, g.padded_width, 3, device=self.device,
+                                 dtype=torch.float32) if training else None
+            f.image = image.data_ptr()
+            f.image_padded = padded.data_ptr() if padded is not None else None
+            _lib.check(_lib.gs_frame_forward(C.byref(f), stream), "gs_frame_forward")
+            self._frame = f
+            self._keep = (pos, quat, scale, opa, rgb, image, padded)
+            if not self.auto_grow:
+                break
+            st = self.stats()
+            if not st.overflow:
+                break
+            self.max_pairs = int(st.overflow * 1.25) + 1024  # grow and redo the frame
+        return image, padded
+
+    def backward(self, grad_image, out=None):
+        """dL/d(image) -> (grad_pos, grad_quat, grad_scale, grad_opa, grad_rgb).  ``out`` may
+        supply the five destination tensors (e.g. views of one flat all-reduce bucket)."""
+        f = self._frame
+        if f is None or not f.training:
+            raise RuntimeError("backward() needs a preceding forward(training=True)")
+        pos, quat, scale, opa, rgb = self._keep[:5]
+        if out is None:
+            out = tuple(torch.empty_like(t) for t in (pos, quat, scale, opa, rgb))
+        grad_image = grad_image.contiguous()
+        if grad_image.dtype != torch.float32 or tuple(grad_image.shape) != (f.height, f.width, 3):
+            raise RuntimeError("grad_image must be float32 [H,W,3]")
+        for t, ref in zip(out, (pos, quat, scale, opa, rgb)):
+            if t.shape != ref.shape or t.dtype != torch.float32 or not t.is_contiguous():
+                raise RuntimeError("gradient destinations must match the parameters")
+        _lib.check(_lib.gs_frame_backward(C.byref(f), grad_image.data_ptr(), *(t.data_ptr() for t in out),
+                                          torch.cuda.current_stream().cuda_stream), "gs_frame_backward")
+        return out
+
+    def profile_forward(self, pos, quat, scale, opa, rgb, camera, training: Optional[bool] = None):
+        """One forward frame with every stage bracketed by hipEvents (synchronises).  Returns
+        {stage: ms}; the raster stage is exactly one kernel launch."""
+        training = self.training if training is None else training
+        f = self._describe(pos, quat, scale, opa, rgb, camera, training)
+        g = self._grid
+        image = torch.empty(g.height, g.width, 3, device=self.device, dtype=torch.float32)
+        padded = torch.empty(g.padded_height, g.padded_width, 3, device=self.device,
+                             dtype=torch.float32) if training else None
+        f.image = image.data_ptr()
+        f.image_padded = padded.data_ptr() if padded is not None else None
+        ms = (C.c_float * 6)()
+        _lib.check(_lib.gs_frame_forward_profile(C.byref(f), ms, torch.cuda.current_stream().cuda_stream),
+                   "gs_frame_forward_profile")
+        self._frame = f
+        self._keep = (pos, quat, scale, opa, rgb, image, padded)
+        return dict(zip(("project", "scan_emit", "sort", "ranges", "raster", "total"), (float(x) for x in ms)))
+
+    def profile_backward(self, grad_image):
+        f = self._frame
+        if f is None or not f.training:
+            raise RuntimeError("profile_backward() needs a preceding training forward")
+        pos, quat, scale, opa, rgb = self._keep[:5]
+        out = tuple(torch.empty_like(t) for t in (pos, quat, scale, opa, rgb))
+        ms = (C.c_float * 3)()
+        _lib.check(_lib.gs_frame_backward_profile(C.byref(f), grad_image.contiguous().data_ptr(),
+                                                  *(t.data_ptr() for t in out), ms,
+                                                  torch.cuda.current_stream().cuda_stream),
+                   "gs_frame_backward_profile")
+        return dict(zip(("raster_bwd", "project_bwd", "total"), (float(x) for x in ms)))
+
+    def stats(self) -> FrameStats:
+        """Synchronises the current stream (one 32-byte D2H copy)."""
+        if self._frame is None:
+            raise RuntimeError("no frame rendered yet")
+        stream = torch.cuda.current_stream()
+        _lib.check(_lib.gs_frame_stats_async(C.byref(self._frame), self._stats_host.data_ptr(), stream.cuda_stream),
+                   "gs_frame_stats_async")
+        stream.synchronize()
+        v, m, o, b = (int(x) for x in self._stats_host.tolist())
+        return FrameStats(v, m, o, b)
+
+    def debug_views(self):
+        """Device tensors aliasing the workspace of the last forward (parity tests)."""
+        f = self._frame
+        ptrs = [C.c_void_p() for _ in range(7)]
+        _lib.check(_lib.gs_frame_debug_views(C.byref(f), *[C.byref(p) for p in ptrs]), "gs_frame_debug_views")
+        st = self.stats()
+        n, m, T = f.N, st.pairs, self._grid.n_tiles
+
+        def view(ptr, nbytes, dtype, shape):
+            off = ptr.value - self._ws.data_ptr()
+            return self._ws[off:off + nbytes].view(dtype).reshape(shape)
+
+        out = {
+            "sorted_keys": view(ptrs[0], 8 * m, torch.int64, (m,)),
+            "sorted_ids": view(ptrs[1], 4 * m, torch.int32, (m,)),
+            "tile_ranges": view(ptrs[2], 8 * T, torch.int32, (T, 2)),
+            "rec_geom": view(ptrs[3], 16 * n, torch.float32, (n, 4)),
+            "rec_cov": view(ptrs[4], 16 * n, torch.float32, (n, 4)),
+            "tiles_touched": view(ptrs[6], 4 * n, torch.int32, (n,)),
+        }
+        if f.color_dim == 3:
+            out["rec_color"] = view(ptrs[5], 16 * n, torch.float32, (n, 4))
+        return out
+
+    # ------------------------------------------------------------------ autograd entry point
+    def render(self, pos, quat, scale, opa, rgb, camera):
+        """Differentiable frame: the drop-in for ``Splatter.forward`` on explicit tensors."""
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (pos, quat, scale, opa, rgb)):
+            return _FrameFunction.apply(pos, quat, scale, opa, rgb, self, camera)
+        return self.forward(pos, quat, scale, opa, rgb, camera, training=False)[0]
+
+
+class _FrameFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pos, quat, scale, opa, rgb, renderer, camera):
+        image, _ = renderer.forward(pos.detach(), quat.detach(), scale.detach(), opa.detach(), rgb.detach(), camera,
+                                    training=True)
+        ctx.renderer = renderer
+        ctx.frame_id = id(renderer._frame)
+        return image
+
+    @staticmethod
+    def backward(ctx, grad_image):
+        r = ctx.renderer
+        if id(r._frame) != ctx.frame_id:
+            raise RuntimeError("FrameRenderer workspace was reused by another forward before backward()")
+        g = r.backward(grad_image)
+        return (*g, None, None)

@@ -1,0 +1,93 @@
+"""Synthetic scenes and cameras for the rasterizer path (SURVEY.md section 8d contract).
+
+The reference has no scene generator (it reads COLMAP Garden, splatter.py:324-454); there
+is no dataset in this environment, so benchmarks and tests use this seeded generator.  The
+distributions are chosen so that ~79 % of the Gaussians survive frustum culling and each
+visible Gaussian touches ~3.6 tiles, which is the Garden-like load SURVEY.md section 8 sizes.
+Everything is produced with NumPy ``default_rng(seed)`` so CPU-only tests and the GPU
+box see identical bytes.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import numpy as np
+
+C0 = 0.28209479177387814  # gaussian.cu:385
+
+
+@dataclass
+class Camera:
+    """Pinhole camera as the reference passes it around (splatter.py:467-511)."""
+
+    width: int
+    height: int
+    focal_x: float
+    focal_y: float
+    rot: np.ndarray  # [3,3] world->camera rotation (current_w2c_rot)
+    tran: np.ndarray  # [3]   world->camera translation (current_w2c_tran)
+    near: float = 0.3  # splatter.py:327
+
+
+@dataclass
+class Scene:
+    pos: np.ndarray  # [N,3]
+    quat: np.ndarray  # [N,4] raw (un-normalised) w,x,y,z
+    scale: np.ndarray  # [N,3] raw; activation "abs": |s|+1e-4 (splatter.py:521)
+    opa: np.ndarray  # [N]   logit
+    rgb: np.ndarray  # [N,3] logit, or [N,27] SH coeffs (channel-major 3x9, utils.py:345-348)
+
+    @property
+    def n(self) -> int:
+        return self.pos.shape[0]
+
+    @property
+    def use_sh(self) -> bool:
+        return self.rgb.shape[1] == 27
+
+
+def make_camera(width: int, height: int, yaw_deg: float = 0.0) -> Camera:
+    """Identity pose (optionally yawed about +y), fx = fy = 0.75 * W."""
+    f = 0.75 * width
+    a = math.radians(yaw_deg)
+    rot = np.array([[math.cos(a), 0.0, math.sin(a)], [0.0, 1.0, 0.0], [-math.sin(a), 0.0, math.cos(a)]],
+                   dtype=np.float32)
+    return Camera(width, height, f, f, rot, np.zeros(3, np.float32))
+
+
+def make_scene(n: int, width: int, height: int, seed: int = 2023, use_sh: bool = False,
+               max_px_sigma: float = 16.0) -> Scene:
+    """SURVEY.md section 8d generator (camera = make_camera(width, height))."""
+    rng = np.random.default_rng(seed)
+    fx = 0.75 * width
+    z = rng.uniform(-0.5, 10.0, n)
+    u = rng.uniform(-1.0, 1.0, n)
+    v = rng.uniform(-1.0, 1.0, n)
+    x = u * 1.3 * (width / 2 / fx) * z
+    y = v * 1.3 * (height / 2 / fx) * z
+    pos = np.stack([x, y, z], 1).astype(np.float32)
+    s_px = np.exp(rng.uniform(0.0, math.log(max_px_sigma), n))
+    scale = (s_px * np.abs(z) / fx)[:, None] * rng.uniform(0.25, 1.0, (n, 3))
+    quat = rng.normal(size=(n, 4))
+    quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+    quat *= rng.uniform(0.5, 2.0, (n, 1))  # raw parameters are not unit length
+    opa = rng.normal(0.0, 2.0, n)
+    if use_sh:
+        rgb = rng.normal(0.0, 0.5, (n, 3, 9))
+        rgb[:, :, 0] = rng.normal(0.0, 1.0, (n, 3)) / C0  # DC like initialize_sh
+        rgb = rgb.reshape(n, 27)
+    else:
+        rgb = rng.normal(0.0, 1.0, (n, 3))
+    return Scene(pos, quat.astype(np.float32), scale.astype(np.float32), opa.astype(np.float32),
+                 rgb.astype(np.float32))
+
+
+# BASELINE.json configs -> (n_gaussians, width, height, use_sh)
+CONFIGS = {
+    "cfg1": (10_000, 256, 256, False),
+    "cfg2": (376_467, 1920, 1080, False),
+    "cfg3": (506_627, 1920, 1080, False),
+    "cfg4": (2_400_000, 1920, 1080, True),
+    "cfg5": (2_400_000, 1920, 1080, False),
+}

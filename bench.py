@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py -- render FPS of the MI355X rasterizer path on BASELINE.json's configs.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one forward frame of the whole hot path (cull+project -> duplicate -> radix sort ->
+tile ranges -> 16x16 compositing -> clamp+crop) on synthetic Gaussians already resident in
+HBM.  Default workload: BASELINE.json configs[1] = 376,467 Gaussians at 1920x1080, no SH,
+forward render.  With N > 1 every rank renders its own view (yaw k x 5 deg) of a full replica of
+the scene -- the path shards by view and the forward render has no exchange step, so there is no
+data-path collective (weak scaling).  The training leg reported under "extra" (fwd + bwd of an L1
+loss) does have one: an RCCL all-reduce of the flat parameter-gradient bucket.
+
+Rank 0 prints ONE JSON line (driver contract) with "roofline" (dominant kernel =
+raster_forward_kernel, timed live with hipEvents on its own stream inside the library) and
+"cpu_baseline" (the C oracle = CPU port of the reference path, one host core).
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "3d-gaussian-splatting_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="cfg2", help="cfg1..cfg5 of gs_scene.CONFIGS")
+    ap.add_argument("--no-extra", action="store_true", help="skip the training / 2.4M legs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from gs_frame import FrameRenderer
+    from gs_scene import CONFIGS, make_camera, make_scene
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def load(cfg):
+        n, W, H, use_sh = CONFIGS[cfg]
+        scene = make_scene(n, W, H, seed=2023, use_sh=use_sh)
+        cam = make_camera(W, H, yaw_deg=5.0 * rank)  # one view per GPU
+        params = [torch.from_numpy(a).to(dev) for a in (scene.pos, scene.quat, scene.scale, scene.opa, scene.rgb)]
+        return scene, cam, params
+
+    def sized_renderer(params, cam, training):
+        r = FrameRenderer(dev, max_pairs=1 << 20, training=training, auto_grow=True)
+        r.forward(*params, cam)  # grows the workspace until the frame fits
+        st = r.stats()
+        r.max_pairs = int(st.pairs * 1.1) + 4096
+        r.auto_grow = False  # from here on: no host synchronisation inside a frame
+        r.forward(*params, cam)
+        return r, r.stats()
+
+    def time_frames(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        barrier()
+        return max_over_ranks(dt)
+
+    # ---------------------------------------------------------------- headline: render FPS
+    scene, cam, params = load(args.config)
+    n, W, H, use_sh = CONFIGS[args.config]
+    r, st = sized_renderer(params, cam, training=False)
+    log(f"[rank {rank}] {args.config}: N={n} V={st.visible} M={st.pairs} {W}x{H} sh={use_sh}")
+    dt = time_frames(lambda: r.forward(*params, cam), args.steps, args.warmup)
+    ms_per_step = dt / args.steps * 1e3
+    fps = world * args.steps / dt
+
+    out = {
+        "metric": "render_fps", "value": round(fps, 2), "unit": "frames/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{args.config}: {n} Gaussians, {W}x{H}, "
+                               f"{'SH deg2 (27 coeff)' if use_sh else 'no SH'}, forward render, one view per GPU",
+                   "n_gaussians": n, "visible": st.visible, "tile_pairs": st.pairs, "width": W, "height": H,
+                   "parallelism": f"view-sharded x{world} (no data-path collective)"},
+    }
+
+    # ---------------------------------------------------------------- roofline of the dominant kernel
+    if rank == 0:
+        prof = [r.profile_forward(*params, cam) for _ in range(25)][5:]
+        stage = {k: statistics.median(p[k] for p in prof) for k in prof[0]}
+        C = 27 if use_sh else 3
+        grid_px = (-(-W // 16) * 16) * (-(-H // 16) * 16)
+        alg_bytes = (4 + 24 + 4 + 4 * C) * st.pairs + 12 * grid_px  # SURVEY.md 8d, stage S5 (raster)
+        achieved = alg_bytes / (stage["raster"] * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "raster_forward_kernel", "achieved": round(achieved, 1),
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                           "traffic": None, "algorithmic_bytes": alg_bytes,
+                           "kernel_ms": round(stage["raster"], 4)}
+        out["stage_ms"] = {k: round(v, 4) for k, v in stage.items()}
+        # whole-frame algorithmic bytes: 44N + (64+8C)V + (72+4C)M + 12P + 4T
+        T = grid_px // 256
+        b_fwd = 44 * n + (64 + 8 * C) * st.visible + (72 + 4 * C) * st.pairs + 12 * grid_px + 4 * T
+        out["frame_roofline"] = {"algorithmic_bytes": b_fwd,
+                                 "achieved_GBs": round(b_fwd / (ms_per_step * 1e-3) / 1e9, 1),
+                                 "frac_of_hbm_peak": round(b_fwd / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+    # ---------------------------------------------------------------- extra legs
+    extra = {}
+    if not args.no_extra:
+        # training iteration: forward (checkpointing) + L1 loss + backward (+ RCCL all-reduce when N > 1)
+        from gs_dp import FlatGaussianParams
+
+        flat = FlatGaussianParams(params, world_size=world)
+        rt, stt = sized_renderer(flat.params, cam, training=True)
+        target = torch.rand(H, W, 3, device=dev)
+
+        def train_iter():
+            img, _ = rt.forward(*flat.params, cam)
+            g = torch.sign(img - target) / img.numel()  # d(L1 mean)/d(img)
+            rt.backward(g, out=flat.grads)
+            flat.all_reduce_grads()
+
+        k = max(args.steps // 4, 10)
+        dtt = time_frames(train_iter, k, max(args.warmup // 4, 3))
+        extra["train_iters_per_s"] = round(world * k / dtt, 2)
+        extra["train_ms_per_iter"] = round(dtt / k * 1e3, 4)
+        if rank == 0:
+            img, _ = rt.forward(*flat.params, cam)
+            pb = [rt.profile_backward(torch.sign(img - target) / img.numel()) for _ in range(8)][3:]
+            extra["backward_stage_ms"] = {key: round(statistics.median(p[key] for p in pb), 4) for key in pb[0]}
+        del rt, flat
+        torch.cuda.empty_cache()
+        if args.config != "cfg5":
+            _, cam5, params5 = load("cfg5")  # 2.4M Gaussians, the north-star target (>= 160 FPS)
+            r5, st5 = sized_renderer(params5, cam5, training=False)
+            k5 = max(args.steps // 4, 10)
+            dt5 = time_frames(lambda: r5.forward(*params5, cam5), k5, 5)
+            extra["cfg5_2p4M_render_fps"] = round(world * k5 / dt5, 2)
+            extra["cfg5_visible"], extra["cfg5_tile_pairs"] = st5.visible, st5.pairs
+    out["extra"] = extra
+
+    # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle  # the checker, timed here as the "port" baseline -- never on the product path
+        from gs_geometry import RayBasis, TileGrid
+
+        grid = TileGrid(W, H, cam.focal_x, cam.focal_y)
+        rays = RayBasis.from_camera(cam.rot, cam.tran, grid.padded_height, grid.padded_width, cam.focal_x, cam.focal_y)
+        t0, frames = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 10.0 or frames < 2:
+            oracle.render_forward(scene.pos, scene.quat, scene.scale, scene.opa, scene.rgb, cam.rot, cam.tran,
+                                  cam.near, W, H, cam.focal_x, cam.focal_y, 0.05, use_sh=use_sh, rays_o=rays.rays_o,
+                                  lefttop=rays.lefttop, vdx=rays.dx, vdy=rays.dy)
+            frames += 1
+        cpu_dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(frames / cpu_dt, 4), "unit": "frames/s", "cores": 1, "kind": "port",
+                               "sample": f"{frames} full forward frames of {args.config} "
+                                         f"(oracle/gs_oracle.c, scalar C, {os.cpu_count()} host cores present)"}
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

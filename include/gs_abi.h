@@ -1,0 +1,220 @@
+/*
+ * gs_abi.h -- C ABI of libgs_amd.so, the MI355X (gfx950) rasterizer library.
+ *
+ * This is the drop-in boundary for the hot path of WangFeng18/3d-gaussian-splatting: the
+ * entry points in section A are exactly what the reference's pybind11 module `gaussian`
+ * (src/bindings.cpp:21-50) binds, with torch::Tensor arguments replaced by raw device
+ * pointers + explicit sizes and an explicit HIP stream.  Section B is the fused,
+ * MI355X-native frame path (cull+project+count -> scan+emit -> radix sort -> ranges ->
+ * raster fwd/bwd -> project bwd) that the reference spreads over 4 native launches and ~25
+ * torch kernels per frame (splatter.py:513-641).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in `_host`;
+ *   - all arrays are contiguous, row-major, fp32 unless stated;
+ *   - the caller owns every buffer; the library never allocates device memory and keeps no
+ *     pointer past the call; it is re-entrant across host threads (forward is called from
+ *     the main thread, backward from PyTorch's autograd thread);
+ *   - every function returns 0 on success, a negative GS_E_* validation code, or a positive
+ *     hipError_t; gs_last_error() returns a thread-local message for the last failure;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream, which is
+ *     what the reference launches on).
+ */
+#ifndef GS_ABI_H
+#define GS_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* the library is built with -fvisibility=hidden; only this header's symbols are exported */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
+
+#define GS_ABI_VERSION 1
+
+#define GS_E_INVALID (-1)   /* bad argument (null pointer, negative size, bad enum)   */
+#define GS_E_UNSUPPORTED (-2) /* valid in the reference but not implemented here      */
+#define GS_E_CAPACITY (-3)  /* workspace too small for this frame                     */
+
+typedef void *gs_stream_t;
+
+const char *gs_last_error(void);
+int gs_abi_version(void);
+
+/* =========================================================================================
+ * A. The reference `gaussian` module surface (src/bindings.cpp:21-50)
+ * ======================================================================================= */
+
+/* bindings.cpp:23 `culling` -> gaussian.cu:6-8: a stub that prints "hellow". Kept as a no-op. */
+int gs_culling(void);
+
+/* bindings.cpp:24 `world2camera(pos, rot, trans, res)` -> gaussian.cu:49-76.
+ * res[i] = rot * pos[i] + tran.   pos,res: [B,3]; rot: [3,3]; tran: [3]. */
+int gs_world2camera(const float *pos, const float *rot, const float *tran, float *res, int64_t B,
+                    gs_stream_t stream);
+
+/* bindings.cpp:25 `world2camera_backward(grad_out, rot, grad_inp)` -> gaussian.cu:78-99. */
+int gs_world2camera_backward(const float *grad_out, const float *rot, float *grad_inp, int64_t B,
+                             gs_stream_t stream);
+
+/* bindings.cpp:26 `jacobian(pos_camera_space, jacobian)` -> gaussian.cu:10-47.  jac: [B,3,3]. */
+int gs_jacobian(const float *pos_cam, float *jac, int64_t B, gs_stream_t stream);
+
+/* bindings.cpp:48 `global_culling` -> gaussian.cu:1182-1369.
+ * pos [N,3], quat [N,4] (pre-normalised), scale [N,3] (pre-activated), rot [3,3], tran [3]
+ * -> res_pos [N,3] = (x/z, y/z, |p_c|), res_cov [N,2,2], culling_mask [N] int64.
+ * Rows of culled Gaussians are left untouched (the caller pre-zeroes, renderer.py:124-126). */
+int gs_global_culling(const float *pos, const float *quat, const float *scale, const float *rot,
+                      const float *tran, int64_t N, float near_plane, float half_width,
+                      float half_height, float *res_pos, float *res_cov, int64_t *culling_mask,
+                      gs_stream_t stream);
+
+/* bindings.cpp:49 `global_culling_backward` -> gaussian.cu:1371-1609. */
+int gs_global_culling_backward(const float *pos, const float *quat, const float *scale,
+                               const float *rot, const float *tran, int64_t N,
+                               const float *gradout_pos, const float *gradout_cov,
+                               const int64_t *culling_mask, float *gradinput_pos,
+                               float *gradinput_quat, float *gradinput_scale, gs_stream_t stream);
+
+/* bindings.cpp:44 `calc_tile_list(Gaussian3ds&, Tiles&, tile_n_point, tile_gaussian_list,
+ * thresh, method, tile_length_x, tile_length_y, n_tiles_x, n_tiles_y, leftmost, topmost)`
+ * -> gaussian.cu:101-335.  The two structs are flattened: Gaussian3ds contributes pos [V,3]
+ * and cov [V,2,2]; Tiles contributes top/bottom/left/right [T] (read by methods 0 and 1 only,
+ * may be NULL for method 2).  tile_n_point [T] int32 must be zeroed by the caller;
+ * tile_gaussian_list is [T, max_points_per_tile] int32.  Race-free: a tile keeps the first
+ * `max_points_per_tile` arrivals, the counter keeps counting (the caller clamps it,
+ * splatter.py:586). */
+int gs_calc_tile_list(const float *pos, const float *cov, int64_t n_point, const float *tile_top,
+                      const float *tile_bottom, const float *tile_left, const float *tile_right,
+                      int32_t *tile_n_point, int32_t *tile_gaussian_list,
+                      int64_t max_points_per_tile, float thresh, int method, float tile_length_x,
+                      float tile_length_y, int32_t n_tiles_x, int32_t n_tiles_y, float leftmost,
+                      float topmost, gs_stream_t stream);
+
+/* bindings.cpp:45 `gather_gaussians(tile_n_point_accum, tile_gaussian_list, gathered_list,
+ * tile_ids_for_points, max_points_for_tile)` -> gaussian.cu:337-381. */
+int gs_gather_gaussians(const int32_t *tile_n_point_accum, const int32_t *tile_gaussian_list,
+                        int32_t *gathered_list, int32_t *tile_ids_for_points, int64_t n_tiles,
+                        int64_t max_points_for_tile, int64_t list_row_size, gs_stream_t stream);
+
+/* bindings.cpp:46 `draw` -> gaussian.cu:806-1043.
+ * pos [M,3] (z ignored), rgb [M,D] (D = 3, or 27 when use_sh_coeff), opa [M], cov [M,2,2],
+ * tile_n_point_accum [T+1] int32, res [h,w,3] with h,w the PADDED size (multiples of 16).
+ * rays_o/lefttop_pos/vec_dx/vec_dy: device float[3], only read when use_sh_coeff. */
+int gs_draw(const float *pos, const float *rgb, const float *opa, const float *cov,
+            const int32_t *tile_n_point_accum, float *res, int32_t h, int32_t w, int64_t M,
+            float focal_x, float focal_y, int weight_normalize, int sigmoid, int fast,
+            const float *rays_o, const float *lefttop_pos, const float *vec_dx,
+            const float *vec_dy, int use_sh_coeff, gs_stream_t stream);
+
+/* bindings.cpp:47 `draw_backward` -> gaussian.cu:440-803, 1045-1129.
+ * grad_pos [M,3] (column 2 is never written), grad_rgb [M,D], grad_opa [M], grad_cov [M,2,2]:
+ * one row per (tile, Gaussian) pair.  `workspace` holds the per-bucket pixel checkpoints of
+ * the replayed forward pass: gs_draw_backward_workspace_bytes(M, h, w) bytes. */
+size_t gs_draw_backward_workspace_bytes(int64_t M, int32_t h, int32_t w);
+int gs_draw_backward(const float *pos, const float *rgb, const float *opa, const float *cov,
+                     const int32_t *tile_n_point_accum, const float *output,
+                     const float *grad_output, float *grad_pos, float *grad_rgb, float *grad_opa,
+                     float *grad_cov, int32_t h, int32_t w, int64_t M, float focal_x,
+                     float focal_y, int weight_normalize, int sigmoid, int fast,
+                     const float *rays_o, const float *lefttop_pos, const float *vec_dx,
+                     const float *vec_dy, int use_sh_coeff, void *workspace,
+                     size_t workspace_bytes, gs_stream_t stream);
+
+/* =========================================================================================
+ * B. Fused frame path (replaces splatter.py:513-655 forward and its autograd backward)
+ * ======================================================================================= */
+
+/* Device radix sort of (key, value) pairs on key bits [0, end_bit), stable, ascending (LSD,
+ * 8 bits per pass).  The element count is read from DEVICE memory (*d_count, clamped to
+ * `capacity`) so that the frame needs no host synchronisation.  The input lives in buffer 0
+ * (keys0/vals0, destroyed); buffer 1 is scratch; on return *sorted_in_buffer1 tells which
+ * buffer holds the result (it only depends on end_bit).  tmp: gs_sort_pairs_tmp_bytes(capacity). */
+size_t gs_sort_pairs_tmp_bytes(int64_t capacity);
+int gs_sort_pairs(uint64_t *keys0, uint32_t *vals0, uint64_t *keys1, uint32_t *vals1,
+                  const uint32_t *d_count, int64_t capacity, int end_bit, void *tmp,
+                  size_t tmp_bytes, int *sorted_in_buffer1, gs_stream_t stream);
+
+/* Frame descriptor.  All scalars are per-camera constants computed on the host exactly as
+ * splatter.py does (Tiles, RayInfo, frustum guard band); rot/tran are passed by value. */
+typedef struct gs_frame {
+    /* scene (raw parameters, activations are fused: |s|+1e-4 / exp, q/|q|, sigmoid) */
+    int64_t N;
+    int32_t color_dim;        /* 3 (sigmoid colour) or 27 (degree-2 SH coefficients)    */
+    int32_t scale_activation; /* 0 = abs (+1e-4), 1 = exp   (splatter.py:520-524)       */
+    const float *pos;         /* [N,3]  */
+    const float *quat;        /* [N,4]  */
+    const float *scale;       /* [N,3]  */
+    const float *opa;         /* [N]    */
+    const float *rgb;         /* [N,color_dim] */
+    /* camera */
+    float rot[9];
+    float tran[3];
+    float near_plane, half_width, half_height;
+    int32_t width, height;    /* un-padded output size */
+    float focal_x, focal_y;
+    /* Tiles.create_tiles scalars, computed by the host in double (splatter.py:279-282) */
+    float tile_length_x, tile_length_y, leftmost, topmost;
+    float thresh;             /* tile_culling_prob_thresh (train.py: 0.05) */
+    float rays_o[3], lefttop[3], vec_dx[3], vec_dy[3];
+    /* workspace (caller-allocated, sizes from gs_frame_workspace_layout) */
+    int64_t max_pairs;        /* capacity for (tile, Gaussian) pairs                      */
+    void *workspace;
+    size_t workspace_bytes;
+    /* outputs */
+    float *image;             /* [height,width,3] clamped + cropped (may be NULL)         */
+    float *image_padded;      /* [padH,padW,3] raw draw output (may be NULL if !training) */
+    int32_t training;         /* 1: keep per-bucket checkpoints for gs_frame_backward      */
+    int32_t reserved;
+} gs_frame;
+
+/* Bytes of workspace needed for N Gaussians, `max_pairs` pairs, a width x height image. */
+size_t gs_frame_workspace_bytes(int64_t N, int64_t max_pairs, int32_t width, int32_t height,
+                                int32_t color_dim, int32_t training);
+
+/* Forward frame.  Launches everything on `stream`, never synchronises. */
+int gs_frame_forward(const gs_frame *f, gs_stream_t stream);
+
+/* Same work as gs_frame_forward, but brackets every stage with hipEvents on `stream` and
+ * returns the stage durations in milliseconds (synchronises; for bench.py / profiling only):
+ * stage_ms_host[0..5] = project+count, scan+emit, radix sort, tile ranges, raster, total. */
+#define GS_N_STAGES 6
+int gs_frame_forward_profile(const gs_frame *f, float *stage_ms_host, gs_stream_t stream);
+/* Likewise for gs_frame_backward: [0..2] = raster backward (incl. memset + bucket scan),
+ * project backward, total. */
+int gs_frame_backward_profile(const gs_frame *f, const float *grad_image, float *grad_pos,
+                              float *grad_quat, float *grad_scale, float *grad_opa,
+                              float *grad_rgb, float *stage_ms_host, gs_stream_t stream);
+
+/* Counters of the last forward on this workspace, copied device->host asynchronously into
+ * `stats_host` (4 x int64: V visible, M pairs, overflow flag, processed buckets).  The
+ * caller synchronises the stream before reading. */
+int gs_frame_stats_async(const gs_frame *f, int64_t *stats_host, gs_stream_t stream);
+
+/* Read-only views into the workspace of the last forward (for parity tests): sorted keys
+ * (u64 [M]), sorted Gaussian ids (u32 [M]), per-tile ranges (int32 [T,2]), projected
+ * pos/cov/mask-equivalents.  Any out pointer may be NULL. */
+int gs_frame_debug_views(const gs_frame *f, const uint64_t **sorted_keys,
+                         const uint32_t **sorted_ids, const int32_t **tile_ranges,
+                         const float **rec_geom, const float **rec_cov, const float **rec_color,
+                         const uint32_t **tiles_touched);
+
+/* Backward frame: grad_image is dL/d(image) [height,width,3] (w.r.t. the clamped, cropped
+ * output).  Writes dL/d(raw parameter) for every Gaussian (zeros for culled ones):
+ * grad_pos [N,3], grad_quat [N,4], grad_scale [N,3], grad_opa [N], grad_rgb [N,color_dim].
+ * Must follow a gs_frame_forward with training=1 on the same workspace. */
+int gs_frame_backward(const gs_frame *f, const float *grad_image, float *grad_pos,
+                      float *grad_quat, float *grad_scale, float *grad_opa, float *grad_rgb,
+                      gs_stream_t stream);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
+#ifdef __cplusplus
+}
+#endif
+#endif /* GS_ABI_H */

@@ -1,0 +1,247 @@
+"""GPU parity: every reference-API entry point of libgs_amd.so (through the `gaussian` /
+`renderer` drop-in modules, i.e. through the C ABI) against the CPU oracle on seeded inputs.
+
+Tolerances: integer / index results bit-exact; cull+project forward bit-exact (both sides are
+IEEE fp32 in source order, no contraction); rasterizer images abs 5e-5 (v_exp_f32 vs expf and
+the hoisted conic division), gradients 2e-4 relative to the tensor's max magnitude.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from gs_geometry import TileGrid
+from gs_scene import make_camera, make_scene
+from gs_testutil import OracleFrame, activate, frame_scalars, rel_err
+
+pytestmark = pytest.mark.gpu
+
+IMG_ATOL = 5e-5
+GRAD_RTOL = 2e-4
+
+
+def dev(a, device, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(device)
+
+
+def small_case(n=20000, W=320, H=200, seed=7, use_sh=False):
+    scene = make_scene(n, W, H, seed=seed, use_sh=use_sh)
+    cam = make_camera(W, H, yaw_deg=3.0)
+    cam.tran = np.array([0.05, -0.02, 0.1], np.float32)
+    return scene, cam
+
+
+# ------------------------------------------------------------------ K1 / K2 / legacy
+def test_global_culling_forward_bit_exact(gpu):
+    import gaussian
+
+    scene, cam = small_case()
+    qn, sn = activate(scene)
+    grid, hw, hh, _ = frame_scalars(cam)
+    rp, rc, mk = oracle.global_culling(scene.pos, qn, sn, cam.rot, cam.tran, cam.near, hw, hh)
+    n = scene.n
+    res_pos = torch.zeros(n, 3, device=gpu)
+    res_cov = torch.zeros(n, 2, 2, device=gpu)
+    mask = torch.zeros(n, dtype=torch.long, device=gpu)
+    gaussian.global_culling(dev(scene.pos, gpu), dev(qn, gpu), dev(sn, gpu), dev(cam.rot, gpu), dev(cam.tran, gpu),
+                            res_pos, res_cov, mask, cam.near, hw, hh)
+    assert np.array_equal(mask.cpu().numpy(), mk)
+    assert 0 < mk.sum() < n
+    assert np.array_equal(res_pos.cpu().numpy().view(np.uint32), rp.view(np.uint32)), "pos_i bits differ"
+    assert np.array_equal(res_cov.cpu().numpy().view(np.uint32), rc.view(np.uint32)), "cov bits differ"
+
+
+def test_global_culling_backward(gpu):
+    import gaussian
+
+    scene, cam = small_case()
+    qn, sn = activate(scene)
+    grid, hw, hh, _ = frame_scalars(cam)
+    _, _, mk = oracle.global_culling(scene.pos, qn, sn, cam.rot, cam.tran, cam.near, hw, hh)
+    rng = np.random.default_rng(1)
+    gop = rng.normal(size=(scene.n, 3)).astype(np.float32)
+    goc = rng.normal(size=(scene.n, 2, 2)).astype(np.float32)
+    ref = oracle.global_culling_backward(scene.pos, qn, sn, cam.rot, cam.tran, gop, goc, mk)
+    outs = [torch.zeros(scene.n, k, device=gpu) for k in (3, 4, 3)]
+    gaussian.global_culling_backward(dev(scene.pos, gpu), dev(qn, gpu), dev(sn, gpu), dev(cam.rot, gpu),
+                                     dev(cam.tran, gpu), dev(gop, gpu), dev(goc, gpu), dev(mk, gpu), *outs)
+    for o, r, name in zip(outs, ref, ("pos", "quat", "scale")):
+        o = o.cpu().numpy()
+        assert np.all(o[mk == 0] == 0), name
+        assert np.allclose(o, r, rtol=1e-5, atol=1e-6 * np.abs(r).max()), (name, rel_err(o, r))
+
+
+def test_world2camera_and_jacobian(gpu):
+    import gaussian
+
+    rng = np.random.default_rng(3)
+    pos = rng.normal(size=(1001, 3)).astype(np.float32) + np.array([0, 0, 4], np.float32)
+    _, cam = small_case()
+    res = torch.zeros(1001, 3, device=gpu)
+    gaussian.world2camera(dev(pos, gpu), dev(cam.rot, gpu), dev(cam.tran, gpu), res)
+    ref = oracle.world2camera(pos, cam.rot, cam.tran)
+    assert np.allclose(res.cpu().numpy(), ref, rtol=1e-6, atol=1e-6)
+    gi = torch.zeros(1001, 3, device=gpu)
+    gaussian.world2camera_backward(dev(pos, gpu), dev(cam.rot, gpu), gi)
+    assert np.allclose(gi.cpu().numpy(), oracle.world2camera_backward(pos, cam.rot), rtol=1e-6, atol=1e-6)
+    jac = torch.zeros(1001, 3, 3, device=gpu)
+    gaussian.jacobian(dev(ref, gpu), jac)
+    assert np.allclose(jac.cpu().numpy(), oracle.jacobian(ref), rtol=1e-5, atol=1e-6)
+
+
+def test_renderer_world2camera_autograd(gpu):
+    from renderer import world2camera_func
+
+    _, cam = small_case()
+    pos = torch.randn(257, 3, device=gpu, requires_grad=True)
+    rot, tran = dev(cam.rot, gpu), dev(cam.tran, gpu)
+    out = world2camera_func(pos, rot, tran)
+    ref = pos @ rot.T + tran
+    assert torch.allclose(out, ref, atol=1e-5)
+    g = torch.randn_like(out)
+    (gin,) = torch.autograd.grad(out, pos, g)
+    (gref,) = torch.autograd.grad(ref, pos, g)
+    assert torch.allclose(gin, gref, atol=1e-5)
+
+
+# ------------------------------------------------------------------ K3/K4/K5/K6
+def _projected(scene, cam):
+    qn, sn = activate(scene)
+    grid, hw, hh, _ = frame_scalars(cam)
+    rp, rc, mk = oracle.global_culling(scene.pos, qn, sn, cam.rot, cam.tran, cam.near, hw, hh)
+    keep = mk.astype(bool)
+    return grid, rp[keep], rc[keep].reshape(-1, 4)
+
+
+@pytest.mark.parametrize("method", [2, 1, 0])
+def test_calc_tile_list_and_gather(gpu, method):
+    import gaussian
+
+    scene, cam = small_case(n=3000 if method != 2 else 20000, W=160, H=96)
+    grid, pos_i, cov = _projected(scene, cam)
+    V, T = pos_i.shape[0], grid.n_tiles
+    maxp = max(V // 20, 8)  # splatter.py:569
+    top, bottom, left, right = grid.tile_edges()
+    thresh = 0.05 if method else (grid.tile_geo_length_x / 0.3) ** 2
+    n_ref, list_ref = oracle.calc_tile_list(pos_i, cov, maxp, thresh, method, grid.tile_geo_length_x,
+                                            grid.tile_geo_length_y, grid.n_tile_x, grid.n_tile_y, grid.leftmost,
+                                            grid.topmost, top, bottom, left, right)
+    g3 = gaussian.Gaussian3ds()
+    g3.pos, g3.cov = dev(pos_i, gpu), dev(cov.reshape(-1, 2, 2), gpu)
+    ti = gaussian.Tiles()
+    ti.top, ti.bottom, ti.left, ti.right = (dev(a, gpu) for a in (top, bottom, left, right))
+    tile_n_point = torch.zeros(T, dtype=torch.int32, device=gpu)
+    tile_list = torch.full((T, maxp), -1, dtype=torch.int32, device=gpu)
+    gaussian.calc_tile_list(g3, ti, tile_n_point, tile_list, thresh, method, grid.tile_geo_length_x,
+                            grid.tile_geo_length_y, grid.n_tile_x, grid.n_tile_y, grid.leftmost, grid.topmost)
+    cnt = torch.min(tile_n_point, torch.full_like(tile_n_point, maxp))  # splatter.py:586
+    cnt_np = cnt.cpu().numpy()
+    assert np.array_equal(cnt_np, np.minimum(n_ref, maxp))
+    assert cnt_np.sum() > 0
+    lst = tile_list.cpu().numpy()
+    for t in range(T):
+        if n_ref[t] <= maxp:  # below the cap the SET of Gaussians is defined (order is atomic order)
+            assert np.array_equal(np.sort(lst[t, :cnt_np[t]]), np.sort(list_ref[t, :n_ref[t]])), t
+    accum = torch.cat([torch.zeros(1, dtype=torch.int32, device=gpu), torch.cumsum(cnt, 0).to(torch.int32)])
+    M = int(accum[-1])
+    gathered = torch.empty(M, dtype=torch.int32, device=gpu)
+    tile_ids = torch.empty(M, dtype=torch.int32, device=gpu)
+    gaussian.gather_gaussians(accum, tile_list, gathered, tile_ids, int(cnt.max()))
+    g_ref, t_ref = oracle.gather_gaussians(accum.cpu().numpy(), lst)
+    assert np.array_equal(gathered.cpu().numpy(), g_ref)
+    assert np.array_equal(tile_ids.cpu().numpy(), t_ref)
+
+
+# ------------------------------------------------------------------ radix sort
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 2047, 2048, 2049, 5000, 300001])
+def test_sort_pairs(gpu, n):
+    import ctypes as C
+
+    from gaussian import _lib
+
+    rng = np.random.default_rng(n + 11)
+    cap = n + 1000
+    tiles = rng.integers(0, 700, cap).astype(np.uint64)
+    depth = rng.integers(0, 40, cap).astype(np.uint64) * np.uint64(0x01000193) % np.uint64(1 << 32)  # many ties
+    keys = (tiles << np.uint64(32)) | depth
+    vals = np.arange(cap, dtype=np.uint32)
+    k0, v0 = dev(keys.view(np.int64), gpu), dev(vals.view(np.int32), gpu)
+    k1, v1 = torch.empty_like(k0), torch.empty_like(v0)
+    cnt = torch.tensor([n, 0], dtype=torch.int32, device=gpu)
+    tmp = torch.empty(_lib.gs_sort_pairs_tmp_bytes(cap), dtype=torch.uint8, device=gpu)
+    in1 = C.c_int(0)
+    end_bit = 32 + 10
+    _lib.check(_lib.gs_sort_pairs(k0.data_ptr(), v0.data_ptr(), k1.data_ptr(), v1.data_ptr(), cnt.data_ptr(), cap,
+                                  end_bit, tmp.data_ptr(), tmp.numel(), C.byref(in1),
+                                  torch.cuda.current_stream().cuda_stream), "gs_sort_pairs")
+    ks, vs = (k1, v1) if in1.value else (k0, v0)
+    order = np.argsort(keys[:n], kind="stable")
+    assert np.array_equal(ks.cpu().numpy().view(np.uint64)[:n], keys[:n][order])
+    assert np.array_equal(vs.cpu().numpy().view(np.uint32)[:n], vals[:n][order])  # stability
+
+
+# ------------------------------------------------------------------ K7 / K8 through renderer.py
+def _sorted_inputs(scene, cam, thresh=0.05):
+    of = OracleFrame(scene, cam, thresh)
+    return of
+
+
+@pytest.mark.parametrize("use_sh", [False, True])
+def test_draw_forward_backward(gpu, use_sh):
+    from renderer import draw
+
+    scene, cam = small_case(n=12000, W=200, H=120, seed=5, use_sh=use_sh)
+    of = _sorted_inputs(scene, cam)
+    grid, rays = of.grid, of.rays
+    assert of.accum.max() > 0 and np.diff(of.accum).max() > 64  # multi-bucket tiles
+    t = [dev(a, gpu).requires_grad_(True) for a in (of.s_pos, of.s_rgb, of.s_opa, of.s_cov.reshape(-1, 2, 2))]
+    accum = dev(of.accum, gpu)
+    img = draw(*t, accum, grid.padded_height, grid.padded_width, grid.focal_x, grid.focal_y, False, False, use_sh,
+               True, dev(rays.rays_o, gpu), dev(rays.lefttop, gpu), dev(rays.dx, gpu), dev(rays.dy, gpu))
+    err = np.abs(img.detach().cpu().numpy() - of.padded)
+    assert err.max() < IMG_ATOL, err.max()
+    rng = np.random.default_rng(9)
+    gpad = rng.normal(size=of.padded.shape).astype(np.float32)
+    img.backward(dev(gpad, gpu))
+    ref = oracle.draw_backward(of.s_pos, of.s_rgb, of.s_opa, of.s_cov, of.accum, of.padded, gpad, grid.focal_x,
+                               grid.focal_y, use_sh=use_sh, fast=True, rays_o=rays.rays_o, lefttop=rays.lefttop,
+                               vdx=rays.dx, vdy=rays.dy)
+    got = [x.grad.cpu().numpy() for x in t]
+    assert np.all(got[0][:, 2] == 0)  # grad_pos z is never written
+    for g, r, name in zip(got, ref, ("pos", "rgb", "opa", "cov")):
+        assert rel_err(g.reshape(r.shape), r) < GRAD_RTOL, (name, rel_err(g.reshape(r.shape), r))
+
+
+def test_draw_flags_weight_normalize_and_sigmoid(gpu):
+    import gaussian
+
+    scene, cam = small_case(n=6000, W=96, H=64, seed=2)
+    of = _sorted_inputs(scene, cam)
+    grid = of.grid
+    args = [dev(a, gpu) for a in (of.s_pos, of.s_rgb, of.s_opa, of.s_cov.reshape(-1, 2, 2))]
+    accum = dev(of.accum, gpu)
+    for wn, sg in ((True, False), (False, True), (True, True)):
+        res = torch.zeros(grid.padded_height, grid.padded_width, 3, device=gpu)
+        gaussian.draw(*args, accum, res, grid.focal_x, grid.focal_y, wn, sg, True, None, None, None, None, False)
+        ref = oracle.draw(of.s_pos, of.s_rgb, of.s_opa, of.s_cov, of.accum, grid.padded_height, grid.padded_width,
+                          grid.focal_x, grid.focal_y, weight_normalize=wn, sigmoid=sg, fast=True)
+        assert np.abs(res.cpu().numpy() - ref).max() < 2e-4, (wn, sg)
+
+
+def test_draw_empty_and_errors(gpu):
+    import gaussian
+
+    res = torch.zeros(32, 48, 3, device=gpu)
+    accum = torch.zeros(2 * 3 + 1, dtype=torch.int32, device=gpu)
+    z = lambda *s: torch.zeros(*s, device=gpu)
+    gaussian.draw(z(0, 3), z(0, 3), z(0), z(0, 2, 2), accum, res, 100.0, 100.0, False, False, True, None, None, None,
+                  None, False)
+    assert float(res.abs().max()) == 0.0
+    with pytest.raises(RuntimeError):  # wrong dtype, like data_ptr<float>() in the reference
+        gaussian.draw(z(0, 3).double(), z(0, 3), z(0), z(0, 2, 2), accum, res, 100.0, 100.0, False, False, True,
+                      None, None, None, None, False)
+    with pytest.raises(RuntimeError):  # CPU tensor
+        gaussian.world2camera(torch.zeros(4, 3), z(3, 3), z(3), z(4, 3))
