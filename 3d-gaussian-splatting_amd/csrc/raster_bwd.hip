@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, Raste
 
         const float dx = px - g.x, dy = py - g.y;
         const float dxx = dx * dx, dxy = dx * dy, dyy = dy * dy;
-        const float q = cA * dxx - cB * dxy + cC * dyy;
+        const float q = fmaf(cC * dy, dy, dx * fmaf(-cB, dy, cA * dx));  // same evaluation order as the forward
         const float Gv = gs_exp2(-q);
         const bool live = T > GS_T_STOP;
         const float alpha = live ? Gv * opa : 0.f;
@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, Raste
         Syy += s * dyy;
         Su += s * u;
         // outgoing state
-        oT = T * one_m;
+        oT = fmaf(-alpha, T, T);  // identical to the forward's update
         oR0 = R0;
         oR1 = R1;
         oR2 = R2;

@@ -37,13 +37,13 @@ struct FwdSmem<27> {
     int done[2][4];
 };
 
-template <int CDIM, bool FRAME, bool CKPT, bool SIG>
+template <int CDIM, bool FRAME, bool CKPT, bool SIG, bool WN>
 __global__ void __launch_bounds__(256) raster_forward_kernel(RasterSrc S, RasterGeom G,
                                                             const int32_t *__restrict__ ranges,
                                                             float *__restrict__ out_padded,
                                                             float *__restrict__ out_image,
                                                             float4 *__restrict__ ckpt,
-                                                            uint32_t *__restrict__ tile_nproc, int weight_normalize) {
+                                                            uint32_t *__restrict__ tile_nproc) {
     using SM = FwdSmem<CDIM>;
     constexpr int CH = SM::CH;
     __shared__ SM sm;
@@ -100,6 +100,16 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(RasterSrc S, Raster
 #pragma unroll
                 for (int q = 0; q < 27; ++q) sm.sh[buf][p][q] = src[q];
             }
+        } else if ((uint32_t)p < (uint32_t)CH && base + p < ((n + 3u) & ~3u)) {
+            // pad the ragged tail to a multiple of 4 with null Gaussians (opacity 0 => alpha 0)
+            sm.a[buf][p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            sm.b[buf][p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (CDIM == 3) {
+                sm.c[buf][p] = 0.f;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 27; ++q) sm.sh[buf][p][q] = 0.f;
+            }
         }
         if (lane == 0) sm.done[buf][wave] = wave_done ? 1 : 0;
         __syncthreads();
@@ -110,46 +120,52 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(RasterSrc S, Raster
             if (CKPT) write_ckpt(base + sub);
             if (wave_done) continue;
             const uint32_t lim = (sub + GS_BUCKET) < cnt ? (sub + GS_BUCKET) : cnt;
-#pragma unroll 4
-            for (uint32_t i = sub; i < lim; ++i) {
-                const bool live = T > GS_T_STOP;
-                if (__ballot(live) == 0ull) {
+            // groups of 4 Gaussians: one wave-uniform liveness test per group, per-pixel masking
+            // inside (exactly the reference's per-pixel `accum < 0.0001` test, gaussian.cu:906)
+            for (uint32_t i = sub; i < lim; i += 4) {
+                if (__ballot(T > GS_T_STOP) == 0ull) {
                     wave_done = true;
                     break;
                 }
-                const float4 ga = sm.a[buf][i], gb = sm.b[buf][i];
-                const float dx = px - ga.x, dy = py - ga.y;
-                const float pw = -(ga.z * dx * dx - ga.w * dx * dy + gb.x * dy * dy);
-                float alpha = gs_exp2(pw) * gb.y;
-                if (SIG) alpha = 2.0f / (__expf(-alpha) + 1.0f) - 1.0f;  // gaussian.cu:930
-                alpha = live ? alpha : 0.0f;
-                const float wgt = alpha * T;
-                if constexpr (CDIM == 3) {
-                    cr += gb.z * wgt;
-                    cg += gb.w * wgt;
-                    cb += sm.c[buf][i] * wgt;
-                } else {
-                    const float *co = sm.sh[buf][i];
-                    float v0 = 0.f, v1 = 0.f, v2 = 0.f;
 #pragma unroll
-                    for (int q = 0; q < 9; ++q) {
-                        v0 += SH[q] * co[q];
-                        v1 += SH[q] * co[9 + q];
-                        v2 += SH[q] * co[18 + q];
+                for (int u = 0; u < 4; ++u) {
+                    const float4 ga = sm.a[buf][i + u], gb = sm.b[buf][i + u];
+                    const float dx = px - ga.x, dy = py - ga.y;
+                    float t = ga.z * dx;
+                    t = fmaf(-ga.w, dy, t);  // A dx - B dy
+                    float q = dx * t;
+                    q = fmaf(gb.x * dy, dy, q);  // + C dy^2
+                    float alpha = gs_exp2(-q) * gb.y;
+                    if (SIG) alpha = 2.0f / (__expf(-alpha) + 1.0f) - 1.0f;  // gaussian.cu:930
+                    alpha = (T > GS_T_STOP) ? alpha : 0.0f;
+                    const float wgt = alpha * T;
+                    if constexpr (CDIM == 3) {
+                        cr = fmaf(gb.z, wgt, cr);
+                        cg = fmaf(gb.w, wgt, cg);
+                        cb = fmaf(sm.c[buf][i + u], wgt, cb);
+                    } else {
+                        const float *co = sm.sh[buf][i + u];
+                        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+#pragma unroll
+                        for (int k9 = 0; k9 < 9; ++k9) {
+                            v0 = fmaf(SH[k9], co[k9], v0);
+                            v1 = fmaf(SH[k9], co[9 + k9], v1);
+                            v2 = fmaf(SH[k9], co[18 + k9], v2);
+                        }
+                        cr = fmaf(wgt, gs_rcp(1.0f + __expf(-v0)), cr);
+                        cg = fmaf(wgt, gs_rcp(1.0f + __expf(-v1)), cg);
+                        cb = fmaf(wgt, gs_rcp(1.0f + __expf(-v2)), cb);
                     }
-                    cr += wgt * gs_rcp(1.0f + __expf(-v0));
-                    cg += wgt * gs_rcp(1.0f + __expf(-v1));
-                    cb += wgt * gs_rcp(1.0f + __expf(-v2));
+                    if (WN) accw += wgt;
+                    T = fmaf(-alpha, T, T);  // T * (1 - alpha)
                 }
-                accw += wgt;
-                T *= (1.0f - alpha);
             }
         }
         nproc = base + cnt;
     }
     if (tile_nproc && p == 0) tile_nproc[tile] = nproc;
 
-    if (accw < 0.01f || !weight_normalize) accw = 1.0f;  // gaussian.cu:964-969
+    if (!WN || accw < 0.01f) accw = 1.0f;  // gaussian.cu:964-969
     const float o0 = cr / accw, o1 = cg / accw, o2 = cb / accw;
     if (out_padded) {
         float *o = out_padded + ((size_t)id_y * G.padW + id_x) * 3;
@@ -171,8 +187,12 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(RasterSrc S, Raster
 template <int CDIM, bool FRAME, bool CKPT, bool SIG>
 void launch_fwd(const RasterSrc &S, const RasterGeom &G, const int32_t *ranges, float *out_padded, float *out_image,
                 float4 *ckpt, uint32_t *tile_nproc, int wn, hipStream_t stream) {
-    hipLaunchKernelGGL((raster_forward_kernel<CDIM, FRAME, CKPT, SIG>), dim3(G.ntx * G.nty), dim3(256), 0, stream, S,
-                       G, ranges, out_padded, out_image, ckpt, tile_nproc, wn);
+    if (wn)
+        hipLaunchKernelGGL((raster_forward_kernel<CDIM, FRAME, CKPT, SIG, true>), dim3(G.ntx * G.nty), dim3(256), 0,
+                           stream, S, G, ranges, out_padded, out_image, ckpt, tile_nproc);
+    else
+        hipLaunchKernelGGL((raster_forward_kernel<CDIM, FRAME, CKPT, SIG, false>), dim3(G.ntx * G.nty), dim3(256), 0,
+                           stream, S, G, ranges, out_padded, out_image, ckpt, tile_nproc);
 }
 
 }  // namespace

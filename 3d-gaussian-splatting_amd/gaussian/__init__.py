@@ -140,7 +140,7 @@ def draw(gaussian_pos, gaussian_rgb, gaussian_opa, gaussian_cov, tile_n_point_ac
     h, w = int(res.shape[0]), int(res.shape[1])
     M = int(gaussian_pos.shape[0])
     D = 27 if use_sh_coeff else 3
-    if gaussian_rgb.shape[0] != M or gaussian_rgb.reshape(M, -1).shape[1] != D:
+    if gaussian_rgb.shape[0] != M or gaussian_rgb.numel() != M * D:
         raise RuntimeError(f"gaussian_rgb must be [M,{D}]")
     if tile_n_point_accum.shape[0] != (h // 16) * (w // 16) + 1:
         raise RuntimeError("tile_n_point_accum must have n_tiles + 1 entries")

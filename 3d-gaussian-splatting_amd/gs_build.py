@@ -21,8 +21,9 @@ SOURCES = {
     "cull_project.hip": ["-ffp-contract=off"],
     "binning.hip": ["-ffp-contract=off"],
     "radix_sort.hip": [],
-    "raster_fwd.hip": [],
-    "raster_bwd.hip": [],
+    # no SLP packing: v_pk_*_f32 has no rate advantage on gfx950 and costs extra v_mov shuffles
+    "raster_fwd.hip": ["-fno-slp-vectorize"],
+    "raster_bwd.hip": ["-fno-slp-vectorize"],
     "gs_frame.hip": [],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall",

@@ -143,7 +143,7 @@ def test_calc_tile_list_and_gather(gpu, method):
     assert cnt_np.sum() > 0
     lst = tile_list.cpu().numpy()
     for t in range(T):
-        if n_ref[t] <= maxp:  # below the cap the SET of Gaussians is defined (order is atomic order)
+        if n_ref[t] < maxp:  # strictly below the cap the SET of Gaussians is defined (order is atomic order)
             assert np.array_equal(np.sort(lst[t, :cnt_np[t]]), np.sort(list_ref[t, :n_ref[t]])), t
     accum = torch.cat([torch.zeros(1, dtype=torch.int32, device=gpu), torch.cumsum(cnt, 0).to(torch.int32)])
     M = int(accum[-1])
