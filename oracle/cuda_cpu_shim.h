@@ -44,7 +44,7 @@ static uint3 threadIdx, blockIdx;
 static dim3 blockDim, gridDim;
 
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
-static inline float __expf(float x) { return expf(x); }
+#define __expf(x) expf(x) /* fast-math intrinsic -> libm (glibc reserves the name __expf) */
 static inline int atomicAdd(int *p, int v) {
     int o = *p;
     *p = o + v;

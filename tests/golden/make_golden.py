@@ -1,0 +1,158 @@
+"""Generate tests/golden/*.npz from the REFERENCE itself (run in the build container only).
+
+    python tests/golden/make_golden.py
+
+Two sources, both the reference's own code executed here:
+  A. its CUDA kernels (src/gaussian.cu) compiled for the CPU by oracle/build_ref.py and run on
+     the SIMT emulator (oracle/ref.py)            -> kernels_*.npz
+  B. its Python host code (splatter.Tiles, splatter.RayInfo, utils.q2r, utils.jacobian_torch,
+     Gaussian3ds.get_gaussian_3d_cov, camera_to_image) imported from /root/reference with the
+     missing third-party modules (kornia, cv2, pykdtree, the compiled `gaussian` extension)
+     stubbed out -- none of them is touched by the functions used  -> host_geometry.npz
+
+The fixtures are small (tens of KB) and committed; the tests that read them run anywhere.
+Inputs are stored next to the outputs so that no generator state is needed to replay them.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "3d-gaussian-splatting_amd"), os.path.join(ROOT, "tests")]
+
+import oracle  # noqa: E402
+from gs_scene import make_camera, make_scene  # noqa: E402
+from gs_testutil import OracleFrame, activate, frame_scalars  # noqa: E402
+from oracle import build_ref, ref  # noqa: E402
+
+
+def kernels_case(name, n, W, H, seed, use_sh, opa_shift, with_backward):
+    scene = make_scene(n, W, H, seed=seed, use_sh=use_sh)
+    scene.opa = (scene.opa + opa_shift).astype(np.float32)
+    cam = make_camera(W, H, yaw_deg=2.0)
+    cam.tran = np.array([0.04, -0.03, 0.15], np.float32)
+    qn, sn = activate(scene)
+    grid, hw, hh, rays = frame_scalars(cam)
+    out = dict(pos=scene.pos, quat=qn, scale=sn, rot=cam.rot, tran=cam.tran, near=np.float32(cam.near),
+               half_w=np.float32(hw), half_h=np.float32(hh), W=W, H=H, fx=np.float32(cam.focal_x),
+               fy=np.float32(cam.focal_y), use_sh=use_sh)
+    # K1 / K2
+    rp, rc, mk = ref.global_culling(scene.pos, qn, sn, cam.rot, cam.tran, cam.near, hw, hh)
+    rng = np.random.default_rng(seed + 100)
+    gop = rng.normal(size=(n, 3)).astype(np.float32)
+    goc = rng.normal(size=(n, 2, 2)).astype(np.float32)
+    gp, gq, gs = ref.global_culling_backward(scene.pos, qn, sn, cam.rot, cam.tran, gop, goc, mk)
+    out.update(k1_pos=rp, k1_cov=rc, k1_mask=mk, k2_gop=gop, k2_goc=goc, k2_gpos=gp, k2_gquat=gq, k2_gscale=gs)
+    # K3 (three methods) / K6 on the culled set (splatter.py:536-541)
+    keep = mk.astype(bool)
+    pos_i, cov = rp[keep], rc[keep].reshape(-1, 4)
+    maxp = max(len(pos_i) // 20, 8)  # splatter.py:569
+    top, bottom, left, right = grid.tile_edges()
+    geom = (grid.tile_geo_length_x, grid.tile_geo_length_y, grid.n_tile_x, grid.n_tile_y, grid.leftmost, grid.topmost)
+    out.update(k3_maxp=maxp, k3_geom=np.array(geom, np.float64), tiles_top=top, tiles_bottom=bottom, tiles_left=left,
+               tiles_right=right)
+    for method in (0, 1, 2):
+        thresh = 0.05 if method else (grid.tile_geo_length_x / 0.3) ** 2
+        cnt, lst = ref.calc_tile_list(pos_i, cov, maxp, thresh, method, *geom, top, bottom, left, right)
+        out[f"k3_m{method}_thresh"] = np.float32(thresh)
+        out[f"k3_m{method}_count"] = cnt
+        out[f"k3_m{method}_list"] = lst
+        if method == 2:
+            cntc = np.minimum(cnt, maxp)
+            accum = np.concatenate([[0], np.cumsum(cntc)]).astype(np.int32)
+            g, t = ref.gather_gaussians(accum, lst, int(cntc.max()))
+            out.update(k6_accum=accum, k6_gathered=g, k6_tile_ids=t)
+    # K7 / K8 on the canonically sorted pair list
+    of = OracleFrame(scene, cam)
+    kw = dict(use_sh=use_sh, fast=True, rays_o=rays.rays_o, lefttop=rays.lefttop, vdx=rays.dx, vdy=rays.dy)
+    img = ref.draw(of.s_pos, of.s_rgb, of.s_opa, of.s_cov, of.accum, grid.padded_height, grid.padded_width,
+                   grid.focal_x, grid.focal_y, **kw)
+    out.update(k7_pos=of.s_pos, k7_rgb=of.s_rgb, k7_opa=of.s_opa, k7_cov=of.s_cov, k7_accum=of.accum, k7_image=img,
+               rays_o=rays.rays_o, lefttop=rays.lefttop, vdx=rays.dx, vdy=rays.dy,
+               max_per_tile=int(np.diff(of.accum).max()))
+    if with_backward:
+        gpad = rng.normal(size=img.shape).astype(np.float32)
+        ref.reset_counters()
+        g = ref.draw_backward(of.s_pos, of.s_rgb, of.s_opa, of.s_cov, of.accum, img, gpad, grid.focal_x, grid.focal_y,
+                              **kw)
+        out.update(k8_grad_output=gpad, k8_gpos=g[0], k8_grgb=g[1], k8_gopa=g[2], k8_gcov=g[3],
+                   k8_undefined_reads=ref.undefined_reads())
+    assert out["max_per_tile"] <= (340 if use_sh else 1200), "stay inside one forward chunk (see below)"
+    np.savez_compressed(os.path.join(HERE, f"kernels_{name}.npz"), **out)
+    print(name, "V", int(keep.sum()), "M", len(of.ids), "max/tile", out["max_per_tile"],
+          "undefined shuffles", out.get("k8_undefined_reads"))
+
+
+def host_geometry():
+    """Reference Python host code with unavailable imports stubbed."""
+    import torch
+
+    class _Anything(types.ModuleType):
+        def __getattr__(self, k):
+            return type(k, (), {})
+
+    for m in ("kornia", "cv2", "pykdtree", "pykdtree.kdtree", "gaussian"):
+        sys.modules[m] = _Anything(m)
+    sys.modules["kornia"].create_meshgrid = lambda *a, **k: None
+    sys.modules["pykdtree.kdtree"].KDTree = object
+    sys.path.insert(0, "/root/reference")
+    for m in ("utils", "renderer", "splatter", "transforms"):
+        sys.modules.pop(m, None)
+    import splatter as ref_splatter  # the reference's splatter.py
+    import utils as ref_utils  # the reference's utils.py
+
+    out = {}
+    cfgs = [(1920, 1080, 1440.0, 1440.0), (1297, 840, 961.3, 958.7), (256, 256, 192.0, 192.0), (333, 201, 250.5, 249.25)]
+    for i, (W, H, fx, fy) in enumerate(cfgs):
+        t = ref_splatter.Tiles(W, H, fx, fy, torch.device("cpu"))
+        t.create_tiles()
+        crop = t.crop(torch.arange(t.padded_height * t.padded_width * 3, dtype=torch.float32).reshape(
+            t.padded_height, t.padded_width, 3))
+        out[f"tiles{i}_cfg"] = np.array([W, H, fx, fy], np.float64)
+        out[f"tiles{i}_scalars"] = np.array([t.padded_width, t.padded_height, t.n_tile_x, t.n_tile_y,
+                                             t.tile_geo_length_x, t.tile_geo_length_y, t.leftmost, t.topmost],
+                                            np.float64)
+        out[f"tiles{i}_edges"] = np.stack([t.tiles_top.numpy(), t.tiles_bottom.numpy(), t.tiles_left.numpy(),
+                                           t.tiles_right.numpy()])
+        out[f"tiles{i}_crop_first"] = crop[0, 0].numpy()
+        out[f"tiles{i}_crop_shape"] = np.array(crop.shape)
+    rng = np.random.default_rng(77)
+    q = rng.normal(size=(1, 4))
+    rot = ref_utils.q2r(torch.from_numpy(q).float())[0]
+    tran = torch.from_numpy(rng.normal(size=3)).float()
+    ri = ref_splatter.RayInfo(rot, tran, 1088, 1920, 1440.0, 1437.5)
+    out.update(ray_rot=rot.numpy(), ray_tran=tran.numpy(), ray_cfg=np.array([1088, 1920, 1440.0, 1437.5]),
+               ray_o=ri.rays_o.numpy(), ray_lefttop=ri.lefttop.numpy(), ray_dx=ri.dx.numpy(), ray_dy=ri.dy.numpy())
+    # projection through the reference's torch path (splatter.py:231-253 assembled from its own functions)
+    n = 500
+    pos = torch.from_numpy(rng.normal(size=(n, 3)) * [2, 2, 1] + [0, 0, 5]).float()
+    quat = torch.from_numpy(rng.normal(size=(n, 4))).float()
+    scale = torch.from_numpy(rng.normal(size=(n, 3)) * 0.05).float()
+    g3 = ref_splatter.Gaussian3ds(pos=pos, rgb=torch.zeros(n, 3), opa=torch.zeros(n), quat=quat, scale=scale)
+    cov3d = g3.get_gaussian_3d_cov(scale_activation="abs")
+    pos_cam = pos @ rot.T + tran.unsqueeze(0)  # splatter.py:26 (the reference's torch world_to_camera)
+    pos_img = ref_splatter.camera_to_image(pos_cam)
+    J = ref_utils.jacobian_torch(pos_cam)
+    JW = torch.matmul(J, rot.unsqueeze(0))
+    cov2d = torch.bmm(torch.bmm(JW, cov3d), JW.permute(0, 2, 1))[:, :2, :2]
+    out.update(proj_pos=pos.numpy(), proj_quat=quat.numpy(), proj_scale=scale.numpy(), proj_rot=rot.numpy(),
+               proj_tran=tran.numpy(), proj_pos_cam=pos_cam.numpy(), proj_pos_img=pos_img.numpy(),
+               proj_cov2d=cov2d.numpy(), proj_R=ref_utils.q2r(quat).numpy(), proj_J=J.numpy())
+    np.savez_compressed(os.path.join(HERE, "host_geometry.npz"), **out)
+    print("host_geometry ok")
+
+
+if __name__ == "__main__":
+    assert os.path.isdir("/root/reference"), "needs the reference checkout"
+    oracle.build()
+    build_ref.build()
+    kernels_case("nosh", 700, 64, 48, seed=21, use_sh=False, opa_shift=-3.0, with_backward=True)
+    kernels_case("sh", 330, 48, 32, seed=6, use_sh=True, opa_shift=-3.0, with_backward=True)
+    # <= 1200 Gaussians per tile: beyond one shared-memory chunk the reference forward kernel has a
+    # race (no barrier after its compute loop, gaussian.cu:878-962) that the emulator's serial
+    # schedule exposes deterministically (measured: 5 tiles of 1450 -> max image error 0.47).
+    kernels_case("dense_fwd", 4500, 64, 48, seed=22, use_sh=False, opa_shift=1.5, with_backward=False)
+    host_geometry()

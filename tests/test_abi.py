@@ -1,0 +1,100 @@
+"""CPU tier: libgs_amd.so loads and exports every symbol include/gs_abi.h declares; the
+host-only entry points (size queries, argument validation) behave without a GPU.  No kernel is
+launched here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "gs_abi.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_functions_are_all_exported():
+    from gaussian import _lib
+
+    names = declared_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(_lib.lib, n), f"{n} declared in gs_abi.h but not exported by libgs_amd.so"
+    assert sorted(_lib.EXPORTS) == names, "gaussian/_lib.py EXPORTS out of sync with gs_abi.h"
+
+
+def test_version_and_error_string():
+    from gaussian import _lib
+
+    assert _lib.gs_abi_version() == 1
+    assert _lib.gs_culling() == 0
+    assert isinstance(_lib.gs_last_error(), bytes)
+
+
+def test_size_queries_are_host_only_and_monotone():
+    from gaussian import _lib
+
+    a = _lib.gs_frame_workspace_bytes(100_000, 500_000, 1920, 1080, 3, 0)
+    b = _lib.gs_frame_workspace_bytes(100_000, 500_000, 1920, 1080, 3, 1)
+    c = _lib.gs_frame_workspace_bytes(200_000, 1_000_000, 1920, 1080, 3, 1)
+    assert 0 < a < b < c
+    # keys (8 B) + ids (4 B), double-buffered, dominate the inference workspace
+    assert a >= 500_000 * 24
+    assert _lib.gs_sort_pairs_tmp_bytes(1 << 20) >= 256 * 4 * ((1 << 20) // 2048)
+    assert _lib.gs_draw_backward_workspace_bytes(0, 16, 16) > 0
+    assert _lib.gs_frame_workspace_bytes(-1, 10, 16, 16, 3, 0) == 0
+
+
+def test_argument_validation_returns_error_codes_without_touching_the_gpu():
+    from gaussian import _lib
+
+    GS_E_INVALID = -1
+    assert _lib.gs_world2camera(None, None, None, None, -5, None) == GS_E_INVALID
+    assert b"B < 0" in _lib.gs_last_error()
+    assert _lib.gs_world2camera(None, None, None, None, 7, None) == GS_E_INVALID  # null pointers
+    assert _lib.gs_draw(None, None, None, None, None, None, 17, 32, 0, 1.0, 1.0, 0, 0, 1, None, None, None, None, 0,
+                        None) == GS_E_INVALID  # h not a multiple of 16
+    assert _lib.gs_calc_tile_list(None, None, 5, None, None, None, None, None, None, 4, 0.05, 7, 1.0, 1.0, 2, 2, 0.0,
+                                  0.0, None) == GS_E_INVALID  # unknown method
+    in1 = C.c_int(-1)
+    assert _lib.gs_sort_pairs(None, None, None, None, None, 0, 45, None, 0, C.byref(in1), None) == 0  # empty sort
+    assert in1.value == 0  # 6 passes -> result back in buffer 0
+    f = _lib.GsFrame()
+    assert _lib.gs_frame_forward(C.byref(f), None) == GS_E_INVALID
+    with pytest.raises(RuntimeError):
+        _lib.check(GS_E_INVALID, "demo")
+
+
+def test_gaussian_module_surface_matches_the_reference_bindings():
+    """bindings.cpp:21-50: 10 functions + 2 default-constructible attribute bags."""
+    import gaussian
+
+    for name in ("culling", "world2camera", "world2camera_backward", "jacobian", "calc_tile_list",
+                 "gather_gaussians", "draw", "draw_backward", "global_culling", "global_culling_backward"):
+        assert callable(getattr(gaussian, name)), name
+    t, g = gaussian.Tiles(), gaussian.Gaussian3ds()
+    for a in ("top", "bottom", "left", "right"):
+        setattr(t, a, 1)
+    for a in ("pos", "rgb", "opa", "quat", "scale", "cov"):
+        setattr(g, a, 1)
+    import renderer
+
+    for name in ("draw", "global_culling", "world2camera_func", "trunc_exp"):
+        assert callable(getattr(renderer, name)), name
+
+
+def test_cpu_tensors_are_rejected_not_silently_processed():
+    import torch
+
+    import gaussian
+
+    with pytest.raises(RuntimeError):
+        gaussian.world2camera(torch.zeros(4, 3), torch.eye(3), torch.zeros(3), torch.zeros(4, 3))
+    from gs_frame import FrameRenderer
+
+    with pytest.raises(RuntimeError):
+        FrameRenderer("cpu")

@@ -1,0 +1,54 @@
+"""CPU tier (optional): live comparison of the oracle with the reference's own kernels on the
+SIMT emulator, on fresh seeds.  Needs oracle/_ref/libgs_ref.so, which only the build container
+can produce (oracle/build_ref.py reads /root/reference); it travels to the GPU box as a built
+artefact.  Skipped when absent."""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import ref
+from gs_scene import make_camera, make_scene
+from gs_testutil import OracleFrame, activate, frame_scalars, rel_err
+
+pytestmark = pytest.mark.skipif(not ref.available(), reason="oracle/_ref/libgs_ref.so not built")
+
+
+@pytest.mark.parametrize("seed", [31, 32])
+def test_oracle_vs_reference_kernels_fresh_seed(seed):
+    scene = make_scene(1500, 80, 64, seed=seed)
+    cam = make_camera(80, 64, yaw_deg=1.5 * (seed - 30))
+    qn, sn = activate(scene)
+    grid, hw, hh, _ = frame_scalars(cam)
+    a = oracle.global_culling(scene.pos, qn, sn, cam.rot, cam.tran, cam.near, hw, hh)
+    b = ref.global_culling(scene.pos, qn, sn, cam.rot, cam.tran, cam.near, hw, hh)
+    assert np.array_equal(a[2], b[2])
+    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+    assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    of = OracleFrame(scene, cam)
+    assert np.diff(of.accum).max() <= 1200
+    img = ref.draw(of.s_pos, of.s_rgb, of.s_opa, of.s_cov, of.accum, grid.padded_height, grid.padded_width,
+                   grid.focal_x, grid.focal_y, fast=True)
+    assert np.array_equal(img.view(np.uint32), of.padded.view(np.uint32))
+
+
+def test_reference_backward_defect_between_chunks_is_real():
+    """SURVEY.md section 0 item 1, measured: with more Gaussians in a tile than the backward
+    kernel's shared-memory chunk (160 with SH), the reference's gradient slots are not re-zeroed
+    between chunks (gaussian.cu:508-522 vs :550-802) and its gradients are wrong, while inside
+    one chunk it agrees with the oracle to 1e-6.  The new implementation follows the oracle."""
+    res = {}
+    for n in (330, 420):
+        scene = make_scene(n, 48, 32, seed=6, use_sh=True)
+        scene.opa -= 3.0
+        cam = make_camera(48, 32, yaw_deg=2.0)
+        of = OracleFrame(scene, cam)
+        r = of.rays
+        kw = dict(use_sh=True, fast=True, rays_o=r.rays_o, lefttop=r.lefttop, vdx=r.dx, vdy=r.dy)
+        g = np.random.default_rng(1).normal(size=of.padded.shape).astype(np.float32)
+        a = oracle.draw_backward(of.s_pos, of.s_rgb, of.s_opa, of.s_cov, of.accum, of.padded, g, of.grid.focal_x,
+                                 of.grid.focal_y, **kw)
+        b = ref.draw_backward(of.s_pos, of.s_rgb, of.s_opa, of.s_cov, of.accum, of.padded, g, of.grid.focal_x,
+                              of.grid.focal_y, **kw)
+        res[n] = (int(np.diff(of.accum).max()), max(rel_err(x, y) for x, y in zip(a, b)))
+    assert res[330][0] <= 160 and res[330][1] < 2e-6
+    assert res[420][0] > 160 and res[420][1] > 1e-2
