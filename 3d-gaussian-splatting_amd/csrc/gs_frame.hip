@@ -38,11 +38,12 @@ static int validate(const gs_frame *f) {
     GS_CHECK_ARG(f->scale_activation == 0 || f->scale_activation == 1, "scale_activation must be 0 (abs) or 1 (exp)");
     GS_CHECK_ARG(f->width > 0 && f->height > 0, "empty image");
     GS_CHECK_ARG(f->width <= 65535 * 16 && f->height <= 65535 * 16, "image too large");
-    GS_CHECK_ARG(f->max_pairs > 0 && f->max_pairs < (1ll << 32), "max_pairs out of range");
+    GS_CHECK_ARG(f->max_pairs > 0 && f->max_pairs < (1ll << 30), "max_pairs out of range");
     GS_CHECK_ARG(f->N == 0 || (f->pos && f->quat && f->scale && f->opa && f->rgb), "null scene pointer");
     GS_CHECK_ARG(((uintptr_t)f->quat & 15) == 0, "quat must be 16-byte aligned");
     GS_CHECK_ARG(f->workspace != nullptr && ((uintptr_t)f->workspace & 255) == 0, "workspace null or not 256-byte aligned");
     GS_CHECK_ARG(f->thresh > 0.f && f->thresh < 1.f, "thresh must be in (0,1)");
+    GS_CHECK_ARG(f->sort_mode == 0 || f->sort_mode == 1, "sort_mode must be 0 (full LSD radix) or 1 (tile-bit radix + per-tile LDS sort)");
     const size_t need = gs_frame_workspace_bytes(f->N, f->max_pairs, f->width, f->height, f->color_dim, f->training);
     if (f->workspace_bytes < need) {
         gs_set_error("gs_frame: workspace too small (%zu < %zu bytes)", f->workspace_bytes, need);
@@ -57,11 +58,18 @@ extern "C" size_t gs_frame_workspace_bytes(int64_t N, int64_t max_pairs, int32_t
     return gs_frame_carve(nullptr, N, max_pairs, width, height, color_dim, training).total_bytes;
 }
 
-static void sorted_buffers(const gs_frame *f, const gs_frame_ws &ws, const uint64_t **keys, const uint32_t **ids) {
+// Which double-buffer half holds the sorted (keys, ids) after the radix passes of this mode.
+static int sort_passes(const gs_frame *f) {
     gs_frame_geom G = gs_frame_geometry(f);
-    const int npass = (32 + tile_bits(G.n_tiles) + 7) / 8;
-    *keys = (npass & 1) ? ws.keys_b : ws.keys_a;
-    *ids = (npass & 1) ? ws.vals_b : ws.vals_a;
+    const int tb = tile_bits(G.n_tiles);
+    return f->sort_mode == 1 ? (tb + 7) / 8 : (32 + tb + 7) / 8;
+}
+static void sorted_buffers(const gs_frame *f, const gs_frame_ws &ws, uint64_t **keys, uint32_t **ids,
+                           uint64_t **other_keys) {
+    const bool in_b = sort_passes(f) & 1;
+    *keys = in_b ? ws.keys_b : ws.keys_a;
+    *ids = in_b ? ws.vals_b : ws.vals_a;
+    *other_keys = in_b ? ws.keys_a : ws.keys_b;
 }
 
 struct StageTimer {
@@ -99,23 +107,28 @@ static int frame_forward_impl(const gs_frame *f, hipStream_t s, float *stage_ms)
     gs_frame_geom G = gs_frame_geometry(f);
     StageTimer tm(stage_ms != nullptr, s);
     tm.mark();
-    GS_HIP(hipMemsetAsync(ws.counters, 0, sizeof(unsigned long long) * GS_CNT_N, s));
+    GS_HIP(hipMemsetAsync(ws.counters, 0, ws.zero_bytes, s));
     if (f->N > 0 && (rc = gs_stage_project(f, ws, s))) return rc;
     tm.mark();
+    uint64_t *skeys, *okeys;
+    uint32_t *sids;
+    sorted_buffers(f, ws, &skeys, &sids, &okeys);
     if (f->N > 0 && (rc = gs_stage_scan_emit(f, ws, s))) return rc;
     tm.mark();
     if (f->N > 0) {
+        // mode 0: all 32 + tile_bits key bits; mode 1: the tile bits only (stable => grouped by tile,
+        // Gaussian-index order inside a tile), the depth order is finished per tile in LDS below
         int in1 = 0;
-        rc = gs_sort_pairs(ws.keys_a, ws.vals_a, ws.keys_b, ws.vals_b, (const uint32_t *)(ws.counters + GS_CNT_PAIRS),
-                           f->max_pairs, 32 + tile_bits(G.n_tiles), ws.sort_tmp, ws.sort_tmp_bytes, &in1, s);
+        const int tb = tile_bits(G.n_tiles);
+        rc = gs_sort_pairs_bits(ws.keys_a, ws.vals_a, ws.keys_b, ws.vals_b,
+                                (const uint32_t *)(ws.counters + GS_CNT_PAIRS), f->max_pairs,
+                                f->sort_mode == 1 ? 32 : 0, 32 + tb, ws.sort_tmp, ws.sort_tmp_bytes, &in1, s);
         if (rc) return rc;
     }
     tm.mark();
-    const uint64_t *skeys;
-    const uint32_t *sids;
-    sorted_buffers(f, ws, &skeys, &sids);
     if ((rc = gs_stage_tile_ranges(f, ws, skeys, s))) return rc;
-    tm.mark();
+    if (f->sort_mode == 1 && f->N > 0 && (rc = gs_stage_tile_sort(f, ws, skeys, sids, okeys, s))) return rc;
+    tm.mark();  // stage "ranges" = tile ranges (+ the per-tile depth sort in mode 1)
     if ((rc = gs_stage_raster_forward(f, ws, sids, s))) return rc;
     tm.mark();
     return tm.finish(stage_ms, GS_N_STAGES);
@@ -139,9 +152,9 @@ static int frame_backward_impl(const gs_frame *f, const float *grad_image, float
     GS_CHECK_ARG(((uintptr_t)grad_quat & 15) == 0, "grad_quat must be 16-byte aligned");
     if (f->N == 0) return 0;
     gs_frame_ws ws = gs_frame_carve(f->workspace, f->N, f->max_pairs, f->width, f->height, f->color_dim, 1);
-    const uint64_t *skeys;
-    const uint32_t *sids;
-    sorted_buffers(f, ws, &skeys, &sids);
+    uint64_t *skeys, *okeys;
+    uint32_t *sids;
+    sorted_buffers(f, ws, &skeys, &sids, &okeys);
     StageTimer tm(stage_ms != nullptr, s);
     tm.mark();
     if ((rc = gs_stage_raster_backward(f, ws, sids, grad_image, grad_rgb, s))) return rc;
@@ -180,9 +193,9 @@ extern "C" int gs_frame_debug_views(const gs_frame *f, const uint64_t **sorted_k
     int rc = validate(f);
     if (rc) return rc;
     gs_frame_ws ws = gs_frame_carve(f->workspace, f->N, f->max_pairs, f->width, f->height, f->color_dim, f->training);
-    const uint64_t *skeys;
-    const uint32_t *sids;
-    sorted_buffers(f, ws, &skeys, &sids);
+    uint64_t *skeys, *okeys;
+    uint32_t *sids;
+    sorted_buffers(f, ws, &skeys, &sids, &okeys);
     if (sorted_keys) *sorted_keys = skeys;
     if (sorted_ids) *sorted_ids = sids;
     if (tile_ranges) *tile_ranges = ws.tile_ranges;

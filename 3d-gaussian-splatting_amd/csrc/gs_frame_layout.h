@@ -54,6 +54,7 @@ struct gs_frame_ws {
     float4 *ckpt;                  // [max_buckets][256] (T, Cr, Cg, Cb) at bucket starts
     float *dgeom;                  // [N][12]
     int64_t max_buckets;
+    size_t zero_bytes;             // prefix of the workspace cleared at the start of every frame
     size_t total_bytes;
 };
 
@@ -74,6 +75,7 @@ static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pair
     };
     const int64_t nblk = gs_div_up(N > 0 ? N : 1, 256);
     ws.counters = (unsigned long long *)take(sizeof(unsigned long long) * GS_CNT_N);
+    ws.zero_bytes = off;
     ws.rec_geom = (float4 *)take(sizeof(float4) * N);
     ws.rec_cov = (float4 *)take(sizeof(float4) * N);
     ws.rec_color = (float4 *)take(color_dim == 3 ? sizeof(float4) * N : 0);
@@ -109,6 +111,8 @@ int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t strea
 int gs_stage_project_backward(const gs_frame *f, const gs_frame_ws &ws, float *grad_pos, float *grad_quat,
                               float *grad_scale, float *grad_opa, float *grad_rgb, hipStream_t stream);
 int gs_stage_scan_emit(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream);
+int gs_stage_tile_sort(const gs_frame *f, const gs_frame_ws &ws, uint64_t *keys, uint32_t *ids, uint64_t *scratch,
+                       hipStream_t stream);
 int gs_stage_tile_ranges(const gs_frame *f, const gs_frame_ws &ws, const uint64_t *sorted_keys, hipStream_t stream);
 int gs_stage_raster_forward(const gs_frame *f, const gs_frame_ws &ws, const uint32_t *sorted_ids, hipStream_t stream);
 int gs_stage_raster_backward(const gs_frame *f, const gs_frame_ws &ws, const uint32_t *sorted_ids,

@@ -165,9 +165,16 @@ extern "C" size_t gs_sort_pairs_tmp_bytes(int64_t capacity) {
 extern "C" int gs_sort_pairs(uint64_t *keys0, uint32_t *vals0, uint64_t *keys1, uint32_t *vals1,
                              const uint32_t *d_count, int64_t capacity, int end_bit, void *tmp, size_t tmp_bytes,
                              int *sorted_in_buffer1, gs_stream_t stream) {
+    return gs_sort_pairs_bits(keys0, vals0, keys1, vals1, d_count, capacity, 0, end_bit, tmp, tmp_bytes,
+                              sorted_in_buffer1, stream);
+}
+
+extern "C" int gs_sort_pairs_bits(uint64_t *keys0, uint32_t *vals0, uint64_t *keys1, uint32_t *vals1,
+                                  const uint32_t *d_count, int64_t capacity, int begin_bit, int end_bit, void *tmp,
+                                  size_t tmp_bytes, int *sorted_in_buffer1, gs_stream_t stream) {
     GS_CHECK_ARG(capacity >= 0 && capacity < (1ll << 32), "capacity out of range");
-    GS_CHECK_ARG(end_bit >= 0 && end_bit <= 64, "end_bit must be in [0,64]");
-    const int npass = (end_bit + 7) / 8;
+    GS_CHECK_ARG(begin_bit >= 0 && begin_bit <= end_bit && end_bit <= 64, "need 0 <= begin_bit <= end_bit <= 64");
+    const int npass = (end_bit - begin_bit + 7) / 8;
     if (sorted_in_buffer1) *sorted_in_buffer1 = npass & 1;
     if (capacity == 0 || npass == 0) return 0;
     GS_CHECK_ARG(keys0 && vals0 && keys1 && vals1 && d_count && tmp, "null pointer");
@@ -179,7 +186,7 @@ extern "C" int gs_sort_pairs(uint64_t *keys0, uint32_t *vals0, uint64_t *keys1, 
     uint64_t *kin = keys0, *kout = keys1;
     uint32_t *vin = vals0, *vout = vals1;
     for (int p = 0; p < npass; ++p) {
-        const int shift = p * 8;
+        const int shift = begin_bit + p * 8;
         hipLaunchKernelGGL(digit_histogram_kernel, dim3(nwg), dim3(RS_THREADS), 0, s, kin, d_count, capacity, shift,
                            nwg, hist);
         hipLaunchKernelGGL(row_scan_kernel, dim3(RS_BINS), dim3(RS_THREADS), 0, s, hist, digit_total, d_count,

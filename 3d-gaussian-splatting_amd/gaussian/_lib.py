@@ -37,7 +37,7 @@ class GsFrame(C.Structure):
         ("rays_o", f32 * 3), ("lefttop", f32 * 3), ("vec_dx", f32 * 3), ("vec_dy", f32 * 3),
         ("max_pairs", i64), ("workspace", vp), ("workspace_bytes", sz),
         ("image", vp), ("image_padded", vp),
-        ("training", i32), ("reserved", i32),
+        ("training", i32), ("sort_mode", i32),
     ]
 
 
@@ -66,6 +66,7 @@ gs_draw_backward = _sig("gs_draw_backward", ci, vp, vp, vp, vp, vp, vp, vp, vp, 
                         ci, ci, ci, vp, vp, vp, vp, ci, vp, sz, vp)
 gs_sort_pairs_tmp_bytes = _sig("gs_sort_pairs_tmp_bytes", sz, i64)
 gs_sort_pairs = _sig("gs_sort_pairs", ci, vp, vp, vp, vp, vp, i64, ci, vp, sz, C.POINTER(ci), vp)
+gs_sort_pairs_bits = _sig("gs_sort_pairs_bits", ci, vp, vp, vp, vp, vp, i64, ci, ci, vp, sz, C.POINTER(ci), vp)
 gs_frame_workspace_bytes = _sig("gs_frame_workspace_bytes", sz, i64, i64, i32, i32, i32, i32)
 gs_frame_forward = _sig("gs_frame_forward", ci, C.POINTER(GsFrame), vp)
 gs_frame_backward = _sig("gs_frame_backward", ci, C.POINTER(GsFrame), vp, vp, vp, vp, vp, vp, vp)
@@ -81,7 +82,7 @@ EXPORTS = [
     "gs_last_error", "gs_abi_version", "gs_culling", "gs_world2camera", "gs_world2camera_backward",
     "gs_jacobian", "gs_global_culling", "gs_global_culling_backward", "gs_calc_tile_list",
     "gs_gather_gaussians", "gs_draw", "gs_draw_backward_workspace_bytes", "gs_draw_backward",
-    "gs_sort_pairs_tmp_bytes", "gs_sort_pairs", "gs_frame_workspace_bytes", "gs_frame_forward",
+    "gs_sort_pairs_tmp_bytes", "gs_sort_pairs", "gs_sort_pairs_bits", "gs_frame_workspace_bytes", "gs_frame_forward",
     "gs_frame_stats_async", "gs_frame_debug_views", "gs_frame_backward", "gs_frame_forward_profile",
     "gs_frame_backward_profile",
 ]

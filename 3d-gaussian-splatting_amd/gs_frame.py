@@ -38,7 +38,8 @@ class FrameStats:
 
 class FrameRenderer:
     def __init__(self, device="cuda", max_pairs: int = 1 << 20, training: bool = False,
-                 thresh: float = 0.05, scale_activation: str = "abs", auto_grow: bool = True):
+                 thresh: float = 0.05, scale_activation: str = "abs", auto_grow: bool = True,
+                 sort_mode: int = 1):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("FrameRenderer needs a HIP device; there is no CPU fallback")
@@ -47,6 +48,7 @@ class FrameRenderer:
         self.thresh = float(thresh)
         self.scale_activation = SCALE_ACT[scale_activation]
         self.auto_grow = auto_grow
+        self.sort_mode = int(sort_mode)  # 0: LSD radix on 64-bit keys, 1: MSD tile-bucketed (same order)
         self._ws: Optional[torch.Tensor] = None
         self._stats_host = torch.zeros(4, dtype=torch.int64).pin_memory()
         self._frame: Optional[_lib.GsFrame] = None
@@ -85,6 +87,7 @@ class FrameRenderer:
         f.vec_dy = (C.c_float * 3)(*rays.dy)
         f.max_pairs = self.max_pairs
         f.training = int(training)
+        f.sort_mode = self.sort_mode
         need = _lib.gs_frame_workspace_bytes(n, self.max_pairs, grid.width, grid.height, color_dim, int(training))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(int(need) + 256, dtype=torch.uint8, device=self.device)

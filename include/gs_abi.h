@@ -138,6 +138,11 @@ size_t gs_sort_pairs_tmp_bytes(int64_t capacity);
 int gs_sort_pairs(uint64_t *keys0, uint32_t *vals0, uint64_t *keys1, uint32_t *vals1,
                   const uint32_t *d_count, int64_t capacity, int end_bit, void *tmp,
                   size_t tmp_bytes, int *sorted_in_buffer1, gs_stream_t stream);
+/* Same, restricted to key bits [begin_bit, end_bit): a stable partial sort (used by sort_mode 1
+ * to group pairs by tile id only). */
+int gs_sort_pairs_bits(uint64_t *keys0, uint32_t *vals0, uint64_t *keys1, uint32_t *vals1,
+                       const uint32_t *d_count, int64_t capacity, int begin_bit, int end_bit,
+                       void *tmp, size_t tmp_bytes, int *sorted_in_buffer1, gs_stream_t stream);
 
 /* Frame descriptor.  All scalars are per-camera constants computed on the host exactly as
  * splatter.py does (Tiles, RayInfo, frustum guard band); rot/tran are passed by value. */
@@ -169,7 +174,10 @@ typedef struct gs_frame {
     float *image;             /* [height,width,3] clamped + cropped (may be NULL)         */
     float *image_padded;      /* [padH,padW,3] raw draw output (may be NULL if !training) */
     int32_t training;         /* 1: keep per-bucket checkpoints for gs_frame_backward      */
-    int32_t reserved;
+    int32_t sort_mode;        /* how the (tile, depth) order is produced -- same result either way:
+                                 0 = LSD radix sort of 64-bit (tile<<32|depth) keys (gs_sort_pairs)
+                                 1 = hybrid: stable LSD radix passes on the tile bits only (2 passes at
+                                     1080p), then every tile's bucket sorted on (depth, id) in LDS */
 } gs_frame;
 
 /* Bytes of workspace needed for N Gaussians, `max_pairs` pairs, a width x height image. */

@@ -27,9 +27,10 @@ def case(n, W, H, seed=7, use_sh=False, yaw=2.0):
     return scene, cam
 
 
-def check_forward(gpu, scene, cam, training=False):
+def check_forward(gpu, scene, cam, training=False, sort_mode=1):
     of = OracleFrame(scene, cam)
-    r = FrameRenderer(gpu, max_pairs=max(len(of.ids) + 17, 64), training=training, auto_grow=False)
+    r = FrameRenderer(gpu, max_pairs=max(len(of.ids) + 17, 64), training=training, auto_grow=False,
+                      sort_mode=sort_mode)
     params = to_torch(scene, gpu)
     image, padded = r.forward(*params, cam)
     st = r.stats()
@@ -58,20 +59,29 @@ def check_forward(gpu, scene, cam, training=False):
     return of, r, params
 
 
+@pytest.mark.parametrize("sort_mode", [0, 1])
 @pytest.mark.parametrize("n,W,H", [(10_000, 256, 256), (30_000, 333, 201), (2_000, 64, 48)])
-def test_frame_forward_parity(gpu, n, W, H):
-    check_forward(gpu, *case(n, W, H))
+def test_frame_forward_parity(gpu, n, W, H, sort_mode):
+    check_forward(gpu, *case(n, W, H), sort_mode=sort_mode)
+
+
+def test_frame_forward_giant_bucket_sorted_in_global_memory(gpu):
+    # > 4096 pairs in one tile: the per-tile sort leaves LDS and runs in place in global memory
+    scene, cam = case(40_000, 32, 32, seed=8)
+    of, _, _ = check_forward(gpu, scene, cam, sort_mode=1)
+    assert np.diff(of.accum).max() > 4096
 
 
 def test_frame_forward_sh(gpu):
     check_forward(gpu, *case(8_000, 160, 96, use_sh=True))
 
 
-def test_frame_forward_dense_tiles_multi_chunk(gpu):
+@pytest.mark.parametrize("sort_mode", [0, 1])
+def test_frame_forward_dense_tiles_multi_chunk(gpu, sort_mode):
     # ~1.5k Gaussians per tile: several 256-Gaussian LDS chunks per tile + early termination
     scene, cam = case(60_000, 96, 64, seed=3)
     scene.opa += 2.0
-    of, _, _ = check_forward(gpu, scene, cam)
+    of, _, _ = check_forward(gpu, scene, cam, sort_mode=sort_mode)
     assert np.diff(of.accum).max() > 600
 
 
@@ -132,9 +142,10 @@ def test_frame_capacity_overflow_grows(gpu):
     assert r2.stats().overflow == len(of.ids)  # reported, never silently dropped
 
 
-def test_frame_repeatable_bitwise(gpu):
+@pytest.mark.parametrize("sort_mode", [0, 1])
+def test_frame_repeatable_bitwise(gpu, sort_mode):
     scene, cam = case(10_000, 128, 128)
-    r = FrameRenderer(gpu, max_pairs=1 << 17, auto_grow=False)
+    r = FrameRenderer(gpu, max_pairs=1 << 17, auto_grow=False, sort_mode=sort_mode)
     p = to_torch(scene, gpu)
     a = r.forward(*p, cam)[0].clone()
     b = r.forward(*p, cam)[0].clone()
