@@ -7,7 +7,7 @@
 // the key -- and then orders every bucket by the unique composite (depth_bits << 32 | gaussian_id)
 // with an all-ascending bitonic network:
 //   * buckets <= 128 pairs : one wave, no workgroup barrier at all;
-//   * buckets <= 4096 pairs: in LDS; comparator strides <= 64 stay inside one wave's 128-element
+//   * buckets <= 2048 pairs: in LDS; comparator strides <= 64 stay inside one wave's 128-element
 //     window, so those stages only need wave-level ordering -- a workgroup barrier is paid only
 //     for the few stages with stride >= 128;
 //   * larger buckets        : same network in place on a global scratch segment (rare).
@@ -106,8 +106,7 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(uint64_t *__restrict__ k
     const uint32_t tile = blockIdx.x;
     const uint32_t start = (uint32_t)ranges[2 * tile], end = (uint32_t)ranges[2 * tile + 1];
     const uint32_t n = end - start;
-    // this instantiation's share: CAP = 1024 takes n in [2, 1024], CAP = 4096 everything larger
-    if (n < 2 || (CAP == 1024 ? n > 1024 : n <= 1024)) return;
+    if (n < 2) return;
     uint32_t P = 1;
     while (P < n) P <<= 1;
     if (P <= 128) {  // one wave does everything; the other three leave
@@ -142,9 +141,9 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(uint64_t *__restrict__ k
 int gs_stage_tile_sort(const gs_frame *f, const gs_frame_ws &ws, uint64_t *keys, uint32_t *ids, uint64_t *scratch,
                        hipStream_t stream) {
     gs_frame_geom G = gs_frame_geometry(f);
-    hipLaunchKernelGGL(tile_sort_kernel<1024>, dim3(G.n_tiles), dim3(256), 0, stream, keys, ids, scratch,
-                       ws.tile_ranges);
-    hipLaunchKernelGGL(tile_sort_kernel<4096>, dim3(G.n_tiles), dim3(256), 0, stream, keys, ids, scratch,
+    // 2048 pairs (16 KiB of LDS, 8 workgroups per CU) cover Garden-scale tiles; longer buckets
+    // take the in-place global path of the same kernel
+    hipLaunchKernelGGL(tile_sort_kernel<2048>, dim3(G.n_tiles), dim3(256), 0, stream, keys, ids, scratch,
                        ws.tile_ranges);
     GS_CHECK_LAUNCH();
     return 0;

@@ -27,9 +27,10 @@ ORDER = ("quat", "pos", "scale", "opa", "rgb")  # storage order inside the flat 
 class FlatGaussianParams:
     """params / grads in the canonical (pos, quat, scale, opa, rgb) order, stored flat."""
 
-    def __init__(self, params: Sequence[torch.Tensor], world_size: int = 1):
+    def __init__(self, params: Sequence[torch.Tensor], world_size: int = 1, force_collective: bool = False):
         pos, quat, scale, opa, rgb = params
         self.world_size = int(world_size)
+        self.force_collective = bool(force_collective)  # issue the all-reduce even with one rank
         by_name = {"pos": pos, "quat": quat, "scale": scale, "opa": opa, "rgb": rgb}
         total = sum(by_name[k].numel() for k in ORDER)
         dev = pos.device
@@ -53,7 +54,7 @@ class FlatGaussianParams:
 
     def all_reduce_grads(self, async_op: bool = False):
         """Mean of the per-view gradients over all ranks (no-op for a single process)."""
-        if self.world_size <= 1 or not dist.is_initialized():
+        if not dist.is_initialized() or (self.world_size <= 1 and not self.force_collective):
             return None
         work = dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, async_op=async_op)
         if async_op:

@@ -56,8 +56,10 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ  # under torchrun always go through RCCL
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
@@ -65,12 +67,12 @@ def main():
     from gs_scene import CONFIGS, make_camera, make_scene
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     def max_over_ranks(x):
-        if world == 1:
+        if not use_dist:
             return x
         t = torch.tensor([x], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -150,7 +152,7 @@ def main():
         # training iteration: forward (checkpointing) + L1 loss + backward (+ RCCL all-reduce when N > 1)
         from gs_dp import FlatGaussianParams
 
-        flat = FlatGaussianParams(params, world_size=world)
+        flat = FlatGaussianParams(params, world_size=world, force_collective=use_dist)
         rt, stt = sized_renderer(flat.params, cam, training=True)
         target = torch.rand(H, W, 3, device=dev)
 
@@ -199,7 +201,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

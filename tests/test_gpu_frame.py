@@ -66,7 +66,7 @@ def test_frame_forward_parity(gpu, n, W, H, sort_mode):
 
 
 def test_frame_forward_giant_bucket_sorted_in_global_memory(gpu):
-    # > 4096 pairs in one tile: the per-tile sort leaves LDS and runs in place in global memory
+    # > 2048 pairs in one tile: the per-tile sort leaves LDS and runs in place in global memory
     scene, cam = case(40_000, 32, 32, seed=8)
     of, _, _ = check_forward(gpu, scene, cam, sort_mode=1)
     assert np.diff(of.accum).max() > 4096
