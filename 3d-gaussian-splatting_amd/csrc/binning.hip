@@ -110,17 +110,20 @@ __global__ void __launch_bounds__(256) gather_gaussians_kernel(const int32_t *__
 // ---------------------------------------------------------------- frame stage S3
 // One workgroup scans the per-block pair sums (<= ~40k values for 10M Gaussians).
 __global__ void __launch_bounds__(1024) scan_block_sums_kernel(const uint32_t *__restrict__ block_sums,
+                                                              const uint32_t *__restrict__ block_vis,
                                                               uint32_t *__restrict__ block_offsets, int nblk,
                                                               unsigned long long *__restrict__ counters,
                                                               unsigned long long max_pairs) {
     __shared__ uint32_t s_wave[16];
-    __shared__ uint32_t s_carry;
-    if (threadIdx.x == 0) s_carry = 0;
+    __shared__ uint32_t s_carry, s_vis;
+    if (threadIdx.x == 0) s_carry = s_vis = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t vis = 0;
     for (int base = 0; base < nblk; base += 1024) {
         const int i = base + threadIdx.x;
         uint32_t v = i < nblk ? block_sums[i] : 0;
+        vis += i < nblk ? block_vis[i] : 0;
         uint32_t incl = gs_wave_incl_scan_u32(v);
         if (lane == 63) s_wave[wave] = incl;
         __syncthreads();
@@ -133,10 +136,14 @@ __global__ void __launch_bounds__(1024) scan_block_sums_kernel(const uint32_t *_
         if (threadIdx.x == 1023) s_carry = carry + wave_off + incl;
         __syncthreads();
     }
+    vis = gs_wave_sum_u32(vis);
+    if (lane == 0 && vis) atomicAdd(&s_vis, vis);
+    __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long total = s_carry;
         counters[GS_CNT_PAIRS] = total < max_pairs ? total : max_pairs;
         counters[GS_CNT_OVERFLOW] = total > max_pairs ? total : 0ull;
+        counters[GS_CNT_VISIBLE] = s_vis;
     }
 }
 
@@ -278,7 +285,8 @@ extern "C" int gs_gather_gaussians(const int32_t *tile_n_point_accum, const int3
 int gs_stage_scan_emit(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream) {
     const int nblk = (int)gs_div_up(f->N, 256);
     gs_frame_geom G = gs_frame_geometry(f);
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, stream, ws.block_sums, ws.block_offsets,
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, stream, ws.block_sums, ws.block_vis,
+                       ws.block_offsets,
                        nblk, ws.counters, (unsigned long long)f->max_pairs);
     GS_CHECK_LAUNCH();
     hipLaunchKernelGGL(emit_pairs_kernel, dim3(nblk), dim3(256), 0, stream, ws.tiles_touched, ws.rects,

@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(256) frame_project_kernel(
     const float *__restrict__ opa, const float *__restrict__ rgb, int64_t n, ProjectParams P,
     float4 *__restrict__ rec_geom, float4 *__restrict__ rec_cov, float4 *__restrict__ rec_color,
     uint32_t *__restrict__ tiles_touched, uint2 *__restrict__ rects, uint32_t *__restrict__ block_sums,
-    unsigned long long *__restrict__ counters) {
+    uint32_t *__restrict__ block_vis) {
     const int64_t pid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t cnt = 0, vis = 0;
     if (pid < n) {
@@ -364,7 +364,8 @@ __global__ void __launch_bounds__(256) frame_project_kernel(
         tiles_touched[pid] = cnt;
         rects[pid] = rc;
     }
-    // block sum of cnt (and of the visible flag) -> one store / one atomic per block
+    // block sums of cnt and of the visible flag -> two plain stores per block (a same-address
+    // atomic per block would serialise at ~12 ns each: 112 us for 2.4 M Gaussians)
     __shared__ uint32_t s_cnt[4], s_vis[4];
     uint32_t wsum = gs_wave_sum_u32(cnt), wvis = gs_wave_sum_u32(vis);
     const int wave = threadIdx.x >> 6;
@@ -375,8 +376,7 @@ __global__ void __launch_bounds__(256) frame_project_kernel(
     __syncthreads();
     if (threadIdx.x == 0) {
         block_sums[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-        uint32_t v = s_vis[0] + s_vis[1] + s_vis[2] + s_vis[3];
-        if (v) atomicAdd(&counters[GS_CNT_VISIBLE], (unsigned long long)v);
+        block_vis[blockIdx.x] = s_vis[0] + s_vis[1] + s_vis[2] + s_vis[3];
     }
 }
 
@@ -541,7 +541,7 @@ int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t strea
     int nblk = (int)gs_div_up(f->N, 256);
     hipLaunchKernelGGL(frame_project_kernel, dim3(nblk), dim3(256), 0, stream, f->pos, (const float4 *)f->quat,
                        f->scale, f->opa, f->rgb, f->N, P, ws.rec_geom, ws.rec_cov, ws.rec_color,
-                       ws.tiles_touched, ws.rects, ws.block_sums, ws.counters);
+                       ws.tiles_touched, ws.rects, ws.block_sums, ws.block_vis);
     GS_CHECK_LAUNCH();
     return 0;
 }

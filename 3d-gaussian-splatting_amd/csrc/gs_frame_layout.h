@@ -41,7 +41,8 @@ struct gs_frame_ws {
     float4 *rec_color;             // [N] (r, g, b, -)  (color_dim == 3 only)
     uint32_t *tiles_touched;       // [N]
     uint2 *rects;                  // [N] (y0 | y1 << 16, x0 | x1 << 16)
-    uint32_t *block_sums;          // [ceil(N/256)]
+    uint32_t *block_sums;          // [ceil(N/256)] pairs emitted by each 256-Gaussian block
+    uint32_t *block_vis;           // [ceil(N/256)] visible Gaussians of each block
     uint32_t *block_offsets;       // [ceil(N/256)]
     uint64_t *keys_a, *keys_b;     // [max_pairs]
     uint32_t *vals_a, *vals_b;     // [max_pairs]
@@ -82,6 +83,7 @@ static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pair
     ws.tiles_touched = (uint32_t *)take(sizeof(uint32_t) * N);
     ws.rects = (uint2 *)take(sizeof(uint2) * N);
     ws.block_sums = (uint32_t *)take(sizeof(uint32_t) * nblk);
+    ws.block_vis = (uint32_t *)take(sizeof(uint32_t) * nblk);
     ws.block_offsets = (uint32_t *)take(sizeof(uint32_t) * nblk);
     ws.keys_a = (uint64_t *)take(sizeof(uint64_t) * max_pairs);
     ws.keys_b = (uint64_t *)take(sizeof(uint64_t) * max_pairs);

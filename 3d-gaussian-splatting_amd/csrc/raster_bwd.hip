@@ -79,16 +79,14 @@ struct BwdIn {
     const int32_t *ranges;           // FRAME: [T][2]; REF: accum [T+1]
 };
 
-template <int CDIM>
-struct PixState {  // what travels from lane to lane
-    float T, R0, R1, R2, g0, g1, g2, px, py;
-    float sh[CDIM == 27 ? 9 : 1];
-};
-
 template <int CDIM, bool FRAME>
 __global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
+    // Feed ring: the 256 pixel states of a bucket enter lane 0 in four segments of 64; while a
+    // segment streams through the lanes, the next one is prefetched into registers and then
+    // written to the other half of the ring.  ~6 KiB of LDS per wave keeps occupancy
+    // register-limited (the dependent DPP chain needs >= 5 waves per SIMD to stay hidden).
     constexpr int NF = CDIM == 27 ? 5 : 3;  // float4 feed records per pixel
-    __shared__ float4 s_feed[4][NF][256];
+    __shared__ float4 s_feed[4][2][NF][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t n_tiles = (uint32_t)(G.ntx * G.nty);
     const uint32_t kb = blockIdx.x * 4 + wave;
@@ -107,44 +105,55 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, Raste
     const uint32_t jloc = b * GS_BUCKET + lane;
     const bool gvalid = jloc < nproc;
     const uint32_t j = start + jloc;
+    const int nvalid = (int)((nproc - b * GS_BUCKET) < (uint32_t)GS_BUCKET ? (nproc - b * GS_BUCKET) : GS_BUCKET);
 
-    // ---- stage the 256 pixel states of this bucket into the wave's LDS slice
+    // ---- per-segment staging of the pixel states (pixel p = 64 seg + lane)
     const float4 *ck = I.ckpt + raster_ckpt_slot(start, tile, b) * 256;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int p = r * 64 + lane;
-        const uint32_t id_x = tx * 16 + (p & 15), id_y = ty * 16 + (p >> 4);
-        const float4 c = ck[p];
+    const uint32_t id_x = tx * 16 + (lane & 15);
+    const float my_px = raster_pixel_coord(id_x, G.padW, G.focal_x);
+    float4 pc;            // prefetched checkpoint (T, C_run)
+    float pf0, pf1, pf2;  // final colour
+    float pg0, pg1, pg2;  // dL/dC
+    auto load_segment = [&](int seg) {
+        const int p = seg * 64 + lane;
+        const uint32_t id_y = ty * 16 + (p >> 4);
+        pc = ck[p];
         const float *cf = I.c_final + ((size_t)id_y * G.padW + id_x) * 3;
-        const float f0 = cf[0], f1 = cf[1], f2 = cf[2];
-        float g0, g1, g2;
+        pf0 = cf[0];
+        pf1 = cf[1];
+        pf2 = cf[2];
         if (FRAME) {  // grad w.r.t. the clamped + cropped output (splatter.py:652-653)
             const int ox = (int)id_x - G.crop_left, oy = (int)id_y - G.crop_top;
             const bool in = ox >= 0 && ox < G.width && oy >= 0 && oy < G.height;
             const float *gp = I.grad + ((size_t)(in ? oy : 0) * G.width + (in ? ox : 0)) * 3;
-            g0 = (in && f0 >= 0.f && f0 <= 1.f) ? gp[0] : 0.f;
-            g1 = (in && f1 >= 0.f && f1 <= 1.f) ? gp[1] : 0.f;
-            g2 = (in && f2 >= 0.f && f2 <= 1.f) ? gp[2] : 0.f;
+            pg0 = (in && pf0 >= 0.f && pf0 <= 1.f) ? gp[0] : 0.f;
+            pg1 = (in && pf1 >= 0.f && pf1 <= 1.f) ? gp[1] : 0.f;
+            pg2 = (in && pf2 >= 0.f && pf2 <= 1.f) ? gp[2] : 0.f;
         } else {
             const float *gp = I.grad + ((size_t)id_y * G.padW + id_x) * 3;
-            g0 = gp[0];
-            g1 = gp[1];
-            g2 = gp[2];
+            pg0 = gp[0];
+            pg1 = gp[1];
+            pg2 = gp[2];
         }
-        const float px = raster_pixel_coord(id_x, G.padW, G.focal_x);
+    };
+    auto write_segment = [&](int buf, int seg) {
+        const uint32_t id_y = ty * 16 + seg * 4 + (lane >> 4);
         const float py = raster_pixel_coord(id_y, G.padH, G.focal_y);
-        s_feed[wave][0][p] = make_float4(c.x, f0 - c.y, f1 - c.z, f2 - c.w);
-        s_feed[wave][1][p] = make_float4(g0, g1, g2, px);
+        s_feed[wave][buf][0][lane] = make_float4(pc.x, pf0 - pc.y, pf1 - pc.z, pf2 - pc.w);
+        s_feed[wave][buf][1][lane] = make_float4(pg0, pg1, pg2, my_px);
         if (CDIM == 27) {
             float SH[9];
             raster_pixel_sh(id_x, id_y, G, SH);
-            s_feed[wave][2][p] = make_float4(py, SH[0], SH[1], SH[2]);
-            s_feed[wave][3][p] = make_float4(SH[3], SH[4], SH[5], SH[6]);
-            s_feed[wave][4][p] = make_float4(SH[7], SH[8], 0.f, 0.f);
+            s_feed[wave][buf][2][lane] = make_float4(py, SH[0], SH[1], SH[2]);
+            s_feed[wave][buf][CDIM == 27 ? 3 : 0][lane] = make_float4(SH[3], SH[4], SH[5], SH[6]);
+            s_feed[wave][buf][CDIM == 27 ? 4 : 0][lane] = make_float4(SH[7], SH[8], 0.f, 0.f);
         } else {
-            s_feed[wave][2][p] = make_float4(py, 0.f, 0.f, 0.f);
+            s_feed[wave][buf][2][lane] = make_float4(py, 0.f, 0.f, 0.f);
         }
-    }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    load_segment(0);
 
     // ---- this lane's Gaussian
     GaussianRec g = {0, 0, 0, 0, 0, 0, 0};
@@ -167,6 +176,7 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, Raste
     float cA = 0, cB = 0, cC = 0;
     if (gvalid) raster_conic(g, cA, cB, cC);
     const float opa = gvalid ? g.opa : 0.f;  // opacity 0 => alpha 0 => state passes through unchanged
+    write_segment(0, 0);
 
     // gradient accumulators
     float Sx = 0, Sy = 0, Sxx = 0, Sxy = 0, Syy = 0, Su = 0, Sopa = 0, Sc0 = 0, Sc1 = 0, Sc2 = 0;
@@ -175,8 +185,6 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, Raste
 #pragma unroll
         for (int q = 0; q < 27; ++q) Ssh[q] = 0.f;
     }
-
-    __builtin_amdgcn_wave_barrier();
     // outgoing state of the previous step (T = 0 means "no pixel here")
     float oT = 0, oR0 = 0, oR1 = 0, oR2 = 0, og0 = 0, og1 = 0, og2 = 0, opx = 0, opy = 0;
     float osh[CDIM == 27 ? 9 : 1];
@@ -185,93 +193,101 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, Raste
         for (int q = 0; q < 9; ++q) osh[q] = 0.f;
     }
 
-    for (int t = 0; t < 256 + GS_BUCKET - 1; ++t) {
-        // feed for lane 0 (broadcast LDS reads; beyond the last pixel feed T = 0)
-        const int tp = t < 256 ? t : 255;
-        const float4 f0 = s_feed[wave][0][tp], f1 = s_feed[wave][1][tp], f2 = s_feed[wave][2][tp];
-        const float fT = t < 256 ? f0.x : 0.f;
-        // state entering this lane: lane l-1's output of the previous step; lane 0 takes the feed
-        const float T = gs_wave_shr1(fT, oT);
-        float R0 = gs_wave_shr1(f0.y, oR0), R1 = gs_wave_shr1(f0.z, oR1), R2 = gs_wave_shr1(f0.w, oR2);
-        const float g0 = gs_wave_shr1(f1.x, og0), g1 = gs_wave_shr1(f1.y, og1), g2 = gs_wave_shr1(f1.z, og2);
-        const float px = gs_wave_shr1(f1.w, opx), py = gs_wave_shr1(f2.x, opy);
-        float sh[CDIM == 27 ? 9 : 1];
-        if (CDIM == 27) {
-            const float4 f3 = s_feed[wave][CDIM == 27 ? 3 : 0][tp], f4 = s_feed[wave][CDIM == 27 ? 4 : 0][tp];
-            sh[0] = gs_wave_shr1(f2.y, osh[0]);
-            sh[1] = gs_wave_shr1(f2.z, osh[1]);
-            sh[2] = gs_wave_shr1(f2.w, osh[2]);
-            sh[3] = gs_wave_shr1(f3.x, osh[3]);
-            sh[4] = gs_wave_shr1(f3.y, osh[4]);
-            sh[5] = gs_wave_shr1(f3.z, osh[5]);
-            sh[6] = gs_wave_shr1(f3.w, osh[6]);
-            sh[7] = gs_wave_shr1(f4.x, osh[7]);
-            sh[8] = gs_wave_shr1(f4.y, osh[8]);
-        }
+    for (int seg = 0; seg < 5; ++seg) {
+        const int buf = seg & 1;
+        if (seg + 1 < 4) load_segment(seg + 1);  // in flight while this segment streams
+        const bool feeding = seg < 4;
+        const int nsteps = feeding ? 64 : nvalid - 1;  // drain: the last pixel leaves lane nvalid-1
+#pragma unroll 2
+        for (int t = 0; t < nsteps; ++t) {
+            // feed for lane 0 (broadcast LDS reads; while draining feed T = 0)
+            const float4 f0 = s_feed[wave][buf][0][t], f1 = s_feed[wave][buf][1][t], f2 = s_feed[wave][buf][2][t];
+            const float fT = feeding ? f0.x : 0.f;
+            // state entering this lane: lane l-1's output of the previous step; lane 0 takes the feed
+            const float T = gs_wave_shr1(fT, oT);
+            float R0 = gs_wave_shr1(f0.y, oR0), R1 = gs_wave_shr1(f0.z, oR1), R2 = gs_wave_shr1(f0.w, oR2);
+            const float g0 = gs_wave_shr1(f1.x, og0), g1 = gs_wave_shr1(f1.y, og1), g2 = gs_wave_shr1(f1.z, og2);
+            const float px = gs_wave_shr1(f1.w, opx), py = gs_wave_shr1(f2.x, opy);
+            float sh[CDIM == 27 ? 9 : 1];
+            if (CDIM == 27) {
+                const float4 f3 = s_feed[wave][buf][CDIM == 27 ? 3 : 0][t], f4 = s_feed[wave][buf][CDIM == 27 ? 4 : 0][t];
+                sh[0] = gs_wave_shr1(f2.y, osh[0]);
+                sh[1] = gs_wave_shr1(f2.z, osh[1]);
+                sh[2] = gs_wave_shr1(f2.w, osh[2]);
+                sh[3] = gs_wave_shr1(f3.x, osh[3]);
+                sh[4] = gs_wave_shr1(f3.y, osh[4]);
+                sh[5] = gs_wave_shr1(f3.z, osh[5]);
+                sh[6] = gs_wave_shr1(f3.w, osh[6]);
+                sh[7] = gs_wave_shr1(f4.x, osh[7]);
+                sh[8] = gs_wave_shr1(f4.y, osh[8]);
+            }
 
-        const float dx = px - g.x, dy = py - g.y;
-        const float dxx = dx * dx, dxy = dx * dy, dyy = dy * dy;
-        const float q = fmaf(cC * dy, dy, dx * fmaf(-cB, dy, cA * dx));  // same evaluation order as the forward
-        const float Gv = gs_exp2(-q);
-        const bool live = T > GS_T_STOP;
-        const float alpha = live ? Gv * opa : 0.f;
-        const float w = alpha * T;
-        if (CDIM == 27) {
-            float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+            const float dx = px - g.x, dy = py - g.y;
+            const float dxx = dx * dx, dxy = dx * dy, dyy = dy * dy;
+            const float q = fmaf(cC * dy, dy, dx * fmaf(-cB, dy, cA * dx));  // same evaluation order as the forward
+            const float Gv = gs_exp2(-q);
+            const bool live = T > GS_T_STOP;
+            const float alpha = live ? Gv * opa : 0.f;
+            const float w = alpha * T;
+            if (CDIM == 27) {
+                float v0 = 0.f, v1 = 0.f, v2 = 0.f;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                v0 += sh[k] * coef[k];
-                v1 += sh[k] * coef[9 + k];
-                v2 += sh[k] * coef[18 + k];
+                for (int k = 0; k < 9; ++k) {
+                    v0 = fmaf(sh[k], coef[k], v0);
+                    v1 = fmaf(sh[k], coef[9 + k], v1);
+                    v2 = fmaf(sh[k], coef[18 + k], v2);
+                }
+                col0 = gs_rcp(1.0f + __expf(-v0));
+                col1 = gs_rcp(1.0f + __expf(-v1));
+                col2 = gs_rcp(1.0f + __expf(-v2));
             }
-            col0 = gs_rcp(1.0f + __expf(-v0));
-            col1 = gs_rcp(1.0f + __expf(-v1));
-            col2 = gs_rcp(1.0f + __expf(-v2));
-        }
-        // remaining colour AFTER this Gaussian (the reference's cur_out - color, :719)
-        R0 -= col0 * w;
-        R1 -= col1 * w;
-        R2 -= col2 * w;
-        const float one_m = 1.0f - alpha;
-        float d_alpha = T * (g0 * col0 + g1 * col1 + g2 * col2) - (g0 * R0 + g1 * R1 + g2 * R2) * gs_rcp(one_m + 1e-7f);
-        d_alpha = live ? d_alpha : 0.f;
-        if (CDIM == 27) {
-            const float D0 = g0 * w * (col0 * (1.0f - col0)), D1 = g1 * w * (col1 * (1.0f - col1)),
-                        D2 = g2 * w * (col2 * (1.0f - col2));
+            // remaining colour AFTER this Gaussian (the reference's cur_out - color, :719)
+            R0 -= col0 * w;
+            R1 -= col1 * w;
+            R2 -= col2 * w;
+            const float one_m = 1.0f - alpha;
+            float d_alpha =
+                T * (g0 * col0 + g1 * col1 + g2 * col2) - (g0 * R0 + g1 * R1 + g2 * R2) * gs_rcp(one_m + 1e-7f);
+            d_alpha = live ? d_alpha : 0.f;
+            if (CDIM == 27) {
+                const float D0 = g0 * w * (col0 * (1.0f - col0)), D1 = g1 * w * (col1 * (1.0f - col1)),
+                            D2 = g2 * w * (col2 * (1.0f - col2));
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                Ssh[k] += D0 * sh[k];
-                Ssh[9 + k] += D1 * sh[k];
-                Ssh[18 + k] += D2 * sh[k];
+                for (int k = 0; k < 9; ++k) {
+                    Ssh[k] = fmaf(D0, sh[k], Ssh[k]);
+                    Ssh[9 + k] = fmaf(D1, sh[k], Ssh[9 + k]);
+                    Ssh[18 + k] = fmaf(D2, sh[k], Ssh[18 + k]);
+                }
+            } else {
+                Sc0 = fmaf(g0, w, Sc0);
+                Sc1 = fmaf(g1, w, Sc1);
+                Sc2 = fmaf(g2, w, Sc2);
             }
-        } else {
-            Sc0 += g0 * w;
-            Sc1 += g1 * w;
-            Sc2 += g2 * w;
-        }
-        Sopa += d_alpha * Gv;
-        const float s = d_alpha * alpha;
-        const float u = q * GS_LN2;
-        Sx += s * dx;
-        Sy += s * dy;
-        Sxx += s * dxx;
-        Sxy += s * dxy;
-        Syy += s * dyy;
-        Su += s * u;
-        // outgoing state
-        oT = fmaf(-alpha, T, T);  // identical to the forward's update
-        oR0 = R0;
-        oR1 = R1;
-        oR2 = R2;
-        og0 = g0;
-        og1 = g1;
-        og2 = g2;
-        opx = px;
-        opy = py;
-        if (CDIM == 27) {
+            Sopa = fmaf(d_alpha, Gv, Sopa);
+            const float s = d_alpha * alpha;
+            const float u = q * GS_LN2;
+            Sx = fmaf(s, dx, Sx);
+            Sy = fmaf(s, dy, Sy);
+            Sxx = fmaf(s, dxx, Sxx);
+            Sxy = fmaf(s, dxy, Sxy);
+            Syy = fmaf(s, dyy, Syy);
+            Su = fmaf(s, u, Su);
+            // outgoing state
+            oT = fmaf(-alpha, T, T);  // identical to the forward's update
+            oR0 = R0;
+            oR1 = R1;
+            oR2 = R2;
+            og0 = g0;
+            og1 = g1;
+            og2 = g2;
+            opx = px;
+            opy = py;
+            if (CDIM == 27) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) osh[k] = sh[k];
+                for (int k = 0; k < 9; ++k) osh[k] = sh[k];
+            }
         }
+        if (seg + 1 < 4) write_segment(buf ^ 1, seg + 1);
     }
 
     if (!gvalid) return;
