@@ -134,9 +134,16 @@ def main():
         grid_px = (-(-W // 16) * 16) * (-(-H // 16) * 16)
         alg_bytes = (4 + 24 + 4 + 4 * C) * st.pairs + 12 * grid_px  # SURVEY.md 8d, stage S5 (raster)
         achieved = alg_bytes / (stage["raster"] * 1e-3) / 1e9
+        traffic = None  # HBM bytes per launch from committed PMC passes (profiles/traffic.json), if they match
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[args.config]
+            if tj["tile_pairs"] == st.pairs:
+                traffic = tj["raster_forward_kernel"]["traffic_bytes"]
+        except (OSError, KeyError, ValueError):
+            pass
         out["roofline"] = {"bound": "hbm", "kernel": "raster_forward_kernel", "achieved": round(achieved, 1),
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                           "traffic": None, "algorithmic_bytes": alg_bytes,
+                           "traffic": traffic, "algorithmic_bytes": alg_bytes,
                            "kernel_ms": round(stage["raster"], 4)}
         out["stage_ms"] = {k: round(v, 4) for k, v in stage.items()}
         # whole-frame algorithmic bytes: 44N + (64+8C)V + (72+4C)M + 12P + 4T
