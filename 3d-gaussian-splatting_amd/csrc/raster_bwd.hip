@@ -8,8 +8,8 @@
 //   * one wave64 owns one BUCKET of 64 consecutive Gaussians of a tile's sorted list; lane l
 //     keeps Gaussian l's parameters AND its gradient accumulators in registers;
 //   * the tile's 256 pixels stream through the lanes: at step t lane l handles pixel t - l.
-//     A pixel's running state (transmittance T, remaining colour R = C_final - C_run, dL/dC,
-//     pixel centre) moves from lane l to lane l+1 with one DPP `wave_shr:1` per register;
+//     A pixel's running state (transmittance T, rho = dL/dC . (C_final - C_run), dL/dC, pixel
+//     centre: 7 registers) moves from lane l to lane l+1 with one DPP `wave_shr:1` per register;
 //     lane 0 is fed from LDS (broadcast read of the staged per-pixel state);
 //   * therefore NO cross-lane reduction and NO atomics inside the loop: after 256+63 steps
 //     every lane holds the complete sum over the tile's pixels for its Gaussian.
@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, Raste
     // segment streams through the lanes, the next one is prefetched into registers and then
     // written to the other half of the ring.  ~6 KiB of LDS per wave keeps occupancy
     // register-limited (the dependent DPP chain needs >= 5 waves per SIMD to stay hidden).
-    constexpr int NF = CDIM == 27 ? 5 : 3;  // float4 feed records per pixel
+    constexpr int NF = CDIM == 27 ? 4 : 2;  // float4 feed records per pixel
     __shared__ float4 s_feed[4][2][NF][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t n_tiles = (uint32_t)(G.ntx * G.nty);
@@ -139,16 +139,18 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, Raste
     auto write_segment = [&](int buf, int seg) {
         const uint32_t id_y = ty * 16 + seg * 4 + (lane >> 4);
         const float py = raster_pixel_coord(id_y, G.padH, G.focal_y);
-        s_feed[wave][buf][0][lane] = make_float4(pc.x, pf0 - pc.y, pf1 - pc.z, pf2 - pc.w);
-        s_feed[wave][buf][1][lane] = make_float4(pg0, pg1, pg2, my_px);
+        // rho = dL/dC . (C_final - C_run): the only way the remaining colour enters dL/dalpha
+        // (gaussian.cu:716-722), so one scalar travels instead of three colour channels
+        const float rho = pg0 * (pf0 - pc.y) + pg1 * (pf1 - pc.z) + pg2 * (pf2 - pc.w);
+        s_feed[wave][buf][0][lane] = make_float4(pc.x, rho, my_px, py);
         if (CDIM == 27) {
             float SH[9];
             raster_pixel_sh(id_x, id_y, G, SH);
-            s_feed[wave][buf][2][lane] = make_float4(py, SH[0], SH[1], SH[2]);
-            s_feed[wave][buf][CDIM == 27 ? 3 : 0][lane] = make_float4(SH[3], SH[4], SH[5], SH[6]);
-            s_feed[wave][buf][CDIM == 27 ? 4 : 0][lane] = make_float4(SH[7], SH[8], 0.f, 0.f);
+            s_feed[wave][buf][1][lane] = make_float4(pg0, pg1, pg2, SH[0]);
+            s_feed[wave][buf][CDIM == 27 ? 2 : 0][lane] = make_float4(SH[1], SH[2], SH[3], SH[4]);
+            s_feed[wave][buf][CDIM == 27 ? 3 : 0][lane] = make_float4(SH[5], SH[6], SH[7], SH[8]);
         } else {
-            s_feed[wave][buf][2][lane] = make_float4(py, 0.f, 0.f, 0.f);
+            s_feed[wave][buf][1][lane] = make_float4(pg0, pg1, pg2, 0.f);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -179,14 +181,14 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, Raste
     write_segment(0, 0);
 
     // gradient accumulators
-    float Sx = 0, Sy = 0, Sxx = 0, Sxy = 0, Syy = 0, Su = 0, Sopa = 0, Sc0 = 0, Sc1 = 0, Sc2 = 0;
+    float Sx = 0, Sy = 0, Sxx = 0, Sxy = 0, Syy = 0, Sq = 0, Sopa = 0, Sc0 = 0, Sc1 = 0, Sc2 = 0;
     float Ssh[CDIM == 27 ? 27 : 1];
     if (CDIM == 27) {
 #pragma unroll
         for (int q = 0; q < 27; ++q) Ssh[q] = 0.f;
     }
     // outgoing state of the previous step (T = 0 means "no pixel here")
-    float oT = 0, oR0 = 0, oR1 = 0, oR2 = 0, og0 = 0, og1 = 0, og2 = 0, opx = 0, opy = 0;
+    float oT = 0, orho = 0, og0 = 0, og1 = 0, og2 = 0, opx = 0, opy = 0;
     float osh[CDIM == 27 ? 9 : 1];
     if (CDIM == 27) {
 #pragma unroll
@@ -201,29 +203,28 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, Raste
 #pragma unroll 2
         for (int t = 0; t < nsteps; ++t) {
             // feed for lane 0 (broadcast LDS reads; while draining feed T = 0)
-            const float4 f0 = s_feed[wave][buf][0][t], f1 = s_feed[wave][buf][1][t], f2 = s_feed[wave][buf][2][t];
+            const float4 f0 = s_feed[wave][buf][0][t], f1 = s_feed[wave][buf][1][t];
             const float fT = feeding ? f0.x : 0.f;
             // state entering this lane: lane l-1's output of the previous step; lane 0 takes the feed
             const float T = gs_wave_shr1(fT, oT);
-            float R0 = gs_wave_shr1(f0.y, oR0), R1 = gs_wave_shr1(f0.z, oR1), R2 = gs_wave_shr1(f0.w, oR2);
+            float rho = gs_wave_shr1(f0.y, orho);
+            const float px = gs_wave_shr1(f0.z, opx), py = gs_wave_shr1(f0.w, opy);
             const float g0 = gs_wave_shr1(f1.x, og0), g1 = gs_wave_shr1(f1.y, og1), g2 = gs_wave_shr1(f1.z, og2);
-            const float px = gs_wave_shr1(f1.w, opx), py = gs_wave_shr1(f2.x, opy);
             float sh[CDIM == 27 ? 9 : 1];
             if (CDIM == 27) {
-                const float4 f3 = s_feed[wave][buf][CDIM == 27 ? 3 : 0][t], f4 = s_feed[wave][buf][CDIM == 27 ? 4 : 0][t];
-                sh[0] = gs_wave_shr1(f2.y, osh[0]);
-                sh[1] = gs_wave_shr1(f2.z, osh[1]);
-                sh[2] = gs_wave_shr1(f2.w, osh[2]);
-                sh[3] = gs_wave_shr1(f3.x, osh[3]);
-                sh[4] = gs_wave_shr1(f3.y, osh[4]);
-                sh[5] = gs_wave_shr1(f3.z, osh[5]);
-                sh[6] = gs_wave_shr1(f3.w, osh[6]);
-                sh[7] = gs_wave_shr1(f4.x, osh[7]);
-                sh[8] = gs_wave_shr1(f4.y, osh[8]);
+                const float4 f2 = s_feed[wave][buf][CDIM == 27 ? 2 : 0][t], f3 = s_feed[wave][buf][CDIM == 27 ? 3 : 0][t];
+                sh[0] = gs_wave_shr1(f1.w, osh[0]);
+                sh[1] = gs_wave_shr1(f2.x, osh[1]);
+                sh[2] = gs_wave_shr1(f2.y, osh[2]);
+                sh[3] = gs_wave_shr1(f2.z, osh[3]);
+                sh[4] = gs_wave_shr1(f2.w, osh[4]);
+                sh[5] = gs_wave_shr1(f3.x, osh[5]);
+                sh[6] = gs_wave_shr1(f3.y, osh[6]);
+                sh[7] = gs_wave_shr1(f3.z, osh[7]);
+                sh[8] = gs_wave_shr1(f3.w, osh[8]);
             }
 
             const float dx = px - g.x, dy = py - g.y;
-            const float dxx = dx * dx, dxy = dx * dy, dyy = dy * dy;
             const float q = fmaf(cC * dy, dy, dx * fmaf(-cB, dy, cA * dx));  // same evaluation order as the forward
             const float Gv = gs_exp2(-q);
             const bool live = T > GS_T_STOP;
@@ -241,13 +242,11 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, Raste
                 col1 = gs_rcp(1.0f + __expf(-v1));
                 col2 = gs_rcp(1.0f + __expf(-v2));
             }
-            // remaining colour AFTER this Gaussian (the reference's cur_out - color, :719)
-            R0 -= col0 * w;
-            R1 -= col1 * w;
-            R2 -= col2 * w;
+            // dL/dC . colour of this Gaussian, and rho AFTER it (the reference's cur_out - color, :719)
+            const float gc = fmaf(g2, col2, fmaf(g1, col1, g0 * col0));
+            rho = fmaf(-w, gc, rho);
             const float one_m = 1.0f - alpha;
-            float d_alpha =
-                T * (g0 * col0 + g1 * col1 + g2 * col2) - (g0 * R0 + g1 * R1 + g2 * R2) * gs_rcp(one_m + 1e-7f);
+            float d_alpha = fmaf(T, gc, -(rho * gs_rcp(one_m + 1e-7f)));
             d_alpha = live ? d_alpha : 0.f;
             if (CDIM == 27) {
                 const float D0 = g0 * w * (col0 * (1.0f - col0)), D1 = g1 * w * (col1 * (1.0f - col1)),
@@ -265,18 +264,16 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, Raste
             }
             Sopa = fmaf(d_alpha, Gv, Sopa);
             const float s = d_alpha * alpha;
-            const float u = q * GS_LN2;
-            Sx = fmaf(s, dx, Sx);
-            Sy = fmaf(s, dy, Sy);
-            Sxx = fmaf(s, dxx, Sxx);
-            Sxy = fmaf(s, dxy, Sxy);
-            Syy = fmaf(s, dyy, Syy);
-            Su = fmaf(s, u, Su);
+            const float sdx = s * dx, sdy = s * dy;
+            Sx += sdx;
+            Sy += sdy;
+            Sxx = fmaf(sdx, dx, Sxx);
+            Sxy = fmaf(sdx, dy, Sxy);
+            Syy = fmaf(sdy, dy, Syy);
+            Sq = fmaf(s, q, Sq);
             // outgoing state
             oT = fmaf(-alpha, T, T);  // identical to the forward's update
-            oR0 = R0;
-            oR1 = R1;
-            oR2 = R2;
+            orho = rho;
             og0 = g0;
             og1 = g1;
             og2 = g2;
@@ -293,6 +290,7 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, Raste
     if (!gvalid) return;
     const float det = raster_det(g.a, g.b, g.c, g.d);
     const float iPn = 1.0f / (2.0f * det + 1e-14f);
+    const float Su = Sq * GS_LN2;  // u = -ln G = q ln 2
     const float gx = GS_LN2 * (2.0f * cA * Sx - cB * Sy);
     const float gy = GS_LN2 * (2.0f * cC * Sy - cB * Sx);
     const float ga = iPn * (-Syy + 2.0f * g.d * Su);
