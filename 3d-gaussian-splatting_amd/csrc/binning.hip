@@ -157,7 +157,8 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(const uint32_t *__restr
                                                         const float4 *__restrict__ rec_geom,
                                                         const uint32_t *__restrict__ block_offsets, int64_t n,
                                                         uint32_t ntx, uint64_t *__restrict__ keys,
-                                                        uint32_t *__restrict__ vals, uint64_t max_pairs) {
+                                                        uint32_t *__restrict__ vals, uint64_t max_pairs,
+                                                        uint32_t *__restrict__ pair_offsets) {
     const int64_t pid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t cnt = pid < n ? tiles_touched[pid] : 0;
@@ -168,6 +169,7 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(const uint32_t *__restr
     uint32_t off = block_offsets[blockIdx.x] + incl - cnt;
 #pragma unroll
     for (int w = 0; w < 4; ++w) off += w < wave ? s_wave[w] : 0;
+    if (pid < n) pair_offsets[pid] = off;  // the backward pass addresses its per-pair rows with it
 
     uint2 rc = make_uint2(0, 0);
     uint32_t dbits = 0;
@@ -291,7 +293,7 @@ int gs_stage_scan_emit(const gs_frame *f, const gs_frame_ws &ws, hipStream_t str
     GS_CHECK_LAUNCH();
     hipLaunchKernelGGL(emit_pairs_kernel, dim3(nblk), dim3(256), 0, stream, ws.tiles_touched, ws.rects,
                        ws.rec_geom, ws.block_offsets, f->N, (uint32_t)G.ntx, ws.keys_a, ws.vals_a,
-                       (uint64_t)f->max_pairs);
+                       (uint64_t)f->max_pairs, ws.pair_offsets);
     GS_CHECK_LAUNCH();
     return 0;
 }

@@ -381,20 +381,51 @@ __global__ void __launch_bounds__(256) frame_project_kernel(
 }
 
 // ---------------------------------------------------------------- fused frame stage B2
-// dgeom[N][12] = (dx, dy, da, db, dc, dd, dopa, dr, dg, db, -, -) accumulated by the raster
-// backward.  Writes dL/d(raw parameters); culled Gaussians get zeros.
+// rows[pair][12|36] = (dx, dy, da, db, dc, dd, dopa, colour grads..) written by the raster backward
+// in emission order: Gaussian g owns rows [pair_offsets[g], +tiles_touched[g]).  They are summed
+// here in a fixed order (the reference's index_put_(accumulate=True), but deterministic) and pushed
+// through the projection + activation backward.  Culled Gaussians get zeros.
 __global__ void __launch_bounds__(256) frame_project_backward_kernel(
     const float *__restrict__ pos, const float4 *__restrict__ quat, const float *__restrict__ scale,
     const float *__restrict__ rgb, int64_t n, ProjectParams P, const float4 *__restrict__ rec_geom,
-    const float4 *__restrict__ rec_color, const float4 *__restrict__ dgeom, float *__restrict__ grad_pos,
+    const float4 *__restrict__ rec_color, const float4 *__restrict__ rows,
+    const uint32_t *__restrict__ pair_offsets, const uint32_t *__restrict__ tiles_touched, uint64_t max_pairs,
+    float *__restrict__ grad_pos,
     float4 *__restrict__ grad_quat, float *__restrict__ grad_scale, float *__restrict__ grad_opa,
     float *__restrict__ grad_rgb) {
     const int64_t pid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (pid >= n) return;
     const float4 g = rec_geom[pid];
     float gp[3] = {0, 0, 0}, gqr[4] = {0, 0, 0, 0}, gsr[3] = {0, 0, 0}, gopa = 0, gcol[3] = {0, 0, 0};
+    float gsh[27];
     if (g.z != 0.0f) {  // visible (depth > near > 0)
-        const float4 d0 = dgeom[pid * 3 + 0], d1 = dgeom[pid * 3 + 1], d2 = dgeom[pid * 3 + 2];
+        float4 d0 = make_float4(0, 0, 0, 0), d1 = d0, d2 = d0;
+        if (P.color_dim == 27) {
+#pragma unroll
+            for (int k = 0; k < 27; ++k) gsh[k] = 0.f;
+        }
+        const uint32_t cnt = tiles_touched[pid];
+        const uint64_t off = pair_offsets[pid];
+        const int RW4 = P.color_dim == 3 ? 3 : 9;  // float4s per row
+        for (uint32_t k = 0; k < cnt && off + k < max_pairs; ++k) {
+            const float4 *row = rows + (off + k) * RW4;
+            const float4 r0 = row[0], r1 = row[1];
+            d0.x += r0.x; d0.y += r0.y; d0.z += r0.z; d0.w += r0.w;
+            d1.x += r1.x; d1.y += r1.y; d1.z += r1.z;
+            if (P.color_dim == 3) {
+                const float4 r2 = row[2];
+                d1.w += r1.w; d2.x += r2.x; d2.y += r2.y;
+            } else {
+                gsh[0] += r1.w;
+#pragma unroll
+                for (int m = 0; m < 6; ++m) {
+                    const float4 r = row[2 + m];
+                    gsh[1 + 4 * m] += r.x; gsh[2 + 4 * m] += r.y; gsh[3 + 4 * m] += r.z; gsh[4 + 4 * m] += r.w;
+                }
+                const float4 r8 = row[8];
+                gsh[25] += r8.x; gsh[26] += r8.y;
+            }
+        }
         float p[3], sraw[3], q[4], s[3];
         load3(pos, pid, p);
         load3(scale, pid, sraw);
@@ -435,6 +466,10 @@ __global__ void __launch_bounds__(256) frame_project_backward_kernel(
         grad_rgb[pid * 3 + 0] = gcol[0];
         grad_rgb[pid * 3 + 1] = gcol[1];
         grad_rgb[pid * 3 + 2] = gcol[2];
+    } else {  // SH coefficients are raw parameters: the summed rows are the gradient
+        const bool vis = g.z != 0.0f;
+#pragma unroll
+        for (int k = 0; k < 27; ++k) grad_rgb[pid * 27 + k] = vis ? gsh[k] : 0.f;
     }
     (void)rgb;
 }
@@ -552,7 +587,8 @@ int gs_stage_project_backward(const gs_frame *f, const gs_frame_ws &ws, float *g
     int nblk = (int)gs_div_up(f->N, 256);
     hipLaunchKernelGGL(frame_project_backward_kernel, dim3(nblk), dim3(256), 0, stream, f->pos,
                        (const float4 *)f->quat, f->scale, f->rgb, f->N, P, ws.rec_geom, ws.rec_color,
-                       (const float4 *)ws.dgeom, grad_pos, (float4 *)grad_quat, grad_scale, grad_opa, grad_rgb);
+                       (const float4 *)ws.rows, ws.pair_offsets, ws.tiles_touched, (uint64_t)f->max_pairs, grad_pos,
+                       (float4 *)grad_quat, grad_scale, grad_opa, grad_rgb);
     GS_CHECK_LAUNCH();
     return 0;
 }

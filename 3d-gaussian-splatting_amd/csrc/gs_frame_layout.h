@@ -7,6 +7,9 @@ enum { GS_CNT_VISIBLE = 0, GS_CNT_PAIRS = 1, GS_CNT_OVERFLOW = 2, GS_CNT_BUCKETS
 #define GS_BUCKET 64          // Gaussians per backward bucket (= wavefront size)
 #define GS_SORT_TILE 2048     // keys per radix-sort workgroup (256 threads x 8)
 
+// floats per per-pair gradient row: (dx, dy, da, db, dc, dd, dopa) + colour grads, padded to float4s
+static inline int gs_row_floats(int color_dim) { return color_dim == 3 ? 12 : 36; }
+
 struct gs_frame_geom {
     int padW, padH, ntx, nty, n_tiles, crop_top, crop_left;
     float tlx, tly, leftmost, topmost;
@@ -44,6 +47,7 @@ struct gs_frame_ws {
     uint32_t *block_sums;          // [ceil(N/256)] pairs emitted by each 256-Gaussian block
     uint32_t *block_vis;           // [ceil(N/256)] visible Gaussians of each block
     uint32_t *block_offsets;       // [ceil(N/256)]
+    uint32_t *pair_offsets;        // [N] emission offset of each Gaussian's first pair (prefix sum of tiles_touched)
     uint64_t *keys_a, *keys_b;     // [max_pairs]
     uint32_t *vals_a, *vals_b;     // [max_pairs]
     void *sort_tmp;
@@ -53,7 +57,7 @@ struct gs_frame_ws {
     uint32_t *tile_nproc;          // [T] Gaussians processed by the forward (multiple of the chunk)
     uint32_t *bucket_offsets;      // [T+1] exclusive scan of ceil(nproc/64)
     float4 *ckpt;                  // [max_buckets][256] (T, Cr, Cg, Cb) at bucket starts
-    float *dgeom;                  // [N][12]
+    float *rows;                   // [max_pairs][GS_ROW(C)] per-pair gradient rows in EMISSION order
     int64_t max_buckets;
     size_t zero_bytes;             // prefix of the workspace cleared at the start of every frame
     size_t total_bytes;
@@ -85,6 +89,7 @@ static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pair
     ws.block_sums = (uint32_t *)take(sizeof(uint32_t) * nblk);
     ws.block_vis = (uint32_t *)take(sizeof(uint32_t) * nblk);
     ws.block_offsets = (uint32_t *)take(sizeof(uint32_t) * nblk);
+    ws.pair_offsets = (uint32_t *)take(sizeof(uint32_t) * N);
     ws.keys_a = (uint64_t *)take(sizeof(uint64_t) * max_pairs);
     ws.keys_b = (uint64_t *)take(sizeof(uint64_t) * max_pairs);
     ws.vals_a = (uint32_t *)take(sizeof(uint32_t) * max_pairs);
@@ -97,12 +102,12 @@ static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pair
         ws.tile_nproc = (uint32_t *)take(sizeof(uint32_t) * G.n_tiles);
         ws.bucket_offsets = (uint32_t *)take(sizeof(uint32_t) * (G.n_tiles + 1));
         ws.ckpt = (float4 *)take(sizeof(float4) * 256 * (size_t)ws.max_buckets);
-        ws.dgeom = (float *)take(sizeof(float) * 12 * N);
+        ws.rows = (float *)take(sizeof(float) * (size_t)gs_row_floats(color_dim) * max_pairs);
     } else {
         ws.tile_nproc = nullptr;
         ws.bucket_offsets = nullptr;
         ws.ckpt = nullptr;
-        ws.dgeom = nullptr;
+        ws.rows = nullptr;
     }
     ws.total_bytes = off;
     return ws;

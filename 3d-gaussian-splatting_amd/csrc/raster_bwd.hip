@@ -63,9 +63,12 @@ __global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t *__res
 }
 
 struct BwdOut {
-    // FRAME: atomically accumulated per-Gaussian sums
-    float *dgeom;     // [N][12]
-    float *grad_sh;   // [N][27] (SH only)
+    // FRAME: one row per pair, addressed in EMISSION order (pair_offsets[g] + index of the tile
+    // inside g's rectangle), so the per-Gaussian sum is a contiguous, deterministic reduction
+    float *rows;                   // [max_pairs][12 | 36]
+    const uint32_t *pair_offsets;  // [N]
+    const uint2 *rects;            // [N]
+    uint64_t max_pairs;
     // REF: one row per pair
     float *grad_pos, *grad_rgb, *grad_opa, *grad_cov;
 };
@@ -298,22 +301,23 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, Raste
     const float gc = iPn * (Sxy - 2.0f * g.b * Su);
     const float gd = iPn * (-Sxx + 2.0f * g.a * Su);
     if (FRAME) {
-        float *dg = O.dgeom + (size_t)gid * 12;
-        unsafeAtomicAdd(dg + 0, gx);
-        unsafeAtomicAdd(dg + 1, gy);
-        unsafeAtomicAdd(dg + 2, ga);
-        unsafeAtomicAdd(dg + 3, gb);
-        unsafeAtomicAdd(dg + 4, gc);
-        unsafeAtomicAdd(dg + 5, gd);
-        unsafeAtomicAdd(dg + 6, Sopa);
-        if (CDIM == 3) {
-            unsafeAtomicAdd(dg + 7, Sc0);
-            unsafeAtomicAdd(dg + 8, Sc1);
-            unsafeAtomicAdd(dg + 9, Sc2);
-        } else {
-            float *gs = O.grad_sh + (size_t)gid * 27;
+        const uint2 rc = O.rects[gid];
+        const uint32_t y0 = rc.x & 0xffff, x0 = rc.y & 0xffff, x1 = rc.y >> 16;
+        const uint64_t slot = (uint64_t)O.pair_offsets[gid] + (ty - y0) * (x1 - x0) + (tx - x0);
+        if (slot < O.max_pairs) {
+            constexpr int RW = CDIM == 3 ? 12 : 36;
+            float4 *row = reinterpret_cast<float4 *>(O.rows + slot * RW);
+            row[0] = make_float4(gx, gy, ga, gb);
+            if (CDIM == 3) {
+                row[1] = make_float4(gc, gd, Sopa, Sc0);
+                row[2] = make_float4(Sc1, Sc2, 0.f, 0.f);
+            } else {
+                row[1] = make_float4(gc, gd, Sopa, Ssh[0]);
 #pragma unroll
-            for (int k = 0; k < 27; ++k) unsafeAtomicAdd(gs + k, Ssh[k]);
+                for (int k = 0; k < 6; ++k)
+                    row[2 + k] = make_float4(Ssh[1 + 4 * k], Ssh[2 + 4 * k], Ssh[3 + 4 * k], Ssh[4 + 4 * k]);
+                row[8] = make_float4(Ssh[25], Ssh[26], 0.f, 0.f);
+            }
         }
     } else {
         O.grad_pos[(size_t)j * 3 + 0] = gx;
@@ -429,7 +433,7 @@ extern "C" int gs_draw_backward(const float *pos, const float *rgb, const float 
                        ws.bucket_offsets, ws.n_buckets);
     // 3. systolic backward, one wave per bucket, one output row per pair
     BwdIn I = {output, grad_output, ws.ckpt, ws.tile_nproc, ws.bucket_offsets, tile_n_point_accum};
-    BwdOut O = {nullptr, nullptr, grad_pos, grad_rgb, grad_opa, grad_cov};
+    BwdOut O = {nullptr, nullptr, nullptr, 0, grad_pos, grad_rgb, grad_opa, grad_cov};
     if (use_sh_coeff)
         launch_bwd<27, false>(S, G, I, O, ws.max_buckets, s);
     else
@@ -464,12 +468,13 @@ int gs_stage_raster_backward(const gs_frame *f, const gs_frame_ws &ws, const uin
         G.vdx[i] = f->vec_dx[i];
         G.vdy[i] = f->vec_dy[i];
     }
-    GS_HIP(hipMemsetAsync(ws.dgeom, 0, sizeof(float) * 12 * (size_t)f->N, stream));
-    if (f->color_dim == 27) GS_HIP(hipMemsetAsync(grad_rgb, 0, sizeof(float) * 27 * (size_t)f->N, stream));
+    // rows of pairs the forward never reached (early termination) must read as zero
+    GS_HIP(hipMemsetAsync(ws.rows, 0, sizeof(float) * (size_t)gs_row_floats(f->color_dim) * f->max_pairs, stream));
+    (void)grad_rgb;
     hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, ws.tile_nproc, FG.n_tiles,
                        ws.bucket_offsets, ws.counters + GS_CNT_BUCKETS);
     BwdIn I = {f->image_padded, grad_image, ws.ckpt, ws.tile_nproc, ws.bucket_offsets, ws.tile_ranges};
-    BwdOut O = {ws.dgeom, grad_rgb, nullptr, nullptr, nullptr, nullptr};
+    BwdOut O = {ws.rows, ws.pair_offsets, ws.rects, (uint64_t)f->max_pairs, nullptr, nullptr, nullptr, nullptr};
     if (f->color_dim == 27)
         launch_bwd<27, true>(S, G, I, O, ws.max_buckets, stream);
     else

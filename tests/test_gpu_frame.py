@@ -150,3 +150,17 @@ def test_frame_repeatable_bitwise(gpu, sort_mode):
     a = r.forward(*p, cam)[0].clone()
     b = r.forward(*p, cam)[0].clone()
     assert torch.equal(a, b)  # forward is deterministic (no atomics on the data path)
+
+
+def test_frame_backward_repeatable_bitwise(gpu):
+    """No atomics anywhere on the gradient path: two backward passes give identical bits."""
+    scene, cam = case(15_000, 160, 112, seed=21)
+    gimg = torch.from_numpy(np.random.default_rng(6).normal(size=(112, 160, 3)).astype(np.float32)).to(gpu)
+    grads = []
+    for _ in range(2):
+        params = to_torch(scene, gpu, requires_grad=True)
+        r = FrameRenderer(gpu, max_pairs=1 << 17, training=True, auto_grow=False)
+        r.render(*params, cam).backward(gimg)
+        grads.append([t.grad.clone() for t in params])
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
