@@ -18,14 +18,17 @@
 
 namespace {
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 template <int CDIM>
 struct FwdSmem;
 template <>
 struct FwdSmem<3> {
+    // structure of arrays: four consecutive Gaussians of one field are one ds_read_b128, and two
+    // consecutive ones sit in an even/odd register pair -- the operand shape of v_pk_*_f32
     static constexpr int CH = 256;
-    float4 a[2][CH];  // x, y, A, B
-    float4 b[2][CH];  // C, opacity, r, g
-    float c[2][CH];   // b
+    enum { X, Y, A, B, C, OPA, R, G, BL, NFIELD };
+    float f[2][NFIELD][CH] __attribute__((aligned(16)));
     int done[2][4];
 };
 template <>
@@ -61,6 +64,8 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(RasterSrc S, Raster
     if (CDIM == 27) raster_pixel_sh(id_x, id_y, G, SH);
 
     float T = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, accw = 0.f;
+    f2 cr2 = {0.f, 0.f}, cg2 = {0.f, 0.f}, cb2 = {0.f, 0.f};  // even/odd partial colours of the packed path
+    const f2 px2 = {px, px}, py2 = {py, py};
     bool wave_done = false;
     uint32_t nproc = 0;
 
@@ -77,7 +82,8 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(RasterSrc S, Raster
         }
     };
     auto write_ckpt = [&](uint32_t idx_in_tile) {
-        ckpt[raster_ckpt_slot(start, tile, idx_in_tile / GS_BUCKET) * 256 + p] = make_float4(T, cr, cg, cb);
+        ckpt[raster_ckpt_slot(start, tile, idx_in_tile / GS_BUCKET) * 256 + p] =
+            make_float4(T, cr + cr2.x + cr2.y, cg + cg2.x + cg2.y, cb + cb2.x + cb2.y);
     };
 
     fetch(0);
@@ -90,11 +96,18 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(RasterSrc S, Raster
             float opa = g.opa;
             if (SIG)  // gaussian.cu:918: (1.0/2*3.1415926536) * rsqrtf(det + 1e-7), folded into opacity
                 opa *= 1.5707963268f * rsqrtf(raster_det(g.a, g.b, g.c, g.d) + 1e-7f);
-            sm.a[buf][p] = make_float4(g.x, g.y, A, B);
             if constexpr (CDIM == 3) {
-                sm.b[buf][p] = make_float4(C, opa, r0, r1);
-                sm.c[buf][p] = r2;
+                sm.f[buf][SM::X][p] = g.x;
+                sm.f[buf][SM::Y][p] = g.y;
+                sm.f[buf][SM::A][p] = A;
+                sm.f[buf][SM::B][p] = B;
+                sm.f[buf][SM::C][p] = C;
+                sm.f[buf][SM::OPA][p] = opa;
+                sm.f[buf][SM::R][p] = r0;
+                sm.f[buf][SM::G][p] = r1;
+                sm.f[buf][SM::BL][p] = r2;
             } else {
+                sm.a[buf][p] = make_float4(g.x, g.y, A, B);
                 sm.b[buf][p] = make_float4(C, opa, 0.f, 0.f);
                 const float *src = raster_sh_ptr<FRAME>(S, start + base + p, gid);
 #pragma unroll
@@ -102,11 +115,12 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(RasterSrc S, Raster
             }
         } else if ((uint32_t)p < (uint32_t)CH && base + p < ((n + 3u) & ~3u)) {
             // pad the ragged tail to a multiple of 4 with null Gaussians (opacity 0 => alpha 0)
-            sm.a[buf][p] = make_float4(0.f, 0.f, 0.f, 0.f);
-            sm.b[buf][p] = make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (CDIM == 3) {
-                sm.c[buf][p] = 0.f;
+#pragma unroll
+                for (int k = 0; k < SM::NFIELD; ++k) sm.f[buf][k][p] = 0.f;
             } else {
+                sm.a[buf][p] = make_float4(0.f, 0.f, 0.f, 0.f);
+                sm.b[buf][p] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int q = 0; q < 27; ++q) sm.sh[buf][p][q] = 0.f;
             }
@@ -127,23 +141,55 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(RasterSrc S, Raster
                     wave_done = true;
                     break;
                 }
+                if constexpr (CDIM == 3) {
+                    // two Gaussians per packed instruction (v_pk_add/mul/fma_f32); the transmittance
+                    // recurrence and the per-pixel liveness test stay scalar and in order
+                    auto ld4 = [&](int k) {
+                        return *(const float4 *)__builtin_assume_aligned(&sm.f[buf][k][i], 16);
+                    };
+                    const float4 X = ld4(SM::X), Y = ld4(SM::Y), A4 = ld4(SM::A), B4 = ld4(SM::B), C4 = ld4(SM::C);
+                    const float4 O4 = ld4(SM::OPA), R4 = ld4(SM::R), G4 = ld4(SM::G), L4 = ld4(SM::BL);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float4 ga = sm.a[buf][i + u], gb = sm.b[buf][i + u];
-                    const float dx = px - ga.x, dy = py - ga.y;
-                    float t = ga.z * dx;
-                    t = fmaf(-ga.w, dy, t);  // A dx - B dy
-                    float q = dx * t;
-                    q = fmaf(gb.x * dy, dy, q);  // + C dy^2
-                    float alpha = gs_exp2(-q) * gb.y;
-                    if (SIG) alpha = 2.0f / (__expf(-alpha) + 1.0f) - 1.0f;  // gaussian.cu:930
-                    alpha = (T > GS_T_STOP) ? alpha : 0.0f;
-                    const float wgt = alpha * T;
-                    if constexpr (CDIM == 3) {
-                        cr = fmaf(gb.z, wgt, cr);
-                        cg = fmaf(gb.w, wgt, cg);
-                        cb = fmaf(sm.c[buf][i + u], wgt, cb);
-                    } else {
+                    for (int h = 0; h < 2; ++h) {
+                        const f2 gx = h ? f2{X.z, X.w} : f2{X.x, X.y}, gy = h ? f2{Y.z, Y.w} : f2{Y.x, Y.y};
+                        const f2 cA = h ? f2{A4.z, A4.w} : f2{A4.x, A4.y}, cB = h ? f2{B4.z, B4.w} : f2{B4.x, B4.y};
+                        const f2 cC = h ? f2{C4.z, C4.w} : f2{C4.x, C4.y}, op = h ? f2{O4.z, O4.w} : f2{O4.x, O4.y};
+                        const f2 dx = px2 - gx, dy = py2 - gy;
+                        f2 t = __builtin_elementwise_fma(-cB, dy, cA * dx);  // A dx - B dy
+                        f2 q = __builtin_elementwise_fma(cC * dy, dy, dx * t);  // + C dy^2
+                        f2 al;
+                        al.x = gs_exp2(-q.x);
+                        al.y = gs_exp2(-q.y);
+                        al = al * op;
+                        if (SIG) {  // gaussian.cu:930
+                            al.x = 2.0f / (__expf(-al.x) + 1.0f) - 1.0f;
+                            al.y = 2.0f / (__expf(-al.y) + 1.0f) - 1.0f;
+                        }
+                        f2 w;
+                        const float a0 = (T > GS_T_STOP) ? al.x : 0.0f;
+                        w.x = a0 * T;
+                        T = fmaf(-a0, T, T);  // T * (1 - alpha)
+                        const float a1 = (T > GS_T_STOP) ? al.y : 0.0f;
+                        w.y = a1 * T;
+                        T = fmaf(-a1, T, T);
+                        cr2 = __builtin_elementwise_fma(h ? f2{R4.z, R4.w} : f2{R4.x, R4.y}, w, cr2);
+                        cg2 = __builtin_elementwise_fma(h ? f2{G4.z, G4.w} : f2{G4.x, G4.y}, w, cg2);
+                        cb2 = __builtin_elementwise_fma(h ? f2{L4.z, L4.w} : f2{L4.x, L4.y}, w, cb2);
+                        if (WN) accw += w.x + w.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float4 ga = sm.a[buf][i + u], gb = sm.b[buf][i + u];
+                        const float dx = px - ga.x, dy = py - ga.y;
+                        float t = ga.z * dx;
+                        t = fmaf(-ga.w, dy, t);  // A dx - B dy
+                        float q = dx * t;
+                        q = fmaf(gb.x * dy, dy, q);  // + C dy^2
+                        float alpha = gs_exp2(-q) * gb.y;
+                        if (SIG) alpha = 2.0f / (__expf(-alpha) + 1.0f) - 1.0f;  // gaussian.cu:930
+                        alpha = (T > GS_T_STOP) ? alpha : 0.0f;
+                        const float wgt = alpha * T;
                         const float *co = sm.sh[buf][i + u];
                         float v0 = 0.f, v1 = 0.f, v2 = 0.f;
 #pragma unroll
@@ -155,9 +201,9 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(RasterSrc S, Raster
                         cr = fmaf(wgt, gs_rcp(1.0f + __expf(-v0)), cr);
                         cg = fmaf(wgt, gs_rcp(1.0f + __expf(-v1)), cg);
                         cb = fmaf(wgt, gs_rcp(1.0f + __expf(-v2)), cb);
+                        if (WN) accw += wgt;
+                        T = fmaf(-alpha, T, T);  // T * (1 - alpha)
                     }
-                    if (WN) accw += wgt;
-                    T = fmaf(-alpha, T, T);  // T * (1 - alpha)
                 }
             }
         }
@@ -166,6 +212,9 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(RasterSrc S, Raster
     if (tile_nproc && p == 0) tile_nproc[tile] = nproc;
 
     if (!WN || accw < 0.01f) accw = 1.0f;  // gaussian.cu:964-969
+    cr += cr2.x + cr2.y;
+    cg += cg2.x + cg2.y;
+    cb += cb2.x + cb2.y;
     const float o0 = cr / accw, o1 = cg / accw, o2 = cb / accw;
     if (out_padded) {
         float *o = out_padded + ((size_t)id_y * G.padW + id_x) * 3;
