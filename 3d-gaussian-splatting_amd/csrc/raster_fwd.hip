@@ -1,7 +1,7 @@
 // raster_fwd.hip -- 16x16-tile front-to-back alpha compositing, forward.
 //
-// Replaces draw_kernel (gaussian.cu:806-970).  One 256-thread workgroup (4 wave64) per tile,
-// one pixel per lane (wave w owns pixel rows 4w..4w+3 of the tile).  The tile's sorted
+// Replaces draw_kernel (gaussian.cu:806-970).  One 128-thread workgroup (2 wave64) per tile,
+// two pixels per lane (wave w owns pixel rows 8w..8w+7 of the tile).  The tile's sorted
 // Gaussian list is streamed through LDS in chunks with a two-deep ring: every thread gathers
 // one Gaussian of the NEXT chunk from HBM/L2 into registers while the waves composite the
 // current chunk out of LDS (broadcast ds_read_b128), so a chunk costs a single barrier.
@@ -20,33 +20,42 @@ namespace {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
+constexpr int FWD_THREADS = 128;  // 2 wave64 per 16x16 tile, 2 pixels per lane
+
 template <int CDIM>
 struct FwdSmem;
 template <>
 struct FwdSmem<3> {
-    // structure of arrays: four consecutive Gaussians of one field are one ds_read_b128, and two
-    // consecutive ones sit in an even/odd register pair -- the operand shape of v_pk_*_f32
-    static constexpr int CH = 256;
+    // structure of arrays: four consecutive Gaussians of one field are one ds_read_b128
+    static constexpr int CH = 128;
     enum { X, Y, A, B, C, OPA, R, G, BL, NFIELD };
     float f[2][NFIELD][CH] __attribute__((aligned(16)));
-    int done[2][4];
+    int done[2][2];
 };
 template <>
 struct FwdSmem<27> {
     static constexpr int CH = 64;
-    float4 a[2][CH];
-    float4 b[2][CH];  // C, opacity, -, -
-    float sh[2][CH][28];
-    int done[2][4];
+    enum { X, Y, A, B, C, OPA, NFIELD };
+    float f[2][NFIELD][CH] __attribute__((aligned(16)));
+    float sh[2][CH][28] __attribute__((aligned(16)));
+    int done[2][2];
 };
 
+__device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// Lane l of wave w owns pixels (x, yA) and (x, yA + 4) of the tile, x = l & 15, yA = 8 w + (l >> 4):
+// every broadcast LDS read of a Gaussian now feeds 128 pixel evaluations per wave instead of 64
+// (the one-pixel-per-lane version was LDS-issue bound: 9 ds_read_b128 per 4 Gaussians per wave),
+// and the fp32 math is packed over the PIXEL pair (v_pk_*_f32; dx is shared), including the
+// transmittance recurrence.  Pixel index inside the tile: pA = 128 w + l, pB = pA + 64.
 template <int CDIM, bool FRAME, bool CKPT, bool SIG, bool WN>
-__global__ void __launch_bounds__(256) raster_forward_kernel(RasterSrc S, RasterGeom G,
-                                                            const int32_t *__restrict__ ranges,
-                                                            float *__restrict__ out_padded,
-                                                            float *__restrict__ out_image,
-                                                            float4 *__restrict__ ckpt,
-                                                            uint32_t *__restrict__ tile_nproc) {
+__global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S, RasterGeom G,
+                                                                    const int32_t *__restrict__ ranges,
+                                                                    float *__restrict__ out_padded,
+                                                                    float *__restrict__ out_image,
+                                                                    float4 *__restrict__ ckpt,
+                                                                    uint32_t *__restrict__ tile_nproc) {
     using SM = FwdSmem<CDIM>;
     constexpr int CH = SM::CH;
     __shared__ SM sm;
@@ -57,19 +66,24 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(RasterSrc S, Raster
     const uint32_t end = (uint32_t)(FRAME ? ranges[2 * tile + 1] : ranges[tile + 1]);
     const uint32_t n = end - start;
     const int p = threadIdx.x, wave = p >> 6, lane = p & 63;
-    const uint32_t id_x = tx * 16 + (p & 15), id_y = ty * 16 + (p >> 4);
+    const int pA = wave * 128 + lane, pB = pA + 64;
+    const uint32_t id_x = tx * 16 + (lane & 15), id_yA = ty * 16 + wave * 8 + (lane >> 4), id_yB = id_yA + 4;
     const float px = raster_pixel_coord(id_x, G.padW, G.focal_x);
-    const float py = raster_pixel_coord(id_y, G.padH, G.focal_y);
-    float SH[9];
-    if (CDIM == 27) raster_pixel_sh(id_x, id_y, G, SH);
+    const f2 py2 = {raster_pixel_coord(id_yA, G.padH, G.focal_y), raster_pixel_coord(id_yB, G.padH, G.focal_y)};
+    f2 SH[9];
+    if (CDIM == 27) {
+        float a9[9], b9[9];
+        raster_pixel_sh(id_x, id_yA, G, a9);
+        raster_pixel_sh(id_x, id_yB, G, b9);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) SH[k] = f2{a9[k], b9[k]};
+    }
 
-    float T = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, accw = 0.f;
-    f2 cr2 = {0.f, 0.f}, cg2 = {0.f, 0.f}, cb2 = {0.f, 0.f};  // even/odd partial colours of the packed path
-    const f2 px2 = {px, px}, py2 = {py, py};
+    f2 T = {1.0f, 1.0f}, cr = {0.f, 0.f}, cg = {0.f, 0.f}, cb = {0.f, 0.f}, accw = {0.f, 0.f};
     bool wave_done = false;
     uint32_t nproc = 0;
 
-    // register stage for the next chunk
+    // register stage for the next chunk (one Gaussian per thread)
     GaussianRec g;
     float r0 = 0, r1 = 0, r2 = 0;
     uint32_t gid = 0;
@@ -82,8 +96,9 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(RasterSrc S, Raster
         }
     };
     auto write_ckpt = [&](uint32_t idx_in_tile) {
-        ckpt[raster_ckpt_slot(start, tile, idx_in_tile / GS_BUCKET) * 256 + p] =
-            make_float4(T, cr + cr2.x + cr2.y, cg + cg2.x + cg2.y, cb + cb2.x + cb2.y);
+        float4 *c = ckpt + raster_ckpt_slot(start, tile, idx_in_tile / GS_BUCKET) * 256;
+        c[pA] = make_float4(T.x, cr.x, cg.x, cb.x);
+        c[pB] = make_float4(T.y, cr.y, cg.y, cb.y);
     };
 
     fetch(0);
@@ -96,38 +111,33 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(RasterSrc S, Raster
             float opa = g.opa;
             if (SIG)  // gaussian.cu:918: (1.0/2*3.1415926536) * rsqrtf(det + 1e-7), folded into opacity
                 opa *= 1.5707963268f * rsqrtf(raster_det(g.a, g.b, g.c, g.d) + 1e-7f);
+            sm.f[buf][SM::X][p] = g.x;
+            sm.f[buf][SM::Y][p] = g.y;
+            sm.f[buf][SM::A][p] = A;
+            sm.f[buf][SM::B][p] = B;
+            sm.f[buf][SM::C][p] = C;
+            sm.f[buf][SM::OPA][p] = opa;
             if constexpr (CDIM == 3) {
-                sm.f[buf][SM::X][p] = g.x;
-                sm.f[buf][SM::Y][p] = g.y;
-                sm.f[buf][SM::A][p] = A;
-                sm.f[buf][SM::B][p] = B;
-                sm.f[buf][SM::C][p] = C;
-                sm.f[buf][SM::OPA][p] = opa;
                 sm.f[buf][SM::R][p] = r0;
                 sm.f[buf][SM::G][p] = r1;
                 sm.f[buf][SM::BL][p] = r2;
             } else {
-                sm.a[buf][p] = make_float4(g.x, g.y, A, B);
-                sm.b[buf][p] = make_float4(C, opa, 0.f, 0.f);
                 const float *src = raster_sh_ptr<FRAME>(S, start + base + p, gid);
 #pragma unroll
                 for (int q = 0; q < 27; ++q) sm.sh[buf][p][q] = src[q];
             }
         } else if ((uint32_t)p < (uint32_t)CH && base + p < ((n + 3u) & ~3u)) {
             // pad the ragged tail to a multiple of 4 with null Gaussians (opacity 0 => alpha 0)
-            if constexpr (CDIM == 3) {
 #pragma unroll
-                for (int k = 0; k < SM::NFIELD; ++k) sm.f[buf][k][p] = 0.f;
-            } else {
-                sm.a[buf][p] = make_float4(0.f, 0.f, 0.f, 0.f);
-                sm.b[buf][p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = 0; q < SM::NFIELD; ++q) sm.f[buf][q][p] = 0.f;
+            if constexpr (CDIM == 27) {
 #pragma unroll
                 for (int q = 0; q < 27; ++q) sm.sh[buf][p][q] = 0.f;
             }
         }
         if (lane == 0) sm.done[buf][wave] = wave_done ? 1 : 0;
         __syncthreads();
-        if (sm.done[buf][0] & sm.done[buf][1] & sm.done[buf][2] & sm.done[buf][3]) break;
+        if (sm.done[buf][0] & sm.done[buf][1]) break;
         fetch(base + CH);  // overlaps with the compositing below
         const uint32_t cnt = (n - base) < (uint32_t)CH ? (n - base) : (uint32_t)CH;
         for (uint32_t sub = 0; sub < cnt; sub += GS_BUCKET) {
@@ -137,73 +147,64 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(RasterSrc S, Raster
             // groups of 4 Gaussians: one wave-uniform liveness test per group, per-pixel masking
             // inside (exactly the reference's per-pixel `accum < 0.0001` test, gaussian.cu:906)
             for (uint32_t i = sub; i < lim; i += 4) {
-                if (__ballot(T > GS_T_STOP) == 0ull) {
+                if (__ballot(T.x > GS_T_STOP || T.y > GS_T_STOP) == 0ull) {
                     wave_done = true;
                     break;
                 }
+                auto ld4 = [&](int q) { return *(const float4 *)__builtin_assume_aligned(&sm.f[buf][q][i], 16); };
+                const float4 X = ld4(SM::X), Y = ld4(SM::Y), A4 = ld4(SM::A), B4 = ld4(SM::B), C4 = ld4(SM::C);
+                const float4 O4 = ld4(SM::OPA);
+                float4 R4, G4, L4;
                 if constexpr (CDIM == 3) {
-                    // two Gaussians per packed instruction (v_pk_add/mul/fma_f32); the transmittance
-                    // recurrence and the per-pixel liveness test stay scalar and in order
-                    auto ld4 = [&](int k) {
-                        return *(const float4 *)__builtin_assume_aligned(&sm.f[buf][k][i], 16);
-                    };
-                    const float4 X = ld4(SM::X), Y = ld4(SM::Y), A4 = ld4(SM::A), B4 = ld4(SM::B), C4 = ld4(SM::C);
-                    const float4 O4 = ld4(SM::OPA), R4 = ld4(SM::R), G4 = ld4(SM::G), L4 = ld4(SM::BL);
+                    R4 = ld4(SM::R);
+                    G4 = ld4(SM::G);
+                    L4 = ld4(SM::BL);
+                }
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const f2 gx = h ? f2{X.z, X.w} : f2{X.x, X.y}, gy = h ? f2{Y.z, Y.w} : f2{Y.x, Y.y};
-                        const f2 cA = h ? f2{A4.z, A4.w} : f2{A4.x, A4.y}, cB = h ? f2{B4.z, B4.w} : f2{B4.x, B4.y};
-                        const f2 cC = h ? f2{C4.z, C4.w} : f2{C4.x, C4.y}, op = h ? f2{O4.z, O4.w} : f2{O4.x, O4.y};
-                        const f2 dx = px2 - gx, dy = py2 - gy;
-                        f2 t = __builtin_elementwise_fma(-cB, dy, cA * dx);  // A dx - B dy
-                        f2 q = __builtin_elementwise_fma(cC * dy, dy, dx * t);  // + C dy^2
-                        f2 al;
-                        al.x = gs_exp2(-q.x);
-                        al.y = gs_exp2(-q.y);
-                        al = al * op;
-                        if (SIG) {  // gaussian.cu:930
-                            al.x = 2.0f / (__expf(-al.x) + 1.0f) - 1.0f;
-                            al.y = 2.0f / (__expf(-al.y) + 1.0f) - 1.0f;
-                        }
-                        f2 w;
-                        const float a0 = (T > GS_T_STOP) ? al.x : 0.0f;
-                        w.x = a0 * T;
-                        T = fmaf(-a0, T, T);  // T * (1 - alpha)
-                        const float a1 = (T > GS_T_STOP) ? al.y : 0.0f;
-                        w.y = a1 * T;
-                        T = fmaf(-a1, T, T);
-                        cr2 = __builtin_elementwise_fma(h ? f2{R4.z, R4.w} : f2{R4.x, R4.y}, w, cr2);
-                        cg2 = __builtin_elementwise_fma(h ? f2{G4.z, G4.w} : f2{G4.x, G4.y}, w, cg2);
-                        cb2 = __builtin_elementwise_fma(h ? f2{L4.z, L4.w} : f2{L4.x, L4.y}, w, cb2);
-                        if (WN) accw += w.x + w.y;
+                for (int u = 0; u < 4; ++u) {
+                    const float gx = u == 0 ? X.x : u == 1 ? X.y : u == 2 ? X.z : X.w;
+                    const float gy = u == 0 ? Y.x : u == 1 ? Y.y : u == 2 ? Y.z : Y.w;
+                    const float cA = u == 0 ? A4.x : u == 1 ? A4.y : u == 2 ? A4.z : A4.w;
+                    const float cB = u == 0 ? B4.x : u == 1 ? B4.y : u == 2 ? B4.z : B4.w;
+                    const float cC = u == 0 ? C4.x : u == 1 ? C4.y : u == 2 ? C4.z : C4.w;
+                    const float op = u == 0 ? O4.x : u == 1 ? O4.y : u == 2 ? O4.z : O4.w;
+                    const float dx = px - gx;
+                    const f2 dy = py2 - splat(gy);
+                    const f2 t = pk_fma(splat(-cB), dy, splat(cA * dx));    // A dx - B dy
+                    const f2 q = pk_fma(splat(cC) * dy, dy, splat(dx) * t);  // + C dy^2
+                    f2 al;
+                    al.x = gs_exp2(-q.x);
+                    al.y = gs_exp2(-q.y);
+                    al = al * splat(op);
+                    if (SIG) {  // gaussian.cu:930
+                        al.x = 2.0f / (__expf(-al.x) + 1.0f) - 1.0f;
+                        al.y = 2.0f / (__expf(-al.y) + 1.0f) - 1.0f;
                     }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const float4 ga = sm.a[buf][i + u], gb = sm.b[buf][i + u];
-                        const float dx = px - ga.x, dy = py - ga.y;
-                        float t = ga.z * dx;
-                        t = fmaf(-ga.w, dy, t);  // A dx - B dy
-                        float q = dx * t;
-                        q = fmaf(gb.x * dy, dy, q);  // + C dy^2
-                        float alpha = gs_exp2(-q) * gb.y;
-                        if (SIG) alpha = 2.0f / (__expf(-alpha) + 1.0f) - 1.0f;  // gaussian.cu:930
-                        alpha = (T > GS_T_STOP) ? alpha : 0.0f;
-                        const float wgt = alpha * T;
+                    al.x = (T.x > GS_T_STOP) ? al.x : 0.0f;
+                    al.y = (T.y > GS_T_STOP) ? al.y : 0.0f;
+                    const f2 w = al * T;
+                    if constexpr (CDIM == 3) {
+                        cr = pk_fma(splat(u == 0 ? R4.x : u == 1 ? R4.y : u == 2 ? R4.z : R4.w), w, cr);
+                        cg = pk_fma(splat(u == 0 ? G4.x : u == 1 ? G4.y : u == 2 ? G4.z : G4.w), w, cg);
+                        cb = pk_fma(splat(u == 0 ? L4.x : u == 1 ? L4.y : u == 2 ? L4.z : L4.w), w, cb);
+                    } else {
                         const float *co = sm.sh[buf][i + u];
-                        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+                        f2 v0 = {0.f, 0.f}, v1 = {0.f, 0.f}, v2 = {0.f, 0.f};
 #pragma unroll
                         for (int k9 = 0; k9 < 9; ++k9) {
-                            v0 = fmaf(SH[k9], co[k9], v0);
-                            v1 = fmaf(SH[k9], co[9 + k9], v1);
-                            v2 = fmaf(SH[k9], co[18 + k9], v2);
+                            v0 = pk_fma(SH[k9], splat(co[k9]), v0);
+                            v1 = pk_fma(SH[k9], splat(co[9 + k9]), v1);
+                            v2 = pk_fma(SH[k9], splat(co[18 + k9]), v2);
                         }
-                        cr = fmaf(wgt, gs_rcp(1.0f + __expf(-v0)), cr);
-                        cg = fmaf(wgt, gs_rcp(1.0f + __expf(-v1)), cg);
-                        cb = fmaf(wgt, gs_rcp(1.0f + __expf(-v2)), cb);
-                        if (WN) accw += wgt;
-                        T = fmaf(-alpha, T, T);  // T * (1 - alpha)
+                        const f2 c0 = {gs_rcp(1.0f + __expf(-v0.x)), gs_rcp(1.0f + __expf(-v0.y))};
+                        const f2 c1 = {gs_rcp(1.0f + __expf(-v1.x)), gs_rcp(1.0f + __expf(-v1.y))};
+                        const f2 c2 = {gs_rcp(1.0f + __expf(-v2.x)), gs_rcp(1.0f + __expf(-v2.y))};
+                        cr = pk_fma(w, c0, cr);
+                        cg = pk_fma(w, c1, cg);
+                        cb = pk_fma(w, c2, cb);
                     }
+                    if (WN) accw += w;
+                    T = pk_fma(-al, T, T);  // T * (1 - alpha)
                 }
             }
         }
@@ -211,24 +212,26 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(RasterSrc S, Raster
     }
     if (tile_nproc && p == 0) tile_nproc[tile] = nproc;
 
-    if (!WN || accw < 0.01f) accw = 1.0f;  // gaussian.cu:964-969
-    cr += cr2.x + cr2.y;
-    cg += cg2.x + cg2.y;
-    cb += cb2.x + cb2.y;
-    const float o0 = cr / accw, o1 = cg / accw, o2 = cb / accw;
-    if (out_padded) {
-        float *o = out_padded + ((size_t)id_y * G.padW + id_x) * 3;
-        o[0] = o0;
-        o[1] = o1;
-        o[2] = o2;
-    }
-    if (out_image) {  // clamp + centred crop (splatter.py:652-653, 267-272)
-        const int ox = (int)id_x - G.crop_left, oy = (int)id_y - G.crop_top;
-        if (ox >= 0 && ox < G.width && oy >= 0 && oy < G.height) {
-            float *o = out_image + ((size_t)oy * G.width + ox) * 3;
-            o[0] = fminf(fmaxf(o0, 0.f), 1.f);
-            o[1] = fminf(fmaxf(o1, 0.f), 1.f);
-            o[2] = fminf(fmaxf(o2, 0.f), 1.f);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const uint32_t id_y = h ? id_yB : id_yA;
+        float aw = h ? accw.y : accw.x;
+        if (!WN || aw < 0.01f) aw = 1.0f;  // gaussian.cu:964-969
+        const float o0 = (h ? cr.y : cr.x) / aw, o1 = (h ? cg.y : cg.x) / aw, o2 = (h ? cb.y : cb.x) / aw;
+        if (out_padded) {
+            float *o = out_padded + ((size_t)id_y * G.padW + id_x) * 3;
+            o[0] = o0;
+            o[1] = o1;
+            o[2] = o2;
+        }
+        if (out_image) {  // clamp + centred crop (splatter.py:652-653, 267-272)
+            const int ox = (int)id_x - G.crop_left, oy = (int)id_y - G.crop_top;
+            if (ox >= 0 && ox < G.width && oy >= 0 && oy < G.height) {
+                float *o = out_image + ((size_t)oy * G.width + ox) * 3;
+                o[0] = fminf(fmaxf(o0, 0.f), 1.f);
+                o[1] = fminf(fmaxf(o1, 0.f), 1.f);
+                o[2] = fminf(fmaxf(o2, 0.f), 1.f);
+            }
         }
     }
 }
@@ -237,10 +240,10 @@ template <int CDIM, bool FRAME, bool CKPT, bool SIG>
 void launch_fwd(const RasterSrc &S, const RasterGeom &G, const int32_t *ranges, float *out_padded, float *out_image,
                 float4 *ckpt, uint32_t *tile_nproc, int wn, hipStream_t stream) {
     if (wn)
-        hipLaunchKernelGGL((raster_forward_kernel<CDIM, FRAME, CKPT, SIG, true>), dim3(G.ntx * G.nty), dim3(256), 0,
+        hipLaunchKernelGGL((raster_forward_kernel<CDIM, FRAME, CKPT, SIG, true>), dim3(G.ntx * G.nty), dim3(FWD_THREADS), 0,
                            stream, S, G, ranges, out_padded, out_image, ckpt, tile_nproc);
     else
-        hipLaunchKernelGGL((raster_forward_kernel<CDIM, FRAME, CKPT, SIG, false>), dim3(G.ntx * G.nty), dim3(256), 0,
+        hipLaunchKernelGGL((raster_forward_kernel<CDIM, FRAME, CKPT, SIG, false>), dim3(G.ntx * G.nty), dim3(FWD_THREADS), 0,
                            stream, S, G, ranges, out_padded, out_image, ckpt, tile_nproc);
 }
 
