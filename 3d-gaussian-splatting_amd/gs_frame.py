@@ -52,6 +52,7 @@ class FrameRenderer:
         self._ws: Optional[torch.Tensor] = None
         self._stats_host = torch.zeros(4, dtype=torch.int64).pin_memory()
         self._frame: Optional[_lib.GsFrame] = None
+        self._cam_cache = {}
         self._keep = None
 
     # ------------------------------------------------------------------ frame descriptor
@@ -66,25 +67,39 @@ class FrameRenderer:
                 raise RuntimeError(f"{name} must be a contiguous float32 HIP tensor")
             if t.shape[0] != n or (cols is not None and (t.dim() != 2 or t.shape[1] != cols)):
                 raise RuntimeError(f"{name} has shape {tuple(t.shape)}, expected [{n},{cols}]")
-        grid = TileGrid(int(camera.width), int(camera.height), float(camera.focal_x), float(camera.focal_y))
-        half_w, half_h = grid.frustum_half_extents()
-        rays = RayBasis.from_camera(camera.rot, camera.tran, grid.padded_height, grid.padded_width, grid.focal_x,
-                                    grid.focal_y)
+        # per-camera constants (tile grid, frustum guard band, ray basis) are cached: a viewer or a
+        # trainer cycles through a fixed set of cameras, and this host work (a 3x3 inverse, ~40
+        # ctypes stores) would otherwise cost more than the launches themselves
+        ck = (id(camera), int(camera.width), int(camera.height), float(camera.focal_x), float(camera.focal_y),
+              float(camera.near), np.asarray(camera.rot, np.float32).tobytes(),
+              np.asarray(camera.tran, np.float32).tobytes())
+        cached = self._cam_cache.get(ck)
+        if cached is None:
+            grid = TileGrid(int(camera.width), int(camera.height), float(camera.focal_x), float(camera.focal_y))
+            half_w, half_h = grid.frustum_half_extents()
+            rays = RayBasis.from_camera(camera.rot, camera.tran, grid.padded_height, grid.padded_width, grid.focal_x,
+                                        grid.focal_y)
+            c = _lib.GsFrame()
+            c.rot = (C.c_float * 9)(*np.asarray(camera.rot, np.float32).reshape(9))
+            c.tran = (C.c_float * 3)(*np.asarray(camera.tran, np.float32).reshape(3))
+            c.near_plane, c.half_width, c.half_height = float(camera.near), half_w, half_h
+            c.width, c.height = grid.width, grid.height
+            c.focal_x, c.focal_y = grid.focal_x, grid.focal_y
+            c.tile_length_x, c.tile_length_y = grid.tile_geo_length_x, grid.tile_geo_length_y
+            c.leftmost, c.topmost = grid.leftmost, grid.topmost
+            c.rays_o = (C.c_float * 3)(*rays.rays_o)
+            c.lefttop = (C.c_float * 3)(*rays.lefttop)
+            c.vec_dx = (C.c_float * 3)(*rays.dx)
+            c.vec_dy = (C.c_float * 3)(*rays.dy)
+            if len(self._cam_cache) > 64:
+                self._cam_cache.clear()
+            cached = self._cam_cache[ck] = (c, grid)
+        proto, grid = cached
         f = _lib.GsFrame()
+        C.memmove(C.byref(f), C.byref(proto), C.sizeof(_lib.GsFrame))
         f.N, f.color_dim, f.scale_activation = n, color_dim, self.scale_activation
         f.pos, f.quat, f.scale, f.opa, f.rgb = (t.data_ptr() for t in (pos, quat, scale, opa, rgb))
-        f.rot = (C.c_float * 9)(*np.asarray(camera.rot, np.float32).reshape(9))
-        f.tran = (C.c_float * 3)(*np.asarray(camera.tran, np.float32).reshape(3))
-        f.near_plane, f.half_width, f.half_height = float(camera.near), half_w, half_h
-        f.width, f.height = grid.width, grid.height
-        f.focal_x, f.focal_y = grid.focal_x, grid.focal_y
-        f.tile_length_x, f.tile_length_y = grid.tile_geo_length_x, grid.tile_geo_length_y
-        f.leftmost, f.topmost = grid.leftmost, grid.topmost
         f.thresh = self.thresh
-        f.rays_o = (C.c_float * 3)(*rays.rays_o)
-        f.lefttop = (C.c_float * 3)(*rays.lefttop)
-        f.vec_dx = (C.c_float * 3)(*rays.dx)
-        f.vec_dy = (C.c_float * 3)(*rays.dy)
         f.max_pairs = self.max_pairs
         f.training = int(training)
         f.sort_mode = self.sort_mode
