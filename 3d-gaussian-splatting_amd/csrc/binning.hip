@@ -300,7 +300,7 @@ int gs_stage_scan_emit(const gs_frame *f, const gs_frame_ws &ws, hipStream_t str
 
 int gs_stage_tile_ranges(const gs_frame *f, const gs_frame_ws &ws, const uint64_t *sorted_keys, hipStream_t stream) {
     gs_frame_geom G = gs_frame_geometry(f);
-    GS_HIP(hipMemsetAsync(ws.tile_ranges, 0, sizeof(int32_t) * 2 * G.n_tiles, stream));
+    // ws.tile_ranges was cleared by the frame-start memset (it sits right behind the counters)
     int grid = (int)(gs_div_up(f->max_pairs, 256) < 4096 ? gs_div_up(f->max_pairs, 256) : 4096);
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(grid), dim3(256), 0, stream, sorted_keys, ws.counters,

@@ -79,7 +79,9 @@ static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pair
         return p;
     };
     const int64_t nblk = gs_div_up(N > 0 ? N : 1, 256);
+    // counters and tile_ranges are adjacent: ONE memset per frame clears both (empty tiles must read (0,0))
     ws.counters = (unsigned long long *)take(sizeof(unsigned long long) * GS_CNT_N);
+    ws.tile_ranges = (int32_t *)take(sizeof(int32_t) * 2 * G.n_tiles);
     ws.zero_bytes = off;
     ws.rec_geom = (float4 *)take(sizeof(float4) * N);
     ws.rec_cov = (float4 *)take(sizeof(float4) * N);
@@ -96,7 +98,6 @@ static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pair
     ws.vals_b = (uint32_t *)take(sizeof(uint32_t) * max_pairs);
     ws.sort_tmp_bytes = gs_sort_pairs_tmp_bytes(max_pairs);
     ws.sort_tmp = take(ws.sort_tmp_bytes);
-    ws.tile_ranges = (int32_t *)take(sizeof(int32_t) * 2 * G.n_tiles);
     ws.max_buckets = gs_max_buckets(max_pairs, G.n_tiles);
     if (training) {
         ws.tile_nproc = (uint32_t *)take(sizeof(uint32_t) * G.n_tiles);

@@ -92,9 +92,13 @@ __device__ __forceinline__ void raster_conic(const GaussianRec &g, float &A, flo
     C = g.a * k;
 }
 
-// Pixel centre in normalised image units (gaussian.cu:839-840: double arithmetic, then float).
+// Pixel centre in normalised image units.  The reference evaluates (id + 0.5 - w/2) / focal in double
+// and rounds to float (gaussian.cu:839-840).  The numerator is a half-integer (exact in fp32), so one
+// correctly-rounded fp32 division gives the same float except in the ~2^-29 of cases where the double
+// quotient sits within half a double-ulp of an fp32 rounding boundary (then 1 ulp): two fp64 divisions
+// per lane were ~15 % of this kernel's per-tile prologue.
 __device__ __forceinline__ float raster_pixel_coord(uint32_t id, int32_t padded, float focal) {
-    return (float)(((double)id + 0.5 - (double)((uint32_t)padded / 2)) / (double)focal);
+    return ((float)id + 0.5f - (float)((uint32_t)padded / 2)) / focal;
 }
 
 // Per-pixel SH basis (gaussian.cu:849-861, 405-426), same promotions as the reference.

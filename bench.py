@@ -114,6 +114,13 @@ def main():
     n, W, H, use_sh = CONFIGS[args.config]
     r, st = sized_renderer(params, cam, training=False)
     log(f"[rank {rank}] {args.config}: N={n} V={st.visible} M={st.pairs} {W}x{H} sh={use_sh}")
+    # host cost of issuing one frame (ctypes call + ~14 launches), GPU free-running
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        r.forward(*params, cam)
+    host_us = (time.perf_counter() - t0) / 50 * 1e6
+    torch.cuda.synchronize()
     dt1 = time_frames(lambda: r.forward(*params, cam), args.steps, args.warmup)
     single_stream_fps = world * args.steps / dt1
     if args.streams > 1:
@@ -144,7 +151,7 @@ def main():
                    "n_gaussians": n, "visible": st.visible, "tile_pairs": st.pairs, "width": W, "height": H,
                    "parallelism": f"view-sharded x{world} (no data-path collective)",
                    "frames_in_flight": args.streams},
-        "single_stream_fps": round(single_stream_fps, 2),
+        "single_stream_fps": round(single_stream_fps, 2), "host_us_per_frame": round(host_us, 1),
     }
 
     # ---------------------------------------------------------------- roofline of the dominant kernel
