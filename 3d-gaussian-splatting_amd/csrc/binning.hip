@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(const uint32_t *__restr
     uint32_t dbits = 0;
     if (cnt) {
         rc = rects[pid];
-        dbits = __float_as_uint(rec_geom[pid].z);
+        dbits = __float_as_uint(rec_geom[pid * GS_REC_STRIDE].z);
     }
     const uint32_t y0 = rc.x & 0xffff, x0 = rc.y & 0xffff, x1 = rc.y >> 16;
     const uint32_t wdt = x1 - x0;

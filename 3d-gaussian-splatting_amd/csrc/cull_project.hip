@@ -358,9 +358,15 @@ __global__ void __launch_bounds__(256) frame_project_kernel(
                 col = make_float4(sigmoid_f(rgb[pid * 3 + 0]), sigmoid_f(rgb[pid * 3 + 1]),
                                   sigmoid_f(rgb[pid * 3 + 2]), 0.0f);
         }
-        rec_geom[pid] = g;
-        rec_cov[pid] = c;
-        if (P.color_dim == 3) rec_color[pid] = col;
+        float cA = 0.f, cB = 0.f, cC = 0.f;
+        if (vis) gs_conic(c.x, c.y, c.z, c.w, cA, cB, cC);
+        float4 *rec = rec_geom + pid * GS_REC_STRIDE;  // one 64-byte record per Gaussian
+        rec[0] = g;
+        rec[1] = c;
+        rec[2] = col;
+        rec[3] = make_float4(cA, cB, cC, 0.f);
+        (void)rec_cov;
+        (void)rec_color;
         tiles_touched[pid] = cnt;
         rects[pid] = rc;
     }
@@ -395,7 +401,7 @@ __global__ void __launch_bounds__(256) frame_project_backward_kernel(
     float *__restrict__ grad_rgb) {
     const int64_t pid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (pid >= n) return;
-    const float4 g = rec_geom[pid];
+    const float4 g = rec_geom[pid * GS_REC_STRIDE];
     float gp[3] = {0, 0, 0}, gqr[4] = {0, 0, 0, 0}, gsr[3] = {0, 0, 0}, gopa = 0, gcol[3] = {0, 0, 0};
     float gsh[27];
     if (g.z != 0.0f) {  // visible (depth > near > 0)
@@ -448,7 +454,7 @@ __global__ void __launch_bounds__(256) frame_project_backward_kernel(
         }
         gopa = d1.z * g.w * (1.0f - g.w);
         if (P.color_dim == 3) {
-            const float4 c = rec_color[pid];
+            const float4 c = rec_color[pid * GS_REC_STRIDE];
             gcol[0] = d1.w * c.x * (1.0f - c.x);
             gcol[1] = d2.x * c.y * (1.0f - c.y);
             gcol[2] = d2.y * c.z * (1.0f - c.z);

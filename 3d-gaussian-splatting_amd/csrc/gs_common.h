@@ -96,4 +96,29 @@ __device__ __forceinline__ float gs_rcp(float x) { return __builtin_amdgcn_rcpf(
 // float below 0.0001, so the test is exactly `accum <= 0.0001f`.
 #define GS_T_STOP 0.0001f
 
+// Per-Gaussian record of the frame path: 4 float4 = 64 B, one cache-line-aligned slot per Gaussian so
+// that a tile's gather of a Gaussian touches ONE line instead of three:
+//   [0] geom  (x/z, y/z, |p_c|, sigmoid(opacity))     [1] cov   (a, b, c, d)
+//   [2] color (sigmoid r, g, b, -)                    [3] conic (A, B, C, -) in log2 units
+#define GS_REC_STRIDE 4
+
+// det = a*d - b*c without FMA contraction: the reference (and the oracle) round both products
+// before subtracting; for needle-like footprints (a*d ~ b*c) a contracted det differs by many
+// ulps and that difference is amplified into the exponent.
+__device__ __forceinline__ float gs_det(float a, float b, float c, float d) {
+#pragma clang fp contract(off)
+    return a * d - b * c;
+}
+
+// Conic in log2 units: G = 2^-(A dx^2 - B dx dy + C dy^2) == exp(-(d dx^2-(b+c)dx dy+a dy^2)/(2det+1e-14))
+// (gaussian.cu:916-923).  Hoists the reference's per-pixel fp64 division to once per Gaussian.
+__device__ __forceinline__ void gs_conic(float a, float b, float c, float d, float &A, float &B, float &C) {
+#pragma clang fp contract(off)
+    const float det = a * d - b * c;
+    const float k = GS_LOG2E / (2.0f * det + 1e-14f);
+    A = d * k;
+    B = (b + c) * k;
+    C = a * k;
+}
+
 #endif  // __HIPCC__

@@ -39,9 +39,12 @@ static inline gs_frame_geom gs_frame_geometry(const gs_frame *f) {
 
 struct gs_frame_ws {
     unsigned long long *counters;  // [GS_CNT_N]
-    float4 *rec_geom;              // [N] (x, y, depth, opacity)
-    float4 *rec_cov;               // [N] (a, b, c, d)
-    float4 *rec_color;             // [N] (r, g, b, -)  (color_dim == 3 only)
+    // one 64-byte record per Gaussian (GS_REC_STRIDE float4s, see gs_common.h); the four pointers
+    // address the four float4 fields of record 0, index with [i * GS_REC_STRIDE]
+    float4 *rec_geom;              // (x, y, depth, opacity)
+    float4 *rec_cov;               // (a, b, c, d)
+    float4 *rec_color;             // (r, g, b, -)
+    float4 *rec_conic;             // (A, B, C, -)
     uint32_t *tiles_touched;       // [N]
     uint2 *rects;                  // [N] (y0 | y1 << 16, x0 | x1 << 16)
     uint32_t *block_sums;          // [ceil(N/256)] pairs emitted by each 256-Gaussian block
@@ -83,9 +86,10 @@ static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pair
     ws.counters = (unsigned long long *)take(sizeof(unsigned long long) * GS_CNT_N);
     ws.tile_ranges = (int32_t *)take(sizeof(int32_t) * 2 * G.n_tiles);
     ws.zero_bytes = off;
-    ws.rec_geom = (float4 *)take(sizeof(float4) * N);
-    ws.rec_cov = (float4 *)take(sizeof(float4) * N);
-    ws.rec_color = (float4 *)take(color_dim == 3 ? sizeof(float4) * N : 0);
+    ws.rec_geom = (float4 *)take(sizeof(float4) * GS_REC_STRIDE * N);
+    ws.rec_cov = ws.rec_geom ? ws.rec_geom + 1 : nullptr;
+    ws.rec_color = ws.rec_geom ? ws.rec_geom + 2 : nullptr;
+    ws.rec_conic = ws.rec_geom ? ws.rec_geom + 3 : nullptr;
     ws.tiles_touched = (uint32_t *)take(sizeof(uint32_t) * N);
     ws.rects = (uint2 *)take(sizeof(uint2) * N);
     ws.block_sums = (uint32_t *)take(sizeof(uint32_t) * nblk);

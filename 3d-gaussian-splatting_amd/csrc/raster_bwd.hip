@@ -450,6 +450,7 @@ int gs_stage_raster_backward(const gs_frame *f, const gs_frame_ws &ws, const uin
     S.geom = ws.rec_geom;
     S.cov4 = ws.rec_cov;
     S.color4 = ws.rec_color;
+    S.conic4 = ws.rec_conic;
     S.sh = f->rgb;
     RasterGeom G = {};
     G.padW = FG.padW;

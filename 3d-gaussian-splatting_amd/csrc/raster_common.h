@@ -10,9 +10,10 @@
 //                 (pos[M,3], rgb[M,D], opa[M], cov[M,2,2]; gaussian.cu:806-813).
 struct RasterSrc {
     const uint32_t *ids;
-    const float4 *geom;    // (x, y, depth, opacity)
-    const float4 *cov4;    // (a, b, c, d)
-    const float4 *color4;  // (r, g, b, -)
+    const float4 *geom;    // (x, y, depth, opacity)   } interleaved, stride GS_REC_STRIDE float4
+    const float4 *cov4;    // (a, b, c, d)             } (one 64-byte record per Gaussian)
+    const float4 *color4;  // (r, g, b, -)             }
+    const float4 *conic4;  // (A, B, C, -)             }
     const float *sh;       // raw rgb parameter [N,27] (SH coefficients)
     const float *pos, *rgb, *opa, *cov;
 };
@@ -32,7 +33,7 @@ template <bool FRAME>
 __device__ __forceinline__ uint32_t raster_load(const RasterSrc &S, uint32_t j, GaussianRec &g) {
     if (FRAME) {
         const uint32_t id = S.ids[j];
-        const float4 ge = S.geom[id], cv = S.cov4[id];
+        const float4 ge = S.geom[(size_t)id * GS_REC_STRIDE], cv = S.cov4[(size_t)id * GS_REC_STRIDE];
         g.x = ge.x;
         g.y = ge.y;
         g.opa = ge.w;
@@ -58,7 +59,7 @@ template <bool FRAME>
 __device__ __forceinline__ void raster_load_rgb(const RasterSrc &S, uint32_t j, uint32_t id, float &r, float &g,
                                                 float &b) {
     if (FRAME) {
-        const float4 c = S.color4[id];
+        const float4 c = S.color4[(size_t)id * GS_REC_STRIDE];
         r = c.x;
         g = c.y;
         b = c.z;
@@ -74,22 +75,9 @@ __device__ __forceinline__ const float *raster_sh_ptr(const RasterSrc &S, uint32
     return FRAME ? S.sh + (size_t)id * 27 : S.rgb + (size_t)j * 27;
 }
 
-// det = a*d - b*c without FMA contraction: the reference (and the oracle) round both products
-// before subtracting; for needle-like footprints (a*d ~ b*c) a contracted det differs by many
-// ulps and that difference is amplified into the exponent.
-__device__ __forceinline__ float raster_det(float a, float b, float c, float d) {
-#pragma clang fp contract(off)
-    return a * d - b * c;
-}
-
-// Conic in log2 units: G = 2^-(A dx^2 - B dx dy + C dy^2) == exp(-(d dx^2-(b+c)dx dy+a dy^2)/(2det+1e-14))
-// (gaussian.cu:916-923).  Hoists the reference's per-pixel fp64 division to once per Gaussian.
+__device__ __forceinline__ float raster_det(float a, float b, float c, float d) { return gs_det(a, b, c, d); }
 __device__ __forceinline__ void raster_conic(const GaussianRec &g, float &A, float &B, float &C) {
-    const float det = raster_det(g.a, g.b, g.c, g.d);
-    const float k = GS_LOG2E / (2.0f * det + 1e-14f);
-    A = g.d * k;
-    B = (g.b + g.c) * k;
-    C = g.a * k;
+    gs_conic(g.a, g.b, g.c, g.d, A, B, C);
 }
 
 // Pixel centre in normalised image units.  The reference evaluates (id + 0.5 - w/2) / focal in double

@@ -86,12 +86,14 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
     // register stage for the next chunk (one Gaussian per thread)
     GaussianRec g;
     float r0 = 0, r1 = 0, r2 = 0;
+    float4 cq = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t gid = 0;
     bool have = false;
     auto fetch = [&](uint32_t base) {
         have = (uint32_t)p < (uint32_t)CH && base + p < n;
         if (have) {
             gid = raster_load<FRAME>(S, start + base + p, g);
+            if (FRAME) cq = S.conic4[(size_t)gid * GS_REC_STRIDE];
             if (CDIM == 3) raster_load_rgb<FRAME>(S, start + base + p, gid, r0, r1, r2);
         }
     };
@@ -107,7 +109,13 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
         const int buf = k & 1;
         if (have) {
             float A, B, C;
-            raster_conic(g, A, B, C);
+            if (FRAME) {  // S1 stored the conic in the Gaussian's record (same line as geom / colour)
+                A = cq.x;
+                B = cq.y;
+                C = cq.z;
+            } else {
+                raster_conic(g, A, B, C);
+            }
             float opa = g.opa;
             if (SIG)  // gaussian.cu:918: (1.0/2*3.1415926536) * rsqrtf(det + 1e-7), folded into opacity
                 opa *= 1.5707963268f * rsqrtf(raster_det(g.a, g.b, g.c, g.d) + 1e-7f);
@@ -330,6 +338,7 @@ int gs_stage_raster_forward(const gs_frame *f, const gs_frame_ws &ws, const uint
     S.geom = ws.rec_geom;
     S.cov4 = ws.rec_cov;
     S.color4 = ws.rec_color;
+    S.conic4 = ws.rec_conic;
     S.sh = f->rgb;
     RasterGeom G = {};
     G.padW = FG.padW;

@@ -213,12 +213,13 @@ class FrameRenderer:
             "sorted_keys": view(ptrs[0], 8 * m, torch.int64, (m,)),
             "sorted_ids": view(ptrs[1], 4 * m, torch.int32, (m,)),
             "tile_ranges": view(ptrs[2], 8 * T, torch.int32, (T, 2)),
-            "rec_geom": view(ptrs[3], 16 * n, torch.float32, (n, 4)),
-            "rec_cov": view(ptrs[4], 16 * n, torch.float32, (n, 4)),
+            # one 64-byte record per Gaussian: geom | cov | color | conic
+            "rec_geom": view(ptrs[3], 64 * n, torch.float32, (n, 16))[:, 0:4],
+            "rec_cov": view(ptrs[3], 64 * n, torch.float32, (n, 16))[:, 4:8],
             "tiles_touched": view(ptrs[6], 4 * n, torch.int32, (n,)),
         }
         if f.color_dim == 3:
-            out["rec_color"] = view(ptrs[5], 16 * n, torch.float32, (n, 4))
+            out["rec_color"] = view(ptrs[3], 64 * n, torch.float32, (n, 16))[:, 8:12]
         return out
 
     # ------------------------------------------------------------------ autograd entry point
