@@ -1,7 +1,6 @@
 // raster_fwd.hip -- 16x16-tile front-to-back alpha compositing, forward.
 //
-// Replaces draw_kernel (gaussian.cu:806-970).  One 128-thread workgroup (2 wave64) per tile,
-// two pixels per lane (wave w owns pixel rows 8w..8w+7 of the tile).  The tile's sorted
+// Replaces draw_kernel (gaussian.cu:806-970).  One wave64 per tile, four pixels per lane.  The tile's sorted
 // Gaussian list is streamed through LDS in chunks with a two-deep ring: every thread gathers
 // one Gaussian of the NEXT chunk from HBM/L2 into registers while the waves composite the
 // current chunk out of LDS (broadcast ds_read_b128), so a chunk costs a single barrier.
@@ -20,17 +19,17 @@ namespace {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-constexpr int FWD_THREADS = 128;  // 2 wave64 per 16x16 tile, 2 pixels per lane
+constexpr int FWD_THREADS = 64;  // ONE wave64 per 16x16 tile, 4 pixels per lane
+constexpr int NPP = 2;           // pixel pairs per lane
 
 template <int CDIM>
 struct FwdSmem;
 template <>
 struct FwdSmem<3> {
     // structure of arrays: four consecutive Gaussians of one field are one ds_read_b128
-    static constexpr int CH = 128;
+    static constexpr int CH = 64;
     enum { X, Y, A, B, C, OPA, R, G, BL, NFIELD };
     float f[2][NFIELD][CH] __attribute__((aligned(16)));
-    int done[2][2];
 };
 template <>
 struct FwdSmem<27> {
@@ -38,17 +37,20 @@ struct FwdSmem<27> {
     enum { X, Y, A, B, C, OPA, NFIELD };
     float f[2][NFIELD][CH] __attribute__((aligned(16)));
     float sh[2][CH][28] __attribute__((aligned(16)));
-    int done[2][2];
 };
 
 __device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
-// Lane l of wave w owns pixels (x, yA) and (x, yA + 4) of the tile, x = l & 15, yA = 8 w + (l >> 4):
-// every broadcast LDS read of a Gaussian now feeds 128 pixel evaluations per wave instead of 64
-// (the one-pixel-per-lane version was LDS-issue bound: 9 ds_read_b128 per 4 Gaussians per wave),
-// and the fp32 math is packed over the PIXEL pair (v_pk_*_f32; dx is shared), including the
-// transmittance recurrence.  Pixel index inside the tile: pA = 128 w + l, pB = pA + 64.
+// Lane l owns the four pixels (x, y0 + 4k), k = 0..3, of the tile, x = l & 15, y0 = l >> 4; pixel
+// index inside the tile p_k = 64 k + l.  Why four pixels per lane: the compositing loop is bound by
+// LDS RETURN bandwidth, not by VALU -- a broadcast ds_read_b128 still delivers 1 KiB to the wave --
+// (ablation on MI355X: dropping exp + masking + colour math changed nothing, dropping the LDS reads
+// removed 85 % of the kernel), so every Gaussian read from LDS should feed as many pixel
+// evaluations as possible: 256 per wave here, against 64 for the one-pixel-per-lane layout.
+// With a single wave per tile there is no workgroup barrier at all; the staging of the next
+// chunk (one Gaussian per lane) overlaps the compositing of the current one through registers.
+// The fp32 math is packed over pixel PAIRS (v_pk_*_f32; dx is shared by all four pixels).
 template <int CDIM, bool FRAME, bool CKPT, bool SIG, bool WN>
 __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S, RasterGeom G,
                                                                     const int32_t *__restrict__ ranges,
@@ -65,48 +67,70 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
     const uint32_t start = (uint32_t)(FRAME ? ranges[2 * tile] : ranges[tile]);
     const uint32_t end = (uint32_t)(FRAME ? ranges[2 * tile + 1] : ranges[tile + 1]);
     const uint32_t n = end - start;
-    const int p = threadIdx.x, wave = p >> 6, lane = p & 63;
-    const int pA = wave * 128 + lane, pB = pA + 64;
-    const uint32_t id_x = tx * 16 + (lane & 15), id_yA = ty * 16 + wave * 8 + (lane >> 4), id_yB = id_yA + 4;
+    const int lane = threadIdx.x;
+    const uint32_t id_x = tx * 16 + (lane & 15), id_y0 = ty * 16 + (lane >> 4);
     const float px = raster_pixel_coord(id_x, G.padW, G.focal_x);
-    const f2 py2 = {raster_pixel_coord(id_yA, G.padH, G.focal_y), raster_pixel_coord(id_yB, G.padH, G.focal_y)};
-    f2 SH[9];
-    if (CDIM == 27) {
-        float a9[9], b9[9];
-        raster_pixel_sh(id_x, id_yA, G, a9);
-        raster_pixel_sh(id_x, id_yB, G, b9);
+    f2 py2[NPP];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) SH[k] = f2{a9[k], b9[k]};
+    for (int h = 0; h < NPP; ++h)
+        py2[h] = f2{raster_pixel_coord(id_y0 + 8 * h, G.padH, G.focal_y),
+                    raster_pixel_coord(id_y0 + 8 * h + 4, G.padH, G.focal_y)};
+    f2 SH[NPP][CDIM == 27 ? 9 : 1];
+    if (CDIM == 27) {
+#pragma unroll
+        for (int h = 0; h < NPP; ++h) {
+            float a9[9], b9[9];
+            raster_pixel_sh(id_x, id_y0 + 8 * h, G, a9);
+            raster_pixel_sh(id_x, id_y0 + 8 * h + 4, G, b9);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) SH[h][k] = f2{a9[k], b9[k]};
+        }
     }
 
-    f2 T = {1.0f, 1.0f}, cr = {0.f, 0.f}, cg = {0.f, 0.f}, cb = {0.f, 0.f}, accw = {0.f, 0.f};
-    bool wave_done = false;
+    // pair h holds rows y0 + 8h (x) and y0 + 8h + 4 (y): tile pixel indices 128h + lane, 128h + 64 + lane
+    f2 T[NPP], cr[NPP], cg[NPP], cb[NPP], accw[NPP];
+#pragma unroll
+    for (int h = 0; h < NPP; ++h) {
+        T[h] = f2{1.0f, 1.0f};
+        cr[h] = cg[h] = cb[h] = accw[h] = f2{0.f, 0.f};
+    }
     uint32_t nproc = 0;
 
-    // register stage for the next chunk (one Gaussian per thread)
+    // register stage for the next chunk (one Gaussian per lane)
     GaussianRec g;
     float r0 = 0, r1 = 0, r2 = 0;
     float4 cq = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t gid = 0;
     bool have = false;
     auto fetch = [&](uint32_t base) {
-        have = (uint32_t)p < (uint32_t)CH && base + p < n;
+        have = base + lane < n;
         if (have) {
-            gid = raster_load<FRAME>(S, start + base + p, g);
+            gid = raster_load<FRAME>(S, start + base + lane, g);
             if (FRAME) cq = S.conic4[(size_t)gid * GS_REC_STRIDE];
-            if (CDIM == 3) raster_load_rgb<FRAME>(S, start + base + p, gid, r0, r1, r2);
+            if (CDIM == 3) raster_load_rgb<FRAME>(S, start + base + lane, gid, r0, r1, r2);
         }
     };
     auto write_ckpt = [&](uint32_t idx_in_tile) {
         float4 *c = ckpt + raster_ckpt_slot(start, tile, idx_in_tile / GS_BUCKET) * 256;
-        c[pA] = make_float4(T.x, cr.x, cg.x, cb.x);
-        c[pB] = make_float4(T.y, cr.y, cg.y, cb.y);
+#pragma unroll
+        for (int h = 0; h < NPP; ++h) {
+            c[128 * h + lane] = make_float4(T[h].x, cr[h].x, cg[h].x, cb[h].x);
+            c[128 * h + 64 + lane] = make_float4(T[h].y, cr[h].y, cg[h].y, cb[h].y);
+        }
+    };
+    auto any_live = [&]() {
+        bool l = false;
+#pragma unroll
+        for (int h = 0; h < NPP; ++h) l = l || T[h].x > GS_T_STOP || T[h].y > GS_T_STOP;
+        return __ballot(l) != 0ull;
     };
 
     fetch(0);
     int k = 0;
-    for (uint32_t base = 0; base < n; base += CH, ++k) {
-        const int buf = k & 1;
+    bool done = false;
+    for (uint32_t base = 0; base < n && !done; base += CH, ++k) {
+        const int buf = k & 1;  // two-deep ring: the wave is in program order, so writing buffer k&1 here
+                                // cannot overtake its own reads of two chunks ago
         if (have) {
             float A, B, C;
             if (FRAME) {  // S1 stored the conic in the Gaussian's record (same line as geom / colour)
@@ -119,66 +143,65 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
             float opa = g.opa;
             if (SIG)  // gaussian.cu:918: (1.0/2*3.1415926536) * rsqrtf(det + 1e-7), folded into opacity
                 opa *= 1.5707963268f * rsqrtf(raster_det(g.a, g.b, g.c, g.d) + 1e-7f);
-            sm.f[buf][SM::X][p] = g.x;
-            sm.f[buf][SM::Y][p] = g.y;
-            sm.f[buf][SM::A][p] = A;
-            sm.f[buf][SM::B][p] = B;
-            sm.f[buf][SM::C][p] = C;
-            sm.f[buf][SM::OPA][p] = opa;
+            sm.f[buf][SM::X][lane] = g.x;
+            sm.f[buf][SM::Y][lane] = g.y;
+            sm.f[buf][SM::A][lane] = A;
+            sm.f[buf][SM::B][lane] = B;
+            sm.f[buf][SM::C][lane] = C;
+            sm.f[buf][SM::OPA][lane] = opa;
             if constexpr (CDIM == 3) {
-                sm.f[buf][SM::R][p] = r0;
-                sm.f[buf][SM::G][p] = r1;
-                sm.f[buf][SM::BL][p] = r2;
+                sm.f[buf][SM::R][lane] = r0;
+                sm.f[buf][SM::G][lane] = r1;
+                sm.f[buf][SM::BL][lane] = r2;
             } else {
-                const float *src = raster_sh_ptr<FRAME>(S, start + base + p, gid);
+                const float *src = raster_sh_ptr<FRAME>(S, start + base + lane, gid);
 #pragma unroll
-                for (int q = 0; q < 27; ++q) sm.sh[buf][p][q] = src[q];
+                for (int q = 0; q < 27; ++q) sm.sh[buf][lane][q] = src[q];
             }
-        } else if ((uint32_t)p < (uint32_t)CH && base + p < ((n + 3u) & ~3u)) {
+        } else if (base + lane < ((n + 3u) & ~3u)) {
             // pad the ragged tail to a multiple of 4 with null Gaussians (opacity 0 => alpha 0)
 #pragma unroll
-            for (int q = 0; q < SM::NFIELD; ++q) sm.f[buf][q][p] = 0.f;
+            for (int q = 0; q < SM::NFIELD; ++q) sm.f[buf][q][lane] = 0.f;
             if constexpr (CDIM == 27) {
 #pragma unroll
-                for (int q = 0; q < 27; ++q) sm.sh[buf][p][q] = 0.f;
+                for (int q = 0; q < 27; ++q) sm.sh[buf][lane][q] = 0.f;
             }
         }
-        if (lane == 0) sm.done[buf][wave] = wave_done ? 1 : 0;
-        __syncthreads();
-        if (sm.done[buf][0] & sm.done[buf][1]) break;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         fetch(base + CH);  // overlaps with the compositing below
         const uint32_t cnt = (n - base) < (uint32_t)CH ? (n - base) : (uint32_t)CH;
-        for (uint32_t sub = 0; sub < cnt; sub += GS_BUCKET) {
-            if (CKPT) write_ckpt(base + sub);
-            if (wave_done) continue;
-            const uint32_t lim = (sub + GS_BUCKET) < cnt ? (sub + GS_BUCKET) : cnt;
-            // groups of 4 Gaussians: one wave-uniform liveness test per group, per-pixel masking
-            // inside (exactly the reference's per-pixel `accum < 0.0001` test, gaussian.cu:906)
-            for (uint32_t i = sub; i < lim; i += 4) {
-                if (__ballot(T.x > GS_T_STOP || T.y > GS_T_STOP) == 0ull) {
-                    wave_done = true;
-                    break;
-                }
-                auto ld4 = [&](int q) { return *(const float4 *)__builtin_assume_aligned(&sm.f[buf][q][i], 16); };
-                const float4 X = ld4(SM::X), Y = ld4(SM::Y), A4 = ld4(SM::A), B4 = ld4(SM::B), C4 = ld4(SM::C);
-                const float4 O4 = ld4(SM::OPA);
-                float4 R4, G4, L4;
-                if constexpr (CDIM == 3) {
-                    R4 = ld4(SM::R);
-                    G4 = ld4(SM::G);
-                    L4 = ld4(SM::BL);
-                }
+        if (CKPT) write_ckpt(base);  // CH == GS_BUCKET: one checkpoint per chunk
+        // groups of 4 Gaussians: one wave-uniform liveness test per group, per-pixel masking inside
+        // (exactly the reference's per-pixel `accum < 0.0001` test, gaussian.cu:906)
+        for (uint32_t i = 0; i < cnt; i += 4) {
+            if (!any_live()) {
+                done = true;
+                break;
+            }
+            auto ld4 = [&](int q) { return *(const float4 *)__builtin_assume_aligned(&sm.f[buf][q][i], 16); };
+            const float4 X = ld4(SM::X), Y = ld4(SM::Y), A4 = ld4(SM::A), B4 = ld4(SM::B), C4 = ld4(SM::C);
+            const float4 O4 = ld4(SM::OPA);
+            float4 R4, G4, L4;
+            if constexpr (CDIM == 3) {
+                R4 = ld4(SM::R);
+                G4 = ld4(SM::G);
+                L4 = ld4(SM::BL);
+            }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float gx = u == 0 ? X.x : u == 1 ? X.y : u == 2 ? X.z : X.w;
-                    const float gy = u == 0 ? Y.x : u == 1 ? Y.y : u == 2 ? Y.z : Y.w;
-                    const float cA = u == 0 ? A4.x : u == 1 ? A4.y : u == 2 ? A4.z : A4.w;
-                    const float cB = u == 0 ? B4.x : u == 1 ? B4.y : u == 2 ? B4.z : B4.w;
-                    const float cC = u == 0 ? C4.x : u == 1 ? C4.y : u == 2 ? C4.z : C4.w;
-                    const float op = u == 0 ? O4.x : u == 1 ? O4.y : u == 2 ? O4.z : O4.w;
-                    const float dx = px - gx;
-                    const f2 dy = py2 - splat(gy);
-                    const f2 t = pk_fma(splat(-cB), dy, splat(cA * dx));    // A dx - B dy
+            for (int u = 0; u < 4; ++u) {
+                const float gx = u == 0 ? X.x : u == 1 ? X.y : u == 2 ? X.z : X.w;
+                const float gy = u == 0 ? Y.x : u == 1 ? Y.y : u == 2 ? Y.z : Y.w;
+                const float cA = u == 0 ? A4.x : u == 1 ? A4.y : u == 2 ? A4.z : A4.w;
+                const float cB = u == 0 ? B4.x : u == 1 ? B4.y : u == 2 ? B4.z : B4.w;
+                const float cC = u == 0 ? C4.x : u == 1 ? C4.y : u == 2 ? C4.z : C4.w;
+                const float op = u == 0 ? O4.x : u == 1 ? O4.y : u == 2 ? O4.z : O4.w;
+                const float dx = px - gx;
+                const float adx = cA * dx;
+#pragma unroll
+                for (int h = 0; h < NPP; ++h) {
+                    const f2 dy = py2[h] - splat(gy);
+                    const f2 t = pk_fma(splat(-cB), dy, splat(adx));        // A dx - B dy
                     const f2 q = pk_fma(splat(cC) * dy, dy, splat(dx) * t);  // + C dy^2
                     f2 al;
                     al.x = gs_exp2(-q.x);
@@ -188,60 +211,65 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
                         al.x = 2.0f / (__expf(-al.x) + 1.0f) - 1.0f;
                         al.y = 2.0f / (__expf(-al.y) + 1.0f) - 1.0f;
                     }
-                    al.x = (T.x > GS_T_STOP) ? al.x : 0.0f;
-                    al.y = (T.y > GS_T_STOP) ? al.y : 0.0f;
-                    const f2 w = al * T;
+                    al.x = (T[h].x > GS_T_STOP) ? al.x : 0.0f;
+                    al.y = (T[h].y > GS_T_STOP) ? al.y : 0.0f;
+                    const f2 w = al * T[h];
                     if constexpr (CDIM == 3) {
-                        cr = pk_fma(splat(u == 0 ? R4.x : u == 1 ? R4.y : u == 2 ? R4.z : R4.w), w, cr);
-                        cg = pk_fma(splat(u == 0 ? G4.x : u == 1 ? G4.y : u == 2 ? G4.z : G4.w), w, cg);
-                        cb = pk_fma(splat(u == 0 ? L4.x : u == 1 ? L4.y : u == 2 ? L4.z : L4.w), w, cb);
+                        cr[h] = pk_fma(splat(u == 0 ? R4.x : u == 1 ? R4.y : u == 2 ? R4.z : R4.w), w, cr[h]);
+                        cg[h] = pk_fma(splat(u == 0 ? G4.x : u == 1 ? G4.y : u == 2 ? G4.z : G4.w), w, cg[h]);
+                        cb[h] = pk_fma(splat(u == 0 ? L4.x : u == 1 ? L4.y : u == 2 ? L4.z : L4.w), w, cb[h]);
                     } else {
                         const float *co = sm.sh[buf][i + u];
                         f2 v0 = {0.f, 0.f}, v1 = {0.f, 0.f}, v2 = {0.f, 0.f};
 #pragma unroll
                         for (int k9 = 0; k9 < 9; ++k9) {
-                            v0 = pk_fma(SH[k9], splat(co[k9]), v0);
-                            v1 = pk_fma(SH[k9], splat(co[9 + k9]), v1);
-                            v2 = pk_fma(SH[k9], splat(co[18 + k9]), v2);
+                            v0 = pk_fma(SH[h][k9], splat(co[k9]), v0);
+                            v1 = pk_fma(SH[h][k9], splat(co[9 + k9]), v1);
+                            v2 = pk_fma(SH[h][k9], splat(co[18 + k9]), v2);
                         }
                         const f2 c0 = {gs_rcp(1.0f + __expf(-v0.x)), gs_rcp(1.0f + __expf(-v0.y))};
                         const f2 c1 = {gs_rcp(1.0f + __expf(-v1.x)), gs_rcp(1.0f + __expf(-v1.y))};
                         const f2 c2 = {gs_rcp(1.0f + __expf(-v2.x)), gs_rcp(1.0f + __expf(-v2.y))};
-                        cr = pk_fma(w, c0, cr);
-                        cg = pk_fma(w, c1, cg);
-                        cb = pk_fma(w, c2, cb);
+                        cr[h] = pk_fma(w, c0, cr[h]);
+                        cg[h] = pk_fma(w, c1, cg[h]);
+                        cb[h] = pk_fma(w, c2, cb[h]);
                     }
-                    if (WN) accw += w;
-                    T = pk_fma(-al, T, T);  // T * (1 - alpha)
+                    if (WN) accw[h] += w;
+                    T[h] = pk_fma(-al, T[h], T[h]);  // T * (1 - alpha)
                 }
             }
         }
+        // a chunk whose checkpoint was written counts as processed even if the wave stopped inside it:
+        // the backward pass masks finished pixels by their transmittance
         nproc = base + cnt;
     }
-    if (tile_nproc && p == 0) tile_nproc[tile] = nproc;
+    if (tile_nproc && lane == 0) tile_nproc[tile] = nproc;
 
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const uint32_t id_y = h ? id_yB : id_yA;
-        float aw = h ? accw.y : accw.x;
-        if (!WN || aw < 0.01f) aw = 1.0f;  // gaussian.cu:964-969
-        const float o0 = (h ? cr.y : cr.x) / aw, o1 = (h ? cg.y : cg.x) / aw, o2 = (h ? cb.y : cb.x) / aw;
-        if (out_padded) {
-            float *o = out_padded + ((size_t)id_y * G.padW + id_x) * 3;
-            o[0] = o0;
-            o[1] = o1;
-            o[2] = o2;
-        }
-        if (out_image) {  // clamp + centred crop (splatter.py:652-653, 267-272)
-            const int ox = (int)id_x - G.crop_left, oy = (int)id_y - G.crop_top;
-            if (ox >= 0 && ox < G.width && oy >= 0 && oy < G.height) {
-                float *o = out_image + ((size_t)oy * G.width + ox) * 3;
-                o[0] = fminf(fmaxf(o0, 0.f), 1.f);
-                o[1] = fminf(fmaxf(o1, 0.f), 1.f);
-                o[2] = fminf(fmaxf(o2, 0.f), 1.f);
+    for (int h = 0; h < NPP; ++h)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const uint32_t id_y = id_y0 + 8 * h + 4 * e;
+            float aw = e ? accw[h].y : accw[h].x;
+            if (!WN || aw < 0.01f) aw = 1.0f;  // gaussian.cu:964-969
+            const float o0 = (e ? cr[h].y : cr[h].x) / aw, o1 = (e ? cg[h].y : cg[h].x) / aw,
+                        o2 = (e ? cb[h].y : cb[h].x) / aw;
+            if (out_padded) {
+                float *o = out_padded + ((size_t)id_y * G.padW + id_x) * 3;
+                o[0] = o0;
+                o[1] = o1;
+                o[2] = o2;
+            }
+            if (out_image) {  // clamp + centred crop (splatter.py:652-653, 267-272)
+                const int ox = (int)id_x - G.crop_left, oy = (int)id_y - G.crop_top;
+                if (ox >= 0 && ox < G.width && oy >= 0 && oy < G.height) {
+                    float *o = out_image + ((size_t)oy * G.width + ox) * 3;
+                    o[0] = fminf(fmaxf(o0, 0.f), 1.f);
+                    o[1] = fminf(fmaxf(o1, 0.f), 1.f);
+                    o[2] = fminf(fmaxf(o2, 0.f), 1.f);
+                }
             }
         }
-    }
 }
 
 template <int CDIM, bool FRAME, bool CKPT, bool SIG>
