@@ -43,7 +43,9 @@ static int validate(const gs_frame *f) {
     GS_CHECK_ARG(((uintptr_t)f->quat & 15) == 0, "quat must be 16-byte aligned");
     GS_CHECK_ARG(f->workspace != nullptr && ((uintptr_t)f->workspace & 255) == 0, "workspace null or not 256-byte aligned");
     GS_CHECK_ARG(f->thresh > 0.f && f->thresh < 1.f, "thresh must be in (0,1)");
-    GS_CHECK_ARG(f->sort_mode == 0 || f->sort_mode == 1, "sort_mode must be 0 (full LSD radix) or 1 (tile-bit radix + per-tile LDS sort)");
+    GS_CHECK_ARG(f->sort_mode >= 0 && f->sort_mode <= 2,
+                 "sort_mode must be 0 (full LSD radix), 1 (tile-bit radix + per-tile LDS sort) or 2 (LDS counting sort "
+                 "by tile + per-tile LDS sort)");
     const size_t need = gs_frame_workspace_bytes(f->N, f->max_pairs, f->width, f->height, f->color_dim, f->training);
     if (f->workspace_bytes < need) {
         gs_set_error("gs_frame: workspace too small (%zu < %zu bytes)", f->workspace_bytes, need);
@@ -58,14 +60,26 @@ extern "C" size_t gs_frame_workspace_bytes(int64_t N, int64_t max_pairs, int32_t
     return gs_frame_carve(nullptr, N, max_pairs, width, height, color_dim, training).total_bytes;
 }
 
+// sort_mode 2 needs one LDS counter per tile; grids beyond that (> 8K x 4K pixels) take mode 1.
+static int effective_sort_mode(const gs_frame *f) {
+    if (f->sort_mode == 2 && gs_frame_geometry(f).n_tiles > GS_BIN_MAX_TILES) return 1;
+    return f->sort_mode;
+}
+
 // Which double-buffer half holds the sorted (keys, ids) after the radix passes of this mode.
 static int sort_passes(const gs_frame *f) {
     gs_frame_geom G = gs_frame_geometry(f);
     const int tb = tile_bits(G.n_tiles);
-    return f->sort_mode == 1 ? (tb + 7) / 8 : (32 + tb + 7) / 8;
+    return effective_sort_mode(f) == 1 ? (tb + 7) / 8 : (32 + tb + 7) / 8;
 }
 static void sorted_buffers(const gs_frame *f, const gs_frame_ws &ws, uint64_t **keys, uint32_t **ids,
                            uint64_t **other_keys) {
+    if (effective_sort_mode(f) == 2) {  // packed pairs in keys_a -> sorted keys in keys_b, ids in vals_a
+        *keys = ws.keys_b;
+        *ids = ws.vals_a;
+        *other_keys = ws.keys_a;
+        return;
+    }
     const bool in_b = sort_passes(f) & 1;
     *keys = in_b ? ws.keys_b : ws.keys_a;
     *ids = in_b ? ws.vals_b : ws.vals_a;
@@ -113,21 +127,30 @@ static int frame_forward_impl(const gs_frame *f, hipStream_t s, float *stage_ms)
     uint64_t *skeys, *okeys;
     uint32_t *sids;
     sorted_buffers(f, ws, &skeys, &sids, &okeys);
-    if (f->N > 0 && (rc = gs_stage_scan_emit(f, ws, s))) return rc;
-    tm.mark();
-    if (f->N > 0) {
-        // mode 0: all 32 + tile_bits key bits; mode 1: the tile bits only (stable => grouped by tile,
-        // Gaussian-index order inside a tile), the depth order is finished per tile in LDS below
-        int in1 = 0;
-        const int tb = tile_bits(G.n_tiles);
-        rc = gs_sort_pairs_bits(ws.keys_a, ws.vals_a, ws.keys_b, ws.vals_b,
-                                (const uint32_t *)(ws.counters + GS_CNT_PAIRS), f->max_pairs,
-                                f->sort_mode == 1 ? 32 : 0, 32 + tb, ws.sort_tmp, ws.sort_tmp_bytes, &in1, s);
-        if (rc) return rc;
+    const int mode = effective_sort_mode(f);
+    if (mode == 2) {
+        // counting sort by tile in LDS (stages "scan_emit" and "sort" collapse into this one)
+        if (f->N > 0 && (rc = gs_stage_tile_bin(f, ws, s))) return rc;
+        tm.mark();
+        tm.mark();
+        if (f->N > 0 && (rc = gs_stage_tile_sort_packed(f, ws, okeys, skeys, sids, s))) return rc;
+    } else {
+        if (f->N > 0 && (rc = gs_stage_scan_emit(f, ws, s))) return rc;
+        tm.mark();
+        if (f->N > 0) {
+            // mode 0: all 32 + tile_bits key bits; mode 1: the tile bits only (stable => grouped by tile,
+            // Gaussian-index order inside a tile), the depth order is finished per tile in LDS below
+            int in1 = 0;
+            const int tb = tile_bits(G.n_tiles);
+            rc = gs_sort_pairs_bits(ws.keys_a, ws.vals_a, ws.keys_b, ws.vals_b,
+                                    (const uint32_t *)(ws.counters + GS_CNT_PAIRS), f->max_pairs, mode == 1 ? 32 : 0,
+                                    32 + tb, ws.sort_tmp, ws.sort_tmp_bytes, &in1, s);
+            if (rc) return rc;
+        }
+        tm.mark();
+        if ((rc = gs_stage_tile_ranges(f, ws, skeys, s))) return rc;
+        if (mode == 1 && f->N > 0 && (rc = gs_stage_tile_sort(f, ws, skeys, sids, okeys, s))) return rc;
     }
-    tm.mark();
-    if ((rc = gs_stage_tile_ranges(f, ws, skeys, s))) return rc;
-    if (f->sort_mode == 1 && f->N > 0 && (rc = gs_stage_tile_sort(f, ws, skeys, sids, okeys, s))) return rc;
     tm.mark();  // stage "ranges" = tile ranges (+ the per-tile depth sort in mode 1)
     if ((rc = gs_stage_raster_forward(f, ws, sids, s))) return rc;
     tm.mark();

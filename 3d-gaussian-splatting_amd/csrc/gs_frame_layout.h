@@ -6,6 +6,8 @@ enum { GS_CNT_VISIBLE = 0, GS_CNT_PAIRS = 1, GS_CNT_OVERFLOW = 2, GS_CNT_BUCKETS
 
 #define GS_BUCKET 64          // Gaussians per backward bucket (= wavefront size)
 #define GS_SORT_TILE 2048     // keys per radix-sort workgroup (256 threads x 8)
+#define GS_BIN_SLICES 256     // sort_mode 2: workgroups (= slices of the Gaussian array) of the counting sort
+#define GS_BIN_MAX_TILES 32768  // sort_mode 2 needs a 4-byte LDS counter per tile (128 KiB of the CU's 160)
 
 // floats per per-pair gradient row: (dx, dy, da, db, dc, dd, dopa) + colour grads, padded to float4s
 static inline int gs_row_floats(int color_dim) { return color_dim == 3 ? 12 : 36; }
@@ -56,6 +58,10 @@ struct gs_frame_ws {
     void *sort_tmp;
     size_t sort_tmp_bytes;
     int32_t *tile_ranges;          // [T][2]
+    // sort_mode 2 (tile_bin.hip)
+    uint32_t *bin_table;           // [GS_BIN_SLICES][T] pairs of (slice, tile); scanned in place over slices
+    uint32_t *tile_count;          // [T]
+    uint32_t *slice_pairs, *slice_vis;  // [GS_BIN_SLICES]
     // training only
     uint32_t *tile_nproc;          // [T] Gaussians processed by the forward (multiple of the chunk)
     uint32_t *bucket_offsets;      // [T+1] exclusive scan of ceil(nproc/64)
@@ -102,6 +108,10 @@ static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pair
     ws.vals_b = (uint32_t *)take(sizeof(uint32_t) * max_pairs);
     ws.sort_tmp_bytes = gs_sort_pairs_tmp_bytes(max_pairs);
     ws.sort_tmp = take(ws.sort_tmp_bytes);
+    ws.bin_table = (uint32_t *)take(sizeof(uint32_t) * GS_BIN_SLICES * (size_t)G.n_tiles);
+    ws.tile_count = (uint32_t *)take(sizeof(uint32_t) * G.n_tiles);
+    ws.slice_pairs = (uint32_t *)take(sizeof(uint32_t) * GS_BIN_SLICES);
+    ws.slice_vis = (uint32_t *)take(sizeof(uint32_t) * GS_BIN_SLICES);
     ws.max_buckets = gs_max_buckets(max_pairs, G.n_tiles);
     if (training) {
         ws.tile_nproc = (uint32_t *)take(sizeof(uint32_t) * G.n_tiles);
@@ -125,6 +135,9 @@ int gs_stage_project_backward(const gs_frame *f, const gs_frame_ws &ws, float *g
 int gs_stage_scan_emit(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream);
 int gs_stage_tile_sort(const gs_frame *f, const gs_frame_ws &ws, uint64_t *keys, uint32_t *ids, uint64_t *scratch,
                        hipStream_t stream);
+int gs_stage_tile_bin(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream);
+int gs_stage_tile_sort_packed(const gs_frame *f, const gs_frame_ws &ws, uint64_t *packed, uint64_t *keys_out,
+                              uint32_t *ids_out, hipStream_t stream);
 int gs_stage_tile_ranges(const gs_frame *f, const gs_frame_ws &ws, const uint64_t *sorted_keys, hipStream_t stream);
 int gs_stage_raster_forward(const gs_frame *f, const gs_frame_ws &ws, const uint32_t *sorted_ids, hipStream_t stream);
 int gs_stage_raster_backward(const gs_frame *f, const gs_frame_ws &ws, const uint32_t *sorted_ids,

@@ -1,0 +1,265 @@
+// tile_bin.hip -- sort_mode 2: one-pass counting sort of the (tile, Gaussian) pairs by tile.
+//
+// The reference duplicates every Gaussian into its tiles and runs a full device radix sort on
+// 64-bit (tile, depth) keys (gaussian.cu:197-250 + torch.sort in renderer.py).  The tile part
+// of that key has at most a few tens of thousands of distinct values, which is a histogram that
+// fits the 160 KiB LDS of one CU.  So the pairs are never materialised in Gaussian order at all:
+//
+//   B1 bin_count_kernel   : <= 256 workgroups, each owns a contiguous slice of the Gaussians and
+//                           histograms the tiles of their rectangles in LDS (ds_add, no global
+//                           atomics); row b of a [B][T] table <- the histogram.
+//   B2 bin_colscan_kernel : exclusive scan of every table column over b (all loads of a column
+//                           are issued up front: one memory round trip), column total -> tile_count.
+//   B3 bin_scatter_kernel : every workgroup scans tile_count itself (T values, redundant but free
+//                           of any grid-wide dependency), adds its table row -> the first output
+//                           slot of (this slice, tile) in LDS, then walks its rectangles again
+//                           and writes (depth_bits << 32 | gaussian) at ds_add_rtn(slot, 1).
+//                           Workgroup 0 also writes tile_ranges and the frame counters.
+//
+// The order inside a (slice, tile) segment depends on LDS arbitration; the per-tile sort that
+// follows (tile_sort.hip) orders each tile by the UNIQUE composite (depth_bits, gaussian), so the
+// final list is the oracle's (tile, depth_bits, gaussian_index) order bit for bit, every run.
+// Traffic per pair: 8 B written here + the tile sort, against 2 x (3 launches, 36 B) of radix
+// passes in sort_mode 1.
+#include "gs_common.h"
+#include "gs_frame_layout.h"
+
+namespace {
+
+#define BIN_THREADS 1024
+#define BIN_SOLO 16  // rectangles up to this many tiles are walked by their own lane
+
+// Walks the rectangle of every Gaussian of this workgroup's slice and calls fn(tile, gaussian, depth_bits).
+// Small rectangles are handled by their own lane, large ones by the whole wave (one screen-filling
+// Gaussian must not serialise 64 lanes behind it).
+template <typename Fn>
+__device__ __forceinline__ void walk_rects(const uint32_t *__restrict__ tiles_touched,
+                                           const uint2 *__restrict__ rects, const float4 *__restrict__ rec_geom,
+                                           int64_t g, int64_t n, uint32_t ntx, bool need_depth, Fn fn) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t cnt = g < n ? tiles_touched[g] : 0;
+    uint2 rc = make_uint2(0, 0);
+    uint32_t dbits = 0;
+    if (cnt) {
+        rc = rects[g];
+        if (need_depth) dbits = __float_as_uint(rec_geom[g * GS_REC_STRIDE].z);
+    }
+    const uint32_t y0 = rc.x & 0xffff, x0 = rc.y & 0xffff, x1 = rc.y >> 16;
+    const uint32_t wdt = x1 - x0;
+    if (cnt && cnt <= BIN_SOLO) {
+        uint32_t ix = x0, iy = y0;
+        for (uint32_t k = 0; k < cnt; ++k) {
+            fn(ix + iy * ntx, (uint32_t)g, dbits);
+            if (++ix == x1) {
+                ix = x0;
+                ++iy;
+            }
+        }
+    }
+    unsigned long long big = __ballot(cnt > BIN_SOLO);
+    while (big) {
+        const int src = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        const uint32_t c = __shfl(cnt, src, 64), d = __shfl(dbits, src, 64);
+        const uint32_t sx0 = __shfl(x0, src, 64), sy0 = __shfl(y0, src, 64), sw = __shfl(wdt, src, 64);
+        const uint32_t id = (uint32_t)(g - lane + src);
+        for (uint32_t k = lane; k < c; k += 64) fn(sx0 + k % sw + (sy0 + k / sw) * ntx, id, d);
+    }
+}
+
+// ---------------------------------------------------------------- B1
+__global__ void __launch_bounds__(BIN_THREADS) bin_count_kernel(
+    const uint32_t *__restrict__ tiles_touched, const uint2 *__restrict__ rects, int64_t n, uint32_t per_block,
+    uint32_t T, uint32_t ntx, uint32_t *__restrict__ table, const uint32_t *__restrict__ block_sums,
+    const uint32_t *__restrict__ block_vis, uint32_t *__restrict__ slice_pairs, uint32_t *__restrict__ slice_vis) {
+    extern __shared__ uint32_t s_hist[];
+    __shared__ uint32_t s_acc[2];
+    for (uint32_t t = threadIdx.x; t < T; t += BIN_THREADS) s_hist[t] = 0;
+    if (threadIdx.x < 2) s_acc[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t g0 = (int64_t)blockIdx.x * per_block;
+    for (uint32_t base = 0; base < per_block; base += BIN_THREADS) {
+        const uint32_t i = base + threadIdx.x;
+        walk_rects(tiles_touched, rects, nullptr, i < per_block ? g0 + i : n, n, ntx, false,
+                   [&](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&s_hist[tile], 1u); });
+    }
+    // pairs / visible Gaussians of this slice: sums over the 256-Gaussian blocks of the project stage
+    const int64_t nblk = (n + 255) / 256;
+    for (uint32_t k = threadIdx.x; k < per_block / 256; k += BIN_THREADS) {
+        const int64_t pb = g0 / 256 + k;
+        if (pb < nblk) {
+            atomicAdd(&s_acc[0], block_sums[pb]);
+            atomicAdd(&s_acc[1], block_vis[pb]);
+        }
+    }
+    __syncthreads();
+    uint32_t *row = table + (size_t)blockIdx.x * T;
+    for (uint32_t t = threadIdx.x; t < T; t += BIN_THREADS) row[t] = s_hist[t];
+    if (threadIdx.x == 0) {
+        slice_pairs[blockIdx.x] = s_acc[0];
+        slice_vis[blockIdx.x] = s_acc[1];
+    }
+}
+
+// ---------------------------------------------------------------- B2
+// Workgroup = 64 consecutive tiles (lane = tile) x 4 waves; wave w owns slices [64 w, 64 w + 64).
+__global__ void __launch_bounds__(256) bin_colscan_kernel(uint32_t *__restrict__ table, uint32_t B, uint32_t T,
+                                                         uint32_t *__restrict__ tile_count) {
+    __shared__ uint32_t s_tot[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t t = blockIdx.x * 64 + lane;
+    const bool ok = t < T;
+    uint32_t v[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        const uint32_t b = wave * 64 + i;
+        v[i] = (ok && b < B) ? table[(size_t)b * T + t] : 0;
+    }
+    uint32_t run = 0;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        const uint32_t c = v[i];
+        v[i] = run;
+        run += c;
+    }
+    s_tot[wave][lane] = run;
+    __syncthreads();
+    uint32_t off = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint32_t x = s_tot[w][lane];
+        off += w < wave ? x : 0;
+        total += x;
+    }
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        const uint32_t b = wave * 64 + i;
+        if (ok && b < B) table[(size_t)b * T + t] = v[i] + off;
+    }
+    if (ok && wave == 0) tile_count[t] = total;
+}
+
+// ---------------------------------------------------------------- B3
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_wave, uint32_t &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t incl = gs_wave_incl_scan_u32(v);
+    __syncthreads();  // s_wave may still be read from the previous call
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t off = 0;
+    total = 0;
+#pragma unroll
+    for (int w = 0; w < BIN_THREADS / 64; ++w) {
+        const uint32_t x = s_wave[w];
+        off += w < wave ? x : 0;
+        total += x;
+    }
+    return off + incl - v;
+}
+
+__global__ void __launch_bounds__(BIN_THREADS) bin_scatter_kernel(
+    const uint32_t *__restrict__ tiles_touched, const uint2 *__restrict__ rects,
+    const float4 *__restrict__ rec_geom, int64_t n, uint32_t per_block, uint32_t T, uint32_t ntx,
+    const uint32_t *__restrict__ table, const uint32_t *__restrict__ tile_count,
+    const uint32_t *__restrict__ slice_pairs, const uint32_t *__restrict__ slice_vis, uint32_t B,
+    uint64_t *__restrict__ out, uint64_t max_pairs, uint32_t *__restrict__ pair_offsets,
+    int32_t *__restrict__ tile_ranges, unsigned long long *__restrict__ counters) {
+    extern __shared__ uint32_t s_slot[];
+    __shared__ uint32_t s_wave[BIN_THREADS / 64];
+    // 1. tile starts = exclusive scan of tile_count (every workgroup computes all of them)
+    const uint32_t per = (T + BIN_THREADS - 1) / BIN_THREADS;
+    const uint32_t t0 = threadIdx.x * per, t1 = t0 + per < T ? t0 + per : T;
+    uint32_t mine = 0;
+    for (uint32_t t = t0; t < t1; ++t) mine += tile_count[t];
+    uint32_t M;
+    uint32_t run = block_excl_scan(mine, s_wave, M);
+    if (M > max_pairs) {  // not enough room: leave the frame empty and report the true count
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            counters[GS_CNT_PAIRS] = 0;
+            counters[GS_CNT_OVERFLOW] = M;
+        }
+        return;
+    }
+    for (uint32_t t = t0; t < t1; ++t) {
+        s_slot[t] = run;
+        run += tile_count[t];
+    }
+    __syncthreads();
+    const uint32_t *row = table + (size_t)blockIdx.x * T;
+    if (blockIdx.x == 0)
+        for (uint32_t t = threadIdx.x; t < T; t += BIN_THREADS) {
+            const uint32_t s = s_slot[t], c = tile_count[t];  // row 0 of the scanned table is all zeros
+            if (c) reinterpret_cast<int2 *>(tile_ranges)[t] = make_int2((int)s, (int)(s + c));
+        }
+    else
+        for (uint32_t t = threadIdx.x; t < T; t += BIN_THREADS) s_slot[t] += row[t];
+    // 2. slice totals: frame counters, and the emission offset of this slice (per-pair gradient rows)
+    uint32_t before = 0, vis = 0, dummy;
+    if (pair_offsets || blockIdx.x == 0) {
+        uint32_t p = 0, v = 0;
+        for (uint32_t b = threadIdx.x; b < B; b += BIN_THREADS) {
+            p += b < blockIdx.x ? slice_pairs[b] : 0;
+            v += slice_vis[b];
+        }
+        block_excl_scan(p, s_wave, before);
+        block_excl_scan(v, s_wave, vis);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            counters[GS_CNT_PAIRS] = M;
+            counters[GS_CNT_OVERFLOW] = 0;
+            counters[GS_CNT_VISIBLE] = vis;
+        }
+    }
+    __syncthreads();
+    // 3. scatter
+    const int64_t g0 = (int64_t)blockIdx.x * per_block;
+    for (uint32_t base = 0; base < per_block; base += BIN_THREADS) {  // uniform trip count (barriers inside)
+        const uint32_t i = base + threadIdx.x;
+        const int64_t g = i < per_block ? g0 + i : n;
+        if (pair_offsets) {  // uniform: prefix sum of tiles_touched in Gaussian order
+            const uint32_t cnt = g < n ? tiles_touched[g] : 0;
+            const uint32_t ex = block_excl_scan(cnt, s_wave, dummy);
+            if (g < n) pair_offsets[g] = before + ex;
+            before += dummy;
+        }
+        walk_rects(tiles_touched, rects, rec_geom, g, n, ntx, true, [&](uint32_t tile, uint32_t id, uint32_t d) {
+            const uint32_t slot = atomicAdd(&s_slot[tile], 1u);
+            out[slot] = ((uint64_t)d << 32) | id;
+        });
+    }
+}
+
+}  // namespace
+
+// Gaussians per slice: a multiple of 256 (the project stage's block) with at most GS_BIN_SLICES slices.
+static uint32_t bin_per_block(int64_t N) {
+    const int64_t per = gs_div_up(gs_div_up(N > 0 ? N : 1, GS_BIN_SLICES), 256) * 256;
+    return (uint32_t)per;
+}
+
+int gs_stage_tile_bin(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream) {
+    gs_frame_geom G = gs_frame_geometry(f);
+    const uint32_t T = (uint32_t)G.n_tiles, per_block = bin_per_block(f->N);
+    const uint32_t B = (uint32_t)gs_div_up(f->N, per_block);
+    const size_t lds = sizeof(uint32_t) * T;
+    static bool attr_set = false;
+    if (!attr_set) {  // histograms above 64 KiB need the opt-in (gfx950: 160 KiB per workgroup)
+        GS_HIP(hipFuncSetAttribute((const void *)bin_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   GS_BIN_MAX_TILES * 4));
+        GS_HIP(hipFuncSetAttribute((const void *)bin_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   GS_BIN_MAX_TILES * 4));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(bin_count_kernel, dim3(B), dim3(BIN_THREADS), lds, stream, ws.tiles_touched, ws.rects, f->N,
+                       per_block, T, (uint32_t)G.ntx, ws.bin_table, ws.block_sums, ws.block_vis, ws.slice_pairs,
+                       ws.slice_vis);
+    GS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bin_colscan_kernel, dim3((unsigned)gs_div_up(T, 64)), dim3(256), 0, stream, ws.bin_table, B,
+                       T, ws.tile_count);
+    GS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3(B), dim3(BIN_THREADS), lds, stream, ws.tiles_touched, ws.rects,
+                       ws.rec_geom, f->N, per_block, T, (uint32_t)G.ntx, ws.bin_table, ws.tile_count,
+                       ws.slice_pairs, ws.slice_vis, B, ws.keys_a, (uint64_t)f->max_pairs,
+                       f->training ? ws.pair_offsets : nullptr, ws.tile_ranges, ws.counters);
+    GS_CHECK_LAUNCH();
+    return 0;
+}

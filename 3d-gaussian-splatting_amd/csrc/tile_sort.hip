@@ -96,9 +96,11 @@ __device__ __forceinline__ void bitonic_sort(Mem a, uint32_t n, uint32_t P) {
     }
 }
 
-// keys: (tile << 32 | depth_bits) grouped by tile, ids: Gaussian index; both are overwritten in
-// place with the depth-sorted order.  scratch: the idle half of the key double buffer.
-template <int CAP>
+// PACKED = false (sort_mode 1): keys = (tile << 32 | depth_bits) grouped by tile, ids = Gaussian index;
+//   both are overwritten in place with the depth-sorted order; scratch = idle half of the key buffer.
+// PACKED = true (sort_mode 2): packed = (depth_bits << 32 | gaussian) grouped by tile in arbitrary
+//   order; the sorted (tile << 32 | depth_bits) and ids go to keys / ids; long buckets sort in place.
+template <int CAP, bool PACKED>
 __global__ void __launch_bounds__(256) tile_sort_kernel(uint64_t *__restrict__ keys, uint32_t *__restrict__ ids,
                                                        uint64_t *__restrict__ scratch,
                                                        const int32_t *__restrict__ ranges) {
@@ -106,45 +108,56 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(uint64_t *__restrict__ k
     const uint32_t tile = blockIdx.x;
     const uint32_t start = (uint32_t)ranges[2 * tile], end = (uint32_t)ranges[2 * tile + 1];
     const uint32_t n = end - start;
-    if (n < 2) return;
+    auto load = [&](uint32_t i) -> uint64_t {
+        return PACKED ? scratch[start + i] : (keys[start + i] << 32) | ids[start + i];
+    };
+    auto store = [&](uint32_t i, uint64_t v) {
+        ids[start + i] = (uint32_t)v;
+        keys[start + i] = ((uint64_t)tile << 32) | (v >> 32);
+    };
+    if (n < 2) {
+        if (PACKED && n == 1 && threadIdx.x == 0) store(0, load(0));
+        return;
+    }
     uint32_t P = 1;
     while (P < n) P <<= 1;
     if (P <= 128) {  // one wave does everything; the other three leave
         if (threadIdx.x >= 64) return;
-        for (uint32_t i = threadIdx.x; i < n; i += 64)
-            s_a[i] = (keys[start + i] << 32) | ids[start + i];
+        for (uint32_t i = threadIdx.x; i < n; i += 64) s_a[i] = load(i);
         __builtin_amdgcn_wave_barrier();
         bitonic_sort<uint64_t *, false>(s_a, n, P);
-        for (uint32_t i = threadIdx.x; i < n; i += 64) {
-            const uint64_t v = s_a[i];
-            ids[start + i] = (uint32_t)v;
-            keys[start + i] = ((uint64_t)tile << 32) | (v >> 32);
-        }
+        for (uint32_t i = threadIdx.x; i < n; i += 64) store(i, s_a[i]);
         return;
     }
     uint64_t *a = n <= (uint32_t)CAP ? s_a : scratch + start;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) a[i] = (keys[start + i] << 32) | ids[start + i];
+    if (!PACKED || n <= (uint32_t)CAP)
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) a[i] = load(i);
     __syncthreads();
     if (n <= (uint32_t)CAP)
         bitonic_sort<uint64_t *, true>(s_a, n, P);
     else
         bitonic_sort_global(scratch + start, n, P);
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const uint64_t v = a[i];
-        ids[start + i] = (uint32_t)v;
-        keys[start + i] = ((uint64_t)tile << 32) | (v >> 32);
-    }
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) store(i, a[i]);
 }
 
 }  // namespace
 
+// 2048 pairs (16 KiB of LDS, 8 workgroups per CU) cover Garden-scale tiles; longer buckets take the
+// in-place global path of the same kernel.
 int gs_stage_tile_sort(const gs_frame *f, const gs_frame_ws &ws, uint64_t *keys, uint32_t *ids, uint64_t *scratch,
                        hipStream_t stream) {
     gs_frame_geom G = gs_frame_geometry(f);
-    // 2048 pairs (16 KiB of LDS, 8 workgroups per CU) cover Garden-scale tiles; longer buckets
-    // take the in-place global path of the same kernel
-    hipLaunchKernelGGL(tile_sort_kernel<2048>, dim3(G.n_tiles), dim3(256), 0, stream, keys, ids, scratch,
+    hipLaunchKernelGGL((tile_sort_kernel<2048, false>), dim3(G.n_tiles), dim3(256), 0, stream, keys, ids, scratch,
                        ws.tile_ranges);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+int gs_stage_tile_sort_packed(const gs_frame *f, const gs_frame_ws &ws, uint64_t *packed, uint64_t *keys_out,
+                              uint32_t *ids_out, hipStream_t stream) {
+    gs_frame_geom G = gs_frame_geometry(f);
+    hipLaunchKernelGGL((tile_sort_kernel<2048, true>), dim3(G.n_tiles), dim3(256), 0, stream, keys_out, ids_out,
+                       packed, ws.tile_ranges);
     GS_CHECK_LAUNCH();
     return 0;
 }

@@ -39,7 +39,7 @@ class FrameStats:
 class FrameRenderer:
     def __init__(self, device="cuda", max_pairs: int = 1 << 20, training: bool = False,
                  thresh: float = 0.05, scale_activation: str = "abs", auto_grow: bool = True,
-                 sort_mode: int = 1):
+                 sort_mode: int = 2):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("FrameRenderer needs a HIP device; there is no CPU fallback")
@@ -48,7 +48,9 @@ class FrameRenderer:
         self.thresh = float(thresh)
         self.scale_activation = SCALE_ACT[scale_activation]
         self.auto_grow = auto_grow
-        self.sort_mode = int(sort_mode)  # 0: LSD radix on 64-bit keys, 1: MSD tile-bucketed (same order)
+        # 0: LSD radix on 64-bit keys, 1: tile-bit radix + per-tile LDS sort, 2: LDS counting sort by tile
+        # + per-tile LDS sort (all three give the same list)
+        self.sort_mode = int(sort_mode)
         self._ws: Optional[torch.Tensor] = None
         self._stats_host = torch.zeros(4, dtype=torch.int64).pin_memory()
         self._frame: Optional[_lib.GsFrame] = None

@@ -177,7 +177,11 @@ typedef struct gs_frame {
     int32_t sort_mode;        /* how the (tile, depth) order is produced -- same result either way:
                                  0 = LSD radix sort of 64-bit (tile<<32|depth) keys (gs_sort_pairs)
                                  1 = hybrid: stable LSD radix passes on the tile bits only (2 passes at
-                                     1080p), then every tile's bucket sorted on (depth, id) in LDS */
+                                     1080p), then every tile's bucket sorted on (depth, id) in LDS
+                                 2 = counting sort by tile with one LDS counter per tile (<= 32768 tiles,
+                                     larger grids take mode 1), then the same per-tile LDS sort.  On
+                                     capacity overflow the frame is left empty (modes 0/1 keep the first
+                                     max_pairs pairs); all modes report the true count in the stats. */
 } gs_frame;
 
 /* Bytes of workspace needed for N Gaussians, `max_pairs` pairs, a width x height image. */

@@ -27,7 +27,7 @@ def case(n, W, H, seed=7, use_sh=False, yaw=2.0):
     return scene, cam
 
 
-def check_forward(gpu, scene, cam, training=False, sort_mode=1):
+def check_forward(gpu, scene, cam, training=False, sort_mode=2):
     of = OracleFrame(scene, cam)
     r = FrameRenderer(gpu, max_pairs=max(len(of.ids) + 17, 64), training=training, auto_grow=False,
                       sort_mode=sort_mode)
@@ -59,7 +59,7 @@ def check_forward(gpu, scene, cam, training=False, sort_mode=1):
     return of, r, params
 
 
-@pytest.mark.parametrize("sort_mode", [0, 1])
+@pytest.mark.parametrize("sort_mode", [0, 1, 2])
 @pytest.mark.parametrize("n,W,H", [(10_000, 256, 256), (30_000, 333, 201), (2_000, 64, 48)])
 def test_frame_forward_parity(gpu, n, W, H, sort_mode):
     check_forward(gpu, *case(n, W, H), sort_mode=sort_mode)
@@ -68,7 +68,7 @@ def test_frame_forward_parity(gpu, n, W, H, sort_mode):
 def test_frame_forward_giant_bucket_sorted_in_global_memory(gpu):
     # > 2048 pairs in one tile: the per-tile sort leaves LDS and runs in place in global memory
     scene, cam = case(40_000, 32, 32, seed=8)
-    of, _, _ = check_forward(gpu, scene, cam, sort_mode=1)
+    of, _, _ = check_forward(gpu, scene, cam, sort_mode=2)
     assert np.diff(of.accum).max() > 4096
 
 
@@ -76,7 +76,7 @@ def test_frame_forward_sh(gpu):
     check_forward(gpu, *case(8_000, 160, 96, use_sh=True))
 
 
-@pytest.mark.parametrize("sort_mode", [0, 1])
+@pytest.mark.parametrize("sort_mode", [0, 1, 2])
 def test_frame_forward_dense_tiles_multi_chunk(gpu, sort_mode):
     # ~1.5k Gaussians per tile: several 256-Gaussian LDS chunks per tile + early termination
     scene, cam = case(60_000, 96, 64, seed=3)
@@ -142,7 +142,7 @@ def test_frame_capacity_overflow_grows(gpu):
     assert r2.stats().overflow == len(of.ids)  # reported, never silently dropped
 
 
-@pytest.mark.parametrize("sort_mode", [0, 1])
+@pytest.mark.parametrize("sort_mode", [0, 1, 2])
 def test_frame_repeatable_bitwise(gpu, sort_mode):
     scene, cam = case(10_000, 128, 128)
     r = FrameRenderer(gpu, max_pairs=1 << 17, auto_grow=False, sort_mode=sort_mode)
@@ -176,7 +176,7 @@ def cfg2_frame(gpu):
     scene, cam = make_scene(n, W, H, seed=2023, use_sh=use_sh), make_camera(W, H)
     params = to_torch(scene, gpu)
     out = {}
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         r = FrameRenderer(gpu, max_pairs=1_300_000, auto_grow=False, sort_mode=mode)
         img, _ = r.forward(*params, cam)
         v = r.debug_views()
@@ -187,8 +187,8 @@ def cfg2_frame(gpu):
 
 def test_full_size_sortedness_and_mode_equivalence(cfg2_frame):
     """Size-independent properties at the headline size: keys ascending, (key, id) strictly ascending
-    (ties resolved by Gaussian index), tile ranges partition the list, and the two sort algorithms
-    (six LSD passes vs tile-bit passes + per-tile LDS sort) give the identical list and image."""
+    (ties resolved by Gaussian index), tile ranges partition the list, and the three sort algorithms
+    (six LSD passes / tile-bit passes + per-tile LDS sort / LDS counting sort + per-tile LDS sort) give the identical list and image."""
     _, _, out = cfg2_frame
     a, b = out[0], out[1]
     assert a["stats"].pairs == b["stats"].pairs == 1_088_150 and a["stats"].visible == 296_317
@@ -202,8 +202,10 @@ def test_full_size_sortedness_and_mode_equivalence(cfg2_frame):
     assert np.array_equal(r[:, 1] - r[:, 0], cnt)
     nz = cnt > 0
     assert np.array_equal(r[nz, 0], (np.cumsum(cnt) - cnt)[nz])
-    assert np.array_equal(a["keys"], b["keys"]) and np.array_equal(a["ids"], b["ids"])
-    assert np.array_equal(a["img"], b["img"])
+    for other in (a, out[2]):
+        assert np.array_equal(other["keys"], b["keys"]) and np.array_equal(other["ids"], b["ids"])
+        assert np.array_equal(other["ranges"], b["ranges"])
+        assert np.array_equal(other["img"], b["img"])
 
 
 def test_full_size_forward_matches_oracle(cfg2_frame):
