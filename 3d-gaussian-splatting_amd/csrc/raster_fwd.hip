@@ -13,6 +13,8 @@
 //   * in training mode the kernel also stores the per-pixel state (T, C) at every 64-Gaussian
 //     bucket boundary; the backward pass uses these checkpoints to process buckets
 //     independently (raster_bwd.hip).
+#include <stdlib.h>
+
 #include "raster_common.h"
 
 namespace {
@@ -21,6 +23,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 constexpr int FWD_THREADS = 64;  // ONE wave64 per 16x16 tile, 4 pixels per lane
 constexpr int NPP = 2;           // pixel pairs per lane
+#ifndef GS_FWD_WAVES_PER_SIMD
+#define GS_FWD_WAVES_PER_SIMD 8
+#endif
 
 template <int CDIM>
 struct FwdSmem;
@@ -28,19 +33,29 @@ template <>
 struct FwdSmem<3> {
     // structure of arrays: four consecutive Gaussians of one field are one ds_read_b128
     static constexpr int CH = 64;
-    enum { X, Y, A, B, C, OPA, R, G, BL, NFIELD };
+    enum { X, Y, A, B, C, NLOP, R, G, BL, NFIELD };  // NLOP = -log2(opacity)
     float f[2][NFIELD][CH] __attribute__((aligned(16)));
 };
 template <>
 struct FwdSmem<27> {
     static constexpr int CH = 64;
-    enum { X, Y, A, B, C, OPA, NFIELD };
+    enum { X, Y, A, B, C, NLOP, NFIELD };
     float f[2][NFIELD][CH] __attribute__((aligned(16)));
     float sh[2][CH][28] __attribute__((aligned(16)));
 };
 
 __device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// Exact per-pixel liveness in ONE packed instruction: m = clamp((t - 0.0001f) * 2^100) is 1.0 when
+// t > 0.0001f and 0.0 otherwise (the fma is exact up to its final rounding, and the smallest positive
+// t - 0.0001f is one ulp of 1e-4, which 2^100 lifts far above 1).  Replaces v_cmp + v_cndmask per pixel.
+#define GS_LIVE_SCALE 1.2676506002282294e30f /* 2^100 */
+__device__ __forceinline__ f2 live_mask(f2 t, f2 scale, f2 bias) {
+    f2 m;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(m) : "v"(t), "v"(scale), "v"(bias));
+    return m;
+}
 
 // Lane l owns the four pixels (x, y0 + 4k), k = 0..3, of the tile, x = l & 15, y0 = l >> 4; pixel
 // index inside the tile p_k = 64 k + l.  Why four pixels per lane: the compositing loop is bound by
@@ -51,23 +66,55 @@ __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elemen
 // With a single wave per tile there is no workgroup barrier at all; the staging of the next
 // chunk (one Gaussian per lane) overlaps the compositing of the current one through registers.
 // The fp32 math is packed over pixel PAIRS (v_pk_*_f32; dx is shared by all four pixels).
+// The kernel is PERSISTENT: the grid is a few waves per SIMD and every wave walks tiles blockIdx.x,
+// blockIdx.x + gridDim.x, ...  While a wave composites the LAST chunk of its tile it already gathers
+// chunk 0 of its NEXT tile, so the dependent id -> record gather latency (and the per-tile range load)
+// sits behind math instead of in front of it.  With one tile per wave all waves run their gather,
+// math and store phases in lockstep and the phases add up instead of overlapping.
 template <int CDIM, bool FRAME, bool CKPT, bool SIG, bool WN>
 __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S, RasterGeom G,
                                                                     const int32_t *__restrict__ ranges,
                                                                     float *__restrict__ out_padded,
                                                                     float *__restrict__ out_image,
                                                                     float4 *__restrict__ ckpt,
-                                                                    uint32_t *__restrict__ tile_nproc) {
+                                                                    uint32_t *__restrict__ tile_nproc,
+                                                                    uint32_t n_tiles) {
     using SM = FwdSmem<CDIM>;
     constexpr int CH = SM::CH;
     __shared__ SM sm;
-
-    const uint32_t tile = blockIdx.x;
-    const uint32_t tx = tile % (uint32_t)G.ntx, ty = tile / (uint32_t)G.ntx;
-    const uint32_t start = (uint32_t)(FRAME ? ranges[2 * tile] : ranges[tile]);
-    const uint32_t end = (uint32_t)(FRAME ? ranges[2 * tile + 1] : ranges[tile + 1]);
-    const uint32_t n = end - start;
     const int lane = threadIdx.x;
+
+    auto range_of = [&](uint32_t t, uint32_t &s0, uint32_t &cnt) {
+        s0 = cnt = 0;
+        if (t < n_tiles) {
+            s0 = (uint32_t)(FRAME ? ranges[2 * t] : ranges[t]);
+            cnt = (uint32_t)(FRAME ? ranges[2 * t + 1] : ranges[t + 1]) - s0;
+        }
+    };
+    uint32_t tile = blockIdx.x, start, n, nstart, nn;
+    range_of(tile, start, n);
+    range_of(tile + gridDim.x, nstart, nn);
+
+    // register stage for the next chunk (one Gaussian per lane)
+    GaussianRec g;
+    float r0 = 0, r1 = 0, r2 = 0;
+    float4 cq = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t gid = 0, gj = 0;
+    bool have = false;
+    auto fetch = [&](uint32_t s0, uint32_t cnt, uint32_t base) {
+        have = base + lane < cnt;
+        if (have) {
+            gj = s0 + base + lane;
+            gid = raster_load<FRAME>(S, gj, g);
+            if (FRAME) cq = S.conic4[(size_t)gid * GS_REC_STRIDE];
+            if (CDIM == 3) raster_load_rgb<FRAME>(S, gj, gid, r0, r1, r2);
+        }
+    };
+    fetch(start, n, 0);
+    int k = 0;  // chunk counter across tiles: LDS ring slot
+
+    for (; tile < n_tiles; tile += gridDim.x) {
+    const uint32_t tx = tile % (uint32_t)G.ntx, ty = tile / (uint32_t)G.ntx;
     const uint32_t id_x = tx * 16 + (lane & 15), id_y0 = ty * 16 + (lane >> 4);
     const float px = raster_pixel_coord(id_x, G.padW, G.focal_x);
     f2 py2[NPP];
@@ -83,33 +130,22 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
             raster_pixel_sh(id_x, id_y0 + 8 * h, G, a9);
             raster_pixel_sh(id_x, id_y0 + 8 * h + 4, G, b9);
 #pragma unroll
-            for (int k = 0; k < 9; ++k) SH[h][k] = f2{a9[k], b9[k]};
+            for (int k9 = 0; k9 < 9; ++k9) SH[h][k9] = f2{a9[k9], b9[k9]};
         }
     }
 
-    // pair h holds rows y0 + 8h (x) and y0 + 8h + 4 (y): tile pixel indices 128h + lane, 128h + 64 + lane
+    // pair h holds rows y0 + 8h (x) and y0 + 8h + 4 (y): tile pixel indices 128h + lane, 128h + 64 + lane.
+    // T is the MASKED transmittance: it drops to exactly 0 once the pixel's transmittance is <= 0.0001
+    // (the reference's per-pixel `accum < 0.0001` stop, gaussian.cu:906), so a finished pixel adds nothing.
     f2 T[NPP], cr[NPP], cg[NPP], cb[NPP], accw[NPP];
 #pragma unroll
     for (int h = 0; h < NPP; ++h) {
         T[h] = f2{1.0f, 1.0f};
         cr[h] = cg[h] = cb[h] = accw[h] = f2{0.f, 0.f};
     }
+    const f2 live_scale = splat(GS_LIVE_SCALE), live_bias = splat(-GS_T_STOP * GS_LIVE_SCALE);
     uint32_t nproc = 0;
 
-    // register stage for the next chunk (one Gaussian per lane)
-    GaussianRec g;
-    float r0 = 0, r1 = 0, r2 = 0;
-    float4 cq = make_float4(0.f, 0.f, 0.f, 0.f);
-    uint32_t gid = 0;
-    bool have = false;
-    auto fetch = [&](uint32_t base) {
-        have = base + lane < n;
-        if (have) {
-            gid = raster_load<FRAME>(S, start + base + lane, g);
-            if (FRAME) cq = S.conic4[(size_t)gid * GS_REC_STRIDE];
-            if (CDIM == 3) raster_load_rgb<FRAME>(S, start + base + lane, gid, r0, r1, r2);
-        }
-    };
     auto write_ckpt = [&](uint32_t idx_in_tile) {
         float4 *c = ckpt + raster_ckpt_slot(start, tile, idx_in_tile / GS_BUCKET) * 256;
 #pragma unroll
@@ -119,15 +155,13 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
         }
     };
     auto any_live = [&]() {
-        bool l = false;
+        f2 sum = T[0];
 #pragma unroll
-        for (int h = 0; h < NPP; ++h) l = l || T[h].x > GS_T_STOP || T[h].y > GS_T_STOP;
-        return __ballot(l) != 0ull;
+        for (int h = 1; h < NPP; ++h) sum += T[h];
+        return __ballot(sum.x + sum.y > 0.0f) != 0ull;
     };
 
-    fetch(0);
-    int k = 0;
-    bool done = false;
+    bool done = false, staged_next = false;  // staged_next: the register stage holds chunk 0 of the NEXT tile
     for (uint32_t base = 0; base < n && !done; base += CH, ++k) {
         const int buf = k & 1;  // two-deep ring: the wave is in program order, so writing buffer k&1 here
                                 // cannot overtake its own reads of two chunks ago
@@ -148,20 +182,22 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
             sm.f[buf][SM::A][lane] = A;
             sm.f[buf][SM::B][lane] = B;
             sm.f[buf][SM::C][lane] = C;
-            sm.f[buf][SM::OPA][lane] = opa;
+            // frame path: the opacity (a sigmoid, > 0) rides in the exponent, alpha = 2^-(q + nlop); the
+            // reference API may be handed any opacity (zero, negative), so it keeps the multiplication
+            sm.f[buf][SM::NLOP][lane] = FRAME ? -__log2f(opa) : opa;
             if constexpr (CDIM == 3) {
                 sm.f[buf][SM::R][lane] = r0;
                 sm.f[buf][SM::G][lane] = r1;
                 sm.f[buf][SM::BL][lane] = r2;
             } else {
-                const float *src = raster_sh_ptr<FRAME>(S, start + base + lane, gid);
+                const float *src = raster_sh_ptr<FRAME>(S, gj, gid);
 #pragma unroll
                 for (int q = 0; q < 27; ++q) sm.sh[buf][lane][q] = src[q];
             }
         } else if (base + lane < ((n + 3u) & ~3u)) {
             // pad the ragged tail to a multiple of 4 with null Gaussians (opacity 0 => alpha 0)
 #pragma unroll
-            for (int q = 0; q < SM::NFIELD; ++q) sm.f[buf][q][lane] = 0.f;
+            for (int q = 0; q < SM::NFIELD; ++q) sm.f[buf][q][lane] = (FRAME && q == SM::NLOP) ? 1e30f : 0.f;
             if constexpr (CDIM == 27) {
 #pragma unroll
                 for (int q = 0; q < 27; ++q) sm.sh[buf][lane][q] = 0.f;
@@ -169,7 +205,12 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        fetch(base + CH);  // overlaps with the compositing below
+        // overlaps with the compositing below: the next chunk of this tile, or chunk 0 of the next tile
+        staged_next = base + CH >= n;
+        if (staged_next)
+            fetch(nstart, nn, 0);
+        else
+            fetch(start, n, base + CH);
         const uint32_t cnt = (n - base) < (uint32_t)CH ? (n - base) : (uint32_t)CH;
         if (CKPT) write_ckpt(base);  // CH == GS_BUCKET: one checkpoint per chunk
         // groups of 4 Gaussians: one wave-uniform liveness test per group, per-pixel masking inside
@@ -181,7 +222,7 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
             }
             auto ld4 = [&](int q) { return *(const float4 *)__builtin_assume_aligned(&sm.f[buf][q][i], 16); };
             const float4 X = ld4(SM::X), Y = ld4(SM::Y), A4 = ld4(SM::A), B4 = ld4(SM::B), C4 = ld4(SM::C);
-            const float4 O4 = ld4(SM::OPA);
+            const float4 O4 = ld4(SM::NLOP);
             float4 R4, G4, L4;
             if constexpr (CDIM == 3) {
                 R4 = ld4(SM::R);
@@ -195,24 +236,23 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
                 const float cA = u == 0 ? A4.x : u == 1 ? A4.y : u == 2 ? A4.z : A4.w;
                 const float cB = u == 0 ? B4.x : u == 1 ? B4.y : u == 2 ? B4.z : B4.w;
                 const float cC = u == 0 ? C4.x : u == 1 ? C4.y : u == 2 ? C4.z : C4.w;
-                const float op = u == 0 ? O4.x : u == 1 ? O4.y : u == 2 ? O4.z : O4.w;
+                const float nlop = u == 0 ? O4.x : u == 1 ? O4.y : u == 2 ? O4.z : O4.w;
+                // q + nlop = (C dy - B dx) dy + (A dx^2 + nlop): dx is shared by the lane's four pixels
                 const float dx = px - gx;
-                const float adx = cA * dx;
+                const float bdx = cB * dx;
+                const float f = FRAME ? fmaf(cA * dx, dx, nlop) : cA * dx * dx;
 #pragma unroll
                 for (int h = 0; h < NPP; ++h) {
                     const f2 dy = py2[h] - splat(gy);
-                    const f2 t = pk_fma(splat(-cB), dy, splat(adx));        // A dx - B dy
-                    const f2 q = pk_fma(splat(cC) * dy, dy, splat(dx) * t);  // + C dy^2
+                    const f2 q = pk_fma(pk_fma(splat(cC), dy, splat(-bdx)), dy, splat(f));
                     f2 al;
                     al.x = gs_exp2(-q.x);
                     al.y = gs_exp2(-q.y);
-                    al = al * splat(op);
+                    if (!FRAME) al = al * splat(nlop);
                     if (SIG) {  // gaussian.cu:930
                         al.x = 2.0f / (__expf(-al.x) + 1.0f) - 1.0f;
                         al.y = 2.0f / (__expf(-al.y) + 1.0f) - 1.0f;
                     }
-                    al.x = (T[h].x > GS_T_STOP) ? al.x : 0.0f;
-                    al.y = (T[h].y > GS_T_STOP) ? al.y : 0.0f;
                     const f2 w = al * T[h];
                     if constexpr (CDIM == 3) {
                         cr[h] = pk_fma(splat(u == 0 ? R4.x : u == 1 ? R4.y : u == 2 ? R4.z : R4.w), w, cr[h]);
@@ -235,7 +275,8 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
                         cb[h] = pk_fma(w, c2, cb[h]);
                     }
                     if (WN) accw[h] += w;
-                    T[h] = pk_fma(-al, T[h], T[h]);  // T * (1 - alpha)
+                    const f2 t = T[h] - w;  // T * (1 - alpha)
+                    T[h] = t * live_mask(t, live_scale, live_bias);
                 }
             }
         }
@@ -243,6 +284,7 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
         // the backward pass masks finished pixels by their transmittance
         nproc = base + cnt;
     }
+    if (!staged_next) fetch(nstart, nn, 0);  // empty tile, or the wave stopped before its last chunk
     if (tile_nproc && lane == 0) tile_nproc[tile] = nproc;
 
 #pragma unroll
@@ -270,17 +312,37 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
                 }
             }
         }
+    start = nstart;
+    n = nn;
+    range_of(tile + 2 * gridDim.x, nstart, nn);
+    }  // tile loop
+}
+
+// Waves in the persistent grid: every wave gets the same number of tiles (+-1), about four waves per
+// SIMD (enough to keep the VALU issue port busy; measured in tools/ubench/raster_loop.hip).
+static uint32_t fwd_grid(uint32_t n_tiles) {
+    static int slots = 0;
+    if (!slots) {
+        hipDeviceProp_t p;
+        int dev = 0, wps = GS_FWD_WAVES_PER_SIMD;
+        if (const char *e = getenv("GS_FWD_WAVES_PER_SIMD")) wps = atoi(e) > 0 ? atoi(e) : wps;  // tuning knob
+        slots = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
+                    ? p.multiProcessorCount * 4 * wps
+                    : 256 * 4 * wps;
+    }
+    const uint32_t rounds = (n_tiles + slots - 1) / slots;
+    return rounds ? (n_tiles + rounds - 1) / rounds : 1;
 }
 
 template <int CDIM, bool FRAME, bool CKPT, bool SIG>
 void launch_fwd(const RasterSrc &S, const RasterGeom &G, const int32_t *ranges, float *out_padded, float *out_image,
                 float4 *ckpt, uint32_t *tile_nproc, int wn, hipStream_t stream) {
     if (wn)
-        hipLaunchKernelGGL((raster_forward_kernel<CDIM, FRAME, CKPT, SIG, true>), dim3(G.ntx * G.nty), dim3(FWD_THREADS), 0,
-                           stream, S, G, ranges, out_padded, out_image, ckpt, tile_nproc);
+        hipLaunchKernelGGL((raster_forward_kernel<CDIM, FRAME, CKPT, SIG, true>), dim3(fwd_grid(G.ntx * G.nty)), dim3(FWD_THREADS), 0,
+                           stream, S, G, ranges, out_padded, out_image, ckpt, tile_nproc, (uint32_t)(G.ntx * G.nty));
     else
-        hipLaunchKernelGGL((raster_forward_kernel<CDIM, FRAME, CKPT, SIG, false>), dim3(G.ntx * G.nty), dim3(FWD_THREADS), 0,
-                           stream, S, G, ranges, out_padded, out_image, ckpt, tile_nproc);
+        hipLaunchKernelGGL((raster_forward_kernel<CDIM, FRAME, CKPT, SIG, false>), dim3(fwd_grid(G.ntx * G.nty)), dim3(FWD_THREADS), 0,
+                           stream, S, G, ranges, out_padded, out_image, ckpt, tile_nproc, (uint32_t)(G.ntx * G.nty));
 }
 
 }  // namespace
