@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(1024) scan_block_sums_kernel(const uint32_t *_
 // does not serialise 64 lanes behind it.
 #define GS_EMIT_SOLO 16
 __global__ void __launch_bounds__(256) emit_pairs_kernel(const uint32_t *__restrict__ tiles_touched,
-                                                        const uint2 *__restrict__ rects,
+                                                        const uint4 *__restrict__ rects,
                                                         const float4 *__restrict__ rec_geom,
                                                         const uint32_t *__restrict__ block_offsets, int64_t n,
                                                         uint32_t ntx, uint64_t *__restrict__ keys,
@@ -171,12 +171,10 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(const uint32_t *__restr
     for (int w = 0; w < 4; ++w) off += w < wave ? s_wave[w] : 0;
     if (pid < n) pair_offsets[pid] = off;  // the backward pass addresses its per-pair rows with it
 
-    uint2 rc = make_uint2(0, 0);
-    uint32_t dbits = 0;
-    if (cnt) {
-        rc = rects[pid];
-        dbits = __float_as_uint(rec_geom[pid * GS_REC_STRIDE].z);
-    }
+    uint4 rc = make_uint4(0, 0, 0, 0);
+    if (cnt) rc = rects[pid];
+    const uint32_t dbits = rc.z;
+    (void)rec_geom;
     const uint32_t y0 = rc.x & 0xffff, x0 = rc.y & 0xffff, x1 = rc.y >> 16;
     const uint32_t wdt = x1 - x0;
     if (cnt && cnt <= GS_EMIT_SOLO) {

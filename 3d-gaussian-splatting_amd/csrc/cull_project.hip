@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(256) frame_project_kernel(
     const float *__restrict__ pos, const float4 *__restrict__ quat, const float *__restrict__ scale,
     const float *__restrict__ opa, const float *__restrict__ rgb, int64_t n, ProjectParams P,
     float4 *__restrict__ rec_geom, float4 *__restrict__ rec_cov, float4 *__restrict__ rec_color,
-    uint32_t *__restrict__ tiles_touched, uint2 *__restrict__ rects, uint32_t *__restrict__ block_sums,
+    uint32_t *__restrict__ tiles_touched, uint4 *__restrict__ rects, uint32_t *__restrict__ block_sums,
     uint32_t *__restrict__ block_vis) {
     const int64_t pid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t cnt = 0, vis = 0;
@@ -368,7 +368,7 @@ __global__ void __launch_bounds__(256) frame_project_kernel(
         (void)rec_cov;
         (void)rec_color;
         tiles_touched[pid] = cnt;
-        rects[pid] = rc;
+        rects[pid] = make_uint4(rc.x, rc.y, __float_as_uint(g.z), cnt);
     }
     // block sums of cnt and of the visible flag -> two plain stores per block (a same-address
     // atomic per block would serialise at ~12 ns each: 112 us for 2.4 M Gaussians)

@@ -121,7 +121,8 @@ static int frame_forward_impl(const gs_frame *f, hipStream_t s, float *stage_ms)
     gs_frame_geom G = gs_frame_geometry(f);
     StageTimer tm(stage_ms != nullptr, s);
     tm.mark();
-    GS_HIP(hipMemsetAsync(ws.counters, 0, ws.zero_bytes, s));
+    // sort_mode 2 writes every counter and every tile range itself (tile_bin.hip, workgroup 0)
+    if (effective_sort_mode(f) != 2 || f->N == 0) GS_HIP(hipMemsetAsync(ws.counters, 0, ws.zero_bytes, s));
     if (f->N > 0 && (rc = gs_stage_project(f, ws, s))) return rc;
     tm.mark();
     uint64_t *skeys, *okeys;

@@ -48,7 +48,7 @@ struct gs_frame_ws {
     float4 *rec_color;             // (r, g, b, -)
     float4 *rec_conic;             // (A, B, C, -)
     uint32_t *tiles_touched;       // [N]
-    uint2 *rects;                  // [N] (y0 | y1 << 16, x0 | x1 << 16)
+    uint4 *rects;                  // [N] (y0 | y1 << 16, x0 | x1 << 16, depth bits, tiles touched): all the binning needs
     uint32_t *block_sums;          // [ceil(N/256)] pairs emitted by each 256-Gaussian block
     uint32_t *block_vis;           // [ceil(N/256)] visible Gaussians of each block
     uint32_t *block_offsets;       // [ceil(N/256)]
@@ -97,7 +97,7 @@ static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pair
     ws.rec_color = ws.rec_geom ? ws.rec_geom + 2 : nullptr;
     ws.rec_conic = ws.rec_geom ? ws.rec_geom + 3 : nullptr;
     ws.tiles_touched = (uint32_t *)take(sizeof(uint32_t) * N);
-    ws.rects = (uint2 *)take(sizeof(uint2) * N);
+    ws.rects = (uint4 *)take(sizeof(uint4) * N);
     ws.block_sums = (uint32_t *)take(sizeof(uint32_t) * nblk);
     ws.block_vis = (uint32_t *)take(sizeof(uint32_t) * nblk);
     ws.block_offsets = (uint32_t *)take(sizeof(uint32_t) * nblk);

@@ -67,7 +67,7 @@ struct BwdOut {
     // inside g's rectangle), so the per-Gaussian sum is a contiguous, deterministic reduction
     float *rows;                   // [max_pairs][12 | 36]
     const uint32_t *pair_offsets;  // [N]
-    const uint2 *rects;            // [N]
+    const uint4 *rects;            // [N]
     uint64_t max_pairs;
     // REF: one row per pair
     float *grad_pos, *grad_rgb, *grad_opa, *grad_cov;
@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, Raste
     const float gc = iPn * (Sxy - 2.0f * g.b * Su);
     const float gd = iPn * (-Sxx + 2.0f * g.a * Su);
     if (FRAME) {
-        const uint2 rc = O.rects[gid];
+        const uint4 rc = O.rects[gid];
         const uint32_t y0 = rc.x & 0xffff, x0 = rc.y & 0xffff, x1 = rc.y >> 16;
         const uint64_t slot = (uint64_t)O.pair_offsets[gid] + (ty - y0) * (x1 - x0) + (tx - x0);
         if (slot < O.max_pairs) {

@@ -33,17 +33,9 @@ namespace {
 // Small rectangles are handled by their own lane, large ones by the whole wave (one screen-filling
 // Gaussian must not serialise 64 lanes behind it).
 template <typename Fn>
-__device__ __forceinline__ void walk_rects(const uint32_t *__restrict__ tiles_touched,
-                                           const uint2 *__restrict__ rects, const float4 *__restrict__ rec_geom,
-                                           int64_t g, int64_t n, uint32_t ntx, bool need_depth, Fn fn) {
+__device__ __forceinline__ void walk_rect(const uint4 rc, int64_t g, uint32_t ntx, Fn fn) {
     const int lane = threadIdx.x & 63;
-    const uint32_t cnt = g < n ? tiles_touched[g] : 0;
-    uint2 rc = make_uint2(0, 0);
-    uint32_t dbits = 0;
-    if (cnt) {
-        rc = rects[g];
-        if (need_depth) dbits = __float_as_uint(rec_geom[g * GS_REC_STRIDE].z);
-    }
+    const uint32_t cnt = rc.w, dbits = rc.z;
     const uint32_t y0 = rc.x & 0xffff, x0 = rc.y & 0xffff, x1 = rc.y >> 16;
     const uint32_t wdt = x1 - x0;
     if (cnt && cnt <= BIN_SOLO) {
@@ -69,8 +61,8 @@ __device__ __forceinline__ void walk_rects(const uint32_t *__restrict__ tiles_to
 
 // ---------------------------------------------------------------- B1
 __global__ void __launch_bounds__(BIN_THREADS) bin_count_kernel(
-    const uint32_t *__restrict__ tiles_touched, const uint2 *__restrict__ rects, int64_t n, uint32_t per_block,
-    uint32_t T, uint32_t ntx, uint32_t *__restrict__ table, const uint32_t *__restrict__ block_sums,
+    const uint4 *__restrict__ rects, int64_t n, uint32_t per_block, uint32_t T, uint32_t ntx,
+    uint32_t *__restrict__ table, const uint32_t *__restrict__ block_sums,
     const uint32_t *__restrict__ block_vis, uint32_t *__restrict__ slice_pairs, uint32_t *__restrict__ slice_vis) {
     extern __shared__ uint32_t s_hist[];
     __shared__ uint32_t s_acc[2];
@@ -80,8 +72,10 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_count_kernel(
     const int64_t g0 = (int64_t)blockIdx.x * per_block;
     for (uint32_t base = 0; base < per_block; base += BIN_THREADS) {
         const uint32_t i = base + threadIdx.x;
-        walk_rects(tiles_touched, rects, nullptr, i < per_block ? g0 + i : n, n, ntx, false,
-                   [&](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&s_hist[tile], 1u); });
+        const int64_t g = g0 + i;
+        // one coalesced 16-byte load per Gaussian: rectangle, depth bits, tile count
+        const uint4 rc = (i < per_block && g < n) ? rects[g] : make_uint4(0, 0, 0, 0);
+        walk_rect(rc, g, ntx, [&](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&s_hist[tile], 1u); });
     }
     // pairs / visible Gaussians of this slice: sums over the 256-Gaussian blocks of the project stage
     const int64_t nblk = (n + 255) / 256;
@@ -158,14 +152,19 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_wave
 }
 
 __global__ void __launch_bounds__(BIN_THREADS) bin_scatter_kernel(
-    const uint32_t *__restrict__ tiles_touched, const uint2 *__restrict__ rects,
-    const float4 *__restrict__ rec_geom, int64_t n, uint32_t per_block, uint32_t T, uint32_t ntx,
+    const uint4 *__restrict__ rects, int64_t n, uint32_t per_block, uint32_t T, uint32_t ntx,
     const uint32_t *__restrict__ table, const uint32_t *__restrict__ tile_count,
     const uint32_t *__restrict__ slice_pairs, const uint32_t *__restrict__ slice_vis, uint32_t B,
     uint64_t *__restrict__ out, uint64_t max_pairs, uint32_t *__restrict__ pair_offsets,
     int32_t *__restrict__ tile_ranges, unsigned long long *__restrict__ counters) {
     extern __shared__ uint32_t s_slot[];
     __shared__ uint32_t s_wave[BIN_THREADS / 64];
+    const int64_t g0 = (int64_t)blockIdx.x * per_block;
+    auto load_rect = [&](uint32_t base) {
+        const uint32_t i = base + threadIdx.x;
+        return (i < per_block && g0 + i < n) ? rects[g0 + i] : make_uint4(0, 0, 0, 0);
+    };
+    uint4 rc = load_rect(0);  // in flight while the tile starts are scanned
     // 1. tile starts = exclusive scan of tile_count (every workgroup computes all of them)
     const uint32_t per = (T + BIN_THREADS - 1) / BIN_THREADS;
     const uint32_t t0 = threadIdx.x * per, t1 = t0 + per < T ? t0 + per : T;
@@ -174,9 +173,15 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_scatter_kernel(
     uint32_t M;
     uint32_t run = block_excl_scan(mine, s_wave, M);
     if (M > max_pairs) {  // not enough room: leave the frame empty and report the true count
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
-            counters[GS_CNT_PAIRS] = 0;
-            counters[GS_CNT_OVERFLOW] = M;
+        if (blockIdx.x == 0) {
+            for (uint32_t t = threadIdx.x; t < T; t += BIN_THREADS) reinterpret_cast<int2 *>(tile_ranges)[t] = make_int2(0, 0);
+            if (threadIdx.x == 0) {
+                uint32_t v = 0;
+                for (uint32_t b = 0; b < B; ++b) v += slice_vis[b];
+                counters[GS_CNT_PAIRS] = 0;
+                counters[GS_CNT_OVERFLOW] = M;
+                counters[GS_CNT_VISIBLE] = v;
+            }
         }
         return;
     }
@@ -189,7 +194,8 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_scatter_kernel(
     if (blockIdx.x == 0)
         for (uint32_t t = threadIdx.x; t < T; t += BIN_THREADS) {
             const uint32_t s = s_slot[t], c = tile_count[t];  // row 0 of the scanned table is all zeros
-            if (c) reinterpret_cast<int2 *>(tile_ranges)[t] = make_int2((int)s, (int)(s + c));
+            // every tile is written (empty ones as (0, 0)): this path needs no memset of the ranges
+            reinterpret_cast<int2 *>(tile_ranges)[t] = c ? make_int2((int)s, (int)(s + c)) : make_int2(0, 0);
         }
     else
         for (uint32_t t = threadIdx.x; t < T; t += BIN_THREADS) s_slot[t] += row[t];
@@ -211,17 +217,16 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_scatter_kernel(
     }
     __syncthreads();
     // 3. scatter
-    const int64_t g0 = (int64_t)blockIdx.x * per_block;
     for (uint32_t base = 0; base < per_block; base += BIN_THREADS) {  // uniform trip count (barriers inside)
         const uint32_t i = base + threadIdx.x;
-        const int64_t g = i < per_block ? g0 + i : n;
-        if (pair_offsets) {  // uniform: prefix sum of tiles_touched in Gaussian order
-            const uint32_t cnt = g < n ? tiles_touched[g] : 0;
-            const uint32_t ex = block_excl_scan(cnt, s_wave, dummy);
-            if (g < n) pair_offsets[g] = before + ex;
+        const int64_t g = g0 + i;
+        if (base) rc = load_rect(base);
+        if (pair_offsets) {  // uniform: prefix sum of the tile counts in Gaussian order
+            const uint32_t ex = block_excl_scan(rc.w, s_wave, dummy);
+            if (i < per_block && g < n) pair_offsets[g] = before + ex;
             before += dummy;
         }
-        walk_rects(tiles_touched, rects, rec_geom, g, n, ntx, true, [&](uint32_t tile, uint32_t id, uint32_t d) {
+        walk_rect(rc, g, ntx, [&](uint32_t tile, uint32_t id, uint32_t d) {
             const uint32_t slot = atomicAdd(&s_slot[tile], 1u);
             out[slot] = ((uint64_t)d << 32) | id;
         });
@@ -249,15 +254,14 @@ int gs_stage_tile_bin(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stre
                                    GS_BIN_MAX_TILES * 4));
         attr_set = true;
     }
-    hipLaunchKernelGGL(bin_count_kernel, dim3(B), dim3(BIN_THREADS), lds, stream, ws.tiles_touched, ws.rects, f->N,
+    hipLaunchKernelGGL(bin_count_kernel, dim3(B), dim3(BIN_THREADS), lds, stream, ws.rects, f->N,
                        per_block, T, (uint32_t)G.ntx, ws.bin_table, ws.block_sums, ws.block_vis, ws.slice_pairs,
                        ws.slice_vis);
     GS_CHECK_LAUNCH();
     hipLaunchKernelGGL(bin_colscan_kernel, dim3((unsigned)gs_div_up(T, 64)), dim3(256), 0, stream, ws.bin_table, B,
                        T, ws.tile_count);
     GS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bin_scatter_kernel, dim3(B), dim3(BIN_THREADS), lds, stream, ws.tiles_touched, ws.rects,
-                       ws.rec_geom, f->N, per_block, T, (uint32_t)G.ntx, ws.bin_table, ws.tile_count,
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3(B), dim3(BIN_THREADS), lds, stream, ws.rects, f->N, per_block, T, (uint32_t)G.ntx, ws.bin_table, ws.tile_count,
                        ws.slice_pairs, ws.slice_vis, B, ws.keys_a, (uint64_t)f->max_pairs,
                        f->training ? ws.pair_offsets : nullptr, ws.tile_ranges, ws.counters);
     GS_CHECK_LAUNCH();

@@ -96,18 +96,52 @@ __device__ __forceinline__ void bitonic_sort(Mem a, uint32_t n, uint32_t P) {
     }
 }
 
+// All-ascending bitonic network run by ONE wave on n <= 512 keys in its own LDS window: every stage is
+// ordered by the wave's program order (the fence only stops the compiler from moving LDS accesses across
+// it), so there is no workgroup barrier anywhere.  Comparators whose low index is >= n are skipped as a
+// block (their partner is the virtual +inf).
+__device__ __forceinline__ void bitonic_sort_wave(uint64_t *a, uint32_t n, uint32_t logP) {
+    const uint32_t lane = threadIdx.x & 63;
+    auto stage_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    // comparators t = 0 .. with lo(t) = (t >> lj) << (lj + 1) | (t & (j - 1)) < n
+    auto live = [&](uint32_t lj) {
+        const uint32_t j = 1u << lj, r = n & (2 * j - 1);
+        return ((n >> (lj + 1)) << lj) + (r < j ? r : j);
+    };
+    for (uint32_t lk = 1; lk <= logP; ++lk) {
+        const uint32_t lhk = lk - 1, hk = 1u << lhk;
+        for (uint32_t t = lane, te = live(lhk); t < te; t += 64) {  // flip
+            const uint32_t base = (t >> lhk) << lk, r = t & (hk - 1);
+            cmpx(a, base + r, base + (2 * hk - 1) - r, n);
+        }
+        stage_sync();
+        for (uint32_t lj = lhk; lj-- > 0;) {  // disperse, strides hk/2 .. 1
+            const uint32_t j = 1u << lj;
+            for (uint32_t t = lane, te = live(lj); t < te; t += 64) {
+                const uint32_t lo = ((t >> lj) << (lj + 1)) | (t & (j - 1));
+                cmpx(a, lo, lo + j, n);
+            }
+            stage_sync();
+        }
+    }
+}
+
 // PACKED = false (sort_mode 1): keys = (tile << 32 | depth_bits) grouped by tile, ids = Gaussian index;
 //   both are overwritten in place with the depth-sorted order; scratch = idle half of the key buffer.
-// PACKED = true (sort_mode 2): packed = (depth_bits << 32 | gaussian) grouped by tile in arbitrary
+// PACKED = true (sort_mode 2): scratch = (depth_bits << 32 | gaussian) grouped by tile in arbitrary
 //   order; the sorted (tile << 32 | depth_bits) and ids go to keys / ids; long buckets sort in place.
+// A workgroup owns four consecutive tiles.  Buckets up to CAP/4 keys are sorted by one wave each,
+// concurrently; longer ones by the whole workgroup in the full CAP-key window (or in global memory).
 template <int CAP, bool PACKED>
 __global__ void __launch_bounds__(256) tile_sort_kernel(uint64_t *__restrict__ keys, uint32_t *__restrict__ ids,
                                                        uint64_t *__restrict__ scratch,
-                                                       const int32_t *__restrict__ ranges) {
+                                                       const int32_t *__restrict__ ranges, uint32_t n_tiles) {
     __shared__ uint64_t s_a[CAP];
-    const uint32_t tile = blockIdx.x;
-    const uint32_t start = (uint32_t)ranges[2 * tile], end = (uint32_t)ranges[2 * tile + 1];
-    const uint32_t n = end - start;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t tile, start, n;
     auto load = [&](uint32_t i) -> uint64_t {
         return PACKED ? scratch[start + i] : (keys[start + i] << 32) | ids[start + i];
     };
@@ -115,29 +149,43 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(uint64_t *__restrict__ k
         ids[start + i] = (uint32_t)v;
         keys[start + i] = ((uint64_t)tile << 32) | (v >> 32);
     };
-    if (n < 2) {
-        if (PACKED && n == 1 && threadIdx.x == 0) store(0, load(0));
-        return;
-    }
-    uint32_t P = 1;
-    while (P < n) P <<= 1;
-    if (P <= 128) {  // one wave does everything; the other three leave
-        if (threadIdx.x >= 64) return;
-        for (uint32_t i = threadIdx.x; i < n; i += 64) s_a[i] = load(i);
+    auto select = [&](uint32_t t) {
+        tile = t;
+        start = n = 0;
+        if (t < n_tiles) {
+            start = (uint32_t)ranges[2 * t];
+            n = (uint32_t)ranges[2 * t + 1] - start;
+        }
+    };
+    // 1. one wave per short bucket
+    select(blockIdx.x * 4 + wave);
+    if (n >= (PACKED ? 1u : 2u) && n <= (uint32_t)CAP / 4) {
+        uint64_t *a = s_a + wave * (CAP / 4);
+        for (uint32_t i = lane; i < n; i += 64) a[i] = load(i);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        bitonic_sort<uint64_t *, false>(s_a, n, P);
-        for (uint32_t i = threadIdx.x; i < n; i += 64) store(i, s_a[i]);
-        return;
+        uint32_t logP = 0;
+        while ((1u << logP) < n) ++logP;
+        bitonic_sort_wave(a, n, logP);
+        for (uint32_t i = lane; i < n; i += 64) store(i, a[i]);
     }
-    uint64_t *a = n <= (uint32_t)CAP ? s_a : scratch + start;
-    if (!PACKED || n <= (uint32_t)CAP)
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) a[i] = load(i);
-    __syncthreads();
-    if (n <= (uint32_t)CAP)
-        bitonic_sort<uint64_t *, true>(s_a, n, P);
-    else
-        bitonic_sort_global(scratch + start, n, P);
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) store(i, a[i]);
+    // 2. long buckets, one after the other, by the whole workgroup (n is uniform => so are the barriers)
+    for (uint32_t q = 0; q < 4; ++q) {
+        select(blockIdx.x * 4 + q);
+        if (n <= (uint32_t)CAP / 4) continue;
+        __syncthreads();
+        uint32_t P = 1;
+        while (P < n) P <<= 1;
+        uint64_t *a = n <= (uint32_t)CAP ? s_a : scratch + start;
+        if (!PACKED || n <= (uint32_t)CAP)
+            for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) a[i] = load(i);
+        __syncthreads();
+        if (n <= (uint32_t)CAP)
+            bitonic_sort<uint64_t *, true>(s_a, n, P);
+        else
+            bitonic_sort_global(scratch + start, n, P);
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) store(i, a[i]);
+    }
 }
 
 }  // namespace
@@ -147,8 +195,8 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(uint64_t *__restrict__ k
 int gs_stage_tile_sort(const gs_frame *f, const gs_frame_ws &ws, uint64_t *keys, uint32_t *ids, uint64_t *scratch,
                        hipStream_t stream) {
     gs_frame_geom G = gs_frame_geometry(f);
-    hipLaunchKernelGGL((tile_sort_kernel<2048, false>), dim3(G.n_tiles), dim3(256), 0, stream, keys, ids, scratch,
-                       ws.tile_ranges);
+    hipLaunchKernelGGL((tile_sort_kernel<2048, false>), dim3((G.n_tiles + 3) / 4), dim3(256), 0, stream, keys, ids, scratch,
+                       ws.tile_ranges, (uint32_t)G.n_tiles);
     GS_CHECK_LAUNCH();
     return 0;
 }
@@ -156,8 +204,8 @@ int gs_stage_tile_sort(const gs_frame *f, const gs_frame_ws &ws, uint64_t *keys,
 int gs_stage_tile_sort_packed(const gs_frame *f, const gs_frame_ws &ws, uint64_t *packed, uint64_t *keys_out,
                               uint32_t *ids_out, hipStream_t stream) {
     gs_frame_geom G = gs_frame_geometry(f);
-    hipLaunchKernelGGL((tile_sort_kernel<2048, true>), dim3(G.n_tiles), dim3(256), 0, stream, keys_out, ids_out,
-                       packed, ws.tile_ranges);
+    hipLaunchKernelGGL((tile_sort_kernel<2048, true>), dim3((G.n_tiles + 3) / 4), dim3(256), 0, stream, keys_out, ids_out,
+                       packed, ws.tile_ranges, (uint32_t)G.n_tiles);
     GS_CHECK_LAUNCH();
     return 0;
 }
