@@ -173,6 +173,15 @@ def main():
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                            "traffic": traffic, "algorithmic_bytes": alg_bytes,
                            "kernel_ms": round(stage["raster"], 4)}
+        if not use_sh:
+            # the kernel is fp32-VALU bound, not HBM bound: 73 flops per Gaussian per
+            # 4 pixels of a lane (5 shared + 34 per packed pixel pair) => 18.25 flops per (pair, pixel);
+            # peak = packed fp32 FMA on 256 CUs x 4 SIMD x 16 lanes at 2.4 GHz
+            flops = 18.25 * 256 * st.pairs
+            out["roofline"]["valu"] = {"achieved": round(flops / (stage["raster"] * 1e-3) / 1e12, 1), "peak": 157.3,
+                                       "unit": "TFLOP/s fp32 vector",
+                                       "frac": round(flops / (stage["raster"] * 1e-3) / 1e12 / 157.3, 3),
+                                       "note": "upper bound on work: early-terminated tiles skip Gaussians"}
         out["stage_ms"] = {k: round(v, 4) for k, v in stage.items()}
         # whole-frame algorithmic bytes: 44N + (64+8C)V + (72+4C)M + 12P + 4T
         T = grid_px // 256

@@ -4,7 +4,7 @@ import torch, numpy as np
 from gs_frame import FrameRenderer
 from gs_scene import CONFIGS, make_camera, make_scene
 dev=torch.device('cuda:0')
-for cfg in ('cfg4','cfg5'):
+for cfg in (sys.argv[1:] or ('cfg2','cfg4','cfg5')):
     n,W,H,use_sh=CONFIGS[cfg]
     scene=make_scene(n,W,H,seed=2023,use_sh=use_sh); cam=make_camera(W,H)
     params=[torch.from_numpy(a).to(dev) for a in (scene.pos,scene.quat,scene.scale,scene.opa,scene.rgb)]
