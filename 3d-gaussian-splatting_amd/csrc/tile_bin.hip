@@ -59,6 +59,17 @@ __device__ __forceinline__ void walk_rect(const uint4 rc, int64_t g, uint32_t nt
     }
 }
 
+// Workgroups are dealt round-robin to the 8 XCDs (each with its own L2), while the output region of a
+// tile is laid out in slice order.  Giving XCD x a CONTIGUOUS range of slices makes the 8-byte pair
+// stores that fill one 128-byte line come from one L2 instead of eight, so lines are merged in L2
+// instead of being written back as eight partial sectors.
+__device__ __forceinline__ uint32_t slice_of_block(uint32_t blk, uint32_t B) {
+    const uint32_t xcd = blk & 7, idx = blk >> 3;
+    uint32_t first = 0;
+    for (uint32_t x = 0; x < xcd; ++x) first += (B - x + 7) >> 3;  // workgroups that landed on XCD x
+    return first + idx;
+}
+
 // ---------------------------------------------------------------- B1
 __global__ void __launch_bounds__(BIN_THREADS) bin_count_kernel(
     const uint4 *__restrict__ rects, int64_t n, uint32_t per_block, uint32_t T, uint32_t ntx,
@@ -69,7 +80,8 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_count_kernel(
     for (uint32_t t = threadIdx.x; t < T; t += BIN_THREADS) s_hist[t] = 0;
     if (threadIdx.x < 2) s_acc[threadIdx.x] = 0;
     __syncthreads();
-    const int64_t g0 = (int64_t)blockIdx.x * per_block;
+    const uint32_t slice = slice_of_block(blockIdx.x, gridDim.x);
+    const int64_t g0 = (int64_t)slice * per_block;
     for (uint32_t base = 0; base < per_block; base += BIN_THREADS) {
         const uint32_t i = base + threadIdx.x;
         const int64_t g = g0 + i;
@@ -87,11 +99,11 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_count_kernel(
         }
     }
     __syncthreads();
-    uint32_t *row = table + (size_t)blockIdx.x * T;
+    uint32_t *row = table + (size_t)slice * T;
     for (uint32_t t = threadIdx.x; t < T; t += BIN_THREADS) row[t] = s_hist[t];
     if (threadIdx.x == 0) {
-        slice_pairs[blockIdx.x] = s_acc[0];
-        slice_vis[blockIdx.x] = s_acc[1];
+        slice_pairs[slice] = s_acc[0];
+        slice_vis[slice] = s_acc[1];
     }
 }
 
@@ -159,7 +171,8 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_scatter_kernel(
     int32_t *__restrict__ tile_ranges, unsigned long long *__restrict__ counters) {
     extern __shared__ uint32_t s_slot[];
     __shared__ uint32_t s_wave[BIN_THREADS / 64];
-    const int64_t g0 = (int64_t)blockIdx.x * per_block;
+    const uint32_t slice = slice_of_block(blockIdx.x, gridDim.x);
+    const int64_t g0 = (int64_t)slice * per_block;
     auto load_rect = [&](uint32_t base) {
         const uint32_t i = base + threadIdx.x;
         return (i < per_block && g0 + i < n) ? rects[g0 + i] : make_uint4(0, 0, 0, 0);
@@ -173,7 +186,7 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_scatter_kernel(
     uint32_t M;
     uint32_t run = block_excl_scan(mine, s_wave, M);
     if (M > max_pairs) {  // not enough room: leave the frame empty and report the true count
-        if (blockIdx.x == 0) {
+        if (slice == 0) {
             for (uint32_t t = threadIdx.x; t < T; t += BIN_THREADS) reinterpret_cast<int2 *>(tile_ranges)[t] = make_int2(0, 0);
             if (threadIdx.x == 0) {
                 uint32_t v = 0;
@@ -190,8 +203,8 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_scatter_kernel(
         run += tile_count[t];
     }
     __syncthreads();
-    const uint32_t *row = table + (size_t)blockIdx.x * T;
-    if (blockIdx.x == 0)
+    const uint32_t *row = table + (size_t)slice * T;
+    if (slice == 0)
         for (uint32_t t = threadIdx.x; t < T; t += BIN_THREADS) {
             const uint32_t s = s_slot[t], c = tile_count[t];  // row 0 of the scanned table is all zeros
             // every tile is written (empty ones as (0, 0)): this path needs no memset of the ranges
@@ -201,15 +214,15 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_scatter_kernel(
         for (uint32_t t = threadIdx.x; t < T; t += BIN_THREADS) s_slot[t] += row[t];
     // 2. slice totals: frame counters, and the emission offset of this slice (per-pair gradient rows)
     uint32_t before = 0, vis = 0, dummy;
-    if (pair_offsets || blockIdx.x == 0) {
+    if (pair_offsets || slice == 0) {
         uint32_t p = 0, v = 0;
         for (uint32_t b = threadIdx.x; b < B; b += BIN_THREADS) {
-            p += b < blockIdx.x ? slice_pairs[b] : 0;
+            p += b < slice ? slice_pairs[b] : 0;
             v += slice_vis[b];
         }
         block_excl_scan(p, s_wave, before);
         block_excl_scan(v, s_wave, vis);
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (slice == 0 && threadIdx.x == 0) {
             counters[GS_CNT_PAIRS] = M;
             counters[GS_CNT_OVERFLOW] = 0;
             counters[GS_CNT_VISIBLE] = vis;
