@@ -1,22 +1,28 @@
-// tile_sort.hip -- sort_mode 1: finish the (tile, depth) order inside each tile's bucket.
+// tile_sort.hip -- sort_modes 1 and 2: finish the (tile, depth) order inside each tile's bucket.
 //
-// The 64-bit key is (tile_id | depth_bits), ties broken by the Gaussian index.  sort_mode 0 runs
-// six stable LSD radix passes over all M pairs (radix_sort.hip: 18 dependent launches, 192 B of
-// traffic per pair).  sort_mode 1 runs the stable LSD passes on the TILE bits only (2 passes at
-// 1080p) -- which groups the pairs by tile, i.e. performs the most-significant-digit split of
-// the key -- and then orders every bucket by the unique composite (depth_bits << 32 | gaussian_id)
-// with an all-ascending bitonic network:
-//   * buckets <= 128 pairs : one wave, no workgroup barrier at all;
-//   * buckets <= 2048 pairs: in LDS; comparator strides <= 64 stay inside one wave's 128-element
-//     window, so those stages only need wave-level ordering -- a workgroup barrier is paid only
-//     for the few stages with stride >= 128;
-//   * larger buckets        : same network in place on a global scratch segment (rare).
-// The composite key is unique, so the result is exactly the oracle's (tile, depth_bits,
-// gaussian_index) order, bit-identical to sort_mode 0, at 64 + 36 B of traffic per pair.
+// The 64-bit key is (tile_id | depth_bits), ties broken by the Gaussian index.  After the pairs have
+// been grouped by tile (sort_mode 1: stable LSD radix passes on the tile bits; sort_mode 2: the LDS
+// counting sort of tile_bin.hip) every bucket is ordered by the UNIQUE composite
+// (depth_bits << 32 | gaussian_id) with an all-ascending bitonic network (flip + disperse), so the
+// result is exactly the oracle's (tile, depth_bits, gaussian_index) order whatever the arrival order.
+//
+// A first version ran every stage of the network through LDS (two 8-byte reads + two writes per
+// comparator and stage): PMC showed 1.47 M LDS instructions per cfg2 frame -- LDS bandwidth bound.
+// Now a wave holds a 128-key WINDOW in registers, two keys per lane (element e = lane and lane + 64):
+//   * strides < 64 are lane exchanges: xor 1, 2, 3, 7, 15 are single DPP moves (quad_perm, row_half_mirror,
+//     row_mirror), xor 4 and 8 two chained DPP moves, xor 16 / 31 / 32 / 63 go through ds_bpermute (the LDS
+//     crossbar, no memory access); stride 64 is a compare-exchange between the lane's two registers;
+//   * a bucket of <= 128 keys never touches LDS memory at all (global -> registers -> global);
+//   * longer buckets use LDS only for the strides >= 128 of the merge levels (k = 256, 512, ...): one
+//     pass per such stride plus one load/store of the window for the seven strides 64..1.
+// At 1024 keys that is 10 LDS passes instead of 55.  Buckets <= 512 keys are sorted by ONE wave (four
+// tiles per workgroup, no workgroup barrier), <= 2048 by the workgroup, longer ones in global memory.
 #include "gs_common.h"
 #include "gs_frame_layout.h"
 
 namespace {
+
+#define KEY_INF 0xffffffffffffffffull  // padding of a window beyond the bucket: sorts to the end
 
 template <typename Mem>
 __device__ __forceinline__ void cmpx(Mem a, uint32_t lo, uint32_t hi, uint32_t n) {
@@ -29,20 +35,139 @@ __device__ __forceinline__ void cmpx(Mem a, uint32_t lo, uint32_t hi, uint32_t n
     }
 }
 
-// Merge steps that stay inside 128-element windows (stride j <= 32, or a flip of span k <= 128):
-// the wave that owns window `win` does them back to back with wave-level ordering only.
-template <typename Mem>
-__device__ __forceinline__ void local_disperse(Mem a, uint32_t n, uint32_t win, int lane, uint32_t j0) {
-    const uint32_t W = win * 128;
-    for (uint32_t j = j0; j >= 1; j >>= 1) {
-        const uint32_t lo = W + (lane / j) * 2 * j + (lane % j);
-        cmpx(a, lo, lo + j, n);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+// ---- lane exchanges -----------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL>
+__device__ __forceinline__ uint64_t dpp64(uint64_t v) {
+    return ((uint64_t)dpp32<CTRL>((uint32_t)(v >> 32)) << 32) | dpp32<CTRL>((uint32_t)v);
+}
+// value of lane (lane ^ M)
+template <int M>
+__device__ __forceinline__ uint64_t xlane(uint64_t v, int lane) {
+    if constexpr (M == 1) return dpp64<0xB1>(v);        // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) return dpp64<0x4E>(v);   // quad_perm [2,3,0,1]
+    else if constexpr (M == 3) return dpp64<0x1B>(v);   // quad_perm [3,2,1,0]
+    else if constexpr (M == 7) return dpp64<0x141>(v);  // row_half_mirror
+    else if constexpr (M == 15) return dpp64<0x140>(v); // row_mirror
+    else if constexpr (M == 4) return dpp64<0x1B>(dpp64<0x141>(v));   // ^7 then ^3
+    else if constexpr (M == 8) return dpp64<0x141>(dpp64<0x140>(v));  // ^15 then ^7
+    else {
+        const int src = (lane ^ M) << 2;
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)v);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)(v >> 32));
+        return ((uint64_t)hi << 32) | lo;
+    }
+}
+constexpr int top_bit(int m) { return m >= 32 ? 32 : m >= 16 ? 16 : m >= 8 ? 8 : m >= 4 ? 4 : m >= 2 ? 2 : 1; }
+
+// compare-exchange with lane ^ M: the lane whose index is lower keeps the smaller key
+template <int M>
+__device__ __forceinline__ void cx(uint64_t &a, int lane) {
+    const uint64_t b = xlane<M>(a, lane);
+    const bool low = (lane & top_bit(M)) == 0;
+    a = ((a < b) == low) ? a : b;
+}
+__device__ __forceinline__ void cx_regs(uint64_t &a0, uint64_t &a1) {  // stride 64: inside the lane
+    const uint64_t lo = a0 < a1 ? a0 : a1, hi = a0 < a1 ? a1 : a0;
+    a0 = lo;
+    a1 = hi;
+}
+template <int J>
+__device__ __forceinline__ void disperse_lanes(uint64_t &a, int lane) {  // strides J, J/2, .., 1
+    if constexpr (J >= 1) {
+        cx<J>(a, lane);
+        disperse_lanes<J / 2>(a, lane);
+    }
+}
+// Windows are padded with KEY_INF beyond their `c` real keys (which occupy the lowest elements).  A
+// block of the network that holds only padding, or a stride that can only pair a key with padding
+// above it, changes nothing, so every routine below stops (wave-uniformly) as soon as c is covered.
+//
+// sorts the 64 keys held one per lane (the first c of them real)
+__device__ __forceinline__ void sort64(uint64_t &a, int lane, uint32_t c) {
+    if (c <= 1) return;
+    cx<1>(a, lane);
+    if (c <= 2) return;
+    cx<3>(a, lane);
+    disperse_lanes<1>(a, lane);
+    if (c <= 4) return;
+    cx<7>(a, lane);
+    disperse_lanes<2>(a, lane);
+    if (c <= 8) return;
+    cx<15>(a, lane);
+    disperse_lanes<4>(a, lane);
+    if (c <= 16) return;
+    cx<31>(a, lane);
+    disperse_lanes<8>(a, lane);
+    if (c <= 32) return;
+    cx<63>(a, lane);
+    disperse_lanes<16>(a, lane);
+}
+// strides 32 .. 1 over one register whose first c keys are real
+__device__ __forceinline__ void disperse64(uint64_t &a, int lane, uint32_t c) {
+    if (c > 32) disperse_lanes<32>(a, lane);
+    else if (c > 16) disperse_lanes<16>(a, lane);
+    else if (c > 8) disperse_lanes<8>(a, lane);
+    else if (c > 4) disperse_lanes<4>(a, lane);
+    else if (c > 2) disperse_lanes<2>(a, lane);
+    else if (c > 1) disperse_lanes<1>(a, lane);
+}
+// strides 64 .. 1 of a 128-key window (element e = lane in a0, lane + 64 in a1; first c keys real)
+__device__ __forceinline__ void disperse_window(uint64_t &a0, uint64_t &a1, int lane, uint32_t c) {
+    if (c > 64) {
+        cx_regs(a0, a1);
+        disperse_lanes<32>(a0, lane);
+        disperse64(a1, lane, c - 64);
+    } else {
+        disperse64(a0, lane, c);
+    }
+}
+// full sort of a 128-key window
+__device__ __forceinline__ void sort_window(uint64_t &a0, uint64_t &a1, int lane, uint32_t c) {
+    sort64(a0, lane, c < 64 ? c : 64);
+    if (c <= 64) return;
+    sort64(a1, lane, c - 64);
+    // flip of span 128: e <-> 127 - e, i.e. a0[lane] with a1[63 - lane]
+    const uint64_t b0 = xlane<63>(a1, lane), b1 = xlane<63>(a0, lane);
+    a0 = a0 < b0 ? a0 : b0;
+    a1 = a1 < b1 ? b1 : a1;
+    disperse_window(a0, a1, lane, c);
+}
+
+// ---- merge levels k >= 256 on an LDS array whose 128-key windows are sorted ----------------------
+// `nthreads` threads with index `tid` cooperate (one wave, or the workgroup); `sync` orders the stages.
+template <typename Sync>
+__device__ __forceinline__ void merge_levels(uint64_t *a, uint32_t n, uint32_t P, uint32_t tid, uint32_t nthreads,
+                                             Sync sync) {
+    const int lane = tid & 63;
+    const uint32_t wave = tid >> 6, nwaves = nthreads >> 6, nwin = (n + 127) / 128;
+    for (uint32_t k = 256; k <= P; k <<= 1) {
+        const uint32_t hk = k >> 1;
+        for (uint32_t t = tid; t < (P >> 1); t += nthreads)  // flip
+            cmpx(a, (t / hk) * k + (t % hk), (t / hk) * k + (k - 1) - (t % hk), n);
+        sync();
+        for (uint32_t j = hk >> 1; j >= 128; j >>= 1) {  // strides that cross windows
+            for (uint32_t t = tid; t < (P >> 1); t += nthreads) {
+                const uint32_t lo = (t / j) * 2 * j + (t % j);
+                cmpx(a, lo, lo + j, n);
+            }
+            sync();
+        }
+        for (uint32_t w = wave; w < nwin; w += nwaves) {  // strides 64 .. 1 in registers
+            const uint32_t e0 = w * 128 + lane, e1 = e0 + 64;
+            uint64_t a0 = e0 < n ? a[e0] : KEY_INF, a1 = e1 < n ? a[e1] : KEY_INF;
+            disperse_window(a0, a1, lane, n - w * 128 < 128 ? n - w * 128 : 128);
+            if (e0 < n) a[e0] = a0;
+            if (e1 < n) a[e1] = a1;
+        }
+        sync();
     }
 }
 
-// Plain version (workgroup barrier after every stage) for buckets that live in global memory.
+// Plain version for buckets that live in global memory (> CAP keys; rare).
 __device__ __forceinline__ void bitonic_sort_global(uint64_t *a, uint32_t n, uint32_t P) {
     for (uint32_t k = 2; k <= P; k <<= 1) {
         const uint32_t hk = k >> 1;
@@ -59,88 +184,17 @@ __device__ __forceinline__ void bitonic_sort_global(uint64_t *a, uint32_t n, uin
     }
 }
 
-template <typename Mem, bool BLOCK>
-__device__ __forceinline__ void bitonic_sort(Mem a, uint32_t n, uint32_t P) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t nwin = (P + 127) / 128;
-    const uint32_t wstep = BLOCK ? 4 : 1;
-    // 1. every 128-window sorted independently (k = 2 .. 128)
-    for (uint32_t win = wave; win < nwin; win += wstep) {
-        const uint32_t W = win * 128;
-        for (uint32_t k = 2; k <= 128 && k <= P; k <<= 1) {
-            const uint32_t hk = k >> 1;
-            const uint32_t base = W + (lane / hk) * k, r = lane % hk;
-            cmpx(a, base + r, base + (k - 1) - r, n);  // flip
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (hk >= 2) local_disperse(a, n, win, lane, hk >> 1);
-        }
-    }
-    if (P <= 128) return;
-    if (BLOCK) __syncthreads();
-    // 2. merges across windows (k = 256 .. P): wide strides with workgroup barriers, then local
-    for (uint32_t k = 256; k <= P; k <<= 1) {
-        const uint32_t hk = k >> 1;
-        for (uint32_t t = threadIdx.x; t < (P >> 1); t += blockDim.x)
-            cmpx(a, (t / hk) * k + (t % hk), (t / hk) * k + (k - 1) - (t % hk), n);
-        __syncthreads();
-        for (uint32_t j = hk >> 1; j >= 128; j >>= 1) {
-            for (uint32_t t = threadIdx.x; t < (P >> 1); t += blockDim.x) {
-                const uint32_t lo = (t / j) * 2 * j + (t % j);
-                cmpx(a, lo, lo + j, n);
-            }
-            __syncthreads();
-        }
-        for (uint32_t win = wave; win < nwin; win += 4) local_disperse(a, n, win, lane, 64);  // strides 64..1
-        __syncthreads();
-    }
-}
-
-// All-ascending bitonic network run by ONE wave on n <= 512 keys in its own LDS window: every stage is
-// ordered by the wave's program order (the fence only stops the compiler from moving LDS accesses across
-// it), so there is no workgroup barrier anywhere.  Comparators whose low index is >= n are skipped as a
-// block (their partner is the virtual +inf).
-__device__ __forceinline__ void bitonic_sort_wave(uint64_t *a, uint32_t n, uint32_t logP) {
-    const uint32_t lane = threadIdx.x & 63;
-    auto stage_sync = [] {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    };
-    // comparators t = 0 .. with lo(t) = (t >> lj) << (lj + 1) | (t & (j - 1)) < n
-    auto live = [&](uint32_t lj) {
-        const uint32_t j = 1u << lj, r = n & (2 * j - 1);
-        return ((n >> (lj + 1)) << lj) + (r < j ? r : j);
-    };
-    for (uint32_t lk = 1; lk <= logP; ++lk) {
-        const uint32_t lhk = lk - 1, hk = 1u << lhk;
-        for (uint32_t t = lane, te = live(lhk); t < te; t += 64) {  // flip
-            const uint32_t base = (t >> lhk) << lk, r = t & (hk - 1);
-            cmpx(a, base + r, base + (2 * hk - 1) - r, n);
-        }
-        stage_sync();
-        for (uint32_t lj = lhk; lj-- > 0;) {  // disperse, strides hk/2 .. 1
-            const uint32_t j = 1u << lj;
-            for (uint32_t t = lane, te = live(lj); t < te; t += 64) {
-                const uint32_t lo = ((t >> lj) << (lj + 1)) | (t & (j - 1));
-                cmpx(a, lo, lo + j, n);
-            }
-            stage_sync();
-        }
-    }
-}
-
 // PACKED = false (sort_mode 1): keys = (tile << 32 | depth_bits) grouped by tile, ids = Gaussian index;
 //   both are overwritten in place with the depth-sorted order; scratch = idle half of the key buffer.
 // PACKED = true (sort_mode 2): scratch = (depth_bits << 32 | gaussian) grouped by tile in arbitrary
 //   order; the sorted (tile << 32 | depth_bits) and ids go to keys / ids; long buckets sort in place.
-// A workgroup owns four consecutive tiles.  Buckets up to CAP/4 keys are sorted by one wave each,
-// concurrently; longer ones by the whole workgroup in the full CAP-key window (or in global memory).
 template <int CAP, bool PACKED>
 __global__ void __launch_bounds__(256) tile_sort_kernel(uint64_t *__restrict__ keys, uint32_t *__restrict__ ids,
                                                        uint64_t *__restrict__ scratch,
                                                        const int32_t *__restrict__ ranges, uint32_t n_tiles) {
     __shared__ uint64_t s_a[CAP];
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = threadIdx.x >> 6;
     uint32_t tile, start, n;
     auto load = [&](uint32_t i) -> uint64_t {
         return PACKED ? scratch[start + i] : (keys[start + i] << 32) | ids[start + i];
@@ -157,46 +211,70 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(uint64_t *__restrict__ k
             n = (uint32_t)ranges[2 * t + 1] - start;
         }
     };
-    // 1. one wave per short bucket
-    select(blockIdx.x * 4 + wave);
-    if (n >= (PACKED ? 1u : 2u) && n <= (uint32_t)CAP / 4) {
-        uint64_t *a = s_a + wave * (CAP / 4);
-        for (uint32_t i = lane; i < n; i += 64) a[i] = load(i);
+    auto wave_sync = [] {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        uint32_t logP = 0;
-        while ((1u << logP) < n) ++logP;
-        bitonic_sort_wave(a, n, logP);
-        for (uint32_t i = lane; i < n; i += 64) store(i, a[i]);
+    };
+    // loads window w of the current bucket into registers, sorts it, hands it to `out(e, key)`
+    auto sort_window_from_global = [&](uint32_t w, auto out) {
+        const uint32_t e0 = w * 128 + lane, e1 = e0 + 64;
+        uint64_t a0 = e0 < n ? load(e0) : KEY_INF, a1 = e1 < n ? load(e1) : KEY_INF;
+        sort_window(a0, a1, lane, n - w * 128 < 128 ? n - w * 128 : 128);
+        if (e0 < n) out(e0, a0);
+        if (e1 < n) out(e1, a1);
+    };
+
+    // 1. one wave per short bucket (<= CAP/4 keys), four buckets per workgroup, no workgroup barrier
+    select(blockIdx.x * 4 + wave);
+    if (n >= (PACKED ? 1u : 2u) && n <= (uint32_t)CAP / 4) {
+        if (n <= 128) {  // registers only
+            sort_window_from_global(0, store);
+        } else {
+            uint64_t *a = s_a + wave * (CAP / 4);
+            const uint32_t nwin = (n + 127) / 128;
+            for (uint32_t w = 0; w < nwin; ++w)
+                sort_window_from_global(w, [&](uint32_t e, uint64_t v) { a[e] = v; });
+            wave_sync();
+            uint32_t P = 256;
+            while (P < n) P <<= 1;
+            merge_levels(a, n, P, (uint32_t)lane, 64u, wave_sync);
+            for (uint32_t i = lane; i < n; i += 64) store(i, a[i]);
+        }
     }
     // 2. long buckets, one after the other, by the whole workgroup (n is uniform => so are the barriers)
     for (uint32_t q = 0; q < 4; ++q) {
         select(blockIdx.x * 4 + q);
         if (n <= (uint32_t)CAP / 4) continue;
         __syncthreads();
-        uint32_t P = 1;
+        uint32_t P = 256;
         while (P < n) P <<= 1;
-        uint64_t *a = n <= (uint32_t)CAP ? s_a : scratch + start;
-        if (!PACKED || n <= (uint32_t)CAP)
-            for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) a[i] = load(i);
-        __syncthreads();
-        if (n <= (uint32_t)CAP)
-            bitonic_sort<uint64_t *, true>(s_a, n, P);
-        else
-            bitonic_sort_global(scratch + start, n, P);
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) store(i, a[i]);
+        if (n <= (uint32_t)CAP) {
+            const uint32_t nwin = (n + 127) / 128;
+            for (uint32_t w = wave; w < nwin; w += 4)
+                sort_window_from_global(w, [&](uint32_t e, uint64_t v) { s_a[e] = v; });
+            __syncthreads();
+            merge_levels(s_a, n, P, threadIdx.x, 256u, [] { __syncthreads(); });
+            for (uint32_t i = threadIdx.x; i < n; i += 256) store(i, s_a[i]);
+        } else {
+            uint64_t *a = scratch + start;  // PACKED: in place; else the idle half of the key buffer
+            if (!PACKED)
+                for (uint32_t i = threadIdx.x; i < n; i += 256) a[i] = load(i);
+            __syncthreads();
+            bitonic_sort_global(a, n, P);
+            for (uint32_t i = threadIdx.x; i < n; i += 256) store(i, a[i]);
+        }
     }
 }
 
 }  // namespace
 
-// 2048 pairs (16 KiB of LDS, 8 workgroups per CU) cover Garden-scale tiles; longer buckets take the
-// in-place global path of the same kernel.
+// CAP = 2048 keys (16 KiB of LDS per workgroup) cover Garden-scale tiles; longer buckets take the in-place
+// global path of the same kernel.
 int gs_stage_tile_sort(const gs_frame *f, const gs_frame_ws &ws, uint64_t *keys, uint32_t *ids, uint64_t *scratch,
                        hipStream_t stream) {
     gs_frame_geom G = gs_frame_geometry(f);
-    hipLaunchKernelGGL((tile_sort_kernel<2048, false>), dim3((G.n_tiles + 3) / 4), dim3(256), 0, stream, keys, ids, scratch,
-                       ws.tile_ranges, (uint32_t)G.n_tiles);
+    hipLaunchKernelGGL((tile_sort_kernel<2048, false>), dim3((G.n_tiles + 3) / 4), dim3(256), 0, stream, keys, ids,
+                       scratch, ws.tile_ranges, (uint32_t)G.n_tiles);
     GS_CHECK_LAUNCH();
     return 0;
 }
@@ -204,8 +282,8 @@ int gs_stage_tile_sort(const gs_frame *f, const gs_frame_ws &ws, uint64_t *keys,
 int gs_stage_tile_sort_packed(const gs_frame *f, const gs_frame_ws &ws, uint64_t *packed, uint64_t *keys_out,
                               uint32_t *ids_out, hipStream_t stream) {
     gs_frame_geom G = gs_frame_geometry(f);
-    hipLaunchKernelGGL((tile_sort_kernel<2048, true>), dim3((G.n_tiles + 3) / 4), dim3(256), 0, stream, keys_out, ids_out,
-                       packed, ws.tile_ranges, (uint32_t)G.n_tiles);
+    hipLaunchKernelGGL((tile_sort_kernel<2048, true>), dim3((G.n_tiles + 3) / 4), dim3(256), 0, stream, keys_out,
+                       ids_out, packed, ws.tile_ranges, (uint32_t)G.n_tiles);
     GS_CHECK_LAUNCH();
     return 0;
 }
