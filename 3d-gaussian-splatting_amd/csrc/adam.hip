@@ -1,0 +1,129 @@
+// adam.hip -- fused Adam step over the flat parameter bucket.
+//
+// Replaces `torch.optim.Adam([...5 groups...], betas=(0.9, 0.99))` + `optimizer.step()` of the
+// reference trainer (train.py:59-67, :113): default eps = 1e-8, no weight decay, no amsgrad.  The
+// reference pays one multi-tensor launch chain per group and keeps its five parameter tensors
+// separate; here all parameters, gradients and both moment buffers are four flat fp32 arrays
+// (gs_dp.FlatGaussianParams), a group is a contiguous index range with its own learning rate, and
+// ONE launch updates everything: 16 B read + 12 B written per parameter -- a pure HBM stream.
+// The densification statistic of train.py:145-154 (`accum_max_grad = max(|pos.grad|, accum)` or
+// `+= |pos.grad|`) rides along for the index range of `pos`, so the gradient is read once.
+// Arithmetic follows torch's _single_tensor_adam:
+//   m <- m + (g - m)(1 - b1);  v <- v b2 + (1 - b2) g g
+//   p <- p - (lr / (1 - b1^t)) m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// with the bias corrections evaluated on the host in double, as torch does.
+#include "gs_common.h"
+
+namespace {
+
+#define GS_ADAM_MAX_GROUPS 8
+
+struct AdamGroups {
+    int64_t end[GS_ADAM_MAX_GROUPS];  // group k covers [end[k-1], end[k])
+    float step_size[GS_ADAM_MAX_GROUPS];  // lr_k / (1 - b1^t)
+    int32_t n;
+};
+
+__device__ __forceinline__ float group_step(const AdamGroups &G, int64_t i) {
+    float s = G.step_size[0];
+#pragma unroll
+    for (int k = 1; k < GS_ADAM_MAX_GROUPS; ++k)
+        if (k < G.n && i >= G.end[k - 1]) s = G.step_size[k];
+    return s;
+}
+
+__device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float step_size, float one_m_b1,
+                                         float b2, float one_m_b2, float inv_bc2_sqrt, float eps) {
+    m = m + (g - m) * one_m_b1;
+    v = v * b2 + one_m_b2 * (g * g);
+    const float denom = sqrtf(v) * inv_bc2_sqrt + eps;
+    p = p - step_size * (m / denom);
+}
+
+__global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ param, const float *__restrict__ grad,
+                                                   float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq,
+                                                   int64_t n, AdamGroups G, float one_m_b1, float b2, float one_m_b2,
+                                                   float inv_bc2_sqrt, float eps, float *__restrict__ stat,
+                                                   int64_t stat_begin, int64_t stat_end, int stat_mode) {
+    const int64_t n4 = n >> 2;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = q << 2;
+        float4 p = reinterpret_cast<float4 *>(param)[q];
+        const float4 g = reinterpret_cast<const float4 *>(grad)[q];
+        float4 m = reinterpret_cast<float4 *>(exp_avg)[q], v = reinterpret_cast<float4 *>(exp_avg_sq)[q];
+        const float s0 = group_step(G, i), s3 = group_step(G, i + 3);
+        const bool uniform = s0 == s3;  // a float4 straddles a group boundary at most five times per launch
+        adam_one(p.x, g.x, m.x, v.x, s0, one_m_b1, b2, one_m_b2, inv_bc2_sqrt, eps);
+        adam_one(p.y, g.y, m.y, v.y, uniform ? s0 : group_step(G, i + 1), one_m_b1, b2, one_m_b2, inv_bc2_sqrt, eps);
+        adam_one(p.z, g.z, m.z, v.z, uniform ? s0 : group_step(G, i + 2), one_m_b1, b2, one_m_b2, inv_bc2_sqrt, eps);
+        adam_one(p.w, g.w, m.w, v.w, s3, one_m_b1, b2, one_m_b2, inv_bc2_sqrt, eps);
+        reinterpret_cast<float4 *>(param)[q] = p;
+        reinterpret_cast<float4 *>(exp_avg)[q] = m;
+        reinterpret_cast<float4 *>(exp_avg_sq)[q] = v;
+        if (stat_mode && i + 3 >= stat_begin && i < stat_end) {
+            const float ga[4] = {fabsf(g.x), fabsf(g.y), fabsf(g.z), fabsf(g.w)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t k = i + e;
+                if (k >= stat_begin && k < stat_end) {
+                    float *d = stat + (k - stat_begin);
+                    *d = stat_mode == 1 ? fmaxf(*d, ga[e]) : *d + ga[e];
+                }
+            }
+        }
+    }
+    // tail (n not a multiple of 4)
+    const int64_t t = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) {
+        float p = param[t], m = exp_avg[t], v = exp_avg_sq[t];
+        const float g = grad[t];
+        adam_one(p, g, m, v, group_step(G, t), one_m_b1, b2, one_m_b2, inv_bc2_sqrt, eps);
+        param[t] = p;
+        exp_avg[t] = m;
+        exp_avg_sq[t] = v;
+        if (stat_mode && t >= stat_begin && t < stat_end) {
+            float *d = stat + (t - stat_begin);
+            *d = stat_mode == 1 ? fmaxf(*d, fabsf(g)) : *d + fabsf(g);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int gs_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                            int32_t n_groups, const int64_t *group_end, const float *lr, float beta1, float beta2,
+                            float eps, int64_t step, float *grad_stat, int64_t stat_begin, int64_t stat_end,
+                            int32_t stat_mode, gs_stream_t stream) {
+    GS_CHECK_ARG(n >= 0, "n < 0");
+    GS_CHECK_ARG(n_groups >= 1 && n_groups <= GS_ADAM_MAX_GROUPS, "n_groups must be in [1, 8]");
+    GS_CHECK_ARG(group_end && lr, "null group table");
+    GS_CHECK_ARG(step >= 1, "step counts from 1 (torch.optim.Adam increments before the update)");
+    GS_CHECK_ARG(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f, "bad hyper-parameters");
+    GS_CHECK_ARG(stat_mode >= 0 && stat_mode <= 2, "stat_mode must be 0 (off), 1 (max) or 2 (sum)");
+    if (n == 0) return 0;
+    GS_CHECK_ARG(param && grad && exp_avg && exp_avg_sq, "null pointer");
+    GS_CHECK_ARG((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
+                 "buffers must be 16-byte aligned");
+    GS_CHECK_ARG(!stat_mode || (grad_stat && stat_begin >= 0 && stat_begin <= stat_end && stat_end <= n),
+                 "bad statistic range");
+    AdamGroups G;
+    int64_t prev = 0;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    for (int k = 0; k < GS_ADAM_MAX_GROUPS; ++k) {
+        const int kk = k < n_groups ? k : n_groups - 1;
+        GS_CHECK_ARG(group_end[kk] >= prev && group_end[kk] <= n, "group_end must be ascending and <= n");
+        prev = group_end[kk];
+        G.end[k] = group_end[kk];
+        G.step_size[k] = (float)((double)lr[kk] / bc1);
+    }
+    GS_CHECK_ARG(group_end[n_groups - 1] == n, "the groups must cover [0, n)");
+    G.n = n_groups;
+    int64_t blocks = gs_div_up(gs_div_up(n, 4) > 0 ? gs_div_up(n, 4) : 1, 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride beyond 16 workgroups per CU
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                       exp_avg_sq, n, G, 1.0f - beta1, beta2, 1.0f - beta2, (float)(1.0 / sqrt(bc2)), eps, grad_stat,
+                       stat_begin, stat_end, (int)stat_mode);
+    GS_CHECK_LAUNCH();
+    return 0;
+}

@@ -27,6 +27,8 @@ SOURCES = {
     "raster_fwd.hip": ["-fno-slp-vectorize"],
     "raster_bwd.hip": ["-fno-slp-vectorize"],
     "gs_frame.hip": [],
+    "adam.hip": ["-ffp-contract=off"],  # same roundings as torch's unfused elementwise kernels
+    "loss.hip": [],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall",
           "-Wno-unused-function", "-munsafe-fp-atomics"]

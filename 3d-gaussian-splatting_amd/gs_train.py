@@ -1,0 +1,182 @@
+"""Training step around the frame path: image loss, fused Adam, the reference's LR schedule.
+
+Mirrors ``Trainer.__init__`` / ``Trainer.train_step`` of the reference (train.py:16-67, 84-200) for the
+part that runs every iteration:
+
+    forward -> loss = (1-w) L1 + w (1-SSIM) -> backward -> [all-reduce] -> Adam step -> LR update
+
+with three differences that matter on MI355X:
+  * the loss and its gradient are two HIP kernels (``gs_loss_l1_ssim``) instead of ~40 torch kernels
+    over five padded copies of the image (torchmetrics SSIM + autograd);
+  * Adam is ONE launch over the flat parameter bucket (``gs_adam_step``), which also accumulates the
+    densification statistic ``accum_max_grad`` of train.py:145-154 while it reads the gradient;
+  * nothing in the step synchronises with the host: the reference calls ``.item()`` three times per
+    iteration (train.py:119-121); here the losses stay on the device until somebody reads them.
+Densification (``adaptive_control``), opacity reset and data loading are out of scope.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence
+
+import torch
+
+from gaussian import _lib
+from gs_dp import ORDER, FlatGaussianParams
+from gs_frame import FrameRenderer
+
+GROUPS = ("opa", "rgb", "pos", "scale", "quat")  # the reference's param-group order (train.py:59-65)
+
+
+@dataclass
+class TrainOptions:
+    """Defaults of the reference's argparse (train.py:297-347) for the options the step uses."""
+    lr: float = 0.003
+    lr_factor_for_scale: float = 1.0
+    lr_factor_for_rgb: float = 10.0
+    lr_factor_for_opa: float = 10.0
+    lr_factor_for_quat: float = 1.0
+    lr_decay: str = "exp"  # "none" | "official" | "exp"
+    n_iters: int = 7001
+    n_iters_warmup: int = 300
+    ssim_weight: float = 0.1
+    grad_accum_method: str = "max"  # "max" | "mean"
+    betas: tuple = (0.9, 0.99)
+    eps: float = 1e-8
+
+
+def lr_lambdas(opt: TrainOptions) -> List[Callable[[int], float]]:
+    """The five per-group multipliers of train.py:29-58, in GROUPS order."""
+    w = opt.n_iters_warmup
+    warm = lambda i: i / w  # noqa: E731  (i <= warmup)
+    if opt.lr_decay == "none":
+        f = lambda i: warm(i) if i <= w else 0.2 ** ((i - w) // 2000)  # noqa: E731
+        return [f] * 5
+    gamma = 0.01 ** (1 / (opt.n_iters - w))
+    decay = lambda i: warm(i) if i <= w else gamma ** (i - w)  # noqa: E731
+    flat = lambda i: warm(i) if i <= w else 1  # noqa: E731
+    if opt.lr_decay == "official":
+        return [decay, flat, decay, flat, flat]
+    if opt.lr_decay != "exp":
+        raise ValueError(f"lr_decay must be none|official|exp, got {opt.lr_decay!r}")
+    return [decay] * 5
+
+
+def base_lrs(opt: TrainOptions) -> List[float]:
+    """train.py:20-25, in GROUPS order."""
+    return [opt.lr * opt.lr_factor_for_opa, opt.lr * opt.lr_factor_for_rgb, opt.lr * 1,
+            opt.lr * opt.lr_factor_for_scale, opt.lr * opt.lr_factor_for_quat]
+
+
+class FusedAdam:
+    """``torch.optim.Adam`` over a FlatGaussianParams bucket, one HIP launch per step."""
+
+    def __init__(self, flat: FlatGaussianParams, lrs: Sequence[float], betas=(0.9, 0.99), eps: float = 1e-8,
+                 grad_stat: Optional[str] = None):
+        if flat.flat_param.device.type != "cuda":
+            raise RuntimeError("FusedAdam needs a HIP device; there is no CPU fallback")
+        self.flat = flat
+        self.betas, self.eps = (float(betas[0]), float(betas[1])), float(eps)
+        self.exp_avg = torch.zeros_like(flat.flat_param)
+        self.exp_avg_sq = torch.zeros_like(flat.flat_param)
+        self.step_count = 0
+        # bucket storage order (gs_dp.ORDER) -> group boundaries; lrs arrive in the reference's GROUPS order
+        sizes = {k: t.numel() for k, t in zip(("pos", "quat", "scale", "opa", "rgb"), flat.params)}
+        ends, off = [], 0
+        for k in ORDER:
+            off += sizes[k]
+            ends.append(off)
+        self._ends = (C.c_int64 * len(ends))(*ends)
+        self._lr = (C.c_float * len(ends))()
+        self.set_lrs(lrs)
+        pos_begin = ends[ORDER.index("pos")] - sizes["pos"]
+        self._stat_range = (pos_begin, pos_begin + sizes["pos"])
+        self.stat_mode = {None: 0, "max": 1, "mean": 2}[grad_stat]
+        self.accum_grad = torch.zeros_like(flat.params[0]) if self.stat_mode else None  # train.py:80-82
+
+    def set_lrs(self, lrs: Sequence[float]):
+        by_group = dict(zip(GROUPS, lrs))
+        for i, k in enumerate(ORDER):
+            self._lr[i] = float(by_group[k])
+
+    def clear_grad_stat(self):
+        if self.accum_grad is not None:
+            self.accum_grad.zero_()
+
+    def step(self):
+        self.step_count += 1
+        f = self.flat
+        b, e = self._stat_range
+        _lib.check(_lib.gs_adam_step(f.flat_param.data_ptr(), f.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
+                                     self.exp_avg_sq.data_ptr(), f.flat_param.numel(), len(ORDER), self._ends, self._lr,
+                                     self.betas[0], self.betas[1], self.eps, self.step_count,
+                                     self.accum_grad.data_ptr() if self.accum_grad is not None else None, b, e,
+                                     self.stat_mode, torch.cuda.current_stream().cuda_stream), "gs_adam_step")
+
+
+class ImageLoss:
+    """``(1-w) * L1 + w * (1 - SSIM)`` and its gradient w.r.t. the rendered image (train.py:99-107)."""
+
+    def __init__(self, height: int, width: int, ssim_weight: float = 0.1, device="cuda"):
+        self.H, self.W, self.w = int(height), int(width), float(ssim_weight)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("ImageLoss needs a HIP device; there is no CPU fallback")
+        nbytes = _lib.gs_loss_workspace_bytes(self.H, self.W)
+        self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        self.grad = torch.empty(self.H, self.W, 3, dtype=torch.float32, device=self.device)
+        self.values = torch.zeros(3, dtype=torch.float32, device=self.device)  # (loss, l1, ssim), stays on device
+
+    def __call__(self, pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        for name, t in (("pred", pred), ("target", target)):
+            if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous() or tuple(t.shape) != (self.H, self.W, 3):
+                raise RuntimeError(f"{name} must be a contiguous float32 HIP tensor of shape [{self.H},{self.W},3]")
+        _lib.check(_lib.gs_loss_l1_ssim(pred.data_ptr(), target.data_ptr(), self.H, self.W, self.w,
+                                        self.grad.data_ptr(), self.values.data_ptr(), self._ws.data_ptr(),
+                                        self._ws.numel(), torch.cuda.current_stream().cuda_stream), "gs_loss_l1_ssim")
+        return self.grad
+
+
+class Trainer:
+    """One view per step on this rank; gradients are averaged over ranks when torch.distributed is up."""
+
+    def __init__(self, params: Sequence[torch.Tensor], cameras, targets: Sequence[torch.Tensor],
+                 opt: Optional[TrainOptions] = None, world_size: int = 1, max_pairs: int = 1 << 20,
+                 scale_activation: str = "abs"):
+        self.opt = opt or TrainOptions()
+        self.flat = FlatGaussianParams(params, world_size=world_size)
+        self.cameras, self.targets = list(cameras), list(targets)
+        dev = self.flat.flat_param.device
+        self.renderer = FrameRenderer(dev, max_pairs=max_pairs, training=True, scale_activation=scale_activation)
+        self._lambdas, self._base = lr_lambdas(self.opt), base_lrs(self.opt)
+        self.optimizer = FusedAdam(self.flat, [b * f(0) for b, f in zip(self._base, self._lambdas)],
+                                   betas=self.opt.betas, eps=self.opt.eps, grad_stat=self.opt.grad_accum_method)
+        self._loss = {}
+
+    def _loss_for(self, h: int, w: int) -> ImageLoss:
+        key = (h, w)
+        if key not in self._loss:
+            self._loss[key] = ImageLoss(h, w, self.opt.ssim_weight, self.flat.flat_param.device)
+        return self._loss[key]
+
+    def train_step(self, i_iter: int, camera_id: int) -> torch.Tensor:
+        """Returns the device tensor (loss, l1, ssim) of this step (no host synchronisation)."""
+        cam, target = self.cameras[camera_id], self.targets[camera_id]
+        image, _ = self.renderer.forward(*self.flat.params, cam)
+        loss = self._loss_for(image.shape[0], image.shape[1])
+        grad_image = loss(image, target)
+        self.renderer.backward(grad_image, out=self.flat.grads)
+        self.flat.all_reduce_grads()
+        self.optimizer.step()
+        # train.py:184-185: the learning rates of the NEXT step
+        self.optimizer.set_lrs([f(i_iter) * b for f, b in zip(self._lambdas, self._base)])
+        return loss.values
+
+    @staticmethod
+    def psnr(image: torch.Tensor, target: torch.Tensor) -> float:
+        """torchmetrics PeakSignalNoiseRatio() with its default data_range = max(target) - min(target)."""
+        mse = torch.mean((image - target) ** 2).item()
+        rng = (target.max() - target.min()).item()
+        return 10.0 * math.log10(rng * rng / mse) if mse > 0 else float("inf")

@@ -223,6 +223,33 @@ int gs_frame_backward(const gs_frame *f, const float *grad_image, float *grad_po
                       float *grad_quat, float *grad_scale, float *grad_opa, float *grad_rgb,
                       gs_stream_t stream);
 
+/* ===================================================================================
+ * Section C -- the training step around the frame
+ * =================================================================================== */
+
+/* torch.optim.Adam(betas=(beta1, beta2), eps) .step() of the reference trainer (train.py:59-67, :113;
+ * no weight decay, no amsgrad) on ONE flat fp32 bucket: param / grad / exp_avg / exp_avg_sq [n], all
+ * 16-byte aligned.  Parameter group k is the index range [group_end[k-1], group_end[k]) (group_end[-1] = 0,
+ * group_end[n_groups-1] = n, n_groups <= 8) with learning rate lr[k]; both tables are HOST arrays.
+ * `step` is the 1-based step count (bias corrections are evaluated in double on the host, like torch).
+ * Optional densification statistic of train.py:145-154 for the index range [stat_begin, stat_end) (the
+ * `pos` group): stat_mode 1: grad_stat = max(grad_stat, |grad|); 2: grad_stat += |grad|; 0: off. */
+int gs_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                 int32_t n_groups, const int64_t *group_end, const float *lr, float beta1, float beta2,
+                 float eps, int64_t step, float *grad_stat, int64_t stat_begin, int64_t stat_end,
+                 int32_t stat_mode, gs_stream_t stream);
+
+/* Image loss of train.py:99-107 and its gradient:
+ *   loss = (1 - ssim_weight) * mean|pred - target| + ssim_weight * (1 - SSIM(pred, target)),
+ * SSIM = torchmetrics StructuralSimilarityIndexMeasure(data_range=1.0) (11x11 Gaussian window, sigma 1.5,
+ * evaluated on the pixels whose window lies inside the image).  pred, target, grad: [H, W, 3] fp32;
+ * grad = dloss/dpred.  loss_out (device, may be NULL) receives (loss, l1 mean, ssim mean).
+ * ssim_weight = 0 skips the SSIM passes (any image size); otherwise H, W must exceed 10. */
+size_t gs_loss_workspace_bytes(int32_t H, int32_t W);
+int gs_loss_l1_ssim(const float *pred, const float *target, int32_t H, int32_t W, float ssim_weight,
+                    float *grad, float *loss_out, void *workspace, size_t workspace_bytes,
+                    gs_stream_t stream);
+
 #if defined(__GNUC__)
 #pragma GCC visibility pop
 #endif

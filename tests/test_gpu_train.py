@@ -1,0 +1,141 @@
+"""GPU parity tests of the training-step kernels (gs_adam_step, gs_loss_l1_ssim) and of the Trainer loop.
+All calls go through the C ABI (ctypes); the oracle is oracle/train_ref.py."""
+import numpy as np
+import pytest
+import torch
+
+from gs_testutil import to_torch
+from oracle import train_ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    return torch.device("cuda:0")
+
+
+def make_flat(gpu, n, seed=0, color_dim=3):
+    from gs_dp import FlatGaussianParams
+
+    rng = np.random.default_rng(seed)
+    shapes = [(n, 3), (n, 4), (n, 3), (n,), (n, color_dim)]
+    params = [torch.from_numpy(rng.normal(size=s).astype(np.float32)).to(gpu) for s in shapes]
+    return FlatGaussianParams(params), rng
+
+
+@pytest.mark.parametrize("n,stat", [(1, None), (37, "max"), (1000, "mean"), (4099, "max")])
+def test_adam_matches_oracle_and_torch(gpu, n, stat):
+    """Five groups with different learning rates, boundaries that are not multiples of 4, 6 steps."""
+    from gs_train import FusedAdam, GROUPS
+
+    flat, rng = make_flat(gpu, n, seed=n)
+    lrs = dict(zip(GROUPS, [0.03, 0.02, 0.003, 0.004, 0.005]))
+    opt = FusedAdam(flat, [lrs[k] for k in GROUPS], betas=(0.9, 0.99), eps=1e-8, grad_stat=stat)
+    names = ("pos", "quat", "scale", "opa", "rgb")
+    ref_p = [p.clone().requires_grad_(True) for p in flat.params]
+    ref = torch.optim.Adam([{"params": [p], "lr": lrs[k]} for p, k in zip(ref_p, names)], betas=(0.9, 0.99),
+                           foreach=False)
+    ora = [(p.cpu().numpy().copy(), np.zeros(p.shape, np.float32), np.zeros(p.shape, np.float32)) for p in flat.params]
+    stat_ref = np.zeros((n, 3), np.float32)
+    for step in range(1, 7):
+        grads = [(rng.normal(size=tuple(p.shape)) * 10.0 ** rng.integers(-3, 1)).astype(np.float32) for p in flat.params]
+        for gview, p, g in zip(flat.grads, ref_p, grads):
+            gview.copy_(torch.from_numpy(g))
+            p.grad = torch.from_numpy(g).to(gpu)
+        opt.step()
+        ref.step()
+        ora = [train_ref.adam_step(p0, g, m, v, lrs[k], 0.9, 0.99, 1e-8, step)
+               for (p0, m, v), g, k in zip(ora, grads, names)]
+        stat_ref = np.maximum(stat_ref, np.abs(grads[0])) if stat == "max" else stat_ref + np.abs(grads[0])
+    for p, pr, (p0, _, _) in zip(flat.params, ref_p, ora):
+        tol = 1e-6 * max(1.0, float(np.abs(p0).max()))
+        assert np.abs(p.cpu().numpy() - p0).max() <= tol                      # vs the oracle
+        assert float((p - pr.detach()).abs().max()) <= tol                    # vs torch.optim.Adam on the GPU
+    if stat:
+        assert np.allclose(opt.accum_grad.cpu().numpy(), stat_ref, rtol=1e-6, atol=0)
+    assert opt.step_count == 6
+
+
+def test_adam_rejects_bad_arguments(gpu):
+    import ctypes as C
+
+    from gaussian import _lib
+
+    t = torch.zeros(16, device=gpu)
+    ends, lr = (C.c_int64 * 1)(15), (C.c_float * 1)(0.1)  # groups do not cover [0, n)
+    rc = _lib.gs_adam_step(t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), 16, 1, ends, lr, 0.9, 0.99, 1e-8, 1,
+                           None, 0, 0, 0, None)
+    assert rc == -1 and b"cover" in _lib.gs_last_error()
+    ends = (C.c_int64 * 1)(16)
+    rc = _lib.gs_adam_step(t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), 16, 1, ends, lr, 0.9, 0.99, 1e-8, 0,
+                           None, 0, 0, 0, None)
+    assert rc == -1 and b"step" in _lib.gs_last_error()
+
+
+@pytest.mark.parametrize("h,w,weight", [(11, 11, 0.1), (37, 53, 0.1), (64, 64, 1.0), (200, 300, 0.25), (40, 33, 0.0),
+                                        (5, 7, 0.0)])
+def test_loss_matches_oracle(gpu, h, w, weight):
+    from gs_train import ImageLoss
+
+    rng = np.random.default_rng(h * 1000 + w)
+    x = rng.uniform(0, 1, (h, w, 3)).astype(np.float32)
+    y = np.clip(x + rng.normal(0, 0.1, x.shape), 0, 1).astype(np.float32)
+    y[::7, ::5] = x[::7, ::5]  # exact ties: sign(0) = 0
+    loss = ImageLoss(h, w, weight, gpu)
+    g = loss(torch.from_numpy(x).to(gpu), torch.from_numpy(y).to(gpu))
+    lo, l1, ssim, grad = train_ref.l1_ssim_loss(x, y, weight)
+    vals = loss.values.cpu().numpy()
+    assert abs(vals[1] - l1) < 1e-6 and abs(vals[2] - ssim) < 2e-6 and abs(vals[0] - lo) < 2e-6
+    err = np.abs(g.cpu().numpy() - grad).max()
+    assert err < 2e-5 * np.abs(grad).max(), (err, np.abs(grad).max())  # fp32 variance cancellation, E[x^2] - mu^2
+
+
+def test_loss_full_hd(gpu):
+    """1080p: the gradient of the loss against the fp64 oracle, and against finite differences of it."""
+    from gs_train import ImageLoss
+
+    rng = np.random.default_rng(3)
+    base = rng.uniform(0, 1, (68, 120, 3))
+    x = np.kron(base, np.ones((16, 16, 1)))[:1080, :1920].astype(np.float32)  # blocky image: flat + edges
+    x = np.clip(x + rng.normal(0, 0.02, x.shape), 0, 1).astype(np.float32)
+    y = np.clip(x + rng.normal(0, 0.05, x.shape), 0, 1).astype(np.float32)
+    loss = ImageLoss(1080, 1920, 0.1, gpu)
+    g = loss(torch.from_numpy(x).to(gpu), torch.from_numpy(y).to(gpu)).cpu().numpy()
+    lo, l1, ssim, grad = train_ref.l1_ssim_loss(x, y, 0.1)
+    vals = loss.values.cpu().numpy()
+    assert abs(vals[0] - lo) < 2e-6 and abs(vals[1] - l1) < 1e-6 and abs(vals[2] - ssim) < 5e-6
+    assert np.abs(g - grad).max() < 2e-4 * np.abs(grad).max()  # flat regions: E[x^2] - mu^2 cancels in fp32
+
+
+def test_trainer_improves_psnr(gpu):
+    """A perturbed copy of a small scene is fitted to renders of the original: loss falls, PSNR rises."""
+    from gs_frame import FrameRenderer
+    from gs_scene import make_camera, make_scene
+    from gs_train import TrainOptions, Trainer
+
+    W, H = 160, 128
+    scene, cam = make_scene(3000, W, H, seed=9), make_camera(W, H)
+    gt = to_torch(scene, gpu)
+    target, _ = FrameRenderer(gpu, max_pairs=1 << 16).forward(*gt, cam)
+    target = target.clone()
+    rng = np.random.default_rng(1)
+    start = [t.clone() for t in gt]
+    start[4] = start[4] + torch.from_numpy(rng.normal(0, 1.0, tuple(start[4].shape)).astype(np.float32)).to(gpu)
+    start[3] = start[3] + torch.from_numpy(rng.normal(0, 0.5, tuple(start[3].shape)).astype(np.float32)).to(gpu)
+    opt = TrainOptions(n_iters=400, n_iters_warmup=10)
+    tr = Trainer(start, [cam], [target], opt, max_pairs=1 << 16)
+    img0, _ = tr.renderer.forward(*tr.flat.params, cam)
+    psnr0 = Trainer.psnr(img0, target)
+    losses = []
+    for it in range(120):
+        losses.append(tr.train_step(it, 0).clone())
+    losses = torch.stack(losses).cpu().numpy()
+    img1, _ = tr.renderer.forward(*tr.flat.params, cam)
+    psnr1 = Trainer.psnr(img1, target)
+    assert np.isfinite(losses).all()
+    assert losses[0, 0] == pytest.approx(losses[1, 0])  # step 0 runs with lr = lambda(0) = 0 (train.py:59-65)
+    assert losses[-1, 0] < 0.6 * losses[1, 0]
+    assert psnr1 > psnr0 + 3.0, (psnr0, psnr1)
