@@ -21,7 +21,8 @@
 namespace {
 
 constexpr int R = 5, K = 11;   // window radius / size
-constexpr int TW = 32, TH = 16;  // output tile of a 256-thread workgroup
+constexpr int TW = 32, TH = 32;  // output tile of a 256-thread workgroup
+constexpr int NB = 4;             // outputs per thread and filter pass: each LDS value feeds up to NB outputs
 constexpr int RW = TW + 2 * R, RH = TH + 2 * R;
 
 struct Window {
@@ -61,54 +62,72 @@ __global__ void __launch_bounds__(256) ssim_moments_kernel(const float *__restri
             s_y[ry][rx] = in ? y[o] : 0.f;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < RH * TW; i += 256) {  // horizontal filter of the five moments
-            const int ry = i / TW, tx = i % TW;
-            float h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0;
+        for (int i = threadIdx.x; i < RH * (TW / NB); i += 256) {  // horizontal filter of the five moments
+            const int ry = i / (TW / NB), tx0 = (i % (TW / NB)) * NB;
+            float h[5][NB];
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const float a = s_x[ry][tx + k], b = s_y[ry][tx + k], w = Wd.g[k];
-                h0 = fmaf(w, a, h0);
-                h1 = fmaf(w, b, h1);
-                h2 = fmaf(w, a * a, h2);
-                h3 = fmaf(w, b * b, h3);
-                h4 = fmaf(w, a * b, h4);
+            for (int m = 0; m < 5; ++m)
+#pragma unroll
+                for (int e = 0; e < NB; ++e) h[m][e] = 0.f;
+#pragma unroll
+            for (int j = 0; j < K + NB - 1; ++j) {  // input column tx0 + j feeds output e with tap j - e
+                const float a = s_x[ry][tx0 + j], b = s_y[ry][tx0 + j];
+                const float aa = a * a, bb = b * b, ab = a * b;
+#pragma unroll
+                for (int e = 0; e < NB; ++e) {
+                    if (j - e < 0 || j - e >= K) continue;
+                    const float w = Wd.g[j - e];
+                    h[0][e] = fmaf(w, a, h[0][e]);
+                    h[1][e] = fmaf(w, b, h[1][e]);
+                    h[2][e] = fmaf(w, aa, h[2][e]);
+                    h[3][e] = fmaf(w, bb, h[3][e]);
+                    h[4][e] = fmaf(w, ab, h[4][e]);
+                }
             }
-            s_h[0][ry][tx] = h0;
-            s_h[1][ry][tx] = h1;
-            s_h[2][ry][tx] = h2;
-            s_h[3][ry][tx] = h3;
-            s_h[4][ry][tx] = h4;
+#pragma unroll
+            for (int m = 0; m < 5; ++m)
+#pragma unroll
+                for (int e = 0; e < NB; ++e) s_h[m][ry][tx0 + e] = h[m][e];
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < TH * TW; i += 256) {  // vertical filter + SSIM + adjoints
-            const int ty = i / TW, tx = i % TW;
-            const int gy = y0 + ty, gx = x0 + tx;
-            if (gy < R || gy >= L.H - R || gx < R || gx >= L.W - R) continue;  // window must lie inside the image
-            float mu = 0, nu = 0, exx = 0, eyy = 0, exy = 0;
+        for (int i = threadIdx.x; i < (TH / NB) * TW; i += 256) {  // vertical filter + SSIM + adjoints
+            const int ty0 = (i / TW) * NB, tx = i % TW;
+            float v[5][NB];
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const float w = Wd.g[k];
-                mu = fmaf(w, s_h[0][ty + k][tx], mu);
-                nu = fmaf(w, s_h[1][ty + k][tx], nu);
-                exx = fmaf(w, s_h[2][ty + k][tx], exx);
-                eyy = fmaf(w, s_h[3][ty + k][tx], eyy);
-                exy = fmaf(w, s_h[4][ty + k][tx], exy);
+            for (int m = 0; m < 5; ++m)
+#pragma unroll
+                for (int e = 0; e < NB; ++e) v[m][e] = 0.f;
+#pragma unroll
+            for (int j = 0; j < K + NB - 1; ++j) {
+#pragma unroll
+                for (int m = 0; m < 5; ++m) {
+                    const float a = s_h[m][ty0 + j][tx];
+#pragma unroll
+                    for (int e = 0; e < NB; ++e)
+                        if (j - e >= 0 && j - e < K) v[m][e] = fmaf(Wd.g[j - e], a, v[m][e]);
+                }
             }
-            const float vx_raw = exx - mu * mu, vy_raw = eyy - nu * nu;
-            const float vx = fmaxf(vx_raw, 0.f), vy = fmaxf(vy_raw, 0.f);
-            const float A1 = 2.f * mu * nu + L.c1, A2 = 2.f * (exy - mu * nu) + L.c2;
-            const float B1 = mu * mu + nu * nu + L.c1, B2 = vx + vy + L.c2;
-            const float inv = 1.0f / (B1 * B2);
-            const float S = A1 * A2 * inv;
-            ssim_sum += S;
-            // dS/dExx = -S/B2 (zero where the variance clamp is active); the same factor enters dS/dmu
-            const float dExx = vx_raw > 0.f ? -S / B2 : 0.f;
-            const float dmu = 2.f * nu * (A2 - A1) * inv - 2.f * mu * S / B1 - 2.f * mu * dExx;
-            const float dExy = 2.f * A1 * inv;
-            const size_t o = (size_t)gy * L.W + gx;
-            D[(size_t)(c * 3 + 0) * plane + o] = dmu;
-            D[(size_t)(c * 3 + 1) * plane + o] = dExx;
-            D[(size_t)(c * 3 + 2) * plane + o] = dExy;
+#pragma unroll
+            for (int e = 0; e < NB; ++e) {
+                const int gy = y0 + ty0 + e, gx = x0 + tx;
+                if (gy < R || gy >= L.H - R || gx < R || gx >= L.W - R) continue;  // window must lie inside the image
+                const float mu = v[0][e], nu = v[1][e], exx = v[2][e], eyy = v[3][e], exy = v[4][e];
+                const float vx_raw = exx - mu * mu, vy_raw = eyy - nu * nu;
+                const float vx = fmaxf(vx_raw, 0.f), vy = fmaxf(vy_raw, 0.f);
+                const float A1 = 2.f * mu * nu + L.c1, A2 = 2.f * (exy - mu * nu) + L.c2;
+                const float B1 = mu * mu + nu * nu + L.c1, B2 = vx + vy + L.c2;
+                const float inv = 1.0f / (B1 * B2);
+                const float S = A1 * A2 * inv;
+                ssim_sum += S;
+                // dS/dExx = -S/B2 (zero where the variance clamp is active); the same factor enters dS/dmu
+                const float dExx = vx_raw > 0.f ? -S / B2 : 0.f;
+                const float dmu = 2.f * nu * (A2 - A1) * inv - 2.f * mu * S / B1 - 2.f * mu * dExx;
+                const float dExy = 2.f * A1 * inv;
+                const size_t o = (size_t)gy * L.W + gx;
+                D[(size_t)(c * 3 + 0) * plane + o] = dmu;
+                D[(size_t)(c * 3 + 1) * plane + o] = dExx;
+                D[(size_t)(c * 3 + 2) * plane + o] = dExy;
+            }
         }
         __syncthreads();
     }
@@ -138,42 +157,58 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(const float *__restrict_
                 for (int m = 0; m < 3; ++m) s_d[m][ry][rx] = in ? D[(size_t)(c * 3 + m) * plane + o] : 0.f;
             }
             __syncthreads();
-            for (int i = threadIdx.x; i < RH * TW; i += 256) {
-                const int ry = i / TW, tx = i % TW;
-                float h0 = 0, h1 = 0, h2 = 0;
+            for (int i = threadIdx.x; i < RH * (TW / NB); i += 256) {
+                const int ry = i / (TW / NB), tx0 = (i % (TW / NB)) * NB;
+                float h[3][NB];
 #pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const float w = Wd.g[k];
-                    h0 = fmaf(w, s_d[0][ry][tx + k], h0);
-                    h1 = fmaf(w, s_d[1][ry][tx + k], h1);
-                    h2 = fmaf(w, s_d[2][ry][tx + k], h2);
-                }
-                s_h[0][ry][tx] = h0;
-                s_h[1][ry][tx] = h1;
-                s_h[2][ry][tx] = h2;
+                for (int m = 0; m < 3; ++m)
+#pragma unroll
+                    for (int e = 0; e < NB; ++e) h[m][e] = 0.f;
+#pragma unroll
+                for (int j = 0; j < K + NB - 1; ++j)
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) {
+                        const float a = s_d[m][ry][tx0 + j];
+#pragma unroll
+                        for (int e = 0; e < NB; ++e)
+                            if (j - e >= 0 && j - e < K) h[m][e] = fmaf(Wd.g[j - e], a, h[m][e]);
+                    }
+#pragma unroll
+                for (int m = 0; m < 3; ++m)
+#pragma unroll
+                    for (int e = 0; e < NB; ++e) s_h[m][ry][tx0 + e] = h[m][e];
             }
             __syncthreads();
         }
-        for (int i = threadIdx.x; i < TH * TW; i += 256) {
-            const int ty = i / TW, tx = i % TW;
-            const int gy = y0 + ty, gx = x0 + tx;
-            if (gy >= L.H || gx >= L.W) continue;
-            const size_t o = ((size_t)gy * L.W + gx) * 3 + c;
-            const float xv = x[o], yv = y[o], d = xv - yv;
-            l1_sum += fabsf(d);
-            float g = L.a * (d > 0.f ? 1.f : d < 0.f ? -1.f : 0.f);  // torch: sign(0) = 0
-            if (use_ssim) {
-                float g0 = 0, g1 = 0, g2 = 0;
+        for (int i = threadIdx.x; i < (TH / NB) * TW; i += 256) {
+            const int ty0 = (i / TW) * NB, tx = i % TW;
+            float gsum[3][NB];
 #pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const float w = Wd.g[k];
-                    g0 = fmaf(w, s_h[0][ty + k][tx], g0);
-                    g1 = fmaf(w, s_h[1][ty + k][tx], g1);
-                    g2 = fmaf(w, s_h[2][ty + k][tx], g2);
-                }
-                g -= L.b * (g0 + 2.f * xv * g1 + yv * g2);
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int e = 0; e < NB; ++e) gsum[m][e] = 0.f;
+            if (use_ssim) {
+#pragma unroll
+                for (int j = 0; j < K + NB - 1; ++j)
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) {
+                        const float a = s_h[m][ty0 + j][tx];
+#pragma unroll
+                        for (int e = 0; e < NB; ++e)
+                            if (j - e >= 0 && j - e < K) gsum[m][e] = fmaf(Wd.g[j - e], a, gsum[m][e]);
+                    }
             }
-            grad[o] = g;
+#pragma unroll
+            for (int e = 0; e < NB; ++e) {
+                const int gy = y0 + ty0 + e, gx = x0 + tx;
+                if (gy >= L.H || gx >= L.W) continue;
+                const size_t o = ((size_t)gy * L.W + gx) * 3 + c;
+                const float xv = x[o], yv = y[o], d = xv - yv;
+                l1_sum += fabsf(d);
+                float g = L.a * (d > 0.f ? 1.f : d < 0.f ? -1.f : 0.f);  // torch: sign(0) = 0
+                if (use_ssim) g -= L.b * (gsum[0][e] + 2.f * xv * gsum[1][e] + yv * gsum[2][e]);
+                grad[o] = g;
+            }
         }
         __syncthreads();
     }

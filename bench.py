@@ -193,27 +193,51 @@ def main():
     # ---------------------------------------------------------------- extra legs
     extra = {}
     if not args.no_extra:
-        # training iteration: forward (checkpointing) + L1 loss + backward (+ RCCL all-reduce when N > 1)
-        from gs_dp import FlatGaussianParams
+        # training iteration of train.py:84-185 without densification: forward (checkpointing) -> L1 + SSIM loss
+        # and its gradient -> backward -> RCCL all-reduce of the flat gradient bucket (N > 1) -> fused Adam
+        from gs_train import TrainOptions, Trainer
 
-        flat = FlatGaussianParams(params, world_size=world, force_collective=use_dist)
-        rt, stt = sized_renderer(flat.params, cam, training=True)
         target = torch.rand(H, W, 3, device=dev)
+        tr = Trainer(params, [cam], [target], TrainOptions(), world_size=world, max_pairs=int(st.pairs * 1.1) + 4096)
+        tr.flat.force_collective = use_dist
+        tr.renderer.auto_grow = False
+        rt, flat = tr.renderer, tr.flat
+        it = [0]
 
         def train_iter():
-            img, _ = rt.forward(*flat.params, cam)
-            g = torch.sign(img - target) / img.numel()  # d(L1 mean)/d(img)
-            rt.backward(g, out=flat.grads)
-            flat.all_reduce_grads()
+            tr.train_step(it[0], 0)
+            it[0] += 1
 
         k = max(args.steps // 4, 10)
         dtt = time_frames(train_iter, k, max(args.warmup // 4, 3))
         extra["train_iters_per_s"] = round(world * k / dtt, 2)
         extra["train_ms_per_iter"] = round(dtt / k * 1e3, 4)
+        extra["train_step"] = "forward + L1/SSIM loss (w=0.1) + backward + grad all-reduce + fused Adam, one view per GPU"
         if rank == 0:
             img, _ = rt.forward(*flat.params, cam)
-            pb = [rt.profile_backward(torch.sign(img - target) / img.numel()) for _ in range(8)][3:]
+            lossk = tr._loss_for(H, W)
+            pb = [rt.profile_backward(lossk(img, target)) for _ in range(8)][3:]
             extra["backward_stage_ms"] = {key: round(statistics.median(p[key] for p in pb), 4) for key in pb[0]}
+
+            def timed(fn, reps=20):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                fn()
+                e0.record()
+                for _ in range(reps):
+                    fn()
+                e1.record()
+                e1.synchronize()
+                return e0.elapsed_time(e1) / reps
+
+            loss_ms, adam_ms = timed(lambda: lossk(img, target)), timed(tr.optimizer.step)
+            n_par = flat.flat_param.numel()
+            extra["loss_ms"], extra["adam_ms"] = round(loss_ms, 4), round(adam_ms, 4)
+            # Adam is a pure stream: 16 B read + 12 B written per parameter
+            extra["adam_roofline"] = {"bound": "hbm", "achieved": round(28 * n_par / (adam_ms * 1e-3) / 1e9, 1),
+                                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": round(28 * n_par / (adam_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                      "parameters": n_par}
+        del tr
         del rt, flat
         torch.cuda.empty_cache()
         if args.config != "cfg5":
