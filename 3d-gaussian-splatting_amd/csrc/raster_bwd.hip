@@ -32,10 +32,10 @@ int gs_raster_forward_ref(const RasterSrc &S, const RasterGeom &G, const int32_t
 
 namespace {
 
-// exclusive scan of ceil(nproc/64) over tiles -> bucket_offsets[T+1], total -> *n_buckets
+// exclusive scan of ceil(nproc/64) (or floor, see full_only) over tiles -> bucket_offsets[T+1], total -> *n_buckets
 __global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t *__restrict__ tile_nproc, int n_tiles,
                                                           uint32_t *__restrict__ bucket_offsets,
-                                                          unsigned long long *__restrict__ n_buckets) {
+                                                          unsigned long long *__restrict__ n_buckets, int full_only) {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
     if (threadIdx.x == 0) s_carry = 0;
@@ -43,7 +43,8 @@ __global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t *__res
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int base = 0; base < n_tiles; base += 1024) {
         const int i = base + threadIdx.x;
-        const uint32_t v = i < n_tiles ? (tile_nproc[i] + GS_BUCKET - 1) / GS_BUCKET : 0;
+        // full_only: the ragged tail of every tile (nproc mod 64 Gaussians) goes to raster_backward_tail_kernel
+        const uint32_t v = i < n_tiles ? (tile_nproc[i] + (full_only ? 0 : GS_BUCKET - 1)) / GS_BUCKET : 0;
         const uint32_t incl = gs_wave_incl_scan_u32(v);
         if (lane == 63) s_wave[wave] = incl;
         __syncthreads();
@@ -129,9 +130,10 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, Raste
             const int ox = (int)id_x - G.crop_left, oy = (int)id_y - G.crop_top;
             const bool in = ox >= 0 && ox < G.width && oy >= 0 && oy < G.height;
             const float *gp = I.grad + ((size_t)(in ? oy : 0) * G.width + (in ? ox : 0)) * 3;
-            pg0 = (in && pf0 >= 0.f && pf0 <= 1.f) ? gp[0] : 0.f;
-            pg1 = (in && pf1 >= 0.f && pf1 <= 1.f) ? gp[1] : 0.f;
-            pg2 = (in && pf2 >= 0.f && pf2 <= 1.f) ? gp[2] : 0.f;
+            const float u0 = gp[0], u1 = gp[1], u2 = gp[2];  // unconditional: no load that depends on c_final
+            pg0 = (in && pf0 >= 0.f && pf0 <= 1.f) ? u0 : 0.f;
+            pg1 = (in && pf1 >= 0.f && pf1 <= 1.f) ? u1 : 0.f;
+            pg2 = (in && pf2 >= 0.f && pf2 <= 1.f) ? u2 : 0.f;
         } else {
             const float *gp = I.grad + ((size_t)id_y * G.padW + id_x) * 3;
             pg0 = gp[0];
@@ -335,11 +337,220 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, Raste
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Ragged tails (no SH).  A systolic bucket streams all 256 pixels through its 64 lanes however few
+// Gaussians it holds: the last bucket of a 133-Gaussian tile keeps 5 lanes busy for 260 steps (17 us of
+// SIMD time, as much as a full bucket).  The r = nproc mod 64 trailing Gaussians of every tile are
+// therefore handled the other way round: ONE wave per tile, lanes own pixels (four each, the forward's
+// layout), the r Gaussians are applied one after the other from the tile's last checkpoint, and the ten
+// per-Gaussian sums are reduced over the wave through LDS, two Gaussians at a time (20 rows of 64
+// partials, summed by 20 lanes).  ~0.25 us per Gaussian instead of 17 us per bucket.
+template <bool FRAME>
+__global__ void __launch_bounds__(64) raster_backward_tail_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
+    constexpr int TG = 2;  // Gaussians per reduction group (LDS: TG x 10 rows of 64 partials)
+    enum { FX, FY, FA, FB, FC, FOPA, FC0, FC1, FC2, FCA, FCB, FCC, FCD, NFLD };
+    __shared__ float s_g[NFLD][64];
+    __shared__ uint32_t s_gid[64];
+    __shared__ float s_red[TG * 10][65];
+    __shared__ float s_tot[64][10];
+    // LDS traffic of ONE wave is processed in program order, so the stages below only need the compiler
+    // not to move LDS accesses across them.  (A `fence acq_rel` would also drain the outstanding global
+    // loads and stores -- measured: 80 us of a 124 us kernel when the row stores sat inside the loop.)
+    auto lds_order = [] {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    };
+    const int lane = threadIdx.x;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t nproc = I.tile_nproc[tile];
+    const uint32_t r = nproc % GS_BUCKET;
+    if (r == 0) return;
+    const uint32_t base = nproc - r;
+    const uint32_t tx = tile % (uint32_t)G.ntx, ty = tile / (uint32_t)G.ntx;
+    const uint32_t start = (uint32_t)(FRAME ? I.ranges[2 * tile] : I.ranges[tile]);
+
+    // ---- stage the r Gaussians (one per lane), zero-padded to a multiple of 4
+    {
+        GaussianRec g = {0, 0, 0, 0, 0, 0, 0};
+        float c0 = 0, c1 = 0, c2 = 0, cA = 0, cB = 0, cC = 0;
+        uint32_t gid = 0;
+        if ((uint32_t)lane < r) {
+            const uint32_t j = start + base + lane;
+            gid = raster_load<FRAME>(S, j, g);
+            raster_load_rgb<FRAME>(S, j, gid, c0, c1, c2);
+            raster_conic(g, cA, cB, cC);
+        }
+        s_g[FX][lane] = g.x;
+        s_g[FY][lane] = g.y;
+        s_g[FA][lane] = cA;
+        s_g[FB][lane] = cB;
+        s_g[FC][lane] = cC;
+        s_g[FOPA][lane] = (uint32_t)lane < r ? g.opa : 0.f;
+        s_g[FC0][lane] = c0;
+        s_g[FC1][lane] = c1;
+        s_g[FC2][lane] = c2;
+        s_g[FCA][lane] = g.a;
+        s_g[FCB][lane] = g.b;
+        s_g[FCC][lane] = g.c;
+        s_g[FCD][lane] = g.d;
+        s_gid[lane] = gid;
+    }
+
+    // ---- this lane's four pixels: (x, y0 + 4k)
+    const uint32_t id_x = tx * 16 + (lane & 15), id_y0 = ty * 16 + (lane >> 4);
+    const float px = raster_pixel_coord(id_x, G.padW, G.focal_x);
+    const float4 *ck = I.ckpt + raster_ckpt_slot(start, tile, base / GS_BUCKET) * 256;
+    float py[4], T[4], rho[4], g0[4], g1[4], g2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t id_y = id_y0 + 4 * k;
+        py[k] = raster_pixel_coord(id_y, G.padH, G.focal_y);
+        const float4 c = ck[64 * k + lane];  // tile pixel index = 16 (y - ty 16) + (x - tx 16)
+        const float *cf = I.c_final + ((size_t)id_y * G.padW + id_x) * 3;
+        const float f0 = cf[0], f1 = cf[1], f2 = cf[2];
+        if (FRAME) {
+            const int ox = (int)id_x - G.crop_left, oy = (int)id_y - G.crop_top;
+            const bool in = ox >= 0 && ox < G.width && oy >= 0 && oy < G.height;
+            const float *gp = I.grad + ((size_t)(in ? oy : 0) * G.width + (in ? ox : 0)) * 3;
+            const float u0 = gp[0], u1 = gp[1], u2 = gp[2];  // loaded unconditionally: a load that depends on
+            g0[k] = (in && f0 >= 0.f && f0 <= 1.f) ? u0 : 0.f;  // c_final would serialise two memory round trips
+            g1[k] = (in && f1 >= 0.f && f1 <= 1.f) ? u1 : 0.f;
+            g2[k] = (in && f2 >= 0.f && f2 <= 1.f) ? u2 : 0.f;
+        } else {
+            const float *gp = I.grad + ((size_t)id_y * G.padW + id_x) * 3;
+            g0[k] = gp[0];
+            g1[k] = gp[1];
+            g2[k] = gp[2];
+        }
+        T[k] = c.x;
+        rho[k] = g0[k] * (f0 - c.y) + g1[k] * (f1 - c.z) + g2[k] * (f2 - c.w);
+    }
+    lds_order();
+
+    for (uint32_t i0 = 0; i0 < r; i0 += TG) {
+#pragma unroll
+        for (int u = 0; u < TG; ++u) {
+            const uint32_t i = i0 + u;  // < 64: padded entries have opacity 0 and contribute exact zeros
+            const float gx = s_g[FX][i], gy = s_g[FY][i], cA = s_g[FA][i], cB = s_g[FB][i], cC = s_g[FC][i];
+            const float opa = s_g[FOPA][i], c0 = s_g[FC0][i], c1 = s_g[FC1][i], c2 = s_g[FC2][i];
+            float Sx = 0, Sy = 0, Sxx = 0, Sxy = 0, Syy = 0, Sq = 0, Sopa = 0, Sc0 = 0, Sc1 = 0, Sc2 = 0;
+            const float dx = px - gx;
+            const float bdx = cB * dx, adx2 = cA * dx * dx;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float dy = py[k] - gy;
+                const float q = fmaf(fmaf(cC, dy, -bdx), dy, adx2);
+                const float Gv = gs_exp2(-q);
+                const bool live = T[k] > GS_T_STOP;
+                const float alpha = live ? Gv * opa : 0.f;
+                const float w = alpha * T[k];
+                const float gc = fmaf(g2[k], c2, fmaf(g1[k], c1, g0[k] * c0));
+                rho[k] = fmaf(-w, gc, rho[k]);
+                float d_alpha = fmaf(T[k], gc, -(rho[k] * gs_rcp(1.0f - alpha + 1e-7f)));
+                d_alpha = live ? d_alpha : 0.f;
+                Sc0 = fmaf(g0[k], w, Sc0);
+                Sc1 = fmaf(g1[k], w, Sc1);
+                Sc2 = fmaf(g2[k], w, Sc2);
+                Sopa = fmaf(d_alpha, Gv, Sopa);
+                const float s = d_alpha * alpha;
+                const float sdx = s * dx, sdy = s * dy;
+                Sx += sdx;
+                Sy += sdy;
+                Sxx = fmaf(sdx, dx, Sxx);
+                Sxy = fmaf(sdx, dy, Sxy);
+                Syy = fmaf(sdy, dy, Syy);
+                Sq = fmaf(s, q, Sq);
+                T[k] = T[k] - w;
+            }
+            float *red = &s_red[u * 10][lane];
+            red[0 * 65] = Sx;
+            red[1 * 65] = Sy;
+            red[2 * 65] = Sxx;
+            red[3 * 65] = Sxy;
+            red[4 * 65] = Syy;
+            red[5 * 65] = Sq;
+            red[6 * 65] = Sopa;
+            red[7 * 65] = Sc0;
+            red[8 * 65] = Sc1;
+            red[9 * 65] = Sc2;
+        }
+        lds_order();
+        if (lane < TG * 10) {  // lane = 10 u + m sums row m of Gaussian i0 + u over the 64 lanes
+            float t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+#pragma unroll
+            for (int l = 0; l < 64; l += 4) {
+                t0 += s_red[lane][l];
+                t1 += s_red[lane][l + 1];
+                t2 += s_red[lane][l + 2];
+                t3 += s_red[lane][l + 3];
+            }
+            s_tot[i0 + lane / 10][lane % 10] = (t0 + t1) + (t2 + t3);
+        }
+        lds_order();
+    }
+    if ((uint32_t)lane < r) {  // one lane per Gaussian finishes the algebra and stores its row
+        const uint32_t i = lane;
+        const float *t = s_tot[lane];
+        const float Sx = t[0], Sy = t[1], Sxx = t[2], Sxy = t[3], Syy = t[4], Sq = t[5];
+        const float cA = s_g[FA][i], cB = s_g[FB][i], cC = s_g[FC][i];
+        const float a = s_g[FCA][i], b = s_g[FCB][i], c = s_g[FCC][i], d = s_g[FCD][i];
+        const float iPn = 1.0f / (2.0f * raster_det(a, b, c, d) + 1e-14f);
+        const float Su = Sq * GS_LN2;
+        const float ogx = GS_LN2 * (2.0f * cA * Sx - cB * Sy), ogy = GS_LN2 * (2.0f * cC * Sy - cB * Sx);
+        const float ga = iPn * (-Syy + 2.0f * d * Su), gb = iPn * (Sxy - 2.0f * c * Su);
+        const float gcc = iPn * (Sxy - 2.0f * b * Su), gd = iPn * (-Sxx + 2.0f * a * Su);
+        if (FRAME) {
+            const uint32_t gid = s_gid[i];
+            const uint4 rc = O.rects[gid];
+            const uint32_t y0 = rc.x & 0xffff, x0 = rc.y & 0xffff, x1 = rc.y >> 16;
+            const uint64_t slot = (uint64_t)O.pair_offsets[gid] + (ty - y0) * (x1 - x0) + (tx - x0);
+            if (slot < O.max_pairs) {
+                float4 *row = reinterpret_cast<float4 *>(O.rows + slot * 12);
+                row[0] = make_float4(ogx, ogy, ga, gb);
+                row[1] = make_float4(gcc, gd, t[6], t[7]);
+                row[2] = make_float4(t[8], t[9], 0.f, 0.f);
+            }
+        } else {
+            const size_t j = (size_t)start + base + i;
+            O.grad_pos[j * 3 + 0] = ogx;
+            O.grad_pos[j * 3 + 1] = ogy;
+            O.grad_opa[j] = t[6];
+            reinterpret_cast<float4 *>(O.grad_cov)[j] = make_float4(ga, gb, gcc, gd);
+            O.grad_rgb[j * 3 + 0] = t[7];
+            O.grad_rgb[j * 3 + 1] = t[8];
+            O.grad_rgb[j * 3 + 2] = t[9];
+        }
+    }
+}
+
 template <int CDIM, bool FRAME>
 void launch_bwd(const RasterSrc &S, const RasterGeom &G, const BwdIn &I, const BwdOut &O, int64_t max_buckets,
                 hipStream_t stream) {
     const int grid = (int)gs_div_up(max_buckets > 0 ? max_buckets : 1, 4);
-    hipLaunchKernelGGL((raster_backward_kernel<CDIM, FRAME>), dim3(grid), dim3(256), 0, stream, S, G, I, O);
+    if (CDIM == 3) {
+        // The systolic kernel sees full buckets only (bucket_scan_kernel, full_only); the ragged tails run in
+        // raster_backward_tail_kernel.  That kernel is short and latency-bound (dependent loads, LDS round trips
+        // per group), the systolic one is VALU-bound, and they write disjoint rows: fork the tails onto a side
+        // stream so that both are resident together, join before the caller's next kernel.
+        static thread_local hipStream_t side = nullptr;
+        static thread_local hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+        bool forked = false;
+        if (!side) {
+            if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess)
+                side = nullptr;  // fall back to the caller's stream (still correct, just serial)
+        }
+        if (side && hipEventRecord(ev_fork, stream) == hipSuccess && hipStreamWaitEvent(side, ev_fork, 0) == hipSuccess)
+            forked = true;
+        hipLaunchKernelGGL((raster_backward_tail_kernel<FRAME>), dim3(G.ntx * G.nty), dim3(64), 0,
+                           forked ? side : stream, S, G, I, O);
+        if (forked && hipEventRecord(ev_join, side) != hipSuccess) forked = false;
+        hipLaunchKernelGGL((raster_backward_kernel<CDIM, FRAME>), dim3(grid), dim3(256), 0, stream, S, G, I, O);
+        if (forked) (void)hipStreamWaitEvent(stream, ev_join, 0);
+    } else {
+        hipLaunchKernelGGL((raster_backward_kernel<CDIM, FRAME>), dim3(grid), dim3(256), 0, stream, S, G, I, O);
+    }
 }
 
 struct RefWs {
@@ -430,7 +641,7 @@ extern "C" int gs_draw_backward(const float *pos, const float *rgb, const float 
     if (rc) return rc;
     // 2. bucket work list
     hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, s, ws.tile_nproc, G.ntx * G.nty,
-                       ws.bucket_offsets, ws.n_buckets);
+                       ws.bucket_offsets, ws.n_buckets, use_sh_coeff ? 0 : 1);
     // 3. systolic backward, one wave per bucket, one output row per pair
     BwdIn I = {output, grad_output, ws.ckpt, ws.tile_nproc, ws.bucket_offsets, tile_n_point_accum};
     BwdOut O = {nullptr, nullptr, nullptr, 0, grad_pos, grad_rgb, grad_opa, grad_cov};
@@ -473,7 +684,7 @@ int gs_stage_raster_backward(const gs_frame *f, const gs_frame_ws &ws, const uin
     GS_HIP(hipMemsetAsync(ws.rows, 0, sizeof(float) * (size_t)gs_row_floats(f->color_dim) * f->max_pairs, stream));
     (void)grad_rgb;
     hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, ws.tile_nproc, FG.n_tiles,
-                       ws.bucket_offsets, ws.counters + GS_CNT_BUCKETS);
+                       ws.bucket_offsets, ws.counters + GS_CNT_BUCKETS, f->color_dim == 27 ? 0 : 1);
     BwdIn I = {f->image_padded, grad_image, ws.ckpt, ws.tile_nproc, ws.bucket_offsets, ws.tile_ranges};
     BwdOut O = {ws.rows, ws.pair_offsets, ws.rects, (uint64_t)f->max_pairs, nullptr, nullptr, nullptr, nullptr};
     if (f->color_dim == 27)
