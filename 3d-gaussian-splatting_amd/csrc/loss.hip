@@ -21,8 +21,15 @@
 namespace {
 
 constexpr int R = 5, K = 11;   // window radius / size
-constexpr int TW = 32, TH = 32;  // output tile of a 256-thread workgroup
-constexpr int NB = 4;             // outputs per thread and filter pass: each LDS value feeds up to NB outputs
+#ifndef GS_LOSS_TH
+#define GS_LOSS_TH 32
+#endif
+#ifndef GS_LOSS_NBV
+#define GS_LOSS_NBV 4
+#endif
+constexpr int TW = 32, TH = GS_LOSS_TH;  // output tile of a 256-thread workgroup
+constexpr int NB = 4;             // horizontal outputs per thread: each LDS value feeds up to NB outputs
+constexpr int NBV = GS_LOSS_NBV;  // vertical outputs per thread
 constexpr int RW = TW + 2 * R, RH = TH + 2 * R;
 
 struct Window {
@@ -52,16 +59,37 @@ __global__ void __launch_bounds__(256) ssim_moments_kernel(const float *__restri
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;  // tile origin (output coordinates)
     const size_t plane = (size_t)L.H * L.W;
     float ssim_sum = 0.f;
-    for (int c = 0; c < 3; ++c) {
-        for (int i = threadIdx.x; i < RH * RW; i += 256) {
+    // the (TH+10) x (TW+10) input region of one channel, NLD elements per thread; the NEXT channel's
+    // region is fetched into registers while the current one is filtered (loads are unconditional with
+    // clamped coordinates: a predicated load would put a branch and a wait in front of every element)
+    constexpr int NLD = (RH * RW + 255) / 256;
+    float rx_[NLD], ry_[NLD];
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int e = 0; e < NLD; ++e) {
+            const int i = threadIdx.x + e * 256;
             const int ry = i / RW, rx = i % RW;
-            const int gy = y0 + ry - R, gx = x0 + rx - R;
-            const bool in = gy >= 0 && gy < L.H && gx >= 0 && gx < L.W;
-            const size_t o = ((size_t)(in ? gy : 0) * L.W + (in ? gx : 0)) * 3 + c;
-            s_x[ry][rx] = in ? x[o] : 0.f;
-            s_y[ry][rx] = in ? y[o] : 0.f;
+            const int gy = min(max(y0 + ry - R, 0), L.H - 1), gx = min(max(x0 + rx - R, 0), L.W - 1);
+            const size_t o = ((size_t)gy * L.W + gx) * 3 + c;
+            rx_[e] = x[o];
+            ry_[e] = y[o];
         }
+    };
+    auto stage = [&]() {  // values outside the image are never used by an interior output; no masking needed
+#pragma unroll
+        for (int e = 0; e < NLD; ++e) {
+            const int i = threadIdx.x + e * 256;
+            if (i < RH * RW) {
+                s_x[i / RW][i % RW] = rx_[e];
+                s_y[i / RW][i % RW] = ry_[e];
+            }
+        }
+    };
+    fetch(0);
+    for (int c = 0; c < 3; ++c) {
+        stage();
         __syncthreads();
+        if (c + 1 < 3) fetch(c + 1);
         for (int i = threadIdx.x; i < RH * (TW / NB); i += 256) {  // horizontal filter of the five moments
             const int ry = i / (TW / NB), tx0 = (i % (TW / NB)) * NB;
             float h[5][NB];
@@ -90,25 +118,25 @@ __global__ void __launch_bounds__(256) ssim_moments_kernel(const float *__restri
                 for (int e = 0; e < NB; ++e) s_h[m][ry][tx0 + e] = h[m][e];
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < (TH / NB) * TW; i += 256) {  // vertical filter + SSIM + adjoints
-            const int ty0 = (i / TW) * NB, tx = i % TW;
-            float v[5][NB];
+        for (int i = threadIdx.x; i < (TH / NBV) * TW; i += 256) {  // vertical filter + SSIM + adjoints
+            const int ty0 = (i / TW) * NBV, tx = i % TW;
+            float v[5][NBV];
 #pragma unroll
             for (int m = 0; m < 5; ++m)
 #pragma unroll
-                for (int e = 0; e < NB; ++e) v[m][e] = 0.f;
+                for (int e = 0; e < NBV; ++e) v[m][e] = 0.f;
 #pragma unroll
-            for (int j = 0; j < K + NB - 1; ++j) {
+            for (int j = 0; j < K + NBV - 1; ++j) {
 #pragma unroll
                 for (int m = 0; m < 5; ++m) {
                     const float a = s_h[m][ty0 + j][tx];
 #pragma unroll
-                    for (int e = 0; e < NB; ++e)
+                    for (int e = 0; e < NBV; ++e)
                         if (j - e >= 0 && j - e < K) v[m][e] = fmaf(Wd.g[j - e], a, v[m][e]);
                 }
             }
 #pragma unroll
-            for (int e = 0; e < NB; ++e) {
+            for (int e = 0; e < NBV; ++e) {
                 const int gy = y0 + ty0 + e, gx = x0 + tx;
                 if (gy < R || gy >= L.H - R || gx < R || gx >= L.W - R) continue;  // window must lie inside the image
                 const float mu = v[0][e], nu = v[1][e], exx = v[2][e], eyy = v[3][e], exy = v[4][e];
@@ -146,17 +174,36 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(const float *__restrict_
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     const size_t plane = (size_t)L.H * L.W;
     float l1_sum = 0.f;
+    constexpr int NLD = (RH * RW + 255) / 256;
+    float rd[3][NLD];
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int e = 0; e < NLD; ++e) {
+            const int i = threadIdx.x + e * 256;
+            const int ry = i / RW, rx = i % RW;
+            const int gy = y0 + ry - R, gx = x0 + rx - R;
+            const bool in = gy >= R && gy < L.H - R && gx >= R && gx < L.W - R;  // adjoints live on the interior
+            const size_t o = (size_t)min(max(gy, 0), L.H - 1) * L.W + min(max(gx, 0), L.W - 1);
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const float v = D[(size_t)(c * 3 + m) * plane + o];  // unconditional load, masked afterwards
+                rd[m][e] = in ? v : 0.f;
+            }
+        }
+    };
+    if (use_ssim) fetch(0);
     for (int c = 0; c < 3; ++c) {
         if (use_ssim) {
-            for (int i = threadIdx.x; i < RH * RW; i += 256) {
-                const int ry = i / RW, rx = i % RW;
-                const int gy = y0 + ry - R, gx = x0 + rx - R;
-                const bool in = gy >= R && gy < L.H - R && gx >= R && gx < L.W - R;  // adjoints live on the interior
-                const size_t o = (size_t)(in ? gy : 0) * L.W + (in ? gx : 0);
 #pragma unroll
-                for (int m = 0; m < 3; ++m) s_d[m][ry][rx] = in ? D[(size_t)(c * 3 + m) * plane + o] : 0.f;
+            for (int e = 0; e < NLD; ++e) {
+                const int i = threadIdx.x + e * 256;
+                if (i < RH * RW) {
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) s_d[m][i / RW][i % RW] = rd[m][e];
+                }
             }
             __syncthreads();
+            if (c + 1 < 3) fetch(c + 1);
             for (int i = threadIdx.x; i < RH * (TW / NB); i += 256) {
                 const int ry = i / (TW / NB), tx0 = (i % (TW / NB)) * NB;
                 float h[3][NB];
@@ -180,26 +227,26 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(const float *__restrict_
             }
             __syncthreads();
         }
-        for (int i = threadIdx.x; i < (TH / NB) * TW; i += 256) {
-            const int ty0 = (i / TW) * NB, tx = i % TW;
-            float gsum[3][NB];
+        for (int i = threadIdx.x; i < (TH / NBV) * TW; i += 256) {
+            const int ty0 = (i / TW) * NBV, tx = i % TW;
+            float gsum[3][NBV];
 #pragma unroll
             for (int m = 0; m < 3; ++m)
 #pragma unroll
-                for (int e = 0; e < NB; ++e) gsum[m][e] = 0.f;
+                for (int e = 0; e < NBV; ++e) gsum[m][e] = 0.f;
             if (use_ssim) {
 #pragma unroll
-                for (int j = 0; j < K + NB - 1; ++j)
+                for (int j = 0; j < K + NBV - 1; ++j)
 #pragma unroll
                     for (int m = 0; m < 3; ++m) {
                         const float a = s_h[m][ty0 + j][tx];
 #pragma unroll
-                        for (int e = 0; e < NB; ++e)
+                        for (int e = 0; e < NBV; ++e)
                             if (j - e >= 0 && j - e < K) gsum[m][e] = fmaf(Wd.g[j - e], a, gsum[m][e]);
                     }
             }
 #pragma unroll
-            for (int e = 0; e < NB; ++e) {
+            for (int e = 0; e < NBV; ++e) {
                 const int gy = y0 + ty0 + e, gx = x0 + tx;
                 if (gy >= L.H || gx >= L.W) continue;
                 const size_t o = ((size_t)gy * L.W + gx) * 3 + c;
