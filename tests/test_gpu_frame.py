@@ -72,6 +72,14 @@ def test_frame_forward_giant_bucket_sorted_in_global_memory(gpu):
     assert np.diff(of.accum).max() > 4096
 
 
+def test_frame_forward_more_tiles_than_lds_counters(gpu):
+    """4096 x 2176 = 34,816 tiles: above the 32,768 LDS counters of sort_mode 2, which must fall back to the
+    tile-bit radix passes (mode 1) and still produce the oracle's list and image."""
+    scene, cam = case(4_000, 4096, 2176, seed=17)
+    of, r, _ = check_forward(gpu, scene, cam, sort_mode=2)
+    assert r.stats().pairs == len(of.ids) > 0
+
+
 def test_frame_forward_sh(gpu):
     check_forward(gpu, *case(8_000, 160, 96, use_sh=True))
 
