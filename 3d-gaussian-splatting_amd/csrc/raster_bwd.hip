@@ -89,8 +89,12 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, Raste
     // segment streams through the lanes, the next one is prefetched into registers and then
     // written to the other half of the ring.  ~6 KiB of LDS per wave keeps occupancy
     // register-limited (the dependent DPP chain needs >= 5 waves per SIMD to stay hidden).
-    constexpr int NF = CDIM == 27 ? 4 : 2;  // float4 feed records per pixel
+    constexpr int NF = 2;  // float4 feed records per pixel
     __shared__ float4 s_feed[4][2][NF][64];
+    // SH only: the 9 basis values of a pixel never change while it travels, so they do not ride the DPP chain
+    // (9 moves = 28 ns of SIMD time per step, tools/ubench/pk_rate.hip); they are staged once per bucket and
+    // every lane reads the record of the pixel it currently holds (3 LDS reads, no VALU issue slots).
+    __shared__ float s_sh[CDIM == 27 ? 4 : 1][CDIM == 27 ? 256 * 9 : 1];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t n_tiles = (uint32_t)(G.ntx * G.nty);
     const uint32_t kb = blockIdx.x * 4 + wave;
@@ -148,14 +152,12 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, Raste
         // (gaussian.cu:716-722), so one scalar travels instead of three colour channels
         const float rho = pg0 * (pf0 - pc.y) + pg1 * (pf1 - pc.z) + pg2 * (pf2 - pc.w);
         s_feed[wave][buf][0][lane] = make_float4(pc.x, rho, my_px, py);
+        s_feed[wave][buf][1][lane] = make_float4(pg0, pg1, pg2, 0.f);
         if (CDIM == 27) {
             float SH[9];
             raster_pixel_sh(id_x, id_y, G, SH);
-            s_feed[wave][buf][1][lane] = make_float4(pg0, pg1, pg2, SH[0]);
-            s_feed[wave][buf][CDIM == 27 ? 2 : 0][lane] = make_float4(SH[1], SH[2], SH[3], SH[4]);
-            s_feed[wave][buf][CDIM == 27 ? 3 : 0][lane] = make_float4(SH[5], SH[6], SH[7], SH[8]);
-        } else {
-            s_feed[wave][buf][1][lane] = make_float4(pg0, pg1, pg2, 0.f);
+#pragma unroll
+            for (int q = 0; q < 9; ++q) s_sh[wave][(seg * 64 + lane) * 9 + q] = SH[q];
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -194,11 +196,6 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, Raste
     }
     // outgoing state of the previous step (T = 0 means "no pixel here")
     float oT = 0, orho = 0, og0 = 0, og1 = 0, og2 = 0, opx = 0, opy = 0;
-    float osh[CDIM == 27 ? 9 : 1];
-    if (CDIM == 27) {
-#pragma unroll
-        for (int q = 0; q < 9; ++q) osh[q] = 0.f;
-    }
 
     for (int seg = 0; seg < 5; ++seg) {
         const int buf = seg & 1;
@@ -217,16 +214,11 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, Raste
             const float g0 = gs_wave_shr1(f1.x, og0), g1 = gs_wave_shr1(f1.y, og1), g2 = gs_wave_shr1(f1.z, og2);
             float sh[CDIM == 27 ? 9 : 1];
             if (CDIM == 27) {
-                const float4 f2 = s_feed[wave][buf][CDIM == 27 ? 2 : 0][t], f3 = s_feed[wave][buf][CDIM == 27 ? 3 : 0][t];
-                sh[0] = gs_wave_shr1(f1.w, osh[0]);
-                sh[1] = gs_wave_shr1(f2.x, osh[1]);
-                sh[2] = gs_wave_shr1(f2.y, osh[2]);
-                sh[3] = gs_wave_shr1(f2.z, osh[3]);
-                sh[4] = gs_wave_shr1(f2.w, osh[4]);
-                sh[5] = gs_wave_shr1(f3.x, osh[5]);
-                sh[6] = gs_wave_shr1(f3.y, osh[6]);
-                sh[7] = gs_wave_shr1(f3.z, osh[7]);
-                sh[8] = gs_wave_shr1(f3.w, osh[8]);
+                // the pixel in this lane entered lane 0 `lane` steps ago: p = 64 seg + t - lane (lanes that hold
+                // no pixel yet / any more read a valid but irrelevant record: their T is 0)
+                const float *rec = &s_sh[wave][((seg * 64 + t - lane) & 255) * 9];
+#pragma unroll
+                for (int q = 0; q < 9; ++q) sh[q] = rec[q];
             }
 
             const float dx = px - g.x, dy = py - g.y;
@@ -284,10 +276,6 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, Raste
             og2 = g2;
             opx = px;
             opy = py;
-            if (CDIM == 27) {
-#pragma unroll
-                for (int k = 0; k < 9; ++k) osh[k] = sh[k];
-            }
         }
         if (seg + 1 < 4) write_segment(buf ^ 1, seg + 1);
     }
