@@ -10,7 +10,8 @@ Gaussians and the parameter gradients are averaged.  Layout choices for MI355X /
     writes straight into the bucket, and the exchange is a single ``all_reduce`` of
     N*(4+3+3+1+C)*4 bytes (134 MB at 2.4 M Gaussians) -- one large collective instead of five
     small ones, which is what a point-to-point xGMI mesh wants (per-link bound, 7 links/GPU);
-  * the reduction is SUM followed by an in-place scale by 1/world (mean over views).
+  * the reduction is the mean over views: ReduceOp.AVG inside the RCCL collective (SUM + an in-place scale
+    by 1/world on backends without AVG, i.e. gloo in the CPU tests).
 
 Works with any torch.distributed backend ("nccl" == RCCL on ROCm; "gloo" in CPU tests).
 """
@@ -56,16 +57,21 @@ class FlatGaussianParams:
         """Mean of the per-view gradients over all ranks (no-op for a single process)."""
         if not dist.is_initialized() or (self.world_size <= 1 and not self.force_collective):
             return None
-        work = dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, async_op=async_op)
+        # RCCL averages inside the collective (ReduceOp.AVG); gloo only sums, so the CPU tests scale afterwards
+        self._avg_in_collective = dist.get_backend() == "nccl"
+        op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
+        work = dist.all_reduce(self.flat_grad, op=op, async_op=async_op)
         if async_op:
             return work
-        self.flat_grad.mul_(1.0 / self.world_size)
+        if not self._avg_in_collective:
+            self.flat_grad.mul_(1.0 / self.world_size)
         return None
 
     def finish_all_reduce(self, work):
         if work is not None:
             work.wait()
-            self.flat_grad.mul_(1.0 / self.world_size)
+            if not self._avg_in_collective:
+                self.flat_grad.mul_(1.0 / self.world_size)
 
     def broadcast_params(self, src: int = 0):
         if self.world_size > 1 and dist.is_initialized():
