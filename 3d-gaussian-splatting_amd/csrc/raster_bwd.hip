@@ -522,12 +522,16 @@ void launch_bwd(const RasterSrc &S, const RasterGeom &G, const BwdIn &I, const B
         // stream so that both are resident together, join before the caller's next kernel.
         static thread_local hipStream_t side = nullptr;
         static thread_local hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+        static thread_local int side_dev = -1;
         bool forked = false;
-        if (!side) {
+        int dev = -1;
+        if (hipGetDevice(&dev) == hipSuccess && (!side || dev != side_dev)) {  // one side stream per (thread, device)
+            side = nullptr;  // a stream made on another device is abandoned (one process per GPU is the norm)
             if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess ||
                 hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess)
                 side = nullptr;  // fall back to the caller's stream (still correct, just serial)
+            side_dev = dev;
         }
         if (side && hipEventRecord(ev_fork, stream) == hipSuccess && hipStreamWaitEvent(side, ev_fork, 0) == hipSuccess)
             forked = true;

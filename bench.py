@@ -238,6 +238,35 @@ def main():
                                       "frac": round(28 * n_par / (adam_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                       "parameters": n_par}
         del tr
+        if rank == 0 and world == 1 and args.config == "cfg2":
+            # BASELINE.json configs[2] in miniature: fit a perturbed copy of the cfg3 scene (506,627 Gaussians, 1080p)
+            # to a render of the original with the reference's training step (train.py defaults: lr 0.003 x
+            # (10, 10, 1, 1, 1), exp decay, L1 + 0.1 SSIM, Adam(0.9, 0.99)); there is no dataset here, so the
+            # figure of merit is the PSNR against that synthetic ground truth before / after a short run
+            _, cam3, params3 = load("cfg3")
+            r3, st3 = sized_renderer(params3, cam3, training=False)
+            target3 = r3.forward(*params3, cam3)[0].clone()
+            del r3
+            g = torch.Generator(device=dev).manual_seed(7)
+            start3 = [t.clone() for t in params3]
+            start3[4] += 0.5 * torch.randn(start3[4].shape, device=dev, generator=g)   # colour logits
+            start3[3] += 0.3 * torch.randn(start3[3].shape, device=dev, generator=g)   # opacity logits
+            n_it = 300
+            tr3 = Trainer(start3, [cam3], [target3], TrainOptions(n_iters=n_it + 1, n_iters_warmup=30),
+                          max_pairs=int(st3.pairs * 1.2) + 4096)
+            psnr0 = Trainer.psnr(tr3.renderer.forward(*tr3.flat.params, cam3)[0], target3)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n_it):
+                tr3.train_step(i, 0)
+            torch.cuda.synchronize()
+            dt3 = time.perf_counter() - t0
+            psnr1 = Trainer.psnr(tr3.renderer.forward(*tr3.flat.params, cam3)[0], target3)
+            extra["cfg3_fit"] = {"n_gaussians": CONFIGS["cfg3"][0], "tile_pairs": st3.pairs, "iters": n_it,
+                                 "iters_per_s": round(n_it / dt3, 1), "psnr_before_dB": round(psnr0, 2),
+                                 "psnr_after_dB": round(psnr1, 2),
+                                 "final_loss": round(float(tr3._loss_for(H, W).values[0]), 5)}
+            del tr3, target3, start3, params3
         del rt, flat
         torch.cuda.empty_cache()
         if args.config != "cfg5":
