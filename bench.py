@@ -10,8 +10,11 @@ tile ranges -> 16x16 compositing -> clamp+crop) on synthetic Gaussians already r
 HBM.  Default workload: BASELINE.json configs[1] = 376,467 Gaussians at 1920x1080, no SH,
 forward render.  With N > 1 every rank renders its own view (yaw k x 5 deg) of a full replica of
 the scene -- the path shards by view and the forward render has no exchange step, so there is no
-data-path collective (weak scaling).  The training leg reported under "extra" (fwd + bwd of an L1
-loss) does have one: an RCCL all-reduce of the flat parameter-gradient bucket.
+data-path collective (weak scaling).  The training leg reported under "extra" is the reference's
+training step without densification (train.py:84-185: forward, L1 + 0.1 SSIM loss, backward, Adam)
+and does have one: an RCCL all-reduce (mean) of the flat parameter-gradient bucket before the fused
+Adam step.  "extra" also carries the loss / Adam kernel times, a 300-iteration fit of the cfg3 scene
+(it/s, PSNR before/after against a synthetic ground truth) and the cfg5 (2.4 M Gaussians) render FPS.
 
 Rank 0 prints ONE JSON line (driver contract) with "roofline" (dominant kernel =
 raster_forward_kernel, timed live with hipEvents on its own stream inside the library) and
