@@ -82,6 +82,21 @@ gs_adam_step = _sig("gs_adam_step", ci, vp, vp, vp, vp, i64, i32, C.POINTER(i64)
 gs_loss_workspace_bytes = _sig("gs_loss_workspace_bytes", sz, i32, i32)
 gs_loss_l1_ssim = _sig("gs_loss_l1_ssim", ci, vp, vp, i32, i32, f32, vp, vp, vp, sz, vp)
 
+
+
+class GsDensifyOpts(C.Structure):
+    """Mirror of ``struct gs_densify_opts``."""
+
+    _fields_ = [("taus", f32), ("delete_thresh", f32), ("grad_thresh", f32), ("clone_dt", f32),
+                ("scale_activation", i32), ("grad_aggregation", i32), ("use_clone", i32), ("use_split", i32),
+                ("color_dim", i32)]
+
+
+gs_densify_workspace_bytes = _sig("gs_densify_workspace_bytes", sz, i64)
+gs_densify_classify = _sig("gs_densify_classify", ci, vp, vp, vp, i64, C.POINTER(GsDensifyOpts), vp, vp, sz, vp)
+gs_densify_apply = _sig("gs_densify_apply", ci, vp, vp, vp, vp, vp, vp, i64, C.POINTER(GsDensifyOpts), vp, vp, i64,
+                        vp, vp, vp, vp, vp, i64, vp, vp, sz, vp)
+
 # Every symbol include/gs_abi.h declares (checked by tests/test_abi.py without a GPU).
 EXPORTS = [
     "gs_last_error", "gs_abi_version", "gs_culling", "gs_world2camera", "gs_world2camera_backward",
@@ -90,6 +105,7 @@ EXPORTS = [
     "gs_sort_pairs_tmp_bytes", "gs_sort_pairs", "gs_sort_pairs_bits", "gs_frame_workspace_bytes", "gs_frame_forward",
     "gs_frame_stats_async", "gs_frame_debug_views", "gs_frame_backward", "gs_frame_forward_profile",
     "gs_frame_backward_profile", "gs_adam_step", "gs_loss_workspace_bytes", "gs_loss_l1_ssim",
+    "gs_densify_workspace_bytes", "gs_densify_classify", "gs_densify_apply",
 ]
 
 

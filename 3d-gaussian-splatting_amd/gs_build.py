@@ -29,6 +29,7 @@ SOURCES = {
     "gs_frame.hip": [],
     "adam.hip": ["-ffp-contract=off"],  # same roundings as torch's unfused elementwise kernels
     "loss.hip": [],
+    "densify.hip": ["-ffp-contract=off"],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall",
           "-Wno-unused-function", "-munsafe-fp-atomics",

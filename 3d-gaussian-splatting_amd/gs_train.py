@@ -12,7 +12,8 @@ with three differences that matter on MI355X:
     densification statistic ``accum_max_grad`` of train.py:145-154 while it reads the gradient;
   * nothing in the step synchronises with the host: the reference calls ``.item()`` three times per
     iteration (train.py:119-121); here the losses stay on the device until somebody reads them.
-Densification (``adaptive_control``), opacity reset and data loading are out of scope.
+Densification (``Trainer(..., densify=True)``: ``gs_densify.adaptive_control`` / ``reset_opa`` on the reference's
+schedule) is SURVEY 8f-2; data loading and the viewer stay out of scope (8f-3, 8f-4).
 """
 from __future__ import annotations
 
@@ -45,6 +46,20 @@ class TrainOptions:
     grad_accum_method: str = "max"  # "max" | "mean"
     betas: tuple = (0.9, 0.99)
     eps: float = 1e-8
+    # densification (train.py:302, 321-324, 340-347); off unless Trainer(..., densify=True)
+    n_adaptive_control: int = 100
+    adaptive_control_start_iter: int = 600  # the literal `i_iter > 600` of train.py:88-90
+    adaptive_control_end_iter: int = 1000000000
+    grad_accum_iters: int = 50
+    n_opa_reset: int = 10000000
+    reset_interval: int = 500
+    split_thresh: float = 0.05
+    delete_thresh: float = 1.5
+    grad_thresh: float = 0.0002
+    grad_aggregation: str = "max"
+    use_clone: int = 0
+    use_split: int = 1
+    clone_dt: float = 0.01
 
 
 def lr_lambdas(opt: TrainOptions) -> List[Callable[[int], float]]:
@@ -144,16 +159,29 @@ class Trainer:
 
     def __init__(self, params: Sequence[torch.Tensor], cameras, targets: Sequence[torch.Tensor],
                  opt: Optional[TrainOptions] = None, world_size: int = 1, max_pairs: int = 1 << 20,
-                 scale_activation: str = "abs"):
+                 scale_activation: str = "abs", densify: bool = False, generator: Optional[torch.Generator] = None):
         self.opt = opt or TrainOptions()
-        self.flat = FlatGaussianParams(params, world_size=world_size)
+        self.world_size = int(world_size)
+        self.scale_activation = scale_activation
+        self.densify, self.generator = bool(densify), generator
         self.cameras, self.targets = list(cameras), list(targets)
-        dev = self.flat.flat_param.device
+        dev = params[0].device
         self.renderer = FrameRenderer(dev, max_pairs=max_pairs, training=True, scale_activation=scale_activation)
         self._lambdas, self._base = lr_lambdas(self.opt), base_lrs(self.opt)
-        self.optimizer = FusedAdam(self.flat, [b * f(0) for b, f in zip(self._base, self._lambdas)],
-                                   betas=self.opt.betas, eps=self.opt.eps, grad_stat=self.opt.grad_accum_method)
         self._loss = {}
+        self._bind(params, 0)
+
+    def _bind(self, params: Sequence[torch.Tensor], i_iter: int):
+        """(Re)creates the flat bucket and the optimizer for a (new) Gaussian set: train.py:59-67 / :169-179 --
+        the reference also starts a fresh torch.optim.Adam after every adaptive_control."""
+        self.flat = FlatGaussianParams(params, world_size=self.world_size)
+        self.optimizer = FusedAdam(self.flat, [b * f(i_iter) for b, f in zip(self._base, self._lambdas)],
+                                   betas=self.opt.betas, eps=self.opt.eps, grad_stat=self.opt.grad_accum_method)
+        self.grad_counter = None  # "mean" accumulation only: per-Gaussian count of views that saw it (train.py:150)
+
+    @property
+    def n_gaussians(self) -> int:
+        return int(self.flat.params[0].shape[0])
 
     def _loss_for(self, h: int, w: int) -> ImageLoss:
         key = (h, w)
@@ -163,16 +191,51 @@ class Trainer:
 
     def train_step(self, i_iter: int, camera_id: int) -> torch.Tensor:
         """Returns the device tensor (loss, l1, ssim) of this step (no host synchronisation)."""
+        o = self.opt
+        # schedule flags, train.py:86-91
+        in_reset = i_iter >= o.n_opa_reset and i_iter % o.n_opa_reset < o.reset_interval
+        past = i_iter > o.adaptive_control_start_iter
+        only_delete = past and i_iter % o.n_adaptive_control == 0
+        control = only_delete and i_iter < o.adaptive_control_end_iter
+        accum_start = past and (i_iter + o.grad_accum_iters - 1) % o.n_adaptive_control == 0
         cam, target = self.cameras[camera_id], self.targets[camera_id]
         image, _ = self.renderer.forward(*self.flat.params, cam)
         loss = self._loss_for(image.shape[0], image.shape[1])
         grad_image = loss(image, target)
         self.renderer.backward(grad_image, out=self.flat.grads)
         self.flat.all_reduce_grads()
-        self.optimizer.step()
+        if self.densify and accum_start:  # train.py:141-142 (before this step's gradient is accumulated)
+            self.optimizer.clear_grad_stat()
+            self.grad_counter = None
+        self.optimizer.step()  # also: accum_max_grad = max(|pos.grad|, accum) or += |pos.grad| (train.py:144-153)
+        if self.densify and o.grad_accum_method == "mean":
+            seen = (self.renderer.debug_views()["rec_geom"][:, 2] != 0).to(torch.float32)  # culling_mask
+            self.grad_counter = seen if self.grad_counter is None else self.grad_counter + seen
+        if self.densify and (control or only_delete):
+            self.adaptive_control(i_iter, densify=control and not in_reset)
         # train.py:184-185: the learning rates of the NEXT step
         self.optimizer.set_lrs([f(i_iter) * b for f, b in zip(self._lambdas, self._base)])
+        if self.densify and i_iter % o.n_opa_reset == 0 and i_iter > 0:  # train.py:189-190
+            from gs_densify import reset_opa
+
+            reset_opa(self.flat.params[3])
         return loss.values
+
+    def adaptive_control(self, i_iter: int, densify: bool = True):
+        """train.py:156-180: prune (+ clone / split when ``densify``), then a fresh optimizer."""
+        from gs_densify import adaptive_control
+
+        o = self.opt
+        counter = 1.0 if o.grad_accum_method == "max" or self.grad_counter is None else self.grad_counter
+        stat = self.optimizer.accum_grad / (counter + 1e-3 if isinstance(counter, float)
+                                            else (counter + 1e-3).unsqueeze(-1))  # train.py:160
+        new, counts = adaptive_control(self.flat.params, stat.contiguous(), taus=o.split_thresh,
+                                       delete_thresh=o.delete_thresh, scale_activation=self.scale_activation,
+                                       grad_thresh=o.grad_thresh, grad_aggregation=o.grad_aggregation,
+                                       use_clone=bool(o.use_clone) and densify, use_split=bool(o.use_split) and densify,
+                                       clone_dt=o.clone_dt, generator=self.generator)
+        self._bind(new, i_iter)
+        return counts
 
     @staticmethod
     def psnr(image: torch.Tensor, target: torch.Tensor) -> float:

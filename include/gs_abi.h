@@ -250,6 +250,37 @@ int gs_loss_l1_ssim(const float *pred, const float *target, int32_t H, int32_t W
                     float *grad, float *loss_out, void *workspace, size_t workspace_bytes,
                     gs_stream_t stream);
 
+/* ---- densification: Gaussian3ds.adaptive_control (splatter.py:122-228) ----
+ * Two calls because the number of split Gaussians decides how many standard-normal draws the split
+ * samples consume (the reference's MultivariateNormal.sample() draws them after its masks are known):
+ *   gs_densify_classify: classes + counts_dev[4] = (kept, cloned, split, kept + cloned + split);
+ *   gs_densify_apply   : writes the new Gaussian set in the reference's order -- kept ones (split ones
+ *                        with scale / 1.6 (abs) or - log 1.6 (exp) and the first sample), clones
+ *                        (pos - grad * clone_dt), second split samples.  eps1 / eps2: [n_eps, 3]
+ *                        standard normals, n_eps >= split count; outputs hold `capacity` Gaussians.
+ *                        Nothing is written if the total exceeds `capacity` or the split count n_eps.
+ * A sample is pos + chol(R S^2 R^T) eps (utils.py:391-402).  grad: [N, 3] accumulated |grad_pos| statistic
+ * (train.py:160).  All arrays fp32, rgb [N, color_dim]; the same workspace must be passed to both calls. */
+typedef struct gs_densify_opts {
+    float taus;              /* --split_thresh: ||act(scale)|| above which a Gaussian is split, else cloned */
+    float delete_thresh;     /* --delete_thresh: Gaussians with ||act(scale)|| >= this are pruned            */
+    float grad_thresh;       /* --grad_thresh                                                                 */
+    float clone_dt;          /* --clone_dt                                                                    */
+    int32_t scale_activation;/* 0 = abs, 1 = exp                                                              */
+    int32_t grad_aggregation;/* 0 = max over xyz, 1 = mean                                                    */
+    int32_t use_clone, use_split;
+    int32_t color_dim;       /* 3 or 27                                                                       */
+} gs_densify_opts;
+size_t gs_densify_workspace_bytes(int64_t N);
+int gs_densify_classify(const float *scale, const float *opa, const float *grad, int64_t N,
+                        const gs_densify_opts *opts, int64_t *counts_dev, void *workspace,
+                        size_t workspace_bytes, gs_stream_t stream);
+int gs_densify_apply(const float *pos, const float *quat, const float *scale, const float *opa,
+                     const float *rgb, const float *grad, int64_t N, const gs_densify_opts *opts,
+                     const float *eps1, const float *eps2, int64_t n_eps, float *out_pos, float *out_quat,
+                     float *out_scale, float *out_opa, float *out_rgb, int64_t capacity,
+                     const int64_t *counts_dev, void *workspace, size_t workspace_bytes, gs_stream_t stream);
+
 #if defined(__GNUC__)
 #pragma GCC visibility pop
 #endif

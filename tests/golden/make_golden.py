@@ -145,6 +145,64 @@ def host_geometry():
     print("host_geometry ok")
 
 
+def densify():
+    """The reference's Gaussian3ds.adaptive_control (splatter.py:122-228) run as is on the CPU."""
+    import torch
+
+    class _Anything(types.ModuleType):
+        def __getattr__(self, k):
+            return type(k, (), {})
+
+    for m in ("kornia", "cv2", "pykdtree", "pykdtree.kdtree", "gaussian"):
+        sys.modules.setdefault(m, _Anything(m))
+    sys.modules["kornia"].create_meshgrid = lambda *a, **k: None
+    sys.modules["pykdtree.kdtree"].KDTree = object
+    if "/root/reference" not in sys.path:
+        sys.path.insert(0, "/root/reference")
+    for m in ("utils", "renderer", "splatter", "transforms"):
+        sys.modules.pop(m, None)
+    import contextlib
+    import io
+
+    import splatter as ref_splatter
+
+    out = {}
+    cases = [("abs", "max", True, True), ("abs", "mean", False, True), ("exp", "max", True, True),
+             ("abs", "max", True, False)]
+    for ci, (act, agg, use_clone, use_split) in enumerate(cases):
+        rng = np.random.default_rng(900 + ci)
+        n = 600
+        pos = rng.normal(size=(n, 3)).astype(np.float32) * 2
+        quat = rng.normal(size=(n, 4)).astype(np.float32)
+        scale = (rng.uniform(0.005, 0.12, size=(n, 3)) * rng.choice([-1, 1], size=(n, 3))).astype(np.float32)
+        if act == "exp":
+            scale = np.log(np.abs(scale)).astype(np.float32)
+        opa = rng.normal(-2.0, 2.5, size=n).astype(np.float32)
+        rgb = rng.normal(size=(n, 3)).astype(np.float32)
+        grad = (rng.normal(size=(n, 3)) * 3e-4).astype(np.float32)
+        g3 = ref_splatter.Gaussian3ds(*(torch.from_numpy(a.copy()) for a in (pos, rgb, opa)),
+                                      quat=torch.from_numpy(quat.copy()), scale=torch.from_numpy(scale.copy()),
+                                      init_values=True)
+        seed = 4242 + ci
+        torch.manual_seed(seed)
+        with contextlib.redirect_stdout(io.StringIO()):
+            g3.adaptive_control(torch.from_numpy(grad.copy()), taus=0.05, delete_thresh=0.17, scale_activation=act,
+                                grad_thresh=0.0002, grad_aggregation=agg, use_clone=use_clone, use_split=use_split,
+                                clone_dt=0.01)
+        # the normal draws MultivariateNormal.sample() consumed: two (n_split, 3) blocks from the same seed
+        torch.manual_seed(seed)
+        eps = [torch.normal(torch.zeros(n, 3), torch.ones(n, 3)) for _ in range(2)]  # upper bound on n_split rows
+        out.update({f"c{ci}_cfg": np.array([act, agg, str(int(use_clone)), str(int(use_split))]),
+                    f"c{ci}_seed": seed, f"c{ci}_pos": pos, f"c{ci}_quat": quat, f"c{ci}_scale": scale,
+                    f"c{ci}_opa": opa, f"c{ci}_rgb": rgb, f"c{ci}_grad": grad,
+                    f"c{ci}_out_pos": g3.pos.detach().numpy(), f"c{ci}_out_quat": g3.quat.detach().numpy(),
+                    f"c{ci}_out_scale": g3.scale.detach().numpy(), f"c{ci}_out_opa": g3.opa.detach().numpy(),
+                    f"c{ci}_out_rgb": g3.rgb.detach().numpy()})
+        print("densify case", ci, act, agg, "N", n, "->", len(g3.pos))
+    out["n_cases"] = len(cases)
+    np.savez_compressed(os.path.join(HERE, "densify.npz"), **out)
+
+
 if __name__ == "__main__":
     assert os.path.isdir("/root/reference"), "needs the reference checkout"
     oracle.build()
@@ -156,3 +214,4 @@ if __name__ == "__main__":
     # schedule exposes deterministically (measured: 5 tiles of 1450 -> max image error 0.47).
     kernels_case("dense_fwd", 4500, 64, 48, seed=22, use_sh=False, opa_shift=1.5, with_backward=False)
     host_geometry()
+    densify()

@@ -139,3 +139,39 @@ def test_trainer_improves_psnr(gpu):
     assert losses[0, 0] == pytest.approx(losses[1, 0])  # step 0 runs with lr = lambda(0) = 0 (train.py:59-65)
     assert losses[-1, 0] < 0.6 * losses[1, 0]
     assert psnr1 > psnr0 + 3.0, (psnr0, psnr1)
+
+
+def test_trainer_with_densification(gpu):
+    """The reference's schedule (train.py:86-91, 141-190) on a small scene: the statistic is cleared
+    grad_accum_iters before every adaptive_control, N changes there, Adam restarts, training stays finite."""
+    from gs_frame import FrameRenderer
+    from gs_scene import make_camera, make_scene
+    from gs_train import TrainOptions, Trainer
+
+    W, H = 128, 96
+    scene, cam = make_scene(2500, W, H, seed=4), make_camera(W, H)
+    gt = to_torch(scene, gpu)
+    target = FrameRenderer(gpu, max_pairs=1 << 16).forward(*gt, cam)[0].clone()
+    start = [t.clone() for t in gt]
+    start[4] = start[4] + 0.8 * torch.randn(start[4].shape, device=gpu, generator=torch.Generator(gpu).manual_seed(0))
+    opt = TrainOptions(n_iters=400, n_iters_warmup=5, adaptive_control_start_iter=20, n_adaptive_control=25,
+                       grad_accum_iters=10, split_thresh=0.02, delete_thresh=1.5, grad_thresh=1e-7, use_clone=1)
+    tr = Trainer(start, [cam], [target], opt, max_pairs=1 << 16, densify=True,
+                 generator=torch.Generator(gpu).manual_seed(1))
+    sizes, losses = [], []
+    for it in range(80):
+        if it == 41:  # cleared at (it + 10 - 1) % 25 == 0, i.e. it = 41 (and 66)
+            assert float(tr.optimizer.accum_grad.abs().max()) > 0
+        losses.append(tr.train_step(it, 0).clone())
+        sizes.append(tr.n_gaussians)
+        if it == 41:
+            stat = tr.optimizer.accum_grad.clone()  # holds exactly this step's |grad_pos| after the clear
+            assert torch.equal(stat, tr.flat.grads[0].abs())
+    losses = torch.stack(losses).cpu().numpy()
+    assert np.isfinite(losses).all()
+    changes = [i for i in range(1, 80) if sizes[i] != sizes[i - 1]]
+    assert changes and set(changes) <= {25, 50, 75}, (changes, sizes[::5])
+    assert sizes[-1] > sizes[0]                       # grad_thresh ~ 0: everything seen is cloned or split
+    assert tr.optimizer.step_count == 80 - 1 - 75     # a fresh Adam after the last adaptive_control at it = 75
+    img, _ = tr.renderer.forward(*tr.flat.params, cam)
+    assert torch.isfinite(img).all()
