@@ -306,9 +306,10 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
                 const int ox = (int)id_x - G.crop_left, oy = (int)id_y - G.crop_top;
                 if (ox >= 0 && ox < G.width && oy >= 0 && oy < G.height) {
                     float *o = out_image + ((size_t)oy * G.width + ox) * 3;
-                    o[0] = fminf(fmaxf(o0, 0.f), 1.f);
-                    o[1] = fminf(fmaxf(o1, 0.f), 1.f);
-                    o[2] = fminf(fmaxf(o2, 0.f), 1.f);
+                    // torch.clamp semantics: NaN stays NaN (fminf / fmaxf would turn it into 0)
+                    o[0] = o0 > 1.f ? 1.f : (o0 < 0.f ? 0.f : o0);
+                    o[1] = o1 > 1.f ? 1.f : (o1 < 0.f ? 0.f : o1);
+                    o[2] = o2 > 1.f ? 1.f : (o2 < 0.f ? 0.f : o2);
                 }
             }
         }

@@ -252,3 +252,44 @@ def test_full_size_backward_properties(gpu):
         assert float((d > 0).float().mean()) < 1e-3, int((d > 0).sum())
         assert float(a[~vis].abs().max()) == 0.0
         assert float(a[vis].abs().max()) > 0.0
+
+
+@pytest.mark.parametrize("kind", ["nan_pos", "inf_pos", "zero_quat", "nan_scale", "huge_scale", "zero_scale", "neg_z"])
+def test_frame_degenerate_inputs(gpu, kind):
+    """Non-finite / degenerate parameters must neither hang nor corrupt anything else: the pair list still
+    equals the oracle's (NaN comparisons behave like the reference's) and so does the image.  (A NaN opacity
+    or colour is not covered: it poisons every pixel of the tiles it touches here, only the still-live
+    pixels in the reference, because finished pixels are masked by a multiplication instead of a branch.)"""
+    scene, cam = case(6_000, 160, 112, seed=3)
+    idx = np.random.default_rng(1).choice(6_000, 60, replace=False)
+    if kind == "nan_pos":
+        scene.pos[idx, 0] = np.nan
+    elif kind == "inf_pos":
+        scene.pos[idx, 1] = np.inf
+    elif kind == "zero_quat":
+        scene.quat[idx] = 0
+    elif kind == "nan_scale":
+        scene.scale[idx, 2] = np.nan
+    elif kind == "huge_scale":
+        scene.scale[idx] = 1e6
+    elif kind == "zero_scale":
+        scene.scale[idx] = 0
+    elif kind == "neg_z":
+        scene.pos[idx, 2] = -1
+    with np.errstate(all="ignore"):
+        of = OracleFrame(scene, cam)
+    r = FrameRenderer(gpu, max_pairs=1 << 18, training=True)
+    params = to_torch(scene, gpu, requires_grad=True)
+    img = r.render(*params, cam)
+    st = r.stats()
+    assert st.overflow == 0 and st.pairs == len(of.ids)
+    v = r.debug_views()
+    assert np.array_equal(v["sorted_ids"].cpu().numpy(), of.ids)
+    got = img.detach().cpu().numpy()
+    finite = np.isfinite(of.image)
+    assert np.array_equal(np.isfinite(got), finite)
+    assert np.abs(got[finite] - of.image[finite]).max() < IMG_ATOL
+    img.sum().backward()  # must terminate; gradients of untouched Gaussians stay finite
+    torch.cuda.synchronize()
+    if kind in ("huge_scale", "zero_scale", "neg_z"):
+        assert all(bool(torch.isfinite(t.grad).all()) for t in params)
