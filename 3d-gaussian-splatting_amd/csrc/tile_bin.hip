@@ -26,7 +26,9 @@
 
 namespace {
 
+#ifndef BIN_THREADS
 #define BIN_THREADS 1024
+#endif
 #define BIN_SOLO 16  // rectangles up to this many tiles are walked by their own lane
 
 // Walks the rectangle of every Gaussian of this workgroup's slice and calls fn(tile, gaussian, depth_bits).
