@@ -237,6 +237,58 @@ class Trainer:
         self._bind(new, i_iter)
         return counts
 
+    # ------------------------------------------------------------------ evaluation / viewer hook
+    @torch.no_grad()
+    def test(self, camera_id, extrinsics=None, intrinsics=None) -> dict:
+        """``Trainer.test`` of the reference (train.py:256-281), which is also what its viser GUI calls per
+        frame (visergui.py:137-149): ``test(None, extrinsics={"rot", "tran"}, intrinsics={"width", "height",
+        "focal_x", "focal_y"})`` renders an arbitrary world->camera pose at an arbitrary resolution (the tile
+        grid is rebuilt, sizes need not be multiples of 16); ``test(camera_id)`` renders a training / test
+        camera and adds ``psnr``, ``ssim`` and ``render_time`` (seconds, device time) against its target."""
+        import numpy as np
+
+        from gs_scene import Camera
+
+        if extrinsics is not None and intrinsics is not None:
+            to_np = lambda a: (a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)).astype(np.float32)  # noqa: E731
+            cam = Camera(int(intrinsics["width"]), int(intrinsics["height"]), float(intrinsics["focal_x"]),
+                         float(intrinsics["focal_y"]), to_np(extrinsics["rot"]).reshape(3, 3),
+                         to_np(extrinsics["tran"]).reshape(3), near=getattr(self.cameras[0], "near", 0.3) if self.cameras else 0.3)
+        elif camera_id is not None:
+            cam = self.cameras[camera_id]
+        else:
+            raise RuntimeError("test() needs a camera_id or extrinsics + intrinsics")
+        if getattr(self, "_eval_renderer", None) is None:
+            self._eval_renderer = FrameRenderer(self.flat.flat_param.device, max_pairs=self.renderer.max_pairs,
+                                                training=False, scale_activation=self.scale_activation)
+        tic, toc = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        tic.record()
+        image, _ = self._eval_renderer.forward(*self.flat.params, cam)
+        toc.record()
+        out = {"image": image}
+        if camera_id is not None:
+            target = self.targets[camera_id]
+            toc.synchronize()
+            out["render_time"] = tic.elapsed_time(toc) / 1000
+            out["psnr"] = self.psnr(image, target)
+            h, w = image.shape[:2]
+            if h > 10 and w > 10:
+                probe = ImageLoss(h, w, 1.0, image.device)  # weight 1: values = (1 - ssim, l1, ssim)
+                probe(image, target)
+                out["ssim"] = float(probe.values[2])
+        return out
+
+    # ------------------------------------------------------------------ checkpoints (train.py:283-291, splatter.py:417-424)
+    def save_checkpoint(self, path: str):
+        """The reference's ``ckpt.pth``: a dict of the five raw parameter tensors."""
+        pos, quat, scale, opa, rgb = (t.detach().clone() for t in self.flat.params)
+        torch.save({"pos": pos, "opa": opa, "rgb": rgb, "quat": quat, "scale": scale}, path)
+
+    def load_checkpoint(self, path: str, i_iter: int = 0):
+        ck = torch.load(path, map_location=self.flat.flat_param.device)
+        params = [ck[k].detach().to(torch.float32).contiguous() for k in ("pos", "quat", "scale", "opa", "rgb")]
+        self._bind(params, i_iter)
+
     @staticmethod
     def psnr(image: torch.Tensor, target: torch.Tensor) -> float:
         """torchmetrics PeakSignalNoiseRatio() with its default data_range = max(target) - min(target)."""

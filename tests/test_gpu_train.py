@@ -175,3 +175,33 @@ def test_trainer_with_densification(gpu):
     assert tr.optimizer.step_count == 80 - 1 - 75     # a fresh Adam after the last adaptive_control at it = 75
     img, _ = tr.renderer.forward(*tr.flat.params, cam)
     assert torch.isfinite(img).all()
+
+
+def test_viewer_hook_and_checkpoint(gpu, tmp_path):
+    """Trainer.test(None, extrinsics, intrinsics) -- the call the reference's viser GUI makes per frame
+    (visergui.py:137-149) -- at a size that is not a multiple of 16, against the oracle; test(camera_id)
+    metrics; the reference's checkpoint dict round trip."""
+    from gs_scene import make_camera, make_scene
+    from gs_testutil import OracleFrame
+    from gs_train import Trainer
+
+    W, H = 333, 201
+    scene, cam = make_scene(8000, W, H, seed=12), make_camera(W, H, yaw_deg=3.0)
+    params = to_torch(scene, gpu)
+    of = OracleFrame(scene, cam)
+    target = torch.from_numpy(of.image).to(gpu)
+    tr = Trainer(params, [cam], [target], max_pairs=1 << 17)
+    out = tr.test(None, extrinsics={"rot": torch.from_numpy(cam.rot), "tran": cam.tran},
+                  intrinsics={"width": W, "height": H, "focal_x": cam.focal_x, "focal_y": cam.focal_y})
+    assert set(out) == {"image"} and tuple(out["image"].shape) == (H, W, 3)
+    assert np.abs(out["image"].cpu().numpy() - of.image).max() < 5e-5
+    m = tr.test(0)
+    assert m["psnr"] > 60 and m["ssim"] > 0.9999 and m["render_time"] > 0
+    path = str(tmp_path / "ckpt.pth")
+    tr.save_checkpoint(path)
+    ck = torch.load(path)
+    assert set(ck) == {"pos", "opa", "rgb", "quat", "scale"}  # train.py:283-291
+    tr2 = Trainer([torch.zeros_like(p) for p in params], [cam], [target], max_pairs=1 << 17)
+    tr2.load_checkpoint(path)
+    assert all(torch.equal(a, b) for a, b in zip(tr2.flat.params, tr.flat.params))
+    assert torch.equal(tr2.test(0)["image"], m["image"])
