@@ -1,0 +1,69 @@
+"""BASELINE.json's metric: render FPS and training iterations/s at 1080p as a function of the number of
+Gaussians (synthetic scenes of gs_scene.py, seed 2023, one MI355X).  Prints one JSON object per size."""
+import json
+import sys
+import time
+
+sys.path[:0] = ['/root/repo', '/root/repo/3d-gaussian-splatting_amd']
+import torch  # noqa: E402
+
+from gs_frame import FrameRenderer  # noqa: E402
+from gs_scene import make_camera, make_scene  # noqa: E402
+from gs_train import TrainOptions, Trainer  # noqa: E402
+
+dev = torch.device('cuda:0')
+W, H = 1920, 1080
+cam = make_camera(W, H)
+sizes = [int(a) for a in sys.argv[1:]] or [10_000, 100_000, 376_467, 506_627, 1_000_000, 2_400_000]
+for n in sizes:
+    scene = make_scene(n, W, H, seed=2023)
+    params = [torch.from_numpy(a).to(dev) for a in (scene.pos, scene.quat, scene.scale, scene.opa, scene.rgb)]
+
+    def sized(training):
+        r = FrameRenderer(dev, max_pairs=1 << 20, training=training, auto_grow=True)
+        r.forward(*params, cam)
+        st = r.stats()
+        r.max_pairs = int(st.pairs * 1.1) + 4096
+        r.auto_grow = False
+        r.forward(*params, cam)
+        return r, st
+
+    def timeit(fn, steps, warm=10):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    r, st = sized(False)
+    steps = 200 if n <= 600_000 else 80
+    t1 = timeit(lambda: r.forward(*params, cam), steps)
+    rs = [r] + [sized(False)[0] for _ in range(2)]
+    streams = [torch.cuda.Stream(device=dev) for _ in rs]
+    k = [0]
+
+    def pipelined():
+        i = k[0] % 3
+        k[0] += 1
+        with torch.cuda.stream(streams[i]):
+            rs[i].forward(*params, cam)
+
+    t3 = timeit(pipelined, steps)
+    del rs
+    tr = Trainer(params, [cam], [torch.rand(H, W, 3, device=dev)], TrainOptions(), max_pairs=int(st.pairs * 1.1) + 4096)
+    tr.renderer.auto_grow = False
+    it = [0]
+
+    def step():
+        tr.train_step(it[0], 0)
+        it[0] += 1
+
+    tt = timeit(step, max(steps // 4, 20), 5)
+    print(json.dumps({"n_gaussians": n, "visible": st.visible, "tile_pairs": st.pairs,
+                      "render_fps_1_stream": round(1 / t1, 1), "render_fps_3_streams": round(1 / t3, 1),
+                      "train_iters_per_s": round(1 / tt, 1), "train_ms_per_iter": round(tt * 1e3, 3)}), flush=True)
+    del tr, r, params
+    torch.cuda.empty_cache()
