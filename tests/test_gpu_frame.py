@@ -80,6 +80,13 @@ def test_frame_forward_more_tiles_than_lds_counters(gpu):
     assert r.stats().pairs == len(of.ids) > 0
 
 
+def test_frame_forward_4k_uses_lds_counters(gpu):
+    """3840 x 2160 = 32,400 tiles: just inside the 32,768 LDS counters (127 KiB of dynamic LDS per workgroup)."""
+    scene, cam = case(6_000, 3840, 2160, seed=19)
+    of, r, _ = check_forward(gpu, scene, cam, sort_mode=2)
+    assert r.stats().pairs == len(of.ids) > 0
+
+
 def test_frame_forward_sh(gpu):
     check_forward(gpu, *case(8_000, 160, 96, use_sh=True))
 
