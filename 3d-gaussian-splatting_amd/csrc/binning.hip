@@ -4,8 +4,9 @@
 // gather_gaussians (gaussian.cu:337-381), which build and compact a fixed-capacity
 // T x MAXP table with atomics.
 //
-// Frame path: the table is gone.  Stage S1 (cull_project.hip) already counted the tiles each
-// Gaussian touches and left one partial sum per 256-Gaussian block; here
+// Frame path, sort_modes 0 and 1 (the default mode 2 bins in tile_bin.hip instead): the table is gone.
+// Stage S1 (cull_project.hip) already counted the tiles each Gaussian touches and left one partial
+// sum per 256-Gaussian block; here
 //   S3  scan_block_sums_kernel : exclusive scan of the block sums, total M -> device counter
 //   S4  emit_pairs_kernel      : block-local scan + emission of (tile<<32 | depth_bits, id)
 //   S6  tile_ranges_kernel     : [start,end) of every tile in the sorted key array

@@ -1,11 +1,14 @@
 // gs_frame.hip -- host orchestration of the fused frame path + error plumbing.
 //
 // gs_frame_forward issues, on ONE stream and with NO host synchronisation:
-//   memset(counters) -> S1 project+count -> S3 scan block sums -> S4 emit keys -> S5 radix sort
-//   (3 launches x ceil((32+tile_bits)/8) passes) -> S6 tile ranges -> S7 raster forward.
+//   sort_mode 2 (default): S1 project+count -> bin count -> column scan -> bin scatter (tile ranges,
+//       counters) -> per-tile sort -> raster forward: six launches, no memset;
+//   sort_modes 0 / 1: memset(counters, ranges) -> S1 -> scan block sums -> emit keys -> LSD radix passes
+//       (3 launches per 8 bits of the key: all of it, or the tile bits only) -> tile ranges
+//       [-> per-tile sort] -> raster forward.
 // The number of (tile, Gaussian) pairs M lives in device memory only; every later stage is
-// launched with a capacity-sized grid and idles past M.  The reference needs >= 8 blocking
-// host syncs for the same work.
+// launched with a capacity-sized grid (or reads the tile ranges) and idles past M.  The reference
+// needs >= 8 blocking host syncs for the same work.
 #include <stdarg.h>
 #include <string.h>
 
