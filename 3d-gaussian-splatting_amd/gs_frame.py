@@ -47,7 +47,15 @@ class FrameRenderer:
         self.training = bool(training)
         self.thresh = float(thresh)
         self.scale_activation = SCALE_ACT[scale_activation]
+        # True: check the pair count after every frame (one host synchronisation per frame, never a truncated
+        # frame); "async": copy the counters to pinned memory after every frame and look at them when the NEXT
+        # frame is issued, without waiting -- no synchronisation in steady state, the workspace grows with 25 %
+        # head room as soon as the copy of an overflowed frame has landed (that one frame was rendered empty /
+        # truncated); False: never check.
         self.auto_grow = auto_grow
+        self._async_host = torch.zeros(4, dtype=torch.int64).pin_memory()
+        self._async_event: Optional[torch.cuda.Event] = None
+        self.headroom = 1.25
         # 0: LSD radix on 64-bit keys, 1: tile-bit radix + per-tile LDS sort, 2: LDS counting sort by tile
         # + per-tile LDS sort (all three give the same list)
         self.sort_mode = int(sort_mode)
@@ -119,6 +127,13 @@ class FrameRenderer:
         """Raw parameters -> (image [H,W,3] clamped+cropped, padded raw image or None)."""
         training = self.training if training is None else training
         stream = torch.cuda.current_stream().cuda_stream
+        if self.auto_grow == "async" and self._async_event is not None and self._async_event.query():
+            v, m, o, b = (int(x) for x in self._async_host.tolist())  # counters of an earlier frame, already on the host
+            self._async_event = None
+            if o:
+                self.max_pairs = int(o * self.headroom) + 1024
+            elif m * self.headroom > self.max_pairs:  # close to the limit: grow before it overflows
+                self.max_pairs = int(m * self.headroom * self.headroom) + 1024
         while True:
             f = self._describe(pos, quat, scale, opa, rgb, camera, training)
             g = self._grid
@@ -130,6 +145,13 @@ class FrameRenderer:
             _lib.check(_lib.gs_frame_forward(C.byref(f), stream), "gs_frame_forward")
             self._frame = f
             self._keep = (pos, quat, scale, opa, rgb, image, padded)
+            if self.auto_grow == "async":
+                if self._async_event is None:  # one copy in flight at a time
+                    _lib.check(_lib.gs_frame_stats_async(C.byref(f), self._async_host.data_ptr(), stream),
+                               "gs_frame_stats_async")
+                    self._async_event = torch.cuda.Event()
+                    self._async_event.record(torch.cuda.current_stream())
+                break
             if not self.auto_grow:
                 break
             st = self.stats()

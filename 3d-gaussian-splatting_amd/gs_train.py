@@ -166,7 +166,10 @@ class Trainer:
         self.densify, self.generator = bool(densify), generator
         self.cameras, self.targets = list(cameras), list(targets)
         dev = params[0].device
-        self.renderer = FrameRenderer(dev, max_pairs=max_pairs, training=True, scale_activation=scale_activation)
+        # "async": the pair capacity is checked from a pinned-memory copy one frame late -- no host
+        # synchronisation in the training loop (the reference synchronises >= 8 times per forward)
+        self.renderer = FrameRenderer(dev, max_pairs=max_pairs, training=True, scale_activation=scale_activation,
+                                      auto_grow="async")
         self._lambdas, self._base = lr_lambdas(self.opt), base_lrs(self.opt)
         self._loss = {}
         self._bind(params, 0)

@@ -300,3 +300,19 @@ def test_frame_degenerate_inputs(gpu, kind):
     torch.cuda.synchronize()
     if kind in ("huge_scale", "zero_scale", "neg_z"):
         assert all(bool(torch.isfinite(t.grad).all()) for t in params)
+
+
+def test_frame_async_growth(gpu):
+    """auto_grow="async": no synchronisation per frame; an overflowed frame is reported one frame late,
+    the workspace grows, and the following frames are complete."""
+    scene, cam = case(10_000, 128, 128)
+    of = OracleFrame(scene, cam)
+    params = to_torch(scene, gpu)
+    r = FrameRenderer(gpu, max_pairs=len(of.ids) // 3, auto_grow="async")
+    imgs = []
+    for _ in range(4):
+        imgs.append(r.forward(*params, cam)[0].clone())
+        torch.cuda.synchronize()  # only so that the test is deterministic: the copy has landed before the next frame
+    assert r.max_pairs >= len(of.ids)
+    assert np.abs(imgs[-1].cpu().numpy() - of.image).max() < IMG_ATOL
+    assert float(imgs[0].abs().max()) == 0.0  # sort_mode 2 renders an overflowed frame empty instead of truncated
