@@ -203,6 +203,83 @@ def densify():
     np.savez_compressed(os.path.join(HERE, "densify.npz"), **out)
 
 
+def colmap():
+    """Synthetic COLMAP binaries (written here, record layout of COLMAP's Reconstruction::Write*Binary) read back
+    with the REFERENCE's readers (utils.py:111-141, 181-224, 259-294); files and parsed values are stored."""
+    import struct
+
+    import torch
+
+    class _Anything(types.ModuleType):
+        def __getattr__(self, k):
+            return type(k, (), {})
+
+    for m in ("kornia", "cv2", "pykdtree", "pykdtree.kdtree", "gaussian"):
+        sys.modules.setdefault(m, _Anything(m))
+    sys.modules["kornia"].create_meshgrid = lambda *a, **k: None
+    if "/root/reference" not in sys.path:
+        sys.path.insert(0, "/root/reference")
+    for m in ("utils", "renderer", "splatter", "transforms"):
+        sys.modules.pop(m, None)
+    import utils as ref_utils
+
+    d = os.path.join(HERE, "colmap")
+    os.makedirs(d, exist_ok=True)
+    rng = np.random.default_rng(31)
+    npar = {0: 3, 1: 4, 2: 4, 4: 8}
+    with open(os.path.join(d, "cameras.bin"), "wb") as f:
+        models = [1, 0, 2, 4]
+        f.write(struct.pack("<Q", len(models)))
+        for i, m in enumerate(models):
+            f.write(struct.pack("<iiQQ", i + 1, m, 1920 + i, 1080 - i))
+            f.write(struct.pack("<%dd" % npar[m], *rng.uniform(0.1, 2000, npar[m])))
+    n_img, n_pts = 5, 300
+    with open(os.path.join(d, "images.bin"), "wb") as f:
+        f.write(struct.pack("<Q", n_img))
+        for i in range(n_img):
+            q = rng.normal(size=4)
+            f.write(struct.pack("<i7di", 10 + i, *(q / np.linalg.norm(q)), *rng.normal(size=3), 1 + i % 4))
+            f.write(("frame_%03d.JPG" % i).encode() + b"\x00")
+            n2d = int(rng.integers(0, 40))
+            f.write(struct.pack("<Q", n2d))
+            for _ in range(n2d):
+                f.write(struct.pack("<ddq", *rng.uniform(0, 1900, 2), int(rng.integers(-1, n_pts))))
+    with open(os.path.join(d, "points3D.bin"), "wb") as f:
+        f.write(struct.pack("<Q", n_pts))
+        for i in range(n_pts):
+            track = int(rng.integers(2, 7))
+            f.write(struct.pack("<q3d3BdQ", 1000 + i, *rng.normal(size=3) * 3, *rng.integers(1, 255, 3).tolist(),
+                                float(rng.uniform(0, 2)), track))
+            f.write(struct.pack("<%di" % (2 * track), *rng.integers(0, 50, 2 * track).tolist()))
+    cams = ref_utils.read_cameras_binary(os.path.join(d, "cameras.bin"))
+    imgs = ref_utils.read_images_binary(os.path.join(d, "images.bin"))
+    pts = ref_utils.read_points3d_binary(os.path.join(d, "points3D.bin"))
+    out = {"cam_ids": np.array(sorted(cams)), "img_ids": np.array(sorted(imgs)), "pt_ids": np.array(list(pts))}
+    for k, c in cams.items():
+        out[f"cam{k}_model"] = np.array(c.model)
+        out[f"cam{k}_wh"] = np.array([c.width, c.height])
+        out[f"cam{k}_params"] = np.asarray(c.params)
+    for k, im in imgs.items():
+        out[f"img{k}_pose"] = np.concatenate([im.qvec, im.tvec])
+        out[f"img{k}_cam"] = np.array(im.camera_id)
+        out[f"img{k}_name"] = np.array(im.name)
+        out[f"img{k}_xys"] = np.asarray(im.xys).reshape(-1, 2)
+        out[f"img{k}_pids"] = np.asarray(im.point3D_ids)
+        out[f"img{k}_rot"] = im.qvec2rotmat()
+    out["pt_xyz"] = np.stack([p.xyz for p in pts.values()])
+    out["pt_rgb"] = np.stack([p.rgb for p in pts.values()])
+    out["pt_err"] = np.array([float(p.error) for p in pts.values()])
+    out["pt_track_len"] = np.array([len(p.image_ids) for p in pts.values()])
+    out["pt_image_ids"] = np.concatenate([p.image_ids for p in pts.values()])
+    out["pt_p2d"] = np.concatenate([p.point2D_idxs for p in pts.values()])
+    # the colour / SH initialisation of Splatter.__init__ (splatter.py:373-384) with the reference's helpers
+    rgb = ref_utils.inverse_sigmoid_torch(torch.from_numpy(out["pt_rgb"] / 255.)).to(torch.float32)
+    out["init_rgb"] = rgb.numpy()
+    out["init_sh"] = ref_utils.initialize_sh(rgb).numpy()
+    np.savez_compressed(os.path.join(HERE, "colmap.npz"), **out)
+    print("colmap ok", len(cams), len(imgs), len(pts))
+
+
 if __name__ == "__main__":
     assert os.path.isdir("/root/reference"), "needs the reference checkout"
     oracle.build()
@@ -215,3 +292,4 @@ if __name__ == "__main__":
     kernels_case("dense_fwd", 4500, 64, 48, seed=22, use_sh=False, opa_shift=1.5, with_backward=False)
     host_geometry()
     densify()
+    colmap()
