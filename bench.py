@@ -32,7 +32,6 @@ for _p in (ROOT, os.path.join(ROOT, "3d-gaussian-splatting_amd")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-import numpy as np
 import torch
 import torch.distributed as dist
 

@@ -22,7 +22,6 @@ scheduling); oracle/ref_harness.inc holds the launch shapes of the reference hos
 from __future__ import annotations
 
 import os
-import re
 import subprocess
 import sys
 

@@ -1,6 +1,5 @@
 """GPU: gs_densify_classify / gs_densify_apply against the reference's own adaptive_control (golden vectors
 recorded from /root/reference/splatter.py) and against the oracle on larger random sets."""
-import os
 
 import numpy as np
 import pytest

@@ -10,7 +10,6 @@ import pytest
 import torch
 
 import oracle
-from gs_geometry import TileGrid
 from gs_scene import make_camera, make_scene
 from gs_testutil import OracleFrame, activate, frame_scalars, rel_err
 

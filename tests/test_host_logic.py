@@ -1,10 +1,8 @@
 """CPU tier: host-side logic -- scene generator determinism, trunc_exp, and the view-parallel
 gradient bucket over a 2-process gloo group (the RCCL path's CPU stand-in)."""
 import os
-import sys
 
 import numpy as np
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp

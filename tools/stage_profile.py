@@ -1,4 +1,4 @@
-import sys, time, json
+import sys
 sys.path[:0]=['/root/repo','/root/repo/3d-gaussian-splatting_amd']
 import torch, numpy as np
 from gs_frame import FrameRenderer
