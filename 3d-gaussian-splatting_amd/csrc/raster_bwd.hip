@@ -83,6 +83,33 @@ struct BwdIn {
     const int32_t *ranges;           // FRAME: [T][2]; REF: accum [T+1]
 };
 
+// Inputs of one pixel for the backward kernels: final colour, and dL/dC -- for the frame path the gradient of
+// the clamped + cropped output (splatter.py:652-653: zero outside the crop and where the colour was clamped).
+// The gradient is loaded unconditionally and masked afterwards: a load that depends on c_final's value would
+// serialise two memory round trips.
+template <bool FRAME>
+__device__ __forceinline__ void load_pixel_inputs(const BwdIn &I, const RasterGeom &G, uint32_t id_x, uint32_t id_y,
+                                                  float f[3], float g[3]) {
+    const float *cf = I.c_final + ((size_t)id_y * G.padW + id_x) * 3;
+    f[0] = cf[0];
+    f[1] = cf[1];
+    f[2] = cf[2];
+    if (FRAME) {
+        const int ox = (int)id_x - G.crop_left, oy = (int)id_y - G.crop_top;
+        const bool in = ox >= 0 && ox < G.width && oy >= 0 && oy < G.height;
+        const float *gp = I.grad + ((size_t)(in ? oy : 0) * G.width + (in ? ox : 0)) * 3;
+        const float u0 = gp[0], u1 = gp[1], u2 = gp[2];
+        g[0] = (in && f[0] >= 0.f && f[0] <= 1.f) ? u0 : 0.f;
+        g[1] = (in && f[1] >= 0.f && f[1] <= 1.f) ? u1 : 0.f;
+        g[2] = (in && f[2] >= 0.f && f[2] <= 1.f) ? u2 : 0.f;
+    } else {
+        const float *gp = I.grad + ((size_t)id_y * G.padW + id_x) * 3;
+        g[0] = gp[0];
+        g[1] = gp[1];
+        g[2] = gp[2];
+    }
+}
+
 template <int CDIM, bool FRAME>
 __global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
     // Feed ring: the 256 pixel states of a bucket enter lane 0 in four segments of 64; while a
@@ -126,24 +153,14 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, Raste
         const int p = seg * 64 + lane;
         const uint32_t id_y = ty * 16 + (p >> 4);
         pc = ck[p];
-        const float *cf = I.c_final + ((size_t)id_y * G.padW + id_x) * 3;
-        pf0 = cf[0];
-        pf1 = cf[1];
-        pf2 = cf[2];
-        if (FRAME) {  // grad w.r.t. the clamped + cropped output (splatter.py:652-653)
-            const int ox = (int)id_x - G.crop_left, oy = (int)id_y - G.crop_top;
-            const bool in = ox >= 0 && ox < G.width && oy >= 0 && oy < G.height;
-            const float *gp = I.grad + ((size_t)(in ? oy : 0) * G.width + (in ? ox : 0)) * 3;
-            const float u0 = gp[0], u1 = gp[1], u2 = gp[2];  // unconditional: no load that depends on c_final
-            pg0 = (in && pf0 >= 0.f && pf0 <= 1.f) ? u0 : 0.f;
-            pg1 = (in && pf1 >= 0.f && pf1 <= 1.f) ? u1 : 0.f;
-            pg2 = (in && pf2 >= 0.f && pf2 <= 1.f) ? u2 : 0.f;
-        } else {
-            const float *gp = I.grad + ((size_t)id_y * G.padW + id_x) * 3;
-            pg0 = gp[0];
-            pg1 = gp[1];
-            pg2 = gp[2];
-        }
+        float f[3], g[3];
+        load_pixel_inputs<FRAME>(I, G, id_x, id_y, f, g);
+        pf0 = f[0];
+        pf1 = f[1];
+        pf2 = f[2];
+        pg0 = g[0];
+        pg1 = g[1];
+        pg2 = g[2];
     };
     auto write_segment = [&](int buf, int seg) {
         const uint32_t id_y = ty * 16 + seg * 4 + (lane >> 4);
@@ -394,22 +411,12 @@ __global__ void __launch_bounds__(64) raster_backward_tail_kernel(RasterSrc S, R
         const uint32_t id_y = id_y0 + 4 * k;
         py[k] = raster_pixel_coord(id_y, G.padH, G.focal_y);
         const float4 c = ck[64 * k + lane];  // tile pixel index = 16 (y - ty 16) + (x - tx 16)
-        const float *cf = I.c_final + ((size_t)id_y * G.padW + id_x) * 3;
-        const float f0 = cf[0], f1 = cf[1], f2 = cf[2];
-        if (FRAME) {
-            const int ox = (int)id_x - G.crop_left, oy = (int)id_y - G.crop_top;
-            const bool in = ox >= 0 && ox < G.width && oy >= 0 && oy < G.height;
-            const float *gp = I.grad + ((size_t)(in ? oy : 0) * G.width + (in ? ox : 0)) * 3;
-            const float u0 = gp[0], u1 = gp[1], u2 = gp[2];  // loaded unconditionally: a load that depends on
-            g0[k] = (in && f0 >= 0.f && f0 <= 1.f) ? u0 : 0.f;  // c_final would serialise two memory round trips
-            g1[k] = (in && f1 >= 0.f && f1 <= 1.f) ? u1 : 0.f;
-            g2[k] = (in && f2 >= 0.f && f2 <= 1.f) ? u2 : 0.f;
-        } else {
-            const float *gp = I.grad + ((size_t)id_y * G.padW + id_x) * 3;
-            g0[k] = gp[0];
-            g1[k] = gp[1];
-            g2[k] = gp[2];
-        }
+        float f[3], g[3];
+        load_pixel_inputs<FRAME>(I, G, id_x, id_y, f, g);
+        const float f0 = f[0], f1 = f[1], f2 = f[2];
+        g0[k] = g[0];
+        g1[k] = g[1];
+        g2[k] = g[2];
         T[k] = c.x;
         rho[k] = g0[k] * (f0 - c.y) + g1[k] * (f1 - c.z) + g2[k] * (f2 - c.w);
     }
