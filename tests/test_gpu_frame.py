@@ -316,3 +316,36 @@ def test_frame_async_growth(gpu):
     assert r.max_pairs >= len(of.ids)
     assert np.abs(imgs[-1].cpu().numpy() - of.image).max() < IMG_ATOL
     assert float(imgs[0].abs().max()) == 0.0  # sort_mode 2 renders an overflowed frame empty instead of truncated
+
+
+def test_c_abi_client_without_torch(gpu, tmp_path):
+    """examples/abi_demo.cpp links libgs_amd.so and the HIP runtime only (no torch, no Python): the same scene
+    rendered through that client and through FrameRenderer gives bit-identical images and counters."""
+    import os
+    import struct
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "abi_demo")
+    if not os.path.exists(exe):
+        pytest.skip("examples/abi_demo not built (python __graft_entry__.py)")
+    libs = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+    assert "libgs_amd.so" in libs and "torch" not in libs and "python" not in libs
+    W, H = 333, 201
+    scene, cam = case(9_000, W, H, seed=23)
+    scene_file, out_file = tmp_path / "scene.bin", tmp_path / "out.bin"
+    with open(scene_file, "wb") as f:
+        f.write(struct.pack("<3i3f", scene.n, W, H, cam.focal_x, cam.focal_y, cam.near))
+        f.write(np.asarray(cam.rot, np.float32).tobytes() + np.asarray(cam.tran, np.float32).tobytes())
+        for a in (scene.pos, scene.quat, scene.scale, scene.opa, scene.rgb):
+            f.write(np.ascontiguousarray(a, np.float32).tobytes())
+    p = subprocess.run([exe, str(scene_file), str(out_file)], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    raw = open(out_file, "rb").read()
+    visible, pairs = struct.unpack_from("<2q", raw, 0)
+    image = np.frombuffer(raw, np.float32, W * H * 3, 16).reshape(H, W, 3)
+    r = FrameRenderer(gpu, max_pairs=8 * scene.n + 4096, auto_grow=False)
+    ref, _ = r.forward(*to_torch(scene, gpu), cam)
+    st = r.stats()
+    assert (visible, pairs) == (st.visible, st.pairs)
+    assert np.array_equal(image, ref.cpu().numpy())
