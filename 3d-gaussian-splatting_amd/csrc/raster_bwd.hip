@@ -180,6 +180,13 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, Raste
         __builtin_amdgcn_wave_barrier();
     };
     load_segment(0);
+    if (CDIM == 27) {
+        // lanes that hold no pixel yet read records of segments that are not staged yet: their weight is exactly
+        // zero, but 0 x (whatever the previous kernel left in LDS, e.g. the tile sort's all-ones padding = NaN)
+        // must not reach the accumulators
+#pragma unroll
+        for (int q = 0; q < 36; ++q) s_sh[wave][q * 64 + lane] = 0.f;
+    }
 
     // ---- this lane's Gaussian
     GaussianRec g = {0, 0, 0, 0, 0, 0, 0};

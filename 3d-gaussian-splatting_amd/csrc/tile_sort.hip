@@ -167,21 +167,29 @@ __device__ __forceinline__ void merge_levels(uint64_t *a, uint32_t n, uint32_t P
     }
 }
 
-// Plain version for buckets that live in global memory (> CAP keys; rare).
-__device__ __forceinline__ void bitonic_sort_global(uint64_t *a, uint32_t n, uint32_t P) {
-    for (uint32_t k = 2; k <= P; k <<= 1) {
-        const uint32_t hk = k >> 1;
-        for (uint32_t t = threadIdx.x; t < (P >> 1); t += blockDim.x)
-            cmpx(a, (t / hk) * k + (t % hk), (t / hk) * k + (k - 1) - (t % hk), n);
-        __syncthreads();
-        for (uint32_t j = hk >> 1; j >= 1; j >>= 1) {
-            for (uint32_t t = threadIdx.x; t < (P >> 1); t += blockDim.x) {
-                const uint32_t lo = (t / j) * 2 * j + (t % j);
-                cmpx(a, lo, lo + j, n);
-            }
-            __syncthreads();
+// Strides top .. 128 through the array, then 64 .. 1 in registers: the tail of a merge level whose wider
+// strides have already been applied (used per CAP-sized chunk of a bucket that does not fit LDS).
+template <typename Sync>
+__device__ __forceinline__ void disperse_levels(uint64_t *a, uint32_t n, uint32_t top, uint32_t tid, uint32_t nthreads,
+                                                Sync sync) {
+    const int lane = tid & 63;
+    const uint32_t wave = tid >> 6, nwaves = nthreads >> 6, nwin = (n + 127) / 128;
+    for (uint32_t j = top; j >= 128; j >>= 1) {
+        // comparator t pairs lo(t) with lo(t) + j; both grow with t, so a thread can stop at its first miss
+        for (uint32_t t = tid; (t / j) * 2 * j + (t % j) + j < n; t += nthreads) {
+            const uint32_t lo = (t / j) * 2 * j + (t % j);
+            cmpx(a, lo, lo + j, n);
         }
+        sync();
     }
+    for (uint32_t w = wave; w < nwin; w += nwaves) {
+        const uint32_t e0 = w * 128 + lane, e1 = e0 + 64;
+        uint64_t a0 = e0 < n ? a[e0] : KEY_INF, a1 = e1 < n ? a[e1] : KEY_INF;
+        disperse_window(a0, a1, lane, n - w * 128 < 128 ? n - w * 128 : 128);
+        if (e0 < n) a[e0] = a0;
+        if (e1 < n) a[e1] = a1;
+    }
+    sync();
 }
 
 // PACKED = false (sort_mode 1): keys = (tile << 32 | depth_bits) grouped by tile, ids = Gaussian index;
@@ -256,12 +264,65 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(uint64_t *__restrict__ k
             merge_levels(s_a, n, P, threadIdx.x, 256u, [] { __syncthreads(); });
             for (uint32_t i = threadIdx.x; i < n; i += 256) store(i, s_a[i]);
         } else {
+            // The bucket does not fit the LDS window: sort it CAP keys at a time in LDS, then finish the merge levels
+            // k = 2 CAP, 4 CAP, .. with their strides >= CAP through global memory (the bucket stays in L2) and
+            // everything below per chunk in LDS / registers again.  (A first version ran the whole network through
+            // global memory: 4.9 ms per frame at 3,500 pairs per tile; this path: see DESIGN.md.)
             uint64_t *a = scratch + start;  // PACKED: in place; else the idle half of the key buffer
             if (!PACKED)
                 for (uint32_t i = threadIdx.x; i < n; i += 256) a[i] = load(i);
             __syncthreads();
-            bitonic_sort_global(a, n, P);
-            for (uint32_t i = threadIdx.x; i < n; i += 256) store(i, a[i]);
+            auto block_sync = [] { __syncthreads(); };
+            const uint32_t nchunk = (n + CAP - 1) / CAP;
+            auto chunk_in = [&](uint32_t c) {
+                const uint32_t cnt = n - c * CAP < (uint32_t)CAP ? n - c * CAP : (uint32_t)CAP;
+                for (uint32_t i = threadIdx.x; i < cnt; i += 256) s_a[i] = a[c * CAP + i];
+                __syncthreads();
+                return cnt;
+            };
+            auto chunk_out = [&](uint32_t c, uint32_t cnt, bool final) {
+                for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
+                    if (final)
+                        store(c * CAP + i, s_a[i]);
+                    else
+                        a[c * CAP + i] = s_a[i];
+                }
+                __syncthreads();
+            };
+            for (uint32_t c = 0; c < nchunk; ++c) {  // every chunk sorted on its own
+                const uint32_t cnt = chunk_in(c);
+                const uint32_t nwin = (cnt + 127) / 128;
+                for (uint32_t w = wave; w < nwin; w += 4) {
+                    const uint32_t e0 = w * 128 + lane, e1 = e0 + 64;
+                    uint64_t a0 = e0 < cnt ? s_a[e0] : KEY_INF, a1 = e1 < cnt ? s_a[e1] : KEY_INF;
+                    sort_window(a0, a1, lane, cnt - w * 128 < 128 ? cnt - w * 128 : 128);
+                    if (e0 < cnt) s_a[e0] = a0;
+                    if (e1 < cnt) s_a[e1] = a1;
+                }
+                __syncthreads();
+                uint32_t Pc = 256;
+                while (Pc < cnt) Pc <<= 1;
+                merge_levels(s_a, cnt, Pc, threadIdx.x, 256u, block_sync);
+                chunk_out(c, cnt, false);
+            }
+            for (uint32_t k = 2 * CAP; k <= P; k <<= 1) {
+                const uint32_t hk = k >> 1;
+                for (uint32_t t = threadIdx.x; t < (P >> 1); t += 256)  // flip, through global memory
+                    cmpx(a, (t / hk) * k + (t % hk), (t / hk) * k + (k - 1) - (t % hk), n);
+                __syncthreads();
+                for (uint32_t j = hk >> 1; j >= (uint32_t)CAP; j >>= 1) {  // strides that cross chunks
+                    for (uint32_t t = threadIdx.x; t < (P >> 1); t += 256) {
+                        const uint32_t lo = (t / j) * 2 * j + (t % j);
+                        cmpx(a, lo, lo + j, n);
+                    }
+                    __syncthreads();
+                }
+                for (uint32_t c = 0; c < nchunk; ++c) {  // strides CAP/2 .. 1 inside every chunk
+                    const uint32_t cnt = chunk_in(c);
+                    disperse_levels(s_a, cnt, CAP / 2, threadIdx.x, 256u, block_sync);
+                    chunk_out(c, cnt, k == P);
+                }
+            }
         }
     }
 }

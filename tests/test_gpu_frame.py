@@ -65,10 +65,12 @@ def test_frame_forward_parity(gpu, n, W, H, sort_mode):
     check_forward(gpu, *case(n, W, H), sort_mode=sort_mode)
 
 
-def test_frame_forward_giant_bucket_sorted_in_global_memory(gpu):
-    # > 2048 pairs in one tile: the per-tile sort leaves LDS and runs in place in global memory
+@pytest.mark.parametrize("sort_mode", [1, 2])
+def test_frame_forward_giant_bucket_sorted_in_chunks(gpu, sort_mode):
+    # > 4096 pairs in one tile: the per-tile sort handles 2048-key chunks in LDS and the strides >= 2048 of the
+    # last merge levels through global memory (both the packed and the (key, id) input variants)
     scene, cam = case(40_000, 32, 32, seed=8)
-    of, _, _ = check_forward(gpu, scene, cam, sort_mode=2)
+    of, _, _ = check_forward(gpu, scene, cam, sort_mode=sort_mode)
     assert np.diff(of.accum).max() > 4096
 
 
