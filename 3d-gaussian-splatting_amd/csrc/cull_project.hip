@@ -387,10 +387,11 @@ __global__ void __launch_bounds__(256) frame_project_kernel(
 }
 
 // ---------------------------------------------------------------- fused frame stage B2
-// rows[pair][12|36] = (dx, dy, da, db, dc, dd, dopa, colour grads..) written by the raster backward
+// rows[pair][12|36|56] = (dx, dy, da, db, dc, dd, dopa, colour grads..) written by the raster backward
 // in emission order: Gaussian g owns rows [pair_offsets[g], +tiles_touched[g]).  They are summed
 // here in a fixed order (the reference's index_put_(accumulate=True), but deterministic) and pushed
 // through the projection + activation backward.  Culled Gaussians get zeros.
+template <int CDIM>
 __global__ void __launch_bounds__(256) frame_project_backward_kernel(
     const float *__restrict__ pos, const float4 *__restrict__ quat, const float *__restrict__ scale,
     const float *__restrict__ rgb, int64_t n, ProjectParams P, const float4 *__restrict__ rec_geom,
@@ -410,15 +411,16 @@ __global__ void __launch_bounds__(256) frame_project_backward_kernel(
     const bool valid = pid < n;
     const float4 g = valid ? rec_geom[pid * GS_REC_STRIDE] : make_float4(0, 0, 0, 0);
     float gp[3] = {0, 0, 0}, gqr[4] = {0, 0, 0, 0}, gsr[3] = {0, 0, 0}, gopa = 0, gcol[3] = {0, 0, 0};
-    float gsh[27];
-    const bool vis = valid && g.z != 0.0f;  // visible (depth > near > 0)
+    constexpr int RW4 = gs_row_floats(CDIM) / 4;  // float4s per row
+    float gsh[CDIM > 3 ? 4 * RW4 - 8 : 1];        // sums of row[2..]: gsh[k - 1] is SH coefficient k >= 1
+    const bool vis = valid && g.z != 0.0f;        // visible (depth > near > 0)
     float4 d0 = make_float4(0, 0, 0, 0), d1 = d0, d2 = d0;
-    if (P.color_dim == 27) {
+    if (CDIM > 3) {
 #pragma unroll
-        for (int k = 0; k < 27; ++k) gsh[k] = 0.f;
+        for (int k = 0; k < 4 * RW4 - 8; ++k) gsh[k] = 0.f;
     }
     const uint64_t off = vis ? pair_offsets[pid] : 0, cnt = vis ? tiles_touched[pid] : 0;
-    if (P.color_dim == 3) {
+    if (CDIM == 3) {
         constexpr uint32_t rows_per_chunk = CHUNK_F4 / 3;
         uint64_t row_begin = pair_offsets[pid0];
         uint64_t row_end = (uint64_t)pair_offsets[pid_last] + tiles_touched[pid_last];
@@ -439,21 +441,18 @@ __global__ void __launch_bounds__(256) frame_project_backward_kernel(
             __syncthreads();
         }
     } else {
-        // SH rows are 144 contiguous bytes: a thread reading its own rows already moves whole sectors (measured:
-        // the LDS detour costs 25 % here)
+        // SH rows are 144 (224) contiguous bytes: a thread reading its own rows already moves whole sectors
+        // (measured: the LDS detour costs 25 % here)
         for (uint64_t k = 0; k < cnt && off + k < max_pairs; ++k) {
-            const float4 *row = rows + (off + k) * 9;
+            const float4 *row = rows + (off + k) * RW4;
             const float4 r0 = row[0], r1 = row[1];
             d0.x += r0.x; d0.y += r0.y; d0.z += r0.z; d0.w += r0.w;
-            d1.x += r1.x; d1.y += r1.y; d1.z += r1.z;
-            gsh[0] += r1.w;
+            d1.x += r1.x; d1.y += r1.y; d1.z += r1.z; d1.w += r1.w;  // d1.w: SH coefficient 0
 #pragma unroll
-            for (int m = 0; m < 6; ++m) {
+            for (int m = 0; m < RW4 - 2; ++m) {
                 const float4 r = row[2 + m];
-                gsh[1 + 4 * m] += r.x; gsh[2 + 4 * m] += r.y; gsh[3 + 4 * m] += r.z; gsh[4 + 4 * m] += r.w;
+                gsh[4 * m] += r.x; gsh[4 * m + 1] += r.y; gsh[4 * m + 2] += r.z; gsh[4 * m + 3] += r.w;
             }
-            const float4 r8 = row[8];
-            gsh[25] += r8.x; gsh[26] += r8.y;
         }
     }
     if (!valid) return;
@@ -479,7 +478,7 @@ __global__ void __launch_bounds__(256) frame_project_backward_kernel(
                 gsr[k] = gs[k] * expf(fminf(fmaxf(sraw[k], -1.0f), 1.0f));
         }
         gopa = d1.z * g.w * (1.0f - g.w);
-        if (P.color_dim == 3) {
+        if (CDIM == 3) {
             const float4 c = rec_color[pid * GS_REC_STRIDE];
             gcol[0] = d1.w * c.x * (1.0f - c.x);
             gcol[1] = d2.x * c.y * (1.0f - c.y);
@@ -494,14 +493,14 @@ __global__ void __launch_bounds__(256) frame_project_backward_kernel(
     grad_scale[pid * 3 + 1] = gsr[1];
     grad_scale[pid * 3 + 2] = gsr[2];
     grad_opa[pid] = gopa;
-    if (P.color_dim == 3) {
+    if (CDIM == 3) {
         grad_rgb[pid * 3 + 0] = gcol[0];
         grad_rgb[pid * 3 + 1] = gcol[1];
         grad_rgb[pid * 3 + 2] = gcol[2];
     } else {  // SH coefficients are raw parameters: the summed rows are the gradient
-        const bool vis = g.z != 0.0f;
+        grad_rgb[pid * CDIM] = vis ? d1.w : 0.f;
 #pragma unroll
-        for (int k = 0; k < 27; ++k) grad_rgb[pid * 27 + k] = vis ? gsh[k] : 0.f;
+        for (int k = 1; k < CDIM; ++k) grad_rgb[pid * CDIM + k] = vis ? gsh[k - 1] : 0.f;
     }
     (void)rgb;
 }
@@ -617,10 +616,18 @@ int gs_stage_project_backward(const gs_frame *f, const gs_frame_ws &ws, float *g
                               float *grad_scale, float *grad_opa, float *grad_rgb, hipStream_t stream) {
     ProjectParams P = make_params(f);
     int nblk = (int)gs_div_up(f->N, 256);
-    hipLaunchKernelGGL(frame_project_backward_kernel, dim3(nblk), dim3(256), 0, stream, f->pos,
-                       (const float4 *)f->quat, f->scale, f->rgb, f->N, P, ws.rec_geom, ws.rec_color,
-                       (const float4 *)ws.rows, ws.pair_offsets, ws.tiles_touched, (uint64_t)f->max_pairs, grad_pos,
-                       (float4 *)grad_quat, grad_scale, grad_opa, grad_rgb);
+#define GS_LAUNCH_PROJECT_BWD(CD)                                                                                  \
+    hipLaunchKernelGGL(frame_project_backward_kernel<CD>, dim3(nblk), dim3(256), 0, stream, f->pos,              \
+                       (const float4 *)f->quat, f->scale, f->rgb, f->N, P, ws.rec_geom, ws.rec_color,             \
+                       (const float4 *)ws.rows, ws.pair_offsets, ws.tiles_touched, (uint64_t)f->max_pairs,        \
+                       grad_pos, (float4 *)grad_quat, grad_scale, grad_opa, grad_rgb)
+    if (f->color_dim == 48)
+        GS_LAUNCH_PROJECT_BWD(48);
+    else if (f->color_dim == 27)
+        GS_LAUNCH_PROJECT_BWD(27);
+    else
+        GS_LAUNCH_PROJECT_BWD(3);
+#undef GS_LAUNCH_PROJECT_BWD
     GS_CHECK_LAUNCH();
     return 0;
 }

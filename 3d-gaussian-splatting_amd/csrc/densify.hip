@@ -225,7 +225,7 @@ int fill_params(const gs_densify_opts *o, DensifyParams &P) {
     GS_CHECK_ARG(o != nullptr, "opts is null");
     GS_CHECK_ARG(o->scale_activation == 0 || o->scale_activation == 1, "scale_activation must be 0 (abs) or 1 (exp)");
     GS_CHECK_ARG(o->grad_aggregation == 0 || o->grad_aggregation == 1, "grad_aggregation must be 0 (max) or 1 (mean)");
-    GS_CHECK_ARG(o->color_dim == 3 || o->color_dim == 27, "color_dim must be 3 or 27");
+    GS_CHECK_ARG(o->color_dim == 3 || o->color_dim == 27 || o->color_dim == 48, "color_dim must be 3, 27 or 48");
     P.taus = o->taus;
     P.delete_thresh = o->delete_thresh;
     P.grad_thresh = o->grad_thresh;

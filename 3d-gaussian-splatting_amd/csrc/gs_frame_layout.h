@@ -10,7 +10,9 @@ enum { GS_CNT_VISIBLE = 0, GS_CNT_PAIRS = 1, GS_CNT_OVERFLOW = 2, GS_CNT_BUCKETS
 #define GS_BIN_MAX_TILES 32768  // sort_mode 2 needs a 4-byte LDS counter per tile (128 KiB of the CU's 160)
 
 // floats per per-pair gradient row: (dx, dy, da, db, dc, dd, dopa) + colour grads, padded to float4s
-static inline int gs_row_floats(int color_dim) { return color_dim == 3 ? 12 : 36; }
+// floats per (tile, Gaussian) gradient row: 7 geometry/opacity sums + color_dim colour sums, rounded up to float4s
+// (12 / 36 / 56 for color_dim 3 / 27 / 48)
+static constexpr int gs_row_floats(int color_dim) { return (7 + color_dim + 3) / 4 * 4; }
 
 struct gs_frame_geom {
     int padW, padH, ntx, nty, n_tiles, crop_top, crop_left;

@@ -110,21 +110,32 @@ __device__ __forceinline__ void load_pixel_inputs(const BwdIn &I, const RasterGe
     }
 }
 
+// waves per workgroup of the systolic kernel: the degree-3 SH basis records need 20 KiB of LDS per wave
+template <int CDIM>
+struct BwdCfg {
+    static constexpr int WPB = CDIM == 48 ? 2 : 4;
+    static constexpr int NB = CDIM > 3 ? CDIM / 3 : 1;        // SH basis functions per channel
+    static constexpr int SHS = CDIM == 48 ? 20 : NB;          // LDS record stride (floats): 9 is conflict-free for
+                                                              // scalar reads, 16 + 4 keeps float4 reads aligned
+};
+
 template <int CDIM, bool FRAME>
-__global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
+__global__ void __launch_bounds__(64 * BwdCfg<CDIM>::WPB) raster_backward_kernel(RasterSrc S, RasterGeom G, BwdIn I,
+                                                                              BwdOut O) {
+    constexpr int WPB = BwdCfg<CDIM>::WPB, NB = BwdCfg<CDIM>::NB, SHS = BwdCfg<CDIM>::SHS;
     // Feed ring: the 256 pixel states of a bucket enter lane 0 in four segments of 64; while a
     // segment streams through the lanes, the next one is prefetched into registers and then
     // written to the other half of the ring.  ~6 KiB of LDS per wave keeps occupancy
     // register-limited (the dependent DPP chain needs >= 5 waves per SIMD to stay hidden).
     constexpr int NF = 2;  // float4 feed records per pixel
-    __shared__ float4 s_feed[4][2][NF][64];
-    // SH only: the 9 basis values of a pixel never change while it travels, so they do not ride the DPP chain
+    __shared__ float4 s_feed[WPB][2][NF][64];
+    // SH only: the 9 (16) basis values of a pixel never change while it travels, so they do not ride the DPP chain
     // (9 moves = 28 ns of SIMD time per step, tools/ubench/pk_rate.hip); they are staged once per bucket and
-    // every lane reads the record of the pixel it currently holds (3 LDS reads, no VALU issue slots).
-    __shared__ float s_sh[CDIM == 27 ? 4 : 1][CDIM == 27 ? 256 * 9 : 1];
+    // every lane reads the record of the pixel it currently holds (3-4 LDS reads, no VALU issue slots).
+    __shared__ float s_sh[CDIM > 3 ? WPB : 1][CDIM > 3 ? 256 * SHS : 4] __attribute__((aligned(16)));
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t n_tiles = (uint32_t)(G.ntx * G.nty);
-    const uint32_t kb = blockIdx.x * 4 + wave;
+    const uint32_t kb = blockIdx.x * WPB + wave;
     if (kb >= I.bucket_offsets[n_tiles]) return;  // whole wave exits; no block-level barrier below
 
     // bucket -> (tile, local bucket): last tile with bucket_offsets[t] <= kb
@@ -170,41 +181,41 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, Raste
         const float rho = pg0 * (pf0 - pc.y) + pg1 * (pf1 - pc.z) + pg2 * (pf2 - pc.w);
         s_feed[wave][buf][0][lane] = make_float4(pc.x, rho, my_px, py);
         s_feed[wave][buf][1][lane] = make_float4(pg0, pg1, pg2, 0.f);
-        if (CDIM == 27) {
-            float SH[9];
-            raster_pixel_sh(id_x, id_y, G, SH);
+        if (CDIM > 3) {
+            float SH[NB];
+            raster_pixel_sh<NB>(id_x, id_y, G, SH);
 #pragma unroll
-            for (int q = 0; q < 9; ++q) s_sh[wave][(seg * 64 + lane) * 9 + q] = SH[q];
+            for (int q = 0; q < NB; ++q) s_sh[wave][(seg * 64 + lane) * SHS + q] = SH[q];
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
     load_segment(0);
-    if (CDIM == 27) {
+    if (CDIM > 3) {
         // lanes that hold no pixel yet read records of segments that are not staged yet: their weight is exactly
         // zero, but 0 x (whatever the previous kernel left in LDS, e.g. the tile sort's all-ones padding = NaN)
         // must not reach the accumulators
 #pragma unroll
-        for (int q = 0; q < 36; ++q) s_sh[wave][q * 64 + lane] = 0.f;
+        for (int q = 0; q < 4 * SHS; ++q) s_sh[wave][q * 64 + lane] = 0.f;
     }
 
     // ---- this lane's Gaussian
     GaussianRec g = {0, 0, 0, 0, 0, 0, 0};
     float col0 = 0, col1 = 0, col2 = 0;
-    float coef[CDIM == 27 ? 27 : 1];
+    float coef[CDIM > 3 ? CDIM : 1];
     uint32_t gid = 0;
     if (gvalid) {
         gid = raster_load<FRAME>(S, j, g);
         if (CDIM == 3) {
             raster_load_rgb<FRAME>(S, j, gid, col0, col1, col2);
         } else {
-            const float *src = raster_sh_ptr<FRAME>(S, j, gid);
+            const float *src = raster_sh_ptr<FRAME, CDIM>(S, j, gid);
 #pragma unroll
-            for (int q = 0; q < 27; ++q) coef[q] = src[q];
+            for (int q = 0; q < CDIM; ++q) coef[q] = src[q];
         }
-    } else if (CDIM == 27) {
+    } else if (CDIM > 3) {
 #pragma unroll
-        for (int q = 0; q < 27; ++q) coef[q] = 0.f;
+        for (int q = 0; q < CDIM; ++q) coef[q] = 0.f;
     }
     float cA = 0, cB = 0, cC = 0;
     if (gvalid) raster_conic(g, cA, cB, cC);
@@ -213,10 +224,10 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, Raste
 
     // gradient accumulators
     float Sx = 0, Sy = 0, Sxx = 0, Sxy = 0, Syy = 0, Sq = 0, Sopa = 0, Sc0 = 0, Sc1 = 0, Sc2 = 0;
-    float Ssh[CDIM == 27 ? 27 : 1];
-    if (CDIM == 27) {
+    float Ssh[CDIM > 3 ? CDIM : 1];
+    if (CDIM > 3) {
 #pragma unroll
-        for (int q = 0; q < 27; ++q) Ssh[q] = 0.f;
+        for (int q = 0; q < CDIM; ++q) Ssh[q] = 0.f;
     }
     // outgoing state of the previous step (T = 0 means "no pixel here")
     float oT = 0, orho = 0, og0 = 0, og1 = 0, og2 = 0, opx = 0, opy = 0;
@@ -236,13 +247,24 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, Raste
             float rho = gs_wave_shr1(f0.y, orho);
             const float px = gs_wave_shr1(f0.z, opx), py = gs_wave_shr1(f0.w, opy);
             const float g0 = gs_wave_shr1(f1.x, og0), g1 = gs_wave_shr1(f1.y, og1), g2 = gs_wave_shr1(f1.z, og2);
-            float sh[CDIM == 27 ? 9 : 1];
-            if (CDIM == 27) {
+            float sh[NB];
+            if (CDIM > 3) {
                 // the pixel in this lane entered lane 0 `lane` steps ago: p = 64 seg + t - lane (lanes that hold
                 // no pixel yet / any more read a valid but irrelevant record: their T is 0)
-                const float *rec = &s_sh[wave][((seg * 64 + t - lane) & 255) * 9];
+                const float *rec = &s_sh[wave][((seg * 64 + t - lane) & 255) * SHS];
+                if (NB % 4 == 0) {
 #pragma unroll
-                for (int q = 0; q < 9; ++q) sh[q] = rec[q];
+                    for (int q = 0; q < NB / 4; ++q) {
+                        const float4 v = reinterpret_cast<const float4 *>(__builtin_assume_aligned(rec, 16))[q];
+                        sh[4 * q] = v.x;
+                        sh[4 * q + 1] = v.y;
+                        sh[4 * q + 2] = v.z;
+                        sh[4 * q + 3] = v.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < NB; ++q) sh[q] = rec[q];
+                }
             }
 
             const float dx = px - g.x, dy = py - g.y;
@@ -251,13 +273,13 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, Raste
             const bool live = T > GS_T_STOP;
             const float alpha = live ? Gv * opa : 0.f;
             const float w = alpha * T;
-            if (CDIM == 27) {
+            if (CDIM > 3) {
                 float v0 = 0.f, v1 = 0.f, v2 = 0.f;
 #pragma unroll
-                for (int k = 0; k < 9; ++k) {
+                for (int k = 0; k < NB; ++k) {
                     v0 = fmaf(sh[k], coef[k], v0);
-                    v1 = fmaf(sh[k], coef[9 + k], v1);
-                    v2 = fmaf(sh[k], coef[18 + k], v2);
+                    v1 = fmaf(sh[k], coef[NB + k], v1);
+                    v2 = fmaf(sh[k], coef[2 * NB + k], v2);
                 }
                 col0 = gs_rcp(1.0f + __expf(-v0));
                 col1 = gs_rcp(1.0f + __expf(-v1));
@@ -269,14 +291,14 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, Raste
             const float one_m = 1.0f - alpha;
             float d_alpha = fmaf(T, gc, -(rho * gs_rcp(one_m + 1e-7f)));
             d_alpha = live ? d_alpha : 0.f;
-            if (CDIM == 27) {
+            if (CDIM > 3) {
                 const float D0 = g0 * w * (col0 * (1.0f - col0)), D1 = g1 * w * (col1 * (1.0f - col1)),
                             D2 = g2 * w * (col2 * (1.0f - col2));
 #pragma unroll
-                for (int k = 0; k < 9; ++k) {
+                for (int k = 0; k < NB; ++k) {
                     Ssh[k] = fmaf(D0, sh[k], Ssh[k]);
-                    Ssh[9 + k] = fmaf(D1, sh[k], Ssh[9 + k]);
-                    Ssh[18 + k] = fmaf(D2, sh[k], Ssh[18 + k]);
+                    Ssh[NB + k] = fmaf(D1, sh[k], Ssh[NB + k]);
+                    Ssh[2 * NB + k] = fmaf(D2, sh[k], Ssh[2 * NB + k]);
                 }
             } else {
                 Sc0 = fmaf(g0, w, Sc0);
@@ -319,7 +341,7 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, Raste
         const uint32_t y0 = rc.x & 0xffff, x0 = rc.y & 0xffff, x1 = rc.y >> 16;
         const uint64_t slot = (uint64_t)O.pair_offsets[gid] + (ty - y0) * (x1 - x0) + (tx - x0);
         if (slot < O.max_pairs) {
-            constexpr int RW = CDIM == 3 ? 12 : 36;
+            constexpr int RW = gs_row_floats(CDIM);  // 7 geometry/opacity sums + CDIM colour sums, padded to float4s
             float4 *row = reinterpret_cast<float4 *>(O.rows + slot * RW);
             row[0] = make_float4(gx, gy, ga, gb);
             if (CDIM == 3) {
@@ -327,10 +349,10 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, Raste
                 row[2] = make_float4(Sc1, Sc2, 0.f, 0.f);
             } else {
                 row[1] = make_float4(gc, gd, Sopa, Ssh[0]);
+                auto at = [&](int k) { return k < CDIM ? Ssh[k < CDIM ? k : 0] : 0.f; };
 #pragma unroll
-                for (int k = 0; k < 6; ++k)
-                    row[2 + k] = make_float4(Ssh[1 + 4 * k], Ssh[2 + 4 * k], Ssh[3 + 4 * k], Ssh[4 + 4 * k]);
-                row[8] = make_float4(Ssh[25], Ssh[26], 0.f, 0.f);
+                for (int k = 0; k < RW / 4 - 2; ++k)
+                    row[2 + k] = make_float4(at(1 + 4 * k), at(2 + 4 * k), at(3 + 4 * k), at(4 + 4 * k));
             }
         }
     } else {
@@ -344,7 +366,7 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(RasterSrc S, Raste
             O.grad_rgb[(size_t)j * 3 + 2] = Sc2;
         } else {
 #pragma unroll
-            for (int k = 0; k < 27; ++k) O.grad_rgb[(size_t)j * 27 + k] = Ssh[k];
+            for (int k = 0; k < CDIM; ++k) O.grad_rgb[(size_t)j * CDIM + k] = Ssh[k];
         }
     }
 }
@@ -528,7 +550,8 @@ __global__ void __launch_bounds__(64) raster_backward_tail_kernel(RasterSrc S, R
 template <int CDIM, bool FRAME>
 void launch_bwd(const RasterSrc &S, const RasterGeom &G, const BwdIn &I, const BwdOut &O, int64_t max_buckets,
                 hipStream_t stream) {
-    const int grid = (int)gs_div_up(max_buckets > 0 ? max_buckets : 1, 4);
+    constexpr int WPB = BwdCfg<CDIM>::WPB;
+    const int grid = (int)gs_div_up(max_buckets > 0 ? max_buckets : 1, WPB);
     if (CDIM == 3) {
         // The systolic kernel sees full buckets only (bucket_scan_kernel, full_only); the ragged tails run in
         // raster_backward_tail_kernel.  That kernel is short and latency-bound (dependent loads, LDS round trips
@@ -552,10 +575,10 @@ void launch_bwd(const RasterSrc &S, const RasterGeom &G, const BwdIn &I, const B
         hipLaunchKernelGGL((raster_backward_tail_kernel<FRAME>), dim3(G.ntx * G.nty), dim3(64), 0,
                            forked ? side : stream, S, G, I, O);
         if (forked && hipEventRecord(ev_join, side) != hipSuccess) forked = false;
-        hipLaunchKernelGGL((raster_backward_kernel<CDIM, FRAME>), dim3(grid), dim3(256), 0, stream, S, G, I, O);
+        hipLaunchKernelGGL((raster_backward_kernel<CDIM, FRAME>), dim3(grid), dim3(64 * WPB), 0, stream, S, G, I, O);
         if (forked) (void)hipStreamWaitEvent(stream, ev_join, 0);
     } else {
-        hipLaunchKernelGGL((raster_backward_kernel<CDIM, FRAME>), dim3(grid), dim3(256), 0, stream, S, G, I, O);
+        hipLaunchKernelGGL((raster_backward_kernel<CDIM, FRAME>), dim3(grid), dim3(64 * WPB), 0, stream, S, G, I, O);
     }
 }
 
@@ -690,10 +713,12 @@ int gs_stage_raster_backward(const gs_frame *f, const gs_frame_ws &ws, const uin
     GS_HIP(hipMemsetAsync(ws.rows, 0, sizeof(float) * (size_t)gs_row_floats(f->color_dim) * f->max_pairs, stream));
     (void)grad_rgb;
     hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, ws.tile_nproc, FG.n_tiles,
-                       ws.bucket_offsets, ws.counters + GS_CNT_BUCKETS, f->color_dim == 27 ? 0 : 1);
+                       ws.bucket_offsets, ws.counters + GS_CNT_BUCKETS, f->color_dim == 3 ? 1 : 0);
     BwdIn I = {f->image_padded, grad_image, ws.ckpt, ws.tile_nproc, ws.bucket_offsets, ws.tile_ranges};
     BwdOut O = {ws.rows, ws.pair_offsets, ws.rects, (uint64_t)f->max_pairs, nullptr, nullptr, nullptr, nullptr};
-    if (f->color_dim == 27)
+    if (f->color_dim == 48)
+        launch_bwd<48, true>(S, G, I, O, ws.max_buckets, stream);
+    else if (f->color_dim == 27)
         launch_bwd<27, true>(S, G, I, O, ws.max_buckets, stream);
     else
         launch_bwd<3, true>(S, G, I, O, ws.max_buckets, stream);

@@ -14,7 +14,7 @@ struct RasterSrc {
     const float4 *cov4;    // (a, b, c, d)             } (one 64-byte record per Gaussian)
     const float4 *color4;  // (r, g, b, -)             }
     const float4 *conic4;  // (A, B, C, -)             }
-    const float *sh;       // raw rgb parameter [N,27] (SH coefficients)
+    const float *sh;       // raw rgb parameter [N,27 | 48] (SH coefficients, channel-major)
     const float *pos, *rgb, *opa, *cov;
 };
 
@@ -70,9 +70,9 @@ __device__ __forceinline__ void raster_load_rgb(const RasterSrc &S, uint32_t j, 
     }
 }
 
-template <bool FRAME>
+template <bool FRAME, int CDIM>
 __device__ __forceinline__ const float *raster_sh_ptr(const RasterSrc &S, uint32_t j, uint32_t id) {
-    return FRAME ? S.sh + (size_t)id * 27 : S.rgb + (size_t)j * 27;
+    return FRAME ? S.sh + (size_t)id * CDIM : S.rgb + (size_t)j * CDIM;
 }
 
 __device__ __forceinline__ float raster_det(float a, float b, float c, float d) { return gs_det(a, b, c, d); }
@@ -89,8 +89,11 @@ __device__ __forceinline__ float raster_pixel_coord(uint32_t id, int32_t padded,
     return ((float)id + 0.5f - (float)((uint32_t)padded / 2)) / focal;
 }
 
-// Per-pixel SH basis (gaussian.cu:849-861, 405-426), same promotions as the reference.
-__device__ __forceinline__ void raster_pixel_sh(uint32_t id_x, uint32_t id_y, const RasterGeom &G, float SH[9]) {
+// Per-pixel SH basis (gaussian.cu:849-861, 405-426), same promotions as the reference.  NB = 9 is the reference's
+// degree 2.  NB = 16 adds the degree-3 band in the same (svox2) sign convention with the C3 table the reference
+// declares (gaussian.cu:395-403) but never reads -- BASELINE config 4 names "SH degree 3"; it is an extension.
+template <int NB>
+__device__ __forceinline__ void raster_pixel_sh(uint32_t id_x, uint32_t id_y, const RasterGeom &G, float *SH) {
     float dir[3], nrm = 0.0f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -111,6 +114,15 @@ __device__ __forceinline__ void raster_pixel_sh(uint32_t id_x, uint32_t id_y, co
     SH[6] = (float)(0.31539156525252005f * (2.0 * zz - xx - yy));
     SH[7] = -1.0925484305920792f * xz;
     SH[8] = 0.5462742152960396f * (xx - yy);
+    if (NB == 16) {
+        SH[9] = -0.5900435899266435f * y * (3.0f * xx - yy);
+        SH[10] = 2.890611442640554f * xy * z;
+        SH[11] = -0.4570457994644658f * y * (4.0f * zz - xx - yy);
+        SH[12] = 0.3731763325901154f * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+        SH[13] = -0.4570457994644658f * x * (4.0f * zz - xx - yy);
+        SH[14] = 1.445305721320277f * z * (xx - yy);
+        SH[15] = -0.5900435899266435f * x * (xx - 3.0f * yy);
+    }
 }
 
 // Checkpoint slot of local bucket b of a tile whose sorted list starts at `start`:

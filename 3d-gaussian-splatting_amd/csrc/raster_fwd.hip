@@ -28,20 +28,20 @@ constexpr int NPP = 2;           // pixel pairs per lane
 #endif
 
 template <int CDIM>
-struct FwdSmem;
+struct FwdSmem {  // SH: CDIM = 27 (degree 2) or 48 (degree 3) raw coefficients per Gaussian, channel-major
+    static constexpr int CH = 64;
+    static constexpr int NB = CDIM / 3;
+    static constexpr int SHS = CDIM == 27 ? 28 : CDIM + 4;  // record stride: 16-byte rows, 4-way conflicts on the fill
+    enum { X, Y, A, B, C, NLOP, NFIELD };
+    float f[2][NFIELD][CH] __attribute__((aligned(16)));
+    float sh[2][CH][SHS] __attribute__((aligned(16)));
+};
 template <>
 struct FwdSmem<3> {
     // structure of arrays: four consecutive Gaussians of one field are one ds_read_b128
     static constexpr int CH = 64;
     enum { X, Y, A, B, C, NLOP, R, G, BL, NFIELD };  // NLOP = -log2(opacity)
     float f[2][NFIELD][CH] __attribute__((aligned(16)));
-};
-template <>
-struct FwdSmem<27> {
-    static constexpr int CH = 64;
-    enum { X, Y, A, B, C, NLOP, NFIELD };
-    float f[2][NFIELD][CH] __attribute__((aligned(16)));
-    float sh[2][CH][28] __attribute__((aligned(16)));
 };
 
 __device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
@@ -122,15 +122,16 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
     for (int h = 0; h < NPP; ++h)
         py2[h] = f2{raster_pixel_coord(id_y0 + 8 * h, G.padH, G.focal_y),
                     raster_pixel_coord(id_y0 + 8 * h + 4, G.padH, G.focal_y)};
-    f2 SH[NPP][CDIM == 27 ? 9 : 1];
-    if (CDIM == 27) {
+    constexpr int NB = CDIM > 3 ? CDIM / 3 : 1;  // SH basis functions per channel
+    f2 SH[NPP][NB];
+    if (CDIM > 3) {
 #pragma unroll
         for (int h = 0; h < NPP; ++h) {
-            float a9[9], b9[9];
-            raster_pixel_sh(id_x, id_y0 + 8 * h, G, a9);
-            raster_pixel_sh(id_x, id_y0 + 8 * h + 4, G, b9);
+            float a9[NB], b9[NB];
+            raster_pixel_sh<NB>(id_x, id_y0 + 8 * h, G, a9);
+            raster_pixel_sh<NB>(id_x, id_y0 + 8 * h + 4, G, b9);
 #pragma unroll
-            for (int k9 = 0; k9 < 9; ++k9) SH[h][k9] = f2{a9[k9], b9[k9]};
+            for (int k9 = 0; k9 < NB; ++k9) SH[h][k9] = f2{a9[k9], b9[k9]};
         }
     }
 
@@ -190,17 +191,17 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
                 sm.f[buf][SM::G][lane] = r1;
                 sm.f[buf][SM::BL][lane] = r2;
             } else {
-                const float *src = raster_sh_ptr<FRAME>(S, gj, gid);
+                const float *src = raster_sh_ptr<FRAME, CDIM>(S, gj, gid);
 #pragma unroll
-                for (int q = 0; q < 27; ++q) sm.sh[buf][lane][q] = src[q];
+                for (int q = 0; q < CDIM; ++q) sm.sh[buf][lane][q] = src[q];
             }
         } else if (base + lane < ((n + 3u) & ~3u)) {
             // pad the ragged tail to a multiple of 4 with null Gaussians (opacity 0 => alpha 0)
 #pragma unroll
             for (int q = 0; q < SM::NFIELD; ++q) sm.f[buf][q][lane] = (FRAME && q == SM::NLOP) ? 1e30f : 0.f;
-            if constexpr (CDIM == 27) {
+            if constexpr (CDIM > 3) {
 #pragma unroll
-                for (int q = 0; q < 27; ++q) sm.sh[buf][lane][q] = 0.f;
+                for (int q = 0; q < CDIM; ++q) sm.sh[buf][lane][q] = 0.f;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -262,10 +263,10 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
                         const float *co = sm.sh[buf][i + u];
                         f2 v0 = {0.f, 0.f}, v1 = {0.f, 0.f}, v2 = {0.f, 0.f};
 #pragma unroll
-                        for (int k9 = 0; k9 < 9; ++k9) {
+                        for (int k9 = 0; k9 < NB; ++k9) {
                             v0 = pk_fma(SH[h][k9], splat(co[k9]), v0);
-                            v1 = pk_fma(SH[h][k9], splat(co[9 + k9]), v1);
-                            v2 = pk_fma(SH[h][k9], splat(co[18 + k9]), v2);
+                            v1 = pk_fma(SH[h][k9], splat(co[NB + k9]), v1);
+                            v2 = pk_fma(SH[h][k9], splat(co[2 * NB + k9]), v2);
                         }
                         const f2 c0 = {gs_rcp(1.0f + __expf(-v0.x)), gs_rcp(1.0f + __expf(-v0.y))};
                         const f2 c1 = {gs_rcp(1.0f + __expf(-v1.x)), gs_rcp(1.0f + __expf(-v1.y))};
@@ -448,7 +449,14 @@ int gs_stage_raster_forward(const gs_frame *f, const gs_frame_ws &ws, const uint
         G.vdx[i] = f->vec_dx[i];
         G.vdy[i] = f->vec_dy[i];
     }
-    if (f->color_dim == 27) {
+    if (f->color_dim == 48) {
+        if (f->training)
+            launch_fwd<48, true, true, false>(S, G, ws.tile_ranges, f->image_padded, f->image, ws.ckpt, ws.tile_nproc,
+                                              0, stream);
+        else
+            launch_fwd<48, true, false, false>(S, G, ws.tile_ranges, f->image_padded, f->image, nullptr, nullptr, 0,
+                                               stream);
+    } else if (f->color_dim == 27) {
         if (f->training)
             launch_fwd<27, true, true, false>(S, G, ws.tile_ranges, f->image_padded, f->image, ws.ckpt, ws.tile_nproc,
                                               0, stream);

@@ -69,8 +69,8 @@ class FrameRenderer:
     def _describe(self, pos, quat, scale, opa, rgb, camera, training) -> _lib.GsFrame:
         n = int(pos.shape[0])
         color_dim = int(rgb.shape[1]) if rgb.dim() == 2 else 1
-        if color_dim not in (3, 27):
-            raise RuntimeError(f"rgb must be [N,3] or [N,27], got {tuple(rgb.shape)}")
+        if color_dim not in (3, 27, 48):  # rgb logits, SH degree 2 (the reference's), SH degree 3 (extension)
+            raise RuntimeError(f"rgb must be [N,3], [N,27] or [N,48], got {tuple(rgb.shape)}")
         for name, t, cols in (("pos", pos, 3), ("quat", quat, 4), ("scale", scale, 3), ("opa", opa, None),
                               ("rgb", rgb, color_dim)):
             if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():

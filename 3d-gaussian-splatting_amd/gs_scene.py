@@ -36,7 +36,7 @@ class Scene:
     quat: np.ndarray  # [N,4] raw (un-normalised) w,x,y,z
     scale: np.ndarray  # [N,3] raw; activation "abs": |s|+1e-4 (splatter.py:521)
     opa: np.ndarray  # [N]   logit
-    rgb: np.ndarray  # [N,3] logit, or [N,27] SH coeffs (channel-major 3x9, utils.py:345-348)
+    rgb: np.ndarray  # [N,3] logit, or [N,27] SH coeffs (channel-major 3x9, utils.py:345-348); [N,48] = 3x16 (degree 3)
 
     @property
     def n(self) -> int:
@@ -44,7 +44,7 @@ class Scene:
 
     @property
     def use_sh(self) -> bool:
-        return self.rgb.shape[1] == 27
+        return self.rgb.shape[1] in (27, 48)
 
 
 def make_camera(width: int, height: int, yaw_deg: float = 0.0) -> Camera:
@@ -57,8 +57,9 @@ def make_camera(width: int, height: int, yaw_deg: float = 0.0) -> Camera:
 
 
 def make_scene(n: int, width: int, height: int, seed: int = 2023, use_sh: bool = False,
-               max_px_sigma: float = 16.0) -> Scene:
-    """SURVEY.md section 8d generator (camera = make_camera(width, height))."""
+               max_px_sigma: float = 16.0, sh_degree: int = 2) -> Scene:
+    """SURVEY.md section 8d generator (camera = make_camera(width, height)).  ``sh_degree`` 2 is what the
+    reference implements (9 functions per channel); 3 (16 per channel) is the extension BASELINE config 4 names."""
     rng = np.random.default_rng(seed)
     fx = 0.75 * width
     z = rng.uniform(-0.5, 10.0, n)
@@ -74,9 +75,12 @@ def make_scene(n: int, width: int, height: int, seed: int = 2023, use_sh: bool =
     quat *= rng.uniform(0.5, 2.0, (n, 1))  # raw parameters are not unit length
     opa = rng.normal(0.0, 2.0, n)
     if use_sh:
-        rgb = rng.normal(0.0, 0.5, (n, 3, 9))
+        if sh_degree not in (2, 3):
+            raise ValueError("sh_degree must be 2 or 3")
+        nb = (sh_degree + 1) ** 2
+        rgb = rng.normal(0.0, 0.5, (n, 3, nb))
         rgb[:, :, 0] = rng.normal(0.0, 1.0, (n, 3)) / C0  # DC like initialize_sh
-        rgb = rgb.reshape(n, 27)
+        rgb = rgb.reshape(n, 3 * nb)
     else:
         rgb = rng.normal(0.0, 1.0, (n, 3))
     return Scene(pos, quat.astype(np.float32), scale.astype(np.float32), opa.astype(np.float32),

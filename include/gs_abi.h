@@ -149,7 +149,8 @@ int gs_sort_pairs_bits(uint64_t *keys0, uint32_t *vals0, uint64_t *keys1, uint32
 typedef struct gs_frame {
     /* scene (raw parameters, activations are fused: |s|+1e-4 / exp, q/|q|, sigmoid) */
     int64_t N;
-    int32_t color_dim;        /* 3 (sigmoid colour) or 27 (degree-2 SH coefficients)    */
+    int32_t color_dim;        /* 3 (sigmoid colour), 27 (degree-2 SH coefficients, the reference's basis_dim 9) or
+                                 48 (degree-3 SH: extension with the C3 table of gaussian.cu:395-403) */
     int32_t scale_activation; /* 0 = abs (+1e-4), 1 = exp   (splatter.py:520-524)       */
     const float *pos;         /* [N,3]  */
     const float *quat;        /* [N,4]  */
@@ -269,7 +270,7 @@ typedef struct gs_densify_opts {
     int32_t scale_activation;/* 0 = abs, 1 = exp                                                              */
     int32_t grad_aggregation;/* 0 = max over xyz, 1 = mean                                                    */
     int32_t use_clone, use_split;
-    int32_t color_dim;       /* 3 or 27                                                                       */
+    int32_t color_dim;       /* 3, 27 or 48 (the colour row is copied through)                                */
 } gs_densify_opts;
 size_t gs_densify_workspace_bytes(int64_t N);
 int gs_densify_classify(const float *scale, const float *opa, const float *grad, int64_t N,

@@ -173,6 +173,27 @@ def sort_float32_key(depth, tile_ids):
     return perm
 
 
+def _sh_code(use_sh, rgb) -> int:
+    """gs_oracle.c's `use_sh`: 0 = rgb logits, 9 = the reference's degree-2 basis, 16 = the degree-3 extension
+    (recognised by the coefficient count: [.., 27] or [.., 48])."""
+    if not use_sh:
+        return 0
+    d = int(np.asarray(rgb).shape[-1])
+    if d not in (27, 48):
+        raise ValueError(f"SH colour needs 27 or 48 coefficients per Gaussian, got {d}")
+    return d // 3
+
+
+def calc_sh(nb, dirs):
+    """SH basis of gaussian.cu:405-426 for unit directions [K,3] -> [K,nb]; nb = 9 (reference) or 16 (degree-3
+    extension, see gs_oracle.c)."""
+    dirs = _f(dirs).reshape(-1, 3)
+    out = np.zeros((dirs.shape[0], nb), np.float32)
+    for k in range(dirs.shape[0]):
+        lib().gso_calc_sh(C.c_int(nb), _vp(dirs[k]), _vp(out[k]))
+    return out
+
+
 def draw(pos, rgb, opa, cov, accum, padded_h, padded_w, focal_x, focal_y, weight_normalize=False,
          sigmoid=False, use_sh=False, fast=False, rays_o=None, lefttop=None, vdx=None, vdy=None):
     """K7 (gaussian.cu:806-970)."""
@@ -183,7 +204,7 @@ def draw(pos, rgb, opa, cov, accum, padded_h, padded_w, focal_x, focal_y, weight
     lib().gso_draw(_vp(pos), _vp(rgb), _vp(opa), _vp(cov), _vp(accum), _vp(res), C.c_int32(padded_h),
                    C.c_int32(padded_w), C.c_float(focal_x), C.c_float(focal_y),
                    C.c_int(bool(weight_normalize)), C.c_int(bool(sigmoid)), C.c_int(bool(fast)),
-                   _vp(rv[0]), _vp(rv[1]), _vp(rv[2]), _vp(rv[3]), C.c_int(bool(use_sh)))
+                   _vp(rv[0]), _vp(rv[1]), _vp(rv[2]), _vp(rv[3]), C.c_int(_sh_code(use_sh, rgb)))
     return res
 
 
@@ -202,7 +223,7 @@ def draw_backward(pos, rgb, opa, cov, accum, output, grad_output, focal_x, focal
                             C.c_int32(w), C.c_float(focal_x), C.c_float(focal_y),
                             C.c_int(bool(weight_normalize)), C.c_int(bool(sigmoid)),
                             C.c_int(bool(fast)), _vp(rv[0]), _vp(rv[1]), _vp(rv[2]), _vp(rv[3]),
-                            C.c_int(bool(use_sh)))
+                            C.c_int(_sh_code(use_sh, rgb)))
     return gp, gr, go, gc
 
 
@@ -215,7 +236,7 @@ def render_forward(pos, quat_raw, scale_raw, opa_raw, rgb_raw, rot, tran, near, 
     V = C.c_int64(0)
     rv = [_f(v) if v is not None else _Z3 for v in (rays_o, lefttop, vdx, vdy)]
     M = lib().gso_render_forward(_vp(pos), _vp(quat_raw), _vp(scale_raw), _vp(opa_raw), _vp(rgb_raw),
-                                 C.c_int64(pos.shape[0]), C.c_int(bool(use_sh)), _vp(rot), _vp(tran),
+                                 C.c_int64(pos.shape[0]), C.c_int(_sh_code(use_sh, rgb_raw)), _vp(rot), _vp(tran),
                                  C.c_float(near), C.c_int32(W), C.c_int32(H), C.c_float(fx),
                                  C.c_float(fy), C.c_float(thresh), _vp(rv[0]), _vp(rv[1]),
                                  _vp(rv[2]), _vp(rv[3]), _vp(img), C.byref(V))

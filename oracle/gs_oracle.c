@@ -444,7 +444,18 @@ static const float C1 = 0.4886025119029199;
 static const float C2[5] = {1.0925484305920792, -1.0925484305920792, 0.31539156525252005,
                             -1.0925484305920792, 0.5462742152960396};
 
-static void calc_sh9(const float *dir, float *out) {
+/* Degree 3 is an EXTENSION (BASELINE config 4 names "SH degree 3"): the reference declares C3
+ * (gaussian.cu:395-403) but calc_sh (:405-426) only has the basis_dim 9 and 4 cases.  The seven extra
+ * functions below are the degree-3 band of the same real-SH convention (svox2 / PlenOctrees) using that
+ * table; tests/test_oracle_kat.py pins them against scipy's spherical harmonics. */
+static const float C3[7] = {-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154,
+                            -0.4570457994644658, 1.445305721320277, -0.5900435899266435};
+
+/* `use_sh` as passed around below: 0 = rgb logits, 1 or 9 = the reference's 9 basis functions (its boolean
+ * use_sh_coeff), 16 = the degree-3 extension.  Coefficient layout [channel][nb] (gaussian.cu:644, 942). */
+static int sh_nb(int use_sh) { return use_sh == 0 ? 0 : (use_sh == 16 ? 16 : 9); }
+
+static void calc_sh(int nb, const float *dir, float *out) {
     out[0] = C0;
     const float x = dir[0], y = dir[1], z = dir[2];
     const float xx = x * x, yy = y * y, zz = z * z;
@@ -457,9 +468,18 @@ static void calc_sh9(const float *dir, float *out) {
     out[1] = -C1 * y;
     out[2] = C1 * z;
     out[3] = -C1 * x;
+    if (nb == 16) {
+        out[9] = C3[0] * y * (3.0f * xx - yy);
+        out[10] = C3[1] * xy * z;
+        out[11] = C3[2] * y * (4.0f * zz - xx - yy);
+        out[12] = C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+        out[13] = C3[4] * x * (4.0f * zz - xx - yy);
+        out[14] = C3[5] * z * (xx - yy);
+        out[15] = C3[6] * x * (xx - 3.0f * yy);
+    }
 }
 
-static void pixel_sh(uint32_t id_x, uint32_t id_y, const float *rays_o, const float *lefttop,
+static void pixel_sh(int nb, uint32_t id_x, uint32_t id_y, const float *rays_o, const float *lefttop,
                      const float *vdx, const float *vdy, float *SH) {
     /* gaussian.cu:849-860 */
     float dir[3], nrm = 0.0f;
@@ -469,13 +489,20 @@ static void pixel_sh(uint32_t id_x, uint32_t id_y, const float *rays_o, const fl
     }
     nrm = sqrtf(nrm);
     for (int i = 0; i < 3; ++i) dir[i] = (float)(dir[i] / (nrm + 1e-7));
-    calc_sh9(dir, SH);
+    calc_sh(nb, dir, SH);
 }
 
 GSO_API void gso_pixel_sh(uint32_t id_x, uint32_t id_y, const float *rays_o, const float *lefttop,
                           const float *vdx, const float *vdy, float *SH) {
-    pixel_sh(id_x, id_y, rays_o, lefttop, vdx, vdy, SH);
+    pixel_sh(9, id_x, id_y, rays_o, lefttop, vdx, vdy, SH);
 }
+
+GSO_API void gso_pixel_sh16(uint32_t id_x, uint32_t id_y, const float *rays_o, const float *lefttop,
+                            const float *vdx, const float *vdy, float *SH) {
+    pixel_sh(16, id_x, id_y, rays_o, lefttop, vdx, vdy, SH);
+}
+
+GSO_API void gso_calc_sh(int nb, const float *dir, float *out) { calc_sh(nb, dir, out); }
 
 /* ---------------------------------------------------------------------------------------
  * K7: tile rasterizer forward                  gaussian.cu:806-970
@@ -488,15 +515,15 @@ GSO_API void gso_draw(const float *pos, const float *rgb, const float *opa, cons
                       const float *rays_o, const float *lefttop, const float *vdx,
                       const float *vdy, int use_sh) {
     const uint32_t ntx = (uint32_t)(w + 15) / 16;
-    const int D = use_sh ? 27 : 3;
+    const int nb = sh_nb(use_sh), D = use_sh ? 3 * nb : 3;
     for (uint32_t id_y = 0; id_y < (uint32_t)h; ++id_y)
         for (uint32_t id_x = 0; id_x < (uint32_t)w; ++id_x) {
             uint32_t id_tile = id_x / 16 + (id_y / 16) * ntx; /* :832 */
             uint32_t start = (uint32_t)accum_idx[id_tile], end = (uint32_t)accum_idx[id_tile + 1];
             float pixel_x = (float)((id_x + 0.5 - (uint32_t)w / 2) / focal_x); /* :839-840 */
             float pixel_y = (float)((id_y + 0.5 - (uint32_t)h / 2) / focal_y);
-            float color[3] = {0, 0, 0}, accum = 1.0f, accum_weight = 0.0f, SH[9];
-            if (use_sh) pixel_sh(id_x, id_y, rays_o, lefttop, vdx, vdy, SH);
+            float color[3] = {0, 0, 0}, accum = 1.0f, accum_weight = 0.0f, SH[16];
+            if (use_sh) pixel_sh(nb, id_x, id_y, rays_o, lefttop, vdx, vdy, SH);
             for (uint32_t g = start; g < end; ++g) {
                 if (accum < 0.0001) break; /* :906, float promoted to double */
                 float a = cov[g * 4], b = cov[g * 4 + 1], c = cov[g * 4 + 2], d = cov[g * 4 + 3];
@@ -515,7 +542,7 @@ GSO_API void gso_draw(const float *pos, const float *rgb, const float *opa, cons
                 if (use_sh) { /* :936-952 */
                     for (int ch = 0; ch < 3; ++ch) {
                         float v = 0.0f;
-                        for (int s = 0; s < 9; ++s) v += SH[s] * rgb[(size_t)g * 27 + ch * 9 + s];
+                        for (int s = 0; s < nb; ++s) v += SH[s] * rgb[(size_t)g * D + ch * nb + s];
                         v = (float)(1. / (1 + expf(-v)));
                         color[ch] += v * weight;
                     }
@@ -553,7 +580,7 @@ GSO_API void gso_draw_backward(const float *pos, const float *rgb, const float *
                                const float *vdx, const float *vdy, int use_sh) {
     (void)weight_normalize; /* the reference backward ignores it too */
     const uint32_t ntx = (uint32_t)(w + 15) / 16, nty = (uint32_t)(h + 15) / 16;
-    const int D = use_sh ? 27 : 3;
+    const int nb = sh_nb(use_sh), D = use_sh ? 3 * nb : 3;
     const int NV = 2 + D + 1 + 4;
     for (uint32_t ty = 0; ty < nty; ++ty)
         for (uint32_t tx = 0; tx < ntx; ++tx) {
@@ -568,8 +595,8 @@ GSO_API void gso_draw_backward(const float *pos, const float *rgb, const float *
                     if (id_x >= (uint32_t)w || id_y >= (uint32_t)h) continue;
                     float pixel_x = (float)((id_x + 0.5 - (uint32_t)w / 2) / focal_x);
                     float pixel_y = (float)((id_y + 0.5 - (uint32_t)h / 2) / focal_y);
-                    float SH[9];
-                    if (use_sh) pixel_sh(id_x, id_y, rays_o, lefttop, vdx, vdy, SH);
+                    float SH[16];
+                    if (use_sh) pixel_sh(nb, id_x, id_y, rays_o, lefttop, vdx, vdy, SH);
                     const float *go = grad_output + ((size_t)id_x + (size_t)id_y * w) * 3;
                     const float *co = output + ((size_t)id_x + (size_t)id_y * w) * 3;
                     float color[3] = {0, 0, 0}, accum = 1.0f;
@@ -608,8 +635,8 @@ GSO_API void gso_draw_backward(const float *pos, const float *rgb, const float *
                         float cpc[3] = {0, 0, 0};
                         if (use_sh) { /* :639-652 */
                             for (int ch = 0; ch < 3; ++ch) {
-                                for (int s = 0; s < 9; ++s)
-                                    cpc[ch] += SH[s] * rgb[(size_t)g * 27 + ch * 9 + s];
+                                for (int s = 0; s < nb; ++s)
+                                    cpc[ch] += SH[s] * rgb[(size_t)g * D + ch * nb + s];
                                 cpc[ch] = (float)(1. / (1 + expf(-cpc[ch])));
                             }
                         } else {
@@ -624,7 +651,7 @@ GSO_API void gso_draw_backward(const float *pos, const float *rgb, const float *
                         if (use_sh) { /* :665-688 */
                             for (int ch = 0; ch < 3; ++ch) {
                                 float Dk = go[ch] * weight * (cpc[ch] * (1 - cpc[ch]));
-                                for (int s = 0; s < 9; ++s) row[2 + ch * 9 + s] += (double)(Dk * SH[s]);
+                                for (int s = 0; s < nb; ++s) row[2 + ch * nb + s] += (double)(Dk * SH[s]);
                             }
                         } else { /* :691-706 */
                             row[2 + 0] += (double)(go[0] * weight);
@@ -677,7 +704,7 @@ GSO_API int64_t gso_render_forward(const float *pos, const float *quat_raw, cons
                                    int32_t W, int32_t H, float fx, float fy, float thresh,
                                    const float *rays_o, const float *lefttop, const float *vdx,
                                    const float *vdy, float *image_out, int64_t *V_out) {
-    const int D = use_sh ? 27 : 3;
+    const int D = use_sh ? 3 * sh_nb(use_sh) : 3;
     int32_t padW = ((W + 15) / 16) * 16, padH = ((H + 15) / 16) * 16; /* splatter.py:259-260 */
     int32_t ntx = padW / 16, nty = padH / 16;
     float tlx = (float)(16 / (double)fx), tly = (float)(16 / (double)fy); /* :279-280 */

@@ -49,7 +49,8 @@ def test_matches_reference_golden(gpu, ci):
             assert np.array_equal(a, w), name
 
 
-@pytest.mark.parametrize("n,color_dim,act", [(1, 3, "abs"), (257, 3, "abs"), (100_003, 3, "exp"), (20_000, 27, "abs")])
+@pytest.mark.parametrize("n,color_dim,act", [(1, 3, "abs"), (257, 3, "abs"), (100_003, 3, "exp"), (20_000, 27, "abs"),
+                                              (5_000, 48, "abs")])
 def test_matches_oracle_random(gpu, n, color_dim, act):
     rng = np.random.default_rng(n)
     pos = rng.normal(size=(n, 3)).astype(np.float32)

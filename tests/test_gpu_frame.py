@@ -20,8 +20,8 @@ IMG_ATOL = 5e-5
 GRAD_RTOL = 3e-4
 
 
-def case(n, W, H, seed=7, use_sh=False, yaw=2.0):
-    scene = make_scene(n, W, H, seed=seed, use_sh=use_sh)
+def case(n, W, H, seed=7, use_sh=False, yaw=2.0, sh_degree=2):
+    scene = make_scene(n, W, H, seed=seed, use_sh=use_sh, sh_degree=sh_degree)
     cam = make_camera(W, H, yaw_deg=yaw)
     cam.tran = np.array([0.03, -0.01, 0.2], np.float32)
     return scene, cam
@@ -89,8 +89,38 @@ def test_frame_forward_4k_uses_lds_counters(gpu):
     assert r.stats().pairs == len(of.ids) > 0
 
 
-def test_frame_forward_sh(gpu):
-    check_forward(gpu, *case(8_000, 160, 96, use_sh=True))
+@pytest.mark.parametrize("sh_degree", [2, 3])
+def test_frame_forward_sh(gpu, sh_degree):
+    # degree 2 = the reference's 27 coefficients; degree 3 (48) is the extension BASELINE config 4 names
+    check_forward(gpu, *case(8_000, 160, 96, use_sh=True, sh_degree=sh_degree))
+
+
+def test_frame_sh_degree3_with_zero_band3_is_degree2(gpu):
+    """Size-independent property: 48 coefficients with a zero degree-3 band render the degree-2 scene.  (Bit-exact
+    in the oracle, tests/test_oracle_kat.py; the two kernel instantiations are compiled separately and the
+    compiler's mul+add contraction differs in a few places, so here: to the last ulp or two.)"""
+    import copy
+
+    s3, cam = case(30_000, 320, 208, seed=21, use_sh=True, sh_degree=3)
+    c = s3.rgb.reshape(-1, 3, 16)
+    c[:, :, 9:] = 0
+    s2 = copy.deepcopy(s3)
+    s2.rgb = np.ascontiguousarray(c[:, :, :9]).reshape(-1, 27)
+    gimg = torch.from_numpy(np.random.default_rng(3).normal(size=(208, 320, 3)).astype(np.float32)).to(gpu)
+    outs = []
+    for sc in (s3, s2):
+        params = to_torch(sc, gpu, requires_grad=True)
+        r = FrameRenderer(gpu, max_pairs=400_000, training=True)
+        img = r.render(*params, cam)
+        img.backward(gimg)
+        outs.append((img.detach().clone(), [t.grad.clone() for t in params]))
+    (i3, g3), (i2, g2) = outs
+    assert float((i3 - i2).abs().max()) <= 2.5e-7
+    for a, b in zip(g3[:4], g2[:4]):
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+    b3 = g3[4].view(-1, 3, 16)
+    assert float((b3[:, :, :9] - g2[4].view(-1, 3, 9)).abs().max()) <= 2e-6 * float(g2[4].abs().max())
+    assert float(b3[:, :, 9:].abs().max()) > 0  # the zero band still receives its gradient
 
 
 @pytest.mark.parametrize("sort_mode", [0, 1, 2])
@@ -102,9 +132,11 @@ def test_frame_forward_dense_tiles_multi_chunk(gpu, sort_mode):
     assert np.diff(of.accum).max() > 600
 
 
-@pytest.mark.parametrize("use_sh", [False, True])
+@pytest.mark.parametrize("use_sh", [False, True, 3])
 def test_frame_backward_parity(gpu, use_sh):
-    scene, cam = case(9_000 if use_sh else 20_000, 160, 112, seed=11, use_sh=use_sh)
+    # use_sh: False = rgb logits, True = the reference's degree-2 SH, 3 = the degree-3 extension
+    scene, cam = case(9_000 if use_sh else 20_000, 160, 112, seed=11, use_sh=bool(use_sh),
+                      sh_degree=3 if use_sh == 3 else 2)
     of, r, _ = check_forward(gpu, scene, cam, training=True)
     rng = np.random.default_rng(4)
     gimg = rng.normal(size=of.image.shape).astype(np.float32)

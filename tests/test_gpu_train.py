@@ -141,6 +141,33 @@ def test_trainer_improves_psnr(gpu):
     assert psnr1 > psnr0 + 3.0, (psnr0, psnr1)
 
 
+def test_trainer_fits_degree3_sh_colours(gpu):
+    """The whole step (render fwd/bwd with 48 SH coefficients per Gaussian, loss, fused Adam) on the degree-3
+    extension: the perturbed coefficients are pulled back towards the target renders."""
+    from gs_frame import FrameRenderer
+    from gs_scene import make_camera, make_scene
+    from gs_train import TrainOptions, Trainer
+
+    W, H = 160, 128
+    scene, cam = make_scene(3000, W, H, seed=10, use_sh=True, sh_degree=3), make_camera(W, H)
+    gt = to_torch(scene, gpu)
+    target, _ = FrameRenderer(gpu, max_pairs=1 << 16).forward(*gt, cam)
+    target = target.clone()
+    start = [t.clone() for t in gt]
+    noise = np.random.default_rng(2).normal(0, 0.5, tuple(start[4].shape)).astype(np.float32)
+    start[4] = start[4] + torch.from_numpy(noise).to(gpu)
+    tr = Trainer(start, [cam], [target], TrainOptions(n_iters=400, n_iters_warmup=10), max_pairs=1 << 16)
+    assert tr.flat.params[4].shape[1] == 48
+    img0, _ = tr.renderer.forward(*tr.flat.params, cam)
+    psnr0 = Trainer.psnr(img0, target)
+    losses = torch.stack([tr.train_step(it, 0).clone() for it in range(120)]).cpu().numpy()
+    img1, _ = tr.renderer.forward(*tr.flat.params, cam)
+    psnr1 = Trainer.psnr(img1, target)
+    assert np.isfinite(losses).all()
+    assert losses[-1, 0] < 0.8 * losses[1, 0]
+    assert psnr1 > psnr0 + 1.5, (psnr0, psnr1)
+
+
 def test_trainer_with_densification(gpu):
     """The reference's schedule (train.py:86-91, 141-190) on a small scene: the statistic is cleared
     grad_accum_iters before every adaptive_control, N changes there, Adam restarts, training stays finite."""

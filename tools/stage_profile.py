@@ -5,8 +5,9 @@ from gs_frame import FrameRenderer
 from gs_scene import CONFIGS, make_camera, make_scene
 dev=torch.device('cuda:0')
 for cfg in (sys.argv[1:] or ('cfg2','cfg4','cfg5')):
-    n,W,H,use_sh=CONFIGS[cfg]
-    scene=make_scene(n,W,H,seed=2023,use_sh=use_sh); cam=make_camera(W,H)
+    deg=3 if cfg.endswith('_deg3') else 2   # e.g. cfg4_deg3: BASELINE config 4 with true degree-3 SH (48 coefficients)
+    n,W,H,use_sh=CONFIGS[cfg.replace('_deg3','')]
+    scene=make_scene(n,W,H,seed=2023,use_sh=use_sh,sh_degree=deg); cam=make_camera(W,H)
     params=[torch.from_numpy(a).to(dev) for a in (scene.pos,scene.quat,scene.scale,scene.opa,scene.rgb)]
     r=FrameRenderer(dev,max_pairs=1<<20,training=True,auto_grow=True)
     r.forward(*params,cam); st=r.stats(); r.max_pairs=int(st.pairs*1.1)+4096; r.auto_grow=False
