@@ -110,10 +110,18 @@ __device__ __forceinline__ void load_pixel_inputs(const BwdIn &I, const RasterGe
     }
 }
 
-// waves per workgroup of the systolic kernel: the degree-3 SH basis records need 20 KiB of LDS per wave
+// waves per workgroup of the systolic kernel: the degree-3 SH basis records need 20 KiB of LDS per wave, and
+// single-wave workgroups pack the CU's 160 KiB best (the waves of a workgroup never synchronise anyway)
 template <int CDIM>
 struct BwdCfg {
-    static constexpr int WPB = CDIM == 48 ? 2 : 4;
+    static constexpr int WPB = CDIM == 48 ? 1 : 4;
+    // What is constant per pixel (dL/dC, pixel centre) either rides the DPP chain with the pixel's running state or
+    // is read by every lane from an LDS table indexed by the pixel it currently holds.  A DPP move costs as much
+    // SIMD time as three plain instructions (tools/ubench/pk_rate.hip), a per-lane LDS read costs no VALU slot but
+    // LDS bandwidth and 4 KiB per wave.  Measured (cfg2 / cfg4, same run): the table is 9 % faster without SH
+    // (issue-bound, 5 waves per SIMD) and 2 % slower with SH (register-limited to 2-3 waves, latency-bound, and
+    // the SH basis records already load the LDS pipe).
+    static constexpr bool TABLE = CDIM == 3;
     static constexpr int NB = CDIM > 3 ? CDIM / 3 : 1;        // SH basis functions per channel
     static constexpr int SHS = CDIM == 48 ? 20 : NB;          // LDS record stride (floats): 9 is conflict-free for
                                                               // scalar reads, 16 + 4 keeps float4 reads aligned
@@ -127,8 +135,11 @@ __global__ void __launch_bounds__(64 * BwdCfg<CDIM>::WPB) raster_backward_kernel
     // segment streams through the lanes, the next one is prefetched into registers and then
     // written to the other half of the ring.  ~6 KiB of LDS per wave keeps occupancy
     // register-limited (the dependent DPP chain needs >= 5 waves per SIMD to stay hidden).
-    constexpr int NF = 2;  // float4 feed records per pixel
+    constexpr bool TABLE = BwdCfg<CDIM>::TABLE;
+    constexpr int NF = TABLE ? 1 : 2;  // float4 feed records per pixel: (T, rho, -, -) | (T, rho, px, py), (dL/dC, -)
     __shared__ float4 s_feed[WPB][2][NF][64];
+    __shared__ float4 s_pix[TABLE ? WPB : 1][TABLE ? 256 : 1];  // TABLE: (dL/dC rgb, pixel centre x) of tile pixel p
+    __shared__ float s_py[TABLE ? WPB : 1][16];                 // TABLE: pixel centre y of tile row p >> 4
     // SH only: the 9 (16) basis values of a pixel never change while it travels, so they do not ride the DPP chain
     // (9 moves = 28 ns of SIMD time per step, tools/ubench/pk_rate.hip); they are staged once per bucket and
     // every lane reads the record of the pixel it currently holds (3-4 LDS reads, no VALU issue slots).
@@ -180,7 +191,12 @@ __global__ void __launch_bounds__(64 * BwdCfg<CDIM>::WPB) raster_backward_kernel
         // (gaussian.cu:716-722), so one scalar travels instead of three colour channels
         const float rho = pg0 * (pf0 - pc.y) + pg1 * (pf1 - pc.z) + pg2 * (pf2 - pc.w);
         s_feed[wave][buf][0][lane] = make_float4(pc.x, rho, my_px, py);
-        s_feed[wave][buf][1][lane] = make_float4(pg0, pg1, pg2, 0.f);
+        if (TABLE) {
+            s_pix[wave][seg * 64 + lane] = make_float4(pg0, pg1, pg2, my_px);
+            if ((lane & 15) == 0) s_py[wave][seg * 4 + (lane >> 4)] = py;
+        } else {
+            s_feed[wave][buf][NF - 1][lane] = make_float4(pg0, pg1, pg2, 0.f);
+        }
         if (CDIM > 3) {
             float SH[NB];
             raster_pixel_sh<NB>(id_x, id_y, G, SH);
@@ -191,6 +207,12 @@ __global__ void __launch_bounds__(64 * BwdCfg<CDIM>::WPB) raster_backward_kernel
         __builtin_amdgcn_wave_barrier();
     };
     load_segment(0);
+    if (TABLE) {
+        // lanes that hold no pixel yet read the records of segment 3 before it is staged: their T is exactly zero,
+        // but 0 x (whatever the previous kernel left in LDS, e.g. the tile sort's all-ones padding = NaN) must stay 0
+        s_pix[wave][192 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < 4) s_py[wave][12 + lane] = 0.f;
+    }
     if (CDIM > 3) {
         // lanes that hold no pixel yet read records of segments that are not staged yet: their weight is exactly
         // zero, but 0 x (whatever the previous kernel left in LDS, e.g. the tile sort's all-ones padding = NaN)
@@ -240,18 +262,26 @@ __global__ void __launch_bounds__(64 * BwdCfg<CDIM>::WPB) raster_backward_kernel
 #pragma unroll 2
         for (int t = 0; t < nsteps; ++t) {
             // feed for lane 0 (broadcast LDS reads; while draining feed T = 0)
-            const float4 f0 = s_feed[wave][buf][0][t], f1 = s_feed[wave][buf][1][t];
+            const float4 f0 = s_feed[wave][buf][0][t];
             const float fT = feeding ? f0.x : 0.f;
             // state entering this lane: lane l-1's output of the previous step; lane 0 takes the feed
             const float T = gs_wave_shr1(fT, oT);
             float rho = gs_wave_shr1(f0.y, orho);
-            const float px = gs_wave_shr1(f0.z, opx), py = gs_wave_shr1(f0.w, opy);
-            const float g0 = gs_wave_shr1(f1.x, og0), g1 = gs_wave_shr1(f1.y, og1), g2 = gs_wave_shr1(f1.z, og2);
+            // the pixel in this lane entered lane 0 `lane` steps ago: p = 64 seg + t - lane (lanes that hold no
+            // pixel yet / any more read a valid but irrelevant record: their T is 0)
+            const int p = (seg * 64 + t - lane) & 255;
+            float px, py, g0, g1, g2;
+            if (TABLE) {
+                const float4 pr = s_pix[wave][p];
+                g0 = pr.x, g1 = pr.y, g2 = pr.z, px = pr.w, py = s_py[wave][p >> 4];
+            } else {
+                const float4 f1 = s_feed[wave][buf][NF - 1][t];
+                px = gs_wave_shr1(f0.z, opx), py = gs_wave_shr1(f0.w, opy);
+                g0 = gs_wave_shr1(f1.x, og0), g1 = gs_wave_shr1(f1.y, og1), g2 = gs_wave_shr1(f1.z, og2);
+            }
             float sh[NB];
             if (CDIM > 3) {
-                // the pixel in this lane entered lane 0 `lane` steps ago: p = 64 seg + t - lane (lanes that hold
-                // no pixel yet / any more read a valid but irrelevant record: their T is 0)
-                const float *rec = &s_sh[wave][((seg * 64 + t - lane) & 255) * SHS];
+                const float *rec = &s_sh[wave][p * SHS];
                 if (NB % 4 == 0) {
 #pragma unroll
                     for (int q = 0; q < NB / 4; ++q) {
