@@ -127,9 +127,14 @@ struct BwdCfg {
                                                               // scalar reads, 16 + 4 keeps float4 reads aligned
 };
 
-template <int CDIM, bool FRAME>
+// SIG (reference API only): the `sigmoid` flag of draw / draw_backward -- alpha is squashed,
+// alpha = 2 / (1 + e^-a) - 1 with a = p0 G opa, p0 = (pi/2) rsqrt(det + 1e-7) (gaussian.cu:593-594, 918, 930).
+// p0 is folded into the lane's opacity; its own cov gradient (gaussian.cu:622-630) only needs sum(dL/da G), which
+// is the opacity accumulator, so the loop pays two extra transcendentals and three plain instructions.
+template <int CDIM, bool FRAME, bool SIG = false>
 __global__ void __launch_bounds__(64 * BwdCfg<CDIM>::WPB) raster_backward_kernel(RasterSrc S, RasterGeom G, BwdIn I,
                                                                               BwdOut O) {
+    static_assert(!(FRAME && SIG), "the frame path has no alpha squashing (splatter.py:627 passes sigmoid=False)");
     constexpr int WPB = BwdCfg<CDIM>::WPB, NB = BwdCfg<CDIM>::NB, SHS = BwdCfg<CDIM>::SHS;
     // Feed ring: the 256 pixel states of a bucket enter lane 0 in four segments of 64; while a
     // segment streams through the lanes, the next one is prefetched into registers and then
@@ -241,7 +246,12 @@ __global__ void __launch_bounds__(64 * BwdCfg<CDIM>::WPB) raster_backward_kernel
     }
     float cA = 0, cB = 0, cC = 0;
     if (gvalid) raster_conic(g, cA, cB, cC);
-    const float opa = gvalid ? g.opa : 0.f;  // opacity 0 => alpha 0 => state passes through unchanged
+    float opa = gvalid ? g.opa : 0.f;  // opacity 0 => alpha 0 => state passes through unchanged
+    float p0 = 1.0f;
+    if (SIG) {  // the same folding as the forward kernel (raster_fwd.hip)
+        p0 = 1.5707963268f * rsqrtf(raster_det(g.a, g.b, g.c, g.d) + 1e-7f);
+        opa *= p0;
+    }
     write_segment(0, 0);
 
     // gradient accumulators
@@ -301,7 +311,8 @@ __global__ void __launch_bounds__(64 * BwdCfg<CDIM>::WPB) raster_backward_kernel
             const float q = fmaf(cC * dy, dy, dx * fmaf(-cB, dy, cA * dx));  // same evaluation order as the forward
             const float Gv = gs_exp2(-q);
             const bool live = T > GS_T_STOP;
-            const float alpha = live ? Gv * opa : 0.f;
+            const float araw = live ? Gv * opa : 0.f;  // before squashing
+            const float alpha = SIG ? 2.0f / (__expf(-araw) + 1.0f) - 1.0f : araw;
             const float w = alpha * T;
             if (CDIM > 3) {
                 float v0 = 0.f, v1 = 0.f, v2 = 0.f;
@@ -321,6 +332,7 @@ __global__ void __launch_bounds__(64 * BwdCfg<CDIM>::WPB) raster_backward_kernel
             const float one_m = 1.0f - alpha;
             float d_alpha = fmaf(T, gc, -(rho * gs_rcp(one_m + 1e-7f)));
             d_alpha = live ? d_alpha : 0.f;
+            if (SIG) d_alpha *= (alpha + 1.0f) - 0.5f * (alpha + 1.0f) * (alpha + 1.0f);  // d squash / da, :727
             if (CDIM > 3) {
                 const float D0 = g0 * w * (col0 * (1.0f - col0)), D1 = g1 * w * (col1 * (1.0f - col1)),
                             D2 = g2 * w * (col2 * (1.0f - col2));
@@ -336,7 +348,7 @@ __global__ void __launch_bounds__(64 * BwdCfg<CDIM>::WPB) raster_backward_kernel
                 Sc2 = fmaf(g2, w, Sc2);
             }
             Sopa = fmaf(d_alpha, Gv, Sopa);
-            const float s = d_alpha * alpha;
+            const float s = d_alpha * araw;
             const float sdx = s * dx, sdy = s * dy;
             Sx += sdx;
             Sy += sdy;
@@ -362,10 +374,20 @@ __global__ void __launch_bounds__(64 * BwdCfg<CDIM>::WPB) raster_backward_kernel
     const float Su = Sq * GS_LN2;  // u = -ln G = q ln 2
     const float gx = GS_LN2 * (2.0f * cA * Sx - cB * Sy);
     const float gy = GS_LN2 * (2.0f * cC * Sy - cB * Sx);
-    const float ga = iPn * (-Syy + 2.0f * g.d * Su);
-    const float gb = iPn * (Sxy - 2.0f * g.c * Su);
-    const float gc = iPn * (Sxy - 2.0f * g.b * Su);
-    const float gd = iPn * (-Sxx + 2.0f * g.a * Su);
+    float ga = iPn * (-Syy + 2.0f * g.d * Su);
+    float gb = iPn * (Sxy - 2.0f * g.c * Su);
+    float gc = iPn * (Sxy - 2.0f * g.b * Su);
+    float gd = iPn * (-Sxx + 2.0f * g.a * Su);
+    if (SIG) {
+        // dp0/d{a,b,c,d} = k0 (-d, c, b, -a), k0 = p0^3 / (2 (pi/2)^2) (gaussian.cu:622-626), times
+        // sum_pixels dL/da G opa_raw (:740-744); Sopa so far is sum dL/da G
+        const float k = 0.5f * (p0 * p0 * p0) / (1.5707963268f * 1.5707963268f) * Sopa * g.opa;
+        ga -= k * g.d;
+        gb += k * g.c;
+        gc += k * g.b;
+        gd -= k * g.a;
+        Sopa *= p0;  // dL/dopa = sum dL/da (p0 G)
+    }
     if (FRAME) {
         const uint4 rc = O.rects[gid];
         const uint32_t y0 = rc.x & 0xffff, x0 = rc.y & 0xffff, x1 = rc.y >> 16;
@@ -577,6 +599,15 @@ __global__ void __launch_bounds__(64) raster_backward_tail_kernel(RasterSrc S, R
     }
 }
 
+// sigmoid=True of the reference API: ceil buckets in the systolic kernel, no tail kernel (a rarely used flag)
+template <int CDIM>
+void launch_bwd_sig(const RasterSrc &S, const RasterGeom &G, const BwdIn &I, const BwdOut &O, int64_t max_buckets,
+                    hipStream_t stream) {
+    constexpr int WPB = BwdCfg<CDIM>::WPB;
+    const int grid = (int)gs_div_up(max_buckets > 0 ? max_buckets : 1, WPB);
+    hipLaunchKernelGGL((raster_backward_kernel<CDIM, false, true>), dim3(grid), dim3(64 * WPB), 0, stream, S, G, I, O);
+}
+
 template <int CDIM, bool FRAME>
 void launch_bwd(const RasterSrc &S, const RasterGeom &G, const BwdIn &I, const BwdOut &O, int64_t max_buckets,
                 hipStream_t stream) {
@@ -655,11 +686,6 @@ extern "C" int gs_draw_backward(const float *pos, const float *rgb, const float 
     (void)weight_normalize;  // the reference backward ignores it as well (gaussian.cu:440-803)
     GS_CHECK_ARG(h > 0 && w > 0 && (h % 16) == 0 && (w % 16) == 0, "h, w must be positive multiples of 16");
     GS_CHECK_ARG(M >= 0, "M < 0");
-    if (sigmoid) {
-        gs_set_error("gs_draw_backward: sigmoid=True (alpha squashing) is not implemented; the reference pipeline "
-                     "always passes False (splatter.py:627)");
-        return GS_E_UNSUPPORTED;
-    }
     if (M == 0) return 0;
     GS_CHECK_ARG(pos && rgb && opa && cov && tile_n_point_accum && output && grad_output && grad_pos && grad_rgb &&
                      grad_opa && grad_cov,
@@ -696,15 +722,20 @@ extern "C" int gs_draw_backward(const float *pos, const float *rgb, const float 
         }
     }
     // 1. replay the forward to checkpoint (T, C_run) at every bucket boundary
-    int rc = gs_raster_forward_ref(S, G, tile_n_point_accum, nullptr, use_sh_coeff, 0, 0, ws.ckpt, ws.tile_nproc, s);
+    int rc = gs_raster_forward_ref(S, G, tile_n_point_accum, nullptr, use_sh_coeff, sigmoid, 0, ws.ckpt,
+                                   ws.tile_nproc, s);
     if (rc) return rc;
     // 2. bucket work list
     hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, s, ws.tile_nproc, G.ntx * G.nty,
-                       ws.bucket_offsets, ws.n_buckets, use_sh_coeff ? 0 : 1);
+                       ws.bucket_offsets, ws.n_buckets, (use_sh_coeff || sigmoid) ? 0 : 1);
     // 3. systolic backward, one wave per bucket, one output row per pair
     BwdIn I = {output, grad_output, ws.ckpt, ws.tile_nproc, ws.bucket_offsets, tile_n_point_accum};
     BwdOut O = {nullptr, nullptr, nullptr, 0, grad_pos, grad_rgb, grad_opa, grad_cov};
-    if (use_sh_coeff)
+    if (sigmoid && use_sh_coeff)
+        launch_bwd_sig<27>(S, G, I, O, ws.max_buckets, s);
+    else if (sigmoid)
+        launch_bwd_sig<3>(S, G, I, O, ws.max_buckets, s);
+    else if (use_sh_coeff)
         launch_bwd<27, false>(S, G, I, O, ws.max_buckets, s);
     else
         launch_bwd<3, false>(S, G, I, O, ws.max_buckets, s);

@@ -354,9 +354,12 @@ int gs_raster_forward_ref(const RasterSrc &S, const RasterGeom &G, const int32_t
                           int sigmoid, int weight_normalize, float4 *ckpt, uint32_t *tile_nproc,
                           hipStream_t stream) {
     if (ckpt) {
-        if (sigmoid) return GS_E_UNSUPPORTED;
-        if (use_sh)
+        if (use_sh && sigmoid)
+            launch_fwd<27, false, true, true>(S, G, accum, res, nullptr, ckpt, tile_nproc, weight_normalize, stream);
+        else if (use_sh)
             launch_fwd<27, false, true, false>(S, G, accum, res, nullptr, ckpt, tile_nproc, weight_normalize, stream);
+        else if (sigmoid)
+            launch_fwd<3, false, true, true>(S, G, accum, res, nullptr, ckpt, tile_nproc, weight_normalize, stream);
         else
             launch_fwd<3, false, true, false>(S, G, accum, res, nullptr, ckpt, tile_nproc, weight_normalize, stream);
     } else if (use_sh) {

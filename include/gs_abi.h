@@ -37,7 +37,7 @@ extern "C" {
 #define GS_ABI_VERSION 1
 
 #define GS_E_INVALID (-1)   /* bad argument (null pointer, negative size, bad enum)   */
-#define GS_E_UNSUPPORTED (-2) /* valid in the reference but not implemented here      */
+#define GS_E_UNSUPPORTED (-2) /* valid in the reference but not implemented here (none at present) */
 #define GS_E_CAPACITY (-3)  /* workspace too small for this frame                     */
 
 typedef void *gs_stream_t;

@@ -230,6 +230,44 @@ def test_draw_flags_weight_normalize_and_sigmoid(gpu):
         assert np.abs(res.cpu().numpy() - ref).max() < 2e-4, (wn, sg)
 
 
+@pytest.mark.parametrize("use_sh", [False, True])
+@pytest.mark.parametrize("saturated", [False, True])
+def test_draw_backward_sigmoid_flag(gpu, use_sh, saturated):
+    """sigmoid=True through forward AND backward (gaussian.cu:593-594, 622-630, 727, 918, 930).  `saturated`:
+    ordinary opacities, where p0 ~ 1e3 drives the squashed alpha to 1 and pixels stop after a few Gaussians;
+    otherwise opacities scaled so that every pixel stays live (the regime tests/test_ref_live.py pins against
+    the reference kernels)."""
+    from renderer import draw
+
+    scene, cam = small_case(n=9000, W=160, H=96, seed=14, use_sh=use_sh)
+    of = _sorted_inputs(scene, cam)
+    grid, rays = of.grid, of.rays
+    assert np.diff(of.accum).max() > 64
+    opa = of.s_opa
+    if not saturated:
+        det = of.s_cov[:, 0] * of.s_cov[:, 3] - of.s_cov[:, 1] * of.s_cov[:, 2]
+        opa = (of.s_opa * 0.02 / (np.pi / 2 / np.sqrt(det + 1e-7))).astype(np.float32)
+    t = [dev(a, gpu).requires_grad_(True) for a in (of.s_pos, of.s_rgb, opa, of.s_cov.reshape(-1, 2, 2))]
+    accum = dev(of.accum, gpu)
+    rv = [dev(v, gpu) for v in (rays.rays_o, rays.lefttop, rays.dx, rays.dy)]
+    img = draw(*t, accum, grid.padded_height, grid.padded_width, grid.focal_x, grid.focal_y, False, True, use_sh,
+               True, *rv)
+    kw = dict(use_sh=use_sh, fast=True, sigmoid=True, rays_o=rays.rays_o, lefttop=rays.lefttop, vdx=rays.dx,
+              vdy=rays.dy)
+    want = oracle.draw(of.s_pos, of.s_rgb, opa, of.s_cov, of.accum, grid.padded_height, grid.padded_width,
+                       grid.focal_x, grid.focal_y, **kw)
+    assert np.abs(img.detach().cpu().numpy() - want).max() < 2e-4
+    gpad = np.random.default_rng(10).normal(size=want.shape).astype(np.float32)
+    img.backward(dev(gpad, gpu))
+    # the backward replays the forward from ITS image argument: hand the oracle the same image the GPU produced
+    ref = oracle.draw_backward(of.s_pos, of.s_rgb, opa, of.s_cov, of.accum, img.detach().cpu().numpy(), gpad,
+                               grid.focal_x, grid.focal_y, **kw)
+    got = [x.grad.cpu().numpy() for x in t]
+    for g, r, name in zip(got, ref, ("pos", "rgb", "opa", "cov")):
+        assert np.isfinite(g).all(), name
+        assert rel_err(g.reshape(r.shape), r) < (2e-3 if saturated else GRAD_RTOL), (name, rel_err(g.reshape(r.shape), r))
+
+
 def test_draw_empty_and_errors(gpu):
     import gaussian
 

@@ -52,3 +52,30 @@ def test_reference_backward_defect_between_chunks_is_real():
         res[n] = (int(np.diff(of.accum).max()), max(rel_err(x, y) for x, y in zip(a, b)))
     assert res[330][0] <= 160 and res[330][1] < 2e-6
     assert res[420][0] > 160 and res[420][1] > 1e-2
+
+
+@pytest.mark.parametrize("use_sh", [False, True])
+def test_sigmoid_flag_forward_and_backward_vs_reference_kernels(use_sh):
+    """draw / draw_backward with sigmoid=True (alpha squashing, gaussian.cu:593-594, 622-630, 727, 918, 930) --
+    never used by the reference's own pipeline, but part of the operator.  The oracle's restatement is pinned
+    against the reference kernels where those are well defined: one backward chunk and every pixel still active
+    (p0 = (pi/2) rsqrt(det) is ~1e3 in normalised image units, so ordinary opacities saturate alpha, pixels stop
+    early and the reference's partial-mask shuffles, gaussian.cu:675-687, take over)."""
+    scene = make_scene(300, 48, 32, seed=12, use_sh=use_sh)
+    cam = make_camera(48, 32, yaw_deg=1.0)
+    of = OracleFrame(scene, cam)
+    assert 0 < np.diff(of.accum).max() <= 160
+    det = of.s_cov[:, 0] * of.s_cov[:, 3] - of.s_cov[:, 1] * of.s_cov[:, 2]
+    opa = (of.s_opa * 0.02 / (np.pi / 2 / np.sqrt(det + 1e-7))).astype(np.float32)  # raw alpha <= 0.02
+    r, grid = of.rays, of.grid
+    kw = dict(use_sh=use_sh, fast=True, sigmoid=True, rays_o=r.rays_o, lefttop=r.lefttop, vdx=r.dx, vdy=r.dy)
+    a = oracle.draw(of.s_pos, of.s_rgb, opa, of.s_cov, of.accum, grid.padded_height, grid.padded_width,
+                    grid.focal_x, grid.focal_y, **kw)
+    b = ref.draw(of.s_pos, of.s_rgb, opa, of.s_cov, of.accum, grid.padded_height, grid.padded_width,
+                 grid.focal_x, grid.focal_y, **kw)
+    assert np.array_equal(a, b) and a.max() > 0.01
+    g = np.random.default_rng(2).normal(size=a.shape).astype(np.float32)
+    ga = oracle.draw_backward(of.s_pos, of.s_rgb, opa, of.s_cov, of.accum, a, g, grid.focal_x, grid.focal_y, **kw)
+    gb = ref.draw_backward(of.s_pos, of.s_rgb, opa, of.s_cov, of.accum, a, g, grid.focal_x, grid.focal_y, **kw)
+    for x, y, name in zip(ga, gb, ("pos", "rgb", "opa", "cov")):
+        assert rel_err(x, y) < 1e-6, (name, rel_err(x, y))
