@@ -155,7 +155,6 @@ __global__ void __launch_bounds__(1024) scan_block_sums_kernel(const uint32_t *_
 #define GS_EMIT_SOLO 16
 __global__ void __launch_bounds__(256) emit_pairs_kernel(const uint32_t *__restrict__ tiles_touched,
                                                         const uint4 *__restrict__ rects,
-                                                        const float4 *__restrict__ rec_geom,
                                                         const uint32_t *__restrict__ block_offsets, int64_t n,
                                                         uint32_t ntx, uint64_t *__restrict__ keys,
                                                         uint32_t *__restrict__ vals, uint64_t max_pairs,
@@ -175,7 +174,6 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(const uint32_t *__restr
     uint4 rc = make_uint4(0, 0, 0, 0);
     if (cnt) rc = rects[pid];
     const uint32_t dbits = rc.z;
-    (void)rec_geom;
     const uint32_t y0 = rc.x & 0xffff, x0 = rc.y & 0xffff, x1 = rc.y >> 16;
     const uint32_t wdt = x1 - x0;
     if (cnt && cnt <= GS_EMIT_SOLO) {
@@ -291,14 +289,13 @@ int gs_stage_scan_emit(const gs_frame *f, const gs_frame_ws &ws, hipStream_t str
                        nblk, ws.counters, (unsigned long long)f->max_pairs);
     GS_CHECK_LAUNCH();
     hipLaunchKernelGGL(emit_pairs_kernel, dim3(nblk), dim3(256), 0, stream, ws.tiles_touched, ws.rects,
-                       ws.rec_geom, ws.block_offsets, f->N, (uint32_t)G.ntx, ws.keys_a, ws.vals_a,
+                       ws.block_offsets, f->N, (uint32_t)G.ntx, ws.keys_a, ws.vals_a,
                        (uint64_t)f->max_pairs, ws.pair_offsets);
     GS_CHECK_LAUNCH();
     return 0;
 }
 
 int gs_stage_tile_ranges(const gs_frame *f, const gs_frame_ws &ws, const uint64_t *sorted_keys, hipStream_t stream) {
-    gs_frame_geom G = gs_frame_geometry(f);
     // ws.tile_ranges was cleared by the frame-start memset (it sits right behind the counters)
     int grid = (int)(gs_div_up(f->max_pairs, 256) < 4096 ? gs_div_up(f->max_pairs, 256) : 4096);
     if (grid < 1) grid = 1;

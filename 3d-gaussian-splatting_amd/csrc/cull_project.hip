@@ -333,7 +333,7 @@ __device__ __forceinline__ void activate(const float qraw[4], const float sraw[3
 __global__ void __launch_bounds__(256) frame_project_kernel(
     const float *__restrict__ pos, const float4 *__restrict__ quat, const float *__restrict__ scale,
     const float *__restrict__ opa, const float *__restrict__ rgb, int64_t n, ProjectParams P,
-    float4 *__restrict__ rec_geom, float4 *__restrict__ rec_cov, float4 *__restrict__ rec_color,
+    float4 *__restrict__ rec_geom,
     uint32_t *__restrict__ tiles_touched, uint4 *__restrict__ rects, uint32_t *__restrict__ block_sums,
     uint32_t *__restrict__ block_vis) {
     const int64_t pid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -365,8 +365,6 @@ __global__ void __launch_bounds__(256) frame_project_kernel(
         rec[1] = c;
         rec[2] = col;
         rec[3] = make_float4(cA, cB, cC, 0.f);
-        (void)rec_cov;
-        (void)rec_color;
         tiles_touched[pid] = cnt;
         rects[pid] = make_uint4(rc.x, rc.y, __float_as_uint(g.z), cnt);
     }
@@ -394,7 +392,7 @@ __global__ void __launch_bounds__(256) frame_project_kernel(
 template <int CDIM>
 __global__ void __launch_bounds__(256) frame_project_backward_kernel(
     const float *__restrict__ pos, const float4 *__restrict__ quat, const float *__restrict__ scale,
-    const float *__restrict__ rgb, int64_t n, ProjectParams P, const float4 *__restrict__ rec_geom,
+    int64_t n, ProjectParams P, const float4 *__restrict__ rec_geom,
     const float4 *__restrict__ rec_color, const float4 *__restrict__ rows,
     const uint32_t *__restrict__ pair_offsets, const uint32_t *__restrict__ tiles_touched, uint64_t max_pairs,
     float *__restrict__ grad_pos,
@@ -502,7 +500,6 @@ __global__ void __launch_bounds__(256) frame_project_backward_kernel(
 #pragma unroll
         for (int k = 1; k < CDIM; ++k) grad_rgb[pid * CDIM + k] = vis ? gsh[k - 1] : 0.f;
     }
-    (void)rgb;
 }
 
 inline int grid_for(int64_t n, int block) {
@@ -606,7 +603,7 @@ int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t strea
     ProjectParams P = make_params(f);
     int nblk = (int)gs_div_up(f->N, 256);
     hipLaunchKernelGGL(frame_project_kernel, dim3(nblk), dim3(256), 0, stream, f->pos, (const float4 *)f->quat,
-                       f->scale, f->opa, f->rgb, f->N, P, ws.rec_geom, ws.rec_cov, ws.rec_color,
+                       f->scale, f->opa, f->rgb, f->N, P, ws.rec_geom,
                        ws.tiles_touched, ws.rects, ws.block_sums, ws.block_vis);
     GS_CHECK_LAUNCH();
     return 0;
@@ -618,7 +615,7 @@ int gs_stage_project_backward(const gs_frame *f, const gs_frame_ws &ws, float *g
     int nblk = (int)gs_div_up(f->N, 256);
 #define GS_LAUNCH_PROJECT_BWD(CD)                                                                                  \
     hipLaunchKernelGGL(frame_project_backward_kernel<CD>, dim3(nblk), dim3(256), 0, stream, f->pos,              \
-                       (const float4 *)f->quat, f->scale, f->rgb, f->N, P, ws.rec_geom, ws.rec_color,             \
+                       (const float4 *)f->quat, f->scale, f->N, P, ws.rec_geom, ws.rec_color,                     \
                        (const float4 *)ws.rows, ws.pair_offsets, ws.tiles_touched, (uint64_t)f->max_pairs,        \
                        grad_pos, (float4 *)grad_quat, grad_scale, grad_opa, grad_rgb)
     if (f->color_dim == 48)

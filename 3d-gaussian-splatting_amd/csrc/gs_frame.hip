@@ -95,23 +95,29 @@ struct StageTimer {
     int n = 0;
     bool on;
     hipStream_t s;
+    bool ok = true;  // any event call failed: finish() reports it instead of returning garbage times
     StageTimer(bool enabled, hipStream_t stream) : on(enabled), s(stream) {
+        for (auto &e : ev) e = nullptr;
         if (on)
-            for (auto &e : ev) hipEventCreate(&e);
+            for (auto &e : ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     }
     ~StageTimer() {
-        if (on)
-            for (auto &e : ev) hipEventDestroy(e);
+        for (auto &e : ev)
+            if (e) (void)hipEventDestroy(e);
     }
     void mark() {
-        if (on && n <= GS_N_STAGES) hipEventRecord(ev[n++], s);
+        if (on && ok && n <= GS_N_STAGES) ok = hipEventRecord(ev[n++], s) == hipSuccess;
     }
     // ms[i] = ev[i+1] - ev[i]; ms[last] = total
     int finish(float *ms, int n_stages) {
         if (!on) return 0;
+        if (!ok || n < 2) {
+            gs_set_error("stage timer: hipEvent create / record failed");
+            return GS_E_INVALID;
+        }
         GS_HIP(hipEventSynchronize(ev[n - 1]));
-        for (int i = 0; i + 1 < n && i < n_stages - 1; ++i) hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]);
-        hipEventElapsedTime(&ms[n_stages - 1], ev[0], ev[n - 1]);
+        for (int i = 0; i + 1 < n && i < n_stages - 1; ++i) GS_HIP(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
+        GS_HIP(hipEventElapsedTime(&ms[n_stages - 1], ev[0], ev[n - 1]));
         return 0;
     }
 };
@@ -185,7 +191,7 @@ static int frame_backward_impl(const gs_frame *f, const float *grad_image, float
     sorted_buffers(f, ws, &skeys, &sids, &okeys);
     StageTimer tm(stage_ms != nullptr, s);
     tm.mark();
-    if ((rc = gs_stage_raster_backward(f, ws, sids, grad_image, grad_rgb, s))) return rc;
+    if ((rc = gs_stage_raster_backward(f, ws, sids, grad_image, s))) return rc;
     tm.mark();
     if ((rc = gs_stage_project_backward(f, ws, grad_pos, grad_quat, grad_scale, grad_opa, grad_rgb, s))) return rc;
     tm.mark();

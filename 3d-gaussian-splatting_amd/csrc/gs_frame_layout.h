@@ -143,4 +143,4 @@ int gs_stage_tile_sort_packed(const gs_frame *f, const gs_frame_ws &ws, uint64_t
 int gs_stage_tile_ranges(const gs_frame *f, const gs_frame_ws &ws, const uint64_t *sorted_keys, hipStream_t stream);
 int gs_stage_raster_forward(const gs_frame *f, const gs_frame_ws &ws, const uint32_t *sorted_ids, hipStream_t stream);
 int gs_stage_raster_backward(const gs_frame *f, const gs_frame_ws &ws, const uint32_t *sorted_ids,
-                             const float *grad_image, float *grad_rgb, hipStream_t stream);
+                             const float *grad_image, hipStream_t stream);

@@ -744,7 +744,7 @@ extern "C" int gs_draw_backward(const float *pos, const float *rgb, const float 
 }
 
 int gs_stage_raster_backward(const gs_frame *f, const gs_frame_ws &ws, const uint32_t *sorted_ids,
-                             const float *grad_image, float *grad_rgb, hipStream_t stream) {
+                             const float *grad_image, hipStream_t stream) {
     gs_frame_geom FG = gs_frame_geometry(f);
     RasterSrc S = {};
     S.ids = sorted_ids;
@@ -772,7 +772,6 @@ int gs_stage_raster_backward(const gs_frame *f, const gs_frame_ws &ws, const uin
     }
     // rows of pairs the forward never reached (early termination) must read as zero
     GS_HIP(hipMemsetAsync(ws.rows, 0, sizeof(float) * (size_t)gs_row_floats(f->color_dim) * f->max_pairs, stream));
-    (void)grad_rgb;
     hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, ws.tile_nproc, FG.n_tiles,
                        ws.bucket_offsets, ws.counters + GS_CNT_BUCKETS, f->color_dim == 3 ? 1 : 0);
     BwdIn I = {f->image_padded, grad_image, ws.ckpt, ws.tile_nproc, ws.bucket_offsets, ws.tile_ranges};
