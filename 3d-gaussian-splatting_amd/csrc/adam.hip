@@ -88,7 +88,29 @@ __global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ param, co
     }
 }
 
+// the statistic alone (view-parallel training: it must see this rank's OWN gradient, before the all-reduce)
+__global__ void __launch_bounds__(256) grad_stat_kernel(const float *__restrict__ grad, float *__restrict__ stat,
+                                                        int64_t n, int mode) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float g = fabsf(grad[i]);
+        stat[i] = mode == 1 ? fmaxf(stat[i], g) : stat[i] + g;
+    }
+}
+
 }  // namespace
+
+extern "C" int gs_grad_stat_update(const float *grad, float *stat, int64_t n, int32_t stat_mode, gs_stream_t stream) {
+    GS_CHECK_ARG(n >= 0, "n < 0");
+    GS_CHECK_ARG(stat_mode == 1 || stat_mode == 2, "stat_mode must be 1 (max) or 2 (sum)");
+    if (n == 0) return 0;
+    GS_CHECK_ARG(grad && stat, "null pointer");
+    int64_t blocks = gs_div_up(n, 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(grad_stat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, grad, stat, n,
+                       (int)stat_mode);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int gs_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
                             int32_t n_groups, const int64_t *group_end, const float *lr, float beta1, float beta2,

@@ -268,9 +268,11 @@ __global__ void __launch_bounds__(64 * BwdCfg<CDIM>::WPB) raster_backward_kernel
         const int buf = seg & 1;
         if (seg + 1 < 4) load_segment(seg + 1);  // in flight while this segment streams
         const bool feeding = seg < 4;
-        const int nsteps = feeding ? 64 : nvalid - 1;  // drain: the last pixel leaves lane nvalid-1
-#pragma unroll 2
-        for (int t = 0; t < nsteps; ++t) {
+        // drain: the last pixel leaves lane nvalid-1 after nvalid-1 more steps; rounded up to an even count (the
+        // extra step moves an empty slot) so that the loop unrolls by two without a remainder loop, which the
+        // convergent DPP moves forbid
+        const int nsteps = feeding ? 64 : (nvalid & ~1);
+        auto step = [&](const int t) {
             // feed for lane 0 (broadcast LDS reads; while draining feed T = 0)
             const float4 f0 = s_feed[wave][buf][0][t];
             const float fT = feeding ? f0.x : 0.f;
@@ -364,6 +366,10 @@ __global__ void __launch_bounds__(64 * BwdCfg<CDIM>::WPB) raster_backward_kernel
             og2 = g2;
             opx = px;
             opy = py;
+        };
+        for (int t = 0; t < nsteps; t += 2) {  // nsteps is even: two steps per iteration, no remainder loop
+            step(t);
+            step(t + 1);
         }
         if (seg + 1 < 4) write_segment(buf ^ 1, seg + 1);
     }

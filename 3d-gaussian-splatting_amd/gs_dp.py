@@ -76,3 +76,51 @@ class FlatGaussianParams:
     def broadcast_params(self, src: int = 0):
         if self.world_size > 1 and dist.is_initialized():
             dist.broadcast(self.flat_param, src=src)
+
+
+class ViewParallelGradStat:
+    """The densification statistic of train.py:145-154 when the views of a step are spread over ranks.
+
+    The reference accumulates |pos.grad| of EACH VIEW (``accum_max_grad = max(accum, |grad|)``, or ``+= |grad|`` with
+    a per-Gaussian visibility counter for "mean").  After the all-reduce every rank only holds the MEAN gradient of
+    the step's views, and |mean| is not what the reference thresholds.  So each rank folds its own, pre-all-reduce
+    gradient into a local statistic (one small HIP launch, ``gs_grad_stat_update``), and the local statistics are
+    combined only where they are consumed -- at a densification boundary -- with ONE collective: elementwise MAX
+    ("max") or SUM ("mean", statistic and counter packed into the same buffer).  Every rank then holds the same
+    numbers and takes the same prune / clone / split decisions.
+    """
+
+    def __init__(self, n: int, device, mode: str = "max", world_size: int = 1):
+        if mode not in ("max", "mean"):
+            raise ValueError("mode must be 'max' or 'mean'")
+        self.mode, self.world_size = mode, int(world_size)
+        # [N,3] statistic + [N] visibility counter in one buffer: a single collective at the boundary
+        self._buf = torch.zeros(int(n) * 4, dtype=torch.float32, device=device)
+        self.accum = self._buf[: int(n) * 3].view(int(n), 3)
+        self.counter = self._buf[int(n) * 3:]
+
+    def clear(self):
+        self._buf.zero_()
+
+    def update(self, pos_grad: torch.Tensor, seen: torch.Tensor = None):
+        """Fold this rank's view in.  ``pos_grad`` [N,3] is the LOCAL gradient (before the all-reduce); ``seen`` [N]
+        is the view's culling mask as float (train.py:152-154), needed for "mean" only."""
+        if pos_grad.device.type != "cuda":
+            raise RuntimeError("ViewParallelGradStat.update needs a HIP device; there is no CPU fallback")
+        if tuple(pos_grad.shape) != tuple(self.accum.shape) or not pos_grad.is_contiguous():
+            raise RuntimeError(f"pos_grad must be contiguous {tuple(self.accum.shape)}")
+        from gaussian import _lib
+
+        _lib.check(_lib.gs_grad_stat_update(pos_grad.data_ptr(), self.accum.data_ptr(), self.accum.numel(),
+                                            1 if self.mode == "max" else 2, torch.cuda.current_stream().cuda_stream),
+                   "gs_grad_stat_update")
+        if self.mode == "mean":
+            if seen is None:
+                raise RuntimeError("the 'mean' statistic needs the view's culling mask")
+            self.counter.add_(seen)
+
+    def reduce(self):
+        """Combine the ranks' statistics in place (no-op for a single process); returns (accum [N,3], counter [N])."""
+        if dist.is_initialized() and self.world_size > 1:
+            dist.all_reduce(self._buf, op=dist.ReduceOp.MAX if self.mode == "max" else dist.ReduceOp.SUM)
+        return self.accum, self.counter

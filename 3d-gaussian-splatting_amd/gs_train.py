@@ -25,7 +25,7 @@ from typing import Callable, List, Optional, Sequence
 import torch
 
 from gaussian import _lib
-from gs_dp import ORDER, FlatGaussianParams
+from gs_dp import ORDER, FlatGaussianParams, ViewParallelGradStat
 from gs_frame import FrameRenderer
 
 GROUPS = ("opa", "rgb", "pos", "scale", "quat")  # the reference's param-group order (train.py:59-65)
@@ -159,9 +159,14 @@ class Trainer:
 
     def __init__(self, params: Sequence[torch.Tensor], cameras, targets: Sequence[torch.Tensor],
                  opt: Optional[TrainOptions] = None, world_size: int = 1, max_pairs: int = 1 << 20,
-                 scale_activation: str = "abs", densify: bool = False, generator: Optional[torch.Generator] = None):
+                 scale_activation: str = "abs", densify: bool = False, generator: Optional[torch.Generator] = None,
+                 per_view_stat: Optional[bool] = None):
         self.opt = opt or TrainOptions()
         self.world_size = int(world_size)
+        # densification statistic: fused into the Adam launch on one GPU; with several ranks it must be taken from
+        # each rank's own gradient before the all-reduce (gs_dp.ViewParallelGradStat).  `per_view_stat=True` forces
+        # that path on a single rank too (it then gives bit-identical results; used by the tests).
+        self.per_view_stat = (self.world_size > 1) if per_view_stat is None else bool(per_view_stat)
         self.scale_activation = scale_activation
         self.densify, self.generator = bool(densify), generator
         self.cameras, self.targets = list(cameras), list(targets)
@@ -178,8 +183,12 @@ class Trainer:
         """(Re)creates the flat bucket and the optimizer for a (new) Gaussian set: train.py:59-67 / :169-179 --
         the reference also starts a fresh torch.optim.Adam after every adaptive_control."""
         self.flat = FlatGaussianParams(params, world_size=self.world_size)
+        split_stat = self.densify and self.per_view_stat
         self.optimizer = FusedAdam(self.flat, [b * f(i_iter) for b, f in zip(self._base, self._lambdas)],
-                                   betas=self.opt.betas, eps=self.opt.eps, grad_stat=self.opt.grad_accum_method)
+                                   betas=self.opt.betas, eps=self.opt.eps,
+                                   grad_stat=None if split_stat else self.opt.grad_accum_method)
+        self.view_stat = (ViewParallelGradStat(self.flat.params[0].shape[0], self.flat.flat_param.device,
+                                               self.opt.grad_accum_method, self.world_size) if split_stat else None)
         self.grad_counter = None  # "mean" accumulation only: per-Gaussian count of views that saw it (train.py:150)
 
     @property
@@ -206,13 +215,19 @@ class Trainer:
         loss = self._loss_for(image.shape[0], image.shape[1])
         grad_image = loss(image, target)
         self.renderer.backward(grad_image, out=self.flat.grads)
-        self.flat.all_reduce_grads()
         if self.densify and accum_start:  # train.py:141-142 (before this step's gradient is accumulated)
             self.optimizer.clear_grad_stat()
             self.grad_counter = None
-        self.optimizer.step()  # also: accum_max_grad = max(|pos.grad|, accum) or += |pos.grad| (train.py:144-153)
+            if self.view_stat is not None:
+                self.view_stat.clear()
+        seen = None
         if self.densify and o.grad_accum_method == "mean":
             seen = (self.renderer.debug_views()["rec_geom"][:, 2] != 0).to(torch.float32)  # culling_mask
+        if self.view_stat is not None:  # this rank's view, before the gradients are averaged over the ranks
+            self.view_stat.update(self.flat.grads[0], seen)
+        self.flat.all_reduce_grads()
+        self.optimizer.step()  # also: accum_max_grad = max(|pos.grad|, accum) or += |pos.grad| (train.py:144-153)
+        if seen is not None and self.view_stat is None:
             self.grad_counter = seen if self.grad_counter is None else self.grad_counter + seen
         if self.densify and (control or only_delete):
             self.adaptive_control(i_iter, densify=control and not in_reset)
@@ -229,15 +244,22 @@ class Trainer:
         from gs_densify import adaptive_control
 
         o = self.opt
-        counter = 1.0 if o.grad_accum_method == "max" or self.grad_counter is None else self.grad_counter
-        stat = self.optimizer.accum_grad / (counter + 1e-3 if isinstance(counter, float)
-                                            else (counter + 1e-3).unsqueeze(-1))  # train.py:160
+        if self.view_stat is not None:  # combine the ranks' per-view statistics: one collective per boundary
+            accum, cnt = self.view_stat.reduce()
+            counter = 1.0 if o.grad_accum_method == "max" else cnt
+        else:
+            accum = self.optimizer.accum_grad
+            counter = 1.0 if o.grad_accum_method == "max" or self.grad_counter is None else self.grad_counter
+        stat = accum / (counter + 1e-3 if isinstance(counter, float) else (counter + 1e-3).unsqueeze(-1))  # train.py:160
         new, counts = adaptive_control(self.flat.params, stat.contiguous(), taus=o.split_thresh,
                                        delete_thresh=o.delete_thresh, scale_activation=self.scale_activation,
                                        grad_thresh=o.grad_thresh, grad_aggregation=o.grad_aggregation,
                                        use_clone=bool(o.use_clone) and densify, use_split=bool(o.use_split) and densify,
                                        clone_dt=o.clone_dt, generator=self.generator)
         self._bind(new, i_iter)
+        # the decisions are identical on every rank (same statistic, same parameters), the Gaussian draws of the
+        # split are not unless every rank seeds `generator` alike: rank 0's new set is the one that counts
+        self.flat.broadcast_params(0)
         return counts
 
     # ------------------------------------------------------------------ evaluation / viewer hook

@@ -240,6 +240,12 @@ int gs_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg
                  float eps, int64_t step, float *grad_stat, int64_t stat_begin, int64_t stat_end,
                  int32_t stat_mode, gs_stream_t stream);
 
+/* The same statistic without the Adam update: stat[i] = max(stat[i], |grad[i]|) (stat_mode 1) or stat[i] += |grad[i]|
+ * (stat_mode 2) for i < n.  View-parallel training (one view per GPU) needs it: train.py:145-154 accumulates the
+ * |gradient| of EACH VIEW, so every rank updates the statistic from its own gradient before the all-reduce averages
+ * the gradients, and the statistics are combined (max / sum over ranks) at the densification boundaries. */
+int gs_grad_stat_update(const float *grad, float *stat, int64_t n, int32_t stat_mode, gs_stream_t stream);
+
 /* Image loss of train.py:99-107 and its gradient:
  *   loss = (1 - ssim_weight) * mean|pred - target| + ssim_weight * (1 - SSIM(pred, target)),
  * SSIM = torchmetrics StructuralSimilarityIndexMeasure(data_range=1.0) (11x11 Gaussian window, sigma 1.5,

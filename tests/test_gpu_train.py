@@ -204,6 +204,56 @@ def test_trainer_with_densification(gpu):
     assert torch.isfinite(img).all()
 
 
+@pytest.mark.parametrize("mode", ["max", "mean"])
+def test_per_view_statistic_path_equals_fused_path(gpu, mode):
+    """View-parallel training takes the densification statistic from each rank's own gradient BEFORE the all-reduce
+    (gs_grad_stat_update + gs_dp.ViewParallelGradStat) instead of inside the Adam launch.  On one rank both paths
+    see the same gradient, so the whole schedule -- statistic, prune / clone / split, parameters -- must agree bit
+    for bit."""
+    from gs_frame import FrameRenderer
+    from gs_scene import make_camera, make_scene
+    from gs_train import TrainOptions, Trainer
+
+    W, H = 128, 96
+    scene, cam = make_scene(2500, W, H, seed=4), make_camera(W, H)
+    gt = to_torch(scene, gpu)
+    target = FrameRenderer(gpu, max_pairs=1 << 16).forward(*gt, cam)[0].clone()
+    start = [t.clone() for t in gt]
+    start[4] = start[4] + 0.8 * torch.randn(start[4].shape, device=gpu, generator=torch.Generator(gpu).manual_seed(0))
+    opt = TrainOptions(n_iters=400, n_iters_warmup=5, adaptive_control_start_iter=20, n_adaptive_control=25,
+                       grad_accum_iters=10, split_thresh=0.02, delete_thresh=1.5, grad_thresh=1e-7, use_clone=1,
+                       grad_accum_method=mode)
+    runs = []
+    for per_view in (False, True):
+        tr = Trainer([t.clone() for t in start], [cam], [target], opt, max_pairs=1 << 16, densify=True,
+                     generator=torch.Generator(gpu).manual_seed(1), per_view_stat=per_view)
+        assert (tr.view_stat is not None) == per_view and (tr.optimizer.accum_grad is None) == per_view
+        for it in range(60):
+            tr.train_step(it, 0)
+            if it == 45:
+                stat = tr.view_stat.accum if per_view else tr.optimizer.accum_grad
+                runs.append(stat.clone())
+        runs.append([p.clone() for p in tr.flat.params])
+    assert float(runs[0].abs().max()) > 0 and torch.equal(runs[0], runs[2])
+    assert runs[1][0].shape[0] != 2500  # the Gaussian set did change (adaptive_control at 25 and 50)
+    for a, b in zip(runs[1], runs[3]):
+        assert torch.equal(a, b)
+
+
+def test_grad_stat_update_kernel(gpu):
+    from gaussian import _lib
+
+    g = torch.randn(100_003, 3, device=gpu)
+    for mode, ref in ((1, lambda s: torch.maximum(s, g.abs())), (2, lambda s: s + g.abs())):
+        s = torch.rand(100_003, 3, device=gpu)
+        want = ref(s)
+        _lib.check(_lib.gs_grad_stat_update(g.data_ptr(), s.data_ptr(), s.numel(), mode,
+                                            torch.cuda.current_stream().cuda_stream), "gs_grad_stat_update")
+        assert torch.equal(s, want)
+    with pytest.raises(RuntimeError):
+        _lib.check(_lib.gs_grad_stat_update(g.data_ptr(), g.data_ptr(), 3, 0, None), "gs_grad_stat_update")
+
+
 def test_viewer_hook_and_checkpoint(gpu, tmp_path):
     """Trainer.test(None, extrinsics, intrinsics) -- the call the reference's viser GUI makes per frame
     (visergui.py:137-149) -- at a size that is not a multiple of 16, against the oracle; test(camera_id)

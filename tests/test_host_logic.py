@@ -3,6 +3,7 @@ gradient bucket over a 2-process gloo group (the RCCL path's CPU stand-in)."""
 import os
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -79,3 +80,34 @@ def test_view_parallel_gradient_bucket_gloo(tmp_path):
     for r in range(world):
         assert np.allclose(red[r], expect, rtol=1e-6, atol=1e-9)
     assert np.array_equal(red[0], red[1])
+
+
+def _stat_worker(rank, world, port, tmp, mode):
+    import torch.distributed as dist
+    from gs_dp import ViewParallelGradStat
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    n = 1000
+    st = ViewParallelGradStat(n, "cpu", mode, world_size=world)
+    rng = np.random.default_rng(7 + rank)
+    # what update() leaves behind on a GPU (the HIP launch itself is covered by tests/test_gpu_train.py)
+    st.accum.copy_(torch.from_numpy(np.abs(rng.normal(size=(n, 3))).astype(np.float32)))
+    st.counter.copy_(torch.from_numpy(rng.integers(0, 5, n).astype(np.float32)))
+    np.save(os.path.join(tmp, f"stat_local_{rank}.npy"), st._buf.numpy().copy())
+    acc, cnt = st.reduce()
+    assert acc.data_ptr() == st.accum.data_ptr() and cnt.data_ptr() == st.counter.data_ptr()  # in place
+    np.save(os.path.join(tmp, f"stat_red_{rank}.npy"), st._buf.numpy().copy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["max", "mean"])
+def test_view_parallel_densification_statistic_gloo(tmp_path, mode):
+    """train.py:145-154 under view parallelism: the ranks' per-view |grad| statistics are combined with ONE
+    collective (elementwise max, or sum of statistic + visibility counter) and every rank ends up with the same
+    numbers -- the precondition for identical prune / clone / split decisions."""
+    world, port = 2, 31500 + (os.getpid() % 2000)
+    mp.spawn(_stat_worker, args=(world, port, str(tmp_path), mode), nprocs=world, join=True)
+    local = [np.load(tmp_path / f"stat_local_{r}.npy") for r in range(world)]
+    red = [np.load(tmp_path / f"stat_red_{r}.npy") for r in range(world)]
+    expect = np.maximum(local[0], local[1]) if mode == "max" else local[0] + local[1]
+    assert np.array_equal(red[0], expect) and np.array_equal(red[1], expect)
