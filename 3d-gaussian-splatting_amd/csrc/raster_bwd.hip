@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(64 * BwdCfg<CDIM>::WPB) raster_backward_kernel
     auto load_segment = [&](int seg) {
         const int p = seg * 64 + lane;
         const uint32_t id_y = ty * 16 + (p >> 4);
-        pc = ck[p];
+        pc = b == 0 ? make_float4(1.f, 0.f, 0.f, 0.f) : ck[p];  // bucket 0 starts from the empty pixel (not stored)
         float f[3], g[3];
         load_pixel_inputs<FRAME>(I, G, id_x, id_y, f, g);
         pf0 = f[0];
@@ -497,7 +497,8 @@ __global__ void __launch_bounds__(64) raster_backward_tail_kernel(RasterSrc S, R
     for (int k = 0; k < 4; ++k) {
         const uint32_t id_y = id_y0 + 4 * k;
         py[k] = raster_pixel_coord(id_y, G.padH, G.focal_y);
-        const float4 c = ck[64 * k + lane];  // tile pixel index = 16 (y - ty 16) + (x - tx 16)
+        // tile pixel index = 16 (y - ty 16) + (x - tx 16); the tile's first bucket starts from the empty pixel
+        const float4 c = base == 0 ? make_float4(1.f, 0.f, 0.f, 0.f) : ck[64 * k + lane];
         float f[3], g[3];
         load_pixel_inputs<FRAME>(I, G, id_x, id_y, f, g);
         const float f0 = f[0], f1 = f[1], f2 = f[2];

@@ -213,7 +213,9 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
         else
             fetch(start, n, base + CH);
         const uint32_t cnt = (n - base) < (uint32_t)CH ? (n - base) : (uint32_t)CH;
-        if (CKPT) write_ckpt(base);  // CH == GS_BUCKET: one checkpoint per chunk
+        // CH == GS_BUCKET: one checkpoint per chunk; the state before the tile's first chunk is (T, C) = (1, 0) by
+        // definition, the backward kernels synthesise it instead of reading 4 KiB per tile back
+        if (CKPT && base > 0) write_ckpt(base);
         // groups of 4 Gaussians: one wave-uniform liveness test per group, per-pixel masking inside
         // (exactly the reference's per-pixel `accum < 0.0001` test, gaussian.cu:906)
         for (uint32_t i = 0; i < cnt; i += 4) {
