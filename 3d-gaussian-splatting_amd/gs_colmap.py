@@ -143,3 +143,110 @@ def initial_gaussians(points3d: Dict[int, ColmapPoint3D], scale_init_value: floa
     quat = np.tile(np.array([1, 0, 0, 0], np.float32), (n, 1))
     opa = np.full(n, -math.log(1 / opa_init_value - 1), np.float32)
     return pos, quat, np.repeat(s[:, None], 3, axis=1).astype(np.float32), opa, rgb
+
+
+# ------------------------------------------------------------------------------------------------
+# Writers (record layout of COLMAP's Reconstruction::Write*Binary): used to build synthetic datasets in the
+# layout train.py expects -- <data>/sparse/0/{cameras,images,points3D}.bin + <data>/images_<downsample>/ --
+# because no real capture is available offline (tools/make_synthetic_colmap.py, tests).
+MODEL_IDS = {name: (mid, n_par) for mid, (name, n_par) in CAMERA_MODELS.items()}
+
+
+def write_cameras_binary(path, cameras: Dict[int, ColmapCamera]):
+    with open(path, "wb") as f:
+        f.write(struct.pack("<Q", len(cameras)))
+        for cam in cameras.values():
+            mid, n_par = MODEL_IDS[cam.model]
+            assert len(cam.params) == n_par, f"{cam.model} takes {n_par} parameters"
+            f.write(struct.pack("<iiQQ", cam.id, mid, cam.width, cam.height))
+            f.write(struct.pack("<%dd" % n_par, *(float(v) for v in cam.params)))
+
+
+def write_images_binary(path, images: Dict[int, ColmapImage]):
+    with open(path, "wb") as f:
+        f.write(struct.pack("<Q", len(images)))
+        for im in images.values():
+            f.write(struct.pack("<i7di", im.id, *(float(v) for v in im.qvec), *(float(v) for v in im.tvec),
+                                im.camera_id))
+            f.write(im.name.encode("utf-8") + b"\x00")
+            f.write(struct.pack("<Q", len(im.point3D_ids)))
+            for xy, pid in zip(np.asarray(im.xys, np.float64).reshape(-1, 2), im.point3D_ids):
+                f.write(struct.pack("<ddq", float(xy[0]), float(xy[1]), int(pid)))
+
+
+def write_points3d_binary(path, points: Dict[int, ColmapPoint3D]):
+    with open(path, "wb") as f:
+        f.write(struct.pack("<Q", len(points)))
+        for p in points.values():
+            f.write(struct.pack("<q3d3BdQ", p.id, *(float(v) for v in p.xyz), *(int(v) for v in p.rgb),
+                                float(p.error), len(p.image_ids)))
+            for a, b in zip(p.image_ids, p.point2D_idxs):
+                f.write(struct.pack("<ii", int(a), int(b)))
+
+
+def rotmat2qvec(R) -> np.ndarray:
+    """Inverse of qvec2rotmat (COLMAP's read_write_model.rotmat2qvec: eigenvector of the symmetric K matrix)."""
+    Rxx, Ryx, Rzx, Rxy, Ryy, Rzy, Rxz, Ryz, Rzz = np.asarray(R, np.float64).flat
+    K = np.array([[Rxx - Ryy - Rzz, 0, 0, 0], [Ryx + Rxy, Ryy - Rxx - Rzz, 0, 0],
+                  [Rzx + Rxz, Rzy + Ryz, Rzz - Rxx - Ryy, 0], [Ryz - Rzy, Rzx - Rxz, Rxy - Ryx, Rxx + Ryy + Rzz]]) / 3.0
+    vals, vecs = np.linalg.eigh(K)
+    q = vecs[[3, 0, 1, 2], np.argmax(vals)]
+    return -q if q[0] < 0 else q
+
+
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class ColmapScene:
+    """What Splatter.__init__ / parse_imgs / set_camera hold for a dataset (splatter.py:356-366, 429-452, 490-503)."""
+    cameras: list          # gs_scene.Camera per image, sorted by COLMAP image id
+    targets: list          # [H, W, 3] float32 tensors in [0, 1]
+    names: list            # image file names
+    points3d: Dict[int, ColmapPoint3D]
+
+
+def load_scene(data_dir: str, render_downsample: int = 4, device="cpu", near: float = 0.3,
+               image_dir: str = None) -> ColmapScene:
+    """``<data_dir>/sparse/0/*.bin`` + ``<data_dir>/images_<render_downsample>/`` (train.py:368-369), as the
+    reference reads them:
+
+    * images sorted by COLMAP image id, files that do not exist are skipped (splatter.py:430-441);
+    * pose: COLMAP's world->camera rotation and translation as they are (splatter.py:445-451);
+    * intrinsics: focal = params[0:2] / render_downsample, size = the size of the LOADED image
+      (splatter.py:497-501) -- the pre-downsampled ``images_<k>`` folders of the usual capture layout;
+    * ground truth: uint8 -> float16 / 255 (splatter.py:443, 494), kept as float32 here because the loss runs in
+      fp32 (the fp16 rounding of the reference's targets is applied, so the values are the same).
+
+    The reference decodes with cv2.imread (absent in this image); Pillow decodes here -- PNG is lossless and both
+    use libjpeg-turbo for JPEG."""
+    import os
+
+    import torch
+    from PIL import Image
+
+    from gs_scene import Camera
+
+    sparse = os.path.join(data_dir, "sparse", "0")
+    cams = read_cameras_binary(os.path.join(sparse, "cameras.bin"))
+    imgs = read_images_binary(os.path.join(sparse, "images.bin"))
+    pts = read_points3d_binary(os.path.join(sparse, "points3D.bin"))
+    image_dir = image_dir or os.path.join(data_dir, f"images_{render_downsample}")
+    out = ColmapScene([], [], [], pts)
+    for image_id in sorted(imgs):
+        info = imgs[image_id]
+        fn = os.path.join(image_dir, info.name)
+        if not os.path.exists(fn):
+            continue
+        rgb = np.asarray(Image.open(fn).convert("RGB"), dtype=np.uint8)
+        target = (torch.from_numpy(rgb.copy()).to(device).to(torch.float16) / 255.0).to(torch.float32).contiguous()
+        cam = cams[info.camera_id]
+        if len(cam.params) < 2:
+            raise RuntimeError(f"camera model {cam.model} has no focal parameters")
+        fx, fy = float(cam.params[0]) / render_downsample, float(cam.params[1]) / render_downsample
+        out.cameras.append(Camera(int(rgb.shape[1]), int(rgb.shape[0]), fx, fy,
+                                  qvec2rotmat(info.qvec).astype(np.float32), np.asarray(info.tvec, np.float32),
+                                  near=near))
+        out.targets.append(target)
+        out.names.append(info.name)
+    if not out.cameras:
+        raise RuntimeError(f"no image of {sparse}/images.bin found in {image_dir}")
+    return out

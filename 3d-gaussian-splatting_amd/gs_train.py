@@ -43,6 +43,8 @@ class TrainOptions:
     n_iters: int = 7001
     n_iters_warmup: int = 300
     ssim_weight: float = 0.1
+    scale_reg: float = 0.0  # train.py:108-109: + scale_reg * mean |scale|
+    opa_reg: float = 0.0    # train.py:110-112: + opa_reg * mean sigma(opa) (1 - sigma(opa))
     grad_accum_method: str = "max"  # "max" | "mean"
     betas: tuple = (0.9, 0.99)
     eps: float = 1e-8
@@ -215,6 +217,8 @@ class Trainer:
         loss = self._loss_for(image.shape[0], image.shape[1])
         grad_image = loss(image, target)
         self.renderer.backward(grad_image, out=self.flat.grads)
+        if o.scale_reg > 0 or o.opa_reg > 0:
+            self._add_regulariser_grads()
         if self.densify and accum_start:  # train.py:141-142 (before this step's gradient is accumulated)
             self.optimizer.clear_grad_stat()
             self.grad_counter = None
@@ -238,6 +242,17 @@ class Trainer:
 
             reset_opa(self.flat.params[3])
         return loss.values
+
+    def _add_regulariser_grads(self):
+        """The two optional penalties of train.py:108-112 (both default to 0 and are off the hot path): their
+        closed-form gradients are added to the bucket with a few elementwise torch ops."""
+        o = self.opt
+        if o.scale_reg > 0:
+            s = self.flat.params[2]
+            self.flat.grads[2].add_(torch.sign(s), alpha=o.scale_reg / s.numel())
+        if o.opa_reg > 0:
+            sg = torch.sigmoid(self.flat.params[3])
+            self.flat.grads[3].add_(sg * (1 - sg) * (1 - 2 * sg), alpha=o.opa_reg / sg.numel())
 
     def adaptive_control(self, i_iter: int, densify: bool = True):
         """train.py:156-180: prune (+ clone / split when ``densify``), then a fresh optimizer."""
@@ -285,7 +300,8 @@ class Trainer:
             raise RuntimeError("test() needs a camera_id or extrinsics + intrinsics")
         if getattr(self, "_eval_renderer", None) is None:
             self._eval_renderer = FrameRenderer(self.flat.flat_param.device, max_pairs=self.renderer.max_pairs,
-                                                training=False, scale_activation=self.scale_activation)
+                                                training=False, scale_activation=self.scale_activation,
+                                                thresh=self.renderer.thresh)
         tic, toc = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         tic.record()
         image, _ = self._eval_renderer.forward(*self.flat.params, cam)

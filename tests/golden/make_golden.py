@@ -280,6 +280,25 @@ def colmap():
     print("colmap ok", len(cams), len(imgs), len(pts))
 
 
+def train_cli():
+    """Flags, types, defaults and choices of the reference's command line (train.py:296-363), read from its SOURCE
+    with the ast module (importing train.py needs cv2 / torchmetrics / viser, which this image lacks)."""
+    import ast
+    import json
+
+    src = open("/root/reference/train.py").read()
+    out = {}
+    for node in ast.walk(ast.parse(src)):
+        if not (isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr == "add_argument"):
+            continue
+        name = ast.literal_eval(node.args[0]).lstrip("-")
+        kw = {k.arg: k.value for k in node.keywords}
+        out[name] = {"type": kw["type"].id, "default": ast.literal_eval(kw["default"]),
+                     "choices": ast.literal_eval(kw["choices"]) if "choices" in kw else None}
+    json.dump(out, open(os.path.join(HERE, "train_cli.json"), "w"), indent=1, sort_keys=True)
+    print("train_cli ok", len(out))
+
+
 if __name__ == "__main__":
     assert os.path.isdir("/root/reference"), "needs the reference checkout"
     oracle.build()
@@ -293,3 +312,4 @@ if __name__ == "__main__":
     host_geometry()
     densify()
     colmap()
+    train_cli()
