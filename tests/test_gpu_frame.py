@@ -295,6 +295,51 @@ def test_full_size_backward_properties(gpu):
         assert float(a[vis].abs().max()) > 0.0
 
 
+def test_full_size_2p4M_forward_matches_oracle(gpu):
+    """BASELINE.json configs[4] geometry (2.4 M Gaussians, 1080p, no SH: the >= 160 FPS target scene): the whole
+    frame against the C oracle -- 6.95 M (tile, depth, id) pairs bit-exact, image to IMG_ATOL (~30 s of CPU)."""
+    from gs_scene import CONFIGS
+
+    n, W, H, use_sh = CONFIGS["cfg5"]
+    scene, cam = make_scene(n, W, H, seed=2023, use_sh=use_sh), make_camera(W, H)
+    params = to_torch(scene, gpu)
+    r = FrameRenderer(gpu, max_pairs=7_600_000, auto_grow=False)
+    img, _ = r.forward(*params, cam)
+    st, v = r.stats(), r.debug_views()
+    assert (st.visible, st.pairs, st.overflow) == (1_887_982, 6_950_364, 0)
+    of = OracleFrame(scene, cam)
+    assert np.array_equal(v["sorted_keys"].cpu().numpy().view(np.uint64), of.keys)
+    assert np.array_equal(v["sorted_ids"].cpu().numpy(), of.ids)
+    err = np.abs(img.cpu().numpy() - of.image)
+    assert err.max() < IMG_ATOL, err.max()
+
+
+def test_full_size_2p4M_sh_forward_backward_properties(gpu):
+    """BASELINE.json configs[3] (2.4 M Gaussians, 1080p, SH, forward + backward) through size-independent
+    properties: same pair list as the no-SH scene of the same geometry, finite image and gradients, bitwise
+    repeatable backward, zero gradient for culled Gaussians, linear in dL/dimage."""
+    from gs_scene import CONFIGS
+
+    n, W, H, use_sh = CONFIGS["cfg4"]
+    scene, cam = make_scene(n, W, H, seed=2023, use_sh=use_sh), make_camera(W, H)
+    params = to_torch(scene, gpu)
+    r = FrameRenderer(gpu, max_pairs=7_600_000, training=True, auto_grow=False)
+    w = torch.randn(H, W, 3, device=gpu)
+    img, _ = r.forward(*params, cam)
+    assert r.stats().pairs == 6_950_364 and bool(torch.isfinite(img).all())
+    g1 = [t.clone() for t in r.backward(w)]
+    r.forward(*params, cam)
+    g1b = r.backward(w)
+    r.forward(*params, cam)
+    g2 = r.backward(2.0 * w)
+    vis = r.debug_views()["rec_geom"][:, 2] != 0
+    assert g1[4].shape == (n, 27)
+    for a, b, c in zip(g1, g1b, g2):
+        assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
+        assert float((2.0 * a - c).abs().max()) <= 1e-6 * float(c.abs().max())
+        assert float(a[~vis].abs().max()) == 0.0 and float(a[vis].abs().max()) > 0.0
+
+
 @pytest.mark.parametrize("kind", ["nan_pos", "inf_pos", "zero_quat", "nan_scale", "huge_scale", "zero_scale", "neg_z"])
 def test_frame_degenerate_inputs(gpu, kind):
     """Non-finite / degenerate parameters must neither hang nor corrupt anything else: the pair list still
