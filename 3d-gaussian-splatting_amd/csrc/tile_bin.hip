@@ -21,6 +21,7 @@
 // final list is the oracle's (tile, depth_bits, gaussian_index) order bit for bit, every run.
 // Traffic per pair: 8 B written here + the tile sort, against 2 x (3 launches, 36 B) of radix
 // passes in sort_mode 1.
+#include <atomic>
 #include <mutex>
 
 #include "gs_common.h"
@@ -263,17 +264,20 @@ int gs_stage_tile_bin(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stre
     const uint32_t T = (uint32_t)G.n_tiles, per_block = bin_per_block(f->N);
     const uint32_t B = (uint32_t)gs_div_up(f->N, per_block);
     const size_t lds = sizeof(uint32_t) * T;
-    // histograms above 64 KiB need the opt-in (gfx950: 160 KiB per workgroup); once per process, thread-safe
-    static std::once_flag attr_once;
-    static hipError_t attr_rc = hipSuccess;
-    std::call_once(attr_once, [] {
-        attr_rc = hipFuncSetAttribute((const void *)bin_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      GS_BIN_MAX_TILES * 4);
-        if (attr_rc == hipSuccess)
-            attr_rc = hipFuncSetAttribute((const void *)bin_scatter_kernel,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, GS_BIN_MAX_TILES * 4);
-    });
-    GS_HIP(attr_rc);
+    // histograms above 64 KiB need the opt-in (gfx950: 160 KiB per workgroup): once per DEVICE (a function
+    // attribute belongs to the device's code object), thread-safe
+    static std::mutex attr_mu;
+    static std::atomic<uint64_t> attr_done{0};
+    int dev = 0;
+    GS_HIP(hipGetDevice(&dev));
+    if (dev < 64 && !((attr_done.load(std::memory_order_acquire) >> dev) & 1)) {
+        std::lock_guard<std::mutex> lock(attr_mu);
+        GS_HIP(hipFuncSetAttribute((const void *)bin_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   GS_BIN_MAX_TILES * 4));
+        GS_HIP(hipFuncSetAttribute((const void *)bin_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   GS_BIN_MAX_TILES * 4));
+        attr_done.fetch_or(1ull << dev, std::memory_order_release);
+    }
     hipLaunchKernelGGL(bin_count_kernel, dim3(B), dim3(BIN_THREADS), lds, stream, ws.rects, f->N,
                        per_block, T, (uint32_t)G.ntx, ws.bin_table, ws.block_sums, ws.block_vis, ws.slice_pairs,
                        ws.slice_vis);
