@@ -221,6 +221,18 @@ class FrameRenderer:
         v, m, o, b = (int(x) for x in self._stats_host.tolist())
         return FrameStats(v, m, o, b)
 
+    def culling_mask(self) -> torch.Tensor:
+        """[N] bool: the Gaussians of the last forward that passed the frustum test (the reference's
+        ``culling_mask``, renderer.py:123-132).  Aliases the workspace; no host synchronisation."""
+        f = self._frame
+        if f is None:
+            raise RuntimeError("no frame rendered yet")
+        ptrs = [C.c_void_p() for _ in range(7)]
+        _lib.check(_lib.gs_frame_debug_views(C.byref(f), *[C.byref(p) for p in ptrs]), "gs_frame_debug_views")
+        off = ptrs[3].value - self._ws.data_ptr()
+        rec = self._ws[off:off + 64 * f.N].view(torch.float32).reshape(f.N, 16)
+        return rec[:, 2] != 0  # depth |p_c| > near > 0 for visible Gaussians, 0 for culled ones
+
     def debug_views(self):
         """Device tensors aliasing the workspace of the last forward (parity tests)."""
         f = self._frame
