@@ -294,9 +294,36 @@ struct ProjectParams {
     uint32_t ntx, nty;
     int32_t scale_act;
     int32_t color_dim;
+    int32_t cull_method;        // 1: "prob" (tile edges), otherwise "prob2" (index arithmetic)
+    float half_padw, half_padh;  // padded size / 2, in pixels (exact in fp32)
+    float fx, fy;
 };
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// "prob" (calc_tile_info_kernel2, gaussian.cu:138-195): tile i of an axis is listed unless
+// `edge(i+1) < lo || hi < edge(i)`, with the tile edges of Tiles.create_tiles (splatter.py:275-293):
+// edge(i) = (-pad/2 + 16 i) / focal, evaluated in fp32 exactly as torch does (an exact integer-valued float divided by
+// the focal length; right(i) = left(i) + 16 before the division, so right(i) == left(i+1) bit for bit).  Both
+// conditions are monotone in i, so the listed tiles are the range [first i with !(edge(i+1) < lo), last i with
+// !(hi < edge(i))]: two binary searches with the reference's own comparisons (NaN bounds list every tile, as there).
+__device__ __forceinline__ void edge_range(float lo, float hi, float half_pad, float focal, uint32_t n,
+                                           uint32_t &i0, uint32_t &i1) {
+    auto edge = [&](uint32_t i) { return (16.0f * (float)i - half_pad) / focal; };
+    uint32_t a = 0, b = n;  // first i in [0, n] with !(edge(i+1) < lo)
+    while (a < b) {
+        const uint32_t m = (a + b) >> 1;
+        if (edge(m + 1) < lo) a = m + 1; else b = m;
+    }
+    i0 = a;
+    a = 0, b = n;  // first i in [0, n] with (hi < edge(i)): one past the last listed tile
+    while (a < b) {
+        const uint32_t m = (a + b) >> 1;
+        if (hi < edge(m)) b = m; else a = m + 1;
+    }
+    i1 = a;
+    if (i0 > i1) i0 = i1;
+}
 
 // Tile rectangle of calc_tile_info_kernel3 (gaussian.cu:226-242); count = 0 if det <= 0.
 __device__ __forceinline__ uint32_t tile_rect(float cx, float cy, const float cv[4], const ProjectParams &P,
@@ -310,6 +337,11 @@ __device__ __forceinline__ uint32_t tile_rect(float cx, float cy, const float cv
     float shift_y = sqrtf(ai * P.tlog * det);
     float bbx_right = cx + shift_x, bbx_left = cx - shift_x;
     float bbx_top = cy - shift_y, bbx_bottom = cy + shift_y;
+    if (P.cull_method == 1) {
+        edge_range(bbx_left, bbx_right, P.half_padw, P.fx, P.ntx, x0, x1);
+        edge_range(bbx_top, bbx_bottom, P.half_padh, P.fy, P.nty, y0, y1);
+        return (y1 - y0) * (x1 - x0);
+    }
     y0 = gs_f2u_sat(fmaxf((bbx_top - P.topmost) / P.tly, 0));
     y1 = gs_f2u_sat((bbx_bottom - P.topmost) / P.tly + 1);
     x0 = gs_f2u_sat(fmaxf((bbx_left - P.leftmost) / P.tlx, 0));
@@ -596,6 +628,11 @@ static ProjectParams make_params(const gs_frame *f) {
     P.nty = (uint32_t)G.nty;
     P.scale_act = f->scale_activation;
     P.color_dim = f->color_dim;
+    P.cull_method = f->tile_culling_method;
+    P.half_padw = (float)(G.padW / 2);
+    P.half_padh = (float)(G.padH / 2);
+    P.fx = f->focal_x;
+    P.fy = f->focal_y;
     return P;
 }
 

@@ -37,6 +37,8 @@ static int tile_bits(int n_tiles) {
 static int validate(const gs_frame *f) {
     GS_CHECK_ARG(f != nullptr, "frame is null");
     GS_CHECK_ARG(f->N >= 0 && f->N < (1ll << 31), "N out of range");
+    GS_CHECK_ARG(f->tile_culling_method >= 0 && f->tile_culling_method <= 2,
+                 "tile_culling_method must be 0 / 2 (prob2) or 1 (prob)");
     GS_CHECK_ARG(f->color_dim == 3 || f->color_dim == 27 || f->color_dim == 48,
                  "color_dim must be 3 (rgb logits), 27 (SH degree 2) or 48 (SH degree 3)");
     GS_CHECK_ARG(f->scale_activation == 0 || f->scale_activation == 1, "scale_activation must be 0 (abs) or 1 (exp)");

@@ -37,7 +37,7 @@ class GsFrame(C.Structure):
         ("rays_o", f32 * 3), ("lefttop", f32 * 3), ("vec_dx", f32 * 3), ("vec_dy", f32 * 3),
         ("max_pairs", i64), ("workspace", vp), ("workspace_bytes", sz),
         ("image", vp), ("image_padded", vp),
-        ("training", i32), ("sort_mode", i32),
+        ("training", i32), ("sort_mode", i32), ("tile_culling_method", i32),
     ]
 
 

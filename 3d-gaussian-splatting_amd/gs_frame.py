@@ -39,8 +39,12 @@ class FrameStats:
 class FrameRenderer:
     def __init__(self, device="cuda", max_pairs: int = 1 << 20, training: bool = False,
                  thresh: float = 0.05, scale_activation: str = "abs", auto_grow: bool = True,
-                 sort_mode: int = 2):
+                 sort_mode: int = 2, tile_culling_method: str = "prob2"):
         self.device = torch.device(device)
+        if tile_culling_method not in ("prob2", "prob"):
+            raise NotImplementedError("the fused frame path lists tiles with 'prob2' (train.py's default) or 'prob'; "
+                                      "'dist' is method 0 of gaussian.calc_tile_list")
+        self.tile_culling_method = {"prob2": 2, "prob": 1}[tile_culling_method]
         if self.device.type != "cuda":
             raise RuntimeError("FrameRenderer needs a HIP device; there is no CPU fallback")
         self.max_pairs = int(max_pairs)
@@ -113,6 +117,7 @@ class FrameRenderer:
         f.max_pairs = self.max_pairs
         f.training = int(training)
         f.sort_mode = self.sort_mode
+        f.tile_culling_method = self.tile_culling_method
         need = _lib.gs_frame_workspace_bytes(n, self.max_pairs, grid.width, grid.height, color_dim, int(training))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(int(need) + 256, dtype=torch.uint8, device=self.device)

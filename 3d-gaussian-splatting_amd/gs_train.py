@@ -302,6 +302,7 @@ class Trainer:
             self._eval_renderer = FrameRenderer(self.flat.flat_param.device, max_pairs=self.renderer.max_pairs,
                                                 training=False, scale_activation=self.scale_activation,
                                                 thresh=self.renderer.thresh)
+            self._eval_renderer.tile_culling_method = self.renderer.tile_culling_method
         tic, toc = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         tic.record()
         image, _ = self._eval_renderer.forward(*self.flat.params, cam)

@@ -16,7 +16,7 @@ three HIP launches of ``gs_densify`` instead of ~40 torch kernels in ``adaptive_
 against the reference's Splatter (its own train.py included) runs unchanged; ``gs_train.Trainer`` / ``train.py`` of
 this package additionally fuse the loss and the optimizer.
 
-Differences, all deliberate: ``tile_culling_method`` must be "prob2" (what train.py passes; "dist" / "prob" exist on
+Differences, all deliberate: ``tile_culling_method`` is "prob2" (what train.py passes) or "prob" ("dist" exists on
 the reference-API ``gaussian.calc_tile_list``); ``cudaculling`` / ``jacobian_calc`` / ``fast_drawing`` / ``debug`` /
 ``debug_align`` select debugging variants of the reference and are accepted and ignored; images are decoded with
 Pillow instead of cv2; ``n_tile_gaussians`` is read from the device on access (one synchronisation) instead of on
@@ -78,9 +78,9 @@ class Splatter(nn.Module):
         super().__init__()
         if not torch.cuda.is_available():
             raise RuntimeError("Splatter needs a HIP device; there is no CPU fallback")
-        if tile_culling_method != "prob2":
-            raise NotImplementedError("the fused frame path implements tile_culling_method='prob2' (train.py's "
-                                      "default); 'dist' / 'prob' are methods 0 / 1 of gaussian.calc_tile_list")
+        if tile_culling_method not in ("prob2", "prob"):
+            raise NotImplementedError("the fused frame path implements tile_culling_method 'prob2' (train.py's "
+                                      "default) and 'prob'; 'dist' is method 0 of gaussian.calc_tile_list")
         if render_weight_normalize:
             raise NotImplementedError("render_weight_normalize is a flag of the reference-API draw(); train.py "
                                       "passes False (splatter.py:627)")
@@ -109,7 +109,8 @@ class Splatter(nn.Module):
                 setattr(self.gaussian_3ds, k, nn.Parameter(ck[k].detach().to(torch.float32).contiguous()))
         # "async": the pair capacity is checked one frame late from pinned memory -- no host synchronisation per frame
         self._renderer = FrameRenderer(self.device, max_pairs=max_pairs, training=True, thresh=tile_culling_prob_thresh,
-                                       scale_activation=scale_activation, auto_grow="async")
+                                       scale_activation=scale_activation, auto_grow="async",
+                                       tile_culling_method=tile_culling_method)
         self.current_camera = None
         self.ground_truth = None
         if not self.test:

@@ -11,8 +11,8 @@ What differs: one fused HIP frame call per direction instead of ~25 torch kernel
 the device every ``--n_history_track`` iterations instead of three ``.item()`` calls per iteration.
 
 Not provided: ``--gui`` (the viser viewer; its per-frame hook ``Trainer.test(None, extrinsics, intrinsics)`` is),
-``--tile_culling_method dist|prob`` on the fused path (use the drop-in ``gaussian`` / ``renderer`` modules with the
-reference's own splatter.py for those), ``--jacobian_track`` / ``--adaptive_lr`` / ``--debug`` (accepted, ignored:
+``--tile_culling_method dist`` on the fused path (use the drop-in ``gaussian`` / ``renderer`` modules with the
+reference's own splatter.py for that one), ``--jacobian_track`` / ``--adaptive_lr`` / ``--debug`` (accepted, ignored:
 they select debugging code paths of the reference).
 """
 from __future__ import annotations
@@ -145,9 +145,9 @@ def main(argv=None) -> dict:
     if opt.gui:
         raise SystemExit("--gui: the viser viewer is not part of this package; drive Trainer.test(None, extrinsics, "
                          "intrinsics) from your viewer instead (see INTEGRATION.md)")
-    if opt.tile_culling_method != "prob2":
-        raise SystemExit("--tile_culling_method dist|prob: only on the reference-API modules (gaussian.calc_tile_list "
-                         "methods 0/1); the fused frame path implements the trainer's default, prob2")
+    if opt.tile_culling_method == "dist":
+        raise SystemExit("--tile_culling_method dist: only on the reference-API modules (gaussian.calc_tile_list "
+                         "method 0); the fused frame path implements prob2 (the default) and prob")
     if not torch.cuda.is_available():
         raise SystemExit("train.py needs a HIP device (there is no CPU fallback)")
     np.random.seed(opt.seed)  # train.py:365: the view order is drawn from numpy's global generator
@@ -166,6 +166,7 @@ def main(argv=None) -> dict:
     trainer = Trainer(params, scene.cameras, scene.targets, train_options(opt), scale_activation=opt.scale_activation,
                       densify=True, generator=torch.Generator(dev).manual_seed(opt.seed))
     trainer.renderer.thresh = float(opt.tile_culling_prob_thresh)
+    trainer.renderer.tile_culling_method = {"prob2": 2, "prob": 1}[opt.tile_culling_method]
     n_cameras = len(scene.cameras)
     test_split = np.arange(0, n_cameras, 8)  # train.py:69-71
     train_split = np.array(sorted(set(range(n_cameras)) - set(test_split.tolist())))

@@ -34,7 +34,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define GS_ABI_VERSION 1
+#define GS_ABI_VERSION 2
 
 #define GS_E_INVALID (-1)   /* bad argument (null pointer, negative size, bad enum)   */
 #define GS_E_UNSUPPORTED (-2) /* valid in the reference but not implemented here (none at present) */
@@ -183,6 +183,13 @@ typedef struct gs_frame {
                                      larger grids take mode 1), then the same per-tile LDS sort.  On
                                      capacity overflow the frame is left empty (modes 0/1 keep the first
                                      max_pairs pairs); all modes report the true count in the stats. */
+    int32_t tile_culling_method; /* which tiles a Gaussian is listed in (splatter.py:571-578, --tile_culling_method):
+                                 0 or 2 = "prob2", the trainer's default (gaussian.cu:197-250: tile rectangle from
+                                     the 2-D covariance's bounding box by index arithmetic);
+                                 1 = "prob" (gaussian.cu:138-195: the same bounding box compared with the tiles'
+                                     edges, Tiles.create_tiles of splatter.py:275-293 -- also a rectangle).
+                                 "dist" (reference method 0, a disc of tile centres around the Gaussian whatever
+                                 its size) exists on gs_calc_tile_list only. */
 } gs_frame;
 
 /* Bytes of workspace needed for N Gaussians, `max_pairs` pairs, a width x height image. */

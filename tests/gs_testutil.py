@@ -35,7 +35,7 @@ def frame_scalars(cam: Camera):
 class OracleFrame:
     """Oracle restatement of one forward frame on raw parameters, keeping every intermediate."""
 
-    def __init__(self, scene: Scene, cam: Camera, thresh=0.05, scale_activation="abs"):
+    def __init__(self, scene: Scene, cam: Camera, thresh=0.05, scale_activation="abs", tile_culling_method="prob2"):
         self.scene, self.cam = scene, cam
         self.scale_activation = scale_activation
         grid, hw, hh, rays = frame_scalars(cam)
@@ -43,9 +43,12 @@ class OracleFrame:
         self.qn, self.sn = activate(scene, scale_activation)
         self.pos_i, self.cov, self.mask = oracle.global_culling(scene.pos, self.qn, self.sn, cam.rot, cam.tran,
                                                                 cam.near, hw, hh)
-        self.keys, self.ids, self.accum = oracle.sorted_pairs(
-            self.pos_i, self.cov.reshape(-1, 4), self.mask, thresh, grid.tile_geo_length_x, grid.tile_geo_length_y,
-            grid.n_tile_x, grid.n_tile_y, grid.leftmost, grid.topmost)
+        if tile_culling_method == "prob2":
+            self.keys, self.ids, self.accum = oracle.sorted_pairs(
+                self.pos_i, self.cov.reshape(-1, 4), self.mask, thresh, grid.tile_geo_length_x,
+                grid.tile_geo_length_y, grid.n_tile_x, grid.n_tile_y, grid.leftmost, grid.topmost)
+        else:
+            self.keys, self.ids, self.accum = self._pairs_from_table(tile_culling_method, thresh)
         self.opa_act = sigmoid32(scene.opa)
         self.col_act = scene.rgb if scene.use_sh else sigmoid32(scene.rgb)
         ids = self.ids
@@ -55,6 +58,26 @@ class OracleFrame:
                                   grid.padded_width, grid.focal_x, grid.focal_y, use_sh=scene.use_sh, fast=True,
                                   rays_o=rays.rays_o, lefttop=rays.lefttop, vdx=rays.dx, vdy=rays.dy)
         self.image = grid.crop(np.clip(self.padded, 0, 1))
+
+    def _pairs_from_table(self, method, thresh):
+        """'prob' / 'dist' (splatter.py:571-578): the oracle's restatement of calc_tile_list methods 1 / 0 (pinned
+        bit for bit against the reference kernels) on the visible Gaussians, uncapped, then the canonical
+        (tile, depth bits, Gaussian index) order."""
+        grid = self.grid
+        vis = np.nonzero(self.mask)[0]
+        top, bottom, left, right = grid.tile_edges()
+        th = (grid.tile_geo_length_x / 0.5) ** 2 if method == "dist" else thresh  # splatter.py:577, dist_thresh 0.5
+        cnt, lst = oracle.calc_tile_list(self.pos_i[vis], self.cov.reshape(-1, 4)[vis], len(vis), th,
+                                         {"dist": 0, "prob": 1}[method], grid.tile_geo_length_x,
+                                         grid.tile_geo_length_y, grid.n_tile_x, grid.n_tile_y, grid.leftmost,
+                                         grid.topmost, top=top, bottom=bottom, left=left, right=right)
+        tiles = np.repeat(np.arange(len(cnt)), cnt)
+        ids = np.concatenate([vis[lst[t, :c]] for t, c in enumerate(cnt)]) if cnt.sum() else np.zeros(0, np.int64)
+        dbits = self.pos_i[ids, 2].view(np.uint32).astype(np.uint64)
+        keys = (tiles.astype(np.uint64) << np.uint64(32)) | dbits
+        order = np.lexsort((ids, keys))
+        accum = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+        return keys[order], ids[order].astype(np.int32), accum
 
     def backward(self, grad_image):
         """dL/d(image) -> dict of dL/d(raw parameter), the chain splatter.py's autograd runs."""

@@ -89,6 +89,30 @@ def test_frame_forward_4k_uses_lds_counters(gpu):
     assert r.stats().pairs == len(of.ids) > 0
 
 
+def test_frame_tile_culling_method_prob(gpu):
+    """--tile_culling_method prob (gaussian.cu:138-195: bounding box against the tiles' edges) on the fused path:
+    the pair list equals the oracle's calc_tile_list method 1 (itself bit-identical to the reference kernel), the
+    frame and its gradients follow.  (The list differs from prob2's only for bounding boxes that touch a tile edge
+    exactly; what is checked is that THIS code path reproduces the reference's edge comparisons.)"""
+    scene, cam = case(15_000, 250, 186, seed=29)
+    of = OracleFrame(scene, cam, tile_culling_method="prob")
+    params = to_torch(scene, gpu, requires_grad=True)
+    r = FrameRenderer(gpu, max_pairs=len(of.ids) + 7, training=True, auto_grow=False, tile_culling_method="prob")
+    img = r.render(*params, cam)
+    v = r.debug_views()
+    assert r.stats().pairs == len(of.ids)
+    assert np.array_equal(v["sorted_keys"].cpu().numpy().view(np.uint64), of.keys)
+    assert np.array_equal(v["sorted_ids"].cpu().numpy(), of.ids)
+    assert np.abs(img.detach().cpu().numpy() - of.image).max() < IMG_ATOL
+    gimg = np.random.default_rng(6).normal(size=of.image.shape).astype(np.float32)
+    img.backward(torch.from_numpy(gimg).to(gpu))
+    ref = of.backward(gimg)
+    for t, name in zip(params, ("pos", "quat", "scale", "opa", "rgb")):
+        assert rel_err(t.grad.cpu().numpy(), ref[name]) < GRAD_RTOL, name
+    with pytest.raises(NotImplementedError):
+        FrameRenderer(gpu, tile_culling_method="dist")
+
+
 @pytest.mark.parametrize("sh_degree", [2, 3])
 def test_frame_forward_sh(gpu, sh_degree):
     # degree 2 = the reference's 27 coefficients; degree 3 (48) is the extension BASELINE config 4 names

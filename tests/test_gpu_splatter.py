@@ -113,4 +113,4 @@ def test_reference_style_training_loop(capture):
                   intrinsics={"width": 150, "height": 90, "focal_x": 100.0, "focal_y": 100.0})
         assert view.shape == (90, 150, 3) and not view.requires_grad and bool(torch.isfinite(view).all())
     g.reset_opa()
-    assert float((g.opa - float(np.log(0.01 / 0.99))).abs().max()) < 1e-6
+    assert float((g.opa.detach() - float(np.log(0.01 / 0.99))).abs().max()) < 1e-6
