@@ -14,7 +14,8 @@ data-path collective (weak scaling).  The training leg reported under "extra" is
 training step without densification (train.py:84-185: forward, L1 + 0.1 SSIM loss, backward, Adam)
 and does have one: an RCCL all-reduce (mean) of the flat parameter-gradient bucket before the fused
 Adam step.  "extra" also carries the loss / Adam kernel times, a 300-iteration fit of the cfg3 scene
-(it/s, PSNR before/after against a synthetic ground truth) and the cfg5 (2.4 M Gaussians) render FPS.
+(it/s, PSNR before/after against a synthetic ground truth), the cfg5 (2.4 M Gaussians) render FPS and the
+cfg4 (2.4 M Gaussians with SH) forward / backward times.
 
 Rank 0 prints ONE JSON line (driver contract) with "roofline" (dominant kernel =
 raster_forward_kernel, timed live with hipEvents on its own stream inside the library) and
@@ -290,6 +291,31 @@ def main():
             dt5 = time_frames(lambda: r5.forward(*params5, cam5), k5, 5)
             extra["cfg5_2p4M_render_fps"] = round(world * k5 / dt5, 2)
             extra["cfg5_visible"], extra["cfg5_tile_pairs"] = st5.visible, st5.pairs
+            del r5, params5
+            torch.cuda.empty_cache()
+        if rank == 0 and world == 1 and args.config == "cfg2":
+            # BASELINE.json configs[3]: 2.4 M Gaussians, 1080p, SH, forward + backward (hipEvent-timed stages).
+            # Degree 2 (27 coefficients) is what the reference implements; degree 3 (48) is the extension.
+            n4, W4, H4, _ = CONFIGS["cfg4"]
+            cam4 = make_camera(W4, H4)
+            cfg4 = {}
+            for deg in (2, 3):
+                sc4 = make_scene(n4, W4, H4, seed=2023, use_sh=True, sh_degree=deg)
+                p4 = [torch.from_numpy(a).to(dev) for a in (sc4.pos, sc4.quat, sc4.scale, sc4.opa, sc4.rgb)]
+                r4, st4 = sized_renderer(p4, cam4, training=True)
+                img4, _ = r4.forward(*p4, cam4)
+                g4 = torch.sign(img4 - 0.5) / img4.numel()
+                fw = [r4.profile_forward(*p4, cam4)["total"] for _ in range(6)][2:]
+                bw = [r4.profile_backward(g4) for _ in range(6)][2:]
+                f_ms = statistics.median(fw)
+                b_ms = statistics.median(x["total"] for x in bw)
+                cfg4[f"sh_degree_{deg}"] = {"coefficients": 3 * (deg + 1) ** 2, "tile_pairs": st4.pairs,
+                                            "forward_ms": round(f_ms, 3), "backward_ms": round(b_ms, 3),
+                                            "raster_bwd_ms": round(statistics.median(x["raster_bwd"] for x in bw), 3),
+                                            "fwd_bwd_iters_per_s": round(1e3 / (f_ms + b_ms), 1)}
+                del r4, p4, sc4, img4, g4
+                torch.cuda.empty_cache()
+            extra["cfg4_2p4M_sh_fwd_bwd"] = cfg4
     out["extra"] = extra
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)
