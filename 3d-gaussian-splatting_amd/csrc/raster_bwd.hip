@@ -24,6 +24,8 @@
 //   dL/dd = (-Sxx + 2 a Su)/Pn,              Sxx = sum s dx^2, ..., Su = sum s u
 // which is the reference's dP1_d{a,b,c,d} (gaussian.cu:610-621) with the per-Gaussian
 // constants factored out of the pixel loop.
+#include <stdlib.h>
+
 #include "raster_common.h"
 
 int gs_raster_forward_ref(const RasterSrc &S, const RasterGeom &G, const int32_t *accum, float *res, int use_sh,
@@ -32,10 +34,13 @@ int gs_raster_forward_ref(const RasterSrc &S, const RasterGeom &G, const int32_t
 
 namespace {
 
-// exclusive scan of ceil(nproc/64) (or floor, see full_only) over tiles -> bucket_offsets[T+1], total -> *n_buckets
+// exclusive scan of ceil(nproc/64) over tiles -> bucket_offsets[T+1], total -> *n_buckets,
+// and the inverse map bucket -> tile (the bucket kernels would otherwise each start with a 13-step binary search
+// of dependent loads)
 __global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t *__restrict__ tile_nproc, int n_tiles,
                                                           uint32_t *__restrict__ bucket_offsets,
-                                                          unsigned long long *__restrict__ n_buckets, int full_only) {
+                                                          unsigned long long *__restrict__ n_buckets,
+                                                          uint32_t *__restrict__ bucket_tile) {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
     if (threadIdx.x == 0) s_carry = 0;
@@ -43,8 +48,7 @@ __global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t *__res
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int base = 0; base < n_tiles; base += 1024) {
         const int i = base + threadIdx.x;
-        // full_only: the ragged tail of every tile (nproc mod 64 Gaussians) goes to raster_backward_tail_kernel
-        const uint32_t v = i < n_tiles ? (tile_nproc[i] + (full_only ? 0 : GS_BUCKET - 1)) / GS_BUCKET : 0;
+        const uint32_t v = i < n_tiles ? (tile_nproc[i] + GS_BUCKET - 1) / GS_BUCKET : 0;
         const uint32_t incl = gs_wave_incl_scan_u32(v);
         if (lane == 63) s_wave[wave] = incl;
         __syncthreads();
@@ -52,7 +56,11 @@ __global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t *__res
 #pragma unroll
         for (int w = 0; w < 16; ++w) woff += w < wave ? s_wave[w] : 0;
         const uint32_t carry = s_carry;
-        if (i < n_tiles) bucket_offsets[i] = carry + woff + incl - v;
+        if (i < n_tiles) {
+            const uint32_t first = carry + woff + incl - v;
+            bucket_offsets[i] = first;
+            for (uint32_t b = 0; b < v; ++b) bucket_tile[first + b] = (uint32_t)i;
+        }
         __syncthreads();
         if (threadIdx.x == 1023) s_carry = carry + woff + incl;
         __syncthreads();
@@ -80,6 +88,7 @@ struct BwdIn {
     const float4 *ckpt;
     const uint32_t *tile_nproc;
     const uint32_t *bucket_offsets;  // [T+1]
+    const uint32_t *bucket_tile;     // [n_buckets]
     const int32_t *ranges;           // FRAME: [T][2]; REF: accum [T+1]
 };
 
@@ -154,13 +163,7 @@ __global__ void __launch_bounds__(64 * BwdCfg<CDIM>::WPB) raster_backward_kernel
     const uint32_t kb = blockIdx.x * WPB + wave;
     if (kb >= I.bucket_offsets[n_tiles]) return;  // whole wave exits; no block-level barrier below
 
-    // bucket -> (tile, local bucket): last tile with bucket_offsets[t] <= kb
-    uint32_t lo = 0, hi = n_tiles;
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (I.bucket_offsets[mid] <= kb) lo = mid; else hi = mid;
-    }
-    const uint32_t tile = lo, b = kb - I.bucket_offsets[tile];
+    const uint32_t tile = I.bucket_tile[kb], b = kb - I.bucket_offsets[tile];  // bucket -> (tile, local bucket)
     const uint32_t tx = tile % (uint32_t)G.ntx, ty = tile / (uint32_t)G.ntx;
     const uint32_t start = (uint32_t)(FRAME ? I.ranges[2 * tile] : I.ranges[tile]);
     const uint32_t nproc = I.tile_nproc[tile];
@@ -430,21 +433,40 @@ __global__ void __launch_bounds__(64 * BwdCfg<CDIM>::WPB) raster_backward_kernel
 }
 
 // ---------------------------------------------------------------------------------------------
-// Ragged tails (no SH).  A systolic bucket streams all 256 pixels through its 64 lanes however few
-// Gaussians it holds: the last bucket of a 133-Gaussian tile keeps 5 lanes busy for 260 steps (17 us of
-// SIMD time, as much as a full bucket).  The r = nproc mod 64 trailing Gaussians of every tile are
-// therefore handled the other way round: ONE wave per tile, lanes own pixels (four each, the forward's
-// layout), the r Gaussians are applied one after the other from the tile's last checkpoint, and the ten
-// per-Gaussian sums are reduced over the wave through LDS, two Gaussians at a time (20 rows of 64
-// partials, summed by 20 lanes).  ~0.25 us per Gaussian instead of 17 us per bucket.
+// No SH: the pixel-parallel bucket kernel.  One wave per (tile, bucket of 64 Gaussians), lanes own PIXELS (four
+// each, the forward's layout), the bucket's Gaussians are applied one after the other from the bucket's checkpoint,
+// and the ten per-Gaussian sums are reduced over the wave through LDS, two Gaussians at a time: 20 rows of 64
+// partials, three lanes per row add a slice each (60 lanes busy), one lane per row adds the three slice sums, and
+// at the end lane i finishes the algebra of Gaussian i and stores its row.
+// Why not the systolic pipeline here: per (pixel, Gaussian) pair it issues 0.89 VALU instructions (every lane
+// carries one pair per step: its own q, exp, rcp, DPP moves, table addressing; PMC), this layout 0.59 (dx and the
+// Gaussian's constants are shared by the lane's four pixels, the reduction costs 20 of 146 instructions per
+// Gaussian) -- and both are VALU-issue bound.  Measured, same run: cfg2 0.450 -> 0.362 ms, 2.4 M Gaussians
+// 0.776 -> 0.611 ms.  It started as the handler of the ragged tails of the systolic kernel (a 5-Gaussian bucket
+// costs the systolic pipeline as much as a full one) and took over the whole no-SH backward.
+#ifndef GS_PP_TG
+#define GS_PP_TG 2
+#endif
+#ifndef GS_PP_WPB
+#define GS_PP_WPB 1
+#endif
 template <bool FRAME>
-__global__ void __launch_bounds__(64) raster_backward_tail_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
-    constexpr int TG = 2;  // Gaussians per reduction group (LDS: TG x 10 rows of 64 partials)
-    enum { FX, FY, FA, FB, FC, FOPA, FC0, FC1, FC2, FCA, FCB, FCC, FCD, NFLD };
-    __shared__ float s_g[NFLD][64];
-    __shared__ uint32_t s_gid[64];
-    __shared__ float s_red[TG * 10][65];
-    __shared__ float s_tot[64][10];
+__global__ void __launch_bounds__(64 * GS_PP_WPB) raster_backward_pixel_kernel(RasterSrc S, RasterGeom G, BwdIn I,
+                                                                                BwdOut O) {
+    constexpr int TG = GS_PP_TG;          // Gaussians per reduction group (LDS: TG x 10 rows of 64 partials)
+    constexpr int LPR = 60 / (10 * TG);   // lanes that share the sum of one row (two-level reduction)
+    constexpr int CH = (64 + LPR - 1) / LPR;
+    enum { FX, FY, FA, FB, FC, FOPA, FC0, FC1, FC2, NFLD };
+    constexpr int WPB = GS_PP_WPB;  // waves per workgroup, one bucket each (they never synchronise); 1 measured best
+    __shared__ float sw_g[WPB][NFLD][64];
+    __shared__ float sw_red[WPB][TG * 10][65];
+    __shared__ float sw_part[WPB][TG * 10][LPR + 1];
+    __shared__ float sw_tot[WPB][64][10];
+    const int wave = threadIdx.x >> 6;
+    float (*s_g)[64] = sw_g[wave];
+    float (*s_red)[65] = sw_red[wave];
+    float (*s_part)[LPR + 1] = sw_part[wave];
+    float (*s_tot)[10] = sw_tot[wave];
     // LDS traffic of ONE wave is processed in program order, so the stages below only need the compiler
     // not to move LDS accesses across them.  (A `fence acq_rel` would also drain the outstanding global
     // loads and stores -- measured: 80 us of a 124 us kernel when the row stores sat inside the loop.)
@@ -452,20 +474,18 @@ __global__ void __launch_bounds__(64) raster_backward_tail_kernel(RasterSrc S, R
         asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
     };
-    const int lane = threadIdx.x;
-    const uint32_t tile = blockIdx.x;
-    const uint32_t nproc = I.tile_nproc[tile];
-    const uint32_t r = nproc % GS_BUCKET;
-    if (r == 0) return;
-    const uint32_t base = nproc - r;
+    const int lane = threadIdx.x & 63;
+    auto run = [&](const uint32_t tile, const uint32_t r, const uint32_t base) {
     const uint32_t tx = tile % (uint32_t)G.ntx, ty = tile / (uint32_t)G.ntx;
     const uint32_t start = (uint32_t)(FRAME ? I.ranges[2 * tile] : I.ranges[tile]);
 
-    // ---- stage the r Gaussians (one per lane), zero-padded to a multiple of 4
+    // ---- stage the r Gaussians (one per lane): what the pixel loop reads goes to LDS, what only the final
+    // algebra of THIS lane's Gaussian needs (covariance, conic, id) stays in its registers
+    GaussianRec g = {0, 0, 0, 0, 0, 0, 0};
+    float cA = 0, cB = 0, cC = 0;
+    uint32_t gid = 0;
     {
-        GaussianRec g = {0, 0, 0, 0, 0, 0, 0};
-        float c0 = 0, c1 = 0, c2 = 0, cA = 0, cB = 0, cC = 0;
-        uint32_t gid = 0;
+        float c0 = 0, c1 = 0, c2 = 0;
         if ((uint32_t)lane < r) {
             const uint32_t j = start + base + lane;
             gid = raster_load<FRAME>(S, j, g);
@@ -481,11 +501,6 @@ __global__ void __launch_bounds__(64) raster_backward_tail_kernel(RasterSrc S, R
         s_g[FC0][lane] = c0;
         s_g[FC1][lane] = c1;
         s_g[FC2][lane] = c2;
-        s_g[FCA][lane] = g.a;
-        s_g[FCB][lane] = g.b;
-        s_g[FCC][lane] = g.c;
-        s_g[FCD][lane] = g.d;
-        s_gid[lane] = gid;
     }
 
     // ---- this lane's four pixels: (x, y0 + 4k)
@@ -514,15 +529,15 @@ __global__ void __launch_bounds__(64) raster_backward_tail_kernel(RasterSrc S, R
 #pragma unroll
         for (int u = 0; u < TG; ++u) {
             const uint32_t i = i0 + u;  // < 64: padded entries have opacity 0 and contribute exact zeros
-            const float gx = s_g[FX][i], gy = s_g[FY][i], cA = s_g[FA][i], cB = s_g[FB][i], cC = s_g[FC][i];
+            const float gx = s_g[FX][i], gy = s_g[FY][i], uA = s_g[FA][i], uB = s_g[FB][i], uC = s_g[FC][i];
             const float opa = s_g[FOPA][i], c0 = s_g[FC0][i], c1 = s_g[FC1][i], c2 = s_g[FC2][i];
             float Sx = 0, Sy = 0, Sxx = 0, Sxy = 0, Syy = 0, Sq = 0, Sopa = 0, Sc0 = 0, Sc1 = 0, Sc2 = 0;
             const float dx = px - gx;
-            const float bdx = cB * dx, adx2 = cA * dx * dx;
+            const float bdx = uB * dx, adx2 = uA * dx * dx;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float dy = py[k] - gy;
-                const float q = fmaf(fmaf(cC, dy, -bdx), dy, adx2);
+                const float q = fmaf(fmaf(uC, dy, -bdx), dy, adx2);
                 const float Gv = gs_exp2(-q);
                 const bool live = T[k] > GS_T_STOP;
                 const float alpha = live ? Gv * opa : 0.f;
@@ -558,16 +573,25 @@ __global__ void __launch_bounds__(64) raster_backward_tail_kernel(RasterSrc S, R
             red[9 * 65] = Sc2;
         }
         lds_order();
-        if (lane < TG * 10) {  // lane = 10 u + m sums row m of Gaussian i0 + u over the 64 lanes
-            float t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        // two-level sum of the TG x 10 rows: LPR lanes per row add a slice each (60 lanes busy), then one lane per
+        // row adds the LPR slice sums.  Row 10 u + m = value m of Gaussian i0 + u.
+        if (lane < TG * 10 * LPR) {
+            const int row = lane / LPR, part = lane % LPR;
+            float t0 = 0, t1 = 0;
 #pragma unroll
-            for (int l = 0; l < 64; l += 4) {
-                t0 += s_red[lane][l];
-                t1 += s_red[lane][l + 1];
-                t2 += s_red[lane][l + 2];
-                t3 += s_red[lane][l + 3];
+            for (int l = 0; l < CH; l += 2) {
+                const int a = part * CH + l;
+                t0 += a < 64 ? s_red[row][a] : 0.f;
+                t1 += a + 1 < 64 ? s_red[row][a + 1] : 0.f;
             }
-            s_tot[i0 + lane / 10][lane % 10] = (t0 + t1) + (t2 + t3);
+            s_part[row][part] = t0 + t1;
+        }
+        lds_order();
+        if (lane < TG * 10) {
+            float t = s_part[lane][0];
+#pragma unroll
+            for (int l = 1; l < LPR; ++l) t += s_part[lane][l];
+            s_tot[i0 + lane / 10][lane % 10] = t;
         }
         lds_order();
     }
@@ -575,15 +599,13 @@ __global__ void __launch_bounds__(64) raster_backward_tail_kernel(RasterSrc S, R
         const uint32_t i = lane;
         const float *t = s_tot[lane];
         const float Sx = t[0], Sy = t[1], Sxx = t[2], Sxy = t[3], Syy = t[4], Sq = t[5];
-        const float cA = s_g[FA][i], cB = s_g[FB][i], cC = s_g[FC][i];
-        const float a = s_g[FCA][i], b = s_g[FCB][i], c = s_g[FCC][i], d = s_g[FCD][i];
+        const float a = g.a, b = g.b, c = g.c, d = g.d;
         const float iPn = 1.0f / (2.0f * raster_det(a, b, c, d) + 1e-14f);
         const float Su = Sq * GS_LN2;
         const float ogx = GS_LN2 * (2.0f * cA * Sx - cB * Sy), ogy = GS_LN2 * (2.0f * cC * Sy - cB * Sx);
         const float ga = iPn * (-Syy + 2.0f * d * Su), gb = iPn * (Sxy - 2.0f * c * Su);
         const float gcc = iPn * (Sxy - 2.0f * b * Su), gd = iPn * (-Sxx + 2.0f * a * Su);
         if (FRAME) {
-            const uint32_t gid = s_gid[i];
             const uint4 rc = O.rects[gid];
             const uint32_t y0 = rc.x & 0xffff, x0 = rc.y & 0xffff, x1 = rc.y >> 16;
             const uint64_t slot = (uint64_t)O.pair_offsets[gid] + (ty - y0) * (x1 - x0) + (tx - x0);
@@ -604,6 +626,17 @@ __global__ void __launch_bounds__(64) raster_backward_tail_kernel(RasterSrc S, R
             O.grad_rgb[j * 3 + 2] = t[9];
         }
     }
+    };
+    // one wave per (tile, bucket) of the ceil-bucket list.  (A persistent grid walking the list was slower at every
+    // grid size, 0.38-0.51 ms against 0.36 ms at cfg2: short-lived waves let the hardware overlap one wave's load
+    // phase with the others' arithmetic.  Several waves per workgroup: no gain either.)
+    const uint32_t n_tiles = (uint32_t)(G.ntx * G.nty), kb = blockIdx.x * WPB + wave;
+    if (kb < I.bucket_offsets[n_tiles]) {
+        const uint32_t tile = I.bucket_tile[kb];
+        const uint32_t base = (kb - I.bucket_offsets[tile]) * GS_BUCKET;
+        const uint32_t nproc = I.tile_nproc[tile];
+        run(tile, nproc - base < (uint32_t)GS_BUCKET ? nproc - base : (uint32_t)GS_BUCKET, base);
+    }
 }
 
 // sigmoid=True of the reference API: ceil buckets in the systolic kernel, no tail kernel (a rarely used flag)
@@ -621,37 +654,16 @@ void launch_bwd(const RasterSrc &S, const RasterGeom &G, const BwdIn &I, const B
     constexpr int WPB = BwdCfg<CDIM>::WPB;
     const int grid = (int)gs_div_up(max_buckets > 0 ? max_buckets : 1, WPB);
     if (CDIM == 3) {
-        // The systolic kernel sees full buckets only (bucket_scan_kernel, full_only); the ragged tails run in
-        // raster_backward_tail_kernel.  That kernel is short and latency-bound (dependent loads, LDS round trips
-        // per group), the systolic one is VALU-bound, and they write disjoint rows: fork the tails onto a side
-        // stream so that both are resident together, join before the caller's next kernel.
-        static thread_local hipStream_t side = nullptr;
-        static thread_local hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-        static thread_local int side_dev = -1;
-        bool forked = false;
-        int dev = -1;
-        if (hipGetDevice(&dev) == hipSuccess && (!side || dev != side_dev)) {  // one side stream per (thread, device)
-            side = nullptr;  // a stream made on another device is abandoned (one process per GPU is the norm)
-            if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess ||
-                hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess)
-                side = nullptr;  // fall back to the caller's stream (still correct, just serial)
-            side_dev = dev;
-        }
-        if (side && hipEventRecord(ev_fork, stream) == hipSuccess && hipStreamWaitEvent(side, ev_fork, 0) == hipSuccess)
-            forked = true;
-        hipLaunchKernelGGL((raster_backward_tail_kernel<FRAME>), dim3(G.ntx * G.nty), dim3(64), 0,
-                           forked ? side : stream, S, G, I, O);
-        if (forked && hipEventRecord(ev_join, side) != hipSuccess) forked = false;
-        hipLaunchKernelGGL((raster_backward_kernel<CDIM, FRAME>), dim3(grid), dim3(64 * WPB), 0, stream, S, G, I, O);
-        if (forked) (void)hipStreamWaitEvent(stream, ev_join, 0);
+        const int64_t blocks = gs_div_up(max_buckets > 0 ? max_buckets : 1, GS_PP_WPB);
+        hipLaunchKernelGGL((raster_backward_pixel_kernel<FRAME>), dim3((unsigned)blocks), dim3(64 * GS_PP_WPB), 0, stream,
+                           S, G, I, O);
     } else {
         hipLaunchKernelGGL((raster_backward_kernel<CDIM, FRAME>), dim3(grid), dim3(64 * WPB), 0, stream, S, G, I, O);
     }
 }
 
 struct RefWs {
-    uint32_t *tile_nproc, *bucket_offsets;
+    uint32_t *tile_nproc, *bucket_offsets, *bucket_tile;
     unsigned long long *n_buckets;
     float4 *ckpt;
     int64_t max_buckets;
@@ -669,6 +681,7 @@ RefWs carve_ref(void *base, int64_t M, int32_t h, int32_t w) {
     r.max_buckets = gs_max_buckets(M, n_tiles);
     r.tile_nproc = (uint32_t *)take(sizeof(uint32_t) * n_tiles);
     r.bucket_offsets = (uint32_t *)take(sizeof(uint32_t) * (n_tiles + 1));
+    r.bucket_tile = (uint32_t *)take(sizeof(uint32_t) * (size_t)r.max_buckets);
     r.n_buckets = (unsigned long long *)take(sizeof(unsigned long long));
     r.ckpt = (float4 *)take(sizeof(float4) * 256 * (size_t)r.max_buckets);
     r.bytes = off;
@@ -734,9 +747,9 @@ extern "C" int gs_draw_backward(const float *pos, const float *rgb, const float 
     if (rc) return rc;
     // 2. bucket work list
     hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, s, ws.tile_nproc, G.ntx * G.nty,
-                       ws.bucket_offsets, ws.n_buckets, (use_sh_coeff || sigmoid) ? 0 : 1);
+                       ws.bucket_offsets, ws.n_buckets, ws.bucket_tile);
     // 3. systolic backward, one wave per bucket, one output row per pair
-    BwdIn I = {output, grad_output, ws.ckpt, ws.tile_nproc, ws.bucket_offsets, tile_n_point_accum};
+    BwdIn I = {output, grad_output, ws.ckpt, ws.tile_nproc, ws.bucket_offsets, ws.bucket_tile, tile_n_point_accum};
     BwdOut O = {nullptr, nullptr, nullptr, 0, grad_pos, grad_rgb, grad_opa, grad_cov};
     if (sigmoid && use_sh_coeff)
         launch_bwd_sig<27>(S, G, I, O, ws.max_buckets, s);
@@ -780,8 +793,8 @@ int gs_stage_raster_backward(const gs_frame *f, const gs_frame_ws &ws, const uin
     // rows of pairs the forward never reached (early termination) must read as zero
     GS_HIP(hipMemsetAsync(ws.rows, 0, sizeof(float) * (size_t)gs_row_floats(f->color_dim) * f->max_pairs, stream));
     hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, ws.tile_nproc, FG.n_tiles,
-                       ws.bucket_offsets, ws.counters + GS_CNT_BUCKETS, f->color_dim == 3 ? 1 : 0);
-    BwdIn I = {f->image_padded, grad_image, ws.ckpt, ws.tile_nproc, ws.bucket_offsets, ws.tile_ranges};
+                       ws.bucket_offsets, ws.counters + GS_CNT_BUCKETS, ws.bucket_tile);
+    BwdIn I = {f->image_padded, grad_image, ws.ckpt, ws.tile_nproc, ws.bucket_offsets, ws.bucket_tile, ws.tile_ranges};
     BwdOut O = {ws.rows, ws.pair_offsets, ws.rects, (uint64_t)f->max_pairs, nullptr, nullptr, nullptr, nullptr};
     if (f->color_dim == 48)
         launch_bwd<48, true>(S, G, I, O, ws.max_buckets, stream);
