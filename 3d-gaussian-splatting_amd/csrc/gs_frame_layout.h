@@ -67,7 +67,7 @@ struct gs_frame_ws {
     // training only
     uint32_t *tile_nproc;          // [T] Gaussians processed by the forward (multiple of the chunk)
     uint32_t *bucket_offsets;      // [T+1] exclusive scan of ceil(nproc/64)
-    uint32_t *bucket_tile;         // [max_buckets] tile of every bucket (written with the scan)
+    uint4 *bucket_info;            // [max_buckets + 8] (tile, first Gaussian, count, list start) per bucket
     float4 *ckpt;                  // [max_buckets][256] (T, Cr, Cg, Cb) at bucket starts
     float *rows;                   // [max_pairs][GS_ROW(C)] per-pair gradient rows in EMISSION order
     int64_t max_buckets;
@@ -119,13 +119,13 @@ static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pair
     if (training) {
         ws.tile_nproc = (uint32_t *)take(sizeof(uint32_t) * G.n_tiles);
         ws.bucket_offsets = (uint32_t *)take(sizeof(uint32_t) * (G.n_tiles + 1));
-        ws.bucket_tile = (uint32_t *)take(sizeof(uint32_t) * (size_t)ws.max_buckets);
+        ws.bucket_info = (uint4 *)take(sizeof(uint4) * (size_t)(ws.max_buckets + 8));
         ws.ckpt = (float4 *)take(sizeof(float4) * 256 * (size_t)ws.max_buckets);
         ws.rows = (float *)take(sizeof(float) * (size_t)gs_row_floats(color_dim) * max_pairs);
     } else {
         ws.tile_nproc = nullptr;
         ws.bucket_offsets = nullptr;
-        ws.bucket_tile = nullptr;
+        ws.bucket_info = nullptr;
         ws.ckpt = nullptr;
         ws.rows = nullptr;
     }

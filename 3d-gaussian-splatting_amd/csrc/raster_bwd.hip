@@ -34,13 +34,15 @@ int gs_raster_forward_ref(const RasterSrc &S, const RasterGeom &G, const int32_t
 
 namespace {
 
-// exclusive scan of ceil(nproc/64) over tiles -> bucket_offsets[T+1], total -> *n_buckets,
-// and the inverse map bucket -> tile (the bucket kernels would otherwise each start with a 13-step binary search
-// of dependent loads)
+// exclusive scan of ceil(nproc/64) over tiles -> bucket_offsets[T+1], total -> *n_buckets, and one record per bucket
+// (tile, first Gaussian of the bucket inside the tile's list, Gaussians in the bucket, start of the tile's list):
+// a bucket kernel's wave learns everything about its work item from ONE load instead of a binary search over the
+// offsets followed by three dependent loads
 __global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t *__restrict__ tile_nproc, int n_tiles,
                                                           uint32_t *__restrict__ bucket_offsets,
                                                           unsigned long long *__restrict__ n_buckets,
-                                                          uint32_t *__restrict__ bucket_tile) {
+                                                          uint4 *__restrict__ bucket_info,
+                                                          const int32_t *__restrict__ ranges, int frame_ranges) {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
     if (threadIdx.x == 0) s_carry = 0;
@@ -59,7 +61,11 @@ __global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t *__res
         if (i < n_tiles) {
             const uint32_t first = carry + woff + incl - v;
             bucket_offsets[i] = first;
-            for (uint32_t b = 0; b < v; ++b) bucket_tile[first + b] = (uint32_t)i;
+            const uint32_t np = tile_nproc[i], st = (uint32_t)(frame_ranges ? ranges[2 * i] : ranges[i]);
+            for (uint32_t b = 0; b < v; ++b) {
+                const uint32_t rem = np - b * GS_BUCKET;
+                bucket_info[first + b] = make_uint4((uint32_t)i, b * GS_BUCKET, rem < GS_BUCKET ? rem : GS_BUCKET, st);
+            }
         }
         __syncthreads();
         if (threadIdx.x == 1023) s_carry = carry + woff + incl;
@@ -88,7 +94,7 @@ struct BwdIn {
     const float4 *ckpt;
     const uint32_t *tile_nproc;
     const uint32_t *bucket_offsets;  // [T+1]
-    const uint32_t *bucket_tile;     // [n_buckets]
+    const uint4 *bucket_info;        // [n_buckets] (tile, first Gaussian, count, start of the tile's list)
     const int32_t *ranges;           // FRAME: [T][2]; REF: accum [T+1]
 };
 
@@ -163,7 +169,8 @@ __global__ void __launch_bounds__(64 * BwdCfg<CDIM>::WPB) raster_backward_kernel
     const uint32_t kb = blockIdx.x * WPB + wave;
     if (kb >= I.bucket_offsets[n_tiles]) return;  // whole wave exits; no block-level barrier below
 
-    const uint32_t tile = I.bucket_tile[kb], b = kb - I.bucket_offsets[tile];  // bucket -> (tile, local bucket)
+    const uint4 info = I.bucket_info[kb];
+    const uint32_t tile = info.x, b = info.y / GS_BUCKET;  // bucket -> (tile, local bucket)
     const uint32_t tx = tile % (uint32_t)G.ntx, ty = tile / (uint32_t)G.ntx;
     const uint32_t start = (uint32_t)(FRAME ? I.ranges[2 * tile] : I.ranges[tile]);
     const uint32_t nproc = I.tile_nproc[tile];
@@ -475,76 +482,127 @@ __global__ void __launch_bounds__(64 * GS_PP_WPB) raster_backward_pixel_kernel(R
         __builtin_amdgcn_wave_barrier();
     };
     const int lane = threadIdx.x & 63;
-    auto run = [&](const uint32_t tile, const uint32_t r, const uint32_t base) {
+    // ---- work item: ONE load; everything below is issued before anything is waited for (the loads of the wave's
+    // short life -- bucket record, ids -> Gaussian records, checkpoints, pixel inputs -- used to be eight dependent
+    // round trips, ~9 us in front of ~11 us of arithmetic)
+    const uint32_t n_tiles = (uint32_t)(G.ntx * G.nty), kb = blockIdx.x * WPB + wave;
+    const uint4 info = I.bucket_info[kb];  // in bounds for every launched wave (the table is padded)
+    if (kb >= I.bucket_offsets[n_tiles]) return;
+    const uint32_t tile = info.x, base = info.y, r = info.z, start = info.w;
     const uint32_t tx = tile % (uint32_t)G.ntx, ty = tile / (uint32_t)G.ntx;
-    const uint32_t start = (uint32_t)(FRAME ? I.ranges[2 * tile] : I.ranges[tile]);
 
-    // ---- stage the r Gaussians (one per lane): what the pixel loop reads goes to LDS, what only the final
-    // algebra of THIS lane's Gaussian needs (covariance, conic, id) stays in its registers
-    GaussianRec g = {0, 0, 0, 0, 0, 0, 0};
-    float cA = 0, cB = 0, cC = 0;
-    uint32_t gid = 0;
-    {
-        float c0 = 0, c1 = 0, c2 = 0;
-        if ((uint32_t)lane < r) {
-            const uint32_t j = start + base + lane;
-            gid = raster_load<FRAME>(S, j, g);
-            raster_load_rgb<FRAME>(S, j, gid, c0, c1, c2);
-            raster_conic(g, cA, cB, cC);
+    // ---- this lane's Gaussian (lanes >= r re-read the bucket's last one and are zeroed below: no branch around
+    // the loads) and its four pixels (x, y0 + 4k)
+    GaussianRec g;
+    float c0, c1, c2;
+    const uint32_t jl = start + base + ((uint32_t)lane < r ? (uint32_t)lane : r - 1);
+    const uint32_t gid = raster_load<FRAME>(S, jl, g);
+    raster_load_rgb<FRAME>(S, jl, gid, c0, c1, c2);
+    const uint32_t id_x = tx * 16 + (lane & 15), id_y0 = ty * 16 + (lane >> 4);
+    const float px = raster_pixel_coord(id_x, G.padW, G.focal_x);
+    const float4 *ck = I.ckpt + raster_ckpt_slot(start, tile, base / GS_BUCKET) * 256;
+    float4 c[4];
+    float f[4][3], gr[4][3];
+    bool inside[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        c[k] = ck[64 * k + lane];  // tile pixel index = 16 (y - ty 16) + (x - tx 16); stale for the first bucket
+        // final colour and dL/dC of the pixel (see load_pixel_inputs): raw loads from clamped addresses here, the
+        // crop / clamp masks after ALL loads are in flight
+        const uint32_t id_y = id_y0 + 4 * k;
+        const float *cf = I.c_final + ((size_t)id_y * G.padW + id_x) * 3;
+        const int ox = FRAME ? (int)id_x - G.crop_left : (int)id_x, oy = FRAME ? (int)id_y - G.crop_top : (int)id_y;
+        inside[k] = !FRAME || (ox >= 0 && ox < G.width && oy >= 0 && oy < G.height);
+        const float *gp = I.grad + ((size_t)(inside[k] ? oy : 0) * (FRAME ? G.width : G.padW) + (inside[k] ? ox : 0)) * 3;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            f[k][e] = cf[e];
+            gr[k][e] = gp[e];
         }
+    }
+    // the compiler would otherwise sink each gradient load behind its `inside` test and wait for it there: four
+    // dependent round trips instead of one
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        asm volatile("" ::"v"(gr[k][0]), "v"(gr[k][1]), "v"(gr[k][2]), "v"(f[k][0]), "v"(f[k][1]), "v"(f[k][2]),
+                     "v"(c[k].x), "v"(c[k].y), "v"(c[k].z), "v"(c[k].w));
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+            gr[k][e] = (inside[k] && (!FRAME || (f[k][e] >= 0.f && f[k][e] <= 1.f))) ? gr[k][e] : 0.f;
+    float cA = 0, cB = 0, cC = 0;
+    {
+        const bool valid = (uint32_t)lane < r;
+        raster_conic(g, cA, cB, cC);
+        // what the pixel loop reads goes to LDS; what only the final algebra of THIS lane's Gaussian needs
+        // (covariance, conic, id) stays in its registers
         s_g[FX][lane] = g.x;
         s_g[FY][lane] = g.y;
         s_g[FA][lane] = cA;
         s_g[FB][lane] = cB;
         s_g[FC][lane] = cC;
-        s_g[FOPA][lane] = (uint32_t)lane < r ? g.opa : 0.f;
+        s_g[FOPA][lane] = valid ? g.opa : 0.f;  // opacity 0 => alpha 0: padded entries contribute exact zeros
         s_g[FC0][lane] = c0;
         s_g[FC1][lane] = c1;
         s_g[FC2][lane] = c2;
     }
-
-    // ---- this lane's four pixels: (x, y0 + 4k)
-    const uint32_t id_x = tx * 16 + (lane & 15), id_y0 = ty * 16 + (lane >> 4);
-    const float px = raster_pixel_coord(id_x, G.padW, G.focal_x);
-    const float4 *ck = I.ckpt + raster_ckpt_slot(start, tile, base / GS_BUCKET) * 256;
     float py[4], T[4], rho[4], g0[4], g1[4], g2[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const uint32_t id_y = id_y0 + 4 * k;
-        py[k] = raster_pixel_coord(id_y, G.padH, G.focal_y);
-        // tile pixel index = 16 (y - ty 16) + (x - tx 16); the tile's first bucket starts from the empty pixel
-        const float4 c = base == 0 ? make_float4(1.f, 0.f, 0.f, 0.f) : ck[64 * k + lane];
-        float f[3], g[3];
-        load_pixel_inputs<FRAME>(I, G, id_x, id_y, f, g);
-        const float f0 = f[0], f1 = f[1], f2 = f[2];
-        g0[k] = g[0];
-        g1[k] = g[1];
-        g2[k] = g[2];
-        T[k] = c.x;
-        rho[k] = g0[k] * (f0 - c.y) + g1[k] * (f1 - c.z) + g2[k] * (f2 - c.w);
+        py[k] = raster_pixel_coord(id_y0 + 4 * k, G.padH, G.focal_y);
+        // the tile's first bucket starts from the empty pixel (T, C) = (1, 0), which the forward does not store
+        const float4 ci = base == 0 ? make_float4(1.f, 0.f, 0.f, 0.f) : c[k];
+        g0[k] = gr[k][0];
+        g1[k] = gr[k][1];
+        g2[k] = gr[k][2];
+        T[k] = ci.x;
+        rho[k] = g0[k] * (f[k][0] - ci.y) + g1[k] * (f[k][1] - ci.z) + g2[k] * (f[k][2] - ci.w);
     }
     lds_order();
 
     for (uint32_t i0 = 0; i0 < r; i0 += TG) {
+        // Step 1, everything that does not depend on the pixels' running state: the exponent, G = 2^-q and
+        // 1 / (1 - alpha + 1e-7) for the TG x 4 (Gaussian, pixel) pairs -- 2 TG x 4 independent transcendentals
+        // in flight (left inside the serial chain below they cost ~10 ns each instead of 3.4: ablation).  The
+        // reciprocal is taken for the live case; a finished pixel has d_alpha forced to zero whatever it is.
+        float dxs[TG], dys[TG][4], qs[TG][4], Gs[TG][4], rcs[TG][4], ops[TG], cc[TG][3];
 #pragma unroll
         for (int u = 0; u < TG; ++u) {
             const uint32_t i = i0 + u;  // < 64: padded entries have opacity 0 and contribute exact zeros
             const float gx = s_g[FX][i], gy = s_g[FY][i], uA = s_g[FA][i], uB = s_g[FB][i], uC = s_g[FC][i];
-            const float opa = s_g[FOPA][i], c0 = s_g[FC0][i], c1 = s_g[FC1][i], c2 = s_g[FC2][i];
-            float Sx = 0, Sy = 0, Sxx = 0, Sxy = 0, Syy = 0, Sq = 0, Sopa = 0, Sc0 = 0, Sc1 = 0, Sc2 = 0;
+            ops[u] = s_g[FOPA][i];
+            cc[u][0] = s_g[FC0][i];
+            cc[u][1] = s_g[FC1][i];
+            cc[u][2] = s_g[FC2][i];
             const float dx = px - gx;
             const float bdx = uB * dx, adx2 = uA * dx * dx;
+            dxs[u] = dx;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float dy = py[k] - gy;
                 const float q = fmaf(fmaf(uC, dy, -bdx), dy, adx2);
                 const float Gv = gs_exp2(-q);
+                dys[u][k] = dy;
+                qs[u][k] = q;
+                Gs[u][k] = Gv;
+                rcs[u][k] = gs_rcp(1.0f - Gv * ops[u] + 1e-7f);
+            }
+        }
+        // Step 2, front to back through the group: the chain through T and rho is plain arithmetic only
+#pragma unroll
+        for (int u = 0; u < TG; ++u) {
+            const float dx = dxs[u], opa = ops[u], c0 = cc[u][0], c1 = cc[u][1], c2 = cc[u][2];
+            float Sx = 0, Sy = 0, Sxx = 0, Sxy = 0, Syy = 0, Sq = 0, Sopa = 0, Sc0 = 0, Sc1 = 0, Sc2 = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float dy = dys[u][k], q = qs[u][k], Gv = Gs[u][k];
                 const bool live = T[k] > GS_T_STOP;
                 const float alpha = live ? Gv * opa : 0.f;
                 const float w = alpha * T[k];
                 const float gc = fmaf(g2[k], c2, fmaf(g1[k], c1, g0[k] * c0));
                 rho[k] = fmaf(-w, gc, rho[k]);
-                float d_alpha = fmaf(T[k], gc, -(rho[k] * gs_rcp(1.0f - alpha + 1e-7f)));
+                float d_alpha = fmaf(T[k], gc, -(rho[k] * rcs[u][k]));
                 d_alpha = live ? d_alpha : 0.f;
                 Sc0 = fmaf(g0[k], w, Sc0);
                 Sc1 = fmaf(g1[k], w, Sc1);
@@ -626,17 +684,6 @@ __global__ void __launch_bounds__(64 * GS_PP_WPB) raster_backward_pixel_kernel(R
             O.grad_rgb[j * 3 + 2] = t[9];
         }
     }
-    };
-    // one wave per (tile, bucket) of the ceil-bucket list.  (A persistent grid walking the list was slower at every
-    // grid size, 0.38-0.51 ms against 0.36 ms at cfg2: short-lived waves let the hardware overlap one wave's load
-    // phase with the others' arithmetic.  Several waves per workgroup: no gain either.)
-    const uint32_t n_tiles = (uint32_t)(G.ntx * G.nty), kb = blockIdx.x * WPB + wave;
-    if (kb < I.bucket_offsets[n_tiles]) {
-        const uint32_t tile = I.bucket_tile[kb];
-        const uint32_t base = (kb - I.bucket_offsets[tile]) * GS_BUCKET;
-        const uint32_t nproc = I.tile_nproc[tile];
-        run(tile, nproc - base < (uint32_t)GS_BUCKET ? nproc - base : (uint32_t)GS_BUCKET, base);
-    }
 }
 
 // sigmoid=True of the reference API: ceil buckets in the systolic kernel, no tail kernel (a rarely used flag)
@@ -663,7 +710,8 @@ void launch_bwd(const RasterSrc &S, const RasterGeom &G, const BwdIn &I, const B
 }
 
 struct RefWs {
-    uint32_t *tile_nproc, *bucket_offsets, *bucket_tile;
+    uint32_t *tile_nproc, *bucket_offsets;
+    uint4 *bucket_info;
     unsigned long long *n_buckets;
     float4 *ckpt;
     int64_t max_buckets;
@@ -681,7 +729,7 @@ RefWs carve_ref(void *base, int64_t M, int32_t h, int32_t w) {
     r.max_buckets = gs_max_buckets(M, n_tiles);
     r.tile_nproc = (uint32_t *)take(sizeof(uint32_t) * n_tiles);
     r.bucket_offsets = (uint32_t *)take(sizeof(uint32_t) * (n_tiles + 1));
-    r.bucket_tile = (uint32_t *)take(sizeof(uint32_t) * (size_t)r.max_buckets);
+    r.bucket_info = (uint4 *)take(sizeof(uint4) * (size_t)(r.max_buckets + 8));
     r.n_buckets = (unsigned long long *)take(sizeof(unsigned long long));
     r.ckpt = (float4 *)take(sizeof(float4) * 256 * (size_t)r.max_buckets);
     r.bytes = off;
@@ -747,9 +795,9 @@ extern "C" int gs_draw_backward(const float *pos, const float *rgb, const float 
     if (rc) return rc;
     // 2. bucket work list
     hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, s, ws.tile_nproc, G.ntx * G.nty,
-                       ws.bucket_offsets, ws.n_buckets, ws.bucket_tile);
+                       ws.bucket_offsets, ws.n_buckets, ws.bucket_info, tile_n_point_accum, 0);
     // 3. systolic backward, one wave per bucket, one output row per pair
-    BwdIn I = {output, grad_output, ws.ckpt, ws.tile_nproc, ws.bucket_offsets, ws.bucket_tile, tile_n_point_accum};
+    BwdIn I = {output, grad_output, ws.ckpt, ws.tile_nproc, ws.bucket_offsets, ws.bucket_info, tile_n_point_accum};
     BwdOut O = {nullptr, nullptr, nullptr, 0, grad_pos, grad_rgb, grad_opa, grad_cov};
     if (sigmoid && use_sh_coeff)
         launch_bwd_sig<27>(S, G, I, O, ws.max_buckets, s);
@@ -793,8 +841,8 @@ int gs_stage_raster_backward(const gs_frame *f, const gs_frame_ws &ws, const uin
     // rows of pairs the forward never reached (early termination) must read as zero
     GS_HIP(hipMemsetAsync(ws.rows, 0, sizeof(float) * (size_t)gs_row_floats(f->color_dim) * f->max_pairs, stream));
     hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, ws.tile_nproc, FG.n_tiles,
-                       ws.bucket_offsets, ws.counters + GS_CNT_BUCKETS, ws.bucket_tile);
-    BwdIn I = {f->image_padded, grad_image, ws.ckpt, ws.tile_nproc, ws.bucket_offsets, ws.bucket_tile, ws.tile_ranges};
+                       ws.bucket_offsets, ws.counters + GS_CNT_BUCKETS, ws.bucket_info, ws.tile_ranges, 1);
+    BwdIn I = {f->image_padded, grad_image, ws.ckpt, ws.tile_nproc, ws.bucket_offsets, ws.bucket_info, ws.tile_ranges};
     BwdOut O = {ws.rows, ws.pair_offsets, ws.rects, (uint64_t)f->max_pairs, nullptr, nullptr, nullptr, nullptr};
     if (f->color_dim == 48)
         launch_bwd<48, true>(S, G, I, O, ws.max_buckets, stream);
