@@ -450,6 +450,65 @@ __global__ void __launch_bounds__(256) frame_project_backward_kernel(
         for (int k = 0; k < 4 * RW4 - 8; ++k) gsh[k] = 0.f;
     }
     const uint64_t off = vis ? pair_offsets[pid] : 0, cnt = vis ? tiles_touched[pid] : 0;
+
+    // A Gaussian that covers hundreds of tiles (early in training from a sparse cloud; a scale that blew up) would
+    // keep ONE thread adding its rows while 255 wait: 195 us instead of 40 us for this kernel in a 500 k-Gaussian fit.
+    // Such Gaussians are summed by the whole workgroup first -- thread t takes rows t, t + 256, ... straight from
+    // global memory (consecutive threads, consecutive rows), a fixed shuffle tree and a fixed wave order give the
+    // total to the owning thread: deterministic -- and are skipped by the per-thread loops below.
+    constexpr uint32_t BIG = 256;
+    constexpr int NA = 4 * RW4;
+    __shared__ uint32_t s_nbig, s_big_owner[256];
+    __shared__ uint64_t s_big_off[256];
+    __shared__ uint32_t s_big_cnt[256];
+    __shared__ float s_big_part[4][NA];
+    const bool big = cnt > BIG;
+    if (threadIdx.x == 0) s_nbig = 0;
+    __syncthreads();
+    if (big) {
+        const uint32_t slot = atomicAdd(&s_nbig, 1u);
+        s_big_owner[slot] = threadIdx.x;
+        s_big_off[slot] = off;
+        s_big_cnt[slot] = (uint32_t)cnt;
+    }
+    __syncthreads();
+    const uint32_t nbig = s_nbig;
+    for (uint32_t b = 0; b < nbig; ++b) {
+        const uint64_t boff = s_big_off[b];
+        const uint32_t bcnt = s_big_cnt[b];
+        float acc[NA];
+#pragma unroll
+        for (int e = 0; e < NA; ++e) acc[e] = 0.f;
+        for (uint32_t k = threadIdx.x; k < bcnt && boff + k < max_pairs; k += 256) {
+            const float4 *row = rows + (boff + k) * RW4;
+#pragma unroll
+            for (int m = 0; m < RW4; ++m) {
+                const float4 r = row[m];
+                acc[4 * m] += r.x; acc[4 * m + 1] += r.y; acc[4 * m + 2] += r.z; acc[4 * m + 3] += r.w;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < NA; ++e) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc[e] += __shfl_xor(acc[e], o, 64);
+            if ((threadIdx.x & 63) == 0) s_big_part[threadIdx.x >> 6][e] = acc[e];
+        }
+        __syncthreads();
+        if (threadIdx.x == s_big_owner[b]) {
+            auto tot = [&](int e) {
+                return (s_big_part[0][e] + s_big_part[1][e]) + (s_big_part[2][e] + s_big_part[3][e]);
+            };
+            d0 = make_float4(tot(0), tot(1), tot(2), tot(3));
+            d1 = make_float4(tot(4), tot(5), tot(6), tot(7));
+            if (CDIM == 3) {
+                d2 = make_float4(tot(8), tot(9), 0.f, 0.f);
+            } else {
+#pragma unroll
+                for (int e = 0; e < NA - 8; ++e) gsh[e] = tot(8 + e);
+            }
+        }
+        __syncthreads();
+    }
     if (CDIM == 3) {
         constexpr uint32_t rows_per_chunk = CHUNK_F4 / 3;
         uint64_t row_begin = pair_offsets[pid0];
@@ -461,7 +520,7 @@ __global__ void __launch_bounds__(256) frame_project_backward_kernel(
             for (uint32_t i = threadIdx.x; i < nrows * 3; i += blockDim.x) s_rows[i] = src[i];
             __syncthreads();
             const uint64_t lo = off > base ? off : base, hi = off + cnt < base + nrows ? off + cnt : base + nrows;
-            for (uint64_t k = lo; k < hi; ++k) {
+            for (uint64_t k = lo; k < hi && !big; ++k) {
                 const float4 *row = s_rows + (k - base) * 3;
                 const float4 r0 = row[0], r1 = row[1], r2 = row[2];
                 d0.x += r0.x; d0.y += r0.y; d0.z += r0.z; d0.w += r0.w;
@@ -473,7 +532,7 @@ __global__ void __launch_bounds__(256) frame_project_backward_kernel(
     } else {
         // SH rows are 144 (224) contiguous bytes: a thread reading its own rows already moves whole sectors
         // (measured: the LDS detour costs 25 % here)
-        for (uint64_t k = 0; k < cnt && off + k < max_pairs; ++k) {
+        for (uint64_t k = 0; k < cnt && off + k < max_pairs && !big; ++k) {
             const float4 *row = rows + (off + k) * RW4;
             const float4 r0 = row[0], r1 = row[1];
             d0.x += r0.x; d0.y += r0.y; d0.z += r0.z; d0.w += r0.w;

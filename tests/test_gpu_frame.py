@@ -178,6 +178,34 @@ def test_frame_backward_parity(gpu, use_sh):
     assert float(np.abs(params[0].grad.cpu().numpy()[culled]).max()) == 0.0
 
 
+def test_frame_backward_screen_filling_gaussians(gpu):
+    """Gaussians that touch more than 256 tiles have their per-pair gradient rows summed by the whole workgroup
+    (cull_project.hip, deterministic tree) instead of by one thread: parity with the oracle for a scene that mixes a
+    few of them -- next to each other in the array and isolated -- with ordinary ones, no SH and SH."""
+    for use_sh in (False, True):
+        scene, cam = case(3_000, 352, 272, seed=31, use_sh=use_sh)
+        big = [10, 11, 12, 700, 2999]
+        scene.scale[big] = np.float32(3.0) * np.abs(scene.pos[big, 2:3]) / cam.focal_x * 40 * \
+            np.array([1.0, 0.55, 0.8], np.float32)  # anisotropic: an isotropic Gaussian has no quaternion gradient
+        scene.pos[big, :2] *= 0.05
+        scene.pos[big, 2] = np.linspace(3.0, 8.0, len(big), dtype=np.float32)
+        scene.opa[big] = -2.0
+        of = OracleFrame(scene, cam)
+        counts = np.bincount(of.ids, minlength=scene.n)
+        assert (counts[big] > 256).all() and counts.max() <= 22 * 17
+        gimg = np.random.default_rng(7).normal(size=of.image.shape).astype(np.float32)
+        ref = of.backward(gimg)
+        params = to_torch(scene, gpu, requires_grad=True)
+        r = FrameRenderer(gpu, max_pairs=len(of.ids) + 9, training=True, auto_grow=False)
+        img = r.render(*params, cam)
+        assert np.abs(img.detach().cpu().numpy() - of.image).max() < IMG_ATOL
+        img.backward(torch.from_numpy(gimg).to(gpu))
+        for t, name in zip(params, ("pos", "quat", "scale", "opa", "rgb")):
+            g = t.grad.cpu().numpy()
+            assert rel_err(g, ref[name]) < GRAD_RTOL, (use_sh, name, rel_err(g, ref[name]))
+            assert rel_err(g[big], ref[name][big]) < 2 * GRAD_RTOL, (use_sh, name, "big", rel_err(g[big], ref[name][big]))
+
+
 def test_frame_backward_exp_scale_activation(gpu):
     scene, cam = case(5_000, 96, 80, seed=13)
     scene.scale = np.log(np.abs(scene.scale) + 1e-4).astype(np.float32)
