@@ -49,17 +49,22 @@ start[4] += 0.5 * torch.randn(start[4].shape, device=dev, generator=g)
 opt = TrainOptions(n_iters=n_iters, use_clone=1, delete_thresh=1.5, grad_thresh=2e-4)
 tr = Trainer(start, cams, targets, opt, max_pairs=1 << 21, densify=True, generator=g)
 rng = np.random.default_rng(0)
-sizes = [tr.n_gaussians]
+sizes, pairs, rates = [tr.n_gaussians], [], []
 torch.cuda.synchronize()
-t0 = time.perf_counter()
+t0 = t_win = time.perf_counter()
 for i in range(n_iters):
     v = tr.train_step(i, int(rng.integers(len(cams))))
     if i % 500 == 0:
         sizes.append(tr.n_gaussians)
+        pairs.append(tr.renderer.stats().pairs)  # synchronises: once per 500 iterations
+        now = time.perf_counter()
+        rates.append(round(500 / (now - t_win), 1) if i else 0.0)
+        t_win = now
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 vals = v.cpu().numpy()
 out["train"] = {"iters": n_iters, "iters_per_s": round(n_iters / dt, 1), "n_gaussians_every_500": sizes,
+                "tile_pairs_every_500": pairs, "iters_per_s_every_500": rates,
                 "final_loss": round(float(vals[0]), 5), "finite": bool(np.isfinite(vals).all()),
                 "peak_memory_GiB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}
 print(json.dumps(out))
