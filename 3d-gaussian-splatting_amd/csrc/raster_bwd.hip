@@ -1,23 +1,26 @@
-// raster_bwd.hip -- tile rasterizer backward as a 64-lane systolic pipeline.
+// raster_bwd.hip -- tile rasterizer backward: one wave per 64-Gaussian bucket, two kernels.
 //
 // Replaces draw_backward_kernel (gaussian.cu:440-803).  The reference keeps one pixel per
 // thread and, for EVERY Gaussian, reduces 10 (no SH) or 34 (SH) gradient terms across the
 // warp with 5-step shuffle trees plus shared-memory atomics -- the reduction is most of its
-// runtime.  Here the roles are swapped:
+// runtime -- and walks a tile's whole list in one workgroup.
 //
-//   * one wave64 owns one BUCKET of 64 consecutive Gaussians of a tile's sorted list; lane l
-//     keeps Gaussian l's parameters AND its gradient accumulators in registers;
-//   * the tile's 256 pixels stream through the lanes: at step t lane l handles pixel t - l.
-//     A pixel's running state (transmittance T, rho = dL/dC . (C_final - C_run), dL/dC, pixel
-//     centre: 7 registers) moves from lane l to lane l+1 with one DPP `wave_shr:1` per register;
-//     lane 0 is fed from LDS (broadcast read of the staged per-pixel state);
-//   * therefore NO cross-lane reduction and NO atomics inside the loop: after 256+63 steps
-//     every lane holds the complete sum over the tile's pixels for its Gaussian.
+// Here a tile's sorted list is cut into BUCKETS of 64 consecutive Gaussians.  Buckets are independent because
+// the forward pass (or its replay for the reference-API entry point) checkpointed every pixel's (T, C_run) at
+// each bucket boundary, so the grid is one wave per (tile, bucket): long tiles are spread over many CUs
+// instead of serialising one workgroup.  Two kernels do the work inside a bucket:
 //
-// Buckets are independent because the forward pass (or its replay for the reference-API
-// entry point) checkpointed every pixel's (T, C_run) at each bucket boundary, so the grid is
-// one wave per (tile, bucket): long tiles are spread over many CUs instead of serialising
-// one workgroup (the reference's per-tile loop).  Gradient identities used (A.8 of SURVEY.md):
+//   * no SH -- raster_backward_pixel_kernel: lanes own PIXELS (four each), the bucket's Gaussians are applied
+//     front to back, the ten per-Gaussian sums are reduced over the wave through LDS (see its header);
+//   * SH (and the reference API's `sigmoid` flag) -- raster_backward_kernel, a 64-lane SYSTOLIC pipeline:
+//     lane l keeps Gaussian l's parameters AND its gradient accumulators (10 + 27 / 48 SH sums) in registers,
+//     the tile's 256 pixels stream through the lanes: at step t lane l handles pixel t - l.  A pixel's
+//     running state (transmittance T, rho = dL/dC . (C_final - C_run), dL/dC, pixel centre: 7 registers) moves
+//     from lane l to lane l+1 with one DPP `wave_shr:1` per register; lane 0 is fed from LDS.  No cross-lane
+//     reduction and no atomics inside the loop: after 256+63 steps every lane holds the complete sums over
+//     the tile's pixels for its Gaussian.
+//
+// Gradient identities used by both (A.8 of SURVEY.md):
 //   s = dL/dalpha * alpha,  u = -ln G
 //   dL/dx = ln2 (2A' Sx - B' Sy),            Sx = sum s dx, Sy = sum s dy
 //   dL/da = (-Syy + 2 d Su)/Pn, dL/db = (Sxy - 2 c Su)/Pn, dL/dc = (Sxy - 2 b Su)/Pn,
@@ -796,7 +799,7 @@ extern "C" int gs_draw_backward(const float *pos, const float *rgb, const float 
     // 2. bucket work list
     hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, s, ws.tile_nproc, G.ntx * G.nty,
                        ws.bucket_offsets, ws.n_buckets, ws.bucket_info, tile_n_point_accum, 0);
-    // 3. systolic backward, one wave per bucket, one output row per pair
+    // 3. one wave per bucket, one output row per pair
     BwdIn I = {output, grad_output, ws.ckpt, ws.tile_nproc, ws.bucket_offsets, ws.bucket_info, tile_n_point_accum};
     BwdOut O = {nullptr, nullptr, nullptr, 0, grad_pos, grad_rgb, grad_opa, grad_cov};
     if (sigmoid && use_sh_coeff)
