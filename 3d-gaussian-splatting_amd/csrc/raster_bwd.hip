@@ -596,7 +596,9 @@ __global__ void __launch_bounds__(64 * GS_PP_WPB) raster_backward_pixel_kernel(R
 #pragma unroll
         for (int u = 0; u < TG; ++u) {
             const float dx = dxs[u], opa = ops[u], c0 = cc[u][0], c1 = cc[u][1], c2 = cc[u][2];
-            float Sx = 0, Sy = 0, Sxx = 0, Sxy = 0, Syy = 0, Sq = 0, Sopa = 0, Sc0 = 0, Sc1 = 0, Sc2 = 0;
+            // dx is the same for the lane's four pixels: sum(s), sum(s dy) are accumulated and multiplied by dx / dx^2
+            // once per Gaussian (Sx, Sxx, Sxy need no per-pixel instruction)
+            float S1 = 0, Sy = 0, Syy = 0, Sq = 0, Sopa = 0, Sc0 = 0, Sc1 = 0, Sc2 = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float dy = dys[u][k], q = qs[u][k], Gv = Gs[u][k];
@@ -612,15 +614,14 @@ __global__ void __launch_bounds__(64 * GS_PP_WPB) raster_backward_pixel_kernel(R
                 Sc2 = fmaf(g2[k], w, Sc2);
                 Sopa = fmaf(d_alpha, Gv, Sopa);
                 const float s = d_alpha * alpha;
-                const float sdx = s * dx, sdy = s * dy;
-                Sx += sdx;
+                const float sdy = s * dy;
+                S1 += s;
                 Sy += sdy;
-                Sxx = fmaf(sdx, dx, Sxx);
-                Sxy = fmaf(sdx, dy, Sxy);
                 Syy = fmaf(sdy, dy, Syy);
                 Sq = fmaf(s, q, Sq);
                 T[k] = T[k] - w;
             }
+            const float Sx = S1 * dx, Sxx = Sx * dx, Sxy = Sy * dx;
             float *red = &s_red[u * 10][lane];
             red[0 * 65] = Sx;
             red[1 * 65] = Sy;
