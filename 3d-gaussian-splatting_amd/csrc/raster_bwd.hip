@@ -589,7 +589,9 @@ __global__ void __launch_bounds__(64 * GS_PP_WPB) raster_backward_pixel_kernel(R
                 dys[u][k] = dy;
                 qs[u][k] = q;
                 Gs[u][k] = Gv;
-                rcs[u][k] = gs_rcp(1.0f - Gv * ops[u] + 1e-7f);
+                // 1 / (1 - alpha + 1e-7) (gaussian.cu:722) as ONE fma + rcp: the constant is the fp32 neighbour of
+                // 1 + 1e-7 (1 + 2^-23), 2e-8 away -- below the rounding of the two-step form it replaces
+                rcs[u][k] = gs_rcp(fmaf(-Gv, ops[u], 1.00000011920928955f));
             }
         }
         // Step 2, front to back through the group: the chain through T and rho is plain arithmetic only
