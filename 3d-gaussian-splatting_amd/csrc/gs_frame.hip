@@ -12,6 +12,9 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "gs_common.h"
 #include "gs_frame_layout.h"
 
@@ -124,6 +127,55 @@ struct StageTimer {
     }
 };
 
+// ---------------------------------------------------------------------------------------------------------------
+// Backward preparation underneath the caller's loss.  After a TRAINING forward the zero-fill of the gradient rows
+// and the bucket work list (gs_stage_backward_prepare: ~25 us at 376 k Gaussians, on the critical path if done
+// inside gs_frame_backward) are issued on a side stream that waits for the forward's last kernel; the backward call
+// waits for the side stream's event instead of doing the work.  The pending state is keyed by the WORKSPACE pointer
+// in a mutex-protected table, not by the calling thread: PyTorch calls backward from its autograd thread.
+// Skipped while the stream is being captured into a graph (the fork would never be joined inside the capture).
+struct PrepState {
+    hipStream_t side = nullptr;
+    hipEvent_t fork = nullptr, done = nullptr;
+    int device = -1;
+    bool pending = false;
+};
+static std::mutex g_prep_mu;
+static std::unordered_map<const void *, PrepState> g_prep;
+
+static void prepare_on_side_stream(const gs_frame *f, const gs_frame_ws &ws, hipStream_t s) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    std::lock_guard<std::mutex> lock(g_prep_mu);
+    PrepState &st = g_prep[f->workspace];
+    st.pending = false;
+    if (!st.side || st.device != dev) {  // first training frame on this workspace (or the device changed)
+        st = PrepState();
+        if (hipStreamCreateWithFlags(&st.side, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&st.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&st.done, hipEventDisableTiming) != hipSuccess) {
+            st = PrepState();  // no side stream: the backward prepares inline
+            return;
+        }
+        st.device = dev;
+    }
+    if (hipEventRecord(st.fork, s) != hipSuccess || hipStreamWaitEvent(st.side, st.fork, 0) != hipSuccess) return;
+    if (gs_stage_backward_prepare(f, ws, st.side) != 0) return;
+    if (hipEventRecord(st.done, st.side) != hipSuccess) return;
+    st.pending = true;
+}
+
+// true: the preparation of this workspace's last forward is (being) done on the side stream and `s` now waits for it
+static bool join_prepared(const gs_frame *f, hipStream_t s) {
+    std::lock_guard<std::mutex> lock(g_prep_mu);
+    auto it = g_prep.find(f->workspace);
+    if (it == g_prep.end() || !it->second.pending) return false;
+    it->second.pending = false;
+    return hipStreamWaitEvent(s, it->second.done, 0) == hipSuccess;
+}
+
 static int frame_forward_impl(const gs_frame *f, hipStream_t s, float *stage_ms) {
     int rc = validate(f);
     if (rc) return rc;
@@ -131,6 +183,8 @@ static int frame_forward_impl(const gs_frame *f, hipStream_t s, float *stage_ms)
     GS_CHECK_ARG(f->image || f->image_padded, "no output image");
     gs_frame_ws ws = gs_frame_carve(f->workspace, f->N, f->max_pairs, f->width, f->height, f->color_dim, f->training);
     gs_frame_geom G = gs_frame_geometry(f);
+    // a forward whose backward never came may still be zero-filling this workspace on the side stream
+    (void)join_prepared(f, s);
     StageTimer tm(stage_ms != nullptr, s);
     tm.mark();
     // sort_mode 2 writes every counter and every tile range itself (tile_bin.hip, workgroup 0)
@@ -167,6 +221,7 @@ static int frame_forward_impl(const gs_frame *f, hipStream_t s, float *stage_ms)
     tm.mark();  // stage "ranges" = tile ranges (+ the per-tile depth sort in mode 1)
     if ((rc = gs_stage_raster_forward(f, ws, sids, s))) return rc;
     tm.mark();
+    if (f->training && f->N > 0) prepare_on_side_stream(f, ws, s);
     return tm.finish(stage_ms, GS_N_STAGES);
 }
 
@@ -193,7 +248,8 @@ static int frame_backward_impl(const gs_frame *f, const float *grad_image, float
     sorted_buffers(f, ws, &skeys, &sids, &okeys);
     StageTimer tm(stage_ms != nullptr, s);
     tm.mark();
-    if ((rc = gs_stage_raster_backward(f, ws, sids, grad_image, s))) return rc;
+    const bool prepared = join_prepared(f, s);
+    if ((rc = gs_stage_raster_backward(f, ws, sids, grad_image, s, prepared))) return rc;
     tm.mark();
     if ((rc = gs_stage_project_backward(f, ws, grad_pos, grad_quat, grad_scale, grad_opa, grad_rgb, s))) return rc;
     tm.mark();

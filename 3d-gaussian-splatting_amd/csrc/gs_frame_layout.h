@@ -145,5 +145,6 @@ int gs_stage_tile_sort_packed(const gs_frame *f, const gs_frame_ws &ws, uint64_t
                               uint32_t *ids_out, hipStream_t stream);
 int gs_stage_tile_ranges(const gs_frame *f, const gs_frame_ws &ws, const uint64_t *sorted_keys, hipStream_t stream);
 int gs_stage_raster_forward(const gs_frame *f, const gs_frame_ws &ws, const uint32_t *sorted_ids, hipStream_t stream);
+int gs_stage_backward_prepare(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream);
 int gs_stage_raster_backward(const gs_frame *f, const gs_frame_ws &ws, const uint32_t *sorted_ids,
-                             const float *grad_image, hipStream_t stream);
+                             const float *grad_image, hipStream_t stream, bool prepared);

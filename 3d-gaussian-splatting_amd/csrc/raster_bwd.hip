@@ -817,8 +817,20 @@ extern "C" int gs_draw_backward(const float *pos, const float *rgb, const float 
     return 0;
 }
 
+// What the backward needs from the forward alone: zeroed gradient rows (pairs behind a tile's early-termination
+// point are never written) and the bucket work list.  gs_frame_forward runs it on a side stream underneath
+// whatever the caller does between forward and backward (the loss); gs_frame_backward runs it inline otherwise.
+int gs_stage_backward_prepare(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream) {
+    gs_frame_geom FG = gs_frame_geometry(f);
+    GS_HIP(hipMemsetAsync(ws.rows, 0, sizeof(float) * (size_t)gs_row_floats(f->color_dim) * f->max_pairs, stream));
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, ws.tile_nproc, FG.n_tiles,
+                       ws.bucket_offsets, ws.counters + GS_CNT_BUCKETS, ws.bucket_info, ws.tile_ranges, 1);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
 int gs_stage_raster_backward(const gs_frame *f, const gs_frame_ws &ws, const uint32_t *sorted_ids,
-                             const float *grad_image, hipStream_t stream) {
+                             const float *grad_image, hipStream_t stream, bool prepared) {
     gs_frame_geom FG = gs_frame_geometry(f);
     RasterSrc S = {};
     S.ids = sorted_ids;
@@ -844,10 +856,10 @@ int gs_stage_raster_backward(const gs_frame *f, const gs_frame_ws &ws, const uin
         G.vdx[i] = f->vec_dx[i];
         G.vdy[i] = f->vec_dy[i];
     }
-    // rows of pairs the forward never reached (early termination) must read as zero
-    GS_HIP(hipMemsetAsync(ws.rows, 0, sizeof(float) * (size_t)gs_row_floats(f->color_dim) * f->max_pairs, stream));
-    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, ws.tile_nproc, FG.n_tiles,
-                       ws.bucket_offsets, ws.counters + GS_CNT_BUCKETS, ws.bucket_info, ws.tile_ranges, 1);
+    if (!prepared) {
+        const int rc = gs_stage_backward_prepare(f, ws, stream);
+        if (rc) return rc;
+    }
     BwdIn I = {f->image_padded, grad_image, ws.ckpt, ws.tile_nproc, ws.bucket_offsets, ws.bucket_info, ws.tile_ranges};
     BwdOut O = {ws.rows, ws.pair_offsets, ws.rects, (uint64_t)f->max_pairs, nullptr, nullptr, nullptr, nullptr};
     if (f->color_dim == 48)

@@ -196,7 +196,12 @@ typedef struct gs_frame {
 size_t gs_frame_workspace_bytes(int64_t N, int64_t max_pairs, int32_t width, int32_t height,
                                 int32_t color_dim, int32_t training);
 
-/* Forward frame.  Launches everything on `stream`, never synchronises. */
+/* Forward frame.  Launches everything on `stream`, never synchronises.
+ * With f->training the zero-fill of the per-pair gradient rows and the backward's bucket list are additionally issued
+ * on a library-owned side stream that waits for the frame's last kernel, so that they run underneath whatever the
+ * caller enqueues between forward and backward (the loss); gs_frame_backward -- from any host thread -- and the next
+ * gs_frame_forward on the same workspace wait for that stream's event.  Not done while `stream` is being captured
+ * into a graph (the backward then prepares inline). */
 int gs_frame_forward(const gs_frame *f, gs_stream_t stream);
 
 /* Same work as gs_frame_forward, but brackets every stage with hipEvents on `stream` and
