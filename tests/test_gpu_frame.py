@@ -510,3 +510,27 @@ def test_frame_forward_is_graph_capturable(gpu):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(img, want2) and not torch.equal(want, want2)
+
+
+def test_training_forward_followed_by_inference_forward_on_the_same_workspace(gpu):
+    """A training forward leaves work on the library's side stream (zero-fill of the gradient rows, bucket list for a
+    backward that may never come).  The next forward on the same workspace -- with the inference layout, where
+    those bytes hold other buffers -- must wait for it: alternate the two many times and compare with a renderer of
+    its own."""
+    scene, cam = case(40_000, 640, 400, seed=37)
+    params = to_torch(scene, gpu)
+    want = FrameRenderer(gpu, max_pairs=400_000, auto_grow=False).forward(*params, cam)[0].clone()
+    r = FrameRenderer(gpu, max_pairs=400_000, training=True, auto_grow=False)
+    for _ in range(25):
+        r.forward(*params, cam, training=True)
+        img, _ = r.forward(*params, cam, training=False)
+        assert torch.equal(img, want)
+    # and the backward of a training forward still gets its zeroed rows after such a sequence
+    g = torch.randn(400, 640, 3, device=gpu)
+    r.forward(*params, cam, training=True)
+    a = [t.clone() for t in r.backward(g)]
+    r.forward(*params, cam, training=False)
+    r.forward(*params, cam, training=True)
+    b = r.backward(g)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
