@@ -10,6 +10,9 @@ What differs: one fused HIP frame call per direction instead of ~25 torch kernel
 (gs_frame.FrameRenderer), fused loss / Adam / densification kernels (gs_train.Trainer), and logging that reads
 the device every ``--n_history_track`` iterations instead of three ``.item()`` calls per iteration.
 
+New: under ``torchrun --nproc-per-node N`` the same script trains view-parallel (one view per GPU per step, RCCL
+all-reduce of the gradients, rank-consistent densification).
+
 Not provided: ``--gui`` (the viser viewer; its per-frame hook ``Trainer.test(None, extrinsics, intrinsics)`` is),
 ``--tile_culling_method dist`` on the fused path (use the drop-in ``gaussian`` / ``renderer`` modules with the
 reference's own splatter.py for that one), ``--jacobian_track`` / ``--adaptive_lr`` / ``--debug`` (accepted, ignored:
@@ -154,6 +157,16 @@ def main(argv=None) -> dict:
     torch.manual_seed(opt.seed)
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
+    # View-parallel training (new; the reference is single-GPU): under torchrun every rank renders its own view of a
+    # step's batch, the parameter gradients are averaged with one RCCL all-reduce (gs_dp.py) and the densification
+    # decisions are kept rank-consistent (gs_dp.ViewParallelGradStat).  Rank 0 logs, evaluates and writes files.
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 or "RANK" in os.environ:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     scene = gs_colmap.load_scene(opt.data, opt.render_downsample_start, dev)
     if opt.ckpt:
@@ -163,8 +176,9 @@ def main(argv=None) -> dict:
         init = gs_colmap.initial_gaussians(scene.points3d, opt.scale_init_value, opt.opa_init_value,
                                            opt.scale_activation, bool(opt.use_sh_coeff))
         params = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in init]
-    trainer = Trainer(params, scene.cameras, scene.targets, train_options(opt), scale_activation=opt.scale_activation,
-                      densify=True, generator=torch.Generator(dev).manual_seed(opt.seed))
+    trainer = Trainer(params, scene.cameras, scene.targets, train_options(opt), world_size=world,
+                      scale_activation=opt.scale_activation, densify=True,
+                      generator=torch.Generator(dev).manual_seed(opt.seed))
     trainer.renderer.thresh = float(opt.tile_culling_prob_thresh)
     trainer.renderer.tile_culling_method = {"prob2": 2, "prob": 1}[opt.tile_culling_method]
     n_cameras = len(scene.cameras)
@@ -172,14 +186,22 @@ def main(argv=None) -> dict:
     train_split = np.array(sorted(set(range(n_cameras)) - set(test_split.tolist())))
     os.makedirs(opt.exp, exist_ok=True)
     if opt.test:
-        return {"test": evaluate(trainer, test_split, os.path.join(opt.exp, "test_imgs"), "test")}
+        return {"test": evaluate(trainer, test_split, os.path.join(opt.exp, "test_imgs"), "test")} if rank == 0 else {}
     if len(train_split) == 0:
         raise SystemExit("the dataset has a single image: nothing left to train on after the every-8th test split")
 
     hist, summary, t_start = [], {}, time.perf_counter()
     for i_iter in range(opt.n_iters):
-        camera_id = int(np.random.choice(train_split, 1)[0])  # train.py:94
+        # train.py:94; with several ranks the same draw of `world` views happens on every rank (same generator
+        # state everywhere) and rank r takes the r-th
+        camera_id = int(np.random.choice(train_split, world)[rank])
         hist.append(trainer.train_step(i_iter, camera_id).clone())
+        if rank != 0:
+            if i_iter == 400 and opt.render_downsample != opt.render_downsample_start:
+                scene = gs_colmap.load_scene(opt.data, opt.render_downsample, dev)
+                trainer.cameras, trainer.targets = scene.cameras, scene.targets
+            del hist[:-1]
+            continue
         if i_iter % opt.n_save_train_img == 0:  # train.py:222-228
             os.makedirs(os.path.join(opt.exp, "imgs"), exist_ok=True)
             save_png(os.path.join(opt.exp, "imgs", f"train_{i_iter}.png"),
@@ -197,7 +219,13 @@ def main(argv=None) -> dict:
             trainer.cameras, trainer.targets = scene.cameras, scene.targets
         if i_iter % opt.n_iters_test == 0:
             summary["test"] = evaluate(trainer, test_split, os.path.join(opt.exp, "test_imgs"), f"iter_{i_iter}")
-    trainer.save_checkpoint(os.path.join(opt.exp, "ckpt.pth"))
+    if rank == 0:
+        trainer.save_checkpoint(os.path.join(opt.exp, "ckpt.pth"))
+    if world > 1 or "RANK" in os.environ:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
     return summary
 
 

@@ -56,6 +56,25 @@ def test_train_cli_end_to_end(capture, tmp_path, capsys):
     assert out is not None
 
 
+def test_train_cli_under_a_torchrun_environment(capture, tmp_path, monkeypatch):
+    """RANK / WORLD_SIZE / MASTER_* set as torchrun does (one rank: there is one GPU here): the script goes through
+    torch.distributed with the RCCL backend, draws its views from the shared generator and still writes rank 0's
+    artefacts."""
+    import torch.distributed as dist
+
+    import train as cli
+
+    for k, v in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"),
+                 ("MASTER_PORT", str(29600 + os.getpid() % 300))):
+        monkeypatch.setenv(k, v)
+    exp = str(tmp_path / "exp_dp")
+    res = cli.main(["--data", capture, "--exp", exp, "--render_downsample_start", "2", "--render_downsample", "2",
+                    "--n_iters", "61", "--n_iters_warmup", "10", "--n_iters_test", "60", "--n_save_train_img", "60",
+                    "--n_history_track", "30"])
+    assert not dist.is_initialized()  # torn down at the end
+    assert os.path.exists(os.path.join(exp, "ckpt.pth")) and np.isfinite(res["loss"]) and "test" in res
+
+
 def test_train_cli_rejects_what_it_does_not_provide(capture, tmp_path):
     import train as cli
 
