@@ -26,7 +26,6 @@ from __future__ import annotations
 
 import math
 import os
-from typing import Optional
 
 import numpy as np
 import torch

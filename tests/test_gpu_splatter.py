@@ -51,7 +51,6 @@ def test_constructor_state_matches_the_reference_conventions(capture):
 
 
 def test_forward_is_the_oracle_frame_and_backward_reaches_the_parameters(capture):
-    import oracle  # noqa: F401  (checker only)
     from gs_scene import Scene
     from gs_testutil import OracleFrame
 
