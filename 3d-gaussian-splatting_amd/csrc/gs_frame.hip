@@ -176,6 +176,20 @@ static bool join_prepared(const gs_frame *f, hipStream_t s) {
     return hipStreamWaitEvent(s, it->second.done, 0) == hipSuccess;
 }
 
+extern "C" int gs_frame_release_workspace(void *workspace, gs_stream_t stream) {
+    std::lock_guard<std::mutex> lock(g_prep_mu);
+    auto it = g_prep.find(workspace);
+    if (it == g_prep.end()) return 0;
+    PrepState &st = it->second;
+    if (st.pending) GS_HIP(hipStreamWaitEvent((hipStream_t)stream, st.done, 0));
+    // the events and the stream are released by the runtime once the work queued on them has drained
+    if (st.fork) (void)hipEventDestroy(st.fork);
+    if (st.done) (void)hipEventDestroy(st.done);
+    if (st.side) (void)hipStreamDestroy(st.side);
+    g_prep.erase(it);
+    return 0;
+}
+
 static int frame_forward_impl(const gs_frame *f, hipStream_t s, float *stage_ms) {
     int rc = validate(f);
     if (rc) return rc;

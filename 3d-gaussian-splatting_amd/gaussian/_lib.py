@@ -80,6 +80,7 @@ gs_frame_debug_views = _sig("gs_frame_debug_views", ci, C.POINTER(GsFrame), C.PO
 gs_adam_step = _sig("gs_adam_step", ci, vp, vp, vp, vp, i64, i32, C.POINTER(i64), C.POINTER(f32), f32, f32, f32, i64,
                     vp, i64, i64, i32, vp)
 gs_grad_stat_update = _sig("gs_grad_stat_update", ci, vp, vp, i64, i32, vp)
+gs_frame_release_workspace = _sig("gs_frame_release_workspace", ci, vp, vp)
 gs_loss_workspace_bytes = _sig("gs_loss_workspace_bytes", sz, i32, i32)
 gs_loss_l1_ssim = _sig("gs_loss_l1_ssim", ci, vp, vp, i32, i32, f32, vp, vp, vp, sz, vp)
 
@@ -105,6 +106,7 @@ EXPORTS = [
     "gs_gather_gaussians", "gs_draw", "gs_draw_backward_workspace_bytes", "gs_draw_backward",
     "gs_sort_pairs_tmp_bytes", "gs_sort_pairs", "gs_sort_pairs_bits", "gs_frame_workspace_bytes", "gs_frame_forward",
     "gs_frame_stats_async", "gs_frame_debug_views", "gs_frame_backward", "gs_frame_forward_profile",
+    "gs_frame_release_workspace",
     "gs_frame_backward_profile", "gs_adam_step", "gs_grad_stat_update", "gs_loss_workspace_bytes", "gs_loss_l1_ssim",
     "gs_densify_workspace_bytes", "gs_densify_classify", "gs_densify_apply",
 ]

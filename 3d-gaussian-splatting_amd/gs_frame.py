@@ -120,12 +120,28 @@ class FrameRenderer:
         f.tile_culling_method = self.tile_culling_method
         need = _lib.gs_frame_workspace_bytes(n, self.max_pairs, grid.width, grid.height, color_dim, int(training))
         if self._ws is None or self._ws.numel() < need:
+            self._release_workspace()  # side-stream work of an earlier training frame may still touch the old one
             self._ws = torch.empty(int(need) + 256, dtype=torch.uint8, device=self.device)
         base = self._ws.data_ptr()
         f.workspace = (base + 255) // 256 * 256
         f.workspace_bytes = self._ws.numel() - (f.workspace - base)
         self._grid = grid
         return f
+
+    def _release_workspace(self):
+        """Before the workspace tensor goes back to torch's allocator: let the current stream wait for what the
+        library's side stream may still be doing in it (include/gs_abi.h, gs_frame_release_workspace)."""
+        if self._ws is not None:
+            key = (self._ws.data_ptr() + 255) // 256 * 256
+            _lib.check(_lib.gs_frame_release_workspace(key, torch.cuda.current_stream().cuda_stream),
+                       "gs_frame_release_workspace")
+            self._frame = None
+
+    def __del__(self):
+        try:
+            self._release_workspace()
+        except Exception:  # interpreter shutdown: the library or torch may already be gone
+            pass
 
     # ------------------------------------------------------------------ low-level API
     def forward(self, pos, quat, scale, opa, rgb, camera, training: Optional[bool] = None):

@@ -204,6 +204,12 @@ size_t gs_frame_workspace_bytes(int64_t N, int64_t max_pairs, int32_t width, int
  * into a graph (the backward then prepares inline). */
 int gs_frame_forward(const gs_frame *f, gs_stream_t stream);
 
+/* Call before FREEING (or re-purposing) a workspace that was used by a training forward: work of the library's side
+ * stream may still be writing into it if no gs_frame_backward / gs_frame_forward followed that frame.  Makes `stream`
+ * wait for it and drops the library's state for this workspace pointer (the value passed as gs_frame.workspace).
+ * A no-op for workspaces the library has no state for. */
+int gs_frame_release_workspace(void *workspace, gs_stream_t stream);
+
 /* Same work as gs_frame_forward, but brackets every stage with hipEvents on `stream` and
  * returns the stage durations in milliseconds (synchronises; for bench.py / profiling only):
  * stage_ms_host[0..5] = project+count, scan+emit, radix sort, tile ranges, raster, total. */
