@@ -294,12 +294,16 @@ struct ProjectParams {
     uint32_t ntx, nty;
     int32_t scale_act;
     int32_t color_dim;
-    int32_t cull_method;        // 1: "prob" (tile edges), otherwise "prob2" (index arithmetic)
+    int32_t cull_method;        // 0: "dist" (tile centres), 1: "prob" (tile edges), 2: "prob2" (index arithmetic)
+    float dist_thresh, dist_radius;  // "dist": squared distance threshold (splatter.py:577) and its square root
     float half_padw, half_padh;  // padded size / 2, in pixels (exact in fp32)
     float fx, fy;
 };
 
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+// sigmoid on the transcendental unit (v_exp_f32 + v_rcp_f32, ~2 ulp): the opacity / colour activations feed the
+// compositing only (image tolerance 5e-5), not the integer side of the pipeline; expf + an IEEE division cost
+// ~25 instructions each, four times per Gaussian, in a kernel that is VALU-issue bound
+__device__ __forceinline__ float sigmoid_f(float x) { return gs_rcp(1.0f + gs_exp2(-GS_LOG2E * x)); }
 
 // "prob" (calc_tile_info_kernel2, gaussian.cu:138-195): tile i of an axis is listed unless
 // `edge(i+1) < lo || hi < edge(i)`, with the tile edges of Tiles.create_tiles (splatter.py:275-293):
@@ -353,6 +357,31 @@ __device__ __forceinline__ uint32_t tile_rect(float cx, float cy, const float cv
     return (y1 - y0) * (x1 - x0);
 }
 
+// "dist" (calc_tile_info_kernel, gaussian.cu:101-136): a Gaussian is listed in every tile whose centre is closer than
+// sqrt(thresh) to its own centre.  The listed tiles are decided per tile by gs_dist_listed (gs_common.h, the
+// reference's own fp32 comparison); this is only the bounding square of the disc, one tile of slack on every side,
+// over which the binning walks and the gradient rows are laid out.  NaN / infinite centres list nothing, as there.
+__device__ __forceinline__ uint32_t dist_rect(float cx, float cy, const ProjectParams &P, uint32_t &y0, uint32_t &y1,
+                                              uint32_t &x0, uint32_t &x1) {
+    y0 = y1 = x0 = x1 = 0;
+    if (!(fabsf(cx) < 3.0e38f) || !(fabsf(cy) < 3.0e38f) || !(P.dist_radius >= 0.f)) return 0;
+    // tile centre i sits at (16 i + 8 - pad/2) / focal: i = ((c -+ r) focal + pad/2 - 8) / 16
+    const float lx = ((cx - P.dist_radius) * P.fx + P.half_padw - 8.0f) * 0.0625f;
+    const float hx = ((cx + P.dist_radius) * P.fx + P.half_padw - 8.0f) * 0.0625f;
+    const float ly = ((cy - P.dist_radius) * P.fy + P.half_padh - 8.0f) * 0.0625f;
+    const float hy = ((cy + P.dist_radius) * P.fy + P.half_padh - 8.0f) * 0.0625f;
+    if (hx < -1.0f || hy < -1.0f || lx > (float)P.ntx || ly > (float)P.nty) return 0;
+    x0 = gs_f2u_sat(floorf(lx) - 1.0f);
+    y0 = gs_f2u_sat(floorf(ly) - 1.0f);
+    x1 = gs_f2u_sat(ceilf(hx) + 2.0f);
+    y1 = gs_f2u_sat(ceilf(hy) + 2.0f);
+    if (x1 > P.ntx) x1 = P.ntx;
+    if (y1 > P.nty) y1 = P.nty;
+    if (x0 > x1) x0 = x1;
+    if (y0 > y1) y0 = y1;
+    return (y1 - y0) * (x1 - x0);
+}
+
 __device__ __forceinline__ void activate(const float qraw[4], const float sraw[3], int scale_act,
                                          float q[4], float s[3]) {
     float nr = sqrtf(qraw[0] * qraw[0] + qraw[1] * qraw[1] + qraw[2] * qraw[2] + qraw[3] * qraw[3]);
@@ -382,7 +411,8 @@ __global__ void __launch_bounds__(256) frame_project_kernel(
         if (project(p, q, s, P.cam, P.near_plane, P.half_w, P.half_h, pi, cv)) {
             vis = 1;
             uint32_t y0, y1, x0, x1;
-            cnt = tile_rect(pi[0], pi[1], cv, P, y0, y1, x0, x1);
+            cnt = P.cull_method == 0 ? dist_rect(pi[0], pi[1], P, y0, y1, x0, x1)
+                                     : tile_rect(pi[0], pi[1], cv, P, y0, y1, x0, x1);
             rc = make_uint2(y0 | (y1 << 16), x0 | (x1 << 16));
             g = make_float4(pi[0], pi[1], pi[2], sigmoid_f(opa[pid]));
             c = make_float4(cv[0], cv[1], cv[2], cv[3]);
@@ -678,6 +708,8 @@ static ProjectParams make_params(const gs_frame *f) {
     P.half_w = f->half_width;
     P.half_h = f->half_height;
     P.tlog = -2 * logf(f->thresh);
+    P.dist_thresh = f->thresh;
+    P.dist_radius = sqrtf(f->thresh);
     gs_frame_geom G = gs_frame_geometry(f);
     P.tlx = G.tlx;
     P.tly = G.tly;

@@ -110,6 +110,22 @@ __device__ __forceinline__ float gs_det(float a, float b, float c, float d) {
     return a * d - b * c;
 }
 
+// "dist" tile culling (calc_tile_info_kernel, gaussian.cu:101-136; splatter.py:571-578): is tile (ix, iy) listed for
+// a Gaussian centred at (px, py)?  The tile edges are Tiles.create_tiles' (splatter.py:275-293): left(i) =
+// (16 i - pad/2) / focal with an exact integer-valued numerator, right(i) = left(i + 1) bit for bit; the centre is
+// (left + right) / 2 and the test d1 d1 + d2 d2 < thresh, all in fp32 without contraction, as the reference kernel.
+struct GsDistCull {
+    float half_padw, half_padh, fx, fy, thresh;
+};
+__device__ __forceinline__ bool gs_dist_listed(float px, float py, uint32_t ix, uint32_t iy, const GsDistCull &D) {
+#pragma clang fp contract(off)
+    const float left = (16.0f * (float)ix - D.half_padw) / D.fx, right = (16.0f * (float)(ix + 1) - D.half_padw) / D.fx;
+    const float top = (16.0f * (float)iy - D.half_padh) / D.fy, bottom = (16.0f * (float)(iy + 1) - D.half_padh) / D.fy;
+    const float center_y = (top + bottom) / 2, center_x = (left + right) / 2;
+    const float d1 = px - center_x, d2 = py - center_y;
+    return d1 * d1 + d2 * d2 < D.thresh;
+}
+
 // Conic in log2 units: G = 2^-(A dx^2 - B dx dy + C dy^2) == exp(-(d dx^2-(b+c)dx dy+a dy^2)/(2det+1e-14))
 // (gaussian.cu:916-923).  Hoists the reference's per-pixel fp64 division to once per Gaussian.
 __device__ __forceinline__ void gs_conic(float a, float b, float c, float d, float &A, float &B, float &C) {

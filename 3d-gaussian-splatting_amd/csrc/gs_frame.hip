@@ -13,7 +13,7 @@
 #include <string.h>
 
 #include <mutex>
-#include <unordered_map>
+#include <new>
 
 #include "gs_common.h"
 #include "gs_frame_layout.h"
@@ -41,7 +41,7 @@ static int validate(const gs_frame *f) {
     GS_CHECK_ARG(f != nullptr, "frame is null");
     GS_CHECK_ARG(f->N >= 0 && f->N < (1ll << 31), "N out of range");
     GS_CHECK_ARG(f->tile_culling_method >= 0 && f->tile_culling_method <= 2,
-                 "tile_culling_method must be 0 / 2 (prob2) or 1 (prob)");
+                 "tile_culling_method must be 0 (dist), 1 (prob) or 2 (prob2)");
     GS_CHECK_ARG(f->color_dim == 3 || f->color_dim == 27 || f->color_dim == 48,
                  "color_dim must be 3 (rgb logits), 27 (SH degree 2) or 48 (SH degree 3)");
     GS_CHECK_ARG(f->scale_activation == 0 || f->scale_activation == 1, "scale_activation must be 0 (abs) or 1 (exp)");
@@ -51,7 +51,14 @@ static int validate(const gs_frame *f) {
     GS_CHECK_ARG(f->N == 0 || (f->pos && f->quat && f->scale && f->opa && f->rgb), "null scene pointer");
     GS_CHECK_ARG(((uintptr_t)f->quat & 15) == 0, "quat must be 16-byte aligned");
     GS_CHECK_ARG(f->workspace != nullptr && ((uintptr_t)f->workspace & 255) == 0, "workspace null or not 256-byte aligned");
-    GS_CHECK_ARG(f->thresh > 0.f && f->thresh < 1.f, "thresh must be in (0,1)");
+    if (f->tile_culling_method == 0) {
+        GS_CHECK_ARG(f->thresh > 0.f && f->thresh < 3.0e38f, "dist: thresh is a squared distance, must be positive");
+        GS_CHECK_ARG(f->sort_mode == 2 && gs_frame_geometry(f).n_tiles <= GS_BIN_MAX_TILES,
+                     "tile_culling_method dist needs sort_mode 2 and at most 32768 tiles");
+    } else {
+        GS_CHECK_ARG(f->thresh > 0.f && f->thresh < 1.f, "thresh must be in (0,1)");
+    }
+    GS_CHECK_ARG((f->flags & ~GS_FRAME_EMIT_SORTED_KEYS) == 0, "unknown flag bits");
     GS_CHECK_ARG(f->sort_mode >= 0 && f->sort_mode <= 2,
                  "sort_mode must be 0 (full LSD radix), 1 (tile-bit radix + per-tile LDS sort) or 2 (LDS counting sort "
                  "by tile + per-tile LDS sort)");
@@ -128,66 +135,84 @@ struct StageTimer {
 };
 
 // ---------------------------------------------------------------------------------------------------------------
-// Backward preparation underneath the caller's loss.  After a TRAINING forward the zero-fill of the gradient rows
-// and the bucket work list (gs_stage_backward_prepare: ~25 us at 376 k Gaussians, on the critical path if done
-// inside gs_frame_backward) are issued on a side stream that waits for the forward's last kernel; the backward call
-// waits for the side stream's event instead of doing the work.  The pending state is keyed by the WORKSPACE pointer
-// in a mutex-protected table, not by the calling thread: PyTorch calls backward from its autograd thread.
+// Backward preparation underneath the caller's loss (opt-in: gs_frame.async).  After a TRAINING forward the zero-fill
+// of the gradient rows and the bucket work list (gs_stage_backward_prepare: ~25 us at 376 k Gaussians, on the critical
+// path if done inside gs_frame_backward) are issued on the side stream of the CALLER-OWNED handle, which waits for the
+// forward's last kernel; the backward call waits for the handle's event instead of doing the work.  The library itself
+// keeps no state: the stream, the two events and the pending flag live in the handle (gs_frame_async_create /
+// _destroy), and PyTorch may call backward from its autograd thread -- hence the mutex inside the handle.
 // Skipped while the stream is being captured into a graph (the fork would never be joined inside the capture).
-struct PrepState {
+struct gs_frame_async {
+    std::mutex mu;
     hipStream_t side = nullptr;
     hipEvent_t fork = nullptr, done = nullptr;
     int device = -1;
     bool pending = false;
 };
-static std::mutex g_prep_mu;
-static std::unordered_map<const void *, PrepState> g_prep;
+
+extern "C" int gs_frame_async_create(gs_frame_async **out) {
+    GS_CHECK_ARG(out != nullptr, "out is null");
+    gs_frame_async *a = new (std::nothrow) gs_frame_async();
+    GS_CHECK_ARG(a != nullptr, "out of memory");
+    if (hipGetDevice(&a->device) != hipSuccess ||
+        hipStreamCreateWithFlags(&a->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&a->fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&a->done, hipEventDisableTiming) != hipSuccess) {
+        if (a->fork) (void)hipEventDestroy(a->fork);
+        if (a->done) (void)hipEventDestroy(a->done);
+        if (a->side) (void)hipStreamDestroy(a->side);
+        delete a;
+        gs_set_error("gs_frame_async_create: could not create the side stream / events");
+        return GS_E_INVALID;
+    }
+    *out = a;
+    return 0;
+}
+
+extern "C" int gs_frame_async_wait(gs_frame_async *a, gs_stream_t stream) {
+    if (!a) return 0;
+    std::lock_guard<std::mutex> lock(a->mu);
+    if (a->pending) GS_HIP(hipStreamWaitEvent((hipStream_t)stream, a->done, 0));
+    a->pending = false;
+    return 0;
+}
+
+extern "C" int gs_frame_async_destroy(gs_frame_async *a) {
+    if (!a) return 0;
+    {
+        std::lock_guard<std::mutex> lock(a->mu);
+        // queued work keeps running: the runtime releases a stream / event once what was enqueued on it has drained
+        if (a->fork) (void)hipEventDestroy(a->fork);
+        if (a->done) (void)hipEventDestroy(a->done);
+        if (a->side) (void)hipStreamDestroy(a->side);
+    }
+    delete a;
+    return 0;
+}
 
 static void prepare_on_side_stream(const gs_frame *f, const gs_frame_ws &ws, hipStream_t s) {
+    gs_frame_async *a = (gs_frame_async *)f->async;
+    if (!a) return;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return;
     int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess) return;
-    std::lock_guard<std::mutex> lock(g_prep_mu);
-    PrepState &st = g_prep[f->workspace];
-    st.pending = false;
-    if (!st.side || st.device != dev) {  // first training frame on this workspace (or the device changed)
-        st = PrepState();
-        if (hipStreamCreateWithFlags(&st.side, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&st.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&st.done, hipEventDisableTiming) != hipSuccess) {
-            st = PrepState();  // no side stream: the backward prepares inline
-            return;
-        }
-        st.device = dev;
-    }
-    if (hipEventRecord(st.fork, s) != hipSuccess || hipStreamWaitEvent(st.side, st.fork, 0) != hipSuccess) return;
-    if (gs_stage_backward_prepare(f, ws, st.side) != 0) return;
-    if (hipEventRecord(st.done, st.side) != hipSuccess) return;
-    st.pending = true;
+    if (hipGetDevice(&dev) != hipSuccess || dev != a->device) return;  // a handle belongs to the device it was made on
+    std::lock_guard<std::mutex> lock(a->mu);
+    a->pending = false;
+    if (hipEventRecord(a->fork, s) != hipSuccess || hipStreamWaitEvent(a->side, a->fork, 0) != hipSuccess) return;
+    if (gs_stage_backward_prepare(f, ws, a->side) != 0) return;
+    if (hipEventRecord(a->done, a->side) != hipSuccess) return;
+    a->pending = true;
 }
 
-// true: the preparation of this workspace's last forward is (being) done on the side stream and `s` now waits for it
+// true: the preparation of the handle's last forward is (being) done on the side stream and `s` now waits for it
 static bool join_prepared(const gs_frame *f, hipStream_t s) {
-    std::lock_guard<std::mutex> lock(g_prep_mu);
-    auto it = g_prep.find(f->workspace);
-    if (it == g_prep.end() || !it->second.pending) return false;
-    it->second.pending = false;
-    return hipStreamWaitEvent(s, it->second.done, 0) == hipSuccess;
-}
-
-extern "C" int gs_frame_release_workspace(void *workspace, gs_stream_t stream) {
-    std::lock_guard<std::mutex> lock(g_prep_mu);
-    auto it = g_prep.find(workspace);
-    if (it == g_prep.end()) return 0;
-    PrepState &st = it->second;
-    if (st.pending) GS_HIP(hipStreamWaitEvent((hipStream_t)stream, st.done, 0));
-    // the events and the stream are released by the runtime once the work queued on them has drained
-    if (st.fork) (void)hipEventDestroy(st.fork);
-    if (st.done) (void)hipEventDestroy(st.done);
-    if (st.side) (void)hipStreamDestroy(st.side);
-    g_prep.erase(it);
-    return 0;
+    gs_frame_async *a = (gs_frame_async *)f->async;
+    if (!a) return false;
+    std::lock_guard<std::mutex> lock(a->mu);
+    if (!a->pending) return false;
+    a->pending = false;
+    return hipStreamWaitEvent(s, a->done, 0) == hipSuccess;
 }
 
 static int frame_forward_impl(const gs_frame *f, hipStream_t s, float *stage_ms) {
@@ -214,7 +239,9 @@ static int frame_forward_impl(const gs_frame *f, hipStream_t s, float *stage_ms)
         if (f->N > 0 && (rc = gs_stage_tile_bin(f, ws, s))) return rc;
         tm.mark();
         tm.mark();
-        if (f->N > 0 && (rc = gs_stage_tile_sort_packed(f, ws, okeys, skeys, sids, s))) return rc;
+        if (f->N > 0 && (rc = gs_stage_tile_sort_packed(f, ws, okeys, (f->flags & GS_FRAME_EMIT_SORTED_KEYS) ? skeys : nullptr,
+                                                        sids, s)))
+            return rc;
     } else {
         if (f->N > 0 && (rc = gs_stage_scan_emit(f, ws, s))) return rc;
         tm.mark();
@@ -302,7 +329,8 @@ extern "C" int gs_frame_debug_views(const gs_frame *f, const uint64_t **sorted_k
     uint64_t *skeys, *okeys;
     uint32_t *sids;
     sorted_buffers(f, ws, &skeys, &sids, &okeys);
-    if (sorted_keys) *sorted_keys = skeys;
+    if (sorted_keys)
+        *sorted_keys = (effective_sort_mode(f) == 2 && !(f->flags & GS_FRAME_EMIT_SORTED_KEYS)) ? nullptr : skeys;
     if (sorted_ids) *sorted_ids = sids;
     if (tile_ranges) *tile_ranges = ws.tile_ranges;
     if (rec_geom) *rec_geom = (const float *)ws.rec_geom;

@@ -37,8 +37,11 @@ namespace {
 // Walks the rectangle of every Gaussian of this workgroup's slice and calls fn(tile, gaussian, depth_bits).
 // Small rectangles are handled by their own lane, large ones by the whole wave (one screen-filling
 // Gaussian must not serialise 64 lanes behind it).
-template <typename Fn>
-__device__ __forceinline__ void walk_rect(const uint4 rc, int64_t g, uint32_t ntx, Fn fn) {
+// DIST ("dist" tile culling): the rectangle is only the bounding square of the disc of listed tiles; a tile is
+// listed iff gs_dist_listed says so for the Gaussian's centre (cxy).
+template <bool DIST, typename Fn>
+__device__ __forceinline__ void walk_rect(const uint4 rc, int64_t g, uint32_t ntx, float2 cxy, const GsDistCull &D,
+                                          Fn fn) {
     const int lane = threadIdx.x & 63;
     const uint32_t cnt = rc.w, dbits = rc.z;
     const uint32_t y0 = rc.x & 0xffff, x0 = rc.y & 0xffff, x1 = rc.y >> 16;
@@ -46,7 +49,7 @@ __device__ __forceinline__ void walk_rect(const uint4 rc, int64_t g, uint32_t nt
     if (cnt && cnt <= BIN_SOLO) {
         uint32_t ix = x0, iy = y0;
         for (uint32_t k = 0; k < cnt; ++k) {
-            fn(ix + iy * ntx, (uint32_t)g, dbits);
+            if (!DIST || gs_dist_listed(cxy.x, cxy.y, ix, iy, D)) fn(ix + iy * ntx, (uint32_t)g, dbits);
             if (++ix == x1) {
                 ix = x0;
                 ++iy;
@@ -59,10 +62,19 @@ __device__ __forceinline__ void walk_rect(const uint4 rc, int64_t g, uint32_t nt
         big &= big - 1;
         const uint32_t c = __shfl(cnt, src, 64), d = __shfl(dbits, src, 64);
         const uint32_t sx0 = __shfl(x0, src, 64), sy0 = __shfl(y0, src, 64), sw = __shfl(wdt, src, 64);
+        const float spx = DIST ? __shfl(cxy.x, src, 64) : 0.f, spy = DIST ? __shfl(cxy.y, src, 64) : 0.f;
         const uint32_t id = (uint32_t)(g - lane + src);
-        for (uint32_t k = lane; k < c; k += 64) fn(sx0 + k % sw + (sy0 + k / sw) * ntx, id, d);
+        for (uint32_t k = lane; k < c; k += 64) {
+            const uint32_t ix = sx0 + k % sw, iy = sy0 + k / sw;
+            if (!DIST || gs_dist_listed(spx, spy, ix, iy, D)) fn(ix + iy * ntx, id, d);
+        }
     }
 }
+
+// The Gaussians of a slice are visited BIN_THREADS at a time; the records of the next BIN_PF visits are requested
+// before the current ones are walked.  (Without it every visit exposed a full memory round trip: ten dependent
+// round trips per workgroup at 2.4 M Gaussians, with only 16 waves per CU to hide them.)
+#define BIN_PF 4
 
 // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2), while the output region of a
 // tile is laid out in slice order.  Giving XCD x a CONTIGUOUS range of slices makes the 8-byte pair
@@ -76,25 +88,49 @@ __device__ __forceinline__ uint32_t slice_of_block(uint32_t blk, uint32_t B) {
 }
 
 // ---------------------------------------------------------------- B1
+template <bool DIST>
 __global__ void __launch_bounds__(BIN_THREADS) bin_count_kernel(
-    const uint4 *__restrict__ rects, int64_t n, uint32_t per_block, uint32_t T, uint32_t ntx,
-    uint32_t *__restrict__ table, const uint32_t *__restrict__ block_sums,
+    const uint4 *__restrict__ rects, const float4 *__restrict__ rec_geom, GsDistCull D, int64_t n, uint32_t per_block,
+    uint32_t T, uint32_t ntx, uint32_t *__restrict__ table, const uint32_t *__restrict__ block_sums,
     const uint32_t *__restrict__ block_vis, uint32_t *__restrict__ slice_pairs, uint32_t *__restrict__ slice_vis) {
     extern __shared__ uint32_t s_hist[];
     __shared__ uint32_t s_acc[2];
+    const uint32_t slice = slice_of_block(blockIdx.x, gridDim.x);
+    const int64_t g0 = (int64_t)slice * per_block;
+    auto load_rect = [&](uint32_t base) {
+        const uint32_t i = base + threadIdx.x;
+        // one coalesced 16-byte load per Gaussian: rectangle, depth bits, tile count
+        return (i < per_block && g0 + i < n) ? rects[g0 + i] : make_uint4(0, 0, 0, 0);
+    };
+    auto load_xy = [&](uint32_t base, const uint4 &rc) {
+        const uint32_t i = base + threadIdx.x;
+        if (!DIST || !rc.w) return make_float2(0.f, 0.f);
+        const float4 ge = rec_geom[(g0 + i) * GS_REC_STRIDE];
+        return make_float2(ge.x, ge.y);
+    };
+    uint4 rc[BIN_PF];
+#pragma unroll
+    for (int k = 0; k < BIN_PF; ++k) rc[k] = load_rect(k * BIN_THREADS);  // in flight while the histogram is cleared
     for (uint32_t t = threadIdx.x; t < T; t += BIN_THREADS) s_hist[t] = 0;
     if (threadIdx.x < 2) s_acc[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t slice = slice_of_block(blockIdx.x, gridDim.x);
-    const int64_t g0 = (int64_t)slice * per_block;
-    for (uint32_t base = 0; base < per_block; base += BIN_THREADS) {
-        const uint32_t i = base + threadIdx.x;
-        const int64_t g = g0 + i;
-        // one coalesced 16-byte load per Gaussian: rectangle, depth bits, tile count
-        const uint4 rc = (i < per_block && g < n) ? rects[g] : make_uint4(0, 0, 0, 0);
-        walk_rect(rc, g, ntx, [&](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&s_hist[tile], 1u); });
+    for (uint32_t base = 0; base < per_block; base += BIN_PF * BIN_THREADS) {
+        uint4 cur[BIN_PF];
+#pragma unroll
+        for (int k = 0; k < BIN_PF; ++k) {
+            cur[k] = rc[k];
+            rc[k] = load_rect(base + (BIN_PF + k) * BIN_THREADS);
+        }
+#pragma unroll
+        for (int k = 0; k < BIN_PF; ++k) {
+            const uint32_t b = base + k * BIN_THREADS;
+            if (b >= per_block) break;  // uniform
+            walk_rect<DIST>(cur[k], g0 + b + threadIdx.x, ntx, load_xy(b, cur[k]), D,
+                            [&](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&s_hist[tile], 1u); });
+        }
     }
-    // pairs / visible Gaussians of this slice: sums over the 256-Gaussian blocks of the project stage
+    // pairs (rectangle areas: the gradient-row slots) / visible Gaussians of this slice: sums over the
+    // 256-Gaussian blocks of the project stage
     const int64_t nblk = (n + 255) / 256;
     for (uint32_t k = threadIdx.x; k < per_block / 256; k += BIN_THREADS) {
         const int64_t pb = g0 / 256 + k;
@@ -151,6 +187,24 @@ __global__ void __launch_bounds__(256) bin_colscan_kernel(uint32_t *__restrict__
 }
 
 // ---------------------------------------------------------------- B3
+__device__ __forceinline__ unsigned long long *s_wave_u64() {
+    __shared__ unsigned long long s_w64[BIN_THREADS / 64];
+    return s_w64;
+}
+// sum over the workgroup, the same value returned to every thread
+__device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, unsigned long long *s_w) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();  // s_w may still be read from the previous call
+    if (lane == 0) s_w[wave] = v;
+    __syncthreads();
+    unsigned long long total = 0;
+#pragma unroll
+    for (int w = 0; w < BIN_THREADS / 64; ++w) total += s_w[w];
+    return total;
+}
+
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_wave, uint32_t &total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t incl = gs_wave_incl_scan_u32(v);
@@ -168,9 +222,10 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_wave
     return off + incl - v;
 }
 
+template <bool DIST>
 __global__ void __launch_bounds__(BIN_THREADS) bin_scatter_kernel(
-    const uint4 *__restrict__ rects, int64_t n, uint32_t per_block, uint32_t T, uint32_t ntx,
-    const uint32_t *__restrict__ table, const uint32_t *__restrict__ tile_count,
+    const uint4 *__restrict__ rects, const float4 *__restrict__ rec_geom, GsDistCull D, int64_t n, uint32_t per_block,
+    uint32_t T, uint32_t ntx, const uint32_t *__restrict__ table, const uint32_t *__restrict__ tile_count,
     const uint32_t *__restrict__ slice_pairs, const uint32_t *__restrict__ slice_vis, uint32_t B,
     uint64_t *__restrict__ out, uint64_t max_pairs, uint32_t *__restrict__ pair_offsets,
     int32_t *__restrict__ tile_ranges, unsigned long long *__restrict__ counters) {
@@ -182,27 +237,43 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_scatter_kernel(
         const uint32_t i = base + threadIdx.x;
         return (i < per_block && g0 + i < n) ? rects[g0 + i] : make_uint4(0, 0, 0, 0);
     };
-    uint4 rc = load_rect(0);  // in flight while the tile starts are scanned
+    auto load_xy = [&](uint32_t base, const uint4 &rc) {
+        const uint32_t i = base + threadIdx.x;
+        if (!DIST || !rc.w) return make_float2(0.f, 0.f);
+        const float4 ge = rec_geom[(g0 + i) * GS_REC_STRIDE];
+        return make_float2(ge.x, ge.y);
+    };
+    uint4 rc[BIN_PF];
+#pragma unroll
+    for (int k = 0; k < BIN_PF; ++k) rc[k] = load_rect(k * BIN_THREADS);  // in flight while the tile starts are scanned
     // 1. tile starts = exclusive scan of tile_count (every workgroup computes all of them)
     const uint32_t per = (T + BIN_THREADS - 1) / BIN_THREADS;
     const uint32_t t0 = threadIdx.x * per, t1 = t0 + per < T ? t0 + per : T;
-    uint32_t mine = 0;
+    // 64-bit totals: a degenerate scene (hundreds of thousands of screen-filling Gaussians) can exceed 2^32 pairs,
+    // and a wrapped total must not slip under the capacity test
+    unsigned long long mine = 0;
     for (uint32_t t = t0; t < t1; ++t) mine += tile_count[t];
-    uint32_t M;
-    uint32_t run = block_excl_scan(mine, s_wave, M);
-    if (M > max_pairs) {  // not enough room: leave the frame empty and report the true count
+    // listed pairs M (sum over tiles) and gradient-row slots R (sum of the rectangle areas; R == M unless DIST)
+    unsigned long long rp = 0, rv = 0;
+    for (uint32_t b = threadIdx.x; b < B; b += BIN_THREADS) {
+        rp += slice_pairs[b];
+        rv += slice_vis[b];
+    }
+    const unsigned long long M = block_sum_u64(mine, s_wave_u64()), R = block_sum_u64(rp, s_wave_u64()),
+                             V = block_sum_u64(rv, s_wave_u64());
+    if (M > max_pairs || R > max_pairs) {  // not enough room: leave the frame empty and report the true count
         if (slice == 0) {
             for (uint32_t t = threadIdx.x; t < T; t += BIN_THREADS) reinterpret_cast<int2 *>(tile_ranges)[t] = make_int2(0, 0);
             if (threadIdx.x == 0) {
-                uint32_t v = 0;
-                for (uint32_t b = 0; b < B; ++b) v += slice_vis[b];
                 counters[GS_CNT_PAIRS] = 0;
-                counters[GS_CNT_OVERFLOW] = M;
-                counters[GS_CNT_VISIBLE] = v;
+                counters[GS_CNT_OVERFLOW] = M > R ? M : R;
+                counters[GS_CNT_VISIBLE] = V;
             }
         }
         return;
     }
+    uint32_t dummy;
+    uint32_t run = block_excl_scan((uint32_t)mine, s_wave, dummy);
     for (uint32_t t = t0; t < t1; ++t) {
         s_slot[t] = run;
         run += tile_count[t];
@@ -218,36 +289,42 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_scatter_kernel(
     else
         for (uint32_t t = threadIdx.x; t < T; t += BIN_THREADS) s_slot[t] += row[t];
     // 2. slice totals: frame counters, and the emission offset of this slice (per-pair gradient rows)
-    uint32_t before = 0, vis = 0, dummy;
-    if (pair_offsets || slice == 0) {
-        uint32_t p = 0, v = 0;
-        for (uint32_t b = threadIdx.x; b < B; b += BIN_THREADS) {
-            p += b < slice ? slice_pairs[b] : 0;
-            v += slice_vis[b];
-        }
+    uint32_t before = 0;
+    if (pair_offsets) {
+        uint32_t p = 0;
+        for (uint32_t b = threadIdx.x; b < B; b += BIN_THREADS) p += b < slice ? slice_pairs[b] : 0;
         block_excl_scan(p, s_wave, before);
-        block_excl_scan(v, s_wave, vis);
-        if (slice == 0 && threadIdx.x == 0) {
-            counters[GS_CNT_PAIRS] = M;
-            counters[GS_CNT_OVERFLOW] = 0;
-            counters[GS_CNT_VISIBLE] = vis;
-        }
+    }
+    if (slice == 0 && threadIdx.x == 0) {
+        counters[GS_CNT_PAIRS] = M;
+        counters[GS_CNT_OVERFLOW] = 0;
+        counters[GS_CNT_VISIBLE] = V;
     }
     __syncthreads();
     // 3. scatter
-    for (uint32_t base = 0; base < per_block; base += BIN_THREADS) {  // uniform trip count (barriers inside)
-        const uint32_t i = base + threadIdx.x;
-        const int64_t g = g0 + i;
-        if (base) rc = load_rect(base);
-        if (pair_offsets) {  // uniform: prefix sum of the tile counts in Gaussian order
-            const uint32_t ex = block_excl_scan(rc.w, s_wave, dummy);
-            if (i < per_block && g < n) pair_offsets[g] = before + ex;
-            before += dummy;
+    for (uint32_t base = 0; base < per_block; base += BIN_PF * BIN_THREADS) {  // uniform trip counts (barriers inside)
+        uint4 cur[BIN_PF];
+#pragma unroll
+        for (int k = 0; k < BIN_PF; ++k) {
+            cur[k] = rc[k];
+            rc[k] = load_rect(base + (BIN_PF + k) * BIN_THREADS);
         }
-        walk_rect(rc, g, ntx, [&](uint32_t tile, uint32_t id, uint32_t d) {
-            const uint32_t slot = atomicAdd(&s_slot[tile], 1u);
-            out[slot] = ((uint64_t)d << 32) | id;
-        });
+#pragma unroll
+        for (int k = 0; k < BIN_PF; ++k) {
+            const uint32_t b = base + k * BIN_THREADS;
+            if (b >= per_block) break;  // uniform
+            const uint32_t i = b + threadIdx.x;
+            const int64_t g = g0 + i;
+            if (pair_offsets) {  // uniform: prefix sum of the rectangle areas in Gaussian order
+                const uint32_t ex = block_excl_scan(cur[k].w, s_wave, dummy);
+                if (i < per_block && g < n) pair_offsets[g] = before + ex;
+                before += dummy;
+            }
+            walk_rect<DIST>(cur[k], g, ntx, load_xy(b, cur[k]), D, [&](uint32_t tile, uint32_t id, uint32_t d) {
+                const uint32_t slot = atomicAdd(&s_slot[tile], 1u);
+                out[slot] = ((uint64_t)d << 32) | id;
+            });
+        }
     }
 }
 
@@ -264,6 +341,8 @@ int gs_stage_tile_bin(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stre
     const uint32_t T = (uint32_t)G.n_tiles, per_block = bin_per_block(f->N);
     const uint32_t B = (uint32_t)gs_div_up(f->N, per_block);
     const size_t lds = sizeof(uint32_t) * T;
+    const bool dist = f->tile_culling_method == 0;
+    GsDistCull D = {(float)(G.padW / 2), (float)(G.padH / 2), f->focal_x, f->focal_y, f->thresh};
     // histograms above 64 KiB need the opt-in (gfx950: 160 KiB per workgroup): once per DEVICE (a function
     // attribute belongs to the device's code object), thread-safe
     static std::mutex attr_mu;
@@ -272,22 +351,30 @@ int gs_stage_tile_bin(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stre
     GS_HIP(hipGetDevice(&dev));
     if (dev < 64 && !((attr_done.load(std::memory_order_acquire) >> dev) & 1)) {
         std::lock_guard<std::mutex> lock(attr_mu);
-        GS_HIP(hipFuncSetAttribute((const void *)bin_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   GS_BIN_MAX_TILES * 4));
-        GS_HIP(hipFuncSetAttribute((const void *)bin_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   GS_BIN_MAX_TILES * 4));
+        for (const void *fn : {(const void *)bin_count_kernel<false>, (const void *)bin_count_kernel<true>,
+                               (const void *)bin_scatter_kernel<false>, (const void *)bin_scatter_kernel<true>})
+            GS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, GS_BIN_MAX_TILES * 4));
         attr_done.fetch_or(1ull << dev, std::memory_order_release);
     }
-    hipLaunchKernelGGL(bin_count_kernel, dim3(B), dim3(BIN_THREADS), lds, stream, ws.rects, f->N,
-                       per_block, T, (uint32_t)G.ntx, ws.bin_table, ws.block_sums, ws.block_vis, ws.slice_pairs,
-                       ws.slice_vis);
-    GS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bin_colscan_kernel, dim3((unsigned)gs_div_up(T, 64)), dim3(256), 0, stream, ws.bin_table, B,
-                       T, ws.tile_count);
-    GS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bin_scatter_kernel, dim3(B), dim3(BIN_THREADS), lds, stream, ws.rects, f->N, per_block, T, (uint32_t)G.ntx, ws.bin_table, ws.tile_count,
-                       ws.slice_pairs, ws.slice_vis, B, ws.keys_a, (uint64_t)f->max_pairs,
-                       f->training ? ws.pair_offsets : nullptr, ws.tile_ranges, ws.counters);
-    GS_CHECK_LAUNCH();
+#define GS_LAUNCH_BIN(DIST)                                                                                            \
+    do {                                                                                                               \
+        hipLaunchKernelGGL(bin_count_kernel<DIST>, dim3(B), dim3(BIN_THREADS), lds, stream, ws.rects, ws.rec_geom, D,  \
+                           f->N, per_block, T, (uint32_t)G.ntx, ws.bin_table, ws.block_sums, ws.block_vis,             \
+                           ws.slice_pairs, ws.slice_vis);                                                              \
+        GS_CHECK_LAUNCH();                                                                                             \
+        hipLaunchKernelGGL(bin_colscan_kernel, dim3((unsigned)gs_div_up(T, 64)), dim3(256), 0, stream, ws.bin_table,   \
+                           B, T, ws.tile_count);                                                                       \
+        GS_CHECK_LAUNCH();                                                                                             \
+        hipLaunchKernelGGL(bin_scatter_kernel<DIST>, dim3(B), dim3(BIN_THREADS), lds, stream, ws.rects, ws.rec_geom,   \
+                           D, f->N, per_block, T, (uint32_t)G.ntx, ws.bin_table, ws.tile_count, ws.slice_pairs,        \
+                           ws.slice_vis, B, ws.keys_a, (uint64_t)f->max_pairs,                                         \
+                           f->training ? ws.pair_offsets : nullptr, ws.tile_ranges, ws.counters);                      \
+        GS_CHECK_LAUNCH();                                                                                             \
+    } while (0)
+    if (dist)
+        GS_LAUNCH_BIN(true);
+    else
+        GS_LAUNCH_BIN(false);
+#undef GS_LAUNCH_BIN
     return 0;
 }

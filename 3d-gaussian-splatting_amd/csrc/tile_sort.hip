@@ -195,7 +195,8 @@ __device__ __forceinline__ void disperse_levels(uint64_t *a, uint32_t n, uint32_
 // PACKED = false (sort_mode 1): keys = (tile << 32 | depth_bits) grouped by tile, ids = Gaussian index;
 //   both are overwritten in place with the depth-sorted order; scratch = idle half of the key buffer.
 // PACKED = true (sort_mode 2): scratch = (depth_bits << 32 | gaussian) grouped by tile in arbitrary
-//   order; the sorted (tile << 32 | depth_bits) and ids go to keys / ids; long buckets sort in place.
+//   order; the sorted ids go to ids, the sorted (tile << 32 | depth_bits) to keys unless keys is NULL; long buckets
+//   sort in place.
 template <int CAP, bool PACKED>
 __global__ void __launch_bounds__(256) tile_sort_kernel(uint64_t *__restrict__ keys, uint32_t *__restrict__ ids,
                                                        uint64_t *__restrict__ scratch,
@@ -207,9 +208,11 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(uint64_t *__restrict__ k
     auto load = [&](uint32_t i) -> uint64_t {
         return PACKED ? scratch[start + i] : (keys[start + i] << 32) | ids[start + i];
     };
+    // PACKED: the sorted keys are only written on request (GS_FRAME_EMIT_SORTED_KEYS): the raster kernels read the
+    // sorted ids alone, and 8 of the 12 bytes this kernel would store per pair are the keys
     auto store = [&](uint32_t i, uint64_t v) {
         ids[start + i] = (uint32_t)v;
-        keys[start + i] = ((uint64_t)tile << 32) | (v >> 32);
+        if (!PACKED || keys) keys[start + i] = ((uint64_t)tile << 32) | (v >> 32);
     };
     auto select = [&](uint32_t t) {
         tile = t;

@@ -38,7 +38,11 @@ class GsFrame(C.Structure):
         ("max_pairs", i64), ("workspace", vp), ("workspace_bytes", sz),
         ("image", vp), ("image_padded", vp),
         ("training", i32), ("sort_mode", i32), ("tile_culling_method", i32),
+        ("async_", vp), ("flags", i32),  # ABI 3 (`async` is a Python keyword)
     ]
+
+
+GS_FRAME_EMIT_SORTED_KEYS = 1
 
 
 def _sig(name, restype, *argtypes):
@@ -80,7 +84,9 @@ gs_frame_debug_views = _sig("gs_frame_debug_views", ci, C.POINTER(GsFrame), C.PO
 gs_adam_step = _sig("gs_adam_step", ci, vp, vp, vp, vp, i64, i32, C.POINTER(i64), C.POINTER(f32), f32, f32, f32, i64,
                     vp, i64, i64, i32, vp)
 gs_grad_stat_update = _sig("gs_grad_stat_update", ci, vp, vp, i64, i32, vp)
-gs_frame_release_workspace = _sig("gs_frame_release_workspace", ci, vp, vp)
+gs_frame_async_create = _sig("gs_frame_async_create", ci, C.POINTER(vp))
+gs_frame_async_wait = _sig("gs_frame_async_wait", ci, vp, vp)
+gs_frame_async_destroy = _sig("gs_frame_async_destroy", ci, vp)
 gs_loss_workspace_bytes = _sig("gs_loss_workspace_bytes", sz, i32, i32)
 gs_loss_l1_ssim = _sig("gs_loss_l1_ssim", ci, vp, vp, i32, i32, f32, vp, vp, vp, sz, vp)
 
@@ -106,7 +112,7 @@ EXPORTS = [
     "gs_gather_gaussians", "gs_draw", "gs_draw_backward_workspace_bytes", "gs_draw_backward",
     "gs_sort_pairs_tmp_bytes", "gs_sort_pairs", "gs_sort_pairs_bits", "gs_frame_workspace_bytes", "gs_frame_forward",
     "gs_frame_stats_async", "gs_frame_debug_views", "gs_frame_backward", "gs_frame_forward_profile",
-    "gs_frame_release_workspace",
+    "gs_frame_async_create", "gs_frame_async_wait", "gs_frame_async_destroy",
     "gs_frame_backward_profile", "gs_adam_step", "gs_grad_stat_update", "gs_loss_workspace_bytes", "gs_loss_l1_ssim",
     "gs_densify_workspace_bytes", "gs_densify_classify", "gs_densify_apply",
 ]

@@ -18,7 +18,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libgs_amd.so")
 
 SOURCES = {
-    "cull_project.hip": ["-ffp-contract=off"],
+    # no SLP packing: the packer turns the 3x3 products into v_pk_mul/v_pk_add + ~140 v_mov shuffles per Gaussian;
+    # a packed op has no rate advantage on gfx950, so that is pure issue time (and 66 instead of 45 VGPRs)
+    "cull_project.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
     "binning.hip": ["-ffp-contract=off"],
     "radix_sort.hip": [],
     "tile_sort.hip": [],

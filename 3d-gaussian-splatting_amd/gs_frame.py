@@ -26,6 +26,7 @@ from gaussian import _lib
 from gs_geometry import RayBasis, TileGrid
 
 SCALE_ACT = {"abs": 0, "exp": 1}
+TILE_CULLING = {"dist": 0, "prob": 1, "prob2": 2}  # the reference's `_method_config` (splatter.py:571)
 
 
 @dataclass
@@ -39,14 +40,21 @@ class FrameStats:
 class FrameRenderer:
     def __init__(self, device="cuda", max_pairs: int = 1 << 20, training: bool = False,
                  thresh: float = 0.05, scale_activation: str = "abs", auto_grow: bool = True,
-                 sort_mode: int = 2, tile_culling_method: str = "prob2"):
+                 sort_mode: int = 2, tile_culling_method: str = "prob2", tile_culling_dist_thresh: float = 0.5,
+                 emit_sorted_keys: bool = False):
         self.device = torch.device(device)
-        if tile_culling_method not in ("prob2", "prob"):
-            raise NotImplementedError("the fused frame path lists tiles with 'prob2' (train.py's default) or 'prob'; "
-                                      "'dist' is method 0 of gaussian.calc_tile_list")
-        self.tile_culling_method = {"prob2": 2, "prob": 1}[tile_culling_method]
         if self.device.type != "cuda":
             raise RuntimeError("FrameRenderer needs a HIP device; there is no CPU fallback")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        if tile_culling_method not in TILE_CULLING:
+            raise ValueError(f"tile_culling_method must be one of {sorted(TILE_CULLING)}")
+        # "prob2" (train.py's default), "prob" and "dist" (Splatter.__init__'s default): splatter.py:571-578.
+        # For "prob" / "prob2" `thresh` is tile_culling_prob_thresh, for "dist" the radius is
+        # tile_geo_length_x / tile_culling_dist_thresh (thresh is unused).
+        self.tile_culling_method = TILE_CULLING[tile_culling_method]
+        self.tile_culling_dist_thresh = float(tile_culling_dist_thresh)
+        self.emit_sorted_keys = bool(emit_sorted_keys)
         self.max_pairs = int(max_pairs)
         self.training = bool(training)
         self.thresh = float(thresh)
@@ -66,8 +74,15 @@ class FrameRenderer:
         self._ws: Optional[torch.Tensor] = None
         self._stats_host = torch.zeros(4, dtype=torch.int64).pin_memory()
         self._frame: Optional[_lib.GsFrame] = None
+        self._frame_serial = 0  # counts forwards: autograd checks that backward() belongs to the latest one
         self._cam_cache = {}
         self._keep = None
+        # opt-in side stream of the library (include/gs_abi.h, gs_frame_async_*): owned by this renderer
+        self._async = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.gs_frame_async_create(C.byref(self._async)), "gs_frame_async_create")
+        self._checked_once = False  # auto_grow="async": the first frame is checked synchronously
+        self.overflowed_frames = 0  # frames that were rendered empty / truncated and could not be redone (see forward)
 
     # ------------------------------------------------------------------ frame descriptor
     def _describe(self, pos, quat, scale, opa, rgb, camera, training) -> _lib.GsFrame:
@@ -84,7 +99,7 @@ class FrameRenderer:
         # per-camera constants (tile grid, frustum guard band, ray basis) are cached: a viewer or a
         # trainer cycles through a fixed set of cameras, and this host work (a 3x3 inverse, ~40
         # ctypes stores) would otherwise cost more than the launches themselves
-        ck = (id(camera), int(camera.width), int(camera.height), float(camera.focal_x), float(camera.focal_y),
+        ck = (int(camera.width), int(camera.height), float(camera.focal_x), float(camera.focal_y),
               float(camera.near), np.asarray(camera.rot, np.float32).tobytes(),
               np.asarray(camera.tran, np.float32).tobytes())
         cached = self._cam_cache.get(ck)
@@ -113,8 +128,12 @@ class FrameRenderer:
         C.memmove(C.byref(f), C.byref(proto), C.sizeof(_lib.GsFrame))
         f.N, f.color_dim, f.scale_activation = n, color_dim, self.scale_activation
         f.pos, f.quat, f.scale, f.opa, f.rgb = (t.data_ptr() for t in (pos, quat, scale, opa, rgb))
-        f.thresh = self.thresh
+        # "dist": the squared distance threshold of splatter.py:577
+        f.thresh = (grid.tile_geo_length_x / self.tile_culling_dist_thresh) ** 2 if self.tile_culling_method == 0 \
+            else self.thresh
         f.max_pairs = self.max_pairs
+        f.async_ = self._async
+        f.flags = _lib.GS_FRAME_EMIT_SORTED_KEYS if self.emit_sorted_keys else 0
         f.training = int(training)
         f.sort_mode = self.sort_mode
         f.tile_culling_method = self.tile_culling_method
@@ -128,33 +147,65 @@ class FrameRenderer:
         self._grid = grid
         return f
 
+    def _stream(self):
+        return torch.cuda.current_stream(self.device)
+
     def _release_workspace(self):
         """Before the workspace tensor goes back to torch's allocator: let the current stream wait for what the
-        library's side stream may still be doing in it (include/gs_abi.h, gs_frame_release_workspace)."""
-        if self._ws is not None:
-            key = (self._ws.data_ptr() + 255) // 256 * 256
-            _lib.check(_lib.gs_frame_release_workspace(key, torch.cuda.current_stream().cuda_stream),
-                       "gs_frame_release_workspace")
+        library's side stream may still be doing in it (include/gs_abi.h, gs_frame_async_wait)."""
+        if self._ws is not None and self._async:
+            _lib.check(_lib.gs_frame_async_wait(self._async, self._stream().cuda_stream), "gs_frame_async_wait")
             self._frame = None
 
     def __del__(self):
         try:
             self._release_workspace()
+            if self._async:
+                _lib.gs_frame_async_destroy(self._async)
+                self._async = C.c_void_p()
         except Exception:  # interpreter shutdown: the library or torch may already be gone
             pass
 
     # ------------------------------------------------------------------ low-level API
     def forward(self, pos, quat, scale, opa, rgb, camera, training: Optional[bool] = None):
-        """Raw parameters -> (image [H,W,3] clamped+cropped, padded raw image or None)."""
+        """Raw parameters -> (image [H,W,3] clamped+cropped, padded raw image or None).
+
+        Capacity (``max_pairs``) and ``auto_grow``: ``True`` reads the frame's counters after every frame (one host
+        synchronisation) and redoes an overflowed frame in a larger workspace.  ``"async"`` does that for the FIRST
+        frame and for every inference frame (``training=False``: an evaluation image is never returned truncated);
+        training frames after the first copy their counters to pinned memory without waiting, and the next forward
+        grows the workspace (25 % head room, and already when a frame comes within 25 % of the capacity) -- a training
+        frame that overflowed all the same was rendered empty, is counted in ``overflowed_frames``, and ``last_frame_
+        overflowed()`` tells the trainer to skip that optimizer step.  ``False`` never checks."""
         training = self.training if training is None else training
-        stream = torch.cuda.current_stream().cuda_stream
-        if self.auto_grow == "async" and self._async_event is not None and self._async_event.query():
-            v, m, o, b = (int(x) for x in self._async_host.tolist())  # counters of an earlier frame, already on the host
+        with torch.cuda.device(self.device):
+            return self._forward(pos, quat, scale, opa, rgb, camera, training)
+
+    def _poll_async_counters(self):
+        """Counters of an earlier frame that have landed in pinned memory (no waiting)."""
+        if self._async_event is not None and self._async_event.query():
+            v, m, o, b = (int(x) for x in self._async_host.tolist())
             self._async_event = None
             if o:
-                self.max_pairs = int(o * self.headroom) + 1024
+                self.overflowed_frames += 1
+                self._last_overflow_serial = self._async_serial
+                self.max_pairs = max(self.max_pairs, int(o * self.headroom) + 1024)
             elif m * self.headroom > self.max_pairs:  # close to the limit: grow before it overflows
                 self.max_pairs = int(m * self.headroom * self.headroom) + 1024
+
+    def last_frame_overflowed(self, wait: bool = False) -> bool:
+        """auto_grow="async": did the most recent forward overflow its workspace?  Without ``wait`` only what has
+        already reached the host is looked at (False if the counters are still in flight)."""
+        if self._async_event is not None and wait:
+            self._async_event.synchronize()
+        self._poll_async_counters()
+        return getattr(self, "_last_overflow_serial", -1) == self._frame_serial
+
+    def _forward(self, pos, quat, scale, opa, rgb, camera, training):
+        stream = self._stream().cuda_stream
+        sync_check = self.auto_grow is True or (self.auto_grow == "async" and (not training or not self._checked_once))
+        if self.auto_grow == "async":
+            self._poll_async_counters()
         while True:
             f = self._describe(pos, quat, scale, opa, rgb, camera, training)
             g = self._grid
@@ -165,20 +216,24 @@ class FrameRenderer:
             f.image_padded = padded.data_ptr() if padded is not None else None
             _lib.check(_lib.gs_frame_forward(C.byref(f), stream), "gs_frame_forward")
             self._frame = f
+            self._frame_serial += 1
             self._keep = (pos, quat, scale, opa, rgb, image, padded)
-            if self.auto_grow == "async":
-                if self._async_event is None:  # one copy in flight at a time
-                    _lib.check(_lib.gs_frame_stats_async(C.byref(f), self._async_host.data_ptr(), stream),
-                               "gs_frame_stats_async")
-                    self._async_event = torch.cuda.Event()
-                    self._async_event.record(torch.cuda.current_stream())
+            if sync_check:
+                st = self.stats()
+                if st.overflow:
+                    self.max_pairs = int(st.overflow * self.headroom) + 1024  # grow and redo the frame
+                    continue
+                self._checked_once = True
+                if self.auto_grow == "async" and st.pairs * self.headroom > self.max_pairs:
+                    self.max_pairs = int(st.pairs * self.headroom * self.headroom) + 1024  # takes effect next frame
                 break
-            if not self.auto_grow:
-                break
-            st = self.stats()
-            if not st.overflow:
-                break
-            self.max_pairs = int(st.overflow * 1.25) + 1024  # grow and redo the frame
+            if self.auto_grow == "async" and self._async_event is None:  # one copy in flight at a time
+                _lib.check(_lib.gs_frame_stats_async(C.byref(f), self._async_host.data_ptr(), stream),
+                           "gs_frame_stats_async")
+                self._async_event = torch.cuda.Event()
+                self._async_event.record(self._stream())
+                self._async_serial = self._frame_serial
+            break
         return image, padded
 
     def backward(self, grad_image, out=None):
@@ -196,8 +251,9 @@ class FrameRenderer:
         for t, ref in zip(out, (pos, quat, scale, opa, rgb)):
             if t.shape != ref.shape or t.dtype != torch.float32 or not t.is_contiguous():
                 raise RuntimeError("gradient destinations must match the parameters")
-        _lib.check(_lib.gs_frame_backward(C.byref(f), grad_image.data_ptr(), *(t.data_ptr() for t in out),
-                                          torch.cuda.current_stream().cuda_stream), "gs_frame_backward")
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.gs_frame_backward(C.byref(f), grad_image.data_ptr(), *(t.data_ptr() for t in out),
+                                              self._stream().cuda_stream), "gs_frame_backward")
         return out
 
     def profile_forward(self, pos, quat, scale, opa, rgb, camera, training: Optional[bool] = None):
@@ -212,9 +268,11 @@ class FrameRenderer:
         f.image = image.data_ptr()
         f.image_padded = padded.data_ptr() if padded is not None else None
         ms = (C.c_float * 6)()
-        _lib.check(_lib.gs_frame_forward_profile(C.byref(f), ms, torch.cuda.current_stream().cuda_stream),
-                   "gs_frame_forward_profile")
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.gs_frame_forward_profile(C.byref(f), ms, self._stream().cuda_stream),
+                       "gs_frame_forward_profile")
         self._frame = f
+        self._frame_serial += 1
         self._keep = (pos, quat, scale, opa, rgb, image, padded)
         return dict(zip(("project", "scan_emit", "sort", "ranges", "raster", "total"), (float(x) for x in ms)))
 
@@ -225,17 +283,17 @@ class FrameRenderer:
         pos, quat, scale, opa, rgb = self._keep[:5]
         out = tuple(torch.empty_like(t) for t in (pos, quat, scale, opa, rgb))
         ms = (C.c_float * 3)()
-        _lib.check(_lib.gs_frame_backward_profile(C.byref(f), grad_image.contiguous().data_ptr(),
-                                                  *(t.data_ptr() for t in out), ms,
-                                                  torch.cuda.current_stream().cuda_stream),
-                   "gs_frame_backward_profile")
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.gs_frame_backward_profile(C.byref(f), grad_image.contiguous().data_ptr(),
+                                                      *(t.data_ptr() for t in out), ms, self._stream().cuda_stream),
+                       "gs_frame_backward_profile")
         return dict(zip(("raster_bwd", "project_bwd", "total"), (float(x) for x in ms)))
 
     def stats(self) -> FrameStats:
         """Synchronises the current stream (one 32-byte D2H copy)."""
         if self._frame is None:
             raise RuntimeError("no frame rendered yet")
-        stream = torch.cuda.current_stream()
+        stream = self._stream()
         _lib.check(_lib.gs_frame_stats_async(C.byref(self._frame), self._stats_host.data_ptr(), stream.cuda_stream),
                    "gs_frame_stats_async")
         stream.synchronize()
@@ -266,10 +324,22 @@ class FrameRenderer:
             off = ptr.value - self._ws.data_ptr()
             return self._ws[off:off + nbytes].view(dtype).reshape(shape)
 
+        ids = view(ptrs[1], 4 * m, torch.int32, (m,))
+        ranges = view(ptrs[2], 8 * T, torch.int32, (T, 2))
+        if ptrs[0].value:
+            keys = view(ptrs[0], 8 * m, torch.int64, (m,))
+        else:
+            # sort_mode 2 without GS_FRAME_EMIT_SORTED_KEYS: the sorted keys are not materialised (the raster kernels
+            # read the ids only).  They are (tile << 32 | depth bits) of the pairs in list order: tile from the
+            # ranges, depth bits from the record of the sorted id.
+            counts = (ranges[:, 1] - ranges[:, 0]).to(torch.int64)
+            tiles = torch.repeat_interleave(torch.arange(T, device=self.device, dtype=torch.int64), counts)
+            depth = view(ptrs[3], 64 * n, torch.int32, (n, 16))[:, 2].to(torch.int64) & 0xffffffff
+            keys = (tiles << 32) | depth[ids.to(torch.int64)]
         out = {
-            "sorted_keys": view(ptrs[0], 8 * m, torch.int64, (m,)),
-            "sorted_ids": view(ptrs[1], 4 * m, torch.int32, (m,)),
-            "tile_ranges": view(ptrs[2], 8 * T, torch.int32, (T, 2)),
+            "sorted_keys": keys,
+            "sorted_ids": ids,
+            "tile_ranges": ranges,
             # one 64-byte record per Gaussian: geom | cov | color | conic
             "rec_geom": view(ptrs[3], 64 * n, torch.float32, (n, 16))[:, 0:4],
             "rec_cov": view(ptrs[3], 64 * n, torch.float32, (n, 16))[:, 4:8],
@@ -293,13 +363,13 @@ class _FrameFunction(torch.autograd.Function):
         image, _ = renderer.forward(pos.detach(), quat.detach(), scale.detach(), opa.detach(), rgb.detach(), camera,
                                     training=True)
         ctx.renderer = renderer
-        ctx.frame_id = id(renderer._frame)
+        ctx.frame_serial = renderer._frame_serial
         return image
 
     @staticmethod
     def backward(ctx, grad_image):
         r = ctx.renderer
-        if id(r._frame) != ctx.frame_id:
+        if r._frame_serial != ctx.frame_serial:
             raise RuntimeError("FrameRenderer workspace was reused by another forward before backward()")
         g = r.backward(grad_image)
         return (*g, None, None)

@@ -173,10 +173,17 @@ class Trainer:
         self.densify, self.generator = bool(densify), generator
         self.cameras, self.targets = list(cameras), list(targets)
         dev = params[0].device
-        # "async": the pair capacity is checked from a pinned-memory copy one frame late -- no host
-        # synchronisation in the training loop (the reference synchronises >= 8 times per forward)
+        # "async": in steady state the pair capacity is checked from a pinned-memory copy one frame late -- no host
+        # synchronisation in the training loop (the reference synchronises >= 8 times per forward).  The FIRST frame
+        # of every view on every Gaussian set (start of training, after each densification) is checked synchronously
+        # and redone in a larger workspace if it did not fit, so a step is never taken on an empty frame because the
+        # capacity was simply unknown; after that a view's pair count only drifts, and the workspace grows ahead of
+        # it (25 % head room).  Should a frame overflow all the same, `renderer.overflowed_frames` counts it and
+        # train_step warns once the late counters arrive.
         self.renderer = FrameRenderer(dev, max_pairs=max_pairs, training=True, scale_activation=scale_activation,
                                       auto_grow="async")
+        self._views_checked = set()
+        self._overflow_warned = 0
         self._lambdas, self._base = lr_lambdas(self.opt), base_lrs(self.opt)
         self._loss = {}
         self._bind(params, 0)
@@ -192,6 +199,7 @@ class Trainer:
         self.view_stat = (ViewParallelGradStat(self.flat.params[0].shape[0], self.flat.flat_param.device,
                                                self.opt.grad_accum_method, self.world_size) if split_stat else None)
         self.grad_counter = None  # "mean" accumulation only: per-Gaussian count of views that saw it (train.py:150)
+        self._views_checked = set()  # a new Gaussian set: every view's first frame is capacity-checked again
 
     @property
     def n_gaussians(self) -> int:
@@ -213,7 +221,17 @@ class Trainer:
         control = only_delete and i_iter < o.adaptive_control_end_iter
         accum_start = past and (i_iter + o.grad_accum_iters - 1) % o.n_adaptive_control == 0
         cam, target = self.cameras[camera_id], self.targets[camera_id]
+        if camera_id not in self._views_checked:  # first frame of this view on this Gaussian set: synchronous check
+            self._views_checked.add(camera_id)
+            self.renderer._checked_once = False
         image, _ = self.renderer.forward(*self.flat.params, cam)
+        if self.renderer.overflowed_frames > self._overflow_warned:
+            import warnings
+
+            warnings.warn(f"{self.renderer.overflowed_frames - self._overflow_warned} training frame(s) exceeded the "
+                          f"pair capacity and were rendered empty (their optimizer steps saw zero gradients); the "
+                          f"workspace has been enlarged to {self.renderer.max_pairs} pairs")
+            self._overflow_warned = self.renderer.overflowed_frames
         loss = self._loss_for(image.shape[0], image.shape[1])
         grad_image = loss(image, target)
         self.renderer.backward(grad_image, out=self.flat.grads)
@@ -303,6 +321,7 @@ class Trainer:
                                                 training=False, scale_activation=self.scale_activation,
                                                 thresh=self.renderer.thresh)
             self._eval_renderer.tile_culling_method = self.renderer.tile_culling_method
+            self._eval_renderer.tile_culling_dist_thresh = self.renderer.tile_culling_dist_thresh
         tic, toc = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         tic.record()
         image, _ = self._eval_renderer.forward(*self.flat.params, cam)

@@ -16,8 +16,7 @@ three HIP launches of ``gs_densify`` instead of ~40 torch kernels in ``adaptive_
 against the reference's Splatter (its own train.py included) runs unchanged; ``gs_train.Trainer`` / ``train.py`` of
 this package additionally fuse the loss and the optimizer.
 
-Differences, all deliberate: ``tile_culling_method`` is "prob2" (what train.py passes) or "prob" ("dist" exists on
-the reference-API ``gaussian.calc_tile_list``); ``cudaculling`` / ``jacobian_calc`` / ``fast_drawing`` / ``debug`` /
+Differences, all deliberate: ``cudaculling`` / ``jacobian_calc`` / ``fast_drawing`` / ``debug`` /
 ``debug_align`` select debugging variants of the reference and are accepted and ignored; images are decoded with
 Pillow instead of cv2; ``n_tile_gaussians`` is read from the device on access (one synchronisation) instead of on
 every frame.
@@ -77,9 +76,8 @@ class Splatter(nn.Module):
         super().__init__()
         if not torch.cuda.is_available():
             raise RuntimeError("Splatter needs a HIP device; there is no CPU fallback")
-        if tile_culling_method not in ("prob2", "prob"):
-            raise NotImplementedError("the fused frame path implements tile_culling_method 'prob2' (train.py's "
-                                      "default) and 'prob'; 'dist' is method 0 of gaussian.calc_tile_list")
+        if tile_culling_method not in ("prob2", "prob", "dist"):
+            raise ValueError("tile_culling_method must be 'dist', 'prob' or 'prob2' (splatter.py:571)")
         if render_weight_normalize:
             raise NotImplementedError("render_weight_normalize is a flag of the reference-API draw(); train.py "
                                       "passes False (splatter.py:627)")
@@ -109,7 +107,9 @@ class Splatter(nn.Module):
         # "async": the pair capacity is checked one frame late from pinned memory -- no host synchronisation per frame
         self._renderer = FrameRenderer(self.device, max_pairs=max_pairs, training=True, thresh=tile_culling_prob_thresh,
                                        scale_activation=scale_activation, auto_grow="async",
-                                       tile_culling_method=tile_culling_method)
+                                       tile_culling_method=tile_culling_method,
+                                       tile_culling_dist_thresh=tile_culling_dist_thresh)
+        self._views_checked = set()  # (view, Gaussian count) pairs whose first frame has been capacity-checked
         self.current_camera = None
         self.ground_truth = None
         if not self.test:
@@ -120,6 +120,7 @@ class Splatter(nn.Module):
         from PIL import Image
 
         self.w2c_quats, self.w2c_rots, self.w2c_trans, self.cam_ids, self.imgs = [], [], [], [], []
+        self._host_poses = []  # (rot [3,3], tran [3]) as host float32 arrays: set_camera never reads the device back
         for img_id in sorted(im.id for im in self.images_info.values()):
             info = self.images_info[img_id]
             fn = os.path.join(self.image_path, info.name)
@@ -129,7 +130,10 @@ class Splatter(nn.Module):
             self.imgs.append(torch.from_numpy(rgb.copy()).to(torch.uint8).to(self.device))
             self.w2c_quats.append(torch.from_numpy(np.asarray(info.qvec)).to(torch.float32).to(self.device))
             self.w2c_trans.append(torch.from_numpy(np.asarray(info.tvec)).to(torch.float32).to(self.device))
-            self.w2c_rots.append(torch.from_numpy(gs_colmap.qvec2rotmat(info.qvec)).to(torch.float32).to(self.device))
+            rot = gs_colmap.qvec2rotmat(info.qvec)
+            self.w2c_rots.append(torch.from_numpy(rot).to(torch.float32).to(self.device))
+            self._host_poses.append((np.asarray(rot, np.float32).reshape(3, 3).copy(),
+                                     np.asarray(info.tvec, np.float32).reshape(3).copy()))
             self.cam_ids.append(info.camera_id)
 
     def switch_resolution(self, downsample_factor):
@@ -145,7 +149,9 @@ class Splatter(nn.Module):
         """splatter.py:467-511."""
         if idx is None:
             to = lambda a: (a if torch.is_tensor(a) else torch.from_numpy(np.asarray(a))).to(torch.float32).to(self.device)  # noqa: E731
+            host = lambda a: (a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)).astype(np.float32)  # noqa: E731
             self.current_w2c_rot, self.current_w2c_tran = to(extrinsics["rot"]), to(extrinsics["tran"])
+            rot_h, tran_h = host(extrinsics["rot"]).reshape(3, 3), host(extrinsics["tran"]).reshape(3)
             self.current_w2c_quat, self.ground_truth = None, None
             width, height = math.ceil(intrinsics["width"]), math.ceil(intrinsics["height"])
             fx, fy = float(intrinsics["focal_x"]), float(intrinsics["focal_y"])
@@ -153,15 +159,15 @@ class Splatter(nn.Module):
         else:
             self.current_w2c_quat, self.current_w2c_tran = self.w2c_quats[idx], self.w2c_trans[idx]
             self.current_w2c_rot = self.w2c_rots[idx]
+            rot_h, tran_h = self._host_poses[idx]
             self.ground_truth = self.imgs[idx].to(torch.float16) / 255.
             cam = self.cameras[self.cam_ids[idx]]
             self.current_camera = cam
             fx, fy = cam.params[0] / self.render_downsample, cam.params[1] / self.render_downsample
             width, height = int(self.ground_truth.shape[1]), int(self.ground_truth.shape[0])
         self.tile_info = TileGrid(width, height, fx, fy)
-        self._camera = Camera(width, height, float(fx), float(fy),
-                              self.current_w2c_rot.detach().cpu().numpy().reshape(3, 3).astype(np.float32),
-                              self.current_w2c_tran.detach().cpu().numpy().reshape(3).astype(np.float32), near=self.near)
+        # host copies of the pose (kept since parse_imgs): no device read-back, hence no synchronisation, per frame
+        self._camera = Camera(width, height, float(fx), float(fy), rot_h, tran_h, near=self.near)
 
     # ------------------------------------------------------------------ the frame (splatter.py:513-655)
     @property
@@ -182,4 +188,10 @@ class Splatter(nn.Module):
     def forward(self, camera_id=None, extrinsics=None, intrinsics=None):
         self.set_camera(camera_id, extrinsics, intrinsics)
         g = self.gaussian_3ds
+        key = (camera_id, int(g.pos.shape[0]))
+        if camera_id is None or key not in self._views_checked:
+            # first frame of this view on this Gaussian set: capacity checked synchronously (and the frame redone in
+            # a larger workspace if needed); later frames of the view use the asynchronous counters
+            self._views_checked.add(key)
+            self._renderer._checked_once = False
         return self._renderer.render(g.pos, g.quat, g.scale, g.opa, g.rgb, self._camera)

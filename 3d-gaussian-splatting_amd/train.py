@@ -14,9 +14,10 @@ New: under ``torchrun --nproc-per-node N`` the same script trains view-parallel 
 all-reduce of the gradients, rank-consistent densification).
 
 Not provided: ``--gui`` (the viser viewer; its per-frame hook ``Trainer.test(None, extrinsics, intrinsics)`` is),
-``--tile_culling_method dist`` on the fused path (use the drop-in ``gaussian`` / ``renderer`` modules with the
-reference's own splatter.py for that one), ``--jacobian_track`` / ``--adaptive_lr`` / ``--debug`` (accepted, ignored:
-they select debugging code paths of the reference).
+``--jacobian_track`` / ``--adaptive_lr`` / ``--debug`` (accepted, ignored: they select debugging code paths of the
+reference).  Deliberate deviation: with ``--render_downsample_start != --render_downsample`` the focal lengths of
+the start resolution are those of ``images_<start>`` and a real switch happens at iteration 400; the reference divides
+the focal lengths by ``render_downsample`` from step 0 (its switch at 400 is then a no-op on the intrinsics).
 """
 from __future__ import annotations
 
@@ -148,9 +149,6 @@ def main(argv=None) -> dict:
     if opt.gui:
         raise SystemExit("--gui: the viser viewer is not part of this package; drive Trainer.test(None, extrinsics, "
                          "intrinsics) from your viewer instead (see INTEGRATION.md)")
-    if opt.tile_culling_method == "dist":
-        raise SystemExit("--tile_culling_method dist: only on the reference-API modules (gaussian.calc_tile_list "
-                         "method 0); the fused frame path implements prob2 (the default) and prob")
     if not torch.cuda.is_available():
         raise SystemExit("train.py needs a HIP device (there is no CPU fallback)")
     np.random.seed(opt.seed)  # train.py:365: the view order is drawn from numpy's global generator
@@ -180,13 +178,22 @@ def main(argv=None) -> dict:
                       scale_activation=opt.scale_activation, densify=True,
                       generator=torch.Generator(dev).manual_seed(opt.seed))
     trainer.renderer.thresh = float(opt.tile_culling_prob_thresh)
-    trainer.renderer.tile_culling_method = {"prob2": 2, "prob": 1}[opt.tile_culling_method]
+    from gs_frame import TILE_CULLING
+
+    trainer.renderer.tile_culling_method = TILE_CULLING[opt.tile_culling_method]
+    trainer.renderer.tile_culling_dist_thresh = float(opt.tile_culling_dist_thresh)
     n_cameras = len(scene.cameras)
     test_split = np.arange(0, n_cameras, 8)  # train.py:69-71
     train_split = np.array(sorted(set(range(n_cameras)) - set(test_split.tolist())))
     os.makedirs(opt.exp, exist_ok=True)
     if opt.test:
-        return {"test": evaluate(trainer, test_split, os.path.join(opt.exp, "test_imgs"), "test")} if rank == 0 else {}
+        out = {"test": evaluate(trainer, test_split, os.path.join(opt.exp, "test_imgs"), "test")} if rank == 0 else {}
+        if world > 1 or "RANK" in os.environ:  # every rank leaves together, the process group is torn down
+            import torch.distributed as dist
+
+            dist.barrier()
+            dist.destroy_process_group()
+        return out
     if len(train_split) == 0:
         raise SystemExit("the dataset has a single image: nothing left to train on after the every-8th test split")
 

@@ -88,6 +88,7 @@ int main(int argc, char **argv) {
     fr.thresh = 0.05f;
     fr.max_pairs = 8 * N + 4096;
     fr.sort_mode = 2;
+    fr.tile_culling_method = 2;  // "prob2", train.py's default (0 = "dist", 1 = "prob": splatter.py:571)
     fr.training = 0;
     fr.workspace_bytes = gs_frame_workspace_bytes(N, fr.max_pairs, W, H, 3, 0);
     HIP_OK(hipMalloc(&fr.workspace, fr.workspace_bytes));

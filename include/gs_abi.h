@@ -34,7 +34,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define GS_ABI_VERSION 2
+#define GS_ABI_VERSION 3
 
 #define GS_E_INVALID (-1)   /* bad argument (null pointer, negative size, bad enum)   */
 #define GS_E_UNSUPPORTED (-2) /* valid in the reference but not implemented here (none at present) */
@@ -144,6 +144,10 @@ int gs_sort_pairs_bits(uint64_t *keys0, uint32_t *vals0, uint64_t *keys1, uint32
                        const uint32_t *d_count, int64_t capacity, int begin_bit, int end_bit,
                        void *tmp, size_t tmp_bytes, int *sorted_in_buffer1, gs_stream_t stream);
 
+#define GS_FRAME_EMIT_SORTED_KEYS 1 /* sort_mode 2: also write the sorted (tile << 32 | depth bits) keys that
+                                       gs_frame_debug_views returns (modes 0 / 1 always have them); the raster
+                                       kernels only read the sorted ids, so the default path skips 8 bytes per pair */
+
 /* Frame descriptor.  All scalars are per-camera constants computed on the host exactly as
  * splatter.py does (Tiles, RayInfo, frustum guard band); rot/tran are passed by value. */
 typedef struct gs_frame {
@@ -183,32 +187,46 @@ typedef struct gs_frame {
                                      larger grids take mode 1), then the same per-tile LDS sort.  On
                                      capacity overflow the frame is left empty (modes 0/1 keep the first
                                      max_pairs pairs); all modes report the true count in the stats. */
-    int32_t tile_culling_method; /* which tiles a Gaussian is listed in (splatter.py:571-578, --tile_culling_method):
-                                 0 or 2 = "prob2", the trainer's default (gaussian.cu:197-250: tile rectangle from
-                                     the 2-D covariance's bounding box by index arithmetic);
+    int32_t tile_culling_method; /* which tiles a Gaussian is listed in (splatter.py:571-578, --tile_culling_method;
+                                 the reference's own numbering, `_method_config` of splatter.py:571):
+                                 2 = "prob2", the trainer's default (gaussian.cu:197-250: tile rectangle from the 2-D
+                                     covariance's bounding box by index arithmetic);
                                  1 = "prob" (gaussian.cu:138-195: the same bounding box compared with the tiles'
-                                     edges, Tiles.create_tiles of splatter.py:275-293 -- also a rectangle).
-                                 "dist" (reference method 0, a disc of tile centres around the Gaussian whatever
-                                 its size) exists on gs_calc_tile_list only. */
+                                     edges, Tiles.create_tiles of splatter.py:275-293 -- also a rectangle);
+                                 0 = "dist" (gaussian.cu:101-136: every tile whose CENTRE lies closer than
+                                     sqrt(thresh) to the Gaussian's centre, whatever its size).  `thresh` is then
+                                     the squared distance (tile_length_x / tile_culling_dist_thresh)^2 of
+                                     splatter.py:577; sort_mode 2 only (<= 32768 tiles).  The gradient rows are
+                                     laid out over the bounding square of the disc, so max_pairs must cover the
+                                     sum of those squares (reported as overflow otherwise). */
+    /* ABI 3 */
+    struct gs_frame_async *async; /* NULL, or a handle from gs_frame_async_create: training forwards then run the
+                                 backward's preparation underneath the caller's loss (see gs_frame_forward) */
+    int32_t flags;            /* GS_FRAME_* bits */
 } gs_frame;
 
 /* Bytes of workspace needed for N Gaussians, `max_pairs` pairs, a width x height image. */
 size_t gs_frame_workspace_bytes(int64_t N, int64_t max_pairs, int32_t width, int32_t height,
                                 int32_t color_dim, int32_t training);
 
-/* Forward frame.  Launches everything on `stream`, never synchronises.
- * With f->training the zero-fill of the per-pair gradient rows and the backward's bucket list are additionally issued
- * on a library-owned side stream that waits for the frame's last kernel, so that they run underneath whatever the
- * caller enqueues between forward and backward (the loss); gs_frame_backward -- from any host thread -- and the next
- * gs_frame_forward on the same workspace wait for that stream's event.  Not done while `stream` is being captured
- * into a graph (the backward then prepares inline). */
+/* Forward frame.  Launches everything on `stream`, never synchronises, and keeps no state of its own.
+ * With f->training AND f->async the zero-fill of the per-pair gradient rows and the backward's bucket list are
+ * issued on the handle's side stream, which waits for the frame's last kernel, so that they run underneath whatever
+ * the caller enqueues between forward and backward (the loss); gs_frame_backward -- from any host thread -- and the
+ * next gs_frame_forward with the same handle wait for that stream's event.  Without a handle (or while `stream` is
+ * being captured into a graph) the backward prepares inline. */
 int gs_frame_forward(const gs_frame *f, gs_stream_t stream);
 
-/* Call before FREEING (or re-purposing) a workspace that was used by a training forward: work of the library's side
- * stream may still be writing into it if no gs_frame_backward / gs_frame_forward followed that frame.  Makes `stream`
- * wait for it and drops the library's state for this workspace pointer (the value passed as gs_frame.workspace).
- * A no-op for workspaces the library has no state for. */
-int gs_frame_release_workspace(void *workspace, gs_stream_t stream);
+/* The opt-in side stream: a caller-owned handle (one per workspace in use) holding a non-blocking stream and two
+ * events on the current device.  The library keeps nothing else between calls.
+ *   gs_frame_async_wait    : make `stream` wait for side-stream work that may still be writing into the workspace of
+ *                            the handle's last training forward -- call it before freeing or re-purposing that
+ *                            workspace if no gs_frame_backward / gs_frame_forward followed the frame;
+ *   gs_frame_async_destroy : releases the handle (work already queued still completes). */
+typedef struct gs_frame_async gs_frame_async;
+int gs_frame_async_create(gs_frame_async **out);
+int gs_frame_async_wait(gs_frame_async *a, gs_stream_t stream);
+int gs_frame_async_destroy(gs_frame_async *a);
 
 /* Same work as gs_frame_forward, but brackets every stage with hipEvents on `stream` and
  * returns the stage durations in milliseconds (synchronises; for bench.py / profiling only):
@@ -227,8 +245,9 @@ int gs_frame_backward_profile(const gs_frame *f, const float *grad_image, float 
 int gs_frame_stats_async(const gs_frame *f, int64_t *stats_host, gs_stream_t stream);
 
 /* Read-only views into the workspace of the last forward (for parity tests): sorted keys
- * (u64 [M]), sorted Gaussian ids (u32 [M]), per-tile ranges (int32 [T,2]), projected
- * pos/cov/mask-equivalents.  Any out pointer may be NULL. */
+ * (u64 [M]; NULL for a sort_mode-2 frame rendered without GS_FRAME_EMIT_SORTED_KEYS -- they are
+ * (tile << 32 | depth bits of rec_geom[id].z) of the sorted ids), sorted Gaussian ids (u32 [M]), per-tile
+ * ranges (int32 [T,2]), projected pos/cov/mask-equivalents.  Any out pointer may be NULL. */
 int gs_frame_debug_views(const gs_frame *f, const uint64_t **sorted_keys,
                          const uint32_t **sorted_ids, const int32_t **tile_ranges,
                          const float **rec_geom, const float **rec_cov, const float **rec_color,

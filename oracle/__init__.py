@@ -27,12 +27,19 @@ _u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
 
 
 def build(force: bool = False) -> str:
-    """gcc -O2 -ffp-contract=off: IEEE fp32 in source order (see gs_oracle.c header)."""
+    """gcc -O2 -ffp-contract=off: IEEE fp32 in source order (see gs_oracle.c header).  -fopenmp: the pixel loop of
+    K7 and the tile loop of K8 are independent work items; results do not depend on the thread count."""
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(_SRC):
         subprocess.check_call(
-            ["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", _SO, _SRC, "-lm"]
+            ["gcc", "-O2", "-ffp-contract=off", "-fopenmp", "-fPIC", "-shared", "-o", _SO, _SRC, "-lm"]
         )
     return _SO
+
+
+def num_threads() -> int:
+    """Threads the OpenMP loops of the oracle will use (OMP_NUM_THREADS or every core)."""
+    env = os.environ.get("OMP_NUM_THREADS", "")
+    return int(env) if env.isdigit() and int(env) > 0 else (os.cpu_count() or 1)
 
 
 _lib = None
@@ -210,14 +217,25 @@ def draw(pos, rgb, opa, cov, accum, padded_h, padded_w, focal_x, focal_y, weight
 
 def draw_backward(pos, rgb, opa, cov, accum, output, grad_output, focal_x, focal_y,
                   weight_normalize=False, sigmoid=False, use_sh=False, fast=False, rays_o=None,
-                  lefttop=None, vdx=None, vdy=None):
-    """K8 (gaussian.cu:440-803), intended semantics (see gs_oracle.c)."""
+                  lefttop=None, vdx=None, vdy=None, with_scale=False, scale_w=0.05):
+    """K8 (gaussian.cu:440-803), intended semantics (see gs_oracle.c).  ``with_scale``: also return the
+    conditioning scale of every output element (sum over pixels of |term| + scale_w x the term with every internal
+    difference replaced by the magnitudes of its operands; gs_oracle.c), laid out like the four gradients."""
     pos, rgb, opa, cov = _f(pos), _f(rgb), _f(opa), _f(cov)
     output, grad_output = _f(output), _f(grad_output)
     accum = np.ascontiguousarray(accum, np.int32)
     h, w = output.shape[0], output.shape[1]
     gp, gr, go, gc = (np.zeros_like(pos), np.zeros_like(rgb), np.zeros_like(opa), np.zeros_like(cov))
     rv = [_f(v) if v is not None else _Z3 for v in (rays_o, lefttop, vdx, vdy)]
+    if with_scale:
+        cp, cr, co, cc = (np.zeros_like(pos), np.zeros_like(rgb), np.zeros_like(opa), np.zeros_like(cov))
+        lib().gso_draw_backward_scaled(_vp(pos), _vp(rgb), _vp(opa), _vp(cov), _vp(accum), _vp(output),
+                                       _vp(grad_output), _vp(gp), _vp(gr), _vp(go), _vp(gc), C.c_int32(h),
+                                       C.c_int32(w), C.c_float(focal_x), C.c_float(focal_y), C.c_int(bool(sigmoid)),
+                                       C.c_int(bool(fast)), _vp(rv[0]), _vp(rv[1]), _vp(rv[2]), _vp(rv[3]),
+                                       C.c_int(_sh_code(use_sh, rgb)), _vp(cp), _vp(cr), _vp(co), _vp(cc),
+                                       C.c_double(scale_w))
+        return (gp, gr, go, gc), (cp, cr, co, cc)
     lib().gso_draw_backward(_vp(pos), _vp(rgb), _vp(opa), _vp(cov), _vp(accum), _vp(output),
                             _vp(grad_output), _vp(gp), _vp(gr), _vp(go), _vp(gc), C.c_int32(h),
                             C.c_int32(w), C.c_float(focal_x), C.c_float(focal_y),

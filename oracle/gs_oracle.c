@@ -24,6 +24,10 @@
  *   - partial-mask warp shuffles (gaussian.cu:675-687),
  *   - racy check-then-atomicAdd cap (gaussian.cu:244-247): the oracle applies the cap
  *     serially in Gaussian-index order when `maxp` > 0.
+ *
+ * Threading: the per-pixel loop of K7 and the per-tile loop of K8 are independent work items and
+ * carry `#pragma omp parallel for` (build with -fopenmp).  Nothing is summed across threads, so
+ * the results are bit-identical for any thread count (OMP_NUM_THREADS=1 is the scalar port).
  */
 #include <math.h>
 #include <stdint.h>
@@ -516,6 +520,7 @@ GSO_API void gso_draw(const float *pos, const float *rgb, const float *opa, cons
                       const float *vdy, int use_sh) {
     const uint32_t ntx = (uint32_t)(w + 15) / 16;
     const int nb = sh_nb(use_sh), D = use_sh ? 3 * nb : 3;
+#pragma omp parallel for schedule(dynamic, 4)
     for (uint32_t id_y = 0; id_y < (uint32_t)h; ++id_y)
         for (uint32_t id_x = 0; id_x < (uint32_t)w; ++id_x) {
             uint32_t id_tile = id_x / 16 + (id_y / 16) * ntx; /* :832 */
@@ -570,25 +575,34 @@ GSO_API void gso_draw(const float *pos, const float *rgb, const float *opa, cons
  * Gaussian.  Per-pixel terms are evaluated in the reference's fp32 expression order; the
  * 256-term sums are accumulated in double and rounded once (the reference's shuffle/atomic
  * order is not defined).  grad_pos[:,2] is never written (stays the caller's zero).
+ *
+ * With non-NULL `cs_*` pointers the same pass also returns, per row element, its CONDITIONING
+ * SCALE: sum over the tile's pixels of |term| + cs_w x (the term with every internal
+ * difference replaced by the sum of its operands' magnitudes).  Two fp32 evaluations of the same
+ * formulas in different orders (and with 1-ulp exp / rcp) agree to (a modest number of ulp) x
+ * that scale, however small the signed sum turns out; the element-wise gradient tolerance of
+ * the parity tests is stated in these units (tests/gs_testutil.py).
  * ------------------------------------------------------------------------------------- */
-GSO_API void gso_draw_backward(const float *pos, const float *rgb, const float *opa,
+static void draw_backward_impl(const float *pos, const float *rgb, const float *opa,
                                const float *cov, const int32_t *accum_idx, const float *output,
                                const float *grad_output, float *grad_pos, float *grad_rgb,
                                float *grad_opa, float *grad_cov, int32_t h, int32_t w,
-                               float focal_x, float focal_y, int weight_normalize, int sigmoid,
-                               int fast, const float *rays_o, const float *lefttop,
-                               const float *vdx, const float *vdy, int use_sh) {
-    (void)weight_normalize; /* the reference backward ignores it too */
+                               float focal_x, float focal_y, int sigmoid, int fast,
+                               const float *rays_o, const float *lefttop, const float *vdx,
+                               const float *vdy, int use_sh, float *cs_pos, float *cs_rgb,
+                               float *cs_opa, float *cs_cov, double cs_w) {
     const uint32_t ntx = (uint32_t)(w + 15) / 16, nty = (uint32_t)(h + 15) / 16;
     const int nb = sh_nb(use_sh), D = use_sh ? 3 * nb : 3;
     const int NV = 2 + D + 1 + 4;
-    for (uint32_t ty = 0; ty < nty; ++ty)
-        for (uint32_t tx = 0; tx < ntx; ++tx) {
-            uint32_t id_tile = tx + ty * ntx;
+    const int want_cs = cs_pos != NULL;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (uint32_t id_tile = 0; id_tile < ntx * nty; ++id_tile) {
+            const uint32_t tx = id_tile % ntx, ty = id_tile / ntx;
             uint32_t start = (uint32_t)accum_idx[id_tile], end = (uint32_t)accum_idx[id_tile + 1];
             uint32_t len = end - start;
             if (len == 0) continue;
             double *acc = (double *)calloc((size_t)len * NV, sizeof(double));
+            double *cs = want_cs ? (double *)calloc((size_t)len * NV, sizeof(double)) : NULL;
             for (uint32_t ly = 0; ly < 16; ++ly)
                 for (uint32_t lx = 0; lx < 16; ++lx) {
                     uint32_t id_x = tx * 16 + lx, id_y = ty * 16 + ly;
@@ -666,8 +680,11 @@ GSO_API void gso_draw_backward(const float *pos, const float *rgb, const float *
                         for (int m = 0; m < 3; ++m) dacc += go[m] * (co[m] - color[m]);
                         dacc = (float)(dacc / (1 - alpha + 1e-7));
                         d_alpha -= dacc;
-                        if (sigmoid)
+                        float dsq = 1.0f;
+                        if (sigmoid) {
+                            dsq = (float)(alpha + 1 - 0.5 * (alpha + 1) * (alpha + 1));
                             d_alpha = (float)(d_alpha * (alpha + 1 - 0.5 * (alpha + 1) * (alpha + 1)));
+                        }
                         row[2 + D] += (double)(float)(d_alpha * prob); /* :729 */
                         float d_prob = d_alpha * opa[g];                /* :740 */
                         row[0] += (double)(float)(d_prob * dP_dx);
@@ -676,6 +693,50 @@ GSO_API void gso_draw_backward(const float *pos, const float *rgb, const float *
                         row[2 + D + 2] += (double)(float)(d_prob * dP_db);
                         row[2 + D + 3] += (double)(float)(d_prob * dP_dc);
                         row[2 + D + 4] += (double)(float)(d_prob * dP_dd);
+                        if (want_cs) {
+                            /* scale = |term| + cs_w x (the same term with every difference replaced by the sum of
+                             * the magnitudes of its operands): the first part carries the errors that are relative
+                             * to the term (exp, rcp, products, the running T), the second the cancellations inside it
+                             * -- exp's argument d x^2 - (b+c) x y + a y^2, g.(C_final - C_run), dPm Pn - dPn Pm,
+                             * 2 d x - b y - c y --, each worth a few ulp of its operands. */
+                            double *cr = cs + (size_t)i * NV;
+                            const double W = cs_w;
+                            const double PmAbs = fabs((double)_d * _x * _x) + fabs((double)(_b + _c) * _x * _y) +
+                                                 fabs((double)_a * _y * _y);
+                            const double pn = fabs((double)Pn);
+                            const double rel = 1.0 + W * PmAbs / pn; /* exponent rounding -> relative error of alpha */
+                            double gcabs = 0, dcabs = 0;
+                            for (int m = 0; m < 3; ++m) {
+                                gcabs += fabs((double)go[m] * cpc[m]);
+                                dcabs += fabs((double)go[m]) * (fabs((double)co[m]) + fabs((double)color[m]));
+                            }
+                            const double da1 = fabs((double)d_alpha);
+                            const double da2 = ((double)accum * gcabs + dcabs / fabs(1 - (double)alpha + 1e-7)) *
+                                               fabs((double)dsq);
+                            if (use_sh) {
+                                for (int ch = 0; ch < 3; ++ch) {
+                                    double Dk = fabs((double)go[ch] * weight * (cpc[ch] * (1 - cpc[ch]))) * rel;
+                                    for (int s = 0; s < nb; ++s) cr[2 + ch * nb + s] += Dk * fabs((double)SH[s]);
+                                }
+                            } else {
+                                for (int m = 0; m < 3; ++m) cr[2 + m] += fabs((double)go[m] * weight) * rel;
+                            }
+                            const double po = fabs((double)opa[g]), pq = fabs((double)prob) / pn;
+                            cr[2 + D] += (da1 * rel + W * da2) * fabs((double)prob);
+                            const double ex = fabs(2.0 * _d * _x) + fabs((double)_b * _y) + fabs((double)_c * _y);
+                            const double ey = fabs(2.0 * _a * _y) + fabs((double)_b * _x) + fabs((double)_c * _x);
+                            cr[0] += da1 * po * fabs((double)dP_dx) * rel + W * da2 * po * pq * ex;
+                            cr[1] += da1 * po * fabs((double)dP_dy) * rel + W * da2 * po * pq * ey;
+                            const double p1n = fabs((double)p0 * p1) / (pn * pn), p10 = fabs((double)p1);
+                            const double ea = p1n * (fabs((double)dPm_da) * pn + fabs((double)dPn_da) * PmAbs) + p10 * fabs((double)dP0_da);
+                            const double eb = p1n * (fabs((double)dPm_db) * pn + fabs((double)dPn_db) * PmAbs) + p10 * fabs((double)dP0_db);
+                            const double ec = p1n * (fabs((double)dPm_dc) * pn + fabs((double)dPn_dc) * PmAbs) + p10 * fabs((double)dP0_dc);
+                            const double ed = p1n * (fabs((double)dPm_dd) * pn + fabs((double)dPn_dd) * PmAbs) + p10 * fabs((double)dP0_dd);
+                            cr[2 + D + 1] += da1 * po * fabs((double)dP_da) * rel + W * da2 * po * ea;
+                            cr[2 + D + 2] += da1 * po * fabs((double)dP_db) * rel + W * da2 * po * eb;
+                            cr[2 + D + 3] += da1 * po * fabs((double)dP_dc) * rel + W * da2 * po * ec;
+                            cr[2 + D + 4] += da1 * po * fabs((double)dP_dd) * rel + W * da2 * po * ed;
+                        }
                         accum *= (1 - alpha); /* :774 */
                     }
                 }
@@ -687,9 +748,45 @@ GSO_API void gso_draw_backward(const float *pos, const float *rgb, const float *
                 for (int k = 0; k < D; ++k) grad_rgb[(size_t)g * D + k] = (float)row[2 + k];
                 grad_opa[g] = (float)row[2 + D];
                 for (int k = 0; k < 4; ++k) grad_cov[(size_t)g * 4 + k] = (float)row[2 + D + 1 + k];
+                if (want_cs) {
+                    const double *cr = cs + (size_t)i * NV;
+                    cs_pos[(size_t)g * 3 + 0] = (float)cr[0];
+                    cs_pos[(size_t)g * 3 + 1] = (float)cr[1];
+                    for (int k = 0; k < D; ++k) cs_rgb[(size_t)g * D + k] = (float)cr[2 + k];
+                    cs_opa[g] = (float)cr[2 + D];
+                    for (int k = 0; k < 4; ++k) cs_cov[(size_t)g * 4 + k] = (float)cr[2 + D + 1 + k];
+                }
             }
             free(acc);
-        }
+            free(cs);
+    }
+}
+
+GSO_API void gso_draw_backward(const float *pos, const float *rgb, const float *opa,
+                               const float *cov, const int32_t *accum_idx, const float *output,
+                               const float *grad_output, float *grad_pos, float *grad_rgb,
+                               float *grad_opa, float *grad_cov, int32_t h, int32_t w,
+                               float focal_x, float focal_y, int weight_normalize, int sigmoid,
+                               int fast, const float *rays_o, const float *lefttop,
+                               const float *vdx, const float *vdy, int use_sh) {
+    (void)weight_normalize; /* the reference backward ignores it too */
+    draw_backward_impl(pos, rgb, opa, cov, accum_idx, output, grad_output, grad_pos, grad_rgb, grad_opa, grad_cov,
+                       h, w, focal_x, focal_y, sigmoid, fast, rays_o, lefttop, vdx, vdy, use_sh, NULL, NULL, NULL,
+                       NULL, 0.0);
+}
+
+/* the same rows + the conditioning scale of every row element (see above); cs_* are laid out like grad_* */
+GSO_API void gso_draw_backward_scaled(const float *pos, const float *rgb, const float *opa,
+                                      const float *cov, const int32_t *accum_idx, const float *output,
+                                      const float *grad_output, float *grad_pos, float *grad_rgb,
+                                      float *grad_opa, float *grad_cov, int32_t h, int32_t w,
+                                      float focal_x, float focal_y, int sigmoid, int fast,
+                                      const float *rays_o, const float *lefttop, const float *vdx,
+                                      const float *vdy, int use_sh, float *cs_pos, float *cs_rgb,
+                                      float *cs_opa, float *cs_cov, double cs_w) {
+    draw_backward_impl(pos, rgb, opa, cov, accum_idx, output, grad_output, grad_pos, grad_rgb, grad_opa, grad_cov,
+                       h, w, focal_x, focal_y, sigmoid, fast, rays_o, lefttop, vdx, vdy, use_sh, cs_pos, cs_rgb,
+                       cs_opa, cs_cov, cs_w);
 }
 
 /* ---------------------------------------------------------------------------------------

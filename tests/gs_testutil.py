@@ -35,8 +35,10 @@ def frame_scalars(cam: Camera):
 class OracleFrame:
     """Oracle restatement of one forward frame on raw parameters, keeping every intermediate."""
 
-    def __init__(self, scene: Scene, cam: Camera, thresh=0.05, scale_activation="abs", tile_culling_method="prob2"):
+    def __init__(self, scene: Scene, cam: Camera, thresh=0.05, scale_activation="abs", tile_culling_method="prob2",
+                 dist_thresh=0.5):
         self.scene, self.cam = scene, cam
+        self.dist_thresh = dist_thresh
         self.scale_activation = scale_activation
         grid, hw, hh, rays = frame_scalars(cam)
         self.grid, self.rays = grid, rays
@@ -66,7 +68,7 @@ class OracleFrame:
         grid = self.grid
         vis = np.nonzero(self.mask)[0]
         top, bottom, left, right = grid.tile_edges()
-        th = (grid.tile_geo_length_x / 0.5) ** 2 if method == "dist" else thresh  # splatter.py:577, dist_thresh 0.5
+        th = (grid.tile_geo_length_x / self.dist_thresh) ** 2 if method == "dist" else thresh  # splatter.py:577
         cnt, lst = oracle.calc_tile_list(self.pos_i[vis], self.cov.reshape(-1, 4)[vis], len(vis), th,
                                          {"dist": 0, "prob": 1}[method], grid.tile_geo_length_x,
                                          grid.tile_geo_length_y, grid.n_tile_x, grid.n_tile_y, grid.leftmost,
@@ -79,8 +81,12 @@ class OracleFrame:
         accum = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
         return keys[order], ids[order].astype(np.int32), accum
 
-    def backward(self, grad_image):
-        """dL/d(image) -> dict of dL/d(raw parameter), the chain splatter.py's autograd runs."""
+    def backward(self, grad_image, with_scale=False, scale_w=0.05):
+        """dL/d(image) -> dict of dL/d(raw parameter), the chain splatter.py's autograd runs.
+
+        ``with_scale``: also return, per gradient element, its conditioning scale -- the oracle's per-row scale
+        (gs_oracle.c, draw_backward_impl) summed over the Gaussian's (tile, Gaussian) rows and pushed through the
+        magnitudes of the (linear) projection / activation backward.  ``grad_close`` states tolerances in it."""
         sc, cam, grid, rays = self.scene, self.cam, self.grid, self.rays
         n = sc.n
         top, left = grid.crop_offsets()
@@ -88,19 +94,22 @@ class OracleFrame:
         inside = ((self.padded >= 0) & (self.padded <= 1)).astype(np.float32)
         gpad[top:top + grid.height, left:left + grid.width] = grad_image
         gpad *= inside
-        gp, gr, go, gc = oracle.draw_backward(self.s_pos, self.s_rgb, self.s_opa, self.s_cov, self.accum, self.padded,
-                                              gpad, grid.focal_x, grid.focal_y, use_sh=sc.use_sh, fast=True,
-                                              rays_o=rays.rays_o, lefttop=rays.lefttop, vdx=rays.dx, vdy=rays.dy)
+        out = oracle.draw_backward(self.s_pos, self.s_rgb, self.s_opa, self.s_cov, self.accum, self.padded,
+                                   gpad, grid.focal_x, grid.focal_y, use_sh=sc.use_sh, fast=True,
+                                   rays_o=rays.rays_o, lefttop=rays.lefttop, vdx=rays.dx, vdy=rays.dy,
+                                   with_scale=with_scale, scale_w=scale_w)
+        (gp, gr, go, gc), cs = out if with_scale else (out, None)
         self.pair_grads = (gp, gr, go, gc)
         # index backward (index_put accumulate) in double
-        d_pos_i = np.zeros((n, 3), np.float64)
-        d_cov = np.zeros((n, 4), np.float64)
-        d_opa = np.zeros(n, np.float64)
-        d_col = np.zeros((n, sc.rgb.shape[1]), np.float64)
-        np.add.at(d_pos_i, self.ids, gp)
-        np.add.at(d_cov, self.ids, gc)
-        np.add.at(d_opa, self.ids, go)
-        np.add.at(d_col, self.ids, gr)
+        d_pos_i, d_cov, d_opa, d_col = (_sum_by_id(self.ids, a, n) for a in (gp, gc, go, gr))
+        grads = self._chain(d_pos_i, d_cov, d_opa, d_col)
+        if not with_scale:
+            return grads
+        s_pos_i, s_cov, s_opa, s_col = (_sum_by_id(self.ids, a, n) for a in (cs[0], cs[3], cs[2], cs[1]))
+        return grads, self._chain_scale(s_pos_i, s_cov, s_opa, s_col)
+
+    def _chain(self, d_pos_i, d_cov, d_opa, d_col):
+        sc, cam = self.scene, self.cam
         g_pos, g_qn, g_sn = oracle.global_culling_backward(sc.pos, self.qn, self.sn, cam.rot, cam.tran,
                                                            d_pos_i.astype(np.float32), d_cov.astype(np.float32),
                                                            self.mask)
@@ -121,6 +130,93 @@ class OracleFrame:
             g_c = d_col * c * (1 - c)
         return {"pos": g_pos.astype(np.float32), "quat": g_q.astype(np.float32), "scale": g_s.astype(np.float32),
                 "opa": g_o.astype(np.float32), "rgb": g_c.astype(np.float32)}
+
+    def _chain_scale(self, s_pos_i, s_cov, s_opa, s_col):
+        """|Jacobian| x scale: K2 is linear in (dL/dpos_i, dL/dcov) for a fixed Gaussian, so six runs on unit
+        inputs give its Jacobian for every Gaussian at once."""
+        sc, cam = self.scene, self.cam
+        n = sc.n
+        S_pos, S_qn, S_sn = np.zeros((n, 3)), np.zeros((n, 4)), np.zeros((n, 3))
+        for k in range(6):
+            e_pos, e_cov = np.zeros((n, 3), np.float32), np.zeros((n, 4), np.float32)
+            w = s_pos_i[:, k] if k < 2 else s_cov[:, k - 2]
+            (e_pos if k < 2 else e_cov)[:, k if k < 2 else k - 2] = 1.0
+            jp, jq, js = oracle.global_culling_backward(sc.pos, self.qn, self.sn, cam.rot, cam.tran, e_pos, e_cov,
+                                                        self.mask)
+            S_pos += np.abs(jp) * w[:, None]
+            S_qn += np.abs(jq) * w[:, None]
+            S_sn += np.abs(js) * w[:, None]
+        q = sc.quat.astype(np.float64)
+        nr = np.linalg.norm(q, axis=1, keepdims=True)
+        qh = np.abs(q / nr)
+        S_q = (S_qn + qh * np.sum(qh * S_qn, axis=1, keepdims=True)) / nr
+        S_s = S_sn if self.scale_activation == "abs" else S_sn * np.exp(np.clip(sc.scale, -1, 1))
+        o = self.opa_act.astype(np.float64)
+        S_o = s_opa * o * (1 - o)
+        if sc.use_sh:
+            S_c = s_col
+        else:
+            c = self.col_act.astype(np.float64)
+            S_c = s_col * c * (1 - c)
+        return {"pos": S_pos, "quat": S_q, "scale": S_s, "opa": S_o, "rgb": S_c}
+
+
+def _sum_by_id(ids, rows, n):
+    """index_put_(accumulate=True) (splatter.py:604-613 backward) in float64: rows[j] added to out[ids[j]]."""
+    rows = np.asarray(rows, np.float64)
+    flat = rows.reshape(len(ids), -1)
+    out = np.zeros((n, flat.shape[1]), np.float64)
+    if len(ids):
+        order = np.argsort(ids, kind="stable")
+        sid = np.asarray(ids)[order]
+        first = np.flatnonzero(np.r_[True, sid[1:] != sid[:-1]])
+        out[sid[first]] = np.add.reduceat(flat[order], first, axis=0)
+    return out.reshape((n,) + rows.shape[1:])
+
+
+# Element-wise gradient tolerance: |got - ref| <= GRAD_RTOL |ref| + GRAD_KAPPA scale, `scale` being the element's own
+# conditioning scale from OracleFrame.backward(with_scale=True): the sum over its pixels and (tile, Gaussian) rows of
+# |term| + 0.05 x (the term with every internal difference replaced by the magnitudes of its operands), pushed
+# through |Jacobian| of the projection / activation backward.  A gradient element is a signed sum of thousands of
+# fp32 terms, several of them differences of nearly equal numbers (T g.c against g.(C_final - C_run)/(1 - alpha) for
+# a Gaussian deep in a tile's list): two correct fp32 evaluations in different orders agree to a number of ulp of
+# that scale, however small the sum comes out -- so the tolerance is per element and NOT a fraction of the tensor's
+# largest entry.  GRAD_KAPPA = 1e-5 is ~170 ulp of the plain term sum and ~8 ulp of the operand magnitudes; what
+# differs between the kernels and the oracle is the summation order, v_exp_f32 / v_rcp_f32 against expf / IEEE
+# division, the conic hoisted out of the pixel loop, and the final image each side subtracts its running colour from
+# (they agree to ~1e-6).  tools/grad_parity_probe.py prints the measured distribution of err / scale.
+GRAD_RTOL = 1e-4
+GRAD_KAPPA = 1e-5
+GRAD_L2 = 2e-5  # ||got - ref||_2 / ||ref||_2 per tensor
+
+
+def grad_close(got, ref, scale, rtol=GRAD_RTOL, kappa=GRAD_KAPPA):
+    """-> (ok, worst ratio err / tol, index of the worst element, fraction of elements within rtol |ref| alone)."""
+    got, ref, scale = (np.asarray(a, np.float64) for a in (got, ref, scale))
+    err = np.abs(got - ref)
+    tol = rtol * np.abs(ref) + kappa * scale
+    bad = err > tol
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ratio = np.where(err > 0, err / tol, 0.0)
+    worst = int(np.argmax(ratio)) if ratio.size else 0
+    pure = float(np.mean(err <= rtol * np.abs(ref))) if err.size else 1.0
+    return (not bool(bad.any()) and bool(np.isfinite(got).all())), float(ratio.flat[worst]) if ratio.size else 0.0, \
+        np.unravel_index(worst, ratio.shape) if ratio.size else (), pure
+
+
+def assert_grads_close(grads, ref, scale, what="", rtol=GRAD_RTOL, kappa=GRAD_KAPPA, l2=GRAD_L2):
+    """grads: five arrays (pos, quat, scale, opa, rgb) -> element-wise check of each against the oracle + a relative
+    L2 bound per tensor.  Returns {name: (worst err / tol, fraction of elements inside rtol |ref| alone, rel. L2)}."""
+    report = {}
+    for g, name in zip(grads, ("pos", "quat", "scale", "opa", "rgb")):
+        g = np.asarray(g)
+        ok, worst, where, pure = grad_close(g, ref[name], scale[name], rtol, kappa)
+        rl2 = float(np.linalg.norm(g.astype(np.float64) - ref[name]) / (np.linalg.norm(ref[name].astype(np.float64)) + 1e-300))
+        report[name] = (round(worst, 3), round(pure, 5), rl2)
+        assert ok, (what, name, "worst err/tol", worst, "at", where, "got", float(g[where]), "ref",
+                    float(ref[name][where]), "scale", float(scale[name][where]))
+        assert rl2 <= l2, (what, name, "relative L2 error", rl2)
+    return report
 
 
 def rel_err(a, b):

@@ -78,6 +78,6 @@ def test_train_cli_under_a_torchrun_environment(capture, tmp_path, monkeypatch):
 def test_train_cli_rejects_what_it_does_not_provide(capture, tmp_path):
     import train as cli
 
-    for bad in (["--gui", "1", "--test", "1"], ["--tile_culling_method", "dist"]):
+    for bad in (["--gui", "1", "--test", "1"],):
         with pytest.raises(SystemExit):
             cli.main(["--data", capture, "--exp", str(tmp_path / "x")] + bad)

@@ -3,8 +3,13 @@ oracle's restatement of Splatter.forward + autograd (tests/gs_testutil.OracleFra
 
  * sorted (tile, depth_bits, gaussian_id) list and tile ranges: BIT-EXACT;
  * projected records: bit-exact (same fp32 expression order on both sides);
- * image: abs 5e-5;  parameter gradients: 3e-4 of the tensor's max magnitude
-   (fp32 atomics reorder the cross-tile sums).
+ * image: abs 5e-5;
+ * parameter gradients: ELEMENT-WISE |got - ref| <= 1e-4 |ref| + 1e-5 scale, `scale` being the element's own
+   conditioning scale (the sum of the magnitudes of the terms it is made of, computed by the oracle next to the
+   gradient: gs_testutil.grad_close), plus a relative L2 bound per tensor -- on small scenes and at the BASELINE
+   sizes (cfg2, cfg3, cfg4 with SH).  The gradient path has no atomics: the sums run in a fixed order and the
+   result is bitwise repeatable; what differs from the oracle is that order, v_exp_f32 / v_rcp_f32, and the
+   conic hoisted out of the pixel loop.
 """
 import numpy as np
 import pytest
@@ -12,12 +17,11 @@ import torch
 
 from gs_frame import FrameRenderer
 from gs_scene import make_camera, make_scene
-from gs_testutil import OracleFrame, rel_err, to_torch
+from gs_testutil import OracleFrame, assert_grads_close, to_torch
 
 pytestmark = pytest.mark.gpu
 
 IMG_ATOL = 5e-5
-GRAD_RTOL = 3e-4
 
 
 def case(n, W, H, seed=7, use_sh=False, yaw=2.0, sh_degree=2):
@@ -106,11 +110,41 @@ def test_frame_tile_culling_method_prob(gpu):
     assert np.abs(img.detach().cpu().numpy() - of.image).max() < IMG_ATOL
     gimg = np.random.default_rng(6).normal(size=of.image.shape).astype(np.float32)
     img.backward(torch.from_numpy(gimg).to(gpu))
-    ref = of.backward(gimg)
-    for t, name in zip(params, ("pos", "quat", "scale", "opa", "rgb")):
-        assert rel_err(t.grad.cpu().numpy(), ref[name]) < GRAD_RTOL, name
-    with pytest.raises(NotImplementedError):
-        FrameRenderer(gpu, tile_culling_method="dist")
+    ref, scale = of.backward(gimg, with_scale=True)
+    assert_grads_close([t.grad.cpu().numpy() for t in params], ref, scale, "prob")
+
+
+@pytest.mark.parametrize("dist_thresh,W,H", [(0.5, 250, 186), (0.3, 333, 201), (1.0, 96, 80)])
+def test_frame_tile_culling_method_dist(gpu, dist_thresh, W, H):
+    """--tile_culling_method dist (gaussian.cu:101-136; Splatter.__init__'s own default): every tile whose CENTRE is
+    closer than tile_length_x / dist_thresh to the Gaussian's centre, whatever its size -- a disc of tiles, not a
+    rectangle.  The fused path walks the disc's bounding square with the reference's per-tile fp32 test: the pair
+    list equals the oracle's calc_tile_list method 0 (itself bit-identical to the reference kernel) bit for bit,
+    image and gradients follow (the gradient rows are laid out over the square, unlisted tiles hold zeros)."""
+    scene, cam = case(12_000, W, H, seed=29)
+    of = OracleFrame(scene, cam, tile_culling_method="dist", dist_thresh=dist_thresh)
+    params = to_torch(scene, gpu, requires_grad=True)
+    r = FrameRenderer(gpu, max_pairs=6 * len(of.ids) + 4096, training=True, auto_grow=False,
+                      tile_culling_method="dist", tile_culling_dist_thresh=dist_thresh)
+    img = r.render(*params, cam)
+    v = r.debug_views()
+    st = r.stats()
+    assert st.overflow == 0 and st.pairs == len(of.ids) > 0
+    assert np.array_equal(v["sorted_keys"].cpu().numpy().view(np.uint64), of.keys)
+    assert np.array_equal(v["sorted_ids"].cpu().numpy(), of.ids)
+    assert np.abs(img.detach().cpu().numpy() - of.image).max() < IMG_ATOL
+    gimg = np.random.default_rng(6).normal(size=of.image.shape).astype(np.float32)
+    img.backward(torch.from_numpy(gimg).to(gpu))
+    ref, scale = of.backward(gimg, with_scale=True)
+    assert_grads_close([t.grad.cpu().numpy() for t in params], ref, scale, "dist")
+    # the rows of a "dist" frame cover the bounding squares: a capacity that holds the pairs but not the squares is
+    # reported as overflow instead of silently dropping gradient rows
+    r2 = FrameRenderer(gpu, max_pairs=len(of.ids) + 16, training=True, auto_grow=False, tile_culling_method="dist",
+                       tile_culling_dist_thresh=dist_thresh)
+    r2.forward(*to_torch(scene, gpu), cam)
+    assert r2.stats().overflow > len(of.ids)
+    with pytest.raises(ValueError):
+        FrameRenderer(gpu, tile_culling_method="nearest")
 
 
 @pytest.mark.parametrize("sh_degree", [2, 3])
@@ -164,15 +198,12 @@ def test_frame_backward_parity(gpu, use_sh):
     of, r, _ = check_forward(gpu, scene, cam, training=True)
     rng = np.random.default_rng(4)
     gimg = rng.normal(size=of.image.shape).astype(np.float32)
-    ref = of.backward(gimg)
+    ref, scale = of.backward(gimg, with_scale=True)
     params = to_torch(scene, gpu, requires_grad=True)
     r2 = FrameRenderer(gpu, max_pairs=len(of.ids) + 5, training=True, auto_grow=False)
     img = r2.render(*params, cam)
     img.backward(torch.from_numpy(gimg).to(gpu))
-    for t, name in zip(params, ("pos", "quat", "scale", "opa", "rgb")):
-        g = t.grad.cpu().numpy()
-        assert np.isfinite(g).all(), name
-        assert rel_err(g, ref[name]) < GRAD_RTOL, (name, rel_err(g, ref[name]))
+    assert_grads_close([t.grad.cpu().numpy() for t in params], ref, scale, f"sh={use_sh}")
     # culled Gaussians get exactly zero
     culled = of.mask == 0
     assert float(np.abs(params[0].grad.cpu().numpy()[culled]).max()) == 0.0
@@ -194,16 +225,16 @@ def test_frame_backward_screen_filling_gaussians(gpu):
         counts = np.bincount(of.ids, minlength=scene.n)
         assert (counts[big] > 256).all() and counts.max() <= 22 * 17
         gimg = np.random.default_rng(7).normal(size=of.image.shape).astype(np.float32)
-        ref = of.backward(gimg)
+        ref, scale = of.backward(gimg, with_scale=True)
         params = to_torch(scene, gpu, requires_grad=True)
         r = FrameRenderer(gpu, max_pairs=len(of.ids) + 9, training=True, auto_grow=False)
         img = r.render(*params, cam)
         assert np.abs(img.detach().cpu().numpy() - of.image).max() < IMG_ATOL
         img.backward(torch.from_numpy(gimg).to(gpu))
-        for t, name in zip(params, ("pos", "quat", "scale", "opa", "rgb")):
-            g = t.grad.cpu().numpy()
-            assert rel_err(g, ref[name]) < GRAD_RTOL, (use_sh, name, rel_err(g, ref[name]))
-            assert rel_err(g[big], ref[name][big]) < 2 * GRAD_RTOL, (use_sh, name, "big", rel_err(g[big], ref[name][big]))
+        grads = [t.grad.cpu().numpy() for t in params]
+        assert_grads_close(grads, ref, scale, f"screen-filling sh={use_sh}")
+        assert_grads_close([g[big] for g in grads], {k: v[big] for k, v in ref.items()},
+                           {k: v[big] for k, v in scale.items()}, f"screen-filling sh={use_sh}, the big ones", l2=1e-4)
 
 
 def test_frame_backward_exp_scale_activation(gpu):
@@ -211,14 +242,14 @@ def test_frame_backward_exp_scale_activation(gpu):
     scene.scale = np.log(np.abs(scene.scale) + 1e-4).astype(np.float32)
     of = OracleFrame(scene, cam, scale_activation="exp")
     gimg = np.random.default_rng(5).normal(size=of.image.shape).astype(np.float32)
-    ref = of.backward(gimg)
+    ref, scale = of.backward(gimg, with_scale=True)
     params = to_torch(scene, gpu, requires_grad=True)
     r = FrameRenderer(gpu, max_pairs=len(of.ids) + 5, training=True, scale_activation="exp", auto_grow=False)
     img = r.render(*params, cam)
     assert np.abs(img.detach().cpu().numpy() - of.image).max() < 2e-4  # expf differs by ulps before projection
     img.backward(torch.from_numpy(gimg).to(gpu))
-    for t, name in zip(params, ("pos", "quat", "scale", "opa", "rgb")):
-        assert rel_err(t.grad.cpu().numpy(), ref[name]) < 2e-3, name
+    # the activated scales differ by an ulp or two of expf before anything else happens: looser than "abs"
+    assert_grads_close([t.grad.cpu().numpy() for t in params], ref, scale, "exp", rtol=1e-3, kappa=1e-4, l2=1e-3)
 
 
 def test_frame_all_culled_and_empty(gpu):
@@ -345,6 +376,33 @@ def test_full_size_backward_properties(gpu):
         assert float((d > 0).float().mean()) < 1e-3, int((d > 0).sum())
         assert float(a[~vis].abs().max()) == 0.0
         assert float(a[vis].abs().max()) > 0.0
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg4"])
+def test_full_size_backward_matches_oracle(gpu, cfg):
+    """BASELINE.json configs[1], [2] (376,467 / 506,627 Gaussians, 1080p, rgb logits) and [3] (2.4 M Gaussians,
+    1080p, SH -- the reference's degree 2) at FULL size: all five parameter gradients of gs_frame_backward against
+    the oracle's draw_backward (gaussian.cu:440-803) + index-backward sum (splatter.py:604-613) + projection
+    backward (gaussian.cu:1371-1576), element by element.  dL/dimage is that of an L1 loss against a grey target.
+    The oracle's loops run on every host core (OpenMP; ~10 s for cfg2 / cfg3, about a minute for cfg4 on 8 cores)."""
+    from gs_scene import CONFIGS
+
+    n, W, H, use_sh = CONFIGS[cfg]
+    scene, cam = make_scene(n, W, H, seed=2023, use_sh=use_sh), make_camera(W, H)
+    of = OracleFrame(scene, cam)
+    gimg = (np.sign(of.image - 0.5) / of.image.size).astype(np.float32)
+    ref, scale = of.backward(gimg, with_scale=True)
+    params = to_torch(scene, gpu, requires_grad=True)
+    r = FrameRenderer(gpu, max_pairs=len(of.ids) + 64, training=True, auto_grow=False)
+    img = r.render(*params, cam)
+    assert r.stats().pairs == len(of.ids)
+    assert np.abs(img.detach().cpu().numpy() - of.image).max() < IMG_ATOL
+    img.backward(torch.from_numpy(gimg).to(gpu))
+    report = assert_grads_close([t.grad.cpu().numpy() for t in params], ref, scale, cfg)
+    print(cfg, "gradient parity (worst err/tol, fraction within rtol alone, rel. L2):", report)
+    culled = of.mask == 0
+    for t in params:
+        assert float(t.grad[torch.from_numpy(culled).to(gpu)].abs().max()) == 0.0
 
 
 def test_full_size_2p4M_forward_matches_oracle(gpu):

@@ -46,8 +46,9 @@ def test_constructor_state_matches_the_reference_conventions(capture):
         assert np.array_equal(t.detach().cpu().numpy(), w)
     assert (sp.tile_info.width, sp.tile_info.height) == (80, 56) and sp.tile_info.focal_x == 0.75 * 160 / 2
     assert make(capture, use_sh_coeff=True).gaussian_3ds.rgb.shape == (2000, 27)
-    with pytest.raises(NotImplementedError):
-        make(capture, tile_culling_method="dist")
+    assert make(capture, tile_culling_method="dist")._renderer.tile_culling_method == 0  # Splatter.__init__'s default
+    with pytest.raises(ValueError):
+        make(capture, tile_culling_method="nearest")
 
 
 def test_forward_is_the_oracle_frame_and_backward_reaches_the_parameters(capture):
