@@ -49,6 +49,16 @@ struct FwdSmem<3> {
 __device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
+#ifndef GS_FWD_LEGACY_MUL
+#define GS_FWD_LEGACY_MUL 1  // 0: plain packed multiply (A/B switch for tools/ab_variants.py)
+#endif
+// a * b with DX9 zero rules: 0 x anything (NaN, infinity) = 0
+__device__ __forceinline__ float mul_legacy(float a, float b) {
+    float r;
+    asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // Exact per-pixel liveness in ONE packed instruction: m = clamp((t - 0.0001f) * 2^100) is 1.0 when
 // t > 0.0001f and 0.0 otherwise (the fma is exact up to its final rounding, and the smallest positive
 // t - 0.0001f is one ulp of 1e-4, which 2^100 lifts far above 1).  Replaces v_cmp + v_cndmask per pixel.
@@ -60,14 +70,14 @@ __device__ __forceinline__ f2 live_mask(f2 t, f2 scale, f2 bias) {
 }
 
 // Lane l owns the four pixels (x, y0 + 4k), k = 0..3, of the tile, x = l & 15, y0 = l >> 4; pixel
-// index inside the tile p_k = 64 k + l.  Why four pixels per lane: the compositing loop is bound by
-// LDS RETURN bandwidth, not by VALU -- a broadcast ds_read_b128 still delivers 1 KiB to the wave --
-// (ablation on MI355X: dropping exp + masking + colour math changed nothing, dropping the LDS reads
-// removed 85 % of the kernel), so every Gaussian read from LDS should feed as many pixel
-// evaluations as possible: 256 per wave here, against 64 for the one-pixel-per-lane layout.
-// With a single wave per tile there is no workgroup barrier at all; the staging of the next
-// chunk (one Gaussian per lane) overlaps the compositing of the current one through registers.
-// The fp32 math is packed over pixel PAIRS (v_pk_*_f32; dx is shared by all four pixels).
+// index inside the tile p_k = 64 k + l.  The compositing loop is bound by fp32 VALU ISSUE (PMC: ~31 VALU
+// wave-instructions per Gaussian step of 256 pixels, 28 of them arithmetic; the same instruction stream fed from
+// registers without any memory access runs at the same speed, tools/ubench/raster_feed.hip), so the layout is chosen
+// to share work between pixels: dx and the three dx-only terms of the exponent are computed once per lane for four
+// pixels, the per-Gaussian operands are read from LDS once per lane (broadcast ds_read_b128, four Gaussians per
+// read) and the fp32 math is packed over pixel PAIRS (v_pk_*_f32).  With a single wave per tile there is no workgroup
+// barrier at all; the staging of the next chunk (one Gaussian per lane) overlaps the compositing of the current one
+// through registers.
 // The kernel is PERSISTENT: the grid is a few waves per SIMD and every wave walks tiles blockIdx.x,
 // blockIdx.x + gridDim.x, ...  While a wave composites the LAST chunk of its tile it already gathers
 // chunk 0 of its NEXT tile, so the dependent id -> record gather latency (and the per-tile range load)
@@ -83,6 +93,13 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
                                                                     uint32_t n_tiles) {
     using SM = FwdSmem<CDIM>;
     constexpr int CH = SM::CH;
+    constexpr uint32_t GROUP = 4;  // Gaussians per ds_read_b128 of a field
+    // the wave-uniform liveness test (3 VALU instructions + a branch) runs before every second group without SH;
+    // with SH a Gaussian step is an order of magnitude longer and every group is tested
+#ifndef GS_FWD_LIVE_EVERY
+#define GS_FWD_LIVE_EVERY 8
+#endif
+    constexpr uint32_t LIVE_EVERY = CDIM == 3 ? GS_FWD_LIVE_EVERY : 4;
     __shared__ SM sm;
     const int lane = threadIdx.x;
 
@@ -146,7 +163,10 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
         T[h] = f2{1.0f, 1.0f};
         cr[h] = cg[h] = cb[h] = accw[h] = f2{0.f, 0.f};
     }
-    const f2 live_scale = splat(GS_LIVE_SCALE), live_bias = splat(-GS_T_STOP * GS_LIVE_SCALE);
+    f2 live_scale = splat(GS_LIVE_SCALE), live_bias = splat(-GS_T_STOP * GS_LIVE_SCALE);
+    // opaque to the compiler: otherwise it keeps the two constants in SGPRs and copies them into VGPR pairs for the
+    // inline v_pk_fma inside the hot loop (two v_mov_b64 per four Gaussians)
+    asm volatile("" : "+v"(live_scale), "+v"(live_bias));
     uint32_t nproc = 0;
 
     auto write_ckpt = [&](uint32_t idx_in_tile) {
@@ -189,6 +209,13 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
             // reference API may be handed any opacity (zero, negative), so it keeps the multiplication
             sm.f[buf][SM::NLOP][lane] = FRAME ? -__log2f(opa) : opa;
             if constexpr (CDIM == 3) {
+                // a NaN colour must reach the LIVE pixels only (the reference never evaluates the Gaussian for a
+                // finished one); 0 x NaN in the colour FMAs would poison every pixel, so the NaN is moved into the
+                // opacity, where v_mul_legacy confines it to live pixels, and the colour becomes 0 (0 x NaN = NaN there)
+                if (r0 != r0 || r1 != r1 || r2 != r2) {
+                    sm.f[buf][SM::NLOP][lane] = __builtin_nanf("");
+                    r0 = r1 = r2 = 0.f;
+                }
                 sm.f[buf][SM::R][lane] = r0;
                 sm.f[buf][SM::G][lane] = r1;
                 sm.f[buf][SM::BL][lane] = r2;
@@ -197,8 +224,8 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
 #pragma unroll
                 for (int q = 0; q < CDIM; ++q) sm.sh[buf][lane][q] = src[q];
             }
-        } else if (base + lane < ((n + 3u) & ~3u)) {
-            // pad the ragged tail to a multiple of 4 with null Gaussians (opacity 0 => alpha 0)
+        } else if (base + lane < ((n + (GROUP - 1u)) & ~(GROUP - 1u))) {
+            // pad the ragged tail to a multiple of GROUP with null Gaussians (opacity 0 => alpha 0)
 #pragma unroll
             for (int q = 0; q < SM::NFIELD; ++q) sm.f[buf][q][lane] = (FRAME && q == SM::NLOP) ? 1e30f : 0.f;
             if constexpr (CDIM > 3) {
@@ -218,14 +245,17 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
         // CH == GS_BUCKET: one checkpoint per chunk; the state before the tile's first chunk is (T, C) = (1, 0) by
         // definition, the backward kernels synthesise it instead of reading 4 KiB per tile back
         if (CKPT && base > 0) write_ckpt(base);
-        // groups of 4 Gaussians: one wave-uniform liveness test per group, per-pixel masking inside
+        // groups of GROUP Gaussians: a wave-uniform liveness test every LIVE_EVERY Gaussians, per-pixel masking inside
         // (exactly the reference's per-pixel `accum < 0.0001` test, gaussian.cu:906)
-        for (uint32_t i = 0; i < cnt; i += 4) {
-            if (!any_live()) {
+#pragma unroll 1
+        for (uint32_t i = 0; i < cnt; i += GROUP) {
+            if ((i & (LIVE_EVERY - 1)) == 0 && !any_live()) {
                 done = true;
                 break;
             }
-            auto ld4 = [&](int q) { return *(const float4 *)__builtin_assume_aligned(&sm.f[buf][q][i], 16); };
+            {
+            constexpr uint32_t i4 = 0;
+            auto ld4 = [&](int q) { return *(const float4 *)__builtin_assume_aligned(&sm.f[buf][q][i + i4], 16); };
             const float4 X = ld4(SM::X), Y = ld4(SM::Y), A4 = ld4(SM::A), B4 = ld4(SM::B), C4 = ld4(SM::C);
             const float4 O4 = ld4(SM::NLOP);
             float4 R4, G4, L4;
@@ -258,13 +288,20 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
                         al.x = 2.0f / (__expf(-al.x) + 1.0f) - 1.0f;
                         al.y = 2.0f / (__expf(-al.y) + 1.0f) - 1.0f;
                     }
+                    // w = alpha T with v_mul_legacy_f32 (0 x anything = 0): a finished pixel (T == 0) stays
+                    // untouched whatever alpha is -- NaN, infinite --, like the reference, which `break`s before it
+                    // evaluates the Gaussian (gaussian.cu:906); a live pixel sees the NaN, as there
+                    #if GS_FWD_LEGACY_MUL
+                    const f2 w = {mul_legacy(al.x, T[h].x), mul_legacy(al.y, T[h].y)};
+#else
                     const f2 w = al * T[h];
+#endif
                     if constexpr (CDIM == 3) {
                         cr[h] = pk_fma(splat(u == 0 ? R4.x : u == 1 ? R4.y : u == 2 ? R4.z : R4.w), w, cr[h]);
                         cg[h] = pk_fma(splat(u == 0 ? G4.x : u == 1 ? G4.y : u == 2 ? G4.z : G4.w), w, cg[h]);
                         cb[h] = pk_fma(splat(u == 0 ? L4.x : u == 1 ? L4.y : u == 2 ? L4.z : L4.w), w, cb[h]);
                     } else {
-                        const float *co = sm.sh[buf][i + u];
+                        const float *co = sm.sh[buf][i + i4 + u];
                         f2 v0 = {0.f, 0.f}, v1 = {0.f, 0.f}, v2 = {0.f, 0.f};
 #pragma unroll
                         for (int k9 = 0; k9 < NB; ++k9) {
@@ -283,6 +320,7 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
                     const f2 t = T[h] - w;  // T * (1 - alpha)
                     T[h] = t * live_mask(t, live_scale, live_bias);
                 }
+            }
             }
         }
         // a chunk whose checkpoint was written counts as processed even if the wave stopped inside it:

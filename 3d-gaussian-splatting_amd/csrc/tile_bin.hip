@@ -74,7 +74,9 @@ __device__ __forceinline__ void walk_rect(const uint4 rc, int64_t g, uint32_t nt
 // The Gaussians of a slice are visited BIN_THREADS at a time; the records of the next BIN_PF visits are requested
 // before the current ones are walked.  (Without it every visit exposed a full memory round trip: ten dependent
 // round trips per workgroup at 2.4 M Gaussians, with only 16 waves per CU to hide them.)
+#ifndef BIN_PF
 #define BIN_PF 4
+#endif
 
 // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2), while the output region of a
 // tile is laid out in slice order.  Giving XCD x a CONTIGUOUS range of slices makes the 8-byte pair

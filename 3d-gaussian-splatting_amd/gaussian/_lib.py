@@ -10,7 +10,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libgs_amd.so")
+# GS_AMD_LIB: an experiment variant of the library (gs_build.build(outdir=...), tools/ab_variants.py); the product
+# always loads the in-tree build
+LIB_PATH = os.environ.get("GS_AMD_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libgs_amd.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -46,16 +46,21 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, outdir: str = None, defines=()) -> str:
+    """Default: csrc/libgs_amd.so.  ``outdir`` + ``defines`` (-D switches) build an experiment VARIANT of the library
+    somewhere else (tools/ab_variants.py; load it with GS_AMD_LIB=<path>): never the product build."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
     objs, jobs = [], []
+    odir = outdir or CSRC
+    os.makedirs(odir, exist_ok=True)
+    lib = os.path.join(odir, "libgs_amd.so")
     for src, extra in SOURCES.items():
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        o = os.path.join(odir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([hipcc, *COMMON, *extra, "-c", s, "-o", o])
+            jobs.append([hipcc, *COMMON, *extra, *defines, "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -65,9 +70,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
             list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
-    return LIB
+    if force or jobs or _stale(lib, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs])
+    return lib
 
 
 if __name__ == "__main__":

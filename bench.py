@@ -5,21 +5,28 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one forward frame of the whole hot path (cull+project -> duplicate -> radix sort ->
-tile ranges -> 16x16 compositing -> clamp+crop) on synthetic Gaussians already resident in
-HBM.  Default workload: BASELINE.json configs[1] = 376,467 Gaussians at 1920x1080, no SH,
-forward render.  With N > 1 every rank renders its own view (yaw k x 5 deg) of a full replica of
-the scene -- the path shards by view and the forward render has no exchange step, so there is no
-data-path collective (weak scaling).  The training leg reported under "extra" is the reference's
-training step without densification (train.py:84-185: forward, L1 + 0.1 SSIM loss, backward, Adam)
-and does have one: an RCCL all-reduce (mean) of the flat parameter-gradient bucket before the fused
-Adam step.  "extra" also carries the loss / Adam kernel times, a 300-iteration fit of the cfg3 scene
-(it/s, PSNR before/after against a synthetic ground truth), the cfg5 (2.4 M Gaussians) render FPS and the
-cfg4 (2.4 M Gaussians with SH) forward / backward times.
+A "step" is ONE forward frame of the whole hot path (cull + project -> tile binning -> per-tile depth sort ->
+16x16 compositing -> clamp + crop) on synthetic Gaussians already resident in HBM, ONE frame in flight (the
+reference renders a frame and synchronises, train.py:256-281).  Headline workload (`--config cfg5`, the default):
+the north-star target scene -- 2.4 M Gaussians at 1920x1080, forward render, the geometry of BASELINE.json
+configs[3] / [4] (target >= 160 FPS on one MI355X).  With N > 1 every rank renders its own view (yaw k x 5 deg) of
+a full replica of the scene: the path shards by view and a forward render has no exchange step, so there is no
+data-path collective (weak scaling); the training step -- which does exchange gradients -- is reported per N under
+"multi_gpu".
 
-Rank 0 prints ONE JSON line (driver contract) with "roofline" (dominant kernel =
-raster_forward_kernel, timed live with hipEvents on its own stream inside the library) and
-"cpu_baseline" (the C oracle = CPU port of the reference path, one host core).
+Rank 0 prints ONE JSON line (driver contract):
+  value / ms_per_step  the K timed steps of the headline workload, one frame in flight;
+  roofline             dominant kernel of that workload (raster_forward_kernel), algorithmic bytes of SURVEY.md 8d S5
+                       / its hipEvent-timed duration (events on the launch stream, inside the library);
+  stages               every stage of the frame: ms, algorithmic bytes (SURVEY.md 8d), GB/s, fraction of HBM peak;
+  cfg2                 BASELINE.json configs[1] (376,467 Gaussians, 1080p): FPS + the same roofline object;
+  extra                training step (forward + L1/SSIM loss + backward + fused Adam) at cfg2 and at 2.4 M Gaussians,
+                       a 300-iteration fit of the cfg3 scene, cfg4 (2.4 M, SH) forward / backward stage times,
+                       three frames in flight;
+  multi_gpu            ranks seen, gradient bucket bytes, all-reduce time, training views/s over all ranks;
+  cpu_baseline         the C oracle (CPU port of the reference path, OpenMP over every host core) on the same scene.
+`--legs` selects what runs (default: everything that fits the rank count); profiles/ holds rocprofv3 traces of
+`--legs headline`.
 """
 import argparse
 import json
@@ -37,10 +44,32 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ALL_LEGS = ("headline", "cfg2", "train", "fit", "cfg4", "pipelined", "multi_gpu", "cpu")
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def stage_table(n, V, M, W, H, C, stage_ms):
+    """Per-stage algorithmic bytes and the HBM fraction they were moved at.
+
+    project   = S1 cull/project (R 40 N, W 4 N + 28 V) + S1b activations (R and W (4 + 4 C) V)
+    bin       = S2 key emission (R 28 V, W 12 M: 8-byte key + 4-byte id)
+    tile_sort = S3 sort, single-pass lower bound (R 12 M + W 12 M) + S4 ranges (R 4 M, W 4 T)
+    raster    = S5 (R (32 + 4 C) M, W 12 P)
+    """
+    P = (-(-W // 16) * 16) * (-(-H // 16) * 16)
+    T = P // 256
+    alg = {"project": 44 * n + 28 * V + 2 * (4 + 4 * C) * V, "bin": 28 * V + 12 * M,
+           "tile_sort": 28 * M + 4 * T, "raster": (32 + 4 * C) * M + 12 * P}
+    out = {}
+    for k, b in alg.items():
+        ms = stage_ms[k]
+        gbs = b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        out[k] = {"ms": round(ms, 4), "algorithmic_bytes": int(b), "GBs": round(gbs, 1),
+                  "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+    return out, alg, P, T
 
 
 def main():
@@ -48,13 +77,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="cfg2", help="cfg1..cfg5 of gs_scene.CONFIGS")
-    ap.add_argument("--no-extra", action="store_true", help="skip the training / 2.4M legs")
+    ap.add_argument("--config", default="cfg5", help="headline workload: cfg1..cfg5 of gs_scene.CONFIGS")
+    ap.add_argument("--legs", default="all", help="comma list of " + ",".join(ALL_LEGS) + " (default: all)")
+    ap.add_argument("--no-extra", action="store_true", help="= --legs headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=3,
-                    help="frames in flight: consecutive frames are independent, so frame i+1's latency-bound "
-                         "binning/sort kernels overlap frame i's compositing on a second HIP stream")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="N = 1: still run the gradient all-reduce (through RCCL when launched under torchrun)")
     args = ap.parse_args()
+    legs = set(ALL_LEGS if args.legs == "all" else args.legs.split(","))
+    if args.no_extra:
+        legs = {"headline"}
+    if args.no_cpu_baseline:
+        legs.discard("cpu")
+    assert legs <= set(ALL_LEGS), f"unknown leg in {sorted(legs)}"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -84,9 +119,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    def load(cfg):
+    def load(cfg, sh_degree=2):
         n, W, H, use_sh = CONFIGS[cfg]
-        scene = make_scene(n, W, H, seed=2023, use_sh=use_sh)
+        scene = make_scene(n, W, H, seed=2023, use_sh=use_sh, sh_degree=sh_degree)
         cam = make_camera(W, H, yaw_deg=5.0 * rank)  # one view per GPU
         params = [torch.from_numpy(a).to(dev) for a in (scene.pos, scene.quat, scene.scale, scene.opa, scene.rgb)]
         return scene, cam, params
@@ -112,30 +147,98 @@ def main():
         barrier()
         return max_over_ranks(dt)
 
-    # ---------------------------------------------------------------- headline: render FPS
-    scene, cam, params = load(args.config)
-    n, W, H, use_sh = CONFIGS[args.config]
-    r, st = sized_renderer(params, cam, training=False)
-    log(f"[rank {rank}] {args.config}: N={n} V={st.visible} M={st.pairs} {W}x{H} sh={use_sh}")
-    # setup, not measurement: ~0.4 s of frames so that the clocks (DVFS) are at their steady state whatever
-    # --warmup the caller picked; the W warm-up and K timed steps below follow the contract unchanged
-    t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < 0.4:
-        for _ in range(50):
-            r.forward(*params, cam)
+    def settle(fn, seconds=0.4):
+        """setup, not measurement: a few tenths of a second of work so that the clocks (DVFS) are at their steady
+        state whatever --warmup the caller picked"""
+        t = time.perf_counter()
+        while time.perf_counter() - t < seconds:
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize()
+
+    def render_leg(cfg, steps, warmup):
+        """One workload, one frame in flight: FPS over `steps` timed frames + roofline objects (rank 0)."""
+        scene, cam, params = load(cfg)
+        n, W, H, use_sh = CONFIGS[cfg]
+        r, st = sized_renderer(params, cam, training=False)
+        log(f"[rank {rank}] {cfg}: N={n} V={st.visible} M={st.pairs} {W}x{H} sh={use_sh}")
+        frame = lambda: r.forward(*params, cam)  # noqa: E731
+        settle(frame)
         torch.cuda.synchronize()
-    # host cost of issuing one frame (ctypes call + ~14 launches), GPU free-running
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(50):
-        r.forward(*params, cam)
-    host_us = (time.perf_counter() - t0) / 50 * 1e6
-    torch.cuda.synchronize()
-    dt1 = time_frames(lambda: r.forward(*params, cam), args.steps, args.warmup)
-    single_stream_fps = world * args.steps / dt1
-    if args.streams > 1:
-        # one renderer (own workspace) per stream; frames alternate between them
-        rs = [r] + [sized_renderer(params, cam, training=False)[0] for _ in range(args.streams - 1)]
+        t0 = time.perf_counter()
+        for _ in range(50):
+            frame()
+        host_us = (time.perf_counter() - t0) / 50 * 1e6  # host cost of issuing one frame, GPU free-running
+        torch.cuda.synchronize()
+        dt = time_frames(frame, steps, warmup)
+        res = {"fps": world * steps / dt, "ms": dt / steps * 1e3, "host_us": host_us, "stats": st,
+               "scene": scene, "cam": cam, "params": params, "renderer": r}
+        if rank == 0:
+            prof = [r.profile_forward(*params, cam) for _ in range(25)][5:]
+            med = {k: statistics.median(p[k] for p in prof) for k in prof[0]}
+            # sort_mode 2: "scan_emit" = count + column scan + scatter (the tile binning), "ranges" = per-tile sort
+            stage_ms = {"project": med["project"], "bin": med["scan_emit"] + med["sort"], "tile_sort": med["ranges"],
+                        "raster": med["raster"]}
+            C = 27 if use_sh else 3
+            stages, alg, P, T = stage_table(n, st.visible, st.pairs, W, H, C, stage_ms)
+            achieved = alg["raster"] / (stage_ms["raster"] * 1e-3) / 1e9
+            traffic = None  # HBM bytes per launch from committed PMC passes (profiles/traffic.json), if they match
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[cfg]
+                if tj["tile_pairs"] == st.pairs:
+                    traffic = tj["raster_forward_kernel"]["traffic_bytes"]
+            except (OSError, KeyError, ValueError):
+                pass
+            roof = {"bound": "hbm", "kernel": "raster_forward_kernel", "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": traffic, "algorithmic_bytes": int(alg["raster"]),
+                    "kernel_ms": round(stage_ms["raster"], 4), "workload": cfg}
+            if not use_sh:
+                # the compositing kernel is fp32-VALU bound, not HBM bound (DESIGN.md section 3): 73 flops per Gaussian
+                # per 4 pixels of a lane (5 shared + 34 per packed pixel pair) => 18.25 flops per (pair, pixel);
+                # peak = packed fp32 FMA on 256 CUs x 4 SIMD x 16 lanes at 2.4 GHz
+                tf = 18.25 * 256 * st.pairs / (stage_ms["raster"] * 1e-3) / 1e12
+                roof["valu"] = {"achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s fp32 vector",
+                                "frac": round(tf / 157.3, 3),
+                                "note": "upper bound on work: early-terminated tiles skip Gaussians"}
+            b_fwd = 44 * n + (64 + 8 * C) * st.visible + (72 + 4 * C) * st.pairs + 12 * P + 4 * T  # SURVEY.md 8d
+            res.update(roofline=roof, stages=stages, stage_total_ms=round(med["total"], 4),
+                       frame_roofline={"algorithmic_bytes": int(b_fwd),
+                                       "achieved_GBs": round(b_fwd / (res["ms"] * 1e-3) / 1e9, 1),
+                                       "frac_of_hbm_peak": round(b_fwd / (res["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+        return res
+
+    def workload_name(cfg, st):
+        n, W, H, use_sh = CONFIGS[cfg]
+        what = {"cfg5": "north-star target scene (geometry of BASELINE configs[3]/[4])",
+                "cfg2": "BASELINE configs[1]", "cfg3": "BASELINE configs[2] scene", "cfg4": "BASELINE configs[3]",
+                "cfg1": "BASELINE configs[0]"}.get(cfg, "")
+        return (f"{cfg}: {n} Gaussians, {W}x{H}, {'SH deg2 (27 coeff)' if use_sh else 'no SH'}, forward render, "
+                f"one frame in flight, one view per GPU -- {what}")
+
+    # ---------------------------------------------------------------- headline: render FPS, one frame in flight
+    head = render_leg(args.config, args.steps, args.warmup)
+    n, W, H, use_sh = CONFIGS[args.config]
+    st = head["stats"]
+    out = {
+        "metric": "render_fps", "value": round(head["fps"], 2), "unit": "frames/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(head["ms"], 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": workload_name(args.config, st), "n_gaussians": n, "visible": st.visible,
+                   "tile_pairs": st.pairs, "width": W, "height": H,
+                   "parallelism": f"view-sharded x{world} (no data-path collective)", "frames_in_flight": 1},
+        "host_us_per_frame": round(head["host_us"], 1),
+    }
+    if rank == 0:
+        out["roofline"], out["stages"] = head["roofline"], head["stages"]
+        out["stage_total_ms"], out["frame_roofline"] = head["stage_total_ms"], head["frame_roofline"]
+
+    extra = {}
+    # ---------------------------------------------------------------- three frames in flight (throughput figure)
+    if "pipelined" in legs:
+        params, cam = head["params"], head["cam"]
+        rs = [head["renderer"]] + [sized_renderer(params, cam, training=False)[0] for _ in range(2)]
         streams = [torch.cuda.Stream(device=dev) for _ in rs]
         counter = [0]
         for i in range(len(rs)):  # setup: the first launch on a fresh HIP stream creates its hardware queue (~ms)
@@ -150,89 +253,55 @@ def main():
             with torch.cuda.stream(streams[i]):
                 rs[i].forward(*params, cam)
 
-        dt = time_frames(pipelined_frame, args.steps, args.warmup)
-    else:
-        dt = dt1
-    ms_per_step = dt / args.steps * 1e3
-    fps = world * args.steps / dt
+        k = max(args.steps, 50)
+        dtp = time_frames(pipelined_frame, k, 10)
+        extra["three_frames_in_flight_fps"] = round(world * k / dtp, 2)
+        del rs, streams
+    head_scene, head_cam = head["scene"], head["cam"]
+    head_params = head["params"]
+    del head["renderer"]
+    torch.cuda.empty_cache()
 
-    out = {
-        "metric": "render_fps", "value": round(fps, 2), "unit": "frames/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic",
-        "config": {"workload": f"{args.config}: {n} Gaussians, {W}x{H}, "
-                               f"{'SH deg2 (27 coeff)' if use_sh else 'no SH'}, forward render, one view per GPU",
-                   "n_gaussians": n, "visible": st.visible, "tile_pairs": st.pairs, "width": W, "height": H,
-                   "parallelism": f"view-sharded x{world} (no data-path collective)",
-                   "frames_in_flight": args.streams},
-        "single_stream_fps": round(single_stream_fps, 2), "host_us_per_frame": round(host_us, 1),
-    }
+    # ---------------------------------------------------------------- BASELINE configs[1]
+    if "cfg2" in legs and args.config != "cfg2":
+        c2 = render_leg("cfg2", max(args.steps, 50), max(args.warmup, 10))
+        out["cfg2"] = {"workload": workload_name("cfg2", c2["stats"]), "render_fps": round(c2["fps"], 2),
+                       "ms_per_frame": round(c2["ms"], 4), "visible": c2["stats"].visible,
+                       "tile_pairs": c2["stats"].pairs, "host_us_per_frame": round(c2["host_us"], 1)}
+        if rank == 0:
+            out["cfg2"].update(roofline=c2["roofline"], stages=c2["stages"], frame_roofline=c2["frame_roofline"])
+        del c2
+        torch.cuda.empty_cache()
 
-    # ---------------------------------------------------------------- roofline of the dominant kernel
-    if rank == 0:
-        prof = [r.profile_forward(*params, cam) for _ in range(25)][5:]
-        stage = {k: statistics.median(p[k] for p in prof) for k in prof[0]}
-        C = 27 if use_sh else 3
-        grid_px = (-(-W // 16) * 16) * (-(-H // 16) * 16)
-        alg_bytes = (4 + 24 + 4 + 4 * C) * st.pairs + 12 * grid_px  # SURVEY.md 8d, stage S5 (raster)
-        achieved = alg_bytes / (stage["raster"] * 1e-3) / 1e9
-        traffic = None  # HBM bytes per launch from committed PMC passes (profiles/traffic.json), if they match
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[args.config]
-            if tj["tile_pairs"] == st.pairs:
-                traffic = tj["raster_forward_kernel"]["traffic_bytes"]
-        except (OSError, KeyError, ValueError):
-            pass
-        out["roofline"] = {"bound": "hbm", "kernel": "raster_forward_kernel", "achieved": round(achieved, 1),
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                           "traffic": traffic, "algorithmic_bytes": alg_bytes,
-                           "kernel_ms": round(stage["raster"], 4)}
-        if not use_sh:
-            # the kernel is fp32-VALU bound, not HBM bound: 73 flops per Gaussian per
-            # 4 pixels of a lane (5 shared + 34 per packed pixel pair) => 18.25 flops per (pair, pixel);
-            # peak = packed fp32 FMA on 256 CUs x 4 SIMD x 16 lanes at 2.4 GHz
-            flops = 18.25 * 256 * st.pairs
-            out["roofline"]["valu"] = {"achieved": round(flops / (stage["raster"] * 1e-3) / 1e12, 1), "peak": 157.3,
-                                       "unit": "TFLOP/s fp32 vector",
-                                       "frac": round(flops / (stage["raster"] * 1e-3) / 1e12 / 157.3, 3),
-                                       "note": "upper bound on work: early-terminated tiles skip Gaussians"}
-        out["stage_ms"] = {k: round(v, 4) for k, v in stage.items()}
-        # whole-frame algorithmic bytes: 44N + (64+8C)V + (72+4C)M + 12P + 4T
-        T = grid_px // 256
-        b_fwd = 44 * n + (64 + 8 * C) * st.visible + (72 + 4 * C) * st.pairs + 12 * grid_px + 4 * T
-        out["frame_roofline"] = {"algorithmic_bytes": b_fwd,
-                                 "achieved_GBs": round(b_fwd / (ms_per_step * 1e-3) / 1e9, 1),
-                                 "frac_of_hbm_peak": round(b_fwd / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-
-    # ---------------------------------------------------------------- extra legs
-    extra = {}
-    if not args.no_extra:
-        # training iteration of train.py:84-185 without densification: forward (checkpointing) -> L1 + SSIM loss
-        # and its gradient -> backward -> RCCL all-reduce of the flat gradient bucket (N > 1) -> fused Adam
+    # ---------------------------------------------------------------- training step (train.py:84-185, no densification)
+    def train_leg(cfg, params, cam, pairs, k, force=False):
+        """forward (checkpointing) -> L1 + 0.1 SSIM loss and gradient -> backward -> all-reduce of the flat gradient
+        bucket (N > 1) -> fused Adam.  Returns (whole-job iterations/s, ms per iteration, detail dict on rank 0)."""
         from gs_train import TrainOptions, Trainer
 
-        target = torch.rand(H, W, 3, device=dev)
-        tr = Trainer(params, [cam], [target], TrainOptions(), world_size=world, max_pairs=int(st.pairs * 1.1) + 4096)
-        tr.flat.force_collective = use_dist
+        _, Wc, Hc, _ = CONFIGS[cfg]
+        target = torch.rand(Hc, Wc, 3, device=dev)
+        tr = Trainer([t.clone() for t in params], [cam], [target], TrainOptions(), world_size=world,
+                     max_pairs=int(pairs * 1.1) + 4096)
+        tr.flat.force_collective = use_dist or force
         tr.renderer.auto_grow = False
-        rt, flat = tr.renderer, tr.flat
         it = [0]
 
         def train_iter():
             tr.train_step(it[0], 0)
             it[0] += 1
 
-        k = max(args.steps // 4, 10)
-        dtt = time_frames(train_iter, k, max(args.warmup // 4, 3))
-        extra["train_iters_per_s"] = round(world * k / dtt, 2)
-        extra["train_ms_per_iter"] = round(dtt / k * 1e3, 4)
-        extra["train_step"] = "forward + L1/SSIM loss (w=0.1) + backward + grad all-reduce + fused Adam, one view per GPU"
+        settle(train_iter, 0.2)
+        dtt = time_frames(train_iter, k, 5)
+        detail = {}
         if rank == 0:
+            rt, flat = tr.renderer, tr.flat
             img, _ = rt.forward(*flat.params, cam)
-            lossk = tr._loss_for(H, W)
+            lossk = tr._loss_for(Hc, Wc)
+            pf = [rt.profile_forward(*flat.params, cam)["total"] for _ in range(8)][3:]
             pb = [rt.profile_backward(lossk(img, target)) for _ in range(8)][3:]
-            extra["backward_stage_ms"] = {key: round(statistics.median(p[key] for p in pb), 4) for key in pb[0]}
+            detail["forward_ms"] = round(statistics.median(pf), 4)
+            detail["backward_stage_ms"] = {key: round(statistics.median(p[key] for p in pb), 4) for key in pb[0]}
 
             def timed(fn, reps=20):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -246,83 +315,130 @@ def main():
 
             loss_ms, adam_ms = timed(lambda: lossk(img, target)), timed(tr.optimizer.step)
             n_par = flat.flat_param.numel()
-            extra["loss_ms"], extra["adam_ms"] = round(loss_ms, 4), round(adam_ms, 4)
+            detail["loss_ms"], detail["adam_ms"] = round(loss_ms, 4), round(adam_ms, 4)
             # Adam is a pure stream: 16 B read + 12 B written per parameter
-            extra["adam_roofline"] = {"bound": "hbm", "achieved": round(28 * n_par / (adam_ms * 1e-3) / 1e9, 1),
-                                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                      "frac": round(28 * n_par / (adam_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                      "parameters": n_par}
-        del tr
-        if rank == 0 and world == 1 and args.config == "cfg2":
-            # BASELINE.json configs[2] in miniature: fit a perturbed copy of the cfg3 scene (506,627 Gaussians, 1080p)
-            # to a render of the original with the reference's training step (train.py defaults: lr 0.003 x
-            # (10, 10, 1, 1, 1), exp decay, L1 + 0.1 SSIM, Adam(0.9, 0.99)); there is no dataset here, so the
-            # figure of merit is the PSNR against that synthetic ground truth before / after a short run
-            _, cam3, params3 = load("cfg3")
-            r3, st3 = sized_renderer(params3, cam3, training=False)
-            target3 = r3.forward(*params3, cam3)[0].clone()
-            del r3
-            g = torch.Generator(device=dev).manual_seed(7)
-            start3 = [t.clone() for t in params3]
-            start3[4] += 0.5 * torch.randn(start3[4].shape, device=dev, generator=g)   # colour logits
-            start3[3] += 0.3 * torch.randn(start3[3].shape, device=dev, generator=g)   # opacity logits
-            n_it = 300
-            tr3 = Trainer(start3, [cam3], [target3], TrainOptions(n_iters=n_it + 1, n_iters_warmup=30),
-                          max_pairs=int(st3.pairs * 1.2) + 4096)
-            psnr0 = Trainer.psnr(tr3.renderer.forward(*tr3.flat.params, cam3)[0], target3)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for i in range(n_it):
-                tr3.train_step(i, 0)
-            torch.cuda.synchronize()
-            dt3 = time.perf_counter() - t0
-            psnr1 = Trainer.psnr(tr3.renderer.forward(*tr3.flat.params, cam3)[0], target3)
-            extra["cfg3_fit"] = {"n_gaussians": CONFIGS["cfg3"][0], "tile_pairs": st3.pairs, "iters": n_it,
-                                 "iters_per_s": round(n_it / dt3, 1), "psnr_before_dB": round(psnr0, 2),
-                                 "psnr_after_dB": round(psnr1, 2),
-                                 "final_loss": round(float(tr3._loss_for(H, W).values[0]), 5)}
-            del tr3, target3, start3, params3
-        del rt, flat
+            detail["adam_roofline"] = {"bound": "hbm", "achieved": round(28 * n_par / (adam_ms * 1e-3) / 1e9, 1),
+                                       "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": round(28 * n_par / (adam_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                       "parameters": n_par}
+        return world * k / dtt, dtt / k * 1e3, detail, tr
+
+    if "train" in legs:
+        k = max(args.steps // 4, 25)
+        _, cam2, params2 = (head_scene, head_cam, head_params) if args.config == "cfg2" else load("cfg2")
+        r2, st2 = sized_renderer(params2, cam2, training=False)
+        del r2
+        ips, ms, detail, tr = train_leg("cfg2", params2, cam2, st2.pairs, k)
+        extra["train_cfg2"] = {"iters_per_s": round(ips, 2), "ms_per_iter": round(ms, 4), **detail,
+                               "step": "forward + L1/SSIM loss (w=0.1) + backward + grad all-reduce (N>1) + fused "
+                                       "Adam, one view per GPU, 376,467 Gaussians, 1080p"}
+        del tr, params2
         torch.cuda.empty_cache()
-        if args.config != "cfg5":
-            _, cam5, params5 = load("cfg5")  # 2.4M Gaussians, the north-star target (>= 160 FPS)
-            r5, st5 = sized_renderer(params5, cam5, training=False)
-            k5 = max(args.steps // 4, 10)
-            dt5 = time_frames(lambda: r5.forward(*params5, cam5), k5, 5)
-            extra["cfg5_2p4M_render_fps"] = round(world * k5 / dt5, 2)
-            extra["cfg5_visible"], extra["cfg5_tile_pairs"] = st5.visible, st5.pairs
-            del r5, params5
+        if not CONFIGS[args.config][3]:
+            ips, ms, detail, tr = train_leg(args.config, head_params, head_cam, st.pairs, k)
+            extra["train_headline_scene"] = {"iters_per_s": round(ips, 2), "ms_per_iter": round(ms, 4), **detail,
+                                             "step": f"the same step on the headline scene ({n} Gaussians)"}
+            del tr
             torch.cuda.empty_cache()
-        if rank == 0 and world == 1 and args.config == "cfg2":
-            # BASELINE.json configs[3]: 2.4 M Gaussians, 1080p, SH, forward + backward (hipEvent-timed stages).
-            # Degree 2 (27 coefficients) is what the reference implements; degree 3 (48) is the extension.
-            n4, W4, H4, _ = CONFIGS["cfg4"]
-            cam4 = make_camera(W4, H4)
-            cfg4 = {}
-            for deg in (2, 3):
-                sc4 = make_scene(n4, W4, H4, seed=2023, use_sh=True, sh_degree=deg)
-                p4 = [torch.from_numpy(a).to(dev) for a in (sc4.pos, sc4.quat, sc4.scale, sc4.opa, sc4.rgb)]
-                r4, st4 = sized_renderer(p4, cam4, training=True)
-                img4, _ = r4.forward(*p4, cam4)
-                g4 = torch.sign(img4 - 0.5) / img4.numel()
-                fw = [r4.profile_forward(*p4, cam4)["total"] for _ in range(6)][2:]
-                bw = [r4.profile_backward(g4) for _ in range(6)][2:]
-                f_ms = statistics.median(fw)
-                b_ms = statistics.median(x["total"] for x in bw)
-                cfg4[f"sh_degree_{deg}"] = {"coefficients": 3 * (deg + 1) ** 2, "tile_pairs": st4.pairs,
-                                            "forward_ms": round(f_ms, 3), "backward_ms": round(b_ms, 3),
-                                            "raster_bwd_ms": round(statistics.median(x["raster_bwd"] for x in bw), 3),
-                                            "fwd_bwd_iters_per_s": round(1e3 / (f_ms + b_ms), 1)}
-                del r4, p4, sc4, img4, g4
-                torch.cuda.empty_cache()
-            extra["cfg4_2p4M_sh_fwd_bwd"] = cfg4
+
+    # ---------------------------------------------------------------- multi-GPU: the gradient exchange of a training step
+    if "multi_gpu" in legs and not CONFIGS[args.config][3] and (use_dist or args.force_collective):
+        k = max(args.steps // 4, 25)
+        views_per_s, ms, _, tr = train_leg(args.config, head_params, head_cam, st.pairs, k, force=True)
+        flat = tr.flat
+        seen = 1
+        if use_dist:
+            t = torch.ones(1, device=dev)
+            dist.all_reduce(t)
+            seen = int(t.item())
+        ar_ms = None
+        if dist.is_initialized():
+            for _ in range(3):
+                flat.all_reduce_grads()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                flat.all_reduce_grads()
+            torch.cuda.synchronize()
+            ar_ms = max_over_ranks((time.perf_counter() - t0) / 10 * 1e3)
+        out["multi_gpu"] = {
+            "ranks_seen": seen, "bucket_bytes": flat.bucket_bytes, "allreduce_ms": None if ar_ms is None else round(ar_ms, 4),
+            "allreduce_busbw_GBs": None if not ar_ms or seen < 2 else round(
+                2 * (seen - 1) / seen * flat.bucket_bytes / (ar_ms * 1e-3) / 1e9, 1),
+            "train_views_per_s": round(views_per_s, 2), "train_ms_per_iter": round(ms, 4),
+            "collective": "one all-reduce (mean) of the flat fp32 gradient bucket per iteration, RCCL"
+                          if use_dist else "no process group: collective skipped (run under torchrun)",
+            "note": "no 2/4/8-GPU scaling curve has been measured by the builder (one GPU per gpurun box)"}
+        del tr
+        torch.cuda.empty_cache()
+    del head_params
+
+    # ---------------------------------------------------------------- cfg3 in miniature: does the step train?
+    if "fit" in legs and rank == 0 and world == 1:
+        # BASELINE.json configs[2] in miniature: fit a perturbed copy of the cfg3 scene (506,627 Gaussians, 1080p)
+        # to a render of the original with the reference's training step (train.py defaults: lr 0.003 x
+        # (10, 10, 1, 1, 1), exp decay, L1 + 0.1 SSIM, Adam(0.9, 0.99)); there is no dataset here, so the
+        # figure of merit is the PSNR against that synthetic ground truth before / after a short run
+        from gs_train import TrainOptions, Trainer
+
+        _, cam3, params3 = load("cfg3")
+        _, W3, H3, _ = CONFIGS["cfg3"]
+        r3, st3 = sized_renderer(params3, cam3, training=False)
+        target3 = r3.forward(*params3, cam3)[0].clone()
+        del r3
+        g = torch.Generator(device=dev).manual_seed(7)
+        start3 = [t.clone() for t in params3]
+        start3[4] += 0.5 * torch.randn(start3[4].shape, device=dev, generator=g)   # colour logits
+        start3[3] += 0.3 * torch.randn(start3[3].shape, device=dev, generator=g)   # opacity logits
+        n_it = 300
+        tr3 = Trainer(start3, [cam3], [target3], TrainOptions(n_iters=n_it + 1, n_iters_warmup=30),
+                      max_pairs=int(st3.pairs * 1.2) + 4096)
+        psnr0 = Trainer.psnr(tr3.renderer.forward(*tr3.flat.params, cam3)[0], target3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_it):
+            tr3.train_step(i, 0)
+        torch.cuda.synchronize()
+        dt3 = time.perf_counter() - t0
+        psnr1 = Trainer.psnr(tr3.renderer.forward(*tr3.flat.params, cam3)[0], target3)
+        extra["cfg3_fit"] = {"n_gaussians": CONFIGS["cfg3"][0], "tile_pairs": st3.pairs, "iters": n_it,
+                             "iters_per_s": round(n_it / dt3, 1), "psnr_before_dB": round(psnr0, 2),
+                             "psnr_after_dB": round(psnr1, 2),
+                             "final_loss": round(float(tr3._loss_for(H3, W3).values[0]), 5)}
+        del tr3, target3, start3, params3
+        torch.cuda.empty_cache()
+
+    # ---------------------------------------------------------------- BASELINE configs[3]: 2.4 M Gaussians, SH, fwd + bwd
+    if "cfg4" in legs and rank == 0 and world == 1:
+        # hipEvent-timed stages.  Degree 2 (27 coefficients) is what the reference implements; degree 3 (48
+        # coefficients, what configs[3] names) is the extension.
+        cfg4 = {}
+        for deg in (2, 3):
+            _, cam4, p4 = load("cfg4", sh_degree=deg)
+            r4, st4 = sized_renderer(p4, cam4, training=True)
+            img4, _ = r4.forward(*p4, cam4)
+            g4 = torch.sign(img4 - 0.5) / img4.numel()
+            fw = [r4.profile_forward(*p4, cam4) for _ in range(6)][2:]
+            bw = [r4.profile_backward(g4) for _ in range(6)][2:]
+            f_ms = statistics.median(x["total"] for x in fw)
+            b_ms = statistics.median(x["total"] for x in bw)
+            cfg4[f"sh_degree_{deg}"] = {"coefficients": 3 * (deg + 1) ** 2, "tile_pairs": st4.pairs,
+                                        "forward_ms": round(f_ms, 3), "backward_ms": round(b_ms, 3),
+                                        "raster_fwd_ms": round(statistics.median(x["raster"] for x in fw), 3),
+                                        "raster_bwd_ms": round(statistics.median(x["raster_bwd"] for x in bw), 3),
+                                        "project_bwd_ms": round(statistics.median(x["project_bwd"] for x in bw), 3),
+                                        "fwd_bwd_iters_per_s": round(1e3 / (f_ms + b_ms), 1)}
+            del r4, p4, img4, g4
+            torch.cuda.empty_cache()
+        extra["cfg4_2p4M_sh_fwd_bwd"] = cfg4
     out["extra"] = extra
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if "cpu" in legs and rank == 0 and world == 1:
         import oracle  # the checker, timed here as the "port" baseline -- never on the product path
         from gs_geometry import RayBasis, TileGrid
 
+        scene, cam = head_scene, head_cam
         grid = TileGrid(W, H, cam.focal_x, cam.focal_y)
         rays = RayBasis.from_camera(cam.rot, cam.tran, grid.padded_height, grid.padded_width, cam.focal_x, cam.focal_y)
         t0, frames = time.perf_counter(), 0
@@ -332,9 +448,11 @@ def main():
                                   lefttop=rays.lefttop, vdx=rays.dx, vdy=rays.dy)
             frames += 1
         cpu_dt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": round(frames / cpu_dt, 4), "unit": "frames/s", "cores": 1, "kind": "port",
-                               "sample": f"{frames} full forward frames of {args.config} "
-                                         f"(oracle/gs_oracle.c, scalar C, {os.cpu_count()} host cores present)"}
+        out["cpu_baseline"] = {"value": round(frames / cpu_dt, 4), "unit": "frames/s", "cores": oracle.num_threads(),
+                               "kind": "port",
+                               "sample": f"{frames} full forward frames of {args.config} (oracle/gs_oracle.c: cull + "
+                                         f"project and the (tile, depth) sort on one core, compositing over "
+                                         f"{oracle.num_threads()} OpenMP threads; {os.cpu_count()} host cores present)"}
 
     if rank == 0:
         print(json.dumps(out), flush=True)

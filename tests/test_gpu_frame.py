@@ -450,12 +450,15 @@ def test_full_size_2p4M_sh_forward_backward_properties(gpu):
         assert float(a[~vis].abs().max()) == 0.0 and float(a[vis].abs().max()) > 0.0
 
 
-@pytest.mark.parametrize("kind", ["nan_pos", "inf_pos", "zero_quat", "nan_scale", "huge_scale", "zero_scale", "neg_z"])
+@pytest.mark.parametrize("kind", ["nan_pos", "inf_pos", "zero_quat", "nan_scale", "huge_scale", "zero_scale", "neg_z",
+                                  "nan_opa", "nan_rgb", "inf_opa"])
 def test_frame_degenerate_inputs(gpu, kind):
     """Non-finite / degenerate parameters must neither hang nor corrupt anything else: the pair list still
-    equals the oracle's (NaN comparisons behave like the reference's) and so does the image.  (A NaN opacity
-    or colour is not covered: it poisons every pixel of the tiles it touches here, only the still-live
-    pixels in the reference, because finished pixels are masked by a multiplication instead of a branch.)"""
+    equals the oracle's (NaN comparisons behave like the reference's) and so does the image -- including WHICH pixels
+    go NaN: a NaN opacity or colour reaches the pixels that are still live when its Gaussian comes up and leaves the
+    finished ones alone, as in the reference, which `break`s before it evaluates the Gaussian (gaussian.cu:906); the
+    kernel multiplies alpha and T with v_mul_legacy_f32 (0 x NaN = 0) and moves a NaN colour into the opacity (so a
+    NaN in ONE colour channel turns all three channels of the live pixels NaN, not just that one: compared per pixel)."""
     scene, cam = case(6_000, 160, 112, seed=3)
     idx = np.random.default_rng(1).choice(6_000, 60, replace=False)
     if kind == "nan_pos":
@@ -472,6 +475,14 @@ def test_frame_degenerate_inputs(gpu, kind):
         scene.scale[idx] = 0
     elif kind == "neg_z":
         scene.pos[idx, 2] = -1
+    elif kind == "nan_opa":
+        scene.opa[idx] = np.nan
+    elif kind == "inf_opa":
+        scene.opa[idx] = np.inf  # sigmoid = 1: alpha = G exactly, a legal fully opaque Gaussian
+    elif kind == "nan_rgb":
+        scene.rgb[idx, 1] = np.nan
+    if kind in ("nan_opa", "nan_rgb"):
+        scene.opa += 3.0  # opaque scene: most pixels are finished long before the list ends
     with np.errstate(all="ignore"):
         of = OracleFrame(scene, cam)
     r = FrameRenderer(gpu, max_pairs=1 << 18, training=True)
@@ -483,6 +494,10 @@ def test_frame_degenerate_inputs(gpu, kind):
     assert np.array_equal(v["sorted_ids"].cpu().numpy(), of.ids)
     got = img.detach().cpu().numpy()
     finite = np.isfinite(of.image)
+    if kind in ("nan_opa", "nan_rgb"):
+        assert 0.02 < 1.0 - finite.mean() < 0.98  # the case really separates live from finished pixels
+    if kind == "nan_rgb":
+        finite = np.repeat(finite.all(axis=2, keepdims=True), 3, axis=2)
     assert np.array_equal(np.isfinite(got), finite)
     assert np.abs(got[finite] - of.image[finite]).max() < IMG_ATOL
     img.sum().backward()  # must terminate; gradients of untouched Gaussians stay finite

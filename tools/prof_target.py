@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""One workload, nothing else: the process rocprofv3 is wrapped around for per-config kernel traces and PMC passes.
+
+    python tools/prof_target.py cfg5 [--frames 60] [--backward] [--sh-degree 3]
+
+Every kernel dispatched after the warm-up belongs to `frames` identical forward (and, with --backward, backward)
+frames of that BASELINE.json config, so per-kernel averages / counter sums in the rocprofv3 output are per-config
+numbers (bench.py mixes its legs).  Prints one JSON line with N, V, M and the hipEvent stage times of the same run.
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "3d-gaussian-splatting_amd")]
+import torch
+
+from gs_frame import FrameRenderer
+from gs_scene import CONFIGS, make_camera, make_scene
+
+ap = argparse.ArgumentParser()
+ap.add_argument("config")
+ap.add_argument("--frames", type=int, default=60)
+ap.add_argument("--backward", action="store_true")
+ap.add_argument("--sh-degree", type=int, default=2)
+ap.add_argument("--no-stage-times", action="store_true", help="skip the hipEvent-bracketed frames (PMC passes)")
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+n, W, H, use_sh = CONFIGS[a.config]
+scene = make_scene(n, W, H, seed=2023, use_sh=use_sh, sh_degree=a.sh_degree)
+cam = make_camera(W, H)
+params = [torch.from_numpy(x).to(dev) for x in (scene.pos, scene.quat, scene.scale, scene.opa, scene.rgb)]
+r = FrameRenderer(dev, max_pairs=1 << 20, training=a.backward, auto_grow=True)
+img, _ = r.forward(*params, cam)
+st = r.stats()
+r.max_pairs = int(st.pairs * 1.1) + 4096
+r.auto_grow = False
+img, _ = r.forward(*params, cam)
+g = (torch.sign(img - 0.5) / img.numel()).contiguous()
+for _ in range(a.frames):
+    img, _ = r.forward(*params, cam)
+    if a.backward:
+        r.backward(g)
+torch.cuda.synchronize()
+out = {"config": a.config, "n": n, "visible": st.visible, "tile_pairs": st.pairs, "frames": a.frames,
+       "backward": a.backward, "sh_degree": a.sh_degree if use_sh else None}
+if not a.no_stage_times:
+    pf = [r.profile_forward(*params, cam) for _ in range(12)][4:]
+    out["forward_stage_ms"] = {k: round(statistics.median(p[k] for p in pf), 4) for k in pf[0]}
+    if a.backward:
+        pb = [r.profile_backward(g) for _ in range(8)][3:]
+        out["backward_stage_ms"] = {k: round(statistics.median(p[k] for p in pb), 4) for k in pb[0]}
+print(json.dumps(out), flush=True)
