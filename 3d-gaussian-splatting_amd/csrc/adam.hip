@@ -42,11 +42,13 @@ __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, 
 
 __global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ param, const float *__restrict__ grad,
                                                    float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq,
-                                                   int64_t n, AdamGroups G, float one_m_b1, float b2, float one_m_b2,
-                                                   float inv_bc2_sqrt, float eps, float *__restrict__ stat,
-                                                   int64_t stat_begin, int64_t stat_end, int stat_mode) {
-    const int64_t n4 = n >> 2;
-    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (int64_t)gridDim.x * blockDim.x) {
+                                                   int64_t lo, int64_t hi, AdamGroups G, float one_m_b1, float b2,
+                                                   float one_m_b2, float inv_bc2_sqrt, float eps,
+                                                   float *__restrict__ stat, int64_t stat_begin, int64_t stat_end,
+                                                   int stat_mode) {
+    // elements [lo, hi) of the (16-byte aligned) arrays: whole float4s [q0, q1) + up to three scalars at either end
+    const int64_t q0 = (lo + 3) >> 2, q1 = hi >> 2;
+    for (int64_t q = q0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < q1; q += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = q << 2;
         float4 p = reinterpret_cast<float4 *>(param)[q];
         const float4 g = reinterpret_cast<const float4 *>(grad)[q];
@@ -72,9 +74,16 @@ __global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ param, co
             }
         }
     }
-    // tail (n not a multiple of 4)
-    const int64_t t = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) {
+    // ragged ends (every element's update is independent of how the range is cut)
+    const int64_t head_end = (q0 << 2) < hi ? (q0 << 2) : hi;
+    const int64_t tail_begin = (q1 << 2) > head_end ? (q1 << 2) : head_end;
+    const int64_t gt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t t = -1;
+    if (lo + gt < head_end)
+        t = lo + gt;
+    else if (gt >= 4 && tail_begin + (gt - 4) < hi)
+        t = tail_begin + (gt - 4);
+    if (t >= 0) {
         float p = param[t], m = exp_avg[t], v = exp_avg_sq[t];
         const float g = grad[t];
         adam_one(p, g, m, v, group_step(G, t), one_m_b1, b2, one_m_b2, inv_bc2_sqrt, eps);
@@ -112,17 +121,18 @@ extern "C" int gs_grad_stat_update(const float *grad, float *stat, int64_t n, in
     return 0;
 }
 
-extern "C" int gs_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
-                            int32_t n_groups, const int64_t *group_end, const float *lr, float beta1, float beta2,
-                            float eps, int64_t step, float *grad_stat, int64_t stat_begin, int64_t stat_end,
-                            int32_t stat_mode, gs_stream_t stream) {
+static int adam_step_impl(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                          int64_t range_begin, int64_t range_end, int32_t n_groups, const int64_t *group_end,
+                          const float *lr, float beta1, float beta2, float eps, int64_t step, float *grad_stat,
+                          int64_t stat_begin, int64_t stat_end, int32_t stat_mode, gs_stream_t stream) {
     GS_CHECK_ARG(n >= 0, "n < 0");
+    GS_CHECK_ARG(range_begin >= 0 && range_begin <= range_end && range_end <= n, "bad element range");
     GS_CHECK_ARG(n_groups >= 1 && n_groups <= GS_ADAM_MAX_GROUPS, "n_groups must be in [1, 8]");
     GS_CHECK_ARG(group_end && lr, "null group table");
     GS_CHECK_ARG(step >= 1, "step counts from 1 (torch.optim.Adam increments before the update)");
     GS_CHECK_ARG(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f, "bad hyper-parameters");
     GS_CHECK_ARG(stat_mode >= 0 && stat_mode <= 2, "stat_mode must be 0 (off), 1 (max) or 2 (sum)");
-    if (n == 0) return 0;
+    if (range_end == range_begin) return 0;
     GS_CHECK_ARG(param && grad && exp_avg && exp_avg_sq, "null pointer");
     GS_CHECK_ARG((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
                  "buffers must be 16-byte aligned");
@@ -140,12 +150,30 @@ extern "C" int gs_adam_step(float *param, const float *grad, float *exp_avg, flo
     }
     GS_CHECK_ARG(group_end[n_groups - 1] == n, "the groups must cover [0, n)");
     G.n = n_groups;
-    int64_t blocks = gs_div_up(gs_div_up(n, 4) > 0 ? gs_div_up(n, 4) : 1, 256);
+    const int64_t len = range_end - range_begin;
+    int64_t blocks = gs_div_up(gs_div_up(len, 4) > 0 ? gs_div_up(len, 4) : 1, 256);
     if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride beyond 16 workgroups per CU
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
-                       exp_avg_sq, n, G, 1.0f - beta1, beta2, 1.0f - beta2, (float)(1.0 / sqrt(bc2)), eps, grad_stat,
-                       stat_begin, stat_end, (int)stat_mode);
+                       exp_avg_sq, range_begin, range_end, G, 1.0f - beta1, beta2, 1.0f - beta2,
+                       (float)(1.0 / sqrt(bc2)), eps, grad_stat, stat_begin, stat_end, (int)stat_mode);
     GS_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int gs_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                            int32_t n_groups, const int64_t *group_end, const float *lr, float beta1, float beta2,
+                            float eps, int64_t step, float *grad_stat, int64_t stat_begin, int64_t stat_end,
+                            int32_t stat_mode, gs_stream_t stream) {
+    return adam_step_impl(param, grad, exp_avg, exp_avg_sq, n, 0, n, n_groups, group_end, lr, beta1, beta2, eps, step,
+                          grad_stat, stat_begin, stat_end, stat_mode, stream);
+}
+
+extern "C" int gs_adam_step_range(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                                  int64_t range_begin, int64_t range_end, int32_t n_groups, const int64_t *group_end,
+                                  const float *lr, float beta1, float beta2, float eps, int64_t step,
+                                  float *grad_stat, int64_t stat_begin, int64_t stat_end, int32_t stat_mode,
+                                  gs_stream_t stream) {
+    return adam_step_impl(param, grad, exp_avg, exp_avg_sq, n, range_begin, range_end, n_groups, group_end, lr, beta1,
+                          beta2, eps, step, grad_stat, stat_begin, stat_end, stat_mode, stream);
 }

@@ -359,8 +359,9 @@ __device__ __forceinline__ uint32_t tile_rect(float cx, float cy, const float cv
 
 // "dist" (calc_tile_info_kernel, gaussian.cu:101-136): a Gaussian is listed in every tile whose centre is closer than
 // sqrt(thresh) to its own centre.  The listed tiles are decided per tile by gs_dist_listed (gs_common.h, the
-// reference's own fp32 comparison); this is only the bounding square of the disc, one tile of slack on every side,
-// over which the binning walks and the gradient rows are laid out.  NaN / infinite centres list nothing, as there.
+// reference's own fp32 comparison); this is only the bounding square of the disc, with one tile of slack on every side
+// (the index arithmetic below is not the reference's edge arithmetic; it is off by rounding only), over which the
+// binning walks and the gradient rows are laid out.  NaN / infinite centres list nothing, as there.
 __device__ __forceinline__ uint32_t dist_rect(float cx, float cy, const ProjectParams &P, uint32_t &y0, uint32_t &y1,
                                               uint32_t &x0, uint32_t &x1) {
     y0 = y1 = x0 = x1 = 0;
@@ -371,10 +372,11 @@ __device__ __forceinline__ uint32_t dist_rect(float cx, float cy, const ProjectP
     const float ly = ((cy - P.dist_radius) * P.fy + P.half_padh - 8.0f) * 0.0625f;
     const float hy = ((cy + P.dist_radius) * P.fy + P.half_padh - 8.0f) * 0.0625f;
     if (hx < -1.0f || hy < -1.0f || lx > (float)P.ntx || ly > (float)P.nty) return 0;
-    x0 = gs_f2u_sat(floorf(lx) - 1.0f);
-    y0 = gs_f2u_sat(floorf(ly) - 1.0f);
-    x1 = gs_f2u_sat(ceilf(hx) + 2.0f);
-    y1 = gs_f2u_sat(ceilf(hy) + 2.0f);
+    // centres i with lx < i < hx can be listed: [ceil(lx), floor(hx)] -> one more on either side
+    x0 = gs_f2u_sat(floorf(lx));
+    y0 = gs_f2u_sat(floorf(ly));
+    x1 = gs_f2u_sat(ceilf(hx) + 1.0f);
+    y1 = gs_f2u_sat(ceilf(hy) + 1.0f);
     if (x1 > P.ntx) x1 = P.ntx;
     if (y1 > P.nty) y1 = P.nty;
     if (x0 > x1) x0 = x1;
@@ -451,7 +453,11 @@ __global__ void __launch_bounds__(256) frame_project_kernel(
 // in emission order: Gaussian g owns rows [pair_offsets[g], +tiles_touched[g]).  They are summed
 // here in a fixed order (the reference's index_put_(accumulate=True), but deterministic) and pushed
 // through the projection + activation backward.  Culled Gaussians get zeros.
-template <int CDIM>
+// PART: 0 = everything; 1 = only the projection / activation backward (grad_pos, grad_quat, grad_scale -- the
+// "geometry" bucket of the view-parallel gradient exchange); 2 = only grad_opa and grad_rgb (the "colour" bucket).
+// Parts 1 and 2 read the same rows and add them in the same order as part 0: their outputs are bit-identical to it.
+// They exist so that the all-reduce of the first bucket can run underneath the second kernel (gs_dp.py).
+template <int CDIM, int PART = 0>
 __global__ void __launch_bounds__(256) frame_project_backward_kernel(
     const float *__restrict__ pos, const float4 *__restrict__ quat, const float *__restrict__ scale,
     int64_t n, ProjectParams P, const float4 *__restrict__ rec_geom,
@@ -564,18 +570,23 @@ __global__ void __launch_bounds__(256) frame_project_backward_kernel(
         // (measured: the LDS detour costs 25 % here)
         for (uint64_t k = 0; k < cnt && off + k < max_pairs && !big; ++k) {
             const float4 *row = rows + (off + k) * RW4;
-            const float4 r0 = row[0], r1 = row[1];
-            d0.x += r0.x; d0.y += r0.y; d0.z += r0.z; d0.w += r0.w;
+            if (PART != 2) {
+                const float4 r0 = row[0];
+                d0.x += r0.x; d0.y += r0.y; d0.z += r0.z; d0.w += r0.w;
+            }
+            const float4 r1 = row[1];
             d1.x += r1.x; d1.y += r1.y; d1.z += r1.z; d1.w += r1.w;  // d1.w: SH coefficient 0
+            if (PART != 1) {
 #pragma unroll
-            for (int m = 0; m < RW4 - 2; ++m) {
-                const float4 r = row[2 + m];
-                gsh[4 * m] += r.x; gsh[4 * m + 1] += r.y; gsh[4 * m + 2] += r.z; gsh[4 * m + 3] += r.w;
+                for (int m = 0; m < RW4 - 2; ++m) {
+                    const float4 r = row[2 + m];
+                    gsh[4 * m] += r.x; gsh[4 * m + 1] += r.y; gsh[4 * m + 2] += r.z; gsh[4 * m + 3] += r.w;
+                }
             }
         }
     }
     if (!valid) return;
-    if (vis) {
+    if (vis && PART != 2) {
         float p[3], sraw[3], q[4], s[3];
         load3(pos, pid, p);
         load3(scale, pid, sraw);
@@ -596,6 +607,8 @@ __global__ void __launch_bounds__(256) frame_project_backward_kernel(
             else  // trunc_exp backward (renderer.py:97-100): g * exp(clamp(x, -1, 1))
                 gsr[k] = gs[k] * expf(fminf(fmaxf(sraw[k], -1.0f), 1.0f));
         }
+    }
+    if (vis && PART != 1) {
         gopa = d1.z * g.w * (1.0f - g.w);
         if (CDIM == 3) {
             const float4 c = rec_color[pid * GS_REC_STRIDE];
@@ -604,13 +617,16 @@ __global__ void __launch_bounds__(256) frame_project_backward_kernel(
             gcol[2] = d2.y * c.z * (1.0f - c.z);
         }
     }
-    grad_pos[pid * 3 + 0] = gp[0];
-    grad_pos[pid * 3 + 1] = gp[1];
-    grad_pos[pid * 3 + 2] = gp[2];
-    grad_quat[pid] = make_float4(gqr[0], gqr[1], gqr[2], gqr[3]);
-    grad_scale[pid * 3 + 0] = gsr[0];
-    grad_scale[pid * 3 + 1] = gsr[1];
-    grad_scale[pid * 3 + 2] = gsr[2];
+    if (PART != 2) {
+        grad_pos[pid * 3 + 0] = gp[0];
+        grad_pos[pid * 3 + 1] = gp[1];
+        grad_pos[pid * 3 + 2] = gp[2];
+        grad_quat[pid] = make_float4(gqr[0], gqr[1], gqr[2], gqr[3]);
+        grad_scale[pid * 3 + 0] = gsr[0];
+        grad_scale[pid * 3 + 1] = gsr[1];
+        grad_scale[pid * 3 + 2] = gsr[2];
+    }
+    if (PART == 1) return;
     grad_opa[pid] = gopa;
     if (CDIM == 3) {
         grad_rgb[pid * 3 + 0] = gcol[0];
@@ -738,20 +754,30 @@ int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t strea
 }
 
 int gs_stage_project_backward(const gs_frame *f, const gs_frame_ws &ws, float *grad_pos, float *grad_quat,
-                              float *grad_scale, float *grad_opa, float *grad_rgb, hipStream_t stream) {
+                              float *grad_scale, float *grad_opa, float *grad_rgb, int part, hipStream_t stream) {
     ProjectParams P = make_params(f);
     int nblk = (int)gs_div_up(f->N, 256);
-#define GS_LAUNCH_PROJECT_BWD(CD)                                                                                  \
-    hipLaunchKernelGGL(frame_project_backward_kernel<CD>, dim3(nblk), dim3(256), 0, stream, f->pos,              \
+#define GS_LAUNCH_PROJECT_BWD(CD, PT)                                                                              \
+    hipLaunchKernelGGL((frame_project_backward_kernel<CD, PT>), dim3(nblk), dim3(256), 0, stream, f->pos,         \
                        (const float4 *)f->quat, f->scale, f->N, P, ws.rec_geom, ws.rec_color,                     \
                        (const float4 *)ws.rows, ws.pair_offsets, ws.tiles_touched, (uint64_t)f->max_pairs,        \
                        grad_pos, (float4 *)grad_quat, grad_scale, grad_opa, grad_rgb)
+#define GS_LAUNCH_PROJECT_BWD_PARTS(CD)  \
+    do {                                 \
+        if (part == 1)                   \
+            GS_LAUNCH_PROJECT_BWD(CD, 1); \
+        else if (part == 2)              \
+            GS_LAUNCH_PROJECT_BWD(CD, 2); \
+        else                             \
+            GS_LAUNCH_PROJECT_BWD(CD, 0); \
+    } while (0)
     if (f->color_dim == 48)
-        GS_LAUNCH_PROJECT_BWD(48);
+        GS_LAUNCH_PROJECT_BWD_PARTS(48);
     else if (f->color_dim == 27)
-        GS_LAUNCH_PROJECT_BWD(27);
+        GS_LAUNCH_PROJECT_BWD_PARTS(27);
     else
-        GS_LAUNCH_PROJECT_BWD(3);
+        GS_LAUNCH_PROJECT_BWD_PARTS(3);
+#undef GS_LAUNCH_PROJECT_BWD_PARTS
 #undef GS_LAUNCH_PROJECT_BWD
     GS_CHECK_LAUNCH();
     return 0;

@@ -275,12 +275,19 @@ extern "C" int gs_frame_forward_profile(const gs_frame *f, float *stage_ms_host,
     return frame_forward_impl(f, (hipStream_t)stream, stage_ms_host);
 }
 
+// part: 0 = the whole backward; GS_BWD_RASTER (1) = the raster backward only (per-pair gradient rows), then any of
+// GS_BWD_GEOMETRY (2) = grad_pos / quat / scale and GS_BWD_COLOR (4) = grad_opa / rgb from those rows, in any order.
 static int frame_backward_impl(const gs_frame *f, const float *grad_image, float *grad_pos, float *grad_quat,
-                               float *grad_scale, float *grad_opa, float *grad_rgb, hipStream_t s, float *stage_ms) {
+                               float *grad_scale, float *grad_opa, float *grad_rgb, int part, hipStream_t s,
+                               float *stage_ms) {
     int rc = validate(f);
     if (rc) return rc;
     GS_CHECK_ARG(f->training && f->image_padded, "gs_frame_backward needs a training forward (image_padded kept)");
-    GS_CHECK_ARG(grad_image && grad_pos && grad_quat && grad_scale && grad_opa && grad_rgb, "null pointer");
+    GS_CHECK_ARG(part == 0 || part == GS_BWD_RASTER || part == GS_BWD_GEOMETRY || part == GS_BWD_COLOR,
+                 "part must be 0, GS_BWD_RASTER, GS_BWD_GEOMETRY or GS_BWD_COLOR");
+    GS_CHECK_ARG(part == GS_BWD_GEOMETRY || part == GS_BWD_COLOR || grad_image, "null pointer");
+    GS_CHECK_ARG(part == GS_BWD_RASTER || part == GS_BWD_COLOR || (grad_pos && grad_quat && grad_scale), "null pointer");
+    GS_CHECK_ARG(part == GS_BWD_RASTER || part == GS_BWD_GEOMETRY || (grad_opa && grad_rgb), "null pointer");
     GS_CHECK_ARG(((uintptr_t)grad_quat & 15) == 0, "grad_quat must be 16-byte aligned");
     if (f->N == 0) return 0;
     gs_frame_ws ws = gs_frame_carve(f->workspace, f->N, f->max_pairs, f->width, f->height, f->color_dim, 1);
@@ -289,17 +296,31 @@ static int frame_backward_impl(const gs_frame *f, const float *grad_image, float
     sorted_buffers(f, ws, &skeys, &sids, &okeys);
     StageTimer tm(stage_ms != nullptr, s);
     tm.mark();
-    const bool prepared = join_prepared(f, s);
-    if ((rc = gs_stage_raster_backward(f, ws, sids, grad_image, s, prepared))) return rc;
+    if (part == 0 || part == GS_BWD_RASTER) {
+        const bool prepared = join_prepared(f, s);
+        if ((rc = gs_stage_raster_backward(f, ws, sids, grad_image, s, prepared))) return rc;
+    }
     tm.mark();
-    if ((rc = gs_stage_project_backward(f, ws, grad_pos, grad_quat, grad_scale, grad_opa, grad_rgb, s))) return rc;
+    if (part != GS_BWD_RASTER &&
+        (rc = gs_stage_project_backward(f, ws, grad_pos, grad_quat, grad_scale, grad_opa, grad_rgb,
+                                        part == GS_BWD_GEOMETRY ? 1 : part == GS_BWD_COLOR ? 2 : 0, s)))
+        return rc;
     tm.mark();
     return tm.finish(stage_ms, 3);
 }
 
 extern "C" int gs_frame_backward(const gs_frame *f, const float *grad_image, float *grad_pos, float *grad_quat,
                                  float *grad_scale, float *grad_opa, float *grad_rgb, gs_stream_t stream) {
-    return frame_backward_impl(f, grad_image, grad_pos, grad_quat, grad_scale, grad_opa, grad_rgb,
+    return frame_backward_impl(f, grad_image, grad_pos, grad_quat, grad_scale, grad_opa, grad_rgb, 0,
+                               (hipStream_t)stream, nullptr);
+}
+
+extern "C" int gs_frame_backward_part(const gs_frame *f, const float *grad_image, float *grad_pos, float *grad_quat,
+                                      float *grad_scale, float *grad_opa, float *grad_rgb, int32_t part,
+                                      gs_stream_t stream) {
+    GS_CHECK_ARG(part == GS_BWD_RASTER || part == GS_BWD_GEOMETRY || part == GS_BWD_COLOR,
+                 "part must be GS_BWD_RASTER, GS_BWD_GEOMETRY or GS_BWD_COLOR");
+    return frame_backward_impl(f, grad_image, grad_pos, grad_quat, grad_scale, grad_opa, grad_rgb, part,
                                (hipStream_t)stream, nullptr);
 }
 
@@ -307,7 +328,7 @@ extern "C" int gs_frame_backward_profile(const gs_frame *f, const float *grad_im
                                          float *grad_quat, float *grad_scale, float *grad_opa, float *grad_rgb,
                                          float *stage_ms_host, gs_stream_t stream) {
     GS_CHECK_ARG(stage_ms_host != nullptr, "stage_ms_host is null");
-    return frame_backward_impl(f, grad_image, grad_pos, grad_quat, grad_scale, grad_opa, grad_rgb,
+    return frame_backward_impl(f, grad_image, grad_pos, grad_quat, grad_scale, grad_opa, grad_rgb, 0,
                                (hipStream_t)stream, stage_ms_host);
 }
 

@@ -136,7 +136,7 @@ static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pair
 // stage entry points (defined across the .hip files)
 int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream);
 int gs_stage_project_backward(const gs_frame *f, const gs_frame_ws &ws, float *grad_pos, float *grad_quat,
-                              float *grad_scale, float *grad_opa, float *grad_rgb, hipStream_t stream);
+                              float *grad_scale, float *grad_opa, float *grad_rgb, int part, hipStream_t stream);
 int gs_stage_scan_emit(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream);
 int gs_stage_tile_sort(const gs_frame *f, const gs_frame_ws &ws, uint64_t *keys, uint32_t *ids, uint64_t *scratch,
                        hipStream_t stream);

@@ -52,12 +52,12 @@ __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elemen
 #ifndef GS_FWD_LEGACY_MUL
 #define GS_FWD_LEGACY_MUL 1  // 0: plain packed multiply (A/B switch for tools/ab_variants.py)
 #endif
-// a * b with DX9 zero rules: 0 x anything (NaN, infinity) = 0
-__device__ __forceinline__ float mul_legacy(float a, float b) {
-    float r;
-    asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
+// a * b with DX9 zero rules: 0 x anything (NaN, infinity) = 0 (v_mul_legacy_f32).  Declared as the LLVM intrinsic, NOT
+// as inline assembly: the operand is the result of a transcendental (v_exp_f32), which on gfx940/950 needs a wait state
+// before a VALU instruction may read it -- the compiler inserts it for instructions it knows, not for opaque asm text
+// (first version: stale alphas in a few pixels per frame).
+extern "C" __device__ float gs_fmul_legacy(float, float) __asm("llvm.amdgcn.fmul.legacy");
+__device__ __forceinline__ float mul_legacy(float a, float b) { return gs_fmul_legacy(a, b); }
 
 // Exact per-pixel liveness in ONE packed instruction: m = clamp((t - 0.0001f) * 2^100) is 1.0 when
 // t > 0.0001f and 0.0 otherwise (the fma is exact up to its final rounding, and the smallest positive

@@ -324,7 +324,11 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_scatter_kernel(
             }
             walk_rect<DIST>(cur[k], g, ntx, load_xy(b, cur[k]), D, [&](uint32_t tile, uint32_t id, uint32_t d) {
                 const uint32_t slot = atomicAdd(&s_slot[tile], 1u);
+#ifdef GS_DIAG_SCATTER_SMALL  // timing experiment only (tools/ab_variants.py): every store lands in a 128 KiB window
+                out[slot & 0x3fff] = ((uint64_t)d << 32) | id;
+#else
                 out[slot] = ((uint64_t)d << 32) | id;
+#endif
             });
         }
     }

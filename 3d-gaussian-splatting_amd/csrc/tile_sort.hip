@@ -211,6 +211,9 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(uint64_t *__restrict__ k
     // PACKED: the sorted keys are only written on request (GS_FRAME_EMIT_SORTED_KEYS): the raster kernels read the
     // sorted ids alone, and 8 of the 12 bytes this kernel would store per pair are the keys
     auto store = [&](uint32_t i, uint64_t v) {
+#ifdef GS_DIAG_SCATTER_SMALL  // the scatter experiment leaves garbage pairs: keep the ids inside any scene >= 64 k
+        v &= 0xffffffff0000ffffull;
+#endif
         ids[start + i] = (uint32_t)v;
         if (!PACKED || keys) keys[start + i] = ((uint64_t)tile << 32) | (v >> 32);
     };

@@ -76,6 +76,8 @@ gs_sort_pairs_bits = _sig("gs_sort_pairs_bits", ci, vp, vp, vp, vp, vp, i64, ci,
 gs_frame_workspace_bytes = _sig("gs_frame_workspace_bytes", sz, i64, i64, i32, i32, i32, i32)
 gs_frame_forward = _sig("gs_frame_forward", ci, C.POINTER(GsFrame), vp)
 gs_frame_backward = _sig("gs_frame_backward", ci, C.POINTER(GsFrame), vp, vp, vp, vp, vp, vp, vp)
+gs_frame_backward_part = _sig("gs_frame_backward_part", ci, C.POINTER(GsFrame), vp, vp, vp, vp, vp, vp, i32, vp)
+GS_BWD_RASTER, GS_BWD_GEOMETRY, GS_BWD_COLOR = 1, 2, 4
 gs_frame_forward_profile = _sig("gs_frame_forward_profile", ci, C.POINTER(GsFrame), C.POINTER(f32), vp)
 gs_frame_backward_profile = _sig("gs_frame_backward_profile", ci, C.POINTER(GsFrame), vp, vp, vp, vp, vp, vp,
                                  C.POINTER(f32), vp)
@@ -85,6 +87,8 @@ gs_frame_debug_views = _sig("gs_frame_debug_views", ci, C.POINTER(GsFrame), C.PO
 
 gs_adam_step = _sig("gs_adam_step", ci, vp, vp, vp, vp, i64, i32, C.POINTER(i64), C.POINTER(f32), f32, f32, f32, i64,
                     vp, i64, i64, i32, vp)
+gs_adam_step_range = _sig("gs_adam_step_range", ci, vp, vp, vp, vp, i64, i64, i64, i32, C.POINTER(i64), C.POINTER(f32),
+                          f32, f32, f32, i64, vp, i64, i64, i32, vp)
 gs_grad_stat_update = _sig("gs_grad_stat_update", ci, vp, vp, i64, i32, vp)
 gs_frame_async_create = _sig("gs_frame_async_create", ci, C.POINTER(vp))
 gs_frame_async_wait = _sig("gs_frame_async_wait", ci, vp, vp)
@@ -114,8 +118,8 @@ EXPORTS = [
     "gs_gather_gaussians", "gs_draw", "gs_draw_backward_workspace_bytes", "gs_draw_backward",
     "gs_sort_pairs_tmp_bytes", "gs_sort_pairs", "gs_sort_pairs_bits", "gs_frame_workspace_bytes", "gs_frame_forward",
     "gs_frame_stats_async", "gs_frame_debug_views", "gs_frame_backward", "gs_frame_forward_profile",
-    "gs_frame_async_create", "gs_frame_async_wait", "gs_frame_async_destroy",
-    "gs_frame_backward_profile", "gs_adam_step", "gs_grad_stat_update", "gs_loss_workspace_bytes", "gs_loss_l1_ssim",
+    "gs_frame_backward_part", "gs_frame_async_create", "gs_frame_async_wait", "gs_frame_async_destroy",
+    "gs_frame_backward_profile", "gs_adam_step", "gs_adam_step_range", "gs_grad_stat_update", "gs_loss_workspace_bytes", "gs_loss_l1_ssim",
     "gs_densify_workspace_bytes", "gs_densify_classify", "gs_densify_apply",
 ]
 

@@ -1,4 +1,4 @@
-"""View-parallel training support: one flat gradient bucket, one RCCL all-reduce per iteration.
+"""View-parallel training support: one flat gradient buffer, exchanged as one or two RCCL all-reduces per iteration.
 
 The reference is single-GPU (no torch.distributed anywhere).  The natural
 shard of its workload is the training VIEW: every iteration renders one camera (train.py:95-96),
@@ -11,7 +11,15 @@ Gaussians and the parameter gradients are averaged.  Layout choices for MI355X /
     N*(4+3+3+1+C)*4 bytes (134 MB at 2.4 M Gaussians) -- one large collective instead of five
     small ones, which is what a point-to-point xGMI mesh wants (per-link bound, 7 links/GPU);
   * the reduction is the mean over views: ReduceOp.AVG inside the RCCL collective (SUM + an in-place scale
-    by 1/world on backends without AVG, i.e. gloo in the CPU tests).
+    by 1/world on backends without AVG, i.e. gloo in the CPU tests);
+  * the buffer is also two BUCKETS -- "geometry" = [quat | pos | scale] (10 N floats) and "color" = [opa | rgb]
+    ((1 + C) N floats), each contiguous -- because every gradient of a frame only becomes final in the LAST kernel of
+    the backward (the per-Gaussian sum of the per-pair rows, frame_project_backward_kernel): that kernel exists in a
+    geometry-only and a colour-only flavour (gs_frame_backward_part), so the asynchronous all-reduce of the bucket
+    written first runs underneath the kernel that writes the other one, and the fused Adam of the first bucket
+    underneath the all-reduce of the second (``begin_bucket`` / ``finish_bucket``; gs_train.Trainer uses them when
+    a process group is up).  That is all the overlap the step structure offers without applying stale gradients:
+    what runs after the raster backward is short next to the exchange.
 
 Works with any torch.distributed backend ("nccl" == RCCL on ROCm; "gloo" in CPU tests).
 """
@@ -48,6 +56,9 @@ class FlatGaussianParams:
         names = ("pos", "quat", "scale", "opa", "rgb")
         self.params: List[torch.Tensor] = [views_p[k] for k in names]
         self.grads: List[torch.Tensor] = [views_g[k] for k in names]
+        n_geom = sum(by_name[k].numel() for k in ("quat", "pos", "scale"))
+        self.bucket_ranges = {"geometry": (0, n_geom), "color": (n_geom, total)}  # element ranges of the flat buffers
+        self._pending = {}
 
     @property
     def bucket_bytes(self) -> int:
@@ -72,6 +83,32 @@ class FlatGaussianParams:
             work.wait()
             if not self._avg_in_collective:
                 self.flat_grad.mul_(1.0 / self.world_size)
+
+    # ---- bucketed, asynchronous exchange ---------------------------------------------------------------------
+    def collective_active(self) -> bool:
+        return dist.is_initialized() and (self.world_size > 1 or self.force_collective)
+
+    def begin_bucket(self, name: str):
+        """Start the mean all-reduce of one bucket ("geometry" or "color") without waiting for it.  The collective
+        runs on the process group's own stream, which first waits for everything enqueued on the current stream so
+        far -- i.e. for the kernel that wrote the bucket."""
+        if not self.collective_active():
+            return
+        lo, hi = self.bucket_ranges[name]
+        avg = dist.get_backend() == "nccl"
+        work = dist.all_reduce(self.flat_grad[lo:hi], op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=True)
+        self._pending[name] = (work, avg)
+
+    def finish_bucket(self, name: str):
+        """Make the current stream wait for the bucket's all-reduce (and scale it on backends without AVG)."""
+        pend = self._pending.pop(name, None)
+        if pend is None:
+            return
+        work, avg = pend
+        work.wait()
+        if not avg:
+            lo, hi = self.bucket_ranges[name]
+            self.flat_grad[lo:hi].mul_(1.0 / self.world_size)
 
     def broadcast_params(self, src: int = 0):
         if self.world_size > 1 and dist.is_initialized():

@@ -236,24 +236,35 @@ class FrameRenderer:
             break
         return image, padded
 
-    def backward(self, grad_image, out=None):
+    def backward(self, grad_image, out=None, part: int = 0):
         """dL/d(image) -> (grad_pos, grad_quat, grad_scale, grad_opa, grad_rgb).  ``out`` may
-        supply the five destination tensors (e.g. views of one flat all-reduce bucket)."""
+        supply the five destination tensors (e.g. views of one flat all-reduce bucket).
+
+        ``part`` (view-parallel gradient exchange, gs_dp.py): 0 = everything; ``_lib.GS_BWD_RASTER`` = only the
+        raster backward (per-pair rows), then ``GS_BWD_GEOMETRY`` (pos / quat / scale) and ``GS_BWD_COLOR`` (opa /
+        rgb) fill their share of ``out`` in either order, bit-identical to the one-call backward; ``grad_image``
+        is only read by part 0 / GS_BWD_RASTER."""
         f = self._frame
         if f is None or not f.training:
             raise RuntimeError("backward() needs a preceding forward(training=True)")
         pos, quat, scale, opa, rgb = self._keep[:5]
         if out is None:
             out = tuple(torch.empty_like(t) for t in (pos, quat, scale, opa, rgb))
-        grad_image = grad_image.contiguous()
-        if grad_image.dtype != torch.float32 or tuple(grad_image.shape) != (f.height, f.width, 3):
-            raise RuntimeError("grad_image must be float32 [H,W,3]")
+        if part in (0, _lib.GS_BWD_RASTER):
+            grad_image = grad_image.contiguous()
+            if grad_image.dtype != torch.float32 or tuple(grad_image.shape) != (f.height, f.width, 3):
+                raise RuntimeError("grad_image must be float32 [H,W,3]")
         for t, ref in zip(out, (pos, quat, scale, opa, rgb)):
             if t.shape != ref.shape or t.dtype != torch.float32 or not t.is_contiguous():
                 raise RuntimeError("gradient destinations must match the parameters")
         with torch.cuda.device(self.device):
-            _lib.check(_lib.gs_frame_backward(C.byref(f), grad_image.data_ptr(), *(t.data_ptr() for t in out),
-                                              self._stream().cuda_stream), "gs_frame_backward")
+            if part == 0:
+                _lib.check(_lib.gs_frame_backward(C.byref(f), grad_image.data_ptr(), *(t.data_ptr() for t in out),
+                                                  self._stream().cuda_stream), "gs_frame_backward")
+            else:
+                _lib.check(_lib.gs_frame_backward_part(C.byref(f), grad_image.data_ptr() if grad_image is not None
+                                                       else None, *(t.data_ptr() for t in out), int(part),
+                                                       self._stream().cuda_stream), "gs_frame_backward_part")
         return out
 
     def profile_forward(self, pos, quat, scale, opa, rgb, camera, training: Optional[bool] = None):

@@ -122,15 +122,20 @@ class FusedAdam:
         if self.accum_grad is not None:
             self.accum_grad.zero_()
 
-    def step(self):
-        self.step_count += 1
+    def step(self, bucket: Optional[str] = None, advance: bool = True):
+        """One Adam step over the whole flat buffer, or over one bucket of it ("geometry" / "color": gs_dp.py; the
+        step counter advances once per optimizer step -- pass ``advance=False`` for the second bucket)."""
+        if advance:
+            self.step_count += 1
         f = self.flat
         b, e = self._stat_range
-        _lib.check(_lib.gs_adam_step(f.flat_param.data_ptr(), f.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
-                                     self.exp_avg_sq.data_ptr(), f.flat_param.numel(), len(ORDER), self._ends, self._lr,
-                                     self.betas[0], self.betas[1], self.eps, self.step_count,
-                                     self.accum_grad.data_ptr() if self.accum_grad is not None else None, b, e,
-                                     self.stat_mode, torch.cuda.current_stream().cuda_stream), "gs_adam_step")
+        n = f.flat_param.numel()
+        lo, hi = (0, n) if bucket is None else f.bucket_ranges[bucket]
+        _lib.check(_lib.gs_adam_step_range(f.flat_param.data_ptr(), f.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
+                                           self.exp_avg_sq.data_ptr(), n, lo, hi, len(ORDER), self._ends, self._lr,
+                                           self.betas[0], self.betas[1], self.eps, self.step_count,
+                                           self.accum_grad.data_ptr() if self.accum_grad is not None else None, b, e,
+                                           self.stat_mode, torch.cuda.current_stream().cuda_stream), "gs_adam_step")
 
 
 class ImageLoss:
@@ -234,9 +239,11 @@ class Trainer:
             self._overflow_warned = self.renderer.overflowed_frames
         loss = self._loss_for(image.shape[0], image.shape[1])
         grad_image = loss(image, target)
-        self.renderer.backward(grad_image, out=self.flat.grads)
-        if o.scale_reg > 0 or o.opa_reg > 0:
-            self._add_regulariser_grads()
+        # With a process group the backward is issued in three parts so that the gradient exchange overlaps what
+        # little work follows the raster backward (gs_dp.py): rows -> the FIRST bucket's per-Gaussian sums -> its
+        # all-reduce starts -> the second bucket's sums run underneath it -> Adam of the first bucket underneath the
+        # second all-reduce.  The larger bucket goes first.  Whatever needs this rank's OWN gradients (regularisers,
+        # the per-view densification statistic) is applied to a bucket right before its all-reduce starts.
         if self.densify and accum_start:  # train.py:141-142 (before this step's gradient is accumulated)
             self.optimizer.clear_grad_stat()
             self.grad_counter = None
@@ -245,10 +252,34 @@ class Trainer:
         seen = None
         if self.densify and o.grad_accum_method == "mean":
             seen = (self.renderer.debug_views()["rec_geom"][:, 2] != 0).to(torch.float32)  # culling_mask
-        if self.view_stat is not None:  # this rank's view, before the gradients are averaged over the ranks
-            self.view_stat.update(self.flat.grads[0], seen)
-        self.flat.all_reduce_grads()
-        self.optimizer.step()  # also: accum_max_grad = max(|pos.grad|, accum) or += |pos.grad| (train.py:144-153)
+
+        def local_terms(bucket):
+            if bucket in (None, "geometry"):
+                if o.scale_reg > 0:  # train.py:108-109
+                    sc = self.flat.params[2]
+                    self.flat.grads[2].add_(torch.sign(sc), alpha=o.scale_reg / sc.numel())
+                if self.view_stat is not None:  # this rank's view, before the gradients are averaged over the ranks
+                    self.view_stat.update(self.flat.grads[0], seen)
+            if bucket in (None, "color") and o.opa_reg > 0:  # train.py:110-112
+                sg = torch.sigmoid(self.flat.params[3])
+                self.flat.grads[3].add_(sg * (1 - sg) * (1 - 2 * sg), alpha=o.opa_reg / sg.numel())
+
+        if self.flat.collective_active():
+            first, second = ("color", "geometry") if self.flat.grads[4].shape[1] > 9 else ("geometry", "color")
+            part_of = {"geometry": _lib.GS_BWD_GEOMETRY, "color": _lib.GS_BWD_COLOR}
+            self.renderer.backward(grad_image, out=self.flat.grads, part=_lib.GS_BWD_RASTER)
+            for name in (first, second):
+                self.renderer.backward(None, out=self.flat.grads, part=part_of[name])
+                local_terms(name)
+                self.flat.begin_bucket(name)
+            self.flat.finish_bucket(first)
+            self.optimizer.step(first)
+            self.flat.finish_bucket(second)
+            self.optimizer.step(second, advance=False)
+        else:
+            self.renderer.backward(grad_image, out=self.flat.grads)
+            local_terms(None)
+            self.optimizer.step()  # also: accum_max_grad = max(|pos.grad|, accum) or += |pos.grad| (train.py:144-153)
         if seen is not None and self.view_stat is None:
             self.grad_counter = seen if self.grad_counter is None else self.grad_counter + seen
         if self.densify and (control or only_delete):
@@ -260,17 +291,6 @@ class Trainer:
 
             reset_opa(self.flat.params[3])
         return loss.values
-
-    def _add_regulariser_grads(self):
-        """The two optional penalties of train.py:108-112 (both default to 0 and are off the hot path): their
-        closed-form gradients are added to the bucket with a few elementwise torch ops."""
-        o = self.opt
-        if o.scale_reg > 0:
-            s = self.flat.params[2]
-            self.flat.grads[2].add_(torch.sign(s), alpha=o.scale_reg / s.numel())
-        if o.opa_reg > 0:
-            sg = torch.sigmoid(self.flat.params[3])
-            self.flat.grads[3].add_(sg * (1 - sg) * (1 - 2 * sg), alpha=o.opa_reg / sg.numel())
 
     def adaptive_control(self, i_iter: int, densify: bool = True):
         """train.py:156-180: prune (+ clone / split when ``densify``), then a fresh optimizer."""

@@ -280,19 +280,22 @@ def main():
         from gs_train import TrainOptions, Trainer
 
         _, Wc, Hc, _ = CONFIGS[cfg]
-        target = torch.rand(Hc, Wc, 3, device=dev)
+        # target = the scene's own render + noise: a non-trivial loss gradient, but the scene stays where it is over the
+        # timed iterations (a random target would drive it away and change the pair count under the fixed workspace)
+        r0 = FrameRenderer(dev, max_pairs=int(pairs * 1.1) + 4096, auto_grow=False)
+        target = (r0.forward(*params, cam)[0] + 0.05 * torch.randn(Hc, Wc, 3, device=dev)).clamp_(0, 1).contiguous()
+        del r0
         tr = Trainer([t.clone() for t in params], [cam], [target], TrainOptions(), world_size=world,
-                     max_pairs=int(pairs * 1.1) + 4096)
+                     max_pairs=int(pairs * 1.25) + 4096)
         tr.flat.force_collective = use_dist or force
-        tr.renderer.auto_grow = False
         it = [0]
 
         def train_iter():
             tr.train_step(it[0], 0)
             it[0] += 1
 
-        settle(train_iter, 0.2)
-        dtt = time_frames(train_iter, k, 5)
+        dtt = time_frames(train_iter, k, 30)
+        assert tr.renderer.overflowed_frames == 0 and not tr.renderer.last_frame_overflowed(wait=True)
         detail = {}
         if rank == 0:
             rt, flat = tr.renderer, tr.flat

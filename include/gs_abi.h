@@ -261,6 +261,17 @@ int gs_frame_backward(const gs_frame *f, const float *grad_image, float *grad_po
                       float *grad_quat, float *grad_scale, float *grad_opa, float *grad_rgb,
                       gs_stream_t stream);
 
+/* The same backward in three calls, for the view-parallel gradient exchange (gs_dp.py): GS_BWD_RASTER runs the raster
+ * backward (per-pair gradient rows in the workspace; needs grad_image only), after which GS_BWD_GEOMETRY writes
+ * grad_pos / grad_quat / grad_scale and GS_BWD_COLOR writes grad_opa / grad_rgb -- in either order, each bit-identical
+ * to what gs_frame_backward writes -- so that the all-reduce of the bucket written first runs underneath the kernel
+ * that writes the other one.  Pointers a part does not write may be NULL. */
+#define GS_BWD_RASTER 1
+#define GS_BWD_GEOMETRY 2
+#define GS_BWD_COLOR 4
+int gs_frame_backward_part(const gs_frame *f, const float *grad_image, float *grad_pos, float *grad_quat,
+                           float *grad_scale, float *grad_opa, float *grad_rgb, int32_t part, gs_stream_t stream);
+
 /* ===================================================================================
  * Section C -- the training step around the frame
  * =================================================================================== */
@@ -276,6 +287,15 @@ int gs_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg
                  int32_t n_groups, const int64_t *group_end, const float *lr, float beta1, float beta2,
                  float eps, int64_t step, float *grad_stat, int64_t stat_begin, int64_t stat_end,
                  int32_t stat_mode, gs_stream_t stream);
+
+/* The same step restricted to the elements [range_begin, range_end) of the same arrays (group table and statistic range
+ * stay absolute): one bucket of the view-parallel gradient exchange at a time, so that the update of the bucket whose
+ * all-reduce has finished runs underneath the all-reduce of the next one.  Every element's update is what gs_adam_step
+ * computes for it.  The statistic is only touched where its range intersects [range_begin, range_end). */
+int gs_adam_step_range(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                       int64_t range_begin, int64_t range_end, int32_t n_groups, const int64_t *group_end,
+                       const float *lr, float beta1, float beta2, float eps, int64_t step, float *grad_stat,
+                       int64_t stat_begin, int64_t stat_end, int32_t stat_mode, gs_stream_t stream);
 
 /* The same statistic without the Adam update: stat[i] = max(stat[i], |grad[i]|) (stat_mode 1) or stat[i] += |grad[i]|
  * (stat_mode 2) for i < n.  View-parallel training (one view per GPU) needs it: train.py:145-154 accumulates the

@@ -124,8 +124,11 @@ def test_frame_tile_culling_method_dist(gpu, dist_thresh, W, H):
     scene, cam = case(12_000, W, H, seed=29)
     of = OracleFrame(scene, cam, tile_culling_method="dist", dist_thresh=dist_thresh)
     params = to_torch(scene, gpu, requires_grad=True)
-    r = FrameRenderer(gpu, max_pairs=6 * len(of.ids) + 4096, training=True, auto_grow=False,
-                      tile_culling_method="dist", tile_culling_dist_thresh=dist_thresh)
+    r = FrameRenderer(gpu, max_pairs=len(of.ids), training=True, auto_grow=True, tile_culling_method="dist",
+                      tile_culling_dist_thresh=dist_thresh)
+    r.forward(*params, cam)  # grows the workspace to the sum of the bounding squares
+    assert len(of.ids) < r.max_pairs < 12 * len(of.ids) + 8192
+    r.auto_grow = False
     img = r.render(*params, cam)
     v = r.debug_views()
     st = r.stats()

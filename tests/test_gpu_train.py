@@ -240,6 +240,91 @@ def test_per_view_statistic_path_equals_fused_path(gpu, mode):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("use_sh", [False, True])
+def test_backward_parts_and_bucketed_adam_equal_the_one_call_step(gpu, use_sh):
+    """The view-parallel gradient exchange issues the backward as GS_BWD_RASTER + GS_BWD_GEOMETRY + GS_BWD_COLOR
+    (either order) and Adam bucket by bucket (gs_adam_step_range), so that the all-reduce of one bucket runs under
+    the kernel of the other.  Nothing may change numerically: gradients and the stepped parameters are bit-identical
+    to gs_frame_backward + one gs_adam_step -- with an odd Gaussian count, where the colour bucket does not start
+    on a 16-byte boundary."""
+    from gaussian import _lib
+    from gs_dp import FlatGaussianParams
+    from gs_frame import FrameRenderer
+    from gs_scene import make_camera, make_scene
+    from gs_train import GROUPS, FusedAdam
+
+    W, H = 160, 112
+    scene, cam = make_scene(7001, W, H, seed=9, use_sh=use_sh), make_camera(W, H, yaw_deg=1.0)
+    params = to_torch(scene, gpu)
+    g = torch.randn(H, W, 3, device=gpu)
+    lrs = dict(zip(GROUPS, [0.03, 0.02, 0.003, 0.004, 0.005]))
+    outs = []
+    for order in (None, ("geometry", "color"), ("color", "geometry")):
+        flat = FlatGaussianParams([t.clone() for t in params])
+        assert flat.bucket_ranges["color"][0] % 4 != 0  # 10 N floats, N odd: misaligned on purpose
+        r = FrameRenderer(gpu, max_pairs=1 << 17, training=True, auto_grow=False)
+        opt = FusedAdam(flat, [lrs[k] for k in GROUPS], grad_stat="max")
+        for _ in range(3):
+            r.forward(*flat.params, cam)
+            flat.flat_grad.fill_(float("nan"))  # every element must be written by exactly one part
+            if order is None:
+                r.backward(g, out=flat.grads)
+                opt.step()
+            else:
+                part = {"geometry": _lib.GS_BWD_GEOMETRY, "color": _lib.GS_BWD_COLOR}
+                r.backward(g, out=flat.grads, part=_lib.GS_BWD_RASTER)
+                for name in order:
+                    r.backward(None, out=flat.grads, part=part[name])
+                opt.step(order[0])
+                opt.step(order[1], advance=False)
+        assert opt.step_count == 3 and bool(torch.isfinite(flat.flat_grad).all())
+        outs.append((flat.flat_grad.clone(), flat.flat_param.clone(), opt.exp_avg_sq.clone(), opt.accum_grad.clone()))
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
+    assert float((outs[0][1] - FlatGaussianParams(params).flat_param).abs().max()) > 0
+
+
+def test_trainer_bucketed_exchange_equals_plain_step(gpu):
+    """Trainer.train_step with a process group up (one rank, RCCL; the collective is forced) takes the bucketed,
+    asynchronous path -- rows, first bucket, its all-reduce, second bucket underneath it, Adam per bucket -- and must
+    reproduce the plain single-process step bit for bit, regularisers and densification statistic included."""
+    import os
+
+    import torch.distributed as dist
+
+    from gs_frame import FrameRenderer
+    from gs_scene import make_camera, make_scene
+    from gs_train import TrainOptions, Trainer
+
+    W, H = 128, 96
+    scene, cam = make_scene(3001, W, H, seed=6), make_camera(W, H)
+    gt = to_torch(scene, gpu)
+    target = FrameRenderer(gpu, max_pairs=1 << 16).forward(*gt, cam)[0].clone()
+    start = [t.clone() for t in gt]
+    start[4] = start[4] + 0.5 * torch.randn(start[4].shape, device=gpu, generator=torch.Generator(gpu).manual_seed(2))
+    opt = TrainOptions(n_iters=100, n_iters_warmup=3, scale_reg=0.01, opa_reg=0.02)
+    runs = []
+    for bucketed in (False, True):
+        if bucketed:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=gpu)
+        try:
+            tr = Trainer([t.clone() for t in start], [cam], [target], opt, max_pairs=1 << 16)
+            tr.flat.force_collective = bucketed
+            assert tr.flat.collective_active() == bucketed
+            vals = [tr.train_step(it, 0).clone() for it in range(12)]
+            runs.append(([p.clone() for p in tr.flat.params], torch.stack(vals), tr.optimizer.accum_grad.clone()))
+        finally:
+            if bucketed:
+                dist.destroy_process_group()
+    for a, b in zip(runs[0][0], runs[1][0]):
+        assert torch.equal(a, b)
+    assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+    assert float((runs[0][0][0] - start[0]).abs().max()) > 0
+
+
 def test_grad_stat_update_kernel(gpu):
     from gaussian import _lib
 

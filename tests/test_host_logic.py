@@ -82,6 +82,48 @@ def test_view_parallel_gradient_bucket_gloo(tmp_path):
     assert np.array_equal(red[0], red[1])
 
 
+def _bucket_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gs_dp import FlatGaussianParams
+
+    rng = np.random.default_rng(40 + rank)
+    n = 501  # odd: the colour bucket starts at element 10 n, not a multiple of 4
+    shapes = [(n, 3), (n, 4), (n, 3), (n,), (n, 27)]
+    params = [torch.from_numpy(rng.normal(size=s).astype(np.float32)) for s in shapes]
+    out = {}
+    for mode in ("blocking", "bucketed"):
+        flat = FlatGaussianParams(params, world_size=world)
+        g = np.random.default_rng(70 + rank).normal(size=flat.flat_grad.numel()).astype(np.float32)
+        flat.flat_grad.copy_(torch.from_numpy(g))
+        if mode == "blocking":
+            flat.all_reduce_grads()
+        else:
+            assert flat.collective_active()
+            assert flat.bucket_ranges == {"geometry": (0, 10 * n), "color": (10 * n, 38 * n)}
+            flat.begin_bucket("color")      # the order gs_train.Trainer uses with SH colours
+            flat.begin_bucket("geometry")
+            flat.finish_bucket("color")
+            flat.finish_bucket("geometry")
+            flat.finish_bucket("geometry")  # idempotent
+        out[mode] = flat.flat_grad.numpy().copy()
+    np.save(os.path.join(tmp, f"bucket_{rank}.npy"), np.stack([g, out["blocking"], out["bucketed"]]))
+    dist.destroy_process_group()
+
+
+def test_bucketed_async_exchange_equals_blocking_all_reduce_gloo(tmp_path):
+    """gs_dp: the two-bucket asynchronous exchange (colour bucket first, geometry second) gives every rank exactly
+    what the single blocking all-reduce of the flat buffer gives: the mean of the ranks' local gradients."""
+    world, port = 2, 33500 + (os.getpid() % 2000)
+    mp.spawn(_bucket_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"bucket_{k}.npy") for k in range(world)]
+    expect = ((r[0][0].astype(np.float64) + r[1][0]) / 2).astype(np.float32)
+    for k in range(world):
+        assert np.array_equal(r[k][1], r[k][2])          # bucketed == blocking, bit for bit
+        assert np.allclose(r[k][1], expect, rtol=1e-6, atol=1e-9)
+    assert np.array_equal(r[0][2], r[1][2])
+
+
 def _stat_worker(rank, world, port, tmp, mode):
     import torch.distributed as dist
     from gs_dp import ViewParallelGradStat
