@@ -1,8 +1,9 @@
 // gs_frame.hip -- host orchestration of the fused frame path + error plumbing.
 //
 // gs_frame_forward issues, on ONE stream and with NO host synchronisation:
-//   sort_mode 2 (default): S1 project+count -> bin count -> column scan -> bin scatter (tile ranges,
-//       counters) -> per-tile sort -> raster forward: six launches, no memset;
+//   sort_mode 2 (default): S1 project+count -> slice sort (every workgroup counting-sorts its slice of the pairs
+//       by tile in LDS) -> tile totals + ranges -> per-tile sort (gathers from the slices) -> raster forward: five
+//       launches, no memset, no scattered global store;
 //   sort_modes 0 / 1: memset(counters, ranges) -> S1 -> scan block sums -> emit keys -> LSD radix passes
 //       (3 launches per 8 bits of the key: all of it, or the tile bits only) -> tile ranges
 //       [-> per-tile sort] -> raster forward.
@@ -239,9 +240,17 @@ static int frame_forward_impl(const gs_frame *f, hipStream_t s, float *stage_ms)
         if (f->N > 0 && (rc = gs_stage_tile_bin(f, ws, s))) return rc;
         tm.mark();
         tm.mark();
-        if (f->N > 0 && (rc = gs_stage_tile_sort_packed(f, ws, okeys, (f->flags & GS_FRAME_EMIT_SORTED_KEYS) ? skeys : nullptr,
-                                                        sids, s)))
-            return rc;
+        if (f->N > 0) {
+            uint64_t *keys_out = (f->flags & GS_FRAME_EMIT_SORTED_KEYS) ? skeys : nullptr;
+            // slice-sorted variant: okeys holds the S tile-ordered slice regions, the per-tile sort gathers from them
+            // (buckets beyond its LDS window are gathered into skeys and sorted there); table variant: okeys holds
+            // the pairs grouped by tile
+            if (gs_bin_plan_for(f->N, f->max_pairs, G.n_tiles).lds_sort)
+                rc = gs_stage_tile_sort_gather(f, ws, okeys, skeys, keys_out, sids, s);
+            else
+                rc = gs_stage_tile_sort_packed(f, ws, okeys, keys_out, sids, s);
+            if (rc) return rc;
+        }
     } else {
         if (f->N > 0 && (rc = gs_stage_scan_emit(f, ws, s))) return rc;
         tm.mark();

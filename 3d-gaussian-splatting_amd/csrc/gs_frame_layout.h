@@ -2,12 +2,47 @@
 #pragma once
 #include "gs_common.h"
 
-enum { GS_CNT_VISIBLE = 0, GS_CNT_PAIRS = 1, GS_CNT_OVERFLOW = 2, GS_CNT_BUCKETS = 3, GS_CNT_N = 8 };
+enum { GS_CNT_VISIBLE = 0, GS_CNT_PAIRS = 1, GS_CNT_OVERFLOW = 2, GS_CNT_BUCKETS = 3, GS_CNT_TICKET = 4, GS_CNT_N = 8 };
 
 #define GS_BUCKET 64          // Gaussians per backward bucket (= wavefront size)
 #define GS_SORT_TILE 2048     // keys per radix-sort workgroup (256 threads x 8)
-#define GS_BIN_SLICES 256     // sort_mode 2: workgroups (= slices of the Gaussian array) of the counting sort
+#define GS_BIN_SLICES 256     // sort_mode 2, table variant: workgroups (= slices of the Gaussian array) of the counting sort
 #define GS_BIN_MAX_TILES 32768  // sort_mode 2 needs a 4-byte LDS counter per tile (128 KiB of the CU's 160)
+#define GS_BIN_MAX_SLICES 1024  // sort_mode 2, slice-sorted variant: at most this many slices
+#define GS_BIN_LDS_BYTES 160000 // dynamic LDS of a slice-sort workgroup (the CU has 160 KiB = 163,840 B)
+
+// sort_mode 2 comes in two variants (tile_bin.hip):
+//   slice-sorted (lds_sort = 1): every workgroup counting-sorts the pairs of ITS slice of the Gaussian array by tile
+//     inside LDS (T counters + `cap` staged 8-byte pairs) and streams them out as one contiguous, tile-ordered
+//     region; the per-tile sort gathers a tile's pairs from the S slices.  No scattered global stores at all.
+//   table (lds_sort = 0): count -> column scan -> scattered 8-byte stores; kept for tile grids whose counters leave
+//     no room for the staging buffer (beyond ~31 k tiles, i.e. 4K images).
+struct gs_bin_plan {
+    int lds_sort;        // 1: slice-sorted variant
+    uint32_t slices;     // S
+    uint32_t per_slice;  // Gaussians per slice (a multiple of 256, the project stage's block)
+    uint32_t cap;        // staged pairs that fit LDS next to the T counters (slices with more take the direct path)
+};
+static inline gs_bin_plan gs_bin_plan_for(int64_t N, int64_t max_pairs, int n_tiles) {
+    gs_bin_plan p;
+    const int64_t room = (int64_t)GS_BIN_LDS_BYTES - 4 * (int64_t)n_tiles;
+    p.cap = room > 0 ? (uint32_t)(room / 8 / 64 * 64) : 0;
+    p.lds_sort = p.cap >= 4096;
+    const int64_t n = N > 0 ? N : 1;
+    int64_t S = GS_BIN_SLICES;
+    if (p.lds_sort) {
+        // slices sized for ~80 % of the staging buffer, estimated from the capacity (>= the frame's pair count);
+        // at least 256 of them when the scene has that many 256-Gaussian blocks (one workgroup per CU)
+        const int64_t want = gs_div_up(max_pairs > 0 ? max_pairs : 1, (int64_t)p.cap * 4 / 5);
+        S = want > GS_BIN_SLICES ? want : GS_BIN_SLICES;
+        if (S > GS_BIN_MAX_SLICES) S = GS_BIN_MAX_SLICES;
+    }
+    const int64_t per = gs_div_up(gs_div_up(n, S), 256) * 256;
+    p.per_slice = (uint32_t)per;
+    p.slices = (uint32_t)gs_div_up(n, per);
+    return p;
+}
+
 
 // floats per per-pair gradient row: (dx, dy, da, db, dc, dd, dopa) + colour grads, padded to float4s
 // floats per (tile, Gaussian) gradient row: 7 geometry/opacity sums + color_dim colour sums, rounded up to float4s
@@ -61,9 +96,12 @@ struct gs_frame_ws {
     size_t sort_tmp_bytes;
     int32_t *tile_ranges;          // [T][2]
     // sort_mode 2 (tile_bin.hip)
-    uint32_t *bin_table;           // [GS_BIN_SLICES][T] pairs of (slice, tile); scanned in place over slices
+    uint32_t *bin_table;           // table variant: [GS_BIN_SLICES][T] pairs of (slice, tile), scanned in place over
+                                   // slices; slice-sorted variant: [S][T + 1] offsets of a tile's pairs inside the
+                                   // slice's region (last entry: the slice's pair count)
     uint32_t *tile_count;          // [T]
-    uint32_t *slice_pairs, *slice_vis;  // [GS_BIN_SLICES]
+    uint32_t *slice_pairs, *slice_vis;  // [GS_BIN_MAX_SLICES]; slice-sorted variant: slice_pairs = start of the
+                                        // slice's region in keys_a
     // training only
     uint32_t *tile_nproc;          // [T] Gaussians processed by the forward (multiple of the chunk)
     uint32_t *bucket_offsets;      // [T+1] exclusive scan of ceil(nproc/64)
@@ -111,10 +149,14 @@ static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pair
     ws.vals_b = (uint32_t *)take(sizeof(uint32_t) * max_pairs);
     ws.sort_tmp_bytes = gs_sort_pairs_tmp_bytes(max_pairs);
     ws.sort_tmp = take(ws.sort_tmp_bytes);
-    ws.bin_table = (uint32_t *)take(sizeof(uint32_t) * GS_BIN_SLICES * (size_t)G.n_tiles);
+    {
+        const gs_bin_plan plan = gs_bin_plan_for(N, max_pairs, G.n_tiles);
+        const size_t rows = plan.lds_sort ? plan.slices : GS_BIN_SLICES;
+        ws.bin_table = (uint32_t *)take(sizeof(uint32_t) * rows * ((size_t)G.n_tiles + 1));
+    }
     ws.tile_count = (uint32_t *)take(sizeof(uint32_t) * G.n_tiles);
-    ws.slice_pairs = (uint32_t *)take(sizeof(uint32_t) * GS_BIN_SLICES);
-    ws.slice_vis = (uint32_t *)take(sizeof(uint32_t) * GS_BIN_SLICES);
+    ws.slice_pairs = (uint32_t *)take(sizeof(uint32_t) * GS_BIN_MAX_SLICES);
+    ws.slice_vis = (uint32_t *)take(sizeof(uint32_t) * GS_BIN_MAX_SLICES);
     ws.max_buckets = gs_max_buckets(max_pairs, G.n_tiles);
     if (training) {
         ws.tile_nproc = (uint32_t *)take(sizeof(uint32_t) * G.n_tiles);
@@ -143,6 +185,8 @@ int gs_stage_tile_sort(const gs_frame *f, const gs_frame_ws &ws, uint64_t *keys,
 int gs_stage_tile_bin(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream);
 int gs_stage_tile_sort_packed(const gs_frame *f, const gs_frame_ws &ws, uint64_t *packed, uint64_t *keys_out,
                               uint32_t *ids_out, hipStream_t stream);
+int gs_stage_tile_sort_gather(const gs_frame *f, const gs_frame_ws &ws, const uint64_t *slice_pairs_buf,
+                              uint64_t *big_scratch, uint64_t *keys_out, uint32_t *ids_out, hipStream_t stream);
 int gs_stage_tile_ranges(const gs_frame *f, const gs_frame_ws &ws, const uint64_t *sorted_keys, hipStream_t stream);
 int gs_stage_raster_forward(const gs_frame *f, const gs_frame_ws &ws, const uint32_t *sorted_ids, hipStream_t stream);
 int gs_stage_backward_prepare(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream);

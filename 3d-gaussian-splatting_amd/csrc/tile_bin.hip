@@ -3,8 +3,24 @@
 // The reference duplicates every Gaussian into its tiles and runs a full device radix sort on
 // 64-bit (tile, depth) keys (gaussian.cu:197-250 + torch.sort in renderer.py).  The tile part
 // of that key has at most a few tens of thousands of distinct values, which is a histogram that
-// fits the 160 KiB LDS of one CU.  So the pairs are never materialised in Gaussian order at all:
+// fits the 160 KiB LDS of one CU.  So the pairs are never materialised in Gaussian order at all.
 //
+// SLICE-SORTED variant (default; gs_bin_plan.lds_sort): S workgroups, each owns a contiguous slice of the Gaussians
+//   S1 slice_sort_kernel : histogram of the tiles of the slice's rectangles in LDS (ds_add) -> exclusive scan of
+//                          the T counters inside the workgroup -> row [T + 1] of the offset table -> second walk
+//                          places every pair (depth_bits << 32 | gaussian) at ds_add_rtn(cursor[tile], 1) in an LDS
+//                          staging buffer -> the buffer is streamed to the slice's own contiguous region of the pair
+//                          array with coalesced stores.  A slice with more pairs than the buffer holds stores
+//                          straight to its region instead (slower, same result).
+//   S2 bin_totals_kernel : per tile, the sum of the S slices' counts; the LAST workgroup to finish scans the T totals
+//                          and writes tile_ranges and the pair counter.
+//   tile_sort.hip then gathers a tile's pairs from the S regions (offset table) while it loads them for sorting.
+// Why: the table variant below scatters 8-byte stores over T output streams per workgroup; at 2.4 M Gaussians that
+// is 33 MB of open cache lines per XCD against 4 MB of L2, every line leaves L2 several times half-filled (PMC:
+// WRITE_SIZE 255 MB for 55.6 MB of pairs) and the scatter alone took 109 us of a 480 us frame.  Here no global store
+// is scattered: the pair array is written once, in full lines.
+//
+// TABLE variant (tile grids whose counters leave no LDS for staging: beyond ~31 k tiles):
 //   B1 bin_count_kernel   : <= 256 workgroups, each owns a contiguous slice of the Gaussians and
 //                           histograms the tiles of their rectangles in LDS (ds_add, no global
 //                           atomics); row b of a [B][T] table <- the histogram.
@@ -19,8 +35,6 @@
 // The order inside a (slice, tile) segment depends on LDS arbitration; the per-tile sort that
 // follows (tile_sort.hip) orders each tile by the UNIQUE composite (depth_bits, gaussian), so the
 // final list is the oracle's (tile, depth_bits, gaussian_index) order bit for bit, every run.
-// Traffic per pair: 8 B written here + the tile sort, against 2 x (3 launches, 36 B) of radix
-// passes in sort_mode 1.
 #include <atomic>
 #include <mutex>
 
@@ -334,6 +348,187 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_scatter_kernel(
     }
 }
 
+// ================================================================= slice-sorted variant
+// Dynamic LDS: s_cnt[T] counters / cursors, then the staging buffer of `cap` pairs (8-byte aligned).
+template <bool DIST>
+__global__ void __launch_bounds__(BIN_THREADS) slice_sort_kernel(
+    const uint4 *__restrict__ rects, const float4 *__restrict__ rec_geom, GsDistCull D, int64_t n, uint32_t per_slice,
+    uint32_t T, uint32_t ntx, uint32_t cap, const uint32_t *__restrict__ block_sums,
+    const uint32_t *__restrict__ block_vis, uint32_t *__restrict__ table, uint32_t *__restrict__ slice_base,
+    uint64_t *__restrict__ out, uint64_t max_pairs, uint32_t *__restrict__ pair_offsets,
+    unsigned long long *__restrict__ counters) {
+    extern __shared__ uint32_t s_cnt[];
+    uint64_t *s_stage = reinterpret_cast<uint64_t *>(s_cnt + ((T + 1) & ~1u));
+    __shared__ uint32_t s_wave[BIN_THREADS / 64];
+    const uint32_t slice = blockIdx.x;
+    const int64_t g0 = (int64_t)slice * per_slice;
+    auto load_rect = [&](uint32_t base) {
+        const uint32_t i = base + threadIdx.x;
+        return (i < per_slice && g0 + i < n) ? rects[g0 + i] : make_uint4(0, 0, 0, 0);
+    };
+    auto load_xy = [&](uint32_t base, const uint4 &rc) {
+        const uint32_t i = base + threadIdx.x;
+        if (!DIST || !rc.w) return make_float2(0.f, 0.f);
+        const float4 ge = rec_geom[(g0 + i) * GS_REC_STRIDE];
+        return make_float2(ge.x, ge.y);
+    };
+    uint4 rc[BIN_PF];
+#pragma unroll
+    for (int k = 0; k < BIN_PF; ++k) rc[k] = load_rect(k * BIN_THREADS);  // in flight during the set-up below
+    for (uint32_t t = threadIdx.x; t < T; t += BIN_THREADS) s_cnt[t] = 0;
+    // frame totals from the project stage's per-block sums (rectangle areas = gradient-row slots; == pairs unless
+    // DIST): R over all blocks, `base` over the blocks in front of this slice = start of its region
+    const uint32_t nblk = (uint32_t)((n + 255) / 256), first_blk = slice * (per_slice / 256);
+    unsigned long long r_all = 0, r_before = 0, v_all = 0;
+    for (uint32_t b = threadIdx.x; b < nblk; b += BIN_THREADS) {
+        const uint32_t c = block_sums[b];
+        r_all += c;
+        r_before += b < first_blk ? c : 0;
+        v_all += block_vis[b];
+    }
+    const unsigned long long R = block_sum_u64(r_all, s_wave_u64()), base = block_sum_u64(r_before, s_wave_u64()),
+                             V = block_sum_u64(v_all, s_wave_u64());
+    uint32_t *row = table + (size_t)slice * (T + 1);
+    if (slice == 0 && threadIdx.x == 0) {
+        counters[GS_CNT_VISIBLE] = V;
+        counters[GS_CNT_OVERFLOW] = R > max_pairs ? R : 0;
+        counters[GS_CNT_TICKET] = 0;  // bin_totals_kernel counts its finished workgroups here
+    }
+    if (R > max_pairs) {  // not enough room: an all-zero table = an empty frame, the true count is reported
+        for (uint32_t t = threadIdx.x; t <= T; t += BIN_THREADS) row[t] = 0;
+        if (threadIdx.x == 0) slice_base[slice] = 0;
+        return;
+    }
+    if (threadIdx.x == 0) slice_base[slice] = (uint32_t)base;
+    __syncthreads();
+    // ---- 1. count (and, for the backward, the emission offset of every Gaussian: prefix sum of the areas)
+    uint32_t before = (uint32_t)base, dummy;
+    for (uint32_t b0 = 0; b0 < per_slice; b0 += BIN_PF * BIN_THREADS) {
+        uint4 cur[BIN_PF];
+#pragma unroll
+        for (int k = 0; k < BIN_PF; ++k) {
+            cur[k] = rc[k];
+            rc[k] = load_rect(b0 + (BIN_PF + k) * BIN_THREADS);
+        }
+#pragma unroll
+        for (int k = 0; k < BIN_PF; ++k) {
+            const uint32_t b = b0 + k * BIN_THREADS;
+            if (b >= per_slice) break;  // uniform
+            const uint32_t i = b + threadIdx.x;
+            if (pair_offsets) {  // uniform
+                const uint32_t ex = block_excl_scan(cur[k].w, s_wave, dummy);
+                if (i < per_slice && g0 + i < n) pair_offsets[g0 + i] = before + ex;
+                before += dummy;
+            }
+            walk_rect<DIST>(cur[k], g0 + i, ntx, load_xy(b, cur[k]), D,
+                            [&](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&s_cnt[tile], 1u); });
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < BIN_PF; ++k) rc[k] = load_rect(k * BIN_THREADS);  // for the second walk, under the scan
+    __syncthreads();
+    // ---- 2. exclusive scan of the T counters in place -> offsets of the tiles inside this slice's region
+    const uint32_t per = (T + BIN_THREADS - 1) / BIN_THREADS;
+    const uint32_t t0 = threadIdx.x * per < T ? threadIdx.x * per : T, t1 = t0 + per < T ? t0 + per : T;
+    uint32_t mine = 0;
+    for (uint32_t t = t0; t < t1; ++t) mine += s_cnt[t];
+    uint32_t L;
+    uint32_t run = block_excl_scan(mine, s_wave, L);
+    for (uint32_t t = t0; t < t1; ++t) {
+        const uint32_t c = s_cnt[t];
+        s_cnt[t] = run;
+        run += c;
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < T; t += BIN_THREADS) row[t] = s_cnt[t];
+    if (threadIdx.x == 0) row[T] = L;
+    __syncthreads();  // the offsets are on their way to the table before the cursors start moving
+    // ---- 3. place: into the staging buffer, or straight into the region when the slice does not fit
+    const bool fits = L <= cap;  // uniform
+    uint64_t *region = out + base;
+    for (uint32_t b0 = 0; b0 < per_slice; b0 += BIN_PF * BIN_THREADS) {
+        uint4 cur[BIN_PF];
+#pragma unroll
+        for (int k = 0; k < BIN_PF; ++k) {
+            cur[k] = rc[k];
+            rc[k] = load_rect(b0 + (BIN_PF + k) * BIN_THREADS);
+        }
+#pragma unroll
+        for (int k = 0; k < BIN_PF; ++k) {
+            const uint32_t b = b0 + k * BIN_THREADS;
+            if (b >= per_slice) break;  // uniform
+            walk_rect<DIST>(cur[k], g0 + b + threadIdx.x, ntx, load_xy(b, cur[k]), D,
+                            [&](uint32_t tile, uint32_t id, uint32_t d) {
+                                const uint32_t slot = atomicAdd(&s_cnt[tile], 1u);
+                                const uint64_t pair = ((uint64_t)d << 32) | id;
+                                if (fits)
+                                    s_stage[slot] = pair;
+                                else
+                                    region[slot] = pair;
+                            });
+        }
+    }
+    if (!fits) return;
+    __syncthreads();
+    // ---- 4. stream the tile-ordered pairs out: consecutive lanes, consecutive addresses
+    for (uint32_t i = threadIdx.x; i < L; i += BIN_THREADS) region[i] = s_stage[i];
+}
+
+// Per tile: number of pairs over all slices; the last workgroup to finish turns the totals into tile ranges.
+__global__ void __launch_bounds__(256) bin_totals_kernel(const uint32_t *__restrict__ table, uint32_t S, uint32_t T,
+                                                        uint32_t *__restrict__ tile_count,
+                                                        int32_t *__restrict__ tile_ranges,
+                                                        unsigned long long *__restrict__ counters) {
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_last;
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t < T) {
+        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;  // four independent chains of loads
+        const uint32_t *p = table + t;
+        const size_t stride = (size_t)T + 1;
+        uint32_t s = 0;
+        for (; s + 4 <= S; s += 4) {
+            a0 += p[(s + 0) * stride + 1] - p[(s + 0) * stride];
+            a1 += p[(s + 1) * stride + 1] - p[(s + 1) * stride];
+            a2 += p[(s + 2) * stride + 1] - p[(s + 2) * stride];
+            a3 += p[(s + 3) * stride + 1] - p[(s + 3) * stride];
+        }
+        for (; s < S; ++s) a0 += p[s * stride + 1] - p[s * stride];
+        tile_count[t] = (a0 + a1) + (a2 + a3);
+    }
+    __threadfence();  // the totals are visible device-wide before this workgroup takes its ticket
+    __syncthreads();
+    if (threadIdx.x == 0)
+        s_last = atomicAdd(&counters[GS_CNT_TICKET], 1ull) == (unsigned long long)gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    // exclusive scan of the T totals by this (the last) workgroup: thread i owns a contiguous run of tiles
+    const uint32_t per = (T + 255) / 256;
+    const uint32_t t0 = threadIdx.x * per < T ? threadIdx.x * per : T, t1 = t0 + per < T ? t0 + per : T;
+    const volatile uint32_t *tc = tile_count;  // written by other workgroups: no stale non-coherent reads
+    uint32_t mine = 0;
+    for (uint32_t i = t0; i < t1; ++i) mine += tc[i];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t incl = gs_wave_incl_scan_u32(mine);
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t off = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        off += w < wave ? s_wave[w] : 0;
+        total += s_wave[w];
+    }
+    uint32_t run = off + incl - mine;
+    for (uint32_t i = t0; i < t1; ++i) {
+        const uint32_t c = tc[i];
+        // every tile is written (empty ones as (0, 0)): no memset of the ranges
+        reinterpret_cast<int2 *>(tile_ranges)[i] = c ? make_int2((int)run, (int)(run + c)) : make_int2(0, 0);
+        run += c;
+    }
+    if (threadIdx.x == 0) counters[GS_CNT_PAIRS] = total;
+}
+
 }  // namespace
 
 // Gaussians per slice: a multiple of 256 (the project stage's block) with at most GS_BIN_SLICES slices.
@@ -344,12 +539,11 @@ static uint32_t bin_per_block(int64_t N) {
 
 int gs_stage_tile_bin(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream) {
     gs_frame_geom G = gs_frame_geometry(f);
-    const uint32_t T = (uint32_t)G.n_tiles, per_block = bin_per_block(f->N);
-    const uint32_t B = (uint32_t)gs_div_up(f->N, per_block);
-    const size_t lds = sizeof(uint32_t) * T;
+    const gs_bin_plan plan = gs_bin_plan_for(f->N, f->max_pairs, G.n_tiles);
+    const uint32_t T = (uint32_t)G.n_tiles;
     const bool dist = f->tile_culling_method == 0;
     GsDistCull D = {(float)(G.padW / 2), (float)(G.padH / 2), f->focal_x, f->focal_y, f->thresh};
-    // histograms above 64 KiB need the opt-in (gfx950: 160 KiB per workgroup): once per DEVICE (a function
+    // dynamic LDS above 64 KiB needs the opt-in (gfx950: 160 KiB per workgroup): once per DEVICE (a function
     // attribute belongs to the device's code object), thread-safe
     static std::mutex attr_mu;
     static std::atomic<uint64_t> attr_done{0};
@@ -360,8 +554,31 @@ int gs_stage_tile_bin(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stre
         for (const void *fn : {(const void *)bin_count_kernel<false>, (const void *)bin_count_kernel<true>,
                                (const void *)bin_scatter_kernel<false>, (const void *)bin_scatter_kernel<true>})
             GS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, GS_BIN_MAX_TILES * 4));
+        for (const void *fn : {(const void *)slice_sort_kernel<false>, (const void *)slice_sort_kernel<true>})
+            GS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, GS_BIN_LDS_BYTES + 64));
         attr_done.fetch_or(1ull << dev, std::memory_order_release);
     }
+    if (plan.lds_sort) {
+        const size_t lds = sizeof(uint32_t) * ((T + 1) & ~1u) + sizeof(uint64_t) * plan.cap;
+#define GS_LAUNCH_SLICE_SORT(DIST)                                                                                     \
+    hipLaunchKernelGGL(slice_sort_kernel<DIST>, dim3(plan.slices), dim3(BIN_THREADS), lds, stream, ws.rects,           \
+                       ws.rec_geom, D, f->N, plan.per_slice, T, (uint32_t)G.ntx, plan.cap, ws.block_sums,              \
+                       ws.block_vis, ws.bin_table, ws.slice_pairs, ws.keys_a, (uint64_t)f->max_pairs,                  \
+                       f->training ? ws.pair_offsets : nullptr, ws.counters)
+        if (dist)
+            GS_LAUNCH_SLICE_SORT(true);
+        else
+            GS_LAUNCH_SLICE_SORT(false);
+#undef GS_LAUNCH_SLICE_SORT
+        GS_CHECK_LAUNCH();
+        hipLaunchKernelGGL(bin_totals_kernel, dim3((unsigned)gs_div_up(T, 256)), dim3(256), 0, stream, ws.bin_table,
+                           plan.slices, T, ws.tile_count, ws.tile_ranges, ws.counters);
+        GS_CHECK_LAUNCH();
+        return 0;
+    }
+    const uint32_t per_block = bin_per_block(f->N);
+    const uint32_t B = (uint32_t)gs_div_up(f->N, per_block);
+    const size_t lds = sizeof(uint32_t) * T;
 #define GS_LAUNCH_BIN(DIST)                                                                                            \
     do {                                                                                                               \
         hipLaunchKernelGGL(bin_count_kernel<DIST>, dim3(B), dim3(BIN_THREADS), lds, stream, ws.rects, ws.rec_geom, D,  \

@@ -192,16 +192,31 @@ __device__ __forceinline__ void disperse_levels(uint64_t *a, uint32_t n, uint32_
     sync();
 }
 
-// PACKED = false (sort_mode 1): keys = (tile << 32 | depth_bits) grouped by tile, ids = Gaussian index;
-//   both are overwritten in place with the depth-sorted order; scratch = idle half of the key buffer.
-// PACKED = true (sort_mode 2): scratch = (depth_bits << 32 | gaussian) grouped by tile in arbitrary
-//   order; the sorted ids go to ids, the sorted (tile << 32 | depth_bits) to keys unless keys is NULL; long buckets
-//   sort in place.
-template <int CAP, bool PACKED>
+// Where a tile's unsorted pairs come from.
+//   SRC_KEYS   (sort_mode 1): keys = (tile << 32 | depth_bits) grouped by tile, ids = Gaussian index; both are
+//              overwritten in place with the depth-sorted order; scratch = idle half of the key buffer.
+//   SRC_PACKED (sort_mode 2, table variant): scratch = (depth_bits << 32 | gaussian) grouped by tile in arbitrary
+//              order; the sorted ids go to ids, the sorted (tile << 32 | depth_bits) to keys unless keys is NULL;
+//              long buckets sort in place.
+//   SRC_GATHER (sort_mode 2, slice-sorted variant): the pairs of tile t sit in S slice regions of `pairs`, region s
+//              holding them at [slice_base[s] + table[s][t], slice_base[s] + table[s][t + 1]); they are gathered
+//              into LDS while the tile is loaded (buckets beyond CAP: into scratch + start, then sorted there).
+enum { SRC_KEYS = 0, SRC_PACKED = 1, SRC_GATHER = 2 };
+struct GatherSrc {
+    const uint64_t *pairs;
+    const uint32_t *table;       // [S][T + 1]
+    const uint32_t *slice_base;  // [S]
+    uint32_t S, T;
+};
+
+template <int CAP, int SRC>
 __global__ void __launch_bounds__(256) tile_sort_kernel(uint64_t *__restrict__ keys, uint32_t *__restrict__ ids,
                                                        uint64_t *__restrict__ scratch,
-                                                       const int32_t *__restrict__ ranges, uint32_t n_tiles) {
+                                                       const int32_t *__restrict__ ranges, uint32_t n_tiles,
+                                                       GatherSrc GS) {
+    constexpr bool PACKED = SRC != SRC_KEYS;  // the unsorted element already is (depth_bits << 32 | gaussian)
     __shared__ uint64_t s_a[CAP];
+    __shared__ uint32_t s_scan[4];
     const int lane = threadIdx.x & 63;
     const uint32_t wave = threadIdx.x >> 6;
     uint32_t tile, start, n;
@@ -229,10 +244,51 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(uint64_t *__restrict__ k
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
+    // SRC_GATHER: copies the current tile's pairs from the S slice regions to dst[0 .. n) (any order: the sort that
+    // follows orders by the unique (depth_bits, gaussian)).  `nthreads` threads with index `tid` cooperate (one wave
+    // or the workgroup: `wg` selects the cross-wave prefix); four slices per thread are in flight at a time.
+    auto gather = [&](uint64_t *dst, uint32_t tid, uint32_t nthreads, bool wg) {
+        uint32_t filled = 0;
+        const size_t stride = (size_t)GS.T + 1;
+        for (uint32_t s0 = 0; s0 < GS.S; s0 += 4 * nthreads) {
+            uint32_t o0[4], c[4], sb[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t sl = s0 + q * nthreads + tid;
+                o0[q] = c[q] = sb[q] = 0;
+                if (sl < GS.S) {
+                    const uint32_t *r = GS.table + sl * stride + tile;
+                    o0[q] = r[0];
+                    c[q] = r[1] - o0[q];
+                    sb[q] = GS.slice_base[sl];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (s0 + q * nthreads >= GS.S) break;  // uniform
+                const uint32_t incl = gs_wave_incl_scan_u32(c[q]);
+                uint32_t off = incl - c[q], total = __shfl(incl, 63, 64);
+                if (wg) {  // uniform: prefix over the four waves
+                    __syncthreads();
+                    if (lane == 63) s_scan[wave] = incl;
+                    __syncthreads();
+                    total = 0;
+#pragma unroll
+                    for (uint32_t w = 0; w < 4; ++w) {
+                        off += w < wave ? s_scan[w] : 0;
+                        total += s_scan[w];
+                    }
+                }
+                const uint64_t *src = GS.pairs + sb[q] + o0[q];
+                for (uint32_t k = 0; k < c[q]; ++k) dst[filled + off + k] = src[k];
+                filled += total;
+            }
+        }
+    };
     // loads window w of the current bucket into registers, sorts it, hands it to `out(e, key)`
-    auto sort_window_from_global = [&](uint32_t w, auto out) {
+    auto sort_window_from = [&](auto in, uint32_t w, auto out) {
         const uint32_t e0 = w * 128 + lane, e1 = e0 + 64;
-        uint64_t a0 = e0 < n ? load(e0) : KEY_INF, a1 = e1 < n ? load(e1) : KEY_INF;
+        uint64_t a0 = e0 < n ? in(e0) : KEY_INF, a1 = e1 < n ? in(e1) : KEY_INF;
         sort_window(a0, a1, lane, n - w * 128 < 128 ? n - w * 128 : 128);
         if (e0 < n) out(e0, a0);
         if (e1 < n) out(e1, a1);
@@ -241,13 +297,25 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(uint64_t *__restrict__ k
     // 1. one wave per short bucket (<= CAP/4 keys), four buckets per workgroup, no workgroup barrier
     select(blockIdx.x * 4 + wave);
     if (n >= (PACKED ? 1u : 2u) && n <= (uint32_t)CAP / 4) {
-        if (n <= 128) {  // registers only
-            sort_window_from_global(0, store);
+        uint64_t *a = s_a + wave * (CAP / 4);
+        if (SRC == SRC_GATHER) {
+            gather(a, (uint32_t)lane, 64u, false);
+            wave_sync();
+        }
+        auto from_lds = [&](uint32_t e) -> uint64_t { return a[e]; };
+        if (n <= 128) {  // registers only (SRC_GATHER: through the wave's LDS window)
+            if (SRC == SRC_GATHER)
+                sort_window_from(from_lds, 0, store);
+            else
+                sort_window_from(load, 0, store);
         } else {
-            uint64_t *a = s_a + wave * (CAP / 4);
             const uint32_t nwin = (n + 127) / 128;
-            for (uint32_t w = 0; w < nwin; ++w)
-                sort_window_from_global(w, [&](uint32_t e, uint64_t v) { a[e] = v; });
+            for (uint32_t w = 0; w < nwin; ++w) {
+                if (SRC == SRC_GATHER)
+                    sort_window_from(from_lds, w, [&](uint32_t e, uint64_t v) { a[e] = v; });
+                else
+                    sort_window_from(load, w, [&](uint32_t e, uint64_t v) { a[e] = v; });
+            }
             wave_sync();
             uint32_t P = 256;
             while (P < n) P <<= 1;
@@ -264,8 +332,16 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(uint64_t *__restrict__ k
         while (P < n) P <<= 1;
         if (n <= (uint32_t)CAP) {
             const uint32_t nwin = (n + 127) / 128;
-            for (uint32_t w = wave; w < nwin; w += 4)
-                sort_window_from_global(w, [&](uint32_t e, uint64_t v) { s_a[e] = v; });
+            if (SRC == SRC_GATHER) {
+                gather(s_a, threadIdx.x, 256u, true);
+                __syncthreads();
+                for (uint32_t w = wave; w < nwin; w += 4)
+                    sort_window_from([&](uint32_t e) -> uint64_t { return s_a[e]; }, w,
+                                     [&](uint32_t e, uint64_t v) { s_a[e] = v; });
+            } else {
+                for (uint32_t w = wave; w < nwin; w += 4)
+                    sort_window_from(load, w, [&](uint32_t e, uint64_t v) { s_a[e] = v; });
+            }
             __syncthreads();
             merge_levels(s_a, n, P, threadIdx.x, 256u, [] { __syncthreads(); });
             for (uint32_t i = threadIdx.x; i < n; i += 256) store(i, s_a[i]);
@@ -275,7 +351,9 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(uint64_t *__restrict__ k
             // everything below per chunk in LDS / registers again.  (A first version ran the whole network through
             // global memory: 4.9 ms per frame at 3,500 pairs per tile; this path: see DESIGN.md.)
             uint64_t *a = scratch + start;  // PACKED: in place; else the idle half of the key buffer
-            if (!PACKED)
+            if (SRC == SRC_GATHER)
+                gather(a, threadIdx.x, 256u, true);
+            else if (!PACKED)
                 for (uint32_t i = threadIdx.x; i < n; i += 256) a[i] = load(i);
             __syncthreads();
             auto block_sync = [] { __syncthreads(); };
@@ -340,8 +418,8 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(uint64_t *__restrict__ k
 int gs_stage_tile_sort(const gs_frame *f, const gs_frame_ws &ws, uint64_t *keys, uint32_t *ids, uint64_t *scratch,
                        hipStream_t stream) {
     gs_frame_geom G = gs_frame_geometry(f);
-    hipLaunchKernelGGL((tile_sort_kernel<2048, false>), dim3((G.n_tiles + 3) / 4), dim3(256), 0, stream, keys, ids,
-                       scratch, ws.tile_ranges, (uint32_t)G.n_tiles);
+    hipLaunchKernelGGL((tile_sort_kernel<2048, SRC_KEYS>), dim3((G.n_tiles + 3) / 4), dim3(256), 0, stream, keys, ids,
+                       scratch, ws.tile_ranges, (uint32_t)G.n_tiles, GatherSrc{});
     GS_CHECK_LAUNCH();
     return 0;
 }
@@ -349,8 +427,21 @@ int gs_stage_tile_sort(const gs_frame *f, const gs_frame_ws &ws, uint64_t *keys,
 int gs_stage_tile_sort_packed(const gs_frame *f, const gs_frame_ws &ws, uint64_t *packed, uint64_t *keys_out,
                               uint32_t *ids_out, hipStream_t stream) {
     gs_frame_geom G = gs_frame_geometry(f);
-    hipLaunchKernelGGL((tile_sort_kernel<2048, true>), dim3((G.n_tiles + 3) / 4), dim3(256), 0, stream, keys_out,
-                       ids_out, packed, ws.tile_ranges, (uint32_t)G.n_tiles);
+    hipLaunchKernelGGL((tile_sort_kernel<2048, SRC_PACKED>), dim3((G.n_tiles + 3) / 4), dim3(256), 0, stream,
+                       keys_out, ids_out, packed, ws.tile_ranges, (uint32_t)G.n_tiles, GatherSrc{});
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+// slice-sorted variant of sort_mode 2: `slice_pairs_buf` holds the S tile-ordered slice regions, `big_scratch` is
+// where buckets beyond the LDS window are gathered and sorted (indexed like the final list)
+int gs_stage_tile_sort_gather(const gs_frame *f, const gs_frame_ws &ws, const uint64_t *slice_pairs_buf,
+                              uint64_t *big_scratch, uint64_t *keys_out, uint32_t *ids_out, hipStream_t stream) {
+    gs_frame_geom G = gs_frame_geometry(f);
+    const gs_bin_plan plan = gs_bin_plan_for(f->N, f->max_pairs, G.n_tiles);
+    GatherSrc gsrc = {slice_pairs_buf, ws.bin_table, ws.slice_pairs, plan.slices, (uint32_t)G.n_tiles};
+    hipLaunchKernelGGL((tile_sort_kernel<2048, SRC_GATHER>), dim3((G.n_tiles + 3) / 4), dim3(256), 0, stream,
+                       keys_out, ids_out, big_scratch, ws.tile_ranges, (uint32_t)G.n_tiles, gsrc);
     GS_CHECK_LAUNCH();
     return 0;
 }

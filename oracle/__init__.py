@@ -215,6 +215,17 @@ def draw(pos, rgb, opa, cov, accum, padded_h, padded_w, focal_x, focal_y, weight
     return res
 
 
+def draw_ambiguous(pos, opa, cov, accum, padded_h, padded_w, focal_x, focal_y, band=1e-4):
+    """[padded_h, padded_w] bool: pixels whose transmittance passes within ``band`` (relative) of the 1e-4 stop
+    threshold of K7 / K8 -- where stopping one Gaussian earlier or later is a legitimate fp32 outcome (gs_oracle.c)."""
+    pos, opa, cov = _f(pos), _f(opa), _f(cov)
+    accum = np.ascontiguousarray(accum, np.int32)
+    amb = np.zeros((padded_h, padded_w), np.uint8)
+    lib().gso_draw_ambiguous(_vp(pos), _vp(opa), _vp(cov), _vp(accum), _vp(amb), C.c_int32(padded_h),
+                             C.c_int32(padded_w), C.c_float(focal_x), C.c_float(focal_y), C.c_float(band))
+    return amb.astype(bool)
+
+
 def draw_backward(pos, rgb, opa, cov, accum, output, grad_output, focal_x, focal_y,
                   weight_normalize=False, sigmoid=False, use_sh=False, fast=False, rays_o=None,
                   lefttop=None, vdx=None, vdy=None, with_scale=False, scale_w=0.05):

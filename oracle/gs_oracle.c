@@ -569,6 +569,42 @@ GSO_API void gso_draw(const float *pos, const float *rgb, const float *opa, cons
 }
 
 /* ---------------------------------------------------------------------------------------
+ * Pixels whose early-stop decision is not robust in fp32 (test infrastructure for the gradient parity tests).
+ * K7 / K8 stop a pixel at the first Gaussian that finds its transmittance below 1e-4 (gaussian.cu:906, :578).
+ * The transmittance is a product of up to hundreds of rounded factors (1 - alpha): two correct fp32 evaluations
+ * (other expression order, 1-ulp exp) agree on it to ~1e-5 relative at best, so when it passes within `band`
+ * (relative) of the threshold, stopping one Gaussian earlier or later is a legitimate outcome -- and changes WHICH
+ * terms exist for that pixel.  amb[h,w] <- 1 for those pixels; the gradient parity tests feed a dL/dimage that is
+ * zero there, so that every remaining term is comparable.  Same loop as gso_draw (fast exp path), alpha only.
+ * ------------------------------------------------------------------------------------- */
+GSO_API void gso_draw_ambiguous(const float *pos, const float *opa, const float *cov, const int32_t *accum_idx,
+                                uint8_t *amb, int32_t h, int32_t w, float focal_x, float focal_y, float band) {
+    const uint32_t ntx = (uint32_t)(w + 15) / 16;
+    const float lo = 0.0001f * (1.0f - band), hi = 0.0001f * (1.0f + band);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (uint32_t id_y = 0; id_y < (uint32_t)h; ++id_y)
+        for (uint32_t id_x = 0; id_x < (uint32_t)w; ++id_x) {
+            uint32_t id_tile = id_x / 16 + (id_y / 16) * ntx;
+            uint32_t start = (uint32_t)accum_idx[id_tile], end = (uint32_t)accum_idx[id_tile + 1];
+            float pixel_x = (float)((id_x + 0.5 - (uint32_t)w / 2) / focal_x);
+            float pixel_y = (float)((id_y + 0.5 - (uint32_t)h / 2) / focal_y);
+            float accum = 1.0f;
+            uint8_t flag = 0;
+            for (uint32_t g = start; g < end; ++g) {
+                if (accum >= lo && accum <= hi) flag = 1; /* this test could go either way */
+                if (accum < lo) break;                    /* well below: every evaluation has stopped */
+                float a = cov[g * 4], b = cov[g * 4 + 1], c = cov[g * 4 + 2], d = cov[g * 4 + 3];
+                float x = pixel_x - pos[g * 3], y = pixel_y - pos[g * 3 + 1];
+                float det = (a * d - b * c);
+                double q = -(d * x * x - (b + c) * x * y + a * y * y) / (2 * det + 1e-14);
+                float alpha = expf((float)q) * opa[g];
+                accum *= (1 - alpha);
+            }
+            amb[(size_t)id_x + (size_t)id_y * w] = flag;
+        }
+}
+
+/* ---------------------------------------------------------------------------------------
  * K8: tile rasterizer backward                 gaussian.cu:440-803
  * Intended semantics: each (tile, Gaussian) row = sum over the tile's 256 pixels of the
  * per-pixel contribution, for pixels whose transmittance is still >= 1e-4 before that

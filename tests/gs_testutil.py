@@ -61,6 +61,17 @@ class OracleFrame:
                                   rays_o=rays.rays_o, lefttop=rays.lefttop, vdx=rays.dx, vdy=rays.dy)
         self.image = grid.crop(np.clip(self.padded, 0, 1))
 
+    def robust_grad_image(self, grad_image, band=1e-4):
+        """dL/dimage with the pixels zeroed whose early-stop decision is not robust in fp32 (their transmittance
+        passes within ``band`` of the 1e-4 threshold: oracle.draw_ambiguous) -- typically a few hundred of 2 M.
+        Every gradient term is proportional to its pixel's dL/dimage, so with this input two evaluations that stop
+        such a pixel one Gaussian apart still have the same set of terms to compare.  -> (grad_image, #pixels zeroed)"""
+        grid = self.grid
+        amb = oracle.draw_ambiguous(self.s_pos, self.s_opa, self.s_cov, self.accum, grid.padded_height,
+                                    grid.padded_width, grid.focal_x, grid.focal_y, band)
+        keep = ~grid.crop(amb[:, :, None])
+        return np.ascontiguousarray(grad_image * keep, np.float32), int((~keep).sum())
+
     def _pairs_from_table(self, method, thresh):
         """'prob' / 'dist' (splatter.py:571-578): the oracle's restatement of calc_tile_list methods 1 / 0 (pinned
         bit for bit against the reference kernels) on the visible Gaussians, uncapped, then the canonical
@@ -190,11 +201,14 @@ GRAD_KAPPA = 1e-5
 GRAD_L2 = 2e-5  # ||got - ref||_2 / ||ref||_2 per tensor
 
 
+GRAD_FLOOR = 1e-30  # the GPU flushes subnormal results to zero, the CPU oracle keeps them (1e-38 .. 1e-45)
+
+
 def grad_close(got, ref, scale, rtol=GRAD_RTOL, kappa=GRAD_KAPPA):
     """-> (ok, worst ratio err / tol, index of the worst element, fraction of elements within rtol |ref| alone)."""
     got, ref, scale = (np.asarray(a, np.float64) for a in (got, ref, scale))
     err = np.abs(got - ref)
-    tol = rtol * np.abs(ref) + kappa * scale
+    tol = rtol * np.abs(ref) + kappa * scale + GRAD_FLOOR
     bad = err > tol
     with np.errstate(divide="ignore", invalid="ignore"):
         ratio = np.where(err > 0, err / tol, 0.0)

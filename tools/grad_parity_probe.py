@@ -33,6 +33,7 @@ def probe(name, scene, cam, grad_kind="sign"):
         gimg = (np.sign(of.image - 0.5) / of.image.size).astype(np.float32)
     else:
         gimg = np.random.default_rng(4).normal(size=of.image.shape).astype(np.float32)
+    gimg, n_amb = of.robust_grad_image(gimg)
     t0 = time.time()
     ref, s05 = of.backward(gimg, with_scale=True, scale_w=0.05)
     t_bwd = time.time() - t0
@@ -42,7 +43,7 @@ def probe(name, scene, cam, grad_kind="sign"):
     img = r.render(*params, cam)
     img_err = float(np.abs(img.detach().cpu().numpy() - of.image).max())
     img.backward(torch.from_numpy(gimg).to(dev))
-    out = {"config": name, "grad": grad_kind, "n": scene.n, "pairs": int(len(of.ids)), "image_err": img_err,
+    out = {"config": name, "grad": grad_kind, "n": scene.n, "pairs": int(len(of.ids)), "image_err": img_err, "ambiguous_pixels_zeroed": n_amb,
            "oracle_fwd_s": round(t_fwd, 2), "oracle_bwd_s": round(t_bwd, 2), "tensors": {}}
     for t, key in zip(params, ("pos", "quat", "scale", "opa", "rgb")):
         got = t.grad.cpu().numpy().astype(np.float64)
