@@ -350,6 +350,16 @@ extern "C" int gs_frame_stats_async(const gs_frame *f, int64_t *stats_host, gs_s
     return 0;
 }
 
+extern "C" int gs_frame_debug_tile_nproc(const gs_frame *f, const uint32_t **tile_nproc) {
+    int rc = validate(f);
+    if (rc) return rc;
+    GS_CHECK_ARG(tile_nproc != nullptr, "tile_nproc is null");
+    GS_CHECK_ARG(f->training, "the per-tile processed counts are kept by training forwards only");
+    gs_frame_ws ws = gs_frame_carve(f->workspace, f->N, f->max_pairs, f->width, f->height, f->color_dim, 1);
+    *tile_nproc = ws.tile_nproc;
+    return 0;
+}
+
 extern "C" int gs_frame_debug_views(const gs_frame *f, const uint64_t **sorted_keys, const uint32_t **sorted_ids,
                                     const int32_t **tile_ranges, const float **rec_geom, const float **rec_cov,
                                     const float **rec_color, const uint32_t **tiles_touched) {

@@ -31,10 +31,12 @@ static inline gs_bin_plan gs_bin_plan_for(int64_t N, int64_t max_pairs, int n_ti
     const int64_t n = N > 0 ? N : 1;
     int64_t S = GS_BIN_SLICES;
     if (p.lds_sort) {
-        // slices sized for ~80 % of the staging buffer, estimated from the capacity (>= the frame's pair count);
-        // at least 256 of them when the scene has that many 256-Gaussian blocks (one workgroup per CU)
-        const int64_t want = gs_div_up(max_pairs > 0 ? max_pairs : 1, (int64_t)p.cap * 4 / 5);
-        S = want > GS_BIN_SLICES ? want : GS_BIN_SLICES;
+        // A slice-sort workgroup owns a CU's LDS, so the slices run in rounds of 256 (one per CU): their number is a
+        // multiple of 256, the smallest one that keeps the average slice within 95 % of the staging buffer --
+        // estimated from the capacity, which is >= the frame's pair count (a slice that does not fit still works,
+        // through the direct path)
+        const int64_t want = gs_div_up(max_pairs > 0 ? max_pairs : 1, (int64_t)p.cap * 95 / 100);
+        S = gs_div_up(want, GS_BIN_SLICES) * GS_BIN_SLICES;
         if (S > GS_BIN_MAX_SLICES) S = GS_BIN_MAX_SLICES;
     }
     const int64_t per = gs_div_up(gs_div_up(n, S), 256) * 256;

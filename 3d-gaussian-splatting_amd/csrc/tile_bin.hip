@@ -356,7 +356,7 @@ __global__ void __launch_bounds__(BIN_THREADS) slice_sort_kernel(
     uint32_t T, uint32_t ntx, uint32_t cap, const uint32_t *__restrict__ block_sums,
     const uint32_t *__restrict__ block_vis, uint32_t *__restrict__ table, uint32_t *__restrict__ slice_base,
     uint64_t *__restrict__ out, uint64_t max_pairs, uint32_t *__restrict__ pair_offsets,
-    unsigned long long *__restrict__ counters) {
+    uint32_t *__restrict__ tile_count, unsigned long long *__restrict__ counters) {
     extern __shared__ uint32_t s_cnt[];
     uint64_t *s_stage = reinterpret_cast<uint64_t *>(s_cnt + ((T + 1) & ~1u));
     __shared__ uint32_t s_wave[BIN_THREADS / 64];
@@ -376,6 +376,8 @@ __global__ void __launch_bounds__(BIN_THREADS) slice_sort_kernel(
 #pragma unroll
     for (int k = 0; k < BIN_PF; ++k) rc[k] = load_rect(k * BIN_THREADS);  // in flight during the set-up below
     for (uint32_t t = threadIdx.x; t < T; t += BIN_THREADS) s_cnt[t] = 0;
+    if (slice == 0)  // bin_totals_kernel accumulates the per-tile totals with atomics
+        for (uint32_t t = threadIdx.x; t < T; t += BIN_THREADS) tile_count[t] = 0;
     // frame totals from the project stage's per-block sums (rectangle areas = gradient-row slots; == pairs unless
     // DIST): R over all blocks, `base` over the blocks in front of this slice = start of its region
     const uint32_t nblk = (uint32_t)((n + 255) / 256), first_blk = slice * (per_slice / 256);
@@ -446,35 +448,39 @@ __global__ void __launch_bounds__(BIN_THREADS) slice_sort_kernel(
     // ---- 3. place: into the staging buffer, or straight into the region when the slice does not fit
     const bool fits = L <= cap;  // uniform
     uint64_t *region = out + base;
-    for (uint32_t b0 = 0; b0 < per_slice; b0 += BIN_PF * BIN_THREADS) {
-        uint4 cur[BIN_PF];
+    auto place = [&](auto put) {
+        for (uint32_t b0 = 0; b0 < per_slice; b0 += BIN_PF * BIN_THREADS) {
+            uint4 cur[BIN_PF];
 #pragma unroll
-        for (int k = 0; k < BIN_PF; ++k) {
-            cur[k] = rc[k];
-            rc[k] = load_rect(b0 + (BIN_PF + k) * BIN_THREADS);
-        }
+            for (int k = 0; k < BIN_PF; ++k) {
+                cur[k] = rc[k];
+                rc[k] = load_rect(b0 + (BIN_PF + k) * BIN_THREADS);
+            }
 #pragma unroll
-        for (int k = 0; k < BIN_PF; ++k) {
-            const uint32_t b = b0 + k * BIN_THREADS;
-            if (b >= per_slice) break;  // uniform
-            walk_rect<DIST>(cur[k], g0 + b + threadIdx.x, ntx, load_xy(b, cur[k]), D,
-                            [&](uint32_t tile, uint32_t id, uint32_t d) {
-                                const uint32_t slot = atomicAdd(&s_cnt[tile], 1u);
-                                const uint64_t pair = ((uint64_t)d << 32) | id;
-                                if (fits)
-                                    s_stage[slot] = pair;
-                                else
-                                    region[slot] = pair;
-                            });
+            for (int k = 0; k < BIN_PF; ++k) {
+                const uint32_t b = b0 + k * BIN_THREADS;
+                if (b >= per_slice) break;  // uniform
+                walk_rect<DIST>(cur[k], g0 + b + threadIdx.x, ntx, load_xy(b, cur[k]), D,
+                                [&](uint32_t tile, uint32_t id, uint32_t d) {
+                                    put(atomicAdd(&s_cnt[tile], 1u), ((uint64_t)d << 32) | id);
+                                });
+            }
         }
-    }
+    };
+    if (fits)  // uniform: LDS stores in the common case, global ones for a slice that does not fit
+        place([&](uint32_t slot, uint64_t pair) { s_stage[slot] = pair; });
+    else
+        place([&](uint32_t slot, uint64_t pair) { region[slot] = pair; });
     if (!fits) return;
     __syncthreads();
     // ---- 4. stream the tile-ordered pairs out: consecutive lanes, consecutive addresses
     for (uint32_t i = threadIdx.x; i < L; i += BIN_THREADS) region[i] = s_stage[i];
 }
 
-// Per tile: number of pairs over all slices; the last workgroup to finish turns the totals into tile ranges.
+// Per tile: number of pairs over all slices (grid.y cuts the slices into chunks that add their partial sums with one
+// atomic per tile; tile_count was zeroed by slice 0 of slice_sort_kernel); the last workgroup to finish turns the
+// totals into tile ranges.
+#define TOT_CHUNK 32  // slices per workgroup
 __global__ void __launch_bounds__(256) bin_totals_kernel(const uint32_t *__restrict__ table, uint32_t S, uint32_t T,
                                                         uint32_t *__restrict__ tile_count,
                                                         int32_t *__restrict__ tile_ranges,
@@ -482,24 +488,26 @@ __global__ void __launch_bounds__(256) bin_totals_kernel(const uint32_t *__restr
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_last;
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t s_begin = blockIdx.y * TOT_CHUNK, s_end = s_begin + TOT_CHUNK < S ? s_begin + TOT_CHUNK : S;
     if (t < T) {
         uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;  // four independent chains of loads
         const uint32_t *p = table + t;
         const size_t stride = (size_t)T + 1;
-        uint32_t s = 0;
-        for (; s + 4 <= S; s += 4) {
+        uint32_t s = s_begin;
+        for (; s + 4 <= s_end; s += 4) {
             a0 += p[(s + 0) * stride + 1] - p[(s + 0) * stride];
             a1 += p[(s + 1) * stride + 1] - p[(s + 1) * stride];
             a2 += p[(s + 2) * stride + 1] - p[(s + 2) * stride];
             a3 += p[(s + 3) * stride + 1] - p[(s + 3) * stride];
         }
-        for (; s < S; ++s) a0 += p[s * stride + 1] - p[s * stride];
-        tile_count[t] = (a0 + a1) + (a2 + a3);
+        for (; s < s_end; ++s) a0 += p[s * stride + 1] - p[s * stride];
+        const uint32_t part = (a0 + a1) + (a2 + a3);
+        if (part) atomicAdd(&tile_count[t], part);
     }
     __threadfence();  // the totals are visible device-wide before this workgroup takes its ticket
     __syncthreads();
     if (threadIdx.x == 0)
-        s_last = atomicAdd(&counters[GS_CNT_TICKET], 1ull) == (unsigned long long)gridDim.x - 1;
+        s_last = atomicAdd(&counters[GS_CNT_TICKET], 1ull) == (unsigned long long)gridDim.x * gridDim.y - 1;
     __syncthreads();
     if (!s_last) return;
     __threadfence();
@@ -564,15 +572,16 @@ int gs_stage_tile_bin(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stre
     hipLaunchKernelGGL(slice_sort_kernel<DIST>, dim3(plan.slices), dim3(BIN_THREADS), lds, stream, ws.rects,           \
                        ws.rec_geom, D, f->N, plan.per_slice, T, (uint32_t)G.ntx, plan.cap, ws.block_sums,              \
                        ws.block_vis, ws.bin_table, ws.slice_pairs, ws.keys_a, (uint64_t)f->max_pairs,                  \
-                       f->training ? ws.pair_offsets : nullptr, ws.counters)
+                       f->training ? ws.pair_offsets : nullptr, ws.tile_count, ws.counters)
         if (dist)
             GS_LAUNCH_SLICE_SORT(true);
         else
             GS_LAUNCH_SLICE_SORT(false);
 #undef GS_LAUNCH_SLICE_SORT
         GS_CHECK_LAUNCH();
-        hipLaunchKernelGGL(bin_totals_kernel, dim3((unsigned)gs_div_up(T, 256)), dim3(256), 0, stream, ws.bin_table,
-                           plan.slices, T, ws.tile_count, ws.tile_ranges, ws.counters);
+        hipLaunchKernelGGL(bin_totals_kernel, dim3((unsigned)gs_div_up(T, 256), (unsigned)gs_div_up(plan.slices, TOT_CHUNK)),
+                           dim3(256), 0, stream, ws.bin_table, plan.slices, T, ws.tile_count, ws.tile_ranges,
+                           ws.counters);
         GS_CHECK_LAUNCH();
         return 0;
     }

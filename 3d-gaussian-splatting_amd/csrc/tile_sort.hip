@@ -217,6 +217,22 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(uint64_t *__restrict__ k
     constexpr bool PACKED = SRC != SRC_KEYS;  // the unsorted element already is (depth_bits << 32 | gaussian)
     __shared__ uint64_t s_a[CAP];
     __shared__ uint32_t s_scan[4];
+    // SRC_GATHER: where the pairs of this workgroup's four tiles start in every slice region (absolute index into
+    // `pairs`), tiles t0 .. t0 + 4 (the fifth column closes the fourth tile): row j holds S entries.  Loaded once per
+    // workgroup -- thread = slice, five consecutive words of its table row: ONE cache line per slice for all four
+    // tiles -- instead of two scattered 4-byte reads per slice and tile.
+    __shared__ uint32_t s_off[SRC == SRC_GATHER ? 5 * GS_BIN_MAX_SLICES : 1];
+    if (SRC == SRC_GATHER) {
+        const uint32_t t0 = blockIdx.x * 4;
+        const size_t stride = (size_t)GS.T + 1;
+        for (uint32_t sl = threadIdx.x; sl < GS.S; sl += 256) {
+            const uint32_t *r = GS.table + sl * stride;
+            const uint32_t b = GS.slice_base[sl];
+#pragma unroll
+            for (uint32_t j = 0; j < 5; ++j) s_off[j * GS.S + sl] = b + r[t0 + j < GS.T ? t0 + j : GS.T];
+        }
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63;
     const uint32_t wave = threadIdx.x >> 6;
     uint32_t tile, start, n;
@@ -246,26 +262,24 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(uint64_t *__restrict__ k
     };
     // SRC_GATHER: copies the current tile's pairs from the S slice regions to dst[0 .. n) (any order: the sort that
     // follows orders by the unique (depth_bits, gaussian)).  `nthreads` threads with index `tid` cooperate (one wave
-    // or the workgroup: `wg` selects the cross-wave prefix); four slices per thread are in flight at a time.
+    // or the workgroup: `wg` selects the cross-wave prefix); the first pair of four slices per thread is in flight
+    // at a time (most (slice, tile) cells hold one or two pairs).
     auto gather = [&](uint64_t *dst, uint32_t tid, uint32_t nthreads, bool wg) {
         uint32_t filled = 0;
-        const size_t stride = (size_t)GS.T + 1;
+        const uint32_t *o_lo = s_off + (tile - blockIdx.x * 4) * GS.S, *o_hi = o_lo + GS.S;
         for (uint32_t s0 = 0; s0 < GS.S; s0 += 4 * nthreads) {
-            uint32_t o0[4], c[4], sb[4];
+            uint32_t a[4], c[4], d[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const uint32_t sl = s0 + q * nthreads + tid;
-                o0[q] = c[q] = sb[q] = 0;
+                a[q] = c[q] = 0;
                 if (sl < GS.S) {
-                    const uint32_t *r = GS.table + sl * stride + tile;
-                    o0[q] = r[0];
-                    c[q] = r[1] - o0[q];
-                    sb[q] = GS.slice_base[sl];
+                    a[q] = o_lo[sl];
+                    c[q] = o_hi[sl] - a[q];
                 }
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                if (s0 + q * nthreads >= GS.S) break;  // uniform
                 const uint32_t incl = gs_wave_incl_scan_u32(c[q]);
                 uint32_t off = incl - c[q], total = __shfl(incl, 63, 64);
                 if (wg) {  // uniform: prefix over the four waves
@@ -279,10 +293,18 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(uint64_t *__restrict__ k
                         total += s_scan[w];
                     }
                 }
-                const uint64_t *src = GS.pairs + sb[q] + o0[q];
-                for (uint32_t k = 0; k < c[q]; ++k) dst[filled + off + k] = src[k];
+                d[q] = filled + off;
                 filled += total;
             }
+            uint64_t first[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) first[q] = c[q] ? GS.pairs[a[q]] : 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (c[q]) dst[d[q]] = first[q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                for (uint32_t k = 1; k < c[q]; ++k) dst[d[q] + k] = GS.pairs[a[q] + k];
         }
     };
     // loads window w of the current bucket into registers, sorts it, hands it to `out(e, key)`

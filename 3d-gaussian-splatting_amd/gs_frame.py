@@ -323,6 +323,18 @@ class FrameRenderer:
         rec = self._ws[off:off + 64 * f.N].view(torch.float32).reshape(f.N, 16)
         return rec[:, 2] != 0  # depth |p_c| > near > 0 for visible Gaussians, 0 for culled ones
 
+    def composited_steps(self) -> int:
+        """Sum over tiles of the Gaussians the last TRAINING forward composited before every pixel of the tile had
+        stopped: the work the compositing kernels really did (the pair count is its upper bound).  Synchronises."""
+        f = self._frame
+        if f is None or not f.training:
+            raise RuntimeError("composited_steps() needs a preceding training forward")
+        ptr = C.c_void_p()
+        _lib.check(_lib.gs_frame_debug_tile_nproc(C.byref(f), C.byref(ptr)), "gs_frame_debug_tile_nproc")
+        off = ptr.value - self._ws.data_ptr()
+        T = self._grid.n_tiles
+        return int(self._ws[off:off + 4 * T].view(torch.int32).to(torch.int64).sum().item())
+
     def debug_views(self):
         """Device tensors aliasing the workspace of the last forward (parity tests)."""
         f = self._frame

@@ -195,12 +195,16 @@ def main():
                     "kernel_ms": round(stage_ms["raster"], 4), "workload": cfg}
             if not use_sh:
                 # the compositing kernel is fp32-VALU bound, not HBM bound: 73 flops per Gaussian
-                # per 4 pixels of a lane (5 shared + 34 per packed pixel pair) => 18.25 flops per (pair, pixel);
-                # peak = packed fp32 FMA on 256 CUs x 4 SIMD x 16 lanes at 2.4 GHz
-                tf = 18.25 * 256 * st.pairs / (stage_ms["raster"] * 1e-3) / 1e12
+                # per 4 pixels of a lane (5 shared + 34 per packed pixel pair) => 18.25 flops per (step, pixel), a step
+                # being one Gaussian composited by one tile; tiles stop when all their pixels have (composited steps
+                # <= pairs, counted by a training forward); peak = packed fp32 FMA, 256 CUs x 4 SIMD x 16 lanes, 2.4 GHz
+                rt = FrameRenderer(dev, max_pairs=r.max_pairs, training=True, auto_grow=False)
+                rt.forward(*params, cam)
+                steps_done = rt.composited_steps()
+                del rt
+                tf = 18.25 * 256 * steps_done / (stage_ms["raster"] * 1e-3) / 1e12
                 roof["valu"] = {"achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s fp32 vector",
-                                "frac": round(tf / 157.3, 3),
-                                "note": "upper bound on work: early-terminated tiles skip Gaussians"}
+                                "frac": round(tf / 157.3, 3), "composited_steps": steps_done}
             b_fwd = 44 * n + (64 + 8 * C) * st.visible + (72 + 4 * C) * st.pairs + 12 * P + 4 * T
             res.update(roofline=roof, stages=stages, stage_total_ms=round(med["total"], 4),
                        frame_roofline={"algorithmic_bytes": int(b_fwd),

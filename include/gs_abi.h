@@ -253,6 +253,11 @@ int gs_frame_debug_views(const gs_frame *f, const uint64_t **sorted_keys,
                          const float **rec_geom, const float **rec_cov, const float **rec_color,
                          const uint32_t **tiles_touched);
 
+/* [T] uint32: how many Gaussians of its list each tile's forward actually composited before all of its pixels had
+ * stopped (a multiple of 64 except for the last chunk), kept by TRAINING forwards for the backward.  Measurement
+ * aid: the compositing work of a frame is sum(tile_nproc) steps, not the pair count. */
+int gs_frame_debug_tile_nproc(const gs_frame *f, const uint32_t **tile_nproc);
+
 /* Backward frame: grad_image is dL/d(image) [height,width,3] (w.r.t. the clamped, cropped
  * output).  Writes dL/d(raw parameter) for every Gaussian (zeros for culled ones):
  * grad_pos [N,3], grad_quat [N,4], grad_scale [N,3], grad_opa [N], grad_rgb [N,color_dim].

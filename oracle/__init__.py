@@ -118,6 +118,19 @@ def global_culling_backward(pos, quat, scale, rot, tran, gradout_pos, gradout_co
     return gp, gq, gs
 
 
+def global_culling_backward_scale(pos, quat, scale, rot, tran, s_pos, s_cov, mask):
+    """Conditioning scales of K2's outputs from those of its inputs (float64 in / out; gs_oracle.c)."""
+    pos, quat, scale, rot, tran = _f(pos), _f(quat), _f(scale), _f(rot), _f(tran)
+    s_pos = np.ascontiguousarray(s_pos, np.float64)
+    s_cov = np.ascontiguousarray(s_cov, np.float64)
+    mask = np.ascontiguousarray(mask, np.int64)
+    n = pos.shape[0]
+    op, oq, os_ = np.zeros((n, 3)), np.zeros((n, 4)), np.zeros((n, 3))
+    lib().gso_global_culling_backward_scale(_vp(pos), _vp(quat), _vp(scale), _vp(rot), _vp(tran), C.c_int64(n),
+                                            _vp(s_pos), _vp(s_cov), _vp(mask), _vp(op), _vp(oq), _vp(os_))
+    return op, oq, os_
+
+
 def tile_rect(cx, cy, a, b, c, d, thresh, tlx, tly, ntx, nty, leftmost, topmost):
     rect = np.zeros(4, np.uint32)
     ok = lib().gso_tile_rect(C.c_float(cx), C.c_float(cy), C.c_float(a), C.c_float(b), C.c_float(c),
@@ -215,7 +228,7 @@ def draw(pos, rgb, opa, cov, accum, padded_h, padded_w, focal_x, focal_y, weight
     return res
 
 
-def draw_ambiguous(pos, opa, cov, accum, padded_h, padded_w, focal_x, focal_y, band=1e-4):
+def draw_ambiguous(pos, opa, cov, accum, padded_h, padded_w, focal_x, focal_y, band=2e-5):
     """[padded_h, padded_w] bool: pixels whose transmittance passes within ``band`` (relative) of the 1e-4 stop
     threshold of K7 / K8 -- where stopping one Gaussian earlier or later is a legitimate fp32 outcome (gs_oracle.c)."""
     pos, opa, cov = _f(pos), _f(opa), _f(cov)

@@ -358,6 +358,88 @@ GSO_API void gso_gather_gaussians(const int32_t *accum, const int32_t *list, int
     }
 }
 
+/* ---------------------------------------------------------------------------------------
+ * Conditioning scale of K2 (test infrastructure, see draw_backward_impl): the same formulas as
+ * gso_global_culling_backward with every product taken between magnitudes and every sum / difference
+ * replaced by the sum of the magnitudes of its operands (double).  s_pos[N,3] / s_cov[N,4] are the scales
+ * of dL/dpos_i and dL/dcov; out_*: the scales of dL/dpos, dL/dquat_hat, dL/dscale_hat.  Any fp32
+ * evaluation of K2 differs from another one by a modest number of ulp of these.
+ * ------------------------------------------------------------------------------------- */
+GSO_API void gso_global_culling_backward_scale(const float *pos, const float *quat, const float *scale,
+                                               const float *rot, const float *tran, int64_t n, const double *s_pos,
+                                               const double *s_cov, const int64_t *mask, double *out_pos,
+                                               double *out_quat, double *out_scale) {
+    for (int64_t pid = 0; pid < n; ++pid) {
+        if (mask[pid] == 0) continue;
+        float pcf[3];
+        world_to_camera(pos + 3 * pid, rot, tran, pcf);
+        const double pc[3] = {fabs((double)pcf[0]), fabs((double)pcf[1]), fabs((double)pcf[2])};
+        const double r = sqrt(pc[0] * pc[0] + pc[1] * pc[1] + pc[2] * pc[2]);
+        const double gi[3] = {s_pos[pid * 3], s_pos[pid * 3 + 1], s_pos[pid * 3 + 2]};
+        double gc[3];
+        gc[0] = gi[0] / pc[2] + gi[2] * pc[0] / r;
+        gc[1] = gi[1] / pc[2] + gi[2] * pc[1] / r;
+        gc[2] = gi[0] * pc[0] / (pc[2] * pc[2]) + gi[1] * pc[1] / (pc[2] * pc[2]) + gi[2] * pc[2] / r;
+        for (int ir = 0; ir < 3; ++ir) {
+            double a = 0;
+            for (int k = 0; k < 3; ++k) a += fabs((double)rot[k * 3 + ir]) * gc[k];
+            out_pos[pid * 3 + ir] = a;
+        }
+        /* |J| (rows 0, 1) and |J| |W| */
+        const double J[9] = {1 / pc[2], 0, pc[0] / (pc[2] * pc[2]), 0, 1 / pc[2], pc[1] / (pc[2] * pc[2]), 0, 0, 0};
+        double JW[9];
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) {
+                double v = 0;
+                for (int k = 0; k < 3; ++k) v += J[a * 3 + k] * fabs((double)rot[k * 3 + c]);
+                JW[a * 3 + c] = v;
+            }
+        const double g2[4] = {s_cov[pid * 4], s_cov[pid * 4 + 1], s_cov[pid * 4 + 2], s_cov[pid * 4 + 3]};
+        double g3[9];
+        for (int ir = 0; ir < 3; ++ir)
+            for (int ic = 0; ic < 3; ++ic) {
+                double v = 0;
+                for (int ii = 0; ii < 2; ++ii)
+                    for (int ij = 0; ij < 2; ++ij) v += g2[ii * 2 + ij] * JW[ii * 3 + ir] * JW[ij * 3 + ic];
+                g3[ir * 3 + ic] = v;
+            }
+        const double w = fabs((double)quat[4 * pid]), x = fabs((double)quat[4 * pid + 1]),
+                     y = fabs((double)quat[4 * pid + 2]), z = fabs((double)quat[4 * pid + 3]);
+        const double R[9] = {1 + 2 * y * y + 2 * z * z, 2 * x * y + 2 * z * w, 2 * x * z + 2 * y * w,
+                             2 * x * y + 2 * z * w, 1 + 2 * x * x + 2 * z * z, 2 * y * z + 2 * x * w,
+                             2 * x * z + 2 * y * w, 2 * y * z + 2 * x * w, 1 + 2 * x * x + 2 * y * y};
+        const double S[3] = {fabs((double)scale[pid * 3]), fabs((double)scale[pid * 3 + 1]),
+                             fabs((double)scale[pid * 3 + 2])};
+        double RS[9], gRS[9];
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) RS[a * 3 + c] = R[a * 3 + c] * S[c];
+        for (int ir = 0; ir < 3; ++ir)
+            for (int ic = 0; ic < 3; ++ic) {
+                double v = 0;
+                for (int k = 0; k < 3; ++k) v += (g3[k * 3 + ir] + g3[ir * 3 + k]) * RS[k * 3 + ic];
+                gRS[ir * 3 + ic] = v;
+            }
+        for (int i = 0; i < 3; ++i)
+            out_scale[pid * 3 + i] = gRS[0 * 3 + i] * R[0 * 3 + i] + gRS[1 * 3 + i] * R[1 * 3 + i] + gRS[2 * 3 + i] * R[2 * 3 + i];
+        const double sx = S[0], sy = S[1], sz = S[2], qr = w, qi = x, qj = y, qk = z;
+        const double c_qr[9] = {0, 2 * sy * qk, 2 * sz * qj, 2 * sx * qk, 0, 2 * sz * qi, 2 * sx * qj, 2 * sy * qi, 0};
+        const double c_qi[9] = {0, 2 * sy * qj, 2 * sz * qk, 2 * sx * qj, 4 * sy * qi, 2 * sz * qr,
+                                2 * sx * qk, 2 * sy * qr, 4 * sz * qi};
+        const double c_qj[9] = {4 * sx * qj, 2 * sy * qi, 2 * sz * qr, 2 * sx * qi, 0, 2 * sz * qk,
+                                2 * sx * qr, 2 * sy * qk, 4 * sz * qj};
+        const double c_qk[9] = {4 * sx * qk, 2 * sy * qr, 2 * sz * qi, 2 * sx * qr, 4 * sy * qk, 2 * sz * qj,
+                                2 * sx * qi, 2 * sy * qj, 0};
+        double gq[4] = {0, 0, 0, 0};
+        for (int i = 0; i < 9; ++i) {
+            gq[0] += c_qr[i] * gRS[i];
+            gq[1] += c_qi[i] * gRS[i];
+            gq[2] += c_qj[i] * gRS[i];
+            gq[3] += c_qk[i] * gRS[i];
+        }
+        for (int k = 0; k < 4; ++k) out_quat[pid * 4 + k] = gq[k];
+    }
+}
+
 /* Canonical (tile, depth-bits, gaussian-index) pair list -- the integer-exact specification
  * of what splatter.py:567-613 intends (bin -> scan -> gather -> sort by (tile, depth)).
  * Pass 1 (out arrays NULL) returns M.  accum has T+1 entries. */
@@ -572,15 +654,14 @@ GSO_API void gso_draw(const float *pos, const float *rgb, const float *opa, cons
  * Pixels whose early-stop decision is not robust in fp32 (test infrastructure for the gradient parity tests).
  * K7 / K8 stop a pixel at the first Gaussian that finds its transmittance below 1e-4 (gaussian.cu:906, :578).
  * The transmittance is a product of up to hundreds of rounded factors (1 - alpha): two correct fp32 evaluations
- * (other expression order, 1-ulp exp) agree on it to ~1e-5 relative at best, so when it passes within `band`
- * (relative) of the threshold, stopping one Gaussian earlier or later is a legitimate outcome -- and changes WHICH
- * terms exist for that pixel.  amb[h,w] <- 1 for those pixels; the gradient parity tests feed a dL/dimage that is
+ * (other expression order, 1-ulp exp) agree on it to ~1e-5 relative at best -- worse behind nearly opaque Gaussians,
+ * see `eps` below -- so when it passes within that uncertainty of the threshold, stopping one Gaussian earlier or
+ * later is a legitimate outcome, and changes WHICH terms exist for that pixel.  amb[h,w] <- 1 for those pixels; the gradient parity tests feed a dL/dimage that is
  * zero there, so that every remaining term is comparable.  Same loop as gso_draw (fast exp path), alpha only.
  * ------------------------------------------------------------------------------------- */
 GSO_API void gso_draw_ambiguous(const float *pos, const float *opa, const float *cov, const int32_t *accum_idx,
                                 uint8_t *amb, int32_t h, int32_t w, float focal_x, float focal_y, float band) {
     const uint32_t ntx = (uint32_t)(w + 15) / 16;
-    const float lo = 0.0001f * (1.0f - band), hi = 0.0001f * (1.0f + band);
 #pragma omp parallel for schedule(dynamic, 4)
     for (uint32_t id_y = 0; id_y < (uint32_t)h; ++id_y)
         for (uint32_t id_x = 0; id_x < (uint32_t)w; ++id_x) {
@@ -589,8 +670,13 @@ GSO_API void gso_draw_ambiguous(const float *pos, const float *opa, const float 
             float pixel_x = (float)((id_x + 0.5 - (uint32_t)w / 2) / focal_x);
             float pixel_y = (float)((id_y + 0.5 - (uint32_t)h / 2) / focal_y);
             float accum = 1.0f;
+            /* relative uncertainty of `accum`: `band` + what the factors (1 - alpha) contribute -- a relative error
+             * e of alpha (exponent rounding: a few 1e-7) is an error e alpha / (1 - alpha) of the factor, which is
+             * large exactly where it matters, behind nearly opaque Gaussians */
+            double eps = band;
             uint8_t flag = 0;
             for (uint32_t g = start; g < end; ++g) {
+                const double lo = 0.0001 * (1.0 - eps), hi = 0.0001 * (1.0 + eps);
                 if (accum >= lo && accum <= hi) flag = 1; /* this test could go either way */
                 if (accum < lo) break;                    /* well below: every evaluation has stopped */
                 float a = cov[g * 4], b = cov[g * 4 + 1], c = cov[g * 4 + 2], d = cov[g * 4 + 3];
@@ -598,6 +684,8 @@ GSO_API void gso_draw_ambiguous(const float *pos, const float *opa, const float 
                 float det = (a * d - b * c);
                 double q = -(d * x * x - (b + c) * x * y + a * y * y) / (2 * det + 1e-14);
                 float alpha = expf((float)q) * opa[g];
+                eps += 2e-6 * fabs((double)alpha) / fabs(1.0 - (double)alpha + 1e-7) + 2e-7;
+                if (!(eps < 0.5)) eps = 0.5;
                 accum *= (1 - alpha);
             }
             amb[(size_t)id_x + (size_t)id_y * w] = flag;

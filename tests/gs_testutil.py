@@ -61,9 +61,10 @@ class OracleFrame:
                                   rays_o=rays.rays_o, lefttop=rays.lefttop, vdx=rays.dx, vdy=rays.dy)
         self.image = grid.crop(np.clip(self.padded, 0, 1))
 
-    def robust_grad_image(self, grad_image, band=1e-4):
+    def robust_grad_image(self, grad_image, band=2e-5):
         """dL/dimage with the pixels zeroed whose early-stop decision is not robust in fp32 (their transmittance
-        passes within ``band`` of the 1e-4 threshold: oracle.draw_ambiguous) -- typically a few hundred of 2 M.
+        passes within its own fp32 uncertainty -- ``band`` plus what nearly opaque Gaussians in front add -- of the 1e-4
+        threshold: oracle.draw_ambiguous) -- typically ~0.1 % of the pixels.
         Every gradient term is proportional to its pixel's dL/dimage, so with this input two evaluations that stop
         such a pixel one Gaussian apart still have the same set of terms to compare.  -> (grad_image, #pixels zeroed)"""
         grid = self.grid
@@ -143,20 +144,11 @@ class OracleFrame:
                 "opa": g_o.astype(np.float32), "rgb": g_c.astype(np.float32)}
 
     def _chain_scale(self, s_pos_i, s_cov, s_opa, s_col):
-        """|Jacobian| x scale: K2 is linear in (dL/dpos_i, dL/dcov) for a fixed Gaussian, so six runs on unit
-        inputs give its Jacobian for every Gaussian at once."""
+        """The scales pushed through K2 and the activations with every product taken between magnitudes and every
+        difference replaced by the sum of its operands' magnitudes (oracle.global_culling_backward_scale)."""
         sc, cam = self.scene, self.cam
-        n = sc.n
-        S_pos, S_qn, S_sn = np.zeros((n, 3)), np.zeros((n, 4)), np.zeros((n, 3))
-        for k in range(6):
-            e_pos, e_cov = np.zeros((n, 3), np.float32), np.zeros((n, 4), np.float32)
-            w = s_pos_i[:, k] if k < 2 else s_cov[:, k - 2]
-            (e_pos if k < 2 else e_cov)[:, k if k < 2 else k - 2] = 1.0
-            jp, jq, js = oracle.global_culling_backward(sc.pos, self.qn, self.sn, cam.rot, cam.tran, e_pos, e_cov,
-                                                        self.mask)
-            S_pos += np.abs(jp) * w[:, None]
-            S_qn += np.abs(jq) * w[:, None]
-            S_sn += np.abs(js) * w[:, None]
+        S_pos, S_qn, S_sn = oracle.global_culling_backward_scale(sc.pos, self.qn, self.sn, cam.rot, cam.tran,
+                                                                 s_pos_i, s_cov.reshape(-1, 4), self.mask)
         q = sc.quat.astype(np.float64)
         nr = np.linalg.norm(q, axis=1, keepdims=True)
         qh = np.abs(q / nr)

