@@ -59,7 +59,7 @@ static int validate(const gs_frame *f) {
     } else {
         GS_CHECK_ARG(f->thresh > 0.f && f->thresh < 1.f, "thresh must be in (0,1)");
     }
-    GS_CHECK_ARG((f->flags & ~GS_FRAME_EMIT_SORTED_KEYS) == 0, "unknown flag bits");
+    GS_CHECK_ARG((f->flags & ~(GS_FRAME_EMIT_SORTED_KEYS | GS_FRAME_SLICE_SORT)) == 0, "unknown flag bits");
     GS_CHECK_ARG(f->sort_mode >= 0 && f->sort_mode <= 2,
                  "sort_mode must be 0 (full LSD radix), 1 (tile-bit radix + per-tile LDS sort) or 2 (LDS counting sort "
                  "by tile + per-tile LDS sort)");
@@ -245,7 +245,7 @@ static int frame_forward_impl(const gs_frame *f, hipStream_t s, float *stage_ms)
             // slice-sorted variant: okeys holds the S tile-ordered slice regions, the per-tile sort gathers from them
             // (buckets beyond its LDS window are gathered into skeys and sorted there); table variant: okeys holds
             // the pairs grouped by tile
-            if (gs_bin_plan_for(f->N, f->max_pairs, G.n_tiles).lds_sort)
+            if (gs_bin_plan_for(f->N, f->max_pairs, G.n_tiles, (f->flags & GS_FRAME_SLICE_SORT) != 0).lds_sort)
                 rc = gs_stage_tile_sort_gather(f, ws, okeys, skeys, keys_out, sids, s);
             else
                 rc = gs_stage_tile_sort_packed(f, ws, okeys, keys_out, sids, s);

@@ -12,7 +12,7 @@ enum { GS_CNT_VISIBLE = 0, GS_CNT_PAIRS = 1, GS_CNT_OVERFLOW = 2, GS_CNT_BUCKETS
 #define GS_BIN_LDS_BYTES 160000 // dynamic LDS of a slice-sort workgroup (the CU has 160 KiB = 163,840 B)
 
 // sort_mode 2 comes in two variants (tile_bin.hip):
-//   slice-sorted (lds_sort = 1): every workgroup counting-sorts the pairs of ITS slice of the Gaussian array by tile
+//   slice-sorted (lds_sort = 1; opt-in per frame with GS_FRAME_SLICE_SORT): every workgroup counting-sorts the pairs of ITS slice of the Gaussian array by tile
 //     inside LDS (T counters + `cap` staged 8-byte pairs) and streams them out as one contiguous, tile-ordered
 //     region; the per-tile sort gathers a tile's pairs from the S slices.  No scattered global stores at all.
 //   table (lds_sort = 0): count -> column scan -> scattered 8-byte stores; kept for tile grids whose counters leave
@@ -23,11 +23,11 @@ struct gs_bin_plan {
     uint32_t per_slice;  // Gaussians per slice (a multiple of 256, the project stage's block)
     uint32_t cap;        // staged pairs that fit LDS next to the T counters (slices with more take the direct path)
 };
-static inline gs_bin_plan gs_bin_plan_for(int64_t N, int64_t max_pairs, int n_tiles) {
+static inline gs_bin_plan gs_bin_plan_for(int64_t N, int64_t max_pairs, int n_tiles, int want_lds_sort = 1) {
     gs_bin_plan p;
     const int64_t room = (int64_t)GS_BIN_LDS_BYTES - 4 * (int64_t)n_tiles;
     p.cap = room > 0 ? (uint32_t)(room / 8 / 64 * 64) : 0;
-    p.lds_sort = p.cap >= 4096;
+    p.lds_sort = want_lds_sort && p.cap >= 4096;
     const int64_t n = N > 0 ? N : 1;
     int64_t S = GS_BIN_SLICES;
     if (p.lds_sort) {
@@ -152,8 +152,9 @@ static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pair
     ws.sort_tmp_bytes = gs_sort_pairs_tmp_bytes(max_pairs);
     ws.sort_tmp = take(ws.sort_tmp_bytes);
     {
+        // sized for whichever variant the frame selects (GS_FRAME_SLICE_SORT is a per-frame flag)
         const gs_bin_plan plan = gs_bin_plan_for(N, max_pairs, G.n_tiles);
-        const size_t rows = plan.lds_sort ? plan.slices : GS_BIN_SLICES;
+        const size_t rows = plan.lds_sort && plan.slices > GS_BIN_SLICES ? plan.slices : GS_BIN_SLICES;
         ws.bin_table = (uint32_t *)take(sizeof(uint32_t) * rows * ((size_t)G.n_tiles + 1));
     }
     ws.tile_count = (uint32_t *)take(sizeof(uint32_t) * G.n_tiles);

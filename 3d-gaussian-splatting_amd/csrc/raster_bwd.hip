@@ -692,6 +692,288 @@ __global__ void __launch_bounds__(64 * GS_PP_WPB) raster_backward_pixel_kernel(R
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// SH: the pixel-parallel bucket kernel with per-pixel colours.  Same layout as raster_backward_pixel_kernel -- one
+// wave per (tile, bucket of 64 Gaussians), lanes own four PIXELS (x, y0 + 4k) as two packed pairs, the bucket's
+// Gaussians are applied front to back from the bucket's checkpoint -- plus what SH adds per (pixel, Gaussian):
+//   colour_c = sigmoid(sum_k sh_k(pixel) coef[c][k])   (27 / 48 FMAs forward, packed over the pixel pair)
+//   dL/dcoef[c][k] += dL/dC_c w colour_c (1 - colour_c) sh_k(pixel)   (27 / 48 sums over the tile's pixels)
+// The basis values of the lane's four pixels live in registers for the whole bucket (9 or 16 pairs x 2), the
+// coefficients of the current Gaussian are wave-uniform (read through the scalar cache), and the 7 + 27 (48) sums of
+// a Gaussian are reduced over the wave through LDS: every lane adds NROW consecutive entries of the [NROW][64] array
+// of partials, the lanes that own a row add the two or three slice sums that fall into it.  The colour and opacity
+// sums go straight to the Gaussian's gradient row; the six geometry sums wait in LDS for the closing algebra.
+// Why it replaces the systolic kernel for the frame path: that one spends ~125 VALU instructions per (pixel,
+// Gaussian) step of ONE pixel per lane plus 25 % pipeline fill; here the per-pixel math is packed two pixels per
+// instruction (v_pk_fma_f32 runs at the rate of v_fma_f32 on this chip: tools/ubench/sort_ops.hip), dx and the
+// Gaussian's constants are shared by the lane's four pixels and there is no fill: ~400 instructions per Gaussian
+// per wave = 1.6 per (pixel, Gaussian) against 2.4.
+template <int CDIM>
+struct PixShCfg {
+    static constexpr int NB = CDIM / 3;
+    static constexpr int NROW = 7 + CDIM;  // Sx Sy Sxx Sxy Syy Sq Sopa + the colour-coefficient sums
+};
+
+template <int CDIM, bool FRAME>
+__global__ void __launch_bounds__(64) raster_backward_pixel_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
+    constexpr int NB = PixShCfg<CDIM>::NB, NROW = PixShCfg<CDIM>::NROW;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    enum { FX, FY, FA, FB, FC, FOPA, NFLD };
+    __shared__ float s_g[NFLD][64];
+    __shared__ uint32_t s_id[64];          // FRAME: Gaussian id; else index of the pair in the sorted arrays
+    __shared__ float s_red[NROW * 64];     // [row][lane] partial sums of the current Gaussian
+    __shared__ float s_part[64][2];        // slice sums of the first reduction level
+    __shared__ float s_tot[64][8];         // geometry sums per Gaussian (Sx Sy Sxx Sxy Syy Sq)
+    __shared__ float *s_row[64];           // where Gaussian i's gradient row starts (nullptr: no row)
+    auto lds_order = [] {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    };
+    const int lane = threadIdx.x & 63;
+    const uint32_t n_tiles = (uint32_t)(G.ntx * G.nty), kb = blockIdx.x;
+    const uint4 info = I.bucket_info[kb];  // in bounds for every launched wave (the table is padded)
+    if (kb >= I.bucket_offsets[n_tiles]) return;
+    const uint32_t tile = info.x, base = info.y, r = info.z, start = info.w;
+    const uint32_t tx = tile % (uint32_t)G.ntx, ty = tile / (uint32_t)G.ntx;
+
+    // ---- this lane's Gaussian (lanes >= r re-read the bucket's last one and are zeroed below)
+    GaussianRec g;
+    const uint32_t jl = start + base + ((uint32_t)lane < r ? (uint32_t)lane : r - 1);
+    const uint32_t gid = raster_load<FRAME>(S, jl, g);
+    const uint32_t id_x = tx * 16 + (lane & 15), id_y0 = ty * 16 + (lane >> 4);
+    const float px = raster_pixel_coord(id_x, G.padW, G.focal_x);
+    const float4 *ck = I.ckpt + raster_ckpt_slot(start, tile, base / GS_BUCKET) * 256;
+    float4 c[4];
+    float f[4][3], gr[4][3];
+    bool inside[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        c[k] = ck[64 * k + lane];
+        const uint32_t id_y = id_y0 + 4 * k;
+        const float *cf = I.c_final + ((size_t)id_y * G.padW + id_x) * 3;
+        const int ox = FRAME ? (int)id_x - G.crop_left : (int)id_x, oy = FRAME ? (int)id_y - G.crop_top : (int)id_y;
+        inside[k] = !FRAME || (ox >= 0 && ox < G.width && oy >= 0 && oy < G.height);
+        const float *gp = I.grad + ((size_t)(inside[k] ? oy : 0) * (FRAME ? G.width : G.padW) + (inside[k] ? ox : 0)) * 3;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            f[k][e] = cf[e];
+            gr[k][e] = gp[e];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)  // keep every load in front of the first use (see raster_backward_pixel_kernel)
+        asm volatile("" ::"v"(gr[k][0]), "v"(gr[k][1]), "v"(gr[k][2]), "v"(f[k][0]), "v"(f[k][1]), "v"(f[k][2]),
+                     "v"(c[k].x), "v"(c[k].y), "v"(c[k].z), "v"(c[k].w));
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+            gr[k][e] = (inside[k] && (!FRAME || (f[k][e] >= 0.f && f[k][e] <= 1.f))) ? gr[k][e] : 0.f;
+    float cA = 0, cB = 0, cC = 0;
+    {
+        const bool valid = (uint32_t)lane < r;
+        raster_conic(g, cA, cB, cC);
+        s_g[FX][lane] = g.x;
+        s_g[FY][lane] = g.y;
+        s_g[FA][lane] = cA;
+        s_g[FB][lane] = cB;
+        s_g[FC][lane] = cC;
+        s_g[FOPA][lane] = valid ? g.opa : 0.f;  // opacity 0 => alpha 0: padded entries contribute exact zeros
+        s_id[lane] = FRAME ? gid : jl;
+        float *row = nullptr;
+        if (valid) {
+            if (FRAME) {
+                const uint4 rc = O.rects[gid];
+                const uint32_t y0 = rc.x & 0xffff, x0 = rc.y & 0xffff, x1 = rc.y >> 16;
+                const uint64_t slot = (uint64_t)O.pair_offsets[gid] + (ty - y0) * (x1 - x0) + (tx - x0);
+                if (slot < O.max_pairs) row = O.rows + slot * gs_row_floats(CDIM);
+            } else {
+                row = O.grad_rgb;  // reference API: separate arrays, addressed through s_id below
+            }
+        }
+        s_row[lane] = row;
+    }
+    // pixel pairs: h = 0: rows y0, y0 + 4 (k = 0, 1); h = 1: rows y0 + 8, y0 + 12 (k = 2, 3)
+    f2 py2[2], T[2], rho[2], g0[2], g1[2], g2[2], SHB[2][NB];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float sa[NB], sb[NB];
+        raster_pixel_sh<NB>(id_x, id_y0 + 8 * h, G, sa);
+        raster_pixel_sh<NB>(id_x, id_y0 + 8 * h + 4, G, sb);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) SHB[h][k] = f2{sa[k], sb[k]};
+        py2[h] = f2{raster_pixel_coord(id_y0 + 8 * h, G.padH, G.focal_y),
+                    raster_pixel_coord(id_y0 + 8 * h + 4, G.padH, G.focal_y)};
+        float Tk[2], rk[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int k = 2 * h + e;
+            // the tile's first bucket starts from the empty pixel (T, C) = (1, 0), which the forward does not store
+            const float4 ci = base == 0 ? make_float4(1.f, 0.f, 0.f, 0.f) : c[k];
+            Tk[e] = ci.x;
+            rk[e] = gr[k][0] * (f[k][0] - ci.y) + gr[k][1] * (f[k][1] - ci.z) + gr[k][2] * (f[k][2] - ci.w);
+        }
+        T[h] = f2{Tk[0], Tk[1]};
+        rho[h] = f2{rk[0], rk[1]};
+        g0[h] = f2{gr[2 * h][0], gr[2 * h + 1][0]};
+        g1[h] = f2{gr[2 * h][1], gr[2 * h + 1][1]};
+        g2[h] = f2{gr[2 * h][2], gr[2 * h + 1][2]};
+    }
+    lds_order();
+
+    auto splat = [](float v) { return f2{v, v}; };
+    auto pk_fma = [](f2 a, f2 b, f2 cc) { return __builtin_elementwise_fma(a, b, cc); };
+    // first reduction level: this lane adds the NROW consecutive entries [lane NROW, (lane + 1) NROW) of s_red, which
+    // lie in row r0 = lane NROW / 64 and, from entry `split` on, in row r0 + 1
+    const uint32_t flat0 = (uint32_t)lane * NROW, r0 = flat0 >> 6;
+    const uint32_t split = (r0 + 1) * 64 - flat0 < (uint32_t)NROW ? (r0 + 1) * 64 - flat0 : (uint32_t)NROW;
+
+    // the coefficients of Gaussian i sit at a wave-uniform address (one cache line broadcast to the wave); those of
+    // Gaussian i + 1 are requested as soon as the forward evaluation of Gaussian i has consumed the registers, so
+    // that the round trip hides behind the gradient half of the iteration
+    float co[CDIM];
+    auto load_coef = [&](uint32_t i) {
+        const uint32_t id = __builtin_amdgcn_readfirstlane(s_id[i]);
+        const float *cf = (FRAME ? S.sh : S.rgb) + (size_t)id * CDIM;
+#pragma unroll
+        for (int k = 0; k < CDIM; ++k) co[k] = cf[k];
+        return id;
+    };
+    uint32_t id_next = load_coef(0);
+    for (uint32_t i = 0; i < r; ++i) {
+        const float gx = s_g[FX][i], gy = s_g[FY][i], uA = s_g[FA][i], uB = s_g[FB][i], uC = s_g[FC][i];
+        const float opa = s_g[FOPA][i];
+        const uint32_t id_i = id_next;
+        const float dx = px - gx;
+        const float bdx = uB * dx, adx2 = uA * dx * dx;
+        float red[NROW];  // this lane's partial sums over its four pixels
+#pragma unroll
+        for (int m = 0; m < NROW; ++m) red[m] = 0.f;
+        f2 S1 = {0.f, 0.f}, Sy = S1, Syy = S1, Sq = S1, Sopa = S1;
+        f2 D[2][3];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f2 dy = py2[h] - splat(gy);
+            const f2 q = pk_fma(pk_fma(splat(uC), dy, splat(-bdx)), dy, splat(adx2));
+            const f2 Gv = {gs_exp2(-q.x), gs_exp2(-q.y)};
+            // colours of the pixel pair
+            f2 v0 = {0.f, 0.f}, v1 = v0, v2 = v0;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                v0 = pk_fma(SHB[h][k], splat(co[k]), v0);
+                v1 = pk_fma(SHB[h][k], splat(co[NB + k]), v1);
+                v2 = pk_fma(SHB[h][k], splat(co[2 * NB + k]), v2);
+            }
+            const f2 c0 = {gs_rcp(1.0f + __expf(-v0.x)), gs_rcp(1.0f + __expf(-v0.y))};
+            const f2 c1 = {gs_rcp(1.0f + __expf(-v1.x)), gs_rcp(1.0f + __expf(-v1.y))};
+            const f2 c2 = {gs_rcp(1.0f + __expf(-v2.x)), gs_rcp(1.0f + __expf(-v2.y))};
+            // 1 / (1 - alpha + 1e-7) as one fma + rcp (see raster_backward_pixel_kernel)
+            const f2 den = pk_fma(-Gv, splat(opa), splat(1.00000011920928955f));
+            const f2 rc = {gs_rcp(den.x), gs_rcp(den.y)};
+            const bool l0 = T[h].x > GS_T_STOP, l1 = T[h].y > GS_T_STOP;
+            const f2 araw = Gv * splat(opa);
+            const f2 alpha = {l0 ? araw.x : 0.f, l1 ? araw.y : 0.f};
+            const f2 w = alpha * T[h];
+            const f2 gc = pk_fma(g2[h], c2, pk_fma(g1[h], c1, g0[h] * c0));
+            rho[h] = pk_fma(-w, gc, rho[h]);
+            f2 d_alpha = pk_fma(T[h], gc, -(rho[h] * rc));
+            d_alpha = f2{l0 ? d_alpha.x : 0.f, l1 ? d_alpha.y : 0.f};
+            const f2 one = {1.0f, 1.0f};
+            D[h][0] = g0[h] * w * (c0 * (one - c0));
+            D[h][1] = g1[h] * w * (c1 * (one - c1));
+            D[h][2] = g2[h] * w * (c2 * (one - c2));
+            Sopa = pk_fma(d_alpha, Gv, Sopa);
+            const f2 s = d_alpha * alpha;
+            const f2 sdy = s * dy;
+            S1 += s;
+            Sy += sdy;
+            Syy = pk_fma(sdy, dy, Syy);
+            Sq = pk_fma(s, q, Sq);
+            T[h] = T[h] - w;
+        }
+        id_next = load_coef(i + 1 < r ? i + 1 : i);
+        {
+            const float s1 = S1.x + S1.y, sy = Sy.x + Sy.y;
+            const float sx = s1 * dx;
+            red[0] = sx;             // Sx
+            red[1] = sy;             // Sy
+            red[2] = sx * dx;        // Sxx
+            red[3] = sy * dx;        // Sxy
+            red[4] = Syy.x + Syy.y;  // Syy
+            red[5] = Sq.x + Sq.y;    // Sq
+            red[6] = Sopa.x + Sopa.y;
+        }
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const f2 p = pk_fma(D[1][ch], SHB[1][k], D[0][ch] * SHB[0][k]);
+                red[7 + ch * NB + k] = p.x + p.y;
+            }
+#pragma unroll
+        for (int m = 0; m < NROW; ++m) s_red[m * 64 + lane] = red[m];
+        lds_order();
+        {
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < NROW; ++j) {
+                const float v = s_red[flat0 + j];
+                if ((uint32_t)j < split)
+                    a0 += v;
+                else
+                    a1 += v;
+            }
+            s_part[lane][0] = a0;
+            s_part[lane][1] = a1;
+        }
+        lds_order();
+        if (lane < NROW) {
+            // row `lane` = entries [64 lane, 64 lane + 64): the slices of lanes l_lo .. l_hi overlap it
+            const uint32_t l_lo = (64u * lane) / NROW, l_hi = (64u * lane + 63u) / NROW;
+            float t = 0.f;
+            for (uint32_t l = l_lo; l <= l_hi; ++l) t += s_part[l][(uint32_t)lane - ((l * NROW) >> 6)];
+            if (lane < 6) {
+                s_tot[i][lane] = t;
+            } else if (FRAME) {
+                float *row = s_row[i];
+                if (row) row[lane] = t;  // float 6 of a row: sum dL/dalpha G (opacity); 7 + m: coefficient m
+            } else {
+                const size_t j = id_i;
+                if (lane == 6)
+                    O.grad_opa[j] = t;
+                else
+                    O.grad_rgb[j * CDIM + (lane - 7)] = t;
+            }
+        }
+        lds_order();
+    }
+    if ((uint32_t)lane < r) {  // one lane per Gaussian finishes the geometry algebra
+        const float *t = s_tot[lane];
+        const float Sx = t[0], Sy = t[1], Sxx = t[2], Sxy = t[3], Syy = t[4], Sq = t[5];
+        const float a = g.a, b = g.b, cc = g.c, d = g.d;
+        const float iPn = 1.0f / (2.0f * raster_det(a, b, cc, d) + 1e-14f);
+        const float Su = Sq * GS_LN2;
+        const float ogx = GS_LN2 * (2.0f * cA * Sx - cB * Sy), ogy = GS_LN2 * (2.0f * cC * Sy - cB * Sx);
+        const float ga = iPn * (-Syy + 2.0f * d * Su), gb = iPn * (Sxy - 2.0f * cc * Su);
+        const float gcc = iPn * (Sxy - 2.0f * b * Su), gd = iPn * (-Sxx + 2.0f * a * Su);
+        if (FRAME) {
+            float *row = s_row[lane];
+            if (row) {
+                reinterpret_cast<float4 *>(row)[0] = make_float4(ogx, ogy, ga, gb);
+                reinterpret_cast<float2 *>(row)[2] = make_float2(gcc, gd);
+                constexpr int RW = gs_row_floats(CDIM);
+#pragma unroll
+                for (int m = 7 + CDIM; m < RW; ++m) row[m] = 0.f;  // padding of the row
+            }
+        } else {
+            const size_t j = (size_t)start + base + lane;
+            O.grad_pos[j * 3 + 0] = ogx;
+            O.grad_pos[j * 3 + 1] = ogy;
+            reinterpret_cast<float4 *>(O.grad_cov)[j] = make_float4(ga, gb, gcc, gd);
+        }
+    }
+}
+
 // sigmoid=True of the reference API: ceil buckets in the systolic kernel, no tail kernel (a rarely used flag)
 template <int CDIM>
 void launch_bwd_sig(const RasterSrc &S, const RasterGeom &G, const BwdIn &I, const BwdOut &O, int64_t max_buckets,
@@ -701,6 +983,9 @@ void launch_bwd_sig(const RasterSrc &S, const RasterGeom &G, const BwdIn &I, con
     hipLaunchKernelGGL((raster_backward_kernel<CDIM, false, true>), dim3(grid), dim3(64 * WPB), 0, stream, S, G, I, O);
 }
 
+#ifndef GS_BWD_SH_PIXEL
+#define GS_BWD_SH_PIXEL 1  // 0: the systolic kernel for SH as well (A/B switch for tools/ab_variants.py)
+#endif
 template <int CDIM, bool FRAME>
 void launch_bwd(const RasterSrc &S, const RasterGeom &G, const BwdIn &I, const BwdOut &O, int64_t max_buckets,
                 hipStream_t stream) {
@@ -710,6 +995,9 @@ void launch_bwd(const RasterSrc &S, const RasterGeom &G, const BwdIn &I, const B
         const int64_t blocks = gs_div_up(max_buckets > 0 ? max_buckets : 1, GS_PP_WPB);
         hipLaunchKernelGGL((raster_backward_pixel_kernel<FRAME>), dim3((unsigned)blocks), dim3(64 * GS_PP_WPB), 0, stream,
                            S, G, I, O);
+    } else if (GS_BWD_SH_PIXEL) {
+        hipLaunchKernelGGL((raster_backward_pixel_sh_kernel<(CDIM == 3 ? 27 : CDIM), FRAME>),
+                           dim3((unsigned)(max_buckets > 0 ? max_buckets : 1)), dim3(64), 0, stream, S, G, I, O);
     } else {
         hipLaunchKernelGGL((raster_backward_kernel<CDIM, FRAME>), dim3(grid), dim3(64 * WPB), 0, stream, S, G, I, O);
     }

@@ -514,9 +514,17 @@ __global__ void __launch_bounds__(256) bin_totals_kernel(const uint32_t *__restr
     // exclusive scan of the T totals by this (the last) workgroup: thread i owns a contiguous run of tiles
     const uint32_t per = (T + 255) / 256;
     const uint32_t t0 = threadIdx.x * per < T ? threadIdx.x * per : T, t1 = t0 + per < T ? t0 + per : T;
-    const volatile uint32_t *tc = tile_count;  // written by other workgroups: no stale non-coherent reads
+    // the totals were written by other workgroups' atomics (L2): read them with device-scope loads, eight in flight
+    // (a `volatile` loop issued them one by one: 64 dependent round trips, 50 us)
+    auto tc = [&](uint32_t i) { return __hip_atomic_load(tile_count + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     uint32_t mine = 0;
-    for (uint32_t i = t0; i < t1; ++i) mine += tc[i];
+    for (uint32_t i = t0; i < t1; i += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = i + k < t1 ? tc(i + k) : 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) mine += v[k];
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t incl = gs_wave_incl_scan_u32(mine);
     if (lane == 63) s_wave[wave] = incl;
@@ -528,11 +536,17 @@ __global__ void __launch_bounds__(256) bin_totals_kernel(const uint32_t *__restr
         total += s_wave[w];
     }
     uint32_t run = off + incl - mine;
-    for (uint32_t i = t0; i < t1; ++i) {
-        const uint32_t c = tc[i];
-        // every tile is written (empty ones as (0, 0)): no memset of the ranges
-        reinterpret_cast<int2 *>(tile_ranges)[i] = c ? make_int2((int)run, (int)(run + c)) : make_int2(0, 0);
-        run += c;
+    for (uint32_t i = t0; i < t1; i += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = i + k < t1 ? tc(i + k) : 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (i + k >= t1) break;
+            // every tile is written (empty ones as (0, 0)): no memset of the ranges
+            reinterpret_cast<int2 *>(tile_ranges)[i + k] = v[k] ? make_int2((int)run, (int)(run + v[k])) : make_int2(0, 0);
+            run += v[k];
+        }
     }
     if (threadIdx.x == 0) counters[GS_CNT_PAIRS] = total;
 }
@@ -547,7 +561,7 @@ static uint32_t bin_per_block(int64_t N) {
 
 int gs_stage_tile_bin(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream) {
     gs_frame_geom G = gs_frame_geometry(f);
-    const gs_bin_plan plan = gs_bin_plan_for(f->N, f->max_pairs, G.n_tiles);
+    const gs_bin_plan plan = gs_bin_plan_for(f->N, f->max_pairs, G.n_tiles, (f->flags & GS_FRAME_SLICE_SORT) != 0);
     const uint32_t T = (uint32_t)G.n_tiles;
     const bool dist = f->tile_culling_method == 0;
     GsDistCull D = {(float)(G.padW / 2), (float)(G.padH / 2), f->focal_x, f->focal_y, f->thresh};

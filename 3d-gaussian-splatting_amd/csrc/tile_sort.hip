@@ -460,7 +460,7 @@ int gs_stage_tile_sort_packed(const gs_frame *f, const gs_frame_ws &ws, uint64_t
 int gs_stage_tile_sort_gather(const gs_frame *f, const gs_frame_ws &ws, const uint64_t *slice_pairs_buf,
                               uint64_t *big_scratch, uint64_t *keys_out, uint32_t *ids_out, hipStream_t stream) {
     gs_frame_geom G = gs_frame_geometry(f);
-    const gs_bin_plan plan = gs_bin_plan_for(f->N, f->max_pairs, G.n_tiles);
+    const gs_bin_plan plan = gs_bin_plan_for(f->N, f->max_pairs, G.n_tiles, (f->flags & GS_FRAME_SLICE_SORT) != 0);
     GatherSrc gsrc = {slice_pairs_buf, ws.bin_table, ws.slice_pairs, plan.slices, (uint32_t)G.n_tiles};
     hipLaunchKernelGGL((tile_sort_kernel<2048, SRC_GATHER>), dim3((G.n_tiles + 3) / 4), dim3(256), 0, stream,
                        keys_out, ids_out, big_scratch, ws.tile_ranges, (uint32_t)G.n_tiles, gsrc);

@@ -45,6 +45,7 @@ class GsFrame(C.Structure):
 
 
 GS_FRAME_EMIT_SORTED_KEYS = 1
+GS_FRAME_SLICE_SORT = 2
 
 
 def _sig(name, restype, *argtypes):

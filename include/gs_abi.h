@@ -148,6 +148,13 @@ int gs_sort_pairs_bits(uint64_t *keys0, uint32_t *vals0, uint64_t *keys1, uint32
                                        gs_frame_debug_views returns (modes 0 / 1 always have them); the raster
                                        kernels only read the sorted ids, so the default path skips 8 bytes per pair */
 
+#define GS_FRAME_SLICE_SORT 2       /* sort_mode 2: the slice-sorted binning variant (tile_bin.hip) -- every workgroup
+                                       counting-sorts the pairs of its slice of the Gaussians by tile inside LDS and
+                                       streams them out contiguously, the per-tile sort gathers from the slices.  No
+                                       scattered global store, but one small (slice, tile) cell per gather step:
+                                       measured slower than the table variant up to 2.4 M Gaussians at 1080p
+                                       (DESIGN.md), so it is opt-in.  Same result either way. */
+
 /* Frame descriptor.  All scalars are per-camera constants computed on the host exactly as
  * splatter.py does (Tiles, RayInfo, frustum guard band); rot/tran are passed by value. */
 typedef struct gs_frame {

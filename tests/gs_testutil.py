@@ -193,14 +193,17 @@ GRAD_KAPPA = 1e-5
 GRAD_L2 = 2e-5  # ||got - ref||_2 / ||ref||_2 per tensor
 
 
-GRAD_FLOOR = 1e-30  # the GPU flushes subnormal results to zero, the CPU oracle keeps them (1e-38 .. 1e-45)
+# Entries 16 orders of magnitude below the tensor's largest are sums of products whose intermediates underflow in
+# fp32 (the transcendental unit flushes subnormal operands, the CPU oracle keeps them): compared up to this floor.
+GRAD_FLOOR_REL = 1e-16
+GRAD_FLOOR = 1e-30
 
 
 def grad_close(got, ref, scale, rtol=GRAD_RTOL, kappa=GRAD_KAPPA):
     """-> (ok, worst ratio err / tol, index of the worst element, fraction of elements within rtol |ref| alone)."""
     got, ref, scale = (np.asarray(a, np.float64) for a in (got, ref, scale))
     err = np.abs(got - ref)
-    tol = rtol * np.abs(ref) + kappa * scale + GRAD_FLOOR
+    tol = rtol * np.abs(ref) + kappa * scale + GRAD_FLOOR + GRAD_FLOOR_REL * (np.abs(ref).max() if ref.size else 0.0)
     bad = err > tol
     with np.errstate(divide="ignore", invalid="ignore"):
         ratio = np.where(err > 0, err / tol, 0.0)

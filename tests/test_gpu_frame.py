@@ -33,10 +33,10 @@ def case(n, W, H, seed=7, use_sh=False, yaw=2.0, sh_degree=2):
     return scene, cam
 
 
-def check_forward(gpu, scene, cam, training=False, sort_mode=2):
+def check_forward(gpu, scene, cam, training=False, sort_mode=2, slice_sort=False):
     of = OracleFrame(scene, cam)
     r = FrameRenderer(gpu, max_pairs=max(len(of.ids) + 17, 64), training=training, auto_grow=False,
-                      sort_mode=sort_mode)
+                      sort_mode=sort_mode, slice_sort=slice_sort)
     params = to_torch(scene, gpu)
     image, padded = r.forward(*params, cam)
     st = r.stats()
@@ -65,18 +65,20 @@ def check_forward(gpu, scene, cam, training=False, sort_mode=2):
     return of, r, params
 
 
-@pytest.mark.parametrize("sort_mode", [0, 1, 2])
+@pytest.mark.parametrize("sort_mode", [0, 1, 2, "2s"])
 @pytest.mark.parametrize("n,W,H", [(10_000, 256, 256), (30_000, 333, 201), (2_000, 64, 48)])
 def test_frame_forward_parity(gpu, n, W, H, sort_mode):
-    check_forward(gpu, *case(n, W, H), sort_mode=sort_mode)
+    # "2s": sort_mode 2 with the slice-sorted binning variant (GS_FRAME_SLICE_SORT)
+    check_forward(gpu, *case(n, W, H), sort_mode=2 if sort_mode == "2s" else sort_mode, slice_sort=sort_mode == "2s")
 
 
-@pytest.mark.parametrize("sort_mode", [1, 2])
+@pytest.mark.parametrize("sort_mode", [1, 2, "2s"])
 def test_frame_forward_giant_bucket_sorted_in_chunks(gpu, sort_mode):
     # > 4096 pairs in one tile: the per-tile sort handles 2048-key chunks in LDS and the strides >= 2048 of the
-    # last merge levels through global memory (both the packed and the (key, id) input variants)
+    # last merge levels through global memory (the packed, the (key, id) and the gathered input variants)
     scene, cam = case(40_000, 32, 32, seed=8)
-    of, _, _ = check_forward(gpu, scene, cam, sort_mode=sort_mode)
+    of, _, _ = check_forward(gpu, scene, cam, sort_mode=2 if sort_mode == "2s" else sort_mode,
+                             slice_sort=sort_mode == "2s")
     assert np.diff(of.accum).max() > 4096
 
 
@@ -90,7 +92,7 @@ def test_frame_forward_slice_larger_than_the_lds_staging_buffer(gpu):
     scene.pos[big, :2] *= 0.05
     scene.pos[big, 2] = np.linspace(3.0, 8.0, len(big), dtype=np.float32)
     scene.opa[big] = -4.0
-    of, r, _ = check_forward(gpu, scene, cam, sort_mode=2)
+    of, r, _ = check_forward(gpu, scene, cam, sort_mode=2, slice_sort=True)
     counts = np.bincount(of.ids, minlength=scene.n)
     assert counts[big].sum() > 40_000  # far more than the ~19 k pairs the staging buffer holds at this tile count
 
@@ -439,15 +441,17 @@ def test_full_size_2p4M_forward_matches_oracle(gpu):
     n, W, H, use_sh = CONFIGS["cfg5"]
     scene, cam = make_scene(n, W, H, seed=2023, use_sh=use_sh), make_camera(W, H)
     params = to_torch(scene, gpu)
-    r = FrameRenderer(gpu, max_pairs=7_600_000, auto_grow=False)
-    img, _ = r.forward(*params, cam)
-    st, v = r.stats(), r.debug_views()
-    assert (st.visible, st.pairs, st.overflow) == (1_887_982, 6_950_364, 0)
     of = OracleFrame(scene, cam)
-    assert np.array_equal(v["sorted_keys"].cpu().numpy().view(np.uint64), of.keys)
-    assert np.array_equal(v["sorted_ids"].cpu().numpy(), of.ids)
-    err = np.abs(img.cpu().numpy() - of.image)
-    assert err.max() < IMG_ATOL, err.max()
+    for slice_sort in (False, True):  # both binning variants of sort_mode 2
+        r = FrameRenderer(gpu, max_pairs=7_600_000, auto_grow=False, slice_sort=slice_sort)
+        img, _ = r.forward(*params, cam)
+        st, v = r.stats(), r.debug_views()
+        assert (st.visible, st.pairs, st.overflow) == (1_887_982, 6_950_364, 0)
+        assert np.array_equal(v["sorted_keys"].cpu().numpy().view(np.uint64), of.keys)
+        assert np.array_equal(v["sorted_ids"].cpu().numpy(), of.ids)
+        err = np.abs(img.cpu().numpy() - of.image)
+        assert err.max() < IMG_ATOL, err.max()
+        del r
 
 
 def test_full_size_2p4M_sh_forward_backward_properties(gpu):

@@ -13,7 +13,7 @@ for STEP in "$@"; do
     pytest)    timeout 1200 python -m pytest tests -m gpu -q -rf --maxfail=25 -p no:cacheprovider > "$OUT/pytest.log" 2>&1 ;;
     pytest_s)  timeout 1200 python -m pytest tests -m gpu -q -rf --maxfail=25 -p no:cacheprovider -s -k "full_size_backward_matches" > "$OUT/pytest_s.log" 2>&1 ;;
     probe)     timeout 900 python tools/grad_parity_probe.py small small_sh cfg2 cfg4 > "$OUT/probe.log" 2>&1 ;;
-    ab)        timeout 900 python tools/ab_variants.py run cfg5 cfg2 cfg5_keys > "$OUT/ab.txt" 2> "$OUT/ab.err" ;;
+    ab)        timeout 900 python tools/ab_variants.py run ${AB_CFGS:-cfg5 cfg2 cfg5_keys} > "$OUT/ab.txt" 2> "$OUT/ab.err" ;;
     prof_cfg5) timeout 600 tools/profile_round.sh $TAG/prof_cfg5 cfg5 fwd > "$OUT/prof_cfg5.log" 2>&1 ;;
     prof_cfg4) timeout 600 tools/profile_round.sh $TAG/prof_cfg4 cfg4 fwdbwd > "$OUT/prof_cfg4.log" 2>&1 ;;
     prof_cfg5t) timeout 600 tools/profile_round.sh $TAG/prof_cfg5t cfg5 fwdbwd > "$OUT/prof_cfg5t.log" 2>&1 ;;

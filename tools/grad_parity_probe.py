@@ -55,6 +55,10 @@ def probe(name, scene, cam, grad_kind="sign"):
             r0 = err[s0[key] > 0] / s0[key][s0[key] > 0]
             r5 = err[s05[key] > 0] / s05[key][s05[key] > 0]
         ok, worst, where, pure = grad_close(got, rf, s05[key])
+        tol = GRAD_RTOL * np.abs(rf) + GRAD_KAPPA * s05[key] + 1e-300
+        top = np.argsort((err / tol).ravel())[-5:][::-1]
+        worst5 = [{"index": [int(x) for x in np.unravel_index(i, rf.shape)], "got": float(got.flat[i]),
+                   "ref": float(rf.flat[i]), "scale": float(s05[key].flat[i])} for i in top]
         out["tensors"][key] = {
             "max_abs_ref": float(np.abs(rf).max()), "rel_l2": float(np.linalg.norm(got - rf) / np.linalg.norm(rf)),
             "maxnorm": float(err.max() / np.abs(rf).max()),
@@ -64,7 +68,7 @@ def probe(name, scene, cam, grad_kind="sign"):
             "scale_over_ref_median": float(np.median(s05[key][nz] / np.abs(rf[nz]))),
             "grad_close": {"ok": ok, "worst_ratio": worst, "where": [int(i) for i in where], "rtol": GRAD_RTOL,
                            "kappa": GRAD_KAPPA, "frac_within_rtol_alone": pure},
-            "nonzero_where_ref_zero": int(((rf == 0) & (got != 0)).sum()),
+            "nonzero_where_ref_zero": int(((rf == 0) & (got != 0)).sum()), "worst5_before_floor": worst5,
         }
     path = os.path.join(ROOT, "gpurun_out", f"grad_parity_{name}_{grad_kind}.json")
     json.dump(out, open(path, "w"), indent=1)
