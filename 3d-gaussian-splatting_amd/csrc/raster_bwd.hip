@@ -721,8 +721,8 @@ __global__ void __launch_bounds__(64) raster_backward_pixel_sh_kernel(RasterSrc 
     enum { FX, FY, FA, FB, FC, FOPA, NFLD };
     __shared__ float s_g[NFLD][64];
     __shared__ uint32_t s_id[64];          // FRAME: Gaussian id; else index of the pair in the sorted arrays
-    __shared__ float s_red[NROW * 64];     // [row][lane] partial sums of the current Gaussian
-    __shared__ float s_part[64][2];        // slice sums of the first reduction level
+    __shared__ float s_red[NROW * 65];     // [row][lane] partial sums of the current Gaussian (rows padded to 65)
+    __shared__ float s_part[NROW][4];      // quarter-row sums of the first reduction level
     __shared__ float s_tot[64][8];         // geometry sums per Gaussian (Sx Sy Sxx Sxy Syy Sq)
     __shared__ float *s_row[64];           // where Gaussian i's gradient row starts (nullptr: no row)
     auto lds_order = [] {
@@ -823,10 +823,10 @@ __global__ void __launch_bounds__(64) raster_backward_pixel_sh_kernel(RasterSrc 
 
     auto splat = [](float v) { return f2{v, v}; };
     auto pk_fma = [](f2 a, f2 b, f2 cc) { return __builtin_elementwise_fma(a, b, cc); };
-    // first reduction level: this lane adds the NROW consecutive entries [lane NROW, (lane + 1) NROW) of s_red, which
-    // lie in row r0 = lane NROW / 64 and, from entry `split` on, in row r0 + 1
-    const uint32_t flat0 = (uint32_t)lane * NROW, r0 = flat0 >> 6;
-    const uint32_t split = (r0 + 1) * 64 - flat0 < (uint32_t)NROW ? (r0 + 1) * 64 - flat0 : (uint32_t)NROW;
+    // first reduction level: in round rd this lane adds quarter `lane / 16` (16 consecutive entries) of row
+    // 16 rd + lane % 16 -- with rows padded to 65 floats the 64 lanes of a read hit every LDS bank exactly twice
+    constexpr int NROUND = (NROW + 15) / 16;
+    const uint32_t red_row = (uint32_t)lane & 15, red_part = (uint32_t)lane >> 4;
 
     // the coefficients of Gaussian i sit at a wave-uniform address (one cache line broadcast to the wave); those of
     // Gaussian i + 1 are requested as soon as the forward evaluation of Gaussian i has consumed the registers, so
@@ -846,9 +846,6 @@ __global__ void __launch_bounds__(64) raster_backward_pixel_sh_kernel(RasterSrc 
         const uint32_t id_i = id_next;
         const float dx = px - gx;
         const float bdx = uB * dx, adx2 = uA * dx * dx;
-        float red[NROW];  // this lane's partial sums over its four pixels
-#pragma unroll
-        for (int m = 0; m < NROW; ++m) red[m] = 0.f;
         f2 S1 = {0.f, 0.f}, Sy = S1, Syy = S1, Sq = S1, Sopa = S1;
         f2 D[2][3];
 #pragma unroll
@@ -895,43 +892,41 @@ __global__ void __launch_bounds__(64) raster_backward_pixel_sh_kernel(RasterSrc 
         {
             const float s1 = S1.x + S1.y, sy = Sy.x + Sy.y;
             const float sx = s1 * dx;
-            red[0] = sx;             // Sx
-            red[1] = sy;             // Sy
-            red[2] = sx * dx;        // Sxx
-            red[3] = sy * dx;        // Sxy
-            red[4] = Syy.x + Syy.y;  // Syy
-            red[5] = Sq.x + Sq.y;    // Sq
-            red[6] = Sopa.x + Sopa.y;
+            s_red[0 * 65 + lane] = sx;             // Sx
+            s_red[1 * 65 + lane] = sy;             // Sy
+            s_red[2 * 65 + lane] = sx * dx;        // Sxx
+            s_red[3 * 65 + lane] = sy * dx;        // Sxy
+            s_red[4 * 65 + lane] = Syy.x + Syy.y;  // Syy
+            s_red[5 * 65 + lane] = Sq.x + Sq.y;    // Sq
+            s_red[6 * 65 + lane] = Sopa.x + Sopa.y;
         }
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch)
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
                 const f2 p = pk_fma(D[1][ch], SHB[1][k], D[0][ch] * SHB[0][k]);
-                red[7 + ch * NB + k] = p.x + p.y;
+                s_red[(7 + ch * NB + k) * 65 + lane] = p.x + p.y;
             }
-#pragma unroll
-        for (int m = 0; m < NROW; ++m) s_red[m * 64 + lane] = red[m];
         lds_order();
-        {
-            float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-            for (int j = 0; j < NROW; ++j) {
-                const float v = s_red[flat0 + j];
-                if ((uint32_t)j < split)
-                    a0 += v;
-                else
-                    a1 += v;
+        for (int rd = 0; rd < NROUND; ++rd) {
+            const uint32_t row = 16 * rd + red_row;
+            if (16 * (rd + 1) <= NROW || row < (uint32_t)NROW) {
+                const float *src = s_red + row * 65 + red_part * 16;
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 16; j += 4) {
+                    a0 += src[j];
+                    a1 += src[j + 1];
+                    a2 += src[j + 2];
+                    a3 += src[j + 3];
+                }
+                s_part[row][red_part] = (a0 + a1) + (a2 + a3);
             }
-            s_part[lane][0] = a0;
-            s_part[lane][1] = a1;
         }
         lds_order();
         if (lane < NROW) {
-            // row `lane` = entries [64 lane, 64 lane + 64): the slices of lanes l_lo .. l_hi overlap it
-            const uint32_t l_lo = (64u * lane) / NROW, l_hi = (64u * lane + 63u) / NROW;
-            float t = 0.f;
-            for (uint32_t l = l_lo; l <= l_hi; ++l) t += s_part[l][(uint32_t)lane - ((l * NROW) >> 6)];
+            const float t = (s_part[lane][0] + s_part[lane][1]) + (s_part[lane][2] + s_part[lane][3]);
             if (lane < 6) {
                 s_tot[i][lane] = t;
             } else if (FRAME) {

@@ -241,7 +241,7 @@ def draw_ambiguous(pos, opa, cov, accum, padded_h, padded_w, focal_x, focal_y, b
 
 def draw_backward(pos, rgb, opa, cov, accum, output, grad_output, focal_x, focal_y,
                   weight_normalize=False, sigmoid=False, use_sh=False, fast=False, rays_o=None,
-                  lefttop=None, vdx=None, vdy=None, with_scale=False, scale_w=0.05):
+                  lefttop=None, vdx=None, vdy=None, with_scale=False, scale_w=0.05, scale_w_exp=0.25):
     """K8 (gaussian.cu:440-803), intended semantics (see gs_oracle.c).  ``with_scale``: also return the
     conditioning scale of every output element (sum over pixels of |term| + scale_w x the term with every internal
     difference replaced by the magnitudes of its operands; gs_oracle.c), laid out like the four gradients."""
@@ -258,7 +258,7 @@ def draw_backward(pos, rgb, opa, cov, accum, output, grad_output, focal_x, focal
                                        C.c_int32(w), C.c_float(focal_x), C.c_float(focal_y), C.c_int(bool(sigmoid)),
                                        C.c_int(bool(fast)), _vp(rv[0]), _vp(rv[1]), _vp(rv[2]), _vp(rv[3]),
                                        C.c_int(_sh_code(use_sh, rgb)), _vp(cp), _vp(cr), _vp(co), _vp(cc),
-                                       C.c_double(scale_w))
+                                       C.c_double(scale_w), C.c_double(scale_w_exp))
         return (gp, gr, go, gc), (cp, cr, co, cc)
     lib().gso_draw_backward(_vp(pos), _vp(rgb), _vp(opa), _vp(cov), _vp(accum), _vp(output),
                             _vp(grad_output), _vp(gp), _vp(gr), _vp(go), _vp(gc), C.c_int32(h),

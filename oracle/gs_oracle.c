@@ -701,8 +701,8 @@ GSO_API void gso_draw_ambiguous(const float *pos, const float *opa, const float 
  * order is not defined).  grad_pos[:,2] is never written (stays the caller's zero).
  *
  * With non-NULL `cs_*` pointers the same pass also returns, per row element, its CONDITIONING
- * SCALE: sum over the tile's pixels of |term| + cs_w x (the term with every internal
- * difference replaced by the sum of its operands' magnitudes).  Two fp32 evaluations of the same
+ * SCALE: sum over the tile's pixels of |term| (1 + cs_w_exp x the cancellation inside exp's argument)
+ * + cs_w x (the term with every other internal difference replaced by the sum of its operands' magnitudes).  Two fp32 evaluations of the same
  * formulas in different orders (and with 1-ulp exp / rcp) agree to (a modest number of ulp) x
  * that scale, however small the signed sum turns out; the element-wise gradient tolerance of
  * the parity tests is stated in these units (tests/gs_testutil.py).
@@ -714,7 +714,7 @@ static void draw_backward_impl(const float *pos, const float *rgb, const float *
                                float focal_x, float focal_y, int sigmoid, int fast,
                                const float *rays_o, const float *lefttop, const float *vdx,
                                const float *vdy, int use_sh, float *cs_pos, float *cs_rgb,
-                               float *cs_opa, float *cs_cov, double cs_w) {
+                               float *cs_opa, float *cs_cov, double cs_w, double cs_w_exp) {
     const uint32_t ntx = (uint32_t)(w + 15) / 16, nty = (uint32_t)(h + 15) / 16;
     const int nb = sh_nb(use_sh), D = use_sh ? 3 * nb : 3;
     const int NV = 2 + D + 1 + 4;
@@ -828,7 +828,7 @@ static void draw_backward_impl(const float *pos, const float *rgb, const float *
                             const double PmAbs = fabs((double)_d * _x * _x) + fabs((double)(_b + _c) * _x * _y) +
                                                  fabs((double)_a * _y * _y);
                             const double pn = fabs((double)Pn);
-                            const double rel = 1.0 + W * PmAbs / pn; /* exponent rounding -> relative error of alpha */
+                            const double rel = 1.0 + cs_w_exp * PmAbs / pn; /* exponent rounding -> relative error of alpha */
                             double gcabs = 0, dcabs = 0;
                             for (int m = 0; m < 3; ++m) {
                                 gcabs += fabs((double)go[m] * cpc[m]);
@@ -896,7 +896,7 @@ GSO_API void gso_draw_backward(const float *pos, const float *rgb, const float *
     (void)weight_normalize; /* the reference backward ignores it too */
     draw_backward_impl(pos, rgb, opa, cov, accum_idx, output, grad_output, grad_pos, grad_rgb, grad_opa, grad_cov,
                        h, w, focal_x, focal_y, sigmoid, fast, rays_o, lefttop, vdx, vdy, use_sh, NULL, NULL, NULL,
-                       NULL, 0.0);
+                       NULL, 0.0, 0.0);
 }
 
 /* the same rows + the conditioning scale of every row element (see above); cs_* are laid out like grad_* */
@@ -907,10 +907,10 @@ GSO_API void gso_draw_backward_scaled(const float *pos, const float *rgb, const 
                                       float focal_x, float focal_y, int sigmoid, int fast,
                                       const float *rays_o, const float *lefttop, const float *vdx,
                                       const float *vdy, int use_sh, float *cs_pos, float *cs_rgb,
-                                      float *cs_opa, float *cs_cov, double cs_w) {
+                                      float *cs_opa, float *cs_cov, double cs_w, double cs_w_exp) {
     draw_backward_impl(pos, rgb, opa, cov, accum_idx, output, grad_output, grad_pos, grad_rgb, grad_opa, grad_cov,
                        h, w, focal_x, focal_y, sigmoid, fast, rays_o, lefttop, vdx, vdy, use_sh, cs_pos, cs_rgb,
-                       cs_opa, cs_cov, cs_w);
+                       cs_opa, cs_cov, cs_w, cs_w_exp);
 }
 
 /* ---------------------------------------------------------------------------------------

@@ -179,8 +179,8 @@ def _sum_by_id(ids, rows, n):
 
 # Element-wise gradient tolerance: |got - ref| <= GRAD_RTOL |ref| + GRAD_KAPPA scale, `scale` being the element's own
 # conditioning scale from OracleFrame.backward(with_scale=True): the sum over its pixels and (tile, Gaussian) rows of
-# |term| + 0.05 x (the term with every internal difference replaced by the magnitudes of its operands), pushed
-# through |Jacobian| of the projection / activation backward.  A gradient element is a signed sum of thousands of
+# |term| (1 + 0.25 x the cancellation inside exp's argument) + 0.05 x (the term with every other internal difference
+# replaced by the magnitudes of its operands), pushed through the projection / activation backward in the same way.  A gradient element is a signed sum of thousands of
 # fp32 terms, several of them differences of nearly equal numbers (T g.c against g.(C_final - C_run)/(1 - alpha) for
 # a Gaussian deep in a tile's list): two correct fp32 evaluations in different orders agree to a number of ulp of
 # that scale, however small the sum comes out -- so the tolerance is per element and NOT a fraction of the tensor's
