@@ -452,7 +452,9 @@ __global__ void __launch_bounds__(256) frame_project_kernel(
 // rows[pair][12|36|56] = (dx, dy, da, db, dc, dd, dopa, colour grads..) written by the raster backward
 // in emission order: Gaussian g owns rows [pair_offsets[g], +tiles_touched[g]).  They are summed
 // here in a fixed order (the reference's index_put_(accumulate=True), but deterministic) and pushed
-// through the projection + activation backward.  Culled Gaussians get zeros.
+// through the projection + activation backward.  Culled Gaussians get zeros.  Only rows whose flag is set were written
+// by the raster backward (pairs behind a tile's early-termination point are not): the others are skipped, never read
+// as numbers -- they are uninitialised memory.
 // PART: 0 = everything; 1 = only the projection / activation backward (grad_pos, grad_quat, grad_scale -- the
 // "geometry" bucket of the view-parallel gradient exchange); 2 = only grad_opa and grad_rgb (the "colour" bucket).
 // Parts 1 and 2 read the same rows and add them in the same order as part 0: their outputs are bit-identical to it.
@@ -461,7 +463,7 @@ template <int CDIM, int PART = 0>
 __global__ void __launch_bounds__(256) frame_project_backward_kernel(
     const float *__restrict__ pos, const float4 *__restrict__ quat, const float *__restrict__ scale,
     int64_t n, ProjectParams P, const float4 *__restrict__ rec_geom,
-    const float4 *__restrict__ rec_color, const float4 *__restrict__ rows,
+    const float4 *__restrict__ rec_color, const float4 *__restrict__ rows, const uint8_t *__restrict__ row_flags,
     const uint32_t *__restrict__ pair_offsets, const uint32_t *__restrict__ tiles_touched, uint64_t max_pairs,
     float *__restrict__ grad_pos,
     float4 *__restrict__ grad_quat, float *__restrict__ grad_scale, float *__restrict__ grad_opa,
@@ -472,6 +474,7 @@ __global__ void __launch_bounds__(256) frame_project_backward_kernel(
     // thread adds up its rows out of LDS in the same k-ascending order (results are bitwise unchanged).
     constexpr int CHUNK_F4 = 1536;  // 24 KiB = 512 rows
     __shared__ float4 s_rows[CHUNK_F4];
+    __shared__ uint8_t s_flag[CHUNK_F4 / 3];
     const int64_t pid0 = (int64_t)blockIdx.x * blockDim.x, pid = pid0 + threadIdx.x;
     const int64_t pid_last = (pid0 + blockDim.x < n ? pid0 + blockDim.x : n) - 1;
     const bool valid = pid < n;
@@ -516,6 +519,7 @@ __global__ void __launch_bounds__(256) frame_project_backward_kernel(
 #pragma unroll
         for (int e = 0; e < NA; ++e) acc[e] = 0.f;
         for (uint32_t k = threadIdx.x; k < bcnt && boff + k < max_pairs; k += 256) {
+            if (!row_flags[boff + k]) continue;
             const float4 *row = rows + (boff + k) * RW4;
 #pragma unroll
             for (int m = 0; m < RW4; ++m) {
@@ -554,9 +558,11 @@ __global__ void __launch_bounds__(256) frame_project_backward_kernel(
             const uint32_t nrows = row_end - base < rows_per_chunk ? (uint32_t)(row_end - base) : rows_per_chunk;
             const float4 *src = rows + base * 3;
             for (uint32_t i = threadIdx.x; i < nrows * 3; i += blockDim.x) s_rows[i] = src[i];
+            for (uint32_t i = threadIdx.x; i < nrows; i += blockDim.x) s_flag[i] = row_flags[base + i];
             __syncthreads();
             const uint64_t lo = off > base ? off : base, hi = off + cnt < base + nrows ? off + cnt : base + nrows;
             for (uint64_t k = lo; k < hi && !big; ++k) {
+                if (!s_flag[k - base]) continue;
                 const float4 *row = s_rows + (k - base) * 3;
                 const float4 r0 = row[0], r1 = row[1], r2 = row[2];
                 d0.x += r0.x; d0.y += r0.y; d0.z += r0.z; d0.w += r0.w;
@@ -569,6 +575,7 @@ __global__ void __launch_bounds__(256) frame_project_backward_kernel(
         // SH rows are 144 (224) contiguous bytes: a thread reading its own rows already moves whole sectors
         // (measured: the LDS detour costs 25 % here)
         for (uint64_t k = 0; k < cnt && off + k < max_pairs && !big; ++k) {
+            if (!row_flags[off + k]) continue;
             const float4 *row = rows + (off + k) * RW4;
             if (PART != 2) {
                 const float4 r0 = row[0];
@@ -760,7 +767,8 @@ int gs_stage_project_backward(const gs_frame *f, const gs_frame_ws &ws, float *g
 #define GS_LAUNCH_PROJECT_BWD(CD, PT)                                                                              \
     hipLaunchKernelGGL((frame_project_backward_kernel<CD, PT>), dim3(nblk), dim3(256), 0, stream, f->pos,         \
                        (const float4 *)f->quat, f->scale, f->N, P, ws.rec_geom, ws.rec_color,                     \
-                       (const float4 *)ws.rows, ws.pair_offsets, ws.tiles_touched, (uint64_t)f->max_pairs,        \
+                       (const float4 *)ws.rows, ws.row_flags, ws.pair_offsets, ws.tiles_touched,                  \
+                       (uint64_t)f->max_pairs,                                                                    \
                        grad_pos, (float4 *)grad_quat, grad_scale, grad_opa, grad_rgb)
 #define GS_LAUNCH_PROJECT_BWD_PARTS(CD)  \
     do {                                 \

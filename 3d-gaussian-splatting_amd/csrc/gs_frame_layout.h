@@ -110,6 +110,8 @@ struct gs_frame_ws {
     uint4 *bucket_info;            // [max_buckets + 8] (tile, first Gaussian, count, list start) per bucket
     float4 *ckpt;                  // [max_buckets][256] (T, Cr, Cg, Cb) at bucket starts
     float *rows;                   // [max_pairs][GS_ROW(C)] per-pair gradient rows in EMISSION order
+    uint8_t *row_flags;            // [max_pairs] 1 = the raster backward wrote this row (cleared per frame: the rows
+                                   // themselves are never zero-filled, unwritten ones are skipped by the reader)
     int64_t max_buckets;
     size_t zero_bytes;             // prefix of the workspace cleared at the start of every frame
     size_t total_bytes;
@@ -167,12 +169,14 @@ static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pair
         ws.bucket_info = (uint4 *)take(sizeof(uint4) * (size_t)(ws.max_buckets + 8));
         ws.ckpt = (float4 *)take(sizeof(float4) * 256 * (size_t)ws.max_buckets);
         ws.rows = (float *)take(sizeof(float) * (size_t)gs_row_floats(color_dim) * max_pairs);
+        ws.row_flags = (uint8_t *)take((size_t)max_pairs);
     } else {
         ws.tile_nproc = nullptr;
         ws.bucket_offsets = nullptr;
         ws.bucket_info = nullptr;
         ws.ckpt = nullptr;
         ws.rows = nullptr;
+        ws.row_flags = nullptr;
     }
     ws.total_bytes = off;
     return ws;

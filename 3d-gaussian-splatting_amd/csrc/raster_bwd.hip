@@ -83,7 +83,8 @@ __global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t *__res
 struct BwdOut {
     // FRAME: one row per pair, addressed in EMISSION order (pair_offsets[g] + index of the tile
     // inside g's rectangle), so the per-Gaussian sum is a contiguous, deterministic reduction
-    float *rows;                   // [max_pairs][12 | 36]
+    float *rows;                   // [max_pairs][12 | 36 | 56]
+    uint8_t *row_flags;            // [max_pairs] set to 1 for every row written (cleared per frame instead of the rows)
     const uint32_t *pair_offsets;  // [N]
     const uint4 *rects;            // [N]
     uint64_t max_pairs;
@@ -414,6 +415,7 @@ __global__ void __launch_bounds__(64 * BwdCfg<CDIM>::WPB) raster_backward_kernel
         if (slot < O.max_pairs) {
             constexpr int RW = gs_row_floats(CDIM);  // 7 geometry/opacity sums + CDIM colour sums, padded to float4s
             float4 *row = reinterpret_cast<float4 *>(O.rows + slot * RW);
+            O.row_flags[slot] = 1;
             row[0] = make_float4(gx, gy, ga, gb);
             if (CDIM == 3) {
                 row[1] = make_float4(gc, gd, Sopa, Sc0);
@@ -675,6 +677,7 @@ __global__ void __launch_bounds__(64 * GS_PP_WPB) raster_backward_pixel_kernel(R
             const uint64_t slot = (uint64_t)O.pair_offsets[gid] + (ty - y0) * (x1 - x0) + (tx - x0);
             if (slot < O.max_pairs) {
                 float4 *row = reinterpret_cast<float4 *>(O.rows + slot * 12);
+                O.row_flags[slot] = 1;
                 row[0] = make_float4(ogx, ogy, ga, gb);
                 row[1] = make_float4(gcc, gd, t[6], t[7]);
                 row[2] = make_float4(t[8], t[9], 0.f, 0.f);
@@ -786,7 +789,10 @@ __global__ void __launch_bounds__(64) raster_backward_pixel_sh_kernel(RasterSrc 
                 const uint4 rc = O.rects[gid];
                 const uint32_t y0 = rc.x & 0xffff, x0 = rc.y & 0xffff, x1 = rc.y >> 16;
                 const uint64_t slot = (uint64_t)O.pair_offsets[gid] + (ty - y0) * (x1 - x0) + (tx - x0);
-                if (slot < O.max_pairs) row = O.rows + slot * gs_row_floats(CDIM);
+                if (slot < O.max_pairs) {
+                    row = O.rows + slot * gs_row_floats(CDIM);
+                    O.row_flags[slot] = 1;  // every float of the row is written below (coefficients, geometry, padding)
+                }
             } else {
                 row = O.grad_rgb;  // reference API: separate arrays, addressed through s_id below
             }
@@ -1087,7 +1093,7 @@ extern "C" int gs_draw_backward(const float *pos, const float *rgb, const float 
                        ws.bucket_offsets, ws.n_buckets, ws.bucket_info, tile_n_point_accum, 0);
     // 3. one wave per bucket, one output row per pair
     BwdIn I = {output, grad_output, ws.ckpt, ws.tile_nproc, ws.bucket_offsets, ws.bucket_info, tile_n_point_accum};
-    BwdOut O = {nullptr, nullptr, nullptr, 0, grad_pos, grad_rgb, grad_opa, grad_cov};
+    BwdOut O = {nullptr, nullptr, nullptr, nullptr, 0, grad_pos, grad_rgb, grad_opa, grad_cov};
     if (sigmoid && use_sh_coeff)
         launch_bwd_sig<27>(S, G, I, O, ws.max_buckets, s);
     else if (sigmoid)
@@ -1100,12 +1106,14 @@ extern "C" int gs_draw_backward(const float *pos, const float *rgb, const float 
     return 0;
 }
 
-// What the backward needs from the forward alone: zeroed gradient rows (pairs behind a tile's early-termination
-// point are never written) and the bucket work list.  gs_frame_forward runs it on a side stream underneath
+// What the backward needs from the forward alone: cleared row flags (one byte per pair: rows of pairs behind a tile's
+// early-termination point are never written, and the reader skips rows whose flag is not set -- the rows themselves,
+// 48 to 224 bytes per pair, are no longer zero-filled: 1.1 GB per frame at 2.4 M Gaussians with SH) and the bucket
+// work list.  gs_frame_forward runs it on a side stream underneath
 // whatever the caller does between forward and backward (the loss); gs_frame_backward runs it inline otherwise.
 int gs_stage_backward_prepare(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream) {
     gs_frame_geom FG = gs_frame_geometry(f);
-    GS_HIP(hipMemsetAsync(ws.rows, 0, sizeof(float) * (size_t)gs_row_floats(f->color_dim) * f->max_pairs, stream));
+    GS_HIP(hipMemsetAsync(ws.row_flags, 0, (size_t)f->max_pairs, stream));
     hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, ws.tile_nproc, FG.n_tiles,
                        ws.bucket_offsets, ws.counters + GS_CNT_BUCKETS, ws.bucket_info, ws.tile_ranges, 1);
     GS_CHECK_LAUNCH();
@@ -1144,7 +1152,7 @@ int gs_stage_raster_backward(const gs_frame *f, const gs_frame_ws &ws, const uin
         if (rc) return rc;
     }
     BwdIn I = {f->image_padded, grad_image, ws.ckpt, ws.tile_nproc, ws.bucket_offsets, ws.bucket_info, ws.tile_ranges};
-    BwdOut O = {ws.rows, ws.pair_offsets, ws.rects, (uint64_t)f->max_pairs, nullptr, nullptr, nullptr, nullptr};
+    BwdOut O = {ws.rows, ws.row_flags, ws.pair_offsets, ws.rects, (uint64_t)f->max_pairs, nullptr, nullptr, nullptr, nullptr};
     if (f->color_dim == 48)
         launch_bwd<48, true>(S, G, I, O, ws.max_buckets, stream);
     else if (f->color_dim == 27)

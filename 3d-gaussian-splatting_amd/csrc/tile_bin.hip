@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_scatter_kernel(
     uint32_t T, uint32_t ntx, const uint32_t *__restrict__ table, const uint32_t *__restrict__ tile_count,
     const uint32_t *__restrict__ slice_pairs, const uint32_t *__restrict__ slice_vis, uint32_t B,
     uint64_t *__restrict__ out, uint64_t max_pairs, uint32_t *__restrict__ pair_offsets,
-    int32_t *__restrict__ tile_ranges, unsigned long long *__restrict__ counters) {
+    int32_t *__restrict__ tile_ranges, unsigned long long *__restrict__ counters, uint32_t n_bands) {
     extern __shared__ uint32_t s_slot[];
     __shared__ uint32_t s_wave[BIN_THREADS / 64];
     const uint32_t slice = slice_of_block(blockIdx.x, gridDim.x);
@@ -317,33 +317,52 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_scatter_kernel(
         counters[GS_CNT_VISIBLE] = V;
     }
     __syncthreads();
-    // 3. scatter
-    for (uint32_t base = 0; base < per_block; base += BIN_PF * BIN_THREADS) {  // uniform trip counts (barriers inside)
-        uint4 cur[BIN_PF];
+    // 3. scatter, one horizontal BAND of the tile grid at a time.  A workgroup writes into T output streams (one per
+    // tile); at 2.4 M Gaussians the lines those streams keep open add up to ~7 MB per XCD against 4 MB of L2, every
+    // line left L2 several times half-filled (PMC: WRITE_SIZE 255 MB for 55.6 MB of pairs, 4.6 x) and the stores made
+    // up half of the kernel's 109 us.  Walking the slice once per band -- rectangles clipped to the band's tile rows,
+    // which costs a little integer work per Gaussian and band -- keeps the open lines of a pass inside L2.
+    const uint32_t nty = (T + ntx - 1) / ntx, rows_per_band = (nty + n_bands - 1) / n_bands;
+    for (uint32_t band = 0; band < n_bands; ++band) {
+        const uint32_t yb0 = band * rows_per_band, yb1 = yb0 + rows_per_band;
+        if (band) {
 #pragma unroll
-        for (int k = 0; k < BIN_PF; ++k) {
-            cur[k] = rc[k];
-            rc[k] = load_rect(base + (BIN_PF + k) * BIN_THREADS);
+            for (int k = 0; k < BIN_PF; ++k) rc[k] = load_rect(k * BIN_THREADS);
         }
+        for (uint32_t base = 0; base < per_block; base += BIN_PF * BIN_THREADS) {  // uniform trip counts (barriers inside)
+            uint4 cur[BIN_PF];
 #pragma unroll
-        for (int k = 0; k < BIN_PF; ++k) {
-            const uint32_t b = base + k * BIN_THREADS;
-            if (b >= per_block) break;  // uniform
-            const uint32_t i = b + threadIdx.x;
-            const int64_t g = g0 + i;
-            if (pair_offsets) {  // uniform: prefix sum of the rectangle areas in Gaussian order
-                const uint32_t ex = block_excl_scan(cur[k].w, s_wave, dummy);
-                if (i < per_block && g < n) pair_offsets[g] = before + ex;
-                before += dummy;
+            for (int k = 0; k < BIN_PF; ++k) {
+                cur[k] = rc[k];
+                rc[k] = load_rect(base + (BIN_PF + k) * BIN_THREADS);
             }
-            walk_rect<DIST>(cur[k], g, ntx, load_xy(b, cur[k]), D, [&](uint32_t tile, uint32_t id, uint32_t d) {
-                const uint32_t slot = atomicAdd(&s_slot[tile], 1u);
+#pragma unroll
+            for (int k = 0; k < BIN_PF; ++k) {
+                const uint32_t b = base + k * BIN_THREADS;
+                if (b >= per_block) break;  // uniform
+                const uint32_t i = b + threadIdx.x;
+                const int64_t g = g0 + i;
+                if (pair_offsets && band == 0) {  // uniform: prefix sum of the rectangle areas in Gaussian order
+                    const uint32_t ex = block_excl_scan(cur[k].w, s_wave, dummy);
+                    if (i < per_block && g < n) pair_offsets[g] = before + ex;
+                    before += dummy;
+                }
+                uint4 rcb = cur[k];
+                if (n_bands > 1) {  // clip the rectangle to the band's tile rows
+                    const uint32_t y0 = rcb.x & 0xffff, y1 = rcb.x >> 16, w = (rcb.y >> 16) - (rcb.y & 0xffff);
+                    const uint32_t cy0 = y0 > yb0 ? y0 : yb0, cy1 = y1 < yb1 ? y1 : yb1;
+                    rcb.x = cy0 | (cy1 << 16);
+                    rcb.w = (rcb.w && cy1 > cy0) ? (cy1 - cy0) * w : 0;
+                }
+                walk_rect<DIST>(rcb, g, ntx, load_xy(b, rcb), D, [&](uint32_t tile, uint32_t id, uint32_t d) {
+                    const uint32_t slot = atomicAdd(&s_slot[tile], 1u);
 #ifdef GS_DIAG_SCATTER_SMALL  // timing experiment only (tools/ab_variants.py): every store lands in a 128 KiB window
-                out[slot & 0x3fff] = ((uint64_t)d << 32) | id;
+                    out[slot & 0x3fff] = ((uint64_t)d << 32) | id;
 #else
-                out[slot] = ((uint64_t)d << 32) | id;
+                    out[slot] = ((uint64_t)d << 32) | id;
 #endif
-            });
+                });
+            }
         }
     }
 }
@@ -602,6 +621,14 @@ int gs_stage_tile_bin(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stre
     const uint32_t per_block = bin_per_block(f->N);
     const uint32_t B = (uint32_t)gs_div_up(f->N, per_block);
     const size_t lds = sizeof(uint32_t) * T;
+    // scatter bands: the pairs of one band (8 B each, capacity as the estimate) should stay within ~2.5 MB per XCD
+    uint32_t n_bands = (uint32_t)gs_div_up(f->max_pairs * 8, (int64_t)8 * 2560 * 1024);
+#ifdef BIN_BANDS
+    n_bands = BIN_BANDS;  // experiments (tools/ab_variants.py)
+#endif
+    if (n_bands < 1) n_bands = 1;
+    if (n_bands > 8) n_bands = 8;
+    if (n_bands > (uint32_t)G.nty) n_bands = (uint32_t)G.nty;
 #define GS_LAUNCH_BIN(DIST)                                                                                            \
     do {                                                                                                               \
         hipLaunchKernelGGL(bin_count_kernel<DIST>, dim3(B), dim3(BIN_THREADS), lds, stream, ws.rects, ws.rec_geom, D,  \
@@ -614,7 +641,7 @@ int gs_stage_tile_bin(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stre
         hipLaunchKernelGGL(bin_scatter_kernel<DIST>, dim3(B), dim3(BIN_THREADS), lds, stream, ws.rects, ws.rec_geom,   \
                            D, f->N, per_block, T, (uint32_t)G.ntx, ws.bin_table, ws.tile_count, ws.slice_pairs,        \
                            ws.slice_vis, B, ws.keys_a, (uint64_t)f->max_pairs,                                         \
-                           f->training ? ws.pair_offsets : nullptr, ws.tile_ranges, ws.counters);                      \
+                           f->training ? ws.pair_offsets : nullptr, ws.tile_ranges, ws.counters, n_bands);             \
         GS_CHECK_LAUNCH();                                                                                             \
     } while (0)
     if (dist)

@@ -839,7 +839,11 @@ static void draw_backward_impl(const float *pos, const float *rgb, const float *
                                                fabs((double)dsq);
                             if (use_sh) {
                                 for (int ch = 0; ch < 3; ++ch) {
-                                    double Dk = fabs((double)go[ch] * weight * (cpc[ch] * (1 - cpc[ch]))) * rel;
+                                    /* c (1 - c): for a saturated colour (c -> 1) the difference 1 - c only has the
+                                     * absolute accuracy of c itself, a few ulp of 1 */
+                                    double Dk = fabs((double)go[ch] * weight * (cpc[ch] * (1 - cpc[ch]))) * rel +
+                                                W * fabs((double)go[ch] * weight) * fabs((double)cpc[ch]) *
+                                                    (1.0 + fabs((double)cpc[ch]));
                                     for (int s = 0; s < nb; ++s) cr[2 + ch * nb + s] += Dk * fabs((double)SH[s]);
                                 }
                             } else {
