@@ -713,15 +713,15 @@ __global__ void __launch_bounds__(64 * GS_PP_WPB) raster_backward_pixel_kernel(R
 // per wave = 1.6 per (pixel, Gaussian) against 2.4.
 template <int CDIM>
 struct PixShCfg {
-    static constexpr int NB = CDIM / 3;
-    static constexpr int NROW = 7 + CDIM;  // Sx Sy Sxx Sxy Syy Sq Sopa + the colour-coefficient sums
+    static constexpr int NB = CDIM > 3 ? CDIM / 3 : 1;
+    static constexpr int NROW = 7 + CDIM;  // Sx Sy Sxx Sxy Syy Sq Sopa + the colour(-coefficient) sums
 };
 
 template <int CDIM, bool FRAME>
 __global__ void __launch_bounds__(64) raster_backward_pixel_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
     constexpr int NB = PixShCfg<CDIM>::NB, NROW = PixShCfg<CDIM>::NROW;
     typedef float f2 __attribute__((ext_vector_type(2)));
-    enum { FX, FY, FA, FB, FC, FOPA, NFLD };
+    enum { FX, FY, FA, FB, FC, FOPA, FC0, FC1, FC2, NFLD };  // FC0..2: the Gaussian's colour (CDIM == 3 only)
     __shared__ float s_g[NFLD][64];
     __shared__ uint32_t s_id[64];          // FRAME: Gaussian id; else index of the pair in the sorted arrays
     __shared__ float s_red[NROW * 65];     // [row][lane] partial sums of the current Gaussian (rows padded to 65)
@@ -782,6 +782,13 @@ __global__ void __launch_bounds__(64) raster_backward_pixel_sh_kernel(RasterSrc 
         s_g[FB][lane] = cB;
         s_g[FC][lane] = cC;
         s_g[FOPA][lane] = valid ? g.opa : 0.f;  // opacity 0 => alpha 0: padded entries contribute exact zeros
+        if (CDIM == 3) {
+            float r0, r1, r2;
+            raster_load_rgb<FRAME>(S, jl, gid, r0, r1, r2);
+            s_g[FC0][lane] = r0;
+            s_g[FC1][lane] = r1;
+            s_g[FC2][lane] = r2;
+        }
         s_id[lane] = FRAME ? gid : jl;
         float *row = nullptr;
         if (valid) {
@@ -803,11 +810,13 @@ __global__ void __launch_bounds__(64) raster_backward_pixel_sh_kernel(RasterSrc 
     f2 py2[2], T[2], rho[2], g0[2], g1[2], g2[2], SHB[2][NB];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        float sa[NB], sb[NB];
-        raster_pixel_sh<NB>(id_x, id_y0 + 8 * h, G, sa);
-        raster_pixel_sh<NB>(id_x, id_y0 + 8 * h + 4, G, sb);
+        if constexpr (CDIM > 3) {
+            float sa[NB], sb[NB];
+            raster_pixel_sh<NB>(id_x, id_y0 + 8 * h, G, sa);
+            raster_pixel_sh<NB>(id_x, id_y0 + 8 * h + 4, G, sb);
 #pragma unroll
-        for (int k = 0; k < NB; ++k) SHB[h][k] = f2{sa[k], sb[k]};
+            for (int k = 0; k < NB; ++k) SHB[h][k] = f2{sa[k], sb[k]};
+        }
         py2[h] = f2{raster_pixel_coord(id_y0 + 8 * h, G.padH, G.focal_y),
                     raster_pixel_coord(id_y0 + 8 * h + 4, G.padH, G.focal_y)};
         float Tk[2], rk[2];
@@ -840,9 +849,11 @@ __global__ void __launch_bounds__(64) raster_backward_pixel_sh_kernel(RasterSrc 
     float co[CDIM];
     auto load_coef = [&](uint32_t i) {
         const uint32_t id = __builtin_amdgcn_readfirstlane(s_id[i]);
-        const float *cf = (FRAME ? S.sh : S.rgb) + (size_t)id * CDIM;
+        if constexpr (CDIM > 3) {
+            const float *cf = (FRAME ? S.sh : S.rgb) + (size_t)id * CDIM;
 #pragma unroll
-        for (int k = 0; k < CDIM; ++k) co[k] = cf[k];
+            for (int k = 0; k < CDIM; ++k) co[k] = cf[k];
+        }
         return id;
     };
     uint32_t id_next = load_coef(0);
@@ -860,16 +871,23 @@ __global__ void __launch_bounds__(64) raster_backward_pixel_sh_kernel(RasterSrc 
             const f2 q = pk_fma(pk_fma(splat(uC), dy, splat(-bdx)), dy, splat(adx2));
             const f2 Gv = {gs_exp2(-q.x), gs_exp2(-q.y)};
             // colours of the pixel pair
-            f2 v0 = {0.f, 0.f}, v1 = v0, v2 = v0;
+            f2 c0, c1, c2;
+            if constexpr (CDIM > 3) {
+                f2 v0 = {0.f, 0.f}, v1 = v0, v2 = v0;
 #pragma unroll
-            for (int k = 0; k < NB; ++k) {
-                v0 = pk_fma(SHB[h][k], splat(co[k]), v0);
-                v1 = pk_fma(SHB[h][k], splat(co[NB + k]), v1);
-                v2 = pk_fma(SHB[h][k], splat(co[2 * NB + k]), v2);
+                for (int k = 0; k < NB; ++k) {
+                    v0 = pk_fma(SHB[h][k], splat(co[k]), v0);
+                    v1 = pk_fma(SHB[h][k], splat(co[NB + k]), v1);
+                    v2 = pk_fma(SHB[h][k], splat(co[2 * NB + k]), v2);
+                }
+                c0 = f2{gs_rcp(1.0f + __expf(-v0.x)), gs_rcp(1.0f + __expf(-v0.y))};
+                c1 = f2{gs_rcp(1.0f + __expf(-v1.x)), gs_rcp(1.0f + __expf(-v1.y))};
+                c2 = f2{gs_rcp(1.0f + __expf(-v2.x)), gs_rcp(1.0f + __expf(-v2.y))};
+            } else {  // one colour per Gaussian
+                c0 = splat(s_g[FC0][i]);
+                c1 = splat(s_g[FC1][i]);
+                c2 = splat(s_g[FC2][i]);
             }
-            const f2 c0 = {gs_rcp(1.0f + __expf(-v0.x)), gs_rcp(1.0f + __expf(-v0.y))};
-            const f2 c1 = {gs_rcp(1.0f + __expf(-v1.x)), gs_rcp(1.0f + __expf(-v1.y))};
-            const f2 c2 = {gs_rcp(1.0f + __expf(-v2.x)), gs_rcp(1.0f + __expf(-v2.y))};
             // 1 / (1 - alpha + 1e-7) as one fma + rcp (see raster_backward_pixel_kernel)
             const f2 den = pk_fma(-Gv, splat(opa), splat(1.00000011920928955f));
             const f2 rc = {gs_rcp(den.x), gs_rcp(den.y)};
@@ -881,10 +899,16 @@ __global__ void __launch_bounds__(64) raster_backward_pixel_sh_kernel(RasterSrc 
             rho[h] = pk_fma(-w, gc, rho[h]);
             f2 d_alpha = pk_fma(T[h], gc, -(rho[h] * rc));
             d_alpha = f2{l0 ? d_alpha.x : 0.f, l1 ? d_alpha.y : 0.f};
-            const f2 one = {1.0f, 1.0f};
-            D[h][0] = g0[h] * w * (c0 * (one - c0));
-            D[h][1] = g1[h] * w * (c1 * (one - c1));
-            D[h][2] = g2[h] * w * (c2 * (one - c2));
+            if constexpr (CDIM > 3) {
+                const f2 one = {1.0f, 1.0f};
+                D[h][0] = g0[h] * w * (c0 * (one - c0));
+                D[h][1] = g1[h] * w * (c1 * (one - c1));
+                D[h][2] = g2[h] * w * (c2 * (one - c2));
+            } else {  // dL/dcolour_c = sum dL/dC_c w (the sigmoid's derivative is applied per Gaussian, later)
+                D[h][0] = g0[h] * w;
+                D[h][1] = g1[h] * w;
+                D[h][2] = g2[h] * w;
+            }
             Sopa = pk_fma(d_alpha, Gv, Sopa);
             const f2 s = d_alpha * alpha;
             const f2 sdy = s * dy;
@@ -907,12 +931,18 @@ __global__ void __launch_bounds__(64) raster_backward_pixel_sh_kernel(RasterSrc 
             s_red[6 * 65 + lane] = Sopa.x + Sopa.y;
         }
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch)
+        for (int ch = 0; ch < 3; ++ch) {
+            if constexpr (CDIM > 3) {
 #pragma unroll
-            for (int k = 0; k < NB; ++k) {
-                const f2 p = pk_fma(D[1][ch], SHB[1][k], D[0][ch] * SHB[0][k]);
-                s_red[(7 + ch * NB + k) * 65 + lane] = p.x + p.y;
+                for (int k = 0; k < NB; ++k) {
+                    const f2 p = pk_fma(D[1][ch], SHB[1][k], D[0][ch] * SHB[0][k]);
+                    s_red[(7 + ch * NB + k) * 65 + lane] = p.x + p.y;
+                }
+            } else {
+                const f2 p = D[0][ch] + D[1][ch];
+                s_red[(7 + ch) * 65 + lane] = p.x + p.y;
             }
+        }
         lds_order();
 #pragma unroll
         for (int rd = 0; rd < NROUND; ++rd) {
@@ -987,17 +1017,20 @@ void launch_bwd_sig(const RasterSrc &S, const RasterGeom &G, const BwdIn &I, con
 #ifndef GS_BWD_SH_PIXEL
 #define GS_BWD_SH_PIXEL 1  // 0: the systolic kernel for SH as well (A/B switch for tools/ab_variants.py)
 #endif
+#ifndef GS_BWD_PACKED_RGB
+#define GS_BWD_PACKED_RGB 1  // 0: the first, unpacked pixel-parallel kernel for rgb colours (A/B switch)
+#endif
 template <int CDIM, bool FRAME>
 void launch_bwd(const RasterSrc &S, const RasterGeom &G, const BwdIn &I, const BwdOut &O, int64_t max_buckets,
                 hipStream_t stream) {
     constexpr int WPB = BwdCfg<CDIM>::WPB;
     const int grid = (int)gs_div_up(max_buckets > 0 ? max_buckets : 1, WPB);
-    if (CDIM == 3) {
+    if (CDIM == 3 && !GS_BWD_PACKED_RGB) {
         const int64_t blocks = gs_div_up(max_buckets > 0 ? max_buckets : 1, GS_PP_WPB);
         hipLaunchKernelGGL((raster_backward_pixel_kernel<FRAME>), dim3((unsigned)blocks), dim3(64 * GS_PP_WPB), 0, stream,
                            S, G, I, O);
-    } else if (GS_BWD_SH_PIXEL) {
-        hipLaunchKernelGGL((raster_backward_pixel_sh_kernel<(CDIM == 3 ? 27 : CDIM), FRAME>),
+    } else if (CDIM == 3 || GS_BWD_SH_PIXEL) {
+        hipLaunchKernelGGL((raster_backward_pixel_sh_kernel<CDIM, FRAME>),
                            dim3((unsigned)(max_buckets > 0 ? max_buckets : 1)), dim3(64), 0, stream, S, G, I, O);
     } else {
         hipLaunchKernelGGL((raster_backward_kernel<CDIM, FRAME>), dim3(grid), dim3(64 * WPB), 0, stream, S, G, I, O);
@@ -1071,18 +1104,11 @@ extern "C" int gs_draw_backward(const float *pos, const float *rgb, const float 
     G.focal_y = focal_y;
     if (use_sh_coeff) {
         GS_CHECK_ARG(rays_o && lefttop_pos && vec_dx && vec_dy, "SH needs the ray basis");
-        float hb[12];
-        GS_HIP(hipMemcpyAsync(hb + 0, rays_o, 12, hipMemcpyDeviceToHost, s));
-        GS_HIP(hipMemcpyAsync(hb + 3, lefttop_pos, 12, hipMemcpyDeviceToHost, s));
-        GS_HIP(hipMemcpyAsync(hb + 6, vec_dx, 12, hipMemcpyDeviceToHost, s));
-        GS_HIP(hipMemcpyAsync(hb + 9, vec_dy, 12, hipMemcpyDeviceToHost, s));
-        GS_HIP(hipStreamSynchronize(s));
-        for (int i = 0; i < 3; ++i) {
-            G.rays_o[i] = hb[i];
-            G.lefttop[i] = hb[3 + i];
-            G.vdx[i] = hb[6 + i];
-            G.vdy[i] = hb[9 + i];
-        }
+        // the basis stays on the device: the kernels load it (raster_common.h), the call never synchronises
+        G.dev_rays_o = rays_o;
+        G.dev_lefttop = lefttop_pos;
+        G.dev_vdx = vec_dx;
+        G.dev_vdy = vec_dy;
     }
     // 1. replay the forward to checkpoint (T, C_run) at every bucket boundary
     int rc = gs_raster_forward_ref(S, G, tile_n_point_accum, nullptr, use_sh_coeff, sigmoid, 0, ws.ckpt,

@@ -23,6 +23,10 @@ struct RasterGeom {
     int32_t width, height, crop_top, crop_left;  // un-padded output (frame path)
     float focal_x, focal_y;
     float rays_o[3], lefttop[3], vdx[3], vdy[3];
+    // reference API (gs_draw / gs_draw_backward): the ray basis arrives as four DEVICE tensors of three floats; the
+    // kernels read them themselves (uniform loads in the prologue) instead of the host copying them back and
+    // synchronising the stream.  All NULL on the frame path, which passes the basis by value above.
+    const float *dev_rays_o, *dev_lefttop, *dev_vdx, *dev_vdy;
 };
 
 struct GaussianRec {
@@ -97,7 +101,10 @@ __device__ __forceinline__ void raster_pixel_sh(uint32_t id_x, uint32_t id_y, co
     float dir[3], nrm = 0.0f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        dir[i] = G.lefttop[i] + id_x * G.vdx[i] + id_y * G.vdy[i] - G.rays_o[i];
+        const bool dev = G.dev_rays_o != nullptr;  // uniform
+        const float lt = dev ? G.dev_lefttop[i] : G.lefttop[i], vx = dev ? G.dev_vdx[i] : G.vdx[i];
+        const float vy = dev ? G.dev_vdy[i] : G.vdy[i], ro = dev ? G.dev_rays_o[i] : G.rays_o[i];
+        dir[i] = lt + id_x * vx + id_y * vy - ro;
         nrm += dir[i] * dir[i];
     }
     nrm = sqrtf(nrm);

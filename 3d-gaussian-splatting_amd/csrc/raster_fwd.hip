@@ -447,19 +447,11 @@ extern "C" int gs_draw(const float *pos, const float *rgb, const float *opa, con
     G.focal_y = focal_y;
     if (use_sh_coeff) {
         GS_CHECK_ARG(rays_o && lefttop_pos && vec_dx && vec_dy, "SH needs the ray basis");
-        float hb[12];
-        hipStream_t s = (hipStream_t)stream;
-        GS_HIP(hipMemcpyAsync(hb + 0, rays_o, 12, hipMemcpyDeviceToHost, s));
-        GS_HIP(hipMemcpyAsync(hb + 3, lefttop_pos, 12, hipMemcpyDeviceToHost, s));
-        GS_HIP(hipMemcpyAsync(hb + 6, vec_dx, 12, hipMemcpyDeviceToHost, s));
-        GS_HIP(hipMemcpyAsync(hb + 9, vec_dy, 12, hipMemcpyDeviceToHost, s));
-        GS_HIP(hipStreamSynchronize(s));
-        for (int i = 0; i < 3; ++i) {
-            G.rays_o[i] = hb[i];
-            G.lefttop[i] = hb[3 + i];
-            G.vdx[i] = hb[6 + i];
-            G.vdy[i] = hb[9 + i];
-        }
+        // the basis stays on the device: the kernels load it (raster_common.h), the call never synchronises
+        G.dev_rays_o = rays_o;
+        G.dev_lefttop = lefttop_pos;
+        G.dev_vdx = vec_dx;
+        G.dev_vdy = vec_dy;
     }
     int rc = gs_raster_forward_ref(S, G, tile_n_point_accum, res, use_sh_coeff, sigmoid, weight_normalize, nullptr,
                                    nullptr, (hipStream_t)stream);

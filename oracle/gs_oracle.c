@@ -738,6 +738,7 @@ static void draw_backward_impl(const float *pos, const float *rgb, const float *
                     const float *go = grad_output + ((size_t)id_x + (size_t)id_y * w) * 3;
                     const float *co = output + ((size_t)id_x + (size_t)id_y * w) * 3;
                     float color[3] = {0, 0, 0}, accum = 1.0f;
+                    double ampT = 0; /* conditioning of the transmittance: sum of alpha / (1 - alpha) so far */
                     for (uint32_t i = 0; i < len; ++i) {
                         uint32_t g = start + i;
                         if (accum < 0.0001) break; /* :578 */
@@ -828,7 +829,11 @@ static void draw_backward_impl(const float *pos, const float *rgb, const float *
                             const double PmAbs = fabs((double)_d * _x * _x) + fabs((double)(_b + _c) * _x * _y) +
                                                  fabs((double)_a * _y * _y);
                             const double pn = fabs((double)Pn);
-                            const double rel = 1.0 + cs_w_exp * PmAbs / pn; /* exponent rounding -> relative error of alpha */
+                            /* every term carries alpha (exponent rounding: relative error ~ PmAbs / Pn ulp) and the
+                             * transmittance, a product of factors 1 - alpha_j whose relative error is that of alpha_j
+                             * times alpha_j / (1 - alpha_j): behind a nearly opaque Gaussian it is far from 1 ulp */
+                            ampT += fabs((double)alpha) / fabs(1.0 - (double)alpha + 1e-7);
+                            const double rel = 1.0 + cs_w_exp * PmAbs / pn + W * ampT;
                             double gcabs = 0, dcabs = 0;
                             for (int m = 0; m < 3; ++m) {
                                 gcabs += fabs((double)go[m] * cpc[m]);
