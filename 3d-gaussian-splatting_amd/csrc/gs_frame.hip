@@ -38,6 +38,8 @@ static int tile_bits(int n_tiles) {
     return b < 1 ? 1 : b;
 }
 
+static bool use_strip_variant(const gs_frame *f);
+
 static int validate(const gs_frame *f) {
     GS_CHECK_ARG(f != nullptr, "frame is null");
     GS_CHECK_ARG(f->N >= 0 && f->N < (1ll << 31), "N out of range");
@@ -54,12 +56,12 @@ static int validate(const gs_frame *f) {
     GS_CHECK_ARG(f->workspace != nullptr && ((uintptr_t)f->workspace & 255) == 0, "workspace null or not 256-byte aligned");
     if (f->tile_culling_method == 0) {
         GS_CHECK_ARG(f->thresh > 0.f && f->thresh < 3.0e38f, "dist: thresh is a squared distance, must be positive");
-        GS_CHECK_ARG(f->sort_mode == 2 && gs_frame_geometry(f).n_tiles <= GS_BIN_MAX_TILES,
-                     "tile_culling_method dist needs sort_mode 2 and at most 32768 tiles");
+        GS_CHECK_ARG(f->sort_mode == 2 && (use_strip_variant(f) || gs_frame_geometry(f).n_tiles <= GS_BIN_MAX_TILES),
+                     "tile_culling_method dist needs sort_mode 2 (table variant: at most 32768 tiles)");
     } else {
         GS_CHECK_ARG(f->thresh > 0.f && f->thresh < 1.f, "thresh must be in (0,1)");
     }
-    GS_CHECK_ARG((f->flags & ~(GS_FRAME_EMIT_SORTED_KEYS | GS_FRAME_SLICE_SORT)) == 0, "unknown flag bits");
+    GS_CHECK_ARG((f->flags & ~(GS_FRAME_EMIT_SORTED_KEYS | GS_FRAME_SLICE_SORT | GS_FRAME_TABLE_BIN)) == 0, "unknown flag bits");
     GS_CHECK_ARG(f->sort_mode >= 0 && f->sort_mode <= 2,
                  "sort_mode must be 0 (full LSD radix), 1 (tile-bit radix + per-tile LDS sort) or 2 (LDS counting sort "
                  "by tile + per-tile LDS sort)");
@@ -77,10 +79,19 @@ extern "C" size_t gs_frame_workspace_bytes(int64_t N, int64_t max_pairs, int32_t
     return gs_frame_carve(nullptr, N, max_pairs, width, height, color_dim, training).total_bytes;
 }
 
-// sort_mode 2 needs one LDS counter per tile; grids beyond that (> 8K x 4K pixels) take mode 1.
+// sort_mode 2: the strip variant needs one LDS counter per strip, the other variants one per tile; grids beyond that
+// (> 8K x 4K pixels) take mode 1.
 static int effective_sort_mode(const gs_frame *f) {
-    if (f->sort_mode == 2 && gs_frame_geometry(f).n_tiles > GS_BIN_MAX_TILES) return 1;
+    if (f->sort_mode == 2 && !use_strip_variant(f) && gs_frame_geometry(f).n_tiles > GS_BIN_MAX_TILES) return 1;
     return f->sort_mode;
+}
+
+// sort_mode 2 runs the strip variant (strip_bin.hip) unless the caller asks for one of the others or the frame is
+// outside its limits (2^26 Gaussians, GS_STRIP_MAX strips).
+static bool use_strip_variant(const gs_frame *f) {
+    if (f->flags & (GS_FRAME_SLICE_SORT | GS_FRAME_TABLE_BIN)) return false;
+    gs_frame_geom G = gs_frame_geometry(f);
+    return gs_strip_plan_for(f->N, G.ntx, G.nty).ok != 0;
 }
 
 // Which double-buffer half holds the sorted (keys, ids) after the radix passes of this mode.
@@ -237,15 +248,19 @@ static int frame_forward_impl(const gs_frame *f, hipStream_t s, float *stage_ms)
     const int mode = effective_sort_mode(f);
     if (mode == 2) {
         // counting sort by tile in LDS (stages "scan_emit" and "sort" collapse into this one)
-        if (f->N > 0 && (rc = gs_stage_tile_bin(f, ws, s))) return rc;
+        const bool strips = use_strip_variant(f);
+        if (f->N > 0 && (rc = strips ? gs_stage_strip_bin(f, ws, s) : gs_stage_tile_bin(f, ws, s))) return rc;
         tm.mark();
         tm.mark();
         if (f->N > 0) {
             uint64_t *keys_out = (f->flags & GS_FRAME_EMIT_SORTED_KEYS) ? skeys : nullptr;
-            // slice-sorted variant: okeys holds the S tile-ordered slice regions, the per-tile sort gathers from them
-            // (buckets beyond its LDS window are gathered into skeys and sorted there); table variant: okeys holds
-            // the pairs grouped by tile
-            if (gs_bin_plan_for(f->N, f->max_pairs, G.n_tiles, (f->flags & GS_FRAME_SLICE_SORT) != 0).lds_sort)
+            // strip variant: okeys holds the strip-ordered entries; half strips beyond the LDS window expand into skeys
+            // and sort there.  Slice-sorted variant: okeys holds the S tile-ordered slice regions, the per-tile sort
+            // gathers from them (buckets beyond its LDS window are gathered into skeys and sorted there); table variant:
+            // okeys holds the pairs grouped by tile
+            if (strips)
+                rc = gs_stage_strip_sort(f, ws, okeys, skeys, keys_out, sids, s);
+            else if (gs_bin_plan_for(f->N, f->max_pairs, G.n_tiles, (f->flags & GS_FRAME_SLICE_SORT) != 0).lds_sort)
                 rc = gs_stage_tile_sort_gather(f, ws, okeys, skeys, keys_out, sids, s);
             else
                 rc = gs_stage_tile_sort_packed(f, ws, okeys, keys_out, sids, s);

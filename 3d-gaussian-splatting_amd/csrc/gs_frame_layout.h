@@ -2,7 +2,7 @@
 #pragma once
 #include "gs_common.h"
 
-enum { GS_CNT_VISIBLE = 0, GS_CNT_PAIRS = 1, GS_CNT_OVERFLOW = 2, GS_CNT_BUCKETS = 3, GS_CNT_TICKET = 4, GS_CNT_N = 8 };
+enum { GS_CNT_VISIBLE = 0, GS_CNT_PAIRS = 1, GS_CNT_OVERFLOW = 2, GS_CNT_BUCKETS = 3, GS_CNT_TICKET = 4, GS_CNT_ENTRIES = 5, GS_CNT_N = 8 };
 
 #define GS_BUCKET 64          // Gaussians per backward bucket (= wavefront size)
 #define GS_SORT_TILE 2048     // keys per radix-sort workgroup (256 threads x 8)
@@ -45,6 +45,35 @@ static inline gs_bin_plan gs_bin_plan_for(int64_t N, int64_t max_pairs, int n_ti
     return p;
 }
 
+// sort_mode 2, STRIP variant (strip_bin.hip; the default): a strip is GS_STRIP_W consecutive tiles of one tile row.
+#define GS_STRIP_W 8          // tiles per strip (3 + 3 bits of an entry name the covered tiles)
+#define GS_STRIP_ID_BITS 26   // an entry keeps the Gaussian index in 26 bits: scenes beyond 2^26 take the table variant
+#define GS_STRIP_MAX 8192     // strips per frame the LDS histograms are sized for
+#define GS_STRIP_SORT_CAP 2048  // pairs strip_sort_kernel's LDS window holds (a half strip's four lists, or one list at a time)
+struct gs_strip_geom {
+    uint32_t ntx, nty, nsx, NS;  // tile grid, strips per tile row, strips per frame
+};
+struct gs_strip_plan {
+    int ok;              // 0: the frame takes the table variant
+    gs_strip_geom geom;
+    uint32_t slices;     // workgroups of the level-1 kernels (= slices of the Gaussian array), <= GS_BIN_SLICES
+    uint32_t per_slice;  // Gaussians per slice (a multiple of 256, the project stage's block)
+    uint32_t cap;        // entries the scatter's LDS staging buffer holds
+};
+static inline gs_strip_plan gs_strip_plan_for(int64_t N, int ntx, int nty) {
+    gs_strip_plan p;
+    p.geom.ntx = (uint32_t)ntx;
+    p.geom.nty = (uint32_t)nty;
+    p.geom.nsx = (uint32_t)((ntx + GS_STRIP_W - 1) / GS_STRIP_W);
+    p.geom.NS = p.geom.nsx * (uint32_t)nty;
+    p.ok = N < (1ll << GS_STRIP_ID_BITS) && p.geom.NS <= GS_STRIP_MAX;
+    const int64_t n = N > 0 ? N : 1;
+    const int64_t per = gs_div_up(gs_div_up(n, GS_BIN_SLICES), 256) * 256;
+    p.per_slice = (uint32_t)per;
+    p.slices = (uint32_t)gs_div_up(n, per);
+    p.cap = p.ok ? (uint32_t)(((int64_t)GS_BIN_LDS_BYTES - 8 * (int64_t)p.geom.NS) / 8) : 0;
+    return p;
+}
 
 // floats per per-pair gradient row: (dx, dy, da, db, dc, dd, dopa) + colour grads, padded to float4s
 // floats per (tile, Gaussian) gradient row: 7 geometry/opacity sums + color_dim colour sums, rounded up to float4s
@@ -104,6 +133,10 @@ struct gs_frame_ws {
     uint32_t *tile_count;          // [T]
     uint32_t *slice_pairs, *slice_vis;  // [GS_BIN_MAX_SLICES]; slice-sorted variant: slice_pairs = start of the
                                         // slice's region in keys_a
+    // sort_mode 2, strip variant (strip_bin.hip): packed (entries << 32 | pairs) per (slice, strip)
+    uint64_t *strip_table;         // [2][GS_BIN_SLICES][NS]: raw counts, then their exclusive scan over the slices
+    uint64_t *strip_tot;           // [NS] totals per strip
+    uint64_t *strip_base;          // [NS] (first entry << 32 | first pair) of every strip
     // training only
     uint32_t *tile_nproc;          // [T] Gaussians processed by the forward (multiple of the chunk)
     uint32_t *bucket_offsets;      // [T+1] exclusive scan of ceil(nproc/64)
@@ -162,6 +195,13 @@ static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pair
     ws.tile_count = (uint32_t *)take(sizeof(uint32_t) * G.n_tiles);
     ws.slice_pairs = (uint32_t *)take(sizeof(uint32_t) * GS_BIN_MAX_SLICES);
     ws.slice_vis = (uint32_t *)take(sizeof(uint32_t) * GS_BIN_MAX_SLICES);
+    {
+        const gs_strip_plan sp = gs_strip_plan_for(N, G.ntx, G.nty);
+        const size_t ns = sp.ok ? sp.geom.NS : 1;
+        ws.strip_table = (uint64_t *)take(sizeof(uint64_t) * 2 * GS_BIN_SLICES * ns);
+        ws.strip_tot = (uint64_t *)take(sizeof(uint64_t) * ns);
+        ws.strip_base = (uint64_t *)take(sizeof(uint64_t) * ns);
+    }
     ws.max_buckets = gs_max_buckets(max_pairs, G.n_tiles);
     if (training) {
         ws.tile_nproc = (uint32_t *)take(sizeof(uint32_t) * G.n_tiles);
@@ -190,6 +230,9 @@ int gs_stage_scan_emit(const gs_frame *f, const gs_frame_ws &ws, hipStream_t str
 int gs_stage_tile_sort(const gs_frame *f, const gs_frame_ws &ws, uint64_t *keys, uint32_t *ids, uint64_t *scratch,
                        hipStream_t stream);
 int gs_stage_tile_bin(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream);
+int gs_stage_strip_bin(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream);
+int gs_stage_strip_sort(const gs_frame *f, const gs_frame_ws &ws, const uint64_t *entries, uint64_t *scratch,
+                        uint64_t *keys_out, uint32_t *ids_out, hipStream_t stream);
 int gs_stage_tile_sort_packed(const gs_frame *f, const gs_frame_ws &ws, uint64_t *packed, uint64_t *keys_out,
                               uint32_t *ids_out, hipStream_t stream);
 int gs_stage_tile_sort_gather(const gs_frame *f, const gs_frame_ws &ws, const uint64_t *slice_pairs_buf,

@@ -1,0 +1,418 @@
+// strip_bin.hip -- sort_mode 2, STRIP variant (default): two-level counting sort of the (tile, Gaussian) pairs.
+//
+// The table variant (tile_bin.hip) scatters one 8-byte pair per (tile, Gaussian) into T output streams per slice of
+// the Gaussian array: at 2.4 M Gaussians / 1080p that is 254 x 8160 segments of 3.4 pairs on average, every store left
+// L2 as its own 32-byte write (PMC, profiles/r02_a: WRITE_SIZE 233 MB for 55.6 MB of pairs, the scatter alone 101 us of
+// a 450 us frame).  Here the T-way scatter is split into two levels with long runs on both:
+//
+//   level 1 (this file): a STRIP is GS_STRIP_W = 8 consecutive tiles of one tile row.  Every Gaussian emits ONE 8-byte
+//     entry (depth_bits << 32 | first covered tile of the strip << 29 | last << 26 | gaussian) per strip its rectangle
+//     crosses -- 2.1 entries instead of 3.7 pairs per Gaussian -- and the entries are counting-sorted by strip:
+//       strip_count_kernel   <= 256 slices of the Gaussian array, one workgroup each: LDS histogram over the strips of
+//                            (entries << 32 | pairs) in one 64-bit LDS atomic per entry -> row of a [S][NS] table;
+//       strip_colscan_kernel exclusive scan of every column over the slices, strip totals;
+//       strip_scatter_kernel every slice scans the strip totals itself (entry and pair base of every strip: redundant,
+//                            but free of any grid-wide dependency -- a "last workgroup finishes" ticket costs a
+//                            device-scope fence per workgroup, measured 13 us for this 2 MB scan; slice 0 writes the
+//                            bases and the frame counters), places its entries by strip in an LDS staging buffer (ds_add_rtn cursors)
+//                            and copies each (slice, strip) run to its final place with consecutive lanes: a run
+//                            is ~15 entries = one 128-byte line, written by one instruction.
+//   level 2 (tile_sort.hip, strip_sort_kernel): one workgroup per half strip (four tiles) reads the strip's entries
+//     (contiguous), expands them into its tiles' pair lists INSIDE LDS, sorts every list by (depth_bits, gaussian) there
+//     and writes only the sorted ids: the unsorted pairs never exist in HBM (table variant: 8 B written + 8 B read per
+//     pair).  A half strip with more pairs than the LDS window expands into global memory and takes the per-tile sort
+//     of the table variant.
+//
+// The result -- tile ranges, sorted ids, optional sorted keys, counters, pair offsets -- is bit-identical to the other
+// variants: the final order is by the unique (tile, depth_bits, gaussian) whatever the arrival order.
+#include <atomic>
+#include <mutex>
+
+#include "gs_common.h"
+#include "gs_frame_layout.h"
+
+namespace {
+
+#define STRIP_THREADS 1024
+#define STRIP_SOLO 8   // Gaussians with up to this many entries are walked by their own lane
+#define STRIP_PF 4     // rectangles in flight per thread
+
+// Calls fn(strip, lo32, depth_bits, pairs) for every strip entry of one Gaussian per lane.  lo32 = first covered tile of
+// the strip << 29 | last covered tile << 26 | gaussian; pairs = listed tiles of the run.  DIST: a tile of the
+// bounding square is listed iff gs_dist_listed says so; runs without a listed tile emit nothing (the same decision
+// in the count and in the scatter pass, and in strip_sort_kernel).
+template <bool DIST, typename Fn>
+__device__ __forceinline__ void walk_strips(const uint4 rc, int64_t g, const gs_strip_geom SG, float2 cxy,
+                                            const GsDistCull &D, Fn fn) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t y0 = rc.x & 0xffff, y1 = rc.x >> 16, x0 = rc.y & 0xffff, x1 = rc.y >> 16, dbits = rc.z;
+    const bool vis = rc.w != 0;
+    const uint32_t sx0 = x0 / GS_STRIP_W, span = vis ? (x1 - 1) / GS_STRIP_W - sx0 + 1 : 0;
+    const uint32_t ne = span * (y1 - y0);
+    auto emit = [&](uint32_t sx, uint32_t iy, uint32_t ex0, uint32_t ex1, uint32_t id, uint32_t d, float px, float py) {
+        const uint32_t t0 = sx * GS_STRIP_W;
+        const uint32_t lo = ex0 > t0 ? ex0 - t0 : 0, hi = (ex1 < t0 + GS_STRIP_W ? ex1 : t0 + GS_STRIP_W) - t0;  // [lo, hi)
+        uint32_t np = hi - lo;
+        if (DIST) {
+            np = 0;
+            for (uint32_t x = lo; x < hi; ++x) np += gs_dist_listed(px, py, t0 + x, iy, D) ? 1u : 0u;
+            if (!np) return;
+        }
+        fn(iy * SG.nsx + sx, (lo << 29) | ((hi - 1) << 26) | id, d, np);
+    };
+    if (ne && ne <= STRIP_SOLO) {
+        uint32_t sx = sx0, iy = y0;
+        for (uint32_t k = 0; k < ne; ++k) {
+            emit(sx, iy, x0, x1, (uint32_t)g, dbits, cxy.x, cxy.y);
+            if (++sx == sx0 + span) {
+                sx = sx0;
+                ++iy;
+            }
+        }
+    }
+    unsigned long long big = __ballot(ne > STRIP_SOLO);
+    while (big) {  // a Gaussian that crosses many strips is walked by the whole wave
+        const int src = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        const uint32_t c = __shfl(ne, src, 64), d = __shfl(dbits, src, 64), sp = __shfl(span, src, 64);
+        const uint32_t bsx0 = __shfl(sx0, src, 64), by0 = __shfl(y0, src, 64);
+        const uint32_t bx0 = __shfl(x0, src, 64), bx1 = __shfl(x1, src, 64);
+        const float spx = DIST ? __shfl(cxy.x, src, 64) : 0.f, spy = DIST ? __shfl(cxy.y, src, 64) : 0.f;
+        const uint32_t id = (uint32_t)(g - lane + src);
+        for (uint32_t k = lane; k < c; k += 64) emit(bsx0 + k % sp, by0 + k / sp, bx0, bx1, id, d, spx, spy);
+    }
+}
+
+// same XCD-contiguous dealing of slices to workgroups as the table variant (tile_bin.hip): the runs of neighbouring
+// slices are neighbours in memory, so the partial lines at run boundaries meet in one L2
+__device__ __forceinline__ uint32_t strip_slice_of_block(uint32_t blk, uint32_t B) {
+    const uint32_t xcd = blk & 7, idx = blk >> 3;
+    uint32_t first = 0;
+    for (uint32_t x = 0; x < xcd; ++x) first += (B - x + 7) >> 3;
+    return first + idx;
+}
+
+struct SliceLoader {
+    const uint4 *rects;
+    const float4 *rec_geom;
+    int64_t n, g0;
+    uint32_t per_slice;
+    __device__ __forceinline__ uint4 rect(uint32_t base) const {
+        const uint32_t i = base + threadIdx.x;
+        return (i < per_slice && g0 + i < n) ? rects[g0 + i] : make_uint4(0, 0, 0, 0);
+    }
+    template <bool DIST>
+    __device__ __forceinline__ float2 xy(uint32_t base, const uint4 &rc) const {
+        if (!DIST || !rc.w) return make_float2(0.f, 0.f);
+        const float4 ge = rec_geom[(g0 + base + threadIdx.x) * GS_REC_STRIDE];
+        return make_float2(ge.x, ge.y);
+    }
+};
+
+// ---------------------------------------------------------------- L1a: count
+template <bool DIST>
+__global__ void __launch_bounds__(STRIP_THREADS) strip_count_kernel(
+    const uint4 *__restrict__ rects, const float4 *__restrict__ rec_geom, GsDistCull D, int64_t n, uint32_t per_slice,
+    gs_strip_geom SG, unsigned long long *__restrict__ table, const uint32_t *__restrict__ block_sums,
+    const uint32_t *__restrict__ block_vis, uint32_t *__restrict__ slice_pairs, uint32_t *__restrict__ slice_vis) {
+    extern __shared__ unsigned long long s_hist[];  // [NS] entries << 32 | pairs of this slice
+    __shared__ uint32_t s_acc[2];
+    const uint32_t slice = strip_slice_of_block(blockIdx.x, gridDim.x);
+    const SliceLoader L = {rects, rec_geom, n, (int64_t)slice * per_slice, per_slice};
+    uint4 rc[STRIP_PF];
+#pragma unroll
+    for (int k = 0; k < STRIP_PF; ++k) rc[k] = L.rect(k * STRIP_THREADS);  // in flight while the histogram is cleared
+    for (uint32_t t = threadIdx.x; t < SG.NS; t += STRIP_THREADS) s_hist[t] = 0;
+    if (threadIdx.x < 2) s_acc[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < per_slice; base += STRIP_PF * STRIP_THREADS) {
+        uint4 cur[STRIP_PF];
+#pragma unroll
+        for (int k = 0; k < STRIP_PF; ++k) {
+            cur[k] = rc[k];
+            rc[k] = L.rect(base + (STRIP_PF + k) * STRIP_THREADS);
+        }
+#pragma unroll
+        for (int k = 0; k < STRIP_PF; ++k) {
+            const uint32_t b = base + k * STRIP_THREADS;
+            if (b >= per_slice) break;  // uniform
+            walk_strips<DIST>(cur[k], L.g0 + b + threadIdx.x, SG, L.xy<DIST>(b, cur[k]), D,
+                              [&](uint32_t strip, uint32_t, uint32_t, uint32_t np) {
+                                  atomicAdd(&s_hist[strip], (1ull << 32) | np);
+                              });
+        }
+    }
+    // rectangle areas (= gradient-row slots; == pairs unless DIST) and visible Gaussians of this slice, from the
+    // project stage's per-block sums
+    const int64_t nblk = (n + 255) / 256;
+    for (uint32_t k = threadIdx.x; k < per_slice / 256; k += STRIP_THREADS) {
+        const int64_t pb = L.g0 / 256 + k;
+        if (pb < nblk) {
+            atomicAdd(&s_acc[0], block_sums[pb]);
+            atomicAdd(&s_acc[1], block_vis[pb]);
+        }
+    }
+    __syncthreads();
+    unsigned long long *row = table + (size_t)slice * SG.NS;
+    for (uint32_t t = threadIdx.x; t < SG.NS; t += STRIP_THREADS) row[t] = s_hist[t];
+    if (threadIdx.x == 0) {
+        slice_pairs[slice] = s_acc[0];
+        slice_vis[slice] = s_acc[1];
+    }
+}
+
+// ---------------------------------------------------------------- L1b: column scan + strip bases
+// Workgroup = 16 consecutive strips x 16 groups of 16 slices (thread = (group, strip): a group's 16 loads of one
+// slice row are one 128-byte line, and all 16 loads of a thread are in flight at once).  The packed
+// (entries << 32 | pairs) sums never carry from the low half: a strip lists at most 8 N < 2^32 pairs.
+__global__ void __launch_bounds__(256) strip_colscan_kernel(
+    const unsigned long long *__restrict__ table, unsigned long long *__restrict__ scan, uint32_t S, uint32_t NS,
+    unsigned long long *__restrict__ strip_tot) {
+    static_assert(GS_BIN_SLICES == 256, "16 groups of 16 slices");
+    __shared__ unsigned long long s_tot[16][17];
+    const uint32_t col = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const uint32_t t = blockIdx.x * 16 + col;
+    const bool ok = t < NS;
+    unsigned long long v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t b = grp * 16 + i;
+        v[i] = (ok && b < S) ? table[(size_t)b * NS + t] : 0;
+    }
+    unsigned long long run = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const unsigned long long c = v[i];
+        v[i] = run;
+        run += c;
+    }
+    s_tot[grp][col] = run;
+    __syncthreads();
+    unsigned long long off = 0, total = 0;
+#pragma unroll
+    for (uint32_t g = 0; g < 16; ++g) {
+        const unsigned long long x = s_tot[g][col];
+        off += g < grp ? x : 0;
+        total += x;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t b = grp * 16 + i;
+        if (ok && b < S) scan[(size_t)b * NS + t] = v[i] + off;
+    }
+    if (ok && grp == 0) strip_tot[t] = total;
+}
+
+// ---------------------------------------------------------------- L1c: scatter through an LDS staging buffer
+__device__ __forceinline__ uint32_t strip_block_excl_scan(uint32_t v, uint32_t *s_wave, uint32_t &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t incl = gs_wave_incl_scan_u32(v);
+    __syncthreads();  // s_wave may still be read from the previous call
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t off = 0;
+    total = 0;
+#pragma unroll
+    for (int w = 0; w < STRIP_THREADS / 64; ++w) {
+        const uint32_t x = s_wave[w];
+        off += w < wave ? x : 0;
+        total += x;
+    }
+    return off + incl - v;
+}
+
+__device__ __forceinline__ unsigned long long strip_block_excl_scan_u64(unsigned long long v, unsigned long long *s_w,
+                                                                        unsigned long long &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    __syncthreads();  // s_w may still be read from the previous call
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    unsigned long long off = 0;
+    total = 0;
+#pragma unroll
+    for (int w = 0; w < STRIP_THREADS / 64; ++w) {
+        const unsigned long long x = s_w[w];
+        off += w < wave ? x : 0;
+        total += x;
+    }
+    return off + incl - v;
+}
+
+// Dynamic LDS: s_cur[NS] (staging cursor of every strip, ends up at the END of the strip's run), s_gd[NS] (final
+// index of staging slot 0 of the strip's run, i.e. entry i of the staging buffer belongs at s_gd[strip] + i), then
+// `cap` staged entries.  Entries beyond `cap` (a slice that does not fit) are stored straight to their final place.
+template <bool DIST>
+__global__ void __launch_bounds__(STRIP_THREADS) strip_scatter_kernel(
+    const uint4 *__restrict__ rects, const float4 *__restrict__ rec_geom, GsDistCull D, int64_t n, uint32_t per_slice,
+    gs_strip_geom SG, uint32_t S, uint32_t cap, const unsigned long long *__restrict__ scan,
+    const unsigned long long *__restrict__ strip_tot, unsigned long long *__restrict__ strip_base,
+    const uint32_t *__restrict__ slice_pairs, const uint32_t *__restrict__ slice_vis, uint64_t max_pairs,
+    unsigned long long *__restrict__ out, uint32_t *__restrict__ pair_offsets,
+    unsigned long long *__restrict__ counters) {
+    extern __shared__ unsigned long long s_dyn[];
+    uint32_t *s_cur = reinterpret_cast<uint32_t *>(s_dyn), *s_gd = s_cur + SG.NS;
+    unsigned long long *s_stage = s_dyn + SG.NS;  // 2 NS uint32 = NS uint64
+    __shared__ uint32_t s_wave[STRIP_THREADS / 64];
+    __shared__ unsigned long long s_wave64[STRIP_THREADS / 64];
+    const uint32_t slice = strip_slice_of_block(blockIdx.x, gridDim.x);
+    const SliceLoader L = {rects, rec_geom, n, (int64_t)slice * per_slice, per_slice};
+    uint4 rc[STRIP_PF];
+#pragma unroll
+    for (int k = 0; k < STRIP_PF; ++k) rc[k] = L.rect(k * STRIP_THREADS);  // in flight during the set-up below
+    // ---- strip totals -> entry / pair base of every strip, frame totals (every workgroup computes all of them)
+    const uint32_t per = (SG.NS + STRIP_THREADS - 1) / STRIP_THREADS;
+    const uint32_t t0 = threadIdx.x * per < SG.NS ? threadIdx.x * per : SG.NS, t1 = t0 + per < SG.NS ? t0 + per : SG.NS;
+    unsigned long long me = 0, mp = 0, rp = 0, rv = 0;  // separate 64-bit sums: a degenerate scene can exceed 2^32 pairs
+    for (uint32_t t = t0; t < t1; ++t) {
+        const unsigned long long x = strip_tot[t];
+        me += x >> 32;
+        mp += x & 0xffffffffull;
+    }
+    for (uint32_t b = threadIdx.x; b < S; b += STRIP_THREADS) {
+        rp += slice_pairs[b];
+        rv += slice_vis[b];
+    }
+    unsigned long long E, M, R, V;
+    unsigned long long be = strip_block_excl_scan_u64(me, s_wave64, E), bp = strip_block_excl_scan_u64(mp, s_wave64, M);
+    strip_block_excl_scan_u64(rp, s_wave64, R);  // listed pairs M; gradient-row slots R (rectangle areas; == M unless DIST)
+    strip_block_excl_scan_u64(rv, s_wave64, V);
+    const bool overflow = M > max_pairs || R > max_pairs;  // not enough room: the frame is left empty, the true count reported
+    if (slice == 0) {
+        for (uint32_t t = t0; t < t1; ++t) {
+            const unsigned long long x = strip_tot[t];
+            strip_base[t] = overflow ? 0ull : (be << 32) | bp;  // both < 2^30 when the frame fits
+            be += x >> 32;
+            bp += x & 0xffffffffull;
+        }
+        be -= me;
+        if (threadIdx.x == 0) {
+            counters[GS_CNT_PAIRS] = overflow ? 0 : M;
+            counters[GS_CNT_OVERFLOW] = overflow ? (M > R ? M : R) : 0;
+            counters[GS_CNT_VISIBLE] = V;
+            counters[GS_CNT_ENTRIES] = overflow ? 0 : E;
+        }
+    }
+    if (overflow) return;  // uniform
+    // ---- run lengths of this slice = next slice's scanned value - this one's -> local starts (exclusive scan over strips)
+    const unsigned long long *row = scan + (size_t)slice * SG.NS, *next = row + SG.NS;
+    const bool last = slice + 1 == S;
+    uint32_t mine = 0;
+    {
+        uint32_t eb = (uint32_t)be;  // first entry of strip t0
+        for (uint32_t t = t0; t < t1; ++t) {
+            const unsigned long long tot = strip_tot[t];
+            const unsigned long long a = row[t], b = last ? tot : next[t];
+            const uint32_t len = (uint32_t)((b - a) >> 32);  // the low halves never borrow: pairs(b) >= pairs(a)
+            s_gd[t] = eb + (uint32_t)(a >> 32);  // final index of the run's first entry
+            s_cur[t] = len;
+            mine += len;
+            eb += (uint32_t)(tot >> 32);
+        }
+    }
+    uint32_t Ls;
+    uint32_t run = strip_block_excl_scan(mine, s_wave, Ls);
+    for (uint32_t t = t0; t < t1; ++t) {
+        const uint32_t len = s_cur[t];
+        s_cur[t] = run;
+        s_gd[t] -= run;  // wraps; s_gd[t] + staging index is the final index
+        run += len;
+    }
+    // emission offset of this slice's first pair (training: per-pair gradient rows in Gaussian order)
+    uint32_t before = 0, dummy;
+    if (pair_offsets) {
+        uint32_t p = 0;
+        for (uint32_t b = threadIdx.x; b < S; b += STRIP_THREADS) p += b < slice ? slice_pairs[b] : 0;
+        strip_block_excl_scan(p, s_wave, before);
+    }
+    __syncthreads();
+    // ---- place
+    for (uint32_t base = 0; base < per_slice; base += STRIP_PF * STRIP_THREADS) {  // uniform trip counts (barriers inside)
+        uint4 cur[STRIP_PF];
+#pragma unroll
+        for (int k = 0; k < STRIP_PF; ++k) {
+            cur[k] = rc[k];
+            rc[k] = L.rect(base + (STRIP_PF + k) * STRIP_THREADS);
+        }
+#pragma unroll
+        for (int k = 0; k < STRIP_PF; ++k) {
+            const uint32_t b = base + k * STRIP_THREADS;
+            if (b >= per_slice) break;  // uniform
+            const uint32_t i = b + threadIdx.x;
+            if (pair_offsets) {  // uniform: prefix sum of the rectangle areas in Gaussian order
+                const uint32_t ex = strip_block_excl_scan(cur[k].w, s_wave, dummy);
+                if (i < per_slice && L.g0 + i < n) pair_offsets[L.g0 + i] = before + ex;
+                before += dummy;
+            }
+            walk_strips<DIST>(cur[k], L.g0 + i, SG, L.xy<DIST>(b, cur[k]), D,
+                              [&](uint32_t strip, uint32_t lo32, uint32_t d, uint32_t) {
+                                  const uint32_t slot = atomicAdd(&s_cur[strip], 1u);
+                                  const unsigned long long e = ((unsigned long long)d << 32) | lo32;
+                                  if (slot < cap)
+                                      s_stage[slot] = e;
+                                  else
+                                      out[s_gd[strip] + slot] = e;
+                              });
+        }
+    }
+    __syncthreads();
+    // ---- flush: run of strip t = staging [end of strip t - 1, end of strip t); a 16-lane group per run
+    const uint32_t sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    for (uint32_t t = grp; t < SG.NS; t += STRIP_THREADS / 16) {
+        const uint32_t lo = t ? s_cur[t - 1] : 0, hi = s_cur[t] < cap ? s_cur[t] : cap, gd = s_gd[t];
+        for (uint32_t i = lo + sub; i < hi; i += 16) out[gd + i] = s_stage[i];
+    }
+}
+
+}  // namespace
+
+// LDS of the count kernel: 8 B per strip; of the scatter kernel: 8 B per strip + the staging buffer
+int gs_stage_strip_bin(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream) {
+    gs_frame_geom G = gs_frame_geometry(f);
+    const gs_strip_plan plan = gs_strip_plan_for(f->N, G.ntx, G.nty);
+    const gs_strip_geom SG = plan.geom;
+    const bool dist = f->tile_culling_method == 0;
+    GsDistCull D = {(float)(G.padW / 2), (float)(G.padH / 2), f->focal_x, f->focal_y, f->thresh};
+    static std::mutex attr_mu;
+    static std::atomic<uint64_t> attr_done{0};
+    int dev = 0;
+    GS_HIP(hipGetDevice(&dev));
+    if (dev < 64 && !((attr_done.load(std::memory_order_acquire) >> dev) & 1)) {
+        std::lock_guard<std::mutex> lock(attr_mu);
+        for (const void *fn : {(const void *)strip_count_kernel<false>, (const void *)strip_count_kernel<true>})
+            GS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, GS_STRIP_MAX * 8));
+        for (const void *fn : {(const void *)strip_scatter_kernel<false>, (const void *)strip_scatter_kernel<true>})
+            GS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, GS_BIN_LDS_BYTES));
+        attr_done.fetch_or(1ull << dev, std::memory_order_release);
+    }
+    unsigned long long *table = (unsigned long long *)ws.strip_table, *scan = table + (size_t)GS_BIN_SLICES * SG.NS;
+    const size_t lds_count = sizeof(unsigned long long) * SG.NS;
+    const size_t lds_scatter = sizeof(unsigned long long) * ((size_t)SG.NS + plan.cap);
+#define GS_LAUNCH_STRIP(DIST)                                                                                          \
+    do {                                                                                                               \
+        hipLaunchKernelGGL(strip_count_kernel<DIST>, dim3(plan.slices), dim3(STRIP_THREADS), lds_count, stream,        \
+                           ws.rects, ws.rec_geom, D, f->N, plan.per_slice, SG, table, ws.block_sums, ws.block_vis,     \
+                           ws.slice_pairs, ws.slice_vis);                                                              \
+        GS_CHECK_LAUNCH();                                                                                             \
+        hipLaunchKernelGGL(strip_colscan_kernel, dim3((unsigned)gs_div_up(SG.NS, 16)), dim3(256), 0, stream, table,    \
+                           scan, plan.slices, SG.NS, (unsigned long long *)ws.strip_tot);                              \
+        GS_CHECK_LAUNCH();                                                                                             \
+        hipLaunchKernelGGL(strip_scatter_kernel<DIST>, dim3(plan.slices), dim3(STRIP_THREADS), lds_scatter, stream,    \
+                           ws.rects, ws.rec_geom, D, f->N, plan.per_slice, SG, plan.slices, plan.cap, scan,            \
+                           (const unsigned long long *)ws.strip_tot, (unsigned long long *)ws.strip_base,              \
+                           ws.slice_pairs, ws.slice_vis, (uint64_t)f->max_pairs, (unsigned long long *)ws.keys_a,      \
+                           f->training ? ws.pair_offsets : nullptr, ws.counters);                                      \
+        GS_CHECK_LAUNCH();                                                                                             \
+    } while (0)
+    if (dist)
+        GS_LAUNCH_STRIP(true);
+    else
+        GS_LAUNCH_STRIP(false);
+#undef GS_LAUNCH_STRIP
+    return 0;
+}

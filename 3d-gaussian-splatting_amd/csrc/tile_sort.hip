@@ -209,30 +209,13 @@ struct GatherSrc {
     uint32_t S, T;
 };
 
-template <int CAP, int SRC>
-__global__ void __launch_bounds__(256) tile_sort_kernel(uint64_t *__restrict__ keys, uint32_t *__restrict__ ids,
-                                                       uint64_t *__restrict__ scratch,
-                                                       const int32_t *__restrict__ ranges, uint32_t n_tiles,
-                                                       GatherSrc GS) {
+// Sorts the (up to) four buckets `sel(q, tile, start, n)` names, q = 0 .. 3, with the 256 threads of the workgroup.
+// s_a: CAP keys of LDS; s_scan: 4 words; s_off: the SRC_GATHER offset table (filled by the caller).
+template <int CAP, int SRC, typename Sel>
+__device__ __forceinline__ void tile_sort_body(uint64_t *__restrict__ keys, uint32_t *__restrict__ ids,
+                                               uint64_t *__restrict__ scratch, Sel sel, const GatherSrc &GS,
+                                               uint64_t *s_a, uint32_t *s_scan, const uint32_t *s_off) {
     constexpr bool PACKED = SRC != SRC_KEYS;  // the unsorted element already is (depth_bits << 32 | gaussian)
-    __shared__ uint64_t s_a[CAP];
-    __shared__ uint32_t s_scan[4];
-    // SRC_GATHER: where the pairs of this workgroup's four tiles start in every slice region (absolute index into
-    // `pairs`), tiles t0 .. t0 + 4 (the fifth column closes the fourth tile): row j holds S entries.  Loaded once per
-    // workgroup -- thread = slice, five consecutive words of its table row: ONE cache line per slice for all four
-    // tiles -- instead of two scattered 4-byte reads per slice and tile.
-    __shared__ uint32_t s_off[SRC == SRC_GATHER ? 5 * GS_BIN_MAX_SLICES : 1];
-    if (SRC == SRC_GATHER) {
-        const uint32_t t0 = blockIdx.x * 4;
-        const size_t stride = (size_t)GS.T + 1;
-        for (uint32_t sl = threadIdx.x; sl < GS.S; sl += 256) {
-            const uint32_t *r = GS.table + sl * stride;
-            const uint32_t b = GS.slice_base[sl];
-#pragma unroll
-            for (uint32_t j = 0; j < 5; ++j) s_off[j * GS.S + sl] = b + r[t0 + j < GS.T ? t0 + j : GS.T];
-        }
-        __syncthreads();
-    }
     const int lane = threadIdx.x & 63;
     const uint32_t wave = threadIdx.x >> 6;
     uint32_t tile, start, n;
@@ -248,13 +231,10 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(uint64_t *__restrict__ k
         ids[start + i] = (uint32_t)v;
         if (!PACKED || keys) keys[start + i] = ((uint64_t)tile << 32) | (v >> 32);
     };
-    auto select = [&](uint32_t t) {
-        tile = t;
-        start = n = 0;
-        if (t < n_tiles) {
-            start = (uint32_t)ranges[2 * t];
-            n = (uint32_t)ranges[2 * t + 1] - start;
-        }
+    uint32_t cur_q = 0;
+    auto select = [&](uint32_t q) {
+        cur_q = q;
+        sel(q, tile, start, n);
     };
     auto wave_sync = [] {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -266,7 +246,7 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(uint64_t *__restrict__ k
     // at a time (most (slice, tile) cells hold one or two pairs).
     auto gather = [&](uint64_t *dst, uint32_t tid, uint32_t nthreads, bool wg) {
         uint32_t filled = 0;
-        const uint32_t *o_lo = s_off + (tile - blockIdx.x * 4) * GS.S, *o_hi = o_lo + GS.S;
+        const uint32_t *o_lo = s_off + cur_q * GS.S, *o_hi = o_lo + GS.S;
         for (uint32_t s0 = 0; s0 < GS.S; s0 += 4 * nthreads) {
             uint32_t a[4], c[4], d[4];
 #pragma unroll
@@ -317,7 +297,7 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(uint64_t *__restrict__ k
     };
 
     // 1. one wave per short bucket (<= CAP/4 keys), four buckets per workgroup, no workgroup barrier
-    select(blockIdx.x * 4 + wave);
+    select(wave);
     if (n >= (PACKED ? 1u : 2u) && n <= (uint32_t)CAP / 4) {
         uint64_t *a = s_a + wave * (CAP / 4);
         if (SRC == SRC_GATHER) {
@@ -347,7 +327,7 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(uint64_t *__restrict__ k
     }
     // 2. long buckets, one after the other, by the whole workgroup (n is uniform => so are the barriers)
     for (uint32_t q = 0; q < 4; ++q) {
-        select(blockIdx.x * 4 + q);
+        select(q);
         if (n <= (uint32_t)CAP / 4) continue;
         __syncthreads();
         uint32_t P = 256;
@@ -433,6 +413,311 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(uint64_t *__restrict__ k
     }
 }
 
+template <int CAP, int SRC>
+__global__ void __launch_bounds__(256) tile_sort_kernel(uint64_t *__restrict__ keys, uint32_t *__restrict__ ids,
+                                                       uint64_t *__restrict__ scratch,
+                                                       const int32_t *__restrict__ ranges, uint32_t n_tiles,
+                                                       GatherSrc GS) {
+    __shared__ uint64_t s_a[CAP];
+    __shared__ uint32_t s_scan[4];
+    // SRC_GATHER: where the pairs of this workgroup's four tiles start in every slice region (absolute index into
+    // `pairs`), tiles t0 .. t0 + 4 (the fifth column closes the fourth tile): row j holds S entries.  Loaded once per
+    // workgroup -- thread = slice, five consecutive words of its table row: ONE cache line per slice for all four
+    // tiles -- instead of two scattered 4-byte reads per slice and tile.
+    __shared__ uint32_t s_off[SRC == SRC_GATHER ? 5 * GS_BIN_MAX_SLICES : 1];
+    if (SRC == SRC_GATHER) {
+        const uint32_t t0 = blockIdx.x * 4;
+        const size_t stride = (size_t)GS.T + 1;
+        for (uint32_t sl = threadIdx.x; sl < GS.S; sl += 256) {
+            const uint32_t *r = GS.table + sl * stride;
+            const uint32_t b = GS.slice_base[sl];
+#pragma unroll
+            for (uint32_t j = 0; j < 5; ++j) s_off[j * GS.S + sl] = b + r[t0 + j < GS.T ? t0 + j : GS.T];
+        }
+        __syncthreads();
+    }
+    tile_sort_body<CAP, SRC>(
+        keys, ids, scratch,
+        [&](uint32_t q, uint32_t &tile, uint32_t &start, uint32_t &n) {
+            tile = blockIdx.x * 4 + q;
+            start = n = 0;
+            if (tile < n_tiles) {
+                start = (uint32_t)ranges[2 * tile];
+                n = (uint32_t)ranges[2 * tile + 1] - start;
+            }
+        },
+        GS, s_a, s_scan, s_off);
+
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// STRIP variant of sort_mode 2 (level 2; level 1 is strip_bin.hip): one workgroup per HALF strip = four consecutive
+// tiles of one tile row.  The strip's entries (depth_bits << 32 | first covered tile << 29 | last << 26 | gaussian),
+// contiguous in `entries`, are read twice (the second time out of L2): once to count the pairs of every tile of the
+// strip -- which gives this workgroup's tile ranges -- and once to place (depth_bits << 32 | gaussian) into the four
+// tiles' lists.  A half strip of up to CAP pairs keeps its lists in LDS and sorts them there: the unsorted pairs never
+// exist in global memory.  Beyond CAP the lists are placed in `scratch` (indexed like the final list: four streams
+// per workgroup) and sorted by the per-tile code of the table variant.
+// DIST: a tile is listed iff gs_dist_listed says so for the Gaussian's centre (the same test as in level 1).
+template <int CAP, bool DIST>
+__global__ void __launch_bounds__(256) strip_sort_kernel(
+    const uint64_t *__restrict__ entries, const uint64_t *__restrict__ strip_base,
+    const uint64_t *__restrict__ strip_tot, const unsigned long long *__restrict__ counters,
+    uint64_t *__restrict__ keys, uint32_t *__restrict__ ids, uint64_t *__restrict__ scratch,
+    int32_t *__restrict__ ranges, gs_strip_geom SG, const float4 *__restrict__ rec_geom, GsDistCull D) {
+    constexpr uint32_t W = GS_STRIP_W, WAVE_MAX = 512, ID_MASK = (1u << GS_STRIP_ID_BITS) - 1;
+    static_assert(GS_STRIP_W == 8, "two half strips of four tiles");
+    __shared__ uint64_t s_a[CAP];
+    __shared__ uint32_t s_scan[4];
+    __shared__ uint32_t s_cnt[4][W];
+    __shared__ uint32_t s_tile[4], s_start[4], s_n[4];
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = threadIdx.x >> 6;
+    // the two halves of a strip are 8 workgroup ids apart: dealt to the same XCD, they share the entries in its L2
+    const uint32_t strip = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7), half = (blockIdx.x >> 3) & 1;
+    if (strip >= SG.NS) return;
+    const uint32_t row = strip / SG.nsx, sx = strip - row * SG.nsx, tx0 = sx * W + half * 4;
+    if (tx0 >= SG.ntx) return;  // the strip ends in its first half
+    if (counters[GS_CNT_OVERFLOW]) {  // the frame did not fit: every tile reads (0, 0)
+        if (threadIdx.x < 4 && tx0 + threadIdx.x < SG.ntx)
+            reinterpret_cast<int2 *>(ranges)[row * SG.ntx + tx0 + threadIdx.x] = make_int2(0, 0);
+        return;
+    }
+    const uint64_t base = strip_base[strip];
+    const uint32_t E = (uint32_t)(strip_tot[strip] >> 32), e0 = (uint32_t)(base >> 32), p0 = (uint32_t)base;
+    const uint64_t *ent = entries + e0;
+    auto covers = [&](bool ok, uint32_t lo32, float2 xy, uint32_t j) {
+        const uint32_t lx0 = lo32 >> 29, lx1 = (lo32 >> 26) & 7;  // [lx0, lx1]
+        bool c = ok && j >= lx0 && j <= lx1;
+        if (DIST) c = c && gs_dist_listed(xy.x, xy.y, sx * W + j, row, D);
+        return c;
+    };
+    auto centre = [&](bool ok, uint32_t lo32) {
+        if (!DIST || !ok) return make_float2(0.f, 0.f);
+        const float4 ge = rec_geom[(size_t)(lo32 & ID_MASK) * GS_REC_STRIDE];
+        return make_float2(ge.x, ge.y);
+    };
+    // Entries are handled in chunks of 16 x 256: all 16 loads of a thread are in flight at once (a loop of dependent
+    // load -> ballot rounds exposed one memory round trip per 256 entries: 150 us for this kernel at 2.4 M
+    // Gaussians), and a strip of up to 4096 entries -- the common case -- is read from memory only once.
+    constexpr uint32_t EPT = 16, CHUNK = EPT * 256;
+    const uint32_t nchunk = (E + CHUNK - 1) / CHUNK;
+    uint64_t er[EPT];
+    auto load_chunk = [&](uint32_t c) {
+#pragma unroll
+        for (uint32_t k = 0; k < EPT; ++k) {
+            const uint32_t i = c * CHUNK + k * 256 + threadIdx.x;
+            er[k] = i < E ? ent[i] : ~0ull;  // run [7, 7] of Gaussian 2^26 - 1 ... masked by `ok` below
+        }
+    };
+    // ---- 1. pairs of every tile of the strip, per wave (wave-uniform counts from ballots)
+    uint32_t c8[W];
+#pragma unroll
+    for (uint32_t j = 0; j < W; ++j) c8[j] = 0;
+    for (uint32_t c = 0; c < nchunk; ++c) {
+        load_chunk(c);
+        if constexpr (DIST) {
+#pragma unroll
+            for (uint32_t k = 0; k < EPT; ++k) {
+                if (c * CHUNK + k * 256 >= E) break;  // uniform
+                const bool ok = c * CHUNK + k * 256 + threadIdx.x < E;
+                const uint32_t lo32 = (uint32_t)er[k];
+                const float2 xy = centre(ok, lo32);
+#pragma unroll
+                for (uint32_t j = 0; j < W; ++j) c8[j] += (uint32_t)__popcll(__ballot(covers(ok, lo32, xy, j)));
+            }
+        } else {
+            // per lane: the run's 8-bit tile mask spread to one byte per tile (4 tiles per register: bit i of the
+            // nibble times (1 + 2^7 + 2^14 + 2^21) lands on bit 8 i, the other partial products on bits that are masked
+            // away), summed over the lane's <= 16 entries; then 16-bit fields summed over the wave (<= 1024)
+            uint32_t acc_lo = 0, acc_hi = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < EPT; ++k) {
+                if (c * CHUNK + k * 256 >= E) break;  // uniform
+                const bool ok = c * CHUNK + k * 256 + threadIdx.x < E;
+                const uint32_t lo32 = (uint32_t)er[k];
+                const uint32_t lx0 = lo32 >> 29, lx1 = (lo32 >> 26) & 7;
+                const uint32_t m = ok ? ((2u << lx1) - 1u) & ~((1u << lx0) - 1u) : 0u;
+                acc_lo += __umul24(m & 15u, 0x204081u) & 0x01010101u;
+                acc_hi += __umul24(m >> 4, 0x204081u) & 0x01010101u;
+            }
+            const uint32_t w02 = gs_wave_sum_u32(acc_lo & 0x00ff00ffu), w13 = gs_wave_sum_u32((acc_lo >> 8) & 0x00ff00ffu);
+            const uint32_t w46 = gs_wave_sum_u32(acc_hi & 0x00ff00ffu), w57 = gs_wave_sum_u32((acc_hi >> 8) & 0x00ff00ffu);
+            c8[0] += w02 & 0xffff;
+            c8[2] += w02 >> 16;
+            c8[1] += w13 & 0xffff;
+            c8[3] += w13 >> 16;
+            c8[4] += w46 & 0xffff;
+            c8[6] += w46 >> 16;
+            c8[5] += w57 & 0xffff;
+            c8[7] += w57 >> 16;
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (uint32_t j = 0; j < W; ++j) s_cnt[wave][j] = c8[j];
+    }
+    __syncthreads();
+    // wave w places its pairs of tile q behind those of the waves before it: no atomics, and the same (wave, round)
+    // order in both passes makes the placement deterministic
+    uint32_t n4[4], wb4[4], st = p0;
+#pragma unroll
+    for (uint32_t j = 0; j < W; ++j) {
+        const uint32_t c0 = s_cnt[0][j], c1 = s_cnt[1][j], c2 = s_cnt[2][j], c3 = s_cnt[3][j];
+        const uint32_t nj = c0 + c1 + c2 + c3;
+        if (j < half * 4) st += nj;
+        if (j >= half * 4 && j < half * 4 + 4) {
+            n4[j - half * 4] = nj;
+            wb4[j - half * 4] = (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
+        }
+    }
+    uint32_t start4[4], loff4[4], total4 = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < 4; ++q) {
+        start4[q] = st + total4;
+        loff4[q] = total4;
+        total4 += n4[q];
+    }
+    if (threadIdx.x < 4) {
+        const uint32_t q = threadIdx.x;
+        const bool valid = tx0 + q < SG.ntx;
+        const uint32_t nq = q == 0 ? n4[0] : q == 1 ? n4[1] : q == 2 ? n4[2] : n4[3];
+        const uint32_t sq = q == 0 ? start4[0] : q == 1 ? start4[1] : q == 2 ? start4[2] : start4[3];
+        const uint32_t tile = row * SG.ntx + tx0 + q;
+        // every tile is written (empty ones as (0, 0)): the frame needs no memset of the ranges
+        if (valid) reinterpret_cast<int2 *>(ranges)[tile] = nq ? make_int2((int)sq, (int)(sq + nq)) : make_int2(0, 0);
+        s_tile[q] = valid ? tile : 0;
+        s_start[q] = sq;
+        s_n[q] = valid ? nq : 0;
+    }
+    if (total4 == 0) return;  // uniform
+    // ---- 2. place (depth_bits << 32 | gaussian) and 3. sort.  A half strip of up to CAP pairs holds its four lists in
+    // LDS side by side (short lists are then sorted by one wave each, concurrently); otherwise the lists take turns
+    // in the LDS window, each placed from the entries in registers and sorted by the workgroup; a single list beyond
+    // CAP is placed in `scratch` and sorted by the per-tile code of the table variant.  (CAP = 4096 for the first case
+    // alone measured slower: 32 KiB of LDS leave four workgroups per CU to hide the barriers of the merge levels.)
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    // QSEL < 0: all four tiles, tile q to dst[q]; else only tile QSEL, to dst[QSEL]
+    auto place = [&](int qsel, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3, bool lds) {
+        uint32_t dst[4] = {d0 + wb4[0], d1 + wb4[1], d2 + wb4[2], d3 + wb4[3]};
+        for (uint32_t c = 0; c < nchunk; ++c) {
+            if (nchunk > 1) load_chunk(c);  // a single chunk is still in registers
+#pragma unroll
+            for (uint32_t k = 0; k < EPT; ++k) {
+                if (c * CHUNK + k * 256 >= E) break;  // uniform
+                const bool ok = c * CHUNK + k * 256 + threadIdx.x < E;
+                const uint64_t e = er[k];
+                const uint32_t lo32 = (uint32_t)e;
+                const float2 xy = centre(ok, lo32);
+                const uint64_t key = (e & 0xffffffff00000000ull) | (lo32 & ID_MASK);
+#pragma unroll
+                for (uint32_t q = 0; q < 4; ++q) {
+                    if (qsel >= 0 && (uint32_t)qsel != q) continue;  // uniform
+                    const bool cv = covers(ok, lo32, xy, half * 4 + q);
+                    const unsigned long long b = __ballot(cv);
+                    if (cv) {
+                        const uint32_t pos = dst[q] + (uint32_t)__popcll(b & lt);
+                        if (lds)
+                            s_a[pos] = key;
+                        else
+                            scratch[pos] = key;
+                    }
+                    dst[q] += (uint32_t)__popcll(b);
+                }
+            }
+        }
+    };
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto block_sync = [] { __syncthreads(); };
+    auto sort_windows = [&](uint64_t *a, uint32_t n, uint32_t w0, uint32_t wstep) {
+        const uint32_t nwin = (n + 127) / 128;
+        for (uint32_t w = w0; w < nwin; w += wstep) {
+            const uint32_t f0 = w * 128 + lane, f1 = f0 + 64;
+            uint64_t a0 = f0 < n ? a[f0] : KEY_INF, a1 = f1 < n ? a[f1] : KEY_INF;
+            sort_window(a0, a1, lane, n - w * 128 < 128 ? n - w * 128 : 128);
+            if (f0 < n) a[f0] = a0;
+            if (f1 < n) a[f1] = a1;
+        }
+    };
+    auto store_list = [&](uint32_t start, uint64_t tile, const uint64_t *a, uint32_t n, uint32_t tid, uint32_t nthreads) {
+        for (uint32_t i = tid; i < n; i += nthreads) {
+            const uint64_t v = a[i];
+            ids[start + i] = (uint32_t)v;
+            if (keys) keys[start + i] = (tile << 32) | (v >> 32);
+        }
+    };
+    auto sort_by_workgroup = [&](uint64_t *a, uint32_t n) {  // a[0 .. n) is complete and visible to the workgroup
+        sort_windows(a, n, wave, 4);
+        __syncthreads();
+        if (n > 128) {
+            uint32_t P = 256;
+            while (P < n) P <<= 1;
+            merge_levels(a, n, P, threadIdx.x, 256u, block_sync);
+        }
+    };
+    const uint32_t tile0 = row * SG.ntx + tx0;
+    if (total4 <= (uint32_t)CAP) {  // uniform
+        place(-1, loff4[0], loff4[1], loff4[2], loff4[3], true);
+        __syncthreads();
+        {  // short lists: one wave each, no workgroup barrier
+            const uint32_t q = wave;
+            const uint32_t n = q == 0 ? n4[0] : q == 1 ? n4[1] : q == 2 ? n4[2] : n4[3];
+            uint64_t *a = s_a + (q == 0 ? loff4[0] : q == 1 ? loff4[1] : q == 2 ? loff4[2] : loff4[3]);
+            if (n >= 1 && n <= WAVE_MAX) {
+                sort_windows(a, n, 0, 1);
+                wave_sync();
+                if (n > 128) {
+                    uint32_t P = 256;
+                    while (P < n) P <<= 1;
+                    merge_levels(a, n, P, (uint32_t)lane, 64u, wave_sync);
+                }
+                store_list(q == 0 ? start4[0] : q == 1 ? start4[1] : q == 2 ? start4[2] : start4[3], tile0 + q, a, n,
+                           (uint32_t)lane, 64u);
+            }
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {  // long lists: the workgroup, one after the other (n is uniform)
+            const uint32_t n = n4[q];
+            if (n <= WAVE_MAX) continue;
+            uint64_t *a = s_a + loff4[q];
+            __syncthreads();
+            sort_by_workgroup(a, n);
+            store_list(start4[q], tile0 + q, a, n, threadIdx.x, 256u);
+        }
+        return;
+    }
+    bool any_big = false;
+#pragma unroll
+    for (uint32_t q = 0; q < 4; ++q) {  // the lists take turns in the LDS window (n is uniform)
+        const uint32_t n = n4[q];
+        if (n == 0) continue;
+        if (n > (uint32_t)CAP) {
+            place((int)q, start4[0], start4[1], start4[2], start4[3], false);
+            any_big = true;
+            continue;
+        }
+        __syncthreads();  // the previous list has been stored
+        place((int)q, 0, 0, 0, 0, true);
+        __syncthreads();
+        sort_by_workgroup(s_a, n);
+        store_list(start4[q], tile0 + q, s_a, n, threadIdx.x, 256u);
+    }
+    if (any_big) {  // lists in global memory: the per-tile sort of the table variant (in place in `scratch`)
+        __syncthreads();
+        tile_sort_body<CAP, SRC_PACKED>(
+            keys, ids, scratch,
+            [&](uint32_t q, uint32_t &tile, uint32_t &start, uint32_t &n) {
+                tile = s_tile[q];
+                start = s_start[q];
+                n = s_n[q] > (uint32_t)CAP ? s_n[q] : 0;
+            },
+            GatherSrc{}, s_a, s_scan, nullptr);
+    }
+}
+
 }  // namespace
 
 // CAP = 2048 keys (16 KiB of LDS per workgroup) cover Garden-scale tiles; longer buckets take the in-place
@@ -464,6 +749,25 @@ int gs_stage_tile_sort_gather(const gs_frame *f, const gs_frame_ws &ws, const ui
     GatherSrc gsrc = {slice_pairs_buf, ws.bin_table, ws.slice_pairs, plan.slices, (uint32_t)G.n_tiles};
     hipLaunchKernelGGL((tile_sort_kernel<2048, SRC_GATHER>), dim3((G.n_tiles + 3) / 4), dim3(256), 0, stream,
                        keys_out, ids_out, big_scratch, ws.tile_ranges, (uint32_t)G.n_tiles, gsrc);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+// STRIP variant: entries (level 1, strip_bin.hip) -> tile ranges + sorted ids (+ sorted keys on request)
+int gs_stage_strip_sort(const gs_frame *f, const gs_frame_ws &ws, const uint64_t *entries, uint64_t *scratch,
+                        uint64_t *keys_out, uint32_t *ids_out, hipStream_t stream) {
+    gs_frame_geom G = gs_frame_geometry(f);
+    const gs_strip_plan plan = gs_strip_plan_for(f->N, G.ntx, G.nty);
+    GsDistCull D = {(float)(G.padW / 2), (float)(G.padH / 2), f->focal_x, f->focal_y, f->thresh};
+    const unsigned grid = (unsigned)gs_div_up(plan.geom.NS, 8) * 16;
+    if (f->tile_culling_method == 0)
+        hipLaunchKernelGGL((strip_sort_kernel<GS_STRIP_SORT_CAP, true>), dim3(grid), dim3(256), 0, stream, entries,
+                           ws.strip_base, ws.strip_tot, ws.counters, keys_out, ids_out, scratch, ws.tile_ranges,
+                           plan.geom, ws.rec_geom, D);
+    else
+        hipLaunchKernelGGL((strip_sort_kernel<GS_STRIP_SORT_CAP, false>), dim3(grid), dim3(256), 0, stream, entries,
+                           ws.strip_base, ws.strip_tot, ws.counters, keys_out, ids_out, scratch, ws.tile_ranges,
+                           plan.geom, ws.rec_geom, D);
     GS_CHECK_LAUNCH();
     return 0;
 }

@@ -25,6 +25,7 @@ SOURCES = {
     "radix_sort.hip": [],
     "tile_sort.hip": [],
     "tile_bin.hip": [],
+    "strip_bin.hip": [],
     # no SLP packing: v_pk_*_f32 has no rate advantage on gfx950 and costs extra v_mov shuffles
     "raster_fwd.hip": ["-fno-slp-vectorize"],
     "raster_bwd.hip": ["-fno-slp-vectorize"],

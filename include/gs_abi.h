@@ -155,6 +155,11 @@ int gs_sort_pairs_bits(uint64_t *keys0, uint32_t *vals0, uint64_t *keys1, uint32
                                        measured slower than the table variant up to 2.4 M Gaussians at 1080p
                                        (DESIGN.md), so it is opt-in.  Same result either way. */
 
+#define GS_FRAME_TABLE_BIN 4        /* sort_mode 2: the table variant (tile_bin.hip: count -> column scan -> one scattered
+                                       8-byte store per pair) instead of the default two-level STRIP variant
+                                       (strip_bin.hip).  Frames beyond the strip variant's limits (2^26 Gaussians, 8192
+                                       strips of 8 tiles) take the table variant by themselves.  Same result. */
+
 /* Frame descriptor.  All scalars are per-camera constants computed on the host exactly as
  * splatter.py does (Tiles, RayInfo, frustum guard band); rot/tran are passed by value. */
 typedef struct gs_frame {

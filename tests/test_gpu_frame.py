@@ -33,10 +33,19 @@ def case(n, W, H, seed=7, use_sh=False, yaw=2.0, sh_degree=2):
     return scene, cam
 
 
-def check_forward(gpu, scene, cam, training=False, sort_mode=2, slice_sort=False):
+def mode_kwargs(sort_mode):
+    """0, 1, 2 (= the default strip variant of sort_mode 2), "2t" (table variant), "2s" (slice-sorted variant)"""
+    if sort_mode == "2s":
+        return dict(sort_mode=2, slice_sort=True)
+    if sort_mode == "2t":
+        return dict(sort_mode=2, table_bin=True)
+    return dict(sort_mode=sort_mode)
+
+
+def check_forward(gpu, scene, cam, training=False, sort_mode=2):
     of = OracleFrame(scene, cam)
     r = FrameRenderer(gpu, max_pairs=max(len(of.ids) + 17, 64), training=training, auto_grow=False,
-                      sort_mode=sort_mode, slice_sort=slice_sort)
+                      **mode_kwargs(sort_mode))
     params = to_torch(scene, gpu)
     image, padded = r.forward(*params, cam)
     st = r.stats()
@@ -65,43 +74,50 @@ def check_forward(gpu, scene, cam, training=False, sort_mode=2, slice_sort=False
     return of, r, params
 
 
-@pytest.mark.parametrize("sort_mode", [0, 1, 2, "2s"])
-@pytest.mark.parametrize("n,W,H", [(10_000, 256, 256), (30_000, 333, 201), (2_000, 64, 48)])
+@pytest.mark.parametrize("sort_mode", [0, 1, 2, "2t", "2s"])
+@pytest.mark.parametrize("n,W,H", [(10_000, 256, 256), (30_000, 333, 201), (2_000, 64, 48), (3_000, 40, 200)])
 def test_frame_forward_parity(gpu, n, W, H, sort_mode):
-    # "2s": sort_mode 2 with the slice-sorted binning variant (GS_FRAME_SLICE_SORT)
-    check_forward(gpu, *case(n, W, H), sort_mode=2 if sort_mode == "2s" else sort_mode, slice_sort=sort_mode == "2s")
+    # 2: the strip variant (default); "2t": the table variant (GS_FRAME_TABLE_BIN); "2s": the slice-sorted variant
+    # (GS_FRAME_SLICE_SORT).  333 x 201 and 40 x 200: tile rows that end inside a strip / inside its first half
+    check_forward(gpu, *case(n, W, H), sort_mode=sort_mode)
 
 
-@pytest.mark.parametrize("sort_mode", [1, 2, "2s"])
+@pytest.mark.parametrize("sort_mode", [1, 2, "2t", "2s"])
 def test_frame_forward_giant_bucket_sorted_in_chunks(gpu, sort_mode):
     # > 4096 pairs in one tile: the per-tile sort handles 2048-key chunks in LDS and the strides >= 2048 of the
     # last merge levels through global memory (the packed, the (key, id) and the gathered input variants)
     scene, cam = case(40_000, 32, 32, seed=8)
-    of, _, _ = check_forward(gpu, scene, cam, sort_mode=2 if sort_mode == "2s" else sort_mode,
-                             slice_sort=sort_mode == "2s")
+    of, _, _ = check_forward(gpu, scene, cam, sort_mode=sort_mode)
     assert np.diff(of.accum).max() > 4096
 
 
-def test_frame_forward_slice_larger_than_the_lds_staging_buffer(gpu):
-    """sort_mode 2 counting-sorts every slice of the Gaussian array by tile inside LDS and streams it out; a slice
-    with more pairs than the staging buffer holds (here: 60 screen-filling Gaussians next to each other in the array,
-    ~60 k pairs in one 256-Gaussian slice against ~19 k slots) stores straight to its region instead -- same list."""
+@pytest.mark.parametrize("sort_mode,n_big", [("2s", 60), (2, 230)])
+def test_frame_forward_slice_larger_than_the_lds_staging_buffer(gpu, sort_mode, n_big):
+    """The slice-sorted variant of sort_mode 2 counting-sorts every slice of the Gaussian array by tile inside LDS and
+    streams it out; a slice with more pairs than the staging buffer holds (here: 60 screen-filling Gaussians next to
+    each other in the array, ~60 k pairs in one 256-Gaussian slice against ~19 k slots) stores straight to its region
+    instead -- same list.  Likewise the strip variant's scatter stages the ENTRIES of a slice (one per strip of eight
+    tiles a Gaussian crosses: 125 per screen-filling Gaussian here, 230 of them = ~29 k against ~19.9 k slots) and
+    stores the ones that do not fit straight to their final place; the half strips then hold far more than the 4096
+    pairs of the LDS sort window and take the global path."""
     scene, cam = case(2_000, 640, 400, seed=41)
-    big = np.arange(60)
+    big = np.arange(n_big)
     scene.scale[big] = np.float32(3.0) * np.abs(scene.pos[big, 2:3]) / cam.focal_x * 200 * np.array([1.0, 0.7, 0.85], np.float32)
     scene.pos[big, :2] *= 0.05
     scene.pos[big, 2] = np.linspace(3.0, 8.0, len(big), dtype=np.float32)
     scene.opa[big] = -4.0
-    of, r, _ = check_forward(gpu, scene, cam, sort_mode=2, slice_sort=True)
+    of, r, _ = check_forward(gpu, scene, cam, sort_mode=sort_mode)
     counts = np.bincount(of.ids, minlength=scene.n)
     assert counts[big].sum() > 40_000  # far more than the ~19 k pairs the staging buffer holds at this tile count
 
 
-def test_frame_forward_more_tiles_than_lds_counters(gpu):
-    """4096 x 2176 = 34,816 tiles: above the 32,768 LDS counters of sort_mode 2, which must fall back to the
-    tile-bit radix passes (mode 1) and still produce the oracle's list and image."""
+@pytest.mark.parametrize("sort_mode", [2, "2t"])
+def test_frame_forward_more_tiles_than_lds_counters(gpu, sort_mode):
+    """4096 x 2176 = 34,816 tiles: above the 32,768 LDS counters of the table variant of sort_mode 2, which must fall
+    back to the tile-bit radix passes (mode 1) and still produce the oracle's list and image; the strip variant needs
+    one counter per strip (4,352 here) and handles the frame itself."""
     scene, cam = case(4_000, 4096, 2176, seed=17)
-    of, r, _ = check_forward(gpu, scene, cam, sort_mode=2)
+    of, r, _ = check_forward(gpu, scene, cam, sort_mode=sort_mode)
     assert r.stats().pairs == len(of.ids) > 0
 
 
@@ -442,8 +458,8 @@ def test_full_size_2p4M_forward_matches_oracle(gpu):
     scene, cam = make_scene(n, W, H, seed=2023, use_sh=use_sh), make_camera(W, H)
     params = to_torch(scene, gpu)
     of = OracleFrame(scene, cam)
-    for slice_sort in (False, True):  # both binning variants of sort_mode 2
-        r = FrameRenderer(gpu, max_pairs=7_600_000, auto_grow=False, slice_sort=slice_sort)
+    for variant in ({}, dict(table_bin=True), dict(slice_sort=True)):  # the three binning variants of sort_mode 2
+        r = FrameRenderer(gpu, max_pairs=7_600_000, auto_grow=False, **variant)
         img, _ = r.forward(*params, cam)
         st, v = r.stats(), r.debug_views()
         assert (st.visible, st.pairs, st.overflow) == (1_887_982, 6_950_364, 0)

@@ -2,7 +2,8 @@
 """hipEvent stage times of one forward + backward frame per config:  python tools/stage_profile.py [cfg2 cfg4 cfg5 cfg4_deg3 ...]
 
 Suffixes: `_deg3` = degree-3 SH (48 coefficients), `_keys` = also write the sorted keys (GS_FRAME_EMIT_SORTED_KEYS),
-`_fwd` = inference forward only (no checkpoints, no backward), `_ss` = slice-sorted binning variant."""
+`_fwd` = inference forward only (no checkpoints, no backward), `_ss` = slice-sorted binning variant, `_tb` = table
+binning variant (default: the strip variant)."""
 import os
 import sys
 
@@ -18,7 +19,7 @@ dev = torch.device("cuda:0")
 for cfg in (sys.argv[1:] or ("cfg2", "cfg4", "cfg5")):
     base = cfg
     flags = set()
-    for suf in ("_deg3", "_keys", "_fwd", "_ss"):
+    for suf in ("_deg3", "_keys", "_fwd", "_ss", "_tb"):
         if suf in base:
             base = base.replace(suf, "")
             flags.add(suf)
@@ -29,7 +30,7 @@ for cfg in (sys.argv[1:] or ("cfg2", "cfg4", "cfg5")):
     params = [torch.from_numpy(a).to(dev) for a in (scene.pos, scene.quat, scene.scale, scene.opa, scene.rgb)]
     training = "_fwd" not in flags
     r = FrameRenderer(dev, max_pairs=1 << 20, training=training, auto_grow=True, emit_sorted_keys="_keys" in flags,
-                      slice_sort="_ss" in flags)
+                      slice_sort="_ss" in flags, table_bin="_tb" in flags)
     r.forward(*params, cam)
     st = r.stats()
     r.max_pairs = int(st.pairs * 1.1) + 4096
