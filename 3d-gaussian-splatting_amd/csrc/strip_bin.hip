@@ -221,29 +221,6 @@ __device__ __forceinline__ uint32_t strip_block_excl_scan(uint32_t v, uint32_t *
     return off + incl - v;
 }
 
-__device__ __forceinline__ unsigned long long strip_block_excl_scan_u64(unsigned long long v, unsigned long long *s_w,
-                                                                        unsigned long long &total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned long long incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned long long t = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t;
-    }
-    __syncthreads();  // s_w may still be read from the previous call
-    if (lane == 63) s_w[wave] = incl;
-    __syncthreads();
-    unsigned long long off = 0;
-    total = 0;
-#pragma unroll
-    for (int w = 0; w < STRIP_THREADS / 64; ++w) {
-        const unsigned long long x = s_w[w];
-        off += w < wave ? x : 0;
-        total += x;
-    }
-    return off + incl - v;
-}
-
 // Dynamic LDS: s_cur[NS] (staging cursor of every strip, ends up at the END of the strip's run), s_gd[NS] (final
 // index of staging slot 0 of the strip's run, i.e. entry i of the staging buffer belongs at s_gd[strip] + i), then
 // `cap` staged entries.  Entries beyond `cap` (a slice that does not fit) are stored straight to their final place.
@@ -259,7 +236,7 @@ __global__ void __launch_bounds__(STRIP_THREADS) strip_scatter_kernel(
     uint32_t *s_cur = reinterpret_cast<uint32_t *>(s_dyn), *s_gd = s_cur + SG.NS;
     unsigned long long *s_stage = s_dyn + SG.NS;  // 2 NS uint32 = NS uint64
     __shared__ uint32_t s_wave[STRIP_THREADS / 64];
-    __shared__ unsigned long long s_wave64[STRIP_THREADS / 64];
+    __shared__ unsigned long long s_wave64[4 * (STRIP_THREADS / 64)];
     const uint32_t slice = strip_slice_of_block(blockIdx.x, gridDim.x);
     const SliceLoader L = {rects, rec_geom, n, (int64_t)slice * per_slice, per_slice};
     uint4 rc[STRIP_PF];
@@ -269,8 +246,14 @@ __global__ void __launch_bounds__(STRIP_THREADS) strip_scatter_kernel(
     const uint32_t per = (SG.NS + STRIP_THREADS - 1) / STRIP_THREADS;
     const uint32_t t0 = threadIdx.x * per < SG.NS ? threadIdx.x * per : SG.NS, t1 = t0 + per < SG.NS ? t0 + per : SG.NS;
     unsigned long long me = 0, mp = 0, rp = 0, rv = 0;  // separate 64-bit sums: a degenerate scene can exceed 2^32 pairs
+    const unsigned long long *row = scan + (size_t)slice * SG.NS, *next = row + SG.NS;
+    const bool last = slice + 1 == S;
+    // all loads of the set-up are issued before the first block scan; the common case (one strip per thread) keeps them
+    // in registers
+    const unsigned long long tot0 = t0 < t1 ? strip_tot[t0] : 0, a0 = t0 < t1 ? row[t0] : 0,
+                             b0 = t0 < t1 ? (last ? tot0 : next[t0]) : 0;
     for (uint32_t t = t0; t < t1; ++t) {
-        const unsigned long long x = strip_tot[t];
+        const unsigned long long x = t == t0 ? tot0 : strip_tot[t];
         me += x >> 32;
         mp += x & 0xffffffffull;
     }
@@ -278,14 +261,50 @@ __global__ void __launch_bounds__(STRIP_THREADS) strip_scatter_kernel(
         rp += slice_pairs[b];
         rv += slice_vis[b];
     }
-    unsigned long long E, M, R, V;
-    unsigned long long be = strip_block_excl_scan_u64(me, s_wave64, E), bp = strip_block_excl_scan_u64(mp, s_wave64, M);
-    strip_block_excl_scan_u64(rp, s_wave64, R);  // listed pairs M; gradient-row slots R (rectangle areas; == M unless DIST)
-    strip_block_excl_scan_u64(rv, s_wave64, V);
+    // one block scan for the four 64-bit values (entries and pairs need the prefix, R and V only the total)
+    unsigned long long E, M, R, V, be, bp;
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        unsigned long long ie = me, ip = mp;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long x = __shfl_up(ie, o, 64), y = __shfl_up(ip, o, 64);
+            if (lane >= o) {
+                ie += x;
+                ip += y;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            rp += __shfl_xor(rp, o, 64);
+            rv += __shfl_xor(rv, o, 64);
+        }
+        if (lane == 63) {
+            s_wave64[wave] = ie;
+            s_wave64[16 + wave] = ip;
+            s_wave64[32 + wave] = rp;
+            s_wave64[48 + wave] = rv;
+        }
+        __syncthreads();
+        unsigned long long oe = 0, op = 0;
+        E = M = R = V = 0;
+#pragma unroll
+        for (int w = 0; w < STRIP_THREADS / 64; ++w) {
+            const unsigned long long x = s_wave64[w], y = s_wave64[16 + w];
+            oe += w < wave ? x : 0;
+            op += w < wave ? y : 0;
+            E += x;
+            M += y;
+            R += s_wave64[32 + w];  // listed pairs M; gradient-row slots R (rectangle areas; == M unless DIST)
+            V += s_wave64[48 + w];
+        }
+        be = oe + ie - me;
+        bp = op + ip - mp;
+    }
     const bool overflow = M > max_pairs || R > max_pairs;  // not enough room: the frame is left empty, the true count reported
     if (slice == 0) {
         for (uint32_t t = t0; t < t1; ++t) {
-            const unsigned long long x = strip_tot[t];
+            const unsigned long long x = t == t0 ? tot0 : strip_tot[t];
             strip_base[t] = overflow ? 0ull : (be << 32) | bp;  // both < 2^30 when the frame fits
             be += x >> 32;
             bp += x & 0xffffffffull;
@@ -300,14 +319,12 @@ __global__ void __launch_bounds__(STRIP_THREADS) strip_scatter_kernel(
     }
     if (overflow) return;  // uniform
     // ---- run lengths of this slice = next slice's scanned value - this one's -> local starts (exclusive scan over strips)
-    const unsigned long long *row = scan + (size_t)slice * SG.NS, *next = row + SG.NS;
-    const bool last = slice + 1 == S;
     uint32_t mine = 0;
     {
         uint32_t eb = (uint32_t)be;  // first entry of strip t0
         for (uint32_t t = t0; t < t1; ++t) {
-            const unsigned long long tot = strip_tot[t];
-            const unsigned long long a = row[t], b = last ? tot : next[t];
+            const unsigned long long tot = t == t0 ? tot0 : strip_tot[t];
+            const unsigned long long a = t == t0 ? a0 : row[t], b = t == t0 ? b0 : (last ? tot : next[t]);
             const uint32_t len = (uint32_t)((b - a) >> 32);  // the low halves never borrow: pairs(b) >= pairs(a)
             s_gd[t] = eb + (uint32_t)(a >> 32);  // final index of the run's first entry
             s_cur[t] = len;

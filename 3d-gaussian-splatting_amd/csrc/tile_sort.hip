@@ -451,6 +451,172 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(uint64_t *__restrict__ k
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Distribution sort of the list a[0 .. n) in LDS by the unique key (depth_bits << 32 | gaussian), result handed to
+// store(position, key).  The bitonic network above costs ~55 compare-exchange stages of 64-bit keys per element at
+// n = 1024 (PMC, profiles/r02_a: 43.5 M VALU wave-instructions for 6.95 M keys = 400 per key: the per-tile sort was
+// VALU-bound at 99 us).  Depth bits of a tile's list are spread over a range, so ONE counting pass over B >= n
+// buckets that are linear in the depth bits (monotone: float conversion, multiplication by a positive constant and
+// truncation all are) leaves ~1 key per bucket:
+//   keys -> registers, min / max of the depth bits -> bucket of every key, rank inside the bucket from ds_add_rtn ->
+//   exclusive scan of the B counters -> keys written back in bucket order -> final position = bucket start + number
+//   of smaller keys in the bucket (a loop over the bucket: buckets are tiny) -> store.
+// Buckets with more than BUCKET_SMALL keys (depth clusters: many Gaussians on one surface; equal depths) are queued
+// and sorted in place by the bitonic network, one wave per bucket (the workgroup for more than 512 keys): the worst
+// case -- all keys in one bucket -- costs what the network cost before.
+// `nthreads` threads with index `tid` cooperate (a wave: n <= 512, sync = wave barrier; the 256-thread workgroup:
+// n <= 2048, sync = __syncthreads); cnt: nthreads x 8 + 1 words, wl: 1 + 2 x 128 words, red: 16 words of LDS.
+#define BUCKET_SMALL 16u
+template <typename Sync, typename Store>
+__device__ __forceinline__ void bucket_sort_store(uint64_t *a, uint32_t n, uint32_t *cnt, uint32_t *wl, uint32_t *red,
+                                                  uint32_t tid, uint32_t nthreads, Sync sync, Store store) {
+    constexpr int R = 8;
+    const int lane = tid & 63;
+    const uint32_t wave = tid >> 6, nwaves = nthreads >> 6;
+    const uint32_t per = (n + nthreads - 1) / nthreads;                 // <= 8
+    const uint32_t CPT = per <= 1 ? 1 : per <= 2 ? 2 : per <= 4 ? 4 : 8;  // counters per thread
+    const uint32_t B = nthreads * CPT;                                  // n <= B < 2 n (or B = nthreads)
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    // ---- keys to registers, range of the depth bits
+    uint64_t k[R];
+    uint32_t dmin = 0xffffffffu, dmax = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t i = tid + r * nthreads;
+        k[r] = i < n ? a[i] : KEY_INF;
+        if (i < n) {
+            const uint32_t d = (uint32_t)(k[r] >> 32);
+            dmin = d < dmin ? d : dmin;
+            dmax = d > dmax ? d : dmax;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t x = __shfl_xor(dmin, o, 64), y = __shfl_xor(dmax, o, 64);
+        dmin = x < dmin ? x : dmin;
+        dmax = y > dmax ? y : dmax;
+    }
+    for (uint32_t c = tid; c <= B; c += nthreads) cnt[c] = 0;
+    if (tid == 0) wl[0] = 0;
+    if (nwaves > 1) {
+        if (lane == 0) {
+            red[wave] = dmin;
+            red[4 + wave] = dmax;
+        }
+        sync();
+#pragma unroll
+        for (uint32_t w = 0; w < 4; ++w) {
+            if (w < nwaves) {
+                dmin = red[w] < dmin ? red[w] : dmin;
+                dmax = red[4 + w] > dmax ? red[4 + w] : dmax;
+            }
+        }
+    } else {
+        sync();
+    }
+    // ---- bucket of every key, rank inside the bucket in arrival order
+    const float scale = (float)B / ((float)(dmax - dmin) + 1.0f);
+    uint32_t bk[R], rk[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        bk[r] = rk[r] = 0;
+        if (tid + r * nthreads < n) {
+            const uint32_t b = (uint32_t)((float)((uint32_t)(k[r] >> 32) - dmin) * scale);
+            bk[r] = b < B - 1 ? b : B - 1;
+            rk[r] = atomicAdd(&cnt[bk[r]], 1u);
+        }
+    }
+    sync();
+    // ---- exclusive scan of the counters (thread t owns counters [t CPT, t CPT + CPT))
+    {
+        uint32_t c[8], sum = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) {
+            c[j] = j < CPT ? cnt[tid * CPT + j] : 0;
+            const uint32_t x = c[j];
+            c[j] = sum;
+            sum += x;
+        }
+        const uint32_t incl = gs_wave_incl_scan_u32(sum);
+        uint32_t off = incl - sum;
+        if (nwaves > 1) {
+            if (lane == 63) red[8 + wave] = incl;
+            sync();
+#pragma unroll
+            for (uint32_t w = 0; w < 4; ++w) off += w < wave ? red[8 + w] : 0;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j)
+            if (j < CPT) cnt[tid * CPT + j] = off + c[j];
+        if (tid == 0) cnt[B] = n;
+    }
+    sync();
+    // ---- keys back in bucket order (in place: every key is in a register)
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (tid + r * nthreads < n) a[cnt[bk[r]] + rk[r]] = k[r];
+    sync();
+    // ---- final position inside the bucket; large buckets are queued
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (tid + r * nthreads < n) {
+            const uint32_t bs = cnt[bk[r]], be = cnt[bk[r] + 1];
+            if (be - bs <= BUCKET_SMALL) {
+                uint32_t c = 0;
+                for (uint32_t j = bs; j < be; ++j) c += a[j] < k[r] ? 1u : 0u;
+                store(bs + c, k[r]);
+            } else if (rk[r] == 0) {
+                const uint32_t slot = atomicAdd(&wl[0], 1u);
+                wl[1 + 2 * slot] = bs;
+                wl[2 + 2 * slot] = be - bs;
+            }
+        }
+    }
+    sync();
+    const uint32_t nwl = wl[0];
+    if (nwl == 0) return;  // uniform
+    auto sort_windows = [&](uint64_t *b, uint32_t m, uint32_t w0, uint32_t wstep) {
+        const uint32_t nwin = (m + 127) / 128;
+        for (uint32_t w = w0; w < nwin; w += wstep) {
+            const uint32_t f0 = w * 128 + lane, f1 = f0 + 64;
+            uint64_t a0 = f0 < m ? b[f0] : KEY_INF, a1 = f1 < m ? b[f1] : KEY_INF;
+            sort_window(a0, a1, lane, m - w * 128 < 128 ? m - w * 128 : 128);
+            if (f0 < m) b[f0] = a0;
+            if (f1 < m) b[f1] = a1;
+        }
+    };
+    for (uint32_t i = wave; i < nwl; i += nwaves) {  // one wave per queued bucket of up to 512 keys
+        const uint32_t bs = wl[1 + 2 * i], m = wl[2 + 2 * i];
+        if (m > 512) continue;
+        uint64_t *b = a + bs;
+        sort_windows(b, m, 0, 1);
+        wave_sync();
+        if (m > 128) {
+            uint32_t P = 256;
+            while (P < m) P <<= 1;
+            merge_levels(b, m, P, (uint32_t)lane, 64u, wave_sync);
+        }
+        for (uint32_t j = lane; j < m; j += 64) store(bs + j, b[j]);
+    }
+    if (nwaves > 1) {
+        for (uint32_t i = 0; i < nwl; ++i) {  // longer ones by the workgroup (uniform)
+            const uint32_t bs = wl[1 + 2 * i], m = wl[2 + 2 * i];
+            if (m <= 512) continue;
+            uint64_t *b = a + bs;
+            sync();
+            sort_windows(b, m, wave, nwaves);
+            sync();
+            uint32_t P = 256;
+            while (P < m) P <<= 1;
+            merge_levels(b, m, P, tid, nthreads, sync);
+            for (uint32_t j = tid; j < m; j += nthreads) store(bs + j, b[j]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // STRIP variant of sort_mode 2 (level 2; level 1 is strip_bin.hip): one workgroup per HALF strip = four consecutive
 // tiles of one tile row.  The strip's entries (depth_bits << 32 | first covered tile << 29 | last << 26 | gaussian),
 // contiguous in `entries`, are read twice (the second time out of L2): once to count the pairs of every tile of the
@@ -460,7 +626,10 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(uint64_t *__restrict__ k
 // per workgroup) and sorted by the per-tile code of the table variant.
 // DIST: a tile is listed iff gs_dist_listed says so for the Gaussian's centre (the same test as in level 1).
 template <int CAP, bool DIST>
-__global__ void __launch_bounds__(256) strip_sort_kernel(
+#ifndef STRIP_SORT_WPE
+#define STRIP_SORT_WPE 4  // waves per SIMD the register allocation aims at (A/B switch, tools/ab_variants.py)
+#endif
+__global__ void __launch_bounds__(256, STRIP_SORT_WPE) strip_sort_kernel(
     const uint64_t *__restrict__ entries, const uint64_t *__restrict__ strip_base,
     const uint64_t *__restrict__ strip_tot, const unsigned long long *__restrict__ counters,
     uint64_t *__restrict__ keys, uint32_t *__restrict__ ids, uint64_t *__restrict__ scratch,
@@ -471,6 +640,9 @@ __global__ void __launch_bounds__(256) strip_sort_kernel(
     __shared__ uint32_t s_scan[4];
     __shared__ uint32_t s_cnt[4][W];
     __shared__ uint32_t s_tile[4], s_start[4], s_n[4];
+    // distribution sort (bucket_sort_store): counters of the workgroup (256 x 8 + 1) or of four waves (64 x 8 + 1 each),
+    // queues of large buckets, cross-wave scratch
+    __shared__ uint32_t s_bcnt[4 * 513 + 4], s_wl[4][1 + 2 * 128], s_red[16];
     const int lane = threadIdx.x & 63;
     const uint32_t wave = threadIdx.x >> 6;
     // the two halves of a strip are 8 workgroup ids apart: dealt to the same XCD, they share the entries in its L2
@@ -598,10 +770,10 @@ __global__ void __launch_bounds__(256) strip_sort_kernel(
     // alone measured slower: 32 KiB of LDS leave four workgroups per CU to hide the barriers of the merge levels.)
     const unsigned long long lt = (1ull << lane) - 1ull;
     // QSEL < 0: all four tiles, tile q to dst[q]; else only tile QSEL, to dst[QSEL]
-    auto place = [&](int qsel, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3, bool lds) {
+    auto place = [&](int qsel, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3, bool lds, bool reload) {
         uint32_t dst[4] = {d0 + wb4[0], d1 + wb4[1], d2 + wb4[2], d3 + wb4[3]};
         for (uint32_t c = 0; c < nchunk; ++c) {
-            if (nchunk > 1) load_chunk(c);  // a single chunk is still in registers
+            if (nchunk > 1 || reload) load_chunk(c);  // else: the single chunk is still in registers
 #pragma unroll
             for (uint32_t k = 0; k < EPT; ++k) {
                 if (c * CHUNK + k * 256 >= E) break;  // uniform
@@ -632,60 +804,70 @@ __global__ void __launch_bounds__(256) strip_sort_kernel(
         __builtin_amdgcn_wave_barrier();
     };
     auto block_sync = [] { __syncthreads(); };
-    auto sort_windows = [&](uint64_t *a, uint32_t n, uint32_t w0, uint32_t wstep) {
-        const uint32_t nwin = (n + 127) / 128;
-        for (uint32_t w = w0; w < nwin; w += wstep) {
-            const uint32_t f0 = w * 128 + lane, f1 = f0 + 64;
-            uint64_t a0 = f0 < n ? a[f0] : KEY_INF, a1 = f1 < n ? a[f1] : KEY_INF;
-            sort_window(a0, a1, lane, n - w * 128 < 128 ? n - w * 128 : 128);
-            if (f0 < n) a[f0] = a0;
-            if (f1 < n) a[f1] = a1;
-        }
-    };
-    auto store_list = [&](uint32_t start, uint64_t tile, const uint64_t *a, uint32_t n, uint32_t tid, uint32_t nthreads) {
-        for (uint32_t i = tid; i < n; i += nthreads) {
-            const uint64_t v = a[i];
+    // a[0 .. n) is complete and visible to the workgroup: sorted and stored as list `start`, tile `tile`
+    auto sort_store_by_workgroup = [&](uint64_t *a, uint32_t n, uint32_t start, uint64_t tile) {
+        auto st = [&](uint32_t i, uint64_t v) {
             ids[start + i] = (uint32_t)v;
             if (keys) keys[start + i] = (tile << 32) | (v >> 32);
+        };
+        if (n <= 128) {  // registers of one wave
+            if (wave == 0) {
+                const uint32_t f0 = lane, f1 = lane + 64;
+                uint64_t a0 = f0 < n ? a[f0] : KEY_INF, a1 = f1 < n ? a[f1] : KEY_INF;
+                sort_window(a0, a1, lane, n);
+                if (f0 < n) st(f0, a0);
+                if (f1 < n) st(f1, a1);
+            }
+            return;
         }
-    };
-    auto sort_by_workgroup = [&](uint64_t *a, uint32_t n) {  // a[0 .. n) is complete and visible to the workgroup
-        sort_windows(a, n, wave, 4);
-        __syncthreads();
-        if (n > 128) {
+        if (n > 2048) {  // beyond the distribution sort's eight keys per thread: the bitonic network, in place
+            const uint32_t nwin = (n + 127) / 128;
+            for (uint32_t w = wave; w < nwin; w += 4) {
+                const uint32_t f0 = w * 128 + lane, f1 = f0 + 64;
+                uint64_t a0 = f0 < n ? a[f0] : KEY_INF, a1 = f1 < n ? a[f1] : KEY_INF;
+                sort_window(a0, a1, lane, n - w * 128 < 128 ? n - w * 128 : 128);
+                if (f0 < n) a[f0] = a0;
+                if (f1 < n) a[f1] = a1;
+            }
+            __syncthreads();
             uint32_t P = 256;
             while (P < n) P <<= 1;
             merge_levels(a, n, P, threadIdx.x, 256u, block_sync);
+            for (uint32_t i = threadIdx.x; i < n; i += 256) st(i, a[i]);
+            return;
         }
+        bucket_sort_store(a, n, s_bcnt, s_wl[0], s_red, threadIdx.x, 256u, block_sync, st);
     };
     const uint32_t tile0 = row * SG.ntx + tx0;
     if (total4 <= (uint32_t)CAP) {  // uniform
-        place(-1, loff4[0], loff4[1], loff4[2], loff4[3], true);
+        place(-1, loff4[0], loff4[1], loff4[2], loff4[3], true, false);
         __syncthreads();
         {  // short lists: one wave each, no workgroup barrier
             const uint32_t q = wave;
             const uint32_t n = q == 0 ? n4[0] : q == 1 ? n4[1] : q == 2 ? n4[2] : n4[3];
+            const uint32_t start = q == 0 ? start4[0] : q == 1 ? start4[1] : q == 2 ? start4[2] : start4[3];
+            const uint64_t tile = tile0 + q;
             uint64_t *a = s_a + (q == 0 ? loff4[0] : q == 1 ? loff4[1] : q == 2 ? loff4[2] : loff4[3]);
-            if (n >= 1 && n <= WAVE_MAX) {
-                sort_windows(a, n, 0, 1);
-                wave_sync();
-                if (n > 128) {
-                    uint32_t P = 256;
-                    while (P < n) P <<= 1;
-                    merge_levels(a, n, P, (uint32_t)lane, 64u, wave_sync);
-                }
-                store_list(q == 0 ? start4[0] : q == 1 ? start4[1] : q == 2 ? start4[2] : start4[3], tile0 + q, a, n,
-                           (uint32_t)lane, 64u);
+            auto st = [&](uint32_t i, uint64_t v) {
+                ids[start + i] = (uint32_t)v;
+                if (keys) keys[start + i] = (tile << 32) | (v >> 32);
+            };
+            if (n >= 1 && n <= 128) {  // registers only
+                const uint32_t f0 = lane, f1 = lane + 64;
+                uint64_t a0 = f0 < n ? a[f0] : KEY_INF, a1 = f1 < n ? a[f1] : KEY_INF;
+                sort_window(a0, a1, lane, n);
+                if (f0 < n) st(f0, a0);
+                if (f1 < n) st(f1, a1);
+            } else if (n <= WAVE_MAX) {
+                bucket_sort_store(a, n, s_bcnt + wave * 513, s_wl[wave], s_red, (uint32_t)lane, 64u, wave_sync, st);
             }
         }
 #pragma unroll
         for (uint32_t q = 0; q < 4; ++q) {  // long lists: the workgroup, one after the other (n is uniform)
             const uint32_t n = n4[q];
             if (n <= WAVE_MAX) continue;
-            uint64_t *a = s_a + loff4[q];
             __syncthreads();
-            sort_by_workgroup(a, n);
-            store_list(start4[q], tile0 + q, a, n, threadIdx.x, 256u);
+            sort_store_by_workgroup(s_a + loff4[q], n, start4[q], tile0 + q);
         }
         return;
     }
@@ -695,15 +877,14 @@ __global__ void __launch_bounds__(256) strip_sort_kernel(
         const uint32_t n = n4[q];
         if (n == 0) continue;
         if (n > (uint32_t)CAP) {
-            place((int)q, start4[0], start4[1], start4[2], start4[3], false);
+            place((int)q, start4[0], start4[1], start4[2], start4[3], false, true);
             any_big = true;
             continue;
         }
         __syncthreads();  // the previous list has been stored
-        place((int)q, 0, 0, 0, 0, true);
+        place((int)q, 0, 0, 0, 0, true, true);  // entries re-read (L2): 32 registers less across the sorts
         __syncthreads();
-        sort_by_workgroup(s_a, n);
-        store_list(start4[q], tile0 + q, s_a, n, threadIdx.x, 256u);
+        sort_store_by_workgroup(s_a, n, start4[q], tile0 + q);
     }
     if (any_big) {  // lists in global memory: the per-tile sort of the table variant (in place in `scratch`)
         __syncthreads();
@@ -753,6 +934,9 @@ int gs_stage_tile_sort_gather(const gs_frame *f, const gs_frame_ws &ws, const ui
     return 0;
 }
 
+#ifndef STRIP_SORT_CAP_
+#define STRIP_SORT_CAP_ GS_STRIP_SORT_CAP  // A/B switch (tools/ab_variants.py)
+#endif
 // STRIP variant: entries (level 1, strip_bin.hip) -> tile ranges + sorted ids (+ sorted keys on request)
 int gs_stage_strip_sort(const gs_frame *f, const gs_frame_ws &ws, const uint64_t *entries, uint64_t *scratch,
                         uint64_t *keys_out, uint32_t *ids_out, hipStream_t stream) {
@@ -761,11 +945,11 @@ int gs_stage_strip_sort(const gs_frame *f, const gs_frame_ws &ws, const uint64_t
     GsDistCull D = {(float)(G.padW / 2), (float)(G.padH / 2), f->focal_x, f->focal_y, f->thresh};
     const unsigned grid = (unsigned)gs_div_up(plan.geom.NS, 8) * 16;
     if (f->tile_culling_method == 0)
-        hipLaunchKernelGGL((strip_sort_kernel<GS_STRIP_SORT_CAP, true>), dim3(grid), dim3(256), 0, stream, entries,
+        hipLaunchKernelGGL((strip_sort_kernel<STRIP_SORT_CAP_, true>), dim3(grid), dim3(256), 0, stream, entries,
                            ws.strip_base, ws.strip_tot, ws.counters, keys_out, ids_out, scratch, ws.tile_ranges,
                            plan.geom, ws.rec_geom, D);
     else
-        hipLaunchKernelGGL((strip_sort_kernel<GS_STRIP_SORT_CAP, false>), dim3(grid), dim3(256), 0, stream, entries,
+        hipLaunchKernelGGL((strip_sort_kernel<STRIP_SORT_CAP_, false>), dim3(grid), dim3(256), 0, stream, entries,
                            ws.strip_base, ws.strip_tot, ws.counters, keys_out, ids_out, scratch, ws.tile_ranges,
                            plan.geom, ws.rec_geom, D);
     GS_CHECK_LAUNCH();
