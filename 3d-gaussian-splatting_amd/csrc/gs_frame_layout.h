@@ -46,7 +46,9 @@ static inline gs_bin_plan gs_bin_plan_for(int64_t N, int64_t max_pairs, int n_ti
 }
 
 // sort_mode 2, STRIP variant (strip_bin.hip; the default): a strip is GS_STRIP_W consecutive tiles of one tile row.
-#define GS_STRIP_W 8          // tiles per strip (3 + 3 bits of an entry name the covered tiles)
+#ifndef GS_STRIP_W
+#define GS_STRIP_W 8          // tiles per strip: 8 or 4 (3 + 3 bits of an entry name the covered tiles)
+#endif
 #define GS_STRIP_ID_BITS 26   // an entry keeps the Gaussian index in 26 bits: scenes beyond 2^26 take the table variant
 #define GS_STRIP_MAX 8192     // strips per frame the LDS histograms are sized for
 #define GS_STRIP_SORT_CAP 2048  // pairs strip_sort_kernel's LDS window holds (a half strip's four lists, or one list at a time)

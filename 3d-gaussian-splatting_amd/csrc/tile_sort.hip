@@ -635,7 +635,7 @@ __global__ void __launch_bounds__(256, STRIP_SORT_WPE) strip_sort_kernel(
     uint64_t *__restrict__ keys, uint32_t *__restrict__ ids, uint64_t *__restrict__ scratch,
     int32_t *__restrict__ ranges, gs_strip_geom SG, const float4 *__restrict__ rec_geom, GsDistCull D) {
     constexpr uint32_t W = GS_STRIP_W, WAVE_MAX = 512, ID_MASK = (1u << GS_STRIP_ID_BITS) - 1;
-    static_assert(GS_STRIP_W == 8, "two half strips of four tiles");
+    static_assert(GS_STRIP_W == 8 || GS_STRIP_W == 4, "a workgroup owns four tiles: a strip or half a strip");
     __shared__ uint64_t s_a[CAP];
     __shared__ uint32_t s_scan[4];
     __shared__ uint32_t s_cnt[4][W];
@@ -646,7 +646,8 @@ __global__ void __launch_bounds__(256, STRIP_SORT_WPE) strip_sort_kernel(
     const int lane = threadIdx.x & 63;
     const uint32_t wave = threadIdx.x >> 6;
     // the two halves of a strip are 8 workgroup ids apart: dealt to the same XCD, they share the entries in its L2
-    const uint32_t strip = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7), half = (blockIdx.x >> 3) & 1;
+    const uint32_t strip = W == 8 ? (blockIdx.x >> 4) * 8 + (blockIdx.x & 7) : blockIdx.x;
+    const uint32_t half = W == 8 ? (blockIdx.x >> 3) & 1 : 0;
     if (strip >= SG.NS) return;
     const uint32_t row = strip / SG.nsx, sx = strip - row * SG.nsx, tx0 = sx * W + half * 4;
     if (tx0 >= SG.ntx) return;  // the strip ends in its first half
@@ -719,10 +720,12 @@ __global__ void __launch_bounds__(256, STRIP_SORT_WPE) strip_sort_kernel(
             c8[2] += w02 >> 16;
             c8[1] += w13 & 0xffff;
             c8[3] += w13 >> 16;
-            c8[4] += w46 & 0xffff;
-            c8[6] += w46 >> 16;
-            c8[5] += w57 & 0xffff;
-            c8[7] += w57 >> 16;
+            if constexpr (W == 8) {
+                c8[4] += w46 & 0xffff;
+                c8[6] += w46 >> 16;
+                c8[5] += w57 & 0xffff;
+                c8[7] += w57 >> 16;
+            }
         }
     }
     if (lane == 0) {
@@ -943,7 +946,7 @@ int gs_stage_strip_sort(const gs_frame *f, const gs_frame_ws &ws, const uint64_t
     gs_frame_geom G = gs_frame_geometry(f);
     const gs_strip_plan plan = gs_strip_plan_for(f->N, G.ntx, G.nty);
     GsDistCull D = {(float)(G.padW / 2), (float)(G.padH / 2), f->focal_x, f->focal_y, f->thresh};
-    const unsigned grid = (unsigned)gs_div_up(plan.geom.NS, 8) * 16;
+    const unsigned grid = GS_STRIP_W == 8 ? (unsigned)gs_div_up(plan.geom.NS, 8) * 16 : plan.geom.NS;
     if (f->tile_culling_method == 0)
         hipLaunchKernelGGL((strip_sort_kernel<STRIP_SORT_CAP_, true>), dim3(grid), dim3(256), 0, stream, entries,
                            ws.strip_base, ws.strip_tot, ws.counters, keys_out, ids_out, scratch, ws.tile_ranges,

@@ -91,6 +91,24 @@ def test_frame_forward_giant_bucket_sorted_in_chunks(gpu, sort_mode):
     assert np.diff(of.accum).max() > 4096
 
 
+@pytest.mark.parametrize("n_sites,jitter", [(40, 0.0), (300, 0.0), (40, 1e-6), (3000, 0.0)])
+def test_frame_forward_depth_clusters(gpu, n_sites, jitter):
+    """The strip variant sorts a tile's list by ONE counting pass over buckets that are linear in the depth bits and
+    only ranks inside a bucket; depth clusters (Gaussians on one surface) put many keys into one bucket, which is then
+    sorted by the bitonic network (a wave up to 512 keys, the workgroup beyond).  30,000 Gaussians on 40 / 300 / 3000
+    sites: 750 / 100 / 10 exact copies per site (equal depth bits: the order inside a cluster is by Gaussian index),
+    and 40 sites with a relative jitter of 1e-6 (distinct depths a few ulp apart).  The list must be the oracle's."""
+    scene, cam = case(30_000, 256, 256, seed=23)
+    site = np.arange(scene.n) % n_sites
+    rng = np.random.default_rng(5)
+    scene.pos[:] = scene.pos[site] * (1.0 + jitter * rng.standard_normal((scene.n, 1))).astype(np.float32)
+    scene.scale[:] = scene.scale[site]
+    scene.quat[:] = scene.quat[site]
+    scene.opa[:] = -3.0  # nearly transparent: every pixel stays live through the long lists
+    of, _, _ = check_forward(gpu, scene, cam, sort_mode=2)
+    assert np.diff(of.accum).max() > 500  # 3000 sites: lists of up to ~520 (one wave each); 40 sites: thousands
+
+
 @pytest.mark.parametrize("sort_mode,n_big", [("2s", 60), (2, 230)])
 def test_frame_forward_slice_larger_than_the_lds_staging_buffer(gpu, sort_mode, n_big):
     """The slice-sorted variant of sort_mode 2 counting-sorts every slice of the Gaussian array by tile inside LDS and
@@ -227,7 +245,7 @@ def test_frame_forward_dense_tiles_multi_chunk(gpu, sort_mode):
     scene, cam = case(60_000, 96, 64, seed=3)
     scene.opa += 2.0
     of, _, _ = check_forward(gpu, scene, cam, sort_mode=sort_mode)
-    assert np.diff(of.accum).max() > 600
+    assert np.diff(of.accum).max() > 500  # 3000 sites: lists of up to ~520 (one wave each); 40 sites: thousands
 
 
 @pytest.mark.parametrize("use_sh", [False, True, 3])
