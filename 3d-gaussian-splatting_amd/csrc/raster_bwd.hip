@@ -717,14 +717,18 @@ struct PixShCfg {
     static constexpr int NROW = 7 + CDIM;  // Sx Sy Sxx Sxy Syy Sq Sopa + the colour(-coefficient) sums
 };
 
+#ifndef GS_BWD_SH_WPE
+#define GS_BWD_SH_WPE 4  // waves per SIMD the register allocation aims at (A/B switch, tools/ab_variants.py)
+#endif
 template <int CDIM, bool FRAME>
-__global__ void __launch_bounds__(64) raster_backward_pixel_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CDIM == 48 ? 2 : GS_BWD_SH_WPE)))
+raster_backward_pixel_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
     constexpr int NB = PixShCfg<CDIM>::NB, NROW = PixShCfg<CDIM>::NROW;
     typedef float f2 __attribute__((ext_vector_type(2)));
     enum { FX, FY, FA, FB, FC, FOPA, FC0, FC1, FC2, NFLD };  // FC0..2: the Gaussian's colour (CDIM == 3 only)
     __shared__ float s_g[NFLD][64];
     __shared__ uint32_t s_id[64];          // FRAME: Gaussian id; else index of the pair in the sorted arrays
-    __shared__ float s_red[NROW * 65];     // [row][lane] partial sums of the current Gaussian (rows padded to 65)
+    __shared__ float s_red[16 * 65];       // [row][lane] partial sums of the current Gaussian, 16 rows at a time (rows padded to 65)
     __shared__ float s_part[NROW][4];      // quarter-row sums of the first reduction level
     __shared__ float s_tot[64][8];         // geometry sums per Gaussian (Sx Sy Sxx Sxy Syy Sq)
     __shared__ float *s_row[64];           // where Gaussian i's gradient row starts (nullptr: no row)
@@ -919,36 +923,36 @@ __global__ void __launch_bounds__(64) raster_backward_pixel_sh_kernel(RasterSrc 
             T[h] = T[h] - w;
         }
         id_next = load_coef(i + 1 < r ? i + 1 : i);
-        {
-            const float s1 = S1.x + S1.y, sy = Sy.x + Sy.y;
-            const float sx = s1 * dx;
-            s_red[0 * 65 + lane] = sx;             // Sx
-            s_red[1 * 65 + lane] = sy;             // Sy
-            s_red[2 * 65 + lane] = sx * dx;        // Sxx
-            s_red[3 * 65 + lane] = sy * dx;        // Sxy
-            s_red[4 * 65 + lane] = Syy.x + Syy.y;  // Syy
-            s_red[5 * 65 + lane] = Sq.x + Sq.y;    // Sq
-            s_red[6 * 65 + lane] = Sopa.x + Sopa.y;
-        }
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
+        // row m of the [NROW][64] array of partial sums: 0..6 geometry / opacity, 7 + ch NB + k colour (coefficient)
+        const float s1 = S1.x + S1.y, sy_ = Sy.x + Sy.y;
+        const float sx_ = s1 * dx;
+        auto row_value = [&](int m) -> float {
+            if (m == 0) return sx_;                // Sx
+            if (m == 1) return sy_;                // Sy
+            if (m == 2) return sx_ * dx;           // Sxx
+            if (m == 3) return sy_ * dx;           // Sxy
+            if (m == 4) return Syy.x + Syy.y;      // Syy
+            if (m == 5) return Sq.x + Sq.y;        // Sq
+            if (m == 6) return Sopa.x + Sopa.y;
+            const int ch = (m - 7) / NB, k = (m - 7) % NB;
             if constexpr (CDIM > 3) {
-#pragma unroll
-                for (int k = 0; k < NB; ++k) {
-                    const f2 p = pk_fma(D[1][ch], SHB[1][k], D[0][ch] * SHB[0][k]);
-                    s_red[(7 + ch * NB + k) * 65 + lane] = p.x + p.y;
-                }
+                const f2 p = pk_fma(D[1][ch], SHB[1][k], D[0][ch] * SHB[0][k]);
+                return p.x + p.y;
             } else {
                 const f2 p = D[0][ch] + D[1][ch];
-                s_red[(7 + ch) * 65 + lane] = p.x + p.y;
+                return p.x + p.y;
             }
-        }
-        lds_order();
+        };
+        // 16 rows at a time through a [16][65] window: the whole [NROW][65] array (8.8 / 14.3 KiB per wave) capped the
+        // kernel at 2-3 waves per SIMD
 #pragma unroll
         for (int rd = 0; rd < NROUND; ++rd) {
+#pragma unroll
+            for (int m = 16 * rd; m < 16 * rd + 16 && m < NROW; ++m) s_red[(m - 16 * rd) * 65 + lane] = row_value(m);
+            lds_order();
             const uint32_t row = 16 * rd + red_row;
             if (16 * (rd + 1) <= NROW || row < (uint32_t)NROW) {
-                const float *src = s_red + row * 65 + red_part * 16;
+                const float *src = s_red + red_row * 65 + red_part * 16;
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
                 for (int j = 0; j < 16; j += 4) {
@@ -959,8 +963,8 @@ __global__ void __launch_bounds__(64) raster_backward_pixel_sh_kernel(RasterSrc 
                 }
                 s_part[row][red_part] = (a0 + a1) + (a2 + a3);
             }
+            lds_order();
         }
-        lds_order();
         if (lane < NROW) {
             const float t = (s_part[lane][0] + s_part[lane][1]) + (s_part[lane][2] + s_part[lane][3]);
             if (lane < 6) {
