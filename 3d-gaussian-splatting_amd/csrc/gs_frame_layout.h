@@ -2,7 +2,7 @@
 #pragma once
 #include "gs_common.h"
 
-enum { GS_CNT_VISIBLE = 0, GS_CNT_PAIRS = 1, GS_CNT_OVERFLOW = 2, GS_CNT_BUCKETS = 3, GS_CNT_TICKET = 4, GS_CNT_ENTRIES = 5, GS_CNT_N = 8 };
+enum { GS_CNT_VISIBLE = 0, GS_CNT_PAIRS = 1, GS_CNT_OVERFLOW = 2, GS_CNT_BUCKETS = 3, GS_CNT_TICKET = 4, GS_CNT_ENTRIES = 5, GS_CNT_BIG = 6, GS_CNT_N = 8 };
 
 #define GS_BUCKET 64          // Gaussians per backward bucket (= wavefront size)
 #define GS_SORT_TILE 2048     // keys per radix-sort workgroup (256 threads x 8)
@@ -139,6 +139,7 @@ struct gs_frame_ws {
     uint64_t *strip_table;         // [2][GS_BIN_SLICES][NS]: raw counts, then their exclusive scan over the slices
     uint64_t *strip_tot;           // [NS] totals per strip
     uint64_t *strip_base;          // [NS] (first entry << 32 | first pair) of every strip
+    uint32_t *big_tiles;           // [T] queue of the tiles whose list exceeds strip_sort_kernel's LDS window
     // training only
     uint32_t *tile_nproc;          // [T] Gaussians processed by the forward (multiple of the chunk)
     uint32_t *bucket_offsets;      // [T+1] exclusive scan of ceil(nproc/64)
@@ -203,6 +204,7 @@ static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pair
         ws.strip_table = (uint64_t *)take(sizeof(uint64_t) * 2 * GS_BIN_SLICES * ns);
         ws.strip_tot = (uint64_t *)take(sizeof(uint64_t) * ns);
         ws.strip_base = (uint64_t *)take(sizeof(uint64_t) * ns);
+        ws.big_tiles = (uint32_t *)take(sizeof(uint32_t) * (sp.ok ? (size_t)G.n_tiles : 1));
     }
     ws.max_buckets = gs_max_buckets(max_pairs, G.n_tiles);
     if (training) {

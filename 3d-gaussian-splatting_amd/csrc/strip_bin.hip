@@ -315,6 +315,7 @@ __global__ void __launch_bounds__(STRIP_THREADS) strip_scatter_kernel(
             counters[GS_CNT_OVERFLOW] = overflow ? (M > R ? M : R) : 0;
             counters[GS_CNT_VISIBLE] = V;
             counters[GS_CNT_ENTRIES] = overflow ? 0 : E;
+            counters[GS_CNT_BIG] = 0;  // strip_sort_kernel queues the tiles whose list exceeds its LDS window
         }
     }
     if (overflow) return;  // uniform

@@ -633,7 +633,8 @@ __global__ void __launch_bounds__(256, STRIP_SORT_WPE) strip_sort_kernel(
     const uint64_t *__restrict__ entries, const uint64_t *__restrict__ strip_base,
     const uint64_t *__restrict__ strip_tot, const unsigned long long *__restrict__ counters,
     uint64_t *__restrict__ keys, uint32_t *__restrict__ ids, uint64_t *__restrict__ scratch,
-    int32_t *__restrict__ ranges, gs_strip_geom SG, const float4 *__restrict__ rec_geom, GsDistCull D) {
+    int32_t *__restrict__ ranges, gs_strip_geom SG, const float4 *__restrict__ rec_geom, GsDistCull D,
+    uint32_t *__restrict__ big_queue, unsigned long long *__restrict__ big_count) {
     constexpr uint32_t W = GS_STRIP_W, WAVE_MAX = 512, ID_MASK = (1u << GS_STRIP_ID_BITS) - 1;
     static_assert(GS_STRIP_W == 8 || GS_STRIP_W == 4, "a workgroup owns four tiles: a strip or half a strip");
     __shared__ uint64_t s_a[CAP];
@@ -889,6 +890,11 @@ __global__ void __launch_bounds__(256, STRIP_SORT_WPE) strip_sort_kernel(
         __syncthreads();
         sort_store_by_workgroup(s_a, n, start4[q], tile0 + q);
     }
+    if (any_big && big_queue) {  // dense frame: big_list_sort_kernel sorts the queued lists, one workgroup per list
+        if (threadIdx.x < 4 && s_n[threadIdx.x] > (uint32_t)CAP)
+            big_queue[atomicAdd(big_count, 1ull)] = s_tile[threadIdx.x];
+        return;
+    }
     if (any_big) {  // lists in global memory: the per-tile sort of the table variant (in place in `scratch`)
         __syncthreads();
         tile_sort_body<CAP, SRC_PACKED>(
@@ -899,6 +905,177 @@ __global__ void __launch_bounds__(256, STRIP_SORT_WPE) strip_sort_kernel(
                 n = s_n[q] > (uint32_t)CAP ? s_n[q] : 0;
             },
             GatherSrc{}, s_a, s_scan, nullptr);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Lists beyond strip_sort_kernel's LDS window (dense scenes: 10 M Gaussians at 1080p are ~3,500 pairs per tile), one
+// workgroup per queued tile.  The list sits unsorted in `scratch` at its final range.  One counting pass over 1024
+// bins that are linear in the depth bits scatters the keys into bin order -- as two 4-byte halves in the list's own
+// slots of the two id arrays (the sorted ids' final home and the idle second id buffer: no extra memory) --, then
+// consecutive bins are grouped into sub-lists of up to CAP keys, contiguous in the final order, and each sub-list is
+// loaded into LDS, sorted by the distribution sort and stored.  A single bin beyond CAP (a depth cluster of
+// thousands) takes the chunked bitonic sort in place.  Only launched when the frame's capacity allows an average
+// list above CAP / 2 (gs_stage_strip_sort); otherwise strip_sort_kernel sorts a rare long list itself.
+template <int CAP>
+__global__ void __launch_bounds__(256) big_list_sort_kernel(const uint32_t *__restrict__ queue,
+                                                           const unsigned long long *__restrict__ counters,
+                                                           const int32_t *__restrict__ ranges,
+                                                           uint64_t *__restrict__ keys, uint32_t *__restrict__ ids,
+                                                           uint64_t *__restrict__ scratch,
+                                                           uint32_t *__restrict__ tmp_depth) {
+    constexpr uint32_t NBIN = 1024;
+    static_assert(CAP == 2048, "sub-lists are loaded eight keys per thread");
+    __shared__ uint64_t s_a[CAP];
+    __shared__ uint32_t s_scan[4];
+    __shared__ uint32_t s_bcnt[256 * 8 + 4], s_wl[1 + 2 * 128], s_red[16];
+    __shared__ uint32_t s_bin[NBIN + 1];
+    uint32_t *s_cursor = reinterpret_cast<uint32_t *>(s_a);
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t nbig = (uint32_t)counters[GS_CNT_BIG];
+    auto block_sync = [] { __syncthreads(); };
+    for (uint32_t w = blockIdx.x; w < nbig; w += gridDim.x) {
+        const uint32_t tile = queue[w];
+        const uint32_t start = (uint32_t)ranges[2 * tile], n = (uint32_t)ranges[2 * tile + 1] - start;
+        uint64_t *a = scratch + start;
+        auto st = [&](uint32_t base, uint32_t i, uint64_t v) {
+            ids[base + i] = (uint32_t)v;
+            if (keys) keys[base + i] = ((uint64_t)tile << 32) | (v >> 32);
+        };
+        __syncthreads();  // LDS of the previous list
+        // every pass over the list keeps eight loads per thread in flight (a plain strided loop exposes one memory
+        // round trip per 256 keys: 136 us per 3,500-key list)
+        auto for_each_key = [&](auto fn) {
+            for (uint32_t i0 = 0; i0 < n; i0 += 2048) {
+                uint64_t kk[8];
+#pragma unroll
+                for (uint32_t j = 0; j < 8; ++j) {
+                    const uint32_t i = i0 + j * 256 + threadIdx.x;
+                    kk[j] = i < n ? a[i] : KEY_INF;
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < 8; ++j)
+                    if (i0 + j * 256 + threadIdx.x < n) fn(kk[j]);
+            }
+        };
+        // ---- range of the depth bits
+        uint32_t dmin = 0xffffffffu, dmax = 0;
+        for_each_key([&](uint64_t key) {
+            const uint32_t d = (uint32_t)(key >> 32);
+            dmin = d < dmin ? d : dmin;
+            dmax = d > dmax ? d : dmax;
+        });
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t x = __shfl_xor(dmin, o, 64), y = __shfl_xor(dmax, o, 64);
+            dmin = x < dmin ? x : dmin;
+            dmax = y > dmax ? y : dmax;
+        }
+        if (lane == 0) {
+            s_red[wave] = dmin;
+            s_red[4 + wave] = dmax;
+        }
+        for (uint32_t c = threadIdx.x; c <= NBIN; c += 256) s_bin[c] = 0;
+        __syncthreads();
+#pragma unroll
+        for (uint32_t x = 0; x < 4; ++x) {
+            dmin = s_red[x] < dmin ? s_red[x] : dmin;
+            dmax = s_red[4 + x] > dmax ? s_red[4 + x] : dmax;
+        }
+        const float scale = (float)NBIN / ((float)(dmax - dmin) + 1.0f);
+        auto bin_of = [&](uint64_t key) {
+            const uint32_t b = (uint32_t)((float)((uint32_t)(key >> 32) - dmin) * scale);
+            return b < NBIN - 1 ? b : NBIN - 1;
+        };
+        for_each_key([&](uint64_t key) { atomicAdd(&s_bin[bin_of(key)], 1u); });
+        __syncthreads();
+        {  // exclusive scan of the 1024 counters: thread t owns counters [4 t, 4 t + 4)
+            uint32_t c[4], sum = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                const uint32_t x = s_bin[4 * threadIdx.x + j];
+                c[j] = sum;
+                sum += x;
+            }
+            const uint32_t incl = gs_wave_incl_scan_u32(sum);
+            if (lane == 63) s_red[8 + wave] = incl;
+            __syncthreads();
+            uint32_t off = incl - sum;
+#pragma unroll
+            for (uint32_t x = 0; x < 4; ++x) off += x < wave ? s_red[8 + x] : 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) s_bin[4 * threadIdx.x + j] = s_cursor[4 * threadIdx.x + j] = off + c[j];
+            if (threadIdx.x == 0) s_bin[NBIN] = n;
+        }
+        __syncthreads();
+        for_each_key([&](uint64_t key) {  // keys into bin order, as halves
+            const uint32_t pos = atomicAdd(&s_cursor[bin_of(key)], 1u);
+            tmp_depth[start + pos] = (uint32_t)(key >> 32);
+            ids[start + pos] = (uint32_t)key;
+        });
+        __syncthreads();
+        // ---- groups of consecutive bins: group g = the bins whose first key has a rank in [g CAP/2, (g + 1) CAP/2), i.e.
+        // at most CAP/2 + (one bin) keys; its bounds come from two binary searches of the bin table (a greedy walk over
+        // the 1024 bins is a chain of 1024 dependent LDS reads: 40 us per list)
+        auto first_bin_at = [&](uint32_t rank) {  // first bin whose start is >= rank (uniform)
+            uint32_t lo = 0, hi = NBIN;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_bin[mid] < rank) lo = mid + 1; else hi = mid;
+            }
+            return lo;
+        };
+        const uint32_t G = (uint32_t)CAP / 2, ngroup = (n + G - 1) / G;
+        for (uint32_t g = 0; g < ngroup; ++g) {
+            const uint32_t b0 = first_bin_at(g * G), b1 = first_bin_at((g + 1) * G);
+            const uint32_t gs0 = s_bin[b0], m = s_bin[b1] - gs0;
+            if (m == 0) continue;
+            if (m <= (uint32_t)CAP) {
+                {
+                    uint32_t hd[8], hi[8];  // CAP = 8 x 256: all sixteen loads in flight
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; ++j) {
+                        const uint32_t i = j * 256 + threadIdx.x;
+                        hd[j] = i < m ? tmp_depth[start + gs0 + i] : 0;
+                        hi[j] = i < m ? ids[start + gs0 + i] : 0;
+                    }
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; ++j) {
+                        const uint32_t i = j * 256 + threadIdx.x;
+                        if (i < m) s_a[i] = ((uint64_t)hd[j] << 32) | hi[j];
+                    }
+                }
+                __syncthreads();
+                const uint32_t base = start + gs0;
+                if (m <= 128) {
+                    if (wave == 0) {
+                        const uint32_t f0 = lane, f1 = lane + 64;
+                        uint64_t a0 = f0 < m ? s_a[f0] : KEY_INF, a1 = f1 < m ? s_a[f1] : KEY_INF;
+                        sort_window(a0, a1, lane, m);
+                        if (f0 < m) st(base, f0, a0);
+                        if (f1 < m) st(base, f1, a1);
+                    }
+                } else {
+                    bucket_sort_store(s_a, m, s_bcnt, s_wl, s_red, threadIdx.x, 256u, block_sync,
+                                      [&](uint32_t i, uint64_t v) { st(base, i, v); });
+                }
+                __syncthreads();
+            } else {  // one bin beyond the window: the chunked bitonic sort, in place in `scratch`
+                for (uint32_t i = threadIdx.x; i < m; i += 256)
+                    a[gs0 + i] = ((uint64_t)tmp_depth[start + gs0 + i] << 32) | ids[start + gs0 + i];
+                __syncthreads();
+                tile_sort_body<CAP, SRC_PACKED>(
+                    keys, ids, scratch,
+                    [&](uint32_t qq, uint32_t &t_, uint32_t &s_, uint32_t &n_) {
+                        t_ = tile;
+                        s_ = start + gs0;
+                        n_ = qq == 0 ? m : 0;
+                    },
+                    GatherSrc{}, s_a, s_scan, nullptr);
+                __syncthreads();
+            }
+        }
     }
 }
 
@@ -947,14 +1124,23 @@ int gs_stage_strip_sort(const gs_frame *f, const gs_frame_ws &ws, const uint64_t
     const gs_strip_plan plan = gs_strip_plan_for(f->N, G.ntx, G.nty);
     GsDistCull D = {(float)(G.padW / 2), (float)(G.padH / 2), f->focal_x, f->focal_y, f->thresh};
     const unsigned grid = GS_STRIP_W == 8 ? (unsigned)gs_div_up(plan.geom.NS, 8) * 16 : plan.geom.NS;
+    // dense frame (the capacity allows an average list above half the LDS window): lists beyond the window are queued
+    // for big_list_sort_kernel, one workgroup each; otherwise strip_sort_kernel sorts a rare long list itself and the
+    // frame saves the launch
+    const bool dense = f->max_pairs / G.n_tiles > STRIP_SORT_CAP_ / 2;
+    uint32_t *queue = dense ? ws.big_tiles : nullptr;
     if (f->tile_culling_method == 0)
         hipLaunchKernelGGL((strip_sort_kernel<STRIP_SORT_CAP_, true>), dim3(grid), dim3(256), 0, stream, entries,
                            ws.strip_base, ws.strip_tot, ws.counters, keys_out, ids_out, scratch, ws.tile_ranges,
-                           plan.geom, ws.rec_geom, D);
+                           plan.geom, ws.rec_geom, D, queue, ws.counters + GS_CNT_BIG);
     else
         hipLaunchKernelGGL((strip_sort_kernel<STRIP_SORT_CAP_, false>), dim3(grid), dim3(256), 0, stream, entries,
                            ws.strip_base, ws.strip_tot, ws.counters, keys_out, ids_out, scratch, ws.tile_ranges,
-                           plan.geom, ws.rec_geom, D);
+                           plan.geom, ws.rec_geom, D, queue, ws.counters + GS_CNT_BIG);
+    GS_CHECK_LAUNCH();
+    if (dense)
+        hipLaunchKernelGGL((big_list_sort_kernel<STRIP_SORT_CAP_>), dim3((unsigned)G.n_tiles), dim3(256), 0, stream,
+                           ws.big_tiles, ws.counters, ws.tile_ranges, keys_out, ids_out, scratch, ws.vals_b);
     GS_CHECK_LAUNCH();
     return 0;
 }

@@ -94,4 +94,5 @@ CONFIGS = {
     "cfg3": (506_627, 1920, 1080, False),
     "cfg4": (2_400_000, 1920, 1080, True),
     "cfg5": (2_400_000, 1920, 1080, False),
+    "cfg6": (10_000_000, 1920, 1080, False),  # dense-scene stress (not a BASELINE config): ~3,500 pairs per tile
 }
