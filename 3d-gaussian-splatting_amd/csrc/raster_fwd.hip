@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include <atomic>
+#include <type_traits>
 
 #include "raster_common.h"
 
@@ -188,6 +189,11 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
     for (uint32_t base = 0; base < n && !done; base += CH, ++k) {
         const int buf = k & 1;  // two-deep ring: the wave is in program order, so writing buffer k&1 here
                                 // cannot overtake its own reads of two chunks ago
+        // Can a Gaussian of this chunk yield a non-finite alpha (or colour) for some pixel?  Not if its record is
+        // finite and its conic positive semi-definite and of ordinary size: then q >= -(rounding of a few hundred) and
+        // alpha = 2^-(q + nlop) stays finite (|dx|, |dy| < 4: visible Gaussians lie inside the guard band).  Only chunks
+        // with a Gaussian that fails the test need the DX9 multiply below (wave-uniform: one ballot per 64 Gaussians).
+        bool suspicious = false;
         if (have) {
             float A, B, C;
             if (FRAME) {  // S1 stored the conic in the Gaussian's record (same line as geom / colour)
@@ -196,6 +202,12 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
                 C = cq.z;
             } else {
                 raster_conic(g, A, B, C);
+            }
+            {
+                const float chk = ((g.x + g.y) + (A + B + C)) + ((r0 + r1 + r2) + g.opa);  // NaN / inf propagate
+                suspicious = !(fabsf(chk) < 3.0e38f) || !(A >= 0.f && A < 1.0e8f) || !(C >= 0.f && C < 1.0e8f) ||
+                             !(4.f * A * C >= B * B) ||
+                             !FRAME || CDIM != 3;
             }
             float opa = g.opa;
             if (SIG)  // gaussian.cu:918: (1.0/2*3.1415926536) * rsqrtf(det + 1e-7), folded into opacity
@@ -247,6 +259,9 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
         if (CKPT && base > 0) write_ckpt(base);
         // groups of GROUP Gaussians: a wave-uniform liveness test every LIVE_EVERY Gaussians, per-pixel masking inside
         // (exactly the reference's per-pixel `accum < 0.0001` test, gaussian.cu:906)
+        const bool chunk_legacy = __ballot(suspicious) != 0ull;
+        auto composite_chunk = [&](auto legacy_tag) {
+        constexpr bool LEGACY = decltype(legacy_tag)::value;
 #pragma unroll 1
         for (uint32_t i = 0; i < cnt; i += GROUP) {
             if ((i & (LIVE_EVERY - 1)) == 0 && !any_live()) {
@@ -291,11 +306,11 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
                     // w = alpha T with v_mul_legacy_f32 (0 x anything = 0): a finished pixel (T == 0) stays
                     // untouched whatever alpha is -- NaN, infinite --, like the reference, which `break`s before it
                     // evaluates the Gaussian (gaussian.cu:906); a live pixel sees the NaN, as there
-                    #if GS_FWD_LEGACY_MUL
-                    const f2 w = {mul_legacy(al.x, T[h].x), mul_legacy(al.y, T[h].y)};
-#else
-                    const f2 w = al * T[h];
-#endif
+                    f2 w;
+                    if constexpr (LEGACY && GS_FWD_LEGACY_MUL)
+                        w = f2{mul_legacy(al.x, T[h].x), mul_legacy(al.y, T[h].y)};
+                    else
+                        w = al * T[h];
                     if constexpr (CDIM == 3) {
                         cr[h] = pk_fma(splat(u == 0 ? R4.x : u == 1 ? R4.y : u == 2 ? R4.z : R4.w), w, cr[h]);
                         cg[h] = pk_fma(splat(u == 0 ? G4.x : u == 1 ? G4.y : u == 2 ? G4.z : G4.w), w, cg[h]);
@@ -323,6 +338,11 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
             }
             }
         }
+        };
+        if (chunk_legacy)
+            composite_chunk(std::true_type{});
+        else
+            composite_chunk(std::false_type{});
         // a chunk whose checkpoint was written counts as processed even if the wave stopped inside it:
         // the backward pass masks finished pixels by their transmittance
         nproc = base + cnt;
