@@ -42,10 +42,10 @@ def mode_kwargs(sort_mode):
     return dict(sort_mode=sort_mode)
 
 
-def check_forward(gpu, scene, cam, training=False, sort_mode=2):
+def check_forward(gpu, scene, cam, training=False, sort_mode=2, emit_sorted_keys=False, img_atol=IMG_ATOL):
     of = OracleFrame(scene, cam)
     r = FrameRenderer(gpu, max_pairs=max(len(of.ids) + 17, 64), training=training, auto_grow=False,
-                      **mode_kwargs(sort_mode))
+                      emit_sorted_keys=emit_sorted_keys, **mode_kwargs(sort_mode))
     params = to_torch(scene, gpu)
     image, padded = r.forward(*params, cam)
     st = r.stats()
@@ -68,7 +68,7 @@ def check_forward(gpu, scene, cam, training=False, sort_mode=2):
     assert np.all(geom[~vis] == 0)
     assert np.array_equal(v["rec_cov"].cpu().numpy()[vis].view(np.uint32), of.cov.reshape(-1, 4)[vis].view(np.uint32))
     err = np.abs(image.cpu().numpy() - of.image).max()
-    assert err < IMG_ATOL, err
+    assert err < img_atol, err
     if padded is not None:
         assert np.abs(padded.cpu().numpy() - of.padded).max() < IMG_ATOL
     return of, r, params
@@ -89,6 +89,34 @@ def test_frame_forward_giant_bucket_sorted_in_chunks(gpu, sort_mode):
     scene, cam = case(40_000, 32, 32, seed=8)
     of, _, _ = check_forward(gpu, scene, cam, sort_mode=sort_mode)
     assert np.diff(of.accum).max() > 4096
+
+
+@pytest.mark.parametrize("sort_mode", [2, "2t", "2s"])
+@pytest.mark.parametrize("n,W,H", [(10_000, 256, 256), (40_000, 32, 32)])
+def test_frame_forward_emitted_sorted_keys(gpu, n, W, H, sort_mode):
+    """GS_FRAME_EMIT_SORTED_KEYS: the per-tile sort also writes the sorted (tile << 32 | depth bits) keys (the default
+    frame only writes the ids; debug_views() then rebuilds the keys from the records).  In the strip variant the key
+    buffer doubles as the scratch of lists beyond the LDS window (40,000 Gaussians on four tiles: the dense-frame
+    queue + big_list_sort_kernel), so the written keys are checked on both paths."""
+    check_forward(gpu, *case(n, W, H, seed=8), sort_mode=sort_mode, emit_sorted_keys=True)
+
+
+def test_frame_forward_dense_frame_with_depth_clusters(gpu):
+    """Dense frame (capacity above 1,024 pairs per tile): lists beyond the LDS window are queued for
+    big_list_sort_kernel.  40,000 Gaussians on four tiles, on 10 sites of 4,000 exact copies each: every depth bin of a
+    list holds thousands of equal keys -- more than the window -- and takes the chunked bitonic sort inside that kernel;
+    300 sites: bins of ~130 copies go through the distribution sort's large-bucket path."""
+    for n_sites in (10, 300):
+        scene, cam = case(40_000, 32, 32, seed=29)
+        site = np.arange(scene.n) % n_sites
+        scene.pos[:] = scene.pos[site]
+        scene.scale[:] = scene.scale[site]
+        scene.quat[:] = scene.quat[site]
+        scene.opa[:] = -9.0
+        # 10,000 coincident layers per pixel: the image's own fp32 conditioning (a transmittance chain of 10,000 steps)
+        # is not what this test is about -- the (tile, depth, id) list is compared exactly, the image to 1e-3
+        of, _, _ = check_forward(gpu, scene, cam, sort_mode=2, img_atol=1e-3)
+        assert np.diff(of.accum).max() > 4096
 
 
 @pytest.mark.parametrize("n_sites,jitter", [(40, 0.0), (300, 0.0), (40, 1e-6), (3000, 0.0)])
