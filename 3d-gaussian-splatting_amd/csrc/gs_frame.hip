@@ -1,9 +1,11 @@
 // gs_frame.hip -- host orchestration of the fused frame path + error plumbing.
 //
 // gs_frame_forward issues, on ONE stream and with NO host synchronisation:
-//   sort_mode 2 (default): S1 project+count -> slice sort (every workgroup counting-sorts its slice of the pairs
-//       by tile in LDS) -> tile totals + ranges -> per-tile sort (gathers from the slices) -> raster forward: five
-//       launches, no memset, no scattered global store;
+//   sort_mode 2 (default), strip variant: S1 project -> strip count -> column scan -> strip scatter (8-byte entries per
+//       (Gaussian, strip of 8 tiles), counting-sorted by strip through LDS) -> strip sort (a workgroup per half strip
+//       expands the entries into its four tile lists inside LDS and sorts them; [-> big-list sort in dense frames])
+//       -> raster forward: six launches, no memset, no scattered global store.  Table / slice-sorted variants of
+//       round 1 behind GS_FRAME_TABLE_BIN / GS_FRAME_SLICE_SORT (tile_bin.hip);
 //   sort_modes 0 / 1: memset(counters, ranges) -> S1 -> scan block sums -> emit keys -> LSD radix passes
 //       (3 launches per 8 bits of the key: all of it, or the tile bits only) -> tile ranges
 //       [-> per-tile sort] -> raster forward.

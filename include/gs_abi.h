@@ -5,7 +5,7 @@
  * entry points in section A are exactly what the reference's pybind11 module `gaussian`
  * (src/bindings.cpp:21-50) binds, with torch::Tensor arguments replaced by raw device
  * pointers + explicit sizes and an explicit HIP stream.  Section B is the fused,
- * MI355X-native frame path (cull+project+count -> scan+emit -> radix sort -> ranges ->
+ * MI355X-native frame path (cull+project -> binning by tile -> per-tile depth sort ->
  * raster fwd/bwd -> project bwd) that the reference spreads over 4 native launches and ~25
  * torch kernels per frame (splatter.py:513-641).
  *
@@ -195,10 +195,13 @@ typedef struct gs_frame {
                                  0 = LSD radix sort of 64-bit (tile<<32|depth) keys (gs_sort_pairs)
                                  1 = hybrid: stable LSD radix passes on the tile bits only (2 passes at
                                      1080p), then every tile's bucket sorted on (depth, id) in LDS
-                                 2 = counting sort by tile with one LDS counter per tile (<= 32768 tiles,
-                                     larger grids take mode 1), then the same per-tile LDS sort.  On
-                                     capacity overflow the frame is left empty (modes 0/1 keep the first
-                                     max_pairs pairs); all modes report the true count in the stats. */
+                                 2 = counting sort in LDS, no radix pass (default).  Strip variant: 8-byte
+                                     entries per (Gaussian, strip of 8 tiles) counting-sorted by strip, expanded
+                                     into the tile lists and depth-sorted inside LDS (up to 2^26 Gaussians and
+                                     8192 strips; beyond that, or with GS_FRAME_TABLE_BIN: one LDS counter per
+                                     tile, <= 32768 tiles, larger grids take mode 1).  On capacity overflow the
+                                     frame is left empty (modes 0/1 keep the first max_pairs pairs); all modes
+                                     report the true count in the stats. */
     int32_t tile_culling_method; /* which tiles a Gaussian is listed in (splatter.py:571-578, --tile_culling_method;
                                  the reference's own numbering, `_method_config` of splatter.py:571):
                                  2 = "prob2", the trainer's default (gaussian.cu:197-250: tile rectangle from the 2-D

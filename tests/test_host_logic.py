@@ -24,7 +24,7 @@ def test_scene_generator_is_deterministic_and_matches_survey_statistics():
     of = OracleFrame(a, make_camera(256, 256))
     V, M = int(of.mask.sum()), len(of.ids)
     assert 7500 < V < 8200 and 27_000 < M < 31_000  # V ~ 7.9 k, M ~ 29 k
-    assert set(CONFIGS) == {"cfg1", "cfg2", "cfg3", "cfg4", "cfg5"}
+    assert set(CONFIGS) == {"cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "cfg6"}  # cfg6: dense-scene stress, not a BASELINE config
 
 
 def test_tile_grid_padding_and_crop():
