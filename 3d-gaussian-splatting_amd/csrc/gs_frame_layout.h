@@ -2,7 +2,7 @@
 #pragma once
 #include "gs_common.h"
 
-enum { GS_CNT_VISIBLE = 0, GS_CNT_PAIRS = 1, GS_CNT_OVERFLOW = 2, GS_CNT_BUCKETS = 3, GS_CNT_TICKET = 4, GS_CNT_ENTRIES = 5, GS_CNT_BIG = 6, GS_CNT_N = 8 };
+enum { GS_CNT_VISIBLE = 0, GS_CNT_PAIRS = 1, GS_CNT_OVERFLOW = 2, GS_CNT_BUCKETS = 3, GS_CNT_TICKET = 4, GS_CNT_ENTRIES = 5, GS_CNT_BIG = 6, GS_CNT_SEGS = 7, GS_CNT_N = 8 };
 
 #define GS_BUCKET 64          // Gaussians per backward bucket (= wavefront size)
 #define GS_SORT_TILE 2048     // keys per radix-sort workgroup (256 threads x 8)
@@ -51,6 +51,14 @@ static inline gs_bin_plan gs_bin_plan_for(int64_t N, int64_t max_pairs, int n_ti
 #endif
 #define GS_STRIP_ID_BITS 26   // an entry keeps the Gaussian index in 26 bits: scenes beyond 2^26 take the table variant
 #define GS_STRIP_MAX 8192     // strips per frame the LDS histograms are sized for
+// Dense frames (capacity above GS_DENSE_AVG pairs per tile on average) launch the extra kernels for long lists: the
+// big-list sort (tile_sort.hip) and the segmented compositing of tiles that are still alive after GS_LONG_MIN
+// Gaussians (raster_fwd.hip); other frames save those launches.
+#define GS_DENSE_AVG 1024
+#define GS_LONG_MIN 4096      // Gaussians a tile's own wave composites before the rest of its list is cut into segments
+#define GS_SEG_LEN 2048       // Gaussians per segment
+static inline bool gs_frame_is_dense(int64_t max_pairs, int n_tiles) { return max_pairs / (n_tiles > 0 ? n_tiles : 1) > GS_DENSE_AVG; }
+static inline int64_t gs_seg_items_cap(int64_t max_pairs, int n_tiles) { return max_pairs / GS_SEG_LEN + n_tiles; }
 #define GS_STRIP_SORT_CAP 2048  // pairs strip_sort_kernel's LDS window holds (a half strip's four lists, or one list at a time)
 struct gs_strip_geom {
     uint32_t ntx, nty, nsx, NS;  // tile grid, strips per tile row, strips per frame
@@ -140,6 +148,14 @@ struct gs_frame_ws {
     uint64_t *strip_tot;           // [NS] totals per strip
     uint64_t *strip_base;          // [NS] (first entry << 32 | first pair) of every strip
     uint32_t *big_tiles;           // [T] queue of the tiles whose list exceeds strip_sort_kernel's LDS window
+    // dense frames only (else NULL): segmented compositing of long tile lists (raster_fwd.hip)
+    float4 *cont_state;            // [T][256] (T, C) of a tile's pixels after its first GS_LONG_MIN Gaussians
+    uint32_t *cont_flag;           // [T] 1: the tile was still alive there and continues in segments
+    uint32_t *seg_item_base;       // [T + 1] first segment item of every tile
+    uint2 *seg_items;              // [items_cap] (tile, segment index)
+    float *seg_P;                  // [items_cap][256] transmittance product of a segment
+    float4 *seg_C;                 // [items_cap][256] (-, C) composited by a segment from its incoming transmittance
+    uint32_t *seg_nproc;           // [items_cap] Gaussians a segment composited before all pixels had stopped
     // training only
     uint32_t *tile_nproc;          // [T] Gaussians processed by the forward (multiple of the chunk)
     uint32_t *bucket_offsets;      // [T+1] exclusive scan of ceil(nproc/64)
@@ -205,6 +221,24 @@ static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pair
         ws.strip_tot = (uint64_t *)take(sizeof(uint64_t) * ns);
         ws.strip_base = (uint64_t *)take(sizeof(uint64_t) * ns);
         ws.big_tiles = (uint32_t *)take(sizeof(uint32_t) * (sp.ok ? (size_t)G.n_tiles : 1));
+    }
+    if (gs_frame_is_dense(max_pairs, G.n_tiles)) {
+        const size_t cap = (size_t)gs_seg_items_cap(max_pairs, G.n_tiles);
+        ws.cont_state = (float4 *)take(sizeof(float4) * 256 * (size_t)G.n_tiles);
+        ws.cont_flag = (uint32_t *)take(sizeof(uint32_t) * G.n_tiles);
+        ws.seg_item_base = (uint32_t *)take(sizeof(uint32_t) * ((size_t)G.n_tiles + 1));
+        ws.seg_items = (uint2 *)take(sizeof(uint2) * cap);
+        ws.seg_P = (float *)take(sizeof(float) * 256 * cap);
+        ws.seg_C = (float4 *)take(sizeof(float4) * 256 * cap);
+        ws.seg_nproc = (uint32_t *)take(sizeof(uint32_t) * cap);
+    } else {
+        ws.cont_state = nullptr;
+        ws.cont_flag = nullptr;
+        ws.seg_item_base = nullptr;
+        ws.seg_items = nullptr;
+        ws.seg_P = nullptr;
+        ws.seg_C = nullptr;
+        ws.seg_nproc = nullptr;
     }
     ws.max_buckets = gs_max_buckets(max_pairs, G.n_tiles);
     if (training) {

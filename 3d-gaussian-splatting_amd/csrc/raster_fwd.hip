@@ -91,7 +91,9 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
                                                                     float *__restrict__ out_image,
                                                                     float4 *__restrict__ ckpt,
                                                                     uint32_t *__restrict__ tile_nproc,
-                                                                    uint32_t n_tiles) {
+                                                                    uint32_t n_tiles,
+                                                                    float4 *__restrict__ cont_state,
+                                                                    uint32_t *__restrict__ cont_flag) {
     using SM = FwdSmem<CDIM>;
     constexpr int CH = SM::CH;
     constexpr uint32_t GROUP = 4;  // Gaussians per ds_read_b128 of a field
@@ -186,7 +188,23 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
     };
 
     bool done = false, staged_next = false;  // staged_next: the register stage holds chunk 0 of the NEXT tile
+    bool continues = false;  // dense frames: the rest of a long list goes to the segment kernels (below)
     for (uint32_t base = 0; base < n && !done; base += CH, ++k) {
+        if (FRAME && cont_flag && base == (uint32_t)GS_LONG_MIN) {  // uniform
+            if (any_live()) {
+                // still alive after GS_LONG_MIN Gaussians (low-opacity pile-ups: a list of 100,000 would keep this
+                // ONE wave busy for milliseconds): the pixels' state is saved and the rest of the list is composited in
+                // segments by many waves (raster_segment_kernel); lists that saturate earlier never get here
+                float4 *c = cont_state + (size_t)tile * 256;
+#pragma unroll
+                for (int h = 0; h < NPP; ++h) {
+                    c[128 * h + lane] = make_float4(T[h].x, cr[h].x, cg[h].x, cb[h].x);
+                    c[128 * h + 64 + lane] = make_float4(T[h].y, cr[h].y, cg[h].y, cb[h].y);
+                }
+                continues = true;
+            }
+            if (continues) break;
+        }
         const int buf = k & 1;  // two-deep ring: the wave is in program order, so writing buffer k&1 here
                                 // cannot overtake its own reads of two chunks ago
         // Can a Gaussian of this chunk yield a non-finite alpha (or colour) for some pixel?  Not if its record is
@@ -349,6 +367,7 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
     }
     if (!staged_next) fetch(nstart, nn, 0);  // empty tile, or the wave stopped before its last chunk
     if (tile_nproc && lane == 0) tile_nproc[tile] = nproc;
+    if (FRAME && cont_flag && lane == 0) cont_flag[tile] = continues ? 1u : 0u;
 
 #pragma unroll
     for (int h = 0; h < NPP; ++h)
@@ -382,6 +401,298 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
     }  // tile loop
 }
 
+// =================================================================================================================
+// Segmented compositing of long tile lists (dense frames only).  A tile whose pixels are still alive after
+// GS_LONG_MIN Gaussians leaves its state in cont_state and raises cont_flag (raster_forward_kernel above); the rest of
+// its list, [GS_LONG_MIN, n), is cut into segments of GS_SEG_LEN Gaussians, one wave each:
+//   seg_scan_kernel            items (tile, segment) of the flagged tiles, first item of every tile;
+//   raster_segment_kernel<1>   P = the segment's transmittance product prod(1 - alpha) per pixel (no colour, no stop);
+//   raster_segment_kernel<2>   T_in = T(GS_LONG_MIN) x the products of the tile's earlier segments; pixels with
+//                              T_in <= 1e-4 are finished (the transmittance only falls, so the reference's stop lies in
+//                              an earlier segment exactly then); the segment is composited from T_in with the same
+//                              per-pixel stop as everywhere, colours from zero; checkpoints with the LOCAL colour;
+//   seg_combine_kernel         per flagged tile: colour = saved colour + the segments' colours in list order, final
+//                              pixel written like the main kernel's; every checkpoint of segment s gets the colour in
+//                              front of s added; tile_nproc = GS_LONG_MIN + the segments' processed counts.
+// Compositing is associative in (C, T) -- segments combine as C1 + T1 C2, T1 T2 -- so the only difference from the serial
+// walk is the rounding of T_in (a product of products instead of a chain): a few ulp.  A list of 100,000 low-opacity
+// Gaussians costs two passes over 2048 Gaussians per wave instead of one pass over 100,000 by ONE wave.
+__global__ void __launch_bounds__(1024) seg_scan_kernel(const uint32_t *__restrict__ cont_flag,
+                                                        const int32_t *__restrict__ ranges, uint32_t n_tiles,
+                                                        uint32_t items_cap, uint32_t *__restrict__ item_base,
+                                                        uint2 *__restrict__ items,
+                                                        unsigned long long *__restrict__ n_items) {
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t base = 0; base < n_tiles; base += 1024) {
+        const uint32_t t = base + threadIdx.x;
+        uint32_t ns = 0;
+        if (t < n_tiles && cont_flag[t]) {
+            const uint32_t n = (uint32_t)(ranges[2 * t + 1] - ranges[2 * t]);
+            ns = (n - GS_LONG_MIN + GS_SEG_LEN - 1) / GS_SEG_LEN;
+        }
+        const uint32_t incl = gs_wave_incl_scan_u32(ns);
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t off = s_carry, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            off += w < wave ? s_wave[w] : 0;
+            tot += s_wave[w];
+        }
+        const uint32_t first = off + incl - ns;
+        if (t < n_tiles) {
+            item_base[t] = first;
+            for (uint32_t q = 0; q < ns && first + q < items_cap; ++q) items[first + q] = make_uint2(t, q);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        item_base[n_tiles] = s_carry;
+        *n_items = s_carry < items_cap ? s_carry : items_cap;  // never more than the buffers hold (M / SEG + T bounds it)
+    }
+}
+
+template <int CDIM, bool CKPT, int PHASE>
+__global__ void __launch_bounds__(FWD_THREADS) raster_segment_kernel(
+    RasterSrc S, RasterGeom G, const int32_t *__restrict__ ranges, const uint2 *__restrict__ items,
+    const unsigned long long *__restrict__ n_items, const float4 *__restrict__ cont_state, float *__restrict__ seg_P,
+    float4 *__restrict__ seg_C, uint32_t *__restrict__ seg_nproc, float4 *__restrict__ ckpt) {
+    using SM = FwdSmem<CDIM>;
+    constexpr int CH = SM::CH;
+    constexpr int NB = CDIM > 3 ? CDIM / 3 : 1;
+    __shared__ SM sm;
+    const int lane = threadIdx.x;
+    const uint32_t item = blockIdx.x;
+    if (item >= (uint32_t)*n_items) return;
+    const uint2 it = items[item];
+    const uint32_t tile = it.x, seg = it.y;
+    const uint32_t start = (uint32_t)ranges[2 * tile], n_all = (uint32_t)ranges[2 * tile + 1] - start;
+    const uint32_t seg_begin = GS_LONG_MIN + seg * GS_SEG_LEN;
+    const uint32_t n = n_all - seg_begin < (uint32_t)GS_SEG_LEN ? n_all - seg_begin : (uint32_t)GS_SEG_LEN;
+    const uint32_t tx = tile % (uint32_t)G.ntx, ty = tile / (uint32_t)G.ntx;
+    const uint32_t id_x = tx * 16 + (lane & 15), id_y0 = ty * 16 + (lane >> 4);
+    const float px = raster_pixel_coord(id_x, G.padW, G.focal_x);
+    f2 py2[NPP], SH[NPP][NB];
+#pragma unroll
+    for (int h = 0; h < NPP; ++h) {
+        py2[h] = f2{raster_pixel_coord(id_y0 + 8 * h, G.padH, G.focal_y),
+                    raster_pixel_coord(id_y0 + 8 * h + 4, G.padH, G.focal_y)};
+        if (CDIM > 3 && PHASE == 2) {
+            float a9[NB], b9[NB];
+            raster_pixel_sh<NB>(id_x, id_y0 + 8 * h, G, a9);
+            raster_pixel_sh<NB>(id_x, id_y0 + 8 * h + 4, G, b9);
+#pragma unroll
+            for (int k9 = 0; k9 < NB; ++k9) SH[h][k9] = f2{a9[k9], b9[k9]};
+        }
+    }
+    // pixel slot of pair h, element e: 128 h + 64 e + lane (the checkpoint layout)
+    f2 T[NPP], cr[NPP], cg[NPP], cb[NPP];
+#pragma unroll
+    for (int h = 0; h < NPP; ++h) {
+        T[h] = f2{1.0f, 1.0f};
+        cr[h] = cg[h] = cb[h] = f2{0.f, 0.f};
+    }
+    if (PHASE == 2) {
+        const float4 *c0 = cont_state + (size_t)tile * 256;
+        const float *Pp = seg_P + (size_t)(item - seg) * 256;  // the tile's items are consecutive
+#pragma unroll
+        for (int h = 0; h < NPP; ++h) {
+            float t0 = c0[128 * h + lane].x, t1 = c0[128 * h + 64 + lane].x;
+            for (uint32_t q = 0; q < seg; ++q) {
+                t0 *= Pp[(size_t)q * 256 + 128 * h + lane];
+                t1 *= Pp[(size_t)q * 256 + 128 * h + 64 + lane];
+            }
+            T[h] = f2{t0 > GS_T_STOP ? t0 : 0.f, t1 > GS_T_STOP ? t1 : 0.f};
+        }
+    }
+    auto any_live = [&]() {
+        f2 sum = T[0];
+#pragma unroll
+        for (int h = 1; h < NPP; ++h) sum += T[h];
+        return __ballot(sum.x + sum.y > 0.0f) != 0ull;
+    };
+    f2 live_scale = splat(GS_LIVE_SCALE), live_bias = splat(-GS_T_STOP * GS_LIVE_SCALE);
+    asm volatile("" : "+v"(live_scale), "+v"(live_bias));
+    uint32_t nproc = 0;
+    bool done = PHASE == 2 && !any_live();
+    for (uint32_t base = 0; base < n && !done; base += CH) {
+        {  // stage the chunk (one Gaussian per lane); a single buffer, the wave is in program order
+            const bool have = base + lane < n;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (have) {
+                GaussianRec g;
+                const uint32_t gj = start + seg_begin + base + lane;
+                const uint32_t gid = raster_load<true>(S, gj, g);
+                const float4 cq = S.conic4[(size_t)gid * GS_REC_STRIDE];
+                sm.f[0][SM::X][lane] = g.x;
+                sm.f[0][SM::Y][lane] = g.y;
+                sm.f[0][SM::A][lane] = cq.x;
+                sm.f[0][SM::B][lane] = cq.y;
+                sm.f[0][SM::C][lane] = cq.z;
+                sm.f[0][SM::NLOP][lane] = -__log2f(g.opa);
+                if constexpr (CDIM == 3) {
+                    float r0, r1, r2;
+                    raster_load_rgb<true>(S, gj, gid, r0, r1, r2);
+                    if (r0 != r0 || r1 != r1 || r2 != r2) {  // see raster_forward_kernel
+                        sm.f[0][SM::NLOP][lane] = __builtin_nanf("");
+                        r0 = r1 = r2 = 0.f;
+                    }
+                    sm.f[0][SM::R][lane] = r0;
+                    sm.f[0][SM::G][lane] = r1;
+                    sm.f[0][SM::BL][lane] = r2;
+                } else if (PHASE == 2) {
+                    const float *src = raster_sh_ptr<true, CDIM>(S, gj, gid);
+#pragma unroll
+                    for (int q = 0; q < CDIM; ++q) sm.sh[0][lane][q] = src[q];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        const uint32_t cnt = (n - base) < (uint32_t)CH ? (n - base) : (uint32_t)CH;
+        if (PHASE == 2 && CKPT) {  // every chunk start of a segment is a bucket boundary of the tile's list
+            float4 *c = ckpt + raster_ckpt_slot(start, tile, (seg_begin + base) / GS_BUCKET) * 256;
+#pragma unroll
+            for (int h = 0; h < NPP; ++h) {
+                c[128 * h + lane] = make_float4(T[h].x, cr[h].x, cg[h].x, cb[h].x);
+                c[128 * h + 64 + lane] = make_float4(T[h].y, cr[h].y, cg[h].y, cb[h].y);
+            }
+        }
+#pragma unroll 1
+        for (uint32_t i = 0; i < cnt; ++i) {
+            if (PHASE == 2 && (i & 7) == 0 && !any_live()) {
+                done = true;
+                break;
+            }
+            const float gx = sm.f[0][SM::X][i], gy = sm.f[0][SM::Y][i], cA = sm.f[0][SM::A][i], cB = sm.f[0][SM::B][i];
+            const float cC = sm.f[0][SM::C][i], nlop = sm.f[0][SM::NLOP][i];
+            // the same expressions as raster_forward_kernel
+            const float dx = px - gx;
+            const float bdx = cB * dx;
+            const float f = fmaf(cA * dx, dx, nlop);
+#pragma unroll
+            for (int h = 0; h < NPP; ++h) {
+                const f2 dy = py2[h] - splat(gy);
+                const f2 q = pk_fma(pk_fma(splat(cC), dy, splat(-bdx)), dy, splat(f));
+                const f2 al = {gs_exp2(-q.x), gs_exp2(-q.y)};
+                const f2 w = {mul_legacy(al.x, T[h].x), mul_legacy(al.y, T[h].y)};
+                if (PHASE == 2) {
+                    if constexpr (CDIM == 3) {
+                        cr[h] = pk_fma(splat(sm.f[0][SM::R][i]), w, cr[h]);
+                        cg[h] = pk_fma(splat(sm.f[0][SM::G][i]), w, cg[h]);
+                        cb[h] = pk_fma(splat(sm.f[0][SM::BL][i]), w, cb[h]);
+                    } else {
+                        const float *co = sm.sh[0][i];
+                        f2 v0 = {0.f, 0.f}, v1 = {0.f, 0.f}, v2 = {0.f, 0.f};
+#pragma unroll
+                        for (int k9 = 0; k9 < NB; ++k9) {
+                            v0 = pk_fma(SH[h][k9], splat(co[k9]), v0);
+                            v1 = pk_fma(SH[h][k9], splat(co[NB + k9]), v1);
+                            v2 = pk_fma(SH[h][k9], splat(co[2 * NB + k9]), v2);
+                        }
+                        const f2 c0 = {gs_rcp(1.0f + __expf(-v0.x)), gs_rcp(1.0f + __expf(-v0.y))};
+                        const f2 c1 = {gs_rcp(1.0f + __expf(-v1.x)), gs_rcp(1.0f + __expf(-v1.y))};
+                        const f2 c2 = {gs_rcp(1.0f + __expf(-v2.x)), gs_rcp(1.0f + __expf(-v2.y))};
+                        cr[h] = pk_fma(w, c0, cr[h]);
+                        cg[h] = pk_fma(w, c1, cg[h]);
+                        cb[h] = pk_fma(w, c2, cb[h]);
+                    }
+                }
+                const f2 t = T[h] - w;  // T (1 - alpha)
+                T[h] = PHASE == 2 ? t * live_mask(t, live_scale, live_bias) : t;
+            }
+        }
+        nproc = base + cnt;
+    }
+    if (PHASE == 1) {
+        float *P = seg_P + (size_t)item * 256;
+#pragma unroll
+        for (int h = 0; h < NPP; ++h) {
+            P[128 * h + lane] = T[h].x;
+            P[128 * h + 64 + lane] = T[h].y;
+        }
+    } else {
+        float4 *C = seg_C + (size_t)item * 256;
+#pragma unroll
+        for (int h = 0; h < NPP; ++h) {
+            C[128 * h + lane] = make_float4(T[h].x, cr[h].x, cg[h].x, cb[h].x);
+            C[128 * h + 64 + lane] = make_float4(T[h].y, cr[h].y, cg[h].y, cb[h].y);
+        }
+        if (lane == 0) seg_nproc[item] = nproc;
+    }
+}
+
+// one workgroup per tile, thread p = pixel slot p of the checkpoint layout (128 h + 64 e + lane)
+template <bool CKPT>
+__global__ void __launch_bounds__(256) seg_combine_kernel(RasterGeom G, const int32_t *__restrict__ ranges,
+                                                          const uint32_t *__restrict__ cont_flag,
+                                                          const uint32_t *__restrict__ item_base,
+                                                          const float4 *__restrict__ cont_state,
+                                                          const float4 *__restrict__ seg_C,
+                                                          const uint32_t *__restrict__ seg_nproc,
+                                                          float4 *__restrict__ ckpt, uint32_t *__restrict__ tile_nproc,
+                                                          float *__restrict__ out_padded, float *__restrict__ out_image) {
+    const uint32_t tile = blockIdx.x;
+    if (!cont_flag[tile]) return;
+    const uint32_t p = threadIdx.x, lane = p & 63, k = p >> 6;  // k = 2 h + e
+    const uint32_t start = (uint32_t)ranges[2 * tile], n_all = (uint32_t)ranges[2 * tile + 1] - start;
+    const uint32_t i0 = item_base[tile], i1 = item_base[tile + 1];
+    const float4 s0 = cont_state[(size_t)tile * 256 + p];
+    float c0 = s0.y, c1 = s0.z, c2 = s0.w;
+    uint32_t nproc = GS_LONG_MIN;
+    for (uint32_t it = i0; it < i1; ++it) {
+        const uint32_t np = seg_nproc[it];  // uniform
+        if (np == 0) break;
+        if (CKPT) {
+            const uint32_t seg_begin = GS_LONG_MIN + (it - i0) * GS_SEG_LEN;
+            for (uint32_t b = 0; b * GS_BUCKET < np; ++b) {
+                float4 *c = ckpt + raster_ckpt_slot(start, tile, seg_begin / GS_BUCKET + b) * 256 + p;
+                float4 v = *c;
+                v.y += c0;
+                v.z += c1;
+                v.w += c2;
+                *c = v;
+            }
+        }
+        const float4 sc = seg_C[(size_t)it * 256 + p];
+        c0 += sc.y;
+        c1 += sc.z;
+        c2 += sc.w;
+        nproc += np;
+        // a segment that stopped inside ends the tile's processed range, whatever the (independently rounded) incoming
+        // transmittance of the next one says: the backward walks the first tile_nproc Gaussians, contiguously
+        const uint32_t seg_begin = GS_LONG_MIN + (it - i0) * GS_SEG_LEN;
+        const uint32_t seg_len = n_all - seg_begin < (uint32_t)GS_SEG_LEN ? n_all - seg_begin : (uint32_t)GS_SEG_LEN;
+        if (np < seg_len) break;
+    }
+    if (tile_nproc && p == 0) tile_nproc[tile] = nproc;
+    const uint32_t tx = tile % (uint32_t)G.ntx, ty = tile / (uint32_t)G.ntx;
+    // k = 2 h + e: row y0 + 8 h + 4 e
+    const uint32_t id_x = tx * 16 + (lane & 15), id_y2 = ty * 16 + (lane >> 4) + 8 * (k >> 1) + 4 * (k & 1);
+    if (out_padded) {
+        float *o = out_padded + ((size_t)id_y2 * G.padW + id_x) * 3;
+        o[0] = c0;
+        o[1] = c1;
+        o[2] = c2;
+    }
+    if (out_image) {
+        const int ox = (int)id_x - G.crop_left, oy = (int)id_y2 - G.crop_top;
+        if (ox >= 0 && ox < G.width && oy >= 0 && oy < G.height) {
+            float *o = out_image + ((size_t)oy * G.width + ox) * 3;
+            o[0] = c0 > 1.f ? 1.f : (c0 < 0.f ? 0.f : c0);
+            o[1] = c1 > 1.f ? 1.f : (c1 < 0.f ? 0.f : c1);
+            o[2] = c2 > 1.f ? 1.f : (c2 < 0.f ? 0.f : c2);
+        }
+    }
+}
+
 // Waves in the persistent grid: every wave gets the same number of tiles (+-1) and there are at most
 // GS_FWD_WAVES_PER_SIMD (default 8) waves per SIMD -- at 1080p that is one tile per wave; fewer, longer-lived waves
 // were slower (122-154 us against 85 us at cfg2).  The slot count is cached from the first device seen (all GPUs of
@@ -404,13 +715,16 @@ static uint32_t fwd_grid(uint32_t n_tiles) {
 
 template <int CDIM, bool FRAME, bool CKPT, bool SIG>
 void launch_fwd(const RasterSrc &S, const RasterGeom &G, const int32_t *ranges, float *out_padded, float *out_image,
-                float4 *ckpt, uint32_t *tile_nproc, int wn, hipStream_t stream) {
+                float4 *ckpt, uint32_t *tile_nproc, int wn, hipStream_t stream, float4 *cont_state = nullptr,
+                uint32_t *cont_flag = nullptr) {
     if (wn)
         hipLaunchKernelGGL((raster_forward_kernel<CDIM, FRAME, CKPT, SIG, true>), dim3(fwd_grid(G.ntx * G.nty)), dim3(FWD_THREADS), 0,
-                           stream, S, G, ranges, out_padded, out_image, ckpt, tile_nproc, (uint32_t)(G.ntx * G.nty));
+                           stream, S, G, ranges, out_padded, out_image, ckpt, tile_nproc, (uint32_t)(G.ntx * G.nty),
+                           cont_state, cont_flag);
     else
         hipLaunchKernelGGL((raster_forward_kernel<CDIM, FRAME, CKPT, SIG, false>), dim3(fwd_grid(G.ntx * G.nty)), dim3(FWD_THREADS), 0,
-                           stream, S, G, ranges, out_padded, out_image, ckpt, tile_nproc, (uint32_t)(G.ntx * G.nty));
+                           stream, S, G, ranges, out_padded, out_image, ckpt, tile_nproc, (uint32_t)(G.ntx * G.nty),
+                           cont_state, cont_flag);
 }
 
 }  // namespace
@@ -510,27 +824,62 @@ int gs_stage_raster_forward(const gs_frame *f, const gs_frame_ws &ws, const uint
         G.vdx[i] = f->vec_dx[i];
         G.vdy[i] = f->vec_dy[i];
     }
-    if (f->color_dim == 48) {
-        if (f->training)
-            launch_fwd<48, true, true, false>(S, G, ws.tile_ranges, f->image_padded, f->image, ws.ckpt, ws.tile_nproc,
-                                              0, stream);
-        else
-            launch_fwd<48, true, false, false>(S, G, ws.tile_ranges, f->image_padded, f->image, nullptr, nullptr, 0,
-                                               stream);
-    } else if (f->color_dim == 27) {
-        if (f->training)
-            launch_fwd<27, true, true, false>(S, G, ws.tile_ranges, f->image_padded, f->image, ws.ckpt, ws.tile_nproc,
-                                              0, stream);
-        else
-            launch_fwd<27, true, false, false>(S, G, ws.tile_ranges, f->image_padded, f->image, nullptr, nullptr, 0,
-                                               stream);
-    } else {
-        if (f->training)
-            launch_fwd<3, true, true, false>(S, G, ws.tile_ranges, f->image_padded, f->image, ws.ckpt, ws.tile_nproc,
-                                             0, stream);
-        else
-            launch_fwd<3, true, false, false>(S, G, ws.tile_ranges, f->image_padded, f->image, nullptr, nullptr, 0,
-                                              stream);
+    // dense frames: tiles still alive after GS_LONG_MIN Gaussians hand the rest of their list to the segment kernels
+    const bool dense = gs_frame_is_dense(f->max_pairs, FG.n_tiles) && ws.cont_state != nullptr &&
+                       !(f->flags & GS_FRAME_SERIAL_LONG_LISTS);
+    float4 *cs = dense ? ws.cont_state : nullptr;
+    uint32_t *cf = dense ? ws.cont_flag : nullptr;
+#define GS_LAUNCH_FRAME_FWD(CD)                                                                                        \
+    do {                                                                                                               \
+        if (f->training)                                                                                               \
+            launch_fwd<CD, true, true, false>(S, G, ws.tile_ranges, f->image_padded, f->image, ws.ckpt, ws.tile_nproc, \
+                                              0, stream, cs, cf);                                                      \
+        else                                                                                                           \
+            launch_fwd<CD, true, false, false>(S, G, ws.tile_ranges, f->image_padded, f->image, nullptr, nullptr, 0,   \
+                                               stream, cs, cf);                                                        \
+    } while (0)
+    if (f->color_dim == 48)
+        GS_LAUNCH_FRAME_FWD(48);
+    else if (f->color_dim == 27)
+        GS_LAUNCH_FRAME_FWD(27);
+    else
+        GS_LAUNCH_FRAME_FWD(3);
+#undef GS_LAUNCH_FRAME_FWD
+    GS_CHECK_LAUNCH();
+    if (dense) {
+        const uint32_t T = (uint32_t)FG.n_tiles, cap = (uint32_t)gs_seg_items_cap(f->max_pairs, FG.n_tiles);
+        unsigned long long *n_items = ws.counters + GS_CNT_SEGS;
+        hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(1024), 0, stream, ws.cont_flag, ws.tile_ranges, T, cap,
+                           ws.seg_item_base, ws.seg_items, n_items);
+        GS_CHECK_LAUNCH();
+#define GS_LAUNCH_SEG(CD, CK)                                                                                          \
+    do {                                                                                                               \
+        hipLaunchKernelGGL((raster_segment_kernel<CD, CK, 1>), dim3(cap), dim3(FWD_THREADS), 0, stream, S, G,          \
+                           ws.tile_ranges, ws.seg_items, n_items, ws.cont_state, ws.seg_P, ws.seg_C, ws.seg_nproc,    \
+                           ws.ckpt);                                                                                   \
+        hipLaunchKernelGGL((raster_segment_kernel<CD, CK, 2>), dim3(cap), dim3(FWD_THREADS), 0, stream, S, G,          \
+                           ws.tile_ranges, ws.seg_items, n_items, ws.cont_state, ws.seg_P, ws.seg_C, ws.seg_nproc,    \
+                           ws.ckpt);                                                                                   \
+        hipLaunchKernelGGL((seg_combine_kernel<CK>), dim3(T), dim3(256), 0, stream, G, ws.tile_ranges, ws.cont_flag,   \
+                           ws.seg_item_base, ws.cont_state, ws.seg_C, ws.seg_nproc, ws.ckpt, ws.tile_nproc,           \
+                           f->image_padded, f->image);                                                                 \
+    } while (0)
+        if (f->training) {
+            if (f->color_dim == 48)
+                GS_LAUNCH_SEG(48, true);
+            else if (f->color_dim == 27)
+                GS_LAUNCH_SEG(27, true);
+            else
+                GS_LAUNCH_SEG(3, true);
+        } else {
+            if (f->color_dim == 48)
+                GS_LAUNCH_SEG(48, false);
+            else if (f->color_dim == 27)
+                GS_LAUNCH_SEG(27, false);
+            else
+                GS_LAUNCH_SEG(3, false);
+        }
+#undef GS_LAUNCH_SEG
     }
     GS_CHECK_LAUNCH();
     return 0;

@@ -1127,7 +1127,7 @@ int gs_stage_strip_sort(const gs_frame *f, const gs_frame_ws &ws, const uint64_t
     // dense frame (the capacity allows an average list above half the LDS window): lists beyond the window are queued
     // for big_list_sort_kernel, one workgroup each; otherwise strip_sort_kernel sorts a rare long list itself and the
     // frame saves the launch
-    const bool dense = f->max_pairs / G.n_tiles > STRIP_SORT_CAP_ / 2;
+    const bool dense = gs_frame_is_dense(f->max_pairs, G.n_tiles);
     uint32_t *queue = dense ? ws.big_tiles : nullptr;
     if (f->tile_culling_method == 0)
         hipLaunchKernelGGL((strip_sort_kernel<STRIP_SORT_CAP_, true>), dim3(grid), dim3(256), 0, stream, entries,

@@ -47,6 +47,7 @@ class GsFrame(C.Structure):
 GS_FRAME_EMIT_SORTED_KEYS = 1
 GS_FRAME_SLICE_SORT = 2
 GS_FRAME_TABLE_BIN = 4
+GS_FRAME_SERIAL_LONG_LISTS = 8
 
 
 def _sig(name, restype, *argtypes):

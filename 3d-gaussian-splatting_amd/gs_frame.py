@@ -41,7 +41,8 @@ class FrameRenderer:
     def __init__(self, device="cuda", max_pairs: int = 1 << 20, training: bool = False,
                  thresh: float = 0.05, scale_activation: str = "abs", auto_grow: bool = True,
                  sort_mode: int = 2, tile_culling_method: str = "prob2", tile_culling_dist_thresh: float = 0.5,
-                 emit_sorted_keys: bool = False, slice_sort: bool = False, table_bin: bool = False):
+                 emit_sorted_keys: bool = False, slice_sort: bool = False, table_bin: bool = False,
+                 serial_long_lists: bool = False):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("FrameRenderer needs a HIP device; there is no CPU fallback")
@@ -57,6 +58,7 @@ class FrameRenderer:
         self.emit_sorted_keys = bool(emit_sorted_keys)
         self.slice_sort = bool(slice_sort)  # sort_mode 2: the slice-sorted binning variant (GS_FRAME_SLICE_SORT)
         self.table_bin = bool(table_bin)  # sort_mode 2: the table variant instead of the default strip variant
+        self.serial_long_lists = bool(serial_long_lists)  # dense frames: no segmented compositing of long tile lists
         self.max_pairs = int(max_pairs)
         self.training = bool(training)
         self.thresh = float(thresh)
@@ -136,7 +138,8 @@ class FrameRenderer:
         f.max_pairs = self.max_pairs
         f.async_ = self._async
         f.flags = (_lib.GS_FRAME_EMIT_SORTED_KEYS if self.emit_sorted_keys else 0) | \
-            (_lib.GS_FRAME_SLICE_SORT if self.slice_sort else 0) | (_lib.GS_FRAME_TABLE_BIN if self.table_bin else 0)
+            (_lib.GS_FRAME_SLICE_SORT if self.slice_sort else 0) | (_lib.GS_FRAME_TABLE_BIN if self.table_bin else 0) | \
+            (_lib.GS_FRAME_SERIAL_LONG_LISTS if self.serial_long_lists else 0)
         f.training = int(training)
         f.sort_mode = self.sort_mode
         f.tile_culling_method = self.tile_culling_method

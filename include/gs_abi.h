@@ -160,6 +160,12 @@ int gs_sort_pairs_bits(uint64_t *keys0, uint32_t *vals0, uint64_t *keys1, uint32
                                        (strip_bin.hip).  Frames beyond the strip variant's limits (2^26 Gaussians, 8192
                                        strips of 8 tiles) take the table variant by themselves.  Same result. */
 
+#define GS_FRAME_SERIAL_LONG_LISTS 8 /* dense frames (capacity above 1024 pairs per tile on average) cut the rest of a tile's
+                                       list into segments composited by many waves when its pixels are still alive after
+                                       4096 Gaussians (raster_fwd.hip); this flag keeps the one-wave-per-tile walk for
+                                       such tiles (A/B and equivalence tests).  Same result up to the rounding of the
+                                       transmittance entering a segment. */
+
 /* Frame descriptor.  All scalars are per-camera constants computed on the host exactly as
  * splatter.py does (Tiles, RayInfo, frustum guard band); rot/tran are passed by value. */
 typedef struct gs_frame {

@@ -91,6 +91,37 @@ def test_frame_forward_giant_bucket_sorted_in_chunks(gpu, sort_mode):
     assert np.diff(of.accum).max() > 4096
 
 
+@pytest.mark.parametrize("use_sh", [False, True])
+def test_long_lists_composited_in_segments(gpu, use_sh):
+    """Dense frame with low-opacity pile-ups: every tile's pixels are still alive after 4096 Gaussians, so the rest
+    of each list (up to ~12,000 here) is composited in segments of 2048 by separate waves (transmittance products ->
+    incoming transmittance -> per-segment colours -> combine; raster_fwd.hip).  Against the one-wave-per-tile walk of
+    the same build (GS_FRAME_SERIAL_LONG_LISTS): image, processed counts and all five parameter gradients must agree to
+    the rounding of the transmittance that enters a segment; against the oracle: the list exactly, the image to 1e-3
+    (a chain of 10,000 layers is conditioned like that in fp32 whoever walks it)."""
+    scene, cam = case(50_000, 64, 64, seed=31, use_sh=use_sh)
+    scene.opa[:] = -6.0
+    of = OracleFrame(scene, cam)
+    assert np.diff(of.accum).min() > 4096 and np.diff(of.accum).max() > 4096 + 2 * 2048
+    outs = []
+    for serial in (False, True):
+        params = to_torch(scene, gpu, requires_grad=True)
+        r = FrameRenderer(gpu, max_pairs=len(of.ids) + 64, training=True, auto_grow=False, serial_long_lists=serial)
+        img = r.render(*params, cam)
+        assert r.stats().pairs == len(of.ids)
+        steps = r.composited_steps()
+        g = torch.from_numpy(np.random.default_rng(3).normal(size=of.image.shape).astype(np.float32)).to(gpu)
+        img.backward(g)
+        outs.append((img.detach().cpu().numpy(), steps, [t.grad.cpu().numpy() for t in params]))
+    (img_a, steps_a, grads_a), (img_b, steps_b, grads_b) = outs
+    assert np.abs(img_a - of.image).max() < 1e-3
+    assert np.abs(img_a - img_b).max() < 1e-5  # partial colours are added in a different association
+    assert steps_a == steps_b  # the same processed range, by either walk (nothing stops early here)
+    for ga, gb, name in zip(grads_a, grads_b, ("pos", "quat", "scale", "opa", "rgb")):
+        assert np.isfinite(ga).all()
+        assert np.abs(ga - gb).max() <= 2e-4 * np.abs(gb).max() + 1e-30, name
+
+
 @pytest.mark.parametrize("sort_mode", [2, "2t", "2s"])
 @pytest.mark.parametrize("n,W,H", [(10_000, 256, 256), (40_000, 32, 32)])
 def test_frame_forward_emitted_sorted_keys(gpu, n, W, H, sort_mode):
