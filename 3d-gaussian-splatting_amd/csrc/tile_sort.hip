@@ -910,13 +910,16 @@ __global__ void __launch_bounds__(256, STRIP_SORT_WPE) strip_sort_kernel(
 
 // ---------------------------------------------------------------------------------------------------------------
 // Lists beyond strip_sort_kernel's LDS window (dense scenes: 10 M Gaussians at 1080p are ~3,500 pairs per tile), one
-// workgroup per queued tile.  The list sits unsorted in `scratch` at its final range.  One counting pass over 1024
-// bins that are linear in the depth bits scatters the keys into bin order -- as two 4-byte halves in the list's own
-// slots of the two id arrays (the sorted ids' final home and the idle second id buffer: no extra memory) --, then
-// consecutive bins are grouped into sub-lists of up to CAP keys, contiguous in the final order, and each sub-list is
-// loaded into LDS, sorted by the distribution sort and stored.  A single bin beyond CAP (a depth cluster of
-// thousands) takes the chunked bitonic sort in place.  Only launched when the frame's capacity allows an average
-// list above CAP / 2 (gs_stage_strip_sort); otherwise strip_sort_kernel sorts a rare long list itself.
+// workgroup per queued tile.  The list sits unsorted in `scratch` at its final range.  A range of keys is refined by
+// one counting pass over 1024 bins that are linear in the 64-bit key (depth_bits << 32 | gaussian): the keys are
+// scattered into bin order -- as two 4-byte halves in the range's own slots of the two id arrays (the sorted ids' final
+// home and the idle second id buffer: no extra memory) --, runs of consecutive small bins form groups of up to CAP
+// keys that are contiguous in the final order, and each group is loaded into LDS, sorted by the distribution sort and
+// stored.  A bin with more than CAP / 2 keys (a depth cluster: a pile of clones at one depth behind a background that
+// spreads the range) goes back to `scratch` and onto a stack of ranges: its own, >= 1024 times narrower key range is
+// binned again (the range includes the id bits, so even equal depths separate).  Only launched when the frame's
+// capacity allows an average list above GS_DENSE_AVG (gs_stage_strip_sort); otherwise strip_sort_kernel sorts a rare
+// long list itself.
 template <int CAP>
 __global__ void __launch_bounds__(256) big_list_sort_kernel(const uint32_t *__restrict__ queue,
                                                            const unsigned long long *__restrict__ counters,
@@ -924,12 +927,16 @@ __global__ void __launch_bounds__(256) big_list_sort_kernel(const uint32_t *__re
                                                            uint64_t *__restrict__ keys, uint32_t *__restrict__ ids,
                                                            uint64_t *__restrict__ scratch,
                                                            uint32_t *__restrict__ tmp_depth) {
-    constexpr uint32_t NBIN = 1024;
-    static_assert(CAP == 2048, "sub-lists are loaded eight keys per thread");
+    constexpr uint32_t NBIN = 1024, STACK = 192;
+    static_assert(CAP == 2048, "groups are loaded eight keys per thread");
     __shared__ uint64_t s_a[CAP];
     __shared__ uint32_t s_scan[4];
     __shared__ uint32_t s_bcnt[256 * 8 + 4], s_wl[1 + 2 * 128], s_red[16];
-    __shared__ uint32_t s_bin[NBIN + 1];
+    __shared__ uint32_t s_bin[NBIN + 1];     // first key of every bin (relative to the range)
+    __shared__ uint32_t s_gstart[NBIN + 2];  // first bin of every group
+    __shared__ uint64_t s_mm[8];
+    __shared__ uint2 s_stack[STACK];         // ranges (offset inside the list, count) still to be refined
+    __shared__ uint32_t s_sp, s_ng;
     uint32_t *s_cursor = reinterpret_cast<uint32_t *>(s_a);
     const int lane = threadIdx.x & 63;
     const uint32_t wave = threadIdx.x >> 6;
@@ -937,144 +944,196 @@ __global__ void __launch_bounds__(256) big_list_sort_kernel(const uint32_t *__re
     auto block_sync = [] { __syncthreads(); };
     for (uint32_t w = blockIdx.x; w < nbig; w += gridDim.x) {
         const uint32_t tile = queue[w];
-        const uint32_t start = (uint32_t)ranges[2 * tile], n = (uint32_t)ranges[2 * tile + 1] - start;
-        uint64_t *a = scratch + start;
+        const uint32_t start = (uint32_t)ranges[2 * tile], n_list = (uint32_t)ranges[2 * tile + 1] - start;
         auto st = [&](uint32_t base, uint32_t i, uint64_t v) {
             ids[base + i] = (uint32_t)v;
             if (keys) keys[base + i] = ((uint64_t)tile << 32) | (v >> 32);
         };
-        __syncthreads();  // LDS of the previous list
-        // every pass over the list keeps eight loads per thread in flight (a plain strided loop exposes one memory
-        // round trip per 256 keys: 136 us per 3,500-key list)
-        auto for_each_key = [&](auto fn) {
-            for (uint32_t i0 = 0; i0 < n; i0 += 2048) {
-                uint64_t kk[8];
+        // sorts and stores the m <= CAP keys that wait as halves at [base, base + m)
+        auto sort_group = [&](uint32_t base, uint32_t m) {
+            {
+                uint32_t hd[8], hi[8];  // CAP = 8 x 256: all sixteen loads in flight
 #pragma unroll
                 for (uint32_t j = 0; j < 8; ++j) {
-                    const uint32_t i = i0 + j * 256 + threadIdx.x;
-                    kk[j] = i < n ? a[i] : KEY_INF;
+                    const uint32_t i = j * 256 + threadIdx.x;
+                    hd[j] = i < m ? tmp_depth[base + i] : 0;
+                    hi[j] = i < m ? ids[base + i] : 0;
                 }
 #pragma unroll
-                for (uint32_t j = 0; j < 8; ++j)
-                    if (i0 + j * 256 + threadIdx.x < n) fn(kk[j]);
+                for (uint32_t j = 0; j < 8; ++j) {
+                    const uint32_t i = j * 256 + threadIdx.x;
+                    if (i < m) s_a[i] = ((uint64_t)hd[j] << 32) | hi[j];
+                }
             }
-        };
-        // ---- range of the depth bits
-        uint32_t dmin = 0xffffffffu, dmax = 0;
-        for_each_key([&](uint64_t key) {
-            const uint32_t d = (uint32_t)(key >> 32);
-            dmin = d < dmin ? d : dmin;
-            dmax = d > dmax ? d : dmax;
-        });
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const uint32_t x = __shfl_xor(dmin, o, 64), y = __shfl_xor(dmax, o, 64);
-            dmin = x < dmin ? x : dmin;
-            dmax = y > dmax ? y : dmax;
-        }
-        if (lane == 0) {
-            s_red[wave] = dmin;
-            s_red[4 + wave] = dmax;
-        }
-        for (uint32_t c = threadIdx.x; c <= NBIN; c += 256) s_bin[c] = 0;
-        __syncthreads();
-#pragma unroll
-        for (uint32_t x = 0; x < 4; ++x) {
-            dmin = s_red[x] < dmin ? s_red[x] : dmin;
-            dmax = s_red[4 + x] > dmax ? s_red[4 + x] : dmax;
-        }
-        const float scale = (float)NBIN / ((float)(dmax - dmin) + 1.0f);
-        auto bin_of = [&](uint64_t key) {
-            const uint32_t b = (uint32_t)((float)((uint32_t)(key >> 32) - dmin) * scale);
-            return b < NBIN - 1 ? b : NBIN - 1;
-        };
-        for_each_key([&](uint64_t key) { atomicAdd(&s_bin[bin_of(key)], 1u); });
-        __syncthreads();
-        {  // exclusive scan of the 1024 counters: thread t owns counters [4 t, 4 t + 4)
-            uint32_t c[4], sum = 0;
-#pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) {
-                const uint32_t x = s_bin[4 * threadIdx.x + j];
-                c[j] = sum;
-                sum += x;
-            }
-            const uint32_t incl = gs_wave_incl_scan_u32(sum);
-            if (lane == 63) s_red[8 + wave] = incl;
             __syncthreads();
-            uint32_t off = incl - sum;
-#pragma unroll
-            for (uint32_t x = 0; x < 4; ++x) off += x < wave ? s_red[8 + x] : 0;
-#pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) s_bin[4 * threadIdx.x + j] = s_cursor[4 * threadIdx.x + j] = off + c[j];
-            if (threadIdx.x == 0) s_bin[NBIN] = n;
+            if (m <= 128) {
+                if (wave == 0) {
+                    const uint32_t f0 = lane, f1 = lane + 64;
+                    uint64_t a0 = f0 < m ? s_a[f0] : KEY_INF, a1 = f1 < m ? s_a[f1] : KEY_INF;
+                    sort_window(a0, a1, lane, m);
+                    if (f0 < m) st(base, f0, a0);
+                    if (f1 < m) st(base, f1, a1);
+                }
+            } else {
+                bucket_sort_store(s_a, m, s_bcnt, s_wl, s_red, threadIdx.x, 256u, block_sync,
+                                  [&](uint32_t i, uint64_t v) { st(base, i, v); });
+            }
+            __syncthreads();
+        };
+        __syncthreads();  // LDS of the previous list
+        if (threadIdx.x == 0) {
+            s_stack[0] = make_uint2(0, n_list);
+            s_sp = 1;
         }
         __syncthreads();
-        for_each_key([&](uint64_t key) {  // keys into bin order, as halves
-            const uint32_t pos = atomicAdd(&s_cursor[bin_of(key)], 1u);
-            tmp_depth[start + pos] = (uint32_t)(key >> 32);
-            ids[start + pos] = (uint32_t)key;
-        });
-        __syncthreads();
-        // ---- groups of consecutive bins: group g = the bins whose first key has a rank in [g CAP/2, (g + 1) CAP/2), i.e.
-        // at most CAP/2 + (one bin) keys; its bounds come from two binary searches of the bin table (a greedy walk over
-        // the 1024 bins is a chain of 1024 dependent LDS reads: 40 us per list)
-        auto first_bin_at = [&](uint32_t rank) {  // first bin whose start is >= rank (uniform)
-            uint32_t lo = 0, hi = NBIN;
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (s_bin[mid] < rank) lo = mid + 1; else hi = mid;
+        while (s_sp > 0) {  // uniform
+            const uint2 top = s_stack[s_sp - 1];
+            __syncthreads();
+            if (threadIdx.x == 0) s_sp = s_sp - 1;
+            const uint32_t off = top.x, n = top.y, r0 = start + off;  // r0: the range's first slot
+            uint64_t *a = scratch + r0;
+            // every pass over the range keeps eight loads per thread in flight
+            auto for_each_key = [&](auto fn) {
+                for (uint32_t i0 = 0; i0 < n; i0 += 2048) {
+                    uint64_t kk[8];
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; ++j) {
+                        const uint32_t i = i0 + j * 256 + threadIdx.x;
+                        kk[j] = i < n ? a[i] : KEY_INF;
+                    }
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; ++j)
+                        if (i0 + j * 256 + threadIdx.x < n) fn(kk[j]);
+                }
+            };
+            // ---- range of the keys
+            uint64_t kmin = KEY_INF, kmax = 0;
+            for_each_key([&](uint64_t key) {
+                kmin = key < kmin ? key : kmin;
+                kmax = key > kmax ? key : kmax;
+            });
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint64_t x = __shfl_xor(kmin, o, 64), y = __shfl_xor(kmax, o, 64);
+                kmin = x < kmin ? x : kmin;
+                kmax = y > kmax ? y : kmax;
             }
-            return lo;
-        };
-        const uint32_t G = (uint32_t)CAP / 2, ngroup = (n + G - 1) / G;
-        for (uint32_t g = 0; g < ngroup; ++g) {
-            const uint32_t b0 = first_bin_at(g * G), b1 = first_bin_at((g + 1) * G);
-            const uint32_t gs0 = s_bin[b0], m = s_bin[b1] - gs0;
-            if (m == 0) continue;
-            if (m <= (uint32_t)CAP) {
-                {
-                    uint32_t hd[8], hi[8];  // CAP = 8 x 256: all sixteen loads in flight
+            if (lane == 0) {
+                s_mm[wave] = kmin;
+                s_mm[4 + wave] = kmax;
+            }
+            for (uint32_t c = threadIdx.x; c <= NBIN; c += 256) s_bin[c] = 0;
+            __syncthreads();
 #pragma unroll
-                    for (uint32_t j = 0; j < 8; ++j) {
-                        const uint32_t i = j * 256 + threadIdx.x;
-                        hd[j] = i < m ? tmp_depth[start + gs0 + i] : 0;
-                        hi[j] = i < m ? ids[start + gs0 + i] : 0;
-                    }
+            for (uint32_t x = 0; x < 4; ++x) {
+                kmin = s_mm[x] < kmin ? s_mm[x] : kmin;
+                kmax = s_mm[4 + x] > kmax ? s_mm[4 + x] : kmax;
+            }
+            const float scale = (float)NBIN / ((float)(kmax - kmin) + 1.0f);
+            auto bin_of = [&](uint64_t key) {  // monotone in the key (u64 -> float, x positive constant, truncation)
+                const uint32_t b = (uint32_t)((float)(key - kmin) * scale);
+                return b < NBIN - 1 ? b : NBIN - 1;
+            };
+            for_each_key([&](uint64_t key) { atomicAdd(&s_bin[bin_of(key)], 1u); });
+            __syncthreads();
+            {  // thread t owns bins [4 t, 4 t + 4): exclusive scan of the counts; group boundaries
+                const uint32_t HALF = (uint32_t)CAP / 2;
+                uint32_t c[4], cs[4], sum = 0, ssum = 0;  // all counts / counts of the small bins only
 #pragma unroll
-                    for (uint32_t j = 0; j < 8; ++j) {
-                        const uint32_t i = j * 256 + threadIdx.x;
-                        if (i < m) s_a[i] = ((uint64_t)hd[j] << 32) | hi[j];
-                    }
+                for (uint32_t j = 0; j < 4; ++j) {
+                    c[j] = s_bin[4 * threadIdx.x + j];
+                    cs[j] = c[j] > HALF ? 0 : c[j];
+                    sum += c[j];
+                    ssum += cs[j];
                 }
-                __syncthreads();
-                const uint32_t base = start + gs0;
-                if (m <= 128) {
-                    if (wave == 0) {
-                        const uint32_t f0 = lane, f1 = lane + 64;
-                        uint64_t a0 = f0 < m ? s_a[f0] : KEY_INF, a1 = f1 < m ? s_a[f1] : KEY_INF;
-                        sort_window(a0, a1, lane, m);
-                        if (f0 < m) st(base, f0, a0);
-                        if (f1 < m) st(base, f1, a1);
-                    }
-                } else {
-                    bucket_sort_store(s_a, m, s_bcnt, s_wl, s_red, threadIdx.x, 256u, block_sync,
-                                      [&](uint32_t i, uint64_t v) { st(base, i, v); });
+                const uint32_t incl = gs_wave_incl_scan_u32(sum), sincl = gs_wave_incl_scan_u32(ssum);
+                if (lane == 63) {
+                    s_red[8 + wave] = incl;
+                    s_red[12 + wave] = sincl;
                 }
+                // the last bin's count of the previous thread decides whether this thread's first bin follows a big bin
+                const uint32_t prev_last = __shfl_up(c[3], 1, 64);
+                if (lane == 63) s_red[wave] = c[3];
                 __syncthreads();
-            } else {  // one bin beyond the window: the chunked bitonic sort, in place in `scratch`
+                uint32_t o = incl - sum, so = sincl - ssum;
+#pragma unroll
+                for (uint32_t x = 0; x < 4; ++x) {
+                    o += x < wave ? s_red[8 + x] : 0;
+                    so += x < wave ? s_red[12 + x] : 0;
+                }
+                uint32_t before = lane > 0 ? prev_last : (wave > 0 ? s_red[wave - 1] : 0);  // count of bin 4 t - 1
+                uint32_t flags = 0;  // bit j: bin 4 t + j starts a group
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    const uint32_t b = 4 * threadIdx.x + j;
+                    // a new group starts at bin 0, at a big bin, behind a big bin, and where the running total of the
+                    // small bins (in front of the bin) enters the next CAP / 2: a run of small bins whose totals in
+                    // front lie in one window of CAP / 2 holds less than CAP / 2 + CAP / 2 keys
+                    const uint32_t prev_so = so - (before > HALF ? 0 : before);
+                    const bool boundary = b == 0 || c[j] > HALF || before > HALF || so / HALF != prev_so / HALF;
+                    flags |= boundary ? 1u << j : 0u;
+                    s_bin[b] = s_cursor[b] = o;
+                    o += c[j];
+                    so += cs[j];
+                    before = c[j];
+                }
+                if (threadIdx.x == 0) s_bin[NBIN] = n;
+                // compact the group starts
+                const uint32_t nf = (uint32_t)__popc(flags);
+                const uint32_t fincl = gs_wave_incl_scan_u32(nf);
+                __syncthreads();
+                if (lane == 63) s_red[8 + wave] = fincl;
+                __syncthreads();
+                uint32_t fo = fincl - nf;
+#pragma unroll
+                for (uint32_t x = 0; x < 4; ++x) fo += x < wave ? s_red[8 + x] : 0;
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j)
+                    if (flags >> j & 1) s_gstart[fo++] = 4 * threadIdx.x + j;
+                if (threadIdx.x == 255) {
+                    s_ng = fo;
+                    s_gstart[fo] = NBIN;
+                }
+            }
+            __syncthreads();
+            for_each_key([&](uint64_t key) {  // keys into bin order, as halves
+                const uint32_t pos = atomicAdd(&s_cursor[bin_of(key)], 1u);
+                tmp_depth[r0 + pos] = (uint32_t)(key >> 32);
+                ids[r0 + pos] = (uint32_t)key;
+            });
+            __syncthreads();
+            const uint32_t ng = s_ng;
+            for (uint32_t g = 0; g < ng; ++g) {
+                const uint32_t gs0 = s_bin[s_gstart[g]], m = s_bin[s_gstart[g + 1]] - gs0;  // uniform
+                if (m == 0) continue;
+                if (m <= (uint32_t)CAP) {
+                    sort_group(r0 + gs0, m);
+                    continue;
+                }
+                // a big bin: back to `scratch`, to be binned again over its own key range -- unless it cannot get
+                // narrower (the whole range fell into it) or the stack is full: then the chunked bitonic sort, in place
                 for (uint32_t i = threadIdx.x; i < m; i += 256)
-                    a[gs0 + i] = ((uint64_t)tmp_depth[start + gs0 + i] << 32) | ids[start + gs0 + i];
+                    a[gs0 + i] = ((uint64_t)tmp_depth[r0 + gs0 + i] << 32) | ids[r0 + gs0 + i];
                 __syncthreads();
-                tile_sort_body<CAP, SRC_PACKED>(
-                    keys, ids, scratch,
-                    [&](uint32_t qq, uint32_t &t_, uint32_t &s_, uint32_t &n_) {
-                        t_ = tile;
-                        s_ = start + gs0;
-                        n_ = qq == 0 ? m : 0;
-                    },
-                    GatherSrc{}, s_a, s_scan, nullptr);
-                __syncthreads();
+                if (m < n && s_sp < STACK) {
+                    if (threadIdx.x == 0) {
+                        s_stack[s_sp] = make_uint2(off + gs0, m);
+                        s_sp = s_sp + 1;
+                    }
+                    __syncthreads();
+                } else {
+                    tile_sort_body<CAP, SRC_PACKED>(
+                        keys, ids, scratch,
+                        [&](uint32_t qq, uint32_t &t_, uint32_t &s_, uint32_t &n_) {
+                            t_ = tile;
+                            s_ = r0 + gs0;
+                            n_ = qq == 0 ? m : 0;
+                        },
+                        GatherSrc{}, s_a, s_scan, nullptr);
+                    __syncthreads();
+                }
             }
+            __syncthreads();
         }
     }
 }
