@@ -2,7 +2,7 @@
 #pragma once
 #include "gs_common.h"
 
-enum { GS_CNT_VISIBLE = 0, GS_CNT_PAIRS = 1, GS_CNT_OVERFLOW = 2, GS_CNT_BUCKETS = 3, GS_CNT_TICKET = 4, GS_CNT_ENTRIES = 5, GS_CNT_BIG = 6, GS_CNT_SEGS = 7, GS_CNT_N = 8 };
+enum { GS_CNT_VISIBLE = 0, GS_CNT_PAIRS = 1, GS_CNT_OVERFLOW = 2, GS_CNT_BUCKETS = 3, GS_CNT_TICKET = 4, GS_CNT_ENTRIES = 5, GS_CNT_BIG = 6, GS_CNT_SEGS = 7, GS_CNT_GROUPS = 8, GS_CNT_N = 16 };
 
 #define GS_BUCKET 64          // Gaussians per backward bucket (= wavefront size)
 #define GS_SORT_TILE 2048     // keys per radix-sort workgroup (256 threads x 8)
@@ -59,6 +59,7 @@ static inline gs_bin_plan gs_bin_plan_for(int64_t N, int64_t max_pairs, int n_ti
 #define GS_SEG_LEN 2048       // Gaussians per segment
 static inline bool gs_frame_is_dense(int64_t max_pairs, int n_tiles) { return max_pairs / (n_tiles > 0 ? n_tiles : 1) > GS_DENSE_AVG; }
 static inline int64_t gs_seg_items_cap(int64_t max_pairs, int n_tiles) { return max_pairs / GS_SEG_LEN + n_tiles; }
+static inline int64_t gs_group_queue_cap(int64_t max_pairs, int n_tiles) { return max_pairs / 256 + 4 * (int64_t)n_tiles; }
 #define GS_STRIP_SORT_CAP 2048  // pairs strip_sort_kernel's LDS window holds (a half strip's four lists, or one list at a time)
 struct gs_strip_geom {
     uint32_t ntx, nty, nsx, NS;  // tile grid, strips per tile row, strips per frame
@@ -148,6 +149,7 @@ struct gs_frame_ws {
     uint64_t *strip_tot;           // [NS] totals per strip
     uint64_t *strip_base;          // [NS] (first entry << 32 | first pair) of every strip
     uint32_t *big_tiles;           // [T] queue of the tiles whose list exceeds strip_sort_kernel's LDS window
+    uint4 *group_queue;            // dense frames: (tile, first slot, keys, -) of the groups big_list_sort_kernel cut
     // dense frames only (else NULL): segmented compositing of long tile lists (raster_fwd.hip)
     float4 *cont_state;            // [T][256] (T, C) of a tile's pixels after its first GS_LONG_MIN Gaussians
     uint32_t *cont_flag;           // [T] 1: the tile was still alive there and continues in segments
@@ -224,6 +226,7 @@ static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pair
     }
     if (gs_frame_is_dense(max_pairs, G.n_tiles)) {
         const size_t cap = (size_t)gs_seg_items_cap(max_pairs, G.n_tiles);
+        ws.group_queue = (uint4 *)take(sizeof(uint4) * (size_t)gs_group_queue_cap(max_pairs, G.n_tiles));
         ws.cont_state = (float4 *)take(sizeof(float4) * 256 * (size_t)G.n_tiles);
         ws.cont_flag = (uint32_t *)take(sizeof(uint32_t) * G.n_tiles);
         ws.seg_item_base = (uint32_t *)take(sizeof(uint32_t) * ((size_t)G.n_tiles + 1));
@@ -232,6 +235,7 @@ static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pair
         ws.seg_C = (float4 *)take(sizeof(float4) * 256 * cap);
         ws.seg_nproc = (uint32_t *)take(sizeof(uint32_t) * cap);
     } else {
+        ws.group_queue = nullptr;
         ws.cont_state = nullptr;
         ws.cont_flag = nullptr;
         ws.seg_item_base = nullptr;

@@ -908,6 +908,65 @@ __global__ void __launch_bounds__(256, STRIP_SORT_WPE) strip_sort_kernel(
     }
 }
 
+// Sorts and stores the m <= CAP keys of tile `tile` that wait as two 4-byte halves (depth bits in tmp_depth, Gaussian in
+// ids) at slots [base, base + m) -- their final range.  256 threads; s_a: CAP keys, s_bcnt / s_wl / s_red: see
+// bucket_sort_store.
+template <int CAP>
+__device__ __forceinline__ void sort_group_halves(uint32_t base, uint32_t m, uint32_t tile, uint64_t *__restrict__ keys,
+                                                  uint32_t *__restrict__ ids, const uint32_t *__restrict__ tmp_depth,
+                                                  uint64_t *s_a, uint32_t *s_bcnt, uint32_t *s_wl, uint32_t *s_red) {
+    static_assert(CAP == 2048, "groups are loaded eight keys per thread");
+    const int lane = threadIdx.x & 63;
+    auto st = [&](uint32_t i, uint64_t v) {
+        ids[base + i] = (uint32_t)v;
+        if (keys) keys[base + i] = ((uint64_t)tile << 32) | (v >> 32);
+    };
+    {
+        uint32_t hd[8], hi[8];  // CAP = 8 x 256: all sixteen loads in flight
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) {
+            const uint32_t i = j * 256 + threadIdx.x;
+            hd[j] = i < m ? tmp_depth[base + i] : 0;
+            hi[j] = i < m ? ids[base + i] : 0;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) {
+            const uint32_t i = j * 256 + threadIdx.x;
+            if (i < m) s_a[i] = ((uint64_t)hd[j] << 32) | hi[j];
+        }
+    }
+    __syncthreads();
+    if (m <= 128) {
+        if (threadIdx.x < 64) {
+            const uint32_t f0 = lane, f1 = lane + 64;
+            uint64_t a0 = f0 < m ? s_a[f0] : KEY_INF, a1 = f1 < m ? s_a[f1] : KEY_INF;
+            sort_window(a0, a1, lane, m);
+            if (f0 < m) st(f0, a0);
+            if (f1 < m) st(f1, a1);
+        }
+    } else {
+        bucket_sort_store(s_a, m, s_bcnt, s_wl, s_red, threadIdx.x, 256u, [] { __syncthreads(); }, st);
+    }
+    __syncthreads();
+}
+
+// The groups big_list_sort_kernel cut, sorted by the whole device instead of by the list's own workgroup.
+template <int CAP>
+__global__ void __launch_bounds__(256) group_sort_kernel(const uint4 *__restrict__ queue,
+                                                        const unsigned long long *__restrict__ counters,
+                                                        uint32_t queue_cap, uint64_t *__restrict__ keys,
+                                                        uint32_t *__restrict__ ids,
+                                                        const uint32_t *__restrict__ tmp_depth) {
+    __shared__ uint64_t s_a[CAP];
+    __shared__ uint32_t s_bcnt[256 * 8 + 4], s_wl[1 + 2 * 128], s_red[16];
+    const unsigned long long total = counters[GS_CNT_GROUPS];
+    const uint32_t ng = total < queue_cap ? (uint32_t)total : queue_cap;
+    for (uint32_t w = blockIdx.x; w < ng; w += gridDim.x) {
+        const uint4 g = queue[w];
+        sort_group_halves<CAP>(g.y, g.z, g.x, keys, ids, tmp_depth, s_a, s_bcnt, s_wl, s_red);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Lists beyond strip_sort_kernel's LDS window (dense scenes: 10 M Gaussians at 1080p are ~3,500 pairs per tile), one
 // workgroup per queued tile.  The list sits unsorted in `scratch` at its final range.  A range of keys is refined by
@@ -926,7 +985,9 @@ __global__ void __launch_bounds__(256) big_list_sort_kernel(const uint32_t *__re
                                                            const int32_t *__restrict__ ranges,
                                                            uint64_t *__restrict__ keys, uint32_t *__restrict__ ids,
                                                            uint64_t *__restrict__ scratch,
-                                                           uint32_t *__restrict__ tmp_depth) {
+                                                           uint32_t *__restrict__ tmp_depth,
+                                                           uint4 *__restrict__ group_queue, uint32_t queue_cap,
+                                                           unsigned long long *__restrict__ group_count) {
     constexpr uint32_t NBIN = 1024, STACK = 192;
     static_assert(CAP == 2048, "groups are loaded eight keys per thread");
     __shared__ uint64_t s_a[CAP];
@@ -936,49 +997,32 @@ __global__ void __launch_bounds__(256) big_list_sort_kernel(const uint32_t *__re
     __shared__ uint32_t s_gstart[NBIN + 2];  // first bin of every group
     __shared__ uint64_t s_mm[8];
     __shared__ uint2 s_stack[STACK];         // ranges (offset inside the list, count) still to be refined
-    __shared__ uint32_t s_sp, s_ng;
+    __shared__ uint32_t s_sp, s_ng, s_queued;
     uint32_t *s_cursor = reinterpret_cast<uint32_t *>(s_a);
     const int lane = threadIdx.x & 63;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t nbig = (uint32_t)counters[GS_CNT_BIG];
-    auto block_sync = [] { __syncthreads(); };
     for (uint32_t w = blockIdx.x; w < nbig; w += gridDim.x) {
         const uint32_t tile = queue[w];
         const uint32_t start = (uint32_t)ranges[2 * tile], n_list = (uint32_t)ranges[2 * tile + 1] - start;
-        auto st = [&](uint32_t base, uint32_t i, uint64_t v) {
-            ids[base + i] = (uint32_t)v;
-            if (keys) keys[base + i] = ((uint64_t)tile << 32) | (v >> 32);
-        };
-        // sorts and stores the m <= CAP keys that wait as halves at [base, base + m)
+        // a group of m <= CAP keys waits as halves at [base, base + m): queued for group_sort_kernel (the device sorts
+        // the groups of all lists in parallel), or sorted here when the queue is full
+        // (only for lists of more than 16 k keys: the queue's counter is ONE address, 12 ns per atomic -- 32,000 groups of
+        // a 10 M-Gaussian frame would spend 0.4 ms there, while a list's few groups are sorted in ~10 us each right here)
+        const bool use_queue = group_queue != nullptr && n_list > 16384;
         auto sort_group = [&](uint32_t base, uint32_t m) {
-            {
-                uint32_t hd[8], hi[8];  // CAP = 8 x 256: all sixteen loads in flight
-#pragma unroll
-                for (uint32_t j = 0; j < 8; ++j) {
-                    const uint32_t i = j * 256 + threadIdx.x;
-                    hd[j] = i < m ? tmp_depth[base + i] : 0;
-                    hi[j] = i < m ? ids[base + i] : 0;
+            bool queued = false;
+            if (use_queue) {  // uniform
+                if (threadIdx.x == 0) {
+                    const unsigned long long slot = atomicAdd(group_count, 1ull);
+                    if (slot < queue_cap) group_queue[slot] = make_uint4(tile, base, m, 0);
+                    s_queued = slot < queue_cap;
                 }
-#pragma unroll
-                for (uint32_t j = 0; j < 8; ++j) {
-                    const uint32_t i = j * 256 + threadIdx.x;
-                    if (i < m) s_a[i] = ((uint64_t)hd[j] << 32) | hi[j];
-                }
+                __syncthreads();
+                queued = s_queued != 0;
+                __syncthreads();
             }
-            __syncthreads();
-            if (m <= 128) {
-                if (wave == 0) {
-                    const uint32_t f0 = lane, f1 = lane + 64;
-                    uint64_t a0 = f0 < m ? s_a[f0] : KEY_INF, a1 = f1 < m ? s_a[f1] : KEY_INF;
-                    sort_window(a0, a1, lane, m);
-                    if (f0 < m) st(base, f0, a0);
-                    if (f1 < m) st(base, f1, a1);
-                }
-            } else {
-                bucket_sort_store(s_a, m, s_bcnt, s_wl, s_red, threadIdx.x, 256u, block_sync,
-                                  [&](uint32_t i, uint64_t v) { st(base, i, v); });
-            }
-            __syncthreads();
+            if (!queued) sort_group_halves<CAP>(base, m, tile, keys, ids, tmp_depth, s_a, s_bcnt, s_wl, s_red);
         };
         __syncthreads();  // LDS of the previous list
         if (threadIdx.x == 0) {
@@ -1197,9 +1241,15 @@ int gs_stage_strip_sort(const gs_frame *f, const gs_frame_ws &ws, const uint64_t
                            ws.strip_base, ws.strip_tot, ws.counters, keys_out, ids_out, scratch, ws.tile_ranges,
                            plan.geom, ws.rec_geom, D, queue, ws.counters + GS_CNT_BIG);
     GS_CHECK_LAUNCH();
-    if (dense)
+    if (dense) {
+        const uint32_t qcap = (uint32_t)gs_group_queue_cap(f->max_pairs, G.n_tiles);
         hipLaunchKernelGGL((big_list_sort_kernel<STRIP_SORT_CAP_>), dim3((unsigned)G.n_tiles), dim3(256), 0, stream,
-                           ws.big_tiles, ws.counters, ws.tile_ranges, keys_out, ids_out, scratch, ws.vals_b);
+                           ws.big_tiles, ws.counters, ws.tile_ranges, keys_out, ids_out, scratch, ws.vals_b,
+                           ws.group_queue, qcap, ws.counters + GS_CNT_GROUPS);
+        GS_CHECK_LAUNCH();
+        hipLaunchKernelGGL((group_sort_kernel<STRIP_SORT_CAP_>), dim3(qcap < 8192u ? qcap : 8192u), dim3(256), 0, stream,
+                           ws.group_queue, ws.counters, qcap, keys_out, ids_out, ws.vals_b);
+    }
     GS_CHECK_LAUNCH();
     return 0;
 }
