@@ -629,7 +629,10 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_segment_kernel(
     }
 }
 
-// one workgroup per tile, thread p = pixel slot p of the checkpoint layout (128 h + 64 e + lane)
+// Workgroup (tile, y): thread p = pixel slot p of the checkpoint layout (128 h + 64 e + lane).  Workgroup y fixes the
+// checkpoints of the tile's segments [8 y, 8 y + 8) -- it first adds up the colours in front of them --, workgroup 0
+// also writes the final pixels and the processed count.  (One workgroup per tile doing all of it: 0.4 ms for the 1,500
+// checkpoints of a 100,000-Gaussian list.)
 template <bool CKPT>
 __global__ void __launch_bounds__(256) seg_combine_kernel(RasterGeom G, const int32_t *__restrict__ ranges,
                                                           const uint32_t *__restrict__ cont_flag,
@@ -639,19 +642,24 @@ __global__ void __launch_bounds__(256) seg_combine_kernel(RasterGeom G, const in
                                                           const uint32_t *__restrict__ seg_nproc,
                                                           float4 *__restrict__ ckpt, uint32_t *__restrict__ tile_nproc,
                                                           float *__restrict__ out_padded, float *__restrict__ out_image) {
+    constexpr uint32_t SEGS_PER_BLOCK = 8;
     const uint32_t tile = blockIdx.x;
     if (!cont_flag[tile]) return;
+    const uint32_t i0 = item_base[tile], i1 = item_base[tile + 1];
+    const uint32_t nseg = i1 - i0;
+    // this workgroup's segments: blocks of eight, dealt round-robin over gridDim.y
+    if (blockIdx.y > 0 && (!CKPT || blockIdx.y * SEGS_PER_BLOCK >= nseg)) return;
     const uint32_t p = threadIdx.x, lane = p & 63, k = p >> 6;  // k = 2 h + e
     const uint32_t start = (uint32_t)ranges[2 * tile], n_all = (uint32_t)ranges[2 * tile + 1] - start;
-    const uint32_t i0 = item_base[tile], i1 = item_base[tile + 1];
     const float4 s0 = cont_state[(size_t)tile * 256 + p];
     float c0 = s0.y, c1 = s0.z, c2 = s0.w;
     uint32_t nproc = GS_LONG_MIN;
-    for (uint32_t it = i0; it < i1; ++it) {
+    for (uint32_t sidx = 0; sidx < nseg; ++sidx) {
+        const uint32_t it = i0 + sidx;
         const uint32_t np = seg_nproc[it];  // uniform
         if (np == 0) break;
-        if (CKPT) {
-            const uint32_t seg_begin = GS_LONG_MIN + (it - i0) * GS_SEG_LEN;
+        const uint32_t seg_begin = GS_LONG_MIN + sidx * GS_SEG_LEN;
+        if (CKPT && (sidx / SEGS_PER_BLOCK) % gridDim.y == blockIdx.y) {
             for (uint32_t b = 0; b * GS_BUCKET < np; ++b) {
                 float4 *c = ckpt + raster_ckpt_slot(start, tile, seg_begin / GS_BUCKET + b) * 256 + p;
                 float4 v = *c;
@@ -668,10 +676,10 @@ __global__ void __launch_bounds__(256) seg_combine_kernel(RasterGeom G, const in
         nproc += np;
         // a segment that stopped inside ends the tile's processed range, whatever the (independently rounded) incoming
         // transmittance of the next one says: the backward walks the first tile_nproc Gaussians, contiguously
-        const uint32_t seg_begin = GS_LONG_MIN + (it - i0) * GS_SEG_LEN;
         const uint32_t seg_len = n_all - seg_begin < (uint32_t)GS_SEG_LEN ? n_all - seg_begin : (uint32_t)GS_SEG_LEN;
         if (np < seg_len) break;
     }
+    if (blockIdx.y > 0) return;
     if (tile_nproc && p == 0) tile_nproc[tile] = nproc;
     const uint32_t tx = tile % (uint32_t)G.ntx, ty = tile / (uint32_t)G.ntx;
     // k = 2 h + e: row y0 + 8 h + 4 e
@@ -860,7 +868,8 @@ int gs_stage_raster_forward(const gs_frame *f, const gs_frame_ws &ws, const uint
         hipLaunchKernelGGL((raster_segment_kernel<CD, CK, 2>), dim3(cap), dim3(FWD_THREADS), 0, stream, S, G,          \
                            ws.tile_ranges, ws.seg_items, n_items, ws.cont_state, ws.seg_P, ws.seg_C, ws.seg_nproc,    \
                            ws.ckpt);                                                                                   \
-        hipLaunchKernelGGL((seg_combine_kernel<CK>), dim3(T), dim3(256), 0, stream, G, ws.tile_ranges, ws.cont_flag,   \
+        hipLaunchKernelGGL((seg_combine_kernel<CK>), dim3(T, CK ? 16 : 1), dim3(256), 0, stream, G, ws.tile_ranges,     \
+                           ws.cont_flag,                                                                               \
                            ws.seg_item_base, ws.cont_state, ws.seg_C, ws.seg_nproc, ws.ckpt, ws.tile_nproc,           \
                            f->image_padded, f->image);                                                                 \
     } while (0)
