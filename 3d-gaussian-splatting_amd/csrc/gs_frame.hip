@@ -64,7 +64,7 @@ static int validate(const gs_frame *f) {
         GS_CHECK_ARG(f->thresh > 0.f && f->thresh < 1.f, "thresh must be in (0,1)");
     }
     GS_CHECK_ARG((f->flags & ~(GS_FRAME_EMIT_SORTED_KEYS | GS_FRAME_SLICE_SORT | GS_FRAME_TABLE_BIN |
-                               GS_FRAME_SERIAL_LONG_LISTS)) == 0,
+                               GS_FRAME_SERIAL_LONG_LISTS | GS_FRAME_LONG_LISTS)) == 0,
                  "unknown flag bits");
     GS_CHECK_ARG(f->sort_mode >= 0 && f->sort_mode <= 2,
                  "sort_mode must be 0 (full LSD radix), 1 (tile-bit radix + per-tile LDS sort) or 2 (LDS counting sort "
@@ -366,6 +366,16 @@ extern "C" int gs_frame_stats_async(const gs_frame *f, int64_t *stats_host, gs_s
     GS_CHECK_ARG(stats_host != nullptr, "stats_host is null");
     gs_frame_ws ws = gs_frame_carve(f->workspace, f->N, f->max_pairs, f->width, f->height, f->color_dim, f->training);
     GS_HIP(hipMemcpyAsync(stats_host, ws.counters, sizeof(int64_t) * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int gs_frame_longest_list_async(const gs_frame *f, int64_t *longest_host, gs_stream_t stream) {
+    int rc = validate(f);
+    if (rc) return rc;
+    GS_CHECK_ARG(longest_host != nullptr, "longest_host is null");
+    gs_frame_ws ws = gs_frame_carve(f->workspace, f->N, f->max_pairs, f->width, f->height, f->color_dim, f->training);
+    GS_HIP(hipMemcpyAsync(longest_host, ws.counters + GS_CNT_MAXLIST, sizeof(int64_t), hipMemcpyDeviceToHost,
+                          (hipStream_t)stream));
     return 0;
 }
 

@@ -2,7 +2,7 @@
 #pragma once
 #include "gs_common.h"
 
-enum { GS_CNT_VISIBLE = 0, GS_CNT_PAIRS = 1, GS_CNT_OVERFLOW = 2, GS_CNT_BUCKETS = 3, GS_CNT_TICKET = 4, GS_CNT_ENTRIES = 5, GS_CNT_BIG = 6, GS_CNT_SEGS = 7, GS_CNT_GROUPS = 8, GS_CNT_N = 16 };
+enum { GS_CNT_VISIBLE = 0, GS_CNT_PAIRS = 1, GS_CNT_OVERFLOW = 2, GS_CNT_BUCKETS = 3, GS_CNT_TICKET = 4, GS_CNT_ENTRIES = 5, GS_CNT_BIG = 6, GS_CNT_SEGS = 7, GS_CNT_GROUPS = 8, GS_CNT_MAXLIST = 9, GS_CNT_N = 16 };
 
 #define GS_BUCKET 64          // Gaussians per backward bucket (= wavefront size)
 #define GS_SORT_TILE 2048     // keys per radix-sort workgroup (256 threads x 8)
@@ -62,6 +62,11 @@ static inline gs_bin_plan gs_bin_plan_for(int64_t N, int64_t max_pairs, int n_ti
 #define GS_SEG_LEN 1024       // Gaussians per segment (measured on a 100,000-Gaussian pile: 4096 / 2048: 1.02 ms, 2048 / 1024: 0.59 ms)
 #endif
 static inline bool gs_frame_is_dense(int64_t max_pairs, int n_tiles) { return max_pairs / (n_tiles > 0 ? n_tiles : 1) > GS_DENSE_AVG; }
+// the long-list kernels run in dense frames and wherever the caller asks for them (GS_FRAME_LONG_LISTS: it has seen a
+// long list in an earlier frame, gs_frame_longest_list_async)
+static inline bool gs_frame_long_lists(const gs_frame *f, int n_tiles) {
+    return gs_frame_is_dense(f->max_pairs, n_tiles) || (f->flags & GS_FRAME_LONG_LISTS) != 0;
+}
 static inline int64_t gs_seg_items_cap(int64_t max_pairs, int n_tiles) { return max_pairs / GS_SEG_LEN + n_tiles; }
 static inline int64_t gs_group_queue_cap(int64_t max_pairs, int n_tiles) { return max_pairs / 256 + 4 * (int64_t)n_tiles; }
 #define GS_STRIP_SORT_CAP 2048  // pairs strip_sort_kernel's LDS window holds (a half strip's four lists, or one list at a time)
@@ -228,7 +233,7 @@ static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pair
         ws.strip_base = (uint64_t *)take(sizeof(uint64_t) * ns);
         ws.big_tiles = (uint32_t *)take(sizeof(uint32_t) * (sp.ok ? (size_t)G.n_tiles : 1));
     }
-    if (gs_frame_is_dense(max_pairs, G.n_tiles)) {
+    if (gs_strip_plan_for(N, G.ntx, G.nty).ok) {  // the long-list kernels belong to the strip variant
         const size_t cap = (size_t)gs_seg_items_cap(max_pairs, G.n_tiles);
         ws.group_queue = (uint4 *)take(sizeof(uint4) * (size_t)gs_group_queue_cap(max_pairs, G.n_tiles));
         ws.cont_state = (float4 *)take(sizeof(float4) * 256 * (size_t)G.n_tiles);

@@ -833,7 +833,7 @@ int gs_stage_raster_forward(const gs_frame *f, const gs_frame_ws &ws, const uint
         G.vdy[i] = f->vec_dy[i];
     }
     // dense frames: tiles still alive after GS_LONG_MIN Gaussians hand the rest of their list to the segment kernels
-    const bool dense = gs_frame_is_dense(f->max_pairs, FG.n_tiles) && ws.cont_state != nullptr &&
+    const bool dense = gs_frame_long_lists(f, FG.n_tiles) && ws.cont_state != nullptr &&
                        !(f->flags & GS_FRAME_SERIAL_LONG_LISTS);
     float4 *cs = dense ? ws.cont_state : nullptr;
     uint32_t *cf = dense ? ws.cont_flag : nullptr;

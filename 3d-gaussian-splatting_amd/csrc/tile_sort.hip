@@ -634,7 +634,8 @@ __global__ void __launch_bounds__(256, STRIP_SORT_WPE) strip_sort_kernel(
     const uint64_t *__restrict__ strip_tot, const unsigned long long *__restrict__ counters,
     uint64_t *__restrict__ keys, uint32_t *__restrict__ ids, uint64_t *__restrict__ scratch,
     int32_t *__restrict__ ranges, gs_strip_geom SG, const float4 *__restrict__ rec_geom, GsDistCull D,
-    uint32_t *__restrict__ big_queue, unsigned long long *__restrict__ big_count) {
+    uint32_t *__restrict__ big_queue, unsigned long long *__restrict__ big_count,
+    unsigned long long *__restrict__ longest) {
     constexpr uint32_t W = GS_STRIP_W, WAVE_MAX = 512, ID_MASK = (1u << GS_STRIP_ID_BITS) - 1;
     static_assert(GS_STRIP_W == 8 || GS_STRIP_W == 4, "a workgroup owns four tiles: a strip or half a strip");
     __shared__ uint64_t s_a[CAP];
@@ -765,6 +766,8 @@ __global__ void __launch_bounds__(256, STRIP_SORT_WPE) strip_sort_kernel(
         s_tile[q] = valid ? tile : 0;
         s_start[q] = sq;
         s_n[q] = valid ? nq : 0;
+        // statistic for the caller (gs_frame_longest_list_async): rare, so the atomic costs nothing
+        if (valid && nq > (uint32_t)GS_DENSE_AVG) atomicMax(longest, (unsigned long long)nq);
     }
     if (total4 == 0) return;  // uniform
     // ---- 2. place (depth_bits << 32 | gaussian) and 3. sort.  A half strip of up to CAP pairs holds its four lists in
@@ -1230,16 +1233,16 @@ int gs_stage_strip_sort(const gs_frame *f, const gs_frame_ws &ws, const uint64_t
     // dense frame (the capacity allows an average list above half the LDS window): lists beyond the window are queued
     // for big_list_sort_kernel, one workgroup each; otherwise strip_sort_kernel sorts a rare long list itself and the
     // frame saves the launch
-    const bool dense = gs_frame_is_dense(f->max_pairs, G.n_tiles);
+    const bool dense = gs_frame_long_lists(f, G.n_tiles) && ws.big_tiles != nullptr;
     uint32_t *queue = dense ? ws.big_tiles : nullptr;
     if (f->tile_culling_method == 0)
         hipLaunchKernelGGL((strip_sort_kernel<STRIP_SORT_CAP_, true>), dim3(grid), dim3(256), 0, stream, entries,
                            ws.strip_base, ws.strip_tot, ws.counters, keys_out, ids_out, scratch, ws.tile_ranges,
-                           plan.geom, ws.rec_geom, D, queue, ws.counters + GS_CNT_BIG);
+                           plan.geom, ws.rec_geom, D, queue, ws.counters + GS_CNT_BIG, ws.counters + GS_CNT_MAXLIST);
     else
         hipLaunchKernelGGL((strip_sort_kernel<STRIP_SORT_CAP_, false>), dim3(grid), dim3(256), 0, stream, entries,
                            ws.strip_base, ws.strip_tot, ws.counters, keys_out, ids_out, scratch, ws.tile_ranges,
-                           plan.geom, ws.rec_geom, D, queue, ws.counters + GS_CNT_BIG);
+                           plan.geom, ws.rec_geom, D, queue, ws.counters + GS_CNT_BIG, ws.counters + GS_CNT_MAXLIST);
     GS_CHECK_LAUNCH();
     if (dense) {
         const uint32_t qcap = (uint32_t)gs_group_queue_cap(f->max_pairs, G.n_tiles);

@@ -35,6 +35,7 @@ class FrameStats:
     pairs: int  # M: (tile, Gaussian) pairs after duplication (clamped to capacity)
     overflow: int  # 0, or the true M when it exceeded the workspace capacity
     buckets: int  # 64-Gaussian buckets processed by the last backward
+    longest_list: int = 0  # longest tile list of the frame (lists of up to 1024 pairs are reported as 0)
 
 
 class FrameRenderer:
@@ -42,7 +43,7 @@ class FrameRenderer:
                  thresh: float = 0.05, scale_activation: str = "abs", auto_grow: bool = True,
                  sort_mode: int = 2, tile_culling_method: str = "prob2", tile_culling_dist_thresh: float = 0.5,
                  emit_sorted_keys: bool = False, slice_sort: bool = False, table_bin: bool = False,
-                 serial_long_lists: bool = False):
+                 serial_long_lists: bool = False, long_lists: Optional[bool] = None):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("FrameRenderer needs a HIP device; there is no CPU fallback")
@@ -59,6 +60,11 @@ class FrameRenderer:
         self.slice_sort = bool(slice_sort)  # sort_mode 2: the slice-sorted binning variant (GS_FRAME_SLICE_SORT)
         self.table_bin = bool(table_bin)  # sort_mode 2: the table variant instead of the default strip variant
         self.serial_long_lists = bool(serial_long_lists)  # dense frames: no segmented compositing of long tile lists
+        # GS_FRAME_LONG_LISTS (big-list sort + segmented compositing also in frames that are sparse on average): True /
+        # False, or None = as soon as an earlier frame of this renderer reported a tile list beyond 2048 pairs (the
+        # counters that auto_grow reads back anyway carry the longest list)
+        self.long_lists = long_lists
+        self._long_lists_seen = False
         self.max_pairs = int(max_pairs)
         self.training = bool(training)
         self.thresh = float(thresh)
@@ -69,14 +75,14 @@ class FrameRenderer:
         # head room as soon as the copy of an overflowed frame has landed (that one frame was rendered empty /
         # truncated); False: never check.
         self.auto_grow = auto_grow
-        self._async_host = torch.zeros(4, dtype=torch.int64).pin_memory()
+        self._async_host = torch.zeros(5, dtype=torch.int64).pin_memory()
         self._async_event: Optional[torch.cuda.Event] = None
         self.headroom = 1.25
         # 0: LSD radix on 64-bit keys, 1: tile-bit radix + per-tile LDS sort, 2: LDS counting sort by tile
         # + per-tile LDS sort (all three give the same list)
         self.sort_mode = int(sort_mode)
         self._ws: Optional[torch.Tensor] = None
-        self._stats_host = torch.zeros(4, dtype=torch.int64).pin_memory()
+        self._stats_host = torch.zeros(5, dtype=torch.int64).pin_memory()
         self._frame: Optional[_lib.GsFrame] = None
         self._frame_serial = 0  # counts forwards: autograd checks that backward() belongs to the latest one
         self._cam_cache = {}
@@ -139,7 +145,8 @@ class FrameRenderer:
         f.async_ = self._async
         f.flags = (_lib.GS_FRAME_EMIT_SORTED_KEYS if self.emit_sorted_keys else 0) | \
             (_lib.GS_FRAME_SLICE_SORT if self.slice_sort else 0) | (_lib.GS_FRAME_TABLE_BIN if self.table_bin else 0) | \
-            (_lib.GS_FRAME_SERIAL_LONG_LISTS if self.serial_long_lists else 0)
+            (_lib.GS_FRAME_SERIAL_LONG_LISTS if self.serial_long_lists else 0) | \
+            (_lib.GS_FRAME_LONG_LISTS if (self.long_lists or (self.long_lists is None and self._long_lists_seen)) else 0)
         f.training = int(training)
         f.sort_mode = self.sort_mode
         f.tile_culling_method = self.tile_culling_method
@@ -190,8 +197,9 @@ class FrameRenderer:
     def _poll_async_counters(self):
         """Counters of an earlier frame that have landed in pinned memory (no waiting)."""
         if self._async_event is not None and self._async_event.query():
-            v, m, o, b = (int(x) for x in self._async_host.tolist())
+            v, m, o, b, longest = (int(x) for x in self._async_host.tolist())
             self._async_event = None
+            self._long_lists_seen = self._long_lists_seen or longest > 2048
             if o:
                 self.overflowed_frames += 1
                 self._last_overflow_serial = self._async_serial
@@ -236,6 +244,8 @@ class FrameRenderer:
             if self.auto_grow == "async" and self._async_event is None:  # one copy in flight at a time
                 _lib.check(_lib.gs_frame_stats_async(C.byref(f), self._async_host.data_ptr(), stream),
                            "gs_frame_stats_async")
+                _lib.check(_lib.gs_frame_longest_list_async(C.byref(f), self._async_host.data_ptr() + 32, stream),
+                           "gs_frame_longest_list_async")
                 self._async_event = torch.cuda.Event()
                 self._async_event.record(self._stream())
                 self._async_serial = self._frame_serial
@@ -313,9 +323,12 @@ class FrameRenderer:
         stream = self._stream()
         _lib.check(_lib.gs_frame_stats_async(C.byref(self._frame), self._stats_host.data_ptr(), stream.cuda_stream),
                    "gs_frame_stats_async")
+        _lib.check(_lib.gs_frame_longest_list_async(C.byref(self._frame), self._stats_host.data_ptr() + 32,
+                                                    stream.cuda_stream), "gs_frame_longest_list_async")
         stream.synchronize()
-        v, m, o, b = (int(x) for x in self._stats_host.tolist())
-        return FrameStats(v, m, o, b)
+        v, m, o, b, longest = (int(x) for x in self._stats_host.tolist())
+        self._long_lists_seen = self._long_lists_seen or longest > 2048
+        return FrameStats(v, m, o, b, longest)
 
     def culling_mask(self) -> torch.Tensor:
         """[N] bool: the Gaussians of the last forward that passed the frustum test (the reference's

@@ -166,6 +166,12 @@ int gs_sort_pairs_bits(uint64_t *keys0, uint32_t *vals0, uint64_t *keys1, uint32
                                        such tiles (A/B and equivalence tests).  Same result up to the rounding of the
                                        transmittance entering a segment. */
 
+#define GS_FRAME_LONG_LISTS 16       /* run the long-list kernels (big-list sort, segmented compositing) although the frame's
+                                       capacity is below 1024 pairs per tile on average: for frames that are sparse on
+                                       average but hold a few very long lists (pile-ups of a degenerate densification
+                                       run).  The library cannot know without a host synchronisation; the caller can:
+                                       gs_frame_longest_list_async reports the longest list of an earlier frame. */
+
 /* Frame descriptor.  All scalars are per-camera constants computed on the host exactly as
  * splatter.py does (Tiles, RayInfo, frustum guard band); rot/tran are passed by value. */
 typedef struct gs_frame {
@@ -264,6 +270,11 @@ int gs_frame_backward_profile(const gs_frame *f, const float *grad_image, float 
  * `stats_host` (4 x int64: V visible, M pairs, overflow flag, processed buckets).  The
  * caller synchronises the stream before reading. */
 int gs_frame_stats_async(const gs_frame *f, int64_t *stats_host, gs_stream_t stream);
+
+/* Length of the longest tile list of the last forward on this workspace (sort_mode 2, strip variant; lists of up to
+ * 1024 pairs are reported as 0), copied device->host asynchronously into *longest_host.  A caller that sees a value
+ * above ~2048 in a frame whose capacity is below 1024 pairs per tile sets GS_FRAME_LONG_LISTS on the following frames. */
+int gs_frame_longest_list_async(const gs_frame *f, int64_t *longest_host, gs_stream_t stream);
 
 /* Read-only views into the workspace of the last forward (for parity tests): sorted keys
  * (u64 [M]; NULL for a sort_mode-2 frame rendered without GS_FRAME_EMIT_SORTED_KEYS -- they are

@@ -91,6 +91,36 @@ def test_frame_forward_giant_bucket_sorted_in_chunks(gpu, sort_mode):
     assert np.diff(of.accum).max() > 4096
 
 
+def test_long_list_kernels_follow_the_longest_list_statistic(gpu):
+    """A frame that is sparse on average (140 pairs per tile) with one 7,000-Gaussian pile: the capacity does not make
+    it a dense frame, so the first frame walks the pile with one wave; its counters report the longest list
+    (gs_frame_longest_list_async, read back with the stats), and the renderer sets GS_FRAME_LONG_LISTS from then on.
+    Images of the two paths agree; long_lists=False never switches."""
+    scene, cam = case(10_000, 256, 256, seed=37)
+    pile = np.arange(3000, 10_000)
+    rng = np.random.default_rng(2)
+    scene.pos[pile] = scene.pos[0] + rng.normal(scale=0.002, size=(len(pile), 3)).astype(np.float32)
+    scene.scale[pile] = np.float32(0.003)
+    scene.opa[pile] = -7.0
+    of = OracleFrame(scene, cam)
+    assert np.diff(of.accum).max() > 4096 and len(of.ids) / 256 < 1024
+    params = to_torch(scene, gpu)
+    auto = FrameRenderer(gpu, max_pairs=len(of.ids) + 64, auto_grow=True)
+    never = FrameRenderer(gpu, max_pairs=len(of.ids) + 64, auto_grow=True, long_lists=False)
+    first, _ = auto.forward(*params, cam)
+    assert auto.stats().longest_list == int(np.diff(of.accum).max()) and auto._long_lists_seen
+    second, _ = auto.forward(*params, cam)
+    assert auto._frame.flags & 16  # GS_FRAME_LONG_LISTS
+    ref, _ = never.forward(*params, cam)
+    ref2, _ = never.forward(*params, cam)
+    assert not (never._frame.flags & 16)
+    assert torch.equal(first, ref) and torch.equal(ref, ref2)
+    assert float((second - ref).abs().max()) < 1e-5
+    assert np.abs(second.cpu().numpy() - of.image).max() < 1e-3
+    v = auto.debug_views()
+    assert np.array_equal(v["sorted_ids"].cpu().numpy(), of.ids)
+
+
 @pytest.mark.parametrize("use_sh", [False, True])
 def test_long_lists_composited_in_segments(gpu, use_sh):
     """Dense frame with low-opacity pile-ups: every tile's pixels are still alive after 4096 Gaussians, so the rest
