@@ -653,13 +653,15 @@ __global__ void __launch_bounds__(256, STRIP_SORT_WPE) strip_sort_kernel(
     if (strip >= SG.NS) return;
     const uint32_t row = strip / SG.nsx, sx = strip - row * SG.nsx, tx0 = sx * W + half * 4;
     if (tx0 >= SG.ntx) return;  // the strip ends in its first half
-    if (counters[GS_CNT_OVERFLOW]) {  // the frame did not fit: every tile reads (0, 0)
+    // the three loads are independent: issued together, one memory round trip in front of the entries instead of two
+    const unsigned long long overflow = counters[GS_CNT_OVERFLOW];
+    const uint64_t base = strip_base[strip], tot = strip_tot[strip];
+    if (overflow) {  // the frame did not fit: every tile reads (0, 0)
         if (threadIdx.x < 4 && tx0 + threadIdx.x < SG.ntx)
             reinterpret_cast<int2 *>(ranges)[row * SG.ntx + tx0 + threadIdx.x] = make_int2(0, 0);
         return;
     }
-    const uint64_t base = strip_base[strip];
-    const uint32_t E = (uint32_t)(strip_tot[strip] >> 32), e0 = (uint32_t)(base >> 32), p0 = (uint32_t)base;
+    const uint32_t E = (uint32_t)(tot >> 32), e0 = (uint32_t)(base >> 32), p0 = (uint32_t)base;
     const uint64_t *ent = entries + e0;
     auto covers = [&](bool ok, uint32_t lo32, float2 xy, uint32_t j) {
         const uint32_t lx0 = lo32 >> 29, lx1 = (lo32 >> 26) & 7;  // [lx0, lx1]
