@@ -717,11 +717,14 @@ struct PixShCfg {
     static constexpr int NROW = 7 + CDIM;  // Sx Sy Sxx Sxy Syy Sq Sopa + the colour(-coefficient) sums
 };
 
+#ifndef GS_BWD_SH48_WPE
+#define GS_BWD_SH48_WPE 3
+#endif
 #ifndef GS_BWD_SH_WPE
 #define GS_BWD_SH_WPE 4  // waves per SIMD the register allocation aims at (A/B switch, tools/ab_variants.py)
 #endif
 template <int CDIM, bool FRAME>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CDIM == 48 ? 2 : GS_BWD_SH_WPE)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CDIM == 48 ? GS_BWD_SH48_WPE : GS_BWD_SH_WPE)))
 raster_backward_pixel_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
     constexpr int NB = PixShCfg<CDIM>::NB, NROW = PixShCfg<CDIM>::NROW;
     typedef float f2 __attribute__((ext_vector_type(2)));
