@@ -36,15 +36,20 @@ struct FwdSmem {  // SH: CDIM = 27 (degree 2) or 48 (degree 3) raw coefficients 
     static constexpr int NB = CDIM / 3;
     static constexpr int SHS = CDIM == 27 ? 28 : CDIM + 4;  // record stride: 16-byte rows, 4-way conflicts on the fill
     enum { X, Y, A, B, C, NLOP, NFIELD };
-    float f[2][NFIELD][CH] __attribute__((aligned(16)));
-    float sh[2][CH][SHS] __attribute__((aligned(16)));
+    // ONE buffer: the single wave stages chunk k + 1 after it has composited chunk k (LDS operations of a wave execute in
+    // order), and the coefficients are loaded in the iteration that consumes them anyway; a second buffer only halved
+    // the waves per SIMD (17 / 30 KiB per wave: 2 / 1 waves per SIMD for degree 2 / 3)
+    static constexpr int NBUF = 1;
+    float f[NBUF][NFIELD][CH] __attribute__((aligned(16)));
+    float sh[NBUF][CH][SHS] __attribute__((aligned(16)));
 };
 template <>
 struct FwdSmem<3> {
     // structure of arrays: four consecutive Gaussians of one field are one ds_read_b128
     static constexpr int CH = 64;
     enum { X, Y, A, B, C, NLOP, R, G, BL, NFIELD };  // NLOP = -log2(opacity)
-    float f[2][NFIELD][CH] __attribute__((aligned(16)));
+    static constexpr int NBUF = 2;
+    float f[NBUF][NFIELD][CH] __attribute__((aligned(16)));
 };
 
 __device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
@@ -84,8 +89,16 @@ __device__ __forceinline__ f2 live_mask(f2 t, f2 scale, f2 bias) {
 // chunk 0 of its NEXT tile, so the dependent id -> record gather latency (and the per-tile range load)
 // sits behind math instead of in front of it.  With one tile per wave all waves run their gather,
 // math and store phases in lockstep and the phases add up instead of overlapping.
+#ifndef GS_FWD_SH27_WPE
+#define GS_FWD_SH27_WPE 2  // waves per SIMD the register allocation of the SH kernels aims at (A/B switches)
+#endif
+#ifndef GS_FWD_SH48_WPE
+#define GS_FWD_SH48_WPE 2
+#endif
 template <int CDIM, bool FRAME, bool CKPT, bool SIG, bool WN>
-__global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S, RasterGeom G,
+__global__ void __launch_bounds__(FWD_THREADS)
+__attribute__((amdgpu_waves_per_eu(CDIM == 48 ? GS_FWD_SH48_WPE : CDIM == 27 ? GS_FWD_SH27_WPE : 1)))
+raster_forward_kernel(RasterSrc S, RasterGeom G,
                                                                     const int32_t *__restrict__ ranges,
                                                                     float *__restrict__ out_padded,
                                                                     float *__restrict__ out_image,
@@ -205,8 +218,8 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_forward_kernel(RasterSrc S
             }
             if (continues) break;
         }
-        const int buf = k & 1;  // two-deep ring: the wave is in program order, so writing buffer k&1 here
-                                // cannot overtake its own reads of two chunks ago
+        const int buf = k & (SM::NBUF - 1);  // no SH: two-deep ring (the wave is in program order, so writing buffer
+                                             // k & 1 here cannot overtake its own reads of two chunks ago)
         // Can a Gaussian of this chunk yield a non-finite alpha (or colour) for some pixel?  Not if its record is
         // finite and its conic positive semi-definite and of ordinary size: then q >= -(rounding of a few hundred) and
         // alpha = 2^-(q + nlop) stays finite (|dx|, |dy| < 4: visible Gaussians lie inside the guard band).  Only chunks
