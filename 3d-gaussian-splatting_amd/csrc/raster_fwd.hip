@@ -89,6 +89,9 @@ __device__ __forceinline__ f2 live_mask(f2 t, f2 scale, f2 bias) {
 // chunk 0 of its NEXT tile, so the dependent id -> record gather latency (and the per-tile range load)
 // sits behind math instead of in front of it.  With one tile per wave all waves run their gather,
 // math and store phases in lockstep and the phases add up instead of overlapping.
+#ifndef GS_FWD_RGB_WPE
+#define GS_FWD_RGB_WPE 1
+#endif
 #ifndef GS_FWD_SH27_WPE
 #define GS_FWD_SH27_WPE 2  // waves per SIMD the register allocation of the SH kernels aims at (A/B switches)
 #endif
@@ -97,7 +100,7 @@ __device__ __forceinline__ f2 live_mask(f2 t, f2 scale, f2 bias) {
 #endif
 template <int CDIM, bool FRAME, bool CKPT, bool SIG, bool WN>
 __global__ void __launch_bounds__(FWD_THREADS)
-__attribute__((amdgpu_waves_per_eu(CDIM == 48 ? GS_FWD_SH48_WPE : CDIM == 27 ? GS_FWD_SH27_WPE : 1)))
+__attribute__((amdgpu_waves_per_eu(CDIM == 48 ? GS_FWD_SH48_WPE : CDIM == 27 ? GS_FWD_SH27_WPE : GS_FWD_RGB_WPE)))
 raster_forward_kernel(RasterSrc S, RasterGeom G,
                                                                     const int32_t *__restrict__ ranges,
                                                                     float *__restrict__ out_padded,
