@@ -881,7 +881,6 @@ __global__ void __launch_bounds__(256, STRIP_SORT_WPE) strip_sort_kernel(
         return;
     }
     bool any_big = false;
-#pragma unroll
     for (uint32_t q = 0; q < 4; ++q) {  // the lists take turns in the LDS window (n is uniform)
         const uint32_t n = n4[q];
         if (n == 0) continue;
