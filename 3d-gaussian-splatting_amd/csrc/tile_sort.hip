@@ -778,8 +778,8 @@ __global__ void __launch_bounds__(256, STRIP_SORT_WPE) strip_sort_kernel(
     // CAP is placed in `scratch` and sorted by the per-tile code of the table variant.  (CAP = 4096 for the first case
     // alone measured slower: 32 KiB of LDS leave four workgroups per CU to hide the barriers of the merge levels.)
     const unsigned long long lt = (1ull << lane) - 1ull;
-    // QSEL < 0: all four tiles, tile q to dst[q]; else only tile QSEL, to dst[QSEL]
-    auto place = [&](int qsel, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3, bool lds, bool reload) {
+    // tile q of the set `qmask` goes to dst[q] (its wave's share of it)
+    auto place = [&](uint32_t qmask, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3, bool lds, bool reload) {
         uint32_t dst[4] = {d0 + wb4[0], d1 + wb4[1], d2 + wb4[2], d3 + wb4[3]};
         for (uint32_t c = 0; c < nchunk; ++c) {
             if (nchunk > 1 || reload) load_chunk(c);  // else: the single chunk is still in registers
@@ -793,7 +793,7 @@ __global__ void __launch_bounds__(256, STRIP_SORT_WPE) strip_sort_kernel(
                 const uint64_t key = (e & 0xffffffff00000000ull) | (lo32 & ID_MASK);
 #pragma unroll
                 for (uint32_t q = 0; q < 4; ++q) {
-                    if (qsel >= 0 && (uint32_t)qsel != q) continue;  // uniform
+                    if (!(qmask >> q & 1u)) continue;  // uniform
                     const bool cv = covers(ok, lo32, xy, half * 4 + q);
                     const unsigned long long b = __ballot(cv);
                     if (cv) {
@@ -849,7 +849,7 @@ __global__ void __launch_bounds__(256, STRIP_SORT_WPE) strip_sort_kernel(
     };
     const uint32_t tile0 = row * SG.ntx + tx0;
     if (total4 <= (uint32_t)CAP) {  // uniform
-        place(-1, loff4[0], loff4[1], loff4[2], loff4[3], true, false);
+        place(15u, loff4[0], loff4[1], loff4[2], loff4[3], true, false);
         __syncthreads();
         {  // short lists: one wave each, no workgroup barrier
             const uint32_t q = wave;
@@ -881,18 +881,27 @@ __global__ void __launch_bounds__(256, STRIP_SORT_WPE) strip_sort_kernel(
         return;
     }
     bool any_big = false;
-    for (uint32_t q = 0; q < 4; ++q) {  // the lists take turns in the LDS window (n is uniform)
+    for (uint32_t q = 0; q < 4; ++q) {  // the lists take turns in the LDS window, two at a time where they fit (uniform)
         const uint32_t n = n4[q];
         if (n == 0) continue;
         if (n > (uint32_t)CAP) {
-            place((int)q, start4[0], start4[1], start4[2], start4[3], false, true);
+            place(1u << q, start4[0], start4[1], start4[2], start4[3], false, true);
             any_big = true;
             continue;
         }
+        const uint32_t n2 = q + 1 < 4 ? n4[q + 1] : 0;
+        const bool pair = n2 > 0 && n + n2 <= (uint32_t)CAP;  // one pass over the entries serves both lists
         __syncthreads();  // the previous list has been stored
-        place((int)q, 0, 0, 0, 0, true, true);  // entries re-read (L2): 32 registers less across the sorts
+        // entries re-read (L2): 32 registers less across the sorts
+        // list q at the start of the window, list q + 1 (if paired) behind it
+        place(pair ? 3u << q : 1u << q, 0, q == 0 ? n : 0, q == 1 ? n : 0, q == 2 ? n : 0, true, true);
         __syncthreads();
         sort_store_by_workgroup(s_a, n, start4[q], tile0 + q);
+        if (pair) {
+            __syncthreads();
+            sort_store_by_workgroup(s_a + n, n2, start4[q + 1], tile0 + q + 1);
+            ++q;
+        }
     }
     if (any_big && big_queue) {  // dense frame: big_list_sort_kernel sorts the queued lists, one workgroup per list
         if (threadIdx.x < 4 && s_n[threadIdx.x] > (uint32_t)CAP)
