@@ -192,264 +192,6 @@ __device__ __forceinline__ void disperse_levels(uint64_t *a, uint32_t n, uint32_
     sync();
 }
 
-// Where a tile's unsorted pairs come from.
-//   SRC_KEYS   (sort_mode 1): keys = (tile << 32 | depth_bits) grouped by tile, ids = Gaussian index; both are
-//              overwritten in place with the depth-sorted order; scratch = idle half of the key buffer.
-//   SRC_PACKED (sort_mode 2, table variant): scratch = (depth_bits << 32 | gaussian) grouped by tile in arbitrary
-//              order; the sorted ids go to ids, the sorted (tile << 32 | depth_bits) to keys unless keys is NULL;
-//              long buckets sort in place.
-//   SRC_GATHER (sort_mode 2, slice-sorted variant): the pairs of tile t sit in S slice regions of `pairs`, region s
-//              holding them at [slice_base[s] + table[s][t], slice_base[s] + table[s][t + 1]); they are gathered
-//              into LDS while the tile is loaded (buckets beyond CAP: into scratch + start, then sorted there).
-enum { SRC_KEYS = 0, SRC_PACKED = 1, SRC_GATHER = 2 };
-struct GatherSrc {
-    const uint64_t *pairs;
-    const uint32_t *table;       // [S][T + 1]
-    const uint32_t *slice_base;  // [S]
-    uint32_t S, T;
-};
-
-// Sorts the (up to) four buckets `sel(q, tile, start, n)` names, q = 0 .. 3, with the 256 threads of the workgroup.
-// s_a: CAP keys of LDS; s_scan: 4 words; s_off: the SRC_GATHER offset table (filled by the caller).
-template <int CAP, int SRC, typename Sel>
-__device__ __forceinline__ void tile_sort_body(uint64_t *__restrict__ keys, uint32_t *__restrict__ ids,
-                                               uint64_t *__restrict__ scratch, Sel sel, const GatherSrc &GS,
-                                               uint64_t *s_a, uint32_t *s_scan, const uint32_t *s_off) {
-    constexpr bool PACKED = SRC != SRC_KEYS;  // the unsorted element already is (depth_bits << 32 | gaussian)
-    const int lane = threadIdx.x & 63;
-    const uint32_t wave = threadIdx.x >> 6;
-    uint32_t tile, start, n;
-    auto load = [&](uint32_t i) -> uint64_t {
-        return PACKED ? scratch[start + i] : (keys[start + i] << 32) | ids[start + i];
-    };
-    // PACKED: the sorted keys are only written on request (GS_FRAME_EMIT_SORTED_KEYS): the raster kernels read the
-    // sorted ids alone, and 8 of the 12 bytes this kernel would store per pair are the keys
-    auto store = [&](uint32_t i, uint64_t v) {
-#ifdef GS_DIAG_SCATTER_SMALL  // the scatter experiment leaves garbage pairs: keep the ids inside any scene >= 64 k
-        v &= 0xffffffff0000ffffull;
-#endif
-        ids[start + i] = (uint32_t)v;
-        if (!PACKED || keys) keys[start + i] = ((uint64_t)tile << 32) | (v >> 32);
-    };
-    uint32_t cur_q = 0;
-    auto select = [&](uint32_t q) {
-        cur_q = q;
-        sel(q, tile, start, n);
-    };
-    auto wave_sync = [] {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    };
-    // SRC_GATHER: copies the current tile's pairs from the S slice regions to dst[0 .. n) (any order: the sort that
-    // follows orders by the unique (depth_bits, gaussian)).  `nthreads` threads with index `tid` cooperate (one wave
-    // or the workgroup: `wg` selects the cross-wave prefix); the first pair of four slices per thread is in flight
-    // at a time (most (slice, tile) cells hold one or two pairs).
-    auto gather = [&](uint64_t *dst, uint32_t tid, uint32_t nthreads, bool wg) {
-        uint32_t filled = 0;
-        const uint32_t *o_lo = s_off + cur_q * GS.S, *o_hi = o_lo + GS.S;
-        for (uint32_t s0 = 0; s0 < GS.S; s0 += 4 * nthreads) {
-            uint32_t a[4], c[4], d[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t sl = s0 + q * nthreads + tid;
-                a[q] = c[q] = 0;
-                if (sl < GS.S) {
-                    a[q] = o_lo[sl];
-                    c[q] = o_hi[sl] - a[q];
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t incl = gs_wave_incl_scan_u32(c[q]);
-                uint32_t off = incl - c[q], total = __shfl(incl, 63, 64);
-                if (wg) {  // uniform: prefix over the four waves
-                    __syncthreads();
-                    if (lane == 63) s_scan[wave] = incl;
-                    __syncthreads();
-                    total = 0;
-#pragma unroll
-                    for (uint32_t w = 0; w < 4; ++w) {
-                        off += w < wave ? s_scan[w] : 0;
-                        total += s_scan[w];
-                    }
-                }
-                d[q] = filled + off;
-                filled += total;
-            }
-            uint64_t first[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) first[q] = c[q] ? GS.pairs[a[q]] : 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (c[q]) dst[d[q]] = first[q];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                for (uint32_t k = 1; k < c[q]; ++k) dst[d[q] + k] = GS.pairs[a[q] + k];
-        }
-    };
-    // loads window w of the current bucket into registers, sorts it, hands it to `out(e, key)`
-    auto sort_window_from = [&](auto in, uint32_t w, auto out) {
-        const uint32_t e0 = w * 128 + lane, e1 = e0 + 64;
-        uint64_t a0 = e0 < n ? in(e0) : KEY_INF, a1 = e1 < n ? in(e1) : KEY_INF;
-        sort_window(a0, a1, lane, n - w * 128 < 128 ? n - w * 128 : 128);
-        if (e0 < n) out(e0, a0);
-        if (e1 < n) out(e1, a1);
-    };
-
-    // 1. one wave per short bucket (<= CAP/4 keys), four buckets per workgroup, no workgroup barrier
-    select(wave);
-    if (n >= (PACKED ? 1u : 2u) && n <= (uint32_t)CAP / 4) {
-        uint64_t *a = s_a + wave * (CAP / 4);
-        if (SRC == SRC_GATHER) {
-            gather(a, (uint32_t)lane, 64u, false);
-            wave_sync();
-        }
-        auto from_lds = [&](uint32_t e) -> uint64_t { return a[e]; };
-        if (n <= 128) {  // registers only (SRC_GATHER: through the wave's LDS window)
-            if (SRC == SRC_GATHER)
-                sort_window_from(from_lds, 0, store);
-            else
-                sort_window_from(load, 0, store);
-        } else {
-            const uint32_t nwin = (n + 127) / 128;
-            for (uint32_t w = 0; w < nwin; ++w) {
-                if (SRC == SRC_GATHER)
-                    sort_window_from(from_lds, w, [&](uint32_t e, uint64_t v) { a[e] = v; });
-                else
-                    sort_window_from(load, w, [&](uint32_t e, uint64_t v) { a[e] = v; });
-            }
-            wave_sync();
-            uint32_t P = 256;
-            while (P < n) P <<= 1;
-            merge_levels(a, n, P, (uint32_t)lane, 64u, wave_sync);
-            for (uint32_t i = lane; i < n; i += 64) store(i, a[i]);
-        }
-    }
-    // 2. long buckets, one after the other, by the whole workgroup (n is uniform => so are the barriers)
-    for (uint32_t q = 0; q < 4; ++q) {
-        select(q);
-        if (n <= (uint32_t)CAP / 4) continue;
-        __syncthreads();
-        uint32_t P = 256;
-        while (P < n) P <<= 1;
-        if (n <= (uint32_t)CAP) {
-            const uint32_t nwin = (n + 127) / 128;
-            if (SRC == SRC_GATHER) {
-                gather(s_a, threadIdx.x, 256u, true);
-                __syncthreads();
-                for (uint32_t w = wave; w < nwin; w += 4)
-                    sort_window_from([&](uint32_t e) -> uint64_t { return s_a[e]; }, w,
-                                     [&](uint32_t e, uint64_t v) { s_a[e] = v; });
-            } else {
-                for (uint32_t w = wave; w < nwin; w += 4)
-                    sort_window_from(load, w, [&](uint32_t e, uint64_t v) { s_a[e] = v; });
-            }
-            __syncthreads();
-            merge_levels(s_a, n, P, threadIdx.x, 256u, [] { __syncthreads(); });
-            for (uint32_t i = threadIdx.x; i < n; i += 256) store(i, s_a[i]);
-        } else {
-            // The bucket does not fit the LDS window: sort it CAP keys at a time in LDS, then finish the merge levels
-            // k = 2 CAP, 4 CAP, .. with their strides >= CAP through global memory (the bucket stays in L2) and
-            // everything below per chunk in LDS / registers again.  (A first version ran the whole network through
-            // global memory: 4.9 ms per frame at 3,500 pairs per tile; this path: see DESIGN.md.)
-            uint64_t *a = scratch + start;  // PACKED: in place; else the idle half of the key buffer
-            if (SRC == SRC_GATHER)
-                gather(a, threadIdx.x, 256u, true);
-            else if (!PACKED)
-                for (uint32_t i = threadIdx.x; i < n; i += 256) a[i] = load(i);
-            __syncthreads();
-            auto block_sync = [] { __syncthreads(); };
-            const uint32_t nchunk = (n + CAP - 1) / CAP;
-            auto chunk_in = [&](uint32_t c) {
-                const uint32_t cnt = n - c * CAP < (uint32_t)CAP ? n - c * CAP : (uint32_t)CAP;
-                for (uint32_t i = threadIdx.x; i < cnt; i += 256) s_a[i] = a[c * CAP + i];
-                __syncthreads();
-                return cnt;
-            };
-            auto chunk_out = [&](uint32_t c, uint32_t cnt, bool final) {
-                for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
-                    if (final)
-                        store(c * CAP + i, s_a[i]);
-                    else
-                        a[c * CAP + i] = s_a[i];
-                }
-                __syncthreads();
-            };
-            for (uint32_t c = 0; c < nchunk; ++c) {  // every chunk sorted on its own
-                const uint32_t cnt = chunk_in(c);
-                const uint32_t nwin = (cnt + 127) / 128;
-                for (uint32_t w = wave; w < nwin; w += 4) {
-                    const uint32_t e0 = w * 128 + lane, e1 = e0 + 64;
-                    uint64_t a0 = e0 < cnt ? s_a[e0] : KEY_INF, a1 = e1 < cnt ? s_a[e1] : KEY_INF;
-                    sort_window(a0, a1, lane, cnt - w * 128 < 128 ? cnt - w * 128 : 128);
-                    if (e0 < cnt) s_a[e0] = a0;
-                    if (e1 < cnt) s_a[e1] = a1;
-                }
-                __syncthreads();
-                uint32_t Pc = 256;
-                while (Pc < cnt) Pc <<= 1;
-                merge_levels(s_a, cnt, Pc, threadIdx.x, 256u, block_sync);
-                chunk_out(c, cnt, false);
-            }
-            for (uint32_t k = 2 * CAP; k <= P; k <<= 1) {
-                const uint32_t hk = k >> 1;
-                for (uint32_t t = threadIdx.x; t < (P >> 1); t += 256)  // flip, through global memory
-                    cmpx(a, (t / hk) * k + (t % hk), (t / hk) * k + (k - 1) - (t % hk), n);
-                __syncthreads();
-                for (uint32_t j = hk >> 1; j >= (uint32_t)CAP; j >>= 1) {  // strides that cross chunks
-                    for (uint32_t t = threadIdx.x; t < (P >> 1); t += 256) {
-                        const uint32_t lo = (t / j) * 2 * j + (t % j);
-                        cmpx(a, lo, lo + j, n);
-                    }
-                    __syncthreads();
-                }
-                for (uint32_t c = 0; c < nchunk; ++c) {  // strides CAP/2 .. 1 inside every chunk
-                    const uint32_t cnt = chunk_in(c);
-                    disperse_levels(s_a, cnt, CAP / 2, threadIdx.x, 256u, block_sync);
-                    chunk_out(c, cnt, k == P);
-                }
-            }
-        }
-    }
-}
-
-template <int CAP, int SRC>
-__global__ void __launch_bounds__(256) tile_sort_kernel(uint64_t *__restrict__ keys, uint32_t *__restrict__ ids,
-                                                       uint64_t *__restrict__ scratch,
-                                                       const int32_t *__restrict__ ranges, uint32_t n_tiles,
-                                                       GatherSrc GS) {
-    __shared__ uint64_t s_a[CAP];
-    __shared__ uint32_t s_scan[4];
-    // SRC_GATHER: where the pairs of this workgroup's four tiles start in every slice region (absolute index into
-    // `pairs`), tiles t0 .. t0 + 4 (the fifth column closes the fourth tile): row j holds S entries.  Loaded once per
-    // workgroup -- thread = slice, five consecutive words of its table row: ONE cache line per slice for all four
-    // tiles -- instead of two scattered 4-byte reads per slice and tile.
-    __shared__ uint32_t s_off[SRC == SRC_GATHER ? 5 * GS_BIN_MAX_SLICES : 1];
-    if (SRC == SRC_GATHER) {
-        const uint32_t t0 = blockIdx.x * 4;
-        const size_t stride = (size_t)GS.T + 1;
-        for (uint32_t sl = threadIdx.x; sl < GS.S; sl += 256) {
-            const uint32_t *r = GS.table + sl * stride;
-            const uint32_t b = GS.slice_base[sl];
-#pragma unroll
-            for (uint32_t j = 0; j < 5; ++j) s_off[j * GS.S + sl] = b + r[t0 + j < GS.T ? t0 + j : GS.T];
-        }
-        __syncthreads();
-    }
-    tile_sort_body<CAP, SRC>(
-        keys, ids, scratch,
-        [&](uint32_t q, uint32_t &tile, uint32_t &start, uint32_t &n) {
-            tile = blockIdx.x * 4 + q;
-            start = n = 0;
-            if (tile < n_tiles) {
-                start = (uint32_t)ranges[2 * tile];
-                n = (uint32_t)ranges[2 * tile + 1] - start;
-            }
-        },
-        GS, s_a, s_scan, s_off);
-
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // Distribution sort of the list a[0 .. n) in LDS by the unique key (depth_bits << 32 | gaussian), result handed to
 // store(position, key).  The bitonic network above costs ~55 compare-exchange stages of 64-bit keys per element at
@@ -614,6 +356,252 @@ __device__ __forceinline__ void bucket_sort_store(uint64_t *a, uint32_t n, uint3
             for (uint32_t j = tid; j < m; j += nthreads) store(bs + j, b[j]);
         }
     }
+}
+
+// Where a tile's unsorted pairs come from.
+//   SRC_KEYS   (sort_mode 1): keys = (tile << 32 | depth_bits) grouped by tile, ids = Gaussian index; both are
+//              overwritten in place with the depth-sorted order; scratch = idle half of the key buffer.
+//   SRC_PACKED (sort_mode 2, table variant): scratch = (depth_bits << 32 | gaussian) grouped by tile in arbitrary
+//              order; the sorted ids go to ids, the sorted (tile << 32 | depth_bits) to keys unless keys is NULL;
+//              long buckets sort in place.
+//   SRC_GATHER (sort_mode 2, slice-sorted variant): the pairs of tile t sit in S slice regions of `pairs`, region s
+//              holding them at [slice_base[s] + table[s][t], slice_base[s] + table[s][t + 1]); they are gathered
+//              into LDS while the tile is loaded (buckets beyond CAP: into scratch + start, then sorted there).
+enum { SRC_KEYS = 0, SRC_PACKED = 1, SRC_GATHER = 2 };
+struct GatherSrc {
+    const uint64_t *pairs;
+    const uint32_t *table;       // [S][T + 1]
+    const uint32_t *slice_base;  // [S]
+    uint32_t S, T;
+};
+
+// Sorts the (up to) four buckets `sel(q, tile, start, n)` names, q = 0 .. 3, with the 256 threads of the workgroup.
+// s_a: CAP keys of LDS; s_scan: 4 words; s_off: the SRC_GATHER offset table (filled by the caller).
+template <int CAP, int SRC, typename Sel>
+__device__ __forceinline__ void tile_sort_body(uint64_t *__restrict__ keys, uint32_t *__restrict__ ids,
+                                               uint64_t *__restrict__ scratch, Sel sel, const GatherSrc &GS,
+                                               uint64_t *s_a, uint32_t *s_scan, const uint32_t *s_off,
+                                               uint32_t *s_bcnt, uint32_t *s_wl, uint32_t *s_red) {
+    static_assert(CAP == 2048, "the distribution sort holds eight keys per thread: 512 per wave, 2048 per workgroup");
+    constexpr bool PACKED = SRC != SRC_KEYS;  // the unsorted element already is (depth_bits << 32 | gaussian)
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = threadIdx.x >> 6;
+    uint32_t tile, start, n;
+    auto load = [&](uint32_t i) -> uint64_t {
+        return PACKED ? scratch[start + i] : (keys[start + i] << 32) | ids[start + i];
+    };
+    // PACKED: the sorted keys are only written on request (GS_FRAME_EMIT_SORTED_KEYS): the raster kernels read the
+    // sorted ids alone, and 8 of the 12 bytes this kernel would store per pair are the keys
+    auto store = [&](uint32_t i, uint64_t v) {
+#ifdef GS_DIAG_SCATTER_SMALL  // the scatter experiment leaves garbage pairs: keep the ids inside any scene >= 64 k
+        v &= 0xffffffff0000ffffull;
+#endif
+        ids[start + i] = (uint32_t)v;
+        if (!PACKED || keys) keys[start + i] = ((uint64_t)tile << 32) | (v >> 32);
+    };
+    uint32_t cur_q = 0;
+    auto select = [&](uint32_t q) {
+        cur_q = q;
+        sel(q, tile, start, n);
+    };
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    // SRC_GATHER: copies the current tile's pairs from the S slice regions to dst[0 .. n) (any order: the sort that
+    // follows orders by the unique (depth_bits, gaussian)).  `nthreads` threads with index `tid` cooperate (one wave
+    // or the workgroup: `wg` selects the cross-wave prefix); the first pair of four slices per thread is in flight
+    // at a time (most (slice, tile) cells hold one or two pairs).
+    auto gather = [&](uint64_t *dst, uint32_t tid, uint32_t nthreads, bool wg) {
+        uint32_t filled = 0;
+        const uint32_t *o_lo = s_off + cur_q * GS.S, *o_hi = o_lo + GS.S;
+        for (uint32_t s0 = 0; s0 < GS.S; s0 += 4 * nthreads) {
+            uint32_t a[4], c[4], d[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t sl = s0 + q * nthreads + tid;
+                a[q] = c[q] = 0;
+                if (sl < GS.S) {
+                    a[q] = o_lo[sl];
+                    c[q] = o_hi[sl] - a[q];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t incl = gs_wave_incl_scan_u32(c[q]);
+                uint32_t off = incl - c[q], total = __shfl(incl, 63, 64);
+                if (wg) {  // uniform: prefix over the four waves
+                    __syncthreads();
+                    if (lane == 63) s_scan[wave] = incl;
+                    __syncthreads();
+                    total = 0;
+#pragma unroll
+                    for (uint32_t w = 0; w < 4; ++w) {
+                        off += w < wave ? s_scan[w] : 0;
+                        total += s_scan[w];
+                    }
+                }
+                d[q] = filled + off;
+                filled += total;
+            }
+            uint64_t first[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) first[q] = c[q] ? GS.pairs[a[q]] : 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (c[q]) dst[d[q]] = first[q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                for (uint32_t k = 1; k < c[q]; ++k) dst[d[q] + k] = GS.pairs[a[q] + k];
+        }
+    };
+    // loads window w of the current bucket into registers, sorts it, hands it to `out(e, key)`
+    auto sort_window_from = [&](auto in, uint32_t w, auto out) {
+        const uint32_t e0 = w * 128 + lane, e1 = e0 + 64;
+        uint64_t a0 = e0 < n ? in(e0) : KEY_INF, a1 = e1 < n ? in(e1) : KEY_INF;
+        sort_window(a0, a1, lane, n - w * 128 < 128 ? n - w * 128 : 128);
+        if (e0 < n) out(e0, a0);
+        if (e1 < n) out(e1, a1);
+    };
+
+    // 1. one wave per short bucket (<= CAP/4 keys), four buckets per workgroup, no workgroup barrier
+    select(wave);
+    if (n >= (PACKED ? 1u : 2u) && n <= (uint32_t)CAP / 4) {
+        uint64_t *a = s_a + wave * (CAP / 4);
+        if (SRC == SRC_GATHER) {
+            gather(a, (uint32_t)lane, 64u, false);
+            wave_sync();
+        }
+        auto from_lds = [&](uint32_t e) -> uint64_t { return a[e]; };
+        if (n <= 128) {  // registers only (SRC_GATHER: through the wave's LDS window)
+            if (SRC == SRC_GATHER)
+                sort_window_from(from_lds, 0, store);
+            else
+                sort_window_from(load, 0, store);
+        } else {  // the distribution sort (bucket_sort_store) on the wave's LDS window
+            if (SRC != SRC_GATHER) {
+                for (uint32_t i = lane; i < n; i += 64) a[i] = load(i);
+                wave_sync();
+            }
+            bucket_sort_store(a, n, s_bcnt + wave * 513, s_wl + wave * 257, s_red, (uint32_t)lane, 64u, wave_sync, store);
+        }
+    }
+    // 2. long buckets, one after the other, by the whole workgroup (n is uniform => so are the barriers)
+    for (uint32_t q = 0; q < 4; ++q) {
+        select(q);
+        if (n <= (uint32_t)CAP / 4) continue;
+        __syncthreads();
+        uint32_t P = 256;
+        while (P < n) P <<= 1;
+        if (n <= (uint32_t)CAP) {
+            if (SRC == SRC_GATHER)
+                gather(s_a, threadIdx.x, 256u, true);
+            else
+                for (uint32_t i = threadIdx.x; i < n; i += 256) s_a[i] = load(i);
+            __syncthreads();
+            bucket_sort_store(s_a, n, s_bcnt, s_wl, s_red, threadIdx.x, 256u, [] { __syncthreads(); }, store);
+        } else {
+            // The bucket does not fit the LDS window: sort it CAP keys at a time in LDS, then finish the merge levels
+            // k = 2 CAP, 4 CAP, .. with their strides >= CAP through global memory (the bucket stays in L2) and
+            // everything below per chunk in LDS / registers again.  (A first version ran the whole network through
+            // global memory: 4.9 ms per frame at 3,500 pairs per tile; this path: see DESIGN.md.)
+            uint64_t *a = scratch + start;  // PACKED: in place; else the idle half of the key buffer
+            if (SRC == SRC_GATHER)
+                gather(a, threadIdx.x, 256u, true);
+            else if (!PACKED)
+                for (uint32_t i = threadIdx.x; i < n; i += 256) a[i] = load(i);
+            __syncthreads();
+            auto block_sync = [] { __syncthreads(); };
+            const uint32_t nchunk = (n + CAP - 1) / CAP;
+            auto chunk_in = [&](uint32_t c) {
+                const uint32_t cnt = n - c * CAP < (uint32_t)CAP ? n - c * CAP : (uint32_t)CAP;
+                for (uint32_t i = threadIdx.x; i < cnt; i += 256) s_a[i] = a[c * CAP + i];
+                __syncthreads();
+                return cnt;
+            };
+            auto chunk_out = [&](uint32_t c, uint32_t cnt, bool final) {
+                for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
+                    if (final)
+                        store(c * CAP + i, s_a[i]);
+                    else
+                        a[c * CAP + i] = s_a[i];
+                }
+                __syncthreads();
+            };
+            for (uint32_t c = 0; c < nchunk; ++c) {  // every chunk sorted on its own
+                const uint32_t cnt = chunk_in(c);
+                const uint32_t nwin = (cnt + 127) / 128;
+                for (uint32_t w = wave; w < nwin; w += 4) {
+                    const uint32_t e0 = w * 128 + lane, e1 = e0 + 64;
+                    uint64_t a0 = e0 < cnt ? s_a[e0] : KEY_INF, a1 = e1 < cnt ? s_a[e1] : KEY_INF;
+                    sort_window(a0, a1, lane, cnt - w * 128 < 128 ? cnt - w * 128 : 128);
+                    if (e0 < cnt) s_a[e0] = a0;
+                    if (e1 < cnt) s_a[e1] = a1;
+                }
+                __syncthreads();
+                uint32_t Pc = 256;
+                while (Pc < cnt) Pc <<= 1;
+                merge_levels(s_a, cnt, Pc, threadIdx.x, 256u, block_sync);
+                chunk_out(c, cnt, false);
+            }
+            for (uint32_t k = 2 * CAP; k <= P; k <<= 1) {
+                const uint32_t hk = k >> 1;
+                for (uint32_t t = threadIdx.x; t < (P >> 1); t += 256)  // flip, through global memory
+                    cmpx(a, (t / hk) * k + (t % hk), (t / hk) * k + (k - 1) - (t % hk), n);
+                __syncthreads();
+                for (uint32_t j = hk >> 1; j >= (uint32_t)CAP; j >>= 1) {  // strides that cross chunks
+                    for (uint32_t t = threadIdx.x; t < (P >> 1); t += 256) {
+                        const uint32_t lo = (t / j) * 2 * j + (t % j);
+                        cmpx(a, lo, lo + j, n);
+                    }
+                    __syncthreads();
+                }
+                for (uint32_t c = 0; c < nchunk; ++c) {  // strides CAP/2 .. 1 inside every chunk
+                    const uint32_t cnt = chunk_in(c);
+                    disperse_levels(s_a, cnt, CAP / 2, threadIdx.x, 256u, block_sync);
+                    chunk_out(c, cnt, k == P);
+                }
+            }
+        }
+    }
+}
+
+template <int CAP, int SRC>
+__global__ void __launch_bounds__(256) tile_sort_kernel(uint64_t *__restrict__ keys, uint32_t *__restrict__ ids,
+                                                       uint64_t *__restrict__ scratch,
+                                                       const int32_t *__restrict__ ranges, uint32_t n_tiles,
+                                                       GatherSrc GS) {
+    __shared__ uint64_t s_a[CAP];
+    __shared__ uint32_t s_scan[4];
+    // SRC_GATHER: where the pairs of this workgroup's four tiles start in every slice region (absolute index into
+    // `pairs`), tiles t0 .. t0 + 4 (the fifth column closes the fourth tile): row j holds S entries.  Loaded once per
+    // workgroup -- thread = slice, five consecutive words of its table row: ONE cache line per slice for all four
+    // tiles -- instead of two scattered 4-byte reads per slice and tile.
+    __shared__ uint32_t s_off[SRC == SRC_GATHER ? 5 * GS_BIN_MAX_SLICES : 1];
+    __shared__ uint32_t s_bcnt[4 * 513 + 4], s_wl[4 * 257], s_red[16];  // distribution sort (bucket_sort_store)
+    if (SRC == SRC_GATHER) {
+        const uint32_t t0 = blockIdx.x * 4;
+        const size_t stride = (size_t)GS.T + 1;
+        for (uint32_t sl = threadIdx.x; sl < GS.S; sl += 256) {
+            const uint32_t *r = GS.table + sl * stride;
+            const uint32_t b = GS.slice_base[sl];
+#pragma unroll
+            for (uint32_t j = 0; j < 5; ++j) s_off[j * GS.S + sl] = b + r[t0 + j < GS.T ? t0 + j : GS.T];
+        }
+        __syncthreads();
+    }
+    tile_sort_body<CAP, SRC>(
+        keys, ids, scratch,
+        [&](uint32_t q, uint32_t &tile, uint32_t &start, uint32_t &n) {
+            tile = blockIdx.x * 4 + q;
+            start = n = 0;
+            if (tile < n_tiles) {
+                start = (uint32_t)ranges[2 * tile];
+                n = (uint32_t)ranges[2 * tile + 1] - start;
+            }
+        },
+        GS, s_a, s_scan, s_off, s_bcnt, s_wl, s_red);
+
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -917,7 +905,7 @@ __global__ void __launch_bounds__(256, STRIP_SORT_WPE) strip_sort_kernel(
                 start = s_start[q];
                 n = s_n[q] > (uint32_t)CAP ? s_n[q] : 0;
             },
-            GatherSrc{}, s_a, s_scan, nullptr);
+            GatherSrc{}, s_a, s_scan, nullptr, s_bcnt, &s_wl[0][0], s_red);
     }
 }
 
@@ -1005,7 +993,7 @@ __global__ void __launch_bounds__(256) big_list_sort_kernel(const uint32_t *__re
     static_assert(CAP == 2048, "groups are loaded eight keys per thread");
     __shared__ uint64_t s_a[CAP];
     __shared__ uint32_t s_scan[4];
-    __shared__ uint32_t s_bcnt[256 * 8 + 4], s_wl[1 + 2 * 128], s_red[16];
+    __shared__ uint32_t s_bcnt[256 * 8 + 4], s_wl[4 * 257], s_red[16];
     __shared__ uint32_t s_bin[NBIN + 1];     // first key of every bin (relative to the range)
     __shared__ uint32_t s_gstart[NBIN + 2];  // first bin of every group
     __shared__ uint64_t s_mm[8];
@@ -1186,7 +1174,7 @@ __global__ void __launch_bounds__(256) big_list_sort_kernel(const uint32_t *__re
                             s_ = r0 + gs0;
                             n_ = qq == 0 ? m : 0;
                         },
-                        GatherSrc{}, s_a, s_scan, nullptr);
+                        GatherSrc{}, s_a, s_scan, nullptr, s_bcnt, s_wl, s_red);
                     __syncthreads();
                 }
             }
