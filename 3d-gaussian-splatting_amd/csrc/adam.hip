@@ -45,7 +45,14 @@ __global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ param, co
                                                    int64_t lo, int64_t hi, AdamGroups G, float one_m_b1, float b2,
                                                    float one_m_b2, float inv_bc2_sqrt, float eps,
                                                    float *__restrict__ stat, int64_t stat_begin, int64_t stat_end,
-                                                   int stat_mode) {
+                                                   int stat_mode, int64_t moment_base,
+                                                   const unsigned long long *__restrict__ skip_if_nonzero) {
+    // a frame that overflowed its workspace was rendered empty: its all-zero gradient must not move the parameters by
+    // momentum (the flag is the frame's device-side overflow counter: no host synchronisation; uniform branch)
+    if (skip_if_nonzero && *skip_if_nonzero) return;
+    // the moments may be a SHARD that starts at element moment_base (a multiple of 4) of the flat index space
+    exp_avg -= moment_base;
+    exp_avg_sq -= moment_base;
     // elements [lo, hi) of the (16-byte aligned) arrays: whole float4s [q0, q1) + up to three scalars at either end
     const int64_t q0 = (lo + 3) >> 2, q1 = hi >> 2;
     for (int64_t q = q0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < q1; q += (int64_t)gridDim.x * blockDim.x) {
@@ -124,9 +131,12 @@ extern "C" int gs_grad_stat_update(const float *grad, float *stat, int64_t n, in
 static int adam_step_impl(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
                           int64_t range_begin, int64_t range_end, int32_t n_groups, const int64_t *group_end,
                           const float *lr, float beta1, float beta2, float eps, int64_t step, float *grad_stat,
-                          int64_t stat_begin, int64_t stat_end, int32_t stat_mode, gs_stream_t stream) {
+                          int64_t stat_begin, int64_t stat_end, int32_t stat_mode, gs_stream_t stream,
+                          int64_t moment_base = 0, const unsigned long long *skip_if_nonzero = nullptr) {
     GS_CHECK_ARG(n >= 0, "n < 0");
     GS_CHECK_ARG(range_begin >= 0 && range_begin <= range_end && range_end <= n, "bad element range");
+    GS_CHECK_ARG(moment_base >= 0 && (moment_base & 3) == 0 && moment_base <= range_begin,
+                 "moment_base must be a multiple of 4 and <= range_begin");
     GS_CHECK_ARG(n_groups >= 1 && n_groups <= GS_ADAM_MAX_GROUPS, "n_groups must be in [1, 8]");
     GS_CHECK_ARG(group_end && lr, "null group table");
     GS_CHECK_ARG(step >= 1, "step counts from 1 (torch.optim.Adam increments before the update)");
@@ -156,7 +166,8 @@ static int adam_step_impl(float *param, const float *grad, float *exp_avg, float
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
                        exp_avg_sq, range_begin, range_end, G, 1.0f - beta1, beta2, 1.0f - beta2,
-                       (float)(1.0 / sqrt(bc2)), eps, grad_stat, stat_begin, stat_end, (int)stat_mode);
+                       (float)(1.0 / sqrt(bc2)), eps, grad_stat, stat_begin, stat_end, (int)stat_mode, moment_base,
+                       skip_if_nonzero);
     GS_CHECK_LAUNCH();
     return 0;
 }
@@ -176,4 +187,20 @@ extern "C" int gs_adam_step_range(float *param, const float *grad, float *exp_av
                                   gs_stream_t stream) {
     return adam_step_impl(param, grad, exp_avg, exp_avg_sq, n, range_begin, range_end, n_groups, group_end, lr, beta1,
                           beta2, eps, step, grad_stat, stat_begin, stat_end, stat_mode, stream);
+}
+
+// View-parallel training with a SHARDED optimizer (gs_dp.py, exchange = "reduce_scatter"): this rank owns elements
+// [range_begin, range_end) of the flat index space and keeps only THEIR moments -- exp_avg[0] / exp_avg_sq[0] belong to
+// element moment_base (a multiple of 4, <= range_begin) -- so the optimizer state and its traffic shrink by the world
+// size.  `skip_if_nonzero` (may be NULL): device address of a counter; when it is non-zero the launch does nothing (a
+// frame that overflowed its workspace was rendered empty: its zero gradient must not move parameters by momentum).
+extern "C" int gs_adam_step_sharded(float *param, const float *grad, float *exp_avg_shard, float *exp_avg_sq_shard,
+                                    int64_t n, int64_t range_begin, int64_t range_end, int64_t moment_base,
+                                    int32_t n_groups, const int64_t *group_end, const float *lr, float beta1,
+                                    float beta2, float eps, int64_t step, float *grad_stat, int64_t stat_begin,
+                                    int64_t stat_end, int32_t stat_mode, const void *skip_if_nonzero,
+                                    gs_stream_t stream) {
+    return adam_step_impl(param, grad, exp_avg_shard, exp_avg_sq_shard, n, range_begin, range_end, n_groups, group_end,
+                          lr, beta1, beta2, eps, step, grad_stat, stat_begin, stat_end, stat_mode, stream, moment_base,
+                          (const unsigned long long *)skip_if_nonzero);
 }

@@ -92,11 +92,7 @@ static int effective_sort_mode(const gs_frame *f) {
 
 // sort_mode 2 runs the strip variant (strip_bin.hip) unless the caller asks for one of the others or the frame is
 // outside its limits (2^26 Gaussians, GS_STRIP_MAX strips).
-static bool use_strip_variant(const gs_frame *f) {
-    if (f->flags & (GS_FRAME_SLICE_SORT | GS_FRAME_TABLE_BIN)) return false;
-    gs_frame_geom G = gs_frame_geometry(f);
-    return gs_strip_plan_for(f->N, G.ntx, G.nty).ok != 0;
-}
+static bool use_strip_variant(const gs_frame *f) { return gs_frame_uses_strips(f); }
 
 // Which double-buffer half holds the sorted (keys, ids) after the radix passes of this mode.
 static int sort_passes(const gs_frame *f) {
@@ -366,6 +362,15 @@ extern "C" int gs_frame_stats_async(const gs_frame *f, int64_t *stats_host, gs_s
     GS_CHECK_ARG(stats_host != nullptr, "stats_host is null");
     gs_frame_ws ws = gs_frame_carve(f->workspace, f->N, f->max_pairs, f->width, f->height, f->color_dim, f->training);
     GS_HIP(hipMemcpyAsync(stats_host, ws.counters, sizeof(int64_t) * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int gs_frame_overflow_flag(const gs_frame *f, const void **device_counter) {
+    int rc = validate(f);
+    if (rc) return rc;
+    GS_CHECK_ARG(device_counter != nullptr, "device_counter is null");
+    gs_frame_ws ws = gs_frame_carve(f->workspace, f->N, f->max_pairs, f->width, f->height, f->color_dim, f->training);
+    *device_counter = ws.counters + GS_CNT_OVERFLOW;
     return 0;
 }
 

@@ -95,6 +95,14 @@ static inline gs_strip_plan gs_strip_plan_for(int64_t N, int ntx, int nty) {
     return p;
 }
 
+// sort_mode 2 runs the strip variant (strip_bin.hip) unless the caller asks for one of the others or the frame is outside
+// its limits (2^26 Gaussians, GS_STRIP_MAX strips)
+static inline bool gs_frame_uses_strips(const gs_frame *f) {
+    if (f->sort_mode != 2 || (f->flags & (GS_FRAME_SLICE_SORT | GS_FRAME_TABLE_BIN))) return false;
+    const int ntx = (f->width + GS_TILE - 1) / GS_TILE, nty = (f->height + GS_TILE - 1) / GS_TILE;
+    return gs_strip_plan_for(f->N, ntx, nty).ok != 0;
+}
+
 // floats per per-pair gradient row: (dx, dy, da, db, dc, dd, dopa) + colour grads, padded to float4s
 // floats per (tile, Gaussian) gradient row: 7 geometry/opacity sums + color_dim colour sums, rounded up to float4s
 // (12 / 36 / 56 for color_dim 3 / 27 / 48)
@@ -158,6 +166,8 @@ struct gs_frame_ws {
     uint64_t *strip_tot;           // [NS] totals per strip
     uint64_t *strip_base;          // [NS] (first entry << 32 | first pair) of every strip
     uint32_t *big_tiles;           // [T] queue of the tiles whose list exceeds strip_sort_kernel's LDS window
+    uint32_t *tile_cost;           // [T] Gaussian steps every tile composited in the LAST forward of this workspace
+    uint32_t *tile_order;          // [T] tiles in descending order of that cost: the dispatch order of this forward
     uint4 *group_queue;            // dense frames: (tile, first slot, keys, -) of the groups big_list_sort_kernel cut
     // dense frames only (else NULL): segmented compositing of long tile lists (raster_fwd.hip)
     float4 *cont_state;            // [T][256] (T, C) of a tile's pixels after its first GS_LONG_MIN Gaussians
@@ -232,6 +242,8 @@ static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pair
         ws.strip_tot = (uint64_t *)take(sizeof(uint64_t) * ns);
         ws.strip_base = (uint64_t *)take(sizeof(uint64_t) * ns);
         ws.big_tiles = (uint32_t *)take(sizeof(uint32_t) * (sp.ok ? (size_t)G.n_tiles : 1));
+        ws.tile_cost = (uint32_t *)take(sizeof(uint32_t) * (sp.ok ? (size_t)G.n_tiles : 1));
+        ws.tile_order = (uint32_t *)take(sizeof(uint32_t) * (sp.ok ? (size_t)G.n_tiles : 1));
     }
     if (gs_strip_plan_for(N, G.ntx, G.nty).ok) {  // the long-list kernels belong to the strip variant
         const size_t cap = (size_t)gs_seg_items_cap(max_pairs, G.n_tiles);

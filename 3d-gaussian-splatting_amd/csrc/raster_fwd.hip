@@ -109,7 +109,9 @@ raster_forward_kernel(RasterSrc S, RasterGeom G,
                                                                     uint32_t *__restrict__ tile_nproc,
                                                                     uint32_t n_tiles,
                                                                     float4 *__restrict__ cont_state,
-                                                                    uint32_t *__restrict__ cont_flag) {
+                                                                    uint32_t *__restrict__ cont_flag,
+                                                                    const uint32_t *__restrict__ tile_order,
+                                                                    uint32_t *__restrict__ tile_cost) {
     using SM = FwdSmem<CDIM>;
     constexpr int CH = SM::CH;
     constexpr uint32_t GROUP = 4;  // Gaussians per ds_read_b128 of a field
@@ -129,9 +131,20 @@ raster_forward_kernel(RasterSrc S, RasterGeom G,
             cnt = (uint32_t)(FRAME ? ranges[2 * t + 1] : ranges[t + 1]) - s0;
         }
     };
-    uint32_t tile = blockIdx.x, start, n, nstart, nn;
+    // Dispatch order (frame path, strip variant): wave k of the grid takes tile_order[k] -- the tiles in descending order
+    // of what they cost in the previous frame of this workspace (strip_bin.hip, tile_order_workgroup), so that the long
+    // tiles start first and the kernel's tail is made of short ones.  Measured at 2.4 M Gaussians (profiles/r03_a):
+    // 146 -> 132 us.  A persistent grid (3 / 4 / 8 waves per SIMD) drawing positions of the same order from a device
+    // ticket was also built and measured: 197 - 236 us -- the hardware's workgroup dispatcher refills a slot faster than
+    // a resident wave can fetch a ticket, the order entry, the range and the first chunk one after the other.
+    auto tile_at = [&](uint32_t li) {  // wave-uniform
+        return li < n_tiles ? (tile_order ? (uint32_t)__builtin_amdgcn_readfirstlane(tile_order[li]) : li) : n_tiles;
+    };
+    auto next_index = [&](uint32_t li) { return li + gridDim.x; };
+    uint32_t li = blockIdx.x, nli = next_index(li);
+    uint32_t tile = tile_at(li), ntile = tile_at(nli), start, n, nstart, nn;
     range_of(tile, start, n);
-    range_of(tile + gridDim.x, nstart, nn);
+    range_of(ntile, nstart, nn);
 
     // register stage for the next chunk (one Gaussian per lane)
     GaussianRec g;
@@ -151,7 +164,8 @@ raster_forward_kernel(RasterSrc S, RasterGeom G,
     fetch(start, n, 0);
     int k = 0;  // chunk counter across tiles: LDS ring slot
 
-    for (; tile < n_tiles; tile += gridDim.x) {
+    for (; li < n_tiles; li = nli, nli = next_index(nli), tile = ntile, ntile = tile_at(nli), start = nstart, n = nn,
+                         range_of(ntile, nstart, nn)) {
     const uint32_t tx = tile % (uint32_t)G.ntx, ty = tile / (uint32_t)G.ntx;
     const uint32_t id_x = tx * 16 + (lane & 15), id_y0 = ty * 16 + (lane >> 4);
     const float px = raster_pixel_coord(id_x, G.padW, G.focal_x);
@@ -186,7 +200,7 @@ raster_forward_kernel(RasterSrc S, RasterGeom G,
     // opaque to the compiler: otherwise it keeps the two constants in SGPRs and copies them into VGPR pairs for the
     // inline v_pk_fma inside the hot loop (two v_mov_b64 per four Gaussians)
     asm volatile("" : "+v"(live_scale), "+v"(live_bias));
-    uint32_t nproc = 0;
+    uint32_t nproc = 0, steps = 0;  // steps: Gaussians composited before the wave stopped (the tile's cost)
 
     auto write_ckpt = [&](uint32_t idx_in_tile) {
         float4 *c = ckpt + raster_ckpt_slot(start, tile, idx_in_tile / GS_BUCKET) * 256;
@@ -296,10 +310,12 @@ raster_forward_kernel(RasterSrc S, RasterGeom G,
         const bool chunk_legacy = __ballot(suspicious) != 0ull;
         auto composite_chunk = [&](auto legacy_tag) {
         constexpr bool LEGACY = decltype(legacy_tag)::value;
+        uint32_t stop = cnt;  // Gaussians of this chunk composited before the wave stopped
 #pragma unroll 1
         for (uint32_t i = 0; i < cnt; i += GROUP) {
             if ((i & (LIVE_EVERY - 1)) == 0 && !any_live()) {
                 done = true;
+                stop = i;
                 break;
             }
             {
@@ -372,17 +388,16 @@ raster_forward_kernel(RasterSrc S, RasterGeom G,
             }
             }
         }
+        return stop;
         };
-        if (chunk_legacy)
-            composite_chunk(std::true_type{});
-        else
-            composite_chunk(std::false_type{});
+        steps = base + (chunk_legacy ? composite_chunk(std::true_type{}) : composite_chunk(std::false_type{}));
         // a chunk whose checkpoint was written counts as processed even if the wave stopped inside it:
         // the backward pass masks finished pixels by their transmittance
         nproc = base + cnt;
     }
     if (!staged_next) fetch(nstart, nn, 0);  // empty tile, or the wave stopped before its last chunk
     if (tile_nproc && lane == 0) tile_nproc[tile] = nproc;
+    if (FRAME && tile_cost && lane == 0) tile_cost[tile] = steps;
     if (FRAME && cont_flag && lane == 0) cont_flag[tile] = continues ? 1u : 0u;
 
 #pragma unroll
@@ -411,9 +426,6 @@ raster_forward_kernel(RasterSrc S, RasterGeom G,
                 }
             }
         }
-    start = nstart;
-    n = nn;
-    range_of(tile + 2 * gridDim.x, nstart, nn);
     }  // tile loop
 }
 
@@ -717,38 +729,49 @@ __global__ void __launch_bounds__(256) seg_combine_kernel(RasterGeom G, const in
     }
 }
 
-// Waves in the persistent grid: every wave gets the same number of tiles (+-1) and there are at most
-// GS_FWD_WAVES_PER_SIMD (default 8) waves per SIMD -- at 1080p that is one tile per wave; fewer, longer-lived waves
-// were slower (122-154 us against 85 us at cfg2).  The slot count is cached from the first device seen (all GPUs of
-// a node are the same part); the race on the cache is benign, every thread computes the same value.
-static uint32_t fwd_grid(uint32_t n_tiles) {
-    static std::atomic<int> cached{0};
-    int slots = cached.load(std::memory_order_relaxed);
-    if (!slots) {
-        hipDeviceProp_t p;
-        int dev = 0, wps = GS_FWD_WAVES_PER_SIMD;
+// Waves in the grid: every wave gets the same number of tiles (+-1) and there are at most GS_FWD_WAVES_PER_SIMD
+// (default 8) waves per SIMD -- at 1080p that is one tile per wave, dispatched by the hardware in index order as slots
+// free up (with tile_order: longest-first list scheduling); fewer, longer-lived waves were slower (122-154 us against
+// 85 us at cfg2).  The slot count is cached from the first device seen (all GPUs of a node are the same part).
+struct FwdPlan {
+    int slots;  // wave slots of the device at GS_FWD_WAVES_PER_SIMD
+    int order;  // use tile_order (default 1; GS_FWD_ORDER=0 in the environment switches it off: A/B measurements)
+};
+static const FwdPlan &fwd_plan() {
+    static const FwdPlan plan = [] {
+        FwdPlan p;
+        hipDeviceProp_t prop;
+        int dev = 0, wps = GS_FWD_WAVES_PER_SIMD, cus = 256;
         if (const char *e = getenv("GS_FWD_WAVES_PER_SIMD")) wps = atoi(e) > 0 ? atoi(e) : wps;  // tuning knob
-        slots = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
-                    ? p.multiProcessorCount * 4 * wps
-                    : 256 * 4 * wps;
-        cached.store(slots, std::memory_order_relaxed);
-    }
-    const uint32_t rounds = (n_tiles + slots - 1) / slots;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        p.slots = cus * 4 * wps;
+        const char *o = getenv("GS_FWD_ORDER");
+        p.order = o ? atoi(o) != 0 : 1;
+        return p;
+    }();
+    return plan;
+}
+static uint32_t fwd_grid(uint32_t n_tiles) {
+    const FwdPlan &p = fwd_plan();
+    const uint32_t rounds = (n_tiles + p.slots - 1) / p.slots;
     return rounds ? (n_tiles + rounds - 1) / rounds : 1;
 }
 
 template <int CDIM, bool FRAME, bool CKPT, bool SIG>
 void launch_fwd(const RasterSrc &S, const RasterGeom &G, const int32_t *ranges, float *out_padded, float *out_image,
                 float4 *ckpt, uint32_t *tile_nproc, int wn, hipStream_t stream, float4 *cont_state = nullptr,
-                uint32_t *cont_flag = nullptr) {
+                uint32_t *cont_flag = nullptr, const uint32_t *tile_order = nullptr, uint32_t *tile_cost = nullptr) {
+    if (!fwd_plan().order) tile_order = nullptr;
+    const uint32_t T = (uint32_t)(G.ntx * G.nty), grid = fwd_grid(T);
     if (wn)
-        hipLaunchKernelGGL((raster_forward_kernel<CDIM, FRAME, CKPT, SIG, true>), dim3(fwd_grid(G.ntx * G.nty)), dim3(FWD_THREADS), 0,
-                           stream, S, G, ranges, out_padded, out_image, ckpt, tile_nproc, (uint32_t)(G.ntx * G.nty),
-                           cont_state, cont_flag);
+        hipLaunchKernelGGL((raster_forward_kernel<CDIM, FRAME, CKPT, SIG, true>), dim3(grid), dim3(FWD_THREADS), 0,
+                           stream, S, G, ranges, out_padded, out_image, ckpt, tile_nproc, T, cont_state, cont_flag,
+                           tile_order, tile_cost);
     else
-        hipLaunchKernelGGL((raster_forward_kernel<CDIM, FRAME, CKPT, SIG, false>), dim3(fwd_grid(G.ntx * G.nty)), dim3(FWD_THREADS), 0,
-                           stream, S, G, ranges, out_padded, out_image, ckpt, tile_nproc, (uint32_t)(G.ntx * G.nty),
-                           cont_state, cont_flag);
+        hipLaunchKernelGGL((raster_forward_kernel<CDIM, FRAME, CKPT, SIG, false>), dim3(grid), dim3(FWD_THREADS), 0,
+                           stream, S, G, ranges, out_padded, out_image, ckpt, tile_nproc, T, cont_state, cont_flag,
+                           tile_order, tile_cost);
 }
 
 }  // namespace
@@ -853,14 +876,19 @@ int gs_stage_raster_forward(const gs_frame *f, const gs_frame_ws &ws, const uint
                        !(f->flags & GS_FRAME_SERIAL_LONG_LISTS);
     float4 *cs = dense ? ws.cont_state : nullptr;
     uint32_t *cf = dense ? ws.cont_flag : nullptr;
+    // longest-first dispatch: the order is written by the strip variant's binning (strip_bin.hip); the cost is recorded
+    // whenever there is room for it, so that a later strip-variant frame of this workspace finds it
+    const bool ordered = gs_frame_uses_strips(f) && f->N > 0 && ws.tile_order != nullptr;
+    const uint32_t *order = ordered ? ws.tile_order : nullptr;
+    uint32_t *cost = ordered ? ws.tile_cost : nullptr;
 #define GS_LAUNCH_FRAME_FWD(CD)                                                                                        \
     do {                                                                                                               \
         if (f->training)                                                                                               \
             launch_fwd<CD, true, true, false>(S, G, ws.tile_ranges, f->image_padded, f->image, ws.ckpt, ws.tile_nproc, \
-                                              0, stream, cs, cf);                                                      \
+                                              0, stream, cs, cf, order, cost);                                         \
         else                                                                                                           \
             launch_fwd<CD, true, false, false>(S, G, ws.tile_ranges, f->image_padded, f->image, nullptr, nullptr, 0,   \
-                                               stream, cs, cf);                                                        \
+                                               stream, cs, cf, order, cost);                                           \
     } while (0)
     if (f->color_dim == 48)
         GS_LAUNCH_FRAME_FWD(48);

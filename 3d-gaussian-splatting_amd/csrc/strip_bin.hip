@@ -113,15 +113,60 @@ struct SliceLoader {
     }
 };
 
+// ---------------------------------------------------------------- compositing order of the tiles (longest first)
+// One tile per wave is serial in the tile's list, and tiles differ by several times in the Gaussians they composite
+// before all their pixels are saturated: dispatched in raster order, the long tiles that happen to start late leave most
+// SIMDs idle at the end of raster_forward_kernel (PMC, round 2: 68 % of the issue cycles busy).  The forward kernel
+// therefore records what every tile cost (Gaussian steps until it stopped) and the NEXT frame of the same workspace
+// dispatches its tiles in descending order of that cost -- longest-processing-time-first list scheduling; a viewer's or
+// a trainer's consecutive frames of one camera are nearly the same picture, and for an unrelated camera the order is
+// merely arbitrary, as raster order is.  Whatever the costs hold (first frame: uninitialised memory), a counting sort
+// of the tile indices yields a permutation, and the image does not depend on the order: tiles are independent.
+// Runs as one EXTRA workgroup of strip_count_kernel's launch, i.e. underneath the binning, three kernels ahead of its
+// consumer.  256 bins of GS_ORDER_QUANTUM steps; arrival order inside a bin is whatever the LDS atomics make it.
+#define GS_ORDER_QUANTUM 8
+__device__ __forceinline__ void tile_order_workgroup(const uint32_t *__restrict__ tile_cost, uint32_t T,
+                                                     uint32_t *__restrict__ tile_order) {
+    __shared__ uint32_t s_bin[256];
+    __shared__ uint32_t s_wsum[4];
+    if (threadIdx.x < 256) s_bin[threadIdx.x] = 0;
+    __syncthreads();
+    auto bin_of = [](uint32_t c) {
+        const uint32_t q = c / GS_ORDER_QUANTUM;
+        return 255u - (q < 255u ? q : 255u);  // descending cost
+    };
+    for (uint32_t t = threadIdx.x; t < T; t += STRIP_THREADS) atomicAdd(&s_bin[bin_of(tile_cost[t])], 1u);
+    __syncthreads();
+    uint32_t cnt = 0, incl = 0;
+    if (threadIdx.x < 256) {
+        cnt = s_bin[threadIdx.x];
+        incl = gs_wave_incl_scan_u32(cnt);
+        if ((threadIdx.x & 63) == 63) s_wsum[threadIdx.x >> 6] = incl;
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        uint32_t off = 0;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) off += s_wsum[w];
+        s_bin[threadIdx.x] = off + incl - cnt;  // cursor = first slot of the bin
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < T; t += STRIP_THREADS) tile_order[atomicAdd(&s_bin[bin_of(tile_cost[t])], 1u)] = t;
+}
+
 // ---------------------------------------------------------------- L1a: count
 template <bool DIST>
 __global__ void __launch_bounds__(STRIP_THREADS) strip_count_kernel(
     const uint4 *__restrict__ rects, const float4 *__restrict__ rec_geom, GsDistCull D, int64_t n, uint32_t per_slice,
-    gs_strip_geom SG, unsigned long long *__restrict__ table, const uint32_t *__restrict__ block_sums,
-    const uint32_t *__restrict__ block_vis, uint32_t *__restrict__ slice_pairs, uint32_t *__restrict__ slice_vis) {
+    gs_strip_geom SG, uint32_t S, unsigned long long *__restrict__ table, const uint32_t *__restrict__ block_sums,
+    const uint32_t *__restrict__ block_vis, uint32_t *__restrict__ slice_pairs, uint32_t *__restrict__ slice_vis,
+    const uint32_t *__restrict__ tile_cost, uint32_t n_tiles, uint32_t *__restrict__ tile_order) {
     extern __shared__ unsigned long long s_hist[];  // [NS] entries << 32 | pairs of this slice
     __shared__ uint32_t s_acc[2];
-    const uint32_t slice = strip_slice_of_block(blockIdx.x, gridDim.x);
+    if (blockIdx.x >= S) {  // the one extra workgroup of the launch (uniform)
+        tile_order_workgroup(tile_cost, n_tiles, tile_order);
+        return;
+    }
+    const uint32_t slice = strip_slice_of_block(blockIdx.x, S);
     const SliceLoader L = {rects, rec_geom, n, (int64_t)slice * per_slice, per_slice};
     uint4 rc[STRIP_PF];
 #pragma unroll
@@ -419,9 +464,10 @@ int gs_stage_strip_bin(const gs_frame *f, const gs_frame_ws &ws, hipStream_t str
     const size_t lds_scatter = sizeof(unsigned long long) * ((size_t)SG.NS + plan.cap);
 #define GS_LAUNCH_STRIP(DIST)                                                                                          \
     do {                                                                                                               \
-        hipLaunchKernelGGL(strip_count_kernel<DIST>, dim3(plan.slices), dim3(STRIP_THREADS), lds_count, stream,        \
-                           ws.rects, ws.rec_geom, D, f->N, plan.per_slice, SG, table, ws.block_sums, ws.block_vis,     \
-                           ws.slice_pairs, ws.slice_vis);                                                              \
+        hipLaunchKernelGGL(strip_count_kernel<DIST>, dim3(plan.slices + 1), dim3(STRIP_THREADS), lds_count, stream,    \
+                           ws.rects, ws.rec_geom, D, f->N, plan.per_slice, SG, plan.slices, table, ws.block_sums,      \
+                           ws.block_vis, ws.slice_pairs, ws.slice_vis, ws.tile_cost, (uint32_t)G.n_tiles,              \
+                           ws.tile_order);                                                                             \
         GS_CHECK_LAUNCH();                                                                                             \
         hipLaunchKernelGGL(strip_colscan_kernel, dim3((unsigned)gs_div_up(SG.NS, 16)), dim3(256), 0, stream, table,    \
                            scan, plan.slices, SG.NS, (unsigned long long *)ws.strip_tot);                              \

@@ -284,6 +284,8 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_scatter_kernel(
                 counters[GS_CNT_PAIRS] = 0;
                 counters[GS_CNT_OVERFLOW] = M > R ? M : R;
                 counters[GS_CNT_VISIBLE] = V;
+                // only the strip variant's kernels maintain these; whoever reads them back must not see stale values
+                counters[GS_CNT_BIG] = counters[GS_CNT_GROUPS] = counters[GS_CNT_MAXLIST] = 0;
             }
         }
         return;
@@ -315,6 +317,7 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_scatter_kernel(
         counters[GS_CNT_PAIRS] = M;
         counters[GS_CNT_OVERFLOW] = 0;
         counters[GS_CNT_VISIBLE] = V;
+        counters[GS_CNT_BIG] = counters[GS_CNT_GROUPS] = counters[GS_CNT_MAXLIST] = 0;  // strip variant only
     }
     __syncthreads();
     // 3. scatter, one horizontal BAND of the tile grid at a time.  A workgroup writes into T output streams (one per
@@ -414,6 +417,7 @@ __global__ void __launch_bounds__(BIN_THREADS) slice_sort_kernel(
         counters[GS_CNT_VISIBLE] = V;
         counters[GS_CNT_OVERFLOW] = R > max_pairs ? R : 0;
         counters[GS_CNT_TICKET] = 0;  // bin_totals_kernel counts its finished workgroups here
+        counters[GS_CNT_BIG] = counters[GS_CNT_GROUPS] = counters[GS_CNT_MAXLIST] = 0;  // strip variant only
     }
     if (R > max_pairs) {  // not enough room: an all-zero table = an empty frame, the true count is reported
         for (uint32_t t = threadIdx.x; t <= T; t += BIN_THREADS) row[t] = 0;

@@ -1160,10 +1160,12 @@ __global__ void __launch_bounds__(256) big_list_sort_kernel(const uint32_t *__re
                 for (uint32_t i = threadIdx.x; i < m; i += 256)
                     a[gs0 + i] = ((uint64_t)tmp_depth[r0 + gs0 + i] << 32) | ids[r0 + gs0 + i];
                 __syncthreads();
-                if (m < n && s_sp < STACK) {
+                const uint32_t sp = s_sp;  // every wave reads the depth BEFORE thread 0 may change it (uniform branch)
+                __syncthreads();
+                if (m < n && sp < STACK) {
                     if (threadIdx.x == 0) {
-                        s_stack[s_sp] = make_uint2(off + gs0, m);
-                        s_sp = s_sp + 1;
+                        s_stack[sp] = make_uint2(off + gs0, m);
+                        s_sp = sp + 1;
                     }
                     __syncthreads();
                 } else {

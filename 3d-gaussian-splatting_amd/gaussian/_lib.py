@@ -96,6 +96,9 @@ gs_adam_step = _sig("gs_adam_step", ci, vp, vp, vp, vp, i64, i32, C.POINTER(i64)
                     vp, i64, i64, i32, vp)
 gs_adam_step_range = _sig("gs_adam_step_range", ci, vp, vp, vp, vp, i64, i64, i64, i32, C.POINTER(i64), C.POINTER(f32),
                           f32, f32, f32, i64, vp, i64, i64, i32, vp)
+gs_adam_step_sharded = _sig("gs_adam_step_sharded", ci, vp, vp, vp, vp, i64, i64, i64, i64, i32, C.POINTER(i64),
+                            C.POINTER(f32), f32, f32, f32, i64, vp, i64, i64, i32, vp, vp)
+gs_frame_overflow_flag = _sig("gs_frame_overflow_flag", ci, C.POINTER(GsFrame), C.POINTER(vp))
 gs_grad_stat_update = _sig("gs_grad_stat_update", ci, vp, vp, i64, i32, vp)
 gs_frame_async_create = _sig("gs_frame_async_create", ci, C.POINTER(vp))
 gs_frame_async_wait = _sig("gs_frame_async_wait", ci, vp, vp)
@@ -126,7 +129,7 @@ EXPORTS = [
     "gs_sort_pairs_tmp_bytes", "gs_sort_pairs", "gs_sort_pairs_bits", "gs_frame_workspace_bytes", "gs_frame_forward",
     "gs_frame_stats_async", "gs_frame_longest_list_async", "gs_frame_debug_views", "gs_frame_debug_tile_nproc", "gs_frame_backward", "gs_frame_forward_profile",
     "gs_frame_backward_part", "gs_frame_async_create", "gs_frame_async_wait", "gs_frame_async_destroy",
-    "gs_frame_backward_profile", "gs_adam_step", "gs_adam_step_range", "gs_grad_stat_update", "gs_loss_workspace_bytes", "gs_loss_l1_ssim",
+    "gs_frame_backward_profile", "gs_adam_step", "gs_adam_step_range", "gs_adam_step_sharded", "gs_frame_overflow_flag", "gs_grad_stat_update", "gs_loss_workspace_bytes", "gs_loss_l1_ssim",
     "gs_densify_workspace_bytes", "gs_densify_classify", "gs_densify_apply",
 ]
 

@@ -188,8 +188,9 @@ class FrameRenderer:
         frame and for every inference frame (``training=False``: an evaluation image is never returned truncated);
         training frames after the first copy their counters to pinned memory without waiting, and the next forward
         grows the workspace (25 % head room, and already when a frame comes within 25 % of the capacity) -- a training
-        frame that overflowed all the same was rendered empty, is counted in ``overflowed_frames``, and ``last_frame_
-        overflowed()`` tells the trainer to skip that optimizer step.  ``False`` never checks."""
+        frame that overflowed all the same was rendered empty and is counted in ``overflowed_frames`` once its counters
+        arrive; ``overflow_flag()`` is the device address of the frame's overflow counter, which gs_train.Trainer hands
+        to the fused Adam so that such a step is skipped on the device.  ``False`` never checks."""
         training = self.training if training is None else training
         with torch.cuda.device(self.device):
             return self._forward(pos, quat, scale, opa, rgb, camera, training)
@@ -329,6 +330,15 @@ class FrameRenderer:
         v, m, o, b, longest = (int(x) for x in self._stats_host.tolist())
         self._long_lists_seen = self._long_lists_seen or longest > 2048
         return FrameStats(v, m, o, b, longest)
+
+    def overflow_flag(self) -> Optional[int]:
+        """Device address of the last frame's 64-bit overflow counter (0 = the frame fitted), for consumers that must
+        not act on an overflowed -- i.e. empty -- frame without asking the host (gs_adam_step_sharded)."""
+        if self._frame is None:
+            return None
+        ptr = C.c_void_p()
+        _lib.check(_lib.gs_frame_overflow_flag(C.byref(self._frame), C.byref(ptr)), "gs_frame_overflow_flag")
+        return ptr.value
 
     def culling_mask(self) -> torch.Tensor:
         """[N] bool: the Gaussians of the last forward that passed the frustum test (the reference's

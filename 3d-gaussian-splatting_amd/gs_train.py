@@ -88,7 +88,10 @@ def base_lrs(opt: TrainOptions) -> List[float]:
 
 
 class FusedAdam:
-    """``torch.optim.Adam`` over a FlatGaussianParams bucket, one HIP launch per step."""
+    """``torch.optim.Adam`` over a FlatGaussianParams bucket, one HIP launch per step (per bucket).
+
+    With ``flat.exchange == "reduce_scatter"`` the optimizer is SHARDED: this rank keeps the moments of its slice of
+    each bucket only and updates that slice only (gs_dp.py); otherwise every rank updates everything."""
 
     def __init__(self, flat: FlatGaussianParams, lrs: Sequence[float], betas=(0.9, 0.99), eps: float = 1e-8,
                  grad_stat: Optional[str] = None):
@@ -96,22 +99,22 @@ class FusedAdam:
             raise RuntimeError("FusedAdam needs a HIP device; there is no CPU fallback")
         self.flat = flat
         self.betas, self.eps = (float(betas[0]), float(betas[1])), float(eps)
-        self.exp_avg = torch.zeros_like(flat.flat_param)
-        self.exp_avg_sq = torch.zeros_like(flat.flat_param)
+        self.sharded = flat.exchange == "reduce_scatter"
+        # moments per bucket, covering what this rank updates of it (gs_dp.FlatGaussianParams.optimizer_range)
+        self.ranges = {name: flat.optimizer_range(name) for name in ("geometry", "color")}
+        dev = flat.flat_param.device
+        self.exp_avg = {k: torch.zeros(hi - lo, dtype=torch.float32, device=dev) for k, (lo, hi) in self.ranges.items()}
+        self.exp_avg_sq = {k: torch.zeros_like(v) for k, v in self.exp_avg.items()}
         self.step_count = 0
         # bucket storage order (gs_dp.ORDER) -> group boundaries; lrs arrive in the reference's GROUPS order
-        sizes = {k: t.numel() for k, t in zip(("pos", "quat", "scale", "opa", "rgb"), flat.params)}
-        ends, off = [], 0
-        for k in ORDER:
-            off += sizes[k]
-            ends.append(off)
+        ends = list(flat.group_ends)
         self._ends = (C.c_int64 * len(ends))(*ends)
         self._lr = (C.c_float * len(ends))()
         self.set_lrs(lrs)
-        pos_begin = ends[ORDER.index("pos")] - sizes["pos"]
-        self._stat_range = (pos_begin, pos_begin + sizes["pos"])
+        self._stat_range = flat.offsets["pos"]
         self.stat_mode = {None: 0, "max": 1, "mean": 2}[grad_stat]
         self.accum_grad = torch.zeros_like(flat.params[0]) if self.stat_mode else None  # train.py:80-82
+        self.skip_flag = None  # device address of a 64-bit counter: non-zero => the step is skipped (gs_abi.h)
 
     def set_lrs(self, lrs: Sequence[float]):
         by_group = dict(zip(GROUPS, lrs))
@@ -123,19 +126,22 @@ class FusedAdam:
             self.accum_grad.zero_()
 
     def step(self, bucket: Optional[str] = None, advance: bool = True):
-        """One Adam step over the whole flat buffer, or over one bucket of it ("geometry" / "color": gs_dp.py; the
-        step counter advances once per optimizer step -- pass ``advance=False`` for the second bucket)."""
+        """One Adam step over everything this rank owns, or over one bucket of it ("geometry" / "color": gs_dp.py;
+        the step counter advances once per optimizer step -- pass ``advance=False`` for the second bucket)."""
         if advance:
             self.step_count += 1
         f = self.flat
         b, e = self._stat_range
         n = f.flat_param.numel()
-        lo, hi = (0, n) if bucket is None else f.bucket_ranges[bucket]
-        _lib.check(_lib.gs_adam_step_range(f.flat_param.data_ptr(), f.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
-                                           self.exp_avg_sq.data_ptr(), n, lo, hi, len(ORDER), self._ends, self._lr,
-                                           self.betas[0], self.betas[1], self.eps, self.step_count,
-                                           self.accum_grad.data_ptr() if self.accum_grad is not None else None, b, e,
-                                           self.stat_mode, torch.cuda.current_stream().cuda_stream), "gs_adam_step")
+        stream = torch.cuda.current_stream().cuda_stream
+        for name in (("geometry", "color") if bucket is None else (bucket,)):
+            lo, hi = self.ranges[name]
+            _lib.check(_lib.gs_adam_step_sharded(
+                f.flat_param.data_ptr(), f.flat_grad.data_ptr(), self.exp_avg[name].data_ptr(),
+                self.exp_avg_sq[name].data_ptr(), n, lo, hi, lo, len(ORDER), self._ends, self._lr, self.betas[0],
+                self.betas[1], self.eps, self.step_count,
+                self.accum_grad.data_ptr() if self.accum_grad is not None else None, b, e, self.stat_mode,
+                self.skip_flag, stream), "gs_adam_step")
 
 
 class ImageLoss:
@@ -167,9 +173,12 @@ class Trainer:
     def __init__(self, params: Sequence[torch.Tensor], cameras, targets: Sequence[torch.Tensor],
                  opt: Optional[TrainOptions] = None, world_size: int = 1, max_pairs: int = 1 << 20,
                  scale_activation: str = "abs", densify: bool = False, generator: Optional[torch.Generator] = None,
-                 per_view_stat: Optional[bool] = None):
+                 per_view_stat: Optional[bool] = None, exchange: str = "all_reduce"):
         self.opt = opt or TrainOptions()
         self.world_size = int(world_size)
+        # gradient exchange under view parallelism (gs_dp.py): "all_reduce" + replicated Adam, or "reduce_scatter" +
+        # sharded Adam + all-gather of the parameters
+        self.exchange = exchange
         # densification statistic: fused into the Adam launch on one GPU; with several ranks it must be taken from
         # each rank's own gradient before the all-reduce (gs_dp.ViewParallelGradStat).  `per_view_stat=True` forces
         # that path on a single rank too (it then gives bit-identical results; used by the tests).
@@ -196,7 +205,9 @@ class Trainer:
     def _bind(self, params: Sequence[torch.Tensor], i_iter: int):
         """(Re)creates the flat bucket and the optimizer for a (new) Gaussian set: train.py:59-67 / :169-179 --
         the reference also starts a fresh torch.optim.Adam after every adaptive_control."""
-        self.flat = FlatGaussianParams(params, world_size=self.world_size)
+        force = getattr(getattr(self, "flat", None), "force_collective", False)
+        self.flat = FlatGaussianParams(params, world_size=self.world_size, exchange=self.exchange,
+                                       force_collective=force)
         split_stat = self.densify and self.per_view_stat
         self.optimizer = FusedAdam(self.flat, [b * f(i_iter) for b, f in zip(self._base, self._lambdas)],
                                    betas=self.opt.betas, eps=self.opt.eps,
@@ -229,12 +240,19 @@ class Trainer:
         if camera_id not in self._views_checked:  # first frame of this view on this Gaussian set: synchronous check
             self._views_checked.add(camera_id)
             self.renderer._checked_once = False
+        self.flat.finish_gather()  # reduce-scatter mode: the parameter all-gather of the previous step
         image, _ = self.renderer.forward(*self.flat.params, cam)
+        # a frame that overflowed its workspace all the same was rendered empty: on a single rank the optimizer step
+        # is skipped ON THE DEVICE (the fused Adam looks at the frame's overflow counter; no host synchronisation).
+        # With several ranks the step is taken -- the other ranks' views still carry gradient, and skipping on one rank
+        # would let the replicas drift apart -- and the warning below reports it once the counters arrive.
+        self.optimizer.skip_flag = self.renderer.overflow_flag() if self.world_size == 1 else None
         if self.renderer.overflowed_frames > self._overflow_warned:
             import warnings
 
             warnings.warn(f"{self.renderer.overflowed_frames - self._overflow_warned} training frame(s) exceeded the "
-                          f"pair capacity and were rendered empty (their optimizer steps saw zero gradients); the "
+                          f"pair capacity and were rendered empty (single rank: their optimizer steps were skipped on "
+                          f"the device; several ranks: this rank contributed zero gradients to them); the "
                           f"workspace has been enlarged to {self.renderer.max_pairs} pairs")
             self._overflow_warned = self.renderer.overflowed_frames
         loss = self._loss_for(image.shape[0], image.shape[1])
@@ -274,8 +292,10 @@ class Trainer:
                 self.flat.begin_bucket(name)
             self.flat.finish_bucket(first)
             self.optimizer.step(first)
+            self.flat.begin_gather(first)   # reduce-scatter mode only: the updated slices travel underneath ...
             self.flat.finish_bucket(second)
-            self.optimizer.step(second, advance=False)
+            self.optimizer.step(second, advance=False)  # ... this
+            self.flat.begin_gather(second)  # waited for where the parameters are read next (finish_gather)
         else:
             self.renderer.backward(grad_image, out=self.flat.grads)
             local_terms(None)
@@ -289,6 +309,7 @@ class Trainer:
         if self.densify and i_iter % o.n_opa_reset == 0 and i_iter > 0:  # train.py:189-190
             from gs_densify import reset_opa
 
+            self.flat.finish_gather()
             reset_opa(self.flat.params[3])
         return loss.values
 
@@ -297,6 +318,7 @@ class Trainer:
         from gs_densify import adaptive_control
 
         o = self.opt
+        self.flat.finish_gather()
         if self.view_stat is not None:  # combine the ranks' per-view statistics: one collective per boundary
             accum, cnt = self.view_stat.reduce()
             counter = 1.0 if o.grad_accum_method == "max" else cnt
@@ -327,6 +349,7 @@ class Trainer:
 
         from gs_scene import Camera
 
+        self.flat.finish_gather()
         if extrinsics is not None and intrinsics is not None:
             to_np = lambda a: (a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)).astype(np.float32)  # noqa: E731
             cam = Camera(int(intrinsics["width"]), int(intrinsics["height"]), float(intrinsics["focal_x"]),
@@ -362,6 +385,7 @@ class Trainer:
     # ------------------------------------------------------------------ checkpoints (train.py:283-291, splatter.py:417-424)
     def save_checkpoint(self, path: str):
         """The reference's ``ckpt.pth``: a dict of the five raw parameter tensors."""
+        self.flat.finish_gather()
         pos, quat, scale, opa, rgb = (t.detach().clone() for t in self.flat.params)
         torch.save({"pos": pos, "opa": opa, "rgb": rgb, "quat": quat, "scale": scale}, path)
 

@@ -2,6 +2,7 @@
 """bench.py -- render FPS of the MI355X rasterizer path on BASELINE.json's configs.
 
     python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus N ...            # no RANK in the environment: re-executes itself under torch.distributed.run
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -15,7 +16,10 @@ data-path collective (weak scaling); the training step -- which does exchange gr
 "multi_gpu".
 
 Rank 0 prints ONE JSON line (driver contract):
-  value / ms_per_step  the K timed steps of the headline workload, one frame in flight;
+  value / ms_per_step  the K timed steps of the headline workload, one frame in flight.  The K-step block (barrier +
+                       synchronize on both sides, max over ranks) is repeated R times ("repeats": R >= 15 and >= 0.3 s
+                       of GPU work, so that an external sampler can see the run); value / ms_per_step are the MEDIAN
+                       block, "ms_per_step_min" / "_max" its spread;
   roofline             dominant kernel of that workload (raster_forward_kernel), algorithmic bytes of SURVEY.md 8d S5
                        / its hipEvent-timed duration (events on the launch stream, inside the library);
   stages               every stage of the frame: ms, algorithmic bytes (SURVEY.md 8d), GB/s, fraction of HBM peak;
@@ -44,7 +48,7 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-ALL_LEGS = ("headline", "cfg2", "train", "fit", "cfg4", "pipelined", "multi_gpu", "cpu")
+ALL_LEGS = ("headline", "cfg2", "train", "fit", "cfg4", "pipelined", "compat", "multi_gpu", "cpu")
 
 
 def log(*a):
@@ -91,18 +95,45 @@ def main():
         legs.discard("cpu")
     assert legs <= set(ALL_LEGS), f"unknown leg in {sorted(legs)}"
 
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device (there is no CPU fallback)")
+    if args.gpus < 1:
+        sys.exit("--gpus must be >= 1")
+    if torch.cuda.device_count() < args.gpus:
+        sys.exit(f"bench.py --gpus {args.gpus} needs {args.gpus} visible devices, found {torch.cuda.device_count()}")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # launched blind (`python bench.py --gpus N`): one rank per GPU under torch.distributed.run, rank 0 prints the
+        # JSON line on the inherited stdout
+        import socket
+        import subprocess
+
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+        log("[bench] no RANK in the environment: " + " ".join(cmd))
+        sys.exit(subprocess.call(cmd, env=env))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    if world != args.gpus:
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or "RANK" in os.environ  # under torchrun always go through RCCL
+    # under torchrun always go through RCCL; a single process does when the collective is asked for (--force-collective)
+    use_dist = world > 1 or "RANK" in os.environ or args.force_collective
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(so.getsockname()[1])
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from gs_frame import FrameRenderer
     from gs_scene import CONFIGS, make_camera, make_scene
@@ -135,9 +166,8 @@ def main():
         r.forward(*params, cam)
         return r, r.stats()
 
-    def time_frames(fn, steps, warmup):
-        for _ in range(warmup):
-            fn()
+    def time_block(fn, steps):
+        """EXACTLY `steps` steps between barrier + synchronize on both sides; max over ranks (seconds)."""
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -146,6 +176,17 @@ def main():
         dt = time.perf_counter() - t0
         barrier()
         return max_over_ranks(dt)
+
+    def time_frames(fn, steps, warmup, repeats=None, min_seconds=0.3):
+        """`warmup` untimed steps, then the `steps`-step block R times: returns (median block seconds, all blocks).
+        R = max(15, enough blocks for `min_seconds` of work), decided on rank 0's first block and shared."""
+        for _ in range(warmup):
+            fn()
+        first = time_block(fn, steps)
+        if repeats is None:
+            repeats = int(min(400, max(15, min_seconds / max(first, 1e-6) + 1)))
+        blocks = [first] + [time_block(fn, steps) for _ in range(repeats - 1)]
+        return statistics.median(blocks), blocks
 
     def settle(fn, seconds=0.4):
         """setup, not measurement: a few tenths of a second of work so that the clocks (DVFS) are at their steady
@@ -170,9 +211,10 @@ def main():
             frame()
         host_us = (time.perf_counter() - t0) / 50 * 1e6  # host cost of issuing one frame, GPU free-running
         torch.cuda.synchronize()
-        dt = time_frames(frame, steps, warmup)
+        dt, blocks = time_frames(frame, steps, warmup)
         res = {"fps": world * steps / dt, "ms": dt / steps * 1e3, "host_us": host_us, "stats": st,
-               "scene": scene, "cam": cam, "params": params, "renderer": r}
+               "scene": scene, "cam": cam, "params": params, "renderer": r, "repeats": len(blocks),
+               "ms_min": min(blocks) / steps * 1e3, "ms_max": max(blocks) / steps * 1e3}
         if rank == 0:
             prof = [r.profile_forward(*params, cam) for _ in range(25)][5:]
             med = {k: statistics.median(p[k] for p in prof) for k in prof[0]}
@@ -182,17 +224,24 @@ def main():
             C = 27 if use_sh else 3
             stages, alg, P, T = stage_table(n, st.visible, st.pairs, W, H, C, stage_ms)
             achieved = alg["raster"] / (stage_ms["raster"] * 1e-3) / 1e9
-            traffic = None  # HBM bytes per launch from committed PMC passes (profiles/traffic.json), if they match
+            # HBM bytes per launch and the SIMDs' VALU-issue occupancy from committed PMC passes (profiles/traffic.json),
+            # if they belong to this workload
+            traffic = issue_busy = None
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[cfg]
                 if tj["tile_pairs"] == st.pairs:
                     traffic = tj["raster_forward_kernel"]["traffic_bytes"]
+                    issue_busy = tj["raster_forward_kernel"].get("issue_busy")
             except (OSError, KeyError, ValueError):
                 pass
             roof = {"bound": "hbm", "kernel": "raster_forward_kernel", "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": traffic, "algorithmic_bytes": int(alg["raster"]),
-                    "kernel_ms": round(stage_ms["raster"], 4), "workload": cfg}
+                    # what rocprof's counters saw move, as a fraction of the HBM peak (tiles stop compositing once all
+                    # their pixels are saturated, so this is BELOW frac on a scene with many hidden Gaussians)
+                    "traffic_frac": None if traffic is None else round(
+                        traffic / (stage_ms["raster"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "issue_busy": issue_busy, "kernel_ms": round(stage_ms["raster"], 4), "workload": cfg}
             if not use_sh:
                 # the compositing kernel is fp32-VALU bound, not HBM bound: 73 flops per Gaussian
                 # per 4 pixels of a lane (5 shared + 34 per packed pixel pair) => 18.25 flops per (step, pixel), a step
@@ -227,6 +276,8 @@ def main():
     out = {
         "metric": "render_fps", "value": round(head["fps"], 2), "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(head["ms"], 4),
+        "repeats": head["repeats"], "ms_per_step_min": round(head["ms_min"], 4),
+        "ms_per_step_max": round(head["ms_max"], 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": workload_name(args.config, st), "n_gaussians": n, "visible": st.visible,
@@ -258,7 +309,7 @@ def main():
                 rs[i].forward(*params, cam)
 
         k = max(args.steps, 50)
-        dtp = time_frames(pipelined_frame, k, 10)
+        dtp, _ = time_frames(pipelined_frame, k, 10)
         extra["three_frames_in_flight_fps"] = round(world * k / dtp, 2)
         del rs, streams
     head_scene, head_cam = head["scene"], head["cam"]
@@ -270,7 +321,9 @@ def main():
     if "cfg2" in legs and args.config != "cfg2":
         c2 = render_leg("cfg2", max(args.steps, 50), max(args.warmup, 10))
         out["cfg2"] = {"workload": workload_name("cfg2", c2["stats"]), "render_fps": round(c2["fps"], 2),
-                       "ms_per_frame": round(c2["ms"], 4), "visible": c2["stats"].visible,
+                       "ms_per_frame": round(c2["ms"], 4), "repeats": c2["repeats"],
+                       "ms_per_frame_min": round(c2["ms_min"], 4), "ms_per_frame_max": round(c2["ms_max"], 4),
+                       "visible": c2["stats"].visible,
                        "tile_pairs": c2["stats"].pairs, "host_us_per_frame": round(c2["host_us"], 1)}
         if rank == 0:
             out["cfg2"].update(roofline=c2["roofline"], stages=c2["stages"], frame_roofline=c2["frame_roofline"])
@@ -278,7 +331,7 @@ def main():
         torch.cuda.empty_cache()
 
     # ---------------------------------------------------------------- training step (train.py:84-185, no densification)
-    def train_leg(cfg, params, cam, pairs, k, force=False):
+    def train_leg(cfg, params, cam, pairs, k, force=False, exchange="all_reduce"):
         """forward (checkpointing) -> L1 + 0.1 SSIM loss and gradient -> backward -> all-reduce of the flat gradient
         bucket (N > 1) -> fused Adam.  Returns (whole-job iterations/s, ms per iteration, detail dict on rank 0)."""
         from gs_train import TrainOptions, Trainer
@@ -290,15 +343,17 @@ def main():
         target = (r0.forward(*params, cam)[0] + 0.05 * torch.randn(Hc, Wc, 3, device=dev)).clamp_(0, 1).contiguous()
         del r0
         tr = Trainer([t.clone() for t in params], [cam], [target], TrainOptions(), world_size=world,
-                     max_pairs=int(pairs * 1.25) + 4096)
-        tr.flat.force_collective = use_dist or force
+                     max_pairs=int(pairs * 1.25) + 4096, exchange=exchange)
+        tr.flat.force_collective = (use_dist or force) and dist.is_initialized()
         it = [0]
 
         def train_iter():
             tr.train_step(it[0], 0)
             it[0] += 1
 
-        dtt = time_frames(train_iter, k, 30)
+        # ONE block: every iteration moves the scene a little (the noisy target lowers opacities, tiles composite more
+        # Gaussians before they saturate), so more blocks would time a different scene, not the same one again
+        dtt, _ = time_frames(train_iter, k, 30, repeats=1)
         assert tr.renderer.overflowed_frames == 0 and not tr.renderer.last_frame_overflowed(wait=True)
         detail = {}
         if rank == 0:
@@ -349,35 +404,51 @@ def main():
             torch.cuda.empty_cache()
 
     # ---------------------------------------------------------------- multi-GPU: the gradient exchange of a training step
-    if "multi_gpu" in legs and not CONFIGS[args.config][3] and (use_dist or args.force_collective):
+    if "multi_gpu" in legs and not CONFIGS[args.config][3] and use_dist:
+        # both exchange modes of gs_dp.py, same scene, same step: (a) two asynchronous mean all-reduces + replicated
+        # fused Adam, (b) two mean reduce-scatters + Adam over the rank's slices + all-gather of the parameters
         k = max(args.steps // 4, 25)
-        views_per_s, ms, _, tr = train_leg(args.config, head_params, head_cam, st.pairs, k, force=True)
-        flat = tr.flat
-        seen = 1
-        if use_dist:
-            t = torch.ones(1, device=dev)
-            dist.all_reduce(t)
-            seen = int(t.item())
-        ar_ms = None
-        if dist.is_initialized():
+        seen = torch.ones(1, device=dev)
+        dist.all_reduce(seen)
+        seen = int(seen.item())
+        mg = {"ranks_seen": seen, "modes": {}}
+        for exchange in ("all_reduce", "reduce_scatter"):
+            views_per_s, ms, _, tr = train_leg(args.config, head_params, head_cam, st.pairs, k, force=True,
+                                               exchange=exchange)
+            flat = tr.flat
+            flat.finish_gather()
+            mg["bucket_bytes"] = flat.bucket_bytes
+
+            def exchange_only():
+                # the collectives of one step, nothing else: both buckets reduced (and, in reduce-scatter mode, the
+                # parameters gathered back), as gs_train.Trainer.train_step issues them
+                for name in ("geometry", "color"):
+                    flat.begin_bucket(name)
+                for name in ("geometry", "color"):
+                    flat.finish_bucket(name)
+                    flat.begin_gather(name)
+                flat.finish_gather()
+
             for _ in range(3):
-                flat.all_reduce_grads()
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(10):
-                flat.all_reduce_grads()
-            torch.cuda.synchronize()
-            ar_ms = max_over_ranks((time.perf_counter() - t0) / 10 * 1e3)
-        out["multi_gpu"] = {
-            "ranks_seen": seen, "bucket_bytes": flat.bucket_bytes, "allreduce_ms": None if ar_ms is None else round(ar_ms, 4),
-            "allreduce_busbw_GBs": None if not ar_ms or seen < 2 else round(
-                2 * (seen - 1) / seen * flat.bucket_bytes / (ar_ms * 1e-3) / 1e9, 1),
-            "train_views_per_s": round(views_per_s, 2), "train_ms_per_iter": round(ms, 4),
-            "collective": "one all-reduce (mean) of the flat fp32 gradient bucket per iteration, RCCL"
-                          if use_dist else "no process group: collective skipped (run under torchrun)",
-            "note": "no 2/4/8-GPU scaling curve has been measured by the builder (one GPU per gpurun box)"}
-        del tr
-        torch.cuda.empty_cache()
+                exchange_only()
+            ex_ms = time_block(exchange_only, 10) / 10 * 1e3
+            mg["modes"][exchange] = {
+                "train_views_per_s": round(views_per_s, 2), "train_ms_per_iter": round(ms, 4),
+                "exchange_ms": round(ex_ms, 4),
+                "busbw_GBs": None if seen < 2 else round(2 * (seen - 1) / seen * flat.bucket_bytes / (ex_ms * 1e-3) / 1e9, 1),
+                "optimizer_state_bytes_per_rank": sum(v.numel() for v in tr.optimizer.exp_avg.values()) * 8}
+            del tr, flat
+            torch.cuda.empty_cache()
+        best = max(mg["modes"], key=lambda m: mg["modes"][m]["train_views_per_s"])
+        mg.update(best_mode=best, train_views_per_s=mg["modes"][best]["train_views_per_s"],
+                  train_ms_per_iter=mg["modes"][best]["train_ms_per_iter"],
+                  allreduce_ms=mg["modes"]["all_reduce"]["exchange_ms"],
+                  allreduce_busbw_GBs=mg["modes"]["all_reduce"]["busbw_GBs"],
+                  collective="per iteration, RCCL: all_reduce = two asynchronous mean all-reduces of the flat fp32 "
+                             "gradient buckets + replicated fused Adam; reduce_scatter = two mean reduce-scatters + "
+                             "fused Adam over the rank's slices + all-gather of the parameters",
+                  note="1-GPU boxes only for the builder: no 2/4/8-GPU curve measured before the driver's SCALE run")
+        out["multi_gpu"] = mg
     del head_params
 
     # ---------------------------------------------------------------- cfg3 in miniature: does the step train?
@@ -418,9 +489,16 @@ def main():
     # ---------------------------------------------------------------- BASELINE configs[3]: 2.4 M Gaussians, SH, fwd + bwd
     if "cfg4" in legs and rank == 0 and world == 1:
         # hipEvent-timed stages.  Degree 2 (27 coefficients) is what the reference implements; degree 3 (48
-        # coefficients, what configs[3] names) is the extension.
+        # coefficients, what configs[3] names) is the extension.  Roofline objects per SURVEY.md 8d:
+        #   B_fwd = 44 N + (64 + 8 C) V + (72 + 4 C) M + 12 P + 4 T,  B_bwd = (32 + 4 C) M + 24 P + (100 + 12 C) V + (44 + 4 C) N
+        # and for the dominant kernel of the backward (raster backward, S6): R (32 + 4 C) M + 24 P, W (28 + 4 C) V.
         cfg4 = {}
+        try:
+            traffic4 = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        except (OSError, ValueError):
+            traffic4 = {}
         for deg in (2, 3):
+            n4, W4, H4, _ = CONFIGS["cfg4"]
             _, cam4, p4 = load("cfg4", sh_degree=deg)
             r4, st4 = sized_renderer(p4, cam4, training=True)
             img4, _ = r4.forward(*p4, cam4)
@@ -429,15 +507,47 @@ def main():
             bw = [r4.profile_backward(g4) for _ in range(6)][2:]
             f_ms = statistics.median(x["total"] for x in fw)
             b_ms = statistics.median(x["total"] for x in bw)
-            cfg4[f"sh_degree_{deg}"] = {"coefficients": 3 * (deg + 1) ** 2, "tile_pairs": st4.pairs,
-                                        "forward_ms": round(f_ms, 3), "backward_ms": round(b_ms, 3),
-                                        "raster_fwd_ms": round(statistics.median(x["raster"] for x in fw), 3),
-                                        "raster_bwd_ms": round(statistics.median(x["raster_bwd"] for x in bw), 3),
-                                        "project_bwd_ms": round(statistics.median(x["project_bwd"] for x in bw), 3),
-                                        "fwd_bwd_iters_per_s": round(1e3 / (f_ms + b_ms), 1)}
+            rb_ms = statistics.median(x["raster_bwd"] for x in bw)
+            C4 = 3 * (deg + 1) ** 2
+            P4 = (-(-W4 // 16) * 16) * (-(-H4 // 16) * 16)
+            V4, M4 = st4.visible, st4.pairs
+            b_fwd = 44 * n4 + (64 + 8 * C4) * V4 + (72 + 4 * C4) * M4 + 12 * P4 + 4 * (P4 // 256)
+            b_bwd = (32 + 4 * C4) * M4 + 24 * P4 + (100 + 12 * C4) * V4 + (44 + 4 * C4) * n4
+            b_rbw = (32 + 4 * C4) * M4 + 24 * P4 + (28 + 4 * C4) * V4
+
+            def roof(b, ms, **kw):
+                gbs = b / (ms * 1e-3) / 1e9
+                return {"bound": "hbm", "algorithmic_bytes": int(b), "ms": round(ms, 4), "achieved": round(gbs, 1),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), **kw}
+
+            tj = traffic4.get(f"cfg4_deg{deg}", {})
+            tr_bw = tj.get("raster_backward_pixel_sh_kernel", {}).get("traffic_bytes") if tj.get("tile_pairs") == M4 else None
+            cfg4[f"sh_degree_{deg}"] = {
+                "coefficients": C4, "visible": V4, "tile_pairs": M4,
+                "forward_ms": round(f_ms, 3), "backward_ms": round(b_ms, 3),
+                "raster_fwd_ms": round(statistics.median(x["raster"] for x in fw), 3),
+                "raster_bwd_ms": round(rb_ms, 3),
+                "project_bwd_ms": round(statistics.median(x["project_bwd"] for x in bw), 3),
+                "fwd_bwd_iters_per_s": round(1e3 / (f_ms + b_ms), 1),
+                "roofline_forward": roof(b_fwd, f_ms), "roofline_backward": roof(b_bwd, b_ms),
+                "roofline_fwd_bwd": roof(b_fwd + b_bwd, f_ms + b_ms),
+                "roofline_raster_backward_kernel": roof(
+                    b_rbw, rb_ms, kernel=f"raster_backward_pixel_sh_kernel<{C4}>", traffic=tr_bw,
+                    traffic_frac=None if tr_bw is None else round(tr_bw / (rb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))}
             del r4, p4, img4, g4
             torch.cuda.empty_cache()
         extra["cfg4_2p4M_sh_fwd_bwd"] = cfg4
+
+    # ---------------------------------------------------------------- zero-change integration mode
+    if "compat" in legs and rank == 0 and world == 1:
+        # the reference's own per-frame call sequence (splatter.py:562-641: T x MAXP table, cumsum, attribute gathers,
+        # torch.sort, host syncs) over the drop-in gaussian / renderer modules, at BASELINE configs[1] and at the
+        # north-star target scene; next to it the fused frame path the headline is measured on
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from compat_fps import measure as compat_measure
+
+        extra["compat_mode"] = {c: compat_measure(c, dev, frames=10 if c == "cfg5" else 20) for c in ("cfg2", "cfg5")}
+        torch.cuda.empty_cache()
     out["extra"] = extra
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)

@@ -334,6 +334,23 @@ int gs_adam_step_range(float *param, const float *grad, float *exp_avg, float *e
                        const float *lr, float beta1, float beta2, float eps, int64_t step, float *grad_stat,
                        int64_t stat_begin, int64_t stat_end, int32_t stat_mode, gs_stream_t stream);
 
+/* View-parallel training with a SHARDED optimizer (reduce-scatter -> this step -> all-gather of the parameters): the
+ * rank owns elements [range_begin, range_end) of the flat index space and keeps only THEIR moments: exp_avg_shard[0] /
+ * exp_avg_sq_shard[0] belong to element `moment_base` (a multiple of 4, <= range_begin); param / grad / the group table
+ * and the statistic range stay absolute.  `skip_if_nonzero` (may be NULL) is the device address of a 64-bit counter:
+ * when it is non-zero the launch leaves everything untouched -- pass gs_frame_overflow_flag() so that a training frame
+ * that overflowed its workspace (rendered empty, all-zero gradient) does not move the parameters by momentum, without
+ * any host synchronisation.  Every element's update is what gs_adam_step computes for it. */
+int gs_adam_step_sharded(float *param, const float *grad, float *exp_avg_shard, float *exp_avg_sq_shard, int64_t n,
+                         int64_t range_begin, int64_t range_end, int64_t moment_base, int32_t n_groups,
+                         const int64_t *group_end, const float *lr, float beta1, float beta2, float eps, int64_t step,
+                         float *grad_stat, int64_t stat_begin, int64_t stat_end, int32_t stat_mode,
+                         const void *skip_if_nonzero, gs_stream_t stream);
+
+/* Device address of the frame's overflow counter (inside the caller's workspace; 64-bit, 0 = the last forward of this
+ * frame description fitted its pair capacity, else the pair count it would have needed).  No launch, no copy. */
+int gs_frame_overflow_flag(const gs_frame *f, const void **device_counter);
+
 /* The same statistic without the Adam update: stat[i] = max(stat[i], |grad[i]|) (stat_mode 1) or stat[i] += |grad[i]|
  * (stat_mode 2) for i < n.  View-parallel training (one view per GPU) needs it: train.py:145-154 accumulates the
  * |gradient| of EACH VIEW, so every rank updates the statistic from its own gradient before the all-reduce averages

@@ -261,12 +261,14 @@ def test_backward_parts_and_bucketed_adam_equal_the_one_call_step(gpu, use_sh):
     outs = []
     for order in (None, ("geometry", "color"), ("color", "geometry")):
         flat = FlatGaussianParams([t.clone() for t in params])
-        assert flat.bucket_ranges["color"][0] % 4 != 0  # 10 N floats, N odd: misaligned on purpose
+        assert flat.offsets["scale"][0] % 4 != 0  # 7 N floats, N odd: a group boundary inside a float4, on purpose
+        assert flat.bucket_ranges["color"][0] % 4 == 0 and flat.bucket_ranges["color"][0] >= 10 * 7001  # padded
         r = FrameRenderer(gpu, max_pairs=1 << 17, training=True, auto_grow=False)
         opt = FusedAdam(flat, [lrs[k] for k in GROUPS], grad_stat="max")
         for _ in range(3):
             r.forward(*flat.params, cam)
-            flat.flat_grad.fill_(float("nan"))  # every element must be written by exactly one part
+            for gview in flat.grads:  # every element must be written by exactly one part (the buckets' padding is
+                gview.fill_(float("nan"))  # nobody's: it stays zero)
             if order is None:
                 r.backward(g, out=flat.grads)
                 opt.step()
@@ -278,7 +280,7 @@ def test_backward_parts_and_bucketed_adam_equal_the_one_call_step(gpu, use_sh):
                 opt.step(order[0])
                 opt.step(order[1], advance=False)
         assert opt.step_count == 3 and bool(torch.isfinite(flat.flat_grad).all())
-        outs.append((flat.flat_grad.clone(), flat.flat_param.clone(), opt.exp_avg_sq.clone(), opt.accum_grad.clone()))
+        outs.append((flat.flat_grad.clone(), flat.flat_param.clone(), torch.cat([opt.exp_avg_sq[k] for k in ("geometry", "color")]), opt.accum_grad.clone()))
     for other in outs[1:]:
         for a, b in zip(outs[0], other):
             assert torch.equal(a, b)
@@ -305,23 +307,28 @@ def test_trainer_bucketed_exchange_equals_plain_step(gpu):
     start[4] = start[4] + 0.5 * torch.randn(start[4].shape, device=gpu, generator=torch.Generator(gpu).manual_seed(2))
     opt = TrainOptions(n_iters=100, n_iters_warmup=3, scale_reg=0.01, opa_reg=0.02)
     runs = []
-    for bucketed in (False, True):
+    # plain step; bucketed all-reduce + replicated Adam; bucketed reduce-scatter + sharded Adam + parameter all-gather
+    for exchange in (None, "all_reduce", "reduce_scatter"):
+        bucketed = exchange is not None
         if bucketed:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=gpu)
         try:
-            tr = Trainer([t.clone() for t in start], [cam], [target], opt, max_pairs=1 << 16)
+            tr = Trainer([t.clone() for t in start], [cam], [target], opt, max_pairs=1 << 16,
+                         exchange=exchange or "all_reduce")
             tr.flat.force_collective = bucketed
-            assert tr.flat.collective_active() == bucketed
+            assert tr.flat.collective_active() == bucketed and tr.optimizer.sharded == (exchange == "reduce_scatter")
             vals = [tr.train_step(it, 0).clone() for it in range(12)]
+            tr.flat.finish_gather()
             runs.append(([p.clone() for p in tr.flat.params], torch.stack(vals), tr.optimizer.accum_grad.clone()))
         finally:
             if bucketed:
                 dist.destroy_process_group()
-    for a, b in zip(runs[0][0], runs[1][0]):
-        assert torch.equal(a, b)
-    assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+    for other in runs[1:]:
+        for a, b in zip(runs[0][0], other[0]):
+            assert torch.equal(a, b)
+        assert torch.equal(runs[0][1], other[1]) and torch.equal(runs[0][2], other[2])
     assert float((runs[0][0][0] - start[0]).abs().max()) > 0
 
 

@@ -100,7 +100,9 @@ def _bucket_worker(rank, world, port, tmp):
             flat.all_reduce_grads()
         else:
             assert flat.collective_active()
-            assert flat.bucket_ranges == {"geometry": (0, 10 * n), "color": (10 * n, 38 * n)}
+            # every bucket is padded to a multiple of 4 x world elements: equal, float4-aligned slices per rank
+            assert flat.bucket_ranges == {"geometry": (0, 5016), "color": (5016, 5016 + 14032)}
+            assert flat.offsets["opa"] == (5016, 5016 + n) and flat.group_ends == [4 * n, 7 * n, 5016, 5016 + n, 19048]
             flat.begin_bucket("color")      # the order gs_train.Trainer uses with SH colours
             flat.begin_bucket("geometry")
             flat.finish_bucket("color")
@@ -122,6 +124,51 @@ def test_bucketed_async_exchange_equals_blocking_all_reduce_gloo(tmp_path):
         assert np.array_equal(r[k][1], r[k][2])          # bucketed == blocking, bit for bit
         assert np.allclose(r[k][1], expect, rtol=1e-6, atol=1e-9)
     assert np.array_equal(r[0][2], r[1][2])
+
+
+def _exchange_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gs_dp import FlatGaussianParams
+
+    n = 333  # 10 n and 4 n are no multiples of 8: both buckets are padded
+    shapes = [(n, 3), (n, 4), (n, 3), (n,), (n, 3)]
+    params = [torch.from_numpy(np.random.default_rng(5).normal(size=s).astype(np.float32)) for s in shapes]  # replicas
+    out = {}
+    for exchange in ("all_reduce", "reduce_scatter"):
+        flat = FlatGaussianParams(params, world_size=world, exchange=exchange)
+        assert flat.rank == rank
+        for step in range(3):
+            g = np.random.default_rng(1000 * step + rank).normal(size=flat.flat_grad.numel()).astype(np.float32)
+            flat.flat_grad.copy_(torch.from_numpy(g))
+            flat.finish_gather()  # what Trainer.train_step does before it reads the parameters
+            for name in ("color", "geometry"):
+                flat.begin_bucket(name)
+            for name in ("color", "geometry"):
+                flat.finish_bucket(name)
+                lo, hi = flat.optimizer_range(name)  # the whole bucket, or this rank's slice of it
+                lo_b, hi_b = flat.bucket_ranges[name]
+                assert (lo, hi) == ((lo_b, hi_b) if exchange == "all_reduce" else flat.shard_range(name))
+                assert (hi - lo) * (world if exchange == "reduce_scatter" else 1) == hi_b - lo_b and lo % 4 == 0
+                # stand-in for the fused Adam (HIP only): an elementwise update of what this rank owns
+                flat.flat_param[lo:hi].sub_(0.1 * flat.flat_grad[lo:hi] + 0.01 * torch.sign(flat.flat_param[lo:hi]))
+                flat.begin_gather(name)
+        flat.finish_gather()
+        out[exchange] = flat.flat_param.numpy().copy()
+    np.save(os.path.join(tmp, f"exchange_{rank}.npy"), np.stack([out["all_reduce"], out["reduce_scatter"]]))
+    dist.destroy_process_group()
+
+
+def test_reduce_scatter_sharded_update_equals_all_reduce_replicated_gloo(tmp_path):
+    """gs_dp exchange modes: reduce-scatter -> update of the rank's own slice -> all-gather of the parameters leaves
+    every rank with exactly the parameters that all-reduce -> update of everything gives (2 gloo ranks, 3 steps)."""
+    world, port = 2, 35500 + (os.getpid() % 2000)
+    mp.spawn(_exchange_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"exchange_{k}.npy") for k in range(world)]
+    for k in range(world):
+        assert np.array_equal(r[k][0], r[k][1])  # sharded == replicated, bit for bit
+    assert np.array_equal(r[0][1], r[1][1])      # and the replicas agree
+    assert np.abs(r[0][0]).max() > 0
 
 
 def _stat_worker(rank, world, port, tmp, mode):
