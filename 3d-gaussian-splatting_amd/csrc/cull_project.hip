@@ -422,13 +422,19 @@ __global__ void __launch_bounds__(256) frame_project_kernel(
                 col = make_float4(sigmoid_f(rgb[pid * 3 + 0]), sigmoid_f(rgb[pid * 3 + 1]),
                                   sigmoid_f(rgb[pid * 3 + 2]), 0.0f);
         }
-        float cA = 0.f, cB = 0.f, cC = 0.f;
-        if (vis) gs_conic(c.x, c.y, c.z, c.w, cA, cB, cC);
-        float4 *rec = rec_geom + pid * GS_REC_STRIDE;  // one 64-byte record per Gaussian
-        rec[0] = g;
-        rec[1] = c;
-        rec[2] = col;
-        rec[3] = make_float4(cA, cB, cC, 0.f);
+        // A culled Gaussian leaves 20 bytes -- its all-zero rectangle, which is what every later stage looks at first
+        // (rects[i].z, the depth bits, is 0 exactly for culled Gaussians: visible ones lie beyond the near plane) --
+        // and NOT its 64-byte record: nothing reads the record of a Gaussian that is in no tile's list (21 % of the
+        // Gaussians of the 2.4 M scene: 33 of this kernel's 337 MB).  The record of a culled Gaussian is unspecified.
+        if (vis) {
+            float cA = 0.f, cB = 0.f, cC = 0.f;
+            gs_conic(c.x, c.y, c.z, c.w, cA, cB, cC);
+            float4 *rec = rec_geom + pid * GS_REC_STRIDE;  // one 64-byte record per Gaussian
+            rec[0] = g;
+            rec[1] = c;
+            rec[2] = col;
+            rec[3] = make_float4(cA, cB, cC, 0.f);
+        }
         tiles_touched[pid] = cnt;
         rects[pid] = make_uint4(rc.x, rc.y, __float_as_uint(g.z), cnt);
     }
@@ -464,7 +470,7 @@ __global__ void __launch_bounds__(256) frame_project_backward_kernel(
     const float *__restrict__ pos, const float4 *__restrict__ quat, const float *__restrict__ scale,
     int64_t n, ProjectParams P, const float4 *__restrict__ rec_geom,
     const float4 *__restrict__ rec_color, const float4 *__restrict__ rows, const uint8_t *__restrict__ row_flags,
-    const uint32_t *__restrict__ pair_offsets, const uint32_t *__restrict__ tiles_touched, uint64_t max_pairs,
+    const uint32_t *__restrict__ pair_offsets, const uint4 *__restrict__ rects, uint64_t max_pairs,
     float *__restrict__ grad_pos,
     float4 *__restrict__ grad_quat, float *__restrict__ grad_scale, float *__restrict__ grad_opa,
     float *__restrict__ grad_rgb) {
@@ -472,23 +478,26 @@ __global__ void __launch_bounds__(256) frame_project_backward_kernel(
     // order).  A thread walking its own 3.7 rows with float4 loads touches 64 different cache lines per wave
     // instruction; instead the range is streamed through LDS with coalesced loads, chunk by chunk, and every
     // thread adds up its rows out of LDS in the same k-ascending order (results are bitwise unchanged).
-    constexpr int CHUNK_F4 = 1536;  // 24 KiB = 512 rows
-    __shared__ float4 s_rows[CHUNK_F4];
-    __shared__ uint8_t s_flag[CHUNK_F4 / 3];
+    constexpr int CHUNK_F4 = 1536;  // 24 KiB = 512 rows (rgb rows only: SH rows are read straight from memory)
+    __shared__ float4 s_rows[CDIM == 3 ? CHUNK_F4 : 1];
+    __shared__ uint8_t s_flag[CDIM == 3 ? CHUNK_F4 / 3 : 1];
     const int64_t pid0 = (int64_t)blockIdx.x * blockDim.x, pid = pid0 + threadIdx.x;
     const int64_t pid_last = (pid0 + blockDim.x < n ? pid0 + blockDim.x : n) - 1;
     const bool valid = pid < n;
-    const float4 g = valid ? rec_geom[pid * GS_REC_STRIDE] : make_float4(0, 0, 0, 0);
+    // (y0 | y1 << 16, x0 | x1 << 16, depth bits, tiles touched); depth bits != 0 <=> visible (depth > near > 0).  The
+    // record of a culled Gaussian is unspecified (frame_project_kernel does not write it): not read.
+    const uint4 rc = valid ? rects[pid] : make_uint4(0, 0, 0, 0);
+    const bool vis = rc.z != 0;
+    const float4 g = vis ? rec_geom[pid * GS_REC_STRIDE] : make_float4(0, 0, 0, 0);
     float gp[3] = {0, 0, 0}, gqr[4] = {0, 0, 0, 0}, gsr[3] = {0, 0, 0}, gopa = 0, gcol[3] = {0, 0, 0};
     constexpr int RW4 = gs_row_floats(CDIM) / 4;  // float4s per row
     float gsh[CDIM > 3 ? 4 * RW4 - 8 : 1];        // sums of row[2..]: gsh[k - 1] is SH coefficient k >= 1
-    const bool vis = valid && g.z != 0.0f;        // visible (depth > near > 0)
     float4 d0 = make_float4(0, 0, 0, 0), d1 = d0, d2 = d0;
     if (CDIM > 3) {
 #pragma unroll
         for (int k = 0; k < 4 * RW4 - 8; ++k) gsh[k] = 0.f;
     }
-    const uint64_t off = vis ? pair_offsets[pid] : 0, cnt = vis ? tiles_touched[pid] : 0;
+    const uint64_t off = vis ? pair_offsets[pid] : 0, cnt = rc.w;
 
     // A Gaussian that covers hundreds of tiles (early in training from a sparse cloud; a scale that blew up) would
     // keep ONE thread adding its rows while 255 wait: 195 us instead of 40 us for this kernel in a 500 k-Gaussian fit.
@@ -552,7 +561,7 @@ __global__ void __launch_bounds__(256) frame_project_backward_kernel(
     if (CDIM == 3) {
         constexpr uint32_t rows_per_chunk = CHUNK_F4 / 3;
         uint64_t row_begin = pair_offsets[pid0];
-        uint64_t row_end = (uint64_t)pair_offsets[pid_last] + tiles_touched[pid_last];
+        uint64_t row_end = (uint64_t)pair_offsets[pid_last] + rects[pid_last].w;
         if (row_end > max_pairs) row_end = max_pairs;
         for (uint64_t base = row_begin; base < row_end; base += rows_per_chunk) {
             const uint32_t nrows = row_end - base < rows_per_chunk ? (uint32_t)(row_end - base) : rows_per_chunk;
@@ -574,8 +583,20 @@ __global__ void __launch_bounds__(256) frame_project_backward_kernel(
     } else {
         // SH rows are 144 (224) contiguous bytes: a thread reading its own rows already moves whole sectors
         // (measured: the LDS detour costs 25 % here)
-        for (uint64_t k = 0; k < cnt && off + k < max_pairs && !big; ++k) {
-            if (!row_flags[off + k]) continue;
+        // Which of this Gaussian's rows were written (a tile that saturated before it reached the Gaussian wrote none:
+        // ~70 % of the rows of the 2.4 M scene) is collected FIRST, 64 one-byte flags at a time -- independent loads,
+        // all in flight together -- and only the written rows are walked.  A wave's trip count is then the largest
+        // number of WRITTEN rows among its 64 Gaussians instead of the largest rectangle (up to ~36 tiles against 3.7
+        // on average): the loop that loads 144 / 224 bytes and adds 36 / 56 floats per trip shrinks ~3x.  Same rows, same
+        // ascending order: the sums are bitwise unchanged.
+        const uint64_t nrow = big ? 0 : (off + cnt < max_pairs ? cnt : (max_pairs > off ? max_pairs - off : 0));
+        for (uint64_t k0 = 0; k0 < nrow; k0 += 64) {
+          const uint32_t m = nrow - k0 < 64 ? (uint32_t)(nrow - k0) : 64u;
+          unsigned long long written = 0;
+          for (uint32_t j = 0; j < m; ++j) written |= (unsigned long long)(row_flags[off + k0 + j] != 0) << j;
+          while (written) {
+            const uint64_t k = k0 + (uint64_t)(__ffsll((long long)written) - 1);
+            written &= written - 1;
             const float4 *row = rows + (off + k) * RW4;
             if (PART != 2) {
                 const float4 r0 = row[0];
@@ -590,6 +611,7 @@ __global__ void __launch_bounds__(256) frame_project_backward_kernel(
                     gsh[4 * m] += r.x; gsh[4 * m + 1] += r.y; gsh[4 * m + 2] += r.z; gsh[4 * m + 3] += r.w;
                 }
             }
+          }
         }
     }
     if (!valid) return;
@@ -635,14 +657,19 @@ __global__ void __launch_bounds__(256) frame_project_backward_kernel(
     }
     if (PART == 1) return;
     grad_opa[pid] = gopa;
-    if (CDIM == 3) {
+    if constexpr (CDIM == 3) {
         grad_rgb[pid * 3 + 0] = gcol[0];
         grad_rgb[pid * 3 + 1] = gcol[1];
         grad_rgb[pid * 3 + 2] = gcol[2];
     } else {  // SH coefficients are raw parameters: the summed rows are the gradient
-        grad_rgb[pid * CDIM] = vis ? d1.w : 0.f;
+        // (staging the CDIM floats of 256 Gaussians in LDS and storing them as consecutive float4s was measured: deg 2
+        // 0.470 against 0.484 ms, deg 3 0.71 against 0.58 ms -- the 54 KiB of LDS cost more than the scattered 4-byte
+        // stores, which L2 merges)
+        if (valid) {
+            grad_rgb[pid * CDIM] = vis ? d1.w : 0.f;
 #pragma unroll
-        for (int k = 1; k < CDIM; ++k) grad_rgb[pid * CDIM + k] = vis ? gsh[k - 1] : 0.f;
+            for (int k = 1; k < CDIM; ++k) grad_rgb[pid * CDIM + k] = vis ? gsh[k - 1] : 0.f;
+        }
     }
 }
 
@@ -767,7 +794,7 @@ int gs_stage_project_backward(const gs_frame *f, const gs_frame_ws &ws, float *g
 #define GS_LAUNCH_PROJECT_BWD(CD, PT)                                                                              \
     hipLaunchKernelGGL((frame_project_backward_kernel<CD, PT>), dim3(nblk), dim3(256), 0, stream, f->pos,         \
                        (const float4 *)f->quat, f->scale, f->N, P, ws.rec_geom, ws.rec_color,                     \
-                       (const float4 *)ws.rows, ws.row_flags, ws.pair_offsets, ws.tiles_touched,                  \
+                       (const float4 *)ws.rows, ws.row_flags, ws.pair_offsets, ws.rects,                          \
                        (uint64_t)f->max_pairs,                                                                    \
                        grad_pos, (float4 *)grad_quat, grad_scale, grad_opa, grad_rgb)
 #define GS_LAUNCH_PROJECT_BWD_PARTS(CD)  \

@@ -64,7 +64,7 @@ static int validate(const gs_frame *f) {
         GS_CHECK_ARG(f->thresh > 0.f && f->thresh < 1.f, "thresh must be in (0,1)");
     }
     GS_CHECK_ARG((f->flags & ~(GS_FRAME_EMIT_SORTED_KEYS | GS_FRAME_SLICE_SORT | GS_FRAME_TABLE_BIN |
-                               GS_FRAME_SERIAL_LONG_LISTS | GS_FRAME_LONG_LISTS)) == 0,
+                               GS_FRAME_SERIAL_LONG_LISTS | GS_FRAME_LONG_LISTS | GS_FRAME_STRIP_BIN)) == 0,
                  "unknown flag bits");
     GS_CHECK_ARG(f->sort_mode >= 0 && f->sort_mode <= 2,
                  "sort_mode must be 0 (full LSD radix), 1 (tile-bit radix + per-tile LDS sort) or 2 (LDS counting sort "
@@ -391,6 +391,26 @@ extern "C" int gs_frame_debug_tile_nproc(const gs_frame *f, const uint32_t **til
     GS_CHECK_ARG(f->training, "the per-tile processed counts are kept by training forwards only");
     gs_frame_ws ws = gs_frame_carve(f->workspace, f->N, f->max_pairs, f->width, f->height, f->color_dim, 1);
     *tile_nproc = ws.tile_nproc;
+    return 0;
+}
+
+// Which binning / sort path gs_frame_forward takes for this frame description: 0 / 1 = sort_mode 0 / 1 (radix passes),
+// 2 = sort_mode 2 table variant, 3 = slice-sorted variant, 4 = strip variant; negative: the description is invalid.
+extern "C" int gs_frame_binning_variant(const gs_frame *f) {
+    int rc = validate(f);
+    if (rc) return rc < 0 ? rc : -rc;
+    const int mode = effective_sort_mode(f);
+    if (mode != 2) return mode;
+    if (use_strip_variant(f)) return 4;
+    return (f->flags & GS_FRAME_SLICE_SORT) ? 3 : 2;
+}
+
+extern "C" int gs_frame_debug_rects(const gs_frame *f, const uint32_t **rects) {
+    int rc = validate(f);
+    if (rc) return rc;
+    GS_CHECK_ARG(rects != nullptr, "rects is null");
+    gs_frame_ws ws = gs_frame_carve(f->workspace, f->N, f->max_pairs, f->width, f->height, f->color_dim, f->training);
+    *rects = reinterpret_cast<const uint32_t *>(ws.rects);
     return 0;
 }
 

@@ -97,10 +97,20 @@ static inline gs_strip_plan gs_strip_plan_for(int64_t N, int ntx, int nty) {
 
 // sort_mode 2 runs the strip variant (strip_bin.hip) unless the caller asks for one of the others or the frame is outside
 // its limits (2^26 Gaussians, GS_STRIP_MAX strips)
+// Below GS_STRIP_AUTO_MIN_N Gaussians the frame is bound by the latency of its chain of dependent kernels, not by their
+// throughput, and the table variant's chain is the shorter one (tools/sweep_n.py --table / --strip, profiles/r03_b_sweep_
+// table_vs_strip.jsonl: 20.2 k against 16.1 k FPS at 10 k Gaussians, equal at 100 k, 9.4 k against 9.7 k at 200 k);
+// GS_FRAME_STRIP_BIN overrides the choice.
+#ifndef GS_STRIP_AUTO_MIN_N
+#define GS_STRIP_AUTO_MIN_N 131072
+#endif
 static inline bool gs_frame_uses_strips(const gs_frame *f) {
     if (f->sort_mode != 2 || (f->flags & (GS_FRAME_SLICE_SORT | GS_FRAME_TABLE_BIN))) return false;
     const int ntx = (f->width + GS_TILE - 1) / GS_TILE, nty = (f->height + GS_TILE - 1) / GS_TILE;
-    return gs_strip_plan_for(f->N, ntx, nty).ok != 0;
+    if (!gs_strip_plan_for(f->N, ntx, nty).ok) return false;
+    if (f->flags & GS_FRAME_STRIP_BIN) return true;
+    // small scenes take the table variant where it exists (one LDS counter per tile)
+    return f->N >= GS_STRIP_AUTO_MIN_N || ntx * nty > GS_BIN_MAX_TILES;
 }
 
 // floats per per-pair gradient row: (dx, dy, da, db, dc, dd, dopa) + colour grads, padded to float4s

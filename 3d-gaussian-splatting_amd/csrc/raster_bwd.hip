@@ -33,7 +33,7 @@
 
 int gs_raster_forward_ref(const RasterSrc &S, const RasterGeom &G, const int32_t *accum, float *res, int use_sh,
                           int sigmoid, int weight_normalize, float4 *ckpt, uint32_t *tile_nproc,
-                          hipStream_t stream);
+                          hipStream_t stream, int exact);
 
 namespace {
 
@@ -150,7 +150,9 @@ struct BwdCfg {
 // alpha = 2 / (1 + e^-a) - 1 with a = p0 G opa, p0 = (pi/2) rsqrt(det + 1e-7) (gaussian.cu:593-594, 918, 930).
 // p0 is folded into the lane's opacity; its own cov gradient (gaussian.cu:622-630) only needs sum(dL/da G), which
 // is the opacity accumulator, so the loop pays two extra transcendentals and three plain instructions.
-template <int CDIM, bool FRAME, bool SIG = false>
+// EXACT (reference API, `fast = 0`, gaussian.cu:596-603): the Gaussian's value through a double-precision exp of the
+// float argument, as the reference's backward evaluates it; v_exp_f32 otherwise.
+template <int CDIM, bool FRAME, bool SIG = false, bool EXACT = false>
 __global__ void __launch_bounds__(64 * BwdCfg<CDIM>::WPB) raster_backward_kernel(RasterSrc S, RasterGeom G, BwdIn I,
                                                                               BwdOut O) {
     static_assert(!(FRAME && SIG), "the frame path has no alpha squashing (splatter.py:627 passes sigmoid=False)");
@@ -325,7 +327,7 @@ __global__ void __launch_bounds__(64 * BwdCfg<CDIM>::WPB) raster_backward_kernel
 
             const float dx = px - g.x, dy = py - g.y;
             const float q = fmaf(cC * dy, dy, dx * fmaf(-cB, dy, cA * dx));  // same evaluation order as the forward
-            const float Gv = gs_exp2(-q);
+            const float Gv = EXACT ? (float)exp(-(double)(q * GS_LN2)) : gs_exp2(-q);
             const bool live = T > GS_T_STOP;
             const float araw = live ? Gv * opa : 0.f;  // before squashing
             const float alpha = SIG ? 2.0f / (__expf(-araw) + 1.0f) - 1.0f : araw;
@@ -723,9 +725,10 @@ struct PixShCfg {
 #ifndef GS_BWD_SH_WPE
 #define GS_BWD_SH_WPE 4  // waves per SIMD the register allocation aims at (A/B switch, tools/ab_variants.py)
 #endif
-template <int CDIM, bool FRAME>
+template <int CDIM, bool FRAME, bool EXACT = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CDIM == 48 ? GS_BWD_SH48_WPE : GS_BWD_SH_WPE)))
 raster_backward_pixel_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
+    static_assert(!(EXACT && FRAME), "the exact-exp flavour belongs to the reference API (gs_draw_backward, fast = 0)");
     constexpr int NB = PixShCfg<CDIM>::NB, NROW = PixShCfg<CDIM>::NROW;
     typedef float f2 __attribute__((ext_vector_type(2)));
     enum { FX, FY, FA, FB, FC, FOPA, FC0, FC1, FC2, NFLD };  // FC0..2: the Gaussian's colour (CDIM == 3 only)
@@ -876,7 +879,10 @@ raster_backward_pixel_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
         for (int h = 0; h < 2; ++h) {
             const f2 dy = py2[h] - splat(gy);
             const f2 q = pk_fma(pk_fma(splat(uC), dy, splat(-bdx)), dy, splat(adx2));
-            const f2 Gv = {gs_exp2(-q.x), gs_exp2(-q.y)};
+            // EXACT: a double-precision exp of the float argument, as the reference's backward does for fast = 0
+            // (gaussian.cu:596-603)
+            const f2 Gv = EXACT ? f2{(float)exp(-(double)(q.x * GS_LN2)), (float)exp(-(double)(q.y * GS_LN2))}
+                                : f2{gs_exp2(-q.x), gs_exp2(-q.y)};
             // colours of the pixel pair
             f2 c0, c1, c2;
             if constexpr (CDIM > 3) {
@@ -1015,10 +1021,13 @@ raster_backward_pixel_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
 // sigmoid=True of the reference API: ceil buckets in the systolic kernel, no tail kernel (a rarely used flag)
 template <int CDIM>
 void launch_bwd_sig(const RasterSrc &S, const RasterGeom &G, const BwdIn &I, const BwdOut &O, int64_t max_buckets,
-                    hipStream_t stream) {
+                    hipStream_t stream, int exact) {
     constexpr int WPB = BwdCfg<CDIM>::WPB;
     const int grid = (int)gs_div_up(max_buckets > 0 ? max_buckets : 1, WPB);
-    hipLaunchKernelGGL((raster_backward_kernel<CDIM, false, true>), dim3(grid), dim3(64 * WPB), 0, stream, S, G, I, O);
+    if (exact)
+        hipLaunchKernelGGL((raster_backward_kernel<CDIM, false, true, true>), dim3(grid), dim3(64 * WPB), 0, stream, S, G, I, O);
+    else
+        hipLaunchKernelGGL((raster_backward_kernel<CDIM, false, true>), dim3(grid), dim3(64 * WPB), 0, stream, S, G, I, O);
 }
 
 #ifndef GS_BWD_SH_PIXEL
@@ -1085,7 +1094,7 @@ extern "C" int gs_draw_backward(const float *pos, const float *rgb, const float 
                                 int sigmoid, int fast, const float *rays_o, const float *lefttop_pos,
                                 const float *vec_dx, const float *vec_dy, int use_sh_coeff, void *workspace,
                                 size_t workspace_bytes, gs_stream_t stream) {
-    (void)fast;
+    const int exact = fast ? 0 : 1;  // fast = 0: the reference's exp() flavour (gaussian.cu:596-603, 922-923)
     (void)weight_normalize;  // the reference backward ignores it as well (gaussian.cu:440-803)
     GS_CHECK_ARG(h > 0 && w > 0 && (h % 16) == 0 && (w % 16) == 0, "h, w must be positive multiples of 16");
     GS_CHECK_ARG(M >= 0, "M < 0");
@@ -1119,7 +1128,7 @@ extern "C" int gs_draw_backward(const float *pos, const float *rgb, const float 
     }
     // 1. replay the forward to checkpoint (T, C_run) at every bucket boundary
     int rc = gs_raster_forward_ref(S, G, tile_n_point_accum, nullptr, use_sh_coeff, sigmoid, 0, ws.ckpt,
-                                   ws.tile_nproc, s);
+                                   ws.tile_nproc, s, exact);
     if (rc) return rc;
     // 2. bucket work list
     hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, s, ws.tile_nproc, G.ntx * G.nty,
@@ -1127,10 +1136,15 @@ extern "C" int gs_draw_backward(const float *pos, const float *rgb, const float 
     // 3. one wave per bucket, one output row per pair
     BwdIn I = {output, grad_output, ws.ckpt, ws.tile_nproc, ws.bucket_offsets, ws.bucket_info, tile_n_point_accum};
     BwdOut O = {nullptr, nullptr, nullptr, nullptr, 0, grad_pos, grad_rgb, grad_opa, grad_cov};
+    const unsigned nb = (unsigned)(ws.max_buckets > 0 ? ws.max_buckets : 1);
     if (sigmoid && use_sh_coeff)
-        launch_bwd_sig<27>(S, G, I, O, ws.max_buckets, s);
+        launch_bwd_sig<27>(S, G, I, O, ws.max_buckets, s, exact);
     else if (sigmoid)
-        launch_bwd_sig<3>(S, G, I, O, ws.max_buckets, s);
+        launch_bwd_sig<3>(S, G, I, O, ws.max_buckets, s, exact);
+    else if (exact && use_sh_coeff)
+        hipLaunchKernelGGL((raster_backward_pixel_sh_kernel<27, false, true>), dim3(nb), dim3(64), 0, s, S, G, I, O);
+    else if (exact)
+        hipLaunchKernelGGL((raster_backward_pixel_sh_kernel<3, false, true>), dim3(nb), dim3(64), 0, s, S, G, I, O);
     else if (use_sh_coeff)
         launch_bwd<27, false>(S, G, I, O, ws.max_buckets, s);
     else

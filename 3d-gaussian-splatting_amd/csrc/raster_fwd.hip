@@ -35,7 +35,7 @@ struct FwdSmem {  // SH: CDIM = 27 (degree 2) or 48 (degree 3) raw coefficients 
     static constexpr int CH = 64;
     static constexpr int NB = CDIM / 3;
     static constexpr int SHS = CDIM == 27 ? 28 : CDIM + 4;  // record stride: 16-byte rows, 4-way conflicts on the fill
-    enum { X, Y, A, B, C, NLOP, NFIELD };
+    enum { X, Y, A, B, C, NLOP, DH, DL, NFIELD };  // DH, DL: exact-exp flavour only (see FwdSmem<3>)
     // ONE buffer: the single wave stages chunk k + 1 after it has composited chunk k (LDS operations of a wave execute in
     // order), and the coefficients are loaded in the iteration that consumes them anyway; a second buffer only halved
     // the waves per SIMD (17 / 30 KiB per wave: 2 / 1 waves per SIMD for degree 2 / 3)
@@ -47,7 +47,10 @@ template <>
 struct FwdSmem<3> {
     // structure of arrays: four consecutive Gaussians of one field are one ds_read_b128
     static constexpr int CH = 64;
-    enum { X, Y, A, B, C, NLOP, R, G, BL, NFIELD };  // NLOP = -log2(opacity)
+    // NLOP = -log2(opacity) (frame path) or the opacity (reference API).  Exact-exp flavour of the reference API
+    // (`fast = 0`, gaussian.cu:922-923): A, B, C hold the raw covariance entries a, b + c, d and DH + DL the double
+    // 2 det + 1e-14 as two floats (48 of its 53 bits)
+    enum { X, Y, A, B, C, NLOP, R, G, BL, DH, DL, NFIELD };
     static constexpr int NBUF = 2;
     float f[NBUF][NFIELD][CH] __attribute__((aligned(16)));
 };
@@ -93,12 +96,13 @@ __device__ __forceinline__ f2 live_mask(f2 t, f2 scale, f2 bias) {
 #define GS_FWD_RGB_WPE 1
 #endif
 #ifndef GS_FWD_SH27_WPE
-#define GS_FWD_SH27_WPE 2  // waves per SIMD the register allocation of the SH kernels aims at (A/B switches)
+#define GS_FWD_SH27_WPE 3  // waves per SIMD the register allocation of the SH kernels aims at (A/B switches; degree 2 at
+                           // 3: 168 VGPRs and 22 spilled outside the loop, 0.535 -> 0.510 ms at 2.4 M Gaussians)
 #endif
 #ifndef GS_FWD_SH48_WPE
 #define GS_FWD_SH48_WPE 2
 #endif
-template <int CDIM, bool FRAME, bool CKPT, bool SIG, bool WN>
+template <int CDIM, bool FRAME, bool CKPT, bool SIG, bool WN, bool EXACT = false>
 __global__ void __launch_bounds__(FWD_THREADS)
 __attribute__((amdgpu_waves_per_eu(CDIM == 48 ? GS_FWD_SH48_WPE : CDIM == 27 ? GS_FWD_SH27_WPE : GS_FWD_RGB_WPE)))
 raster_forward_kernel(RasterSrc S, RasterGeom G,
@@ -112,6 +116,7 @@ raster_forward_kernel(RasterSrc S, RasterGeom G,
                                                                     uint32_t *__restrict__ cont_flag,
                                                                     const uint32_t *__restrict__ tile_order,
                                                                     uint32_t *__restrict__ tile_cost) {
+    static_assert(!(EXACT && FRAME), "the exact-exp flavour belongs to the reference API (gs_draw, fast = 0)");
     using SM = FwdSmem<CDIM>;
     constexpr int CH = SM::CH;
     constexpr uint32_t GROUP = 4;  // Gaussians per ds_read_b128 of a field
@@ -262,9 +267,20 @@ raster_forward_kernel(RasterSrc S, RasterGeom G,
                 opa *= 1.5707963268f * rsqrtf(raster_det(g.a, g.b, g.c, g.d) + 1e-7f);
             sm.f[buf][SM::X][lane] = g.x;
             sm.f[buf][SM::Y][lane] = g.y;
-            sm.f[buf][SM::A][lane] = A;
-            sm.f[buf][SM::B][lane] = B;
-            sm.f[buf][SM::C][lane] = C;
+            if constexpr (EXACT) {
+                // gaussian.cu:916-923: the exponent's argument is a float numerator over the DOUBLE 2 det + 1e-14
+                const double den = (double)(2.0f * raster_det(g.a, g.b, g.c, g.d)) + 1e-14;
+                const float dh = (float)den;
+                sm.f[buf][SM::A][lane] = g.a;
+                sm.f[buf][SM::B][lane] = g.b + g.c;
+                sm.f[buf][SM::C][lane] = g.d;
+                sm.f[buf][SM::DH][lane] = dh;
+                sm.f[buf][SM::DL][lane] = (float)(den - (double)dh);
+            } else {
+                sm.f[buf][SM::A][lane] = A;
+                sm.f[buf][SM::B][lane] = B;
+                sm.f[buf][SM::C][lane] = C;
+            }
             // frame path: the opacity (a sigmoid, > 0) rides in the exponent, alpha = 2^-(q + nlop); the
             // reference API may be handed any opacity (zero, negative), so it keeps the multiplication
             sm.f[buf][SM::NLOP][lane] = FRAME ? -__log2f(opa) : opa;
@@ -287,7 +303,8 @@ raster_forward_kernel(RasterSrc S, RasterGeom G,
         } else if (base + lane < ((n + (GROUP - 1u)) & ~(GROUP - 1u))) {
             // pad the ragged tail to a multiple of GROUP with null Gaussians (opacity 0 => alpha 0)
 #pragma unroll
-            for (int q = 0; q < SM::NFIELD; ++q) sm.f[buf][q][lane] = (FRAME && q == SM::NLOP) ? 1e30f : 0.f;
+            for (int q = 0; q < SM::NFIELD; ++q)  // (exact flavour: denominator 1, so that the null Gaussian's alpha is 0 x exp(0))
+                sm.f[buf][q][lane] = (FRAME && q == SM::NLOP) ? 1e30f : (EXACT && q == SM::DH) ? 1.0f : 0.f;
             if constexpr (CDIM > 3) {
 #pragma unroll
                 for (int q = 0; q < CDIM; ++q) sm.sh[buf][lane][q] = 0.f;
@@ -323,6 +340,11 @@ raster_forward_kernel(RasterSrc S, RasterGeom G,
             auto ld4 = [&](int q) { return *(const float4 *)__builtin_assume_aligned(&sm.f[buf][q][i + i4], 16); };
             const float4 X = ld4(SM::X), Y = ld4(SM::Y), A4 = ld4(SM::A), B4 = ld4(SM::B), C4 = ld4(SM::C);
             const float4 O4 = ld4(SM::NLOP);
+            float4 DH4, DL4;
+            if constexpr (EXACT) {
+                DH4 = ld4(SM::DH);
+                DL4 = ld4(SM::DL);
+            }
             float4 R4, G4, L4;
             if constexpr (CDIM == 3) {
                 R4 = ld4(SM::R);
@@ -344,10 +366,27 @@ raster_forward_kernel(RasterSrc S, RasterGeom G,
 #pragma unroll
                 for (int h = 0; h < NPP; ++h) {
                     const f2 dy = py2[h] - splat(gy);
-                    const f2 q = pk_fma(pk_fma(splat(cC), dy, splat(-bdx)), dy, splat(f));
                     f2 al;
-                    al.x = gs_exp2(-q.x);
-                    al.y = gs_exp2(-q.y);
+                    if constexpr (EXACT) {
+                        // exp(double(-(d x x - (b + c) x y + a y y)) / (2 det + 1e-14)) rounded to float: the reference's
+                        // `fast = 0` flavour (gaussian.cu:922-923), float products in its order (no contraction), then
+                        // the double division and the double exponential it pays per pixel as well
+                        const double den = (double)(u == 0 ? DH4.x : u == 1 ? DH4.y : u == 2 ? DH4.z : DH4.w) +
+                                           (double)(u == 0 ? DL4.x : u == 1 ? DL4.y : u == 2 ? DL4.z : DL4.w);
+                        auto exact_alpha = [&](float y) {
+                            const float t1 = __fmul_rn(__fmul_rn(cC, dx), dx);   // d x x
+                            const float t2 = __fmul_rn(__fmul_rn(cB, dx), y);    // (b + c) x y
+                            const float t3 = __fmul_rn(__fmul_rn(cA, y), y);     // a y y
+                            const float num = -__fadd_rn(__fsub_rn(t1, t2), t3);
+                            return (float)exp((double)num / den);
+                        };
+                        al.x = exact_alpha(dy.x);
+                        al.y = exact_alpha(dy.y);
+                    } else {
+                        const f2 q = pk_fma(pk_fma(splat(cC), dy, splat(-bdx)), dy, splat(f));
+                        al.x = gs_exp2(-q.x);
+                        al.y = gs_exp2(-q.y);
+                    }
                     if (!FRAME) al = al * splat(nlop);
                     if (SIG) {  // gaussian.cu:930
                         al.x = 2.0f / (__expf(-al.x) + 1.0f) - 1.0f;
@@ -758,47 +797,54 @@ static uint32_t fwd_grid(uint32_t n_tiles) {
     return rounds ? (n_tiles + rounds - 1) / rounds : 1;
 }
 
-template <int CDIM, bool FRAME, bool CKPT, bool SIG>
+template <int CDIM, bool FRAME, bool CKPT, bool SIG, bool EXACT = false>
 void launch_fwd(const RasterSrc &S, const RasterGeom &G, const int32_t *ranges, float *out_padded, float *out_image,
                 float4 *ckpt, uint32_t *tile_nproc, int wn, hipStream_t stream, float4 *cont_state = nullptr,
                 uint32_t *cont_flag = nullptr, const uint32_t *tile_order = nullptr, uint32_t *tile_cost = nullptr) {
     if (!fwd_plan().order) tile_order = nullptr;
     const uint32_t T = (uint32_t)(G.ntx * G.nty), grid = fwd_grid(T);
     if (wn)
-        hipLaunchKernelGGL((raster_forward_kernel<CDIM, FRAME, CKPT, SIG, true>), dim3(grid), dim3(FWD_THREADS), 0,
-                           stream, S, G, ranges, out_padded, out_image, ckpt, tile_nproc, T, cont_state, cont_flag,
+        hipLaunchKernelGGL((raster_forward_kernel<CDIM, FRAME, CKPT, SIG, true, EXACT>), dim3(grid), dim3(FWD_THREADS),
+                           0, stream, S, G, ranges, out_padded, out_image, ckpt, tile_nproc, T, cont_state, cont_flag,
                            tile_order, tile_cost);
     else
-        hipLaunchKernelGGL((raster_forward_kernel<CDIM, FRAME, CKPT, SIG, false>), dim3(grid), dim3(FWD_THREADS), 0,
-                           stream, S, G, ranges, out_padded, out_image, ckpt, tile_nproc, T, cont_state, cont_flag,
+        hipLaunchKernelGGL((raster_forward_kernel<CDIM, FRAME, CKPT, SIG, false, EXACT>), dim3(grid), dim3(FWD_THREADS),
+                           0, stream, S, G, ranges, out_padded, out_image, ckpt, tile_nproc, T, cont_state, cont_flag,
                            tile_order, tile_cost);
 }
 
 }  // namespace
 
-// Shared with raster_bwd.hip (replay of the forward for the reference-API backward).
+// Shared with raster_bwd.hip (replay of the forward for the reference-API backward).  `exact`: the reference's
+// `fast = 0` flavour of the exponential (double division + double exp per pixel, gaussian.cu:922-923).
+template <int CDIM, bool CKPT>
+static void fwd_ref_dispatch(const RasterSrc &S, const RasterGeom &G, const int32_t *accum, float *res, int sigmoid,
+                             int weight_normalize, int exact, float4 *ckpt, uint32_t *tile_nproc, hipStream_t stream) {
+    if (sigmoid) {
+        if (exact)
+            launch_fwd<CDIM, false, CKPT, true, true>(S, G, accum, res, nullptr, ckpt, tile_nproc, weight_normalize, stream);
+        else
+            launch_fwd<CDIM, false, CKPT, true, false>(S, G, accum, res, nullptr, ckpt, tile_nproc, weight_normalize, stream);
+    } else {
+        if (exact)
+            launch_fwd<CDIM, false, CKPT, false, true>(S, G, accum, res, nullptr, ckpt, tile_nproc, weight_normalize, stream);
+        else
+            launch_fwd<CDIM, false, CKPT, false, false>(S, G, accum, res, nullptr, ckpt, tile_nproc, weight_normalize, stream);
+    }
+}
 int gs_raster_forward_ref(const RasterSrc &S, const RasterGeom &G, const int32_t *accum, float *res, int use_sh,
                           int sigmoid, int weight_normalize, float4 *ckpt, uint32_t *tile_nproc,
-                          hipStream_t stream) {
+                          hipStream_t stream, int exact) {
     if (ckpt) {
-        if (use_sh && sigmoid)
-            launch_fwd<27, false, true, true>(S, G, accum, res, nullptr, ckpt, tile_nproc, weight_normalize, stream);
-        else if (use_sh)
-            launch_fwd<27, false, true, false>(S, G, accum, res, nullptr, ckpt, tile_nproc, weight_normalize, stream);
-        else if (sigmoid)
-            launch_fwd<3, false, true, true>(S, G, accum, res, nullptr, ckpt, tile_nproc, weight_normalize, stream);
+        if (use_sh)
+            fwd_ref_dispatch<27, true>(S, G, accum, res, sigmoid, weight_normalize, exact, ckpt, tile_nproc, stream);
         else
-            launch_fwd<3, false, true, false>(S, G, accum, res, nullptr, ckpt, tile_nproc, weight_normalize, stream);
-    } else if (use_sh) {
-        if (sigmoid)
-            launch_fwd<27, false, false, true>(S, G, accum, res, nullptr, nullptr, nullptr, weight_normalize, stream);
-        else
-            launch_fwd<27, false, false, false>(S, G, accum, res, nullptr, nullptr, nullptr, weight_normalize, stream);
+            fwd_ref_dispatch<3, true>(S, G, accum, res, sigmoid, weight_normalize, exact, ckpt, tile_nproc, stream);
     } else {
-        if (sigmoid)
-            launch_fwd<3, false, false, true>(S, G, accum, res, nullptr, nullptr, nullptr, weight_normalize, stream);
+        if (use_sh)
+            fwd_ref_dispatch<27, false>(S, G, accum, res, sigmoid, weight_normalize, exact, nullptr, nullptr, stream);
         else
-            launch_fwd<3, false, false, false>(S, G, accum, res, nullptr, nullptr, nullptr, weight_normalize, stream);
+            fwd_ref_dispatch<3, false>(S, G, accum, res, sigmoid, weight_normalize, exact, nullptr, nullptr, stream);
     }
     return 0;
 }
@@ -808,7 +854,7 @@ extern "C" int gs_draw(const float *pos, const float *rgb, const float *opa, con
                        float focal_x, float focal_y, int weight_normalize, int sigmoid, int fast,
                        const float *rays_o, const float *lefttop_pos, const float *vec_dx, const float *vec_dy,
                        int use_sh_coeff, gs_stream_t stream) {
-    (void)fast;  // both exp flavours map to v_exp_f32 here (accuracy ~1 ulp)
+    // fast != 0: v_exp_f32 on the hoisted conic (the reference's __expf); fast == 0: the exact flavour
     GS_CHECK_ARG(h > 0 && w > 0 && (h % 16) == 0 && (w % 16) == 0, "h, w must be positive multiples of 16");
     GS_CHECK_ARG(M >= 0, "M < 0");
     GS_CHECK_ARG(tile_n_point_accum && res, "null pointer");
@@ -835,7 +881,7 @@ extern "C" int gs_draw(const float *pos, const float *rgb, const float *opa, con
         G.dev_vdy = vec_dy;
     }
     int rc = gs_raster_forward_ref(S, G, tile_n_point_accum, res, use_sh_coeff, sigmoid, weight_normalize, nullptr,
-                                   nullptr, (hipStream_t)stream);
+                                   nullptr, (hipStream_t)stream, fast ? 0 : 1);
     if (rc) {
         gs_set_error("gs_draw: unsupported flag combination");
         return rc;

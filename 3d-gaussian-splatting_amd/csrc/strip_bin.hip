@@ -127,30 +127,37 @@ struct SliceLoader {
 #define GS_ORDER_QUANTUM 8
 __device__ __forceinline__ void tile_order_workgroup(const uint32_t *__restrict__ tile_cost, uint32_t T,
                                                      uint32_t *__restrict__ tile_order) {
-    __shared__ uint32_t s_bin[256];
-    __shared__ uint32_t s_wsum[4];
-    if (threadIdx.x < 256) s_bin[threadIdx.x] = 0;
+    // 256 bins x 16 sub-counters (lane % 16): in a sparse frame most tiles cost the same (empty tiles: 0), and 64 lanes
+    // adding to ONE LDS word serialise (first version: +10 us on a 50-us frame of 10,000 Gaussians); with the
+    // sub-counters a wave's add hits every word at most four times.  Slot order: bin-major, sub-counter-minor.
+    constexpr uint32_t SUB = 16, NC = 256 * SUB, PER = NC / STRIP_THREADS;
+    __shared__ uint32_t s_bin[NC];
+    __shared__ uint32_t s_wsum[STRIP_THREADS / 64];
+    for (uint32_t c = threadIdx.x; c < NC; c += STRIP_THREADS) s_bin[c] = 0;
     __syncthreads();
-    auto bin_of = [](uint32_t c) {
+    const uint32_t sub = threadIdx.x & (SUB - 1);
+    auto counter_of = [&](uint32_t c) {
         const uint32_t q = c / GS_ORDER_QUANTUM;
-        return 255u - (q < 255u ? q : 255u);  // descending cost
+        return (255u - (q < 255u ? q : 255u)) * SUB + sub;  // descending cost
     };
-    for (uint32_t t = threadIdx.x; t < T; t += STRIP_THREADS) atomicAdd(&s_bin[bin_of(tile_cost[t])], 1u);
+    for (uint32_t t = threadIdx.x; t < T; t += STRIP_THREADS) atomicAdd(&s_bin[counter_of(tile_cost[t])], 1u);
     __syncthreads();
-    uint32_t cnt = 0, incl = 0;
-    if (threadIdx.x < 256) {
-        cnt = s_bin[threadIdx.x];
-        incl = gs_wave_incl_scan_u32(cnt);
-        if ((threadIdx.x & 63) == 63) s_wsum[threadIdx.x >> 6] = incl;
+    // exclusive scan of the NC counters: thread t owns counters [t PER, t PER + PER)
+    uint32_t c[PER], sum = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < PER; ++j) {
+        c[j] = sum;
+        sum += s_bin[threadIdx.x * PER + j];
     }
+    const uint32_t incl = gs_wave_incl_scan_u32(sum);
+    if ((threadIdx.x & 63) == 63) s_wsum[threadIdx.x >> 6] = incl;
     __syncthreads();
-    if (threadIdx.x < 256) {
-        uint32_t off = 0;
-        for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) off += s_wsum[w];
-        s_bin[threadIdx.x] = off + incl - cnt;  // cursor = first slot of the bin
-    }
+    uint32_t off = incl - sum;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) off += s_wsum[w];
+#pragma unroll
+    for (uint32_t j = 0; j < PER; ++j) s_bin[threadIdx.x * PER + j] = off + c[j];  // cursor = first slot of the counter
     __syncthreads();
-    for (uint32_t t = threadIdx.x; t < T; t += STRIP_THREADS) tile_order[atomicAdd(&s_bin[bin_of(tile_cost[t])], 1u)] = t;
+    for (uint32_t t = threadIdx.x; t < T; t += STRIP_THREADS) tile_order[atomicAdd(&s_bin[counter_of(tile_cost[t])], 1u)] = t;
 }
 
 // ---------------------------------------------------------------- L1a: count

@@ -49,6 +49,7 @@ GS_FRAME_SLICE_SORT = 2
 GS_FRAME_TABLE_BIN = 4
 GS_FRAME_SERIAL_LONG_LISTS = 8
 GS_FRAME_LONG_LISTS = 16
+GS_FRAME_STRIP_BIN = 32
 
 
 def _sig(name, restype, *argtypes):
@@ -90,6 +91,8 @@ gs_frame_longest_list_async = _sig("gs_frame_longest_list_async", ci, C.POINTER(
 gs_frame_debug_views = _sig("gs_frame_debug_views", ci, C.POINTER(GsFrame), C.POINTER(vp), C.POINTER(vp),
                             C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp))
 
+gs_frame_binning_variant = _sig("gs_frame_binning_variant", ci, C.POINTER(GsFrame))
+gs_frame_debug_rects = _sig("gs_frame_debug_rects", ci, C.POINTER(GsFrame), C.POINTER(vp))
 gs_frame_debug_tile_nproc = _sig("gs_frame_debug_tile_nproc", ci, C.POINTER(GsFrame), C.POINTER(vp))
 
 gs_adam_step = _sig("gs_adam_step", ci, vp, vp, vp, vp, i64, i32, C.POINTER(i64), C.POINTER(f32), f32, f32, f32, i64,
@@ -127,7 +130,7 @@ EXPORTS = [
     "gs_jacobian", "gs_global_culling", "gs_global_culling_backward", "gs_calc_tile_list",
     "gs_gather_gaussians", "gs_draw", "gs_draw_backward_workspace_bytes", "gs_draw_backward",
     "gs_sort_pairs_tmp_bytes", "gs_sort_pairs", "gs_sort_pairs_bits", "gs_frame_workspace_bytes", "gs_frame_forward",
-    "gs_frame_stats_async", "gs_frame_longest_list_async", "gs_frame_debug_views", "gs_frame_debug_tile_nproc", "gs_frame_backward", "gs_frame_forward_profile",
+    "gs_frame_stats_async", "gs_frame_longest_list_async", "gs_frame_debug_views", "gs_frame_debug_rects", "gs_frame_binning_variant", "gs_frame_debug_tile_nproc", "gs_frame_backward", "gs_frame_forward_profile",
     "gs_frame_backward_part", "gs_frame_async_create", "gs_frame_async_wait", "gs_frame_async_destroy",
     "gs_frame_backward_profile", "gs_adam_step", "gs_adam_step_range", "gs_adam_step_sharded", "gs_frame_overflow_flag", "gs_grad_stat_update", "gs_loss_workspace_bytes", "gs_loss_l1_ssim",
     "gs_densify_workspace_bytes", "gs_densify_classify", "gs_densify_apply",

@@ -39,11 +39,14 @@ class FrameStats:
 
 
 class FrameRenderer:
+    default_force_strips = False  # see `force_strips`
+
     def __init__(self, device="cuda", max_pairs: int = 1 << 20, training: bool = False,
                  thresh: float = 0.05, scale_activation: str = "abs", auto_grow: bool = True,
                  sort_mode: int = 2, tile_culling_method: str = "prob2", tile_culling_dist_thresh: float = 0.5,
                  emit_sorted_keys: bool = False, slice_sort: bool = False, table_bin: bool = False,
-                 serial_long_lists: bool = False, long_lists: Optional[bool] = None):
+                 serial_long_lists: bool = False, long_lists: Optional[bool] = None,
+                 force_strips: Optional[bool] = None):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("FrameRenderer needs a HIP device; there is no CPU fallback")
@@ -58,7 +61,11 @@ class FrameRenderer:
         self.tile_culling_dist_thresh = float(tile_culling_dist_thresh)
         self.emit_sorted_keys = bool(emit_sorted_keys)
         self.slice_sort = bool(slice_sort)  # sort_mode 2: the slice-sorted binning variant (GS_FRAME_SLICE_SORT)
-        self.table_bin = bool(table_bin)  # sort_mode 2: the table variant instead of the default strip variant
+        self.table_bin = bool(table_bin)  # sort_mode 2: the table variant whatever the scene size
+        # sort_mode 2: the strip variant whatever the scene size (GS_FRAME_STRIP_BIN).  Default (neither flag): the
+        # library picks by N -- table variant below 131,072 Gaussians, strip variant from there on.  None = the class-wide
+        # default below (the GPU test-suite sets it, so that its small scenes keep exercising the strip kernels).
+        self.force_strips = FrameRenderer.default_force_strips if force_strips is None else bool(force_strips)
         self.serial_long_lists = bool(serial_long_lists)  # dense frames: no segmented compositing of long tile lists
         # GS_FRAME_LONG_LISTS (big-list sort + segmented compositing also in frames that are sparse on average): True /
         # False, or None = as soon as an earlier frame of this renderer reported a tile list beyond 2048 pairs (the
@@ -145,6 +152,7 @@ class FrameRenderer:
         f.async_ = self._async
         f.flags = (_lib.GS_FRAME_EMIT_SORTED_KEYS if self.emit_sorted_keys else 0) | \
             (_lib.GS_FRAME_SLICE_SORT if self.slice_sort else 0) | (_lib.GS_FRAME_TABLE_BIN if self.table_bin else 0) | \
+            (_lib.GS_FRAME_STRIP_BIN if (self.force_strips and not (self.slice_sort or self.table_bin)) else 0) | \
             (_lib.GS_FRAME_SERIAL_LONG_LISTS if self.serial_long_lists else 0) | \
             (_lib.GS_FRAME_LONG_LISTS if (self.long_lists or (self.long_lists is None and self._long_lists_seen)) else 0)
         f.training = int(training)
@@ -331,6 +339,15 @@ class FrameRenderer:
         self._long_lists_seen = self._long_lists_seen or longest > 2048
         return FrameStats(v, m, o, b, longest)
 
+    def binning_variant(self) -> str:
+        """Which binning / sort path the last frame took: "radix64", "radix_tile_bits", "table", "slice", "strip"."""
+        if self._frame is None:
+            raise RuntimeError("no frame rendered yet")
+        v = _lib.gs_frame_binning_variant(C.byref(self._frame))
+        if v < 0:
+            raise RuntimeError(f"gs_frame_binning_variant failed (code {v})")
+        return ("radix64", "radix_tile_bits", "table", "slice", "strip")[v]
+
     def overflow_flag(self) -> Optional[int]:
         """Device address of the last frame's 64-bit overflow counter (0 = the frame fitted), for consumers that must
         not act on an overflowed -- i.e. empty -- frame without asking the host (gs_adam_step_sharded)."""
@@ -340,17 +357,20 @@ class FrameRenderer:
         _lib.check(_lib.gs_frame_overflow_flag(C.byref(self._frame), C.byref(ptr)), "gs_frame_overflow_flag")
         return ptr.value
 
-    def culling_mask(self) -> torch.Tensor:
-        """[N] bool: the Gaussians of the last forward that passed the frustum test (the reference's
-        ``culling_mask``, renderer.py:123-132).  Aliases the workspace; no host synchronisation."""
+    def _rects(self) -> torch.Tensor:
+        """[N,4] int32 view of the workspace: (y0 | y1 << 16, x0 | x1 << 16, depth bits, tiles touched) per Gaussian."""
         f = self._frame
         if f is None:
             raise RuntimeError("no frame rendered yet")
-        ptrs = [C.c_void_p() for _ in range(7)]
-        _lib.check(_lib.gs_frame_debug_views(C.byref(f), *[C.byref(p) for p in ptrs]), "gs_frame_debug_views")
-        off = ptrs[3].value - self._ws.data_ptr()
-        rec = self._ws[off:off + 64 * f.N].view(torch.float32).reshape(f.N, 16)
-        return rec[:, 2] != 0  # depth |p_c| > near > 0 for visible Gaussians, 0 for culled ones
+        ptr = C.c_void_p()
+        _lib.check(_lib.gs_frame_debug_rects(C.byref(f), C.byref(ptr)), "gs_frame_debug_rects")
+        off = ptr.value - self._ws.data_ptr()
+        return self._ws[off:off + 16 * f.N].view(torch.int32).reshape(f.N, 4)
+
+    def culling_mask(self) -> torch.Tensor:
+        """[N] bool: the Gaussians of the last forward that passed the frustum test (the reference's
+        ``culling_mask``, renderer.py:123-132).  Computed from the workspace; no host synchronisation."""
+        return self._rects()[:, 2] != 0  # depth bits: |p_c| > near > 0 for visible Gaussians, 0 for culled ones
 
     def composited_steps(self) -> int:
         """Sum over tiles of the Gaussians the last TRAINING forward composited before every pixel of the tile had
@@ -388,17 +408,22 @@ class FrameRenderer:
             tiles = torch.repeat_interleave(torch.arange(T, device=self.device, dtype=torch.int64), counts)
             depth = view(ptrs[3], 64 * n, torch.int32, (n, 16))[:, 2].to(torch.int64) & 0xffffffff
             keys = (tiles << 32) | depth[ids.to(torch.int64)]
+        # one 64-byte record per Gaussian: geom | cov | color | conic -- written for VISIBLE Gaussians only; here the
+        # records of culled ones are shown as zeros (a copy: this is a test aid)
+        visible = self.culling_mask()
+        raw = view(ptrs[3], 64 * n, torch.float32, (n, 16))
+        rec = torch.where(visible.unsqueeze(1), raw, torch.zeros_like(raw))
         out = {
             "sorted_keys": keys,
             "sorted_ids": ids,
             "tile_ranges": ranges,
-            # one 64-byte record per Gaussian: geom | cov | color | conic
-            "rec_geom": view(ptrs[3], 64 * n, torch.float32, (n, 16))[:, 0:4],
-            "rec_cov": view(ptrs[3], 64 * n, torch.float32, (n, 16))[:, 4:8],
+            "visible": visible,
+            "rec_geom": rec[:, 0:4],
+            "rec_cov": rec[:, 4:8],
             "tiles_touched": view(ptrs[6], 4 * n, torch.int32, (n,)),
         }
         if f.color_dim == 3:
-            out["rec_color"] = view(ptrs[3], 64 * n, torch.float32, (n, 16))[:, 8:12]
+            out["rec_color"] = rec[:, 8:12]
         return out
 
     # ------------------------------------------------------------------ autograd entry point

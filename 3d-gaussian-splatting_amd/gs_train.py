@@ -269,7 +269,7 @@ class Trainer:
                 self.view_stat.clear()
         seen = None
         if self.densify and o.grad_accum_method == "mean":
-            seen = (self.renderer.debug_views()["rec_geom"][:, 2] != 0).to(torch.float32)  # culling_mask
+            seen = self.renderer.culling_mask().to(torch.float32)
 
         def local_terms(bucket):
             if bucket in (None, "geometry"):

@@ -34,7 +34,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define GS_ABI_VERSION 3
+#define GS_ABI_VERSION 4
 
 #define GS_E_INVALID (-1)   /* bad argument (null pointer, negative size, bad enum)   */
 #define GS_E_UNSUPPORTED (-2) /* valid in the reference but not implemented here (none at present) */
@@ -172,6 +172,12 @@ int gs_sort_pairs_bits(uint64_t *keys0, uint32_t *vals0, uint64_t *keys1, uint32
                                        run).  The library cannot know without a host synchronisation; the caller can:
                                        gs_frame_longest_list_async reports the longest list of an earlier frame. */
 
+#define GS_FRAME_STRIP_BIN 32        /* sort_mode 2: take the strip variant of the binning whatever the scene size.  Without
+                                       this flag (and without GS_FRAME_TABLE_BIN / GS_FRAME_SLICE_SORT) the library picks
+                                       by N: the table variant below GS_STRIP_AUTO_MIN_N (131,072) Gaussians, where its shorter
+                                       chain of dependent kernels wins, the strip variant from there on.  Every variant
+                                       produces the same lists. */
+
 /* Frame descriptor.  All scalars are per-camera constants computed on the host exactly as
  * splatter.py does (Tiles, RayInfo, frustum guard band); rot/tran are passed by value. */
 typedef struct gs_frame {
@@ -284,6 +290,18 @@ int gs_frame_debug_views(const gs_frame *f, const uint64_t **sorted_keys,
                          const uint32_t **sorted_ids, const int32_t **tile_ranges,
                          const float **rec_geom, const float **rec_cov, const float **rec_color,
                          const uint32_t **tiles_touched);
+
+/* Which binning / sort path gs_frame_forward takes for this frame description: 0 / 1 = sort_mode 0 / 1 (radix passes on
+ * the 64-bit key / on its tile bits), 2 = sort_mode 2 with the table variant, 3 = slice-sorted variant, 4 = strip
+ * variant (see GS_FRAME_STRIP_BIN for the size-based choice).  Negative: the description does not validate. */
+int gs_frame_binning_variant(const gs_frame *f);
+
+/* [N][4] uint32, written for EVERY Gaussian by every forward: (y0 | y1 << 16, x0 | x1 << 16, depth bits, tiles touched) --
+ * the tile rectangle [y0, y1) x [x0, x1), the float bits of the depth |p_c|, the number of tiles listed.  The depth bits
+ * are 0 exactly for the Gaussians the frustum test culled (the reference's culling_mask, renderer.py:123-132, is
+ * `depth bits != 0`); the 64-byte record (rec_geom / rec_cov / rec_color above) of a culled Gaussian is NOT written and
+ * holds whatever an earlier frame left there. */
+int gs_frame_debug_rects(const gs_frame *f, const uint32_t **rects);
 
 /* [T] uint32: how many Gaussians of its list each tile's forward actually composited before all of its pixels had
  * stopped (a multiple of 64 except for the last chunk), kept by TRAINING forwards for the backward.  Measurement

@@ -20,6 +20,13 @@ def pytest_configure(config):
     import oracle
 
     oracle.build()
+    try:  # the suite's scenes are small: keep them on the strip variant of the binning (the product picks by scene size;
+        # tests/test_gpu_frame.py::test_binning_variant_is_chosen_by_scene_size covers that choice)
+        from gs_frame import FrameRenderer
+
+        FrameRenderer.default_force_strips = True
+    except ImportError:  # libgs_amd.so not built: the CPU tier that needs it reports that itself
+        pass
 
 
 @pytest.fixture(scope="session")

@@ -30,7 +30,7 @@ def test_header_functions_are_all_exported():
 def test_version_and_error_string():
     from gaussian import _lib
 
-    assert _lib.gs_abi_version() == 3  # GS_ABI_VERSION of include/gs_abi.h (3: gs_frame.async / flags, 'dist' = 0)
+    assert _lib.gs_abi_version() == 4  # GS_ABI_VERSION of include/gs_abi.h (4: GS_FRAME_STRIP_BIN, sharded Adam, rects)
     assert _lib.gs_culling() == 0
     assert isinstance(_lib.gs_last_error(), bytes)
 

@@ -214,6 +214,39 @@ def test_draw_forward_backward(gpu, use_sh):
         assert rel_err(g.reshape(r.shape), r) < GRAD_RTOL, (name, rel_err(g.reshape(r.shape), r))
 
 
+@pytest.mark.parametrize("use_sh", [False, True])
+def test_draw_exact_exp_flavour(gpu, use_sh):
+    """`fast=False` of draw / draw_backward (gaussian.cu:922-923, 596-603): the exponent's argument in the reference's
+    own float order over the double 2 det + 1e-14, then a double-precision exp.  Against the oracle's fast=False the
+    image agrees to 2e-6 -- more than ten times closer than the `fast` flavour (v_exp_f32 on the hoisted conic) is
+    allowed to be -- and the two flavours really are different kernels (their images differ)."""
+    from renderer import draw
+
+    scene, cam = small_case(n=12000, W=200, H=120, seed=5, use_sh=use_sh)
+    of = _sorted_inputs(scene, cam)
+    grid, rays = of.grid, of.rays
+    kw = dict(use_sh=use_sh, rays_o=rays.rays_o, lefttop=rays.lefttop, vdx=rays.dx, vdy=rays.dy)
+    ref = {f: oracle.draw(of.s_pos, of.s_rgb, of.s_opa, of.s_cov, of.accum, grid.padded_height, grid.padded_width,
+                          grid.focal_x, grid.focal_y, fast=f, **kw) for f in (False, True)}
+    rb = [dev(a, gpu) for a in (rays.rays_o, rays.lefttop, rays.dx, rays.dy)]
+    imgs, grads = {}, {}
+    gpad = np.random.default_rng(9).normal(size=ref[False].shape).astype(np.float32)
+    for fast in (False, True):
+        t = [dev(a, gpu).requires_grad_(True) for a in (of.s_pos, of.s_rgb, of.s_opa, of.s_cov.reshape(-1, 2, 2))]
+        img = draw(*t, dev(of.accum, gpu), grid.padded_height, grid.padded_width, grid.focal_x, grid.focal_y, False,
+                   False, use_sh, fast, *rb)
+        imgs[fast] = img.detach().cpu().numpy()
+        img.backward(dev(gpad, gpu))
+        grads[fast] = [x.grad.cpu().numpy() for x in t]
+    assert np.abs(imgs[False] - ref[False]).max() < 2e-6, np.abs(imgs[False] - ref[False]).max()
+    assert np.abs(imgs[True] - ref[True]).max() < IMG_ATOL
+    assert np.abs(imgs[False] - imgs[True]).max() > 0
+    gref = oracle.draw_backward(of.s_pos, of.s_rgb, of.s_opa, of.s_cov, of.accum, ref[False], gpad, grid.focal_x,
+                                grid.focal_y, fast=False, **kw)
+    for g, r, name in zip(grads[False], gref, ("pos", "rgb", "opa", "cov")):
+        assert rel_err(g.reshape(r.shape), r) < GRAD_RTOL, (name, rel_err(g.reshape(r.shape), r))
+
+
 def test_draw_flags_weight_normalize_and_sigmoid(gpu):
     import gaussian
 

@@ -14,13 +14,16 @@ from gs_train import TrainOptions, Trainer  # noqa: E402
 dev = torch.device('cuda:0')
 W, H = 1920, 1080
 cam = make_camera(W, H)
-sizes = [int(a) for a in sys.argv[1:]] or [10_000, 100_000, 376_467, 506_627, 1_000_000, 2_400_000]
+# --table / --strip: force the table / the strip variant of the binning (default: the library's size-based choice)
+VARIANT = {"--table": "table", "--strip": "strip"}.get(next((a for a in sys.argv[1:] if a.startswith("--")), ""), "auto")
+sizes = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [10_000, 100_000, 376_467, 506_627, 1_000_000, 2_400_000]
+KW = {"table": {"table_bin": True}, "strip": {"force_strips": True}, "auto": {}}[VARIANT]
 for n in sizes:
     scene = make_scene(n, W, H, seed=2023)
     params = [torch.from_numpy(a).to(dev) for a in (scene.pos, scene.quat, scene.scale, scene.opa, scene.rgb)]
 
     def sized(training):
-        r = FrameRenderer(dev, max_pairs=1 << 20, training=training, auto_grow=True)
+        r = FrameRenderer(dev, max_pairs=1 << 20, training=training, auto_grow=True, **KW)
         r.forward(*params, cam)
         st = r.stats()
         r.max_pairs = int(st.pairs * 1.1) + 4096
@@ -55,6 +58,8 @@ for n in sizes:
     del rs
     tr = Trainer(params, [cam], [torch.rand(H, W, 3, device=dev)], TrainOptions(), max_pairs=int(st.pairs * 1.1) + 4096)
     tr.renderer.auto_grow = False
+    for k_, v_ in KW.items():
+        setattr(tr.renderer, k_, v_)
     it = [0]
 
     def step():
@@ -62,7 +67,7 @@ for n in sizes:
         it[0] += 1
 
     tt = timeit(step, max(steps // 4, 20), 5)
-    print(json.dumps({"n_gaussians": n, "visible": st.visible, "tile_pairs": st.pairs,
+    print(json.dumps({"variant": VARIANT, "n_gaussians": n, "visible": st.visible, "tile_pairs": st.pairs,
                       "render_fps_1_stream": round(1 / t1, 1), "render_fps_3_streams": round(1 / t3, 1),
                       "train_iters_per_s": round(1 / tt, 1), "train_ms_per_iter": round(tt * 1e3, 3)}), flush=True)
     del tr, r, params
