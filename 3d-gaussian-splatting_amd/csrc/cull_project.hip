@@ -9,8 +9,12 @@
 // reference's source order, so that depth bits and tile rectangles (the integer inputs of the
 // sort) are bit-identical to oracle/gs_oracle.c.  The stage is HBM-bound (40 B in, <=60 B out,
 // ~300 flops per Gaussian); losing FMA contraction costs nothing measurable.
+#include <atomic>
+#include <mutex>
+
 #include "gs_common.h"
 #include "gs_frame_layout.h"
+#include "strip_common.h"
 
 namespace {
 
@@ -393,6 +397,66 @@ __device__ __forceinline__ void activate(const float qraw[4], const float sraw[3
     for (int k = 0; k < 3; ++k) s[k] = scale_act == 0 ? fabsf(sraw[k]) + 1e-4f : expf(sraw[k]);
 }
 
+// Raw parameters of one Gaussian (what S1 reads: 56 bytes with rgb logits, 44 with SH)
+struct RawGaussian {
+    float p[3], sraw[3], qraw[4], opa, rgb[3];
+};
+__device__ __forceinline__ RawGaussian load_raw(const float *__restrict__ pos, const float4 *__restrict__ quat,
+                                                const float *__restrict__ scale, const float *__restrict__ opa,
+                                                const float *__restrict__ rgb, int64_t pid, int color_dim) {
+    RawGaussian r;
+    load3(pos, pid, r.p);
+    load3(scale, pid, r.sraw);
+    const float4 q4 = quat[pid];
+    r.qraw[0] = q4.x; r.qraw[1] = q4.y; r.qraw[2] = q4.z; r.qraw[3] = q4.w;
+    r.opa = opa[pid];
+    r.rgb[0] = r.rgb[1] = r.rgb[2] = 0.f;
+    if (color_dim == 3) load3(rgb, pid, r.rgb);
+    return r;
+}
+
+// S1 for one Gaussian: activations -> project -> tile rectangle -> 64-byte record (visible Gaussians only) + the
+// 16-byte rectangle record (every Gaussian).  Returns the rectangle record; `vis` = passed the frustum test; `cxy` = the
+// projected centre (the "dist" listing test of the binning needs it).
+__device__ __forceinline__ uint4 project_one(const RawGaussian &in, int64_t pid, const ProjectParams &P,
+                                             float4 *__restrict__ rec_geom, uint32_t *__restrict__ tiles_touched,
+                                             uint4 *__restrict__ rects, uint32_t &vis, float2 &cxy) {
+    float q[4], s[3], pi[3], cv[4];
+    activate(in.qraw, in.sraw, P.scale_act, q, s);
+    uint32_t cnt = 0;
+    vis = 0;
+    cxy = make_float2(0.f, 0.f);
+    uint2 rc = make_uint2(0, 0);
+    float depth = 0.f;
+    // A culled Gaussian leaves 16 (20) bytes -- its all-zero rectangle, which is what every later stage looks at first
+    // (rects[i].z, the depth bits, is 0 exactly for culled Gaussians: visible ones lie beyond the near plane) --
+    // and NOT its 64-byte record: nothing reads the record of a Gaussian that is in no tile's list (21 % of the
+    // Gaussians of the 2.4 M scene: 33 of this stage's 337 MB).  The record of a culled Gaussian is unspecified.
+    if (project(in.p, q, s, P.cam, P.near_plane, P.half_w, P.half_h, pi, cv)) {
+        vis = 1;
+        uint32_t y0, y1, x0, x1;
+        cnt = P.cull_method == 0 ? dist_rect(pi[0], pi[1], P, y0, y1, x0, x1)
+                                 : tile_rect(pi[0], pi[1], cv, P, y0, y1, x0, x1);
+        rc = make_uint2(y0 | (y1 << 16), x0 | (x1 << 16));
+        depth = pi[2];
+        cxy = make_float2(pi[0], pi[1]);
+        float4 col = make_float4(0, 0, 0, 0);
+        if (P.color_dim == 3)
+            col = make_float4(sigmoid_f(in.rgb[0]), sigmoid_f(in.rgb[1]), sigmoid_f(in.rgb[2]), 0.0f);
+        float cA = 0.f, cB = 0.f, cC = 0.f;
+        gs_conic(cv[0], cv[1], cv[2], cv[3], cA, cB, cC);
+        float4 *rec = rec_geom + pid * GS_REC_STRIDE;  // one 64-byte record per Gaussian
+        rec[0] = make_float4(pi[0], pi[1], pi[2], sigmoid_f(in.opa));
+        rec[1] = make_float4(cv[0], cv[1], cv[2], cv[3]);
+        rec[2] = col;
+        rec[3] = make_float4(cA, cB, cC, 0.f);
+    }
+    if (tiles_touched) tiles_touched[pid] = cnt;  // read by the radix paths (sort_modes 0 / 1) only
+    const uint4 out = make_uint4(rc.x, rc.y, __float_as_uint(depth), cnt);
+    rects[pid] = out;
+    return out;
+}
+
 __global__ void __launch_bounds__(256) frame_project_kernel(
     const float *__restrict__ pos, const float4 *__restrict__ quat, const float *__restrict__ scale,
     const float *__restrict__ opa, const float *__restrict__ rgb, int64_t n, ProjectParams P,
@@ -402,41 +466,9 @@ __global__ void __launch_bounds__(256) frame_project_kernel(
     const int64_t pid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t cnt = 0, vis = 0;
     if (pid < n) {
-        float p[3], sraw[3], q[4], s[3], pi[3], cv[4];
-        load3(pos, pid, p);
-        load3(scale, pid, sraw);
-        float4 q4 = quat[pid];
-        float qraw[4] = {q4.x, q4.y, q4.z, q4.w};
-        activate(qraw, sraw, P.scale_act, q, s);
-        float4 g = make_float4(0, 0, 0, 0), c = make_float4(0, 0, 0, 0), col = make_float4(0, 0, 0, 0);
-        uint2 rc = make_uint2(0, 0);
-        if (project(p, q, s, P.cam, P.near_plane, P.half_w, P.half_h, pi, cv)) {
-            vis = 1;
-            uint32_t y0, y1, x0, x1;
-            cnt = P.cull_method == 0 ? dist_rect(pi[0], pi[1], P, y0, y1, x0, x1)
-                                     : tile_rect(pi[0], pi[1], cv, P, y0, y1, x0, x1);
-            rc = make_uint2(y0 | (y1 << 16), x0 | (x1 << 16));
-            g = make_float4(pi[0], pi[1], pi[2], sigmoid_f(opa[pid]));
-            c = make_float4(cv[0], cv[1], cv[2], cv[3]);
-            if (P.color_dim == 3)
-                col = make_float4(sigmoid_f(rgb[pid * 3 + 0]), sigmoid_f(rgb[pid * 3 + 1]),
-                                  sigmoid_f(rgb[pid * 3 + 2]), 0.0f);
-        }
-        // A culled Gaussian leaves 20 bytes -- its all-zero rectangle, which is what every later stage looks at first
-        // (rects[i].z, the depth bits, is 0 exactly for culled Gaussians: visible ones lie beyond the near plane) --
-        // and NOT its 64-byte record: nothing reads the record of a Gaussian that is in no tile's list (21 % of the
-        // Gaussians of the 2.4 M scene: 33 of this kernel's 337 MB).  The record of a culled Gaussian is unspecified.
-        if (vis) {
-            float cA = 0.f, cB = 0.f, cC = 0.f;
-            gs_conic(c.x, c.y, c.z, c.w, cA, cB, cC);
-            float4 *rec = rec_geom + pid * GS_REC_STRIDE;  // one 64-byte record per Gaussian
-            rec[0] = g;
-            rec[1] = c;
-            rec[2] = col;
-            rec[3] = make_float4(cA, cB, cC, 0.f);
-        }
-        tiles_touched[pid] = cnt;
-        rects[pid] = make_uint4(rc.x, rc.y, __float_as_uint(g.z), cnt);
+        float2 cxy;
+        cnt = project_one(load_raw(pos, quat, scale, opa, rgb, pid, P.color_dim), pid, P, rec_geom, tiles_touched, rects,
+                          vis, cxy).w;
     }
     // block sums of cnt and of the visible flag -> two plain stores per block (a same-address
     // atomic per block would serialise at ~12 ns each: 112 us for 2.4 M Gaussians)
@@ -454,6 +486,66 @@ __global__ void __launch_bounds__(256) frame_project_kernel(
     }
 }
 
+// ---------------------------------------------------------------- S1 + L1a fused (strip variant of sort_mode 2)
+// frame_project_kernel writes a 16-byte rectangle per Gaussian and strip_count_kernel (strip_bin.hip) reads all of them
+// back to histogram the strip entries: 38 MB and a 16-us launch at 2.4 M Gaussians for information that was in
+// registers.  Here ONE workgroup per slice of the Gaussian array (the slices of the level-1 kernels: <= 256, dealt to
+// the XCDs in contiguous runs) projects its Gaussians, 1024 at a time, and counts their strip entries on the spot -- one
+// 64-bit LDS atomic per entry, as there.  The raw parameters of the NEXT round are requested before the current one
+// is projected (16 waves per CU hide the rest).  Same outputs as the two kernels: records, rectangles, the [S][NS] table
+// row, the slice's pair / visible counts; the one extra workgroup of the launch writes the tile dispatch order.
+template <bool DIST>
+__global__ void __launch_bounds__(STRIP_THREADS) frame_project_count_kernel(
+    const float *__restrict__ pos, const float4 *__restrict__ quat, const float *__restrict__ scale,
+    const float *__restrict__ opa, const float *__restrict__ rgb, int64_t n, ProjectParams P,
+    float4 *__restrict__ rec_geom, uint32_t *__restrict__ tiles_touched, uint4 *__restrict__ rects, GsDistCull D,
+    uint32_t per_slice, gs_strip_geom SG, uint32_t S, unsigned long long *__restrict__ table,
+    uint32_t *__restrict__ slice_pairs, uint32_t *__restrict__ slice_vis, const uint32_t *__restrict__ tile_cost,
+    uint32_t n_tiles, uint32_t *__restrict__ tile_order) {
+    extern __shared__ unsigned long long s_hist[];  // [NS] entries << 32 | pairs of this slice
+    __shared__ uint32_t s_acc[2];
+    if (blockIdx.x >= S) {  // the one extra workgroup of the launch (uniform)
+        tile_order_workgroup(tile_cost, n_tiles, tile_order);
+        return;
+    }
+    const uint32_t slice = strip_slice_of_block(blockIdx.x, S);
+    const int64_t g0 = (int64_t)slice * per_slice;
+    auto in_range = [&](uint32_t i) { return i < per_slice && g0 + i < n; };
+    RawGaussian cur = {}, nxt = {};
+    if (in_range(threadIdx.x)) cur = load_raw(pos, quat, scale, opa, rgb, g0 + threadIdx.x, P.color_dim);
+    for (uint32_t t = threadIdx.x; t < SG.NS; t += STRIP_THREADS) s_hist[t] = 0;
+    if (threadIdx.x < 2) s_acc[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t acc_cnt = 0, acc_vis = 0;
+    for (uint32_t base = 0; base < per_slice; base += STRIP_THREADS) {  // uniform trip count
+        const uint32_t i = base + threadIdx.x;
+        if (in_range(i + STRIP_THREADS)) nxt = load_raw(pos, quat, scale, opa, rgb, g0 + i + STRIP_THREADS, P.color_dim);
+        uint4 rc = make_uint4(0, 0, 0, 0);
+        uint32_t vis = 0;
+        float2 cxy = make_float2(0.f, 0.f);
+        if (in_range(i)) rc = project_one(cur, g0 + i, P, rec_geom, tiles_touched, rects, vis, cxy);
+        acc_cnt += rc.w;
+        acc_vis += vis;
+        walk_strips<DIST>(rc, g0 + i, SG, cxy, D,
+                          [&](uint32_t strip, uint32_t, uint32_t, uint32_t np) { atomicAdd(&s_hist[strip], (1ull << 32) | np); });
+        cur = nxt;
+    }
+    // rectangle areas (= gradient-row slots; == pairs unless DIST) and visible Gaussians of this slice
+    acc_cnt = gs_wave_sum_u32(acc_cnt);
+    acc_vis = gs_wave_sum_u32(acc_vis);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&s_acc[0], acc_cnt);
+        atomicAdd(&s_acc[1], acc_vis);
+    }
+    __syncthreads();
+    unsigned long long *row = table + (size_t)slice * SG.NS;
+    for (uint32_t t = threadIdx.x; t < SG.NS; t += STRIP_THREADS) row[t] = s_hist[t];
+    if (threadIdx.x == 0) {
+        slice_pairs[slice] = s_acc[0];
+        slice_vis[slice] = s_acc[1];
+    }
+}
+
 // ---------------------------------------------------------------- fused frame stage B2
 // rows[pair][12|36|56] = (dx, dy, da, db, dc, dd, dopa, colour grads..) written by the raster backward
 // in emission order: Gaussian g owns rows [pair_offsets[g], +tiles_touched[g]).  They are summed
@@ -465,8 +557,8 @@ __global__ void __launch_bounds__(256) frame_project_kernel(
 // "geometry" bucket of the view-parallel gradient exchange); 2 = only grad_opa and grad_rgb (the "colour" bucket).
 // Parts 1 and 2 read the same rows and add them in the same order as part 0: their outputs are bit-identical to it.
 // They exist so that the all-reduce of the first bucket can run underneath the second kernel (gs_dp.py).
-template <int CDIM, int PART = 0>
-__global__ void __launch_bounds__(256) frame_project_backward_kernel(
+template <int CDIM, int PART = 0, int BLOCK = (CDIM == 3 ? 256 : 128)>
+__global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
     const float *__restrict__ pos, const float4 *__restrict__ quat, const float *__restrict__ scale,
     int64_t n, ProjectParams P, const float4 *__restrict__ rec_geom,
     const float4 *__restrict__ rec_color, const float4 *__restrict__ rows, const uint8_t *__restrict__ row_flags,
@@ -491,13 +583,12 @@ __global__ void __launch_bounds__(256) frame_project_backward_kernel(
     const float4 g = vis ? rec_geom[pid * GS_REC_STRIDE] : make_float4(0, 0, 0, 0);
     float gp[3] = {0, 0, 0}, gqr[4] = {0, 0, 0, 0}, gsr[3] = {0, 0, 0}, gopa = 0, gcol[3] = {0, 0, 0};
     constexpr int RW4 = gs_row_floats(CDIM) / 4;  // float4s per row
-    float gsh[CDIM > 3 ? 4 * RW4 - 8 : 1];        // sums of row[2..]: gsh[k - 1] is SH coefficient k >= 1
     float4 d0 = make_float4(0, 0, 0, 0), d1 = d0, d2 = d0;
-    if (CDIM > 3) {
-#pragma unroll
-        for (int k = 0; k < 4 * RW4 - 8; ++k) gsh[k] = 0.f;
-    }
     const uint64_t off = vis ? pair_offsets[pid] : 0, cnt = rc.w;
+    // SH: the column sums of every Gaussian's rows, [Gaussian of the workgroup][row float] with an odd stride
+    constexpr int RWF = 4 * RW4, RS = RWF + 1;
+    __shared__ float s_sum[CDIM > 3 ? BLOCK * RS : 1];
+    __shared__ uint32_t s_brow[CDIM > 3 ? BLOCK / 64 : 1][64], s_bown[CDIM > 3 ? BLOCK / 64 : 1][64];
 
     // A Gaussian that covers hundreds of tiles (early in training from a sparse cloud; a scale that blew up) would
     // keep ONE thread adding its rows while 255 wait: 195 us instead of 40 us for this kernel in a 500 k-Gaussian fit.
@@ -506,11 +597,12 @@ __global__ void __launch_bounds__(256) frame_project_backward_kernel(
     // total to the owning thread: deterministic -- and are skipped by the per-thread loops below.
     constexpr uint32_t BIG = 256;
     constexpr int NA = 4 * RW4;
-    __shared__ uint32_t s_nbig, s_big_owner[256];
-    __shared__ uint64_t s_big_off[256];
-    __shared__ uint32_t s_big_cnt[256];
-    __shared__ float s_big_part[4][NA];
-    const bool big = cnt > BIG;
+    constexpr int NBIG = CDIM == 3 ? 256 : 1;  // (SH rows are summed by the whole wave anyway: below)
+    __shared__ uint32_t s_nbig, s_big_owner[NBIG];
+    __shared__ uint64_t s_big_off[NBIG];
+    __shared__ uint32_t s_big_cnt[NBIG];
+    __shared__ float s_big_part[4][CDIM == 3 ? NA : 1];
+    const bool big = CDIM == 3 && cnt > BIG;
     if (threadIdx.x == 0) s_nbig = 0;
     __syncthreads();
     if (big) {
@@ -520,7 +612,7 @@ __global__ void __launch_bounds__(256) frame_project_backward_kernel(
         s_big_cnt[slot] = (uint32_t)cnt;
     }
     __syncthreads();
-    const uint32_t nbig = s_nbig;
+    const uint32_t nbig = CDIM == 3 ? s_nbig : 0;
     for (uint32_t b = 0; b < nbig; ++b) {
         const uint64_t boff = s_big_off[b];
         const uint32_t bcnt = s_big_cnt[b];
@@ -549,12 +641,7 @@ __global__ void __launch_bounds__(256) frame_project_backward_kernel(
             };
             d0 = make_float4(tot(0), tot(1), tot(2), tot(3));
             d1 = make_float4(tot(4), tot(5), tot(6), tot(7));
-            if (CDIM == 3) {
-                d2 = make_float4(tot(8), tot(9), 0.f, 0.f);
-            } else {
-#pragma unroll
-                for (int e = 0; e < NA - 8; ++e) gsh[e] = tot(8 + e);
-            }
+            d2 = make_float4(tot(8), tot(9), 0.f, 0.f);
         }
         __syncthreads();
     }
@@ -581,37 +668,120 @@ __global__ void __launch_bounds__(256) frame_project_backward_kernel(
             __syncthreads();
         }
     } else {
-        // SH rows are 144 (224) contiguous bytes: a thread reading its own rows already moves whole sectors
-        // (measured: the LDS detour costs 25 % here)
-        // Which of this Gaussian's rows were written (a tile that saturated before it reached the Gaussian wrote none:
-        // ~70 % of the rows of the 2.4 M scene) is collected FIRST, 64 one-byte flags at a time -- independent loads,
-        // all in flight together -- and only the written rows are walked.  A wave's trip count is then the largest
-        // number of WRITTEN rows among its 64 Gaussians instead of the largest rectangle (up to ~36 tiles against 3.7
-        // on average): the loop that loads 144 / 224 bytes and adds 36 / 56 floats per trip shrinks ~3x.  Same rows, same
-        // ascending order: the sums are bitwise unchanged.
-        const uint64_t nrow = big ? 0 : (off + cnt < max_pairs ? cnt : (max_pairs > off ? max_pairs - off : 0));
-        for (uint64_t k0 = 0; k0 < nrow; k0 += 64) {
-          const uint32_t m = nrow - k0 < 64 ? (uint32_t)(nrow - k0) : 64u;
-          unsigned long long written = 0;
-          for (uint32_t j = 0; j < m; ++j) written |= (unsigned long long)(row_flags[off + k0 + j] != 0) << j;
-          while (written) {
-            const uint64_t k = k0 + (uint64_t)(__ffsll((long long)written) - 1);
-            written &= written - 1;
-            const float4 *row = rows + (off + k) * RW4;
-            if (PART != 2) {
-                const float4 r0 = row[0];
-                d0.x += r0.x; d0.y += r0.y; d0.z += r0.z; d0.w += r0.w;
-            }
-            const float4 r1 = row[1];
-            d1.x += r1.x; d1.y += r1.y; d1.z += r1.z; d1.w += r1.w;  // d1.w: SH coefficient 0
-            if (PART != 1) {
+        // SH rows are 144 (224) contiguous bytes.  A thread walking its own rows issues, per row, nine (fourteen) loads
+        // whose 64 lanes touch 64 different rows: the texture-address unit serialises them lane by lane -- PMC, round 2:
+        // 157 such loads per wave, 0.48 ms for this kernel, with VALU and HBM both far from busy.  Instead every WAVE
+        // walks the written rows of its 64 Gaussians one row per load instruction, lane c reading float c of the row
+        // (one or two cache lines per instruction), and keeps the running column sums of the current Gaussian in a
+        // register per lane:
+        //   1. every lane (as the owner of a Gaussian) turns the one-byte flags of its next 64 rows into a bit mask --
+        //      4-byte loads, four in flight;
+        //   2. the set bits of all 64 owners are laid out in owner order, 64 entries (row, owner) at a time, in LDS;
+        //   3. the wave takes the entries in order, eight row loads in flight; when the owner changes, the finished
+        //      sums go to s_sum[owner][c] and the next owner's partial sums (zero, or what an earlier window left) come
+        //      back.  A Gaussian's rows are added in ascending order from zero, exactly as its own thread did: the
+        //      results are bitwise what they were, for any PART.
+        // Gaussians with thousands of rows need no special path any more: the wave works through them at one row per
+        // instruction.
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        float *wsum = s_sum + (size_t)wv * 64 * RS;
+        for (int i = lane; i < 64 * RS; i += 64) wsum[i] = 0.f;
+        const uint64_t nrow = off + cnt < max_pairs ? cnt : (max_pairs > off ? max_pairs - off : 0);
+        uint32_t maxrows = (uint32_t)(nrow < 0xffffffffull ? nrow : 0xffffffffull);
 #pragma unroll
-                for (int m = 0; m < RW4 - 2; ++m) {
-                    const float4 r = row[2 + m];
-                    gsh[4 * m] += r.x; gsh[4 * m + 1] += r.y; gsh[4 * m + 2] += r.z; gsh[4 * m + 3] += r.w;
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t x = __shfl_xor(maxrows, o, 64);
+            maxrows = x > maxrows ? x : maxrows;
+        }
+        const float *rowf = reinterpret_cast<const float *>(rows);
+        float acc = 0.f;
+        int cur = -1;  // owner whose sums `acc` holds (wave-uniform)
+        auto wave_sync = [] {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        };
+        for (uint32_t k0 = 0; k0 < maxrows; k0 += 64) {  // windows of 64 rows per owner (uniform trip count)
+            unsigned long long written = 0;
+            if (k0 < nrow) {
+                const uint32_t m = nrow - k0 < 64 ? (uint32_t)(nrow - k0) : 64u;
+                // flag bytes [off + k0, off + k0 + m) lie in the words [w0, w1] of the (256-byte aligned, padded) flag array
+                const uint64_t b0 = off + k0;
+                const uint32_t *fw = reinterpret_cast<const uint32_t *>(row_flags);
+                const uint64_t w0 = b0 >> 2, w1 = (b0 + m - 1) >> 2;
+                for (uint64_t w = w0; w <= w1; w += 4) {
+                    uint32_t f[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) f[j] = w + j <= w1 ? fw[w + j] : 0u;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        // the flags are 0 / 1 bytes: bits 0, 8, 16, 24 of the word -> one nibble (the partial products
+                        // of the multiplication land on distinct bits: no carries)
+                        const unsigned long long nib = ((f[j] & 0x01010101u) * 0x01020408u) >> 24 & 0xfu;
+                        const int64_t sh = (int64_t)((w + j) << 2) - (int64_t)b0;  // row (relative to k0) of the word's byte 0
+                        written |= sh >= 0 ? (sh < 64 ? nib << sh : 0ull) : nib >> (-sh);
+                    }
                 }
+                if (m < 64) written &= (1ull << m) - 1ull;
             }
-          }
+            const uint32_t mine = (uint32_t)__popcll(written);
+            const uint32_t incl = gs_wave_incl_scan_u32(mine), first = incl - mine;
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            for (uint32_t e0 = 0; e0 < total; e0 += 64) {  // batches of 64 entries, in owner order (uniform)
+                {
+                    unsigned long long mm = written;
+                    uint32_t e = first;
+                    while (mm && e < e0 + 64) {
+                        const uint32_t k = (uint32_t)__ffsll((long long)mm) - 1;
+                        mm &= mm - 1;
+                        if (e >= e0) {
+                            s_brow[wv][e - e0] = (uint32_t)(off + k0 + k);  // < max_pairs < 2^30
+                            s_bown[wv][e - e0] = (uint32_t)lane;
+                        }
+                        ++e;
+                    }
+                }
+                wave_sync();
+                const uint32_t nb = total - e0 < 64 ? total - e0 : 64u;
+                constexpr uint32_t U = 8;
+                for (uint32_t e = 0; e < nb; e += U) {
+                    float v[U];
+                    uint32_t own[U];
+#pragma unroll
+                    for (uint32_t u = 0; u < U; ++u) {
+                        const bool ok = e + u < nb;
+                        const uint32_t row = __builtin_amdgcn_readfirstlane(s_brow[wv][ok ? e + u : 0]);
+                        own[u] = __builtin_amdgcn_readfirstlane(s_bown[wv][ok ? e + u : 0]);
+                        v[u] = (ok && lane < RWF) ? rowf[(size_t)row * RWF + lane] : 0.f;
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < U; ++u) {
+                        if (e + u >= nb) break;  // uniform
+                        if ((int)own[u] != cur) {  // uniform
+                            if (cur >= 0 && lane < RWF) wsum[cur * RS + lane] = acc;
+                            cur = (int)own[u];
+                            acc = lane < RWF ? wsum[cur * RS + lane] : 0.f;
+                        }
+                        acc += v[u];
+                    }
+                }
+                wave_sync();  // the batch arrays are rewritten next
+            }
+        }
+        if (cur >= 0 && lane < RWF) wsum[cur * RS + lane] = acc;
+        wave_sync();
+        const float *t = wsum + lane * RS;  // this thread's Gaussian: (dx, dy, da, db | dc, dd, dopa, coefficient 0 | ...)
+        d0 = make_float4(t[0], t[1], t[2], t[3]);
+        d1 = make_float4(t[4], t[5], t[6], t[7]);
+        if (PART != 1) {
+            // coefficient gradients: CDIM consecutive floats per Gaussian in grad_rgb, 64 Gaussians per wave -- written
+            // by the wave as one contiguous run (a culled Gaussian's sums are the zeros the array started with)
+            const int64_t g0w = pid0 + (int64_t)wv * 64;
+            const int ng = n - g0w < 64 ? (int)(n - g0w) : 64;  // Gaussians of this wave inside the array (may be <= 0)
+            float *dst = grad_rgb + g0w * CDIM;
+            for (int e = lane; e < ng * CDIM; e += 64) {
+                const int gl = e / CDIM, c = e - gl * CDIM;
+                dst[e] = wsum[gl * RS + 7 + c];
+            }
         }
     }
     if (!valid) return;
@@ -661,16 +831,7 @@ __global__ void __launch_bounds__(256) frame_project_backward_kernel(
         grad_rgb[pid * 3 + 0] = gcol[0];
         grad_rgb[pid * 3 + 1] = gcol[1];
         grad_rgb[pid * 3 + 2] = gcol[2];
-    } else {  // SH coefficients are raw parameters: the summed rows are the gradient
-        // (staging the CDIM floats of 256 Gaussians in LDS and storing them as consecutive float4s was measured: deg 2
-        // 0.470 against 0.484 ms, deg 3 0.71 against 0.58 ms -- the 54 KiB of LDS cost more than the scattered 4-byte
-        // stores, which L2 merges)
-        if (valid) {
-            grad_rgb[pid * CDIM] = vis ? d1.w : 0.f;
-#pragma unroll
-            for (int k = 1; k < CDIM; ++k) grad_rgb[pid * CDIM + k] = vis ? gsh[k - 1] : 0.f;
-        }
-    }
+    }  // (SH: the coefficient gradients were written by the wave, above)
 }
 
 inline int grid_for(int64_t n, int block) {
@@ -779,10 +940,43 @@ static ProjectParams make_params(const gs_frame *f) {
 
 int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream) {
     ProjectParams P = make_params(f);
+    // sort_modes 0 / 1 read tiles_touched (emit_pairs_kernel); sort_mode 2 reads the rectangle records only
+    uint32_t *touched = f->sort_mode == 2 && gs_frame_geometry(f).n_tiles <= GS_BIN_MAX_TILES ? nullptr : ws.tiles_touched;
+    if (gs_frame_uses_strips(f)) touched = nullptr;
+    if (gs_frame_fused_count(f)) {
+        gs_frame_geom G = gs_frame_geometry(f);
+        const gs_strip_plan plan = gs_strip_plan_for(f->N, G.ntx, G.nty);
+        const gs_strip_geom SG = plan.geom;
+        GsDistCull D = {(float)(G.padW / 2), (float)(G.padH / 2), f->focal_x, f->focal_y, f->thresh};
+        static std::mutex attr_mu;
+        static std::atomic<uint64_t> attr_done{0};
+        int dev = 0;
+        GS_HIP(hipGetDevice(&dev));
+        if (dev < 64 && !((attr_done.load(std::memory_order_acquire) >> dev) & 1)) {
+            std::lock_guard<std::mutex> lock(attr_mu);
+            for (const void *fn : {(const void *)frame_project_count_kernel<false>, (const void *)frame_project_count_kernel<true>})
+                GS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, GS_STRIP_MAX * 8));
+            attr_done.fetch_or(1ull << dev, std::memory_order_release);
+        }
+        unsigned long long *table = (unsigned long long *)ws.strip_table;
+        const size_t lds = sizeof(unsigned long long) * SG.NS;
+#define GS_LAUNCH_PROJECT_COUNT(DIST)                                                                                  \
+    hipLaunchKernelGGL(frame_project_count_kernel<DIST>, dim3(plan.slices + 1), dim3(STRIP_THREADS), lds, stream,      \
+                       f->pos, (const float4 *)f->quat, f->scale, f->opa, f->rgb, f->N, P, ws.rec_geom, touched,       \
+                       ws.rects, D, plan.per_slice, SG, plan.slices, table, ws.slice_pairs, ws.slice_vis,              \
+                       ws.tile_cost, (uint32_t)G.n_tiles, ws.tile_order)
+        if (f->tile_culling_method == 0)
+            GS_LAUNCH_PROJECT_COUNT(true);
+        else
+            GS_LAUNCH_PROJECT_COUNT(false);
+#undef GS_LAUNCH_PROJECT_COUNT
+        GS_CHECK_LAUNCH();
+        return 0;
+    }
     int nblk = (int)gs_div_up(f->N, 256);
     hipLaunchKernelGGL(frame_project_kernel, dim3(nblk), dim3(256), 0, stream, f->pos, (const float4 *)f->quat,
                        f->scale, f->opa, f->rgb, f->N, P, ws.rec_geom,
-                       ws.tiles_touched, ws.rects, ws.block_sums, ws.block_vis);
+                       touched, ws.rects, ws.block_sums, ws.block_vis);
     GS_CHECK_LAUNCH();
     return 0;
 }
@@ -790,9 +984,9 @@ int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t strea
 int gs_stage_project_backward(const gs_frame *f, const gs_frame_ws &ws, float *grad_pos, float *grad_quat,
                               float *grad_scale, float *grad_opa, float *grad_rgb, int part, hipStream_t stream) {
     ProjectParams P = make_params(f);
-    int nblk = (int)gs_div_up(f->N, 256);
 #define GS_LAUNCH_PROJECT_BWD(CD, PT)                                                                              \
-    hipLaunchKernelGGL((frame_project_backward_kernel<CD, PT>), dim3(nblk), dim3(256), 0, stream, f->pos,         \
+    hipLaunchKernelGGL((frame_project_backward_kernel<CD, PT>), dim3((unsigned)gs_div_up(f->N, CD == 3 ? 256 : 128)), \
+                       dim3(CD == 3 ? 256 : 128), 0, stream, f->pos,                                              \
                        (const float4 *)f->quat, f->scale, f->N, P, ws.rec_geom, ws.rec_color,                     \
                        (const float4 *)ws.rows, ws.row_flags, ws.pair_offsets, ws.rects,                          \
                        (uint64_t)f->max_pairs,                                                                    \

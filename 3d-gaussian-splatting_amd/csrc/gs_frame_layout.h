@@ -113,6 +113,13 @@ static inline bool gs_frame_uses_strips(const gs_frame *f) {
     return f->N >= GS_STRIP_AUTO_MIN_N || ntx * nty > GS_BIN_MAX_TILES;
 }
 
+// Strip variant: the strip-entry count (level 1a) is taken inside the project stage (cull_project.hip,
+// frame_project_count_kernel) instead of by strip_count_kernel re-reading the rectangles.
+#ifndef GS_FUSED_PROJECT_COUNT
+#define GS_FUSED_PROJECT_COUNT 1  // A/B switch (tools/ab_variants.py)
+#endif
+static inline bool gs_frame_fused_count(const gs_frame *f) { return GS_FUSED_PROJECT_COUNT && gs_frame_uses_strips(f); }
+
 // floats per per-pair gradient row: (dx, dy, da, db, dc, dd, dopa) + colour grads, padded to float4s
 // floats per (tile, Gaussian) gradient row: 7 geometry/opacity sums + color_dim colour sums, rounded up to float4s
 // (12 / 36 / 56 for color_dim 3 / 27 / 48)

@@ -30,71 +30,9 @@
 
 #include "gs_common.h"
 #include "gs_frame_layout.h"
+#include "strip_common.h"
 
 namespace {
-
-#define STRIP_THREADS 1024
-#ifndef STRIP_SOLO
-#define STRIP_SOLO 16  // Gaussians with up to this many entries are walked by their own lane (4: +15 us, 8: +2 us at 2.4 M)
-#endif
-#ifndef STRIP_PF
-#define STRIP_PF 2     // rectangles in flight per thread (4 left a quarter of the visits of a 9,472-Gaussian slice empty: +7 us)
-#endif
-
-// Calls fn(strip, lo32, depth_bits, pairs) for every strip entry of one Gaussian per lane.  lo32 = first covered tile of
-// the strip << 29 | last covered tile << 26 | gaussian; pairs = listed tiles of the run.  DIST: a tile of the
-// bounding square is listed iff gs_dist_listed says so; runs without a listed tile emit nothing (the same decision
-// in the count and in the scatter pass, and in strip_sort_kernel).
-template <bool DIST, typename Fn>
-__device__ __forceinline__ void walk_strips(const uint4 rc, int64_t g, const gs_strip_geom SG, float2 cxy,
-                                            const GsDistCull &D, Fn fn) {
-    const int lane = threadIdx.x & 63;
-    const uint32_t y0 = rc.x & 0xffff, y1 = rc.x >> 16, x0 = rc.y & 0xffff, x1 = rc.y >> 16, dbits = rc.z;
-    const bool vis = rc.w != 0;
-    const uint32_t sx0 = x0 / GS_STRIP_W, span = vis ? (x1 - 1) / GS_STRIP_W - sx0 + 1 : 0;
-    const uint32_t ne = span * (y1 - y0);
-    auto emit = [&](uint32_t sx, uint32_t iy, uint32_t ex0, uint32_t ex1, uint32_t id, uint32_t d, float px, float py) {
-        const uint32_t t0 = sx * GS_STRIP_W;
-        const uint32_t lo = ex0 > t0 ? ex0 - t0 : 0, hi = (ex1 < t0 + GS_STRIP_W ? ex1 : t0 + GS_STRIP_W) - t0;  // [lo, hi)
-        uint32_t np = hi - lo;
-        if (DIST) {
-            np = 0;
-            for (uint32_t x = lo; x < hi; ++x) np += gs_dist_listed(px, py, t0 + x, iy, D) ? 1u : 0u;
-            if (!np) return;
-        }
-        fn(iy * SG.nsx + sx, (lo << 29) | ((hi - 1) << 26) | id, d, np);
-    };
-    if (ne && ne <= STRIP_SOLO) {
-        uint32_t sx = sx0, iy = y0;
-        for (uint32_t k = 0; k < ne; ++k) {
-            emit(sx, iy, x0, x1, (uint32_t)g, dbits, cxy.x, cxy.y);
-            if (++sx == sx0 + span) {
-                sx = sx0;
-                ++iy;
-            }
-        }
-    }
-    unsigned long long big = __ballot(ne > STRIP_SOLO);
-    while (big) {  // a Gaussian that crosses many strips is walked by the whole wave
-        const int src = __ffsll((long long)big) - 1;
-        big &= big - 1;
-        const uint32_t c = __shfl(ne, src, 64), d = __shfl(dbits, src, 64), sp = __shfl(span, src, 64);
-        const uint32_t bsx0 = __shfl(sx0, src, 64), by0 = __shfl(y0, src, 64);
-        const uint32_t bx0 = __shfl(x0, src, 64), bx1 = __shfl(x1, src, 64);
-        const float spx = DIST ? __shfl(cxy.x, src, 64) : 0.f, spy = DIST ? __shfl(cxy.y, src, 64) : 0.f;
-        const uint32_t id = (uint32_t)(g - lane + src);
-        for (uint32_t k = lane; k < c; k += 64) emit(bsx0 + k % sp, by0 + k / sp, bx0, bx1, id, d, spx, spy);
-    }
-}
-
-// same XCD-contiguous dealing of slices to workgroups as the table variant (tile_bin.hip): the runs of neighbouring
-// slices are neighbours in memory, so the partial lines at run boundaries meet in one L2
-__device__ __forceinline__ uint32_t strip_slice_of_block(uint32_t blk, uint32_t B) {
-    const uint32_t xcd = blk & 7, idx = blk >> 3;
-    uint32_t first = 0;
-    for (uint32_t x = 0; x < xcd; ++x) first += (B - x + 7) >> 3;
-    return first + idx;
-}
 
 struct SliceLoader {
     const uint4 *rects;
@@ -112,53 +50,6 @@ struct SliceLoader {
         return make_float2(ge.x, ge.y);
     }
 };
-
-// ---------------------------------------------------------------- compositing order of the tiles (longest first)
-// One tile per wave is serial in the tile's list, and tiles differ by several times in the Gaussians they composite
-// before all their pixels are saturated: dispatched in raster order, the long tiles that happen to start late leave most
-// SIMDs idle at the end of raster_forward_kernel (PMC, round 2: 68 % of the issue cycles busy).  The forward kernel
-// therefore records what every tile cost (Gaussian steps until it stopped) and the NEXT frame of the same workspace
-// dispatches its tiles in descending order of that cost -- longest-processing-time-first list scheduling; a viewer's or
-// a trainer's consecutive frames of one camera are nearly the same picture, and for an unrelated camera the order is
-// merely arbitrary, as raster order is.  Whatever the costs hold (first frame: uninitialised memory), a counting sort
-// of the tile indices yields a permutation, and the image does not depend on the order: tiles are independent.
-// Runs as one EXTRA workgroup of strip_count_kernel's launch, i.e. underneath the binning, three kernels ahead of its
-// consumer.  256 bins of GS_ORDER_QUANTUM steps; arrival order inside a bin is whatever the LDS atomics make it.
-#define GS_ORDER_QUANTUM 8
-__device__ __forceinline__ void tile_order_workgroup(const uint32_t *__restrict__ tile_cost, uint32_t T,
-                                                     uint32_t *__restrict__ tile_order) {
-    // 256 bins x 16 sub-counters (lane % 16): in a sparse frame most tiles cost the same (empty tiles: 0), and 64 lanes
-    // adding to ONE LDS word serialise (first version: +10 us on a 50-us frame of 10,000 Gaussians); with the
-    // sub-counters a wave's add hits every word at most four times.  Slot order: bin-major, sub-counter-minor.
-    constexpr uint32_t SUB = 16, NC = 256 * SUB, PER = NC / STRIP_THREADS;
-    __shared__ uint32_t s_bin[NC];
-    __shared__ uint32_t s_wsum[STRIP_THREADS / 64];
-    for (uint32_t c = threadIdx.x; c < NC; c += STRIP_THREADS) s_bin[c] = 0;
-    __syncthreads();
-    const uint32_t sub = threadIdx.x & (SUB - 1);
-    auto counter_of = [&](uint32_t c) {
-        const uint32_t q = c / GS_ORDER_QUANTUM;
-        return (255u - (q < 255u ? q : 255u)) * SUB + sub;  // descending cost
-    };
-    for (uint32_t t = threadIdx.x; t < T; t += STRIP_THREADS) atomicAdd(&s_bin[counter_of(tile_cost[t])], 1u);
-    __syncthreads();
-    // exclusive scan of the NC counters: thread t owns counters [t PER, t PER + PER)
-    uint32_t c[PER], sum = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < PER; ++j) {
-        c[j] = sum;
-        sum += s_bin[threadIdx.x * PER + j];
-    }
-    const uint32_t incl = gs_wave_incl_scan_u32(sum);
-    if ((threadIdx.x & 63) == 63) s_wsum[threadIdx.x >> 6] = incl;
-    __syncthreads();
-    uint32_t off = incl - sum;
-    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) off += s_wsum[w];
-#pragma unroll
-    for (uint32_t j = 0; j < PER; ++j) s_bin[threadIdx.x * PER + j] = off + c[j];  // cursor = first slot of the counter
-    __syncthreads();
-    for (uint32_t t = threadIdx.x; t < T; t += STRIP_THREADS) tile_order[atomicAdd(&s_bin[counter_of(tile_cost[t])], 1u)] = t;
-}
 
 // ---------------------------------------------------------------- L1a: count
 template <bool DIST>
@@ -471,11 +362,13 @@ int gs_stage_strip_bin(const gs_frame *f, const gs_frame_ws &ws, hipStream_t str
     const size_t lds_scatter = sizeof(unsigned long long) * ((size_t)SG.NS + plan.cap);
 #define GS_LAUNCH_STRIP(DIST)                                                                                          \
     do {                                                                                                               \
-        hipLaunchKernelGGL(strip_count_kernel<DIST>, dim3(plan.slices + 1), dim3(STRIP_THREADS), lds_count, stream,    \
-                           ws.rects, ws.rec_geom, D, f->N, plan.per_slice, SG, plan.slices, table, ws.block_sums,      \
-                           ws.block_vis, ws.slice_pairs, ws.slice_vis, ws.tile_cost, (uint32_t)G.n_tiles,              \
-                           ws.tile_order);                                                                             \
-        GS_CHECK_LAUNCH();                                                                                             \
+        if (!gs_frame_fused_count(f)) { /* else: counted by the project stage (frame_project_count_kernel) */            \
+            hipLaunchKernelGGL(strip_count_kernel<DIST>, dim3(plan.slices + 1), dim3(STRIP_THREADS), lds_count, stream,\
+                               ws.rects, ws.rec_geom, D, f->N, plan.per_slice, SG, plan.slices, table, ws.block_sums,  \
+                               ws.block_vis, ws.slice_pairs, ws.slice_vis, ws.tile_cost, (uint32_t)G.n_tiles,          \
+                               ws.tile_order);                                                                         \
+            GS_CHECK_LAUNCH();                                                                                         \
+        }                                                                                                              \
         hipLaunchKernelGGL(strip_colscan_kernel, dim3((unsigned)gs_div_up(SG.NS, 16)), dim3(256), 0, stream, table,    \
                            scan, plan.slices, SG.NS, (unsigned long long *)ws.strip_tot);                              \
         GS_CHECK_LAUNCH();                                                                                             \

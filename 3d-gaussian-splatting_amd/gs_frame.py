@@ -420,7 +420,7 @@ class FrameRenderer:
             "visible": visible,
             "rec_geom": rec[:, 0:4],
             "rec_cov": rec[:, 4:8],
-            "tiles_touched": view(ptrs[6], 4 * n, torch.int32, (n,)),
+            "tiles_touched": self._rects()[:, 3],  # (the separate array is only written for sort_modes 0 / 1)
         }
         if f.color_dim == 3:
             out["rec_color"] = rec[:, 8:12]
