@@ -203,22 +203,42 @@ __global__ void __launch_bounds__(256) bin_colscan_kernel(uint32_t *__restrict__
 }
 
 // ---------------------------------------------------------------- B3
-__device__ __forceinline__ unsigned long long *s_wave_u64() {
-    __shared__ unsigned long long s_w64[BIN_THREADS / 64];
-    return s_w64;
-}
-// sum over the workgroup, the same value returned to every thread
-__device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, unsigned long long *s_w) {
+// Three 64-bit block sums -- and the exclusive prefix of the first -- behind ONE pair of barriers (round 2 took three
+// sums and a scan with their own barriers: +5 us on a 45-us frame of a small scene).
+__device__ __forceinline__ void block_sum3_u64(unsigned long long &a, unsigned long long &b, unsigned long long &c,
+                                               unsigned long long *prefix_a = nullptr) {
+    __shared__ unsigned long long s_w[3][BIN_THREADS / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long incl = a;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    __syncthreads();  // s_w may still be read from the previous call
-    if (lane == 0) s_w[wave] = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long x = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += x;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        b += __shfl_xor(b, o, 64);
+        c += __shfl_xor(c, o, 64);
+    }
+    __syncthreads();  // s_w may still be read from a previous call
+    if (lane == 63) s_w[0][wave] = incl;
+    if (lane == 0) {
+        s_w[1][wave] = b;
+        s_w[2][wave] = c;
+    }
     __syncthreads();
-    unsigned long long total = 0;
+    unsigned long long off = 0, ta = 0;
+    b = c = 0;
 #pragma unroll
-    for (int w = 0; w < BIN_THREADS / 64; ++w) total += s_w[w];
-    return total;
+    for (int w = 0; w < BIN_THREADS / 64; ++w) {
+        const unsigned long long x = s_w[0][w];
+        off += w < wave ? x : 0;
+        ta += x;
+        b += s_w[1][w];
+        c += s_w[2][w];
+    }
+    if (prefix_a) *prefix_a = off + incl - a;
+    a = ta;
 }
 
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_wave, uint32_t &total) {
@@ -275,8 +295,8 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_scatter_kernel(
         rp += slice_pairs[b];
         rv += slice_vis[b];
     }
-    const unsigned long long M = block_sum_u64(mine, s_wave_u64()), R = block_sum_u64(rp, s_wave_u64()),
-                             V = block_sum_u64(rv, s_wave_u64());
+    unsigned long long M = mine, R = rp, V = rv, run64 = 0;
+    block_sum3_u64(M, R, V, &run64);
     if (M > max_pairs || R > max_pairs) {  // not enough room: leave the frame empty and report the true count
         if (slice == 0) {
             for (uint32_t t = threadIdx.x; t < T; t += BIN_THREADS) reinterpret_cast<int2 *>(tile_ranges)[t] = make_int2(0, 0);
@@ -291,7 +311,7 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_scatter_kernel(
         return;
     }
     uint32_t dummy;
-    uint32_t run = block_excl_scan((uint32_t)mine, s_wave, dummy);
+    uint32_t run = (uint32_t)run64;  // the frame fits: every prefix is below max_pairs < 2^30
     for (uint32_t t = t0; t < t1; ++t) {
         s_slot[t] = run;
         run += tile_count[t];
@@ -410,8 +430,8 @@ __global__ void __launch_bounds__(BIN_THREADS) slice_sort_kernel(
         r_before += b < first_blk ? c : 0;
         v_all += block_vis[b];
     }
-    const unsigned long long R = block_sum_u64(r_all, s_wave_u64()), base = block_sum_u64(r_before, s_wave_u64()),
-                             V = block_sum_u64(v_all, s_wave_u64());
+    unsigned long long R = r_all, base = r_before, V = v_all;
+    block_sum3_u64(R, base, V);
     uint32_t *row = table + (size_t)slice * (T + 1);
     if (slice == 0 && threadIdx.x == 0) {
         counters[GS_CNT_VISIBLE] = V;

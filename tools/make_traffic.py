@@ -1,9 +1,14 @@
 #!/usr/bin/env python3
-"""profiles/traffic.json from PMC summaries:  python tools/make_traffic.py cfg5=profiles/r02_a_cfg5_pmc_summary.csv:6950364 ...
+"""profiles/traffic.json from PMC summaries:
+
+    python tools/make_traffic.py cfg5=profiles/r03_e_cfg5_forward_pmc_summary.csv:6950364:profiles/r03_e_cfg5_forward_kernel_stats.csv ...
 
 Per kernel of each config: FETCH_SIZE / WRITE_SIZE (KiB per launch, raw) and traffic_bytes = 2 x FETCH + WRITE -- the
 gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE counts a 128-byte request as 64 B), calibrated in
-profiles/traffic.json's note on kernels with known streaming reads."""
+profiles/traffic.json's note on kernels with known streaming reads.  With a kernel_stats.csv of the same workload
+(third field) also `issue_busy` = SQ_ACTIVE_INST_VALU x 4 / (average kernel time x 2.4 GHz x 1024 SIMDs): the fraction
+of the SIMDs' cycles in which a VALU instruction was executing (SQ_ACTIVE_INST_VALU counts in units of 4 cycles, summed
+over the SIMDs)."""
 import csv
 import json
 import os
@@ -12,9 +17,24 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 path = os.path.join(ROOT, "profiles", "traffic.json")
 data = json.load(open(path)) if os.path.exists(path) else {}
+CLOCK_GHZ, SIMDS = 2.4, 1024
+
+
+def short(name):
+    return name.replace("void ", "").replace("(anonymous namespace)::", "").split("<")[0].split("(")[0].strip()
+
+
 for arg in sys.argv[1:]:
     cfg, rest = arg.split("=", 1)
-    fn, pairs = rest.rsplit(":", 1)
+    parts = rest.split(":")
+    fn, pairs = parts[0], parts[1]
+    avg_ns = {}
+    if len(parts) > 2:
+        with open(parts[2], newline="") as f:
+            for r in csv.DictReader(f):
+                k = short(r["Name"])
+                if k not in avg_ns or float(r["TotalDurationNs"]) > avg_ns[k][1]:
+                    avg_ns[k] = (float(r["AverageNs"]), float(r["TotalDurationNs"]))
     entry = {"tile_pairs": int(pairs), "source": os.path.relpath(fn, ROOT)}
     with open(fn, newline="") as f:
         for r in csv.DictReader(f):
@@ -22,12 +42,26 @@ for arg in sys.argv[1:]:
                 continue
             fk, wk = float(r["FETCH_SIZE"]), float(r["WRITE_SIZE"])
             name = r["kernel"].split("<")[0]
+            if name.startswith("at::") or name.startswith("__amd"):
+                continue  # torch helpers of the profiling script, not the path's kernels
             if name in entry:  # several instantiations of one template: keep the one that moved the most
                 if entry[name]["traffic_bytes"] >= int((2 * fk + wk) * 1024):
                     continue
-            entry[name] = {"kernel": r["kernel"], "fetch_kib": fk, "write_kib": wk,
-                           "traffic_bytes": int((2 * fk + wk) * 1024)}
+            e = {"kernel": r["kernel"], "fetch_kib": fk, "write_kib": wk, "traffic_bytes": int((2 * fk + wk) * 1024)}
+            if name in avg_ns and r.get("SQ_ACTIVE_INST_VALU") not in (None, ""):
+                e["kernel_us"] = round(avg_ns[name][0] / 1e3, 2)
+                e["issue_busy"] = round(float(r["SQ_ACTIVE_INST_VALU"]) * 4 / (avg_ns[name][0] * CLOCK_GHZ * SIMDS), 3)
+            entry[name] = e
     data[cfg] = entry
+data["_note"] = (
+    "HBM-side bytes per launch from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of "
+    "tools/prof_target.py <config>; current set: the `source` file of every config, profiles/r03_*). FETCH_SIZE / "
+    "WRITE_SIZE are in KiB. gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 128-B requests as 64 B -> "
+    "x2; calibrated in round 1 on kernels with known streaming reads (bin_count_kernel: 16 B x 376,467 rect records = "
+    "6.02 MB, FETCH_SIZE = 3.07 MB; bin_colscan_kernel: 8.03 MB table, FETCH_SIZE = 4.08 MB) and again in round 3 on "
+    "frame_project_count_kernel at 2.4 M Gaussians: 56 B x 2.4 M = 134.4 MB of parameters read, FETCH_SIZE = 65,725 KiB = "
+    "67.3 MB (ratio 0.50). WRITE_SIZE needs no correction (raster writes 12 B x 2,088,960 px = 25.07 MB, WRITE_SIZE = "
+    "24.9 MB). issue_busy: see tools/make_traffic.py.")
 json.dump(data, open(path, "w"), indent=1)
-print(json.dumps({k: {kk: vv.get("traffic_bytes") for kk, vv in v.items() if isinstance(vv, dict)}
+print(json.dumps({k: {kk: (vv.get("traffic_bytes"), vv.get("issue_busy")) for kk, vv in v.items() if isinstance(vv, dict)}
                   for k, v in data.items() if isinstance(v, dict)}, indent=1))
