@@ -722,6 +722,9 @@ struct PixShCfg {
 #ifndef GS_BWD_SH48_WPE
 #define GS_BWD_SH48_WPE 3
 #endif
+#ifndef GS_BWD_SH_SCALAR_ROWS
+#define GS_BWD_SH_SCALAR_ROWS 1  // A/B switch (tools/ab_variants.py): see row_value below
+#endif
 #ifndef GS_BWD_SH_WPE
 #define GS_BWD_SH_WPE 4  // waves per SIMD the register allocation aims at (A/B switch, tools/ab_variants.py)
 #endif
@@ -730,6 +733,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CDIM ==
 raster_backward_pixel_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
     static_assert(!(EXACT && FRAME), "the exact-exp flavour belongs to the reference API (gs_draw_backward, fast = 0)");
     constexpr int NB = PixShCfg<CDIM>::NB, NROW = PixShCfg<CDIM>::NROW;
+    constexpr bool PRE = GS_SH_PRESCALE && CDIM == 27;  // SH basis pre-scaled by -log2(e): raster_common.h
     typedef float f2 __attribute__((ext_vector_type(2)));
     enum { FX, FY, FA, FB, FC, FOPA, FC0, FC1, FC2, NFLD };  // FC0..2: the Gaussian's colour (CDIM == 3 only)
     __shared__ float s_g[NFLD][64];
@@ -824,8 +828,13 @@ raster_backward_pixel_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
             float sa[NB], sb[NB];
             raster_pixel_sh<NB>(id_x, id_y0 + 8 * h, G, sa);
             raster_pixel_sh<NB>(id_x, id_y0 + 8 * h + 4, G, sb);
+            // pre-scaled by -log2(e) (raster_common.h): the colour's exponent needs no multiplication, and the same
+            // registers serve the coefficient gradients, whose factor c (1 - c) is scaled by -ln 2 instead (below)
+            // (not at degree 3: there the kernel sits at its register limit and the change costs four more spilled
+            // registers -- measured 2.22 against 2.12 ms; degree 2: 1.60 against 1.62 ms)
+            constexpr float KS = PRE ? -GS_LOG2E : 1.0f;
 #pragma unroll
-            for (int k = 0; k < NB; ++k) SHB[h][k] = f2{sa[k], sb[k]};
+            for (int k = 0; k < NB; ++k) SHB[h][k] = f2{KS * sa[k], KS * sb[k]};
         }
         py2[h] = f2{raster_pixel_coord(id_y0 + 8 * h, G.padH, G.focal_y),
                     raster_pixel_coord(id_y0 + 8 * h + 4, G.padH, G.focal_y)};
@@ -893,9 +902,10 @@ raster_backward_pixel_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
                     v1 = pk_fma(SHB[h][k], splat(co[NB + k]), v1);
                     v2 = pk_fma(SHB[h][k], splat(co[2 * NB + k]), v2);
                 }
-                c0 = f2{gs_rcp(1.0f + __expf(-v0.x)), gs_rcp(1.0f + __expf(-v0.y))};
-                c1 = f2{gs_rcp(1.0f + __expf(-v1.x)), gs_rcp(1.0f + __expf(-v1.y))};
-                c2 = f2{gs_rcp(1.0f + __expf(-v2.x)), gs_rcp(1.0f + __expf(-v2.y))};
+                auto sg = [](float v) { return PRE ? gs_rcp(1.0f + gs_exp2(v)) : gs_rcp(1.0f + __expf(-v)); };
+                c0 = f2{sg(v0.x), sg(v0.y)};
+                c1 = f2{sg(v1.x), sg(v1.y)};
+                c2 = f2{sg(v2.x), sg(v2.y)};
             } else {  // one colour per Gaussian
                 c0 = splat(s_g[FC0][i]);
                 c1 = splat(s_g[FC1][i]);
@@ -913,10 +923,12 @@ raster_backward_pixel_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
             f2 d_alpha = pk_fma(T[h], gc, -(rho[h] * rc));
             d_alpha = f2{l0 ? d_alpha.x : 0.f, l1 ? d_alpha.y : 0.f};
             if constexpr (CDIM > 3) {
-                const f2 one = {1.0f, 1.0f};
-                D[h][0] = g0[h] * w * (c0 * (one - c0));
-                D[h][1] = g1[h] * w * (c1 * (one - c1));
-                D[h][2] = g2[h] * w * (c2 * (one - c2));
+                // c (1 - c) [x -ln 2 with the pre-scaled basis: D sh' = D sh] as c (K - K c): one packed FMA either way
+                constexpr float K = PRE ? -GS_LN2 : 1.0f;
+                const f2 kk = {K, K}, nk = {-K, -K};
+                D[h][0] = g0[h] * w * (c0 * pk_fma(c0, nk, kk));
+                D[h][1] = g1[h] * w * (c1 * pk_fma(c1, nk, kk));
+                D[h][2] = g2[h] * w * (c2 * pk_fma(c2, nk, kk));
             } else {  // dL/dcolour_c = sum dL/dC_c w (the sigmoid's derivative is applied per Gaussian, later)
                 D[h][0] = g0[h] * w;
                 D[h][1] = g1[h] * w;
@@ -945,8 +957,16 @@ raster_backward_pixel_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
             if (m == 6) return Sopa.x + Sopa.y;
             const int ch = (m - 7) / NB, k = (m - 7) % NB;
             if constexpr (CDIM > 3) {
+#if GS_BWD_SH_SCALAR_ROWS
+                // four products of the lane's four pixels as ONE chain of scalar FMAs: a packed multiply + packed FMA +
+                // the add of the two halves is three instructions but 5.2 ns of issue (packed fp32 has no rate
+                // advantage on this chip: tools/ubench/pk_rate.hip), the chain is four instructions and 4.2 ns
+                return fmaf(D[1][ch].y, SHB[1][k].y,
+                            fmaf(D[1][ch].x, SHB[1][k].x, fmaf(D[0][ch].y, SHB[0][k].y, D[0][ch].x * SHB[0][k].x)));
+#else
                 const f2 p = pk_fma(D[1][ch], SHB[1][k], D[0][ch] * SHB[0][k]);
                 return p.x + p.y;
+#endif
             } else {
                 const f2 p = D[0][ch] + D[1][ch];
                 return p.x + p.y;

@@ -1,5 +1,12 @@
 // raster_common.h -- shared pieces of the tile rasterizer forward/backward kernels.
 #pragma once
+// SH colours sigma(sum_k sh_k(pixel) coef_k) are evaluated as 1 / (1 + 2^(sum_k sh'_k coef_k)) with the pixel's basis
+// values pre-scaled once per wave, sh'_k = -log2(e) sh_k: the exponential's argument needs no multiplication per
+// (pixel, Gaussian, channel) -- 12 VALU instructions per Gaussian step of a wave in the SH forward and backward
+// kernels (8 % of the forward's).  A/B switch for tools/ab_variants.py.
+#ifndef GS_SH_PRESCALE
+#define GS_SH_PRESCALE 1
+#endif
 #include "gs_common.h"
 #include "gs_frame_layout.h"
 

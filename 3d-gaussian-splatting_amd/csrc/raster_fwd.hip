@@ -187,8 +187,9 @@ raster_forward_kernel(RasterSrc S, RasterGeom G,
             float a9[NB], b9[NB];
             raster_pixel_sh<NB>(id_x, id_y0 + 8 * h, G, a9);
             raster_pixel_sh<NB>(id_x, id_y0 + 8 * h + 4, G, b9);
+            constexpr float KS = GS_SH_PRESCALE ? -GS_LOG2E : 1.0f;  // raster_common.h
 #pragma unroll
-            for (int k9 = 0; k9 < NB; ++k9) SH[h][k9] = f2{a9[k9], b9[k9]};
+            for (int k9 = 0; k9 < NB; ++k9) SH[h][k9] = f2{KS * a9[k9], KS * b9[k9]};
         }
     }
 
@@ -413,9 +414,8 @@ raster_forward_kernel(RasterSrc S, RasterGeom G,
                             v1 = pk_fma(SH[h][k9], splat(co[NB + k9]), v1);
                             v2 = pk_fma(SH[h][k9], splat(co[2 * NB + k9]), v2);
                         }
-                        const f2 c0 = {gs_rcp(1.0f + __expf(-v0.x)), gs_rcp(1.0f + __expf(-v0.y))};
-                        const f2 c1 = {gs_rcp(1.0f + __expf(-v1.x)), gs_rcp(1.0f + __expf(-v1.y))};
-                        const f2 c2 = {gs_rcp(1.0f + __expf(-v2.x)), gs_rcp(1.0f + __expf(-v2.y))};
+                        auto sg = [](float v) { return GS_SH_PRESCALE ? gs_rcp(1.0f + gs_exp2(v)) : gs_rcp(1.0f + __expf(-v)); };
+                        const f2 c0 = {sg(v0.x), sg(v0.y)}, c1 = {sg(v1.x), sg(v1.y)}, c2 = {sg(v2.x), sg(v2.y)};
                         cr[h] = pk_fma(w, c0, cr[h]);
                         cg[h] = pk_fma(w, c1, cg[h]);
                         cb[h] = pk_fma(w, c2, cb[h]);
@@ -554,8 +554,9 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_segment_kernel(
             float a9[NB], b9[NB];
             raster_pixel_sh<NB>(id_x, id_y0 + 8 * h, G, a9);
             raster_pixel_sh<NB>(id_x, id_y0 + 8 * h + 4, G, b9);
+            constexpr float KS = GS_SH_PRESCALE ? -GS_LOG2E : 1.0f;  // raster_common.h
 #pragma unroll
-            for (int k9 = 0; k9 < NB; ++k9) SH[h][k9] = f2{a9[k9], b9[k9]};
+            for (int k9 = 0; k9 < NB; ++k9) SH[h][k9] = f2{KS * a9[k9], KS * b9[k9]};
         }
     }
     // pixel slot of pair h, element e: 128 h + 64 e + lane (the checkpoint layout)
@@ -664,9 +665,8 @@ __global__ void __launch_bounds__(FWD_THREADS) raster_segment_kernel(
                             v1 = pk_fma(SH[h][k9], splat(co[NB + k9]), v1);
                             v2 = pk_fma(SH[h][k9], splat(co[2 * NB + k9]), v2);
                         }
-                        const f2 c0 = {gs_rcp(1.0f + __expf(-v0.x)), gs_rcp(1.0f + __expf(-v0.y))};
-                        const f2 c1 = {gs_rcp(1.0f + __expf(-v1.x)), gs_rcp(1.0f + __expf(-v1.y))};
-                        const f2 c2 = {gs_rcp(1.0f + __expf(-v2.x)), gs_rcp(1.0f + __expf(-v2.y))};
+                        auto sg = [](float v) { return GS_SH_PRESCALE ? gs_rcp(1.0f + gs_exp2(v)) : gs_rcp(1.0f + __expf(-v)); };
+                        const f2 c0 = {sg(v0.x), sg(v0.y)}, c1 = {sg(v1.x), sg(v1.y)}, c2 = {sg(v2.x), sg(v2.y)};
                         cr[h] = pk_fma(w, c0, cr[h]);
                         cg[h] = pk_fma(w, c1, cg[h]);
                         cb[h] = pk_fma(w, c2, cb[h]);

@@ -290,28 +290,47 @@ def main():
         out["stage_total_ms"], out["frame_roofline"] = head["stage_total_ms"], head["frame_roofline"]
 
     extra = {}
+    leg_errors = {}
+
+    def guarded(name, fn):
+        """Run one non-headline leg; an exception there must not cost the headline line (its message is reported).  Under
+        several ranks the same exception is raised on every rank (the legs are rank-symmetric), so nobody is left
+        waiting in a collective."""
+        try:
+            fn()
+        except Exception as e:  # noqa: BLE001
+            import traceback
+
+            log(f"[rank {rank}] leg {name} failed: {e!r}\n{traceback.format_exc()}")
+            leg_errors[name] = repr(e)[:300]
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+
     # ---------------------------------------------------------------- three frames in flight (throughput figure)
     if "pipelined" in legs:
-        params, cam = head["params"], head["cam"]
-        rs = [head["renderer"]] + [sized_renderer(params, cam, training=False)[0] for _ in range(2)]
-        streams = [torch.cuda.Stream(device=dev) for _ in rs]
-        counter = [0]
-        for i in range(len(rs)):  # setup: the first launch on a fresh HIP stream creates its hardware queue (~ms)
-            with torch.cuda.stream(streams[i]):
-                for _ in range(3):
+        def _leg_pipelined():
+            params, cam = head["params"], head["cam"]
+            rs = [head["renderer"]] + [sized_renderer(params, cam, training=False)[0] for _ in range(2)]
+            streams = [torch.cuda.Stream(device=dev) for _ in rs]
+            counter = [0]
+            for i in range(len(rs)):  # setup: the first launch on a fresh HIP stream creates its hardware queue (~ms)
+                with torch.cuda.stream(streams[i]):
+                    for _ in range(3):
+                        rs[i].forward(*params, cam)
+            torch.cuda.synchronize()
+
+            def pipelined_frame():
+                i = counter[0] % len(rs)
+                counter[0] += 1
+                with torch.cuda.stream(streams[i]):
                     rs[i].forward(*params, cam)
-        torch.cuda.synchronize()
 
-        def pipelined_frame():
-            i = counter[0] % len(rs)
-            counter[0] += 1
-            with torch.cuda.stream(streams[i]):
-                rs[i].forward(*params, cam)
+            k = max(args.steps, 50)
+            dtp, _ = time_frames(pipelined_frame, k, 10)
+            extra["three_frames_in_flight_fps"] = round(world * k / dtp, 2)
+            del rs, streams
 
-        k = max(args.steps, 50)
-        dtp, _ = time_frames(pipelined_frame, k, 10)
-        extra["three_frames_in_flight_fps"] = round(world * k / dtp, 2)
-        del rs, streams
+        guarded("pipelined", _leg_pipelined)
     head_scene, head_cam = head["scene"], head["cam"]
     head_params = head["params"]
     del head["renderer"]
@@ -319,16 +338,19 @@ def main():
 
     # ---------------------------------------------------------------- BASELINE configs[1]
     if "cfg2" in legs and args.config != "cfg2":
-        c2 = render_leg("cfg2", max(args.steps, 50), max(args.warmup, 10))
-        out["cfg2"] = {"workload": workload_name("cfg2", c2["stats"]), "render_fps": round(c2["fps"], 2),
-                       "ms_per_frame": round(c2["ms"], 4), "repeats": c2["repeats"],
-                       "ms_per_frame_min": round(c2["ms_min"], 4), "ms_per_frame_max": round(c2["ms_max"], 4),
-                       "visible": c2["stats"].visible,
-                       "tile_pairs": c2["stats"].pairs, "host_us_per_frame": round(c2["host_us"], 1)}
-        if rank == 0:
-            out["cfg2"].update(roofline=c2["roofline"], stages=c2["stages"], frame_roofline=c2["frame_roofline"])
-        del c2
-        torch.cuda.empty_cache()
+        def _leg_cfg2():
+            c2 = render_leg("cfg2", max(args.steps, 50), max(args.warmup, 10))
+            out["cfg2"] = {"workload": workload_name("cfg2", c2["stats"]), "render_fps": round(c2["fps"], 2),
+                           "ms_per_frame": round(c2["ms"], 4), "repeats": c2["repeats"],
+                           "ms_per_frame_min": round(c2["ms_min"], 4), "ms_per_frame_max": round(c2["ms_max"], 4),
+                           "visible": c2["stats"].visible,
+                           "tile_pairs": c2["stats"].pairs, "host_us_per_frame": round(c2["host_us"], 1)}
+            if rank == 0:
+                out["cfg2"].update(roofline=c2["roofline"], stages=c2["stages"], frame_roofline=c2["frame_roofline"])
+            del c2
+            torch.cuda.empty_cache()
+
+        guarded("cfg2", _leg_cfg2)
 
     # ---------------------------------------------------------------- training step (train.py:84-185, no densification)
     def train_leg(cfg, params, cam, pairs, k, force=False, exchange="all_reduce"):
@@ -386,198 +408,218 @@ def main():
         return world * k / dtt, dtt / k * 1e3, detail, tr
 
     if "train" in legs:
-        k = max(args.steps // 4, 25)
-        _, cam2, params2 = (head_scene, head_cam, head_params) if args.config == "cfg2" else load("cfg2")
-        r2, st2 = sized_renderer(params2, cam2, training=False)
-        del r2
-        ips, ms, detail, tr = train_leg("cfg2", params2, cam2, st2.pairs, k)
-        extra["train_cfg2"] = {"iters_per_s": round(ips, 2), "ms_per_iter": round(ms, 4), **detail,
-                               "step": "forward + L1/SSIM loss (w=0.1) + backward + grad all-reduce (N>1) + fused "
-                                       "Adam, one view per GPU, 376,467 Gaussians, 1080p"}
-        del tr, params2
-        torch.cuda.empty_cache()
-        if not CONFIGS[args.config][3]:
-            ips, ms, detail, tr = train_leg(args.config, head_params, head_cam, st.pairs, k)
-            extra["train_headline_scene"] = {"iters_per_s": round(ips, 2), "ms_per_iter": round(ms, 4), **detail,
-                                             "step": f"the same step on the headline scene ({n} Gaussians)"}
-            del tr
+        def _leg_train():
+            k = max(args.steps // 4, 25)
+            _, cam2, params2 = (head_scene, head_cam, head_params) if args.config == "cfg2" else load("cfg2")
+            r2, st2 = sized_renderer(params2, cam2, training=False)
+            del r2
+            ips, ms, detail, tr = train_leg("cfg2", params2, cam2, st2.pairs, k)
+            extra["train_cfg2"] = {"iters_per_s": round(ips, 2), "ms_per_iter": round(ms, 4), **detail,
+                                   "step": "forward + L1/SSIM loss (w=0.1) + backward + grad all-reduce (N>1) + fused "
+                                           "Adam, one view per GPU, 376,467 Gaussians, 1080p"}
+            del tr, params2
             torch.cuda.empty_cache()
+            if not CONFIGS[args.config][3]:
+                ips, ms, detail, tr = train_leg(args.config, head_params, head_cam, st.pairs, k)
+                extra["train_headline_scene"] = {"iters_per_s": round(ips, 2), "ms_per_iter": round(ms, 4), **detail,
+                                                 "step": f"the same step on the headline scene ({n} Gaussians)"}
+                del tr
+                torch.cuda.empty_cache()
+
+        guarded("train", _leg_train)
 
     # ---------------------------------------------------------------- multi-GPU: the gradient exchange of a training step
     if "multi_gpu" in legs and not CONFIGS[args.config][3] and use_dist:
-        # both exchange modes of gs_dp.py, same scene, same step: (a) two asynchronous mean all-reduces + replicated
-        # fused Adam, (b) two mean reduce-scatters + Adam over the rank's slices + all-gather of the parameters
-        k = max(args.steps // 4, 25)
-        seen = torch.ones(1, device=dev)
-        dist.all_reduce(seen)
-        seen = int(seen.item())
-        mg = {"ranks_seen": seen, "modes": {}}
-        for exchange in ("all_reduce", "reduce_scatter"):
-            views_per_s, ms, _, tr = train_leg(args.config, head_params, head_cam, st.pairs, k, force=True,
-                                               exchange=exchange)
-            flat = tr.flat
-            flat.finish_gather()
-            mg["bucket_bytes"] = flat.bucket_bytes
-
-            def exchange_only():
-                # the collectives of one step, nothing else: both buckets reduced (and, in reduce-scatter mode, the
-                # parameters gathered back), as gs_train.Trainer.train_step issues them
-                for name in ("geometry", "color"):
-                    flat.begin_bucket(name)
-                for name in ("geometry", "color"):
-                    flat.finish_bucket(name)
-                    flat.begin_gather(name)
+        def _leg_multi_gpu():
+            # both exchange modes of gs_dp.py, same scene, same step: (a) two asynchronous mean all-reduces + replicated
+            # fused Adam, (b) two mean reduce-scatters + Adam over the rank's slices + all-gather of the parameters
+            k = max(args.steps // 4, 25)
+            seen = torch.ones(1, device=dev)
+            dist.all_reduce(seen)
+            seen = int(seen.item())
+            mg = {"ranks_seen": seen, "modes": {}}
+            for exchange in ("all_reduce", "reduce_scatter"):
+                views_per_s, ms, _, tr = train_leg(args.config, head_params, head_cam, st.pairs, k, force=True,
+                                                   exchange=exchange)
+                flat = tr.flat
                 flat.finish_gather()
+                mg["bucket_bytes"] = flat.bucket_bytes
 
-            for _ in range(3):
-                exchange_only()
-            ex_ms = time_block(exchange_only, 10) / 10 * 1e3
-            mg["modes"][exchange] = {
-                "train_views_per_s": round(views_per_s, 2), "train_ms_per_iter": round(ms, 4),
-                "exchange_ms": round(ex_ms, 4),
-                "busbw_GBs": None if seen < 2 else round(2 * (seen - 1) / seen * flat.bucket_bytes / (ex_ms * 1e-3) / 1e9, 1),
-                "optimizer_state_bytes_per_rank": sum(v.numel() for v in tr.optimizer.exp_avg.values()) * 8}
-            del tr, flat
-            torch.cuda.empty_cache()
-        best = max(mg["modes"], key=lambda m: mg["modes"][m]["train_views_per_s"])
-        mg.update(best_mode=best, train_views_per_s=mg["modes"][best]["train_views_per_s"],
-                  train_ms_per_iter=mg["modes"][best]["train_ms_per_iter"],
-                  allreduce_ms=mg["modes"]["all_reduce"]["exchange_ms"],
-                  allreduce_busbw_GBs=mg["modes"]["all_reduce"]["busbw_GBs"],
-                  collective="per iteration, RCCL: all_reduce = two asynchronous mean all-reduces of the flat fp32 "
-                             "gradient buckets + replicated fused Adam; reduce_scatter = two mean reduce-scatters + "
-                             "fused Adam over the rank's slices + all-gather of the parameters",
-                  note="1-GPU boxes only for the builder: no 2/4/8-GPU curve measured before the driver's SCALE run")
-        out["multi_gpu"] = mg
+                def exchange_only():
+                    # the collectives of one step, nothing else: both buckets reduced (and, in reduce-scatter mode, the
+                    # parameters gathered back), as gs_train.Trainer.train_step issues them
+                    for name in ("geometry", "color"):
+                        flat.begin_bucket(name)
+                    for name in ("geometry", "color"):
+                        flat.finish_bucket(name)
+                        flat.begin_gather(name)
+                    flat.finish_gather()
+
+                for _ in range(3):
+                    exchange_only()
+                ex_ms = time_block(exchange_only, 10) / 10 * 1e3
+                mg["modes"][exchange] = {
+                    "train_views_per_s": round(views_per_s, 2), "train_ms_per_iter": round(ms, 4),
+                    "exchange_ms": round(ex_ms, 4),
+                    "busbw_GBs": None if seen < 2 else round(2 * (seen - 1) / seen * flat.bucket_bytes / (ex_ms * 1e-3) / 1e9, 1),
+                    "optimizer_state_bytes_per_rank": sum(v.numel() for v in tr.optimizer.exp_avg.values()) * 8}
+                del tr, flat
+                torch.cuda.empty_cache()
+            best = max(mg["modes"], key=lambda m: mg["modes"][m]["train_views_per_s"])
+            mg.update(best_mode=best, train_views_per_s=mg["modes"][best]["train_views_per_s"],
+                      train_ms_per_iter=mg["modes"][best]["train_ms_per_iter"],
+                      allreduce_ms=mg["modes"]["all_reduce"]["exchange_ms"],
+                      allreduce_busbw_GBs=mg["modes"]["all_reduce"]["busbw_GBs"],
+                      collective="per iteration, RCCL: all_reduce = two asynchronous mean all-reduces of the flat fp32 "
+                                 "gradient buckets + replicated fused Adam; reduce_scatter = two mean reduce-scatters + "
+                                 "fused Adam over the rank's slices + all-gather of the parameters",
+                      note="1-GPU boxes only for the builder: no 2/4/8-GPU curve measured before the driver's SCALE run")
+            out["multi_gpu"] = mg
+
+        guarded("multi_gpu", _leg_multi_gpu)
     del head_params
 
     # ---------------------------------------------------------------- cfg3 in miniature: does the step train?
     if "fit" in legs and rank == 0 and world == 1:
-        # BASELINE.json configs[2] in miniature: fit a perturbed copy of the cfg3 scene (506,627 Gaussians, 1080p)
-        # to a render of the original with the reference's training step (train.py defaults: lr 0.003 x
-        # (10, 10, 1, 1, 1), exp decay, L1 + 0.1 SSIM, Adam(0.9, 0.99)); there is no dataset here, so the
-        # figure of merit is the PSNR against that synthetic ground truth before / after a short run
-        from gs_train import TrainOptions, Trainer
+        def _leg_fit():
+            # BASELINE.json configs[2] in miniature: fit a perturbed copy of the cfg3 scene (506,627 Gaussians, 1080p)
+            # to a render of the original with the reference's training step (train.py defaults: lr 0.003 x
+            # (10, 10, 1, 1, 1), exp decay, L1 + 0.1 SSIM, Adam(0.9, 0.99)); there is no dataset here, so the
+            # figure of merit is the PSNR against that synthetic ground truth before / after a short run
+            from gs_train import TrainOptions, Trainer
 
-        _, cam3, params3 = load("cfg3")
-        _, W3, H3, _ = CONFIGS["cfg3"]
-        r3, st3 = sized_renderer(params3, cam3, training=False)
-        target3 = r3.forward(*params3, cam3)[0].clone()
-        del r3
-        g = torch.Generator(device=dev).manual_seed(7)
-        start3 = [t.clone() for t in params3]
-        start3[4] += 0.5 * torch.randn(start3[4].shape, device=dev, generator=g)   # colour logits
-        start3[3] += 0.3 * torch.randn(start3[3].shape, device=dev, generator=g)   # opacity logits
-        n_it = 300
-        tr3 = Trainer(start3, [cam3], [target3], TrainOptions(n_iters=n_it + 1, n_iters_warmup=30),
-                      max_pairs=int(st3.pairs * 1.2) + 4096)
-        psnr0 = Trainer.psnr(tr3.renderer.forward(*tr3.flat.params, cam3)[0], target3)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(n_it):
-            tr3.train_step(i, 0)
-        torch.cuda.synchronize()
-        dt3 = time.perf_counter() - t0
-        psnr1 = Trainer.psnr(tr3.renderer.forward(*tr3.flat.params, cam3)[0], target3)
-        extra["cfg3_fit"] = {"n_gaussians": CONFIGS["cfg3"][0], "tile_pairs": st3.pairs, "iters": n_it,
-                             "iters_per_s": round(n_it / dt3, 1), "psnr_before_dB": round(psnr0, 2),
-                             "psnr_after_dB": round(psnr1, 2),
-                             "final_loss": round(float(tr3._loss_for(H3, W3).values[0]), 5)}
-        del tr3, target3, start3, params3
-        torch.cuda.empty_cache()
+            _, cam3, params3 = load("cfg3")
+            _, W3, H3, _ = CONFIGS["cfg3"]
+            r3, st3 = sized_renderer(params3, cam3, training=False)
+            target3 = r3.forward(*params3, cam3)[0].clone()
+            del r3
+            g = torch.Generator(device=dev).manual_seed(7)
+            start3 = [t.clone() for t in params3]
+            start3[4] += 0.5 * torch.randn(start3[4].shape, device=dev, generator=g)   # colour logits
+            start3[3] += 0.3 * torch.randn(start3[3].shape, device=dev, generator=g)   # opacity logits
+            n_it = 300
+            tr3 = Trainer(start3, [cam3], [target3], TrainOptions(n_iters=n_it + 1, n_iters_warmup=30),
+                          max_pairs=int(st3.pairs * 1.2) + 4096)
+            psnr0 = Trainer.psnr(tr3.renderer.forward(*tr3.flat.params, cam3)[0], target3)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n_it):
+                tr3.train_step(i, 0)
+            torch.cuda.synchronize()
+            dt3 = time.perf_counter() - t0
+            psnr1 = Trainer.psnr(tr3.renderer.forward(*tr3.flat.params, cam3)[0], target3)
+            extra["cfg3_fit"] = {"n_gaussians": CONFIGS["cfg3"][0], "tile_pairs": st3.pairs, "iters": n_it,
+                                 "iters_per_s": round(n_it / dt3, 1), "psnr_before_dB": round(psnr0, 2),
+                                 "psnr_after_dB": round(psnr1, 2),
+                                 "final_loss": round(float(tr3._loss_for(H3, W3).values[0]), 5)}
+            del tr3, target3, start3, params3
+            torch.cuda.empty_cache()
+
+        guarded("fit", _leg_fit)
 
     # ---------------------------------------------------------------- BASELINE configs[3]: 2.4 M Gaussians, SH, fwd + bwd
     if "cfg4" in legs and rank == 0 and world == 1:
-        # hipEvent-timed stages.  Degree 2 (27 coefficients) is what the reference implements; degree 3 (48
-        # coefficients, what configs[3] names) is the extension.  Roofline objects per SURVEY.md 8d:
-        #   B_fwd = 44 N + (64 + 8 C) V + (72 + 4 C) M + 12 P + 4 T,  B_bwd = (32 + 4 C) M + 24 P + (100 + 12 C) V + (44 + 4 C) N
-        # and for the dominant kernel of the backward (raster backward, S6): R (32 + 4 C) M + 24 P, W (28 + 4 C) V.
-        cfg4 = {}
-        try:
-            traffic4 = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        except (OSError, ValueError):
-            traffic4 = {}
-        for deg in (2, 3):
-            n4, W4, H4, _ = CONFIGS["cfg4"]
-            _, cam4, p4 = load("cfg4", sh_degree=deg)
-            r4, st4 = sized_renderer(p4, cam4, training=True)
-            img4, _ = r4.forward(*p4, cam4)
-            g4 = torch.sign(img4 - 0.5) / img4.numel()
+        def _leg_cfg4():
+            # hipEvent-timed stages.  Degree 2 (27 coefficients) is what the reference implements; degree 3 (48
+            # coefficients, what configs[3] names) is the extension.  Roofline objects per SURVEY.md 8d:
+            #   B_fwd = 44 N + (64 + 8 C) V + (72 + 4 C) M + 12 P + 4 T,  B_bwd = (32 + 4 C) M + 24 P + (100 + 12 C) V + (44 + 4 C) N
+            # and for the dominant kernel of the backward (raster backward, S6): R (32 + 4 C) M + 24 P, W (28 + 4 C) V.
+            cfg4 = {}
+            try:
+                traffic4 = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            except (OSError, ValueError):
+                traffic4 = {}
+            for deg in (2, 3):
+                n4, W4, H4, _ = CONFIGS["cfg4"]
+                _, cam4, p4 = load("cfg4", sh_degree=deg)
+                r4, st4 = sized_renderer(p4, cam4, training=True)
+                img4, _ = r4.forward(*p4, cam4)
+                g4 = torch.sign(img4 - 0.5) / img4.numel()
 
-            def fwd_bwd4():
-                r4.forward(*p4, cam4)
-                r4.backward(g4)
+                def fwd_bwd4():
+                    r4.forward(*p4, cam4)
+                    r4.backward(g4)
 
-            settle(fwd_bwd4, 0.3)  # clocks at their steady state, as for the headline
-            fw = [r4.profile_forward(*p4, cam4) for _ in range(8)][2:]
-            bw = [r4.profile_backward(g4) for _ in range(8)][2:]
-            f_ms = statistics.median(x["total"] for x in fw)
-            b_ms = statistics.median(x["total"] for x in bw)
-            rb_ms = statistics.median(x["raster_bwd"] for x in bw)
-            C4 = 3 * (deg + 1) ** 2
-            P4 = (-(-W4 // 16) * 16) * (-(-H4 // 16) * 16)
-            V4, M4 = st4.visible, st4.pairs
-            b_fwd = 44 * n4 + (64 + 8 * C4) * V4 + (72 + 4 * C4) * M4 + 12 * P4 + 4 * (P4 // 256)
-            b_bwd = (32 + 4 * C4) * M4 + 24 * P4 + (100 + 12 * C4) * V4 + (44 + 4 * C4) * n4
-            b_rbw = (32 + 4 * C4) * M4 + 24 * P4 + (28 + 4 * C4) * V4
+                settle(fwd_bwd4, 0.3)  # clocks at their steady state, as for the headline
+                fw = [r4.profile_forward(*p4, cam4) for _ in range(8)][2:]
+                bw = [r4.profile_backward(g4) for _ in range(8)][2:]
+                f_ms = statistics.median(x["total"] for x in fw)
+                b_ms = statistics.median(x["total"] for x in bw)
+                rb_ms = statistics.median(x["raster_bwd"] for x in bw)
+                C4 = 3 * (deg + 1) ** 2
+                P4 = (-(-W4 // 16) * 16) * (-(-H4 // 16) * 16)
+                V4, M4 = st4.visible, st4.pairs
+                b_fwd = 44 * n4 + (64 + 8 * C4) * V4 + (72 + 4 * C4) * M4 + 12 * P4 + 4 * (P4 // 256)
+                b_bwd = (32 + 4 * C4) * M4 + 24 * P4 + (100 + 12 * C4) * V4 + (44 + 4 * C4) * n4
+                b_rbw = (32 + 4 * C4) * M4 + 24 * P4 + (28 + 4 * C4) * V4
 
-            def roof(b, ms, **kw):
-                gbs = b / (ms * 1e-3) / 1e9
-                return {"bound": "hbm", "algorithmic_bytes": int(b), "ms": round(ms, 4), "achieved": round(gbs, 1),
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), **kw}
+                def roof(b, ms, **kw):
+                    gbs = b / (ms * 1e-3) / 1e9
+                    return {"bound": "hbm", "algorithmic_bytes": int(b), "ms": round(ms, 4), "achieved": round(gbs, 1),
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), **kw}
 
-            tj = traffic4.get(f"cfg4_deg{deg}", {})
-            tk = tj.get("raster_backward_pixel_sh_kernel", {}) if tj.get("tile_pairs") == M4 else {}
-            tr_bw, busy_bw = tk.get("traffic_bytes"), tk.get("issue_busy")
-            cfg4[f"sh_degree_{deg}"] = {
-                "coefficients": C4, "visible": V4, "tile_pairs": M4,
-                "forward_ms": round(f_ms, 3), "backward_ms": round(b_ms, 3),
-                "raster_fwd_ms": round(statistics.median(x["raster"] for x in fw), 3),
-                "raster_bwd_ms": round(rb_ms, 3),
-                "project_bwd_ms": round(statistics.median(x["project_bwd"] for x in bw), 3),
-                "fwd_bwd_iters_per_s": round(1e3 / (f_ms + b_ms), 1),
-                "roofline_forward": roof(b_fwd, f_ms), "roofline_backward": roof(b_bwd, b_ms),
-                "roofline_fwd_bwd": roof(b_fwd + b_bwd, f_ms + b_ms),
-                "roofline_raster_backward_kernel": roof(
-                    b_rbw, rb_ms, kernel=f"raster_backward_pixel_sh_kernel<{C4}>", traffic=tr_bw,
-                    traffic_frac=None if tr_bw is None else round(tr_bw / (rb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                    issue_busy=busy_bw)}
-            del r4, p4, img4, g4
-            torch.cuda.empty_cache()
-        extra["cfg4_2p4M_sh_fwd_bwd"] = cfg4
+                tj = traffic4.get(f"cfg4_deg{deg}", {})
+                tk = tj.get("raster_backward_pixel_sh_kernel", {}) if tj.get("tile_pairs") == M4 else {}
+                tr_bw, busy_bw = tk.get("traffic_bytes"), tk.get("issue_busy")
+                cfg4[f"sh_degree_{deg}"] = {
+                    "coefficients": C4, "visible": V4, "tile_pairs": M4,
+                    "forward_ms": round(f_ms, 3), "backward_ms": round(b_ms, 3),
+                    "raster_fwd_ms": round(statistics.median(x["raster"] for x in fw), 3),
+                    "raster_bwd_ms": round(rb_ms, 3),
+                    "project_bwd_ms": round(statistics.median(x["project_bwd"] for x in bw), 3),
+                    "fwd_bwd_iters_per_s": round(1e3 / (f_ms + b_ms), 1),
+                    "roofline_forward": roof(b_fwd, f_ms), "roofline_backward": roof(b_bwd, b_ms),
+                    "roofline_fwd_bwd": roof(b_fwd + b_bwd, f_ms + b_ms),
+                    "roofline_raster_backward_kernel": roof(
+                        b_rbw, rb_ms, kernel=f"raster_backward_pixel_sh_kernel<{C4}>", traffic=tr_bw,
+                        traffic_frac=None if tr_bw is None else round(tr_bw / (rb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        issue_busy=busy_bw)}
+                del r4, p4, img4, g4
+                torch.cuda.empty_cache()
+            extra["cfg4_2p4M_sh_fwd_bwd"] = cfg4
+
+        guarded("cfg4", _leg_cfg4)
 
     # ---------------------------------------------------------------- zero-change integration mode
     if "compat" in legs and rank == 0 and world == 1:
-        # the reference's own per-frame call sequence (splatter.py:562-641: T x MAXP table, cumsum, attribute gathers,
-        # torch.sort, host syncs) over the drop-in gaussian / renderer modules, at BASELINE configs[1] and at the
-        # north-star target scene; next to it the fused frame path the headline is measured on
-        sys.path.insert(0, os.path.join(ROOT, "tools"))
-        from compat_fps import measure as compat_measure
+        def _leg_compat():
+            # the reference's own per-frame call sequence (splatter.py:562-641: T x MAXP table, cumsum, attribute gathers,
+            # torch.sort, host syncs) over the drop-in gaussian / renderer modules, at BASELINE configs[1] and at the
+            # north-star target scene; next to it the fused frame path the headline is measured on
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from compat_fps import measure as compat_measure
 
-        extra["compat_mode"] = {c: compat_measure(c, dev, frames=10 if c == "cfg5" else 20) for c in ("cfg2", "cfg5")}
-        torch.cuda.empty_cache()
+            extra["compat_mode"] = {c: compat_measure(c, dev, frames=10 if c == "cfg5" else 20) for c in ("cfg2", "cfg5")}
+            torch.cuda.empty_cache()
+
+        guarded("compat", _leg_compat)
     out["extra"] = extra
+    if leg_errors:
+        out["leg_errors"] = leg_errors
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)
     if "cpu" in legs and rank == 0 and world == 1:
-        import oracle  # the checker, timed here as the "port" baseline -- never on the product path
-        from gs_geometry import RayBasis, TileGrid
+        def _leg_cpu():
+            import oracle  # the checker, timed here as the "port" baseline -- never on the product path
+            from gs_geometry import RayBasis, TileGrid
 
-        scene, cam = head_scene, head_cam
-        grid = TileGrid(W, H, cam.focal_x, cam.focal_y)
-        rays = RayBasis.from_camera(cam.rot, cam.tran, grid.padded_height, grid.padded_width, cam.focal_x, cam.focal_y)
-        t0, frames = time.perf_counter(), 0
-        while time.perf_counter() - t0 < 10.0 or frames < 2:
-            oracle.render_forward(scene.pos, scene.quat, scene.scale, scene.opa, scene.rgb, cam.rot, cam.tran,
-                                  cam.near, W, H, cam.focal_x, cam.focal_y, 0.05, use_sh=use_sh, rays_o=rays.rays_o,
-                                  lefttop=rays.lefttop, vdx=rays.dx, vdy=rays.dy)
-            frames += 1
-        cpu_dt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": round(frames / cpu_dt, 4), "unit": "frames/s", "cores": oracle.num_threads(),
-                               "kind": "port",
-                               "sample": f"{frames} full forward frames of {args.config} (oracle/gs_oracle.c: cull + "
-                                         f"project and the (tile, depth) sort on one core, compositing over "
-                                         f"{oracle.num_threads()} OpenMP threads; {os.cpu_count()} host cores present)"}
+            scene, cam = head_scene, head_cam
+            grid = TileGrid(W, H, cam.focal_x, cam.focal_y)
+            rays = RayBasis.from_camera(cam.rot, cam.tran, grid.padded_height, grid.padded_width, cam.focal_x, cam.focal_y)
+            t0, frames = time.perf_counter(), 0
+            while time.perf_counter() - t0 < 10.0 or frames < 2:
+                oracle.render_forward(scene.pos, scene.quat, scene.scale, scene.opa, scene.rgb, cam.rot, cam.tran,
+                                      cam.near, W, H, cam.focal_x, cam.focal_y, 0.05, use_sh=use_sh, rays_o=rays.rays_o,
+                                      lefttop=rays.lefttop, vdx=rays.dx, vdy=rays.dy)
+                frames += 1
+            cpu_dt = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": round(frames / cpu_dt, 4), "unit": "frames/s", "cores": oracle.num_threads(),
+                                   "kind": "port",
+                                   "sample": f"{frames} full forward frames of {args.config} (oracle/gs_oracle.c: cull + "
+                                             f"project and the (tile, depth) sort on one core, compositing over "
+                                             f"{oracle.num_threads()} OpenMP threads; {os.cpu_count()} host cores present)"}
+
+        guarded("cpu", _leg_cpu)
 
     if rank == 0:
         print(json.dumps(out), flush=True)
