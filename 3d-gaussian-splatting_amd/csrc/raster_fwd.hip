@@ -119,7 +119,12 @@ raster_forward_kernel(RasterSrc S, RasterGeom G,
     static_assert(!(EXACT && FRAME), "the exact-exp flavour belongs to the reference API (gs_draw, fast = 0)");
     using SM = FwdSmem<CDIM>;
     constexpr int CH = SM::CH;
-    constexpr uint32_t GROUP = 4;  // Gaussians per ds_read_b128 of a field
+#ifndef GS_FWD_GROUP
+#define GS_FWD_GROUP 4
+#endif
+    // Gaussians per LDS read of a field (ds_read_b128: 4, ds_read_b64: 2 -- half the operand registers; A/B switch)
+    constexpr uint32_t GROUP = CDIM == 3 ? GS_FWD_GROUP : 4;
+    static_assert(GROUP == 4 || GROUP == 2, "GROUP");
     // the wave-uniform liveness test (3 VALU instructions + a branch) runs before every second group without SH;
     // with SH a Gaussian step is an order of magnitude longer and every group is tested
 #ifndef GS_FWD_LIVE_EVERY
@@ -338,28 +343,36 @@ raster_forward_kernel(RasterSrc S, RasterGeom G,
             }
             {
             constexpr uint32_t i4 = 0;
-            auto ld4 = [&](int q) { return *(const float4 *)__builtin_assume_aligned(&sm.f[buf][q][i + i4], 16); };
-            const float4 X = ld4(SM::X), Y = ld4(SM::Y), A4 = ld4(SM::A), B4 = ld4(SM::B), C4 = ld4(SM::C);
-            const float4 O4 = ld4(SM::NLOP);
-            float4 DH4, DL4;
+            struct Vg {
+                float v[GROUP];
+            };
+            auto ld4 = [&](int q) {
+                Vg r;
+                if constexpr (GROUP == 4) {
+                    const float4 t = *(const float4 *)__builtin_assume_aligned(&sm.f[buf][q][i + i4], 16);
+                    r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+                } else {
+                    const float2 t = *(const float2 *)__builtin_assume_aligned(&sm.f[buf][q][i + i4], 8);
+                    r.v[0] = t.x; r.v[1] = t.y;
+                }
+                return r;
+            };
+            const Vg X = ld4(SM::X), Y = ld4(SM::Y), A4 = ld4(SM::A), B4 = ld4(SM::B), C4 = ld4(SM::C);
+            const Vg O4 = ld4(SM::NLOP);
+            Vg DH4 = {}, DL4 = {};
             if constexpr (EXACT) {
                 DH4 = ld4(SM::DH);
                 DL4 = ld4(SM::DL);
             }
-            float4 R4, G4, L4;
+            Vg R4 = {}, G4 = {}, L4 = {};
             if constexpr (CDIM == 3) {
                 R4 = ld4(SM::R);
                 G4 = ld4(SM::G);
                 L4 = ld4(SM::BL);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float gx = u == 0 ? X.x : u == 1 ? X.y : u == 2 ? X.z : X.w;
-                const float gy = u == 0 ? Y.x : u == 1 ? Y.y : u == 2 ? Y.z : Y.w;
-                const float cA = u == 0 ? A4.x : u == 1 ? A4.y : u == 2 ? A4.z : A4.w;
-                const float cB = u == 0 ? B4.x : u == 1 ? B4.y : u == 2 ? B4.z : B4.w;
-                const float cC = u == 0 ? C4.x : u == 1 ? C4.y : u == 2 ? C4.z : C4.w;
-                const float nlop = u == 0 ? O4.x : u == 1 ? O4.y : u == 2 ? O4.z : O4.w;
+            for (int u = 0; u < (int)GROUP; ++u) {
+                const float gx = X.v[u], gy = Y.v[u], cA = A4.v[u], cB = B4.v[u], cC = C4.v[u], nlop = O4.v[u];
                 // q + nlop = (C dy - B dx) dy + (A dx^2 + nlop): dx is shared by the lane's four pixels
                 const float dx = px - gx;
                 const float bdx = cB * dx;
@@ -372,8 +385,7 @@ raster_forward_kernel(RasterSrc S, RasterGeom G,
                         // exp(double(-(d x x - (b + c) x y + a y y)) / (2 det + 1e-14)) rounded to float: the reference's
                         // `fast = 0` flavour (gaussian.cu:922-923), float products in its order (no contraction), then
                         // the double division and the double exponential it pays per pixel as well
-                        const double den = (double)(u == 0 ? DH4.x : u == 1 ? DH4.y : u == 2 ? DH4.z : DH4.w) +
-                                           (double)(u == 0 ? DL4.x : u == 1 ? DL4.y : u == 2 ? DL4.z : DL4.w);
+                        const double den = (double)DH4.v[u] + (double)DL4.v[u];
                         auto exact_alpha = [&](float y) {
                             const float t1 = __fmul_rn(__fmul_rn(cC, dx), dx);   // d x x
                             const float t2 = __fmul_rn(__fmul_rn(cB, dx), y);    // (b + c) x y
@@ -402,9 +414,9 @@ raster_forward_kernel(RasterSrc S, RasterGeom G,
                     else
                         w = al * T[h];
                     if constexpr (CDIM == 3) {
-                        cr[h] = pk_fma(splat(u == 0 ? R4.x : u == 1 ? R4.y : u == 2 ? R4.z : R4.w), w, cr[h]);
-                        cg[h] = pk_fma(splat(u == 0 ? G4.x : u == 1 ? G4.y : u == 2 ? G4.z : G4.w), w, cg[h]);
-                        cb[h] = pk_fma(splat(u == 0 ? L4.x : u == 1 ? L4.y : u == 2 ? L4.z : L4.w), w, cb[h]);
+                        cr[h] = pk_fma(splat(R4.v[u]), w, cr[h]);
+                        cg[h] = pk_fma(splat(G4.v[u]), w, cg[h]);
+                        cb[h] = pk_fma(splat(L4.v[u]), w, cb[h]);
                     } else {
                         const float *co = sm.sh[buf][i + i4 + u];
                         f2 v0 = {0.f, 0.f}, v1 = {0.f, 0.f}, v2 = {0.f, 0.f};

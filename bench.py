@@ -116,6 +116,12 @@ def main():
         log("[bench] no RANK in the environment: " + " ".join(cmd))
         sys.exit(subprocess.call(cmd, env=env))
 
+    # stdout carries exactly ONE line, the JSON: whatever libraries print to file descriptor 1 while the benchmark runs
+    # (RCCL's version banner, for one) is sent to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -622,7 +628,7 @@ def main():
         guarded("cpu", _leg_cpu)
 
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
 
