@@ -208,10 +208,17 @@ __device__ __forceinline__ void disperse_levels(uint64_t *a, uint32_t n, uint32_
 // `nthreads` threads with index `tid` cooperate (a wave: n <= 512, sync = wave barrier; the 256-thread workgroup:
 // n <= 2048, sync = __syncthreads); cnt: nthreads x 8 + 1 words, wl: 1 + 2 x 128 words, red: 16 words of LDS.
 #define BUCKET_SMALL 16u
+// `nsplit` < n (round 3): a[0 .. nsplit) and a[nsplit .. n) are TWO lists (adjacent tiles) sorted by one call -- every list
+// gets its own share of the buckets and its own depth range, all buckets of the first list come before those of the
+// second, so the result is the first list sorted, then the second list sorted, at the same positions.  One call for
+// two lists of ~850 keys instead of two calls halves the fixed cost (six workgroup barriers, the counters' clear and
+// scan, eight-way unrolled loops that were less than half full).
 template <typename Sync, typename Store>
 __device__ __forceinline__ void bucket_sort_store(uint64_t *a, uint32_t n, uint32_t *cnt, uint32_t *wl, uint32_t *red,
-                                                  uint32_t tid, uint32_t nthreads, Sync sync, Store store) {
+                                                  uint32_t tid, uint32_t nthreads, Sync sync, Store store,
+                                                  uint32_t nsplit = 0xffffffffu) {
     constexpr int R = 8;
+    if (nsplit >= n || nsplit == 0) nsplit = n;  // a single list
     const int lane = tid & 63;
     const uint32_t wave = tid >> 6, nwaves = nthreads >> 6;
     const uint32_t per = (n + nthreads - 1) / nthreads;                 // <= 8
@@ -223,15 +230,21 @@ __device__ __forceinline__ void bucket_sort_store(uint64_t *a, uint32_t n, uint3
     };
     // ---- keys to registers, range of the depth bits
     uint64_t k[R];
-    uint32_t dmin = 0xffffffffu, dmax = 0;
+    const bool two = nsplit < n;  // uniform
+    uint32_t dmin = 0xffffffffu, dmax = 0, dmin1 = 0xffffffffu, dmax1 = 0;  // (.., ..1): the second list
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const uint32_t i = tid + r * nthreads;
         k[r] = i < n ? a[i] : KEY_INF;
         if (i < n) {
             const uint32_t d = (uint32_t)(k[r] >> 32);
-            dmin = d < dmin ? d : dmin;
-            dmax = d > dmax ? d : dmax;
+            if (i < nsplit) {
+                dmin = d < dmin ? d : dmin;
+                dmax = d > dmax ? d : dmax;
+            } else {
+                dmin1 = d < dmin1 ? d : dmin1;
+                dmax1 = d > dmax1 ? d : dmax1;
+            }
         }
     }
 #pragma unroll
@@ -239,6 +252,11 @@ __device__ __forceinline__ void bucket_sort_store(uint64_t *a, uint32_t n, uint3
         const uint32_t x = __shfl_xor(dmin, o, 64), y = __shfl_xor(dmax, o, 64);
         dmin = x < dmin ? x : dmin;
         dmax = y > dmax ? y : dmax;
+        if (two) {
+            const uint32_t x1 = __shfl_xor(dmin1, o, 64), y1 = __shfl_xor(dmax1, o, 64);
+            dmin1 = x1 < dmin1 ? x1 : dmin1;
+            dmax1 = y1 > dmax1 ? y1 : dmax1;
+        }
     }
     for (uint32_t c = tid; c <= B; c += nthreads) cnt[c] = 0;
     if (tid == 0) wl[0] = 0;
@@ -246,6 +264,8 @@ __device__ __forceinline__ void bucket_sort_store(uint64_t *a, uint32_t n, uint3
         if (lane == 0) {
             red[wave] = dmin;
             red[4 + wave] = dmax;
+            red[8 + wave] = dmin1;
+            red[12 + wave] = dmax1;
         }
         sync();
 #pragma unroll
@@ -253,20 +273,37 @@ __device__ __forceinline__ void bucket_sort_store(uint64_t *a, uint32_t n, uint3
             if (w < nwaves) {
                 dmin = red[w] < dmin ? red[w] : dmin;
                 dmax = red[4 + w] > dmax ? red[4 + w] : dmax;
+                dmin1 = red[8 + w] < dmin1 ? red[8 + w] : dmin1;
+                dmax1 = red[12 + w] > dmax1 ? red[12 + w] : dmax1;
             }
         }
+        // (red[8 ..] is written again by the scan below -- behind the barrier that follows the ranking loop)
     } else {
         sync();
     }
-    // ---- bucket of every key, rank inside the bucket in arrival order
-    const float scale = (float)B / ((float)(dmax - dmin) + 1.0f);
+    // ---- bucket of every key, rank inside the bucket in arrival order.  Two lists: buckets [0, B0) belong to the
+    // first, [B0, B) to the second, shared out by their lengths
+    uint32_t B0 = B;
+    if (two) {
+        B0 = (uint32_t)(((uint64_t)B * nsplit) / n);
+        B0 = B0 < 1 ? 1 : (B0 > B - 1 ? B - 1 : B0);
+    }
+    const float scale = (float)B0 / ((float)(dmax - dmin) + 1.0f);
+    const float scale1 = two ? (float)(B - B0) / ((float)(dmax1 - dmin1) + 1.0f) : 0.f;
     uint32_t bk[R], rk[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         bk[r] = rk[r] = 0;
-        if (tid + r * nthreads < n) {
-            const uint32_t b = (uint32_t)((float)((uint32_t)(k[r] >> 32) - dmin) * scale);
-            bk[r] = b < B - 1 ? b : B - 1;
+        const uint32_t i = tid + r * nthreads;
+        if (i < n) {
+            const uint32_t d = (uint32_t)(k[r] >> 32);
+            if (i < nsplit) {
+                const uint32_t b = (uint32_t)((float)(d - dmin) * scale);
+                bk[r] = b < B0 - 1 ? b : B0 - 1;
+            } else {
+                const uint32_t b = B0 + (uint32_t)((float)(d - dmin1) * scale1);
+                bk[r] = b < B - 1 ? b : B - 1;
+            }
             rk[r] = atomicAdd(&cnt[bk[r]], 1u);
         }
     }
@@ -760,6 +797,9 @@ __global__ void __launch_bounds__(256, STRIP_SORT_WPE) strip_sort_kernel(
         if (valid && nq > (uint32_t)GS_DENSE_AVG) atomicMax(longest, (unsigned long long)nq);
     }
     if (total4 == 0) return;  // uniform
+#ifdef GS_DIAG_STRIP_NO_PLACE  // timing experiments only (tools/ab_variants.py): wrong results
+    return;
+#endif
     // ---- 2. place (depth_bits << 32 | gaussian) and 3. sort.  A half strip of up to CAP pairs holds its four lists in
     // LDS side by side (short lists are then sorted by one wave each, concurrently); otherwise the lists take turns
     // in the LDS window, each placed from the entries in registers and sorted by the workgroup; a single list beyond
@@ -884,6 +924,24 @@ __global__ void __launch_bounds__(256, STRIP_SORT_WPE) strip_sort_kernel(
         // list q at the start of the window, list q + 1 (if paired) behind it
         place(pair ? 3u << q : 1u << q, 0, q == 0 ? n : 0, q == 1 ? n : 0, q == 2 ? n : 0, true, true);
         __syncthreads();
+#ifdef GS_DIAG_STRIP_NO_SORT  // timing experiments only (tools/ab_variants.py): wrong results
+        for (uint32_t i = threadIdx.x; i < n + (pair ? n2 : 0); i += 256) ids[start4[q] + i] = (uint32_t)s_a[i];
+        if (pair) ++q;
+        continue;
+#endif
+        if (pair && n + n2 > 256) {
+            // both lists by ONE distribution sort (bucket_sort_store, nsplit): adjacent tiles, adjacent output ranges
+            const uint32_t start = start4[q];
+            const uint64_t tile = tile0 + q;
+            bucket_sort_store(s_a, n + n2, s_bcnt, s_wl[0], s_red, threadIdx.x, 256u, block_sync,
+                              [&](uint32_t i, uint64_t v) {
+                                  ids[start + i] = (uint32_t)v;
+                                  if (keys) keys[start + i] = ((tile + (i >= n ? 1u : 0u)) << 32) | (v >> 32);
+                              },
+                              n);
+            ++q;
+            continue;
+        }
         sort_store_by_workgroup(s_a, n, start4[q], tile0 + q);
         if (pair) {
             __syncthreads();
