@@ -15,6 +15,7 @@
 #include "gs_common.h"
 #include "gs_frame_layout.h"
 #include "strip_common.h"
+#include "tile_bin_common.h"
 
 namespace {
 
@@ -546,6 +547,55 @@ __global__ void __launch_bounds__(STRIP_THREADS) frame_project_count_kernel(
     }
 }
 
+// ---------------------------------------------------------------- S1 + B1 fused (table variant of sort_mode 2: small scenes)
+// The same fusion for the table variant, which small scenes take: a frame of 10,000 Gaussians is six dependent launches
+// of ~7 us each, so the launch that re-reads the rectangles to histogram them per (slice, tile) is worth removing for
+// its latency alone.  One workgroup per slice (tile_bin.hip's slices: a multiple of 256 Gaussians), one LDS counter per
+// tile; same outputs as frame_project_kernel + bin_count_kernel.
+template <bool DIST>
+__global__ void __launch_bounds__(BIN_THREADS) frame_project_bin_count_kernel(
+    const float *__restrict__ pos, const float4 *__restrict__ quat, const float *__restrict__ scale,
+    const float *__restrict__ opa, const float *__restrict__ rgb, int64_t n, ProjectParams P,
+    float4 *__restrict__ rec_geom, uint4 *__restrict__ rects, GsDistCull D, uint32_t per_block, uint32_t T,
+    uint32_t *__restrict__ table, uint32_t *__restrict__ slice_pairs, uint32_t *__restrict__ slice_vis) {
+    extern __shared__ uint32_t s_tile_hist[];  // [T]
+    __shared__ uint32_t s_acc[2];
+    const uint32_t slice = slice_of_block(blockIdx.x, gridDim.x);
+    const int64_t g0 = (int64_t)slice * per_block;
+    auto in_range = [&](uint32_t i) { return i < per_block && g0 + i < n; };
+    RawGaussian cur = {}, nxt = {};
+    if (in_range(threadIdx.x)) cur = load_raw(pos, quat, scale, opa, rgb, g0 + threadIdx.x, P.color_dim);
+    for (uint32_t t = threadIdx.x; t < T; t += BIN_THREADS) s_tile_hist[t] = 0;
+    if (threadIdx.x < 2) s_acc[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t acc_cnt = 0, acc_vis = 0;
+    for (uint32_t base = 0; base < per_block; base += BIN_THREADS) {  // uniform trip count
+        const uint32_t i = base + threadIdx.x;
+        if (in_range(i + BIN_THREADS)) nxt = load_raw(pos, quat, scale, opa, rgb, g0 + i + BIN_THREADS, P.color_dim);
+        uint4 rc = make_uint4(0, 0, 0, 0);
+        uint32_t vis = 0;
+        float2 cxy = make_float2(0.f, 0.f);
+        if (in_range(i)) rc = project_one(cur, g0 + i, P, rec_geom, nullptr, rects, vis, cxy);
+        acc_cnt += rc.w;
+        acc_vis += vis;
+        walk_rect<DIST>(rc, g0 + i, P.ntx, cxy, D, [&](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&s_tile_hist[tile], 1u); });
+        cur = nxt;
+    }
+    acc_cnt = gs_wave_sum_u32(acc_cnt);
+    acc_vis = gs_wave_sum_u32(acc_vis);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&s_acc[0], acc_cnt);
+        atomicAdd(&s_acc[1], acc_vis);
+    }
+    __syncthreads();
+    uint32_t *row = table + (size_t)slice * T;
+    for (uint32_t t = threadIdx.x; t < T; t += BIN_THREADS) row[t] = s_tile_hist[t];
+    if (threadIdx.x == 0) {
+        slice_pairs[slice] = s_acc[0];
+        slice_vis[slice] = s_acc[1];
+    }
+}
+
 // ---------------------------------------------------------------- fused frame stage B2
 // rows[pair][12|36|56] = (dx, dy, da, db, dc, dd, dopa, colour grads..) written by the raster backward
 // in emission order: Gaussian g owns rows [pair_offsets[g], +tiles_touched[g]).  They are summed
@@ -970,6 +1020,33 @@ int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t strea
         else
             GS_LAUNCH_PROJECT_COUNT(false);
 #undef GS_LAUNCH_PROJECT_COUNT
+        GS_CHECK_LAUNCH();
+        return 0;
+    }
+    if (gs_frame_fused_table_count(f)) {
+        gs_frame_geom G = gs_frame_geometry(f);
+        GsDistCull D = {(float)(G.padW / 2), (float)(G.padH / 2), f->focal_x, f->focal_y, f->thresh};
+        static std::mutex attr_mu2;
+        static std::atomic<uint64_t> attr_done2{0};
+        int dev = 0;
+        GS_HIP(hipGetDevice(&dev));
+        if (dev < 64 && !((attr_done2.load(std::memory_order_acquire) >> dev) & 1)) {
+            std::lock_guard<std::mutex> lock(attr_mu2);
+            for (const void *fn : {(const void *)frame_project_bin_count_kernel<false>, (const void *)frame_project_bin_count_kernel<true>})
+                GS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, GS_BIN_MAX_TILES * 4));
+            attr_done2.fetch_or(1ull << dev, std::memory_order_release);
+        }
+        const uint32_t per_block = bin_per_block(f->N), B = (uint32_t)gs_div_up(f->N, per_block);
+        const uint32_t T = (uint32_t)G.n_tiles;
+#define GS_LAUNCH_PROJECT_BIN(DIST)                                                                                    \
+    hipLaunchKernelGGL(frame_project_bin_count_kernel<DIST>, dim3(B), dim3(BIN_THREADS), sizeof(uint32_t) * T, stream, \
+                       f->pos, (const float4 *)f->quat, f->scale, f->opa, f->rgb, f->N, P, ws.rec_geom, ws.rects, D,   \
+                       per_block, T, ws.bin_table, ws.slice_pairs, ws.slice_vis)
+        if (f->tile_culling_method == 0)
+            GS_LAUNCH_PROJECT_BIN(true);
+        else
+            GS_LAUNCH_PROJECT_BIN(false);
+#undef GS_LAUNCH_PROJECT_BIN
         GS_CHECK_LAUNCH();
         return 0;
     }

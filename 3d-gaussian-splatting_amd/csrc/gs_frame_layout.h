@@ -119,6 +119,13 @@ static inline bool gs_frame_uses_strips(const gs_frame *f) {
 #define GS_FUSED_PROJECT_COUNT 1  // A/B switch (tools/ab_variants.py)
 #endif
 static inline bool gs_frame_fused_count(const gs_frame *f) { return GS_FUSED_PROJECT_COUNT && gs_frame_uses_strips(f); }
+// Table variant (small scenes: a frame is a chain of dependent launches of ~7 us each): the per-(slice, tile) count
+// (bin_count_kernel) is taken inside the project stage as well -- five launches per frame instead of six.
+static inline bool gs_frame_fused_table_count(const gs_frame *f) {
+    const int ntx = (f->width + GS_TILE - 1) / GS_TILE, nty = (f->height + GS_TILE - 1) / GS_TILE;
+    return GS_FUSED_PROJECT_COUNT && f->sort_mode == 2 && !gs_frame_uses_strips(f) && !(f->flags & GS_FRAME_SLICE_SORT) &&
+           ntx * nty <= GS_BIN_MAX_TILES;
+}
 
 // floats per per-pair gradient row: (dx, dy, da, db, dc, dd, dopa) + colour grads, padded to float4s
 // floats per (tile, Gaussian) gradient row: 7 geometry/opacity sums + color_dim colour sums, rounded up to float4s

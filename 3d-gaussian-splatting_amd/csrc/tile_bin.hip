@@ -40,50 +40,9 @@
 
 #include "gs_common.h"
 #include "gs_frame_layout.h"
+#include "tile_bin_common.h"
 
 namespace {
-
-#ifndef BIN_THREADS
-#define BIN_THREADS 1024
-#endif
-#define BIN_SOLO 16  // rectangles up to this many tiles are walked by their own lane
-
-// Walks the rectangle of every Gaussian of this workgroup's slice and calls fn(tile, gaussian, depth_bits).
-// Small rectangles are handled by their own lane, large ones by the whole wave (one screen-filling
-// Gaussian must not serialise 64 lanes behind it).
-// DIST ("dist" tile culling): the rectangle is only the bounding square of the disc of listed tiles; a tile is
-// listed iff gs_dist_listed says so for the Gaussian's centre (cxy).
-template <bool DIST, typename Fn>
-__device__ __forceinline__ void walk_rect(const uint4 rc, int64_t g, uint32_t ntx, float2 cxy, const GsDistCull &D,
-                                          Fn fn) {
-    const int lane = threadIdx.x & 63;
-    const uint32_t cnt = rc.w, dbits = rc.z;
-    const uint32_t y0 = rc.x & 0xffff, x0 = rc.y & 0xffff, x1 = rc.y >> 16;
-    const uint32_t wdt = x1 - x0;
-    if (cnt && cnt <= BIN_SOLO) {
-        uint32_t ix = x0, iy = y0;
-        for (uint32_t k = 0; k < cnt; ++k) {
-            if (!DIST || gs_dist_listed(cxy.x, cxy.y, ix, iy, D)) fn(ix + iy * ntx, (uint32_t)g, dbits);
-            if (++ix == x1) {
-                ix = x0;
-                ++iy;
-            }
-        }
-    }
-    unsigned long long big = __ballot(cnt > BIN_SOLO);
-    while (big) {
-        const int src = __ffsll((long long)big) - 1;
-        big &= big - 1;
-        const uint32_t c = __shfl(cnt, src, 64), d = __shfl(dbits, src, 64);
-        const uint32_t sx0 = __shfl(x0, src, 64), sy0 = __shfl(y0, src, 64), sw = __shfl(wdt, src, 64);
-        const float spx = DIST ? __shfl(cxy.x, src, 64) : 0.f, spy = DIST ? __shfl(cxy.y, src, 64) : 0.f;
-        const uint32_t id = (uint32_t)(g - lane + src);
-        for (uint32_t k = lane; k < c; k += 64) {
-            const uint32_t ix = sx0 + k % sw, iy = sy0 + k / sw;
-            if (!DIST || gs_dist_listed(spx, spy, ix, iy, D)) fn(ix + iy * ntx, id, d);
-        }
-    }
-}
 
 // The Gaussians of a slice are visited BIN_THREADS at a time; the records of the next BIN_PF visits are requested
 // before the current ones are walked.  (Without it every visit exposed a full memory round trip: ten dependent
@@ -91,17 +50,6 @@ __device__ __forceinline__ void walk_rect(const uint4 rc, int64_t g, uint32_t nt
 #ifndef BIN_PF
 #define BIN_PF 4
 #endif
-
-// Workgroups are dealt round-robin to the 8 XCDs (each with its own L2), while the output region of a
-// tile is laid out in slice order.  Giving XCD x a CONTIGUOUS range of slices makes the 8-byte pair
-// stores that fill one 128-byte line come from one L2 instead of eight, so lines are merged in L2
-// instead of being written back as eight partial sectors.
-__device__ __forceinline__ uint32_t slice_of_block(uint32_t blk, uint32_t B) {
-    const uint32_t xcd = blk & 7, idx = blk >> 3;
-    uint32_t first = 0;
-    for (uint32_t x = 0; x < xcd; ++x) first += (B - x + 7) >> 3;  // workgroups that landed on XCD x
-    return first + idx;
-}
 
 // ---------------------------------------------------------------- B1
 template <bool DIST>
@@ -596,12 +544,6 @@ __global__ void __launch_bounds__(256) bin_totals_kernel(const uint32_t *__restr
 
 }  // namespace
 
-// Gaussians per slice: a multiple of 256 (the project stage's block) with at most GS_BIN_SLICES slices.
-static uint32_t bin_per_block(int64_t N) {
-    const int64_t per = gs_div_up(gs_div_up(N > 0 ? N : 1, GS_BIN_SLICES), 256) * 256;
-    return (uint32_t)per;
-}
-
 int gs_stage_tile_bin(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream) {
     gs_frame_geom G = gs_frame_geometry(f);
     const gs_bin_plan plan = gs_bin_plan_for(f->N, f->max_pairs, G.n_tiles, (f->flags & GS_FRAME_SLICE_SORT) != 0);
@@ -655,10 +597,12 @@ int gs_stage_tile_bin(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stre
     if (n_bands > (uint32_t)G.nty) n_bands = (uint32_t)G.nty;
 #define GS_LAUNCH_BIN(DIST)                                                                                            \
     do {                                                                                                               \
-        hipLaunchKernelGGL(bin_count_kernel<DIST>, dim3(B), dim3(BIN_THREADS), lds, stream, ws.rects, ws.rec_geom, D,  \
-                           f->N, per_block, T, (uint32_t)G.ntx, ws.bin_table, ws.block_sums, ws.block_vis,             \
-                           ws.slice_pairs, ws.slice_vis);                                                              \
-        GS_CHECK_LAUNCH();                                                                                             \
+        if (!gs_frame_fused_table_count(f)) { /* else: counted by the project stage (frame_project_bin_count_kernel) */ \
+            hipLaunchKernelGGL(bin_count_kernel<DIST>, dim3(B), dim3(BIN_THREADS), lds, stream, ws.rects, ws.rec_geom, \
+                               D, f->N, per_block, T, (uint32_t)G.ntx, ws.bin_table, ws.block_sums, ws.block_vis,      \
+                               ws.slice_pairs, ws.slice_vis);                                                          \
+            GS_CHECK_LAUNCH();                                                                                         \
+        }                                                                                                              \
         hipLaunchKernelGGL(bin_colscan_kernel, dim3((unsigned)gs_div_up(T, 64)), dim3(256), 0, stream, ws.bin_table,   \
                            B, T, ws.tile_count);                                                                       \
         GS_CHECK_LAUNCH();                                                                                             \

@@ -37,7 +37,7 @@ SOURCES = {
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall",
           "-Wno-unused-function", "-munsafe-fp-atomics",
           *os.environ.get("GS_EXTRA_HIPCC_FLAGS", "").split()]  # experiments only (-D switches)
-HEADERS = ["gs_common.h", "gs_frame_layout.h", "raster_common.h", "strip_common.h", os.path.join("..", "..", "include", "gs_abi.h")]
+HEADERS = ["gs_common.h", "gs_frame_layout.h", "raster_common.h", "strip_common.h", "tile_bin_common.h", os.path.join("..", "..", "include", "gs_abi.h")]
 
 
 def _stale(target: str, deps) -> bool:
