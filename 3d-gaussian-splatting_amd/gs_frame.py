@@ -103,6 +103,34 @@ class FrameRenderer:
 
     # ------------------------------------------------------------------ frame descriptor
     def _describe(self, pos, quat, scale, opa, rgb, camera, training) -> _lib.GsFrame:
+        # A viewer or a benchmark renders the same tensors from the same camera object again and again: the descriptor
+        # of the previous call is reused as long as nothing it was built from has changed (tensor identities and
+        # storage, camera object, renderer settings) -- the validation below, ~40 ctypes stores and a library call cost
+        # ~15 us of host time per frame otherwise, which is what bounds small scenes with several frames in flight.
+        # (the camera enters by VALUE: a viewer may move one Camera object in place)
+        ck = (int(camera.width), int(camera.height), float(camera.focal_x), float(camera.focal_y),
+              float(camera.near), np.asarray(camera.rot, np.float32).tobytes(),
+              np.asarray(camera.tran, np.float32).tobytes())
+        key = (ck, pos.data_ptr(), quat.data_ptr(), scale.data_ptr(), opa.data_ptr(), rgb.data_ptr(),
+               pos.shape[0], rgb.shape[-1] if rgb.dim() == 2 else 1, bool(training), self.max_pairs, self.sort_mode,
+               self.tile_culling_method, self.tile_culling_dist_thresh, self.thresh, self.scale_activation,
+               self.emit_sorted_keys, self.slice_sort, self.table_bin, self.force_strips, self.serial_long_lists,
+               self.long_lists, self._long_lists_seen, self._ws.data_ptr() if self._ws is not None else 0)
+        cached = getattr(self, "_desc_cache", None)
+        if cached is not None and cached[0] == key:
+            f = _lib.GsFrame()
+            C.memmove(C.byref(f), C.byref(cached[1]), C.sizeof(_lib.GsFrame))
+            self._grid = cached[3]
+            return f
+        f = self._describe_uncached(pos, quat, scale, opa, rgb, camera, training)
+        # (the key is taken again: building the descriptor may have (re)allocated the workspace)
+        key = key[:-1] + (self._ws.data_ptr(),)
+        keep = _lib.GsFrame()
+        C.memmove(C.byref(keep), C.byref(f), C.sizeof(_lib.GsFrame))
+        self._desc_cache = (key, keep, None, self._grid)
+        return f
+
+    def _describe_uncached(self, pos, quat, scale, opa, rgb, camera, training) -> _lib.GsFrame:
         n = int(pos.shape[0])
         color_dim = int(rgb.shape[1]) if rgb.dim() == 2 else 1
         if color_dim not in (3, 27, 48):  # rgb logits, SH degree 2 (the reference's), SH degree 3 (extension)
