@@ -34,6 +34,9 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
+/* 4 (round 3): GS_FRAME_STRIP_BIN + the size-based choice of the binning variant, gs_frame_binning_variant,
+ * gs_frame_debug_rects (records of culled Gaussians are no longer written), gs_frame_overflow_flag,
+ * gs_adam_step_sharded, `fast = 0` of gs_draw / gs_draw_backward honoured.  3: gs_frame.async / flags. */
 #define GS_ABI_VERSION 4
 
 #define GS_E_INVALID (-1)   /* bad argument (null pointer, negative size, bad enum)   */
@@ -104,7 +107,10 @@ int gs_gather_gaussians(const int32_t *tile_n_point_accum, const int32_t *tile_g
 /* bindings.cpp:46 `draw` -> gaussian.cu:806-1043.
  * pos [M,3] (z ignored), rgb [M,D] (D = 3, or 27 when use_sh_coeff), opa [M], cov [M,2,2],
  * tile_n_point_accum [T+1] int32, res [h,w,3] with h,w the PADDED size (multiples of 16).
- * rays_o/lefttop_pos/vec_dx/vec_dy: device float[3], only read when use_sh_coeff. */
+ * rays_o/lefttop_pos/vec_dx/vec_dy: device float[3], only read when use_sh_coeff.
+ * fast != 0: the Gaussian's value through the hardware exponential on a conic hoisted out of the pixel loop (the
+ * reference's __expf flavour, gaussian.cu:920); fast == 0: the reference's exp() flavour (gaussian.cu:922-923): the
+ * numerator as float products in its order, a double division by 2 det + 1e-14 and a double exp per pixel. */
 int gs_draw(const float *pos, const float *rgb, const float *opa, const float *cov,
             const int32_t *tile_n_point_accum, float *res, int32_t h, int32_t w, int64_t M,
             float focal_x, float focal_y, int weight_normalize, int sigmoid, int fast,
