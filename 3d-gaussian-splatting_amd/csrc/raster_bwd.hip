@@ -738,7 +738,10 @@ raster_backward_pixel_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
     enum { FX, FY, FA, FB, FC, FOPA, FC0, FC1, FC2, NFLD };  // FC0..2: the Gaussian's colour (CDIM == 3 only)
     __shared__ float s_g[NFLD][64];
     __shared__ uint32_t s_id[64];          // FRAME: Gaussian id; else index of the pair in the sorted arrays
-    __shared__ float s_red[16 * 65];       // [row][lane] partial sums of the current Gaussian, 16 rows at a time (rows padded to 65)
+    // [row][lane] partial sums of the current Gaussian, 16 rows at a time (rows padded to 65).  rgb colours have only 10
+    // rows: 2.6 instead of 4.2 KiB, 7.6 KiB of LDS per wave in all -- five resident waves per SIMD instead of four
+    // (same-box A/B, round 3: 0.377 -> 0.359 ms at cfg2, 0.547 -> 0.515 ms at 2.4 M Gaussians)
+    __shared__ float s_red[(NROW < 16 ? NROW : 16) * 65];
     __shared__ float s_part[NROW][4];      // quarter-row sums of the first reduction level
     __shared__ float s_tot[64][8];         // geometry sums per Gaussian (Sx Sy Sxx Sxy Syy Sq)
     __shared__ float *s_row[64];           // where Gaussian i's gradient row starts (nullptr: no row)
