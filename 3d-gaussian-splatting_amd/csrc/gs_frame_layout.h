@@ -51,21 +51,23 @@ static inline gs_bin_plan gs_bin_plan_for(int64_t N, int64_t max_pairs, int n_ti
 #endif
 #define GS_STRIP_ID_BITS 26   // an entry keeps the Gaussian index in 26 bits: scenes beyond 2^26 take the table variant
 #define GS_STRIP_MAX 8192     // strips per frame the LDS histograms are sized for
-// Dense frames (capacity above GS_DENSE_AVG pairs per tile on average) launch the extra kernels for long lists: the
-// big-list sort (tile_sort.hip) and the segmented compositing of tiles that are still alive after GS_LONG_MIN
-// Gaussians (raster_fwd.hip); other frames save those launches.
-#define GS_DENSE_AVG 1024
+// Frames with long tile lists launch the extra kernels for them: the big-list sort (tile_sort.hip) and the segmented
+// compositing of tiles that are still alive after GS_LONG_MIN Gaussians (raster_fwd.hip); other frames save those
+// launches (~25 us of idle grids at 1080p).  The caller asks for them with GS_FRAME_LONG_LISTS, normally once the
+// longest-list statistic of an earlier frame (gs_frame_longest_list_async) exceeded the LDS window; a frame WITHOUT the
+// flag is still correct whatever its lists are (strip_sort_kernel sorts a long list itself, the tile's own wave
+// composites all of it), only slower on such lists.  The CAPACITY of the workspace plays no part: sizing it up never
+// changes the kernel path or the rounding.
+#define GS_LONGEST_MIN 1024   // the longest-list statistic only reports lists beyond this (shorter ones read as 0)
 #ifndef GS_LONG_MIN
 #define GS_LONG_MIN 2048      // Gaussians a tile's own wave composites before the rest of its list is cut into segments
 #endif
 #ifndef GS_SEG_LEN
 #define GS_SEG_LEN 1024       // Gaussians per segment (measured on a 100,000-Gaussian pile: 4096 / 2048: 1.02 ms, 2048 / 1024: 0.59 ms)
 #endif
-static inline bool gs_frame_is_dense(int64_t max_pairs, int n_tiles) { return max_pairs / (n_tiles > 0 ? n_tiles : 1) > GS_DENSE_AVG; }
-// the long-list kernels run in dense frames and wherever the caller asks for them (GS_FRAME_LONG_LISTS: it has seen a
-// long list in an earlier frame, gs_frame_longest_list_async)
 static inline bool gs_frame_long_lists(const gs_frame *f, int n_tiles) {
-    return gs_frame_is_dense(f->max_pairs, n_tiles) || (f->flags & GS_FRAME_LONG_LISTS) != 0;
+    (void)n_tiles;
+    return (f->flags & GS_FRAME_LONG_LISTS) != 0;
 }
 static inline int64_t gs_seg_items_cap(int64_t max_pairs, int n_tiles) { return max_pairs / GS_SEG_LEN + n_tiles; }
 static inline int64_t gs_group_queue_cap(int64_t max_pairs, int n_tiles) { return max_pairs / 256 + 4 * (int64_t)n_tiles; }

@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(STRIP_THREADS) strip_scatter_kernel(
             counters[GS_CNT_ENTRIES] = overflow ? 0 : E;
             counters[GS_CNT_BIG] = 0;  // strip_sort_kernel queues the tiles whose list exceeds its LDS window
             counters[GS_CNT_GROUPS] = 0;  // big_list_sort_kernel queues the groups it cut for group_sort_kernel
-            counters[GS_CNT_MAXLIST] = 0;  // strip_sort_kernel: longest list above GS_DENSE_AVG pairs
+            counters[GS_CNT_MAXLIST] = 0;  // strip_sort_kernel: longest list above GS_LONGEST_MIN pairs
         }
     }
     if (overflow) return;  // uniform

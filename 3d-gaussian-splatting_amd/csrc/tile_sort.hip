@@ -794,7 +794,7 @@ __global__ void __launch_bounds__(256, STRIP_SORT_WPE) strip_sort_kernel(
         s_start[q] = sq;
         s_n[q] = valid ? nq : 0;
         // statistic for the caller (gs_frame_longest_list_async): rare, so the atomic costs nothing
-        if (valid && nq > (uint32_t)GS_DENSE_AVG) atomicMax(longest, (unsigned long long)nq);
+        if (valid && nq > (uint32_t)GS_LONGEST_MIN) atomicMax(longest, (unsigned long long)nq);
     }
     if (total4 == 0) return;  // uniform
 #ifdef GS_DIAG_STRIP_NO_PLACE  // timing experiments only (tools/ab_variants.py): wrong results
@@ -1035,9 +1035,8 @@ __global__ void __launch_bounds__(256) group_sort_kernel(const uint4 *__restrict
 // keys that are contiguous in the final order, and each group is loaded into LDS, sorted by the distribution sort and
 // stored.  A bin with more than CAP / 2 keys (a depth cluster: a pile of clones at one depth behind a background that
 // spreads the range) goes back to `scratch` and onto a stack of ranges: its own, >= 1024 times narrower key range is
-// binned again (the range includes the id bits, so even equal depths separate).  Only launched when the frame's
-// capacity allows an average list above GS_DENSE_AVG (gs_stage_strip_sort); otherwise strip_sort_kernel sorts a rare
-// long list itself.
+// binned again (the range includes the id bits, so even equal depths separate).  Only launched in frames with
+// GS_FRAME_LONG_LISTS (gs_stage_strip_sort); otherwise strip_sort_kernel sorts a long list itself.
 template <int CAP>
 __global__ void __launch_bounds__(256) big_list_sort_kernel(const uint32_t *__restrict__ queue,
                                                            const unsigned long long *__restrict__ counters,
@@ -1288,9 +1287,9 @@ int gs_stage_strip_sort(const gs_frame *f, const gs_frame_ws &ws, const uint64_t
     const gs_strip_plan plan = gs_strip_plan_for(f->N, G.ntx, G.nty);
     GsDistCull D = {(float)(G.padW / 2), (float)(G.padH / 2), f->focal_x, f->focal_y, f->thresh};
     const unsigned grid = GS_STRIP_W == 8 ? (unsigned)gs_div_up(plan.geom.NS, 8) * 16 : plan.geom.NS;
-    // dense frame (the capacity allows an average list above half the LDS window): lists beyond the window are queued
-    // for big_list_sort_kernel, one workgroup each; otherwise strip_sort_kernel sorts a rare long list itself and the
-    // frame saves the launch
+    // GS_FRAME_LONG_LISTS (the caller has seen a long list in an earlier frame): lists beyond the window are queued
+    // for big_list_sort_kernel, one workgroup each; otherwise strip_sort_kernel sorts a long list itself and the
+    // frame saves the launches
     const bool dense = gs_frame_long_lists(f, G.n_tiles) && ws.big_tiles != nullptr;
     uint32_t *queue = dense ? ws.big_tiles : nullptr;
     if (f->tile_culling_method == 0)

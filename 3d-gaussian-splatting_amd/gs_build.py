@@ -31,7 +31,7 @@ SOURCES = {
     "raster_bwd.hip": ["-fno-slp-vectorize"],
     "gs_frame.hip": [],
     "adam.hip": ["-ffp-contract=off"],  # same roundings as torch's unfused elementwise kernels
-    "loss.hip": [],
+    "loss.hip": ["-fno-slp-vectorize"],  # as above: the packer costs ~50 v_mov per row step of the fused kernel
     "densify.hip": ["-ffp-contract=off"],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall",

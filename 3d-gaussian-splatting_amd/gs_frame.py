@@ -66,10 +66,10 @@ class FrameRenderer:
         # library picks by N -- table variant below 131,072 Gaussians, strip variant from there on.  None = the class-wide
         # default below (the GPU test-suite sets it, so that its small scenes keep exercising the strip kernels).
         self.force_strips = FrameRenderer.default_force_strips if force_strips is None else bool(force_strips)
-        self.serial_long_lists = bool(serial_long_lists)  # dense frames: no segmented compositing of long tile lists
-        # GS_FRAME_LONG_LISTS (big-list sort + segmented compositing also in frames that are sparse on average): True /
-        # False, or None = as soon as an earlier frame of this renderer reported a tile list beyond 2048 pairs (the
-        # counters that auto_grow reads back anyway carry the longest list)
+        self.serial_long_lists = bool(serial_long_lists)  # frames with long lists: no segmented compositing
+        # GS_FRAME_LONG_LISTS (big-list sort + segmented compositing of long tile lists): True / False, or None = as soon
+        # as an earlier frame of this renderer reported a tile list beyond 2048 pairs (the counters that auto_grow reads
+        # back anyway carry the longest list).  The workspace capacity plays no part in it.
         self.long_lists = long_lists
         self._long_lists_seen = False
         self.max_pairs = int(max_pairs)

@@ -36,7 +36,8 @@ extern "C" {
 
 /* 4 (round 3): GS_FRAME_STRIP_BIN + the size-based choice of the binning variant, gs_frame_binning_variant,
  * gs_frame_debug_rects (records of culled Gaussians are no longer written), gs_frame_overflow_flag,
- * gs_adam_step_sharded, `fast = 0` of gs_draw / gs_draw_backward honoured.  3: gs_frame.async / flags. */
+ * gs_adam_step_sharded, `fast = 0` of gs_draw / gs_draw_backward honoured, the long-list kernels follow GS_FRAME_LONG_LISTS alone (not the
+ * workspace capacity).  3: gs_frame.async / flags. */
 #define GS_ABI_VERSION 4
 
 #define GS_E_INVALID (-1)   /* bad argument (null pointer, negative size, bad enum)   */
@@ -172,11 +173,14 @@ int gs_sort_pairs_bits(uint64_t *keys0, uint32_t *vals0, uint64_t *keys1, uint32
                                        such tiles (A/B and equivalence tests).  Same result up to the rounding of the
                                        transmittance entering a segment. */
 
-#define GS_FRAME_LONG_LISTS 16       /* run the long-list kernels (big-list sort, segmented compositing) although the frame's
-                                       capacity is below 1024 pairs per tile on average: for frames that are sparse on
-                                       average but hold a few very long lists (pile-ups of a degenerate densification
-                                       run).  The library cannot know without a host synchronisation; the caller can:
-                                       gs_frame_longest_list_async reports the longest list of an earlier frame. */
+#define GS_FRAME_LONG_LISTS 16       /* run the long-list kernels (big-list sort, segmented compositing): for dense scenes (10 M
+                                       Gaussians at 1080p: ~3,500 pairs per tile) and for frames that hold a few very
+                                       long lists (pile-ups of a degenerate densification run).  The library cannot know
+                                       without a host synchronisation; the caller can: gs_frame_longest_list_async
+                                       reports the longest list of an earlier frame.  A frame without the flag is
+                                       correct whatever its lists are, only slower on long ones; the workspace CAPACITY
+                                       never selects the path (up to ABI version 3 a capacity above 1024 pairs per tile
+                                       did). */
 
 #define GS_FRAME_STRIP_BIN 32        /* sort_mode 2: take the strip variant of the binning whatever the scene size.  Without
                                        this flag (and without GS_FRAME_TABLE_BIN / GS_FRAME_SLICE_SORT) the library picks
@@ -285,7 +289,7 @@ int gs_frame_stats_async(const gs_frame *f, int64_t *stats_host, gs_stream_t str
 
 /* Length of the longest tile list of the last forward on this workspace (sort_mode 2, strip variant; lists of up to
  * 1024 pairs are reported as 0), copied device->host asynchronously into *longest_host.  A caller that sees a value
- * above ~2048 in a frame whose capacity is below 1024 pairs per tile sets GS_FRAME_LONG_LISTS on the following frames. */
+ * above ~2048 sets GS_FRAME_LONG_LISTS on the following frames. */
 int gs_frame_longest_list_async(const gs_frame *f, int64_t *longest_host, gs_stream_t stream);
 
 /* Read-only views into the workspace of the last forward (for parity tests): sorted keys

@@ -42,10 +42,13 @@ def mode_kwargs(sort_mode):
     return dict(sort_mode=sort_mode)
 
 
-def check_forward(gpu, scene, cam, training=False, sort_mode=2, emit_sorted_keys=False, img_atol=IMG_ATOL):
+def check_forward(gpu, scene, cam, training=False, sort_mode=2, emit_sorted_keys=False, img_atol=IMG_ATOL,
+                  long_lists=None):
     of = OracleFrame(scene, cam)
+    if long_lists is None:  # scenes with lists beyond the LDS window exercise the long-list kernels
+        long_lists = bool(np.diff(of.accum).max() > 2048)
     r = FrameRenderer(gpu, max_pairs=max(len(of.ids) + 17, 64), training=training, auto_grow=False,
-                      emit_sorted_keys=emit_sorted_keys, **mode_kwargs(sort_mode))
+                      emit_sorted_keys=emit_sorted_keys, long_lists=long_lists, **mode_kwargs(sort_mode))
     params = to_torch(scene, gpu)
     image, padded = r.forward(*params, cam)
     st = r.stats()
@@ -92,8 +95,7 @@ def test_frame_forward_giant_bucket_sorted_in_chunks(gpu, sort_mode):
 
 
 def test_long_list_kernels_follow_the_longest_list_statistic(gpu):
-    """A frame that is sparse on average (140 pairs per tile) with one 7,000-Gaussian pile: the capacity does not make
-    it a dense frame, so the first frame walks the pile with one wave; its counters report the longest list
+    """A frame with one 7,000-Gaussian pile: the first frame walks the pile with one wave; its counters report the longest list
     (gs_frame_longest_list_async, read back with the stats), and the renderer sets GS_FRAME_LONG_LISTS from then on.
     Images of the two paths agree; long_lists=False never switches."""
     scene, cam = case(10_000, 256, 256, seed=37)
@@ -136,7 +138,8 @@ def test_long_lists_composited_in_segments(gpu, use_sh):
     outs = []
     for serial in (False, True):
         params = to_torch(scene, gpu, requires_grad=True)
-        r = FrameRenderer(gpu, max_pairs=len(of.ids) + 64, training=True, auto_grow=False, serial_long_lists=serial)
+        r = FrameRenderer(gpu, max_pairs=len(of.ids) + 64, training=True, auto_grow=False, serial_long_lists=serial,
+                          long_lists=True)
         img = r.render(*params, cam)
         assert r.stats().pairs == len(of.ids)
         steps = r.composited_steps()
@@ -163,8 +166,7 @@ def test_frame_forward_emitted_sorted_keys(gpu, n, W, H, sort_mode):
 
 
 def test_frame_forward_dense_frame_with_depth_clusters(gpu):
-    """Dense frame (capacity above 1,024 pairs per tile): lists beyond the LDS window are queued for
-    big_list_sort_kernel.  40,000 Gaussians on four tiles, on 10 sites of 4,000 exact copies each: every depth bin of a
+    """GS_FRAME_LONG_LISTS: lists beyond the LDS window are queued for big_list_sort_kernel.  40,000 Gaussians on four tiles, on 10 sites of 4,000 exact copies each: every depth bin of a
     list holds thousands of equal keys -- more than the window -- and takes the chunked bitonic sort inside that kernel;
     300 sites: bins of ~130 copies go through the distribution sort's large-bucket path."""
     for n_sites in (10, 300):

@@ -27,10 +27,11 @@ scene.opa[idx] = -7.0
 params = [torch.from_numpy(a).to(dev) for a in (scene.pos, scene.quat, scene.scale, scene.opa, scene.rgb)]
 for training in (False, True):
     for serial in (False, True):
-        r = FrameRenderer(dev, max_pairs=1 << 20, training=training, auto_grow=True, serial_long_lists=serial)
+        r = FrameRenderer(dev, max_pairs=1 << 20, training=training, auto_grow=True, serial_long_lists=serial,
+                          long_lists=True)
         r.forward(*params, cam)
         st = r.stats()
-        r.max_pairs = max(int(st.pairs * 1.1) + 4096, 1100 * 8160)  # a dense frame: above 1024 pairs per tile on average
+        r.max_pairs = max(int(st.pairs * 1.1) + 4096, 1100 * 8160)
         r.auto_grow = False
         img, _ = r.forward(*params, cam)
         ranges = r.debug_views()["tile_ranges"]
