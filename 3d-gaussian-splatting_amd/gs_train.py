@@ -6,7 +6,7 @@ part that runs every iteration:
     forward -> loss = (1-w) L1 + w (1-SSIM) -> backward -> [all-reduce] -> Adam step -> LR update
 
 with three differences that matter on MI355X:
-  * the loss and its gradient are two HIP kernels (``gs_loss_l1_ssim``) instead of ~40 torch kernels
+  * the loss and its gradient are one streaming HIP kernel + a one-block reduction (``gs_loss_l1_ssim``) instead of ~40 torch kernels
     over five padded copies of the image (torchmetrics SSIM + autograd);
   * Adam is ONE launch over the flat parameter bucket (``gs_adam_step``), which also accumulates the
     densification statistic ``accum_max_grad`` of train.py:145-154 while it reads the gradient;
