@@ -828,3 +828,24 @@ def test_training_forward_followed_by_inference_forward_on_the_same_workspace(gp
     b = r.backward(g)
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+def test_ray_basis_is_built_when_an_sh_frame_follows_an_rgb_frame_of_the_same_camera(gpu):
+    """The per-camera constants are cached per camera, and the ray basis (only read by the SH colours) is left out of
+    the rgb entry: an SH frame of the same renderer and camera must not pick that entry up.  Also a camera that moves
+    every frame (no cache hit at all) renders what a fresh renderer renders."""
+    scene, cam = case(3000, 128, 96, seed=51)
+    sh_scene, _ = case(3000, 128, 96, seed=51, use_sh=True)
+    rgb_params, sh_params = to_torch(scene, gpu), to_torch(sh_scene, gpu)
+    want = FrameRenderer(gpu, max_pairs=1 << 16).forward(*sh_params, cam)[0].clone()
+    r = FrameRenderer(gpu, max_pairs=1 << 16)
+    r.forward(*rgb_params, cam)
+    got = r.forward(*sh_params, cam)[0]
+    assert torch.equal(got, want)
+    assert np.abs(got.cpu().numpy() - OracleFrame(sh_scene, cam).image).max() < IMG_ATOL
+    for yaw in (-3.0, 0.5, 2.0):
+        moved = make_camera(128, 96, yaw_deg=yaw)
+        moved.tran = cam.tran
+        a = r.forward(*sh_params, moved)[0]
+        b = FrameRenderer(gpu, max_pairs=1 << 16).forward(*sh_params, moved)[0]
+        assert torch.equal(a, b)
