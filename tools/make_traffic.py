@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """profiles/traffic.json from PMC summaries:
 
-    python tools/make_traffic.py cfg5=profiles/r03_e_cfg5_forward_pmc_summary.csv:6950364:profiles/r03_e_cfg5_forward_kernel_stats.csv ...
+    python tools/make_traffic.py cfg5=profiles/r03_af_cfg5_forward_pmc_summary.csv:6950364:profiles/r03_af_cfg5_forward_kernel_stats.csv ...
 
 Per kernel of each config: FETCH_SIZE / WRITE_SIZE (KiB per launch, raw) and traffic_bytes = 2 x FETCH + WRITE -- the
 gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE counts a 128-byte request as 64 B), calibrated in
