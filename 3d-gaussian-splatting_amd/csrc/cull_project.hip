@@ -599,6 +599,7 @@ __global__ void __launch_bounds__(BIN_THREADS) frame_project_bin_count_kernel(
     for (uint32_t t = threadIdx.x; t < T; t += BIN_THREADS) s_tile_hist[t] = 0;
     if (threadIdx.x < 2) s_acc[threadIdx.x] = 0;
     __syncthreads();
+    settle(cur);
     uint32_t acc_cnt = 0, acc_vis = 0;
     for (uint32_t base = 0; base < per_block; base += BIN_THREADS) {  // uniform trip count
         const uint32_t i = base + threadIdx.x;
