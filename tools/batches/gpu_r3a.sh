@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, call A: validate the tree + ordered-dispatch A/B + forced-collective bench
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$R/gpurun_out/r3a; mkdir -p "$OUT"; cd "$R"
 timeout 1500 python -m pytest tests -m gpu -q -x -p no:cacheprovider > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?"; tail -5 "$OUT/pytest.log"
 for V in "GS_FWD_ORDER=0" "GS_FWD_ORDER=1" "GS_FWD_TICKET=4" "GS_FWD_TICKET=3" "GS_FWD_TICKET=8" "GS_FWD_ORDER=0" "GS_FWD_ORDER=1"; do

@@ -1,6 +1,6 @@
 #!/bin/bash
 # fused image loss: parity tests, A/B of its compile-time variants against the two-pass kernels; long-list tests after the flag-only gating
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$R/gpurun_out/r3aa; rm -rf "$OUT"; mkdir -p "$OUT"; cd "$R"
 timeout 600 python -m pytest tests/test_gpu_train.py -m gpu -q -p no:cacheprovider -k "loss" > "$OUT/pytest_loss.log" 2>&1; echo "pytest loss rc=$?"; tail -5 "$OUT/pytest_loss.log"
 timeout 900 python -m pytest tests/test_gpu_frame.py -m gpu -q -p no:cacheprovider -k "long or dense or emitted or clusters" > "$OUT/pytest_long.log" 2>&1; echo "pytest long rc=$?"; tail -5 "$OUT/pytest_long.log"

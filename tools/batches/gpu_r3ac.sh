@@ -1,6 +1,6 @@
 #!/bin/bash
 # kernel trace + PMC of the fused loss kernel alone
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$R/gpurun_out/r3ac; rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o s -- python "$R/tools/loss_profile.py" > "$OUT/loss.txt" 2> "$OUT/stats.err"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, call C: fused project + count A/B, written-row mask, auto variant sweep, Adam stream rates
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$R/gpurun_out/r3c; mkdir -p "$OUT"; cd "$R"
 timeout 2400 python -m pytest tests -m gpu -q -x -p no:cacheprovider > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?"; tail -4 "$OUT/pytest.log"
 for V in base nofuse; do

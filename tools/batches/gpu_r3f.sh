@@ -1,5 +1,5 @@
 #!/bin/bash
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$R/gpurun_out/r3f; mkdir -p "$OUT"; cd /tmp; export TMPDIR=/tmp
 for T in cur r01h; do
   ROOT=$R; [ $T = r01h ] && ROOT=$R/build/r01h

@@ -1,5 +1,5 @@
 #!/bin/bash
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$R/gpurun_out/r3o; mkdir -p "$OUT"; cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o s -- python "$R/tools/loss_profile.py" > "$OUT/loss.txt" 2> /dev/null
 i=0
