@@ -93,7 +93,9 @@ __device__ __forceinline__ f2 live_mask(f2 t, f2 scale, f2 bias) {
 // sits behind math instead of in front of it.  With one tile per wave all waves run their gather,
 // math and store phases in lockstep and the phases add up instead of overlapping.
 #ifndef GS_FWD_RGB_WPE
-#define GS_FWD_RGB_WPE 1
+#define GS_FWD_RGB_WPE 4  // rgb colours: four waves per SIMD asked for.  Left to itself the allocator gave the training variant
+                         // (checkpoint stores) 130 VGPRs = three waves; with the hint it fits 128 without scratch: training
+                         // forward at 2.4 M Gaussians 136 -> 129 us, inference 126 VGPRs, +-1 % (same-box A/B, round 3)
 #endif
 #ifndef GS_FWD_SH27_WPE
 #define GS_FWD_SH27_WPE 3  // waves per SIMD the register allocation of the SH kernels aims at (A/B switches; degree 2 at
@@ -104,7 +106,8 @@ __device__ __forceinline__ f2 live_mask(f2 t, f2 scale, f2 bias) {
 #endif
 template <int CDIM, bool FRAME, bool CKPT, bool SIG, bool WN, bool EXACT = false>
 __global__ void __launch_bounds__(FWD_THREADS)
-__attribute__((amdgpu_waves_per_eu(CDIM == 48 ? GS_FWD_SH48_WPE : CDIM == 27 ? GS_FWD_SH27_WPE : GS_FWD_RGB_WPE)))
+__attribute__((amdgpu_waves_per_eu(CDIM == 48 ? GS_FWD_SH48_WPE : CDIM == 27 ? GS_FWD_SH27_WPE
+                                               : (SIG || WN || EXACT) ? 1 : GS_FWD_RGB_WPE)))  // (the rare flags would spill at 128)
 raster_forward_kernel(RasterSrc S, RasterGeom G,
                                                                     const int32_t *__restrict__ ranges,
                                                                     float *__restrict__ out_padded,
