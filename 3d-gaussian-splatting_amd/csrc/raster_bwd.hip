@@ -728,6 +728,9 @@ struct PixShCfg {
 #ifndef GS_BWD_SH_WPE
 #define GS_BWD_SH_WPE 4  // waves per SIMD the register allocation aims at (A/B switch, tools/ab_variants.py)
 #endif
+#ifndef GS_BWD_PAIR_SKIP
+#define GS_BWD_PAIR_SKIP 1
+#endif
 template <int CDIM, bool FRAME, bool EXACT = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CDIM == 48 ? GS_BWD_SH48_WPE : GS_BWD_SH_WPE)))
 raster_backward_pixel_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
@@ -879,6 +882,9 @@ raster_backward_pixel_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
         return id;
     };
     uint32_t id_next = load_coef(0);
+    constexpr bool PAIR_SKIP = GS_BWD_PAIR_SKIP && CDIM == 27;
+    bool pair_live[2] = {true, true};
+    (void)pair_live;
     for (uint32_t i = 0; i < r; ++i) {
         const float gx = s_g[FX][i], gy = s_g[FY][i], uA = s_g[FA][i], uB = s_g[FB][i], uC = s_g[FC][i];
         const float opa = s_g[FOPA][i];
@@ -887,8 +893,26 @@ raster_backward_pixel_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
         const float bdx = uB * dx, adx2 = uA * dx * dx;
         f2 S1 = {0.f, 0.f}, Sy = S1, Syy = S1, Sq = S1, Sopa = S1;
         f2 D[2][3];
+        // A pixel pair (= a half of the tile: rows 8 h .. 8 h + 7) whose 128 pixels are all finished adds exact zeros to
+        // every sum below and its transmittance no longer changes: it is left out (wave-uniform branch, re-evaluated
+        // every 8 Gaussians; the transmittance only falls, so a finished pair stays finished).  5 % of the pair
+        // evaluations of the 2.4 M scene (oracle statistics).  Degree-2 SH only -- same-box A/B at 2.4 M
+        // Gaussians: 1.40 -> 1.34 ms; degree 3 is at its register limit and loses (2.13 -> 2.42 ms: 18 spills), rgb
+        // colours have too little work per pair to pay for the branches (0.63 = 0.63 ms, cfg2 +4 %).
+        if constexpr (PAIR_SKIP) {
+            if ((i & 7u) == 0) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) pair_live[h] = __ballot(T[h].x > GS_T_STOP || T[h].y > GS_T_STOP) != 0ull;
+            }
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
+            if constexpr (PAIR_SKIP) {
+                if (!pair_live[h]) {  // uniform
+                    D[h][0] = D[h][1] = D[h][2] = f2{0.f, 0.f};
+                    continue;
+                }
+            }
             const f2 dy = py2[h] - splat(gy);
             const f2 q = pk_fma(pk_fma(splat(uC), dy, splat(-bdx)), dy, splat(adx2));
             // EXACT: a double-precision exp of the float argument, as the reference's backward does for fast = 0
