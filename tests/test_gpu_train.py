@@ -76,7 +76,10 @@ def test_adam_rejects_bad_arguments(gpu):
 
 
 @pytest.mark.parametrize("h,w,weight", [(11, 11, 0.1), (37, 53, 0.1), (64, 64, 1.0), (200, 300, 0.25), (40, 33, 0.0),
-                                        (5, 7, 0.0)])
+                                        (5, 7, 0.0),
+                                        # the streaming kernel's strips are 52 rows x 482 flat columns (3 W floats per
+                                        # row): ragged last strip / column block, exactly one, one more than one
+                                        (53, 483, 0.3), (105, 161, 0.1), (52, 160, 0.5), (104, 322, 0.2), (12, 700, 1.0)])
 def test_loss_matches_oracle(gpu, h, w, weight):
     from gs_train import ImageLoss
 
