@@ -1,7 +1,7 @@
 #!/bin/bash
 # after the fused image loss and the flag-only long-list gating: GPU suite, smoke, default bench, loss kernel trace
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
-OUT=$R/gpurun_out/r3aj; rm -rf "$OUT"; mkdir -p "$OUT"; cd "$R"
+OUT=$R/gpurun_out/r3ao; rm -rf "$OUT"; mkdir -p "$OUT"; cd "$R"
 timeout 2400 python -m pytest tests -m gpu -q -p no:cacheprovider > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?"; tail -4 "$OUT/pytest.log"
 timeout 300 python __graft_entry__.py --smoke 2>&1 | grep -v amdgpu.ids | tail -2
 timeout 900 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"; echo "bench rc=$? lines=$(wc -l < $OUT/bench_default.json)"
