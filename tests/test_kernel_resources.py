@@ -1,0 +1,115 @@
+"""CPU tier: register / scratch budget of the hot kernels, read from the gfx950 code objects inside the built
+libgs_amd.so (no GPU, no recompilation).
+
+The kernels' speed rests on a few occupancy facts that a harmless-looking edit can break without any test noticing --
+the rgb compositing kernels must fit 128 VGPRs (four waves per SIMD; the checkpointing variant once had 130), none of
+the frame path's hot kernels may spill to scratch, the per-tile sort must fit four workgroups per CU.  The numbers come
+from the AMDGPU metadata note of every code object in the library's `.hip_fatbin` (clang offload bundles)."""
+import os
+import struct
+
+import msgpack
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "3d-gaussian-splatting_amd", "csrc", "libgs_amd.so")
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def code_objects(blob):
+    """Every gfx950 ELF inside the clang offload bundles of the library."""
+    pos = 0
+    while True:
+        pos = blob.find(MAGIC, pos)
+        if pos < 0:
+            return
+        n, = struct.unpack_from("<Q", blob, pos + len(MAGIC))
+        cur = pos + len(MAGIC) + 8
+        for _ in range(n):
+            off, size, tlen = struct.unpack_from("<QQQ", blob, cur)
+            triple = blob[cur + 24:cur + 24 + tlen].decode()
+            cur += 24 + tlen
+            if "gfx950" in triple and size:
+                yield blob[pos + off:pos + off + size]
+        pos += len(MAGIC)
+
+
+def kernel_metadata(elf):
+    """{kernel symbol: metadata dict} from the NT_AMDGPU_METADATA note (type 32, name "AMDGPU") of an ELF64 code object."""
+    assert elf[:4] == b"\x7fELF" and elf[4] == 2
+    shoff, = struct.unpack_from("<Q", elf, 0x28)
+    shentsize, shnum = struct.unpack_from("<HH", elf, 0x3A)
+    out = {}
+    for i in range(shnum):
+        sh = shoff + i * shentsize
+        sh_type, = struct.unpack_from("<I", elf, sh + 4)
+        if sh_type != 7:  # SHT_NOTE
+            continue
+        off, size = struct.unpack_from("<QQ", elf, sh + 0x18)
+        p, end = off, off + size
+        while p + 12 <= end:
+            namesz, descsz, ntype = struct.unpack_from("<III", elf, p)
+            name = elf[p + 12:p + 12 + namesz].rstrip(b"\0")
+            dpos = p + 12 + (namesz + 3) // 4 * 4
+            if name == b"AMDGPU" and ntype == 32:
+                md = msgpack.unpackb(elf[dpos:dpos + descsz], raw=False, strict_map_key=False)
+                for k in md.get("amdhsa.kernels", []):
+                    out[k[".name"]] = k
+            p = dpos + (descsz + 3) // 4 * 4
+    return out
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    if not os.path.exists(LIB):
+        pytest.skip("libgs_amd.so is not built")
+    blob = open(LIB, "rb").read()
+    out = {}
+    for elf in code_objects(blob):
+        out.update(kernel_metadata(elf))
+    assert len(out) > 60, f"only {len(out)} kernels found in the library's code objects"
+    return out
+
+
+def pick(kernels, *parts):
+    hits = [v for k, v in kernels.items() if all(p in k for p in parts)]
+    assert len(hits) == 1, (parts, [h[".name"] for h in hits])
+    return hits[0]
+
+
+# (substrings of the mangled name, VGPR limit, scratch allowed?)  <C, FRAME, CKPT, SIG, WN, EXACT> / <DIST> / ...
+BUDGETS = [
+    (("raster_forward_kernelILi3ELb1ELb0ELb0ELb0ELb0E",), 128, False),   # rgb inference frame: four waves per SIMD
+    (("raster_forward_kernelILi3ELb1ELb1ELb0ELb0ELb0E",), 128, False),   # rgb training frame (checkpoints)
+    (("raster_forward_kernelILi27ELb1ELb0ELb0ELb0ELb0E",), 168, True),   # SH degree 2: three waves (a few spilled tile constants)
+    (("raster_forward_kernelILi48ELb1ELb0ELb0ELb0ELb0E",), 256, True),   # SH degree 3: two waves
+    (("raster_backward_pixel_sh_kernelILi3ELb1ELb0E",), 96, False),      # rgb backward: five waves (LDS-limited at 7.6 KiB)
+    (("raster_backward_pixel_sh_kernelILi27ELb1ELb0E",), 128, True),
+    (("raster_backward_pixel_sh_kernelILi48ELb1ELb0E",), 168, True),
+    (("frame_project_count_kernelILb0E",), 128, False),                   # 1024 threads per workgroup: 128 is the hard limit
+    (("frame_project_bin_count_kernelILb0E",), 128, False),
+    (("strip_sort_kernelILi2048ELb0E",), 128, False),                    # four workgroups of 256 per CU
+    (("loss_fused_kernel",), 256, False),                                # one workgroup of 512 per CU: two waves per SIMD
+    (("adam_kernelILb0E",), 64, False),
+    (("adam_kernelILb1E",), 64, False),
+]
+
+
+@pytest.mark.parametrize("parts,vgprs,scratch_ok", BUDGETS, ids=[b[0][0] for b in BUDGETS])
+def test_hot_kernel_fits_its_register_budget(kernels, parts, vgprs, scratch_ok):
+    k = pick(kernels, *parts)
+    assert k[".vgpr_count"] <= vgprs, (k[".name"], k[".vgpr_count"])
+    if not scratch_ok:
+        assert k[".vgpr_spill_count"] == 0 and k[".private_segment_fixed_size"] == 0, \
+            (k[".name"], k[".vgpr_spill_count"], k[".private_segment_fixed_size"])
+
+
+def test_lds_budgets(kernels):
+    """Static LDS (dynamic LDS is added at launch): the compositing kernels must leave room for their resident waves."""
+    fwd = pick(kernels, "raster_forward_kernelILi3ELb1ELb0ELb0ELb0ELb0E")
+    assert fwd[".group_segment_fixed_size"] * 16 <= 160 * 1024      # 16 waves (= one-wave workgroups) per CU
+    bwd = pick(kernels, "raster_backward_pixel_sh_kernelILi3ELb1ELb0E")
+    assert bwd[".group_segment_fixed_size"] * 20 <= 160 * 1024      # five waves per SIMD
+    sort = pick(kernels, "strip_sort_kernelILi2048ELb0E")
+    assert sort[".group_segment_fixed_size"] * 4 <= 160 * 1024      # four workgroups per CU
+    assert pick(kernels, "frame_project_count_kernelILb0E")[".group_segment_fixed_size"] + 8192 * 8 <= 160 * 1024
