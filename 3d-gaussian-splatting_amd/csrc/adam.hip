@@ -46,16 +46,12 @@ __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, 
 }
 
 template <bool NT>
-__global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ param, const float *__restrict__ grad,
-                                                   float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq,
-                                                   int64_t lo, int64_t hi, AdamGroups G, float one_m_b1, float b2,
-                                                   float one_m_b2, float inv_bc2_sqrt, float eps,
-                                                   float *__restrict__ stat, int64_t stat_begin, int64_t stat_end,
-                                                   int stat_mode, int64_t moment_base,
-                                                   const unsigned long long *__restrict__ skip_if_nonzero) {
-    // a frame that overflowed its workspace was rendered empty: its all-zero gradient must not move the parameters by
-    // momentum (the flag is the frame's device-side overflow counter: no host synchronisation; uniform branch)
-    if (skip_if_nonzero && *skip_if_nonzero) return;
+__device__ __forceinline__ void adam_range(float *__restrict__ param, const float *__restrict__ grad,
+                                           float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq,
+                                           int64_t lo, int64_t hi, const AdamGroups &G, float one_m_b1, float b2,
+                                           float one_m_b2, float inv_bc2_sqrt, float eps,
+                                           float *__restrict__ stat, int64_t stat_begin, int64_t stat_end,
+                                           int stat_mode, int64_t moment_base) {
     // the moments may be a SHARD that starts at element moment_base (a multiple of 4) of the flat index space
     exp_avg -= moment_base;
     exp_avg_sq -= moment_base;
@@ -125,6 +121,42 @@ __global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ param, co
             *d = stat_mode == 1 ? fmaxf(*d, fabsf(g)) : *d + fabsf(g);
         }
     }
+}
+
+template <bool NT>
+__global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ param, const float *__restrict__ grad,
+                                                   float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq,
+                                                   int64_t lo, int64_t hi, AdamGroups G, float one_m_b1, float b2,
+                                                   float one_m_b2, float inv_bc2_sqrt, float eps,
+                                                   float *__restrict__ stat, int64_t stat_begin, int64_t stat_end,
+                                                   int stat_mode, int64_t moment_base,
+                                                   const unsigned long long *__restrict__ skip_if_nonzero) {
+    // a frame that overflowed its workspace was rendered empty: its all-zero gradient must not move the parameters by
+    // momentum (the flag is the frame's device-side overflow counter: no host synchronisation; uniform branch)
+    if (skip_if_nonzero && *skip_if_nonzero) return;
+    adam_range<NT>(param, grad, exp_avg, exp_avg_sq, lo, hi, G, one_m_b1, b2, one_m_b2, inv_bc2_sqrt, eps, stat,
+                   stat_begin, stat_end, stat_mode, moment_base);
+}
+
+// Several element ranges in ONE launch (blockIdx.y = range): a slice of the view-parallel exchange is one range of
+// Gaussians in each of the five parameter arrays (gs_dp.py) -- five launches of ~2 us of work each would cost more in
+// dependent-launch latency than they compute.
+#define GS_ADAM_MAX_RANGES 8
+struct AdamRanges {
+    int64_t lo[GS_ADAM_MAX_RANGES], hi[GS_ADAM_MAX_RANGES], moment_base[GS_ADAM_MAX_RANGES];
+};
+template <bool NT>
+__global__ void __launch_bounds__(256) adam_multi_kernel(float *__restrict__ param, const float *__restrict__ grad,
+                                                         float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq,
+                                                         AdamRanges R, AdamGroups G, float one_m_b1, float b2,
+                                                         float one_m_b2, float inv_bc2_sqrt, float eps,
+                                                         float *__restrict__ stat, int64_t stat_begin, int64_t stat_end,
+                                                         int stat_mode,
+                                                         const unsigned long long *__restrict__ skip_if_nonzero) {
+    if (skip_if_nonzero && *skip_if_nonzero) return;
+    const int r = blockIdx.y;
+    adam_range<NT>(param, grad, exp_avg, exp_avg_sq, R.lo[r], R.hi[r], G, one_m_b1, b2, one_m_b2, inv_bc2_sqrt, eps,
+                   stat, stat_begin, stat_end, stat_mode, R.moment_base[r]);
 }
 
 // the statistic alone (view-parallel training: it must see this rank's OWN gradient, before the all-reduce)
@@ -232,4 +264,70 @@ extern "C" int gs_adam_step_sharded(float *param, const float *grad, float *exp_
     return adam_step_impl(param, grad, exp_avg_shard, exp_avg_sq_shard, n, range_begin, range_end, n_groups, group_end,
                           lr, beta1, beta2, eps, step, grad_stat, stat_begin, stat_end, stat_mode, stream, moment_base,
                           (const unsigned long long *)skip_if_nonzero);
+}
+
+// Up to 8 element ranges [range_begin[r], range_end[r]) of the same flat arrays in one launch (host arrays).  The moments
+// of range r start at exp_avg + moment_offset[r] (a multiple of 4): element i of range r keeps its moments at index
+// moment_offset[r] + (i - range_begin[r]) -- identity (moment_offset = range_begin) for a replicated optimizer, densely
+// packed shards for a sharded one.  range_begin[r] must be a multiple of 4.  Every element's update is what gs_adam_step
+// computes for it.
+extern "C" int gs_adam_step_multi(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                                  int32_t n_ranges, const int64_t *range_begin, const int64_t *range_end,
+                                  const int64_t *moment_offset, int32_t n_groups, const int64_t *group_end,
+                                  const float *lr, float beta1, float beta2, float eps, int64_t step, float *grad_stat,
+                                  int64_t stat_begin, int64_t stat_end, int32_t stat_mode, const void *skip_if_nonzero,
+                                  gs_stream_t stream) {
+    GS_CHECK_ARG(n >= 0, "n < 0");
+    GS_CHECK_ARG(n_ranges >= 1 && n_ranges <= GS_ADAM_MAX_RANGES, "n_ranges must be in [1, 8]");
+    GS_CHECK_ARG(range_begin && range_end && moment_offset, "null range table");
+    GS_CHECK_ARG(n_groups >= 1 && n_groups <= GS_ADAM_MAX_GROUPS, "n_groups must be in [1, 8]");
+    GS_CHECK_ARG(group_end && lr, "null group table");
+    GS_CHECK_ARG(step >= 1, "step counts from 1 (torch.optim.Adam increments before the update)");
+    GS_CHECK_ARG(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f, "bad hyper-parameters");
+    GS_CHECK_ARG(stat_mode >= 0 && stat_mode <= 2, "stat_mode must be 0 (off), 1 (max) or 2 (sum)");
+    GS_CHECK_ARG(param && grad && exp_avg && exp_avg_sq, "null pointer");
+    GS_CHECK_ARG((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
+                 "buffers must be 16-byte aligned");
+    GS_CHECK_ARG(!stat_mode || (grad_stat && stat_begin >= 0 && stat_begin <= stat_end && stat_end <= n),
+                 "bad statistic range");
+    AdamRanges R;
+    int64_t longest = 0;
+    for (int r = 0; r < GS_ADAM_MAX_RANGES; ++r) {
+        const int rr = r < n_ranges ? r : 0;
+        const int64_t lo = range_begin[rr], hi = r < n_ranges ? range_end[rr] : range_begin[rr];
+        GS_CHECK_ARG(lo >= 0 && lo <= hi && hi <= n && (lo & 3) == 0, "bad element range (begin must be a multiple of 4)");
+        GS_CHECK_ARG(moment_offset[rr] >= 0 && (moment_offset[rr] & 3) == 0, "moment_offset must be a multiple of 4");
+        R.lo[r] = lo;
+        R.hi[r] = hi;
+        R.moment_base[r] = lo - moment_offset[rr];  // the kernel indexes the moments with (element - moment_base)
+        if (hi - lo > longest) longest = hi - lo;
+    }
+    if (longest == 0) return 0;
+    AdamGroups G;
+    int64_t prev = 0;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    for (int k = 0; k < GS_ADAM_MAX_GROUPS; ++k) {
+        const int kk = k < n_groups ? k : n_groups - 1;
+        GS_CHECK_ARG(group_end[kk] >= prev && group_end[kk] <= n, "group_end must be ascending and <= n");
+        prev = group_end[kk];
+        G.end[k] = group_end[kk];
+        G.step_size[k] = (float)((double)lr[kk] / bc1);
+    }
+    GS_CHECK_ARG(group_end[n_groups - 1] == n, "the groups must cover [0, n)");
+    G.n = n_groups;
+    int64_t blocks = gs_div_up(gs_div_up(longest, 4), 256);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+    const dim3 grid((unsigned)blocks, (unsigned)n_ranges);
+    // streaming accesses once the four arrays as a whole exceed the Infinity Cache (the ranges of one step add up to them)
+    if ((unsigned long long)n * 16ull > GS_ADAM_NT_BYTES)
+        hipLaunchKernelGGL(adam_multi_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                           exp_avg_sq, R, G, 1.0f - beta1, beta2, 1.0f - beta2, (float)(1.0 / sqrt(bc2)), eps, grad_stat,
+                           stat_begin, stat_end, (int)stat_mode, (const unsigned long long *)skip_if_nonzero);
+    else
+        hipLaunchKernelGGL(adam_multi_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                           exp_avg_sq, R, G, 1.0f - beta1, beta2, 1.0f - beta2, (float)(1.0 / sqrt(bc2)), eps, grad_stat,
+                           stat_begin, stat_end, (int)stat_mode, (const unsigned long long *)skip_if_nonzero);
+    GS_CHECK_LAUNCH();
+    return 0;
 }

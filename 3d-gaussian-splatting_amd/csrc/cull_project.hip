@@ -120,16 +120,23 @@ __device__ __forceinline__ bool project(const float p[3], const float q[4], cons
 
 // Backward of `project` w.r.t. (p, q_hat, s_hat) given dL/dpos_i and dL/dcov
 // (gaussian.cu:1393-1575; the dependence of J on p is dropped exactly as there).
+// Unlike the forward (depth bits and tile rectangles must equal the oracle's bit for bit: -ffp-contract=off for the
+// file), gradients are compared within a tolerance: everything between the two pragmas contracts to FMAs, and the
+// backward uses v_rcp_f32 / v_rsq_f32 (1 ulp) for its reciprocals -- seven correctly rounded divisions, a square root and
+// ~150 separate multiplies and adds were a third of the projection backward's instructions (round 4: the kernel turned
+// out to be VALU-bound, not HBM-bound, once it stopped fetching rows nobody wrote).
+#pragma clang fp contract(fast)
 __device__ __forceinline__ void project_backward(const float p[3], const float q[4], const float s[3],
                                                  const Cam &cam, const float gi[3], const float g2[4],
                                                  float gp[3], float gq[4], float gs[3]) {
     float pc[3];
-    world_to_camera(p, cam, pc);
-    float r = sqrtf(pc[0] * pc[0] + pc[1] * pc[1] + pc[2] * pc[2]);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) pc[r] = cam.rot[r * 3 + 0] * p[0] + cam.rot[r * 3 + 1] * p[1] + cam.rot[r * 3 + 2] * p[2] + cam.tran[r];
+    const float ir_ = gs_rsq(pc[0] * pc[0] + pc[1] * pc[1] + pc[2] * pc[2]), iz = gs_rcp(pc[2]);
     float gc[3];
-    gc[0] = gi[0] / pc[2] + gi[2] * pc[0] / r;
-    gc[1] = gi[1] / pc[2] + gi[2] * pc[1] / r;
-    gc[2] = -gi[0] * pc[0] / (pc[2] * pc[2]) - gi[1] * pc[1] / (pc[2] * pc[2]) + gi[2] * pc[2] / r;
+    gc[0] = gi[0] * iz + gi[2] * pc[0] * ir_;
+    gc[1] = gi[1] * iz + gi[2] * pc[1] * ir_;
+    gc[2] = -(gi[0] * pc[0] + gi[1] * pc[1]) * (iz * iz) + gi[2] * pc[2] * ir_;
 #pragma unroll
     for (int ir = 0; ir < 3; ++ir) {
         float a = 0;
@@ -137,9 +144,14 @@ __device__ __forceinline__ void project_backward(const float p[3], const float q
         for (int k = 0; k < 3; ++k) a += cam.rot[k * 3 + ir] * gc[k];
         gp[ir] = a;
     }
-    float J[9], JW[9];
-    jacobian_rows(pc, J);
-    mm3(J, cam.rot, JW);
+    // rows 0, 1 of J W (J = [[1/z, 0, -x/z^2], [0, 1/z, -y/z^2]])
+    float JW[6];
+    const float jx = -pc[0] * (iz * iz), jy = -pc[1] * (iz * iz);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        JW[c] = iz * cam.rot[c] + jx * cam.rot[6 + c];
+        JW[3 + c] = iz * cam.rot[3 + c] + jy * cam.rot[6 + c];
+    }
     float g3[9];
 #pragma unroll
     for (int ir = 0; ir < 3; ++ir)
@@ -152,9 +164,10 @@ __device__ __forceinline__ void project_backward(const float p[3], const float q
                 for (int ij = 0; ij < 2; ++ij) a += g2[ii * 2 + ij] * JW[ii * 3 + ir] * JW[ij * 3 + ic];
             g3[ir * 3 + ic] = a;
         }
-    float R[9], S[9] = {s[0], 0, 0, 0, s[1], 0, 0, 0, s[2]}, RS[9], gRS[9];
+    float R[9], RS[9], gRS[9];
     quat_to_R(q[0], q[1], q[2], q[3], R);
-    mm3(R, S, RS);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) RS[i] = R[i] * s[i % 3];
 #pragma unroll
     for (int ir = 0; ir < 3; ++ir)
 #pragma unroll
@@ -189,6 +202,7 @@ __device__ __forceinline__ void project_backward(const float p[3], const float q
     gq[2] = a2;
     gq[3] = a3;
 }
+#pragma clang fp contract(off)
 
 __device__ __forceinline__ void load3(const float *base, int64_t i, float v[3]) {
     v[0] = base[i * 3 + 0];
@@ -529,7 +543,7 @@ __global__ void __launch_bounds__(STRIP_THREADS) frame_project_count_kernel(
     const float *__restrict__ pos, const float4 *__restrict__ quat, const float *__restrict__ scale,
     const float *__restrict__ opa, const float *__restrict__ rgb, int64_t n, ProjectParams P,
     float4 *__restrict__ rec_geom, uint32_t *__restrict__ tiles_touched, uint4 *__restrict__ rects, GsDistCull D,
-    uint32_t per_slice, gs_strip_geom SG, uint32_t S, unsigned long long *__restrict__ table,
+    uint32_t per_slice, gs_strip_geom SG, uint32_t S, uint32_t slice0, unsigned long long *__restrict__ table,
     uint32_t *__restrict__ slice_pairs, uint32_t *__restrict__ slice_vis, const uint32_t *__restrict__ tile_cost,
     uint32_t n_tiles, uint32_t *__restrict__ tile_order) {
     extern __shared__ unsigned long long s_hist[];  // [NS] entries << 32 | pairs of this slice
@@ -538,7 +552,10 @@ __global__ void __launch_bounds__(STRIP_THREADS) frame_project_count_kernel(
         tile_order_workgroup(tile_cost, n_tiles, tile_order);
         return;
     }
-    const uint32_t slice = strip_slice_of_block(blockIdx.x, S);
+    // this launch covers the slices [slice0, slice0 + S): all of them, or one range of a frame whose project stage is
+    // issued range by range (gs_frame_forward_project: the view-parallel trainer projects a range of Gaussians as soon
+    // as their parameters have been updated)
+    const uint32_t slice = slice0 + strip_slice_of_block(blockIdx.x, S);
     const int64_t g0 = (int64_t)slice * per_slice;
     auto in_range = [&](uint32_t i) { return i < per_slice && g0 + i < n; };
     RawGaussian cur = {}, nxt = {};
@@ -639,30 +656,50 @@ __global__ void __launch_bounds__(BIN_THREADS) frame_project_bin_count_kernel(
 // "geometry" bucket of the view-parallel gradient exchange); 2 = only grad_opa and grad_rgb (the "colour" bucket).
 // Parts 1 and 2 read the same rows and add them in the same order as part 0: their outputs are bit-identical to it.
 // They exist so that the all-reduce of the first bucket can run underneath the second kernel (gs_dp.py).
+#ifndef GS_PB_DIRECT
+#define GS_PB_DIRECT 1  // A/B switch (tools/ab_variants.py): how the rgb rows are fetched, see below
+#endif
 template <int CDIM, int PART = 0, int BLOCK = (CDIM == 3 ? 256 : 128)>
 __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
     const float *__restrict__ pos, const float4 *__restrict__ quat, const float *__restrict__ scale,
     int64_t n, ProjectParams P, const float4 *__restrict__ rec_geom,
     const float4 *__restrict__ rec_color, const float4 *__restrict__ rows, const uint8_t *__restrict__ row_flags,
-    const uint32_t *__restrict__ pair_offsets, const uint4 *__restrict__ rects, uint64_t max_pairs,
+    const unsigned long long *__restrict__ stop_keys, const float *__restrict__ opa_raw,
+    const float *__restrict__ rgb_raw, GsDistCull D,
+    const uint32_t *__restrict__ pair_offsets, const uint4 *__restrict__ rects, uint64_t max_pairs, int64_t g_first,
     float *__restrict__ grad_pos,
     float4 *__restrict__ grad_quat, float *__restrict__ grad_scale, float *__restrict__ grad_opa,
     float *__restrict__ grad_rgb) {
-    // The rows of the 256 Gaussians of this workgroup are one contiguous range (emission order = Gaussian
-    // order).  A thread walking its own 3.7 rows with float4 loads touches 64 different cache lines per wave
-    // instruction; instead the range is streamed through LDS with coalesced loads, chunk by chunk, and every
-    // thread adds up its rows out of LDS in the same k-ascending order (results are bitwise unchanged).
-    constexpr int CHUNK_F4 = 1536;  // 24 KiB = 512 rows (rgb rows only: SH rows are read straight from memory)
-    __shared__ float4 s_rows[CDIM == 3 ? CHUNK_F4 : 1];
-    __shared__ uint8_t s_flag[CDIM == 3 ? CHUNK_F4 / 3 : 1];
-    const int64_t pid0 = (int64_t)blockIdx.x * blockDim.x, pid = pid0 + threadIdx.x;
+    // rgb rows (round 4): only rows that EXIST are fetched.  71 % of the pairs of the 2.4 M scene lie behind their
+    // tile's stop point and their rows are uninitialised memory; round 3 streamed all of them through LDS and looked at
+    // the flags afterwards (PMC: 916 MB of traffic against 316 MB algorithmic).  Whether the row of pair (tile, g) was
+    // written follows from one number per TILE -- the key of the last list entry the forward processed there (stop_keys,
+    // raster_bwd.hip: stop_key_kernel): the tile's list ascends in (depth bits, Gaussian), so the row exists iff
+    // key(g) <= stop key.  Every thread first turns its rectangle into a bit mask of existing rows (stop-key loads eight
+    // at a time: a loop with one dependent load per row costs a memory round trip per row -- the first version of this
+    // kernel: 278 us against round 3's 175), then adds the rows up in ascending order, as before: bitwise unchanged.
+    //   GS_PB_DIRECT 1: every thread fetches its own existing rows (one aligned 64-byte line each, ~1 per visible
+    //                   Gaussian at 2.4 M Gaussians), two rows in flight;
+    //   GS_PB_DIRECT 0: the workgroup's contiguous row range goes through LDS chunk by chunk, four lanes per existing
+    //                   row, and every thread adds its rows out of LDS.
+    constexpr int CHUNK_ROWS = 512;  // staged variant: 24 KiB of LDS, three float4s (the 10 floats in use) per row
+    __shared__ float4 s_rows[(CDIM == 3 && !GS_PB_DIRECT) ? CHUNK_ROWS * 3 : 1];
+    __shared__ uint8_t s_flag[(CDIM == 3 && !GS_PB_DIRECT) ? CHUNK_ROWS : 1];
+    const int64_t pid0 = (int64_t)blockIdx.x * blockDim.x + g_first, pid = pid0 + threadIdx.x;
     const int64_t pid_last = (pid0 + blockDim.x < n ? pid0 + blockDim.x : n) - 1;
     const bool valid = pid < n;
+    (void)pid_last;
+    (void)s_rows;
+    (void)s_flag;
     // (y0 | y1 << 16, x0 | x1 << 16, depth bits, tiles touched); depth bits != 0 <=> visible (depth > near > 0).  The
     // record of a culled Gaussian is unspecified (frame_project_kernel does not write it): not read.
     const uint4 rc = valid ? rects[pid] : make_uint4(0, 0, 0, 0);
     const bool vis = rc.z != 0;
-    const float4 g = vis ? rec_geom[pid * GS_REC_STRIDE] : make_float4(0, 0, 0, 0);
+    // rgb colours: the record is not needed -- sigma(opa) and the sigma(colour)s are recomputed from the raw parameters
+    // (two coalesced streams, the same instructions as project_one: the same bits) instead of gathering one 64-byte
+    // line per visible Gaussian for 16 + 12 of its bytes; only the "dist" listing test needs the projected centre
+    const bool need_rec = CDIM > 3 || P.cull_method == 0;
+    const float4 g = (vis && need_rec) ? rec_geom[pid * GS_REC_STRIDE] : make_float4(0, 0, 0, 0);
     float gp[3] = {0, 0, 0}, gqr[4] = {0, 0, 0, 0}, gsr[3] = {0, 0, 0}, gopa = 0, gcol[3] = {0, 0, 0};
     constexpr int RW4 = gs_row_floats(CDIM) / 4;  // float4s per row
     float4 d0 = make_float4(0, 0, 0, 0), d1 = d0, d2 = d0;
@@ -672,13 +709,21 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
     __shared__ float s_sum[CDIM > 3 ? BLOCK * RS : 1];
     __shared__ uint32_t s_brow[CDIM > 3 ? BLOCK / 64 : 1][64], s_bown[CDIM > 3 ? BLOCK / 64 : 1][64];
 
+    // rgb: does the row of tile (ix, iy) of the Gaussian with key `key` exist?  (`sk` = that tile's stop key)
+    auto row_exists = [&](unsigned long long sk, unsigned long long key, uint32_t ix, uint32_t iy, float cx, float cy) {
+        if (P.cull_method == 0 && !gs_dist_listed(cx, cy, ix, iy, D)) return false;  // "dist": holes in the square
+        return key <= sk;
+    };
+    const uint32_t my_y0 = rc.x & 0xffff, my_x0 = rc.y & 0xffff, my_x1 = rc.y >> 16;
+    const unsigned long long my_key = ((unsigned long long)rc.z << 32) | (unsigned long long)(uint32_t)pid;
+
     // A Gaussian that covers hundreds of tiles (early in training from a sparse cloud; a scale that blew up) would
     // keep ONE thread adding its rows while 255 wait: 195 us instead of 40 us for this kernel in a 500 k-Gaussian fit.
     // Such Gaussians are summed by the whole workgroup first -- thread t takes rows t, t + 256, ... straight from
     // global memory (consecutive threads, consecutive rows), a fixed shuffle tree and a fixed wave order give the
     // total to the owning thread: deterministic -- and are skipped by the per-thread loops below.
     constexpr uint32_t BIG = 256;
-    constexpr int NA = 4 * RW4;
+    constexpr int NA = 12;  // floats of an rgb row that are summed (10 in use)
     constexpr int NBIG = CDIM == 3 ? 256 : 1;  // (SH rows are summed by the whole wave anyway: below)
     __shared__ uint32_t s_nbig, s_big_owner[NBIG];
     __shared__ uint64_t s_big_off[NBIG];
@@ -698,14 +743,26 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
     for (uint32_t b = 0; b < nbig; ++b) {
         const uint64_t boff = s_big_off[b];
         const uint32_t bcnt = s_big_cnt[b];
+        // the owner's rectangle and key (read back from its rectangle record: uniform over the workgroup)
+        const int64_t bpid = pid0 + s_big_owner[b];
+        const uint4 brc = rects[bpid];
+        const uint32_t by0 = brc.x & 0xffff, bx0 = brc.y & 0xffff, bw = (brc.y >> 16) - (brc.y & 0xffff);
+        const unsigned long long bkey = ((unsigned long long)brc.z << 32) | (unsigned long long)(uint32_t)bpid;
+        float bcx = 0.f, bcy = 0.f;
+        if (P.cull_method == 0) {
+            const float4 bg = rec_geom[bpid * GS_REC_STRIDE];
+            bcx = bg.x;
+            bcy = bg.y;
+        }
         float acc[NA];
 #pragma unroll
         for (int e = 0; e < NA; ++e) acc[e] = 0.f;
         for (uint32_t k = threadIdx.x; k < bcnt && boff + k < max_pairs; k += 256) {
-            if (!row_flags[boff + k]) continue;
+            const uint32_t iy = by0 + k / bw, ix = bx0 + k % bw;
+            if (!row_exists(stop_keys[iy * P.ntx + ix], bkey, ix, iy, bcx, bcy)) continue;
             const float4 *row = rows + (boff + k) * RW4;
 #pragma unroll
-            for (int m = 0; m < RW4; ++m) {
+            for (int m = 0; m < NA / 4; ++m) {
                 const float4 r = row[m];
                 acc[4 * m] += r.x; acc[4 * m + 1] += r.y; acc[4 * m + 2] += r.z; acc[4 * m + 3] += r.w;
             }
@@ -728,18 +785,98 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
         __syncthreads();
     }
     if (CDIM == 3) {
-        constexpr uint32_t rows_per_chunk = CHUNK_F4 / 3;
+        // ---- which of this Gaussian's (at most 256) rows exist: four 64-bit words, stop keys loaded eight at a time
+        unsigned long long wmask[4] = {0ull, 0ull, 0ull, 0ull};
+        if (vis && !big && cnt) {
+            uint32_t ix = my_x0, iy = my_y0;  // tile of row k, advanced row by row (no division)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                if ((uint32_t)w * 64u >= cnt) break;
+                unsigned long long m = 0;
+                for (uint32_t k0 = (uint32_t)w * 64u; k0 < (uint32_t)w * 64u + 64u && k0 < cnt; k0 += 8) {
+                    unsigned long long sk[8];
+                    uint32_t tx8[8], ty8[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const bool in = k0 + j < cnt;
+                        tx8[j] = ix;
+                        ty8[j] = iy;
+                        sk[j] = in ? stop_keys[iy * P.ntx + ix] : 0ull;
+                        if (in && ++ix == my_x1) {
+                            ix = my_x0;
+                            ++iy;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (k0 + j < cnt && off + k0 + j < max_pairs && my_key <= sk[j]) m |= 1ull << ((k0 + j) & 63u);
+                    if (P.cull_method == 0) {  // "dist": not every tile of the bounding square is listed (uniform branch)
+                        for (int j = 0; j < 8; ++j)
+                            if (k0 + j < cnt && !gs_dist_listed(g.x, g.y, tx8[j], ty8[j], D)) m &= ~(1ull << ((k0 + j) & 63u));
+                    }
+                }
+                wmask[w] = m;
+            }
+        }
+#if GS_PB_DIRECT
+        // ---- every thread adds its existing rows in ascending order, two rows (six loads) in flight
+        const float4 *myrows = rows + off * RW4;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            unsigned long long m = wmask[w];
+            while (m) {
+                const uint32_t ka = (uint32_t)__ffsll((long long)m) - 1;
+                m &= m - 1;
+                const bool two = m != 0;
+                const uint32_t kb = two ? (uint32_t)__ffsll((long long)m) - 1 : ka;
+                if (two) m &= m - 1;
+                const float4 *ra = myrows + (size_t)(w * 64 + ka) * RW4, *rb = myrows + (size_t)(w * 64 + kb) * RW4;
+                const float4 a0 = ra[0], a1 = ra[1], a2 = ra[2], b0 = rb[0], b1 = rb[1], b2 = rb[2];
+                d0.x += a0.x; d0.y += a0.y; d0.z += a0.z; d0.w += a0.w;
+                d1.x += a1.x; d1.y += a1.y; d1.z += a1.z; d1.w += a1.w;
+                d2.x += a2.x; d2.y += a2.y;
+                if (two) {
+                    d0.x += b0.x; d0.y += b0.y; d0.z += b0.z; d0.w += b0.w;
+                    d1.x += b1.x; d1.y += b1.y; d1.z += b1.z; d1.w += b1.w;
+                    d2.x += b2.x; d2.y += b2.y;
+                }
+            }
+        }
+#else
+        auto mask_bit = [&](uint32_t k) -> bool {  // k < 256
+            const unsigned long long m = k < 64 ? wmask[0] : k < 128 ? wmask[1] : k < 192 ? wmask[2] : wmask[3];
+            return (m >> (k & 63u)) & 1ull;
+        };
         uint64_t row_begin = pair_offsets[pid0];
         uint64_t row_end = (uint64_t)pair_offsets[pid_last] + rects[pid_last].w;
         if (row_end > max_pairs) row_end = max_pairs;
-        for (uint64_t base = row_begin; base < row_end; base += rows_per_chunk) {
-            const uint32_t nrows = row_end - base < rows_per_chunk ? (uint32_t)(row_end - base) : rows_per_chunk;
-            const float4 *src = rows + base * 3;
-            for (uint32_t i = threadIdx.x; i < nrows * 3; i += blockDim.x) s_rows[i] = src[i];
-            for (uint32_t i = threadIdx.x; i < nrows; i += blockDim.x) s_flag[i] = row_flags[base + i];
-            __syncthreads();
+        for (uint64_t base = row_begin; base < row_end; base += CHUNK_ROWS) {
+            const uint32_t nrows = row_end - base < CHUNK_ROWS ? (uint32_t)(row_end - base) : (uint32_t)CHUNK_ROWS;
             const uint64_t lo = off > base ? off : base, hi = off + cnt < base + nrows ? off + cnt : base + nrows;
-            for (uint64_t k = lo; k < hi && !big; ++k) {
+            // 1. every thread marks which of ITS rows inside this chunk exist (a row belongs to exactly one Gaussian;
+            //    the rows of "big" Gaussians were summed above and are marked absent)
+            for (uint64_t k = lo; k < hi; ++k) s_flag[k - base] = !big && mask_bit((uint32_t)(k - off));
+            __syncthreads();
+            // 2. existing rows -> LDS, four lanes per 64-byte row (the fourth quarter is padding: not fetched); all
+            //    loads of the chunk are issued before the first one is stored
+            const float4 *src = rows + base * RW4;
+            constexpr int PER = CHUNK_ROWS * 4 / 256;
+            float4 v[PER];
+            bool take[PER];
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const uint32_t i = threadIdx.x + 256u * u, r = i >> 2, q = i & 3;
+                take[u] = i < nrows * 4 && q < 3 && s_flag[r];
+                if (take[u]) v[u] = src[i];
+            }
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const uint32_t i = threadIdx.x + 256u * u, r = i >> 2, q = i & 3;
+                if (take[u]) s_rows[r * 3 + q] = v[u];
+            }
+            __syncthreads();
+            // 3. every thread adds its existing rows in ascending order
+            for (uint64_t k = lo; k < hi; ++k) {
                 if (!s_flag[k - base]) continue;
                 const float4 *row = s_rows + (k - base) * 3;
                 const float4 r0 = row[0], r1 = row[1], r2 = row[2];
@@ -749,6 +886,7 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
             }
             __syncthreads();
         }
+#endif
     } else {
         // SH rows are 144 (224) contiguous bytes.  A thread walking its own rows issues, per row, nine (fourteen) loads
         // whose 64 lanes touch 64 different rows: the texture-address unit serialises them lane by lane -- PMC, round 2:
@@ -877,10 +1015,10 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
         float gi[3] = {d0.x, d0.y, 0.0f}, g2[4] = {d0.z, d0.w, d1.x, d1.y}, gq[4], gs[3];
         project_backward(p, q, s, P.cam, gi, g2, gp, gq, gs);
         // q_hat = q / |q|  ->  dq = (dq_hat - q_hat (q_hat . dq_hat)) / |q|
-        float nr = sqrtf(qraw[0] * qraw[0] + qraw[1] * qraw[1] + qraw[2] * qraw[2] + qraw[3] * qraw[3]);
+        const float inr = gs_rsq(qraw[0] * qraw[0] + qraw[1] * qraw[1] + qraw[2] * qraw[2] + qraw[3] * qraw[3]);
         float dt = q[0] * gq[0] + q[1] * gq[1] + q[2] * gq[2] + q[3] * gq[3];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) gqr[k] = (gq[k] - q[k] * dt) / nr;
+        for (int k = 0; k < 4; ++k) gqr[k] = (gq[k] - q[k] * dt) * inr;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             if (P.scale_act == 0)  // |s| + 1e-4 : d/ds = sign(s)
@@ -890,12 +1028,17 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
         }
     }
     if (vis && PART != 1) {
-        gopa = d1.z * g.w * (1.0f - g.w);
         if (CDIM == 3) {
-            const float4 c = rec_color[pid * GS_REC_STRIDE];
-            gcol[0] = d1.w * c.x * (1.0f - c.x);
-            gcol[1] = d2.x * c.y * (1.0f - c.y);
-            gcol[2] = d2.y * c.z * (1.0f - c.z);
+            // sigma(opa), sigma(colour): the expressions of project_one, which wrote them into the record
+            const float so = sigmoid_f(opa_raw[pid]);
+            const float c0 = sigmoid_f(rgb_raw[pid * 3 + 0]), c1 = sigmoid_f(rgb_raw[pid * 3 + 1]);
+            const float c2 = sigmoid_f(rgb_raw[pid * 3 + 2]);
+            gopa = d1.z * so * (1.0f - so);
+            gcol[0] = d1.w * c0 * (1.0f - c0);
+            gcol[1] = d2.x * c1 * (1.0f - c1);
+            gcol[2] = d2.y * c2 * (1.0f - c2);
+        } else {
+            gopa = d1.z * g.w * (1.0f - g.w);
         }
     }
     if (PART != 2) {
@@ -1020,7 +1163,9 @@ static ProjectParams make_params(const gs_frame *f) {
     return P;
 }
 
-int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream) {
+// slice_begin / slice_end: the slices of the Gaussian array to project (strip variant with the fused count only:
+// gs_frame_project_slices; every other path projects everything at once: 0, -1)
+int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream, int slice_begin, int slice_end) {
     ProjectParams P = make_params(f);
     // sort_modes 0 / 1 read tiles_touched (emit_pairs_kernel); sort_mode 2 reads the rectangle records only
     uint32_t *touched = f->sort_mode == 2 && gs_frame_geometry(f).n_tiles <= GS_BIN_MAX_TILES ? nullptr : ws.tiles_touched;
@@ -1042,11 +1187,15 @@ int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t strea
         }
         unsigned long long *table = (unsigned long long *)ws.strip_table;
         const size_t lds = sizeof(unsigned long long) * SG.NS;
+        if (slice_end < 0) slice_end = (int)plan.slices;
+        GS_CHECK_ARG(slice_begin >= 0 && slice_begin < slice_end && slice_end <= (int)plan.slices, "bad slice range");
+        const uint32_t nsl = (uint32_t)(slice_end - slice_begin);
+        const uint32_t extra = slice_begin == 0 ? 1u : 0u;  // the tile-order workgroup rides with the first range
 #define GS_LAUNCH_PROJECT_COUNT(DIST)                                                                                  \
-    hipLaunchKernelGGL(frame_project_count_kernel<DIST>, dim3(plan.slices + 1), dim3(STRIP_THREADS), lds, stream,      \
+    hipLaunchKernelGGL(frame_project_count_kernel<DIST>, dim3(nsl + extra), dim3(STRIP_THREADS), lds, stream,          \
                        f->pos, (const float4 *)f->quat, f->scale, f->opa, f->rgb, f->N, P, ws.rec_geom, touched,       \
-                       ws.rects, D, plan.per_slice, SG, plan.slices, table, ws.slice_pairs, ws.slice_vis,              \
-                       ws.tile_cost, (uint32_t)G.n_tiles, ws.tile_order)
+                       ws.rects, D, plan.per_slice, SG, nsl, (uint32_t)slice_begin, table, ws.slice_pairs,             \
+                       ws.slice_vis, ws.tile_cost, (uint32_t)G.n_tiles, ws.tile_order)
         if (f->tile_culling_method == 0)
             GS_LAUNCH_PROJECT_COUNT(true);
         else
@@ -1055,6 +1204,7 @@ int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t strea
         GS_CHECK_LAUNCH();
         return 0;
     }
+    GS_CHECK_ARG(slice_begin == 0 && slice_end < 0, "this frame's project stage cannot be issued in ranges");
     if (gs_frame_fused_table_count(f)) {
         gs_frame_geom G = gs_frame_geometry(f);
         GsDistCull D = {(float)(G.padW / 2), (float)(G.padH / 2), f->focal_x, f->focal_y, f->thresh};
@@ -1090,15 +1240,22 @@ int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t strea
     return 0;
 }
 
+// Gaussians [g_begin, g_end) only (g_begin a multiple of 256; the whole array: 0, N): the view-parallel exchange sums
+// the rows slice by slice, so that a slice's gradients travel while the next slice is summed (gs_dp.py).
 int gs_stage_project_backward(const gs_frame *f, const gs_frame_ws &ws, float *grad_pos, float *grad_quat,
-                              float *grad_scale, float *grad_opa, float *grad_rgb, int part, hipStream_t stream) {
+                              float *grad_scale, float *grad_opa, float *grad_rgb, int part, int64_t g_begin,
+                              int64_t g_end, hipStream_t stream) {
+    if (g_end <= g_begin) return 0;
     ProjectParams P = make_params(f);
+    gs_frame_geom Gf = gs_frame_geometry(f);
+    GsDistCull Dc = {(float)(Gf.padW / 2), (float)(Gf.padH / 2), f->focal_x, f->focal_y, f->thresh};
 #define GS_LAUNCH_PROJECT_BWD(CD, PT)                                                                              \
-    hipLaunchKernelGGL((frame_project_backward_kernel<CD, PT>), dim3((unsigned)gs_div_up(f->N, CD == 3 ? 256 : 128)), \
+    hipLaunchKernelGGL((frame_project_backward_kernel<CD, PT>),                                                   \
+                       dim3((unsigned)gs_div_up(g_end - g_begin, CD == 3 ? 256 : 128)),                           \
                        dim3(CD == 3 ? 256 : 128), 0, stream, f->pos,                                              \
-                       (const float4 *)f->quat, f->scale, f->N, P, ws.rec_geom, ws.rec_color,                     \
-                       (const float4 *)ws.rows, ws.row_flags, ws.pair_offsets, ws.rects,                          \
-                       (uint64_t)f->max_pairs,                                                                    \
+                       (const float4 *)f->quat, f->scale, g_end, P, ws.rec_geom, ws.rec_color,                    \
+                       (const float4 *)ws.rows, ws.row_flags, (const unsigned long long *)ws.stop_keys, f->opa,   \
+                       f->rgb, Dc, ws.pair_offsets, ws.rects, (uint64_t)f->max_pairs, g_begin,                    \
                        grad_pos, (float4 *)grad_quat, grad_scale, grad_opa, grad_rgb)
 #define GS_LAUNCH_PROJECT_BWD_PARTS(CD)  \
     do {                                 \

@@ -87,6 +87,7 @@ __device__ __forceinline__ float gs_wave_shr1(float old, float src) {
 // 2^x on the transcendental unit (v_exp_f32)
 __device__ __forceinline__ float gs_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float gs_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float gs_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 
 #define GS_LOG2E 1.4426950408889634f
 #define GS_LN2 0.6931471805599453f

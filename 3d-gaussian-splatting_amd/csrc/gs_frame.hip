@@ -202,7 +202,7 @@ extern "C" int gs_frame_async_destroy(gs_frame_async *a) {
     return 0;
 }
 
-static void prepare_on_side_stream(const gs_frame *f, const gs_frame_ws &ws, hipStream_t s) {
+static void prepare_on_side_stream(const gs_frame *f, const gs_frame_ws &ws, const uint32_t *sorted_ids, hipStream_t s) {
     gs_frame_async *a = (gs_frame_async *)f->async;
     if (!a) return;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -212,7 +212,7 @@ static void prepare_on_side_stream(const gs_frame *f, const gs_frame_ws &ws, hip
     std::lock_guard<std::mutex> lock(a->mu);
     a->pending = false;
     if (hipEventRecord(a->fork, s) != hipSuccess || hipStreamWaitEvent(a->side, a->fork, 0) != hipSuccess) return;
-    if (gs_stage_backward_prepare(f, ws, a->side) != 0) return;
+    if (gs_stage_backward_prepare(f, ws, sorted_ids, a->side) != 0) return;
     if (hipEventRecord(a->done, a->side) != hipSuccess) return;
     a->pending = true;
 }
@@ -227,20 +227,35 @@ static bool join_prepared(const gs_frame *f, hipStream_t s) {
     return hipStreamWaitEvent(s, a->done, 0) == hipSuccess;
 }
 
-static int frame_forward_impl(const gs_frame *f, hipStream_t s, float *stage_ms) {
+// The forward in two phases: PROJECT (cull + project + activations + level-1 count; with the strip variant's fused count
+// it may be issued as several ranges of slices of the Gaussian array, in any order, slice 0's range first) and REST
+// (binning, per-tile sort, compositing).  gs_frame_forward = both; gs_frame_forward_project / _rest expose them to the
+// view-parallel trainer, which projects the NEXT frame's Gaussians range by range as their parameters come out of the
+// optimizer, underneath the gradient exchange of the remaining ranges (gs_dp.py).
+// phases: 1 = project, 2 = rest, 3 = both
+static int frame_forward_impl(const gs_frame *f, hipStream_t s, float *stage_ms, int phases = 3, int slice_begin = 0,
+                              int slice_end = -1) {
     int rc = validate(f);
     if (rc) return rc;
     GS_CHECK_ARG(!f->training || f->image_padded, "training needs image_padded");
     GS_CHECK_ARG(f->image || f->image_padded, "no output image");
     gs_frame_ws ws = gs_frame_carve(f->workspace, f->N, f->max_pairs, f->width, f->height, f->color_dim, f->training);
     gs_frame_geom G = gs_frame_geometry(f);
-    // a forward whose backward never came may still be zero-filling this workspace on the side stream
-    (void)join_prepared(f, s);
     StageTimer tm(stage_ms != nullptr, s);
-    tm.mark();
-    // sort_mode 2 writes every counter and every tile range itself (tile_bin.hip, workgroup 0)
-    if (effective_sort_mode(f) != 2 || f->N == 0) GS_HIP(hipMemsetAsync(ws.counters, 0, ws.zero_bytes, s));
-    if (f->N > 0 && (rc = gs_stage_project(f, ws, s))) return rc;
+    if (phases & 1) {
+        if (slice_begin == 0) {
+            // a forward whose backward never came may still be zero-filling this workspace on the side stream
+            (void)join_prepared(f, s);
+        }
+        tm.mark();
+        // sort_mode 2 writes every counter and every tile range itself (tile_bin.hip, workgroup 0)
+        if ((effective_sort_mode(f) != 2 || f->N == 0) && slice_begin == 0)
+            GS_HIP(hipMemsetAsync(ws.counters, 0, ws.zero_bytes, s));
+        if (f->N > 0 && (rc = gs_stage_project(f, ws, s, slice_begin, slice_end))) return rc;
+        if (!(phases & 2)) return 0;
+    } else {
+        tm.mark();
+    }
     tm.mark();
     uint64_t *skeys, *okeys;
     uint32_t *sids;
@@ -286,12 +301,39 @@ static int frame_forward_impl(const gs_frame *f, hipStream_t s, float *stage_ms)
     tm.mark();  // stage "ranges" = tile ranges (+ the per-tile depth sort in mode 1)
     if ((rc = gs_stage_raster_forward(f, ws, sids, s))) return rc;
     tm.mark();
-    if (f->training && f->N > 0) prepare_on_side_stream(f, ws, s);
+    if (f->training && f->N > 0) prepare_on_side_stream(f, ws, sids, s);
     return tm.finish(stage_ms, GS_N_STAGES);
 }
 
 extern "C" int gs_frame_forward(const gs_frame *f, gs_stream_t stream) {
     return frame_forward_impl(f, (hipStream_t)stream, nullptr);
+}
+
+// How the project phase of this frame may be cut: *slices = number of slices of the Gaussian array (0: the frame's
+// project stage cannot be issued in ranges -- only the strip variant with the fused count can), *per_slice = Gaussians per
+// slice (a multiple of 256; the last slice may be short).
+extern "C" int gs_frame_project_slices(const gs_frame *f, int32_t *slices, int64_t *per_slice) {
+    int rc = validate(f);
+    if (rc) return rc;
+    GS_CHECK_ARG(slices && per_slice, "null pointer");
+    *slices = 0;
+    *per_slice = 0;
+    if (f->N > 0 && effective_sort_mode(f) == 2 && gs_frame_fused_count(f)) {
+        gs_frame_geom G = gs_frame_geometry(f);
+        const gs_strip_plan plan = gs_strip_plan_for(f->N, G.ntx, G.nty);
+        *slices = (int32_t)plan.slices;
+        *per_slice = plan.per_slice;
+    }
+    return 0;
+}
+
+extern "C" int gs_frame_forward_project(const gs_frame *f, int32_t slice_begin, int32_t slice_end, gs_stream_t stream) {
+    GS_CHECK_ARG(slice_begin >= 0 && slice_end > slice_begin, "bad slice range");
+    return frame_forward_impl(f, (hipStream_t)stream, nullptr, 1, slice_begin, slice_end);
+}
+
+extern "C" int gs_frame_forward_rest(const gs_frame *f, gs_stream_t stream) {
+    return frame_forward_impl(f, (hipStream_t)stream, nullptr, 2);
 }
 
 extern "C" int gs_frame_forward_profile(const gs_frame *f, float *stage_ms_host, gs_stream_t stream) {
@@ -303,13 +345,17 @@ extern "C" int gs_frame_forward_profile(const gs_frame *f, float *stage_ms_host,
 // GS_BWD_GEOMETRY (2) = grad_pos / quat / scale and GS_BWD_COLOR (4) = grad_opa / rgb from those rows, in any order.
 static int frame_backward_impl(const gs_frame *f, const float *grad_image, float *grad_pos, float *grad_quat,
                                float *grad_scale, float *grad_opa, float *grad_rgb, int part, hipStream_t s,
-                               float *stage_ms) {
+                               float *stage_ms, int64_t g_begin = 0, int64_t g_end = -1) {
     int rc = validate(f);
     if (rc) return rc;
+    if (g_end < 0) g_end = f->N;
+    GS_CHECK_ARG(g_begin >= 0 && g_begin <= g_end && g_end <= f->N && (g_begin & 255) == 0,
+                 "bad Gaussian range (g_begin must be a multiple of 256)");
     GS_CHECK_ARG(f->training && f->image_padded, "gs_frame_backward needs a training forward (image_padded kept)");
-    GS_CHECK_ARG(part == 0 || part == GS_BWD_RASTER || part == GS_BWD_GEOMETRY || part == GS_BWD_COLOR,
+    // (part -1, internal: the projection backward alone, both buckets in one kernel -- gs_frame_backward_slice)
+    GS_CHECK_ARG(part == -1 || part == 0 || part == GS_BWD_RASTER || part == GS_BWD_GEOMETRY || part == GS_BWD_COLOR,
                  "part must be 0, GS_BWD_RASTER, GS_BWD_GEOMETRY or GS_BWD_COLOR");
-    GS_CHECK_ARG(part == GS_BWD_GEOMETRY || part == GS_BWD_COLOR || grad_image, "null pointer");
+    GS_CHECK_ARG(part == -1 || part == GS_BWD_GEOMETRY || part == GS_BWD_COLOR || grad_image, "null pointer");
     GS_CHECK_ARG(part == GS_BWD_RASTER || part == GS_BWD_COLOR || (grad_pos && grad_quat && grad_scale), "null pointer");
     GS_CHECK_ARG(part == GS_BWD_RASTER || part == GS_BWD_GEOMETRY || (grad_opa && grad_rgb), "null pointer");
     GS_CHECK_ARG(((uintptr_t)grad_quat & 15) == 0, "grad_quat must be 16-byte aligned");
@@ -321,13 +367,14 @@ static int frame_backward_impl(const gs_frame *f, const float *grad_image, float
     StageTimer tm(stage_ms != nullptr, s);
     tm.mark();
     if (part == 0 || part == GS_BWD_RASTER) {
+        GS_CHECK_ARG(g_begin == 0 && g_end == f->N, "the raster backward has no Gaussian range");
         const bool prepared = join_prepared(f, s);
         if ((rc = gs_stage_raster_backward(f, ws, sids, grad_image, s, prepared))) return rc;
     }
     tm.mark();
     if (part != GS_BWD_RASTER &&
         (rc = gs_stage_project_backward(f, ws, grad_pos, grad_quat, grad_scale, grad_opa, grad_rgb,
-                                        part == GS_BWD_GEOMETRY ? 1 : part == GS_BWD_COLOR ? 2 : 0, s)))
+                                        part == GS_BWD_GEOMETRY ? 1 : part == GS_BWD_COLOR ? 2 : 0, g_begin, g_end, s)))
         return rc;
     tm.mark();
     return tm.finish(stage_ms, 3);
@@ -346,6 +393,23 @@ extern "C" int gs_frame_backward_part(const gs_frame *f, const float *grad_image
                  "part must be GS_BWD_RASTER, GS_BWD_GEOMETRY or GS_BWD_COLOR");
     return frame_backward_impl(f, grad_image, grad_pos, grad_quat, grad_scale, grad_opa, grad_rgb, part,
                                (hipStream_t)stream, nullptr);
+}
+
+// The per-Gaussian sums (projection + activation backward) of Gaussians [g_begin, g_end) only; `part` = GS_BWD_GEOMETRY,
+// GS_BWD_COLOR or both.  After gs_frame_backward_part(GS_BWD_RASTER); any partition of [0, N) into ranges gives exactly
+// what gs_frame_backward writes.
+extern "C" int gs_frame_backward_slice(const gs_frame *f, float *grad_pos, float *grad_quat, float *grad_scale,
+                                       float *grad_opa, float *grad_rgb, int32_t part, int64_t g_begin, int64_t g_end,
+                                       gs_stream_t stream) {
+    GS_CHECK_ARG(part == GS_BWD_GEOMETRY || part == GS_BWD_COLOR || part == (GS_BWD_GEOMETRY | GS_BWD_COLOR),
+                 "part must be GS_BWD_GEOMETRY, GS_BWD_COLOR or both");
+    if (part == (GS_BWD_GEOMETRY | GS_BWD_COLOR)) {  // everything of the range in one kernel: the rows are read once
+        GS_CHECK_ARG(grad_pos && grad_quat && grad_scale && grad_opa && grad_rgb, "null pointer");
+        return frame_backward_impl(f, nullptr, grad_pos, grad_quat, grad_scale, grad_opa, grad_rgb, -1,
+                                   (hipStream_t)stream, nullptr, g_begin, g_end);
+    }
+    return frame_backward_impl(f, nullptr, grad_pos, grad_quat, grad_scale, grad_opa, grad_rgb, part,
+                               (hipStream_t)stream, nullptr, g_begin, g_end);
 }
 
 extern "C" int gs_frame_backward_profile(const gs_frame *f, const float *grad_image, float *grad_pos,

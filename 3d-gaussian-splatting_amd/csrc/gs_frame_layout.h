@@ -131,8 +131,10 @@ static inline bool gs_frame_fused_table_count(const gs_frame *f) {
 
 // floats per per-pair gradient row: (dx, dy, da, db, dc, dd, dopa) + colour grads, padded to float4s
 // floats per (tile, Gaussian) gradient row: 7 geometry/opacity sums + color_dim colour sums, rounded up to float4s
-// (12 / 36 / 56 for color_dim 3 / 27 / 48)
-static constexpr int gs_row_floats(int color_dim) { return (7 + color_dim + 3) / 4 * 4; }
+// (36 / 56 for color_dim 27 / 48).  rgb colours (10 floats): the row is padded to ONE aligned 64-byte line (16 floats), which
+// the raster backward writes with a single store instruction (four lanes x 16 bytes) -- a 48-byte row straddled two
+// lines every other time and reached HBM as 32-byte partial writes (round 3, PMC: 134 B written per 48-byte row).
+static constexpr int gs_row_floats(int color_dim) { return color_dim == 3 ? 16 : (7 + color_dim + 3) / 4 * 4; }
 
 struct gs_frame_geom {
     int padW, padH, ntx, nty, n_tiles, crop_top, crop_left;
@@ -209,8 +211,12 @@ struct gs_frame_ws {
     uint4 *bucket_info;            // [max_buckets + 8] (tile, first Gaussian, count, list start) per bucket
     float4 *ckpt;                  // [max_buckets][256] (T, Cr, Cg, Cb) at bucket starts
     float *rows;                   // [max_pairs][GS_ROW(C)] per-pair gradient rows in EMISSION order
-    uint8_t *row_flags;            // [max_pairs] 1 = the raster backward wrote this row (cleared per frame: the rows
-                                   // themselves are never zero-filled, unwritten ones are skipped by the reader)
+    uint8_t *row_flags;            // [max_pairs] SH rows: 1 = the raster backward wrote this row (cleared per frame: the
+                                   // rows themselves are never zero-filled, unwritten ones are skipped by the reader)
+    uint64_t *stop_keys;           // [T] (depth bits << 32 | Gaussian) of the LAST list entry the forward processed in
+                                   // each tile (0: none).  A tile's list ascends in exactly this key, so the pair
+                                   // (tile, g) was processed -- its gradient row written -- iff key(g) <= stop_keys[tile]:
+                                   // the rgb reader needs no per-row flag (stop_key_kernel, raster_bwd.hip)
     int64_t max_buckets;
     size_t zero_bytes;             // prefix of the workspace cleared at the start of every frame
     size_t total_bytes;
@@ -299,6 +305,7 @@ static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pair
         ws.ckpt = (float4 *)take(sizeof(float4) * 256 * (size_t)ws.max_buckets);
         ws.rows = (float *)take(sizeof(float) * (size_t)gs_row_floats(color_dim) * max_pairs);
         ws.row_flags = (uint8_t *)take((size_t)max_pairs);
+        ws.stop_keys = (uint64_t *)take(sizeof(uint64_t) * G.n_tiles);
     } else {
         ws.tile_nproc = nullptr;
         ws.bucket_offsets = nullptr;
@@ -306,15 +313,17 @@ static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pair
         ws.ckpt = nullptr;
         ws.rows = nullptr;
         ws.row_flags = nullptr;
+        ws.stop_keys = nullptr;
     }
     ws.total_bytes = off;
     return ws;
 }
 
 // stage entry points (defined across the .hip files)
-int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream);
+int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream, int slice_begin = 0, int slice_end = -1);
 int gs_stage_project_backward(const gs_frame *f, const gs_frame_ws &ws, float *grad_pos, float *grad_quat,
-                              float *grad_scale, float *grad_opa, float *grad_rgb, int part, hipStream_t stream);
+                              float *grad_scale, float *grad_opa, float *grad_rgb, int part, int64_t g_begin,
+                              int64_t g_end, hipStream_t stream);
 int gs_stage_scan_emit(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream);
 int gs_stage_tile_sort(const gs_frame *f, const gs_frame_ws &ws, uint64_t *keys, uint32_t *ids, uint64_t *scratch,
                        hipStream_t stream);
@@ -328,6 +337,6 @@ int gs_stage_tile_sort_gather(const gs_frame *f, const gs_frame_ws &ws, const ui
                               uint64_t *big_scratch, uint64_t *keys_out, uint32_t *ids_out, hipStream_t stream);
 int gs_stage_tile_ranges(const gs_frame *f, const gs_frame_ws &ws, const uint64_t *sorted_keys, hipStream_t stream);
 int gs_stage_raster_forward(const gs_frame *f, const gs_frame_ws &ws, const uint32_t *sorted_ids, hipStream_t stream);
-int gs_stage_backward_prepare(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream);
+int gs_stage_backward_prepare(const gs_frame *f, const gs_frame_ws &ws, const uint32_t *sorted_ids, hipStream_t stream);
 int gs_stage_raster_backward(const gs_frame *f, const gs_frame_ws &ws, const uint32_t *sorted_ids,
                              const float *grad_image, hipStream_t stream, bool prepared);

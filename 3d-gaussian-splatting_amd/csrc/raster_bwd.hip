@@ -80,6 +80,27 @@ __global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t *__res
     }
 }
 
+// Frame path, rgb rows: the key (depth bits << 32 | Gaussian) of the last list entry the forward processed in every
+// tile (0: none).  A tile's list ascends in exactly this key and the key is unique, so "pair (tile, g) was processed --
+// its gradient row written" <=> key(g) <= stop_keys[tile]: what the projection backward needs to know about a row
+// without a flag per row (no scattered flag stores, no flag memset; gs_frame_layout.h).  One thread per tile, three
+// dependent loads; runs with the bucket scan underneath the caller's loss.
+__global__ void __launch_bounds__(256) stop_key_kernel(const uint32_t *__restrict__ tile_nproc, int n_tiles,
+                                                       const int32_t *__restrict__ ranges,
+                                                       const uint32_t *__restrict__ sorted_ids,
+                                                       const uint4 *__restrict__ rects,
+                                                       unsigned long long *__restrict__ stop_keys) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_tiles) return;
+    const uint32_t np = tile_nproc[i];
+    unsigned long long key = 0;
+    if (np) {
+        const uint32_t id = sorted_ids[(uint32_t)ranges[2 * i] + np - 1];
+        key = ((unsigned long long)rects[id].z << 32) | id;
+    }
+    stop_keys[i] = key;
+}
+
 struct BwdOut {
     // FRAME: one row per pair, addressed in EMISSION order (pair_offsets[g] + index of the tile
     // inside g's rectangle), so the per-Gaussian sum is a contiguous, deterministic reduction
@@ -678,7 +699,7 @@ __global__ void __launch_bounds__(64 * GS_PP_WPB) raster_backward_pixel_kernel(R
             const uint32_t y0 = rc.x & 0xffff, x0 = rc.y & 0xffff, x1 = rc.y >> 16;
             const uint64_t slot = (uint64_t)O.pair_offsets[gid] + (ty - y0) * (x1 - x0) + (tx - x0);
             if (slot < O.max_pairs) {
-                float4 *row = reinterpret_cast<float4 *>(O.rows + slot * 12);
+                float4 *row = reinterpret_cast<float4 *>(O.rows + slot * gs_row_floats(3));
                 O.row_flags[slot] = 1;
                 row[0] = make_float4(ogx, ogy, ga, gb);
                 row[1] = make_float4(gcc, gd, t[6], t[7]);
@@ -746,8 +767,15 @@ raster_backward_pixel_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
     // (same-box A/B, round 3: 0.377 -> 0.359 ms at cfg2, 0.547 -> 0.515 ms at 2.4 M Gaussians)
     __shared__ float s_red[(NROW < 16 ? NROW : 16) * 65];
     __shared__ float s_part[NROW][4];      // quarter-row sums of the first reduction level
-    __shared__ float s_tot[64][8];         // geometry sums per Gaussian (Sx Sy Sxx Sxy Syy Sq)
-    __shared__ float *s_row[64];           // where Gaussian i's gradient row starts (nullptr: no row)
+    // geometry sums per Gaussian (Sx Sy Sxx Sxy Syy Sq).  rgb frame rows: also the opacity and the three colour sums --
+    // the complete 10-float row is put together here and leaves as ONE aligned 64-byte line at the end of the bucket
+    // (four lanes x 16 bytes).  Round 3 stored floats 6..9 of a row from the Gaussian loop and the geometry part after
+    // it: two or three partial 32-byte sectors per 48-byte row plus a flag byte = 134 bytes of HBM writes per row.
+    constexpr bool STAGED = FRAME && CDIM == 3;
+    constexpr int TOTW = STAGED ? 10 : 8;
+    __shared__ float s_tot[64][TOTW];
+    __shared__ uint32_t s_slot[64];        // FRAME: emission slot of Gaussian i's gradient row (GS_NO_SLOT: no row)
+    constexpr uint32_t GS_NO_SLOT = 0xffffffffu;
     auto lds_order = [] {
         asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
@@ -810,21 +838,19 @@ raster_backward_pixel_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
             s_g[FC2][lane] = r2;
         }
         s_id[lane] = FRAME ? gid : jl;
-        float *row = nullptr;
-        if (valid) {
-            if (FRAME) {
-                const uint4 rc = O.rects[gid];
-                const uint32_t y0 = rc.x & 0xffff, x0 = rc.y & 0xffff, x1 = rc.y >> 16;
-                const uint64_t slot = (uint64_t)O.pair_offsets[gid] + (ty - y0) * (x1 - x0) + (tx - x0);
-                if (slot < O.max_pairs) {
-                    row = O.rows + slot * gs_row_floats(CDIM);
-                    O.row_flags[slot] = 1;  // every float of the row is written below (coefficients, geometry, padding)
-                }
-            } else {
-                row = O.grad_rgb;  // reference API: separate arrays, addressed through s_id below
+        uint32_t myslot = GS_NO_SLOT;
+        if (valid && FRAME) {
+            const uint4 rc = O.rects[gid];
+            const uint32_t y0 = rc.x & 0xffff, x0 = rc.y & 0xffff, x1 = rc.y >> 16;
+            const uint64_t slot = (uint64_t)O.pair_offsets[gid] + (ty - y0) * (x1 - x0) + (tx - x0);
+            if (slot < O.max_pairs) {  // (max_pairs < 2^30: gs_frame validate)
+                myslot = (uint32_t)slot;
+                // SH rows are flagged (every float of the row is written below: coefficients, geometry, padding); rgb
+                // rows need no flag: the reader derives "written" from the tile's stop key (gs_frame_layout.h)
+                if (CDIM > 3) O.row_flags[slot] = 1;
             }
         }
-        s_row[lane] = row;
+        s_slot[lane] = myslot;
     }
     // pixel pairs: h = 0: rows y0, y0 + 4 (k = 0, 1); h = 1: rows y0 + 8, y0 + 12 (k = 2, 3)
     f2 py2[2], T[2], rho[2], g0[2], g1[2], g2[2], SHB[2][NB];
@@ -1023,11 +1049,11 @@ raster_backward_pixel_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
         }
         if (lane < NROW) {
             const float t = (s_part[lane][0] + s_part[lane][1]) + (s_part[lane][2] + s_part[lane][3]);
-            if (lane < 6) {
+            if (lane < 6 || STAGED) {
                 s_tot[i][lane] = t;
             } else if (FRAME) {
-                float *row = s_row[i];
-                if (row) row[lane] = t;  // float 6 of a row: sum dL/dalpha G (opacity); 7 + m: coefficient m
+                const uint32_t sl = s_slot[i];  // float 6 of a row: sum dL/dalpha G (opacity); 7 + m: coefficient m
+                if (sl != GS_NO_SLOT) O.rows[(size_t)sl * gs_row_floats(CDIM) + lane] = t;
             } else {
                 const size_t j = id_i;
                 if (lane == 6)
@@ -1047,12 +1073,16 @@ raster_backward_pixel_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
         const float ogx = GS_LN2 * (2.0f * cA * Sx - cB * Sy), ogy = GS_LN2 * (2.0f * cC * Sy - cB * Sx);
         const float ga = iPn * (-Syy + 2.0f * d * Su), gb = iPn * (Sxy - 2.0f * cc * Su);
         const float gcc = iPn * (Sxy - 2.0f * b * Su), gd = iPn * (-Sxx + 2.0f * a * Su);
-        if (FRAME) {
-            float *row = s_row[lane];
-            if (row) {
+        if (STAGED) {  // the finished geometry part replaces the sums it was computed from (this lane's own entries)
+            float *t2 = s_tot[lane];
+            t2[0] = ogx; t2[1] = ogy; t2[2] = ga; t2[3] = gb; t2[4] = gcc; t2[5] = gd;
+        } else if (FRAME) {
+            const uint32_t sl = s_slot[lane];
+            if (sl != GS_NO_SLOT) {
+                constexpr int RW = gs_row_floats(CDIM);
+                float *row = O.rows + (size_t)sl * RW;
                 reinterpret_cast<float4 *>(row)[0] = make_float4(ogx, ogy, ga, gb);
                 reinterpret_cast<float2 *>(row)[2] = make_float2(gcc, gd);
-                constexpr int RW = gs_row_floats(CDIM);
 #pragma unroll
                 for (int m = 7 + CDIM; m < RW; ++m) row[m] = 0.f;  // padding of the row
             }
@@ -1061,6 +1091,24 @@ raster_backward_pixel_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
             O.grad_pos[j * 3 + 0] = ogx;
             O.grad_pos[j * 3 + 1] = ogy;
             reinterpret_cast<float4 *>(O.grad_cov)[j] = make_float4(ga, gb, gcc, gd);
+        }
+    }
+    if constexpr (STAGED) {
+        // rows leave as whole 64-byte lines: lane l stores quarter l % 4 of row 16 it + l / 4 -- sixteen rows per store
+        // instruction, every line written completely by one instruction (floats 10..15 are zero padding)
+        lds_order();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const uint32_t j = 16u * it + ((uint32_t)lane >> 2), qd = (uint32_t)lane & 3u;
+            if (j >= r) break;  // (lanes of one row leave together; rows beyond r do not exist)
+            const uint32_t sl = s_slot[j];
+            if (sl == GS_NO_SLOT) continue;
+            const float *t = s_tot[j];
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (qd == 0) v = make_float4(t[0], t[1], t[2], t[3]);
+            else if (qd == 1) v = make_float4(t[4], t[5], t[6], t[7]);
+            else if (qd == 2) v = make_float4(t[8], t[9], 0.f, 0.f);
+            reinterpret_cast<float4 *>(O.rows + (size_t)sl * gs_row_floats(3))[qd] = v;
         }
     }
 }
@@ -1200,14 +1248,21 @@ extern "C" int gs_draw_backward(const float *pos, const float *rgb, const float 
     return 0;
 }
 
-// What the backward needs from the forward alone: cleared row flags (one byte per pair: rows of pairs behind a tile's
-// early-termination point are never written, and the reader skips rows whose flag is not set -- the rows themselves,
-// 48 to 224 bytes per pair, are no longer zero-filled: 1.1 GB per frame at 2.4 M Gaussians with SH) and the bucket
+// What the backward needs from the forward alone: which rows will exist -- rows of pairs behind a tile's
+// early-termination point are never written, and the reader must skip them; the rows themselves, 64 to 224 bytes per
+// pair, are not zero-filled (1.1 GB per frame at 2.4 M Gaussians with SH).  SH rows: one flag byte per pair, cleared
+// here and set by the writer; rgb rows (round 4): nothing per pair at all, one "stop key" per TILE -- and the bucket
 // work list.  gs_frame_forward runs it on a side stream underneath
 // whatever the caller does between forward and backward (the loss); gs_frame_backward runs it inline otherwise.
-int gs_stage_backward_prepare(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream) {
+int gs_stage_backward_prepare(const gs_frame *f, const gs_frame_ws &ws, const uint32_t *sorted_ids, hipStream_t stream) {
     gs_frame_geom FG = gs_frame_geometry(f);
-    GS_HIP(hipMemsetAsync(ws.row_flags, 0, (size_t)f->max_pairs, stream));
+    // rgb rows carry no flags: the reader decides from the tiles' stop keys which rows exist
+    if (f->color_dim != 3)
+        GS_HIP(hipMemsetAsync(ws.row_flags, 0, (size_t)f->max_pairs, stream));
+    else
+        hipLaunchKernelGGL(stop_key_kernel, dim3((unsigned)gs_div_up(FG.n_tiles, 256)), dim3(256), 0, stream,
+                           ws.tile_nproc, FG.n_tiles, ws.tile_ranges, sorted_ids, ws.rects,
+                           (unsigned long long *)ws.stop_keys);
     hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, ws.tile_nproc, FG.n_tiles,
                        ws.bucket_offsets, ws.counters + GS_CNT_BUCKETS, ws.bucket_info, ws.tile_ranges, 1);
     GS_CHECK_LAUNCH();
@@ -1242,7 +1297,7 @@ int gs_stage_raster_backward(const gs_frame *f, const gs_frame_ws &ws, const uin
         G.vdy[i] = f->vec_dy[i];
     }
     if (!prepared) {
-        const int rc = gs_stage_backward_prepare(f, ws, stream);
+        const int rc = gs_stage_backward_prepare(f, ws, sorted_ids, stream);
         if (rc) return rc;
     }
     BwdIn I = {f->image_padded, grad_image, ws.ckpt, ws.tile_nproc, ws.bucket_offsets, ws.bucket_info, ws.tile_ranges};

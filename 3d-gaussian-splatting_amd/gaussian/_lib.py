@@ -83,6 +83,10 @@ gs_frame_forward = _sig("gs_frame_forward", ci, C.POINTER(GsFrame), vp)
 gs_frame_backward = _sig("gs_frame_backward", ci, C.POINTER(GsFrame), vp, vp, vp, vp, vp, vp, vp)
 gs_frame_backward_part = _sig("gs_frame_backward_part", ci, C.POINTER(GsFrame), vp, vp, vp, vp, vp, vp, i32, vp)
 GS_BWD_RASTER, GS_BWD_GEOMETRY, GS_BWD_COLOR = 1, 2, 4
+gs_frame_backward_slice = _sig("gs_frame_backward_slice", ci, C.POINTER(GsFrame), vp, vp, vp, vp, vp, i32, i64, i64, vp)
+gs_frame_project_slices = _sig("gs_frame_project_slices", ci, C.POINTER(GsFrame), C.POINTER(i32), C.POINTER(i64))
+gs_frame_forward_project = _sig("gs_frame_forward_project", ci, C.POINTER(GsFrame), i32, i32, vp)
+gs_frame_forward_rest = _sig("gs_frame_forward_rest", ci, C.POINTER(GsFrame), vp)
 gs_frame_forward_profile = _sig("gs_frame_forward_profile", ci, C.POINTER(GsFrame), C.POINTER(f32), vp)
 gs_frame_backward_profile = _sig("gs_frame_backward_profile", ci, C.POINTER(GsFrame), vp, vp, vp, vp, vp, vp,
                                  C.POINTER(f32), vp)
@@ -101,6 +105,9 @@ gs_adam_step_range = _sig("gs_adam_step_range", ci, vp, vp, vp, vp, i64, i64, i6
                           f32, f32, f32, i64, vp, i64, i64, i32, vp)
 gs_adam_step_sharded = _sig("gs_adam_step_sharded", ci, vp, vp, vp, vp, i64, i64, i64, i64, i32, C.POINTER(i64),
                             C.POINTER(f32), f32, f32, f32, i64, vp, i64, i64, i32, vp, vp)
+gs_adam_step_multi = _sig("gs_adam_step_multi", ci, vp, vp, vp, vp, i64, i32, C.POINTER(i64), C.POINTER(i64),
+                          C.POINTER(i64), i32, C.POINTER(i64), C.POINTER(f32), f32, f32, f32, i64, vp, i64, i64, i32, vp,
+                          vp)
 gs_frame_overflow_flag = _sig("gs_frame_overflow_flag", ci, C.POINTER(GsFrame), C.POINTER(vp))
 gs_grad_stat_update = _sig("gs_grad_stat_update", ci, vp, vp, i64, i32, vp)
 gs_frame_async_create = _sig("gs_frame_async_create", ci, C.POINTER(vp))
@@ -132,6 +139,8 @@ EXPORTS = [
     "gs_sort_pairs_tmp_bytes", "gs_sort_pairs", "gs_sort_pairs_bits", "gs_frame_workspace_bytes", "gs_frame_forward",
     "gs_frame_stats_async", "gs_frame_longest_list_async", "gs_frame_debug_views", "gs_frame_debug_rects", "gs_frame_binning_variant", "gs_frame_debug_tile_nproc", "gs_frame_backward", "gs_frame_forward_profile",
     "gs_frame_backward_part", "gs_frame_async_create", "gs_frame_async_wait", "gs_frame_async_destroy",
+    "gs_frame_backward_slice", "gs_frame_project_slices", "gs_frame_forward_project", "gs_frame_forward_rest",
+    "gs_adam_step_multi",
     "gs_frame_backward_profile", "gs_adam_step", "gs_adam_step_range", "gs_adam_step_sharded", "gs_frame_overflow_flag", "gs_grad_stat_update", "gs_loss_workspace_bytes", "gs_loss_l1_ssim",
     "gs_densify_workspace_bytes", "gs_densify_classify", "gs_densify_apply",
 ]

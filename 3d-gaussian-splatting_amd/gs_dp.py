@@ -36,62 +36,134 @@ Works with any torch.distributed backend ("nccl" == RCCL on ROCm; "gloo" in CPU 
 """
 from __future__ import annotations
 
+import math
 from typing import List, Sequence
 
 import torch
 import torch.distributed as dist
 
 ORDER = ("quat", "pos", "scale", "opa", "rgb")  # storage order inside the flat bucket
+WIDTH = {"quat": 4, "pos": 3, "scale": 3, "opa": 1}  # floats per Gaussian ("rgb": its colour dimension)
 
 
 EXCHANGES = ("all_reduce", "reduce_scatter")
 
 
+def project_slice_size(n: int) -> int:
+    """Gaussians per slice of the frame path's project stage (csrc/gs_frame_layout.h: gs_strip_plan_for): the array is
+    cut into at most 256 slices of a multiple of 256 Gaussians.  The exchange slices below are made of whole project
+    slices, so that the NEXT frame's project stage can be issued slice by slice behind the optimizer."""
+    n = max(int(n), 1)
+    return -(-(-(-n // 256)) // 256) * 256
+
+
+class _Works:
+    """The pending collective(s) of one exchange unit: a coalescing manager (RCCL: one grouped launch) or a list of
+    works (backends without coalesced collectives, i.e. gloo in the CPU tests)."""
+
+    def __init__(self, works):
+        self.works = works
+
+    def wait(self):
+        for w in self.works:
+            if w is not None:
+                w.wait()
+
+
 class FlatGaussianParams:
-    """params / grads in the canonical (pos, quat, scale, opa, rgb) order, stored flat."""
+    """params / grads in the canonical (pos, quat, scale, opa, rgb) order, stored flat.
+
+    Layout (round 4): every tensor owns a region of ``Np * width`` floats, ``Np`` = N rounded up to a multiple of
+    4 x world -- [quat | pos | scale | opa | rgb]; the pad rows have zero gradient and never move.  Two views of it:
+      * BUCKETS (round 2): "geometry" = [quat | pos | scale], "color" = [opa | rgb], each one contiguous range;
+      * SLICES (round 4): slice k = Gaussians [g_k, g_k+1) -- one range in each of the five regions.  The gradients of
+        a frame only become final in the LAST kernel of the backward, the per-Gaussian sum of the gradient rows
+        (frame_project_backward_kernel), and that kernel is independent per Gaussian: it is issued slice by slice, and a
+        slice's exchange starts as soon as its sums are written -- underneath the sums of the following slices, the fused
+        Adam of the preceding ones and (gs_train.Trainer) the project stage of the NEXT frame, which needs nothing but
+        the updated parameters of its slice.  Slice boundaries are whole project slices (``project_slice_size``) and
+        multiples of 4 x world Gaussians, so every range splits into equal, float4-aligned shards ("reduce_scatter").
+    """
 
     def __init__(self, params: Sequence[torch.Tensor], world_size: int = 1, force_collective: bool = False,
-                 exchange: str = "all_reduce", rank: int = None):
+                 exchange: str = "all_reduce", rank: int = None, n_slices: int = None):
         pos, quat, scale, opa, rgb = params
         if exchange not in EXCHANGES:
             raise ValueError(f"exchange must be one of {EXCHANGES}")
         self.world_size = int(world_size)
         self.exchange = exchange
         self.force_collective = bool(force_collective)  # issue the collectives even with one rank
+        self.enable_collective = True  # False (measurement only, bench.py): the step without its gradient exchange
         if rank is None:
             rank = dist.get_rank() if (dist.is_initialized() and self.world_size > 1) else 0
         self.rank = int(rank)
         by_name = {"pos": pos, "quat": quat, "scale": scale, "opa": opa, "rgb": rgb}
         dev = pos.device
-        # two buckets, each padded to a multiple of 4 * world elements (equal, float4-aligned slices per rank)
+        n = int(pos.shape[0])
+        self.n = n
         quantum = 4 * max(self.world_size, 1)
-        pad_to = lambda n: (n + quantum - 1) // quantum * quantum  # noqa: E731
-        n_geom = pad_to(sum(by_name[k].numel() for k in ("quat", "pos", "scale")))
-        n_col = pad_to(sum(by_name[k].numel() for k in ("opa", "rgb")))
-        total = n_geom + n_col
+        self.n_pad = (n + quantum - 1) // quantum * quantum  # rows of every region
+        width = dict(WIDTH, rgb=int(rgb.numel() // max(n, 1)) if n else (rgb.shape[1] if rgb.dim() == 2 else 1))
+        self.width = width
+        total = self.n_pad * sum(width[k] for k in ORDER)
         self.flat_param = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
-        views_p, views_g, self.offsets = {}, {}, {}
+        views_p, views_g, self.offsets, self.region = {}, {}, {}, {}
         off = 0
         for k in ORDER:
-            if k == "opa":
-                off = n_geom  # the colour bucket starts behind the geometry bucket's padding
             t = by_name[k]
-            n = t.numel()
-            self.offsets[k] = (off, off + n)
-            views_p[k] = self.flat_param[off:off + n].view(t.shape)
-            views_g[k] = self.flat_grad[off:off + n].view(t.shape)
+            cnt = t.numel()
+            self.offsets[k] = (off, off + cnt)
+            self.region[k] = off
+            views_p[k] = self.flat_param[off:off + cnt].view(t.shape)
+            views_g[k] = self.flat_grad[off:off + cnt].view(t.shape)
             views_p[k].copy_(t)
-            off += n
+            off += self.n_pad * width[k]
         names = ("pos", "quat", "scale", "opa", "rgb")
         self.params: List[torch.Tensor] = [views_p[k] for k in names]
         self.grads: List[torch.Tensor] = [views_g[k] for k in names]
+        n_geom = self.region["opa"]
         self.bucket_ranges = {"geometry": (0, n_geom), "color": (n_geom, total)}  # element ranges of the flat buffers
-        # Adam group table in ORDER: a group ends where the next begins, so the padding of a bucket belongs to its
-        # last group (zero gradient, zero moments: it never moves)
-        self.group_ends = [self.offsets["quat"][1], self.offsets["pos"][1], n_geom, self.offsets["opa"][1], total]
+        # Adam group table in ORDER: a group ends where the next region begins (pad rows: zero gradient, zero moments)
+        self.group_ends = [self.region["pos"], self.region["scale"], self.region["opa"], self.region["rgb"], total]
+        # ---- slices of the Gaussian array (exchange units)
+        per = project_slice_size(n)
+        step = per * (quantum // math.gcd(per, quantum))  # whole project slices AND multiples of 4 x world Gaussians
+        n_steps = max(-(-self.n_pad // step), 1)
+        if n_slices is None:
+            n_slices = min(max(n // 250_000, 1), 8)  # ~8 slices at 2.4 M Gaussians; small scenes: one (launch-bound)
+        k_slices = max(1, min(int(n_slices), n_steps))
+        bounds = sorted({min(round(i * n_steps / k_slices) * step, self.n_pad) for i in range(k_slices)} | {self.n_pad})
+        self.slice_bounds = [0] + [b for b in bounds if b > 0]
+        self.project_slice = per
         self._pending = {}
         self._pending_gather = {}
+
+    # ---- geometry of the exchange units --------------------------------------------------------------------------
+    @property
+    def n_slices(self) -> int:
+        return len(self.slice_bounds) - 1
+
+    def slice_gaussians(self, k: int):
+        """Gaussian range [g0, g1) of slice k, clipped to the real Gaussians (the pad rows belong to the last slice)."""
+        return self.slice_bounds[k], min(self.slice_bounds[k + 1], self.n)
+
+    def slice_ranges(self, k: int):
+        """The five element ranges (ORDER) slice k owns in the flat buffers."""
+        g0, g1 = self.slice_bounds[k], self.slice_bounds[k + 1]
+        return [(self.region[t] + g0 * self.width[t], self.region[t] + g1 * self.width[t]) for t in ORDER]
+
+    def owned(self, ranges):
+        """What this rank's optimizer updates of ``ranges``: all of it (replicated) or its 1/world shard of every range
+        (sharded; every range length is a multiple of 4 x world by construction)."""
+        if self.exchange != "reduce_scatter":
+            return list(ranges)
+        w = max(self.world_size, 1)
+        out = []
+        for lo, hi in ranges:
+            s = (hi - lo) // w
+            out.append((lo + self.rank * s, lo + (self.rank + 1) * s))
+        return out
 
     @property
     def bucket_bytes(self) -> int:
@@ -127,53 +199,88 @@ class FlatGaussianParams:
             if not self._avg_in_collective:
                 self.flat_grad.mul_(1.0 / self.world_size)
 
-    # ---- bucketed, asynchronous exchange ---------------------------------------------------------------------
+    # ---- asynchronous exchange of one unit (a bucket or a slice) ---------------------------------------------------
     def collective_active(self) -> bool:
-        return dist.is_initialized() and (self.world_size > 1 or self.force_collective)
+        return self.enable_collective and dist.is_initialized() and (self.world_size > 1 or self.force_collective)
 
-    def begin_bucket(self, name: str):
-        """Start the mean all-reduce (or reduce-scatter) of one bucket ("geometry" or "color") without waiting for it.
-        The collective runs on the process group's own stream, which first waits for everything enqueued on the
-        current stream so far -- i.e. for the kernel that wrote the bucket."""
+    def _issue(self, fn, args_list):
+        """One collective per entry of ``args_list``, asynchronously; several of them travel as ONE grouped RCCL launch
+        (torch's coalescing manager: ncclGroupStart / End), backends without coalesced collectives get one call each."""
+        if len(args_list) > 1 and dist.get_backend() == "nccl":
+            with dist._coalescing_manager(async_ops=True) as cm:
+                for args, kw in args_list:
+                    fn(*args, **kw)
+            return _Works([cm])
+        return _Works([fn(*args, async_op=True, **kw) for args, kw in args_list])
+
+    def begin_exchange(self, key, ranges):
+        """Start the mean all-reduce (or reduce-scatter) of the element ranges of one unit without waiting for it.  The
+        collective runs on the process group's own stream, which first waits for everything enqueued on the current
+        stream so far -- i.e. for the kernel that wrote the ranges."""
         if not self.collective_active():
             return
-        lo, hi = self.bucket_ranges[name]
         avg = dist.get_backend() == "nccl"
         op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+        g = self.flat_grad
         if self.exchange == "reduce_scatter":
-            slo, shi = self.shard_range(name)
-            # in place: the output is this rank's slice of the input (RCCL's in-place reduce-scatter layout)
-            work = dist.reduce_scatter_tensor(self.flat_grad[slo:shi], self.flat_grad[lo:hi], op=op, async_op=True)
-            self._pending[name] = (work, avg, (slo, shi))
+            own = self.owned(ranges)
+            # in place: the output is this rank's shard of the input (RCCL's in-place reduce-scatter layout)
+            works = self._issue(dist.reduce_scatter_tensor,
+                                [((g[slo:shi], g[lo:hi]), {"op": op}) for (lo, hi), (slo, shi) in zip(ranges, own)])
+            self._pending[key] = (works, avg, own)
         else:
-            work = dist.all_reduce(self.flat_grad[lo:hi], op=op, async_op=True)
-            self._pending[name] = (work, avg, (lo, hi))
+            works = self._issue(dist.all_reduce, [((g[lo:hi],), {"op": op}) for lo, hi in ranges])
+            self._pending[key] = (works, avg, list(ranges))
 
-    def finish_bucket(self, name: str):
-        """Make the current stream wait for the bucket's reduction (and scale it on backends without AVG)."""
-        pend = self._pending.pop(name, None)
+    def finish_exchange(self, key):
+        """Make the current stream wait for the unit's reduction (and scale it on backends without AVG)."""
+        pend = self._pending.pop(key, None)
         if pend is None:
             return
-        work, avg, (lo, hi) = pend
-        work.wait()
+        works, avg, touched = pend
+        works.wait()
         if not avg:
-            self.flat_grad[lo:hi].mul_(1.0 / self.world_size)
+            for lo, hi in touched:
+                self.flat_grad[lo:hi].mul_(1.0 / self.world_size)
 
-    def begin_gather(self, name: str):
-        """reduce-scatter mode: all-gather the bucket's updated PARAMETER slices (in place), without waiting."""
+    def begin_param_gather(self, key, ranges):
+        """reduce-scatter mode: all-gather the unit's updated PARAMETER shards (in place), without waiting."""
         if not self.collective_active() or self.exchange != "reduce_scatter":
             return
-        lo, hi = self.bucket_ranges[name]
-        slo, shi = self.shard_range(name)
-        self._pending_gather[name] = dist.all_gather_into_tensor(self.flat_param[lo:hi], self.flat_param[slo:shi],
-                                                                 async_op=True)
+        p = self.flat_param
+        own = self.owned(ranges)
+        self._pending_gather[key] = self._issue(
+            dist.all_gather_into_tensor, [((p[lo:hi], p[slo:shi]), {}) for (lo, hi), (slo, shi) in zip(ranges, own)])
 
-    def finish_gather(self, name: str = None):
+    def finish_gather(self, name=None):
         """Make the current stream wait for the parameter all-gather(s): before anything reads the parameters."""
-        for k in ([name] if name else list(self._pending_gather)):
+        for k in ([name] if name is not None else list(self._pending_gather)):
             work = self._pending_gather.pop(k, None)
             if work is not None:
                 work.wait()
+
+    # buckets (round 2 API: one contiguous range per unit)
+    def begin_bucket(self, name: str):
+        self.begin_exchange(name, [self.bucket_ranges[name]])
+
+    def finish_bucket(self, name: str):
+        self.finish_exchange(name)
+
+    def begin_gather(self, name: str):
+        self.begin_param_gather(name, [self.bucket_ranges[name]])
+
+    # slices (round 4)
+    def begin_slice(self, k: int):
+        self.begin_exchange(("slice", k), self.slice_ranges(k))
+
+    def finish_slice(self, k: int):
+        self.finish_exchange(("slice", k))
+
+    def begin_slice_gather(self, k: int):
+        self.begin_param_gather(("slice", k), self.slice_ranges(k))
+
+    def finish_slice_gather(self, k: int):
+        self.finish_gather(("slice", k))
 
     def broadcast_params(self, src: int = 0):
         if self.world_size > 1 and dist.is_initialized():
@@ -219,6 +326,26 @@ class ViewParallelGradStat:
         if self.mode == "mean":
             if seen is None:
                 raise RuntimeError("the 'mean' statistic needs the view's culling mask")
+            self.counter.add_(seen)
+
+    def update_range(self, pos_grad: torch.Tensor, g0: int, g1: int):
+        """``update`` for the Gaussians [g0, g1) only (the exchange slices of gs_train.Trainer; the visibility counter of
+        the "mean" statistic is added once per view with ``add_seen``)."""
+        if pos_grad.device.type != "cuda":
+            raise RuntimeError("ViewParallelGradStat.update_range needs a HIP device; there is no CPU fallback")
+        if tuple(pos_grad.shape) != tuple(self.accum.shape) or not pos_grad.is_contiguous():
+            raise RuntimeError(f"pos_grad must be contiguous {tuple(self.accum.shape)}")
+        if g1 <= g0:
+            return
+        from gaussian import _lib
+
+        _lib.check(_lib.gs_grad_stat_update(pos_grad.data_ptr() + 12 * g0, self.accum.data_ptr() + 12 * g0, 3 * (g1 - g0),
+                                            1 if self.mode == "max" else 2, torch.cuda.current_stream().cuda_stream),
+                   "gs_grad_stat_update")
+
+    def add_seen(self, seen: torch.Tensor):
+        """"mean" statistic: the view's culling mask as float (train.py:152-154)."""
+        if self.mode == "mean":
             self.counter.add_(seen)
 
     def reduce(self):

@@ -297,6 +297,96 @@ class FrameRenderer:
             break
         return image, padded
 
+    # ------------------------------------------------------------------ a frame in two phases (view-parallel trainer)
+    def forward_begin(self, pos, quat, scale, opa, rgb, camera, slice_begin: int, slice_end: int) -> bool:
+        """Issue the PROJECT stage of the next training frame for the slices [slice_begin, slice_end) of the Gaussian
+        array (``project_slices()`` of them, ``project_slice_size`` Gaussians each); the range that starts at slice 0
+        opens the frame.  gs_train.Trainer calls this slice by slice behind the optimizer of the previous step, so that
+        the next frame's cull + project + count runs underneath the gradient exchange of the remaining slices.
+        Returns False -- nothing issued -- when this frame cannot be split (binning variant without the fused count, a
+        pending workspace growth, a capacity check due): the caller then renders it with ``forward``.  The frame is
+        completed by ``forward_finish``; no capacity check happens in between (steady-state training frames only)."""
+        with torch.cuda.device(self.device):
+            stream = self._stream().cuda_stream
+            if slice_begin == 0:
+                self._begun = None
+                cur = self._frame
+                if (cur is None or not cur.training or self.auto_grow is True or not self._checked_once
+                        or cur.max_pairs != self.max_pairs or cur.N != pos.shape[0]):
+                    return False
+                f = self._describe(pos, quat, scale, opa, rgb, camera, True)
+                if f.workspace != cur.workspace:
+                    return False
+                n_sl, per = C.c_int32(), C.c_int64()
+                g = self._grid
+                image = torch.empty(g.height, g.width, 3, device=self.device, dtype=torch.float32)
+                padded = torch.empty(g.padded_height, g.padded_width, 3, device=self.device, dtype=torch.float32)
+                f.image, f.image_padded = image.data_ptr(), padded.data_ptr()
+                _lib.check(_lib.gs_frame_project_slices(C.byref(f), C.byref(n_sl), C.byref(per)), "gs_frame_project_slices")
+                if n_sl.value == 0:
+                    return False
+                self._begun = {"f": f, "image": image, "padded": padded, "keep": (pos, quat, scale, opa, rgb),
+                               "camera": camera, "slices": n_sl.value, "per_slice": per.value, "done": 0}
+            b = getattr(self, "_begun", None)
+            if b is None:
+                return False
+            slice_end = min(int(slice_end), b["slices"])
+            if slice_end <= slice_begin:
+                return True
+            _lib.check(_lib.gs_frame_forward_project(C.byref(b["f"]), int(slice_begin), slice_end, stream),
+                       "gs_frame_forward_project")
+            b["done"] += slice_end - slice_begin
+            return True
+
+    def begun_frame_matches(self, pos, quat, scale, opa, rgb, camera) -> bool:
+        """Is a completely projected frame of exactly these tensors and this camera waiting for ``forward_finish``?"""
+        b = getattr(self, "_begun", None)
+        return (b is not None and b["done"] == b["slices"] and b["camera"] is camera
+                and all(x is y for x, y in zip(b["keep"], (pos, quat, scale, opa, rgb))))
+
+    def forward_abandon(self):
+        """Drop a frame opened by ``forward_begin`` (its project stage only wrote per-frame scratch)."""
+        self._begun = None
+
+    def forward_finish(self):
+        """Binning, per-tile sort and compositing of the frame opened by ``forward_begin`` -> (image, padded)."""
+        b = getattr(self, "_begun", None)
+        if b is None or b["done"] != b["slices"]:
+            raise RuntimeError("forward_finish() needs a frame whose project stage was issued completely")
+        self._begun = None
+        with torch.cuda.device(self.device):
+            stream = self._stream().cuda_stream
+            if self.auto_grow == "async":
+                self._poll_async_counters()
+            f = b["f"]
+            _lib.check(_lib.gs_frame_forward_rest(C.byref(f), stream), "gs_frame_forward_rest")
+            self._frame = f
+            self._frame_serial += 1
+            self._keep = (*b["keep"], b["image"], b["padded"])
+            if self.auto_grow == "async" and self._async_event is None:  # one copy in flight at a time
+                _lib.check(_lib.gs_frame_stats_async(C.byref(f), self._async_host.data_ptr(), stream),
+                           "gs_frame_stats_async")
+                _lib.check(_lib.gs_frame_longest_list_async(C.byref(f), self._async_host.data_ptr() + 32, stream),
+                           "gs_frame_longest_list_async")
+                self._async_event = torch.cuda.Event()
+                self._async_event.record(self._stream())
+                self._async_serial = self._frame_serial
+        return b["image"], b["padded"]
+
+    def backward_slice(self, out, g_begin: int, g_end: int, part: int = None):
+        """After ``backward(part=GS_BWD_RASTER)``: the per-Gaussian sums (projection + activation backward) of the
+        Gaussians [g_begin, g_end) -- g_begin a multiple of 256 -- into ``out``; ``part`` = GS_BWD_GEOMETRY, GS_BWD_COLOR
+        or (default) both in one kernel.  Any partition of the Gaussians gives exactly what ``backward`` writes."""
+        f = self._frame
+        if f is None or not f.training:
+            raise RuntimeError("backward_slice() needs a preceding forward(training=True)")
+        if part is None:
+            part = _lib.GS_BWD_GEOMETRY | _lib.GS_BWD_COLOR
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.gs_frame_backward_slice(C.byref(f), *(t.data_ptr() for t in out), int(part), int(g_begin),
+                                                    int(g_end), self._stream().cuda_stream), "gs_frame_backward_slice")
+        return out
+
     def backward(self, grad_image, out=None, part: int = 0):
         """dL/d(image) -> (grad_pos, grad_quat, grad_scale, grad_opa, grad_rgb).  ``out`` may
         supply the five destination tensors (e.g. views of one flat all-reduce bucket).

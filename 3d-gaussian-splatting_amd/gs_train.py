@@ -88,10 +88,12 @@ def base_lrs(opt: TrainOptions) -> List[float]:
 
 
 class FusedAdam:
-    """``torch.optim.Adam`` over a FlatGaussianParams bucket, one HIP launch per step (per bucket).
+    """``torch.optim.Adam`` over a FlatGaussianParams buffer: ONE HIP launch per step on a single GPU, one launch per
+    exchange slice (five element ranges each, ``gs_adam_step_multi``) under view parallelism.
 
-    With ``flat.exchange == "reduce_scatter"`` the optimizer is SHARDED: this rank keeps the moments of its slice of
-    each bucket only and updates that slice only (gs_dp.py); otherwise every rank updates everything."""
+    With ``flat.exchange == "reduce_scatter"`` the optimizer is SHARDED: this rank keeps the moments of its 1/world shard
+    of every slice range only (densely packed, slice by slice) and updates those shards only (gs_dp.py); otherwise every
+    rank updates everything and the moments mirror the flat buffer."""
 
     def __init__(self, flat: FlatGaussianParams, lrs: Sequence[float], betas=(0.9, 0.99), eps: float = 1e-8,
                  grad_stat: Optional[str] = None):
@@ -100,13 +102,24 @@ class FusedAdam:
         self.flat = flat
         self.betas, self.eps = (float(betas[0]), float(betas[1])), float(eps)
         self.sharded = flat.exchange == "reduce_scatter"
-        # moments per bucket, covering what this rank updates of it (gs_dp.FlatGaussianParams.optimizer_range)
-        self.ranges = {name: flat.optimizer_range(name) for name in ("geometry", "color")}
         dev = flat.flat_param.device
-        self.exp_avg = {k: torch.zeros(hi - lo, dtype=torch.float32, device=dev) for k, (lo, hi) in self.ranges.items()}
-        self.exp_avg_sq = {k: torch.zeros_like(v) for k, v in self.exp_avg.items()}
+        # per slice: the (up to five) element ranges this rank updates and where their moments start
+        self._units = []
+        off = 0
+        for k in range(flat.n_slices):
+            own = [r for r in flat.owned(flat.slice_ranges(k)) if r[1] > r[0]]
+            offs = []
+            for lo, hi in own:
+                offs.append(off if self.sharded else lo)  # replicated: the moments mirror the flat buffer
+                off += hi - lo
+            n_r = len(own)
+            self._units.append((n_r, (C.c_int64 * n_r)(*[r[0] for r in own]), (C.c_int64 * n_r)(*[r[1] for r in own]),
+                                (C.c_int64 * n_r)(*offs)))
+        size = off if self.sharded else flat.flat_param.numel()
+        self.exp_avg = torch.zeros(size, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros_like(self.exp_avg)
         self.step_count = 0
-        # bucket storage order (gs_dp.ORDER) -> group boundaries; lrs arrive in the reference's GROUPS order
+        # buffer storage order (gs_dp.ORDER) -> group boundaries; lrs arrive in the reference's GROUPS order
         ends = list(flat.group_ends)
         self._ends = (C.c_int64 * len(ends))(*ends)
         self._lr = (C.c_float * len(ends))()
@@ -115,6 +128,11 @@ class FusedAdam:
         self.stat_mode = {None: 0, "max": 1, "mean": 2}[grad_stat]
         self.accum_grad = torch.zeros_like(flat.params[0]) if self.stat_mode else None  # train.py:80-82
         self.skip_flag = None  # device address of a 64-bit counter: non-zero => the step is skipped (gs_abi.h)
+
+    @property
+    def state_bytes(self) -> int:
+        """Optimizer state this rank keeps (both moments)."""
+        return self.exp_avg.numel() * 8
 
     def set_lrs(self, lrs: Sequence[float]):
         by_group = dict(zip(GROUPS, lrs))
@@ -125,23 +143,39 @@ class FusedAdam:
         if self.accum_grad is not None:
             self.accum_grad.zero_()
 
-    def step(self, bucket: Optional[str] = None, advance: bool = True):
-        """One Adam step over everything this rank owns, or over one bucket of it ("geometry" / "color": gs_dp.py;
-        the step counter advances once per optimizer step -- pass ``advance=False`` for the second bucket)."""
+    def step(self, advance: bool = True):
+        """One Adam step over everything this rank owns (the step counter advances once per optimizer step).  Note: a
+        step the device skips because its frame overflowed (``skip_flag``) still counts for the bias corrections --
+        the host cannot know without synchronising."""
         if advance:
             self.step_count += 1
+        if self.sharded:
+            for k in range(len(self._units)):
+                self.step_slice(k, advance=False)
+            return
         f = self.flat
         b, e = self._stat_range
         n = f.flat_param.numel()
-        stream = torch.cuda.current_stream().cuda_stream
-        for name in (("geometry", "color") if bucket is None else (bucket,)):
-            lo, hi = self.ranges[name]
-            _lib.check(_lib.gs_adam_step_sharded(
-                f.flat_param.data_ptr(), f.flat_grad.data_ptr(), self.exp_avg[name].data_ptr(),
-                self.exp_avg_sq[name].data_ptr(), n, lo, hi, lo, len(ORDER), self._ends, self._lr, self.betas[0],
-                self.betas[1], self.eps, self.step_count,
-                self.accum_grad.data_ptr() if self.accum_grad is not None else None, b, e, self.stat_mode,
-                self.skip_flag, stream), "gs_adam_step")
+        _lib.check(_lib.gs_adam_step_sharded(
+            f.flat_param.data_ptr(), f.flat_grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), n, 0, n,
+            0, len(ORDER), self._ends, self._lr, self.betas[0], self.betas[1], self.eps, self.step_count,
+            self.accum_grad.data_ptr() if self.accum_grad is not None else None, b, e, self.stat_mode, self.skip_flag,
+            torch.cuda.current_stream().cuda_stream), "gs_adam_step")
+
+    def step_slice(self, k: int, advance: bool = False):
+        """The same step for exchange slice ``k`` only (pass ``advance=True`` for the first slice of a step)."""
+        if advance:
+            self.step_count += 1
+        n_r, lo, hi, off = self._units[k]
+        if n_r == 0:
+            return
+        f = self.flat
+        b, e = self._stat_range
+        _lib.check(_lib.gs_adam_step_multi(
+            f.flat_param.data_ptr(), f.flat_grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+            f.flat_param.numel(), n_r, lo, hi, off, len(ORDER), self._ends, self._lr, self.betas[0], self.betas[1],
+            self.eps, self.step_count, self.accum_grad.data_ptr() if self.accum_grad is not None else None, b, e,
+            self.stat_mode, self.skip_flag, torch.cuda.current_stream().cuda_stream), "gs_adam_step_multi")
 
 
 class ImageLoss:
@@ -173,9 +207,17 @@ class Trainer:
     def __init__(self, params: Sequence[torch.Tensor], cameras, targets: Sequence[torch.Tensor],
                  opt: Optional[TrainOptions] = None, world_size: int = 1, max_pairs: int = 1 << 20,
                  scale_activation: str = "abs", densify: bool = False, generator: Optional[torch.Generator] = None,
-                 per_view_stat: Optional[bool] = None, exchange: str = "all_reduce"):
+                 per_view_stat: Optional[bool] = None, exchange: str = "all_reduce", n_slices: Optional[int] = None):
         self.opt = opt or TrainOptions()
         self.world_size = int(world_size)
+        self.n_slices = n_slices  # exchange slices of the Gaussian array (gs_dp.py; None: by scene size)
+        if exchange == "reduce_scatter" and self.world_size > 1:
+            import torch.distributed as dist
+
+            if not dist.is_initialized():
+                # every rank would keep and update its own 1/world of the optimizer state while nobody exchanges
+                # anything: (world - 1)/world of the parameters would silently never train
+                raise RuntimeError("exchange='reduce_scatter' with world_size > 1 needs an initialised process group")
         # gradient exchange under view parallelism (gs_dp.py): "all_reduce" + replicated Adam, or "reduce_scatter" +
         # sharded Adam + all-gather of the parameters
         self.exchange = exchange
@@ -207,7 +249,8 @@ class Trainer:
         the reference also starts a fresh torch.optim.Adam after every adaptive_control."""
         force = getattr(getattr(self, "flat", None), "force_collective", False)
         self.flat = FlatGaussianParams(params, world_size=self.world_size, exchange=self.exchange,
-                                       force_collective=force)
+                                       force_collective=force, n_slices=self.n_slices)
+        self.renderer.forward_abandon()  # a frame projected ahead belonged to the old Gaussian set
         split_stat = self.densify and self.per_view_stat
         self.optimizer = FusedAdam(self.flat, [b * f(i_iter) for b, f in zip(self._base, self._lambdas)],
                                    betas=self.opt.betas, eps=self.opt.eps,
@@ -227,8 +270,13 @@ class Trainer:
             self._loss[key] = ImageLoss(h, w, self.opt.ssim_weight, self.flat.flat_param.device)
         return self._loss[key]
 
-    def train_step(self, i_iter: int, camera_id: int) -> torch.Tensor:
-        """Returns the device tensor (loss, l1, ssim) of this step (no host synchronisation)."""
+    def train_step(self, i_iter: int, camera_id: int, next_camera_id: Optional[int] = None) -> torch.Tensor:
+        """Returns the device tensor (loss, l1, ssim) of this step (no host synchronisation).
+
+        ``next_camera_id``: the view the NEXT step will render, if the caller knows it (a fixed view per rank, a
+        pre-drawn camera schedule).  Under view parallelism the project stage of that frame is then issued slice by slice
+        behind this step's optimizer, underneath the gradient exchange of the remaining slices (gs_dp.py); the next
+        ``train_step`` picks the frame up if it is called with that camera, and renders from scratch otherwise."""
         o = self.opt
         # schedule flags, train.py:86-91
         in_reset = i_iter >= o.n_opa_reset and i_iter % o.n_opa_reset < o.reset_interval
@@ -237,31 +285,31 @@ class Trainer:
         control = only_delete and i_iter < o.adaptive_control_end_iter
         accum_start = past and (i_iter + o.grad_accum_iters - 1) % o.n_adaptive_control == 0
         cam, target = self.cameras[camera_id], self.targets[camera_id]
-        if camera_id not in self._views_checked:  # first frame of this view on this Gaussian set: synchronous check
-            self._views_checked.add(camera_id)
-            self.renderer._checked_once = False
-        self.flat.finish_gather()  # reduce-scatter mode: the parameter all-gather of the previous step
-        image, _ = self.renderer.forward(*self.flat.params, cam)
+        flat, r = self.flat, self.renderer
+        flat.finish_gather()  # reduce-scatter mode: parameter all-gathers of the previous step that nobody waited for yet
+        if r.begun_frame_matches(*flat.params, cam):
+            image, _ = r.forward_finish()  # projected behind the previous step's optimizer
+        else:
+            r.forward_abandon()
+            if camera_id not in self._views_checked:  # first frame of this view on this Gaussian set: synchronous check
+                self._views_checked.add(camera_id)
+                r._checked_once = False
+            image, _ = r.forward(*flat.params, cam)
         # a frame that overflowed its workspace all the same was rendered empty: on a single rank the optimizer step
         # is skipped ON THE DEVICE (the fused Adam looks at the frame's overflow counter; no host synchronisation).
         # With several ranks the step is taken -- the other ranks' views still carry gradient, and skipping on one rank
         # would let the replicas drift apart -- and the warning below reports it once the counters arrive.
-        self.optimizer.skip_flag = self.renderer.overflow_flag() if self.world_size == 1 else None
-        if self.renderer.overflowed_frames > self._overflow_warned:
+        self.optimizer.skip_flag = r.overflow_flag() if self.world_size == 1 else None
+        if r.overflowed_frames > self._overflow_warned:
             import warnings
 
-            warnings.warn(f"{self.renderer.overflowed_frames - self._overflow_warned} training frame(s) exceeded the "
+            warnings.warn(f"{r.overflowed_frames - self._overflow_warned} training frame(s) exceeded the "
                           f"pair capacity and were rendered empty (single rank: their optimizer steps were skipped on "
                           f"the device; several ranks: this rank contributed zero gradients to them); the "
-                          f"workspace has been enlarged to {self.renderer.max_pairs} pairs")
-            self._overflow_warned = self.renderer.overflowed_frames
+                          f"workspace has been enlarged to {r.max_pairs} pairs")
+            self._overflow_warned = r.overflowed_frames
         loss = self._loss_for(image.shape[0], image.shape[1])
         grad_image = loss(image, target)
-        # With a process group the backward is issued in three parts so that the gradient exchange overlaps what
-        # little work follows the raster backward (gs_dp.py): rows -> the FIRST bucket's per-Gaussian sums -> its
-        # all-reduce starts -> the second bucket's sums run underneath it -> Adam of the first bucket underneath the
-        # second all-reduce.  The larger bucket goes first.  Whatever needs this rank's OWN gradients (regularisers,
-        # the per-view densification statistic) is applied to a bucket right before its all-reduce starts.
         if self.densify and accum_start:  # train.py:141-142 (before this step's gradient is accumulated)
             self.optimizer.clear_grad_stat()
             self.grad_counter = None
@@ -269,36 +317,55 @@ class Trainer:
                 self.view_stat.clear()
         seen = None
         if self.densify and o.grad_accum_method == "mean":
-            seen = self.renderer.culling_mask().to(torch.float32)
+            seen = r.culling_mask().to(torch.float32)
 
-        def local_terms(bucket):
-            if bucket in (None, "geometry"):
-                if o.scale_reg > 0:  # train.py:108-109
-                    sc = self.flat.params[2]
-                    self.flat.grads[2].add_(torch.sign(sc), alpha=o.scale_reg / sc.numel())
-                if self.view_stat is not None:  # this rank's view, before the gradients are averaged over the ranks
-                    self.view_stat.update(self.flat.grads[0], seen)
-            if bucket in (None, "color") and o.opa_reg > 0:  # train.py:110-112
-                sg = torch.sigmoid(self.flat.params[3])
-                self.flat.grads[3].add_(sg * (1 - sg) * (1 - 2 * sg), alpha=o.opa_reg / sg.numel())
+        def local_terms(g0, g1):
+            """What needs this rank's OWN gradients of the Gaussians [g0, g1) -- regularisers, the per-view densification
+            statistic -- before they are averaged over the ranks."""
+            if o.scale_reg > 0:  # train.py:108-109
+                sc = flat.params[2]
+                flat.grads[2][g0:g1].add_(torch.sign(sc[g0:g1]), alpha=o.scale_reg / sc.numel())
+            if self.view_stat is not None:
+                self.view_stat.update_range(flat.grads[0], g0, g1)
+            if o.opa_reg > 0:  # train.py:110-112
+                sg = torch.sigmoid(flat.params[3][g0:g1])
+                flat.grads[3][g0:g1].add_(sg * (1 - sg) * (1 - 2 * sg), alpha=o.opa_reg / flat.params[3].numel())
 
-        if self.flat.collective_active():
-            first, second = ("color", "geometry") if self.flat.grads[4].shape[1] > 9 else ("geometry", "color")
-            part_of = {"geometry": _lib.GS_BWD_GEOMETRY, "color": _lib.GS_BWD_COLOR}
-            self.renderer.backward(grad_image, out=self.flat.grads, part=_lib.GS_BWD_RASTER)
-            for name in (first, second):
-                self.renderer.backward(None, out=self.flat.grads, part=part_of[name])
-                local_terms(name)
-                self.flat.begin_bucket(name)
-            self.flat.finish_bucket(first)
-            self.optimizer.step(first)
-            self.flat.begin_gather(first)   # reduce-scatter mode only: the updated slices travel underneath ...
-            self.flat.finish_bucket(second)
-            self.optimizer.step(second, advance=False)  # ... this
-            self.flat.begin_gather(second)  # waited for where the parameters are read next (finish_gather)
+        if flat.collective_active():
+            # View parallelism.  Every gradient of the frame becomes final in the LAST kernel of the backward, the
+            # per-Gaussian sum of the gradient rows; that kernel, the exchange, the optimizer and the NEXT frame's project
+            # stage are all independent per Gaussian, so they run as a pipeline over K slices of the Gaussian array:
+            #   main stream : rows | S_0 S_1 ... S_K-1 | A_0 P_0 | A_1 P_1 | ...   (S = sums, A = Adam, P = next project)
+            #   RCCL stream :        X_0 X_1 ...                                    (X_k starts when S_k is done,
+            #                                                                        A_k waits for X_k)
+            # Nothing of a slice is applied before its exchange has finished: no stale gradients, the same numbers as
+            # the blocking path bit for bit (tests/test_host_logic.py, tests/test_gpu_train.py).
+            K = flat.n_slices
+            r.backward(grad_image, out=flat.grads, part=_lib.GS_BWD_RASTER)
+            if self.view_stat is not None and seen is not None:
+                self.view_stat.add_seen(seen)
+            for k in range(K):
+                g0, g1 = flat.slice_gaussians(k)
+                r.backward_slice(flat.grads, g0, g1)
+                local_terms(g0, g1)
+                flat.begin_slice(k)
+            ahead = self._can_project_ahead(i_iter, next_camera_id, control or only_delete)
+            lag = 1 if flat.exchange == "reduce_scatter" else 0  # the project needs the GATHERED parameters of its slice
+            for k in range(K + lag):
+                if k < K:
+                    flat.finish_slice(k)
+                    self.optimizer.step_slice(k, advance=(k == 0))
+                    flat.begin_slice_gather(k)  # reduce-scatter mode only: the updated shards travel underneath ...
+                j = k - lag
+                if ahead and j >= 0:
+                    flat.finish_slice_gather(j)  # ... the next slice's reduce-scatter + Adam
+                    ahead = self._project_ahead(j, next_camera_id)
+            # (gathers nobody waited for are waited for where the parameters are read next: finish_gather)
         else:
-            self.renderer.backward(grad_image, out=self.flat.grads)
-            local_terms(None)
+            r.backward(grad_image, out=flat.grads)
+            local_terms(0, flat.n)
+            if self.view_stat is not None and seen is not None:
+                self.view_stat.add_seen(seen)
             self.optimizer.step()  # also: accum_max_grad = max(|pos.grad|, accum) or += |pos.grad| (train.py:144-153)
         if seen is not None and self.view_stat is None:
             self.grad_counter = seen if self.grad_counter is None else self.grad_counter + seen
@@ -310,8 +377,29 @@ class Trainer:
             from gs_densify import reset_opa
 
             self.flat.finish_gather()
+            self.renderer.forward_abandon()
             reset_opa(self.flat.params[3])
         return loss.values
+
+    def _can_project_ahead(self, i_iter: int, next_camera_id: Optional[int], rebinding: bool) -> bool:
+        """May the next frame's project stage be issued behind this step's optimizer?  Only for a view whose capacity
+        has been checked on this Gaussian set, and not across a densification / opacity reset (the parameters the
+        project stage read would no longer be the ones the frame is rendered with)."""
+        o = self.opt
+        if next_camera_id is None or next_camera_id not in self._views_checked:
+            return False
+        if self.densify and (rebinding or (i_iter % o.n_opa_reset == 0 and i_iter > 0)):
+            return False
+        return True
+
+    def _project_ahead(self, k: int, next_camera_id: int) -> bool:
+        """Project stage of the next frame for the Gaussians of exchange slice ``k`` (whole project slices)."""
+        flat = self.flat
+        per = flat.project_slice
+        b0, b1 = flat.slice_bounds[k], min(flat.slice_bounds[k + 1], flat.n)
+        if b1 <= b0:
+            return True
+        return self.renderer.forward_begin(*flat.params, self.cameras[next_camera_id], b0 // per, -(-b1 // per))
 
     def adaptive_control(self, i_iter: int, densify: bool = True):
         """train.py:156-180: prune (+ clone / split when ``densify``), then a fresh optimizer."""

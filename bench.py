@@ -47,6 +47,8 @@ for _p in (ROOT, os.path.join(ROOT, "3d-gaussian-splatting_amd")):
 import torch
 import torch.distributed as dist
 
+sys.path.insert(0, os.path.join(ROOT, "tools"))  # train_timing.py, compat_fps.py (measurement helpers, not product code)
+
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALL_LEGS = ("headline", "cfg2", "train", "fit", "cfg4", "pipelined", "compat", "multi_gpu", "cpu")
 
@@ -359,10 +361,15 @@ def main():
         guarded("cfg2", _leg_cfg2)
 
     # ---------------------------------------------------------------- training step (train.py:84-185, no densification)
-    def train_leg(cfg, params, cam, pairs, k, force=False, exchange="all_reduce"):
-        """forward (checkpointing) -> L1 + 0.1 SSIM loss and gradient -> backward -> all-reduce of the flat gradient
-        bucket (N > 1) -> fused Adam.  Returns (whole-job iterations/s, ms per iteration, detail dict on rank 0)."""
+    def train_leg(cfg, params, cam, pairs, k, force=False, exchange="all_reduce", collective=True, repeats=15):
+        """forward (checkpointing) -> L1 + 0.1 SSIM loss and gradient -> backward -> exchange of the flat gradient buffer
+        (N > 1, or forced) -> fused Adam.  Timed with the snapshot / restore protocol of tools/train_timing.py: 30 warm-up
+        iterations, then the SAME k iterations `repeats` times (everything the step changes is restored between blocks,
+        outside the timed region).  Returns (whole-job iterations/s, ms per iteration, detail dict on rank 0, trainer).
+        `collective=False` (measurement only): the same step without its gradient exchange -- the reference the
+        exchange's exposed time is taken against."""
         from gs_train import TrainOptions, Trainer
+        from train_timing import time_training
 
         _, Wc, Hc, _ = CONFIGS[cfg]
         # target = the scene's own render + noise: a non-trivial loss gradient, but the scene stays where it is over the
@@ -373,19 +380,14 @@ def main():
         tr = Trainer([t.clone() for t in params], [cam], [target], TrainOptions(), world_size=world,
                      max_pairs=int(pairs * 1.25) + 4096, exchange=exchange)
         tr.flat.force_collective = (use_dist or force) and dist.is_initialized()
-        it = [0]
-
-        def train_iter():
-            tr.train_step(it[0], 0)
-            it[0] += 1
-
-        # ONE block: every iteration moves the scene a little (the noisy target lowers opacities, tiles composite more
-        # Gaussians before they saturate), so more blocks would time a different scene, not the same one again
-        dtt, _ = time_frames(train_iter, k, 30, repeats=1)
+        tr.flat.enable_collective = bool(collective)
+        dtt, blocks = time_training(tr, k, warm=30, repeats=repeats, barrier=barrier, max_over_ranks=max_over_ranks)
         assert tr.renderer.overflowed_frames == 0 and not tr.renderer.last_frame_overflowed(wait=True)
         detail = {}
         if rank == 0:
             rt, flat = tr.renderer, tr.flat
+            flat.finish_gather()
+            rt.forward_abandon()
             img, _ = rt.forward(*flat.params, cam)
             lossk = tr._loss_for(Hc, Wc)
             pf = [rt.profile_forward(*flat.params, cam)["total"] for _ in range(8)][3:]
@@ -411,6 +413,10 @@ def main():
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": round(28 * n_par / (adam_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                        "parameters": n_par}
+        detail.update(repeats=len(blocks), ms_per_iter_min=round(min(blocks) / k * 1e3, 4),
+                      ms_per_iter_max=round(max(blocks) / k * 1e3, 4), iters_per_block=k,
+                      protocol="30 warm-up iterations, then the same k iterations per block: parameters, Adam moments "
+                               "and step counter restored from a snapshot between blocks (tools/train_timing.py)")
         return world * k / dtt, dtt / k * 1e3, detail, tr
 
     if "train" in legs:
@@ -437,48 +443,77 @@ def main():
     # ---------------------------------------------------------------- multi-GPU: the gradient exchange of a training step
     if "multi_gpu" in legs and not CONFIGS[args.config][3] and use_dist:
         def _leg_multi_gpu():
-            # both exchange modes of gs_dp.py, same scene, same step: (a) two asynchronous mean all-reduces + replicated
-            # fused Adam, (b) two mean reduce-scatters + Adam over the rank's slices + all-gather of the parameters
-            k = max(args.steps // 4, 25)
+            # The training step of the view-parallel job: one view per rank, gradients exchanged once per iteration.
+            # Both exchange modes of gs_dp.py -- (a) mean all-reduce + replicated fused Adam, (b) mean reduce-scatter +
+            # Adam over the rank's shards + all-gather of the parameters -- as a pipeline over slices of the Gaussian
+            # array (sums -> exchange -> Adam -> next frame's project stage, slice by slice), on the headline scene (rgb
+            # colours) and on the cfg4 scene (degree-2 SH: 73 % of the exchanged bytes are coefficients).  Next to every
+            # mode the SAME step without its exchange, in the same process: exposed_ms = what the exchange costs the step.
+            k = max(args.steps // 8, 15)
             seen = torch.ones(1, device=dev)
             dist.all_reduce(seen)
             seen = int(seen.item())
-            mg = {"ranks_seen": seen, "modes": {}}
-            for exchange in ("all_reduce", "reduce_scatter"):
-                views_per_s, ms, _, tr = train_leg(args.config, head_params, head_cam, st.pairs, k, force=True,
-                                                   exchange=exchange)
-                flat = tr.flat
-                flat.finish_gather()
-                mg["bucket_bytes"] = flat.bucket_bytes
+            mg = {"ranks_seen": seen, "scenes": {}}
 
-                def exchange_only():
-                    # the collectives of one step, nothing else: both buckets reduced (and, in reduce-scatter mode, the
-                    # parameters gathered back), as gs_train.Trainer.train_step issues them
-                    for name in ("geometry", "color"):
-                        flat.begin_bucket(name)
-                    for name in ("geometry", "color"):
-                        flat.finish_bucket(name)
-                        flat.begin_gather(name)
-                    flat.finish_gather()
-
-                for _ in range(3):
-                    exchange_only()
-                ex_ms = time_block(exchange_only, 10) / 10 * 1e3
-                mg["modes"][exchange] = {
-                    "train_views_per_s": round(views_per_s, 2), "train_ms_per_iter": round(ms, 4),
-                    "exchange_ms": round(ex_ms, 4),
-                    "busbw_GBs": None if seen < 2 else round(2 * (seen - 1) / seen * flat.bucket_bytes / (ex_ms * 1e-3) / 1e9, 1),
-                    "optimizer_state_bytes_per_rank": sum(v.numel() for v in tr.optimizer.exp_avg.values()) * 8}
-                del tr, flat
+            def one_scene(tag, cfg_name, params_s, cam_s, pairs_s):
+                res = {"modes": {}}
+                _, plain_ms, _, tr = train_leg(cfg_name, params_s, cam_s, pairs_s, k, force=True, collective=False)
+                res["plain_step_ms"] = round(plain_ms, 4)
+                res["n_slices"] = tr.flat.n_slices
+                del tr
                 torch.cuda.empty_cache()
-            best = max(mg["modes"], key=lambda m: mg["modes"][m]["train_views_per_s"])
-            mg.update(best_mode=best, train_views_per_s=mg["modes"][best]["train_views_per_s"],
-                      train_ms_per_iter=mg["modes"][best]["train_ms_per_iter"],
-                      allreduce_ms=mg["modes"]["all_reduce"]["exchange_ms"],
-                      allreduce_busbw_GBs=mg["modes"]["all_reduce"]["busbw_GBs"],
-                      collective="per iteration, RCCL: all_reduce = two asynchronous mean all-reduces of the flat fp32 "
-                                 "gradient buckets + replicated fused Adam; reduce_scatter = two mean reduce-scatters + "
-                                 "fused Adam over the rank's slices + all-gather of the parameters",
+                for exchange in ("all_reduce", "reduce_scatter"):
+                    views_per_s, ms, det, tr = train_leg(cfg_name, params_s, cam_s, pairs_s, k, force=True,
+                                                         exchange=exchange)
+                    flat = tr.flat
+                    flat.finish_gather()
+                    tr.renderer.forward_abandon()
+                    res["bucket_bytes"] = flat.bucket_bytes
+
+                    def exchange_only():
+                        # the collectives of one step, nothing else, as gs_train.Trainer.train_step issues them
+                        for i in range(flat.n_slices):
+                            flat.begin_slice(i)
+                        for i in range(flat.n_slices):
+                            flat.finish_slice(i)
+                            flat.begin_slice_gather(i)
+                        flat.finish_gather()
+
+                    for _ in range(3):
+                        exchange_only()
+                    ex_ms = time_block(exchange_only, 10) / 10 * 1e3
+                    res["modes"][exchange] = {
+                        "train_views_per_s": round(views_per_s, 2), "train_ms_per_iter": round(ms, 4),
+                        "train_ms_per_iter_min": det.get("ms_per_iter_min"), "train_ms_per_iter_max": det.get("ms_per_iter_max"),
+                        "repeats": det.get("repeats"),
+                        # what the exchange adds to the step of the same process without it
+                        "exposed_ms": round(ms - plain_ms, 4),
+                        "exchange_ms": round(ex_ms, 4),
+                        "busbw_GBs": None if seen < 2 else round(2 * (seen - 1) / seen * flat.bucket_bytes / (ex_ms * 1e-3) / 1e9, 1),
+                        "optimizer_state_bytes_per_rank": tr.optimizer.state_bytes}
+                    del tr, flat
+                    torch.cuda.empty_cache()
+                mg["scenes"][tag] = res
+                return res
+
+            head_res = one_scene(args.config, args.config, head_params, head_cam, st.pairs)
+            _, cam4, p4 = load("cfg4")
+            r4, st4 = sized_renderer(p4, cam4, training=False)
+            del r4
+            one_scene("cfg4_sh_deg2", "cfg4", p4, cam4, st4.pairs)
+            del p4
+            torch.cuda.empty_cache()
+            best = max(head_res["modes"], key=lambda m: head_res["modes"][m]["train_views_per_s"])
+            mg.update(modes=head_res["modes"], bucket_bytes=head_res["bucket_bytes"], best_mode=best,
+                      train_views_per_s=head_res["modes"][best]["train_views_per_s"],
+                      train_ms_per_iter=head_res["modes"][best]["train_ms_per_iter"],
+                      exposed_ms=head_res["modes"][best]["exposed_ms"],
+                      allreduce_ms=head_res["modes"]["all_reduce"]["exchange_ms"],
+                      allreduce_busbw_GBs=head_res["modes"]["all_reduce"]["busbw_GBs"],
+                      collective="per iteration, RCCL, one grouped launch per slice of the Gaussian array: all_reduce = "
+                                 "mean all-reduce of the slice's five gradient ranges + replicated fused Adam; "
+                                 "reduce_scatter = mean reduce-scatter + fused Adam over the rank's shards + all-gather "
+                                 "of the parameters; the next frame's project stage follows the optimizer slice by slice",
                       note="1-GPU boxes only for the builder: no 2/4/8-GPU curve measured before the driver's SCALE run")
             out["multi_gpu"] = mg
 
@@ -547,6 +582,9 @@ def main():
                     r4.backward(g4)
 
                 settle(fwd_bwd4, 0.3)  # clocks at their steady state, as for the headline
+                # wall clock of the free-running forward + backward loop (no events, no synchronisation inside a block),
+                # next to the per-stage hipEvent profiles below (which synchronise per frame)
+                wall_dt, wall_blocks = time_frames(fwd_bwd4, 10, 3, repeats=15)
                 fw = [r4.profile_forward(*p4, cam4) for _ in range(8)][2:]
                 bw = [r4.profile_backward(g4) for _ in range(8)][2:]
                 f_ms = statistics.median(x["total"] for x in fw)
@@ -574,6 +612,10 @@ def main():
                     "raster_bwd_ms": round(rb_ms, 3),
                     "project_bwd_ms": round(statistics.median(x["project_bwd"] for x in bw), 3),
                     "fwd_bwd_iters_per_s": round(1e3 / (f_ms + b_ms), 1),
+                    "fwd_bwd_wall": {"ms_per_iter": round(wall_dt / 10 * 1e3, 4), "iters_per_s": round(10 / wall_dt, 1),
+                                     "ms_per_iter_min": round(min(wall_blocks) / 10 * 1e3, 4),
+                                     "ms_per_iter_max": round(max(wall_blocks) / 10 * 1e3, 4), "repeats": len(wall_blocks),
+                                     "what": "free-running forward + backward loop, 10 iterations per block"},
                     "roofline_forward": roof(b_fwd, f_ms), "roofline_backward": roof(b_bwd, b_ms),
                     "roofline_fwd_bwd": roof(b_fwd + b_bwd, f_ms + b_ms),
                     "roofline_raster_backward_kernel": roof(
@@ -592,7 +634,6 @@ def main():
             # the reference's own per-frame call sequence (splatter.py:562-641: T x MAXP table, cumsum, attribute gathers,
             # torch.sort, host syncs) over the drop-in gaussian / renderer modules, at BASELINE configs[1] and at the
             # north-star target scene; next to it the fused frame path the headline is measured on
-            sys.path.insert(0, os.path.join(ROOT, "tools"))
             from compat_fps import measure as compat_measure
 
             extra["compat_mode"] = {c: compat_measure(c, dev, frames=10 if c == "cfg5" else 20) for c in ("cfg2", "cfg5")}

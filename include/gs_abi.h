@@ -38,7 +38,7 @@ extern "C" {
  * gs_frame_debug_rects (records of culled Gaussians are no longer written), gs_frame_overflow_flag,
  * gs_adam_step_sharded, `fast = 0` of gs_draw / gs_draw_backward honoured, the long-list kernels follow GS_FRAME_LONG_LISTS alone (not the
  * workspace capacity).  3: gs_frame.async / flags. */
-#define GS_ABI_VERSION 4
+#define GS_ABI_VERSION 5
 
 #define GS_E_INVALID (-1)   /* bad argument (null pointer, negative size, bad enum)   */
 #define GS_E_UNSUPPORTED (-2) /* valid in the reference but not implemented here (none at present) */
@@ -337,6 +337,31 @@ int gs_frame_backward(const gs_frame *f, const float *grad_image, float *grad_po
 int gs_frame_backward_part(const gs_frame *f, const float *grad_image, float *grad_pos, float *grad_quat,
                            float *grad_scale, float *grad_opa, float *grad_rgb, int32_t part, gs_stream_t stream);
 
+/* ABI 5 -- the frame in pieces, for the view-parallel trainer (gs_dp.py, gs_train.py; no reference analogue: the
+ * reference is single-GPU).  The gradients of a frame only become final in the last kernel of the backward -- the
+ * per-Gaussian sum of the per-pair gradient rows -- and that kernel is independent per Gaussian:
+ *   gs_frame_backward_slice : after gs_frame_backward_part(GS_BWD_RASTER), the sums of the Gaussians [g_begin, g_end)
+ *                             only (g_begin a multiple of 256; `part` = GS_BWD_GEOMETRY, GS_BWD_COLOR or both OR-ed:
+ *                             both in ONE kernel, the rows are read once).  Any partition of [0, N) into ranges writes
+ *                             exactly what gs_frame_backward writes, so that the exchange of one range's gradients
+ *                             runs underneath the sums of the next.
+ * and the NEXT frame's project stage (cull + project + activations + level-1 count) needs nothing but the parameters of
+ * its own Gaussians:
+ *   gs_frame_project_slices : *slices = how many slices of the Gaussian array the project stage of this frame is made
+ *                             of (0: it cannot be issued in pieces -- only sort_mode 2's strip variant can),
+ *                             *per_slice = Gaussians per slice (a multiple of 256);
+ *   gs_frame_forward_project: the project stage of slices [slice_begin, slice_end) -- call it for every slice exactly
+ *                             once, the range that starts at slice 0 first;
+ *   gs_frame_forward_rest   : binning, per-tile sort, compositing.  project(all slices) + rest == gs_frame_forward.
+ * Nothing of the previous frame's workspace contents that its backward still needs is touched by the project stage
+ * except the per-Gaussian records and rectangles, i.e. issue a slice's project only after that slice's
+ * gs_frame_backward_slice (same stream). */
+int gs_frame_backward_slice(const gs_frame *f, float *grad_pos, float *grad_quat, float *grad_scale, float *grad_opa,
+                            float *grad_rgb, int32_t part, int64_t g_begin, int64_t g_end, gs_stream_t stream);
+int gs_frame_project_slices(const gs_frame *f, int32_t *slices, int64_t *per_slice);
+int gs_frame_forward_project(const gs_frame *f, int32_t slice_begin, int32_t slice_end, gs_stream_t stream);
+int gs_frame_forward_rest(const gs_frame *f, gs_stream_t stream);
+
 /* ===================================================================================
  * Section C -- the training step around the frame
  * =================================================================================== */
@@ -374,6 +399,18 @@ int gs_adam_step_sharded(float *param, const float *grad, float *exp_avg_shard, 
                          const int64_t *group_end, const float *lr, float beta1, float beta2, float eps, int64_t step,
                          float *grad_stat, int64_t stat_begin, int64_t stat_end, int32_t stat_mode,
                          const void *skip_if_nonzero, gs_stream_t stream);
+
+/* Up to 8 element ranges [range_begin[r], range_end[r]) of the same flat arrays in ONE launch (host tables;
+ * range_begin a multiple of 4): one slice of the view-parallel exchange is a range of Gaussians in each of the five
+ * parameter arrays.  The moments of range r start at exp_avg + moment_offset[r] (a multiple of 4): element i keeps its
+ * moments at index moment_offset[r] + (i - range_begin[r]) -- moment_offset = range_begin for a replicated optimizer,
+ * densely packed shards for a sharded one.  Group table, statistic and skip flag as in gs_adam_step_sharded; every
+ * element's update is what gs_adam_step computes for it. */
+int gs_adam_step_multi(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, int32_t n_ranges,
+                       const int64_t *range_begin, const int64_t *range_end, const int64_t *moment_offset,
+                       int32_t n_groups, const int64_t *group_end, const float *lr, float beta1, float beta2, float eps,
+                       int64_t step, float *grad_stat, int64_t stat_begin, int64_t stat_end, int32_t stat_mode,
+                       const void *skip_if_nonzero, gs_stream_t stream);
 
 /* Device address of the frame's overflow counter (inside the caller's workspace; 64-bit, 0 = the last forward of this
  * frame description fitted its pair capacity, else the pair count it would have needed).  No launch, no copy. */

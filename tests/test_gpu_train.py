@@ -28,7 +28,7 @@ def make_flat(gpu, n, seed=0, color_dim=3):
 
 @pytest.mark.parametrize("n,stat", [(1, None), (37, "max"), (1000, "mean"), (4099, "max")])
 def test_adam_matches_oracle_and_torch(gpu, n, stat):
-    """Five groups with different learning rates, boundaries that are not multiples of 4, 6 steps."""
+    """Five groups with different learning rates, 6 steps (group boundaries inside a float4: next test)."""
     from gs_train import FusedAdam, GROUPS
 
     flat, rng = make_flat(gpu, n, seed=n)
@@ -57,6 +57,63 @@ def test_adam_matches_oracle_and_torch(gpu, n, stat):
     if stat:
         assert np.allclose(opt.accum_grad.cpu().numpy(), stat_ref, rtol=1e-6, atol=0)
     assert opt.step_count == 6
+
+
+def test_adam_group_boundaries_inside_a_float4(gpu):
+    """gs_adam_step with group boundaries that are no multiples of 4 (FlatGaussianParams pads its regions to multiples
+    of 4 rows since round 4, so the trainer no longer produces them; the C ABI still takes any ascending table): the
+    float4 lanes that straddle a boundary must pick their own group's learning rate.  Also a sub-range launch
+    (gs_adam_step_range) with ragged ends and the multi-range launch against the one-launch result."""
+    import ctypes as C
+
+    from gaussian import _lib
+
+    n = 1003
+    rng = np.random.default_rng(5)
+    ends_l, lrs_l = [7, 310, 311, 640, 1003], [0.03, 0.02, 0.003, 0.004, 0.005]
+    ends, lr = (C.c_int64 * 5)(*ends_l), (C.c_float * 5)(*lrs_l)
+    p0 = rng.normal(size=n).astype(np.float32)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def run(kind):
+        p, m, v = (torch.from_numpy(p0.copy()).to(gpu), torch.zeros(n, device=gpu), torch.zeros(n, device=gpu))
+        g_rng = np.random.default_rng(6)
+        for step in range(1, 5):
+            g = torch.from_numpy(g_rng.normal(size=n).astype(np.float32)).to(gpu)
+            a = (p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n)
+            tail = (5, ends, lr, 0.9, 0.99, 1e-8, step, None, 0, 0, 0)
+            if kind == "one":
+                _lib.check(_lib.gs_adam_step(*a, *tail, stream), "gs_adam_step")
+            elif kind == "ranges":
+                for lo, hi in ((0, 5), (5, 309), (309, 1003)):
+                    _lib.check(_lib.gs_adam_step_range(*a, lo, hi, *tail, stream), "gs_adam_step_range")
+            else:
+                lo_t, hi_t = (C.c_int64 * 3)(0, 308, 312), (C.c_int64 * 3)(308, 312, 1003)
+                _lib.check(_lib.gs_adam_step_multi(*a, 3, lo_t, hi_t, lo_t, *tail, None, stream), "gs_adam_step_multi")
+        return p.cpu().numpy(), m.cpu().numpy(), v.cpu().numpy()
+
+    one = run("one")
+    for kind in ("ranges", "multi"):
+        for x, y in zip(one, run(kind)):
+            assert np.array_equal(x, y)
+    # against the oracle, group by group
+    want = p0.copy()
+    m = np.zeros(n, np.float32)
+    v = np.zeros(n, np.float32)
+    g_rng = np.random.default_rng(6)
+    for step in range(1, 5):
+        g = g_rng.normal(size=n).astype(np.float32)
+        lo = 0
+        for hi, l in zip(ends_l, lrs_l):
+            want[lo:hi], m[lo:hi], v[lo:hi] = train_ref.adam_step(want[lo:hi], g[lo:hi], m[lo:hi], v[lo:hi], l, 0.9, 0.99,
+                                                                  1e-8, step)
+            lo = hi
+    assert np.abs(one[0] - want).max() <= 1e-6 * max(1.0, float(np.abs(want).max()))
+    # the multi-range launch validates its tables
+    bad = (C.c_int64 * 1)(2)
+    rc = _lib.gs_adam_step_multi(0, 0, 0, 0, n, 1, bad, (C.c_int64 * 1)(8), bad, 5, ends, lr, 0.9, 0.99, 1e-8, 1, None, 0, 0,
+                                 0, None, stream)
+    assert rc == -1
 
 
 def test_adam_rejects_bad_arguments(gpu):
@@ -245,11 +302,12 @@ def test_per_view_statistic_path_equals_fused_path(gpu, mode):
 
 @pytest.mark.parametrize("use_sh", [False, True])
 def test_backward_parts_and_bucketed_adam_equal_the_one_call_step(gpu, use_sh):
-    """The view-parallel gradient exchange issues the backward as GS_BWD_RASTER + GS_BWD_GEOMETRY + GS_BWD_COLOR
-    (either order) and Adam bucket by bucket (gs_adam_step_range), so that the all-reduce of one bucket runs under
-    the kernel of the other.  Nothing may change numerically: gradients and the stepped parameters are bit-identical
-    to gs_frame_backward + one gs_adam_step -- with an odd Gaussian count, where the colour bucket does not start
-    on a 16-byte boundary."""
+    """The view-parallel gradient exchange issues the backward as GS_BWD_RASTER + the per-Gaussian sums in pieces --
+    GS_BWD_GEOMETRY / GS_BWD_COLOR over everything (round 2), or slice by slice of the Gaussian array
+    (gs_frame_backward_slice, round 4: both buckets in one kernel, or one part at a time) -- and Adam slice by slice
+    (gs_adam_step_multi), so that a slice's exchange runs under the sums of the next.  Nothing may change numerically:
+    gradients, stepped parameters, moments and the densification statistic are bit-identical to gs_frame_backward + one
+    gs_adam_step -- with an odd Gaussian count (padded regions) and a ragged last slice."""
     from gaussian import _lib
     from gs_dp import FlatGaussianParams
     from gs_frame import FrameRenderer
@@ -262,32 +320,47 @@ def test_backward_parts_and_bucketed_adam_equal_the_one_call_step(gpu, use_sh):
     g = torch.randn(H, W, 3, device=gpu)
     lrs = dict(zip(GROUPS, [0.03, 0.02, 0.003, 0.004, 0.005]))
     outs = []
-    for order in (None, ("geometry", "color"), ("color", "geometry")):
-        flat = FlatGaussianParams([t.clone() for t in params])
-        assert flat.offsets["scale"][0] % 4 != 0  # 7 N floats, N odd: a group boundary inside a float4, on purpose
+    for mode in ("one_call", "parts_gc", "parts_cg", "slices", "slices_by_part"):
+        flat = FlatGaussianParams([t.clone() for t in params], n_slices=3 if mode.startswith("slices") else 1)
+        assert flat.n_pad == 7004 and flat.region["scale"] == 7 * 7004  # regions padded to a multiple of 4 rows
         assert flat.bucket_ranges["color"][0] % 4 == 0 and flat.bucket_ranges["color"][0] >= 10 * 7001  # padded
+        if mode.startswith("slices"):
+            assert flat.n_slices == 3 and flat.slice_gaussians(2)[1] == 7001 and flat.slice_bounds[1] % 256 == 0
         r = FrameRenderer(gpu, max_pairs=1 << 17, training=True, auto_grow=False)
         opt = FusedAdam(flat, [lrs[k] for k in GROUPS], grad_stat="max")
         for _ in range(3):
             r.forward(*flat.params, cam)
-            for gview in flat.grads:  # every element must be written by exactly one part (the buckets' padding is
+            for gview in flat.grads:  # every element must be written by exactly one piece (the regions' padding is
                 gview.fill_(float("nan"))  # nobody's: it stays zero)
-            if order is None:
+            if mode == "one_call":
                 r.backward(g, out=flat.grads)
                 opt.step()
-            else:
-                part = {"geometry": _lib.GS_BWD_GEOMETRY, "color": _lib.GS_BWD_COLOR}
+            elif mode.startswith("parts"):
+                part = {"g": _lib.GS_BWD_GEOMETRY, "c": _lib.GS_BWD_COLOR}
                 r.backward(g, out=flat.grads, part=_lib.GS_BWD_RASTER)
-                for name in order:
+                for name in mode[-2:]:
                     r.backward(None, out=flat.grads, part=part[name])
-                opt.step(order[0])
-                opt.step(order[1], advance=False)
+                opt.step()
+            else:
+                r.backward(g, out=flat.grads, part=_lib.GS_BWD_RASTER)
+                for k in (2, 0, 1):  # any order
+                    g0, g1 = flat.slice_gaussians(k)
+                    if mode == "slices":
+                        r.backward_slice(flat.grads, g0, g1)
+                    else:
+                        r.backward_slice(flat.grads, g0, g1, part=_lib.GS_BWD_COLOR)
+                        r.backward_slice(flat.grads, g0, g1, part=_lib.GS_BWD_GEOMETRY)
+                for i, k in enumerate((1, 2, 0)):
+                    opt.step_slice(k, advance=(i == 0))
         assert opt.step_count == 3 and bool(torch.isfinite(flat.flat_grad).all())
-        outs.append((flat.flat_grad.clone(), flat.flat_param.clone(), torch.cat([opt.exp_avg_sq[k] for k in ("geometry", "color")]), opt.accum_grad.clone()))
+        outs.append((flat.flat_grad.clone(), flat.flat_param.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(),
+                     opt.accum_grad.clone()))
     for other in outs[1:]:
         for a, b in zip(outs[0], other):
             assert torch.equal(a, b)
     assert float((outs[0][1] - FlatGaussianParams(params).flat_param).abs().max()) > 0
+    with pytest.raises(RuntimeError):  # slices start on multiples of 256 Gaussians
+        r.backward_slice(flat.grads, 100, 300)
 
 
 def test_trainer_bucketed_exchange_equals_plain_step(gpu):
@@ -310,8 +383,11 @@ def test_trainer_bucketed_exchange_equals_plain_step(gpu):
     start[4] = start[4] + 0.5 * torch.randn(start[4].shape, device=gpu, generator=torch.Generator(gpu).manual_seed(2))
     opt = TrainOptions(n_iters=100, n_iters_warmup=3, scale_reg=0.01, opa_reg=0.02)
     runs = []
-    # plain step; bucketed all-reduce + replicated Adam; bucketed reduce-scatter + sharded Adam + parameter all-gather
-    for exchange in (None, "all_reduce", "reduce_scatter"):
+    # plain step; then through RCCL (one rank, collective forced): all-reduce + replicated Adam / reduce-scatter + sharded
+    # Adam + parameter all-gather, as ONE exchange unit and as a pipeline over three slices of the Gaussian array with
+    # the next frame's project stage issued slice by slice behind the optimizer (round 4: next_camera_id)
+    for exchange, n_slices, ahead in ((None, 1, False), ("all_reduce", 1, False), ("reduce_scatter", 1, False),
+                                      ("all_reduce", 3, True), ("reduce_scatter", 3, True), ("all_reduce", 3, False)):
         bucketed = exchange is not None
         if bucketed:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -319,10 +395,17 @@ def test_trainer_bucketed_exchange_equals_plain_step(gpu):
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=gpu)
         try:
             tr = Trainer([t.clone() for t in start], [cam], [target], opt, max_pairs=1 << 16,
-                         exchange=exchange or "all_reduce")
+                         exchange=exchange or "all_reduce", n_slices=n_slices)
             tr.flat.force_collective = bucketed
+            assert tr.flat.n_slices == n_slices
             assert tr.flat.collective_active() == bucketed and tr.optimizer.sharded == (exchange == "reduce_scatter")
-            vals = [tr.train_step(it, 0).clone() for it in range(12)]
+            finishes = 0
+            vals = []
+            for it in range(12):
+                finishes += int(tr.renderer.begun_frame_matches(*tr.flat.params, cam))
+                vals.append(tr.train_step(it, 0, next_camera_id=0 if ahead else None).clone())
+            # every frame but the first (whose capacity is checked synchronously) was projected behind the previous step
+            assert finishes == (11 if ahead else 0)
             tr.flat.finish_gather()
             runs.append(([p.clone() for p in tr.flat.params], torch.stack(vals), tr.optimizer.accum_grad.clone()))
         finally:

@@ -88,7 +88,7 @@ def _bucket_worker(rank, world, port, tmp):
     from gs_dp import FlatGaussianParams
 
     rng = np.random.default_rng(40 + rank)
-    n = 501  # odd: the colour bucket starts at element 10 n, not a multiple of 4
+    n = 501  # odd: every tensor's region is padded to 504 rows (a multiple of 4 x world)
     shapes = [(n, 3), (n, 4), (n, 3), (n,), (n, 27)]
     params = [torch.from_numpy(rng.normal(size=s).astype(np.float32)) for s in shapes]
     out = {}
@@ -100,9 +100,12 @@ def _bucket_worker(rank, world, port, tmp):
             flat.all_reduce_grads()
         else:
             assert flat.collective_active()
-            # every bucket is padded to a multiple of 4 x world elements: equal, float4-aligned slices per rank
-            assert flat.bucket_ranges == {"geometry": (0, 5016), "color": (5016, 5016 + 14032)}
-            assert flat.offsets["opa"] == (5016, 5016 + n) and flat.group_ends == [4 * n, 7 * n, 5016, 5016 + n, 19048]
+            # round 4 layout: every tensor owns a region of n_pad rows, n_pad = n rounded up to a multiple of 4 x world
+            # (equal, float4-aligned shards of every bucket AND of every slice range); pad rows never move
+            assert flat.n_pad == 504
+            assert flat.bucket_ranges == {"geometry": (0, 5040), "color": (5040, 5040 + 28 * 504)}
+            assert flat.offsets["opa"] == (5040, 5040 + n)
+            assert flat.group_ends == [4 * 504, 7 * 504, 5040, 5040 + 504, 5040 + 28 * 504]
             flat.begin_bucket("color")      # the order gs_train.Trainer uses with SH colours
             flat.begin_bucket("geometry")
             flat.finish_bucket("color")
@@ -168,6 +171,67 @@ def test_reduce_scatter_sharded_update_equals_all_reduce_replicated_gloo(tmp_pat
     for k in range(world):
         assert np.array_equal(r[k][0], r[k][1])  # sharded == replicated, bit for bit
     assert np.array_equal(r[0][1], r[1][1])      # and the replicas agree
+    assert np.abs(r[0][0]).max() > 0
+
+
+def _slice_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gs_dp import ORDER, FlatGaussianParams, project_slice_size
+
+    n = 1999  # project slices of 256 Gaussians -> 8 of them; three exchange slices, the last one ragged + 1 pad row
+    shapes = [(n, 3), (n, 4), (n, 3), (n,), (n, 27)]
+    params = [torch.from_numpy(np.random.default_rng(5).normal(size=s).astype(np.float32)) for s in shapes]  # replicas
+    out = {}
+    for exchange, sliced in (("all_reduce", False), ("all_reduce", True), ("reduce_scatter", True)):
+        flat = FlatGaussianParams(params, world_size=world, exchange=exchange, n_slices=3 if sliced else 1)
+        if sliced:
+            assert project_slice_size(n) == 256 and flat.n_pad == 2000 and flat.n_slices == 3
+            assert flat.slice_bounds == [0, 768, 1280, 2000]  # whole project slices, multiples of 4 x world
+            # the slices tile every region exactly
+            cover = sorted(rg for k in range(flat.n_slices) for rg in flat.slice_ranges(k))
+            assert cover[0][0] == 0 and cover[-1][1] == flat.flat_grad.numel()
+            assert all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+            assert [flat.slice_gaussians(k) for k in range(3)] == [(0, 768), (768, 1280), (1280, 1999)]
+        for step in range(3):
+            g = np.random.default_rng(1000 * step + rank).normal(size=flat.flat_grad.numel()).astype(np.float32)
+            flat.flat_grad.copy_(torch.from_numpy(g))
+            for t in ORDER:  # what the kernels guarantee: pad rows carry zero gradient
+                lo = flat.offsets[t][1]
+                hi = flat.region[t] + flat.n_pad * flat.width[t]
+                flat.flat_grad[lo:hi].zero_()
+            flat.finish_gather()
+            # the order gs_train.Trainer uses: all exchanges started slice by slice, then per slice: wait, update what
+            # this rank owns, send the updated shards on their way (reduce-scatter mode)
+            for k in range(flat.n_slices):
+                flat.begin_slice(k)
+            for k in range(flat.n_slices):
+                flat.finish_slice(k)
+                for lo, hi in flat.owned(flat.slice_ranges(k)):
+                    assert lo % 4 == 0 and (hi - lo) % 4 == 0
+                    # stand-in for the fused Adam (HIP only): an elementwise update of what this rank owns
+                    flat.flat_param[lo:hi].sub_(0.1 * flat.flat_grad[lo:hi] + 0.01 * torch.sign(flat.flat_param[lo:hi]))
+                flat.begin_slice_gather(k)
+                if k:
+                    flat.finish_slice_gather(k - 1)  # where the next frame's project stage of slice k - 1 would start
+        flat.finish_gather()
+        out[(exchange, sliced)] = flat.flat_param.numpy().copy()
+    np.save(os.path.join(tmp, f"slices_{rank}.npy"), np.stack([out[("all_reduce", False)], out[("all_reduce", True)],
+                                                              out[("reduce_scatter", True)]]))
+    dist.destroy_process_group()
+
+
+def test_slice_pipeline_equals_one_blocking_exchange_gloo(tmp_path):
+    """gs_dp round 4: the gradient exchange cut into slices of the Gaussian array (five element ranges per slice, started
+    slice by slice, waited for slice by slice; all-reduce + replicated update, or reduce-scatter + sharded update +
+    all-gather of the parameters) leaves every rank with exactly the parameters of the single-slice exchange."""
+    world, port = 2, 37500 + (os.getpid() % 2000)
+    mp.spawn(_slice_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"slices_{k}.npy") for k in range(world)]
+    for k in range(world):
+        assert np.array_equal(r[k][0], r[k][1])  # sliced == unsliced, bit for bit
+        assert np.array_equal(r[k][0], r[k][2])  # sharded == replicated
+    assert np.array_equal(r[0][0], r[1][0])      # and the replicas agree
     assert np.abs(r[0][0]).max() > 0
 
 

@@ -56,17 +56,16 @@ for n in sizes:
 
     t3 = timeit(pipelined, steps)
     del rs
-    tr = Trainer(params, [cam], [torch.rand(H, W, 3, device=dev)], TrainOptions(), max_pairs=int(st.pairs * 1.1) + 4096)
-    tr.renderer.auto_grow = False
+    # the training step, timed exactly as bench.py times it (tools/train_timing.py: noisy render of the scene itself as
+    # the target, 30 warm-up iterations, the same k iterations per block restored from a snapshot, median of 15 blocks)
+    from train_timing import time_training
+
+    target = (r.forward(*params, cam)[0] + 0.05 * torch.randn(H, W, 3, device=dev)).clamp_(0, 1).contiguous()
+    tr = Trainer([t.clone() for t in params], [cam], [target], TrainOptions(), max_pairs=int(st.pairs * 1.25) + 4096)
     for k_, v_ in KW.items():
         setattr(tr.renderer, k_, v_)
-    it = [0]
-
-    def step():
-        tr.train_step(it[0], 0)
-        it[0] += 1
-
-    tt = timeit(step, max(steps // 4, 20), 5)
+    k_it = max(steps // 4, 25)
+    tt = time_training(tr, k_it, warm=30, repeats=15)[0] / k_it
     print(json.dumps({"variant": VARIANT, "n_gaussians": n, "visible": st.visible, "tile_pairs": st.pairs,
                       "render_fps_1_stream": round(1 / t1, 1), "render_fps_3_streams": round(1 / t3, 1),
                       "train_iters_per_s": round(1 / tt, 1), "train_ms_per_iter": round(tt * 1e3, 3)}), flush=True)
