@@ -51,7 +51,9 @@ __device__ __forceinline__ void adam_range(float *__restrict__ param, const floa
                                            int64_t lo, int64_t hi, const AdamGroups &G, float one_m_b1, float b2,
                                            float one_m_b2, float inv_bc2_sqrt, float eps,
                                            float *__restrict__ stat, int64_t stat_begin, int64_t stat_end,
-                                           int stat_mode, int64_t moment_base) {
+                                           int stat_mode, int64_t moment_base, float grad_scale = 1.0f) {
+    // grad_scale: the gradient is used as grad * grad_scale (x * 1.0f == x: the plain step is unchanged bit for bit).
+    // The view-parallel exchange SUMS the ranks' gradients and leaves the 1 / world of the mean to this kernel.
     // the moments may be a SHARD that starts at element moment_base (a multiple of 4) of the flat index space
     exp_avg -= moment_base;
     exp_avg_sq -= moment_base;
@@ -74,6 +76,7 @@ __device__ __forceinline__ void adam_range(float *__restrict__ param, const floa
             m = reinterpret_cast<float4 *>(exp_avg)[q];
             v = reinterpret_cast<float4 *>(exp_avg_sq)[q];
         }
+        g.x *= grad_scale; g.y *= grad_scale; g.z *= grad_scale; g.w *= grad_scale;
         const float s0 = group_step(G, i), s3 = group_step(G, i + 3);
         const bool uniform = s0 == s3;  // a float4 straddles a group boundary at most five times per launch
         adam_one(p.x, g.x, m.x, v.x, s0, one_m_b1, b2, one_m_b2, inv_bc2_sqrt, eps);
@@ -111,7 +114,7 @@ __device__ __forceinline__ void adam_range(float *__restrict__ param, const floa
         t = tail_begin + (gt - 4);
     if (t >= 0) {
         float p = param[t], m = exp_avg[t], v = exp_avg_sq[t];
-        const float g = grad[t];
+        const float g = grad[t] * grad_scale;
         adam_one(p, g, m, v, group_step(G, t), one_m_b1, b2, one_m_b2, inv_bc2_sqrt, eps);
         param[t] = p;
         exp_avg[t] = m;
@@ -152,11 +155,12 @@ __global__ void __launch_bounds__(256) adam_multi_kernel(float *__restrict__ par
                                                          float one_m_b2, float inv_bc2_sqrt, float eps,
                                                          float *__restrict__ stat, int64_t stat_begin, int64_t stat_end,
                                                          int stat_mode,
-                                                         const unsigned long long *__restrict__ skip_if_nonzero) {
+                                                         const unsigned long long *__restrict__ skip_if_nonzero,
+                                                         float grad_scale) {
     if (skip_if_nonzero && *skip_if_nonzero) return;
     const int r = blockIdx.y;
     adam_range<NT>(param, grad, exp_avg, exp_avg_sq, R.lo[r], R.hi[r], G, one_m_b1, b2, one_m_b2, inv_bc2_sqrt, eps,
-                   stat, stat_begin, stat_end, stat_mode, R.moment_base[r]);
+                   stat, stat_begin, stat_end, stat_mode, R.moment_base[r], grad_scale);
 }
 
 // the statistic alone (view-parallel training: it must see this rank's OWN gradient, before the all-reduce)
@@ -269,15 +273,16 @@ extern "C" int gs_adam_step_sharded(float *param, const float *grad, float *exp_
 // Up to 8 element ranges [range_begin[r], range_end[r]) of the same flat arrays in one launch (host arrays).  The moments
 // of range r start at exp_avg + moment_offset[r] (a multiple of 4): element i of range r keeps its moments at index
 // moment_offset[r] + (i - range_begin[r]) -- identity (moment_offset = range_begin) for a replicated optimizer, densely
-// packed shards for a sharded one.  range_begin[r] must be a multiple of 4.  Every element's update is what gs_adam_step
-// computes for it.
+// packed shards for a sharded one.  range_begin[r] must be a multiple of 4.  grad_scale: the gradient is used as
+// grad * grad_scale (1 / world after a SUM all-reduce; 1: every element's update is what gs_adam_step computes for it).
 extern "C" int gs_adam_step_multi(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
                                   int32_t n_ranges, const int64_t *range_begin, const int64_t *range_end,
                                   const int64_t *moment_offset, int32_t n_groups, const int64_t *group_end,
                                   const float *lr, float beta1, float beta2, float eps, int64_t step, float *grad_stat,
                                   int64_t stat_begin, int64_t stat_end, int32_t stat_mode, const void *skip_if_nonzero,
-                                  gs_stream_t stream) {
+                                  float grad_scale, gs_stream_t stream) {
     GS_CHECK_ARG(n >= 0, "n < 0");
+    GS_CHECK_ARG(grad_scale > 0.f && grad_scale < 3.0e38f, "grad_scale must be positive and finite");
     GS_CHECK_ARG(n_ranges >= 1 && n_ranges <= GS_ADAM_MAX_RANGES, "n_ranges must be in [1, 8]");
     GS_CHECK_ARG(range_begin && range_end && moment_offset, "null range table");
     GS_CHECK_ARG(n_groups >= 1 && n_groups <= GS_ADAM_MAX_GROUPS, "n_groups must be in [1, 8]");
@@ -323,11 +328,11 @@ extern "C" int gs_adam_step_multi(float *param, const float *grad, float *exp_av
     if ((unsigned long long)n * 16ull > GS_ADAM_NT_BYTES)
         hipLaunchKernelGGL(adam_multi_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
                            exp_avg_sq, R, G, 1.0f - beta1, beta2, 1.0f - beta2, (float)(1.0 / sqrt(bc2)), eps, grad_stat,
-                           stat_begin, stat_end, (int)stat_mode, (const unsigned long long *)skip_if_nonzero);
+                           stat_begin, stat_end, (int)stat_mode, (const unsigned long long *)skip_if_nonzero, grad_scale);
     else
         hipLaunchKernelGGL(adam_multi_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
                            exp_avg_sq, R, G, 1.0f - beta1, beta2, 1.0f - beta2, (float)(1.0 / sqrt(bc2)), eps, grad_stat,
-                           stat_begin, stat_end, (int)stat_mode, (const unsigned long long *)skip_if_nonzero);
+                           stat_begin, stat_end, (int)stat_mode, (const unsigned long long *)skip_if_nonzero, grad_scale);
     GS_CHECK_LAUNCH();
     return 0;
 }

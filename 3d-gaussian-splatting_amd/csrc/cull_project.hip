@@ -190,12 +190,18 @@ __device__ __forceinline__ void project_backward(const float p[3], const float q
     const float c_qk[9] = {-4 * sx * qk, -2 * sy * qr, 2 * sz * qi, 2 * sx * qr, -4 * sy * qk, 2 * sz * qj,
                            2 * sx * qi, 2 * sy * qj, 0};
     float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    {
+        // NOT contracted: for an isotropic Gaussian the rotation has no effect and these sums are +p - p with both
+        // products rounded alike, i.e. exactly zero (COLMAP-initialised scenes are all isotropic); an fma would leave the
+        // rounding error of one product as a "gradient" (tests/test_gpu_splatter.py caught 5e-8 against an exact 0)
+#pragma clang fp contract(off)
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        a0 += c_qr[i] * gRS[i];
-        a1 += c_qi[i] * gRS[i];
-        a2 += c_qj[i] * gRS[i];
-        a3 += c_qk[i] * gRS[i];
+        for (int i = 0; i < 9; ++i) {
+            a0 += c_qr[i] * gRS[i];
+            a1 += c_qi[i] * gRS[i];
+            a2 += c_qj[i] * gRS[i];
+            a3 += c_qk[i] * gRS[i];
+        }
     }
     gq[0] = a0;
     gq[1] = a1;

@@ -111,6 +111,9 @@ static inline bool gs_frame_uses_strips(const gs_frame *f) {
     const int ntx = (f->width + GS_TILE - 1) / GS_TILE, nty = (f->height + GS_TILE - 1) / GS_TILE;
     if (!gs_strip_plan_for(f->N, ntx, nty).ok) return false;
     if (f->flags & GS_FRAME_STRIP_BIN) return true;
+    // the kernels for long tile lists (big-list sort, segmented compositing) belong to the strip variant: a frame that
+    // asks for them gets it whatever its size (round 4: below GS_STRIP_AUTO_MIN_N the flag used to be ignored silently)
+    if (f->flags & GS_FRAME_LONG_LISTS) return true;
     // small scenes take the table variant where it exists (one LDS counter per tile)
     return f->N >= GS_STRIP_AUTO_MIN_N || ntx * nty > GS_BIN_MAX_TILES;
 }

@@ -937,8 +937,8 @@ int gs_stage_raster_forward(const gs_frame *f, const gs_frame_ws &ws, const uint
                        !(f->flags & GS_FRAME_SERIAL_LONG_LISTS);
     float4 *cs = dense ? ws.cont_state : nullptr;
     uint32_t *cf = dense ? ws.cont_flag : nullptr;
-    // longest-first dispatch: the order is written by the strip variant's binning (strip_bin.hip); the cost is recorded
-    // whenever there is room for it, so that a later strip-variant frame of this workspace finds it
+    // longest-first dispatch: the order is written by the strip variant's project + count launch and the cost is recorded
+    // by strip-variant frames only (frames of the other variants neither read the order nor record a cost)
     const bool ordered = gs_frame_uses_strips(f) && f->N > 0 && ws.tile_order != nullptr;
     const uint32_t *order = ordered ? ws.tile_order : nullptr;
     uint32_t *cost = ordered ? ws.tile_cost : nullptr;

@@ -236,7 +236,14 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_scatter_kernel(
     // 64-bit totals: a degenerate scene (hundreds of thousands of screen-filling Gaussians) can exceed 2^32 pairs,
     // and a wrapped total must not slip under the capacity test
     unsigned long long mine = 0;
-    for (uint32_t t = t0; t < t1; ++t) mine += tile_count[t];
+    uint32_t longest = 0;  // the frame's longest tile list (slice 0 reports it: GS_CNT_MAXLIST)
+    for (uint32_t t = t0; t < t1; ++t) {
+        const uint32_t c = tile_count[t];
+        mine += c;
+        longest = c > longest ? c : longest;
+    }
+    __shared__ uint32_t s_longest;
+    if (threadIdx.x == 0) s_longest = 0;
     // listed pairs M (sum over tiles) and gradient-row slots R (sum of the rectangle areas; R == M unless DIST)
     unsigned long long rp = 0, rv = 0;
     for (uint32_t b = threadIdx.x; b < B; b += BIN_THREADS) {
@@ -281,13 +288,20 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_scatter_kernel(
         for (uint32_t b = threadIdx.x; b < B; b += BIN_THREADS) p += b < slice ? slice_pairs[b] : 0;
         block_excl_scan(p, s_wave, before);
     }
+    // the longest-list statistic (lists beyond GS_LONGEST_MIN only, as strip_sort_kernel reports it): the table variant
+    // has no kernels for long lists, but a renderer that reads the statistic back must learn that the frame has one --
+    // it then asks for the strip variant and its long-list kernels (GS_FRAME_LONG_LISTS; ADVICE round 3: a small scene
+    // with a pile-up used to stay on the serial path for ever because this counter read 0 here)
+    if (slice == 0 && longest > (uint32_t)GS_LONGEST_MIN) atomicMax(&s_longest, longest);  // (s_longest was zeroed before
+                                                                                           // the barriers of the block sums)
     if (slice == 0 && threadIdx.x == 0) {
         counters[GS_CNT_PAIRS] = M;
         counters[GS_CNT_OVERFLOW] = 0;
         counters[GS_CNT_VISIBLE] = V;
-        counters[GS_CNT_BIG] = counters[GS_CNT_GROUPS] = counters[GS_CNT_MAXLIST] = 0;  // strip variant only
+        counters[GS_CNT_BIG] = counters[GS_CNT_GROUPS] = 0;  // strip variant only
     }
     __syncthreads();
+    if (slice == 0 && threadIdx.x == 0) counters[GS_CNT_MAXLIST] = s_longest;
     // 3. scatter, one horizontal BAND of the tile grid at a time.  A workgroup writes into T output streams (one per
     // tile); at 2.4 M Gaussians the lines those streams keep open add up to ~7 MB per XCD against 4 MB of L2, every
     // line left L2 several times half-filled (PMC: WRITE_SIZE 255 MB for 55.6 MB of pairs, 4.6 x) and the stores made

@@ -107,7 +107,7 @@ gs_adam_step_sharded = _sig("gs_adam_step_sharded", ci, vp, vp, vp, vp, i64, i64
                             C.POINTER(f32), f32, f32, f32, i64, vp, i64, i64, i32, vp, vp)
 gs_adam_step_multi = _sig("gs_adam_step_multi", ci, vp, vp, vp, vp, i64, i32, C.POINTER(i64), C.POINTER(i64),
                           C.POINTER(i64), i32, C.POINTER(i64), C.POINTER(f32), f32, f32, f32, i64, vp, i64, i64, i32, vp,
-                          vp)
+                          f32, vp)
 gs_frame_overflow_flag = _sig("gs_frame_overflow_flag", ci, C.POINTER(GsFrame), C.POINTER(vp))
 gs_grad_stat_update = _sig("gs_grad_stat_update", ci, vp, vp, i64, i32, vp)
 gs_frame_async_create = _sig("gs_frame_async_create", ci, C.POINTER(vp))

@@ -57,19 +57,6 @@ def project_slice_size(n: int) -> int:
     return -(-(-(-n // 256)) // 256) * 256
 
 
-class _Works:
-    """The pending collective(s) of one exchange unit: a coalescing manager (RCCL: one grouped launch) or a list of
-    works (backends without coalesced collectives, i.e. gloo in the CPU tests)."""
-
-    def __init__(self, works):
-        self.works = works
-
-    def wait(self):
-        for w in self.works:
-            if w is not None:
-                w.wait()
-
-
 class FlatGaussianParams:
     """params / grads in the canonical (pos, quat, scale, opa, rgb) order, stored flat.
 
@@ -94,6 +81,12 @@ class FlatGaussianParams:
         self.exchange = exchange
         self.force_collective = bool(force_collective)  # issue the collectives even with one rank
         self.enable_collective = True  # False (measurement only, bench.py): the step without its gradient exchange
+        # True (gs_train.Trainer): the exchange SUMS and the optimizer applies the 1 / world of the mean to the gradient
+        # it reads (gs_adam_step_multi's grad_scale).  RCCL's ReduceOp.AVG is a pre-multiplied sum: it launches its
+        # scaling kernel for every range even on ONE rank (oneRankReduce<FuncPreMulSum>: 40 launches, 0.28 ms per step
+        # at 2.4 M Gaussians in the round-4 trace), a SUM over one rank is nothing at all.  False: after finish_exchange
+        # the buffer holds the mean (AVG inside RCCL; SUM + a scaling pass on backends without AVG).
+        self.mean_in_optimizer = False
         if rank is None:
             rank = dist.get_rank() if (dist.is_initialized() and self.world_size > 1) else 0
         self.rank = int(rank)
@@ -131,13 +124,19 @@ class FlatGaussianParams:
         step = per * (quantum // math.gcd(per, quantum))  # whole project slices AND multiples of 4 x world Gaussians
         n_steps = max(-(-self.n_pad // step), 1)
         if n_slices is None:
-            n_slices = min(max(n // 250_000, 1), 8)  # ~8 slices at 2.4 M Gaussians; small scenes: one (launch-bound)
+            # One slice on a single rank (nothing travels: nothing to hide), two from a million Gaussians on when there
+            # are peers.  Measured on one rank at 2.4 M Gaussians (round 4, profiles/r04_e_exchange_probe_*.jsonl): every
+            # extra slice costs the step 70 - 90 us -- the per-slice kernels fill less of the chip (a project launch over
+            # half the slices takes 55 us against 80 us for all of them) -- while the exchange time a further slice can
+            # hide shrinks as 1 / K: DESIGN.md section 4 has the model.
+            n_slices = 2 if (n >= 1_000_000 and self.world_size > 1) else 1
         k_slices = max(1, min(int(n_slices), n_steps))
         bounds = sorted({min(round(i * n_steps / k_slices) * step, self.n_pad) for i in range(k_slices)} | {self.n_pad})
         self.slice_bounds = [0] + [b for b in bounds if b > 0]
         self.project_slice = per
         self._pending = {}
         self._pending_gather = {}
+        self._view_cache = {}
 
     # ---- geometry of the exchange units --------------------------------------------------------------------------
     @property
@@ -203,15 +202,18 @@ class FlatGaussianParams:
     def collective_active(self) -> bool:
         return self.enable_collective and dist.is_initialized() and (self.world_size > 1 or self.force_collective)
 
-    def _issue(self, fn, args_list):
-        """One collective per entry of ``args_list``, asynchronously; several of them travel as ONE grouped RCCL launch
-        (torch's coalescing manager: ncclGroupStart / End), backends without coalesced collectives get one call each."""
-        if len(args_list) > 1 and dist.get_backend() == "nccl":
-            with dist._coalescing_manager(async_ops=True) as cm:
-                for args, kw in args_list:
-                    fn(*args, **kw)
-            return _Works([cm])
-        return _Works([fn(*args, async_op=True, **kw) for args, kw in args_list])
+    # The collectives go straight to the process group's C++ entry points (allreduce_coalesced & co.: several ranges = ONE
+    # grouped RCCL launch) with tensor views that are built once per unit: torch.distributed's Python wrappers cost
+    # ~80 us per grouped call on the host (21 us this way, measured on gloo), and a step issues two or three per slice.
+    def _views(self, key, ranges):
+        v = self._view_cache.get(key)
+        if v is None:
+            own = self.owned(ranges)
+            v = {"ranges": list(ranges), "own": own,
+                 "g": [self.flat_grad[lo:hi] for lo, hi in ranges], "g_own": [self.flat_grad[lo:hi] for lo, hi in own],
+                 "p": [self.flat_param[lo:hi] for lo, hi in ranges], "p_own": [self.flat_param[lo:hi] for lo, hi in own]}
+            self._view_cache[key] = v
+        return v
 
     def begin_exchange(self, key, ranges):
         """Start the mean all-reduce (or reduce-scatter) of the element ranges of one unit without waiting for it.  The
@@ -219,38 +221,42 @@ class FlatGaussianParams:
         stream so far -- i.e. for the kernel that wrote the ranges."""
         if not self.collective_active():
             return
-        avg = dist.get_backend() == "nccl"
+        pg = dist.distributed_c10d._get_default_group()
+        # mean: inside the collective (RCCL: AVG), by a scaling pass in finish_exchange (gloo: SUM only), or left to the
+        # optimizer (mean_in_optimizer: SUM, nothing else)
+        avg = dist.get_backend() == "nccl" and not self.mean_in_optimizer
         op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
-        g = self.flat_grad
+        v = self._views(key, ranges)
         if self.exchange == "reduce_scatter":
-            own = self.owned(ranges)
+            o = dist.ReduceScatterOptions()
+            o.reduceOp = op
             # in place: the output is this rank's shard of the input (RCCL's in-place reduce-scatter layout)
-            works = self._issue(dist.reduce_scatter_tensor,
-                                [((g[slo:shi], g[lo:hi]), {"op": op}) for (lo, hi), (slo, shi) in zip(ranges, own)])
-            self._pending[key] = (works, avg, own)
+            work = pg.reduce_scatter_tensor_coalesced(v["g_own"], v["g"], o)
+            self._pending[key] = (work, avg, v["g_own"])
         else:
-            works = self._issue(dist.all_reduce, [((g[lo:hi],), {"op": op}) for lo, hi in ranges])
-            self._pending[key] = (works, avg, list(ranges))
+            o = dist.AllreduceCoalescedOptions()
+            o.reduceOp = op
+            work = pg.allreduce_coalesced(v["g"], o)
+            self._pending[key] = (work, avg, v["g"])
 
     def finish_exchange(self, key):
         """Make the current stream wait for the unit's reduction (and scale it on backends without AVG)."""
         pend = self._pending.pop(key, None)
         if pend is None:
             return
-        works, avg, touched = pend
-        works.wait()
-        if not avg:
-            for lo, hi in touched:
-                self.flat_grad[lo:hi].mul_(1.0 / self.world_size)
+        work, avg, touched = pend
+        work.wait()
+        if not avg and not self.mean_in_optimizer:
+            for t in touched:
+                t.mul_(1.0 / self.world_size)
 
     def begin_param_gather(self, key, ranges):
         """reduce-scatter mode: all-gather the unit's updated PARAMETER shards (in place), without waiting."""
         if not self.collective_active() or self.exchange != "reduce_scatter":
             return
-        p = self.flat_param
-        own = self.owned(ranges)
-        self._pending_gather[key] = self._issue(
-            dist.all_gather_into_tensor, [((p[lo:hi], p[slo:shi]), {}) for (lo, hi), (slo, shi) in zip(ranges, own)])
+        pg = dist.distributed_c10d._get_default_group()
+        v = self._views(key, ranges)
+        self._pending_gather[key] = pg.allgather_into_tensor_coalesced(v["p"], v["p_own"])
 
     def finish_gather(self, name=None):
         """Make the current stream wait for the parameter all-gather(s): before anything reads the parameters."""

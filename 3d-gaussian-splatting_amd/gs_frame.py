@@ -111,7 +111,14 @@ class FrameRenderer:
         ck = (int(camera.width), int(camera.height), float(camera.focal_x), float(camera.focal_y),
               float(camera.near), np.asarray(camera.rot, np.float32).tobytes(),
               np.asarray(camera.tran, np.float32).tobytes())
+        # what a cache hit must not skip: a different tensor may reuse an address -- a freed fp32 tensor
+        # replaced by an fp16 one, a strided view that shares its base's data_ptr.  dtype / contiguity are checked on every
+        # call (~1 us), the shapes are part of the key.
+        for name, t in (("pos", pos), ("quat", quat), ("scale", scale), ("opa", opa), ("rgb", rgb)):
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise RuntimeError(f"{name} must be a contiguous float32 HIP tensor")
         key = (ck, pos.data_ptr(), quat.data_ptr(), scale.data_ptr(), opa.data_ptr(), rgb.data_ptr(),
+               tuple(pos.shape), tuple(quat.shape), tuple(scale.shape), tuple(opa.shape), tuple(rgb.shape),
                pos.shape[0], rgb.shape[-1] if rgb.dim() == 2 else 1, bool(training), self.max_pairs, self.sort_mode,
                self.tile_culling_method, self.tile_culling_dist_thresh, self.thresh, self.scale_activation,
                self.emit_sorted_keys, self.slice_sort, self.table_bin, self.force_strips, self.serial_long_lists,

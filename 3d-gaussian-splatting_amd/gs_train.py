@@ -162,8 +162,9 @@ class FusedAdam:
             self.accum_grad.data_ptr() if self.accum_grad is not None else None, b, e, self.stat_mode, self.skip_flag,
             torch.cuda.current_stream().cuda_stream), "gs_adam_step")
 
-    def step_slice(self, k: int, advance: bool = False):
-        """The same step for exchange slice ``k`` only (pass ``advance=True`` for the first slice of a step)."""
+    def step_slice(self, k: int, advance: bool = False, grad_scale: float = 1.0):
+        """The same step for exchange slice ``k`` only (pass ``advance=True`` for the first slice of a step).
+        ``grad_scale``: the gradient enters as grad * grad_scale (1 / world after a SUM exchange: gs_dp.py)."""
         if advance:
             self.step_count += 1
         n_r, lo, hi, off = self._units[k]
@@ -175,7 +176,8 @@ class FusedAdam:
             f.flat_param.data_ptr(), f.flat_grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
             f.flat_param.numel(), n_r, lo, hi, off, len(ORDER), self._ends, self._lr, self.betas[0], self.betas[1],
             self.eps, self.step_count, self.accum_grad.data_ptr() if self.accum_grad is not None else None, b, e,
-            self.stat_mode, self.skip_flag, torch.cuda.current_stream().cuda_stream), "gs_adam_step_multi")
+            self.stat_mode, self.skip_flag, float(grad_scale), torch.cuda.current_stream().cuda_stream),
+            "gs_adam_step_multi")
 
 
 class ImageLoss:
@@ -250,6 +252,7 @@ class Trainer:
         force = getattr(getattr(self, "flat", None), "force_collective", False)
         self.flat = FlatGaussianParams(params, world_size=self.world_size, exchange=self.exchange,
                                        force_collective=force, n_slices=self.n_slices)
+        self.flat.mean_in_optimizer = True  # the exchange sums, step_slice applies 1 / world (gs_dp.py)
         self.renderer.forward_abandon()  # a frame projected ahead belonged to the old Gaussian set
         split_stat = self.densify and self.per_view_stat
         self.optimizer = FusedAdam(self.flat, [b * f(i_iter) for b, f in zip(self._base, self._lambdas)],
@@ -354,7 +357,7 @@ class Trainer:
             for k in range(K + lag):
                 if k < K:
                     flat.finish_slice(k)
-                    self.optimizer.step_slice(k, advance=(k == 0))
+                    self.optimizer.step_slice(k, advance=(k == 0), grad_scale=1.0 / max(self.world_size, 1))
                     flat.begin_slice_gather(k)  # reduce-scatter mode only: the updated shards travel underneath ...
                 j = k - lag
                 if ahead and j >= 0:

@@ -234,12 +234,16 @@ def main():
             achieved = alg["raster"] / (stage_ms["raster"] * 1e-3) / 1e9
             # HBM bytes per launch and the SIMDs' VALU-issue occupancy from committed PMC passes (profiles/traffic.json),
             # if they belong to this workload
-            traffic = issue_busy = None
+            traffic = issue_busy = correction = bounds = None
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[cfg]
                 if tj["tile_pairs"] == st.pairs:
                     traffic = tj["raster_forward_kernel"]["traffic_bytes"]
                     issue_busy = tj["raster_forward_kernel"].get("issue_busy")
+                    # how FETCH_SIZE was turned into bytes for THIS kernel's access pattern (round 4: calibrated per
+                    # pattern, profiles/r04_fetch_calibration.json) and the bounds the truth lies between
+                    correction = tj["raster_forward_kernel"].get("correction")
+                    bounds = tj["raster_forward_kernel"].get("traffic_bytes_bounds")
             except (OSError, KeyError, ValueError):
                 pass
             roof = {"bound": "hbm", "kernel": "raster_forward_kernel", "achieved": round(achieved, 1),
@@ -249,6 +253,7 @@ def main():
                     # their pixels are saturated, so this is BELOW frac on a scene with many hidden Gaussians)
                     "traffic_frac": None if traffic is None else round(
                         traffic / (stage_ms["raster"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "correction": correction, "traffic_bounds": bounds,
                     "issue_busy": issue_busy, "kernel_ms": round(stage_ms["raster"], 4), "workload": cfg}
             if not use_sh:
                 # the compositing kernel is fp32-VALU bound, not HBM bound: 73 flops per Gaussian

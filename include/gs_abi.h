@@ -292,7 +292,11 @@ int gs_frame_stats_async(const gs_frame *f, int64_t *stats_host, gs_stream_t str
  * above ~2048 sets GS_FRAME_LONG_LISTS on the following frames. */
 int gs_frame_longest_list_async(const gs_frame *f, int64_t *longest_host, gs_stream_t stream);
 
-/* Read-only views into the workspace of the last forward (for parity tests): sorted keys
+/* (Validity, since ABI 4: `tiles_touched` is written by sort_modes 0 / 1 only -- sort_mode 2 keeps the count in
+ * rects[i].w, gs_frame_debug_rects -- and the rec_* records are written for VISIBLE Gaussians only: the record of a
+ * culled Gaussian holds whatever an earlier frame left there.  The culling mask is `rects[i].z != 0`, never
+ * `rec_geom[i].z != 0`.)
+ * Read-only views into the workspace of the last forward (for parity tests): sorted keys
  * (u64 [M]; NULL for a sort_mode-2 frame rendered without GS_FRAME_EMIT_SORTED_KEYS -- they are
  * (tile << 32 | depth bits of rec_geom[id].z) of the sorted ids), sorted Gaussian ids (u32 [M]), per-tile
  * ranges (int32 [T,2]), projected pos/cov/mask-equivalents.  Any out pointer may be NULL. */
@@ -404,13 +408,15 @@ int gs_adam_step_sharded(float *param, const float *grad, float *exp_avg_shard, 
  * range_begin a multiple of 4): one slice of the view-parallel exchange is a range of Gaussians in each of the five
  * parameter arrays.  The moments of range r start at exp_avg + moment_offset[r] (a multiple of 4): element i keeps its
  * moments at index moment_offset[r] + (i - range_begin[r]) -- moment_offset = range_begin for a replicated optimizer,
- * densely packed shards for a sharded one.  Group table, statistic and skip flag as in gs_adam_step_sharded; every
- * element's update is what gs_adam_step computes for it. */
+ * densely packed shards for a sharded one.  Group table, statistic and skip flag as in gs_adam_step_sharded.
+ * grad_scale: the gradient enters as grad * grad_scale -- 1 / world when the exchange SUMS the ranks' gradients and
+ * leaves the mean to the optimizer (RCCL's ReduceOp.AVG is a pre-multiplied sum that launches a scaling kernel even on
+ * one rank; SUM does not), 1 otherwise: every element's update is then what gs_adam_step computes for it. */
 int gs_adam_step_multi(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, int32_t n_ranges,
                        const int64_t *range_begin, const int64_t *range_end, const int64_t *moment_offset,
                        int32_t n_groups, const int64_t *group_end, const float *lr, float beta1, float beta2, float eps,
                        int64_t step, float *grad_stat, int64_t stat_begin, int64_t stat_end, int32_t stat_mode,
-                       const void *skip_if_nonzero, gs_stream_t stream);
+                       const void *skip_if_nonzero, float grad_scale, gs_stream_t stream);
 
 /* Device address of the frame's overflow counter (inside the caller's workspace; 64-bit, 0 = the last forward of this
  * frame description fitted its pair capacity, else the pair count it would have needed).  No launch, no copy. */

@@ -123,6 +123,35 @@ def test_long_list_kernels_follow_the_longest_list_statistic(gpu):
     assert np.array_equal(v["sorted_ids"].cpu().numpy(), of.ids)
 
 
+def test_small_scene_with_a_pile_switches_to_the_long_list_kernels(gpu):
+    """below 131,072 Gaussians sort_mode 2 takes the TABLE variant, whose kernels used to report 0 for the
+    longest list -- a small scene with a pile-up (the case the long-list kernels were built for) stayed on the serial path
+    for ever.  Now the table variant reports its longest list too, the renderer latches GS_FRAME_LONG_LISTS, and a frame
+    with that flag takes the strip variant (which owns the long-list kernels) whatever the scene size."""
+    scene, cam = case(10_000, 256, 256, seed=37)
+    pile = np.arange(3000, 10_000)
+    rng = np.random.default_rng(2)
+    scene.pos[pile] = scene.pos[0] + rng.normal(scale=0.002, size=(len(pile), 3)).astype(np.float32)
+    scene.scale[pile] = np.float32(0.003)
+    scene.opa[pile] = -7.0
+    of = OracleFrame(scene, cam)
+    longest = int(np.diff(of.accum).max())
+    assert longest > 4096
+    params = to_torch(scene, gpu)
+    r = FrameRenderer(gpu, max_pairs=len(of.ids) + 64, auto_grow=True, force_strips=False)  # the library's own choice
+    first, _ = r.forward(*params, cam)
+    assert r.binning_variant() == "table" and not (r._frame.flags & 16)
+    assert r.stats().longest_list == longest and r._long_lists_seen
+    second, _ = r.forward(*params, cam)
+    assert r._frame.flags & 16 and r.binning_variant() == "strip"  # GS_FRAME_LONG_LISTS => strips + long-list kernels
+    assert float((second - first).abs().max()) < 1e-5
+    assert np.array_equal(r.debug_views()["sorted_ids"].cpu().numpy(), of.ids)
+    # an explicit long_lists=True on a small scene no longer falls through to the table variant either
+    r2 = FrameRenderer(gpu, max_pairs=len(of.ids) + 64, auto_grow=False, force_strips=False, long_lists=True)
+    third, _ = r2.forward(*params, cam)
+    assert r2.binning_variant() == "strip" and torch.equal(third, second)
+
+
 @pytest.mark.parametrize("use_sh", [False, True])
 def test_long_lists_composited_in_segments(gpu, use_sh):
     """Dense frame with low-opacity pile-ups: every tile's pixels are still alive after 4096 Gaussians, so the rest

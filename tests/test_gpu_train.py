@@ -89,7 +89,7 @@ def test_adam_group_boundaries_inside_a_float4(gpu):
                     _lib.check(_lib.gs_adam_step_range(*a, lo, hi, *tail, stream), "gs_adam_step_range")
             else:
                 lo_t, hi_t = (C.c_int64 * 3)(0, 308, 312), (C.c_int64 * 3)(308, 312, 1003)
-                _lib.check(_lib.gs_adam_step_multi(*a, 3, lo_t, hi_t, lo_t, *tail, None, stream), "gs_adam_step_multi")
+                _lib.check(_lib.gs_adam_step_multi(*a, 3, lo_t, hi_t, lo_t, *tail, None, 1.0, stream), "gs_adam_step_multi")
         return p.cpu().numpy(), m.cpu().numpy(), v.cpu().numpy()
 
     one = run("one")
@@ -112,7 +112,7 @@ def test_adam_group_boundaries_inside_a_float4(gpu):
     # the multi-range launch validates its tables
     bad = (C.c_int64 * 1)(2)
     rc = _lib.gs_adam_step_multi(0, 0, 0, 0, n, 1, bad, (C.c_int64 * 1)(8), bad, 5, ends, lr, 0.9, 0.99, 1e-8, 1, None, 0, 0,
-                                 0, None, stream)
+                                 0, None, 1.0, stream)
     assert rc == -1
 
 

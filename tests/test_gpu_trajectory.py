@@ -1,0 +1,93 @@
+"""BASELINE configs[2] ("training loop ... PSNR parity") without a dataset: the training TRAJECTORY is pinned instead.
+
+K steps of the HIP trainer (gs_train.Trainer: fused frame forward / backward, fused L1 + SSIM loss, fused Adam, the
+reference's learning-rate schedule) against K steps of an ORACLE trainer assembled from the checkers only -- the C
+oracle's forward / backward (oracle/gs_oracle.c, pinned against the reference's kernels), oracle/train_ref.py's loss
+gradient (fp64) and Adam (torch's operation order), and the schedule of train.py:29-58 restated here -- on the same
+~3 k-Gaussian scene, from the same perturbed start.  What is bounded: the loss of every step, and how far the two
+parameter trajectories drift apart relative to how far they travel (train.py:84-185)."""
+import numpy as np
+import pytest
+import torch
+
+from gs_testutil import OracleFrame, to_torch
+from oracle import train_ref
+
+pytestmark = pytest.mark.gpu
+
+
+# Bounds (measured on MI355X: profiles/r04_trajectory_pin.txt; the test prints its figures)
+LOSS_TOL, SSIM_TOL = 5e-5, 5e-4  # |loss_hip - loss_oracle|, |ssim_hip - ssim_oracle| at any of the K steps
+DRIFT_TOL = 2e-2                 # ||params_hip - params_oracle|| / ||params_oracle - start|| per tensor after K steps
+OFF_TOL = 0.02                   # share of the moved elements that differ by more than 5 % of their own path
+
+
+def _lr_factor(i, warm, n_iters):
+    """train.py:29-58, lr_decay "exp": linear warm-up to the base rate, then exponential decay to 1 % at n_iters."""
+    return i / warm if i <= warm else (0.01 ** (1 / (n_iters - warm))) ** (i - warm)
+
+
+@pytest.mark.parametrize("use_sh", [False, True])
+def test_twenty_training_steps_follow_the_oracle_trainer(use_sh, capsys):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    gpu = torch.device("cuda:0")
+    from gs_frame import FrameRenderer
+    from gs_scene import Scene, make_camera, make_scene
+    from gs_train import TrainOptions, Trainer
+
+    W, H, K = 160, 128, 20
+    scene, cam = make_scene(3000, W, H, seed=21, use_sh=use_sh), make_camera(W, H, yaw_deg=2.0)
+    target = FrameRenderer(gpu, max_pairs=1 << 17).forward(*to_torch(scene, gpu), cam)[0].clone()
+    rng = np.random.default_rng(3)
+    start = {"pos": scene.pos.copy(), "quat": scene.quat.copy(), "scale": scene.scale.copy(),
+             "opa": (scene.opa + rng.normal(0, 0.5, scene.opa.shape)).astype(np.float32),
+             "rgb": (scene.rgb + rng.normal(0, 0.3 if use_sh else 1.0, scene.rgb.shape)).astype(np.float32)}
+    names = ("pos", "quat", "scale", "opa", "rgb")
+    opt = TrainOptions(n_iters=200, n_iters_warmup=4)
+    # ---- HIP trainer
+    tr = Trainer([torch.from_numpy(start[k]).to(gpu) for k in names], [cam], [target], opt, max_pairs=1 << 17)
+    hip_loss = torch.stack([tr.train_step(i, 0).clone() for i in range(K)]).cpu().numpy()
+    hip = {k: p.cpu().numpy() for k, p in zip(names, tr.flat.params)}
+    # ---- oracle trainer (CPU): gs_oracle.c forward / backward + train_ref loss and Adam
+    tgt = target.cpu().numpy()
+    base = {"opa": opt.lr * opt.lr_factor_for_opa, "rgb": opt.lr * opt.lr_factor_for_rgb, "pos": opt.lr,
+            "scale": opt.lr * opt.lr_factor_for_scale, "quat": opt.lr * opt.lr_factor_for_quat}  # train.py:20-25
+    p = {k: v.copy() for k, v in start.items()}
+    m = {k: np.zeros_like(v) for k, v in start.items()}
+    v2 = {k: np.zeros_like(v) for k, v in start.items()}
+    lr_now = {k: base[k] * _lr_factor(0, opt.n_iters_warmup, opt.n_iters) for k in names}  # LambdaLR's initial step
+    ora_loss = []
+    for i in range(K):
+        of = OracleFrame(Scene(p["pos"], p["quat"], p["scale"], p["opa"], p["rgb"]), cam)
+        lo, l1, ssim, g_img = train_ref.l1_ssim_loss(of.image, tgt, opt.ssim_weight)
+        ora_loss.append((lo, l1, ssim))
+        g = of.backward(g_img.astype(np.float32))
+        for k in names:
+            p[k], m[k], v2[k] = train_ref.adam_step(p[k], g[k].astype(np.float32), m[k], v2[k], lr_now[k], *opt.betas,
+                                                    opt.eps, i + 1)
+        lr_now = {k: base[k] * _lr_factor(i, opt.n_iters_warmup, opt.n_iters) for k in names}  # train.py:184-185
+    ora_loss = np.asarray(ora_loss)
+    # ---- the losses of all K steps
+    dl = np.abs(hip_loss - ora_loss)
+    report = [f"loss: first {ora_loss[0, 0]:.5f} last {ora_loss[-1, 0]:.5f}, max |hip - oracle| = {dl[:, 0].max():.2e} "
+              f"(l1 {dl[:, 1].max():.2e}, ssim {dl[:, 2].max():.2e})"]
+    checks = [("the oracle trainer trains", ora_loss[-1, 0] < 0.9 * ora_loss[1, 0]),
+              # (the two trajectories drift apart step by step: the last steps carry the largest differences)
+              ("loss", dl[:, 0].max() < LOSS_TOL), ("l1", dl[:, 1].max() < LOSS_TOL), ("ssim", dl[:, 2].max() < SSIM_TOL)]
+    # ---- drift of the parameter trajectories relative to their length
+    for k in names:
+        travelled = p[k] - start[k]
+        drift = hip[k] - p[k]
+        rel = float(np.linalg.norm(drift) / (np.linalg.norm(travelled) + 1e-30))
+        moved = np.abs(travelled) > 1e-7
+        # Adam divides by sqrt(v): an element whose gradient is rounding noise around zero takes steps of +- lr whose
+        # sign is that noise -- such elements may differ by their whole (tiny) path; they must stay rare
+        off = float((np.abs(drift) > 0.05 * np.abs(travelled) + 1e-6)[moved].mean()) if moved.any() else 0.0
+        report.append(f"{k:6s} |travelled| {np.linalg.norm(travelled):.3e}  rel. drift {rel:.2e}  elements off by > 5 %: "
+                      f"{100 * off:.3f} %  max |drift| {np.abs(drift).max():.2e}")
+        checks += [(f"{k}: relative drift", rel < DRIFT_TOL), (f"{k}: elements off", off < OFF_TOL)]
+    with capsys.disabled():
+        print("\n[trajectory, use_sh=%s]\n  " % use_sh + "\n  ".join(report))
+    failed = [name for name, ok in checks if not ok]
+    assert not failed, failed

@@ -4,7 +4,7 @@ import json
 import sys
 import time
 
-sys.path[:0] = ['/root/repo', '/root/repo/3d-gaussian-splatting_amd']
+sys.path[:0] = ['/root/repo', '/root/repo/3d-gaussian-splatting_amd', '/root/repo/tools']
 import torch  # noqa: E402
 
 from gs_frame import FrameRenderer  # noqa: E402
