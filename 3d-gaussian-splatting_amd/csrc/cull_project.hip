@@ -793,7 +793,10 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
     if (CDIM == 3) {
         // ---- which of this Gaussian's (at most 256) rows exist: four 64-bit words, stop keys loaded eight at a time
         unsigned long long wmask[4] = {0ull, 0ull, 0ull, 0ull};
-        if (vis && !big && cnt) {
+#ifndef GS_PB_DIAG
+#define GS_PB_DIAG 0  // timing-only builds (tools/ab_variants.py): 1 = no mask, no rows; 2 = mask but no row loads
+#endif
+        if (GS_PB_DIAG != 1 && vis && !big && cnt) {
             uint32_t ix = my_x0, iy = my_y0;  // tile of row k, advanced row by row (no division)
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
@@ -830,6 +833,10 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             unsigned long long m = wmask[w];
+            if (GS_PB_DIAG == 2) {  // keep the mask alive, fetch nothing
+                d0.x += (float)__popcll(m);
+                m = 0;
+            }
             while (m) {
                 const uint32_t ka = (uint32_t)__ffsll((long long)m) - 1;
                 m &= m - 1;

@@ -426,7 +426,8 @@ def main():
 
     if "train" in legs:
         def _leg_train():
-            k = max(args.steps // 4, 25)
+            k = 25  # iterations per timed block, the same everywhere the step is timed (train_timing.py: the scene
+            # drifts while it is trained on, so the block length is part of the protocol)
             _, cam2, params2 = (head_scene, head_cam, head_params) if args.config == "cfg2" else load("cfg2")
             r2, st2 = sized_renderer(params2, cam2, training=False)
             del r2
@@ -454,7 +455,7 @@ def main():
             # array (sums -> exchange -> Adam -> next frame's project stage, slice by slice), on the headline scene (rgb
             # colours) and on the cfg4 scene (degree-2 SH: 73 % of the exchanged bytes are coefficients).  Next to every
             # mode the SAME step without its exchange, in the same process: exposed_ms = what the exchange costs the step.
-            k = max(args.steps // 8, 15)
+            k = 25
             seen = torch.ones(1, device=dev)
             dist.all_reduce(seen)
             seen = int(seen.item())

@@ -193,6 +193,13 @@ def _sum_by_id(ids, rows, n):
 GRAD_RTOL = 1e-4
 GRAD_KAPPA = 3e-5
 GRAD_L2 = 2e-5  # ||got - ref||_2 / ||ref||_2 per tensor
+# Independent of the oracle-supplied scale: the PURE relative error |got - ref| / |ref|
+# over the elements above 1e-6 of the tensor's largest entry -- its 99.9th percentile, and its maximum (single elements
+# that are small differences of large terms: measured up to 7.6 % at full size, profiles/r03_b_full_size_gradient_parity.txt
+# and profiles/r04_*_gradient_parity.txt)
+GRAD_REL_P999 = 1e-2   # measured (round 4, profiles/r04_g_full_size_gradient_parity.txt): pos 1.7e-3 ... 5.4e-3 -- dL/dx =
+                       # ln2 (2 A' Sx - B' Sy) is a difference of two sums of like magnitude --, every other tensor far below
+GRAD_REL_MAX = 0.15
 
 
 # Entries 14 orders of magnitude below the tensor's largest are compared up to this floor: they are sums of products
@@ -218,25 +225,32 @@ def grad_close(got, ref, scale, rtol=GRAD_RTOL, kappa=GRAD_KAPPA):
         np.unravel_index(worst, ratio.shape) if ratio.size else (), pure
 
 
-def assert_grads_close(grads, ref, scale, what="", rtol=GRAD_RTOL, kappa=GRAD_KAPPA, l2=GRAD_L2):
+def assert_grads_close(grads, ref, scale, what="", rtol=GRAD_RTOL, kappa=GRAD_KAPPA, l2=GRAD_L2, rel_bounds=False):
     """grads: five arrays (pos, quat, scale, opa, rgb) -> element-wise check of each against the oracle + a relative
-    L2 bound per tensor.  Returns {name: (worst err / tol, fraction of elements inside rtol |ref| alone, rel. L2,
-    worst pure relative error over the elements above 1e-6 of the tensor's maximum)}."""
+    L2 bound per tensor + bounds on the pure relative error.  Returns {name: (worst err / tol, fraction of elements inside
+    rtol |ref| alone, rel. L2, worst pure relative error over the elements above 1e-6 of the tensor's maximum, its 99.9th
+    percentile)}."""
     report = {}
     for g, name in zip(grads, ("pos", "quat", "scale", "opa", "rgb")):
         g = np.asarray(g)
         ok, worst, where, pure = grad_close(g, ref[name], scale[name], rtol, kappa)
         rl2 = float(np.linalg.norm(g.astype(np.float64) - ref[name]) / (np.linalg.norm(ref[name].astype(np.float64)) + 1e-300))
         # worst PURE relative error |got - ref| / |ref| over the elements above 1e-6 of the tensor's largest: a figure
-        # that does not involve the oracle-supplied conditioning scale at all (reported, not asserted: an element that
-        # is the small difference of large terms is legitimately off by many of its own ulp)
+        # that does not involve the oracle-supplied conditioning scale at all (asserted since round 4: GRAD_REL_MAX and,
+        # for the bulk, GRAD_REL_P999; an element that is the small difference of large terms is legitimately off by
+        # many of its own ulp, which is why the maximum gets 15 % and the 99.9th percentile 0.1 %)
         r64 = np.abs(np.asarray(ref[name], np.float64))
         big = r64 > 1e-6 * (r64.max() if r64.size else 0.0)
-        rel_big = float((np.abs(g.astype(np.float64) - ref[name])[big] / r64[big]).max()) if big.any() else 0.0
-        report[name] = (round(worst, 3), round(pure, 5), rl2, rel_big)
+        rels = np.abs(g.astype(np.float64) - ref[name])[big] / r64[big] if big.any() else np.zeros(1)
+        rel_big = float(rels.max())
+        rel_p999 = float(np.quantile(rels, 0.999))
+        report[name] = (round(worst, 3), round(pure, 5), rl2, rel_big, rel_p999)
         assert ok, (what, name, "worst err/tol", worst, "at", where, "got", float(g[where]), "ref",
                     float(ref[name][where]), "scale", float(scale[name][where]))
         assert rl2 <= l2, (what, name, "relative L2 error", rl2)
+    if rel_bounds:  # the full-size tests (>= 376 k Gaussians: the percentile means something there)
+        bad = {k: v[3:] for k, v in report.items() if v[4] > GRAD_REL_P999 or v[3] > GRAD_REL_MAX}
+        assert not bad, (what, "pure relative error (worst above 1e-6 of the maximum, 99.9th percentile)", bad, report)
     return report
 
 

@@ -16,9 +16,10 @@ from oracle import train_ref
 pytestmark = pytest.mark.gpu
 
 
-# Bounds (measured on MI355X: profiles/r04_trajectory_pin.txt; the test prints its figures)
+# Bounds (measured on MI355X, profiles/r04_f_trajectory_pin.txt: loss 1.6e-5, ssim 1.4e-4, drift <= 2.5e-3, elements off
+# <= 0.85 %; the test prints its figures)
 LOSS_TOL, SSIM_TOL = 5e-5, 5e-4  # |loss_hip - loss_oracle|, |ssim_hip - ssim_oracle| at any of the K steps
-DRIFT_TOL = 2e-2                 # ||params_hip - params_oracle|| / ||params_oracle - start|| per tensor after K steps
+DRIFT_TOL = 1e-2                 # ||params_hip - params_oracle|| / ||params_oracle - start|| per tensor after K steps
 OFF_TOL = 0.02                   # share of the moved elements that differ by more than 5 % of their own path
 
 
