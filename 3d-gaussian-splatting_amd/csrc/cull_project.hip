@@ -663,7 +663,7 @@ __global__ void __launch_bounds__(BIN_THREADS) frame_project_bin_count_kernel(
 // Parts 1 and 2 read the same rows and add them in the same order as part 0: their outputs are bit-identical to it.
 // They exist so that the all-reduce of the first bucket can run underneath the second kernel (gs_dp.py).
 #ifndef GS_PB_DIRECT
-#define GS_PB_DIRECT 1  // A/B switch (tools/ab_variants.py): how the rgb rows are fetched, see below
+#define GS_PB_DIRECT 2  // A/B switch (tools/ab_variants.py): how the rgb rows are fetched, see below
 #endif
 template <int CDIM, int PART = 0, int BLOCK = (CDIM == 3 ? 256 : 128)>
 __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
@@ -684,13 +684,14 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
     // key(g) <= stop key.  Every thread first turns its rectangle into a bit mask of existing rows (stop-key loads eight
     // at a time: a loop with one dependent load per row costs a memory round trip per row -- the first version of this
     // kernel: 278 us against round 3's 175), then adds the rows up in ascending order, as before: bitwise unchanged.
+    //   GS_PB_DIRECT 2: the wave fetches the existing rows of its 64 Gaussians together, 16 rows per load instruction;
     //   GS_PB_DIRECT 1: every thread fetches its own existing rows (one aligned 64-byte line each, ~1 per visible
     //                   Gaussian at 2.4 M Gaussians), two rows in flight;
     //   GS_PB_DIRECT 0: the workgroup's contiguous row range goes through LDS chunk by chunk, four lanes per existing
     //                   row, and every thread adds its rows out of LDS.
     constexpr int CHUNK_ROWS = 512;  // staged variant: 24 KiB of LDS, three float4s (the 10 floats in use) per row
-    __shared__ float4 s_rows[(CDIM == 3 && !GS_PB_DIRECT) ? CHUNK_ROWS * 3 : 1];
-    __shared__ uint8_t s_flag[(CDIM == 3 && !GS_PB_DIRECT) ? CHUNK_ROWS : 1];
+    __shared__ float4 s_rows[(CDIM == 3 && GS_PB_DIRECT == 0) ? CHUNK_ROWS * 3 : 1];
+    __shared__ uint8_t s_flag[(CDIM == 3 && GS_PB_DIRECT == 0) ? CHUNK_ROWS : 1];
     const int64_t pid0 = (int64_t)blockIdx.x * blockDim.x + g_first, pid = pid0 + threadIdx.x;
     const int64_t pid_last = (pid0 + blockDim.x < n ? pid0 + blockDim.x : n) - 1;
     const bool valid = pid < n;
@@ -796,6 +797,19 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
 #ifndef GS_PB_DIAG
 #define GS_PB_DIAG 0  // timing-only builds (tools/ab_variants.py): 1 = no mask, no rows; 2 = mask but no row loads
 #endif
+#if GS_PB_DIRECT == 2
+        constexpr int WAVES = BLOCK / 64;
+        __shared__ uint32_t s_list[WAVES][64];   // row (relative to `rows`) of entry e of the current batch
+        __shared__ float4 s_win[WAVES][64 * 3];  // the 12 leading floats of the batch's rows
+        auto wave_sync = [] {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        };
+        // (Measured and dropped, round 4: looking the stop keys up wave-cooperatively as well -- the lanes list the tiles of
+        // their rectangles in owner order, the wave fetches 256 stop keys in one round trip, every owner compares its own
+        // -- 0.125 - 0.133 ms against 0.129 - 0.131 ms for the per-thread walk below at 2.4 M Gaussians, 0.044 against
+        // 0.043 ms at cfg2: the LDS hand-overs cost what the shorter dependency chain saves.)
+#endif
         if (GS_PB_DIAG != 1 && vis && !big && cnt) {
             uint32_t ix = my_x0, iy = my_y0;  // tile of row k, advanced row by row (no division)
 #pragma unroll
@@ -827,7 +841,66 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
                 wmask[w] = m;
             }
         }
-#if GS_PB_DIRECT
+#if GS_PB_DIRECT == 2
+        // ---- the WAVE fetches the existing rows of its 64 Gaussians together.  A thread fetching its own rows keeps the
+        // wave in the loop for as long as its busiest lane has rows (a Gaussian in front of a dense region: 9+ rows, the
+        // average: 1.06), with a memory round trip per pair of rows -- 74 of the kernel's 162 us in a timing-only build
+        // (profiles/r04_g_project_backward_time_split_diag.txt).  Instead the lanes' existing rows are listed in owner
+        // order (LDS), the wave loads them 16 per instruction -- four lanes per aligned 64-byte line, every lane busy --
+        // into an LDS window, and every owner adds ITS rows out of LDS in ascending order: the same sums, bit for bit.
+        {
+            const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {  // rows 64 w .. 64 w + 63 of every Gaussian (beyond the first word: rare)
+                const unsigned long long wm = wmask[w];
+                if (__ballot(wm != 0ull) == 0ull) continue;  // uniform
+                const uint32_t mine = (uint32_t)__popcll(wm);
+                const uint32_t incl = gs_wave_incl_scan_u32(mine), first = incl - mine;
+                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                unsigned long long cm = wm;  // this lane's rows not yet added
+                uint32_t done = 0;
+                for (uint32_t e0 = 0; e0 < total; e0 += 64) {  // uniform trip count
+                    // 1. list the entries [e0, e0 + 64) in owner order: this lane's are first + done .. first + mine - 1
+                    {
+                        unsigned long long lm = cm;
+                        for (uint32_t e = first + done; e < e0 + 64 && lm; ++e) {
+                            if (e >= e0) s_list[wv][e - e0] = (uint32_t)(off + (uint32_t)w * 64u + (uint32_t)__ffsll((long long)lm) - 1u);
+                            lm &= lm - 1;
+                        }
+                    }
+                    wave_sync();
+                    // 2. the wave loads the batch: lane l = quarter l % 4 of entry 16 it + l / 4 (quarter 3 is padding)
+                    const uint32_t nb = total - e0 < 64 ? total - e0 : 64u;
+                    float4 v[4];
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const uint32_t j = 16u * it + ((uint32_t)lane >> 2), q = (uint32_t)lane & 3u;
+                        v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (j < nb && q < 3) v[it] = rows[(size_t)s_list[wv][j] * RW4 + q];
+                    }
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const uint32_t j = 16u * it + ((uint32_t)lane >> 2), q = (uint32_t)lane & 3u;
+                        if (j < nb && q < 3) s_win[wv][j * 3 + q] = v[it];
+                    }
+                    wave_sync();
+                    // 3. every owner adds its rows of this batch, ascending
+                    const uint32_t lo_e = first + done > e0 ? first + done : e0;
+                    const uint32_t hi_e = first + mine < e0 + 64 ? first + mine : e0 + 64;
+                    for (uint32_t x = lo_e; x < hi_e; ++x) {
+                        const float4 *row = &s_win[wv][(x - e0) * 3];
+                        const float4 r0 = row[0], r1 = row[1], r2 = row[2];
+                        d0.x += r0.x; d0.y += r0.y; d0.z += r0.z; d0.w += r0.w;
+                        d1.x += r1.x; d1.y += r1.y; d1.z += r1.z; d1.w += r1.w;
+                        d2.x += r2.x; d2.y += r2.y;
+                        cm &= cm - 1;  // consumed
+                        ++done;
+                    }
+                    wave_sync();  // the batch arrays are rewritten next
+                }
+            }
+        }
+#elif GS_PB_DIRECT
         // ---- every thread adds its existing rows in ascending order, two rows (six loads) in flight
         const float4 *myrows = rows + off * RW4;
 #pragma unroll

@@ -366,7 +366,8 @@ def main():
         guarded("cfg2", _leg_cfg2)
 
     # ---------------------------------------------------------------- training step (train.py:84-185, no densification)
-    def train_leg(cfg, params, cam, pairs, k, force=False, exchange="all_reduce", collective=True, repeats=15):
+    def train_leg(cfg, params, cam, pairs, k, force=False, exchange="all_reduce", collective=True, repeats=15,
+                  n_slices=None):
         """forward (checkpointing) -> L1 + 0.1 SSIM loss and gradient -> backward -> exchange of the flat gradient buffer
         (N > 1, or forced) -> fused Adam.  Timed with the snapshot / restore protocol of tools/train_timing.py: 30 warm-up
         iterations, then the SAME k iterations `repeats` times (everything the step changes is restored between blocks,
@@ -383,7 +384,7 @@ def main():
         target = (r0.forward(*params, cam)[0] + 0.05 * torch.randn(Hc, Wc, 3, device=dev)).clamp_(0, 1).contiguous()
         del r0
         tr = Trainer([t.clone() for t in params], [cam], [target], TrainOptions(), world_size=world,
-                     max_pairs=int(pairs * 1.25) + 4096, exchange=exchange)
+                     max_pairs=int(pairs * 1.25) + 4096, exchange=exchange, n_slices=n_slices)
         tr.flat.force_collective = (use_dist or force) and dist.is_initialized()
         tr.flat.enable_collective = bool(collective)
         dtt, blocks = time_training(tr, k, warm=30, repeats=repeats, barrier=barrier, max_over_ranks=max_over_ranks)
@@ -497,8 +498,17 @@ def main():
                         "exchange_ms": round(ex_ms, 4),
                         "busbw_GBs": None if seen < 2 else round(2 * (seen - 1) / seen * flat.bucket_bytes / (ex_ms * 1e-3) / 1e9, 1),
                         "optimizer_state_bytes_per_rank": tr.optimizer.state_bytes}
+                    res["modes"][exchange]["n_slices"] = flat.n_slices
                     del tr, flat
                     torch.cuda.empty_cache()
+                # the same step as a TWO-slice pipeline whatever the rank count (one rank takes one slice by default:
+                # nothing travels, nothing to hide): what the slicing itself costs -- per-slice kernels that fill less of
+                # the chip, the extra launches and stream joins
+                _, ms2, det2, tr = train_leg(cfg_name, params_s, cam_s, pairs_s, k, force=True, n_slices=2)
+                res["two_slice_pipeline"] = {"n_slices": tr.flat.n_slices, "train_ms_per_iter": round(ms2, 4),
+                                             "exposed_ms": round(ms2 - plain_ms, 4)}
+                del tr
+                torch.cuda.empty_cache()
                 mg["scenes"][tag] = res
                 return res
 
