@@ -555,7 +555,7 @@ __global__ void __launch_bounds__(STRIP_THREADS) frame_project_count_kernel(
     extern __shared__ unsigned long long s_hist[];  // [NS] entries << 32 | pairs of this slice
     __shared__ uint32_t s_acc[2];
     if (blockIdx.x >= S) {  // the one extra workgroup of the launch (uniform)
-        tile_order_workgroup(tile_cost, n_tiles, tile_order);
+        tile_order_workgroup(tile_cost, n_tiles, tile_order, SG.ntx, SG.nty);
         return;
     }
     // this launch covers the slices [slice0, slice0 + S): all of them, or one range of a frame whose project stage is
@@ -716,13 +716,17 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
     __shared__ float s_sum[CDIM > 3 ? BLOCK * RS : 1];
     __shared__ uint32_t s_brow[CDIM > 3 ? BLOCK / 64 : 1][64], s_bown[CDIM > 3 ? BLOCK / 64 : 1][64];
 
-    // rgb: does the row of tile (ix, iy) of the Gaussian with key `key` exist?  (`sk` = that tile's stop key)
-    auto row_exists = [&](unsigned long long sk, unsigned long long key, uint32_t ix, uint32_t iy, float cx, float cy) {
+    // the stop keys as two arrays of T words: depth bits, Gaussian index (stop_key_kernel)
+    const uint32_t *stop_depth = reinterpret_cast<const uint32_t *>(stop_keys);
+    const uint32_t n_tiles_pb = P.ntx * P.nty;
+    const uint32_t *stop_id = stop_depth + n_tiles_pb;
+    // rgb: does the row of tile t = (ix, iy) of the Gaussian (depth bits dz, index id) exist?  key(g) <= stop key(t)
+    auto row_exists = [&](uint32_t t, uint32_t dz, uint32_t id, uint32_t ix, uint32_t iy, float cx, float cy) {
         if (P.cull_method == 0 && !gs_dist_listed(cx, cy, ix, iy, D)) return false;  // "dist": holes in the square
-        return key <= sk;
+        const uint32_t sd = stop_depth[t];
+        return dz < sd || (dz == sd && id <= stop_id[t]);
     };
     const uint32_t my_y0 = rc.x & 0xffff, my_x0 = rc.y & 0xffff, my_x1 = rc.y >> 16;
-    const unsigned long long my_key = ((unsigned long long)rc.z << 32) | (unsigned long long)(uint32_t)pid;
 
     // A Gaussian that covers hundreds of tiles (early in training from a sparse cloud; a scale that blew up) would
     // keep ONE thread adding its rows while 255 wait: 195 us instead of 40 us for this kernel in a 500 k-Gaussian fit.
@@ -754,7 +758,6 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
         const int64_t bpid = pid0 + s_big_owner[b];
         const uint4 brc = rects[bpid];
         const uint32_t by0 = brc.x & 0xffff, bx0 = brc.y & 0xffff, bw = (brc.y >> 16) - (brc.y & 0xffff);
-        const unsigned long long bkey = ((unsigned long long)brc.z << 32) | (unsigned long long)(uint32_t)bpid;
         float bcx = 0.f, bcy = 0.f;
         if (P.cull_method == 0) {
             const float4 bg = rec_geom[bpid * GS_REC_STRIDE];
@@ -766,7 +769,7 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
         for (int e = 0; e < NA; ++e) acc[e] = 0.f;
         for (uint32_t k = threadIdx.x; k < bcnt && boff + k < max_pairs; k += 256) {
             const uint32_t iy = by0 + k / bw, ix = bx0 + k % bw;
-            if (!row_exists(stop_keys[iy * P.ntx + ix], bkey, ix, iy, bcx, bcy)) continue;
+            if (!row_exists(iy * P.ntx + ix, brc.z, (uint32_t)bpid, ix, iy, bcx, bcy)) continue;
             const float4 *row = rows + (boff + k) * RW4;
 #pragma unroll
             for (int m = 0; m < NA / 4; ++m) {
@@ -817,22 +820,26 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
                 if ((uint32_t)w * 64u >= cnt) break;
                 unsigned long long m = 0;
                 for (uint32_t k0 = (uint32_t)w * 64u; k0 < (uint32_t)w * 64u + 64u && k0 < cnt; k0 += 8) {
-                    unsigned long long sk[8];
-                    uint32_t tx8[8], ty8[8];
+                    uint32_t sd[8], tx8[8], ty8[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const bool in = k0 + j < cnt;
                         tx8[j] = ix;
                         ty8[j] = iy;
-                        sk[j] = in ? stop_keys[iy * P.ntx + ix] : 0ull;
+                        sd[j] = in ? stop_depth[iy * P.ntx + ix] : 0u;  // 0: nothing processed / not a pair of mine
                         if (in && ++ix == my_x1) {
                             ix = my_x0;
                             ++iy;
                         }
                     }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (k0 + j < cnt && off + k0 + j < max_pairs && my_key <= sk[j]) m |= 1ull << ((k0 + j) & 63u);
+                    for (int j = 0; j < 8; ++j) {
+                        const bool in = k0 + j < cnt && off + k0 + j < max_pairs;
+                        bool yes = in && rc.z < sd[j];
+                        // equal depth bits (the tile's stop entry itself, exact copies): the Gaussian index decides
+                        if (in && rc.z == sd[j]) yes = (uint32_t)pid <= stop_id[ty8[j] * P.ntx + tx8[j]];
+                        if (yes) m |= 1ull << ((k0 + j) & 63u);
+                    }
                     if (P.cull_method == 0) {  // "dist": not every tile of the bounding square is listed (uniform branch)
                         for (int j = 0; j < 8; ++j)
                             if (k0 + j < cnt && !gs_dist_listed(g.x, g.y, tx8[j], ty8[j], D)) m &= ~(1ull << ((k0 + j) & 63u));

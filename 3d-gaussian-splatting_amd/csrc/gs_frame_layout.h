@@ -216,8 +216,8 @@ struct gs_frame_ws {
     float *rows;                   // [max_pairs][GS_ROW(C)] per-pair gradient rows in EMISSION order
     uint8_t *row_flags;            // [max_pairs] SH rows: 1 = the raster backward wrote this row (cleared per frame: the
                                    // rows themselves are never zero-filled, unwritten ones are skipped by the reader)
-    uint64_t *stop_keys;           // [T] (depth bits << 32 | Gaussian) of the LAST list entry the forward processed in
-                                   // each tile (0: none).  A tile's list ascends in exactly this key, so the pair
+    uint64_t *stop_keys;           // 2 x [T] u32: depth bits, then Gaussian index, of the LAST list entry the forward
+                                   // processed in each tile (depth 0: none).  A tile's list ascends in exactly this key, so the pair
                                    // (tile, g) was processed -- its gradient row written -- iff key(g) <= stop_keys[tile]:
                                    // the rgb reader needs no per-row flag (stop_key_kernel, raster_bwd.hip)
     int64_t max_buckets;

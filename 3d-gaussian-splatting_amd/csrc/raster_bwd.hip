@@ -80,8 +80,8 @@ __global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t *__res
     }
 }
 
-// Frame path, rgb rows: the key (depth bits << 32 | Gaussian) of the last list entry the forward processed in every
-// tile (0: none).  A tile's list ascends in exactly this key and the key is unique, so "pair (tile, g) was processed --
+// Frame path, rgb rows: the key (depth bits, Gaussian) of the last list entry the forward processed in every tile
+// (depth 0: none), as two arrays of T 32-bit words.  A tile's list ascends in exactly this key and the key is unique, so "pair (tile, g) was processed --
 // its gradient row written" <=> key(g) <= stop_keys[tile]: what the projection backward needs to know about a row
 // without a flag per row (no scattered flag stores, no flag memset; gs_frame_layout.h).  One thread per tile, three
 // dependent loads; runs with the bucket scan underneath the caller's loss.
@@ -93,12 +93,16 @@ __global__ void __launch_bounds__(256) stop_key_kernel(const uint32_t *__restric
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_tiles) return;
     const uint32_t np = tile_nproc[i];
-    unsigned long long key = 0;
+    uint32_t depth = 0, id = 0;
     if (np) {
-        const uint32_t id = sorted_ids[(uint32_t)ranges[2 * i] + np - 1];
-        key = ((unsigned long long)rects[id].z << 32) | id;
+        id = sorted_ids[(uint32_t)ranges[2 * i] + np - 1];
+        depth = rects[id].z;
     }
-    stop_keys[i] = key;
+    // two arrays of T words, depth bits first: the reader decides almost every pair from the 4-byte depth word alone (a
+    // table of 32 KiB at 1080p instead of 64) and looks at the Gaussian index only where the depth bits are equal
+    uint32_t *sk = reinterpret_cast<uint32_t *>(stop_keys);
+    sk[i] = depth;
+    sk[n_tiles + i] = id;
 }
 
 struct BwdOut {

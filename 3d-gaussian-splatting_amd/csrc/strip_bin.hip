@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(STRIP_THREADS) strip_count_kernel(
     extern __shared__ unsigned long long s_hist[];  // [NS] entries << 32 | pairs of this slice
     __shared__ uint32_t s_acc[2];
     if (blockIdx.x >= S) {  // the one extra workgroup of the launch (uniform)
-        tile_order_workgroup(tile_cost, n_tiles, tile_order);
+        tile_order_workgroup(tile_cost, n_tiles, tile_order, SG.ntx, SG.nty);
         return;
     }
     const uint32_t slice = strip_slice_of_block(blockIdx.x, S);

@@ -81,8 +81,93 @@ __device__ __forceinline__ uint32_t strip_slice_of_block(uint32_t blk, uint32_t 
 // Runs as one EXTRA workgroup of strip_count_kernel's launch, i.e. underneath the binning, three kernels ahead of its
 // consumer.  256 bins of GS_ORDER_QUANTUM steps; arrival order inside a bin is whatever the LDS atomics make it.
 #define GS_ORDER_QUANTUM 8
+#ifndef GS_ORDER_BLOCKS
+#define GS_ORDER_BLOCKS 0  // A/B switch (tools/ab_variants.py): 1 = coarse cost classes, 2 x 2 tile blocks kept on one XCD
+#endif
+#ifndef GS_ORDER_CLASS
+#define GS_ORDER_CLASS 64  // GS_ORDER_BLOCKS: Gaussian steps per cost class (16 classes)
+#endif
+// GS_ORDER_BLOCKS (round 4): the longest-first order above made neighbouring tiles run at
+// unrelated times on unrelated XCDs, so a record shared by the tiles of one Gaussian's rectangle was fetched once per
+// tile (FETCH_SIZE of the compositing kernel 73 -> 135 MB per launch, now about the bytes of the records it composites).
+// Workgroup p of a launch runs on XCD p % 8 (observed, MI355X_MICROARCH.md), so the four tiles of an aligned 2 x 2 block
+// share an L2 -- and run at about the same time -- when they sit at positions p, p + 8, p + 16, p + 24 of the order.
+// Tiles are classed by cost (GS_ORDER_CLASS steps per class, longest class first: still longest-processing-time-first at
+// that granularity); inside a class the blocks whose four tiles all belong to it are laid out eight per group of 32
+// positions, block j of the group at positions j + 8 i; the other tiles follow in arrival order.  Any cost array
+// (first frame: uninitialised memory) still yields a permutation.
+__device__ __forceinline__ void tile_order_blocks_workgroup(const uint32_t *__restrict__ tile_cost, uint32_t T,
+                                                            uint32_t *__restrict__ tile_order, uint32_t ntx, uint32_t nty) {
+    constexpr uint32_t NC = 16;
+    __shared__ uint32_t s_full[NC], s_loose[NC], s_groups[NC], s_base_full[NC], s_base_loose[NC], s_cf[NC], s_cl[NC];
+    if (threadIdx.x < NC) s_full[threadIdx.x] = s_loose[threadIdx.x] = s_cf[threadIdx.x] = s_cl[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t nbx = (ntx + 1) / 2, nby = (nty + 1) / 2, NB = nbx * nby;
+    auto cls = [](uint32_t c) {
+        const uint32_t q = c / GS_ORDER_CLASS;
+        return q < NC - 1 ? q : NC - 1;
+    };
+    auto block_tiles = [&](uint32_t b, uint32_t tile[4], uint32_t cl[4]) -> uint32_t {  // -> tiles of the block (1, 2 or 4)
+        const uint32_t bx = b % nbx, by = b / nbx;
+        uint32_t n = 0;
+        for (uint32_t dy = 0; dy < 2; ++dy)
+            for (uint32_t dx = 0; dx < 2; ++dx) {
+                const uint32_t x = 2 * bx + dx, y = 2 * by + dy;
+                if (x < ntx && y < nty && y * ntx + x < T) {
+                    tile[n] = y * ntx + x;
+                    cl[n] = cls(tile_cost[tile[n]]);
+                    ++n;
+                }
+            }
+        return n;
+    };
+    for (uint32_t b = threadIdx.x; b < NB; b += STRIP_THREADS) {
+        uint32_t tile[4], cl[4];
+        const uint32_t n = block_tiles(b, tile, cl);
+        if (n == 4 && cl[0] == cl[1] && cl[0] == cl[2] && cl[0] == cl[3])
+            atomicAdd(&s_full[cl[0]], 1u);
+        else
+            for (uint32_t i = 0; i < n; ++i) atomicAdd(&s_loose[cl[i]], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int c = (int)NC - 1; c >= 0; --c) {  // longest class first
+            const uint32_t g = s_full[c] / 8, rem = s_full[c] % 8;
+            s_groups[c] = g;
+            s_base_full[c] = run;
+            run += 32 * g;
+            s_base_loose[c] = run;
+            run += s_loose[c] + 4 * rem;
+        }
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < NB; b += STRIP_THREADS) {
+        uint32_t tile[4], cl[4];
+        const uint32_t n = block_tiles(b, tile, cl);
+        if (n == 4 && cl[0] == cl[1] && cl[0] == cl[2] && cl[0] == cl[3]) {
+            const uint32_t c = cl[0], j = atomicAdd(&s_cf[c], 1u);
+            if (j < 8 * s_groups[c]) {
+                const uint32_t at = s_base_full[c] + 32 * (j / 8) + (j % 8);
+                for (uint32_t i = 0; i < 4; ++i) tile_order[at + 8 * i] = tile[i];
+            } else {
+                const uint32_t at = s_base_loose[c] + atomicAdd(&s_cl[c], 4u);
+                for (uint32_t i = 0; i < 4; ++i) tile_order[at + i] = tile[i];
+            }
+        } else {
+            for (uint32_t i = 0; i < n; ++i) tile_order[s_base_loose[cl[i]] + atomicAdd(&s_cl[cl[i]], 1u)] = tile[i];
+        }
+    }
+}
+
 __device__ __forceinline__ void tile_order_workgroup(const uint32_t *__restrict__ tile_cost, uint32_t T,
-                                                     uint32_t *__restrict__ tile_order) {
+                                                     uint32_t *__restrict__ tile_order, uint32_t ntx = 0, uint32_t nty = 0) {
+#if GS_ORDER_BLOCKS
+    if (ntx && nty && (uint64_t)ntx * nty == T) {
+        tile_order_blocks_workgroup(tile_cost, T, tile_order, ntx, nty);
+        return;
+    }
+#endif
     // 256 bins x 16 sub-counters (lane % 16): in a sparse frame most tiles cost the same (empty tiles: 0), and 64 lanes
     // adding to ONE LDS word serialise (first version: +10 us on a 50-us frame of 10,000 Gaussians); with the
     // sub-counters a wave's add hits every word at most four times.  Slot order: bin-major, sub-counter-minor.
