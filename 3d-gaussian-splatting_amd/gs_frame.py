@@ -268,6 +268,7 @@ class FrameRenderer:
         return getattr(self, "_last_overflow_serial", -1) == self._frame_serial
 
     def _forward(self, pos, quat, scale, opa, rgb, camera, training):
+        self._begun = None  # any frame opened by forward_begin lived in the workspace this frame is about to overwrite
         stream = self._stream().cuda_stream
         sync_check = self.auto_grow is True or (self.auto_grow == "async" and (not training or not self._checked_once))
         if self.auto_grow == "async":
@@ -429,6 +430,7 @@ class FrameRenderer:
         """One forward frame with every stage bracketed by hipEvents (synchronises).  Returns
         {stage: ms}; the raster stage is exactly one kernel launch."""
         training = self.training if training is None else training
+        self._begun = None
         f = self._describe(pos, quat, scale, opa, rgb, camera, training)
         g = self._grid
         image = torch.empty(g.height, g.width, 3, device=self.device, dtype=torch.float32)

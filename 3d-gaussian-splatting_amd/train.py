@@ -198,11 +198,15 @@ def main(argv=None) -> dict:
         raise SystemExit("the dataset has a single image: nothing left to train on after the every-8th test split")
 
     hist, summary, t_start = [], {}, time.perf_counter()
+    # train.py:94; with several ranks the same draw of `world` views happens on every rank (same generator state
+    # everywhere) and rank r takes the r-th.  The draw of iteration i + 1 is made before step i runs (nothing else consumes
+    # this generator, so the sequence of views is the reference's): the view-parallel step can then issue the next frame's
+    # project stage behind its optimizer (gs_train.Trainer.train_step, next_camera_id)
+    next_id = int(np.random.choice(train_split, world)[rank])
     for i_iter in range(opt.n_iters):
-        # train.py:94; with several ranks the same draw of `world` views happens on every rank (same generator
-        # state everywhere) and rank r takes the r-th
-        camera_id = int(np.random.choice(train_split, world)[rank])
-        hist.append(trainer.train_step(i_iter, camera_id).clone())
+        camera_id = next_id
+        next_id = int(np.random.choice(train_split, world)[rank]) if i_iter + 1 < opt.n_iters else None
+        hist.append(trainer.train_step(i_iter, camera_id, next_camera_id=next_id if world > 1 else None).clone())
         if rank != 0:
             if i_iter == 400 and opt.render_downsample != opt.render_downsample_start:
                 scene = gs_colmap.load_scene(opt.data, opt.render_downsample, dev)

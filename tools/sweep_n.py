@@ -62,6 +62,12 @@ for n in sizes:
 
     target = (r.forward(*params, cam)[0] + 0.05 * torch.randn(H, W, 3, device=dev)).clamp_(0, 1).contiguous()
     tr = Trainer([t.clone() for t in params], [cam], [target], TrainOptions(), max_pairs=int(st.pairs * 1.25) + 4096)
+    # (as in rounds 1 - 3: no capacity read-back inside the timed loop -- the workspace was sized above; the trainer's
+    # default, auto_grow="async", copies the frame counters to the host after every frame, which costs a small scene that
+    # is bound by its host time ~0.05 ms per step: set GS_SWEEP_ASYNC=1 to time that)
+    import os
+    if not os.environ.get("GS_SWEEP_ASYNC"):
+        tr.renderer.auto_grow = False
     for k_, v_ in KW.items():
         setattr(tr.renderer, k_, v_)
     k_it = max(steps // 4, 25)
