@@ -367,11 +367,16 @@ def main():
 
     # ---------------------------------------------------------------- training step (train.py:84-185, no densification)
     def train_leg(cfg, params, cam, pairs, k, force=False, exchange="all_reduce", collective=True, repeats=15,
-                  n_slices=None):
+                  n_slices=None, fixed_scene=True):
         """forward (checkpointing) -> L1 + 0.1 SSIM loss and gradient -> backward -> exchange of the flat gradient buffer
         (N > 1, or forced) -> fused Adam.  Timed with the snapshot / restore protocol of tools/train_timing.py: 30 warm-up
         iterations, then the SAME k iterations `repeats` times (everything the step changes is restored between blocks,
-        outside the timed region).  Returns (whole-job iterations/s, ms per iteration, detail dict on rank 0, trainer).
+        outside the timed region).  `fixed_scene` (default): the learning rate is 0 -- every kernel of the step runs in full,
+        Adam included, but the parameters stay where they are, so that the step is timed on the SAME synthetic scene the
+        render figures are quoted on, whatever the block length; False: the reference's learning rates, i.e. the scene
+        as 30 + k iterations against the noisy target have left it (lower opacities: tiles composite more Gaussians before
+        they saturate; the step is 5 - 10 % slower at 2.4 M Gaussians and keeps slowing down).
+        Returns (whole-job iterations/s, ms per iteration, detail dict on rank 0, trainer).
         `collective=False` (measurement only): the same step without its gradient exchange -- the reference the
         exchange's exposed time is taken against."""
         from gs_train import TrainOptions, Trainer
@@ -383,11 +388,11 @@ def main():
         r0 = FrameRenderer(dev, max_pairs=int(pairs * 1.1) + 4096, auto_grow=False)
         target = (r0.forward(*params, cam)[0] + 0.05 * torch.randn(Hc, Wc, 3, device=dev)).clamp_(0, 1).contiguous()
         del r0
-        tr = Trainer([t.clone() for t in params], [cam], [target], TrainOptions(), world_size=world,
-                     max_pairs=int(pairs * 1.25) + 4096, exchange=exchange, n_slices=n_slices)
+        tr = Trainer([t.clone() for t in params], [cam], [target], TrainOptions(lr=0.0) if fixed_scene else TrainOptions(),
+                     world_size=world, max_pairs=int(pairs * 1.25) + 4096, exchange=exchange, n_slices=n_slices)
         tr.flat.force_collective = (use_dist or force) and dist.is_initialized()
         tr.flat.enable_collective = bool(collective)
-        dtt, blocks = time_training(tr, k, warm=30, repeats=repeats, barrier=barrier, max_over_ranks=max_over_ranks)
+        dtt, blocks, k = time_training(tr, k, warm=30, repeats=repeats, barrier=barrier, max_over_ranks=max_over_ranks)
         assert tr.renderer.overflowed_frames == 0 and not tr.renderer.last_frame_overflowed(wait=True)
         detail = {}
         if rank == 0:
@@ -421,18 +426,23 @@ def main():
                                        "parameters": n_par}
         detail.update(repeats=len(blocks), ms_per_iter_min=round(min(blocks) / k * 1e3, 4),
                       ms_per_iter_max=round(max(blocks) / k * 1e3, 4), iters_per_block=k,
+                      scene="fixed (learning rate 0: the full step runs, the parameters stay put)" if fixed_scene else
+                            "moving (the reference's learning rates, iterations 30 .. 30 + k against a noisy target)",
                       protocol="30 warm-up iterations, then the same k iterations per block: parameters, Adam moments "
                                "and step counter restored from a snapshot between blocks (tools/train_timing.py)")
         return world * k / dtt, dtt / k * 1e3, detail, tr
 
     if "train" in legs:
         def _leg_train():
-            k = 25  # iterations per timed block, the same everywhere the step is timed (train_timing.py: the scene
-            # drifts while it is trained on, so the block length is part of the protocol)
+            k = None  # iterations per timed block: train_timing.block_length (25, or ~30 ms of work if that is more)
             _, cam2, params2 = (head_scene, head_cam, head_params) if args.config == "cfg2" else load("cfg2")
             r2, st2 = sized_renderer(params2, cam2, training=False)
             del r2
             ips, ms, detail, tr = train_leg("cfg2", params2, cam2, st2.pairs, k)
+            del tr
+            ips_m, ms_m, det_m, tr = train_leg("cfg2", params2, cam2, st2.pairs, 25, fixed_scene=False)
+            detail["moving_scene"] = {"iters_per_s": round(ips_m, 2), "ms_per_iter": round(ms_m, 4),
+                                      "iters_per_block": det_m.get("iters_per_block"), "scene": det_m.get("scene")}
             extra["train_cfg2"] = {"iters_per_s": round(ips, 2), "ms_per_iter": round(ms, 4), **detail,
                                    "step": "forward + L1/SSIM loss (w=0.1) + backward + grad all-reduce (N>1) + fused "
                                            "Adam, one view per GPU, 376,467 Gaussians, 1080p"}
@@ -440,6 +450,10 @@ def main():
             torch.cuda.empty_cache()
             if not CONFIGS[args.config][3]:
                 ips, ms, detail, tr = train_leg(args.config, head_params, head_cam, st.pairs, k)
+                del tr
+                ips_m, ms_m, det_m, tr = train_leg(args.config, head_params, head_cam, st.pairs, 25, fixed_scene=False)
+                detail["moving_scene"] = {"iters_per_s": round(ips_m, 2), "ms_per_iter": round(ms_m, 4),
+                                          "iters_per_block": det_m.get("iters_per_block"), "scene": det_m.get("scene")}
                 extra["train_headline_scene"] = {"iters_per_s": round(ips, 2), "ms_per_iter": round(ms, 4), **detail,
                                                  "step": f"the same step on the headline scene ({n} Gaussians)"}
                 del tr
@@ -456,7 +470,7 @@ def main():
             # array (sums -> exchange -> Adam -> next frame's project stage, slice by slice), on the headline scene (rgb
             # colours) and on the cfg4 scene (degree-2 SH: 73 % of the exchanged bytes are coefficients).  Next to every
             # mode the SAME step without its exchange, in the same process: exposed_ms = what the exchange costs the step.
-            k = 25
+            k = None  # train_timing.block_length
             seen = torch.ones(1, device=dev)
             dist.all_reduce(seen)
             seen = int(seen.item())
@@ -509,6 +523,17 @@ def main():
                                              "exposed_ms": round(ms2 - plain_ms, 4)}
                 del tr
                 torch.cuda.empty_cache()
+                if seen >= 2:
+                    # with peers the number of slices is a trade between hidden wire time and per-slice overhead that only
+                    # a run on the real links can settle: one and four slices next to the default
+                    res["slices_sweep_all_reduce"] = {}
+                    for ns in (1, 4):
+                        vps, msn, _, tr = train_leg(cfg_name, params_s, cam_s, pairs_s, k, force=True, n_slices=ns)
+                        res["slices_sweep_all_reduce"][str(tr.flat.n_slices)] = {
+                            "train_views_per_s": round(vps, 2), "train_ms_per_iter": round(msn, 4),
+                            "exposed_ms": round(msn - plain_ms, 4)}
+                        del tr
+                        torch.cuda.empty_cache()
                 mg["scenes"][tag] = res
                 return res
 

@@ -235,6 +235,53 @@ def test_slice_pipeline_equals_one_blocking_exchange_gloo(tmp_path):
     assert np.abs(r[0][0]).max() > 0
 
 
+@pytest.mark.parametrize("n,world,n_slices", [(1, 1, None), (255, 1, 3), (1999, 2, 3), (7001, 1, 3), (100_000, 4, 5),
+                                              (2_400_000, 8, None), (2_400_000, 1, None), (1_000_003, 3, 4)])
+def test_exchange_slices_tile_the_flat_buffer(n, world, n_slices):
+    """gs_dp.FlatGaussianParams (CPU tensors, no process group): regions padded to a multiple of 4 x world rows, slices
+    made of whole project slices that are multiples of 4 x world Gaussians, the slices' element ranges tile the buffer
+    exactly once, every range splits into equal float4-aligned shards; defaults: one slice on one rank, two from a
+    million Gaussians on with peers."""
+    from gs_dp import ORDER, FlatGaussianParams, project_slice_size
+
+    shapes = [(n, 3), (n, 4), (n, 3), (n,), (n, 3)]
+    flat = FlatGaussianParams([torch.zeros(s) for s in shapes], world_size=world, rank=world - 1,
+                              exchange="reduce_scatter", n_slices=n_slices)
+    q = 4 * world
+    assert flat.n_pad % q == 0 and 0 <= flat.n_pad - n < q
+    assert [tuple(p.shape) for p in flat.params] == shapes and all(p.is_contiguous() for p in flat.params)
+    per = project_slice_size(n)
+    assert per % 256 == 0 and -(-n // per) <= 256
+    b = flat.slice_bounds
+    assert b[0] == 0 and b[-1] == flat.n_pad and all(x < y for x, y in zip(b, b[1:]))
+    assert all(x % per == 0 and x % q == 0 for x in b[:-1])
+    if n_slices is None:
+        assert flat.n_slices == (2 if (n >= 1_000_000 and world > 1) else 1)
+    else:
+        assert 1 <= flat.n_slices <= n_slices
+    covered = torch.zeros(flat.flat_grad.numel(), dtype=torch.int32)
+    for k in range(flat.n_slices):
+        g0, g1 = flat.slice_gaussians(k)
+        assert g0 % 256 == 0 and g0 <= g1 <= n
+        for (lo, hi), (slo, shi), t in zip(flat.slice_ranges(k), flat.owned(flat.slice_ranges(k)), ORDER):
+            covered[lo:hi] += 1
+            assert lo % 4 == 0 and (hi - lo) % q == 0 and (shi - slo) * world == hi - lo and slo % 4 == 0
+            assert flat.region[t] <= lo and (hi - flat.region[t]) % flat.width[t] == 0
+    assert bool((covered == 1).all())
+    assert flat.group_ends[-1] == flat.flat_grad.numel() and all(e % 4 == 0 for e in flat.group_ends)
+
+
+def test_training_block_length_rule():
+    """tools/train_timing.py: 25 iterations per timed block, or what ~30 ms of work take if that is more (capped)."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from train_timing import block_length
+
+    assert block_length(1.34e-3) == 25 and block_length(4e-3) == 25
+    assert block_length(0.56e-3) == 54 and block_length(0.2e-3) == 150 and block_length(1e-5) == 200
+
+
 def _stat_worker(rank, world, port, tmp, mode):
     import torch.distributed as dist
     from gs_dp import ViewParallelGradStat

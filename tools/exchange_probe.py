@@ -52,7 +52,7 @@ def run(mode, n_slices, collective):
                  exchange=mode, n_slices=n_slices)
     tr.flat.force_collective = True
     tr.flat.enable_collective = collective
-    dt, blocks = time_training(tr, a.k, warm=30, repeats=a.repeats)
+    dt, blocks, _ = time_training(tr, a.k, warm=30, repeats=a.repeats)
     # host time of issuing a step: restore, drain, then issue k steps without waiting for the GPU
     snap = snapshot(tr)
     restore(tr, snap)

@@ -61,7 +61,9 @@ for n in sizes:
     from train_timing import time_training
 
     target = (r.forward(*params, cam)[0] + 0.05 * torch.randn(H, W, 3, device=dev)).clamp_(0, 1).contiguous()
-    tr = Trainer([t.clone() for t in params], [cam], [target], TrainOptions(), max_pairs=int(st.pairs * 1.25) + 4096)
+    # learning rate 0: the full step runs (Adam included) on the SAME scene the render figures are quoted on, whatever the
+    # block length; with the reference's rates the scene drifts while it is timed (bench.py reports that figure as well)
+    tr = Trainer([t.clone() for t in params], [cam], [target], TrainOptions(lr=0.0), max_pairs=int(st.pairs * 1.25) + 4096)
     # (as in rounds 1 - 3: no capacity read-back inside the timed loop -- the workspace was sized above; the trainer's
     # default, auto_grow="async", copies the frame counters to the host after every frame, which costs a small scene that
     # is bound by its host time ~0.05 ms per step: set GS_SWEEP_ASYNC=1 to time that)
@@ -70,8 +72,8 @@ for n in sizes:
         tr.renderer.auto_grow = False
     for k_, v_ in KW.items():
         setattr(tr.renderer, k_, v_)
-    k_it = max(steps // 4, 25)
-    tt = time_training(tr, k_it, warm=30, repeats=15)[0] / k_it
+    dt_block, _, k_it = time_training(tr, None, warm=30, repeats=15)
+    tt = dt_block / k_it
     print(json.dumps({"variant": VARIANT, "n_gaussians": n, "visible": st.visible, "tile_pairs": st.pairs,
                       "render_fps_1_stream": round(1 / t1, 1), "render_fps_3_streams": round(1 / t3, 1),
                       "train_iters_per_s": round(1 / tt, 1), "train_ms_per_iter": round(tt * 1e3, 3)}), flush=True)
