@@ -57,6 +57,20 @@ def project_slice_size(n: int) -> int:
     return -(-(-(-n // 256)) // 256) * 256
 
 
+class _WorkList:
+    """Several works waited for as one (the fallback path of backends without grouped collectives on device tensors);
+    `copies`: (destination, source) pairs to copy once the works are done (the emulated all-gather)."""
+
+    def __init__(self, works, copies=()):
+        self.works, self.copies = works, copies
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        for dst, src in self.copies:
+            dst.copy_(src)
+
+
 class FlatGaussianParams:
     """params / grads in the canonical (pos, quat, scale, opa, rgb) order, stored flat.
 
@@ -202,6 +216,9 @@ class FlatGaussianParams:
     def collective_active(self) -> bool:
         return self.enable_collective and dist.is_initialized() and (self.world_size > 1 or self.force_collective)
 
+    def _plain_collectives(self) -> bool:
+        return dist.get_backend() != "nccl" and self.flat_grad.is_cuda
+
     # The collectives go straight to the process group's C++ entry points (allreduce_coalesced & co.: several ranges = ONE
     # grouped RCCL launch) with tensor views that are built once per unit: torch.distributed's Python wrappers cost
     # ~80 us per grouped call on the host (21 us this way, measured on gloo), and a step issues two or three per slice.
@@ -227,6 +244,13 @@ class FlatGaussianParams:
         avg = dist.get_backend() == "nccl" and not self.mean_in_optimizer
         op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
         v = self._views(key, ranges)
+        if self._plain_collectives():
+            # a backend without grouped / scattering collectives on device tensors (gloo with HIP tensors: the two-rank
+            # test on ONE GPU, tests/test_gpu_train.py): one all-reduce per range; the rank's shard of a reduce-scatter
+            # is simply its part of the all-reduced range
+            works = [dist.all_reduce(t, op=op, async_op=True) for t in v["g"]]
+            self._pending[key] = (_WorkList(works), avg, v["g_own"] if self.exchange == "reduce_scatter" else v["g"])
+            return
         if self.exchange == "reduce_scatter":
             o = dist.ReduceScatterOptions()
             o.reduceOp = op
@@ -256,6 +280,17 @@ class FlatGaussianParams:
             return
         pg = dist.distributed_c10d._get_default_group()
         v = self._views(key, ranges)
+        if self._plain_collectives():
+            # all-gather as a SUM all-reduce of a copy in which everything but this rank's shard is zero (exact: the
+            # other ranks contribute zeros there)
+            works, copies = [], []
+            for full, own, (lo, hi), (slo, shi) in zip(v["p"], v["p_own"], v["ranges"], v["own"]):
+                tmp = torch.zeros_like(full)
+                tmp[slo - lo:shi - lo].copy_(own)
+                works.append(dist.all_reduce(tmp, op=dist.ReduceOp.SUM, async_op=True))
+                copies.append((full, tmp))
+            self._pending_gather[key] = _WorkList(works, copies)
+            return
         self._pending_gather[key] = pg.allgather_into_tensor_coalesced(v["p"], v["p_own"])
 
     def finish_gather(self, name=None):

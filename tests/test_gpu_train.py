@@ -1,5 +1,7 @@
 """GPU parity tests of the training-step kernels (gs_adam_step, gs_loss_l1_ssim) and of the Trainer loop.
 All calls go through the C ABI (ctypes); the oracle is oracle/train_ref.py."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -416,6 +418,94 @@ def test_trainer_bucketed_exchange_equals_plain_step(gpu):
             assert torch.equal(a, b)
         assert torch.equal(runs[0][1], other[1]) and torch.equal(runs[0][2], other[2])
     assert float((runs[0][0][0] - start[0]).abs().max()) > 0
+
+
+def _two_rank_worker(rank, world, port, tmp, exchange):
+    """One of two ranks that share ONE GPU (gloo moves the device tensors through the host): rank r trains on view r."""
+    import os
+
+    import torch.distributed as dist
+
+    from gs_frame import FrameRenderer
+    from gs_scene import make_camera, make_scene
+    from gs_train import TrainOptions, Trainer
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    gpu = torch.device("cuda:0")
+    torch.cuda.set_device(gpu)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    FrameRenderer.default_force_strips = True  # (tests/conftest.py does this in the parent: project stage in slices)
+    W, H = 128, 96
+    scene = make_scene(3001, W, H, seed=6)
+    cams = [make_camera(W, H, yaw_deg=0.0), make_camera(W, H, yaw_deg=4.0)]
+    gt = to_torch(scene, gpu)
+    targets = [FrameRenderer(gpu, max_pairs=1 << 16).forward(*gt, c)[0].clone() for c in cams]
+    start = [t.clone() for t in gt]
+    start[4] = start[4] + 0.5 * torch.randn(start[4].shape, device=gpu, generator=torch.Generator(gpu).manual_seed(2))
+    tr = Trainer(start, cams, targets, TrainOptions(n_iters=100, n_iters_warmup=3), world_size=world, max_pairs=1 << 16,
+                 exchange=exchange, n_slices=3)
+    assert tr.flat.collective_active() and tr.flat.rank == rank and tr.flat.n_slices == 3
+    ahead = 0
+    for it in range(6):
+        ahead += int(tr.renderer.begun_frame_matches(*tr.flat.params, cams[rank]))
+        tr.train_step(it, rank, next_camera_id=rank)
+    assert ahead == 5  # every frame but the first was projected behind the previous step's optimizer
+    tr.flat.finish_gather()
+    torch.save({"param": tr.flat.flat_param.cpu(), "state_bytes": tr.optimizer.state_bytes},
+               os.path.join(tmp, f"two_rank_{exchange}_{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange", ["all_reduce", "reduce_scatter"])
+def test_two_ranks_on_one_gpu_equal_the_summed_gradient_step(gpu, tmp_path, exchange):
+    """View parallelism with REAL kernels on two ranks: both ranks run on this one GPU and exchange through gloo (which
+    stages device tensors through the host), rank r renders view r.  After six steps of the slice pipeline (three
+    slices, SUM exchange, 1 / world inside the fused Adam, the next frame's project stage issued ahead; all-reduce +
+    replicated Adam, and reduce-scatter + sharded Adam + parameter all-gather with a non-zero rank's shard offsets) both
+    ranks hold the same parameters, and they are bit for bit those of a single process that renders both views itself,
+    adds the two gradients and takes the same steps."""
+    import torch.multiprocessing as mp
+
+    from gs_dp import FlatGaussianParams
+    from gs_frame import FrameRenderer
+    from gs_scene import make_camera, make_scene
+    from gs_train import FusedAdam, ImageLoss, TrainOptions, base_lrs, lr_lambdas
+
+    world, port = 2, 38500 + (os.getpid() % 1500) + (7 if exchange == "reduce_scatter" else 0)
+    mp.spawn(_two_rank_worker, args=(world, port, str(tmp_path), exchange), nprocs=world, join=True)
+    got = [torch.load(tmp_path / f"two_rank_{exchange}_{r}.pt") for r in range(world)]
+    assert torch.equal(got[0]["param"], got[1]["param"])
+    # ---- the same six steps in ONE process: gradient of view 0 + gradient of view 1, Adam with grad_scale 1 / 2
+    W, H = 128, 96
+    scene = make_scene(3001, W, H, seed=6)
+    cams = [make_camera(W, H, yaw_deg=0.0), make_camera(W, H, yaw_deg=4.0)]
+    gt = to_torch(scene, gpu)
+    targets = [FrameRenderer(gpu, max_pairs=1 << 16).forward(*gt, c)[0].clone() for c in cams]
+    start = [t.clone() for t in gt]
+    start[4] = start[4] + 0.5 * torch.randn(start[4].shape, device=gpu, generator=torch.Generator(gpu).manual_seed(2))
+    opt = TrainOptions(n_iters=100, n_iters_warmup=3)
+    flat = FlatGaussianParams(start, world_size=world, rank=0, n_slices=3)  # same padded layout, no process group
+    lam, base = lr_lambdas(opt), base_lrs(opt)
+    adam = FusedAdam(flat, [b * f(0) for b, f in zip(base, lam)], betas=opt.betas, eps=opt.eps, grad_stat="max")
+    r = FrameRenderer(gpu, max_pairs=1 << 16, training=True, auto_grow=False)
+    loss = ImageLoss(H, W, opt.ssim_weight, gpu)
+    other = [torch.empty_like(g) for g in flat.grads]
+    for it in range(6):
+        img, _ = r.forward(*flat.params, cams[1])
+        r.backward(loss(img, targets[1]), out=other)
+        img, _ = r.forward(*flat.params, cams[0])
+        r.backward(loss(img, targets[0]), out=flat.grads)
+        for a, b in zip(flat.grads, other):
+            a.add_(b)
+        for k in range(flat.n_slices):
+            adam.step_slice(k, advance=(k == 0), grad_scale=0.5)
+        adam.set_lrs([f(it) * b for f, b in zip(lam, base)])
+    assert torch.equal(flat.flat_param.cpu(), got[0]["param"])
+    assert float((flat.flat_param.cpu() - FlatGaussianParams(start, world_size=world, rank=0).flat_param.cpu()).abs().max()) > 0
+    # the sharded optimizer keeps half of the state per rank
+    full = 8 * flat.flat_param.numel()
+    assert got[1]["state_bytes"] == (full // 2 if exchange == "reduce_scatter" else full)
 
 
 def test_grad_stat_update_kernel(gpu):
