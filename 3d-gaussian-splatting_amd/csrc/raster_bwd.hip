@@ -912,7 +912,10 @@ raster_backward_pixel_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
         return id;
     };
     uint32_t id_next = load_coef(0);
-    constexpr bool PAIR_SKIP = GS_BWD_PAIR_SKIP && CDIM == 27;
+#ifndef GS_BWD_PAIR_SKIP48
+#define GS_BWD_PAIR_SKIP48 0  // A/B switch: the finished-half-tile skip for degree 3 as well (round 3: 18 spills at 3 waves)
+#endif
+    constexpr bool PAIR_SKIP = GS_BWD_PAIR_SKIP && (CDIM == 27 || (GS_BWD_PAIR_SKIP48 && CDIM == 48));
     bool pair_live[2] = {true, true};
     (void)pair_live;
     for (uint32_t i = 0; i < r; ++i) {
