@@ -21,13 +21,21 @@ Rank 0 prints ONE JSON line (driver contract):
                        of GPU work, so that an external sampler can see the run); value / ms_per_step are the MEDIAN
                        block, "ms_per_step_min" / "_max" its spread;
   roofline             dominant kernel of that workload (raster_forward_kernel), algorithmic bytes of SURVEY.md 8d S5
-                       / its hipEvent-timed duration (events on the launch stream, inside the library);
+                       / its hipEvent-timed duration (events on the launch stream, inside the library); `traffic` = HBM-side
+                       bytes per launch from the committed PMC passes (profiles/traffic.json) with `correction` = how
+                       FETCH_SIZE was turned into bytes for this kernel's access pattern and `traffic_bounds`;
   stages               every stage of the frame: ms, algorithmic bytes (SURVEY.md 8d), GB/s, fraction of HBM peak;
   cfg2                 BASELINE.json configs[1] (376,467 Gaussians, 1080p): FPS + the same roofline object;
-  extra                training step (forward + L1/SSIM loss + backward + fused Adam) at cfg2 and at 2.4 M Gaussians,
-                       a 300-iteration fit of the cfg3 scene, cfg4 (2.4 M, SH) forward / backward stage times,
-                       three frames in flight;
-  multi_gpu            ranks seen, gradient bucket bytes, all-reduce time, training views/s over all ranks;
+  extra                training step (forward + L1/SSIM loss + backward + fused Adam) at cfg2 and at 2.4 M Gaussians -- timed
+                       with tools/train_timing.py: the same iterations per block restored from a snapshot, 15 blocks, on the
+                       FIXED scene (learning rate 0: the full step runs, the parameters stay put) with the moving-scene
+                       figure (the reference's learning rates) next to it --, a 300-iteration fit of the cfg3 scene, cfg4
+                       (2.4 M, SH) forward / backward stage times and the wall clock of the free-running loop, three
+                       frames in flight;
+  multi_gpu            (under torchrun, or with --force-collective on one rank) ranks seen, gradient buffer bytes, and per
+                       scene (rgb, SH) and exchange mode: training views/s over all ranks, the exchange alone, bus
+                       bandwidth, and exposed_ms = the step with its exchange minus the same step without it in the same
+                       process; the two-slice pipeline's figure; with peers also one and four slices;
   cpu_baseline         the C oracle (CPU port of the reference path, OpenMP over every host core) on the same scene.
 `--legs` selects what runs (default: everything that fits the rank count); profiles/ holds rocprofv3 traces of
 `--legs headline`.
