@@ -86,6 +86,7 @@ BUDGETS = [
     (("raster_backward_pixel_sh_kernelILi3ELb1ELb0E",), 96, False),      # rgb backward: five waves (LDS-limited at 7.6 KiB)
     (("raster_backward_pixel_sh_kernelILi27ELb1ELb0E",), 128, True),
     (("raster_backward_pixel_sh_kernelILi48ELb1ELb0E",), 168, True),
+    (("frame_project_backward_kernelILi3ELi0ELi256E",), 80, False),      # rgb projection backward: six waves per SIMD
     (("frame_project_count_kernelILb0E",), 128, False),                   # 1024 threads per workgroup: 128 is the hard limit
     (("frame_project_bin_count_kernelILb0E",), 128, False),
     (("strip_sort_kernelILi2048ELb0E",), 128, False),                    # four workgroups of 256 per CU
@@ -110,6 +111,10 @@ def test_lds_budgets(kernels):
     assert fwd[".group_segment_fixed_size"] * 16 <= 160 * 1024      # 16 waves (= one-wave workgroups) per CU
     bwd = pick(kernels, "raster_backward_pixel_sh_kernelILi3ELb1ELb0E")
     assert bwd[".group_segment_fixed_size"] * 20 <= 160 * 1024      # five waves per SIMD
+    # the rgb backward stages its 64 rows in LDS for the one-line stores: it must stay at 20 one-wave workgroups per CU
+    assert bwd[".group_segment_fixed_size"] <= 8192
+    pb = pick(kernels, "frame_project_backward_kernelILi3ELi0ELi256E")
+    assert pb[".group_segment_fixed_size"] * 6 <= 160 * 1024        # six workgroups of 256 per CU
     sort = pick(kernels, "strip_sort_kernelILi2048ELb0E")
     assert sort[".group_segment_fixed_size"] * 4 <= 160 * 1024      # four workgroups per CU
     assert pick(kernels, "frame_project_count_kernelILb0E")[".group_segment_fixed_size"] + 8192 * 8 <= 160 * 1024
