@@ -134,9 +134,23 @@ class FlatGaussianParams:
         # Adam group table in ORDER: a group ends where the next region begins (pad rows: zero gradient, zero moments)
         self.group_ends = [self.region["pos"], self.region["scale"], self.region["opa"], self.region["rgb"], total]
         # ---- slices of the Gaussian array (exchange units)
-        per = project_slice_size(n)
+        self.project_slice = project_slice_size(n)
+        self._pending = {}
+        self._pending_gather = {}
+        self._view_cache = {}
+        self.set_slices(n_slices)
+
+    def set_slices(self, n_slices: int = None):
+        """(Re)cut the Gaussian array into exchange slices.  Allowed at any time between steps for a replicated optimizer
+        (its moments mirror the flat buffer); a sharded optimizer packs its moments by slice and must be rebuilt."""
+        if self._pending or self._pending_gather:
+            raise RuntimeError("set_slices() with an exchange in flight")
+        n = self.n
+        quantum = 4 * max(self.world_size, 1)
+        per = self.project_slice
         step = per * (quantum // math.gcd(per, quantum))  # whole project slices AND multiples of 4 x world Gaussians
         n_steps = max(-(-self.n_pad // step), 1)
+        self._view_cache = {k: v for k, v in self._view_cache.items() if not (isinstance(k, tuple) and k[0] == "slice")}
         if n_slices is None:
             # One slice on a single rank (nothing travels: nothing to hide), two from a million Gaussians on when there
             # are peers.  Measured on one rank at 2.4 M Gaussians (round 4, profiles/r04_e_exchange_probe_*.jsonl): every
@@ -147,10 +161,6 @@ class FlatGaussianParams:
         k_slices = max(1, min(int(n_slices), n_steps))
         bounds = sorted({min(round(i * n_steps / k_slices) * step, self.n_pad) for i in range(k_slices)} | {self.n_pad})
         self.slice_bounds = [0] + [b for b in bounds if b > 0]
-        self.project_slice = per
-        self._pending = {}
-        self._pending_gather = {}
-        self._view_cache = {}
 
     # ---- geometry of the exchange units --------------------------------------------------------------------------
     @property

@@ -103,19 +103,7 @@ class FusedAdam:
         self.betas, self.eps = (float(betas[0]), float(betas[1])), float(eps)
         self.sharded = flat.exchange == "reduce_scatter"
         dev = flat.flat_param.device
-        # per slice: the (up to five) element ranges this rank updates and where their moments start
-        self._units = []
-        off = 0
-        for k in range(flat.n_slices):
-            own = [r for r in flat.owned(flat.slice_ranges(k)) if r[1] > r[0]]
-            offs = []
-            for lo, hi in own:
-                offs.append(off if self.sharded else lo)  # replicated: the moments mirror the flat buffer
-                off += hi - lo
-            n_r = len(own)
-            self._units.append((n_r, (C.c_int64 * n_r)(*[r[0] for r in own]), (C.c_int64 * n_r)(*[r[1] for r in own]),
-                                (C.c_int64 * n_r)(*offs)))
-        size = off if self.sharded else flat.flat_param.numel()
+        size = self._build_units()
         self.exp_avg = torch.zeros(size, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros_like(self.exp_avg)
         self.step_count = 0
@@ -128,6 +116,30 @@ class FusedAdam:
         self.stat_mode = {None: 0, "max": 1, "mean": 2}[grad_stat]
         self.accum_grad = torch.zeros_like(flat.params[0]) if self.stat_mode else None  # train.py:80-82
         self.skip_flag = None  # device address of a 64-bit counter: non-zero => the step is skipped (gs_abi.h)
+
+    def _build_units(self) -> int:
+        """Per exchange slice: the (up to five) element ranges this rank updates and where their moments start -> size of
+        the moment arrays."""
+        flat = self.flat
+        self._units = []
+        off = 0
+        for k in range(flat.n_slices):
+            own = [r for r in flat.owned(flat.slice_ranges(k)) if r[1] > r[0]]
+            offs = []
+            for lo, hi in own:
+                offs.append(off if self.sharded else lo)  # replicated: the moments mirror the flat buffer
+                off += hi - lo
+            n_r = len(own)
+            self._units.append((n_r, (C.c_int64 * n_r)(*[r[0] for r in own]), (C.c_int64 * n_r)(*[r[1] for r in own]),
+                                (C.c_int64 * n_r)(*offs)))
+        return off if self.sharded else flat.flat_param.numel()
+
+    def reslice(self):
+        """After ``flat.set_slices``: a replicated optimizer's moments mirror the flat buffer, so only the unit tables
+        change; a sharded one packs its moments by slice and cannot follow."""
+        if self.sharded:
+            raise RuntimeError("a sharded optimizer cannot be re-sliced (its moments are packed slice by slice)")
+        self._build_units()
 
     @property
     def state_bytes(self) -> int:
@@ -383,6 +395,49 @@ class Trainer:
             self.renderer.forward_abandon()
             reset_opa(self.flat.params[3])
         return loss.values
+
+    def tune_slices(self, i_iter: int, camera_id: int, candidates: Sequence[int] = (1, 2, 4), iters: int = 6,
+                    next_camera_id: Optional[int] = None) -> int:
+        """Pick the number of exchange slices by measurement: ``iters`` real training steps (starting at iteration
+        ``i_iter``, all on view ``camera_id``) per candidate, timed with a device synchronisation around each group, the
+        slowest rank's time decides (one MAX all-reduce per candidate, so every rank picks the same).  How much wire time
+        a further slice hides against what it costs depends on the links, and the builder of this
+        code never had more than one GPU: the first steps of a multi-GPU run can settle it themselves.  Replicated
+        optimizer ("all_reduce") only.  Returns the chosen count; ``candidates * iters`` steps have been taken."""
+        import time
+
+        import torch.distributed as dist
+
+        flat = self.flat
+        if not flat.collective_active() or flat.exchange != "all_reduce":
+            return flat.n_slices
+        dev = flat.flat_param.device
+        best, best_t, it = flat.n_slices, None, i_iter
+        for ns in candidates:
+            flat.finish_gather()
+            self.renderer.forward_abandon()
+            flat.set_slices(ns)
+            self.optimizer.reslice()
+            self.train_step(it, camera_id, next_camera_id=next_camera_id)  # (first step after a re-slice: views, caches)
+            it += 1
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(iters - 1):
+                self.train_step(it, camera_id, next_camera_id=next_camera_id)
+                it += 1
+            torch.cuda.synchronize(dev)
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            if self.world_size > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t = float(t.item())
+            if best_t is None or t < best_t:
+                best, best_t = flat.n_slices, t
+        flat.finish_gather()
+        self.renderer.forward_abandon()
+        flat.set_slices(best)
+        self.optimizer.reslice()
+        self.n_slices = best  # a later _bind (densification) keeps the choice
+        return best
 
     def _can_project_ahead(self, i_iter: int, next_camera_id: Optional[int], rebinding: bool) -> bool:
         """May the next frame's project stage be issued behind this step's optimizer?  Only for a view whose capacity

@@ -451,8 +451,16 @@ def _two_rank_worker(rank, world, port, tmp, exchange):
         tr.train_step(it, rank, next_camera_id=rank)
     assert ahead == 5  # every frame but the first was projected behind the previous step's optimizer
     tr.flat.finish_gather()
-    torch.save({"param": tr.flat.flat_param.cpu(), "state_bytes": tr.optimizer.state_bytes},
-               os.path.join(tmp, f"two_rank_{exchange}_{rank}.pt"))
+    out = {"param": tr.flat.flat_param.cpu(), "state_bytes": tr.optimizer.state_bytes}
+    # the number of slices picked by measurement (replicated optimizer only): every rank must arrive at the same count,
+    # and the steps taken while measuring are ordinary training steps
+    out["tuned"] = tr.tune_slices(6, rank, candidates=(1, 2, 3), iters=2, next_camera_id=rank)
+    out["slices_after"] = tr.flat.n_slices
+    tr.train_step(20, rank, next_camera_id=rank)
+    tr.flat.finish_gather()
+    out["finite"] = bool(torch.isfinite(tr.flat.flat_param).all())
+    out["param_after"] = tr.flat.flat_param.cpu()
+    torch.save(out, os.path.join(tmp, f"two_rank_{exchange}_{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -503,6 +511,10 @@ def test_two_ranks_on_one_gpu_equal_the_summed_gradient_step(gpu, tmp_path, exch
         adam.set_lrs([f(it) * b for f, b in zip(lam, base)])
     assert torch.equal(flat.flat_param.cpu(), got[0]["param"])
     assert float((flat.flat_param.cpu() - FlatGaussianParams(start, world_size=world, rank=0).flat_param.cpu()).abs().max()) > 0
+    # Trainer.tune_slices: the same choice on both ranks, the replicas still agree afterwards
+    assert got[0]["tuned"] == got[1]["tuned"] == got[0]["slices_after"] == got[1]["slices_after"]
+    assert got[0]["tuned"] in ((1, 2, 3) if exchange == "all_reduce" else (3,))
+    assert got[0]["finite"] and got[1]["finite"] and torch.equal(got[0]["param_after"], got[1]["param_after"])
     # the sharded optimizer keeps half of the state per rank
     full = 8 * flat.flat_param.numel()
     assert got[1]["state_bytes"] == (full // 2 if exchange == "reduce_scatter" else full)
