@@ -1120,6 +1120,345 @@ raster_backward_pixel_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// SH, frame path: the two contractions of the SH backward on the matrix pipe (raster_backward_mfma_sh_kernel).
+//
+// Per bucket of 64 Gaussians and tile of 256 pixels the SH backward holds two true matrix products
+//   logit[(g, ch)][p]   = sum_k  coef[g][ch][k] sh_k(p)          (64 x 3 rows, K = 9 | 16, 256 columns)
+//   dcoef[(g, ch)][k]   = sum_p  D[g][ch][p]   sh_k(p)           (K = 256 pixels: the cross-pixel reduction itself)
+// which the pixel-parallel kernel above evaluates with 2 x 27 | 48 FMAs per (pixel, Gaussian) on the VALU plus, for the
+// second one, a 64 : 1 reduction of 27 | 48 rows through LDS per Gaussian -- together ~3/4 of its ~360 VALU
+// instructions per Gaussian step.  An fp32 MFMA (v_mfma_f32_16x16x4_f32: exact fp32, a k-ordered fmaf chain) has the
+// VALU's FMA rate but runs BESIDE the VALU and contracts across lanes for free.  The layouts that make both products
+// MFMA-shaped at once: a wave works on 16 Gaussians x 16 pixels (one pixel row of the tile) per step,
+//   lane l  <->  Gaussian g' = l & 15 of the current group of 16,  pixel quad j = l >> 4  (pixels x = 4 j + i, i = 0..3)
+// * colour logits:   D[row = pixel x][col = g'] = sum_k A[x][k] B[k][g'],  A = sh_k(x, y) from an LDS table (lane: x = l & 15,
+//   k = 4 kk + (l >> 4)), B = coef[g'][ch][k] (held in registers for the 16 pixel rows).  The result lands exactly where
+//   the per-pixel arithmetic wants it: lane (g', j) gets the logits of its four pixels 4 j + reg.
+// * coefficient sums: D[row = k][col = g'] += sum_x A'[k][x] B'[x][g'],  B' = D[g'][ch][pixel 4 j + i] -- register i of
+//   lane (g', j), as computed --, A' = sh_k(x, y) from the same table (lane: k = l & 15, x = 4 (l >> 4) + i).  The MFMA's
+//   K index contracts over the pixel quads, its accumulator over i and over the 16 pixel rows: after 16 steps lane (g', j)
+//   holds dL/dcoef[g'][ch][4 j + reg] complete -- no reduction of the coefficient rows through LDS at all.
+// What stays on the VALU per (pixel, Gaussian): the Gaussian's value (one v_exp), three sigmoids, the transmittance and
+// rho recursions -- over the 16 Gaussians of a group they are a prefix product / prefix sum across the 16 lanes of a DPP
+// row (row_shr 1, 2, 4, 8) -- and the seven geometry / opacity sums, which accumulate over the pixel rows in registers
+// (dx of a lane's four pixel columns is constant over the rows) and are reduced 4 : 1 once per group.
+// A workgroup = one tile, W waves; wave w takes buckets w, w + W, ...: the SH table (pre-scaled by -log2 e as in the
+// kernels above), dL/dC and the final colours are staged once per tile; per wave only the pixels' (T, rho) live in LDS
+// (read as broadcast float4, written back by the lanes of Gaussian 15 after every pixel row).
+// Transmittance: T_before(g') = T_in prod_{h < g'} max(1 - alpha_h, 0) with UNMASKED alphas; a pixel is live while that
+// is > 1e-4, exactly the reference's test (gaussian.cu:906) up to the rounding of a product tree against a chain; behind
+// the stop every contribution is masked to zero and the unmasked product only ever falls, so it never revives a pixel.
+#ifndef GS_BWD_SH_MFMA
+#define GS_BWD_SH_MFMA 0  // A/B switch (tools/ab_variants.py)
+#endif
+#ifndef GS_BWD_MFMA_WAVES
+#define GS_BWD_MFMA_WAVES 4
+#endif
+#ifndef GS_BWD_MFMA_WPE
+#define GS_BWD_MFMA_WPE 3
+#endif
+
+template <int CTRL>
+__device__ __forceinline__ float gs_dpp(float old, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src),
+                                                                 CTRL, 0xf, 0xf, false));
+}
+// inclusive product / sum over the 16 lanes of a DPP row (lanes whose source falls outside the row keep the identity)
+__device__ __forceinline__ float gs_row_scan_mul(float v) {
+    v *= gs_dpp<0x111>(1.0f, v);
+    v *= gs_dpp<0x112>(1.0f, v);
+    v *= gs_dpp<0x114>(1.0f, v);
+    v *= gs_dpp<0x118>(1.0f, v);
+    return v;
+}
+__device__ __forceinline__ float gs_row_scan_add(float v) {
+    v += gs_dpp<0x111>(0.0f, v);
+    v += gs_dpp<0x112>(0.0f, v);
+    v += gs_dpp<0x114>(0.0f, v);
+    v += gs_dpp<0x118>(0.0f, v);
+    return v;
+}
+
+// The same scans for the lane's four pixels at once, every step ONE instruction per pixel (v_mul_f32_dpp v, v, v row_shr:n:
+// lanes whose source falls outside the row are disabled by the DPP bound check and keep v -- the identity for free;
+// through the builtin the compiler emits v_mov 1.0 + v_mov_dpp + v_mul for a product step).  The four chains are
+// interleaved so that the write of a register and its DPP read in the next step are three instructions apart (the
+// hardware wants two wait states there, and the compiler's hazard pass does not look into inline assembly: hence also
+// the s_nop in front of the first and behind the last instruction of the block).
+#ifndef GS_BWD_MFMA_ASM_SCAN
+#define GS_BWD_MFMA_ASM_SCAN 1
+#endif
+#define GS_SCAN4(OP)                                                                                                   \
+    asm volatile("s_nop 1\n\t" OP " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t" OP                                          \
+                    " %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t" OP                                          \
+                    " %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\t" OP                                          \
+                    " %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\t" OP                                          \
+                    " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t" OP                                          \
+                    " %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t" OP                                          \
+                    " %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf\n\t" OP                                          \
+                    " %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf\n\t" OP                                          \
+                    " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t" OP                                          \
+                    " %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t" OP                                          \
+                    " %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf\n\t" OP                                          \
+                    " %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf\n\t" OP                                          \
+                    " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t" OP                                          \
+                    " %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t" OP                                          \
+                    " %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf\n\t" OP                                          \
+                    " %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1"                                        \
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]))
+__device__ __forceinline__ void gs_row_scan_mul4(float v[4]) {
+#if GS_BWD_MFMA_ASM_SCAN
+    GS_SCAN4("v_mul_f32_dpp");
+#else
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = gs_row_scan_mul(v[i]);
+#endif
+}
+__device__ __forceinline__ void gs_row_scan_add4(float v[4]) {
+#if GS_BWD_MFMA_ASM_SCAN
+    GS_SCAN4("v_add_f32_dpp");
+#else
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = gs_row_scan_add(v[i]);
+#endif
+}
+
+template <int CDIM, int W>
+__global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GS_BWD_MFMA_WPE)))
+raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
+    static_assert(CDIM == 27 || CDIM == 48, "SH colours only");
+    constexpr int NB = CDIM / 3;          // basis functions per channel: 9 | 16
+    constexpr int KQ = (NB + 3) / 4;      // k blocks of four of the colour product: 3 | 4
+    constexpr int P = 17;                 // floats per pixel in the SH table (16 + 1: both operand patterns nearly conflict-free)
+    constexpr int RW = gs_row_floats(CDIM);
+    constexpr uint32_t GS_NO_SLOT = 0xffffffffu;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    __shared__ float s_sh[256 * P];                                  // [pixel 16 y + x][k], entries k >= NB are zero
+    __shared__ __attribute__((aligned(16))) float s_f[3][256];      // final colour of the pixel
+    __shared__ __attribute__((aligned(16))) float s_gr[3][256];     // dL/dC (masked: crop, clamp)
+    __shared__ float s_py[16];
+    __shared__ __attribute__((aligned(16))) float s_T[W][256];      // per wave: transmittance / rho in front of the current group
+    __shared__ __attribute__((aligned(16))) float s_rho[W][256];
+    auto lds_order = [] {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t nproc = I.tile_nproc[tile];
+    if (nproc == 0) return;  // uniform: nothing of this tile was composited
+    const uint32_t start = (uint32_t)I.ranges[2 * tile];
+    const uint32_t tx = tile % (uint32_t)G.ntx, ty = tile / (uint32_t)G.ntx;
+    constexpr float KS = -GS_LOG2E;  // the table holds sh'_k = -log2(e) sh_k (raster_common.h)
+
+    // ---- per tile: SH table, dL/dC, final colours, pixel-row centres
+    for (int p = tid; p < 256; p += 64 * W) {
+        const uint32_t id_x = tx * 16 + (p & 15), id_y = ty * 16 + (p >> 4);
+        float sh[NB];
+        raster_pixel_sh<NB>(id_x, id_y, G, sh);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s_sh[p * P + k] = k < NB ? KS * sh[k < NB ? k : 0] : 0.f;
+        float f[3], gr[3];
+        load_pixel_inputs<true>(I, G, id_x, id_y, f, gr);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            s_f[e][p] = f[e];
+            s_gr[e][p] = gr[e];
+        }
+    }
+    if (tid < 16) s_py[tid] = raster_pixel_coord(ty * 16 + tid, G.padH, G.focal_y);
+    __syncthreads();
+
+    const uint32_t gq = (uint32_t)lane & 15u, jq = (uint32_t)lane >> 4;  // Gaussian of the group, pixel quad
+    float px[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) px[i] = raster_pixel_coord(tx * 16 + 4 * jq + i, G.padW, G.focal_x);
+    float *sT = s_T[wave], *sR = s_rho[wave];
+    const uint32_t nbk = (nproc + GS_BUCKET - 1) / GS_BUCKET;
+    for (uint32_t b = wave; b < nbk; b += W) {
+        const uint32_t base = b * GS_BUCKET, rem = nproc - base, r = rem < GS_BUCKET ? rem : GS_BUCKET;
+        // ---- pixel states at the bucket's boundary: the forward's checkpoint ((1, 0) in front of the tile's first bucket)
+        {
+            const float4 *ck = I.ckpt + raster_ckpt_slot(start, tile, b) * 256;
+            float4 c[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) c[k] = b == 0 ? make_float4(1.f, 0.f, 0.f, 0.f) : ck[64 * k + lane];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int p = 64 * k + lane;  // == 16 y + x of pixel (x = lane & 15, y = (lane >> 4) + 4 k)
+                sT[p] = c[k].x;
+                sR[p] = s_gr[0][p] * (s_f[0][p] - c[k].y) + s_gr[1][p] * (s_f[1][p] - c[k].z) +
+                        s_gr[2][p] * (s_f[2][p] - c[k].w);
+            }
+        }
+        lds_order();
+        const uint32_t ngrp = (r + 15) / 16;
+        for (uint32_t grp = 0; grp < ngrp; ++grp) {
+            // ---- this lane's Gaussian (entries beyond r re-read the bucket's last one with opacity 0: alpha = 0)
+            const uint32_t gi = grp * 16 + gq;
+            const bool valid = gi < r;
+            GaussianRec g;
+            const uint32_t gid = raster_load<true>(S, start + base + (valid ? gi : r - 1), g);
+            float cA, cB, cC;
+            raster_conic(g, cA, cB, cC);
+            const float opa = valid ? g.opa : 0.f;
+            float cob[3][KQ];  // B operand of the colour product: coef[g'][ch][4 kk + jq]
+            {
+                const float *cf = S.sh + (size_t)gid * CDIM;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+                    for (int kk = 0; kk < KQ; ++kk) {
+                        const uint32_t k = 4 * kk + jq;
+                        cob[ch][kk] = (4 * kk + 3 < NB || k < (uint32_t)NB) ? cf[ch * NB + (k < (uint32_t)NB ? k : 0)] : 0.f;
+                    }
+            }
+            uint32_t slot = GS_NO_SLOT;
+            if (valid) {
+                const uint4 rc = O.rects[gid];
+                const uint32_t y0 = rc.x & 0xffff, x0 = rc.y & 0xffff, x1 = rc.y >> 16;
+                const uint64_t sl = (uint64_t)O.pair_offsets[gid] + (ty - y0) * (x1 - x0) + (tx - x0);
+                if (sl < O.max_pairs) slot = (uint32_t)sl;
+            }
+            float dx[4], bdx[4], adx2[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                dx[i] = px[i] - g.x;
+                bdx[i] = cB * dx[i];
+                adx2[i] = cA * dx[i] * dx[i];
+            }
+            f4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            float S1[4] = {0.f, 0.f, 0.f, 0.f}, Sy[4] = {0.f, 0.f, 0.f, 0.f}, Syy = 0.f, Sq = 0.f, Sopa = 0.f;
+            for (int s = 0; s < 16; ++s) {  // pixel row s of the tile
+                const int prow = 16 * s;
+                // colour logits of (pixel 4 jq + reg, Gaussian gq) on the matrix pipe
+                f4 lg[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int kk = 0; kk < KQ; ++kk) {
+                    const float a = s_sh[(prow + (int)gq) * P + 4 * kk + (int)jq];  // here l & 15 is the pixel column
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) lg[ch] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, cob[ch][kk], lg[ch], 0, 0, 0);
+                }
+                const float dy = s_py[s] - g.y;
+                const f4 Tin = *reinterpret_cast<const f4 *>(sT + prow + 4 * jq);
+                const f4 Rin = *reinterpret_cast<const f4 *>(sR + prow + 4 * jq);
+                const f4 G0 = *reinterpret_cast<const f4 *>(s_gr[0] + prow + 4 * jq);
+                const f4 G1 = *reinterpret_cast<const f4 *>(s_gr[1] + prow + 4 * jq);
+                const f4 G2 = *reinterpret_cast<const f4 *>(s_gr[2] + prow + 4 * jq);
+                f4 Tout, Rout;
+                float dv[3][4];
+                float q[4], Gv[4], araw[4], pin[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    q[i] = fmaf(fmaf(cC, dy, -bdx[i]), dy, adx2[i]);
+                    Gv[i] = gs_exp2(-q[i]);
+                    araw[i] = Gv[i] * opa;
+                    pin[i] = fmaxf(1.0f - araw[i], 0.f);
+                }
+                // transmittance in front of this Gaussian: T_in times the product over the group's earlier Gaussians
+                gs_row_scan_mul4(pin);
+                float Tb[4], alpha[4], w[4], gc[4], wg[4], cc[3][4];
+                bool live[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    Tb[i] = Tin[i] * gs_dpp<0x111>(1.0f, pin[i]);
+                    live[i] = Tb[i] > GS_T_STOP;
+                    alpha[i] = live[i] ? araw[i] : 0.f;
+                    w[i] = alpha[i] * Tb[i];
+                    // colours sigma(logit) = 1 / (1 + 2^(logit')) with the pre-scaled basis
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) cc[ch][i] = gs_rcp(1.0f + gs_exp2(lg[ch][i]));
+                    gc[i] = fmaf(G2[i], cc[2][i], fmaf(G1[i], cc[1][i], G0[i] * cc[0][i]));
+                    wg[i] = w[i] * gc[i];
+                    Tout[i] = Tin[i] * pin[i];  // (meaningful in the lanes of Gaussian 15: the whole group's product)
+                }
+                // rho behind this Gaussian: rho_in minus the inclusive prefix sum of w gc
+                gs_row_scan_add4(wg);
+                float ssum = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float rho = Rin[i] - wg[i];
+                    const float rc = gs_rcp(fmaf(-Gv[i], opa, 1.00000011920928955f));  // 1 / (1 - alpha + 1e-7)
+                    float d_alpha = fmaf(Tb[i], gc[i], -(rho * rc));
+                    d_alpha = live[i] ? d_alpha : 0.f;
+                    // D = dL/dC_ch w c (1 - c) [x -ln 2: D sh' = D' sh]
+                    constexpr float K = -GS_LN2;
+                    dv[0][i] = G0[i] * w[i] * (cc[0][i] * fmaf(cc[0][i], -K, K));
+                    dv[1][i] = G1[i] * w[i] * (cc[1][i] * fmaf(cc[1][i], -K, K));
+                    dv[2][i] = G2[i] * w[i] * (cc[2][i] * fmaf(cc[2][i], -K, K));
+                    Sopa = fmaf(d_alpha, Gv[i], Sopa);
+                    const float sv = d_alpha * alpha[i];
+                    S1[i] += sv;
+                    Sy[i] = fmaf(sv, dy, Sy[i]);
+                    ssum += sv;
+                    Sq = fmaf(sv, q[i], Sq);
+                    Rout[i] = rho;
+                }
+                Syy = fmaf(ssum * dy, dy, Syy);
+                // coefficient sums: acc[ch][reg] += sum over the row's 16 pixels of D[ch] sh'_(4 jq + reg)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float tb = s_sh[(prow + 4 * (int)jq + i) * P + (int)gq];  // here l & 15 is the basis function
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) acc[ch] = __builtin_amdgcn_mfma_f32_16x16x4f32(tb, dv[ch][i], acc[ch], 0, 0, 0);
+                }
+                if (gq == 15) {  // the row's pixel states in front of the next group
+                    *reinterpret_cast<f4 *>(sT + prow + 4 * jq) = Tout;
+                    *reinterpret_cast<f4 *>(sR + prow + 4 * jq) = Rout;
+                }
+            }
+            // ---- close the group: the lane's four pixel columns, then the four pixel quads of the Gaussian
+            float Sx = 0.f, Sxx = 0.f, Sxy = 0.f, Syt = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float sx = S1[i] * dx[i];
+                Sx += sx;
+                Sxx = fmaf(sx, dx[i], Sxx);
+                Sxy = fmaf(Sy[i], dx[i], Sxy);
+                Syt += Sy[i];
+            }
+            auto quad_sum = [](float v) {
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                return v;
+            };
+            Sx = quad_sum(Sx);
+            Syt = quad_sum(Syt);
+            Sxx = quad_sum(Sxx);
+            Sxy = quad_sum(Sxy);
+            Syy = quad_sum(Syy);
+            Sq = quad_sum(Sq);
+            Sopa = quad_sum(Sopa);
+            if (slot != GS_NO_SLOT) {
+                float *row = O.rows + (size_t)slot * RW;
+                if (jq == 0) {
+                    const float a = g.a, bb = g.b, cc = g.c, d = g.d;
+                    const float iPn = 1.0f / (2.0f * raster_det(a, bb, cc, d) + 1e-14f);
+                    const float Su = Sq * GS_LN2;
+                    const float ogx = GS_LN2 * (2.0f * cA * Sx - cB * Syt), ogy = GS_LN2 * (2.0f * cC * Syt - cB * Sx);
+                    const float ga = iPn * (-Syy + 2.0f * d * Su), gb = iPn * (Sxy - 2.0f * cc * Su);
+                    const float gcc = iPn * (Sxy - 2.0f * bb * Su), gd = iPn * (-Sxx + 2.0f * a * Su);
+                    O.row_flags[slot] = 1;
+                    reinterpret_cast<float4 *>(row)[0] = make_float4(ogx, ogy, ga, gb);
+                    reinterpret_cast<float2 *>(row)[2] = make_float2(gcc, gd);
+                    row[6] = Sopa;
+#pragma unroll
+                    for (int m = 7 + CDIM; m < RW; ++m) row[m] = 0.f;  // padding of the row
+                }
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const uint32_t k = 4 * jq + e;
+                        if (NB == 16 || k < (uint32_t)NB) row[7 + ch * NB + k] = acc[ch][e];
+                    }
+            }
+        }
+        lds_order();  // (the next bucket's states overwrite this wave's arrays)
+    }
+}
+
 // sigmoid=True of the reference API: ceil buckets in the systolic kernel, no tail kernel (a rarely used flag)
 template <int CDIM>
 void launch_bwd_sig(const RasterSrc &S, const RasterGeom &G, const BwdIn &I, const BwdOut &O, int64_t max_buckets,
@@ -1143,6 +1482,12 @@ void launch_bwd(const RasterSrc &S, const RasterGeom &G, const BwdIn &I, const B
                 hipStream_t stream) {
     constexpr int WPB = BwdCfg<CDIM>::WPB;
     const int grid = (int)gs_div_up(max_buckets > 0 ? max_buckets : 1, WPB);
+    if constexpr (FRAME && CDIM > 3 && GS_BWD_SH_MFMA) {
+        // one workgroup per tile (tiles nothing was composited in leave at once)
+        hipLaunchKernelGGL((raster_backward_mfma_sh_kernel<CDIM, GS_BWD_MFMA_WAVES>), dim3((unsigned)(G.ntx * G.nty)),
+                           dim3(64 * GS_BWD_MFMA_WAVES), 0, stream, S, G, I, O);
+        return;
+    }
     if (CDIM == 3 && !GS_BWD_PACKED_RGB) {
         const int64_t blocks = gs_div_up(max_buckets > 0 ? max_buckets : 1, GS_PP_WPB);
         hipLaunchKernelGGL((raster_backward_pixel_kernel<FRAME>), dim3((unsigned)blocks), dim3(64 * GS_PP_WPB), 0, stream,
