@@ -125,6 +125,7 @@ struct BwdIn {
     const uint32_t *bucket_offsets;  // [T+1]
     const uint4 *bucket_info;        // [n_buckets] (tile, first Gaussian, count, start of the tile's list)
     const int32_t *ranges;           // FRAME: [T][2]; REF: accum [T+1]
+    const uint32_t *tile_order;      // FRAME, optional: the tiles in descending order of their cost (one workgroup per tile)
 };
 
 // Inputs of one pixel for the backward kernels: final colour, and dL/dC -- for the frame path the gradient of
@@ -1150,7 +1151,7 @@ raster_backward_pixel_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
 // is > 1e-4, exactly the reference's test (gaussian.cu:906) up to the rounding of a product tree against a chain; behind
 // the stop every contribution is masked to zero and the unmasked product only ever falls, so it never revives a pixel.
 #ifndef GS_BWD_SH_MFMA
-#define GS_BWD_SH_MFMA 0  // A/B switch (tools/ab_variants.py)
+#define GS_BWD_SH_MFMA 2  // 0: never, 1: degree 3 (48 coefficients) only, 2: degree 2 as well (A/B switch, tools/ab_variants.py)
 #endif
 #ifndef GS_BWD_MFMA_WAVES
 #define GS_BWD_MFMA_WAVES 4
@@ -1224,7 +1225,19 @@ __device__ __forceinline__ void gs_row_scan_add4(float v[4]) {
 #endif
 }
 
-template <int CDIM, int W>
+#ifndef GS_BWD_MFMA_PF
+#define GS_BWD_MFMA_PF 1
+#endif
+#ifndef GS_BWD_MFMA_ORDER
+#define GS_BWD_MFMA_ORDER 1
+#endif
+#ifndef GS_BWD_MFMA_ROW_SKIP
+#define GS_BWD_MFMA_ROW_SKIP 1
+#endif
+#ifndef GS_BWD_MFMA_TILES
+#define GS_BWD_MFMA_TILES 1  // tiles per workgroup (see the kernel's header: the waves of a workgroup share their buckets)
+#endif
+template <int CDIM, int W, int TPW>
 __global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GS_BWD_MFMA_WPE)))
 raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
     static_assert(CDIM == 27 || CDIM == 48, "SH colours only");
@@ -1234,62 +1247,92 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
     constexpr int RW = gs_row_floats(CDIM);
     constexpr uint32_t GS_NO_SLOT = 0xffffffffu;
     typedef float f4 __attribute__((ext_vector_type(4)));
-    __shared__ float s_sh[256 * P];                                  // [pixel 16 y + x][k], entries k >= NB are zero
-    __shared__ __attribute__((aligned(16))) float s_f[3][256];      // final colour of the pixel
-    __shared__ __attribute__((aligned(16))) float s_gr[3][256];     // dL/dC (masked: crop, clamp)
-    __shared__ float s_py[16];
-    __shared__ __attribute__((aligned(16))) float s_T[W][256];      // per wave: transmittance / rho in front of the current group
+    __shared__ float s_sh[TPW][256 * P];                                 // [pixel 16 y + x][k], entries k >= NB are zero
+    __shared__ __attribute__((aligned(16))) float s_gr[TPW][3][256];    // dL/dC (masked: crop, clamp)
+    __shared__ float s_py[TPW][16];
+    __shared__ __attribute__((aligned(16))) float s_T[W][256];          // per wave: transmittance / rho in front of the current group
     __shared__ __attribute__((aligned(16))) float s_rho[W][256];
     auto lds_order = [] {
         asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
     };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t tile = blockIdx.x;
-    const uint32_t nproc = I.tile_nproc[tile];
-    if (nproc == 0) return;  // uniform: nothing of this tile was composited
-    const uint32_t start = (uint32_t)I.ranges[2 * tile];
-    const uint32_t tx = tile % (uint32_t)G.ntx, ty = tile / (uint32_t)G.ntx;
+    // One workgroup per tile walks the tile's buckets W at a time: a tile of 14 buckets holds its workgroup four times as
+    // long as the average one, so the workgroups are dealt in the forward's dispatch order -- the tiles in descending
+    // order of what they cost in the previous frame of this workspace (raster_fwd.hip) -- where the frame has one.
+    const uint32_t n_tiles = (uint32_t)(G.ntx * G.nty);
+    const uint32_t tile0 = (TPW == 1 && I.tile_order) ? I.tile_order[blockIdx.x] : blockIdx.x * TPW;
+    // the workgroup's TPW consecutive tiles: their buckets form ONE work list that the W waves share (a tile has 4.3
+    // buckets on average at 2.4 M Gaussians: alone it keeps four waves busy 68 % of the time, two tiles together 85 %)
+    uint32_t nbk[TPW], nproc_t[TPW], total_bk = 0;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        nproc_t[t] = tile0 + t < n_tiles ? I.tile_nproc[tile0 + t] : 0;
+        nbk[t] = (nproc_t[t] + GS_BUCKET - 1) / GS_BUCKET;
+        total_bk += nbk[t];
+    }
+    if (total_bk == 0) return;  // uniform: nothing of these tiles was composited
     constexpr float KS = -GS_LOG2E;  // the table holds sh'_k = -log2(e) sh_k (raster_common.h)
 
-    // ---- per tile: SH table, dL/dC, final colours, pixel-row centres
-    for (int p = tid; p < 256; p += 64 * W) {
+    // ---- per tile: SH table, dL/dC, pixel-row centres
+    for (int q = tid; q < 256 * TPW; q += 64 * W) {
+        const int t = q >> 8, p = q & 255;
+        if (nbk[t] == 0) continue;
+        const uint32_t tile = tile0 + t, tx = tile % (uint32_t)G.ntx, ty = tile / (uint32_t)G.ntx;
         const uint32_t id_x = tx * 16 + (p & 15), id_y = ty * 16 + (p >> 4);
         float sh[NB];
         raster_pixel_sh<NB>(id_x, id_y, G, sh);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) s_sh[p * P + k] = k < NB ? KS * sh[k < NB ? k : 0] : 0.f;
+        for (int k = 0; k < 16; ++k) s_sh[t][p * P + k] = k < NB ? KS * sh[k < NB ? k : 0] : 0.f;
         float f[3], gr[3];
         load_pixel_inputs<true>(I, G, id_x, id_y, f, gr);
 #pragma unroll
-        for (int e = 0; e < 3; ++e) {
-            s_f[e][p] = f[e];
-            s_gr[e][p] = gr[e];
-        }
+        for (int e = 0; e < 3; ++e) s_gr[t][e][p] = gr[e];
     }
-    if (tid < 16) s_py[tid] = raster_pixel_coord(ty * 16 + tid, G.padH, G.focal_y);
+    if (tid < 16 * TPW) {
+        const uint32_t tile = tile0 + (tid >> 4);
+        s_py[tid >> 4][tid & 15] = raster_pixel_coord((tile / (uint32_t)G.ntx) * 16 + (tid & 15), G.padH, G.focal_y);
+    }
     __syncthreads();
 
     const uint32_t gq = (uint32_t)lane & 15u, jq = (uint32_t)lane >> 4;  // Gaussian of the group, pixel quad
-    float px[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) px[i] = raster_pixel_coord(tx * 16 + 4 * jq + i, G.padW, G.focal_x);
     float *sT = s_T[wave], *sR = s_rho[wave];
-    const uint32_t nbk = (nproc + GS_BUCKET - 1) / GS_BUCKET;
-    for (uint32_t b = wave; b < nbk; b += W) {
+    for (uint32_t u = wave; u < total_bk; u += W) {
+        int t = 0;
+        uint32_t b = u;
+#pragma unroll
+        for (int k = 0; k + 1 < TPW; ++k)
+            if (t == k && b >= nbk[k]) {
+                b -= nbk[k];
+                t = k + 1;
+            }
+        const uint32_t tile = tile0 + t, nproc = nproc_t[t];
+        const uint32_t tx = tile % (uint32_t)G.ntx, ty = tile / (uint32_t)G.ntx;
+        const uint32_t start = (uint32_t)I.ranges[2 * tile];
+        const float *tab = s_sh[t], *gr0 = s_gr[t][0], *gr1 = s_gr[t][1], *gr2 = s_gr[t][2], *pyt = s_py[t];
         const uint32_t base = b * GS_BUCKET, rem = nproc - base, r = rem < GS_BUCKET ? rem : GS_BUCKET;
+        // the bucket's 64 Gaussian ids, one per lane: a group learns its ids from a lane exchange instead of a load that
+        // everything else of the group's set-up would wait for
+        const uint32_t id_lane = S.ids[start + base + ((uint32_t)lane < r ? (uint32_t)lane : r - 1)];
         // ---- pixel states at the bucket's boundary: the forward's checkpoint ((1, 0) in front of the tile's first bucket)
         {
             const float4 *ck = I.ckpt + raster_ckpt_slot(start, tile, b) * 256;
             float4 c[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) c[k] = b == 0 ? make_float4(1.f, 0.f, 0.f, 0.f) : ck[64 * k + lane];
+            float f[4][3];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int p = 64 * k + lane;  // == 16 y + x of pixel (x = lane & 15, y = (lane >> 4) + 4 k)
+                c[k] = b == 0 ? make_float4(1.f, 0.f, 0.f, 0.f) : ck[64 * k + lane];
+                // pixel (x = lane & 15, y = (lane >> 4) + 4 k) == index 64 k + lane of the tile
+                const float *cf = I.c_final + ((size_t)(ty * 16 + (lane >> 4) + 4 * k) * G.padW + tx * 16 + (lane & 15)) * 3;
+                f[k][0] = cf[0];
+                f[k][1] = cf[1];
+                f[k][2] = cf[2];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int p = 64 * k + lane;
                 sT[p] = c[k].x;
-                sR[p] = s_gr[0][p] * (s_f[0][p] - c[k].y) + s_gr[1][p] * (s_f[1][p] - c[k].z) +
-                        s_gr[2][p] * (s_f[2][p] - c[k].w);
+                sR[p] = gr0[p] * (f[k][0] - c[k].y) + gr1[p] * (f[k][1] - c[k].z) + gr2[p] * (f[k][2] - c[k].w);
             }
         }
         lds_order();
@@ -1298,22 +1341,40 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
             // ---- this lane's Gaussian (entries beyond r re-read the bucket's last one with opacity 0: alpha = 0)
             const uint32_t gi = grp * 16 + gq;
             const bool valid = gi < r;
+            const uint32_t gid = (uint32_t)__shfl((int)id_lane, (int)(valid ? gi : r - 1), 64);
             GaussianRec g;
-            const uint32_t gid = raster_load<true>(S, start + base + (valid ? gi : r - 1), g);
+            {
+                const float4 ge = S.geom[(size_t)gid * GS_REC_STRIDE], cv = S.cov4[(size_t)gid * GS_REC_STRIDE];
+                g.x = ge.x;
+                g.y = ge.y;
+                g.opa = ge.w;
+                g.a = cv.x;
+                g.b = cv.y;
+                g.c = cv.z;
+                g.d = cv.w;
+            }
+            const float *cf = S.sh + (size_t)gid * CDIM;
+            float cob[3][KQ];  // B operand of the colour product: coef[g'][ch][4 kk + jq]
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+                for (int kk = 0; kk < KQ; ++kk) {
+                    const uint32_t k = 4 * kk + jq;
+                    cob[ch][kk] = (4 * kk + 3 < NB || k < (uint32_t)NB) ? cf[ch * NB + (k < (uint32_t)NB ? k : 0)] : 0.f;
+                }
+            // the next group's coefficient rows (192 bytes = three lines per Gaussian at degree 3; 2.4 M of them do not
+            // fit the Infinity Cache) and records are asked for now, one line per lane, and nothing waits for them: by the
+            // time the next group sets up they sit in L2
+            float warm = 0.f;
+            if (grp + 1 < ngrp) {
+                const uint32_t gn = (grp + 1) * 16 + gq;
+                const uint32_t idn = (uint32_t)__shfl((int)id_lane, (int)(gn < r ? gn : r - 1), 64);
+                warm = jq * 16 < (uint32_t)CDIM ? S.sh[(size_t)idn * CDIM + jq * 16]
+                                                : reinterpret_cast<const float *>(S.geom + (size_t)idn * GS_REC_STRIDE)[0];
+            }
             float cA, cB, cC;
             raster_conic(g, cA, cB, cC);
             const float opa = valid ? g.opa : 0.f;
-            float cob[3][KQ];  // B operand of the colour product: coef[g'][ch][4 kk + jq]
-            {
-                const float *cf = S.sh + (size_t)gid * CDIM;
-#pragma unroll
-                for (int ch = 0; ch < 3; ++ch)
-#pragma unroll
-                    for (int kk = 0; kk < KQ; ++kk) {
-                        const uint32_t k = 4 * kk + jq;
-                        cob[ch][kk] = (4 * kk + 3 < NB || k < (uint32_t)NB) ? cf[ch * NB + (k < (uint32_t)NB ? k : 0)] : 0.f;
-                    }
-            }
             uint32_t slot = GS_NO_SLOT;
             if (valid) {
                 const uint4 rc = O.rects[gid];
@@ -1321,31 +1382,63 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
                 const uint64_t sl = (uint64_t)O.pair_offsets[gid] + (ty - y0) * (x1 - x0) + (tx - x0);
                 if (sl < O.max_pairs) slot = (uint32_t)sl;
             }
-            float dx[4], bdx[4], adx2[4];
+            // (what only the group's closing needs -- dx, the covariance, two of the conic's terms -- is recomputed /
+            // re-read there instead of living in registers through the 16 pixel rows: the loop sits at the register
+            // limit of three waves per SIMD)
+            float bdx[4], adx2[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                dx[i] = px[i] - g.x;
-                bdx[i] = cB * dx[i];
-                adx2[i] = cA * dx[i] * dx[i];
+                const float dxi = raster_pixel_coord(tx * 16 + 4 * jq + i, G.padW, G.focal_x) - g.x;
+                bdx[i] = cB * dxi;
+                adx2[i] = cA * dxi * dxi;
             }
+            const float gy = g.y;
             f4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
             float S1[4] = {0.f, 0.f, 0.f, 0.f}, Sy[4] = {0.f, 0.f, 0.f, 0.f}, Syy = 0.f, Sq = 0.f, Sopa = 0.f;
+            // The LDS operands of a pixel row -- the A operands of both products, the row's pixel states and dL/dC -- are
+            // requested one row ahead, behind the row's arithmetic and in front of its twelve coefficient MFMAs (registers
+            // are free there, and the ~100 cycles of LDS latency pass under the MFMAs; asked for where they are used,
+            // every row started and ended with an exposed wait).  GS_BWD_MFMA_PF = 0: loads where they are used.
+            float a_n[KQ], tb_n[4];
+            f4 Tin_n, Rin_n, G0_n, G1_n, G2_n;
+            auto row_loads = [&](int s) {
+                const int prow = 16 * s;
+#pragma unroll
+                for (int kk = 0; kk < KQ; ++kk) a_n[kk] = tab[(prow + (int)gq) * P + 4 * kk + (int)jq];  // l & 15: pixel column
+#pragma unroll
+                for (int i = 0; i < 4; ++i) tb_n[i] = tab[(prow + 4 * (int)jq + i) * P + (int)gq];       // l & 15: basis function
+                Tin_n = *reinterpret_cast<const f4 *>(sT + prow + 4 * jq);
+                Rin_n = *reinterpret_cast<const f4 *>(sR + prow + 4 * jq);
+                G0_n = *reinterpret_cast<const f4 *>(gr0 + prow + 4 * jq);
+                G1_n = *reinterpret_cast<const f4 *>(gr1 + prow + 4 * jq);
+                G2_n = *reinterpret_cast<const f4 *>(gr2 + prow + 4 * jq);
+            };
+            if (GS_BWD_MFMA_PF) row_loads(0);
             for (int s = 0; s < 16; ++s) {  // pixel row s of the tile
                 const int prow = 16 * s;
+                if (!GS_BWD_MFMA_PF) row_loads(s);
+                float a[KQ], tb[4];
+#pragma unroll
+                for (int kk = 0; kk < KQ; ++kk) a[kk] = a_n[kk];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) tb[i] = tb_n[i];
+                const f4 Tin = Tin_n, Rin = Rin_n, G0 = G0_n, G1 = G1_n, G2 = G2_n;
+                // A pixel row whose 16 pixels have all stopped (T <= 1e-4 in front of the group: the transmittance only
+                // falls) adds exact zeros to every sum of every Gaussian of the group and its states need not move: the
+                // row is left out (wave-uniform).  The tile's list ends where its LAST pixel stops, so at 2.4 M Gaussians a
+                // good part of the rows of a tile's later groups are of this kind.
+                if (GS_BWD_MFMA_ROW_SKIP &&
+                    __ballot(Tin[0] > GS_T_STOP || Tin[1] > GS_T_STOP || Tin[2] > GS_T_STOP || Tin[3] > GS_T_STOP) == 0ull) {
+                    if (GS_BWD_MFMA_PF && s + 1 < 16) row_loads(s + 1);
+                    continue;
+                }
                 // colour logits of (pixel 4 jq + reg, Gaussian gq) on the matrix pipe
                 f4 lg[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-                for (int kk = 0; kk < KQ; ++kk) {
-                    const float a = s_sh[(prow + (int)gq) * P + 4 * kk + (int)jq];  // here l & 15 is the pixel column
+                for (int kk = 0; kk < KQ; ++kk)
 #pragma unroll
-                    for (int ch = 0; ch < 3; ++ch) lg[ch] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, cob[ch][kk], lg[ch], 0, 0, 0);
-                }
-                const float dy = s_py[s] - g.y;
-                const f4 Tin = *reinterpret_cast<const f4 *>(sT + prow + 4 * jq);
-                const f4 Rin = *reinterpret_cast<const f4 *>(sR + prow + 4 * jq);
-                const f4 G0 = *reinterpret_cast<const f4 *>(s_gr[0] + prow + 4 * jq);
-                const f4 G1 = *reinterpret_cast<const f4 *>(s_gr[1] + prow + 4 * jq);
-                const f4 G2 = *reinterpret_cast<const f4 *>(s_gr[2] + prow + 4 * jq);
+                    for (int ch = 0; ch < 3; ++ch) lg[ch] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], cob[ch][kk], lg[ch], 0, 0, 0);
+                const float dy = pyt[s] - gy;
                 f4 Tout, Rout;
                 float dv[3][4];
                 float q[4], Gv[4], araw[4], pin[4];
@@ -1396,26 +1489,32 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
                     Rout[i] = rho;
                 }
                 Syy = fmaf(ssum * dy, dy, Syy);
+                if (GS_BWD_MFMA_PF && s + 1 < 16) {
+                    row_loads(s + 1);
+                    __builtin_amdgcn_sched_barrier(0);  // (the requests stay in front of the MFMAs below)
+                }
                 // coefficient sums: acc[ch][reg] += sum over the row's 16 pixels of D[ch] sh'_(4 jq + reg)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float tb = s_sh[(prow + 4 * (int)jq + i) * P + (int)gq];  // here l & 15 is the basis function
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int ch = 0; ch < 3; ++ch) acc[ch] = __builtin_amdgcn_mfma_f32_16x16x4f32(tb, dv[ch][i], acc[ch], 0, 0, 0);
-                }
+                    for (int ch = 0; ch < 3; ++ch) acc[ch] = __builtin_amdgcn_mfma_f32_16x16x4f32(tb[i], dv[ch][i], acc[ch], 0, 0, 0);
                 if (gq == 15) {  // the row's pixel states in front of the next group
                     *reinterpret_cast<f4 *>(sT + prow + 4 * jq) = Tout;
                     *reinterpret_cast<f4 *>(sR + prow + 4 * jq) = Rout;
                 }
             }
+            asm volatile("" ::"v"(warm));  // (the warming load must not be dropped; its value is not used)
             // ---- close the group: the lane's four pixel columns, then the four pixel quads of the Gaussian
+            const uint32_t gid2 = (uint32_t)__shfl((int)id_lane, (int)(valid ? gi : r - 1), 64);
+            const float4 ge2 = S.geom[(size_t)gid2 * GS_REC_STRIDE], cv2 = S.cov4[(size_t)gid2 * GS_REC_STRIDE];
             float Sx = 0.f, Sxx = 0.f, Sxy = 0.f, Syt = 0.f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float sx = S1[i] * dx[i];
+                const float dxi = raster_pixel_coord(tx * 16 + 4 * jq + i, G.padW, G.focal_x) - ge2.x;
+                const float sx = S1[i] * dxi;
                 Sx += sx;
-                Sxx = fmaf(sx, dx[i], Sxx);
-                Sxy = fmaf(Sy[i], dx[i], Sxy);
+                Sxx = fmaf(sx, dxi, Sxx);
+                Sxy = fmaf(Sy[i], dxi, Sxy);
                 Syt += Sy[i];
             }
             auto quad_sum = [](float v) {
@@ -1433,7 +1532,9 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
             if (slot != GS_NO_SLOT) {
                 float *row = O.rows + (size_t)slot * RW;
                 if (jq == 0) {
-                    const float a = g.a, bb = g.b, cc = g.c, d = g.d;
+                    const float a = cv2.x, bb = cv2.y, cc = cv2.z, d = cv2.w;
+                    float cA, cB, cC;
+                    gs_conic(a, bb, cc, d, cA, cB, cC);
                     const float iPn = 1.0f / (2.0f * raster_det(a, bb, cc, d) + 1e-14f);
                     const float Su = Sq * GS_LN2;
                     const float ogx = GS_LN2 * (2.0f * cA * Sx - cB * Syt), ogy = GS_LN2 * (2.0f * cC * Syt - cB * Sx);
@@ -1482,10 +1583,11 @@ void launch_bwd(const RasterSrc &S, const RasterGeom &G, const BwdIn &I, const B
                 hipStream_t stream) {
     constexpr int WPB = BwdCfg<CDIM>::WPB;
     const int grid = (int)gs_div_up(max_buckets > 0 ? max_buckets : 1, WPB);
-    if constexpr (FRAME && CDIM > 3 && GS_BWD_SH_MFMA) {
-        // one workgroup per tile (tiles nothing was composited in leave at once)
-        hipLaunchKernelGGL((raster_backward_mfma_sh_kernel<CDIM, GS_BWD_MFMA_WAVES>), dim3((unsigned)(G.ntx * G.nty)),
-                           dim3(64 * GS_BWD_MFMA_WAVES), 0, stream, S, G, I, O);
+    if constexpr (FRAME && ((CDIM == 48 && GS_BWD_SH_MFMA >= 1) || (CDIM == 27 && GS_BWD_SH_MFMA >= 2))) {
+        // one workgroup per GS_BWD_MFMA_TILES tiles (tiles nothing was composited in leave at once)
+        hipLaunchKernelGGL((raster_backward_mfma_sh_kernel<CDIM, GS_BWD_MFMA_WAVES, GS_BWD_MFMA_TILES>),
+                           dim3((unsigned)gs_div_up(G.ntx * G.nty, GS_BWD_MFMA_TILES)), dim3(64 * GS_BWD_MFMA_WAVES), 0,
+                           stream, S, G, I, O);
         return;
     }
     if (CDIM == 3 && !GS_BWD_PACKED_RGB) {
@@ -1652,7 +1754,8 @@ int gs_stage_raster_backward(const gs_frame *f, const gs_frame_ws &ws, const uin
         const int rc = gs_stage_backward_prepare(f, ws, sorted_ids, stream);
         if (rc) return rc;
     }
-    BwdIn I = {f->image_padded, grad_image, ws.ckpt, ws.tile_nproc, ws.bucket_offsets, ws.bucket_info, ws.tile_ranges};
+    BwdIn I = {f->image_padded, grad_image, ws.ckpt, ws.tile_nproc, ws.bucket_offsets, ws.bucket_info, ws.tile_ranges,
+               (gs_frame_uses_strips(f) && f->N > 0 && GS_BWD_MFMA_ORDER) ? ws.tile_order : nullptr};
     BwdOut O = {ws.rows, ws.row_flags, ws.pair_offsets, ws.rects, (uint64_t)f->max_pairs, nullptr, nullptr, nullptr, nullptr};
     if (f->color_dim == 48)
         launch_bwd<48, true>(S, G, I, O, ws.max_buckets, stream);

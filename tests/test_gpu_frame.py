@@ -388,6 +388,26 @@ def test_frame_backward_parity(gpu, use_sh):
     assert float(np.abs(params[0].grad.cpu().numpy()[culled]).max()) == 0.0
 
 
+@pytest.mark.parametrize("sh_degree", [2, 3])
+def test_frame_backward_sh_deep_saturating_tiles(gpu, sh_degree):
+    """The SH backward on the matrix pipe (raster_bwd.hip: raster_backward_mfma_sh_kernel) where its structure shows: tiles
+    several 64-Gaussian buckets deep (checkpoints, four waves sharing a tile), ragged last buckets and groups of 16,
+    opaque Gaussians so that pixels -- and whole pixel rows, which the kernel then leaves out -- stop inside the list."""
+    scene, cam = case(14_000, 96, 64, seed=5, use_sh=True, sh_degree=sh_degree)
+    scene.opa += 1.5
+    of, r, _ = check_forward(gpu, scene, cam, training=True)
+    assert np.diff(of.accum).max() > 300  # several buckets per tile
+    rng = np.random.default_rng(8)
+    gimg = rng.normal(size=of.image.shape).astype(np.float32)
+    gimg, _ = of.robust_grad_image(gimg)
+    ref, scale = of.backward(gimg, with_scale=True)
+    params = to_torch(scene, gpu, requires_grad=True)
+    r2 = FrameRenderer(gpu, max_pairs=len(of.ids) + 5, training=True, auto_grow=False)
+    img = r2.render(*params, cam)
+    img.backward(torch.from_numpy(gimg).to(gpu))
+    assert_grads_close([t.grad.cpu().numpy() for t in params], ref, scale, f"deep tiles, degree {sh_degree}")
+
+
 def test_frame_backward_screen_filling_gaussians(gpu):
     """Gaussians that touch more than 256 tiles have their per-pair gradient rows summed by the whole workgroup
     (cull_project.hip, deterministic tree) instead of by one thread: parity with the oracle for a scene that mixes a

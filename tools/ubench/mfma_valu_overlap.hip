@@ -9,6 +9,7 @@
 //   seq       8 MFMAs, then 128 v_fma_f32            (one after the other in program order)
 //   mix       8 x (1 MFMA + 16 v_fma_f32)            (interleaved in program order)
 //   exp, rcp, dpp   32 v_exp_f32 / 32 v_rcp_f32 / 32 v_add_f32_dpp row_shr
+//   bf16      8 independent v_mfma_f32_16x16x32_bf16;  bfmix / bfseq: the same with 128 v_fma_f32 interleaved / behind
 // at 1, 2, 3 and 4 waves per SIMD.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -19,9 +20,10 @@ constexpr int ITERS = 4096;
 #define F8(a) "v_fma_f32 %" #a ", %" #a ", %10, %11\n\t"
 #define FMA8 F8(12) F8(13) F8(14) F8(15) F8(16) F8(17) F8(18) F8(19)
 #define FMA16 FMA8 FMA8
+#define MB(i) "v_mfma_f32_16x16x32_bf16 %" #i ", %20, %21, %" #i "\n\t"
 #define OPS                                                                                                       \
     : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7])              \
-    : "v"(a), "v"(b), "v"(m), "v"(c), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7])
+    : "v"(a), "v"(b), "v"(m), "v"(c), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(ha), "v"(hb)
 
 template <int MODE>
 __global__ void __launch_bounds__(64) k(float *out, float s) {
@@ -33,12 +35,23 @@ __global__ void __launch_bounds__(64) k(float *out, float s) {
         x[i] = s * (lane + i);
     }
     float a = s * lane, b = s + lane, m = 0.999f, c = 1e-7f * s;
+    typedef short h8 __attribute__((ext_vector_type(8)));
+    h8 ha, hb;
+    for (int i = 0; i < 8; ++i) {
+        ha[i] = (short)(0x3f80 + lane + i);  // bf16 bit patterns near 1.0
+        hb[i] = (short)(0x3c00 + i);
+    }
     for (int it = 0; it < ITERS; ++it) {
         if (MODE == 0) asm volatile(MF(0) MF(1) MF(2) MF(3) MF(4) MF(5) MF(6) MF(7) OPS);
         if (MODE == 1) asm volatile(FMA16 FMA16 FMA16 FMA16 FMA16 FMA16 FMA16 FMA16 OPS);
         if (MODE == 2) asm volatile(MF(0) MF(1) MF(2) MF(3) MF(4) MF(5) MF(6) MF(7) FMA16 FMA16 FMA16 FMA16 FMA16 FMA16 FMA16 FMA16 OPS);
         if (MODE == 3)
             asm volatile(MF(0) FMA16 MF(1) FMA16 MF(2) FMA16 MF(3) FMA16 MF(4) FMA16 MF(5) FMA16 MF(6) FMA16 MF(7) FMA16 OPS);
+        if (MODE == 7) asm volatile(MB(0) MB(1) MB(2) MB(3) MB(4) MB(5) MB(6) MB(7) OPS);
+        if (MODE == 8)
+            asm volatile(MB(0) FMA16 MB(1) FMA16 MB(2) FMA16 MB(3) FMA16 MB(4) FMA16 MB(5) FMA16 MB(6) FMA16 MB(7) FMA16 OPS);
+        if (MODE == 9)
+            asm volatile(MB(0) MB(1) MB(2) MB(3) MB(4) MB(5) MB(6) MB(7) FMA16 FMA16 FMA16 FMA16 FMA16 FMA16 FMA16 FMA16 OPS);
         if (MODE == 4) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -100,5 +113,8 @@ int main() {
     run<4>("exp", out);
     run<5>("rcp", out);
     run<6>("dpp", out);
+    run<7>("bf16", out);
+    run<8>("bfmix", out);
+    run<9>("bfseq", out);
     return 0;
 }
