@@ -665,6 +665,9 @@ __global__ void __launch_bounds__(BIN_THREADS) frame_project_bin_count_kernel(
 #ifndef GS_PB_DIRECT
 #define GS_PB_DIRECT 2  // A/B switch (tools/ab_variants.py): how the rgb rows are fetched, see below
 #endif
+#ifndef GS_PB_SH_U
+#define GS_PB_SH_U 8  // A/B switch: row loads the SH walk keeps in flight
+#endif
 template <int CDIM, int PART = 0, int BLOCK = (CDIM == 3 ? 256 : 128)>
 __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
     const float *__restrict__ pos, const float4 *__restrict__ quat, const float *__restrict__ scale,
@@ -1055,7 +1058,7 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
                 }
                 wave_sync();
                 const uint32_t nb = total - e0 < 64 ? total - e0 : 64u;
-                constexpr uint32_t U = 8;
+                constexpr uint32_t U = GS_PB_SH_U;  // row loads in flight per wave
                 for (uint32_t e = 0; e < nb; e += U) {
                     float v[U];
                     uint32_t own[U];

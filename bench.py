@@ -652,8 +652,18 @@ def main():
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), **kw}
 
                 tj = traffic4.get(f"cfg4_deg{deg}", {})
-                tk = tj.get("raster_backward_pixel_sh_kernel", {}) if tj.get("tile_pairs") == M4 else {}
+                # round 4: the SH backward of the frame path runs on the matrix pipe (raster_backward_mfma_sh_kernel);
+                # a traffic.json recorded before that still carries the pixel-parallel kernel's entry
+                bwd_kernel = "raster_backward_mfma_sh_kernel" if "raster_backward_mfma_sh_kernel" in tj \
+                    else "raster_backward_pixel_sh_kernel"
+                tk = tj.get(bwd_kernel, {}) if tj.get("tile_pairs") == M4 else {}
                 tr_bw, busy_bw = tk.get("traffic_bytes"), tk.get("issue_busy")
+                # its fp32 MFMAs: per 16 Gaussians x 16 pixels 3 x ceil(NB / 4) (colour logits) + 12 (coefficient sums)
+                # v_mfma_f32_16x16x4_f32 of 2,048 flops each, i.e. per composited (Gaussian, tile) step 1 / 16 of
+                # that x 16 pixel rows; the matrix pipe's fp32 peak equals the vector peak (157.3 TFLOP/s) and on gfx950
+                # an MFMA does not overlap the VALU stream of its SIMD (tools/ubench/mfma_valu_overlap.hip)
+                steps4 = r4.composited_steps()
+                mfma_flops = steps4 * (3 * -(-(C4 // 3) // 4) + 12) * 2048
                 cfg4[f"sh_degree_{deg}"] = {
                     "coefficients": C4, "visible": V4, "tile_pairs": M4,
                     "forward_ms": round(f_ms, 3), "backward_ms": round(b_ms, 3),
@@ -668,9 +678,14 @@ def main():
                     "roofline_forward": roof(b_fwd, f_ms), "roofline_backward": roof(b_bwd, b_ms),
                     "roofline_fwd_bwd": roof(b_fwd + b_bwd, f_ms + b_ms),
                     "roofline_raster_backward_kernel": roof(
-                        b_rbw, rb_ms, kernel=f"raster_backward_pixel_sh_kernel<{C4}>", traffic=tr_bw,
+                        b_rbw, rb_ms, kernel=f"raster_backward_mfma_sh_kernel<{C4}>", traffic=tr_bw,
                         traffic_frac=None if tr_bw is None else round(tr_bw / (rb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                        issue_busy=busy_bw)}
+                        issue_busy=busy_bw, composited_steps=steps4,
+                        mfma={"bound": "mfma", "flops": int(mfma_flops),
+                              "achieved": round(mfma_flops / (rb_ms * 1e-3) / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s",
+                              "frac": round(mfma_flops / (rb_ms * 1e-3) / 1e12 / 157.3, 4),
+                              "what": "fp32 MFMA flops of the kernel / its time; MFMAs and VALU instructions of a SIMD "
+                                      "do not overlap on gfx950, so this fraction and issue_busy share the same cycles"})}
                 del r4, p4, img4, g4
                 torch.cuda.empty_cache()
             extra["cfg4_2p4M_sh_fwd_bwd"] = cfg4

@@ -30,6 +30,7 @@ FETCH_FACTOR = {
                                              "pair offsets are gathered (x1); SH coefficients are contiguous 108 / 192-B "
                                              "runs per Gaussian (between the two)"),
     "raster_backward_pixel_kernel": (1.5, "as raster_backward_pixel_sh_kernel"),
+    "raster_backward_mfma_sh_kernel": (1.5, "as raster_backward_pixel_sh_kernel (round 4: the SH backward of the frame path)"),
     "raster_backward_kernel": (1.5, "as raster_backward_pixel_sh_kernel"),
     "frame_project_backward_kernel": (1.5, "mixed: rectangles, offsets and raw parameters stream (x2), gradient rows are "
                                            "isolated 64-byte lines (rgb, x1) or 144 / 224-byte runs (SH)"),
