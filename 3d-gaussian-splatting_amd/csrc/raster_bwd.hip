@@ -1717,8 +1717,12 @@ int gs_stage_backward_prepare(const gs_frame *f, const gs_frame_ws &ws, const ui
         hipLaunchKernelGGL(stop_key_kernel, dim3((unsigned)gs_div_up(FG.n_tiles, 256)), dim3(256), 0, stream,
                            ws.tile_nproc, FG.n_tiles, ws.tile_ranges, sorted_ids, ws.rects,
                            (unsigned long long *)ws.stop_keys);
-    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, ws.tile_nproc, FG.n_tiles,
-                       ws.bucket_offsets, ws.counters + GS_CNT_BUCKETS, ws.bucket_info, ws.tile_ranges, 1);
+    // the bucket work list is what the one-wave-per-bucket kernels read; the SH backward on the matrix pipe walks a
+    // tile's buckets itself (one workgroup per tile) and needs none
+    const bool per_tile = (f->color_dim == 48 && GS_BWD_SH_MFMA >= 1) || (f->color_dim == 27 && GS_BWD_SH_MFMA >= 2);
+    if (!per_tile)
+        hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, ws.tile_nproc, FG.n_tiles,
+                           ws.bucket_offsets, ws.counters + GS_CNT_BUCKETS, ws.bucket_info, ws.tile_ranges, 1);
     GS_CHECK_LAUNCH();
     return 0;
 }
