@@ -1394,7 +1394,7 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
             }
             const float gy = g.y;
             f4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-            float S1[4] = {0.f, 0.f, 0.f, 0.f}, Sy[4] = {0.f, 0.f, 0.f, 0.f}, Syy = 0.f, Sq = 0.f, Sopa = 0.f;
+            float S1[4] = {0.f, 0.f, 0.f, 0.f}, Sy[4] = {0.f, 0.f, 0.f, 0.f}, Syy = 0.f, Sq = 0.f;
             // The LDS operands of a pixel row -- the A operands of both products, the row's pixel states and dL/dC -- are
             // requested one row ahead, behind the row's arithmetic and in front of its twelve coefficient MFMAs (registers
             // are free there, and the ~100 cycles of LDS latency pass under the MFMAs; asked for where they are used,
@@ -1447,7 +1447,9 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
                     q[i] = fmaf(fmaf(cC, dy, -bdx[i]), dy, adx2[i]);
                     Gv[i] = gs_exp2(-q[i]);
                     araw[i] = Gv[i] * opa;
-                    pin[i] = fmaxf(1.0f - araw[i], 0.f);
+                    // (0 <= 1 - alpha <= 1 holds anyway for sane records; written as a clamp to [0, 1] it is the clamp
+                    // modifier of the subtraction, one instruction -- and a NaN / > 1 alpha of a broken record stops the pixel)
+                    pin[i] = fminf(fmaxf(1.0f - araw[i], 0.f), 1.0f);
                 }
                 // transmittance in front of this Gaussian: T_in times the product over the group's earlier Gaussians
                 gs_row_scan_mul4(pin);
@@ -1476,11 +1478,11 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
                     float d_alpha = fmaf(Tb[i], gc[i], -(rho * rc));
                     d_alpha = live[i] ? d_alpha : 0.f;
                     // D = dL/dC_ch w c (1 - c) [x -ln 2: D sh' = D' sh]
-                    constexpr float K = -GS_LN2;
-                    dv[0][i] = G0[i] * w[i] * (cc[0][i] * fmaf(cc[0][i], -K, K));
-                    dv[1][i] = G1[i] * w[i] * (cc[1][i] * fmaf(cc[1][i], -K, K));
-                    dv[2][i] = G2[i] * w[i] * (cc[2][i] * fmaf(cc[2][i], -K, K));
-                    Sopa = fmaf(d_alpha, Gv[i], Sopa);
+                    const float wk = w[i] * -GS_LN2;
+                    dv[0][i] = (G0[i] * wk) * fmaf(-cc[0][i], cc[0][i], cc[0][i]);
+                    dv[1][i] = (G1[i] * wk) * fmaf(-cc[1][i], cc[1][i], cc[1][i]);
+                    dv[2][i] = (G2[i] * wk) * fmaf(-cc[2][i], cc[2][i], cc[2][i]);
+                    // (the opacity sum, sum of dL/dalpha G over the live pixels, is sum of s / opacity: at the group's end)
                     const float sv = d_alpha * alpha[i];
                     S1[i] += sv;
                     Sy[i] = fmaf(sv, dy, Sy[i]);
@@ -1508,6 +1510,9 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
             const uint32_t gid2 = (uint32_t)__shfl((int)id_lane, (int)(valid ? gi : r - 1), 64);
             const float4 ge2 = S.geom[(size_t)gid2 * GS_REC_STRIDE], cv2 = S.cov4[(size_t)gid2 * GS_REC_STRIDE];
             float Sx = 0.f, Sxx = 0.f, Sxy = 0.f, Syt = 0.f;
+            // s = dL/dalpha alpha and alpha = G sigma(opa) on every live pixel: sum dL/dalpha G = (sum s) / sigma(opa).  (An
+            // opacity that underflowed to 0 composites nothing; its derivative sigma (1 - sigma) downstream is 0 as well.)
+            float Sopa = ((S1[0] + S1[1]) + (S1[2] + S1[3])) * (ge2.w > 0.f ? gs_rcp(ge2.w) : 0.f);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float dxi = raster_pixel_coord(tx * 16 + 4 * jq + i, G.padW, G.focal_x) - ge2.x;
