@@ -497,3 +497,16 @@ extern "C" int gs_frame_debug_views(const gs_frame *f, const uint64_t **sorted_k
     if (tiles_touched) *tiles_touched = ws.tiles_touched;
     return 0;
 }
+
+#ifdef GS_DIAG_CKPT
+// diagnostic builds only (tools/dead_pixel_stats.py with a variant library): the forward's checkpoints
+extern "C" __attribute__((visibility("default"))) int gs_diag_ckpt(const gs_frame *f, const float **ckpt,
+                                                                   int64_t *max_buckets) {
+    int rc = validate(f);
+    if (rc) return rc;
+    gs_frame_ws ws = gs_frame_carve(f->workspace, f->N, f->max_pairs, f->width, f->height, f->color_dim, 1);
+    *ckpt = reinterpret_cast<const float *>(ws.ckpt);
+    *max_buckets = ws.max_buckets;
+    return 0;
+}
+#endif

@@ -1242,7 +1242,11 @@ __global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GS_
 raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
     static_assert(CDIM == 27 || CDIM == 48, "SH colours only");
     constexpr int NB = CDIM / 3;          // basis functions per channel: 9 | 16
-    constexpr int KQ = (NB + 3) / 4;      // k blocks of four of the colour product: 3 | 4
+    constexpr int KQ = NB / 4;            // k blocks of four of the colour product on the matrix pipe: 2 | 4
+    // degree 2 has nine basis functions: the ninth would cost a third, three-quarters empty MFMA per channel (14 ns each);
+    // it enters the logits as the MFMAs' initial accumulator instead, sh'_8(pixel) coef[ch][8]: 12 multiplications
+    constexpr bool TAIL = NB % 4 != 0;
+    static_assert(!TAIL || NB == 4 * KQ + 1, "one basis function beside the blocks of four");
     constexpr int P = 17;                 // floats per pixel in the SH table (16 + 1: both operand patterns nearly conflict-free)
     constexpr int RW = gs_row_floats(CDIM);
     constexpr uint32_t GS_NO_SLOT = 0xffffffffu;
@@ -1250,6 +1254,7 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
     __shared__ float s_sh[TPW][256 * P];                                 // [pixel 16 y + x][k], entries k >= NB are zero
     __shared__ __attribute__((aligned(16))) float s_gr[TPW][3][256];    // dL/dC (masked: crop, clamp)
     __shared__ float s_py[TPW][16];
+    __shared__ __attribute__((aligned(16))) float s_sh8[TAIL ? TPW : 1][TAIL ? 256 : 4];  // sh'_(NB - 1) of the pixel
     __shared__ __attribute__((aligned(16))) float s_T[W][256];          // per wave: transmittance / rho in front of the current group
     __shared__ __attribute__((aligned(16))) float s_rho[W][256];
     auto lds_order = [] {
@@ -1284,6 +1289,7 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
         raster_pixel_sh<NB>(id_x, id_y, G, sh);
 #pragma unroll
         for (int k = 0; k < 16; ++k) s_sh[t][p * P + k] = k < NB ? KS * sh[k < NB ? k : 0] : 0.f;
+        if (TAIL) s_sh8[t][p] = KS * sh[NB - 1];
         float f[3], gr[3];
         load_pixel_inputs<true>(I, G, id_x, id_y, f, gr);
 #pragma unroll
@@ -1310,6 +1316,7 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
         const uint32_t tx = tile % (uint32_t)G.ntx, ty = tile / (uint32_t)G.ntx;
         const uint32_t start = (uint32_t)I.ranges[2 * tile];
         const float *tab = s_sh[t], *gr0 = s_gr[t][0], *gr1 = s_gr[t][1], *gr2 = s_gr[t][2], *pyt = s_py[t];
+        const float *tab8 = s_sh8[TAIL ? t : 0];
         const uint32_t base = b * GS_BUCKET, rem = nproc - base, r = rem < GS_BUCKET ? rem : GS_BUCKET;
         // the bucket's 64 Gaussian ids, one per lane: a group learns its ids from a lane exchange instead of a load that
         // everything else of the group's set-up would wait for
@@ -1362,6 +1369,11 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
                     const uint32_t k = 4 * kk + jq;
                     cob[ch][kk] = (4 * kk + 3 < NB || k < (uint32_t)NB) ? cf[ch * NB + (k < (uint32_t)NB ? k : 0)] : 0.f;
                 }
+            float ctail[3] = {0.f, 0.f, 0.f};
+            if (TAIL) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) ctail[ch] = cf[ch * NB + NB - 1];
+            }
             // the next group's coefficient rows (192 bytes = three lines per Gaussian at degree 3; 2.4 M of them do not
             // fit the Infinity Cache) and records are asked for now, one line per lane, and nothing waits for them: by the
             // time the next group sets up they sit in L2
@@ -1400,7 +1412,7 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
             // are free there, and the ~100 cycles of LDS latency pass under the MFMAs; asked for where they are used,
             // every row started and ended with an exposed wait).  GS_BWD_MFMA_PF = 0: loads where they are used.
             float a_n[KQ], tb_n[4];
-            f4 Tin_n, Rin_n, G0_n, G1_n, G2_n;
+            f4 Tin_n, Rin_n, G0_n, G1_n, G2_n, S8_n = {0.f, 0.f, 0.f, 0.f};
             auto row_loads = [&](int s) {
                 const int prow = 16 * s;
 #pragma unroll
@@ -1412,6 +1424,7 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
                 G0_n = *reinterpret_cast<const f4 *>(gr0 + prow + 4 * jq);
                 G1_n = *reinterpret_cast<const f4 *>(gr1 + prow + 4 * jq);
                 G2_n = *reinterpret_cast<const f4 *>(gr2 + prow + 4 * jq);
+                if (TAIL) S8_n = *reinterpret_cast<const f4 *>(tab8 + prow + 4 * jq);
             };
             if (GS_BWD_MFMA_PF) row_loads(0);
             for (int s = 0; s < 16; ++s) {  // pixel row s of the tile
@@ -1422,7 +1435,7 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
                 for (int kk = 0; kk < KQ; ++kk) a[kk] = a_n[kk];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) tb[i] = tb_n[i];
-                const f4 Tin = Tin_n, Rin = Rin_n, G0 = G0_n, G1 = G1_n, G2 = G2_n;
+                const f4 Tin = Tin_n, Rin = Rin_n, G0 = G0_n, G1 = G1_n, G2 = G2_n, S8 = S8_n;
                 // A pixel row whose 16 pixels have all stopped (T <= 1e-4 in front of the group: the transmittance only
                 // falls) adds exact zeros to every sum of every Gaussian of the group and its states need not move: the
                 // row is left out (wave-uniform).  The tile's list ends where its LAST pixel stops, so at 2.4 M Gaussians a
@@ -1434,6 +1447,10 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
                 }
                 // colour logits of (pixel 4 jq + reg, Gaussian gq) on the matrix pipe
                 f4 lg[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                if (TAIL) {
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) lg[ch] = S8 * ctail[ch];
+                }
 #pragma unroll
                 for (int kk = 0; kk < KQ; ++kk)
 #pragma unroll
