@@ -658,12 +658,13 @@ def main():
                     else "raster_backward_pixel_sh_kernel"
                 tk = tj.get(bwd_kernel, {}) if tj.get("tile_pairs") == M4 else {}
                 tr_bw, busy_bw = tk.get("traffic_bytes"), tk.get("issue_busy")
-                # its fp32 MFMAs: per 16 Gaussians x 16 pixels 3 x ceil(NB / 4) (colour logits) + 12 (coefficient sums)
+                # its fp32 MFMAs: per 16 Gaussians x 16 pixels 3 x floor(NB / 4) (colour logits; degree 2's ninth basis
+                # function is added on the VALU) + 12 (coefficient sums)
                 # v_mfma_f32_16x16x4_f32 of 2,048 flops each, i.e. per composited (Gaussian, tile) step 1 / 16 of
                 # that x 16 pixel rows; the matrix pipe's fp32 peak equals the vector peak (157.3 TFLOP/s) and on gfx950
                 # an MFMA does not overlap the VALU stream of its SIMD (tools/ubench/mfma_valu_overlap.hip)
                 steps4 = r4.composited_steps()
-                mfma_flops = steps4 * (3 * -(-(C4 // 3) // 4) + 12) * 2048
+                mfma_flops = steps4 * (3 * ((C4 // 3) // 4) + 12) * 2048
                 cfg4[f"sh_degree_{deg}"] = {
                     "coefficients": C4, "visible": V4, "tile_pairs": M4,
                     "forward_ms": round(f_ms, 3), "backward_ms": round(b_ms, 3),
