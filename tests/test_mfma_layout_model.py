@@ -1,0 +1,141 @@
+"""CPU tier: the index algebra of the SH backward on the matrix pipe (raster_bwd.hip: raster_backward_mfma_sh_kernel), run as a
+NumPy model of the wave's 64 lanes against the plain per-pixel recursion it replaces.
+
+The kernel rests on three layout facts that no compiler checks: (1) with lane l = (Gaussian l & 15, pixel quad l >> 4) the
+fp32 MFMA v_mfma_f32_16x16x4_f32 (A[l & 15][l >> 4], B[l >> 4][l & 15], D[4 (l >> 4) + reg][l & 15]: cdna_hip_programming.md)
+puts the colour logit of (Gaussian, pixel 4 (l >> 4) + reg) into register `reg` of exactly that lane; (2) the same lanes'
+registers, fed back as B with the SH table read transposed as A, accumulate dL/dcoef[g][4 (l >> 4) + reg] over the pixel
+quads, the quad's pixels and the pixel rows with no cross-lane reduction; (3) the transmittance / rho recursions over the
+16 Gaussians of a group are an exclusive product / inclusive sum over the 16 lanes of a DPP row, with UNMASKED alphas in
+the product and the reference's stop (gaussian.cu:906) as a mask.  The model below performs exactly the kernel's lane-level
+steps for one group of 16 Gaussians on one 16 x 16 tile and is compared with the sequential front-to-back loop."""
+import numpy as np
+
+T_STOP = np.float32(1e-4)
+
+
+def mfma_16x16x4(a, b, c):
+    """D = A B + C in the lane layout of v_mfma_f32_16x16x4_f32: a, b [64]; c [64][4] (lane, register)."""
+    A = np.zeros((16, 4))
+    B = np.zeros((4, 16))
+    for l in range(64):
+        A[l & 15, l >> 4] = a[l]
+        B[l >> 4, l & 15] = b[l]
+    D = A @ B
+    out = c.copy()
+    for l in range(64):
+        for r in range(4):
+            out[l, r] += D[4 * (l >> 4) + r, l & 15]
+    return out
+
+
+def row_scan(v, op, identity):
+    """Inclusive scan over the 16 lanes of every DPP row (row_shr 1, 2, 4, 8; lanes outside the row keep the identity)."""
+    v = v.copy()
+    for sh in (1, 2, 4, 8):
+        src = np.full_like(v, identity)
+        for l in range(64):
+            if (l & 15) >= sh:
+                src[l] = v[l - sh]
+        v = op(v, src)
+    return v
+
+
+def test_lane_model_equals_the_sequential_recursion():
+    rng = np.random.default_rng(5)
+    NB = 16
+    sh = rng.normal(size=(256, NB))                       # sh'_k of pixel 16 y + x
+    coef = rng.normal(size=(16, 3, NB)) * 0.5             # the group's 16 Gaussians
+    G = rng.normal(size=(3, 256))                         # dL/dC per pixel
+    alpha_raw = rng.uniform(0.0, 0.9, size=(16, 256))     # G(pixel) sigma(opa) of (Gaussian, pixel)
+    alpha_raw[5] = rng.uniform(0.95, 0.999, size=256)     # an opaque one: pixels stop inside the group
+    gv = rng.uniform(0.1, 1.0, size=(16, 256))            # stands for the Gaussian's value (weights the opacity sum)
+    T_in = rng.uniform(0.0, 1.0, size=256)
+    T_in[::7] = 5e-5                                       # pixels that had stopped before the group
+    T_in[32:48] = 5e-5                                     # ... and a whole pixel row of them
+    rho_in = rng.normal(size=256)
+
+    # ---- reference: pixel by pixel, front to back
+    dcoef_ref = np.zeros((16, 3, NB))
+    s_ref = np.zeros((16, 256))
+    T_ref, rho_ref = T_in.copy(), rho_in.copy()
+    for p in range(256):
+        T, rho = T_in[p], rho_in[p]
+        for g in range(16):
+            live = T > T_STOP
+            a = alpha_raw[g, p] if live else 0.0
+            w = a * T
+            c = 1.0 / (1.0 + np.exp2(coef[g] @ sh[p]))     # [3]; the table is pre-scaled: sigma(x) = 1 / (1 + 2^x')
+            gc = float(G[:, p] @ c)
+            rho = rho - w * gc
+            d_alpha = (T * gc - rho / (1.0 - alpha_raw[g, p] + 1e-7)) if live else 0.0
+            s_ref[g, p] = d_alpha * a
+            dcoef_ref[g] += (G[:, p] * w * c * (1.0 - c))[:, None] * sh[p][None, :]
+            T = T - w
+        T_ref[p], rho_ref[p] = T, rho
+
+    # ---- the kernel's lanes: lane l = (Gaussian gq = l & 15, pixel quad jq = l >> 4), pixel row s per step
+    lanes = np.arange(64)
+    gq, jq = lanes & 15, lanes >> 4
+    acc = np.zeros((3, 64, 4))                             # MFMA accumulators of the coefficient sums
+    s_model = np.zeros((16, 256))
+    T_state, rho_state = T_in.copy(), rho_in.copy()
+    for s in range(16):
+        prow = 16 * s
+        # colour logits: A = sh'_(4 kk + jq)(pixel prow + (l & 15)), B = coef[gq][ch][4 kk + jq]
+        lg = np.zeros((3, 64, 4))
+        for kk in range(NB // 4):
+            a_op = sh[prow + (lanes & 15), 4 * kk + jq]
+            for ch in range(3):
+                lg[ch] = mfma_16x16x4(a_op, coef[gq, ch, 4 * kk + jq], lg[ch])
+        dv = np.zeros((3, 64, 4))
+        Tout = np.zeros((64, 4))
+        Rout = np.zeros((64, 4))
+        for i in range(4):
+            pix = prow + 4 * jq + i                       # this lane's pixel i
+            araw = alpha_raw[gq, pix]
+            pin = row_scan(np.clip(1.0 - araw, 0.0, 1.0), np.multiply, 1.0)
+            pex = np.ones(64)
+            pex[gq > 0] = pin[lanes[gq > 0] - 1]          # row_shr:1 with 1.0 in lane 0 of the row
+            Tb = T_state[pix] * pex
+            live = Tb > T_STOP
+            alpha = np.where(live, araw, 0.0)
+            w = alpha * Tb
+            c = 1.0 / (1.0 + np.exp2(lg[:, lanes, i]))    # [3][64]: register i of the lane
+            # (1): the logit in register i of lane (gq, jq) is that of (Gaussian gq, pixel 4 jq + i)
+            assert np.allclose(lg[:, lanes, i], np.einsum("lck,lk->cl", coef[gq], sh[pix]), atol=1e-12)
+            gc = (G[:, pix] * c).sum(0)
+            rho = rho_state[pix] - row_scan(w * gc, np.add, 0.0)
+            d_alpha = np.where(live, Tb * gc - rho / (1.0 - araw + 1e-7), 0.0)
+            s_model[gq, pix] = d_alpha * alpha
+            dv[:, :, i] = G[:, pix] * w * c * (1.0 - c)
+            Tout[:, i] = T_state[pix] * pin
+            Rout[:, i] = rho
+        # coefficient sums: A' = sh'_(l & 15)(pixel prow + 4 jq + i), B' = register i of the lane
+        for i in range(4):
+            tb = sh[prow + 4 * jq + i, lanes & 15]
+            for ch in range(3):
+                acc[ch] = mfma_16x16x4(tb, dv[ch, :, i], acc[ch])
+        for l in lanes[gq == 15]:                          # the lanes of Gaussian 15 carry the row's states on
+            for i in range(4):
+                T_state[prow + 4 * (l >> 4) + i] = Tout[l, i]
+                rho_state[prow + 4 * (l >> 4) + i] = Rout[l, i]
+
+    # (2): lane (gq, jq) register r holds dL/dcoef[gq][ch][4 jq + r]
+    dcoef_model = np.zeros((16, 3, NB))
+    for l in range(64):
+        for r in range(4):
+            dcoef_model[l & 15, :, 4 * (l >> 4) + r] = acc[:, l, r]
+    assert np.allclose(dcoef_model, dcoef_ref, rtol=1e-10, atol=1e-12)
+    assert np.allclose(s_model, s_ref, rtol=1e-10, atol=1e-12)
+    assert np.allclose(rho_state, rho_ref, rtol=1e-10, atol=1e-12)
+    # (3): the carried transmittance is the UNMASKED product: equal to the recursion's while the pixel lives, and at most
+    # the stop threshold -- like the recursion's frozen value -- once it has stopped
+    alive = T_ref > T_STOP
+    assert np.allclose(T_state[alive], T_ref[alive], rtol=1e-10)
+    assert np.all(T_state[~alive] <= T_STOP) and np.all(T_ref[~alive] <= T_STOP)
+    # a pixel row whose 16 pixels had all stopped contributes exact zeros (the kernel leaves such rows out)
+    dead_rows = [s for s in range(16) if np.all(T_in[16 * s:16 * s + 16] <= T_STOP)]
+    assert dead_rows == [2]
+    for s in dead_rows:
+        assert np.all(s_model[:, 16 * s:16 * s + 16] == 0.0)
