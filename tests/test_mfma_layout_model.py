@@ -49,7 +49,6 @@ def test_lane_model_equals_the_sequential_recursion():
     G = rng.normal(size=(3, 256))                         # dL/dC per pixel
     alpha_raw = rng.uniform(0.0, 0.9, size=(16, 256))     # G(pixel) sigma(opa) of (Gaussian, pixel)
     alpha_raw[5] = rng.uniform(0.95, 0.999, size=256)     # an opaque one: pixels stop inside the group
-    gv = rng.uniform(0.1, 1.0, size=(16, 256))            # stands for the Gaussian's value (weights the opacity sum)
     T_in = rng.uniform(0.0, 1.0, size=256)
     T_in[::7] = 5e-5                                       # pixels that had stopped before the group
     T_in[32:48] = 5e-5                                     # ... and a whole pixel row of them
