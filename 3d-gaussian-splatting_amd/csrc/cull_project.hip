@@ -665,6 +665,9 @@ __global__ void __launch_bounds__(BIN_THREADS) frame_project_bin_count_kernel(
 #ifndef GS_PB_DIRECT
 #define GS_PB_DIRECT 2  // A/B switch (tools/ab_variants.py): how the rgb rows are fetched, see below
 #endif
+#ifndef GS_PB_SH_PASSES
+#define GS_PB_SH_PASSES 2  // A/B switch: the SH row walk in this many passes over 64 / PASSES owners each (LDS per wave)
+#endif
 #ifndef GS_PB_SH_U
 #define GS_PB_SH_U 8  // A/B switch: row loads the SH walk keeps in flight
 #endif
@@ -716,7 +719,7 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
     const uint64_t off = vis ? pair_offsets[pid] : 0, cnt = rc.w;
     // SH: the column sums of every Gaussian's rows, [Gaussian of the workgroup][row float] with an odd stride
     constexpr int RWF = 4 * RW4, RS = RWF + 1;
-    __shared__ float s_sum[CDIM > 3 ? BLOCK * RS : 1];
+    __shared__ float s_sum[CDIM > 3 ? BLOCK / GS_PB_SH_PASSES * RS : 1];
     __shared__ uint32_t s_brow[CDIM > 3 ? BLOCK / 64 : 1][64], s_bown[CDIM > 3 ? BLOCK / 64 : 1][64];
 
     // the stop keys as two arrays of T words: depth bits, Gaussian index (stop_key_kernel)
@@ -1000,8 +1003,12 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
         // Gaussians with thousands of rows need no special path any more: the wave works through them at one row per
         // instruction.
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        float *wsum = s_sum + (size_t)wv * 64 * RS;
-        for (int i = lane; i < 64 * RS; i += 64) wsum[i] = 0.f;
+        // The walk runs GS_PB_SH_PASSES times, each over the rows of 64 / PASSES owners (lanes [OWN pass, OWN (pass + 1))): the
+        // column sums need [OWN][RS] floats of LDS per wave instead of [64][RS] -- 30 KiB per workgroup at degree 3 left 10 of
+        // the CU's 32 wave slots filled, and the walk is bound by the latency of its row loads, i.e. by how many waves wait
+        // at once.  Every owner's rows are still added in ascending order from zero: bitwise the same sums.
+        constexpr int OWN = 64 / GS_PB_SH_PASSES;
+        float *wsum = s_sum + (size_t)wv * OWN * RS;
         const uint64_t nrow = off + cnt < max_pairs ? cnt : (max_pairs > off ? max_pairs - off : 0);
         uint32_t maxrows = (uint32_t)(nrow < 0xffffffffull ? nrow : 0xffffffffull);
 #pragma unroll
@@ -1010,15 +1017,20 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
             maxrows = x > maxrows ? x : maxrows;
         }
         const float *rowf = reinterpret_cast<const float *>(rows);
-        float acc = 0.f;
-        int cur = -1;  // owner whose sums `acc` holds (wave-uniform)
         auto wave_sync = [] {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         };
+        for (int pass = 0; pass < GS_PB_SH_PASSES; ++pass) {
+        const int own0 = pass * OWN;
+        const bool mine_pass = lane >= own0 && lane < own0 + OWN;
+        for (int i = lane; i < OWN * RS; i += 64) wsum[i] = 0.f;
+        wave_sync();
+        float acc = 0.f;
+        int cur = -1;  // owner whose sums `acc` holds (wave-uniform)
         for (uint32_t k0 = 0; k0 < maxrows; k0 += 64) {  // windows of 64 rows per owner (uniform trip count)
             unsigned long long written = 0;
-            if (k0 < nrow) {
+            if (k0 < nrow && mine_pass) {
                 const uint32_t m = nrow - k0 < 64 ? (uint32_t)(nrow - k0) : 64u;
                 // flag bytes [off + k0, off + k0 + m) lie in the words [w0, w1] of the (256-byte aligned, padded) flag array
                 const uint64_t b0 = off + k0;
@@ -1073,9 +1085,9 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
                     for (uint32_t u = 0; u < U; ++u) {
                         if (e + u >= nb) break;  // uniform
                         if ((int)own[u] != cur) {  // uniform
-                            if (cur >= 0 && lane < RWF) wsum[cur * RS + lane] = acc;
+                            if (cur >= 0 && lane < RWF) wsum[(cur - own0) * RS + lane] = acc;
                             cur = (int)own[u];
-                            acc = lane < RWF ? wsum[cur * RS + lane] : 0.f;
+                            acc = lane < RWF ? wsum[(cur - own0) * RS + lane] : 0.f;
                         }
                         acc += v[u];
                     }
@@ -1083,21 +1095,25 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
                 wave_sync();  // the batch arrays are rewritten next
             }
         }
-        if (cur >= 0 && lane < RWF) wsum[cur * RS + lane] = acc;
+        if (cur >= 0 && lane < RWF) wsum[(cur - own0) * RS + lane] = acc;
         wave_sync();
-        const float *t = wsum + lane * RS;  // this thread's Gaussian: (dx, dy, da, db | dc, dd, dopa, coefficient 0 | ...)
-        d0 = make_float4(t[0], t[1], t[2], t[3]);
-        d1 = make_float4(t[4], t[5], t[6], t[7]);
+        if (mine_pass) {
+            const float *t = wsum + (lane - own0) * RS;  // this thread's Gaussian: (dx, dy, da, db | dc, dd, dopa, coefficient 0 | ...)
+            d0 = make_float4(t[0], t[1], t[2], t[3]);
+            d1 = make_float4(t[4], t[5], t[6], t[7]);
+        }
         if (PART != 1) {
-            // coefficient gradients: CDIM consecutive floats per Gaussian in grad_rgb, 64 Gaussians per wave -- written
+            // coefficient gradients: CDIM consecutive floats per Gaussian in grad_rgb, the pass's OWN Gaussians -- written
             // by the wave as one contiguous run (a culled Gaussian's sums are the zeros the array started with)
-            const int64_t g0w = pid0 + (int64_t)wv * 64;
-            const int ng = n - g0w < 64 ? (int)(n - g0w) : 64;  // Gaussians of this wave inside the array (may be <= 0)
+            const int64_t g0w = pid0 + (int64_t)wv * 64 + own0;
+            const int ng = n - g0w < OWN ? (int)(n - g0w) : OWN;  // Gaussians of this pass inside the array (may be <= 0)
             float *dst = grad_rgb + g0w * CDIM;
             for (int e = lane; e < ng * CDIM; e += 64) {
                 const int gl = e / CDIM, c = e - gl * CDIM;
                 dst[e] = wsum[gl * RS + 7 + c];
             }
+        }
+        wave_sync();  // (the next pass clears the sums)
         }
     }
     if (!valid) return;
