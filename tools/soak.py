@@ -1,5 +1,7 @@
 """Soak test: a long render loop and a long training run with densification on the reference's schedule;
-checks that results stay finite, memory does not creep and nothing stalls.  Prints one JSON object."""
+checks that results stay finite, memory does not creep and nothing stalls.  Prints one JSON object.
+
+    python tools/soak.py [render frames] [training iterations] [SH degree: 0 (rgb logits, default) | 2 | 3]"""
 import json
 import sys
 import time
@@ -17,7 +19,9 @@ dev = torch.device('cuda:0')
 W, H = 1920, 1080
 out = {}
 # ---- render: 3 frames in flight, changing cameras
-scene = make_scene(376_467, W, H, seed=2023)
+sh_degree = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+scene = make_scene(376_467, W, H, seed=2023, use_sh=sh_degree > 0, sh_degree=sh_degree if sh_degree else 2)
+out["sh_degree"] = sh_degree
 params = [torch.from_numpy(a).to(dev) for a in (scene.pos, scene.quat, scene.scale, scene.opa, scene.rgb)]
 cams = [make_camera(W, H, yaw_deg=float(y)) for y in np.linspace(-10, 10, 9)]
 rs = [FrameRenderer(dev, max_pairs=1 << 21, auto_grow="async") for _ in range(3)]
@@ -32,8 +36,9 @@ for k in range(n_frames):
         last = rs[k % 3].forward(*params, cams[k % len(cams)])[0]
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-out["render"] = {"frames": n_frames, "fps": round(n_frames / dt, 1), "finite": bool(torch.isfinite(last).all()),
-                 "memory_growth_MiB": round((torch.cuda.memory_allocated() - m0) / 2**20, 1)}
+if n_frames:
+    out["render"] = {"frames": n_frames, "fps": round(n_frames / dt, 1), "finite": bool(torch.isfinite(last).all()),
+                     "memory_growth_MiB": round((torch.cuda.memory_allocated() - m0) / 2**20, 1)}
 del rs, last
 # ---- training with densification every 100 iterations (train.py schedule), 16 cameras
 n_iters = int(sys.argv[2]) if len(sys.argv) > 2 else 6000
