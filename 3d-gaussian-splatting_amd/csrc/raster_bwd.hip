@@ -126,6 +126,9 @@ struct BwdIn {
     const uint4 *bucket_info;        // [n_buckets] (tile, first Gaussian, count, start of the tile's list)
     const int32_t *ranges;           // FRAME: [T][2]; REF: accum [T+1]
     const uint32_t *tile_order;      // FRAME, optional: the tiles in descending order of their cost (one workgroup per tile)
+    // Long lists (frames flagged GS_FRAME_LONG_LISTS): the per-tile SH kernel takes the first bucket_cap buckets of a tile
+    // (0: all of them), the one-wave-per-bucket kernel the buckets from bucket_first on (see launch_bwd)
+    uint32_t bucket_cap, bucket_first;
 };
 
 // Inputs of one pixel for the backward kernels: final colour, and dL/dC -- for the frame path the gradient of
@@ -790,6 +793,7 @@ raster_backward_pixel_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
     const uint4 info = I.bucket_info[kb];  // in bounds for every launched wave (the table is padded)
     if (kb >= I.bucket_offsets[n_tiles]) return;
     const uint32_t tile = info.x, base = info.y, r = info.z, start = info.w;
+    if (base < I.bucket_first * GS_BUCKET) return;  // (uniform) a bucket the per-tile SH kernel has taken: launch_bwd
     const uint32_t tx = tile % (uint32_t)G.ntx, ty = tile / (uint32_t)G.ntx;
 
     // ---- this lane's Gaussian (lanes >= r re-read the bucket's last one and are zeroed below)
@@ -1274,6 +1278,7 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
     for (int t = 0; t < TPW; ++t) {
         nproc_t[t] = tile0 + t < n_tiles ? I.tile_nproc[tile0 + t] : 0;
         nbk[t] = (nproc_t[t] + GS_BUCKET - 1) / GS_BUCKET;
+        if (I.bucket_cap && nbk[t] > I.bucket_cap) nbk[t] = I.bucket_cap;  // the rest: one wave per bucket (launch_bwd)
         total_bk += nbk[t];
     }
     if (total_bk == 0) return;  // uniform: nothing of these tiles was composited
@@ -1610,6 +1615,16 @@ void launch_bwd(const RasterSrc &S, const RasterGeom &G, const BwdIn &I, const B
         hipLaunchKernelGGL((raster_backward_mfma_sh_kernel<CDIM, GS_BWD_MFMA_WAVES, GS_BWD_MFMA_TILES>),
                            dim3((unsigned)gs_div_up(G.ntx * G.nty, GS_BWD_MFMA_TILES)), dim3(64 * GS_BWD_MFMA_WAVES), 0,
                            stream, S, G, I, O);
+        // A workgroup walks its tile's buckets four at a time: a 100,000-Gaussian pile in one tile (a degenerate
+        // densification run) would keep ONE workgroup busy for 26 ms.  Frames the caller has flagged for long lists
+        // (GS_FRAME_LONG_LISTS, as for the forward's long-list kernels) leave a tile's buckets beyond the first 32 -- the
+        // part of a list beyond the forward's own 2,048 -- to the one-wave-per-bucket kernel: spread over the device.
+        if (I.bucket_first) {
+            BwdIn I2 = I;
+            I2.bucket_cap = 0;
+            hipLaunchKernelGGL((raster_backward_pixel_sh_kernel<CDIM, FRAME>),
+                               dim3((unsigned)(max_buckets > 0 ? max_buckets : 1)), dim3(64), 0, stream, S, G, I2, O);
+        }
         return;
     }
     if (CDIM == 3 && !GS_BWD_PACKED_RGB) {
@@ -1741,7 +1756,8 @@ int gs_stage_backward_prepare(const gs_frame *f, const gs_frame_ws &ws, const ui
                            (unsigned long long *)ws.stop_keys);
     // the bucket work list is what the one-wave-per-bucket kernels read; the SH backward on the matrix pipe walks a
     // tile's buckets itself (one workgroup per tile) and needs none
-    const bool per_tile = (f->color_dim == 48 && GS_BWD_SH_MFMA >= 1) || (f->color_dim == 27 && GS_BWD_SH_MFMA >= 2);
+    const bool per_tile = ((f->color_dim == 48 && GS_BWD_SH_MFMA >= 1) || (f->color_dim == 27 && GS_BWD_SH_MFMA >= 2)) &&
+                          !gs_frame_long_lists(f, FG.n_tiles);  // (flagged frames: the buckets beyond a tile's first 32)
     if (!per_tile)
         hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, ws.tile_nproc, FG.n_tiles,
                            ws.bucket_offsets, ws.counters + GS_CNT_BUCKETS, ws.bucket_info, ws.tile_ranges, 1);
@@ -1781,7 +1797,8 @@ int gs_stage_raster_backward(const gs_frame *f, const gs_frame_ws &ws, const uin
         if (rc) return rc;
     }
     BwdIn I = {f->image_padded, grad_image, ws.ckpt, ws.tile_nproc, ws.bucket_offsets, ws.bucket_info, ws.tile_ranges,
-               (gs_frame_uses_strips(f) && f->N > 0 && GS_BWD_MFMA_ORDER) ? ws.tile_order : nullptr};
+               (gs_frame_uses_strips(f) && f->N > 0 && GS_BWD_MFMA_ORDER) ? ws.tile_order : nullptr, 0, 0};
+    if (f->color_dim != 3 && gs_frame_long_lists(f, FG.n_tiles)) I.bucket_cap = I.bucket_first = GS_LONG_MIN / GS_BUCKET;
     BwdOut O = {ws.rows, ws.row_flags, ws.pair_offsets, ws.rects, (uint64_t)f->max_pairs, nullptr, nullptr, nullptr, nullptr};
     if (f->color_dim == 48)
         launch_bwd<48, true>(S, G, I, O, ws.max_buckets, stream);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A pathological pile-up: cfg2's scene plus PILE low-opacity Gaussians inside one tile (what a degenerate densification
 run produces, tools/soak.py 1000 12000).  Forward stage times with the segmented compositing / big-list sort of dense
-frames and with the serial walk (GS_FRAME_SERIAL_LONG_LISTS):  python tools/long_list.py [pile=100000]"""
+frames and with the serial walk (GS_FRAME_SERIAL_LONG_LISTS):  python tools/long_list.py [pile=100000] [SH degree 0 | 2 | 3]"""
 import os
 import sys
 
@@ -16,7 +16,8 @@ from gs_scene import CONFIGS, make_camera, make_scene
 dev = torch.device("cuda:0")
 pile = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
 n, W, H, _ = CONFIGS["cfg2"]
-scene = make_scene(n + pile, W, H, seed=2023)
+sh = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+scene = make_scene(n + pile, W, H, seed=2023, use_sh=sh > 0, sh_degree=sh if sh else 2)
 cam = make_camera(W, H)
 rng = np.random.default_rng(1)
 idx = np.arange(n, n + pile)
@@ -25,8 +26,8 @@ scene.pos[idx] = centre + rng.normal(scale=0.002, size=(pile, 3)).astype(np.floa
 scene.scale[idx] = np.float32(0.002)
 scene.opa[idx] = -7.0
 params = [torch.from_numpy(a).to(dev) for a in (scene.pos, scene.quat, scene.scale, scene.opa, scene.rgb)]
-for training in (False, True):
-    for serial in (False, True):
+for training in ((True,) if sh else (False, True)):
+    for serial in ((False,) if sh else (False, True)):
         r = FrameRenderer(dev, max_pairs=1 << 20, training=training, auto_grow=True, serial_long_lists=serial,
                           long_lists=True)
         r.forward(*params, cam)
