@@ -662,6 +662,83 @@ __global__ void __launch_bounds__(BIN_THREADS) frame_project_bin_count_kernel(
 // "geometry" bucket of the view-parallel gradient exchange); 2 = only grad_opa and grad_rgb (the "colour" bucket).
 // Parts 1 and 2 read the same rows and add them in the same order as part 0: their outputs are bit-identical to it.
 // They exist so that the all-reduce of the first bucket can run underneath the second kernel (gs_dp.py).
+// SH rows of Gaussians that cover hundreds of tiles.  The projection backward's wave walks the rows of its 64 Gaussians one
+// row per load instruction; a Gaussian with thousands of rows (a blown-up scale, a background blob: every densifying run
+// has a few) kept ONE wave walking for a millisecond while the rest of the device had finished -- 1.04 of the 2.9 ms of a
+// training iteration in the SH soak of round 4 (376 k Gaussians, profiles/r04_zn_*).  This kernel runs once per backward,
+// right behind the raster backward: a workgroup scans its slice of the rectangles, and for every Gaussian with more than
+// GS_PB_SH_BIG rows its sixteen waves add a sixteenth of the Gaussian's existing rows each (ascending, lane c = float c),
+// the partial sums are added in a fixed order and the TOTAL replaces the first row of the Gaussian's region.  The
+// projection backward then treats such a Gaussian as having that one row (whatever its flag says), in every part and
+// slice.  Deterministic: fixed partition, fixed order.
+#ifndef GS_PB_SH_BIG
+#define GS_PB_SH_BIG 256
+#endif
+template <int CDIM>
+__global__ void __launch_bounds__(1024) sh_big_rows_kernel(const uint4 *__restrict__ rects,
+                                                          const uint32_t *__restrict__ pair_offsets,
+                                                          float *__restrict__ rows, const uint8_t *__restrict__ row_flags,
+                                                          int64_t n, uint64_t max_pairs, int64_t per_block) {
+    constexpr int RWF = gs_row_floats(CDIM), WAVES = 16;
+    static_assert(RWF <= 64, "a row is read by one wave instruction");
+    __shared__ uint8_t s_big[1024];
+    __shared__ float s_part[WAVES][RWF];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t g_begin = (int64_t)blockIdx.x * per_block;
+    const int64_t g_end = g_begin + per_block < n ? g_begin + per_block : n;
+    for (int64_t b0 = g_begin; b0 < g_end; b0 += 1024) {  // (uniform trip count)
+        const int64_t i = b0 + threadIdx.x;
+        const uint4 rc = i < g_end ? rects[i] : make_uint4(0, 0, 0, 0);
+        const bool big = rc.z != 0 && rc.w > (uint32_t)GS_PB_SH_BIG;
+        if (!__syncthreads_or(big)) continue;  // nearly every batch
+        s_big[threadIdx.x] = big ? 1 : 0;
+        __syncthreads();
+        for (int j = 0; j < 1024; ++j) {
+            if (!s_big[j]) continue;  // uniform
+            const int64_t g = b0 + j;
+            const uint64_t off = pair_offsets[g];
+            uint64_t cnt = rects[g].w;
+            if (off >= max_pairs) cnt = 0;
+            else if (off + cnt > max_pairs) cnt = max_pairs - off;
+            const uint32_t chunk = (uint32_t)((cnt + WAVES - 1) / WAVES);
+            const uint32_t k1 = (uint32_t)((uint64_t)(wv + 1) * chunk < cnt ? (uint64_t)(wv + 1) * chunk : cnt);
+            float acc = 0.f;
+            for (uint32_t k = (uint32_t)wv * chunk; k < k1; k += 64) {
+                const uint32_t kk = k + (uint32_t)lane;
+                unsigned long long m = __ballot(kk < k1 && row_flags[off + kk] != 0);
+                while (m) {  // the window's existing rows in ascending order, eight loads in flight
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        v[u] = 0.f;
+                        if (m) {
+                            const uint32_t r = (uint32_t)__ffsll((long long)m) - 1;
+                            m &= m - 1;
+                            if (lane < RWF) v[u] = rows[(off + k + r) * RWF + lane];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc += v[u];
+                }
+            }
+            if (lane < RWF) s_part[wv][lane] = acc;
+            __syncthreads();  // every wave has read its rows (the first row among them) and left its partial sums
+            if (threadIdx.x < (unsigned)RWF && cnt) {
+                const int c = threadIdx.x;
+                float t[WAVES];
+#pragma unroll
+                for (int w = 0; w < WAVES; ++w) t[w] = s_part[w][c];
+#pragma unroll
+                for (int st = 1; st < WAVES; st <<= 1)  // fixed pairwise tree
+#pragma unroll
+                    for (int w = 0; w < WAVES; w += 2 * st) t[w] += t[w + st];
+                rows[off * RWF + c] = t[0];
+            }
+            __syncthreads();
+        }
+    }
+}
+
 #ifndef GS_PB_DIRECT
 #define GS_PB_DIRECT 2  // A/B switch (tools/ab_variants.py): how the rgb rows are fetched, see below
 #endif
@@ -1009,7 +1086,10 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
         // at once.  Every owner's rows are still added in ascending order from zero: bitwise the same sums.
         constexpr int OWN = 64 / GS_PB_SH_PASSES;
         float *wsum = s_sum + (size_t)wv * OWN * RS;
-        const uint64_t nrow = off + cnt < max_pairs ? cnt : (max_pairs > off ? max_pairs - off : 0);
+        // (a Gaussian beyond GS_PB_SH_BIG rows: its first row holds the total of all of them, sh_big_rows_kernel)
+        const bool big_sh = cnt > (uint64_t)GS_PB_SH_BIG;
+        const uint64_t nrow_all = off + cnt < max_pairs ? cnt : (max_pairs > off ? max_pairs - off : 0);
+        const uint64_t nrow = big_sh ? (nrow_all ? 1 : 0) : nrow_all;
         uint32_t maxrows = (uint32_t)(nrow < 0xffffffffull ? nrow : 0xffffffffull);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -1030,7 +1110,9 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
         int cur = -1;  // owner whose sums `acc` holds (wave-uniform)
         for (uint32_t k0 = 0; k0 < maxrows; k0 += 64) {  // windows of 64 rows per owner (uniform trip count)
             unsigned long long written = 0;
-            if (k0 < nrow && mine_pass) {
+            if (k0 < nrow && mine_pass && big_sh) {
+                written = 1ull;
+            } else if (k0 < nrow && mine_pass) {
                 const uint32_t m = nrow - k0 < 64 ? (uint32_t)(nrow - k0) : 64u;
                 // flag bytes [off + k0, off + k0 + m) lie in the words [w0, w1] of the (256-byte aligned, padded) flag array
                 const uint64_t b0 = off + k0;
@@ -1354,6 +1436,22 @@ int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t strea
 
 // Gaussians [g_begin, g_end) only (g_begin a multiple of 256; the whole array: 0, N): the view-parallel exchange sums
 // the rows slice by slice, so that a slice's gradients travel while the next slice is summed (gs_dp.py).
+// SH frames, once per backward, behind the raster backward: the rows of Gaussians beyond GS_PB_SH_BIG rows are summed
+// by whole workgroups (sh_big_rows_kernel)
+int gs_stage_sh_big_rows(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream) {
+    if (f->color_dim == 3 || f->N <= 0) return 0;
+    const int blocks = 512;
+    const int64_t per_block = gs_div_up(f->N, blocks);  // (the kernel walks its slice 1,024 Gaussians at a time)
+    if (f->color_dim == 48)
+        hipLaunchKernelGGL(sh_big_rows_kernel<48>, dim3(blocks), dim3(1024), 0, stream, ws.rects, ws.pair_offsets, ws.rows,
+                           ws.row_flags, f->N, (uint64_t)f->max_pairs, per_block);
+    else
+        hipLaunchKernelGGL(sh_big_rows_kernel<27>, dim3(blocks), dim3(1024), 0, stream, ws.rects, ws.pair_offsets, ws.rows,
+                           ws.row_flags, f->N, (uint64_t)f->max_pairs, per_block);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
 int gs_stage_project_backward(const gs_frame *f, const gs_frame_ws &ws, float *grad_pos, float *grad_quat,
                               float *grad_scale, float *grad_opa, float *grad_rgb, int part, int64_t g_begin,
                               int64_t g_end, hipStream_t stream) {

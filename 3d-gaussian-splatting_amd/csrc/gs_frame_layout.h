@@ -341,5 +341,6 @@ int gs_stage_tile_sort_gather(const gs_frame *f, const gs_frame_ws &ws, const ui
 int gs_stage_tile_ranges(const gs_frame *f, const gs_frame_ws &ws, const uint64_t *sorted_keys, hipStream_t stream);
 int gs_stage_raster_forward(const gs_frame *f, const gs_frame_ws &ws, const uint32_t *sorted_ids, hipStream_t stream);
 int gs_stage_backward_prepare(const gs_frame *f, const gs_frame_ws &ws, const uint32_t *sorted_ids, hipStream_t stream);
+int gs_stage_sh_big_rows(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream);
 int gs_stage_raster_backward(const gs_frame *f, const gs_frame_ws &ws, const uint32_t *sorted_ids,
                              const float *grad_image, hipStream_t stream, bool prepared);

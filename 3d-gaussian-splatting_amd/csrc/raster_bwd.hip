@@ -1807,5 +1807,6 @@ int gs_stage_raster_backward(const gs_frame *f, const gs_frame_ws &ws, const uin
     else
         launch_bwd<3, true>(S, G, I, O, ws.max_buckets, stream);
     GS_CHECK_LAUNCH();
-    return 0;
+    // SH rows of Gaussians that cover hundreds of tiles are summed here, once, by whole workgroups (cull_project.hip)
+    return gs_stage_sh_big_rows(f, ws, stream);
 }
