@@ -816,7 +816,10 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
     // Such Gaussians are summed by the whole workgroup first -- thread t takes rows t, t + 256, ... straight from
     // global memory (consecutive threads, consecutive rows), a fixed shuffle tree and a fixed wave order give the
     // total to the owning thread: deterministic -- and are skipped by the per-thread loops below.
-    constexpr uint32_t BIG = 256;
+#ifndef GS_PB_BIG
+#define GS_PB_BIG 64  // rows beyond which the whole workgroup sums an rgb Gaussian (A/B switch; at most 256: the row masks)
+#endif
+    constexpr uint32_t BIG = GS_PB_BIG;
     constexpr int NA = 12;  // floats of an rgb row that are summed (10 in use)
     constexpr int NBIG = CDIM == 3 ? 256 : 1;  // (SH rows are summed by the whole wave anyway: below)
     __shared__ uint32_t s_nbig, s_big_owner[NBIG];

@@ -420,9 +420,19 @@ def test_frame_backward_screen_filling_gaussians(gpu):
         scene.pos[big, :2] *= 0.05
         scene.pos[big, 2] = np.linspace(3.0, 8.0, len(big), dtype=np.float32)
         scene.opa[big] = -2.0
+        # ... and a few of 65 - 256 rows: beyond the rgb kernel's threshold for the workgroup's cooperative sum (64 rows since
+        # round 4), below the SH pre-pass's (256), adjacent in the array as clones of a densification step are
+        mid = [1500, 1501, 1503, 2200]
+        scene.scale[mid] = np.float32(3.0) * np.abs(scene.pos[mid, 2:3]) / cam.focal_x * 13 * \
+            np.array([1.0, 0.7, 0.85], np.float32)
+        scene.pos[mid, :2] *= 0.3
+        scene.pos[mid, 2] = np.linspace(4.0, 6.0, len(mid), dtype=np.float32)
+        scene.opa[mid] = -2.5
         of = OracleFrame(scene, cam)
         counts = np.bincount(of.ids, minlength=scene.n)
         assert (counts[big] > 256).all() and counts.max() <= 22 * 17
+        assert (counts[mid] > 64).all() and (counts[mid] <= 256).all(), counts[mid]
+        big = big + mid
         gimg = np.random.default_rng(7).normal(size=of.image.shape).astype(np.float32)
         gimg, _ = of.robust_grad_image(gimg)  # zero on the few pixels whose stop decision is not robust in fp32
         ref, scale = of.backward(gimg, with_scale=True)
