@@ -1148,7 +1148,7 @@ raster_backward_pixel_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
 // rho recursions -- over the 16 Gaussians of a group they are a prefix product / prefix sum across the 16 lanes of a DPP
 // row (row_shr 1, 2, 4, 8) -- and the seven geometry / opacity sums, which accumulate over the pixel rows in registers
 // (dx of a lane's four pixel columns is constant over the rows) and are reduced 4 : 1 once per group.
-// A workgroup = one tile, W waves; wave w takes buckets w, w + W, ...: the SH table (pre-scaled by -log2 e as in the
+// A workgroup = one tile (or half of its buckets: GS_BWD_MFMA_SPLIT), W waves; wave w takes buckets w, w + W, ...: the SH table (pre-scaled by -log2 e as in the
 // kernels above), dL/dC and the final colours are staged once per tile; per wave only the pixels' (T, rho) live in LDS
 // (read as broadcast float4, written back by the lanes of Gaussian 15 after every pixel row).
 // Transmittance: T_before(g') = T_in prod_{h < g'} max(1 - alpha_h, 0) with UNMASKED alphas; a pixel is live while that
@@ -1158,7 +1158,18 @@ raster_backward_pixel_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
 #define GS_BWD_SH_MFMA 2  // 0: never, 1: degree 3 (48 coefficients) only, 2: degree 2 as well (A/B switch, tools/ab_variants.py)
 #endif
 #ifndef GS_BWD_MFMA_WAVES
-#define GS_BWD_MFMA_WAVES 4
+#define GS_BWD_MFMA_WAVES 0  // waves per workgroup: 0 = by the size of the tile grid (below), 2 / 4 = fixed (A/B switch)
+#endif
+// Waves per workgroup, workgroups per tile.  A tile of the 376 k-Gaussian scene has two or three buckets, one of the 2.4 M
+// scene four or five, a dense one dozens.  Four waves per tile left one or two of their register / LDS slots idle for the
+// workgroup's whole life on the short tiles (376 k Gaussians, degree 2: 1.12 ms against 1.00 ms for the pixel-parallel
+// kernel); TWO waves: 1.01 ms there, and no worse at 2.4 M Gaussians (1.44 = 1.44 ms at degree 2, 1.46 against 1.50 ms at
+// degree 3; the kernel's first version had lost 5 % with two).  Only a small tile grid with long lists wants the four (192
+// tiles, 900 pairs each: 0.120 against 0.187 ms): fewer workgroups than the device has slots.  Hence two waves from 1,024
+// tiles on, four below.  Measured and dropped (profiles/r04_zz_*): TWO workgroups of two waves per tile (GS_BWD_MFMA_SPLIT =
+// 2: workgroup h takes buckets 2 h + wave, + 4, ...; the second leaves at once on short tiles): 1.61 / 1.67 ms.
+#ifndef GS_BWD_MFMA_SPLIT
+#define GS_BWD_MFMA_SPLIT 1
 #endif
 #ifndef GS_BWD_MFMA_WPE
 #define GS_BWD_MFMA_WPE 3
@@ -1270,7 +1281,9 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
     // long as the average one, so the workgroups are dealt in the forward's dispatch order -- the tiles in descending
     // order of what they cost in the previous frame of this workspace (raster_fwd.hip) -- where the frame has one.
     const uint32_t n_tiles = (uint32_t)(G.ntx * G.nty);
-    const uint32_t tile0 = (TPW == 1 && I.tile_order) ? I.tile_order[blockIdx.x] : blockIdx.x * TPW;
+    constexpr uint32_t SPLIT = TPW == 1 ? GS_BWD_MFMA_SPLIT : 1;
+    const uint32_t wg = blockIdx.x / SPLIT, part = blockIdx.x % SPLIT;  // workgroup `part` of SPLIT of this tile
+    const uint32_t tile0 = (TPW == 1 && I.tile_order) ? I.tile_order[wg] : wg * TPW;
     // the workgroup's TPW consecutive tiles: their buckets form ONE work list that the W waves share (a tile has 4.3
     // buckets on average at 2.4 M Gaussians: alone it keeps four waves busy 68 % of the time, two tiles together 85 %)
     uint32_t nbk[TPW], nproc_t[TPW], total_bk = 0;
@@ -1281,7 +1294,7 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
         if (I.bucket_cap && nbk[t] > I.bucket_cap) nbk[t] = I.bucket_cap;  // the rest: one wave per bucket (launch_bwd)
         total_bk += nbk[t];
     }
-    if (total_bk == 0) return;  // uniform: nothing of these tiles was composited
+    if (total_bk <= part * W) return;  // uniform: nothing (left) of these tiles for this workgroup
     constexpr float KS = -GS_LOG2E;  // the table holds sh'_k = -log2(e) sh_k (raster_common.h)
 
     // ---- per tile: SH table, dL/dC, pixel-row centres
@@ -1308,7 +1321,7 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
 
     const uint32_t gq = (uint32_t)lane & 15u, jq = (uint32_t)lane >> 4;  // Gaussian of the group, pixel quad
     float *sT = s_T[wave], *sR = s_rho[wave];
-    for (uint32_t u = wave; u < total_bk; u += W) {
+    for (uint32_t u = part * W + wave; u < total_bk; u += W * SPLIT) {
         int t = 0;
         uint32_t b = u;
 #pragma unroll
@@ -1612,9 +1625,15 @@ void launch_bwd(const RasterSrc &S, const RasterGeom &G, const BwdIn &I, const B
     const int grid = (int)gs_div_up(max_buckets > 0 ? max_buckets : 1, WPB);
     if constexpr (FRAME && ((CDIM == 48 && GS_BWD_SH_MFMA >= 1) || (CDIM == 27 && GS_BWD_SH_MFMA >= 2))) {
         // one workgroup per GS_BWD_MFMA_TILES tiles (tiles nothing was composited in leave at once)
-        hipLaunchKernelGGL((raster_backward_mfma_sh_kernel<CDIM, GS_BWD_MFMA_WAVES, GS_BWD_MFMA_TILES>),
-                           dim3((unsigned)gs_div_up(G.ntx * G.nty, GS_BWD_MFMA_TILES)), dim3(64 * GS_BWD_MFMA_WAVES), 0,
-                           stream, S, G, I, O);
+        const unsigned mgrid = (unsigned)(gs_div_up(G.ntx * G.nty, GS_BWD_MFMA_TILES) *
+                                          (GS_BWD_MFMA_TILES == 1 ? GS_BWD_MFMA_SPLIT : 1));
+        const int mwaves = GS_BWD_MFMA_WAVES ? GS_BWD_MFMA_WAVES : (G.ntx * G.nty >= 1024 ? 2 : 4);
+        if (mwaves == 2)
+            hipLaunchKernelGGL((raster_backward_mfma_sh_kernel<CDIM, 2, GS_BWD_MFMA_TILES>), dim3(mgrid), dim3(128), 0,
+                               stream, S, G, I, O);
+        else
+            hipLaunchKernelGGL((raster_backward_mfma_sh_kernel<CDIM, 4, GS_BWD_MFMA_TILES>), dim3(mgrid), dim3(256), 0,
+                               stream, S, G, I, O);
         // A workgroup walks its tile's buckets four at a time: a 100,000-Gaussian pile in one tile (a degenerate
         // densification run) would keep ONE workgroup busy for 26 ms.  Frames the caller has flagged for long lists
         // (GS_FRAME_LONG_LISTS, as for the forward's long-list kernels) leave a tile's buckets beyond the first 32 -- the

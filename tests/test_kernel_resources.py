@@ -88,8 +88,10 @@ BUDGETS = [
     (("raster_backward_pixel_sh_kernelILi48ELb1ELb0E",), 168, True),
     # SH backward on the matrix pipe (round 4): three waves per SIMD; the spills the allocator leaves at that budget sit in
     # the per-tile / per-group set-up, not in the pixel-row loop (checked in the ISA when the kernel was written)
-    (("raster_backward_mfma_sh_kernelILi27E",), 168, True),
-    (("raster_backward_mfma_sh_kernelILi48E",), 168, True),
+    (("raster_backward_mfma_sh_kernelILi27ELi2E",), 168, True),          # two waves per workgroup: 1,024 tiles and more
+    (("raster_backward_mfma_sh_kernelILi48ELi2E",), 168, True),
+    (("raster_backward_mfma_sh_kernelILi27ELi4E",), 168, True),          # four: small tile grids
+    (("raster_backward_mfma_sh_kernelILi48ELi4E",), 168, True),
     (("frame_project_backward_kernelILi3ELi0ELi256E",), 80, False),      # rgb projection backward: six waves per SIMD
     (("frame_project_count_kernelILb0E",), 128, False),                   # 1024 threads per workgroup: 128 is the hard limit
     (("frame_project_bin_count_kernelILb0E",), 128, False),
@@ -119,8 +121,9 @@ def test_lds_budgets(kernels):
     assert bwd[".group_segment_fixed_size"] <= 8192
     pb = pick(kernels, "frame_project_backward_kernelILi3ELi0ELi256E")
     assert pb[".group_segment_fixed_size"] * 6 <= 160 * 1024        # six workgroups of 256 per CU
-    for c in ("27", "48"):  # SH backward on the matrix pipe: three workgroups of four waves per CU (the register limit)
-        assert pick(kernels, f"raster_backward_mfma_sh_kernelILi{c}E")[".group_segment_fixed_size"] * 3 <= 160 * 1024
+    for c in ("27", "48"):  # SH backward on the matrix pipe: twelve waves per CU (the register limit) in workgroups of 2 / 4
+        assert pick(kernels, f"raster_backward_mfma_sh_kernelILi{c}ELi2E")[".group_segment_fixed_size"] * 6 <= 160 * 1024
+        assert pick(kernels, f"raster_backward_mfma_sh_kernelILi{c}ELi4E")[".group_segment_fixed_size"] * 3 <= 160 * 1024
     # SH projection backward: its row walk is bound by load latency -- ten workgroups of two waves per CU at degree 3
     # (the walk runs in two passes over 32 owners each: half the column sums in LDS; one pass left five workgroups)
     assert pick(kernels, "frame_project_backward_kernelILi48ELi0ELi128E")[".group_segment_fixed_size"] * 10 <= 160 * 1024

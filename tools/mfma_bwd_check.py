@@ -5,7 +5,8 @@
     python tools/mfma_bwd_check.py dump <out.npz> <scene>                                        # (one library, one scene)
 
 Scenes: s2 / s3 = 30,000 Gaussians at 512 x 384 with degree-2 / degree-3 SH, d2 / d3 = a dense small scene (every tile
-several buckets deep), cfg4 / cfg4_deg3 = the 2.4 M-Gaussian scene of BASELINE configs[3].  `compare` runs `dump` once per
+several buckets deep), c2 / c2_deg3 = 376,467 Gaussians at 1080p (two or three buckets per tile), cfg4 / cfg4_deg3 = the
+2.4 M-Gaussian scene of BASELINE configs[3].  `compare` runs `dump` once per
 library in fresh processes (GS_AMD_LIB selects the variant) and prints, per gradient tensor, the relative L2 distance,
 the largest difference over the tensor's maximum and the number of non-finite entries, with both builds' stage times.
 Built for the SH backward on the matrix pipe (raster_backward_mfma_sh_kernel); works for any backward variant."""
@@ -22,6 +23,8 @@ SCENES = {  # name: (Gaussians, W, H, SH degree, scale multiplier)
     "s3": (30_000, 512, 384, 3, 1.0),
     "d2": (60_000, 256, 192, 2, 1.0),
     "d3": (60_000, 256, 192, 3, 1.0),
+    "c2": (376_467, 1920, 1080, 2, 1.0),       # BASELINE configs[1]'s size with SH: ~135 pairs per tile, nothing saturates
+    "c2_deg3": (376_467, 1920, 1080, 3, 1.0),
     "cfg4": (2_400_000, 1920, 1080, 2, 1.0),
     "cfg4_deg3": (2_400_000, 1920, 1080, 3, 1.0),
 }
