@@ -672,7 +672,7 @@ __global__ void __launch_bounds__(BIN_THREADS) frame_project_bin_count_kernel(
 // projection backward then treats such a Gaussian as having that one row (whatever its flag says), in every part and
 // slice.  Deterministic: fixed partition, fixed order.
 #ifndef GS_PB_SH_BIG
-#define GS_PB_SH_BIG 256
+#define GS_PB_SH_BIG 64
 #endif
 template <int CDIM>
 __global__ void __launch_bounds__(1024) sh_big_rows_kernel(const uint4 *__restrict__ rects,
