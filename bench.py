@@ -30,8 +30,9 @@ Rank 0 prints ONE JSON line (driver contract):
                        with tools/train_timing.py: the same iterations per block restored from a snapshot, 15 blocks, on the
                        FIXED scene (learning rate 0: the full step runs, the parameters stay put) with the moving-scene
                        figure (the reference's learning rates) next to it --, a 300-iteration fit of the cfg3 scene, cfg4
-                       (2.4 M, SH) forward / backward stage times and the wall clock of the free-running loop, three
-                       frames in flight;
+                       (2.4 M, SH) forward / backward stage times and the wall clock of the free-running loop -- its
+                       `roofline_raster_backward_kernel` also carries `mfma`: the fp32 MFMA flops of the SH backward on
+                       the matrix pipe / its time against the 157.3 TFLOP/s matrix peak --, three frames in flight;
   multi_gpu            (under torchrun, or with --force-collective on one rank) ranks seen, gradient buffer bytes, and per
                        scene (rgb, SH) and exchange mode: training views/s over all ranks, the exchange alone, bus
                        bandwidth, and exposed_ms = the step with its exchange minus the same step without it in the same
