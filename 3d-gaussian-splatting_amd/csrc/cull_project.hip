@@ -669,21 +669,26 @@ __global__ void __launch_bounds__(BIN_THREADS) frame_project_bin_count_kernel(
 // right behind the raster backward: a workgroup scans its slice of the rectangles, and for every Gaussian with more than
 // GS_PB_SH_BIG rows its sixteen waves add a sixteenth of the Gaussian's existing rows each (ascending, lane c = float c),
 // the partial sums are added in a fixed order and the TOTAL replaces the first row of the Gaussian's region.  The
-// projection backward then treats such a Gaussian as having that one row (whatever its flag says), in every part and
-// slice.  Deterministic: fixed partition, fixed order.
+// projection backward then treats such a Gaussian as having that one row (whether or not its own pair was processed), in
+// every part and slice.  Deterministic: fixed partition, fixed order.  Which rows exist: the tiles' stop keys (round 5; a
+// flag byte per row until then), exactly the test of the rgb reader below.
 #ifndef GS_PB_SH_BIG
 #define GS_PB_SH_BIG 64
 #endif
 template <int CDIM>
 __global__ void __launch_bounds__(1024) sh_big_rows_kernel(const uint4 *__restrict__ rects,
                                                           const uint32_t *__restrict__ pair_offsets,
-                                                          float *__restrict__ rows, const uint8_t *__restrict__ row_flags,
+                                                          float *__restrict__ rows,
+                                                          const unsigned long long *__restrict__ stop_keys,
+                                                          const float4 *__restrict__ rec_geom, uint32_t ntx, uint32_t n_tiles,
+                                                          int cull_method, GsDistCull D,
                                                           int64_t n, uint64_t max_pairs, int64_t per_block) {
     constexpr int RWF = gs_row_floats(CDIM), WAVES = 16;
     static_assert(RWF <= 64, "a row is read by one wave instruction");
     __shared__ uint8_t s_big[1024];
     __shared__ float s_part[WAVES][RWF];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t *stop_depth = reinterpret_cast<const uint32_t *>(stop_keys), *stop_id = stop_depth + n_tiles;
     const int64_t g_begin = (int64_t)blockIdx.x * per_block;
     const int64_t g_end = g_begin + per_block < n ? g_begin + per_block : n;
     for (int64_t b0 = g_begin; b0 < g_end; b0 += 1024) {  // (uniform trip count)
@@ -697,7 +702,15 @@ __global__ void __launch_bounds__(1024) sh_big_rows_kernel(const uint4 *__restri
             if (!s_big[j]) continue;  // uniform
             const int64_t g = b0 + j;
             const uint64_t off = pair_offsets[g];
-            uint64_t cnt = rects[g].w;
+            const uint4 grc = rects[g];  // (uniform)
+            const uint32_t gy0 = grc.x & 0xffff, gx0 = grc.y & 0xffff, gw = (grc.y >> 16) - (grc.y & 0xffff);
+            float gcx = 0.f, gcy = 0.f;
+            if (cull_method == 0) {  // "dist": not every tile of the bounding square is listed
+                const float4 gg = rec_geom[g * GS_REC_STRIDE];
+                gcx = gg.x;
+                gcy = gg.y;
+            }
+            uint64_t cnt = grc.w;
             if (off >= max_pairs) cnt = 0;
             else if (off + cnt > max_pairs) cnt = max_pairs - off;
             const uint32_t chunk = (uint32_t)((cnt + WAVES - 1) / WAVES);
@@ -705,7 +718,14 @@ __global__ void __launch_bounds__(1024) sh_big_rows_kernel(const uint4 *__restri
             float acc = 0.f;
             for (uint32_t k = (uint32_t)wv * chunk; k < k1; k += 64) {
                 const uint32_t kk = k + (uint32_t)lane;
-                unsigned long long m = __ballot(kk < k1 && row_flags[off + kk] != 0);
+                bool ex = false;
+                if (kk < k1) {  // row kk = tile (gx0 + kk % gw, gy0 + kk / gw): processed iff key(g) <= the tile's stop key
+                    const uint32_t iy = gy0 + kk / gw, ix = gx0 + kk % gw, t = iy * ntx + ix;
+                    const uint32_t sd = stop_depth[t];
+                    ex = grc.z < sd || (grc.z == sd && (uint32_t)g <= stop_id[t]);
+                    if (cull_method == 0 && !gs_dist_listed(gcx, gcy, ix, iy, D)) ex = false;
+                }
+                unsigned long long m = __ballot(ex);
                 while (m) {  // the window's existing rows in ascending order, eight loads in flight
                     float v[8];
 #pragma unroll
@@ -752,7 +772,7 @@ template <int CDIM, int PART = 0, int BLOCK = (CDIM == 3 ? 256 : 128)>
 __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
     const float *__restrict__ pos, const float4 *__restrict__ quat, const float *__restrict__ scale,
     int64_t n, ProjectParams P, const float4 *__restrict__ rec_geom,
-    const float4 *__restrict__ rec_color, const float4 *__restrict__ rows, const uint8_t *__restrict__ row_flags,
+    const float4 *__restrict__ rec_color, const float4 *__restrict__ rows,
     const unsigned long long *__restrict__ stop_keys, const float *__restrict__ opa_raw,
     const float *__restrict__ rgb_raw, GsDistCull D,
     const uint32_t *__restrict__ pair_offsets, const uint4 *__restrict__ rects, uint64_t max_pairs, int64_t g_first,
@@ -794,8 +814,10 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
     constexpr int RW4 = gs_row_floats(CDIM) / 4;  // float4s per row
     float4 d0 = make_float4(0, 0, 0, 0), d1 = d0, d2 = d0;
     const uint64_t off = vis ? pair_offsets[pid] : 0, cnt = rc.w;
-    // SH: the column sums of every Gaussian's rows, [Gaussian of the workgroup][row float] with an odd stride
-    constexpr int RWF = 4 * RW4, RS = RWF + 1;
+    // SH: the column sums of every Gaussian's rows, [Gaussian of the workgroup][sum] with an odd stride, the sums in the
+    // COMPACT order (dx, dy, da, db, dc, dd, dopa, coefficient 0 ..): the row's padding floats (gs_frame_layout.h) are
+    // neither loaded nor kept
+    constexpr int RWF = 4 * RW4, RS = ((7 + CDIM + 3) / 4) * 4 + 1;
     __shared__ float s_sum[CDIM > 3 ? BLOCK / GS_PB_SH_PASSES * RS : 1];
     __shared__ uint32_t s_brow[CDIM > 3 ? BLOCK / 64 : 1][64], s_bown[CDIM > 3 ? BLOCK / 64 : 1][64];
 
@@ -1100,6 +1122,7 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
             maxrows = x > maxrows ? x : maxrows;
         }
         const float *rowf = reinterpret_cast<const float *>(rows);
+        const int cidx = lane < RWF ? gs_row_compact(CDIM, lane) : -1;  // this lane's float of a row, in the compact order
         auto wave_sync = [] {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -1116,25 +1139,35 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
             if (k0 < nrow && mine_pass && big_sh) {
                 written = 1ull;
             } else if (k0 < nrow && mine_pass) {
+                // which of the rows [k0, k0 + m) exist: key(g) <= the stop key of the row's tile (round 5; until then a flag
+                // byte per row, written by the raster backward and cleared by a memset per frame).  Stop keys eight at a
+                // time, the tile advanced row by row, as in the rgb branch above.  (Gaussians beyond GS_PB_SH_BIG = 64 rows
+                // present one row: k0 is 0 in practice.)
                 const uint32_t m = nrow - k0 < 64 ? (uint32_t)(nrow - k0) : 64u;
-                // flag bytes [off + k0, off + k0 + m) lie in the words [w0, w1] of the (256-byte aligned, padded) flag array
-                const uint64_t b0 = off + k0;
-                const uint32_t *fw = reinterpret_cast<const uint32_t *>(row_flags);
-                const uint64_t w0 = b0 >> 2, w1 = (b0 + m - 1) >> 2;
-                for (uint64_t w = w0; w <= w1; w += 4) {
-                    uint32_t f[4];
+                const uint32_t wdt = my_x1 - my_x0;
+                uint32_t iy = my_y0 + k0 / wdt, ix = my_x0 + k0 % wdt;
+                for (uint32_t j0 = 0; j0 < m; j0 += 8) {
+                    uint32_t sd[8], tx8[8], ty8[8];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) f[j] = w + j <= w1 ? fw[w + j] : 0u;
+                    for (int j = 0; j < 8; ++j) {
+                        const bool in = j0 + j < m;
+                        tx8[j] = ix;
+                        ty8[j] = iy;
+                        sd[j] = in ? stop_depth[iy * P.ntx + ix] : 0u;
+                        if (in && ++ix == my_x1) {
+                            ix = my_x0;
+                            ++iy;
+                        }
+                    }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        // the flags are 0 / 1 bytes: bits 0, 8, 16, 24 of the word -> one nibble (the partial products
-                        // of the multiplication land on distinct bits: no carries)
-                        const unsigned long long nib = ((f[j] & 0x01010101u) * 0x01020408u) >> 24 & 0xfu;
-                        const int64_t sh = (int64_t)((w + j) << 2) - (int64_t)b0;  // row (relative to k0) of the word's byte 0
-                        written |= sh >= 0 ? (sh < 64 ? nib << sh : 0ull) : nib >> (-sh);
+                    for (int j = 0; j < 8; ++j) {
+                        const bool in = j0 + j < m;
+                        bool yes = in && rc.z < sd[j];
+                        if (in && rc.z == sd[j]) yes = (uint32_t)pid <= stop_id[ty8[j] * P.ntx + tx8[j]];
+                        if (yes && P.cull_method == 0 && !gs_dist_listed(g.x, g.y, tx8[j], ty8[j], D)) yes = false;
+                        if (yes) written |= 1ull << (j0 + j);
                     }
                 }
-                if (m < 64) written &= (1ull << m) - 1ull;
             }
             const uint32_t mine = (uint32_t)__popcll(written);
             const uint32_t incl = gs_wave_incl_scan_u32(mine), first = incl - mine;
@@ -1164,15 +1197,15 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
                         const bool ok = e + u < nb;
                         const uint32_t row = __builtin_amdgcn_readfirstlane(s_brow[wv][ok ? e + u : 0]);
                         own[u] = __builtin_amdgcn_readfirstlane(s_bown[wv][ok ? e + u : 0]);
-                        v[u] = (ok && lane < RWF) ? rowf[(size_t)row * RWF + lane] : 0.f;
+                        v[u] = (ok && cidx >= 0) ? rowf[(size_t)row * RWF + lane] : 0.f;
                     }
 #pragma unroll
                     for (uint32_t u = 0; u < U; ++u) {
                         if (e + u >= nb) break;  // uniform
                         if ((int)own[u] != cur) {  // uniform
-                            if (cur >= 0 && lane < RWF) wsum[(cur - own0) * RS + lane] = acc;
+                            if (cur >= 0 && cidx >= 0) wsum[(cur - own0) * RS + cidx] = acc;
                             cur = (int)own[u];
-                            acc = lane < RWF ? wsum[(cur - own0) * RS + lane] : 0.f;
+                            acc = cidx >= 0 ? wsum[(cur - own0) * RS + cidx] : 0.f;
                         }
                         acc += v[u];
                     }
@@ -1180,7 +1213,7 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
                 wave_sync();  // the batch arrays are rewritten next
             }
         }
-        if (cur >= 0 && lane < RWF) wsum[(cur - own0) * RS + lane] = acc;
+        if (cur >= 0 && cidx >= 0) wsum[(cur - own0) * RS + cidx] = acc;
         wave_sync();
         if (mine_pass) {
             const float *t = wsum + (lane - own0) * RS;  // this thread's Gaussian: (dx, dy, da, db | dc, dd, dopa, coefficient 0 | ...)
@@ -1445,12 +1478,17 @@ int gs_stage_sh_big_rows(const gs_frame *f, const gs_frame_ws &ws, hipStream_t s
     if (f->color_dim == 3 || f->N <= 0) return 0;
     const int blocks = 512;
     const int64_t per_block = gs_div_up(f->N, blocks);  // (the kernel walks its slice 1,024 Gaussians at a time)
+    gs_frame_geom G = gs_frame_geometry(f);
+    GsDistCull D = {(float)(G.padW / 2), (float)(G.padH / 2), f->focal_x, f->focal_y, f->thresh};
+#define GS_LAUNCH_BIG_ROWS(CD)                                                                                          \
+    hipLaunchKernelGGL(sh_big_rows_kernel<CD>, dim3(blocks), dim3(1024), 0, stream, ws.rects, ws.pair_offsets, ws.rows, \
+                       (const unsigned long long *)ws.stop_keys, ws.rec_geom, (uint32_t)G.ntx, (uint32_t)G.n_tiles,     \
+                       f->tile_culling_method, D, f->N, (uint64_t)f->max_pairs, per_block)
     if (f->color_dim == 48)
-        hipLaunchKernelGGL(sh_big_rows_kernel<48>, dim3(blocks), dim3(1024), 0, stream, ws.rects, ws.pair_offsets, ws.rows,
-                           ws.row_flags, f->N, (uint64_t)f->max_pairs, per_block);
+        GS_LAUNCH_BIG_ROWS(48);
     else
-        hipLaunchKernelGGL(sh_big_rows_kernel<27>, dim3(blocks), dim3(1024), 0, stream, ws.rects, ws.pair_offsets, ws.rows,
-                           ws.row_flags, f->N, (uint64_t)f->max_pairs, per_block);
+        GS_LAUNCH_BIG_ROWS(27);
+#undef GS_LAUNCH_BIG_ROWS
     GS_CHECK_LAUNCH();
     return 0;
 }
@@ -1467,7 +1505,7 @@ int gs_stage_project_backward(const gs_frame *f, const gs_frame_ws &ws, float *g
                        dim3((unsigned)gs_div_up(g_end - g_begin, CD == 3 ? 256 : 128)),                           \
                        dim3(CD == 3 ? 256 : 128), 0, stream, f->pos,                                              \
                        (const float4 *)f->quat, f->scale, g_end, P, ws.rec_geom, ws.rec_color,                    \
-                       (const float4 *)ws.rows, ws.row_flags, (const unsigned long long *)ws.stop_keys, f->opa,   \
+                       (const float4 *)ws.rows, (const unsigned long long *)ws.stop_keys, f->opa,                 \
                        f->rgb, Dc, ws.pair_offsets, ws.rects, (uint64_t)f->max_pairs, g_begin,                    \
                        grad_pos, (float4 *)grad_quat, grad_scale, grad_opa, grad_rgb)
 #define GS_LAUNCH_PROJECT_BWD_PARTS(CD)  \

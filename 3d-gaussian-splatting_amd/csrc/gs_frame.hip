@@ -458,6 +458,19 @@ extern "C" int gs_frame_debug_tile_nproc(const gs_frame *f, const uint32_t **til
     return 0;
 }
 
+int gs_bwd_mfma_slots(int color_dim, int n_tiles);  // raster_bwd.hip: (workgroup, wave) slots of the SH backward on the matrix pipe
+
+extern "C" int gs_frame_debug_bwd_exec_rows(const gs_frame *f, const uint32_t **exec_rows, int32_t *n_slots) {
+    int rc = validate(f);
+    if (rc) return rc;
+    GS_CHECK_ARG(exec_rows != nullptr && n_slots != nullptr, "null pointer");
+    GS_CHECK_ARG(f->training, "the executed-row counters are kept by training frames only");
+    gs_frame_ws ws = gs_frame_carve(f->workspace, f->N, f->max_pairs, f->width, f->height, f->color_dim, 1);
+    *exec_rows = ws.bwd_exec_rows;
+    *n_slots = gs_bwd_mfma_slots(f->color_dim, gs_frame_geometry(f).n_tiles);
+    return 0;
+}
+
 // Which binning / sort path gs_frame_forward takes for this frame description: 0 / 1 = sort_mode 0 / 1 (radix passes),
 // 2 = sort_mode 2 table variant, 3 = slice-sorted variant, 4 = strip variant; negative: the description is invalid.
 extern "C" int gs_frame_binning_variant(const gs_frame *f) {

@@ -132,12 +132,47 @@ static inline bool gs_frame_fused_table_count(const gs_frame *f) {
            ntx * nty <= GS_BIN_MAX_TILES;
 }
 
-// floats per per-pair gradient row: (dx, dy, da, db, dc, dd, dopa) + colour grads, padded to float4s
-// floats per (tile, Gaussian) gradient row: 7 geometry/opacity sums + color_dim colour sums, rounded up to float4s
-// (36 / 56 for color_dim 27 / 48).  rgb colours (10 floats): the row is padded to ONE aligned 64-byte line (16 floats), which
+// floats per (tile, Gaussian) gradient row: 7 geometry/opacity sums + color_dim colour sums, in whole 64-byte lines (16 /
+// 48 / 64 floats for color_dim 3 / 27 / 48).  rgb colours (10 floats): the row is ONE aligned 64-byte line (16 floats), which
 // the raster backward writes with a single store instruction (four lanes x 16 bytes) -- a 48-byte row straddled two
 // lines every other time and reached HBM as 32-byte partial writes (round 3, PMC: 134 B written per 48-byte row).
-static constexpr int gs_row_floats(int color_dim) { return color_dim == 3 ? 16 : (7 + color_dim + 3) / 4 * 4; }
+// SH rows (round 5): whole 64-byte lines, every line written completely by ONE store instruction (four lanes x 16 bytes, as
+// the rgb rows since round 4).  Round 4 wrote a 144 / 224-byte row as per-lane scalars at a 28-byte offset into rows that
+// straddle lines: PMC WRITE_SIZE 2.2 x / 1.32 x the row bytes, plus a flag byte (a 32-byte write) per row.  The raster
+// backward on the matrix pipe holds a row spread over the four lanes (g, jq) of its Gaussian -- lane (g, jq) has the
+// coefficient sums k = 4 jq .. 4 jq + 3 of every channel -- so the row is laid out by LINES of four 16-byte pieces, piece q
+// of a line coming from lane (g, q):
+//   degree 2 (27 coefficients, 9 per channel), 48 floats = 3 lines:  line ch = [coef(ch, 0..11: 9 sums + 3 zeros) | header piece ch]
+//       header pieces: 0 = (dx, dy, da, db), 1 = (dc, dd, dopa, 0), 2 = zeros   (lane (g, 3) has no coefficient: it carries them)
+//   degree 3 (48 coefficients, 16 per channel), 64 floats = 4 lines: line 0 = header (dx, dy, da, db | dc, dd, dopa, 0 | 0 | 0),
+//       line 1 + ch = coef(ch, 0..15)
+//   rgb: 16 floats = 1 line: (dx, dy, da, db, dc, dd, dopa, dr, dg, db, 0 ...)
+// gs_row_geo / gs_row_col give the position of a row's floats; every writer and reader goes through them.
+static constexpr int gs_row_floats(int color_dim) {
+    return color_dim == 3 ? 16 : color_dim == 27 ? 48 : color_dim == 48 ? 64 : (7 + color_dim + 3) / 4 * 4;
+}
+// m = 0..6: dL/d(x, y, a, b, c, d, opacity) of the pair
+static constexpr int gs_row_geo(int color_dim, int m) { return color_dim == 27 ? (m < 4 ? 12 + m : 28 + (m - 4)) : m; }
+// colour float c (rgb: channel; SH: coefficient ch * NB + k, the parameter's own order)
+static constexpr int gs_row_col(int color_dim, int c) {
+    return color_dim == 27 ? 16 * (c / 9) + c % 9 : color_dim == 48 ? 16 + c : 7 + c;
+}
+// inverse: float f of a row -> its index in the compact order (dx, dy, da, db, dc, dd, dopa, colour 0 .. color_dim - 1), or -1
+// for a padding float
+static constexpr int gs_row_compact(int color_dim, int f) {
+    if (color_dim == 27) {
+        const int line = f / 16, o = f % 16;
+        if (line > 2) return -1;
+        if (o < 9) return 7 + 9 * line + o;
+        if (o < 12) return -1;
+        return line == 0 ? o - 12 : (line == 1 && o < 15) ? 4 + (o - 12) : -1;
+    }
+    if (color_dim == 48) return f < 7 ? f : f < 16 ? -1 : f < 64 ? 7 + (f - 16) : -1;
+    return f < 7 + color_dim ? f : -1;
+}
+// executed pixel-row steps of the SH backward on the matrix pipe, one counter per (workgroup, wave): what its MFMA flops
+// are counted from (bench.py); [GS_BWD_EXEC_SLOTS x T] u32
+#define GS_BWD_EXEC_SLOTS 8
 
 struct gs_frame_geom {
     int padW, padH, ntx, nty, n_tiles, crop_top, crop_left;
@@ -214,12 +249,15 @@ struct gs_frame_ws {
     uint4 *bucket_info;            // [max_buckets + 8] (tile, first Gaussian, count, list start) per bucket
     float4 *ckpt;                  // [max_buckets][256] (T, Cr, Cg, Cb) at bucket starts
     float *rows;                   // [max_pairs][GS_ROW(C)] per-pair gradient rows in EMISSION order
-    uint8_t *row_flags;            // [max_pairs] SH rows: 1 = the raster backward wrote this row (cleared per frame: the
-                                   // rows themselves are never zero-filled, unwritten ones are skipped by the reader)
+    uint32_t *bwd_exec_rows;       // [GS_BWD_EXEC_SLOTS x T] SH backward on the matrix pipe: pixel-row steps (16 Gaussians x 16
+                                   // pixels) every wave executed in the last backward (rows whose pixels had all stopped are
+                                   // left out); slot = workgroup x waves + wave.  Diagnostic (bench.py's MFMA flop count).
     uint64_t *stop_keys;           // 2 x [T] u32: depth bits, then Gaussian index, of the LAST list entry the forward
                                    // processed in each tile (depth 0: none).  A tile's list ascends in exactly this key, so the pair
                                    // (tile, g) was processed -- its gradient row written -- iff key(g) <= stop_keys[tile]:
-                                   // the rgb reader needs no per-row flag (stop_key_kernel, raster_bwd.hip)
+                                   // no reader needs a per-row flag (stop_key_kernel, raster_bwd.hip; rgb rows since round 4,
+                                   // SH rows since round 5: the rows themselves are never zero-filled, unwritten ones are
+                                   // never read)
     int64_t max_buckets;
     size_t zero_bytes;             // prefix of the workspace cleared at the start of every frame
     size_t total_bytes;
@@ -307,7 +345,7 @@ static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pair
         ws.bucket_info = (uint4 *)take(sizeof(uint4) * (size_t)(ws.max_buckets + 8));
         ws.ckpt = (float4 *)take(sizeof(float4) * 256 * (size_t)ws.max_buckets);
         ws.rows = (float *)take(sizeof(float) * (size_t)gs_row_floats(color_dim) * max_pairs);
-        ws.row_flags = (uint8_t *)take((size_t)max_pairs);
+        ws.bwd_exec_rows = (uint32_t *)take(sizeof(uint32_t) * GS_BWD_EXEC_SLOTS * (size_t)G.n_tiles);
         ws.stop_keys = (uint64_t *)take(sizeof(uint64_t) * G.n_tiles);
     } else {
         ws.tile_nproc = nullptr;
@@ -315,7 +353,7 @@ static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pair
         ws.bucket_info = nullptr;
         ws.ckpt = nullptr;
         ws.rows = nullptr;
-        ws.row_flags = nullptr;
+        ws.bwd_exec_rows = nullptr;
         ws.stop_keys = nullptr;
     }
     ws.total_bytes = off;

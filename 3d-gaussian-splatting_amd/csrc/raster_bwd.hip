@@ -108,8 +108,8 @@ __global__ void __launch_bounds__(256) stop_key_kernel(const uint32_t *__restric
 struct BwdOut {
     // FRAME: one row per pair, addressed in EMISSION order (pair_offsets[g] + index of the tile
     // inside g's rectangle), so the per-Gaussian sum is a contiguous, deterministic reduction
-    float *rows;                   // [max_pairs][12 | 36 | 56]
-    uint8_t *row_flags;            // [max_pairs] set to 1 for every row written (cleared per frame instead of the rows)
+    float *rows;                   // [max_pairs][16 | 48 | 64]: gs_frame_layout.h (gs_row_floats, gs_row_geo, gs_row_col)
+    uint32_t *exec_rows;           // SH backward on the matrix pipe: pixel-row steps executed per (workgroup, wave)
     const uint32_t *pair_offsets;  // [N]
     const uint4 *rects;            // [N]
     uint64_t max_pairs;
@@ -444,19 +444,22 @@ __global__ void __launch_bounds__(64 * BwdCfg<CDIM>::WPB) raster_backward_kernel
         const uint32_t y0 = rc.x & 0xffff, x0 = rc.y & 0xffff, x1 = rc.y >> 16;
         const uint64_t slot = (uint64_t)O.pair_offsets[gid] + (ty - y0) * (x1 - x0) + (tx - x0);
         if (slot < O.max_pairs) {
-            constexpr int RW = gs_row_floats(CDIM);  // 7 geometry/opacity sums + CDIM colour sums, padded to float4s
-            float4 *row = reinterpret_cast<float4 *>(O.rows + slot * RW);
-            O.row_flags[slot] = 1;
-            row[0] = make_float4(gx, gy, ga, gb);
-            if (CDIM == 3) {
-                row[1] = make_float4(gc, gd, Sopa, Sc0);
-                row[2] = make_float4(Sc1, Sc2, 0.f, 0.f);
-            } else {
-                row[1] = make_float4(gc, gd, Sopa, Ssh[0]);
-                auto at = [&](int k) { return k < CDIM ? Ssh[k < CDIM ? k : 0] : 0.f; };
+            // (the A/B fallback of the frame path -- GS_BWD_SH_PIXEL = 0 -- and no hot path: float by float through the row
+            // layout of gs_frame_layout.h, every float of the row written)
+            constexpr int RW = gs_row_floats(CDIM);
+            float *row = O.rows + slot * RW;
 #pragma unroll
-                for (int k = 0; k < RW / 4 - 2; ++k)
-                    row[2 + k] = make_float4(at(1 + 4 * k), at(2 + 4 * k), at(3 + 4 * k), at(4 + 4 * k));
+            for (int m = 0; m < RW; ++m) row[m] = 0.f;
+            const float geo[7] = {gx, gy, ga, gb, gc, gd, Sopa};
+#pragma unroll
+            for (int m = 0; m < 7; ++m) row[gs_row_geo(CDIM, m)] = geo[m];
+            if (CDIM == 3) {
+                row[gs_row_col(3, 0)] = Sc0;
+                row[gs_row_col(3, 1)] = Sc1;
+                row[gs_row_col(3, 2)] = Sc2;
+            } else {
+#pragma unroll
+                for (int k = 0; k < CDIM; ++k) row[gs_row_col(CDIM, k)] = Ssh[k];
             }
         }
     } else {
@@ -708,10 +711,10 @@ __global__ void __launch_bounds__(64 * GS_PP_WPB) raster_backward_pixel_kernel(R
             const uint64_t slot = (uint64_t)O.pair_offsets[gid] + (ty - y0) * (x1 - x0) + (tx - x0);
             if (slot < O.max_pairs) {
                 float4 *row = reinterpret_cast<float4 *>(O.rows + slot * gs_row_floats(3));
-                O.row_flags[slot] = 1;
                 row[0] = make_float4(ogx, ogy, ga, gb);
                 row[1] = make_float4(gcc, gd, t[6], t[7]);
                 row[2] = make_float4(t[8], t[9], 0.f, 0.f);
+                row[3] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         } else {
             const size_t j = (size_t)start + base + i;
@@ -852,12 +855,9 @@ raster_backward_pixel_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
             const uint4 rc = O.rects[gid];
             const uint32_t y0 = rc.x & 0xffff, x0 = rc.y & 0xffff, x1 = rc.y >> 16;
             const uint64_t slot = (uint64_t)O.pair_offsets[gid] + (ty - y0) * (x1 - x0) + (tx - x0);
-            if (slot < O.max_pairs) {  // (max_pairs < 2^30: gs_frame validate)
-                myslot = (uint32_t)slot;
-                // SH rows are flagged (every float of the row is written below: coefficients, geometry, padding); rgb
-                // rows need no flag: the reader derives "written" from the tile's stop key (gs_frame_layout.h)
-                if (CDIM > 3) O.row_flags[slot] = 1;
-            }
+            // (no flag per row: the reader derives "written" from the tile's stop key, gs_frame_layout.h; SH rows: every
+            // float of the row is written below -- coefficients, geometry, padding)
+            if (slot < O.max_pairs) myslot = (uint32_t)slot;  // (max_pairs < 2^30: gs_frame validate)
         }
         s_slot[lane] = myslot;
     }
@@ -1064,8 +1064,9 @@ raster_backward_pixel_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
             if (lane < 6 || STAGED) {
                 s_tot[i][lane] = t;
             } else if (FRAME) {
-                const uint32_t sl = s_slot[i];  // float 6 of a row: sum dL/dalpha G (opacity); 7 + m: coefficient m
-                if (sl != GS_NO_SLOT) O.rows[(size_t)sl * gs_row_floats(CDIM) + lane] = t;
+                const uint32_t sl = s_slot[i];  // sum dL/dalpha G (opacity), then the coefficient sums (row layout: gs_frame_layout.h)
+                if (sl != GS_NO_SLOT)
+                    O.rows[(size_t)sl * gs_row_floats(CDIM) + (lane == 6 ? gs_row_geo(CDIM, 6) : gs_row_col(CDIM, lane - 7))] = t;
             } else {
                 const size_t j = id_i;
                 if (lane == 6)
@@ -1093,10 +1094,18 @@ raster_backward_pixel_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
             if (sl != GS_NO_SLOT) {
                 constexpr int RW = gs_row_floats(CDIM);
                 float *row = O.rows + (size_t)sl * RW;
-                reinterpret_cast<float4 *>(row)[0] = make_float4(ogx, ogy, ga, gb);
-                reinterpret_cast<float2 *>(row)[2] = make_float2(gcc, gd);
+                reinterpret_cast<float4 *>(row + gs_row_geo(CDIM, 0))[0] = make_float4(ogx, ogy, ga, gb);
+                reinterpret_cast<float2 *>(row + gs_row_geo(CDIM, 4))[0] = make_float2(gcc, gd);
+                // the floats of the row that are neither a sum nor the geometry: zero (the reader adds whole rows)
 #pragma unroll
-                for (int m = 7 + CDIM; m < RW; ++m) row[m] = 0.f;  // padding of the row
+                for (int m = 0; m < RW; ++m) {
+                    bool used = false;
+#pragma unroll
+                    for (int e = 0; e < 7; ++e) used = used || m == gs_row_geo(CDIM, e);
+#pragma unroll
+                    for (int e = 0; e < CDIM; ++e) used = used || m == gs_row_col(CDIM, e);
+                    if (!used) row[m] = 0.f;
+                }
             }
         } else {
             const size_t j = (size_t)start + base + lane;
@@ -1294,7 +1303,11 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
         if (I.bucket_cap && nbk[t] > I.bucket_cap) nbk[t] = I.bucket_cap;  // the rest: one wave per bucket (launch_bwd)
         total_bk += nbk[t];
     }
-    if (total_bk <= part * W) return;  // uniform: nothing (left) of these tiles for this workgroup
+    if (total_bk <= part * W) {  // uniform: nothing (left) of these tiles for this workgroup
+        if (tid < W) O.exec_rows[(size_t)blockIdx.x * W + tid] = 0;
+        return;
+    }
+    uint32_t n_exec = 0;  // (wave-uniform) pixel-row steps this wave executed: what its MFMA flops are counted from
     constexpr float KS = -GS_LOG2E;  // the table holds sh'_k = -log2(e) sh_k (raster_common.h)
 
     // ---- per tile: SH table, dL/dC, pixel-row centres
@@ -1463,6 +1476,7 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
                     if (GS_BWD_MFMA_PF && s + 1 < 16) row_loads(s + 1);
                     continue;
                 }
+                ++n_exec;
                 // colour logits of (pixel 4 jq + reg, Gaussian gq) on the matrix pipe
                 f4 lg[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
                 if (TAIL) {
@@ -1569,35 +1583,69 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
             Syy = quad_sum(Syy);
             Sq = quad_sum(Sq);
             Sopa = quad_sum(Sopa);
-            if (slot != GS_NO_SLOT) {
-                float *row = O.rows + (size_t)slot * RW;
-                if (jq == 0) {
-                    const float a = cv2.x, bb = cv2.y, cc = cv2.z, d = cv2.w;
-                    float cA, cB, cC;
-                    gs_conic(a, bb, cc, d, cA, cB, cC);
-                    const float iPn = 1.0f / (2.0f * raster_det(a, bb, cc, d) + 1e-14f);
-                    const float Su = Sq * GS_LN2;
-                    const float ogx = GS_LN2 * (2.0f * cA * Sx - cB * Syt), ogy = GS_LN2 * (2.0f * cC * Syt - cB * Sx);
-                    const float ga = iPn * (-Syy + 2.0f * d * Su), gb = iPn * (Sxy - 2.0f * cc * Su);
-                    const float gcc = iPn * (Sxy - 2.0f * bb * Su), gd = iPn * (-Sxx + 2.0f * a * Su);
-                    O.row_flags[slot] = 1;
-                    reinterpret_cast<float4 *>(row)[0] = make_float4(ogx, ogy, ga, gb);
-                    reinterpret_cast<float2 *>(row)[2] = make_float2(gcc, gd);
-                    row[6] = Sopa;
+            // ---- the group's 16 rows leave as whole 64-byte lines (round 5; row layout: gs_frame_layout.h).  A row is spread
+            // over the four lanes (g, jq) of its Gaussian; line `it` of the row is put together from one 16-byte piece of each
+            // of them -- destination lane 4 r + q takes the piece of lane (g = r, jq = q) through four ds_bpermute -- and
+            // stored by ONE instruction, four lanes x 16 bytes per line, sixteen rows per instruction: every line reaches
+            // the memory system complete (round 4: twelve scalar stores per lane at a 28-byte offset into rows that straddle
+            // lines and a flag byte per row -- PMC WRITE_SIZE 2.2 x / 1.32 x the row bytes).  The geometry algebra runs in
+            // all four lanes of a Gaussian (they hold the same sums after quad_sum): whichever lane carries a header piece
+            // has it.
+            float h0[4], h1[4];  // header pieces (dx, dy, da, db), (dc, dd, dopa, 0)
+            {
+                const float a = cv2.x, bb = cv2.y, cc = cv2.z, d = cv2.w;
+                float cA, cB, cC;
+                gs_conic(a, bb, cc, d, cA, cB, cC);
+                const float iPn = 1.0f / (2.0f * raster_det(a, bb, cc, d) + 1e-14f);
+                const float Su = Sq * GS_LN2;
+                h0[0] = GS_LN2 * (2.0f * cA * Sx - cB * Syt);
+                h0[1] = GS_LN2 * (2.0f * cC * Syt - cB * Sx);
+                h0[2] = iPn * (-Syy + 2.0f * d * Su);
+                h0[3] = iPn * (Sxy - 2.0f * cc * Su);
+                h1[0] = iPn * (Sxy - 2.0f * bb * Su);
+                h1[1] = iPn * (-Sxx + 2.0f * a * Su);
+                h1[2] = Sopa;
+                h1[3] = 0.f;
+            }
+            {
+                const int dr = lane >> 2, dq = lane & 3, src = dr + 16 * dq;  // destination row / piece, its source lane
+                const uint32_t dslot = (uint32_t)__shfl((int)slot, dr, 64);
+                float4 *drow = reinterpret_cast<float4 *>(O.rows + (size_t)(dslot != GS_NO_SLOT ? dslot : 0) * RW);
+                auto put = [&](int line, const float v[4]) {  // this lane OFFERS v; lane 4 r + q stores what lane (r, q) offers
+                    float4 o;
+                    o.x = __shfl(v[0], src, 64);
+                    o.y = __shfl(v[1], src, 64);
+                    o.z = __shfl(v[2], src, 64);
+                    o.w = __shfl(v[3], src, 64);
+                    if (dslot != GS_NO_SLOT) drow[4 * line + dq] = o;
+                };
+                if constexpr (NB == 16) {
+                    // line 0: the header, pieces 0 / 1 from lanes jq = 0 / 1, zeros from the others; line 1 + ch: coef(ch, 0..15)
+                    float hv[4];
 #pragma unroll
-                    for (int m = 7 + CDIM; m < RW; ++m) row[m] = 0.f;  // padding of the row
-                }
+                    for (int e = 0; e < 4; ++e) hv[e] = jq == 0 ? h0[e] : jq == 1 ? h1[e] : 0.f;
+                    put(0, hv);
 #pragma unroll
-                for (int ch = 0; ch < 3; ++ch)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const uint32_t k = 4 * jq + e;
-                        if (NB == 16 || k < (uint32_t)NB) row[7 + ch * NB + k] = acc[ch][e];
+                    for (int ch = 0; ch < 3; ++ch) {
+                        const float cv[4] = {acc[ch][0], acc[ch][1], acc[ch][2], acc[ch][3]};
+                        put(1 + ch, cv);
                     }
+                } else {
+                    // line ch: coef(ch, 0..11) from lanes jq = 0..2 (k >= 9: the table's zero entries: exact zeros), header
+                    // piece ch from lane jq = 3, which has no coefficient
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        float cv[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) cv[e] = jq == 3 ? (ch == 0 ? h0[e] : ch == 1 ? h1[e] : 0.f) : acc[ch][e];
+                        put(ch, cv);
+                    }
+                }
             }
         }
         lds_order();  // (the next bucket's states overwrite this wave's arrays)
     }
+    if (lane == 0) O.exec_rows[(size_t)blockIdx.x * W + wave] = n_exec;
 }
 
 // sigmoid=True of the reference API: ceil buckets in the systolic kernel, no tail kernel (a rarely used flag)
@@ -1628,6 +1676,7 @@ void launch_bwd(const RasterSrc &S, const RasterGeom &G, const BwdIn &I, const B
         const unsigned mgrid = (unsigned)(gs_div_up(G.ntx * G.nty, GS_BWD_MFMA_TILES) *
                                           (GS_BWD_MFMA_TILES == 1 ? GS_BWD_MFMA_SPLIT : 1));
         const int mwaves = GS_BWD_MFMA_WAVES ? GS_BWD_MFMA_WAVES : (G.ntx * G.nty >= 1024 ? 2 : 4);
+        static_assert((GS_BWD_MFMA_TILES == 1 ? GS_BWD_MFMA_SPLIT : 1) * 4 <= GS_BWD_EXEC_SLOTS, "executed-row counters");
         if (mwaves == 2)
             hipLaunchKernelGGL((raster_backward_mfma_sh_kernel<CDIM, 2, GS_BWD_MFMA_TILES>), dim3(mgrid), dim3(128), 0,
                                stream, S, G, I, O);
@@ -1657,6 +1706,20 @@ void launch_bwd(const RasterSrc &S, const RasterGeom &G, const BwdIn &I, const B
         hipLaunchKernelGGL((raster_backward_kernel<CDIM, FRAME>), dim3(grid), dim3(64 * WPB), 0, stream, S, G, I, O);
     }
 }
+
+}  // namespace
+
+// (workgroup, wave) slots the SH backward on the matrix pipe writes its executed-row counters to (0: this colour model
+// takes another kernel): the launch geometry of launch_bwd above
+int gs_bwd_mfma_slots(int color_dim, int n_tiles) {
+    const bool mfma = (color_dim == 48 && GS_BWD_SH_MFMA >= 1) || (color_dim == 27 && GS_BWD_SH_MFMA >= 2);
+    if (!mfma) return 0;
+    const int mgrid = (int)(gs_div_up(n_tiles, GS_BWD_MFMA_TILES) * (GS_BWD_MFMA_TILES == 1 ? GS_BWD_MFMA_SPLIT : 1));
+    const int mwaves = GS_BWD_MFMA_WAVES ? GS_BWD_MFMA_WAVES : (n_tiles >= 1024 ? 2 : 4);
+    return mgrid * mwaves;
+}
+
+namespace {
 
 struct RefWs {
     uint32_t *tile_nproc, *bucket_offsets;
@@ -1740,7 +1803,7 @@ extern "C" int gs_draw_backward(const float *pos, const float *rgb, const float 
                        ws.bucket_offsets, ws.n_buckets, ws.bucket_info, tile_n_point_accum, 0);
     // 3. one wave per bucket, one output row per pair
     BwdIn I = {output, grad_output, ws.ckpt, ws.tile_nproc, ws.bucket_offsets, ws.bucket_info, tile_n_point_accum};
-    BwdOut O = {nullptr, nullptr, nullptr, nullptr, 0, grad_pos, grad_rgb, grad_opa, grad_cov};
+    BwdOut O = {nullptr, nullptr, nullptr, nullptr, 0, grad_pos, grad_rgb, grad_opa, grad_cov};  // (reference API: no rows)
     const unsigned nb = (unsigned)(ws.max_buckets > 0 ? ws.max_buckets : 1);
     if (sigmoid && use_sh_coeff)
         launch_bwd_sig<27>(S, G, I, O, ws.max_buckets, s, exact);
@@ -1766,13 +1829,10 @@ extern "C" int gs_draw_backward(const float *pos, const float *rgb, const float 
 // whatever the caller does between forward and backward (the loss); gs_frame_backward runs it inline otherwise.
 int gs_stage_backward_prepare(const gs_frame *f, const gs_frame_ws &ws, const uint32_t *sorted_ids, hipStream_t stream) {
     gs_frame_geom FG = gs_frame_geometry(f);
-    // rgb rows carry no flags: the reader decides from the tiles' stop keys which rows exist
-    if (f->color_dim != 3)
-        GS_HIP(hipMemsetAsync(ws.row_flags, 0, (size_t)f->max_pairs, stream));
-    else
-        hipLaunchKernelGGL(stop_key_kernel, dim3((unsigned)gs_div_up(FG.n_tiles, 256)), dim3(256), 0, stream,
-                           ws.tile_nproc, FG.n_tiles, ws.tile_ranges, sorted_ids, ws.rects,
-                           (unsigned long long *)ws.stop_keys);
+    // no row carries a flag: the readers decide from the tiles' stop keys which rows exist (rgb: round 4; SH: round 5 --
+    // until then a flag byte per pair, set by scattered one-byte stores = a 32-byte write each, cleared by a memset here)
+    hipLaunchKernelGGL(stop_key_kernel, dim3((unsigned)gs_div_up(FG.n_tiles, 256)), dim3(256), 0, stream, ws.tile_nproc,
+                       FG.n_tiles, ws.tile_ranges, sorted_ids, ws.rects, (unsigned long long *)ws.stop_keys);
     // the bucket work list is what the one-wave-per-bucket kernels read; the SH backward on the matrix pipe walks a
     // tile's buckets itself (one workgroup per tile) and needs none
     const bool per_tile = ((f->color_dim == 48 && GS_BWD_SH_MFMA >= 1) || (f->color_dim == 27 && GS_BWD_SH_MFMA >= 2)) &&
@@ -1818,7 +1878,7 @@ int gs_stage_raster_backward(const gs_frame *f, const gs_frame_ws &ws, const uin
     BwdIn I = {f->image_padded, grad_image, ws.ckpt, ws.tile_nproc, ws.bucket_offsets, ws.bucket_info, ws.tile_ranges,
                (gs_frame_uses_strips(f) && f->N > 0 && GS_BWD_MFMA_ORDER) ? ws.tile_order : nullptr, 0, 0};
     if (f->color_dim != 3 && gs_frame_long_lists(f, FG.n_tiles)) I.bucket_cap = I.bucket_first = GS_LONG_MIN / GS_BUCKET;
-    BwdOut O = {ws.rows, ws.row_flags, ws.pair_offsets, ws.rects, (uint64_t)f->max_pairs, nullptr, nullptr, nullptr, nullptr};
+    BwdOut O = {ws.rows, ws.bwd_exec_rows, ws.pair_offsets, ws.rects, (uint64_t)f->max_pairs, nullptr, nullptr, nullptr, nullptr};
     if (f->color_dim == 48)
         launch_bwd<48, true>(S, G, I, O, ws.max_buckets, stream);
     else if (f->color_dim == 27)

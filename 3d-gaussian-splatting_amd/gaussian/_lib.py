@@ -98,6 +98,7 @@ gs_frame_debug_views = _sig("gs_frame_debug_views", ci, C.POINTER(GsFrame), C.PO
 gs_frame_binning_variant = _sig("gs_frame_binning_variant", ci, C.POINTER(GsFrame))
 gs_frame_debug_rects = _sig("gs_frame_debug_rects", ci, C.POINTER(GsFrame), C.POINTER(vp))
 gs_frame_debug_tile_nproc = _sig("gs_frame_debug_tile_nproc", ci, C.POINTER(GsFrame), C.POINTER(vp))
+gs_frame_debug_bwd_exec_rows = _sig("gs_frame_debug_bwd_exec_rows", ci, C.POINTER(GsFrame), C.POINTER(vp), C.POINTER(C.c_int32))
 
 gs_adam_step = _sig("gs_adam_step", ci, vp, vp, vp, vp, i64, i32, C.POINTER(i64), C.POINTER(f32), f32, f32, f32, i64,
                     vp, i64, i64, i32, vp)
@@ -137,7 +138,7 @@ EXPORTS = [
     "gs_jacobian", "gs_global_culling", "gs_global_culling_backward", "gs_calc_tile_list",
     "gs_gather_gaussians", "gs_draw", "gs_draw_backward_workspace_bytes", "gs_draw_backward",
     "gs_sort_pairs_tmp_bytes", "gs_sort_pairs", "gs_sort_pairs_bits", "gs_frame_workspace_bytes", "gs_frame_forward",
-    "gs_frame_stats_async", "gs_frame_longest_list_async", "gs_frame_debug_views", "gs_frame_debug_rects", "gs_frame_binning_variant", "gs_frame_debug_tile_nproc", "gs_frame_backward", "gs_frame_forward_profile",
+    "gs_frame_stats_async", "gs_frame_longest_list_async", "gs_frame_debug_views", "gs_frame_debug_rects", "gs_frame_binning_variant", "gs_frame_debug_tile_nproc", "gs_frame_debug_bwd_exec_rows", "gs_frame_backward", "gs_frame_forward_profile",
     "gs_frame_backward_part", "gs_frame_async_create", "gs_frame_async_wait", "gs_frame_async_destroy",
     "gs_frame_backward_slice", "gs_frame_project_slices", "gs_frame_forward_project", "gs_frame_forward_rest",
     "gs_adam_step_multi",

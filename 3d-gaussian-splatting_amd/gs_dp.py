@@ -157,7 +157,12 @@ class FlatGaussianParams:
             # extra slice costs the step 70 - 90 us -- the per-slice kernels fill less of the chip (a project launch over
             # half the slices takes 55 us against 80 us for all of them) -- while the exchange time a further slice can
             # hide shrinks as 1 / K: DESIGN.md section 4 has the model.
-            n_slices = 2 if (n >= 1_000_000 and self.world_size > 1) else 1
+            # Round 5: with peers a single slice leaves the whole exchange exposed (sums -> exchange -> wait
+            # -> Adam), whatever the scene size; the 1 M threshold of round 4 came from single-GPU measurements only.  Two
+            # slices whenever there are peers and the array can be cut (below 65,536 Gaussians every kernel of the step is
+            # launch-latency bound and the exchange is a few tens of microseconds of wire latency: nothing to hide);
+            # Trainer.tune_slices settles it by measurement on the real links.
+            n_slices = 2 if (n >= 65_536 and self.world_size > 1) else 1
         k_slices = max(1, min(int(n_slices), n_steps))
         bounds = sorted({min(round(i * n_steps / k_slices) * step, self.n_pad) for i in range(k_slices)} | {self.n_pad})
         self.slice_bounds = [0] + [b for b in bounds if b > 0]
@@ -229,6 +234,115 @@ class FlatGaussianParams:
     def _plain_collectives(self) -> bool:
         return dist.get_backend() != "nccl" and self.flat_grad.is_cuda
 
+    # ---- which API the exchange goes through ------------------------------------------------------
+    # "grouped": the process group's C++ entry points, one launch per unit, in place (each output view sits inside its
+    #            input) -- fast on the host, but a private API whose in-place layout no test exercised with world > 1 on RCCL;
+    # "public" : torch.distributed's documented calls, one per range (all_reduce / reduce_scatter_tensor /
+    #            all_gather_into_tensor, async_op=True), same in-place views.
+    # GS_DP_COLLECTIVES=public forces the second; otherwise the grouped path is used once `self_check()` has seen it
+    # produce the closed-form result of a known pattern on THIS backend and world size (run on the first exchange with
+    # peers); a mismatch or an exception switches to the public path (checked the same way) with a warning.
+    def _api(self) -> str:
+        api = getattr(self, "_collective_api", None)
+        if api is None:
+            api = self._collective_api = self._initial_api()
+            if self.world_size > 1 and dist.is_initialized() and not self._plain_collectives():
+                api = self.self_check()
+        return api
+
+    @staticmethod
+    def _initial_api() -> str:
+        import os
+
+        return "public" if os.environ.get("GS_DP_COLLECTIVES", "").lower() == "public" else "grouped"
+
+    def _issue_reduce(self, api, op, g, g_own):
+        """-> work of the (all-)reduce of ranges `g` (reduce_scatter: result in `g_own`, a view inside each range)."""
+        if api == "grouped":
+            pg = dist.distributed_c10d._get_default_group()
+            if self.exchange == "reduce_scatter":
+                o = dist.ReduceScatterOptions()
+                o.reduceOp = op
+                return pg.reduce_scatter_tensor_coalesced(g_own, g, o)
+            o = dist.AllreduceCoalescedOptions()
+            o.reduceOp = op
+            return pg.allreduce_coalesced(g, o)
+        if self.exchange == "reduce_scatter":
+            return _WorkList([dist.reduce_scatter_tensor(o_, i_, op=op, async_op=True) for o_, i_ in zip(g_own, g)])
+        return _WorkList([dist.all_reduce(t, op=op, async_op=True) for t in g])
+
+    def _issue_gather(self, api, p, p_own):
+        if api == "grouped":
+            return dist.distributed_c10d._get_default_group().allgather_into_tensor_coalesced(p, p_own)
+        return _WorkList([dist.all_gather_into_tensor(o_, i_, async_op=True) for o_, i_ in zip(p, p_own)])
+
+    def self_check(self) -> str:
+        """One exchange of a known pattern through the selected API, compared with its closed form (exact: small integers
+        in fp32).  Five ranges of different lengths, as a slice has; SUM; this rank's exchange mode; and the parameter
+        all-gather of the reduce-scatter mode.  Costs one host synchronisation, once.  Returns the API in use."""
+        w, r = self.world_size, self.rank
+        dev = self.flat_grad.device
+        lens = [4 * w * k for k in (4, 3, 3, 1, 27)]
+        total = sum(lens)
+
+        def pattern(rank_plus_1):
+            return (torch.arange(total, device=dev, dtype=torch.float32) % 97 + 1) * rank_plus_1
+
+        def run(api):
+            buf, ranges, off = pattern(r + 1), [], 0
+            for n_ in lens:
+                ranges.append((off, off + n_))
+                off += n_
+            own = []
+            for lo, hi in ranges:
+                s_ = (hi - lo) // w
+                own.append((lo + r * s_, lo + (r + 1) * s_))
+            g = [buf[lo:hi] for lo, hi in ranges]
+            g_own = [buf[lo:hi] for lo, hi in own]
+            self._issue_reduce(api, dist.ReduceOp.SUM, g, g_own).wait()
+            want = pattern(w * (w + 1) // 2)
+            touched = own if self.exchange == "reduce_scatter" else ranges
+            ok = all(bool(torch.equal(buf[lo:hi], want[lo:hi])) for lo, hi in touched)
+            if self.exchange == "reduce_scatter":
+                par = torch.zeros(total, device=dev)
+                for lo, hi in own:
+                    par[lo:hi] = pattern(r + 1)[lo:hi]
+                self._issue_gather(api, [par[lo:hi] for lo, hi in ranges], [par[lo:hi] for lo, hi in own]).wait()
+                want_p = torch.empty(total, device=dev)
+                for lo, hi in ranges:
+                    s_ = (hi - lo) // w
+                    for q in range(w):
+                        want_p[lo + q * s_:lo + (q + 1) * s_] = pattern(q + 1)[lo + q * s_:lo + (q + 1) * s_]
+                ok = ok and bool(torch.equal(par, want_p))
+            return ok
+
+        def agreed(ok):  # every rank must take the same path: one MIN over the ranks' verdicts
+            t = torch.tensor([1.0 if ok else 0.0], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item() > 0.5)
+
+        api = getattr(self, "_collective_api", None) or self._initial_api()
+        if api == "grouped":
+            try:
+                ok = run("grouped")
+            except Exception as e:  # noqa: BLE001 -- a private API that moved or refuses the in-place views
+                import warnings
+
+                warnings.warn(f"gs_dp: grouped collectives unavailable ({e!r}); using torch.distributed's public API")
+                ok = False
+            if agreed(ok):
+                self._collective_api = "grouped"
+                return "grouped"
+            import warnings
+
+            warnings.warn("gs_dp: the grouped in-place collectives did not reproduce the known pattern on this backend; "
+                          "falling back to torch.distributed's public API (one call per range)")
+        if not agreed(run("public")):
+            raise RuntimeError("gs_dp: the gradient exchange does not reproduce a known pattern on this backend "
+                               f"({dist.get_backend()}, world {w}, {self.exchange}): refusing to train on it")
+        self._collective_api = "public"
+        return "public"
+
     # The collectives go straight to the process group's C++ entry points (allreduce_coalesced & co.: several ranges = ONE
     # grouped RCCL launch) with tensor views that are built once per unit: torch.distributed's Python wrappers cost
     # ~80 us per grouped call on the host (21 us this way, measured on gloo), and a step issues two or three per slice.
@@ -248,7 +362,6 @@ class FlatGaussianParams:
         stream so far -- i.e. for the kernel that wrote the ranges."""
         if not self.collective_active():
             return
-        pg = dist.distributed_c10d._get_default_group()
         # mean: inside the collective (RCCL: AVG), by a scaling pass in finish_exchange (gloo: SUM only), or left to the
         # optimizer (mean_in_optimizer: SUM, nothing else)
         avg = dist.get_backend() == "nccl" and not self.mean_in_optimizer
@@ -261,17 +374,9 @@ class FlatGaussianParams:
             works = [dist.all_reduce(t, op=op, async_op=True) for t in v["g"]]
             self._pending[key] = (_WorkList(works), avg, v["g_own"] if self.exchange == "reduce_scatter" else v["g"])
             return
-        if self.exchange == "reduce_scatter":
-            o = dist.ReduceScatterOptions()
-            o.reduceOp = op
-            # in place: the output is this rank's shard of the input (RCCL's in-place reduce-scatter layout)
-            work = pg.reduce_scatter_tensor_coalesced(v["g_own"], v["g"], o)
-            self._pending[key] = (work, avg, v["g_own"])
-        else:
-            o = dist.AllreduceCoalescedOptions()
-            o.reduceOp = op
-            work = pg.allreduce_coalesced(v["g"], o)
-            self._pending[key] = (work, avg, v["g"])
+        # in place: a reduce-scatter's output is this rank's shard of its input (RCCL's in-place reduce-scatter layout)
+        work = self._issue_reduce(self._api(), op, v["g"], v["g_own"])
+        self._pending[key] = (work, avg, v["g_own"] if self.exchange == "reduce_scatter" else v["g"])
 
     def finish_exchange(self, key):
         """Make the current stream wait for the unit's reduction (and scale it on backends without AVG)."""
@@ -288,7 +393,6 @@ class FlatGaussianParams:
         """reduce-scatter mode: all-gather the unit's updated PARAMETER shards (in place), without waiting."""
         if not self.collective_active() or self.exchange != "reduce_scatter":
             return
-        pg = dist.distributed_c10d._get_default_group()
         v = self._views(key, ranges)
         if self._plain_collectives():
             # all-gather as a SUM all-reduce of a copy in which everything but this rank's shard is zero (exact: the
@@ -301,7 +405,7 @@ class FlatGaussianParams:
                 copies.append((full, tmp))
             self._pending_gather[key] = _WorkList(works, copies)
             return
-        self._pending_gather[key] = pg.allgather_into_tensor_coalesced(v["p"], v["p_own"])
+        self._pending_gather[key] = self._issue_gather(self._api(), v["p"], v["p_own"])
 
     def finish_gather(self, name=None):
         """Make the current stream wait for the parameter all-gather(s): before anything reads the parameters."""

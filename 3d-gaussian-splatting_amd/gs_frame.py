@@ -306,14 +306,19 @@ class FrameRenderer:
         return image, padded
 
     # ------------------------------------------------------------------ a frame in two phases (view-parallel trainer)
-    def forward_begin(self, pos, quat, scale, opa, rgb, camera, slice_begin: int, slice_end: int) -> bool:
+    def forward_begin(self, pos, quat, scale, opa, rgb, camera, slice_begin: int, slice_end: int,
+                      expect_per_slice: int = None) -> bool:
         """Issue the PROJECT stage of the next training frame for the slices [slice_begin, slice_end) of the Gaussian
         array (``project_slices()`` of them, ``project_slice_size`` Gaussians each); the range that starts at slice 0
         opens the frame.  gs_train.Trainer calls this slice by slice behind the optimizer of the previous step, so that
         the next frame's cull + project + count runs underneath the gradient exchange of the remaining slices.
         Returns False -- nothing issued -- when this frame cannot be split (binning variant without the fused count, a
         pending workspace growth, a capacity check due): the caller then renders it with ``forward``.  The frame is
-        completed by ``forward_finish``; no capacity check happens in between (steady-state training frames only)."""
+        completed by ``forward_finish``; no capacity check happens in between (steady-state training frames only).
+        ``expect_per_slice``: the slice size the caller converted its Gaussian ranges with (gs_dp.project_slice_size
+        restates the library's plan in Python); if the library's plan for this frame says otherwise, nothing is issued
+        and the frame is rendered from scratch (the duplicated formula must not be able to project the
+        wrong Gaussians silently)."""
         with torch.cuda.device(self.device):
             stream = self._stream().cuda_stream
             if slice_begin == 0:
@@ -333,10 +338,19 @@ class FrameRenderer:
                 _lib.check(_lib.gs_frame_project_slices(C.byref(f), C.byref(n_sl), C.byref(per)), "gs_frame_project_slices")
                 if n_sl.value == 0:
                     return False
+                if expect_per_slice is not None and int(expect_per_slice) != per.value:
+                    import warnings
+
+                    warnings.warn(f"forward_begin: the caller cut the Gaussian array into project slices of "
+                                  f"{expect_per_slice}, the library's plan says {per.value}; rendering from scratch")
+                    return False
                 self._begun = {"f": f, "image": image, "padded": padded, "keep": (pos, quat, scale, opa, rgb),
                                "camera": camera, "slices": n_sl.value, "per_slice": per.value, "done": 0}
             b = getattr(self, "_begun", None)
             if b is None:
+                return False
+            if expect_per_slice is not None and int(expect_per_slice) != b["per_slice"]:
+                self._begun = None
                 return False
             slice_end = min(int(slice_end), b["slices"])
             if slice_end <= slice_begin:
@@ -518,6 +532,20 @@ class FrameRenderer:
         off = ptr.value - self._ws.data_ptr()
         T = self._grid.n_tiles
         return int(self._ws[off:off + 4 * T].view(torch.int32).to(torch.int64).sum().item())
+
+    def executed_row_steps(self) -> int:
+        """SH frames: pixel-row steps (16 Gaussians x 16 pixels) the last backward's matrix-pipe kernel executed -- rows
+        whose 16 pixels had all stopped are left out --, i.e. what its MFMA flops are counted from; 0 for frames that
+        take another kernel (rgb colours, long-list tails).  Synchronises."""
+        f = self._frame
+        if f is None or not f.training:
+            raise RuntimeError("executed_row_steps() needs a preceding training forward + backward")
+        ptr, n = C.c_void_p(), C.c_int32()
+        _lib.check(_lib.gs_frame_debug_bwd_exec_rows(C.byref(f), C.byref(ptr), C.byref(n)), "gs_frame_debug_bwd_exec_rows")
+        if n.value == 0:
+            return 0
+        off = ptr.value - self._ws.data_ptr()
+        return int(self._ws[off:off + 4 * n.value].view(torch.int32).to(torch.int64).sum().item())
 
     def debug_views(self):
         """Device tensors aliasing the workspace of the last forward (parity tests)."""

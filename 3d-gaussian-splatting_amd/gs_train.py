@@ -285,6 +285,11 @@ class Trainer:
             self._loss[key] = ImageLoss(h, w, self.opt.ssim_weight, self.flat.flat_param.device)
         return self._loss[key]
 
+    def _is_control_iteration(self, i_iter: int) -> bool:
+        """Does train_step(i_iter) run adaptive_control (prune, or prune + densify)?  train.py:86-91."""
+        o = self.opt
+        return i_iter > o.adaptive_control_start_iter and i_iter % o.n_adaptive_control == 0
+
     def train_step(self, i_iter: int, camera_id: int, next_camera_id: Optional[int] = None) -> torch.Tensor:
         """Returns the device tensor (loss, l1, ssim) of this step (no host synchronisation).
 
@@ -411,9 +416,20 @@ class Trainer:
         flat = self.flat
         if not flat.collective_active() or flat.exchange != "all_reduce":
             return flat.n_slices
+        o = self.opt
+        total = len(candidates) * iters
+        if self.densify:
+            # a step that runs adaptive_control rebuilds self.flat and the optimizer (_bind), and an opacity
+            # reset changes what a step costs -- neither belongs inside a timing comparison.  Refuse a window that holds
+            # a control point; the caller tunes between two of them (they are n_adaptive_control iterations apart).
+            for it_ in range(i_iter, i_iter + total):
+                if self._is_control_iteration(it_) or (it_ % o.n_opa_reset == 0 and it_ > 0):
+                    raise RuntimeError(f"tune_slices({i_iter}): iteration {it_} of the {total} tuning steps is a densification "
+                                       "/ opacity-reset boundary; start right after one")
         dev = flat.flat_param.device
         best, best_t, it = flat.n_slices, None, i_iter
         for ns in candidates:
+            flat = self.flat  # (re-read: nothing below may act on a stale object)
             flat.finish_gather()
             self.renderer.forward_abandon()
             flat.set_slices(ns)
@@ -432,6 +448,7 @@ class Trainer:
             t = float(t.item())
             if best_t is None or t < best_t:
                 best, best_t = flat.n_slices, t
+        flat = self.flat
         flat.finish_gather()
         self.renderer.forward_abandon()
         flat.set_slices(best)
@@ -457,7 +474,9 @@ class Trainer:
         b0, b1 = flat.slice_bounds[k], min(flat.slice_bounds[k + 1], flat.n)
         if b1 <= b0:
             return True
-        return self.renderer.forward_begin(*flat.params, self.cameras[next_camera_id], b0 // per, -(-b1 // per))
+        ok = self.renderer.forward_begin(*flat.params, self.cameras[next_camera_id], b0 // per, -(-b1 // per),
+                                         expect_per_slice=per)
+        return ok
 
     def adaptive_control(self, i_iter: int, densify: bool = True):
         """train.py:156-180: prune (+ clone / split when ``densify``), then a fresh optimizer."""

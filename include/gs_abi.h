@@ -34,11 +34,16 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-/* 4 (round 3): GS_FRAME_STRIP_BIN + the size-based choice of the binning variant, gs_frame_binning_variant,
+/* 6 (round 5): gs_frame_debug_bwd_exec_rows; SH gradient rows in whole 64-byte lines without per-row flags (workspace
+ * layout only: no signature changed).
+ * 5 (round 4): the frame in pieces -- gs_frame_forward_project + gs_frame_forward_rest == gs_frame_forward,
+ * gs_frame_backward_slice (the per-Gaussian sums of a range of Gaussians), gs_frame_project_slices --, gs_adam_step_multi /
+ * gs_adam_step_range (up to eight element ranges per launch, grad_scale), gs_grad_stat_update, gs_frame_longest_list_async.
+ * 4 (round 3): GS_FRAME_STRIP_BIN + the size-based choice of the binning variant, gs_frame_binning_variant,
  * gs_frame_debug_rects (records of culled Gaussians are no longer written), gs_frame_overflow_flag,
  * gs_adam_step_sharded, `fast = 0` of gs_draw / gs_draw_backward honoured, the long-list kernels follow GS_FRAME_LONG_LISTS alone (not the
  * workspace capacity).  3: gs_frame.async / flags. */
-#define GS_ABI_VERSION 5
+#define GS_ABI_VERSION 6
 
 #define GS_E_INVALID (-1)   /* bad argument (null pointer, negative size, bad enum)   */
 #define GS_E_UNSUPPORTED (-2) /* valid in the reference but not implemented here (none at present) */
@@ -321,6 +326,12 @@ int gs_frame_debug_rects(const gs_frame *f, const uint32_t **rects);
  * stopped (a multiple of 64 except for the last chunk), kept by TRAINING forwards for the backward.  Measurement
  * aid: the compositing work of a frame is sum(tile_nproc) steps, not the pair count. */
 int gs_frame_debug_tile_nproc(const gs_frame *f, const uint32_t **tile_nproc);
+
+/* SH training frames whose raster backward ran on the matrix pipe (color_dim 27 / 48, frame path): [*n_slots] uint32, the
+ * pixel-row steps (16 Gaussians x 16 pixels: 3 floor(NB / 4) + 12 fp32 MFMAs each) every wave of the LAST backward executed --
+ * rows whose 16 pixels had all stopped are left out, so this, not 16 x the composited steps / 16, is what the kernel's
+ * MFMA flops are counted from (bench.py).  *n_slots = 0 for frames that take another kernel.  Measurement aid. */
+int gs_frame_debug_bwd_exec_rows(const gs_frame *f, const uint32_t **exec_rows, int32_t *n_slots);
 
 /* Backward frame: grad_image is dL/d(image) [height,width,3] (w.r.t. the clamped, cropped
  * output).  Writes dL/d(raw parameter) for every Gaussian (zeros for culled ones):

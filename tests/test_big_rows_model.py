@@ -1,11 +1,12 @@
 """CPU tier: the contract between the SH big-row pre-pass (cull_project.hip: sh_big_rows_kernel) and the projection backward's row
 walk, as a NumPy model.
 
-A Gaussian's per-pair gradient rows lie in one contiguous region (emission order); a flag byte says which rows the raster
-backward wrote.  The projection backward sums a Gaussian's existing rows.  For a Gaussian beyond GS_PB_SH_BIG rows the
+A Gaussian's per-pair gradient rows lie in one contiguous region (emission order); which rows the raster backward wrote
+is a predicate of the row (`flags` below: until round 4 a flag byte per row, since round 5 "the Gaussian's key <= the stop
+key of the row's tile", evaluated by both kernels with the same expression).  The projection backward sums a Gaussian's existing rows.  For a Gaussian beyond GS_PB_SH_BIG rows the
 pre-pass -- sixteen waves, each adding a sixteenth of the region's existing rows in ascending order, a fixed pairwise tree over
 the sixteen partial sums -- stores the TOTAL in the region's first row; the walk then presents such a Gaussian with exactly that
-row, whatever its flag says, in every part and slice.  The model checks that (1) the walk's result equals the plain sum of
+row, whether or not that row's own pair exists, in every part and slice.  The model checks that (1) the walk's result equals the plain sum of
 the existing rows for small and big Gaussians alike, (2) it does so when the first row did not exist, when no row existed,
 and when the region is cut short by the workspace capacity, (3) running the walk twice (geometry part, colour part) reads the
 same totals."""
@@ -13,7 +14,7 @@ import numpy as np
 
 BIG = 64      # GS_PB_SH_BIG
 WAVES = 16
-RW = 56       # floats per row at degree 3
+RW = 64       # floats per row at degree 3 (whole 64-byte lines since round 5)
 
 
 def prepass(rows, flags, offsets, counts, max_pairs):

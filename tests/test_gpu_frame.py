@@ -184,6 +184,42 @@ def test_long_lists_composited_in_segments(gpu, use_sh):
         assert np.abs(ga - gb).max() <= 2e-4 * np.abs(gb).max() + 1e-30, name
 
 
+# tolerance of the seam test below: the element-wise criterion of gs_testutil with kappa x LONG_KAPPA_X -- a pixel's state
+# crosses the seam after 2,048 layers and the forward's segment kernels round the incoming transmittance differently from
+# the oracle's serial chain (test_long_lists_composited_in_segments: 2e-4 of the tensor maximum between the two HIP walks)
+LONG_KAPPA_X = 4.0
+LONG_L2 = 1e-4
+
+
+@pytest.mark.parametrize("sh_degree", [2, 3])
+def test_long_lists_sh_backward_hand_over_matches_oracle(gpu, sh_degree):
+    """in a frame flagged GS_FRAME_LONG_LISTS the SH backward on the matrix pipe takes a
+    tile's first 32 buckets and hands the rest of the list to raster_backward_pixel_sh_kernel, one wave per bucket
+    (raster_bwd.hip: launch_bwd, bucket_cap / bucket_first).  Until round 5 that seam was only compared with the serial
+    walk of the same build.  Here every tile's list is 40 - 80 buckets deep (2,600 - 5,000 Gaussians of opacity 0.0067:
+    pixels stop at T <= 1e-4 around the 4,600th layer, i.e. INSIDE the part the per-bucket kernel walks) and all five
+    gradients meet the oracle's draw_backward + index sum + projection backward (gaussian.cu:440-803, splatter.py:604-613,
+    gaussian.cu:1371-1576) element by element."""
+    scene, cam = case(30_000, 64, 64, seed=33, use_sh=True, sh_degree=sh_degree)
+    scene.opa[:] = -5.0
+    of = OracleFrame(scene, cam)
+    lens = np.diff(of.accum)
+    assert lens.min() > 32 * 64 + 4 * 64 and lens.max() > 4096, (lens.min(), lens.max())  # every tile crosses the seam
+    gimg = np.random.default_rng(12).normal(size=of.image.shape).astype(np.float32)
+    gimg, n_masked = of.robust_grad_image(gimg)
+    ref, scale = of.backward(gimg, with_scale=True)
+    params = to_torch(scene, gpu, requires_grad=True)
+    r = FrameRenderer(gpu, max_pairs=len(of.ids) + 64, training=True, auto_grow=False, long_lists=True)
+    img = r.render(*params, cam)
+    assert r._frame.flags & 16  # GS_FRAME_LONG_LISTS: the hand-over is on
+    assert r.stats().pairs == len(of.ids)
+    assert np.abs(img.detach().cpu().numpy() - of.image).max() < 1e-3
+    img.backward(torch.from_numpy(gimg).to(gpu))
+    report = assert_grads_close([t.grad.cpu().numpy() for t in params], ref, scale, f"long-list seam, degree {sh_degree}",
+                                kappa=LONG_KAPPA_X * 3e-5, l2=LONG_L2)
+    print(f"long-list seam, degree {sh_degree}: lists {lens.min()} .. {lens.max()}, masked pixels {n_masked};", report)
+
+
 @pytest.mark.parametrize("sort_mode", [2, "2t", "2s"])
 @pytest.mark.parametrize("n,W,H", [(10_000, 256, 256), (40_000, 32, 32)])
 def test_frame_forward_emitted_sorted_keys(gpu, n, W, H, sort_mode):

@@ -235,13 +235,76 @@ def test_slice_pipeline_equals_one_blocking_exchange_gloo(tmp_path):
     assert np.abs(r[0][0]).max() > 0
 
 
+def _api_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import warnings
+
+    from gs_dp import FlatGaussianParams
+
+    n = 1999
+    shapes = [(n, 3), (n, 4), (n, 3), (n,), (n, 27)]
+    params = [torch.from_numpy(np.random.default_rng(5).normal(size=s).astype(np.float32)) for s in shapes]
+    res = {}
+    for exchange in ("all_reduce", "reduce_scatter"):
+        outs = []
+        for forced in ("", "public"):
+            os.environ["GS_DP_COLLECTIVES"] = forced
+            flat = FlatGaussianParams(params, world_size=world, exchange=exchange, n_slices=3)
+            with warnings.catch_warnings(record=True) as wlist:
+                warnings.simplefilter("always")
+                api = flat.self_check()  # the closed-form pattern through the selected API; falls back if it must
+            assert api in ("grouped", "public") and (forced != "public" or api == "public")
+            res[f"{exchange}/{forced or 'auto'}"] = api + ("" if not wlist else " (fell back)")
+            for step in range(2):  # and a real exchange through whichever API was settled on
+                g = np.random.default_rng(77 * step + rank).normal(size=flat.flat_grad.numel()).astype(np.float32)
+                flat.flat_grad.copy_(torch.from_numpy(g))
+                for k in range(flat.n_slices):
+                    flat.begin_slice(k)
+                for k in range(flat.n_slices):
+                    flat.finish_slice(k)
+                    for lo, hi in flat.owned(flat.slice_ranges(k)):
+                        flat.flat_param[lo:hi].sub_(0.1 * flat.flat_grad[lo:hi])
+                    flat.begin_slice_gather(k)
+                flat.finish_gather()
+            assert flat._api() == api
+            outs.append(flat.flat_param.numpy().copy())
+        assert np.array_equal(outs[0], outs[1]), exchange  # grouped (or what it fell back to) == public, bit for bit
+        np.save(os.path.join(tmp, f"api_{exchange}_{rank}.npy"), outs[0])
+    os.environ.pop("GS_DP_COLLECTIVES", None)
+    if rank == 0:
+        import json
+
+        json.dump(res, open(os.path.join(tmp, "api.json"), "w"))
+    dist.destroy_process_group()
+
+
+def test_exchange_api_self_check_and_public_fallback_gloo(tmp_path):
+    """the exchange goes through private ProcessGroup entry points with in-place views.  gs_dp now
+    (a) checks one grouped exchange of a known pattern against its closed form before it trusts that path with world > 1,
+    (b) falls back to torch.distributed's public calls if the check (or the call) fails, and (c) can be forced onto the
+    public calls (GS_DP_COLLECTIVES=public).  Two gloo ranks: the check passes on some API in both modes, and a sliced
+    exchange + sharded update gives the same parameters bit for bit through either API and on both ranks."""
+    world, port = 2, 39500 + (os.getpid() % 2000)
+    mp.spawn(_api_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    import json
+
+    res = json.load(open(tmp_path / "api.json"))
+    assert set(res) == {"all_reduce/auto", "all_reduce/public", "reduce_scatter/auto", "reduce_scatter/public"}, res
+    assert res["all_reduce/public"] == "public" and res["reduce_scatter/public"] == "public"
+    for exchange in ("all_reduce", "reduce_scatter"):
+        a, b = (np.load(tmp_path / f"api_{exchange}_{k}.npy") for k in range(world))
+        assert np.array_equal(a, b)
+    assert np.array_equal(np.load(tmp_path / "api_all_reduce_0.npy"), np.load(tmp_path / "api_reduce_scatter_0.npy"))
+
+
 @pytest.mark.parametrize("n,world,n_slices", [(1, 1, None), (255, 1, 3), (1999, 2, 3), (7001, 1, 3), (100_000, 4, 5),
                                               (2_400_000, 8, None), (2_400_000, 1, None), (1_000_003, 3, 4)])
 def test_exchange_slices_tile_the_flat_buffer(n, world, n_slices):
     """gs_dp.FlatGaussianParams (CPU tensors, no process group): regions padded to a multiple of 4 x world rows, slices
     made of whole project slices that are multiples of 4 x world Gaussians, the slices' element ranges tile the buffer
-    exactly once, every range splits into equal float4-aligned shards; defaults: one slice on one rank, two from a
-    million Gaussians on with peers."""
+    exactly once, every range splits into equal float4-aligned shards; defaults: one slice on one rank, two with peers
+    (from 65,536 Gaussians on: ADVICE round 4)."""
     from gs_dp import ORDER, FlatGaussianParams, project_slice_size
 
     shapes = [(n, 3), (n, 4), (n, 3), (n,), (n, 3)]
@@ -256,7 +319,7 @@ def test_exchange_slices_tile_the_flat_buffer(n, world, n_slices):
     assert b[0] == 0 and b[-1] == flat.n_pad and all(x < y for x, y in zip(b, b[1:]))
     assert all(x % per == 0 and x % q == 0 for x in b[:-1])
     if n_slices is None:
-        assert flat.n_slices == (2 if (n >= 1_000_000 and world > 1) else 1)
+        assert flat.n_slices == (2 if (n >= 65_536 and world > 1) else 1)
     else:
         assert 1 <= flat.n_slices <= n_slices
     covered = torch.zeros(flat.flat_grad.numel(), dtype=torch.int32)

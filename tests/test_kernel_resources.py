@@ -131,3 +131,58 @@ def test_lds_budgets(kernels):
     sort = pick(kernels, "strip_sort_kernelILi2048ELb0E")
     assert sort[".group_segment_fixed_size"] * 4 <= 160 * 1024      # four workgroups per CU
     assert pick(kernels, "frame_project_count_kernelILb0E")[".group_segment_fixed_size"] + 8192 * 8 <= 160 * 1024
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# "The spills sit in the set-up, not in the hot loop" as an assertion.  The SH compositing
+# kernels and the SH backward on the matrix pipe are allocated 168 / 255 VGPRs and the allocator leaves a few spilled
+# registers (scratch_load / scratch_store); what matters is WHERE: a spill in the per-Gaussian / per-pixel-row loop is paid
+# hundreds of times per tile, one in the per-tile or per-group set-up once.  tools/isa_loops.py disassembles the code
+# objects of the built library, finds the loops (backward branches) and the innermost one that holds the kernel's
+# characteristic instructions; that loop must be free of scratch instructions.
+HOT_LOOPS = [
+    # (kernel name substrings, marker mnemonic prefix, markers the hot loop holds at least)
+    (("raster_forward_kernelILi27ELb1ELb0ELb0ELb0ELb0E",), "v_exp_f32", 32),   # SH degree 2 compositing (inference frame)
+    (("raster_forward_kernelILi27ELb1ELb1ELb0ELb0ELb0E",), "v_exp_f32", 32),   # ... training frame (checkpoints)
+    (("raster_forward_kernelILi48ELb1ELb0ELb0ELb0ELb0E",), "v_exp_f32", 32),   # SH degree 3
+    (("raster_forward_kernelILi48ELb1ELb1ELb0ELb0ELb0E",), "v_exp_f32", 32),
+    (("raster_backward_mfma_sh_kernelILi27ELi2E",), "v_mfma_f32_16x16x4", 12),  # the pixel-row loop: 16 Gaussians x 16 pixels
+    (("raster_backward_mfma_sh_kernelILi27ELi4E",), "v_mfma_f32_16x16x4", 12),
+    (("raster_backward_mfma_sh_kernelILi48ELi2E",), "v_mfma_f32_16x16x4", 12),
+    (("raster_backward_mfma_sh_kernelILi48ELi4E",), "v_mfma_f32_16x16x4", 12),
+    (("raster_forward_kernelILi3ELb1ELb0ELb0ELb0ELb0E",), "v_exp_f32", 8),     # rgb compositing: no scratch anywhere anyway
+    (("raster_backward_pixel_sh_kernelILi3ELb1ELb0E",), "v_exp_f32", 4),
+]
+
+
+@pytest.fixture(scope="module")
+def disassembly():
+    import shutil
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_loops
+
+    if not os.path.exists(LIB):
+        pytest.skip("libgs_amd.so is not built")
+    if not (os.path.exists(isa_loops.OBJDUMP) or shutil.which(isa_loops.OBJDUMP)):
+        pytest.skip("llvm-objdump not found")
+    return isa_loops, isa_loops.disassemble_library()
+
+
+@pytest.mark.parametrize("parts,marker,at_least", HOT_LOOPS, ids=[h[0][0] for h in HOT_LOOPS])
+def test_hot_loop_is_free_of_scratch_instructions(disassembly, parts, marker, at_least):
+    isa, dis = disassembly
+    hits = [k for k in dis if all(p in k for p in parts)]
+    assert len(hits) == 1, (parts, hits)
+    insns = dis[hits[0]]
+    # EVERY innermost loop with the marker count (the compositing kernels hold two copies of their loop: with and without
+    # the NaN-exact multiply) -- innermost = no other qualifying loop nested inside it
+    cands = [(lo, hi) for lo, hi in isa.loops(insns) if isa.count(insns, lo, hi, marker) >= at_least]
+    assert cands, (hits[0], "no loop with", at_least, marker)
+    inner = [(lo, hi) for lo, hi in cands if not any((l2, h2) != (lo, hi) and lo <= l2 and h2 <= hi for l2, h2 in cands)]
+    for lo, hi in inner:
+        n_scratch = isa.count(insns, lo, hi, "scratch_")
+        assert n_scratch == 0, (hits[0], f"hot loop [{lo}, {hi}] of {hi - lo + 1} instructions holds {n_scratch} scratch "
+                                         f"instructions: a spill inside the per-row / per-Gaussian loop")
+        assert hi - lo + 1 >= 100  # (a real loop body, not a two-instruction wait loop)

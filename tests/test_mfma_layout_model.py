@@ -138,3 +138,87 @@ def test_lane_model_equals_the_sequential_recursion():
     assert dead_rows == [2]
     for s in dead_rows:
         assert np.all(s_model[:, 16 * s:16 * s + 16] == 0.0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 5: how a group's 16 gradient rows leave the wave.  Lane (g, jq) = g + 16 jq holds the coefficient sums
+# acc[ch][e] = dL/dcoef[g][ch][4 jq + e] (fact (2) above) and -- after the quad sums -- every lane of Gaussian g holds its
+# geometry sums.  The rows are stored as whole 64-byte lines: for line `it`, lane l offers one 16-byte piece, destination lane
+# 4 r + q fetches the piece of lane r + 16 q (ds_bpermute) and stores it as float4 number 4 it + q of row r.  The row layout
+# this produces must be the one the readers index through (csrc/gs_frame_layout.h: gs_row_geo, gs_row_col, gs_row_compact --
+# restated here and checked against the header's text so that the two cannot drift apart).
+def _row_geo(cd, m):
+    return (12 + m if m < 4 else 28 + (m - 4)) if cd == 27 else m
+
+
+def _row_col(cd, c):
+    return 16 * (c // 9) + c % 9 if cd == 27 else (16 + c if cd == 48 else 7 + c)
+
+
+def _row_floats(cd):
+    return {3: 16, 27: 48, 48: 64}[cd]
+
+
+def _store_rows_model(cd, header, acc):
+    """header [16][7] (dx, dy, da, db, dc, dd, dopa) per Gaussian, acc [64][3][4] per lane -> rows [16][RW] as the kernel's
+    closing section writes them (NaN where nothing was written)."""
+    NB = cd // 3
+    RW = _row_floats(cd)
+    rows = np.full((16, RW), np.nan)
+    h0 = lambda g: [header[g, 0], header[g, 1], header[g, 2], header[g, 3]]  # noqa: E731
+    h1 = lambda g: [header[g, 4], header[g, 5], header[g, 6], 0.0]  # noqa: E731
+    lines = range(4) if NB == 16 else range(3)
+    for it in lines:
+        offered = np.zeros((64, 4))
+        for l in range(64):
+            g, jq = l & 15, l >> 4
+            if NB == 16:
+                if it == 0:
+                    offered[l] = h0(g) if jq == 0 else h1(g) if jq == 1 else [0, 0, 0, 0]
+                else:
+                    offered[l] = acc[l, it - 1]
+            else:
+                ch = it
+                offered[l] = (h0(g) if ch == 0 else h1(g) if ch == 1 else [0, 0, 0, 0]) if jq == 3 else acc[l, ch]
+        for l in range(64):  # destination lanes
+            dr, dq = l >> 2, l & 3
+            rows[dr, 4 * (4 * it + dq):4 * (4 * it + dq) + 4] = offered[dr + 16 * dq]
+    return rows
+
+
+def test_row_store_permutation_writes_the_documented_layout():
+    import os
+    import re
+
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "3d-gaussian-splatting_amd", "csrc",
+                            "gs_frame_layout.h")).read()
+    # the header's definitions are the ones restated above
+    assert "return color_dim == 27 ? (m < 4 ? 12 + m : 28 + (m - 4)) : m;" in hdr
+    assert "return color_dim == 27 ? 16 * (c / 9) + c % 9 : color_dim == 48 ? 16 + c : 7 + c;" in hdr
+    assert re.search(r"color_dim == 3 \? 16 : color_dim == 27 \? 48 : color_dim == 48 \? 64", hdr)
+    rng = np.random.default_rng(11)
+    for cd in (27, 48):
+        NB, RW = cd // 3, _row_floats(cd)
+        header = rng.normal(size=(16, 7))
+        dcoef = rng.normal(size=(16, 3, NB))
+        acc = np.zeros((64, 3, 4))
+        for l in range(64):
+            g, jq = l & 15, l >> 4
+            for ch in range(3):
+                for e in range(4):
+                    k = 4 * jq + e
+                    acc[l, ch, e] = dcoef[g, ch, k] if k < NB else 0.0  # (k >= NB: the SH table's zero entries)
+        rows = _store_rows_model(cd, header, acc)
+        assert not np.isnan(rows).any()  # every float of every line is written: whole lines, nothing left to a memset
+        used = np.zeros(RW, bool)
+        for m in range(7):
+            assert np.array_equal(rows[:, _row_geo(cd, m)], header[:, m]), (cd, "geometry", m)
+            used[_row_geo(cd, m)] = True
+        for c in range(cd):
+            assert np.array_equal(rows[:, _row_col(cd, c)], dcoef[:, c // NB, c % NB]), (cd, "coefficient", c)
+            assert not used[_row_col(cd, c)]
+            used[_row_col(cd, c)] = True
+        assert np.all(rows[:, ~used] == 0.0)  # padding floats are exact zeros (the pre-pass adds whole rows)
+        assert used.sum() == 7 + cd
+    # rgb rows (one line) keep the plain order
+    assert [_row_geo(3, m) for m in range(7)] == list(range(7)) and [_row_col(3, c) for c in range(3)] == [7, 8, 9]
