@@ -25,14 +25,21 @@ Rank 0 prints ONE JSON line (driver contract):
                        bytes per launch from the committed PMC passes (profiles/traffic.json) with `correction` = how
                        FETCH_SIZE was turned into bytes for this kernel's access pattern and `traffic_bounds`;
   stages               every stage of the frame: ms, algorithmic bytes (SURVEY.md 8d), GB/s, fraction of HBM peak;
+  cfg1                 BASELINE.json configs[0] (10 k Gaussians, 256 x 256, forward): GPU FPS next to the CPU oracle timed on
+                       the SAME scene (BASELINE.md section 3 plans exactly this pair);
   cfg2                 BASELINE.json configs[1] (376,467 Gaussians, 1080p): FPS + the same roofline object;
   extra                training step (forward + L1/SSIM loss + backward + fused Adam) at cfg2 and at 2.4 M Gaussians -- timed
-                       with tools/train_timing.py: the same iterations per block restored from a snapshot, 15 blocks, on the
-                       FIXED scene (learning rate 0: the full step runs, the parameters stay put) with the moving-scene
-                       figure (the reference's learning rates) next to it --, a 300-iteration fit of the cfg3 scene, cfg4
+                       with tools/train_timing.py: the same iterations per block restored from a snapshot, 15 blocks.
+                       `iters_per_s` is the MOVING scene (the reference's learning rates: what a training run sees; round 5,
+                       ADVICE round 4), `fixed_scene` the same step with learning rate 0 (the full step runs, the parameters
+                       stay put: the repeatability diagnostic, and the scene the render figures are quoted on), each with its
+                       per-stage split and `moving_minus_fixed_ms` --, a 300-iteration fit of the cfg3 scene, cfg4
                        (2.4 M, SH) forward / backward stage times and the wall clock of the free-running loop -- its
                        `roofline_raster_backward_kernel` also carries `mfma`: the fp32 MFMA flops of the SH backward on
-                       the matrix pipe / its time against the 157.3 TFLOP/s matrix peak --, three frames in flight;
+                       the matrix pipe, counted from the pixel-row steps the kernel EXECUTED (a device counter: rows whose
+                       pixels had all stopped are left out) / its time against the 157.3 TFLOP/s matrix peak --, `soak`:
+                       the densifying training run of tools/soak.py (376 k Gaussians growing, rgb / SH degree 2 / 3), rate
+                       per block of 100 iterations --, three frames in flight;
   multi_gpu            (under torchrun, or with --force-collective on one rank) ranks seen, gradient buffer bytes, and per
                        scene (rgb, SH) and exchange mode: training views/s over all ranks, the exchange alone, bus
                        bandwidth, and exposed_ms = the step with its exchange minus the same step without it in the same
@@ -59,7 +66,7 @@ import torch.distributed as dist
 sys.path.insert(0, os.path.join(ROOT, "tools"))  # train_timing.py, compat_fps.py (measurement helpers, not product code)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-ALL_LEGS = ("headline", "cfg2", "train", "fit", "cfg4", "pipelined", "compat", "multi_gpu", "cpu")
+ALL_LEGS = ("headline", "cfg1", "cfg2", "train", "fit", "cfg4", "soak", "pipelined", "compat", "multi_gpu", "cpu")
 
 
 def log(*a):
@@ -98,7 +105,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-collective", action="store_true",
                     help="N = 1: still run the gradient all-reduce (through RCCL when launched under torchrun)")
+    ap.add_argument("--quick", action="store_true",
+                    help="test hook (tests/test_gpu_train.py runs this file's multi_gpu leg under two ranks): three blocks "
+                         "per timing instead of 15, the multi_gpu leg on the headline scene only -- not a measurement")
     args = ap.parse_args()
+    # test hooks: GS_BENCH_BACKEND=gloo + GS_BENCH_SHARE_GPU=1 run N ranks on ONE device (RCCL refuses two ranks on a
+    # device; gloo stages device tensors through the host) so that the N > 1 code path of this file -- rank-symmetric
+    # legs, barriers, max over ranks, the multi_gpu leg -- is executed on the one-GPU boxes the builder has
+    backend = os.environ.get("GS_BENCH_BACKEND", "nccl")
+    share_gpu = os.environ.get("GS_BENCH_SHARE_GPU", "") == "1"
     legs = set(ALL_LEGS if args.legs == "all" else args.legs.split(","))
     if args.no_extra:
         legs = {"headline"}
@@ -110,7 +125,7 @@ def main():
         sys.exit("bench.py needs a HIP device (there is no CPU fallback)")
     if args.gpus < 1:
         sys.exit("--gpus must be >= 1")
-    if torch.cuda.device_count() < args.gpus:
+    if torch.cuda.device_count() < args.gpus and not share_gpu:
         sys.exit(f"bench.py --gpus {args.gpus} needs {args.gpus} visible devices, found {torch.cuda.device_count()}")
     if args.gpus > 1 and "RANK" not in os.environ:
         # launched blind (`python bench.py --gpus N`): one rank per GPU under torch.distributed.run, rank 0 prints the
@@ -134,7 +149,7 @@ def main():
     os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
@@ -150,7 +165,10 @@ def main():
             with socket.socket() as so:
                 so.bind(("127.0.0.1", 0))
                 os.environ["MASTER_PORT"] = str(so.getsockname()[1])
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from gs_frame import FrameRenderer
     from gs_scene import CONFIGS, make_camera, make_scene
@@ -201,7 +219,7 @@ def main():
             fn()
         first = time_block(fn, steps)
         if repeats is None:
-            repeats = int(min(400, max(15, min_seconds / max(first, 1e-6) + 1)))
+            repeats = 3 if args.quick else int(min(400, max(15, min_seconds / max(first, 1e-6) + 1)))
         blocks = [first] + [time_block(fn, steps) for _ in range(repeats - 1)]
         return statistics.median(blocks), blocks
 
@@ -358,6 +376,43 @@ def main():
     del head["renderer"]
     torch.cuda.empty_cache()
 
+    # ---------------------------------------------------------------- BASELINE configs[0]: the reference's CPU-runnable case
+    if "cfg1" in legs and args.config != "cfg1" and rank == 0 and world == 1:
+        def _leg_cfg1():
+            # 10 k Gaussians, 256 x 256, no SH, forward: the GPU path and the CPU oracle on the SAME scene (BASELINE.md
+            # section 3: "CPU oracle (ours) on config 1" next to "MI355X, this repo, config 1").  A frame here is a chain of
+            # five dependent launches of a few microseconds each: the figure is latency, not throughput.
+            c1 = render_leg("cfg1", max(args.steps, 200), max(args.warmup, 20))
+            n1, W1, H1, _ = CONFIGS["cfg1"]
+            res = {"workload": workload_name("cfg1", c1["stats"]), "render_fps": round(c1["fps"], 2),
+                   "ms_per_frame": round(c1["ms"], 4), "repeats": c1["repeats"],
+                   "ms_per_frame_min": round(c1["ms_min"], 4), "ms_per_frame_max": round(c1["ms_max"], 4),
+                   "visible": c1["stats"].visible, "tile_pairs": c1["stats"].pairs,
+                   "host_us_per_frame": round(c1["host_us"], 1), "binning_variant": c1["renderer"].binning_variant(),
+                   "stages": c1["stages"], "roofline": c1["roofline"]}
+            if "cpu" in legs:
+                import oracle  # the checker, timed as the "port" baseline -- never on the product path
+                from gs_geometry import RayBasis, TileGrid
+
+                sc, cam = c1["scene"], c1["cam"]
+                grid = TileGrid(W1, H1, cam.focal_x, cam.focal_y)
+                rays = RayBasis.from_camera(cam.rot, cam.tran, grid.padded_height, grid.padded_width, cam.focal_x, cam.focal_y)
+                t0, frames = time.perf_counter(), 0
+                while time.perf_counter() - t0 < 3.0 or frames < 5:
+                    oracle.render_forward(sc.pos, sc.quat, sc.scale, sc.opa, sc.rgb, cam.rot, cam.tran, cam.near, W1, H1,
+                                          cam.focal_x, cam.focal_y, 0.05, use_sh=False, rays_o=rays.rays_o,
+                                          lefttop=rays.lefttop, vdx=rays.dx, vdy=rays.dy)
+                    frames += 1
+                cpu_dt = time.perf_counter() - t0
+                res["cpu_baseline"] = {"value": round(frames / cpu_dt, 3), "unit": "frames/s", "cores": oracle.num_threads(),
+                                       "kind": "port", "sample": f"{frames} forward frames of cfg1 (oracle/gs_oracle.c)"}
+                res["gpu_over_cpu"] = round(c1["fps"] / (frames / cpu_dt), 1)
+            out["cfg1"] = res
+            del c1
+            torch.cuda.empty_cache()
+
+        guarded("cfg1", _leg_cfg1)
+
     # ---------------------------------------------------------------- BASELINE configs[1]
     if "cfg2" in legs and args.config != "cfg2":
         def _leg_cfg2():
@@ -375,8 +430,8 @@ def main():
         guarded("cfg2", _leg_cfg2)
 
     # ---------------------------------------------------------------- training step (train.py:84-185, no densification)
-    def train_leg(cfg, params, cam, pairs, k, force=False, exchange="all_reduce", collective=True, repeats=15,
-                  n_slices=None, fixed_scene=True):
+    def train_leg(cfg, params, cam, pairs, k, force=False, exchange="all_reduce", collective=True,
+                  repeats=3 if args.quick else 15, n_slices=None, fixed_scene=True):
         """forward (checkpointing) -> L1 + 0.1 SSIM loss and gradient -> backward -> exchange of the flat gradient buffer
         (N > 1, or forced) -> fused Adam.  Timed with the snapshot / restore protocol of tools/train_timing.py: 30 warm-up
         iterations, then the SAME k iterations `repeats` times (everything the step changes is restored between blocks,
@@ -412,6 +467,7 @@ def main():
             lossk = tr._loss_for(Hc, Wc)
             pf = [rt.profile_forward(*flat.params, cam)["total"] for _ in range(8)][3:]
             pb = [rt.profile_backward(lossk(img, target)) for _ in range(8)][3:]
+            detail["composited_steps"] = rt.composited_steps()  # (Gaussian, tile) steps of this scene state's frame
             detail["forward_ms"] = round(statistics.median(pf), 4)
             detail["backward_stage_ms"] = {key: round(statistics.median(p[key] for p in pb), 4) for key in pb[0]}
 
@@ -441,31 +497,42 @@ def main():
                                "and step counter restored from a snapshot between blocks (tools/train_timing.py)")
         return world * k / dtt, dtt / k * 1e3, detail, tr
 
+    def train_pair(cfg, params, cam, pairs, k, what):
+        """The training step on the MOVING scene (headline: `iters_per_s`) and on the FIXED scene, with both stage splits."""
+        ips_f, ms_f, det_f, tr = train_leg(cfg, params, cam, pairs, k)
+        del tr
+        ips_m, ms_m, det_m, tr = train_leg(cfg, params, cam, pairs, 25, fixed_scene=False)
+        del tr
+        res = {"iters_per_s": round(ips_m, 2), "ms_per_iter": round(ms_m, 4),
+               "headline": "moving scene: the reference's learning rates, iterations 30 .. 55 against a noisy target -- what a "
+                           "training run sees (ADVICE round 4); fixed_scene = the same step with learning rate 0",
+               "iters_per_s_moving_scene": round(ips_m, 2), "iters_per_s_fixed_scene": round(ips_f, 2),
+               **det_m, "fixed_scene": {"iters_per_s": round(ips_f, 2), "ms_per_iter": round(ms_f, 4), **det_f},
+               "step": what}
+        if rank == 0 and "backward_stage_ms" in det_m and "backward_stage_ms" in det_f:
+            # where the moving scene's extra time goes (hipEvent stage times of one frame of each scene's final state)
+            diff = {"forward": round(det_m["forward_ms"] - det_f["forward_ms"], 4),
+                    "loss": round(det_m["loss_ms"] - det_f["loss_ms"], 4), "adam": round(det_m["adam_ms"] - det_f["adam_ms"], 4)}
+            for key in det_m["backward_stage_ms"]:
+                diff["backward." + key] = round(det_m["backward_stage_ms"][key] - det_f["backward_stage_ms"].get(key, 0.0), 4)
+            res["moving_minus_fixed_ms"] = diff
+            res["composited_steps"] = {"moving": det_m.get("composited_steps"), "fixed": det_f.get("composited_steps")}
+        return res
+
     if "train" in legs:
         def _leg_train():
             k = None  # iterations per timed block: train_timing.block_length (25, or ~30 ms of work if that is more)
             _, cam2, params2 = (head_scene, head_cam, head_params) if args.config == "cfg2" else load("cfg2")
             r2, st2 = sized_renderer(params2, cam2, training=False)
             del r2
-            ips, ms, detail, tr = train_leg("cfg2", params2, cam2, st2.pairs, k)
-            del tr
-            ips_m, ms_m, det_m, tr = train_leg("cfg2", params2, cam2, st2.pairs, 25, fixed_scene=False)
-            detail["moving_scene"] = {"iters_per_s": round(ips_m, 2), "ms_per_iter": round(ms_m, 4),
-                                      "iters_per_block": det_m.get("iters_per_block"), "scene": det_m.get("scene")}
-            extra["train_cfg2"] = {"iters_per_s": round(ips, 2), "ms_per_iter": round(ms, 4), **detail,
-                                   "step": "forward + L1/SSIM loss (w=0.1) + backward + grad all-reduce (N>1) + fused "
-                                           "Adam, one view per GPU, 376,467 Gaussians, 1080p"}
-            del tr, params2
+            extra["train_cfg2"] = train_pair("cfg2", params2, cam2, st2.pairs, k,
+                                             "forward + L1/SSIM loss (w=0.1) + backward + grad all-reduce (N>1) + fused "
+                                             "Adam, one view per GPU, 376,467 Gaussians, 1080p")
+            del params2
             torch.cuda.empty_cache()
             if not CONFIGS[args.config][3]:
-                ips, ms, detail, tr = train_leg(args.config, head_params, head_cam, st.pairs, k)
-                del tr
-                ips_m, ms_m, det_m, tr = train_leg(args.config, head_params, head_cam, st.pairs, 25, fixed_scene=False)
-                detail["moving_scene"] = {"iters_per_s": round(ips_m, 2), "ms_per_iter": round(ms_m, 4),
-                                          "iters_per_block": det_m.get("iters_per_block"), "scene": det_m.get("scene")}
-                extra["train_headline_scene"] = {"iters_per_s": round(ips, 2), "ms_per_iter": round(ms, 4), **detail,
-                                                 "step": f"the same step on the headline scene ({n} Gaussians)"}
-                del tr
+                extra["train_headline_scene"] = train_pair(args.config, head_params, head_cam, st.pairs, k,
+                                                           f"the same step on the headline scene ({n} Gaussians)")
                 torch.cuda.empty_cache()
 
         guarded("train", _leg_train)
@@ -499,6 +566,7 @@ def main():
                     flat.finish_gather()
                     tr.renderer.forward_abandon()
                     res["bucket_bytes"] = flat.bucket_bytes
+                    res["collective_api"] = "plain per-range all-reduces" if flat._plain_collectives() else flat._api()
 
                     def exchange_only():
                         # the collectives of one step, nothing else, as gs_train.Trainer.train_step issues them
@@ -547,12 +615,13 @@ def main():
                 return res
 
             head_res = one_scene(args.config, args.config, head_params, head_cam, st.pairs)
-            _, cam4, p4 = load("cfg4")
-            r4, st4 = sized_renderer(p4, cam4, training=False)
-            del r4
-            one_scene("cfg4_sh_deg2", "cfg4", p4, cam4, st4.pairs)
-            del p4
-            torch.cuda.empty_cache()
+            if not args.quick:
+                _, cam4, p4 = load("cfg4")
+                r4, st4 = sized_renderer(p4, cam4, training=False)
+                del r4
+                one_scene("cfg4_sh_deg2", "cfg4", p4, cam4, st4.pairs)
+                del p4
+                torch.cuda.empty_cache()
             best = max(head_res["modes"], key=lambda m: head_res["modes"][m]["train_views_per_s"])
             mg.update(modes=head_res["modes"], bucket_bytes=head_res["bucket_bytes"], best_mode=best,
                       train_views_per_s=head_res["modes"][best]["train_views_per_s"],
@@ -564,6 +633,7 @@ def main():
                                  "mean all-reduce of the slice's five gradient ranges + replicated fused Adam; "
                                  "reduce_scatter = mean reduce-scatter + fused Adam over the rank's shards + all-gather "
                                  "of the parameters; the next frame's project stage follows the optimizer slice by slice",
+                      backend=dist.get_backend(), collective_api=head_res.get("collective_api"),
                       note="1-GPU boxes only for the builder: no 2/4/8-GPU curve measured before the driver's SCALE run")
             out["multi_gpu"] = mg
 
@@ -665,7 +735,15 @@ def main():
                 # that x 16 pixel rows; the matrix pipe's fp32 peak equals the vector peak (157.3 TFLOP/s) and on gfx950
                 # an MFMA does not overlap the VALU stream of its SIMD (tools/ubench/mfma_valu_overlap.hip)
                 steps4 = r4.composited_steps()
-                mfma_flops = steps4 * (3 * ((C4 // 3) // 4) + 12) * 2048
+                r4.forward(*p4, cam4)
+                r4.backward(g4)
+                # pixel-row steps (16 Gaussians x 16 pixels) the kernel EXECUTED: a device counter per wave (round 5).  A
+                # composited (Gaussian, tile) step is 16 pixel rows / 16 Gaussians = one row step if no row is skipped;
+                # rows whose 16 pixels have all stopped are left out (the count by composited steps
+                # overstated the flops by the skipped share)
+                rows4 = r4.executed_row_steps()
+                mfma_per_row = 3 * ((C4 // 3) // 4) + 12
+                mfma_flops = rows4 * mfma_per_row * 2048
                 cfg4[f"sh_degree_{deg}"] = {
                     "coefficients": C4, "visible": V4, "tile_pairs": M4,
                     "forward_ms": round(f_ms, 3), "backward_ms": round(b_ms, 3),
@@ -683,7 +761,10 @@ def main():
                         b_rbw, rb_ms, kernel=f"raster_backward_mfma_sh_kernel<{C4}>", traffic=tr_bw,
                         traffic_frac=None if tr_bw is None else round(tr_bw / (rb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                         issue_busy=busy_bw, composited_steps=steps4,
-                        mfma={"bound": "mfma", "flops": int(mfma_flops),
+                        traffic_source=tk.get("source"),
+                        mfma={"bound": "mfma", "flops": int(mfma_flops), "executed_row_steps": rows4,
+                              "row_steps_if_none_skipped": steps4,  # = composited (Gaussian, tile) steps (ragged groups aside)
+                              "rows_skipped_frac": round(1.0 - rows4 / max(steps4, 1), 4),
                               "achieved": round(mfma_flops / (rb_ms * 1e-3) / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s",
                               "frac": round(mfma_flops / (rb_ms * 1e-3) / 1e12 / 157.3, 4),
                               "what": "fp32 MFMA flops of the kernel / its time; MFMAs and VALU instructions of a SIMD "
@@ -693,6 +774,25 @@ def main():
             extra["cfg4_2p4M_sh_fwd_bwd"] = cfg4
 
         guarded("cfg4", _leg_cfg4)
+
+    # ---------------------------------------------------------------- training where it is slow: the densifying run
+    if "soak" in legs and rank == 0 and world == 1:
+        def _leg_soak():
+            # tools/soak.py's training run: 376,467 Gaussians growing under the reference's densification schedule
+            # (train.py:86-91, 141-190; clone + split every 100 iterations), nine views, a random one per iteration,
+            # colours perturbed at the start -- opacities fall, Gaussians blow up, lists grow: the state a real run is in.
+            # The rate is reported per block of 100 iterations (one device synchronisation per block).
+            from soak import training_soak
+
+            sk = {}
+            for deg, iters in ((0, 1500), (2, 1500), (3, 1500)):
+                r_ = training_soak(dev, deg, iters)
+                r_.pop("iters_per_s_blocks", None)
+                sk["rgb" if deg == 0 else f"sh_degree_{deg}"] = r_
+                torch.cuda.empty_cache()
+            extra["soak_densifying"] = sk
+
+        guarded("soak", _leg_soak)
 
     # ---------------------------------------------------------------- zero-change integration mode
     if "compat" in legs and rank == 0 and world == 1:

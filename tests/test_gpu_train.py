@@ -562,3 +562,41 @@ def test_viewer_hook_and_checkpoint(gpu, tmp_path):
     tr2.load_checkpoint(path)
     assert all(torch.equal(a, b) for a, b in zip(tr2.flat.params, tr.flat.params))
     assert torch.equal(tr2.test(0)["image"], m["image"])
+
+
+def test_bench_multi_gpu_leg_runs_under_two_ranks(gpu, tmp_path):
+    """bench.py's own N > 1 path -- `python -m torch.distributed.run --nproc-per-node 2 bench.py
+    --gpus 2 ...`, the driver's SCALE command line -- had never executed with more than one rank anywhere: the builder's
+    boxes have one GPU and RCCL refuses two ranks on a device.  With the file's test hooks (gloo as the backend, both
+    ranks on this GPU) the very same code runs: rank-symmetric legs, barriers, max over ranks, one view per rank, and the
+    multi_gpu leg with both exchange modes, the two-slice pipeline and the slice sweep.  Checked: ONE JSON line from rank
+    0, n_gpus = 2, two ranks seen by a collective, every mode timed, no leg failed.  Not a measurement (--quick)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 40500 + (os.getpid() % 1500)
+    env = dict(os.environ, GS_BENCH_BACKEND="gloo", GS_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+           "--config", "cfg1", "--legs", "headline,multi_gpu", "--quick"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]  # rank 0 alone prints, exactly one line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["warmup"] == 2 and out["value"] > 0
+    assert out["scaling"] == "weak" and "x2" in out["config"]["parallelism"]
+    assert "leg_errors" not in out, out.get("leg_errors")
+    mg = out["multi_gpu"]
+    assert mg["ranks_seen"] == 2 and mg["backend"] == "gloo"
+    scene = mg["scenes"]["cfg1"]
+    for mode in ("all_reduce", "reduce_scatter"):
+        m = scene["modes"][mode]
+        assert m["train_views_per_s"] > 0 and np.isfinite(m["exposed_ms"]) and m["exchange_ms"] > 0 and m["busbw_GBs"] > 0
+    assert scene["two_slice_pipeline"]["n_slices"] == 2
+    assert set(scene["slices_sweep_all_reduce"]) >= {"1"}
+    # sharded optimizer: half the state per rank
+    assert scene["modes"]["reduce_scatter"]["optimizer_state_bytes_per_rank"] * 2 <= \
+        scene["modes"]["all_reduce"]["optimizer_state_bytes_per_rank"] + 64
