@@ -1127,6 +1127,40 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         };
+        // Which of this lane's rows exist (at most 64: a Gaussian beyond GS_PB_SH_BIG = 64 rows presents one), once for both
+        // passes: key(g) <= the stop key of the row's tile (round 5; until then a flag byte per row, written by the raster
+        // backward and cleared by a memset per frame).  Stop keys eight at a time, the tile advanced row by row, as in the
+        // rgb branch above.
+        unsigned long long written_all = 0;
+        if (big_sh) {
+            written_all = nrow ? 1ull : 0ull;
+        } else if (nrow) {
+            const uint32_t m = nrow < 64 ? (uint32_t)nrow : 64u;  // (nrow <= GS_PB_SH_BIG = 64 here)
+            uint32_t iy = my_y0, ix = my_x0;
+            for (uint32_t j0 = 0; j0 < m; j0 += 8) {
+                uint32_t sd[8], tx8[8], ty8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool in = j0 + j < m;
+                    tx8[j] = ix;
+                    ty8[j] = iy;
+                    sd[j] = in ? stop_depth[iy * P.ntx + ix] : 0u;
+                    if (in && ++ix == my_x1) {
+                        ix = my_x0;
+                        ++iy;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool in = j0 + j < m;
+                    bool yes = in && rc.z < sd[j];
+                    if (in && rc.z == sd[j]) yes = (uint32_t)pid <= stop_id[ty8[j] * P.ntx + tx8[j]];
+                    if (yes && P.cull_method == 0 && !gs_dist_listed(g.x, g.y, tx8[j], ty8[j], D)) yes = false;
+                    if (yes) written_all |= 1ull << (j0 + j);
+                }
+            }
+        }
+        static_assert(GS_PB_SH_BIG <= 64, "one 64-bit row mask per Gaussian");
         for (int pass = 0; pass < GS_PB_SH_PASSES; ++pass) {
         const int own0 = pass * OWN;
         const bool mine_pass = lane >= own0 && lane < own0 + OWN;
@@ -1135,40 +1169,7 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
         float acc = 0.f;
         int cur = -1;  // owner whose sums `acc` holds (wave-uniform)
         for (uint32_t k0 = 0; k0 < maxrows; k0 += 64) {  // windows of 64 rows per owner (uniform trip count)
-            unsigned long long written = 0;
-            if (k0 < nrow && mine_pass && big_sh) {
-                written = 1ull;
-            } else if (k0 < nrow && mine_pass) {
-                // which of the rows [k0, k0 + m) exist: key(g) <= the stop key of the row's tile (round 5; until then a flag
-                // byte per row, written by the raster backward and cleared by a memset per frame).  Stop keys eight at a
-                // time, the tile advanced row by row, as in the rgb branch above.  (Gaussians beyond GS_PB_SH_BIG = 64 rows
-                // present one row: k0 is 0 in practice.)
-                const uint32_t m = nrow - k0 < 64 ? (uint32_t)(nrow - k0) : 64u;
-                const uint32_t wdt = my_x1 - my_x0;
-                uint32_t iy = my_y0 + k0 / wdt, ix = my_x0 + k0 % wdt;
-                for (uint32_t j0 = 0; j0 < m; j0 += 8) {
-                    uint32_t sd[8], tx8[8], ty8[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const bool in = j0 + j < m;
-                        tx8[j] = ix;
-                        ty8[j] = iy;
-                        sd[j] = in ? stop_depth[iy * P.ntx + ix] : 0u;
-                        if (in && ++ix == my_x1) {
-                            ix = my_x0;
-                            ++iy;
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const bool in = j0 + j < m;
-                        bool yes = in && rc.z < sd[j];
-                        if (in && rc.z == sd[j]) yes = (uint32_t)pid <= stop_id[ty8[j] * P.ntx + tx8[j]];
-                        if (yes && P.cull_method == 0 && !gs_dist_listed(g.x, g.y, tx8[j], ty8[j], D)) yes = false;
-                        if (yes) written |= 1ull << (j0 + j);
-                    }
-                }
-            }
+            const unsigned long long written = (k0 == 0 && mine_pass) ? written_all : 0ull;
             const uint32_t mine = (uint32_t)__popcll(written);
             const uint32_t incl = gs_wave_incl_scan_u32(mine), first = incl - mine;
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);

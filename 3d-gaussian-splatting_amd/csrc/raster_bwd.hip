@@ -1249,6 +1249,49 @@ __device__ __forceinline__ void gs_row_scan_add4(float v[4]) {
 #endif
 }
 
+// Inclusive prefix sum over the 16 lanes of a DPP row for the lane's four pixels, OUT of place: the first step's
+// bound_ctrl:0 reads 0 where a lane has no source -- the sum's identity --, so `in` survives (round 5: the unscanned w gc
+// gives s = w gc - rho beta one instruction cheaper than dL/dalpha alpha).
+__device__ __forceinline__ void gs_row_scan_add4_oop(float out[4], const float in[4]) {
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "v_add_f32_dpp %1, %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "v_add_f32_dpp %2, %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "v_add_f32_dpp %3, %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+                 : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3])
+                 : "v"(in[0]), "v"(in[1]), "v"(in[2]), "v"(in[3]));
+}
+// T in front of the lane's Gaussian = T_in x the inclusive product scan of the lane to the left (row_shr:1); the row's first
+// lane has no source: the DPP bound check disables it and it keeps T_in.  t: T_in on entry, the result on exit.
+__device__ __forceinline__ void gs_row_excl_mul4(float t[4], const float scanned[4]) {
+    asm volatile("s_nop 1\n\t"
+                 "v_mul_f32_dpp %0, %4, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mul_f32_dpp %1, %5, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mul_f32_dpp %2, %6, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mul_f32_dpp %3, %7, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3])
+                 : "v"(scanned[0]), "v"(scanned[1]), "v"(scanned[2]), "v"(scanned[3]));
+}
+// Round 5 instruction diet of the SH row loop (first used by raster_backward_rows_kernel below): the opacity in the
+// exponent's constant term (no G x opacity product), T in front of the Gaussian as one DPP multiply (the builtin costs
+// v_mov 1.0 + v_mov_dpp + v_mul), s = w gc - rho beta.  A/B switch (tools/ab_variants.py).
+#ifndef GS_BWD_MFMA_DIET
+#define GS_BWD_MFMA_DIET 1
+#endif
+
 #ifndef GS_BWD_MFMA_PF
 #define GS_BWD_MFMA_PF 1
 #endif
@@ -1418,6 +1461,8 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
             float cA, cB, cC;
             raster_conic(g, cA, cB, cC);
             const float opa = valid ? g.opa : 0.f;
+            const float lopa = fmaxf(__log2f(g.opa), -200.0f);
+            (void)lopa;
             uint32_t slot = GS_NO_SLOT;
             if (valid) {
                 const uint4 rc = O.rects[gid];
@@ -1434,6 +1479,11 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
                 const float dxi = raster_pixel_coord(tx * 16 + 4 * jq + i, G.padW, G.focal_x) - g.x;
                 bdx[i] = cB * dxi;
                 adx2[i] = cA * dxi * dxi;
+#if GS_BWD_MFMA_DIET
+                // q' = q - log2 sigma(opa): alpha = 2^-q'.  A padded entry: q' = 1e30 => alpha = 0 exactly, 0 x 1e30 = 0 in
+                // the sum of s q'; an opacity that underflowed to 0: 2^-(q + 200) is flushed to 0
+                adx2[i] = valid ? adx2[i] - lopa : 1e30f;
+#endif
             }
             const float gy = g.y;
             f4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -1495,7 +1545,7 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
                 for (int i = 0; i < 4; ++i) {
                     q[i] = fmaf(fmaf(cC, dy, -bdx[i]), dy, adx2[i]);
                     Gv[i] = gs_exp2(-q[i]);
-                    araw[i] = Gv[i] * opa;
+                    araw[i] = GS_BWD_MFMA_DIET ? Gv[i] : Gv[i] * opa;  // (diet: q is q', 2^-q' is alpha itself)
                     // (0 <= 1 - alpha <= 1 holds anyway for sane records; written as a clamp to [0, 1] it is the clamp
                     // modifier of the subtraction, one instruction -- and a NaN / > 1 alpha of a broken record stops the pixel)
                     pin[i] = fminf(fmaxf(1.0f - araw[i], 0.f), 1.0f);
@@ -1504,9 +1554,14 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
                 gs_row_scan_mul4(pin);
                 float Tb[4], alpha[4], w[4], gc[4], wg[4], cc[3][4];
                 bool live[4];
+#if GS_BWD_MFMA_DIET
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Tb[i] = Tin[i];
+                gs_row_excl_mul4(Tb, pin);
+#endif
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    Tb[i] = Tin[i] * gs_dpp<0x111>(1.0f, pin[i]);
+                    if (!GS_BWD_MFMA_DIET) Tb[i] = Tin[i] * gs_dpp<0x111>(1.0f, pin[i]);
                     live[i] = Tb[i] > GS_T_STOP;
                     alpha[i] = live[i] ? araw[i] : 0.f;
                     w[i] = alpha[i] * Tb[i];
@@ -1518,21 +1573,32 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
                     Tout[i] = Tin[i] * pin[i];  // (meaningful in the lanes of Gaussian 15: the whole group's product)
                 }
                 // rho behind this Gaussian: rho_in minus the inclusive prefix sum of w gc
+#if GS_BWD_MFMA_DIET
+                float wsum[4];
+                gs_row_scan_add4_oop(wsum, wg);
+#else
                 gs_row_scan_add4(wg);
+                const float *wsum = wg;
+#endif
                 float ssum = 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float rho = Rin[i] - wg[i];
+                    const float rho = Rin[i] - wsum[i];
+#if GS_BWD_MFMA_DIET
+                    // s = dL/dalpha alpha = w gc - rho beta, beta = alpha / (1 - alpha + 1e-7): masked with alpha, like w
+                    const float sv = fmaf(-rho, alpha[i] * gs_rcp(1.00000011920928955f - araw[i]), wg[i]);
+#else
                     const float rc = gs_rcp(fmaf(-Gv[i], opa, 1.00000011920928955f));  // 1 / (1 - alpha + 1e-7)
                     float d_alpha = fmaf(Tb[i], gc[i], -(rho * rc));
                     d_alpha = live[i] ? d_alpha : 0.f;
+                    const float sv = d_alpha * alpha[i];
+#endif
                     // D = dL/dC_ch w c (1 - c) [x -ln 2: D sh' = D' sh]
                     const float wk = w[i] * -GS_LN2;
                     dv[0][i] = (G0[i] * wk) * fmaf(-cc[0][i], cc[0][i], cc[0][i]);
                     dv[1][i] = (G1[i] * wk) * fmaf(-cc[1][i], cc[1][i], cc[1][i]);
                     dv[2][i] = (G2[i] * wk) * fmaf(-cc[2][i], cc[2][i], cc[2][i]);
                     // (the opacity sum, sum of dL/dalpha G over the live pixels, is sum of s / opacity: at the group's end)
-                    const float sv = d_alpha * alpha[i];
                     S1[i] += sv;
                     Sy[i] = fmaf(sv, dy, Sy[i]);
                     ssum += sv;
@@ -1562,6 +1628,8 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
             // s = dL/dalpha alpha and alpha = G sigma(opa) on every live pixel: sum dL/dalpha G = (sum s) / sigma(opa).  (An
             // opacity that underflowed to 0 composites nothing; its derivative sigma (1 - sigma) downstream is 0 as well.)
             float Sopa = ((S1[0] + S1[1]) + (S1[2] + S1[3])) * (ge2.w > 0.f ? gs_rcp(ge2.w) : 0.f);
+            const float lopa2 = fmaxf(__log2f(ge2.w), -200.0f);
+            (void)lopa2;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float dxi = raster_pixel_coord(tx * 16 + 4 * jq + i, G.padW, G.focal_x) - ge2.x;
@@ -1597,7 +1665,8 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
                 float cA, cB, cC;
                 gs_conic(a, bb, cc, d, cA, cB, cC);
                 const float iPn = 1.0f / (2.0f * raster_det(a, bb, cc, d) + 1e-14f);
-                const float Su = Sq * GS_LN2;
+                // (diet: the loop summed s q' with q' = q - log2 sigma(opa); Sopa x sigma(opa) is the sum of s)
+                const float Su = (GS_BWD_MFMA_DIET ? fmaf(lopa2, Sopa * ge2.w, Sq) : Sq) * GS_LN2;
                 h0[0] = GS_LN2 * (2.0f * cA * Sx - cB * Syt);
                 h0[1] = GS_LN2 * (2.0f * cC * Syt - cB * Sx);
                 h0[2] = iPn * (-Syy + 2.0f * d * Su);
@@ -1648,6 +1717,311 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
     if (lane == 0) O.exec_rows[(size_t)blockIdx.x * W + wave] = n_exec;
 }
 
+// ---------------------------------------------------------------------------------------------
+// rgb colours, frame path (round 5): the ROW layout of the kernel above without its matrix products.
+//
+// One wave per (tile, bucket of 64 Gaussians) -- the grid of raster_backward_pixel_sh_kernel<3>, which this kernel replaces on
+// the frame path --, but inside the bucket lanes own GAUSSIANS, not pixels: lane l = (Gaussian l & 15 of the current group of
+// 16, pixel quad l >> 4), and a step is one pixel ROW of the tile: 16 Gaussians x 16 pixels, four (pixel, Gaussian) pairs per
+// lane.  What that buys for rgb colours, where there is no contraction to hand to the matrix pipe:
+//   * the ten per-Gaussian sums accumulate in the lane's registers over the 16 pixel rows (a lane's four pixel columns have
+//     constant dx) and are reduced 4 : 1 once per group -- the pixel-parallel kernel reduces ten rows of 64 partials through
+//     LDS for EVERY Gaussian (PMC round 4: 42.8 M LDS + ~40 M VALU wave instructions of its 237 M per launch);
+//   * the Gaussian's constants live in registers (no nine broadcast LDS reads per Gaussian);
+//   * a pixel row whose 16 pixels have all stopped is left out, wave-uniformly: 14 % of the row steps of the 2.4 M scene
+//     (the pixel layout could only skip half tiles, 5 %, and lost the gain to the branches).
+// What it pays: the transmittance / rho recursions over the group's 16 Gaussians are DPP row scans (36 DPP instructions per
+// step against eight plain ones).  Two more savings that the SH kernel does not have yet: the opacity is folded into the
+// exponent (alpha = 2^(log2 sigma(opa) - q), as the forward does: no G x opacity product; sum dL/dalpha G is (sum s) /
+// sigma(opa) and sum s q is corrected by log2 sigma(opa) sum s at the group's end), and the transmittance in front of a
+// Gaussian is ONE v_mul_f32_dpp (row_shr:1 of the scanned products times T_in, lanes without a source keep T_in).
+// Rows leave as one aligned 64-byte line each, sixteen rows per store instruction; no flags (stop keys).  No atomics; the
+// sums run in a fixed order: bitwise repeatable.
+#ifndef GS_BWD_RGB_ROWS
+#define GS_BWD_RGB_ROWS 1  // 0: raster_backward_pixel_sh_kernel<3> (A/B switch, tools/ab_variants.py)
+#endif
+#ifndef GS_BWD_ROWS_PF
+#define GS_BWD_ROWS_PF 1   // LDS operands of a pixel row requested one row ahead
+#endif
+#ifndef GS_BWD_ROWS_WPE
+#define GS_BWD_ROWS_WPE 4  // waves per SIMD the register allocation aims at
+#endif
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GS_BWD_ROWS_WPE)))
+raster_backward_rows_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    constexpr uint32_t GS_NO_SLOT = 0xffffffffu;
+    constexpr int RW = gs_row_floats(3);
+    __shared__ __attribute__((aligned(16))) float s_gr[3][256];  // dL/dC of the tile's pixels (masked: crop, clamp)
+    __shared__ __attribute__((aligned(16))) float s_T[256];      // transmittance / rho in front of the current group
+    __shared__ __attribute__((aligned(16))) float s_rho[256];
+    __shared__ float s_py[16];
+    auto lds_order = [] {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    };
+    const int lane = threadIdx.x;
+    const uint32_t n_tiles = (uint32_t)(G.ntx * G.nty), kb = blockIdx.x;
+    const uint4 info = I.bucket_info[kb];  // in bounds for every launched wave (the table is padded)
+    if (kb >= I.bucket_offsets[n_tiles]) return;
+    const uint32_t tile = info.x, base = info.y, r = info.z, start = info.w;
+    const uint32_t tx = tile % (uint32_t)G.ntx, ty = tile / (uint32_t)G.ntx;
+    // the bucket's 64 Gaussian ids, one per lane (a group learns its ids from a lane exchange)
+    const uint32_t id_lane = S.ids[start + base + ((uint32_t)lane < r ? (uint32_t)lane : r - 1)];
+
+    // ---- the tile's pixels at the bucket's boundary: pixel 64 k + lane = (x = lane & 15, y = (lane >> 4) + 4 k).  Every
+    // load is issued before anything is waited for (see raster_backward_pixel_kernel).
+    {
+        const uint32_t id_x = tx * 16 + ((uint32_t)lane & 15), id_y0 = ty * 16 + ((uint32_t)lane >> 4);
+        const float4 *ck = I.ckpt + raster_ckpt_slot(start, tile, base / GS_BUCKET) * 256;
+        float4 c[4];
+        float f[4][3], gr[4][3];
+        bool inside[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            c[k] = ck[64 * k + lane];  // (stale for the tile's first bucket: replaced below)
+            const uint32_t id_y = id_y0 + 4 * k;
+            const float *cf = I.c_final + ((size_t)id_y * G.padW + id_x) * 3;
+            const int ox = (int)id_x - G.crop_left, oy = (int)id_y - G.crop_top;
+            inside[k] = ox >= 0 && ox < G.width && oy >= 0 && oy < G.height;
+            const float *gp = I.grad + ((size_t)(inside[k] ? oy : 0) * G.width + (inside[k] ? ox : 0)) * 3;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                f[k][e] = cf[e];
+                gr[k][e] = gp[e];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            asm volatile("" ::"v"(gr[k][0]), "v"(gr[k][1]), "v"(gr[k][2]), "v"(f[k][0]), "v"(f[k][1]), "v"(f[k][2]),
+                         "v"(c[k].x), "v"(c[k].y), "v"(c[k].z), "v"(c[k].w));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int p = 64 * k + lane;
+            float g3[3];
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                g3[e] = (inside[k] && f[k][e] >= 0.f && f[k][e] <= 1.f) ? gr[k][e] : 0.f;
+                s_gr[e][p] = g3[e];
+            }
+            // the tile's first bucket starts from the empty pixel (T, C) = (1, 0), which the forward does not store
+            const float4 ci = base == 0 ? make_float4(1.f, 0.f, 0.f, 0.f) : c[k];
+            s_T[p] = ci.x;
+            // rho = dL/dC . (C_final - C_run): the only way the remaining colour enters dL/dalpha (gaussian.cu:716-722)
+            s_rho[p] = g3[0] * (f[k][0] - ci.y) + g3[1] * (f[k][1] - ci.z) + g3[2] * (f[k][2] - ci.w);
+        }
+        if (lane < 16) s_py[lane] = raster_pixel_coord(ty * 16 + (uint32_t)lane, G.padH, G.focal_y);
+    }
+    const uint32_t gq = (uint32_t)lane & 15u, jq = (uint32_t)lane >> 4;  // Gaussian of the group, pixel quad
+    float pxs[4];  // centres of this lane's four pixel columns
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pxs[i] = raster_pixel_coord(tx * 16 + 4 * jq + i, G.padW, G.focal_x);
+    lds_order();
+
+    const uint32_t ngrp = (r + 15) / 16;
+    for (uint32_t grp = 0; grp < ngrp; ++grp) {
+        // ---- this lane's Gaussian (entries beyond r re-read the bucket's last one and are switched off: alpha = 0)
+        const uint32_t gi = grp * 16 + gq;
+        const bool valid = gi < r;
+        const uint32_t gid = (uint32_t)__shfl((int)id_lane, (int)(valid ? gi : r - 1), 64);
+        const float4 *rec = S.geom + (size_t)gid * GS_REC_STRIDE;  // ONE 64-byte line: geom | cov | colour | conic
+        const float4 ge = rec[0], col = rec[2], cq = rec[3];
+        uint32_t slot = GS_NO_SLOT;
+        if (valid) {
+            const uint4 rc = O.rects[gid];
+            const uint32_t y0 = rc.x & 0xffff, x0 = rc.y & 0xffff, x1 = rc.y >> 16;
+            const uint64_t sl = (uint64_t)O.pair_offsets[gid] + (ty - y0) * (x1 - x0) + (tx - x0);
+            if (sl < O.max_pairs) slot = (uint32_t)sl;
+        }
+        // alpha = sigma(opa) 2^-q = 2^-(q - log2 sigma(opa)): the opacity rides in the exponent's constant term (an opacity
+        // that underflowed to 0 composites nothing: the clamp keeps q' finite, 2^-(q + 200) is flushed to 0)
+        const float lopa = fmaxf(__log2f(ge.w), -200.0f);
+        const float cC = cq.z, gy = ge.y, c0 = col.x, c1 = col.y, c2 = col.z;
+        float nbdx[4], adx2[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float dxi = pxs[i] - ge.x;
+            nbdx[i] = -(cq.y * dxi);
+            // (a padded entry: q' = 1e30 => alpha = 0 exactly, and 0 x 1e30 = 0 in the sum of s q')
+            adx2[i] = valid ? fmaf(cq.x * dxi, dxi, -lopa) : 1e30f;
+        }
+        float S1[4] = {0.f, 0.f, 0.f, 0.f}, Sy[4] = {0.f, 0.f, 0.f, 0.f}, Syy = 0.f, Sq = 0.f;
+        float Sc0 = 0.f, Sc1 = 0.f, Sc2 = 0.f;
+        // The LDS operands of a pixel row are requested one row ahead (GS_BWD_ROWS_PF); the loop runs two rows per trip so
+        // that the two register sets take turns without moves.
+        struct RowIn {
+            f4 T, R, G0, G1, G2;
+            float py;
+        };
+        auto row_loads = [&](RowIn &d, int s) {
+            const int prow = 16 * s + 4 * (int)jq;
+            d.T = *reinterpret_cast<const f4 *>(s_T + prow);
+            d.R = *reinterpret_cast<const f4 *>(s_rho + prow);
+            d.G0 = *reinterpret_cast<const f4 *>(s_gr[0] + prow);
+            d.G1 = *reinterpret_cast<const f4 *>(s_gr[1] + prow);
+            d.G2 = *reinterpret_cast<const f4 *>(s_gr[2] + prow);
+            d.py = s_py[s];
+        };
+        auto row_step = [&](RowIn &cur, RowIn &nxt, int s) {  // pixel row s of the tile
+            if (!GS_BWD_ROWS_PF) row_loads(cur, s);
+            // a pixel row whose 16 pixels have all stopped adds exact zeros to every sum of every Gaussian of the group and
+            // its states need not move: left out (wave-uniform; the transmittance only falls)
+            const bool any_live = __ballot(cur.T[0] > GS_T_STOP || cur.T[1] > GS_T_STOP || cur.T[2] > GS_T_STOP ||
+                                           cur.T[3] > GS_T_STOP) != 0ull;
+            if (GS_BWD_ROWS_PF && s + 1 < 16) row_loads(nxt, s + 1);
+            if (!any_live) return;
+            const float dy = cur.py - gy;
+            float q[4], araw[4], pin[4], Tb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                q[i] = fmaf(fmaf(cC, dy, nbdx[i]), dy, adx2[i]);  // q' = q - log2 sigma(opa); the forward's evaluation order
+                araw[i] = gs_exp2(-q[i]);
+                // (0 <= 1 - alpha <= 1 for sane records; as a clamp it is the subtraction's clamp modifier, and a NaN /
+                // > 1 alpha of a broken record stops the pixel)
+                pin[i] = fminf(fmaxf(1.0f - araw[i], 0.f), 1.0f);
+                Tb[i] = cur.T[i];
+            }
+            // inclusive product over the group's Gaussians, in place
+            gs_row_scan_mul4(pin);
+            // transmittance in front of this Gaussian: T_in x the product over the group's EARLIER Gaussians -- one DPP
+            // multiply: lane g >= 1 takes the scanned product of lane g - 1, lane 0 has no source and keeps T_in
+            asm volatile("s_nop 1\n\t"
+                         "v_mul_f32_dpp %0, %4, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_mul_f32_dpp %1, %5, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_mul_f32_dpp %2, %6, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_mul_f32_dpp %3, %7, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1"
+                         : "+v"(Tb[0]), "+v"(Tb[1]), "+v"(Tb[2]), "+v"(Tb[3])
+                         : "v"(pin[0]), "v"(pin[1]), "v"(pin[2]), "v"(pin[3]));
+            float alpha[4], w[4], wg[4], ws[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                alpha[i] = Tb[i] > GS_T_STOP ? araw[i] : 0.f;
+                w[i] = alpha[i] * Tb[i];
+                wg[i] = w[i] * fmaf(cur.G2[i], c2, fmaf(cur.G1[i], c1, cur.G0[i] * c0));  // w (dL/dC . colour)
+            }
+            // inclusive prefix sum of w gc over the group's Gaussians, OUT of place (ws): the first step's bound_ctrl:0 reads
+            // 0 where a lane has no source -- the sum's identity --, so the unscanned wg stays for s below
+            asm volatile("s_nop 1\n\t"
+                         "v_add_f32_dpp %0, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                         "v_add_f32_dpp %1, %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                         "v_add_f32_dpp %2, %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                         "v_add_f32_dpp %3, %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                         "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_add_f32_dpp %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_add_f32_dpp %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_add_f32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_add_f32_dpp %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_add_f32_dpp %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_add_f32_dpp %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+                         : "=&v"(ws[0]), "=&v"(ws[1]), "=&v"(ws[2]), "=&v"(ws[3])
+                         : "v"(wg[0]), "v"(wg[1]), "v"(wg[2]), "v"(wg[3]));
+            float ssum = 0.f;
+            f4 Rout;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float rho = cur.R[i] - ws[i];  // rho behind this Gaussian
+                // s = dL/dalpha alpha with dL/dalpha = T gc - rho / (1 - alpha + 1e-7) (gaussian.cu:716-722)
+                //   = w gc - rho beta,  beta = alpha / (1 - alpha + 1e-7): masked with alpha, like w
+                const float beta = alpha[i] * gs_rcp(1.00000011920928955f - araw[i]);
+                const float sv = fmaf(-rho, beta, wg[i]);
+                Sc0 = fmaf(cur.G0[i], w[i], Sc0);
+                Sc1 = fmaf(cur.G1[i], w[i], Sc1);
+                Sc2 = fmaf(cur.G2[i], w[i], Sc2);
+                S1[i] += sv;
+                Sy[i] = fmaf(sv, dy, Sy[i]);
+                ssum += sv;
+                Sq = fmaf(sv, q[i], Sq);
+                Rout[i] = rho;
+            }
+            Syy = fmaf(ssum * dy, dy, Syy);
+            if (gq == 15) {  // the row's pixel states in front of the next group: T behind the group's last Gaussian
+                f4 Tout;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Tout[i] = cur.T[i] * pin[i];
+                *reinterpret_cast<f4 *>(s_T + 16 * s + 4 * jq) = Tout;
+                *reinterpret_cast<f4 *>(s_rho + 16 * s + 4 * jq) = Rout;
+            }
+        };
+        RowIn ra, rb;
+        if (GS_BWD_ROWS_PF) row_loads(ra, 0);
+        for (int s = 0; s < 16; s += 2) {
+            row_step(ra, rb, s);
+            row_step(rb, ra, s + 1);
+        }
+        // ---- close the group: the lane's four pixel columns, then the four pixel quads of the Gaussian
+        const float4 cv = rec[1];
+        float Sx = 0.f, Sxx = 0.f, Sxy = 0.f, Syt = 0.f, Stot = (S1[0] + S1[1]) + (S1[2] + S1[3]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float dxi = pxs[i] - ge.x;
+            const float sx = S1[i] * dxi;
+            Sx += sx;
+            Sxx = fmaf(sx, dxi, Sxx);
+            Sxy = fmaf(Sy[i], dxi, Sxy);
+            Syt += Sy[i];
+        }
+        auto quad_sum = [](float v) {
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            return v;
+        };
+        Sx = quad_sum(Sx);
+        Syt = quad_sum(Syt);
+        Sxx = quad_sum(Sxx);
+        Sxy = quad_sum(Sxy);
+        Syy = quad_sum(Syy);
+        Sq = quad_sum(Sq);
+        Stot = quad_sum(Stot);
+        Sc0 = quad_sum(Sc0);
+        Sc1 = quad_sum(Sc1);
+        Sc2 = quad_sum(Sc2);
+        // s = dL/dalpha alpha and alpha = G sigma(opa) on every live pixel: sum dL/dalpha G = (sum s) / sigma(opa); the
+        // loop summed s q' with q' = q - log2 sigma(opa)
+        const float Sopa = Stot * (ge.w > 0.f ? gs_rcp(ge.w) : 0.f);
+        const float Su = fmaf(lopa, Stot, Sq) * GS_LN2;  // u = -ln G = q ln 2
+        float piece[4];
+        {
+            const float a = cv.x, bb = cv.y, cc = cv.z, d = cv.w;
+            const float iPn = 1.0f / (2.0f * raster_det(a, bb, cc, d) + 1e-14f);
+            // every lane of the Gaussian holds the same sums: lane (g, jq) puts piece jq of the row together
+            if (jq == 0) {
+                piece[0] = GS_LN2 * (2.0f * cq.x * Sx - cq.y * Syt);
+                piece[1] = GS_LN2 * (2.0f * cq.z * Syt - cq.y * Sx);
+                piece[2] = iPn * (-Syy + 2.0f * d * Su);
+                piece[3] = iPn * (Sxy - 2.0f * cc * Su);
+            } else if (jq == 1) {
+                piece[0] = iPn * (Sxy - 2.0f * bb * Su);
+                piece[1] = iPn * (-Sxx + 2.0f * a * Su);
+                piece[2] = Sopa;
+                piece[3] = Sc0;
+            } else {
+                piece[0] = jq == 2 ? Sc1 : 0.f;
+                piece[1] = jq == 2 ? Sc2 : 0.f;
+                piece[2] = 0.f;
+                piece[3] = 0.f;
+            }
+        }
+        {
+            // the group's 16 rows as ONE store instruction of whole 64-byte lines: destination lane 4 r + q takes piece q of
+            // row r from lane (g = r, jq = q)
+            const int dr = lane >> 2, dq = lane & 3, src = dr + 16 * dq;
+            const uint32_t dslot = (uint32_t)__shfl((int)slot, dr, 64);
+            float4 o;
+            o.x = __shfl(piece[0], src, 64);
+            o.y = __shfl(piece[1], src, 64);
+            o.z = __shfl(piece[2], src, 64);
+            o.w = __shfl(piece[3], src, 64);
+            if (dslot != GS_NO_SLOT) reinterpret_cast<float4 *>(O.rows + (size_t)dslot * RW)[dq] = o;
+        }
+        lds_order();  // (the next group reads the states the lanes of Gaussian 15 wrote)
+    }
+}
+
 // sigmoid=True of the reference API: ceil buckets in the systolic kernel, no tail kernel (a rarely used flag)
 template <int CDIM>
 void launch_bwd_sig(const RasterSrc &S, const RasterGeom &G, const BwdIn &I, const BwdOut &O, int64_t max_buckets,
@@ -1693,6 +2067,11 @@ void launch_bwd(const RasterSrc &S, const RasterGeom &G, const BwdIn &I, const B
             hipLaunchKernelGGL((raster_backward_pixel_sh_kernel<CDIM, FRAME>),
                                dim3((unsigned)(max_buckets > 0 ? max_buckets : 1)), dim3(64), 0, stream, S, G, I2, O);
         }
+        return;
+    }
+    if constexpr (FRAME && CDIM == 3 && GS_BWD_RGB_ROWS) {
+        hipLaunchKernelGGL(raster_backward_rows_kernel, dim3((unsigned)(max_buckets > 0 ? max_buckets : 1)), dim3(64), 0,
+                           stream, S, G, I, O);
         return;
     }
     if (CDIM == 3 && !GS_BWD_PACKED_RGB) {

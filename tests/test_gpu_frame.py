@@ -184,11 +184,11 @@ def test_long_lists_composited_in_segments(gpu, use_sh):
         assert np.abs(ga - gb).max() <= 2e-4 * np.abs(gb).max() + 1e-30, name
 
 
-# tolerance of the seam test below: the element-wise criterion of gs_testutil with kappa x LONG_KAPPA_X -- a pixel's state
-# crosses the seam after 2,048 layers and the forward's segment kernels round the incoming transmittance differently from
-# the oracle's serial chain (test_long_lists_composited_in_segments: 2e-4 of the tensor maximum between the two HIP walks)
-LONG_KAPPA_X = 4.0
-LONG_L2 = 1e-4
+# tolerance of the seam test below: gs_testutil's standard element-wise criterion (kappa x 1, relative L2 2e-5) -- measured
+# on the first run (profiles/r05_a_full_size_gradient_parity.txt): worst element at 0.12 x its tolerance with kappa x 4,
+# relative L2 1.3e-6 ... 9.6e-6 per tensor -- the 5,000-layer chains are what the oracle's conditioning scale is for
+LONG_KAPPA_X = 1.0
+LONG_L2 = 2e-5
 
 
 @pytest.mark.parametrize("sh_degree", [2, 3])

@@ -222,3 +222,126 @@ def test_row_store_permutation_writes_the_documented_layout():
         assert used.sum() == 7 + cd
     # rgb rows (one line) keep the plain order
     assert [_row_geo(3, m) for m in range(7)] == list(range(7)) and [_row_col(3, c) for c in range(3)] == [7, 8, 9]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 5: the rgb backward in the row layout (raster_bwd.hip: raster_backward_rows_kernel) -- the same lanes = (Gaussian,
+# pixel quad) and DPP row scans as above, without the matrix products, plus three identities of its own:
+#   (a) the opacity rides in the exponent: alpha = 2^-(q - log2 sigma) and sum s q = sum s q' + log2 sigma sum s;
+#   (b) T in front of Gaussian g = T_in x (inclusive product scan of lane g - 1), lane 0 keeps T_in (one v_mul_f32_dpp
+#       row_shr:1 whose disabled lanes keep the destination);
+#   (c) s = dL/dalpha alpha = w gc - rho beta with beta = alpha / (1 - alpha + 1e-7) -- the prefix sum of w gc is taken out
+#       of place (first scan step with bound_ctrl:0: lanes without a source add 0), so the unscanned w gc is still there.
+def _row_shr(v, sh, fill):
+    """DPP row_shr:sh over the 16 lanes of every row: lane l reads lane l - sh of its row; `fill` where there is none."""
+    out = np.array(fill, dtype=np.float64, copy=True) if np.ndim(fill) else np.full_like(v, fill)
+    for l in range(64):
+        if (l & 15) >= sh:
+            out[l] = v[l - sh]
+    return out
+
+
+def test_rgb_row_layout_model_equals_the_sequential_recursion():
+    rng = np.random.default_rng(9)
+    n_g = 16
+    gx, gy = rng.uniform(-0.2, 0.2, n_g), rng.uniform(-0.2, 0.2, n_g)
+    A, C = rng.uniform(20, 400, n_g), rng.uniform(20, 400, n_g)
+    B = rng.uniform(-0.9, 0.9, n_g) * 2 * np.sqrt(A * C)
+    sig = rng.uniform(0.02, 0.99, n_g)
+    sig[6] = 0.999
+    col = rng.uniform(0, 1, (n_g, 3))
+    px, py = (np.arange(16) - 7.5) / 40.0, (np.arange(16) - 7.5) / 40.0
+    Gimg = rng.normal(size=(3, 16, 16))        # dL/dC [ch][y][x]
+    T_in = rng.uniform(0.0, 1.0, (16, 16))
+    T_in[3, :] = 5e-5                           # a pixel row that had stopped before the group: skipped
+    T_in[::5, ::3] = 2e-5
+    rho_in = rng.normal(size=(16, 16))
+
+    # ---- reference: pixel by pixel, Gaussian by Gaussian (raster_backward_pixel_kernel's arithmetic, float64)
+    ref = np.zeros((n_g, 10))  # Sx Sy Sxx Sxy Syy Su' (= sum s q) Sopa Sc0 Sc1 Sc2
+    T_ref, rho_ref = T_in.copy(), rho_in.copy()
+    for y in range(16):
+        for x in range(16):
+            T, rho = T_ref[y, x], rho_ref[y, x]
+            for g in range(n_g):
+                dx, dy = px[x] - gx[g], py[y] - gy[g]
+                q = A[g] * dx * dx - B[g] * dx * dy + C[g] * dy * dy
+                Gv = 2.0 ** -q
+                live = T > T_STOP
+                alpha = Gv * sig[g] if live else 0.0
+                w = alpha * T
+                gc = Gimg[:, y, x] @ col[g]
+                rho = rho - w * gc
+                d_alpha = (T * gc - rho / (1.00000011920928955 - Gv * sig[g])) if live else 0.0  # (the kernels' fp32 constant)
+                s = d_alpha * alpha
+                ref[g] += [s * dx, s * dy, s * dx * dx, s * dx * dy, s * dy * dy, s * q, d_alpha * Gv,
+                           Gimg[0, y, x] * w, Gimg[1, y, x] * w, Gimg[2, y, x] * w]
+                T = T - w
+            T_ref[y, x], rho_ref[y, x] = T, rho
+
+    # ---- the kernel's lanes: lane l = (g = l & 15, jq = l >> 4), four pixels x = 4 jq + i of row s per step
+    lanes = np.arange(64)
+    g_of, jq_of = lanes & 15, lanes >> 4
+    lopa = np.log2(sig)
+    S1, Sy = np.zeros((64, 4)), np.zeros((64, 4))
+    Syy, Sq, Sc = np.zeros(64), np.zeros(64), np.zeros((64, 3))
+    sT, sR = T_in.copy(), rho_in.copy()
+    skipped = 0
+    for s in range(16):
+        Tin = np.stack([sT[s, 4 * jq_of + i] for i in range(4)], 1)   # [lane][i]
+        Rin = np.stack([sR[s, 4 * jq_of + i] for i in range(4)], 1)
+        if not (Tin > T_STOP).any():
+            skipped += 1
+            continue
+        dy = py[s] - gy[g_of]
+        for i in range(4):
+            x = 4 * jq_of + i
+            dx = px[x] - gx[g_of]
+            qp = (C[g_of] * dy - B[g_of] * dx) * dy + (A[g_of] * dx * dx - lopa[g_of])  # q' = q - log2 sigma
+            araw = 2.0 ** -qp
+            pin = np.clip(1.0 - araw, 0.0, 1.0)
+            scan = pin.copy()
+            for sh in (1, 2, 4, 8):                      # in-place inclusive product, disabled lanes keep their value
+                scan = scan * _row_shr(scan, sh, 1.0)
+            Tb = Tin[:, i] * _row_shr(scan, 1, 1.0)      # (b): lane 0 keeps T_in
+            alpha = np.where(Tb > T_STOP, araw, 0.0)
+            w = alpha * Tb
+            gc = sum(Gimg[ch, s, x] * col[g_of, ch] for ch in range(3))
+            wg = w * gc
+            ws = wg + _row_shr(wg, 1, 0.0)               # (c): first step with bound_ctrl:0
+            for sh in (2, 4, 8):
+                ws = ws + _row_shr(ws, sh, 0.0)
+            rho = Rin[:, i] - ws
+            beta = alpha / (1.00000011920928955 - araw)
+            sv = wg - rho * beta
+            for ch in range(3):
+                Sc[:, ch] += Gimg[ch, s, x] * w
+            S1[:, i] += sv
+            Sy[:, i] += sv * dy
+            Syy += sv * dy * dy
+            Sq += sv * qp
+            last = g_of == 15                             # lanes of Gaussian 15 hand the row's states on
+            sT[s, x[last]] = (Tin[:, i] * scan)[last]
+            sR[s, x[last]] = rho[last]
+    assert skipped == 1
+    # ---- the group's closing: the lane's four columns, then the Gaussian's four quads
+    got = np.zeros((n_g, 10))
+    for l in range(64):
+        g, jq = g_of[l], jq_of[l]
+        st = S1[l].sum()
+        for i in range(4):
+            dx = px[4 * jq + i] - gx[g]
+            got[g, 0] += S1[l, i] * dx
+            got[g, 2] += S1[l, i] * dx * dx
+            got[g, 3] += Sy[l, i] * dx
+            got[g, 1] += Sy[l, i]
+        got[g, 4] += Syy[l]
+        got[g, 5] += Sq[l] + lopa[g] * st                # (a): sum s q = sum s q' + log2 sigma sum s
+        got[g, 6] += st / sig[g]                         # sum dL/dalpha G = (sum s) / sigma
+        got[g, 7:10] += Sc[l]
+    scale = np.abs(ref).max(axis=0) + 1e-30
+    assert np.abs(got - ref).max(axis=0).max() < 1e-9 * scale.max(), np.abs(got - ref).max(axis=0) / scale
+    # pixel states behind the group (dead pixels: the unmasked product keeps falling, harmlessly; rho must agree)
+    live_end = T_ref > T_STOP
+    assert np.allclose(sT[live_end], T_ref[live_end], rtol=1e-9, atol=0)
+    assert np.allclose(np.delete(sR, 3, axis=0), np.delete(rho_ref, 3, axis=0), rtol=1e-9, atol=1e-12)
