@@ -41,42 +41,66 @@ namespace {
 // (tile, first Gaussian of the bucket inside the tile's list, Gaussians in the bucket, start of the tile's list):
 // a bucket kernel's wave learns everything about its work item from ONE load instead of a binary search over the
 // offsets followed by three dependent loads
+// Round 5, `split` (rgb frames): TWO work lists.  List B takes the buckets of the tiles whose compositing stopped before the
+// end of their list -- every pixel saturated: from some bucket on whole pixel rows are dead, which the row-layout kernel
+// (raster_backward_rows_kernel) leaves out --, list A the buckets of the tiles composited to the end of their list, where
+// nothing can be left out and the pixel-parallel kernel is the faster one (same-box A/B, profiles/r05_b_*: 2.4 M
+// Gaussians, every tile saturates: 0.60 -> 0.50 ms with the row kernel; 376 k Gaussians, none does: 0.30 -> 0.32 ms).  The
+// decision costs nothing where it is taken: this kernel runs on the side stream underneath the caller's loss.
 __global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t *__restrict__ tile_nproc, int n_tiles,
                                                           uint32_t *__restrict__ bucket_offsets,
                                                           unsigned long long *__restrict__ n_buckets,
                                                           uint4 *__restrict__ bucket_info,
-                                                          const int32_t *__restrict__ ranges, int frame_ranges) {
-    __shared__ uint32_t s_wave[16];
-    __shared__ uint32_t s_carry;
-    if (threadIdx.x == 0) s_carry = 0;
+                                                          const int32_t *__restrict__ ranges, int frame_ranges,
+                                                          uint32_t *__restrict__ bucket_offsets_b = nullptr,
+                                                          uint4 *__restrict__ bucket_info_b = nullptr, int split = 0) {
+    __shared__ uint32_t s_wave[2][16];
+    __shared__ uint32_t s_carry[2];
+    if (threadIdx.x < 2) s_carry[threadIdx.x] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int base = 0; base < n_tiles; base += 1024) {
         const int i = base + threadIdx.x;
-        const uint32_t v = i < n_tiles ? (tile_nproc[i] + GS_BUCKET - 1) / GS_BUCKET : 0;
-        const uint32_t incl = gs_wave_incl_scan_u32(v);
-        if (lane == 63) s_wave[wave] = incl;
+        const uint32_t np = i < n_tiles ? tile_nproc[i] : 0;
+        const uint32_t v = (np + GS_BUCKET - 1) / GS_BUCKET;
+        // (split needs the list's length: frame ranges only)
+        const bool to_b = split && i < n_tiles && np < (uint32_t)(ranges[2 * i + 1] - ranges[2 * i]);
+        const uint32_t va = to_b ? 0u : v, vb = to_b ? v : 0u;
+        const uint32_t incl_a = gs_wave_incl_scan_u32(va), incl_b = split ? gs_wave_incl_scan_u32(vb) : 0u;
+        if (lane == 63) {
+            s_wave[0][wave] = incl_a;
+            s_wave[1][wave] = incl_b;
+        }
         __syncthreads();
-        uint32_t woff = 0;
+        uint32_t woff_a = 0, woff_b = 0;
 #pragma unroll
-        for (int w = 0; w < 16; ++w) woff += w < wave ? s_wave[w] : 0;
-        const uint32_t carry = s_carry;
+        for (int w = 0; w < 16; ++w) {
+            woff_a += w < wave ? s_wave[0][w] : 0;
+            woff_b += w < wave ? s_wave[1][w] : 0;
+        }
+        const uint32_t carry_a = s_carry[0], carry_b = s_carry[1];
         if (i < n_tiles) {
-            const uint32_t first = carry + woff + incl - v;
-            bucket_offsets[i] = first;
-            const uint32_t np = tile_nproc[i], st = (uint32_t)(frame_ranges ? ranges[2 * i] : ranges[i]);
+            const uint32_t first_a = carry_a + woff_a + incl_a - va, first_b = carry_b + woff_b + incl_b - vb;
+            bucket_offsets[i] = first_a;
+            if (split) bucket_offsets_b[i] = first_b;
+            const uint32_t st = (uint32_t)(frame_ranges ? ranges[2 * i] : ranges[i]);
+            uint4 *dst = to_b ? bucket_info_b + first_b : bucket_info + first_a;
             for (uint32_t b = 0; b < v; ++b) {
                 const uint32_t rem = np - b * GS_BUCKET;
-                bucket_info[first + b] = make_uint4((uint32_t)i, b * GS_BUCKET, rem < GS_BUCKET ? rem : GS_BUCKET, st);
+                dst[b] = make_uint4((uint32_t)i, b * GS_BUCKET, rem < GS_BUCKET ? rem : GS_BUCKET, st);
             }
         }
         __syncthreads();
-        if (threadIdx.x == 1023) s_carry = carry + woff + incl;
+        if (threadIdx.x == 1023) {
+            s_carry[0] = carry_a + woff_a + incl_a;
+            s_carry[1] = carry_b + woff_b + incl_b;
+        }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        bucket_offsets[n_tiles] = s_carry;
-        *n_buckets = s_carry;
+        bucket_offsets[n_tiles] = s_carry[0];
+        if (split) bucket_offsets_b[n_tiles] = s_carry[1];
+        *n_buckets = (unsigned long long)s_carry[0] + s_carry[1];
     }
 }
 
@@ -129,6 +153,9 @@ struct BwdIn {
     // Long lists (frames flagged GS_FRAME_LONG_LISTS): the per-tile SH kernel takes the first bucket_cap buckets of a tile
     // (0: all of them), the one-wave-per-bucket kernel the buckets from bucket_first on (see launch_bwd)
     uint32_t bucket_cap, bucket_first;
+    // rgb frames, GS_BWD_RGB_ROWS == 2: the second work list (the tiles whose pixels all saturated: bucket_scan_kernel)
+    const uint32_t *bucket_offsets_b;
+    const uint4 *bucket_info_b;
 };
 
 // Inputs of one pixel for the backward kernels: final colour, and dL/dC -- for the frame path the gradient of
@@ -1269,9 +1296,11 @@ __device__ __forceinline__ void gs_row_scan_add4_oop(float out[4], const float i
                  "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
                  "v_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
                  "v_add_f32_dpp %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_add_f32_dpp %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+                 "v_add_f32_dpp %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf"
                  : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3])
                  : "v"(in[0]), "v"(in[1]), "v"(in[2]), "v"(in[3]));
+    // (no s_nop behind the block: the hazard is VALU write -> DPP READ; what follows reads the results with plain VALU
+    // instructions, and the kernels that use this helper contain no compiler-generated DPP instruction)
 }
 // T in front of the lane's Gaussian = T_in x the inclusive product scan of the lane to the left (row_shr:1); the row's first
 // lane has no source: the DPP bound check disables it and it keeps T_in.  t: T_in on entry, the result on exit.
@@ -1284,6 +1313,32 @@ __device__ __forceinline__ void gs_row_excl_mul4(float t[4], const float scanned
                  "s_nop 1"
                  : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3])
                  : "v"(scanned[0]), "v"(scanned[1]), "v"(scanned[2]), "v"(scanned[3]));
+}
+// Both at once (one asm block, no s_nop between the two: a register written by the scan's last step is read four
+// instructions later): p <- inclusive product scan of p; t <- t x (scanned p of the lane to the left), lane 0 keeps t.
+__device__ __forceinline__ void gs_row_scan_mul4_excl(float p[4], float t[4]) {
+    asm volatile("s_nop 1\n\t"
+                 "v_mul_f32_dpp %4, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mul_f32_dpp %5, %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mul_f32_dpp %6, %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mul_f32_dpp %7, %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mul_f32_dpp %4, %4, %4 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mul_f32_dpp %5, %5, %5 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mul_f32_dpp %6, %6, %6 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mul_f32_dpp %7, %7, %7 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mul_f32_dpp %4, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mul_f32_dpp %5, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mul_f32_dpp %6, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mul_f32_dpp %7, %7, %7 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mul_f32_dpp %4, %4, %4 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mul_f32_dpp %5, %5, %5 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mul_f32_dpp %6, %6, %6 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mul_f32_dpp %7, %7, %7 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mul_f32_dpp %0, %4, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mul_f32_dpp %1, %5, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mul_f32_dpp %2, %6, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mul_f32_dpp %3, %7, %3 row_shr:1 row_mask:0xf bank_mask:0xf"
+                 : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]));
 }
 // Round 5 instruction diet of the SH row loop (first used by raster_backward_rows_kernel below): the opacity in the
 // exponent's constant term (no G x opacity product), T in front of the Gaussian as one DPP multiply (the builtin costs
@@ -1551,13 +1606,14 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
                     pin[i] = fminf(fmaxf(1.0f - araw[i], 0.f), 1.0f);
                 }
                 // transmittance in front of this Gaussian: T_in times the product over the group's earlier Gaussians
-                gs_row_scan_mul4(pin);
                 float Tb[4], alpha[4], w[4], gc[4], wg[4], cc[3][4];
                 bool live[4];
 #if GS_BWD_MFMA_DIET
 #pragma unroll
                 for (int i = 0; i < 4; ++i) Tb[i] = Tin[i];
-                gs_row_excl_mul4(Tb, pin);
+                gs_row_scan_mul4_excl(pin, Tb);
+#else
+                gs_row_scan_mul4(pin);
 #endif
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -1738,10 +1794,16 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
 // Rows leave as one aligned 64-byte line each, sixteen rows per store instruction; no flags (stop keys).  No atomics; the
 // sums run in a fixed order: bitwise repeatable.
 #ifndef GS_BWD_RGB_ROWS
-#define GS_BWD_RGB_ROWS 1  // 0: raster_backward_pixel_sh_kernel<3> (A/B switch, tools/ab_variants.py)
+// 2: this kernel for the buckets of the tiles whose pixels all saturated, raster_backward_pixel_sh_kernel<3> for the tiles
+//    composited to the end of their list (two work lists: bucket_scan_kernel); 1: this kernel for every bucket; 0: the
+//    pixel-parallel kernel for every bucket (A/B switch, tools/ab_variants.py)
+#define GS_BWD_RGB_ROWS 2
 #endif
 #ifndef GS_BWD_ROWS_PF
-#define GS_BWD_ROWS_PF 1   // LDS operands of a pixel row requested one row ahead
+// 1: LDS operands of a pixel row requested one row ahead.  Measured equal (same box, 2.4 M Gaussians: 0.497 / 0.514 ms
+// without against 0.508 / 0.498 ms with; profiles/r05_b_*): four resident waves per SIMD cover the LDS latency, and without
+// the second register set the kernel needs 105 VGPRs and no scratch (128 and three spilled registers with it)
+#define GS_BWD_ROWS_PF 0
 #endif
 #ifndef GS_BWD_ROWS_WPE
 #define GS_BWD_ROWS_WPE 4  // waves per SIMD the register allocation aims at
@@ -1880,18 +1942,10 @@ raster_backward_rows_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
                 pin[i] = fminf(fmaxf(1.0f - araw[i], 0.f), 1.0f);
                 Tb[i] = cur.T[i];
             }
-            // inclusive product over the group's Gaussians, in place
-            gs_row_scan_mul4(pin);
-            // transmittance in front of this Gaussian: T_in x the product over the group's EARLIER Gaussians -- one DPP
-            // multiply: lane g >= 1 takes the scanned product of lane g - 1, lane 0 has no source and keeps T_in
-            asm volatile("s_nop 1\n\t"
-                         "v_mul_f32_dpp %0, %4, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                         "v_mul_f32_dpp %1, %5, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                         "v_mul_f32_dpp %2, %6, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                         "v_mul_f32_dpp %3, %7, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                         "s_nop 1"
-                         : "+v"(Tb[0]), "+v"(Tb[1]), "+v"(Tb[2]), "+v"(Tb[3])
-                         : "v"(pin[0]), "v"(pin[1]), "v"(pin[2]), "v"(pin[3]));
+            // inclusive product over the group's Gaussians, in place; the transmittance in front of this Gaussian: T_in x the
+            // product over the group's EARLIER Gaussians -- one DPP multiply: lane g >= 1 takes the scanned product of lane
+            // g - 1, lane 0 has no source and keeps T_in
+            gs_row_scan_mul4_excl(pin, Tb);
             float alpha[4], w[4], wg[4], ws[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -1899,27 +1953,8 @@ raster_backward_rows_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
                 w[i] = alpha[i] * Tb[i];
                 wg[i] = w[i] * fmaf(cur.G2[i], c2, fmaf(cur.G1[i], c1, cur.G0[i] * c0));  // w (dL/dC . colour)
             }
-            // inclusive prefix sum of w gc over the group's Gaussians, OUT of place (ws): the first step's bound_ctrl:0 reads
-            // 0 where a lane has no source -- the sum's identity --, so the unscanned wg stays for s below
-            asm volatile("s_nop 1\n\t"
-                         "v_add_f32_dpp %0, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                         "v_add_f32_dpp %1, %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                         "v_add_f32_dpp %2, %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                         "v_add_f32_dpp %3, %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                         "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-                         "v_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-                         "v_add_f32_dpp %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-                         "v_add_f32_dpp %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-                         "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-                         "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-                         "v_add_f32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-                         "v_add_f32_dpp %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-                         "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-                         "v_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-                         "v_add_f32_dpp %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-                         "v_add_f32_dpp %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
-                         : "=&v"(ws[0]), "=&v"(ws[1]), "=&v"(ws[2]), "=&v"(ws[3])
-                         : "v"(wg[0]), "v"(wg[1]), "v"(wg[2]), "v"(wg[3]));
+            // inclusive prefix sum of w gc over the group's Gaussians, OUT of place: the unscanned wg stays for s below
+            gs_row_scan_add4_oop(ws, wg);
             float ssum = 0.f;
             f4 Rout;
 #pragma unroll
@@ -2069,9 +2104,19 @@ void launch_bwd(const RasterSrc &S, const RasterGeom &G, const BwdIn &I, const B
         }
         return;
     }
-    if constexpr (FRAME && CDIM == 3 && GS_BWD_RGB_ROWS) {
+    if constexpr (FRAME && CDIM == 3 && GS_BWD_RGB_ROWS == 1) {
         hipLaunchKernelGGL(raster_backward_rows_kernel, dim3((unsigned)(max_buckets > 0 ? max_buckets : 1)), dim3(64), 0,
                            stream, S, G, I, O);
+        return;
+    }
+    if constexpr (FRAME && CDIM == 3 && GS_BWD_RGB_ROWS == 2) {
+        // list A (I.bucket_info): tiles composited to the end of their list; list B: tiles whose pixels all saturated
+        BwdIn IB = I;
+        IB.bucket_offsets = I.bucket_offsets_b;
+        IB.bucket_info = I.bucket_info_b;
+        const unsigned nb = (unsigned)(max_buckets > 0 ? max_buckets : 1);
+        hipLaunchKernelGGL(raster_backward_rows_kernel, dim3(nb), dim3(64), 0, stream, S, G, IB, O);
+        hipLaunchKernelGGL((raster_backward_pixel_sh_kernel<3, true>), dim3(nb), dim3(64), 0, stream, S, G, I, O);
         return;
     }
     if (CDIM == 3 && !GS_BWD_PACKED_RGB) {
@@ -2218,7 +2263,8 @@ int gs_stage_backward_prepare(const gs_frame *f, const gs_frame_ws &ws, const ui
                           !gs_frame_long_lists(f, FG.n_tiles);  // (flagged frames: the buckets beyond a tile's first 32)
     if (!per_tile)
         hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, ws.tile_nproc, FG.n_tiles,
-                           ws.bucket_offsets, ws.counters + GS_CNT_BUCKETS, ws.bucket_info, ws.tile_ranges, 1);
+                           ws.bucket_offsets, ws.counters + GS_CNT_BUCKETS, ws.bucket_info, ws.tile_ranges, 1,
+                           ws.bucket_offsets_b, ws.bucket_info_b, (f->color_dim == 3 && GS_BWD_RGB_ROWS == 2) ? 1 : 0);
     GS_CHECK_LAUNCH();
     return 0;
 }
@@ -2255,7 +2301,8 @@ int gs_stage_raster_backward(const gs_frame *f, const gs_frame_ws &ws, const uin
         if (rc) return rc;
     }
     BwdIn I = {f->image_padded, grad_image, ws.ckpt, ws.tile_nproc, ws.bucket_offsets, ws.bucket_info, ws.tile_ranges,
-               (gs_frame_uses_strips(f) && f->N > 0 && GS_BWD_MFMA_ORDER) ? ws.tile_order : nullptr, 0, 0};
+               (gs_frame_uses_strips(f) && f->N > 0 && GS_BWD_MFMA_ORDER) ? ws.tile_order : nullptr, 0, 0,
+               ws.bucket_offsets_b, ws.bucket_info_b};
     if (f->color_dim != 3 && gs_frame_long_lists(f, FG.n_tiles)) I.bucket_cap = I.bucket_first = GS_LONG_MIN / GS_BUCKET;
     BwdOut O = {ws.rows, ws.bwd_exec_rows, ws.pair_offsets, ws.rects, (uint64_t)f->max_pairs, nullptr, nullptr, nullptr, nullptr};
     if (f->color_dim == 48)

@@ -84,6 +84,7 @@ BUDGETS = [
     (("raster_forward_kernelILi27ELb1ELb0ELb0ELb0ELb0E",), 168, True),   # SH degree 2: three waves (a few spilled tile constants)
     (("raster_forward_kernelILi48ELb1ELb0ELb0ELb0ELb0E",), 256, True),   # SH degree 3: two waves
     (("raster_backward_pixel_sh_kernelILi3ELb1ELb0E",), 96, False),      # rgb backward: five waves (LDS-limited at 7.6 KiB)
+    (("raster_backward_rows_kernel",), 128, False),                      # rgb backward, row layout (round 5): four waves
     (("raster_backward_pixel_sh_kernelILi27ELb1ELb0E",), 128, True),
     (("raster_backward_pixel_sh_kernelILi48ELb1ELb0E",), 168, True),
     # SH backward on the matrix pipe (round 4): three waves per SIMD; the spills the allocator leaves at that budget sit in
@@ -152,6 +153,7 @@ HOT_LOOPS = [
     (("raster_backward_mfma_sh_kernelILi48ELi4E",), "v_mfma_f32_16x16x4", 12),
     (("raster_forward_kernelILi3ELb1ELb0ELb0ELb0ELb0E",), "v_exp_f32", 8),     # rgb compositing: no scratch anywhere anyway
     (("raster_backward_pixel_sh_kernelILi3ELb1ELb0E",), "v_exp_f32", 4),
+    (("raster_backward_rows_kernel",), "v_exp_f32", 4),                        # rgb backward, row layout: the pixel-row step
 ]
 
 
