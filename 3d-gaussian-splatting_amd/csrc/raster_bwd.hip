@@ -791,7 +791,8 @@ struct PixShCfg {
 #define GS_BWD_PAIR_SKIP 1
 #endif
 template <int CDIM, bool FRAME, bool EXACT = false>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CDIM == 48 ? GS_BWD_SH48_WPE : GS_BWD_SH_WPE)))
+__global__ void __launch_bounds__(64)
+__attribute__((amdgpu_waves_per_eu(CDIM == 48 ? GS_BWD_SH48_WPE : CDIM == 3 ? 5 : GS_BWD_SH_WPE)))  // rgb: five (LDS: 7.9 KiB per wave)
 raster_backward_pixel_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
     static_assert(!(EXACT && FRAME), "the exact-exp flavour belongs to the reference API (gs_draw_backward, fast = 0)");
     constexpr int NB = PixShCfg<CDIM>::NB, NROW = PixShCfg<CDIM>::NROW;
@@ -819,11 +820,15 @@ raster_backward_pixel_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
         __builtin_amdgcn_wave_barrier();
     };
     const int lane = threadIdx.x & 63;
-    const uint32_t n_tiles = (uint32_t)(G.ntx * G.nty), kb = blockIdx.x;
-    const uint4 info = I.bucket_info[kb];  // in bounds for every launched wave (the table is padded)
-    if (kb >= I.bucket_offsets[n_tiles]) return;
+    // The work list is walked with the grid as the stride (round 5): the launch need not cover the list's CAPACITY
+    // (max_pairs / 64 + T buckets: 128 k waves at 2.4 M Gaussians, of which 31 k have a bucket -- the empty ones cost the
+    // dispatcher 22 us of the kernel's 455, kernel trace profiles/r05_d_*), any grid is correct, and a grid beyond the
+    // list's length gives every wave at most one bucket, as before (launch_bwd picks it).
+    const uint32_t n_tiles = (uint32_t)(G.ntx * G.nty), n_work = I.bucket_offsets[n_tiles];
+    for (uint32_t kb = blockIdx.x; kb < n_work; kb += gridDim.x) {
+    const uint4 info = I.bucket_info[kb];
     const uint32_t tile = info.x, base = info.y, r = info.z, start = info.w;
-    if (base < I.bucket_first * GS_BUCKET) return;  // (uniform) a bucket the per-tile SH kernel has taken: launch_bwd
+    if (base < I.bucket_first * GS_BUCKET) continue;  // (uniform) a bucket the per-tile SH kernel has taken: launch_bwd
     const uint32_t tx = tile % (uint32_t)G.ntx, ty = tile / (uint32_t)G.ntx;
 
     // ---- this lane's Gaussian (lanes >= r re-read the bucket's last one and are zeroed below)
@@ -1158,6 +1163,8 @@ raster_backward_pixel_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
             else if (qd == 2) v = make_float4(t[8], t[9], 0.f, 0.f);
             reinterpret_cast<float4 *>(O.rows + (size_t)sl * gs_row_floats(3))[qd] = v;
         }
+    }
+    lds_order();  // (the next bucket of this wave reuses the LDS arrays)
     }
 }
 
@@ -1822,9 +1829,11 @@ raster_backward_rows_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
         __builtin_amdgcn_wave_barrier();
     };
     const int lane = threadIdx.x;
-    const uint32_t n_tiles = (uint32_t)(G.ntx * G.nty), kb = blockIdx.x;
-    const uint4 info = I.bucket_info[kb];  // in bounds for every launched wave (the table is padded)
-    if (kb >= I.bucket_offsets[n_tiles]) return;
+    const uint32_t gq = (uint32_t)lane & 15u, jq = (uint32_t)lane >> 4;  // Gaussian of the group, pixel quad
+    // the work list with the grid as the stride: see raster_backward_pixel_sh_kernel
+    const uint32_t n_tiles = (uint32_t)(G.ntx * G.nty), n_work = I.bucket_offsets[n_tiles];
+    for (uint32_t kb = blockIdx.x; kb < n_work; kb += gridDim.x) {
+    const uint4 info = I.bucket_info[kb];
     const uint32_t tile = info.x, base = info.y, r = info.z, start = info.w;
     const uint32_t tx = tile % (uint32_t)G.ntx, ty = tile / (uint32_t)G.ntx;
     // the bucket's 64 Gaussian ids, one per lane (a group learns its ids from a lane exchange)
@@ -1873,7 +1882,6 @@ raster_backward_rows_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
         }
         if (lane < 16) s_py[lane] = raster_pixel_coord(ty * 16 + (uint32_t)lane, G.padH, G.focal_y);
     }
-    const uint32_t gq = (uint32_t)lane & 15u, jq = (uint32_t)lane >> 4;  // Gaussian of the group, pixel quad
     float pxs[4];  // centres of this lane's four pixel columns
 #pragma unroll
     for (int i = 0; i < 4; ++i) pxs[i] = raster_pixel_coord(tx * 16 + 4 * jq + i, G.padW, G.focal_x);
@@ -2055,6 +2063,7 @@ raster_backward_rows_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
         }
         lds_order();  // (the next group reads the states the lanes of Gaussian 15 wrote)
     }
+    }  // work list
 }
 
 // sigmoid=True of the reference API: ceil buckets in the systolic kernel, no tail kernel (a rarely used flag)
@@ -2080,6 +2089,15 @@ void launch_bwd(const RasterSrc &S, const RasterGeom &G, const BwdIn &I, const B
                 hipStream_t stream) {
     constexpr int WPB = BwdCfg<CDIM>::WPB;
     const int grid = (int)gs_div_up(max_buckets > 0 ? max_buckets : 1, WPB);
+    // Grid of the one-wave-per-bucket kernels of the frame path: the work list's capacity, but at most GS_BWD_GRID_CAP waves.
+    // The kernels walk the list with the grid as the stride, so the cap only decides how many waves come up empty (a frame
+    // whose tiles saturate early fills a third of the capacity) or take a second bucket (a frame beyond the cap: the waves
+    // are still 8 x the device's resident slots, i.e. fresh waves keep arriving while others are in their load phase -- what
+    // the measured-and-dropped persistent grids of round 2 lacked).
+#ifndef GS_BWD_GRID_CAP
+#define GS_BWD_GRID_CAP 40960
+#endif
+    const unsigned fgrid = (unsigned)(max_buckets > 0 ? (max_buckets < GS_BWD_GRID_CAP ? max_buckets : GS_BWD_GRID_CAP) : 1);
     if constexpr (FRAME && ((CDIM == 48 && GS_BWD_SH_MFMA >= 1) || (CDIM == 27 && GS_BWD_SH_MFMA >= 2))) {
         // one workgroup per GS_BWD_MFMA_TILES tiles (tiles nothing was composited in leave at once)
         const unsigned mgrid = (unsigned)(gs_div_up(G.ntx * G.nty, GS_BWD_MFMA_TILES) *
@@ -2099,14 +2117,12 @@ void launch_bwd(const RasterSrc &S, const RasterGeom &G, const BwdIn &I, const B
         if (I.bucket_first) {
             BwdIn I2 = I;
             I2.bucket_cap = 0;
-            hipLaunchKernelGGL((raster_backward_pixel_sh_kernel<CDIM, FRAME>),
-                               dim3((unsigned)(max_buckets > 0 ? max_buckets : 1)), dim3(64), 0, stream, S, G, I2, O);
+            hipLaunchKernelGGL((raster_backward_pixel_sh_kernel<CDIM, FRAME>), dim3(fgrid), dim3(64), 0, stream, S, G, I2, O);
         }
         return;
     }
     if constexpr (FRAME && CDIM == 3 && GS_BWD_RGB_ROWS == 1) {
-        hipLaunchKernelGGL(raster_backward_rows_kernel, dim3((unsigned)(max_buckets > 0 ? max_buckets : 1)), dim3(64), 0,
-                           stream, S, G, I, O);
+        hipLaunchKernelGGL(raster_backward_rows_kernel, dim3(fgrid), dim3(64), 0, stream, S, G, I, O);
         return;
     }
     if constexpr (FRAME && CDIM == 3 && GS_BWD_RGB_ROWS == 2) {
@@ -2114,9 +2130,8 @@ void launch_bwd(const RasterSrc &S, const RasterGeom &G, const BwdIn &I, const B
         BwdIn IB = I;
         IB.bucket_offsets = I.bucket_offsets_b;
         IB.bucket_info = I.bucket_info_b;
-        const unsigned nb = (unsigned)(max_buckets > 0 ? max_buckets : 1);
-        hipLaunchKernelGGL(raster_backward_rows_kernel, dim3(nb), dim3(64), 0, stream, S, G, IB, O);
-        hipLaunchKernelGGL((raster_backward_pixel_sh_kernel<3, true>), dim3(nb), dim3(64), 0, stream, S, G, I, O);
+        hipLaunchKernelGGL(raster_backward_rows_kernel, dim3(fgrid), dim3(64), 0, stream, S, G, IB, O);
+        hipLaunchKernelGGL((raster_backward_pixel_sh_kernel<3, true>), dim3(fgrid), dim3(64), 0, stream, S, G, I, O);
         return;
     }
     if (CDIM == 3 && !GS_BWD_PACKED_RGB) {
@@ -2125,7 +2140,7 @@ void launch_bwd(const RasterSrc &S, const RasterGeom &G, const BwdIn &I, const B
                            S, G, I, O);
     } else if (CDIM == 3 || GS_BWD_SH_PIXEL) {
         hipLaunchKernelGGL((raster_backward_pixel_sh_kernel<CDIM, FRAME>),
-                           dim3((unsigned)(max_buckets > 0 ? max_buckets : 1)), dim3(64), 0, stream, S, G, I, O);
+                           dim3(FRAME ? fgrid : (unsigned)(max_buckets > 0 ? max_buckets : 1)), dim3(64), 0, stream, S, G, I, O);
     } else {
         hipLaunchKernelGGL((raster_backward_kernel<CDIM, FRAME>), dim3(grid), dim3(64 * WPB), 0, stream, S, G, I, O);
     }
