@@ -247,8 +247,6 @@ struct gs_frame_ws {
     uint32_t *tile_nproc;          // [T] Gaussians processed by the forward (multiple of the chunk)
     uint32_t *bucket_offsets;      // [T+1] exclusive scan of ceil(nproc/64)
     uint4 *bucket_info;            // [max_buckets + 8] (tile, first Gaussian, count, list start) per bucket
-    uint32_t *bucket_offsets_b;    // [T+1] } rgb frames: the second work list -- the buckets of the tiles whose pixels all
-    uint4 *bucket_info_b;          // [max_buckets + 8] } saturated (raster_bwd.hip: bucket_scan_kernel, `split`)
     float4 *ckpt;                  // [max_buckets][256] (T, Cr, Cg, Cb) at bucket starts
     float *rows;                   // [max_pairs][GS_ROW(C)] per-pair gradient rows in EMISSION order
     uint32_t *bwd_exec_rows;       // [GS_BWD_EXEC_SLOTS x T] SH backward on the matrix pipe: pixel-row steps (16 Gaussians x 16
@@ -345,8 +343,6 @@ static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pair
         ws.tile_nproc = (uint32_t *)take(sizeof(uint32_t) * G.n_tiles);
         ws.bucket_offsets = (uint32_t *)take(sizeof(uint32_t) * (G.n_tiles + 1));
         ws.bucket_info = (uint4 *)take(sizeof(uint4) * (size_t)(ws.max_buckets + 8));
-        ws.bucket_offsets_b = (uint32_t *)take(sizeof(uint32_t) * (G.n_tiles + 1));
-        ws.bucket_info_b = (uint4 *)take(sizeof(uint4) * (size_t)(color_dim == 3 ? ws.max_buckets + 8 : 1));
         ws.ckpt = (float4 *)take(sizeof(float4) * 256 * (size_t)ws.max_buckets);
         ws.rows = (float *)take(sizeof(float) * (size_t)gs_row_floats(color_dim) * max_pairs);
         ws.bwd_exec_rows = (uint32_t *)take(sizeof(uint32_t) * GS_BWD_EXEC_SLOTS * (size_t)G.n_tiles);
@@ -355,8 +351,6 @@ static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pair
         ws.tile_nproc = nullptr;
         ws.bucket_offsets = nullptr;
         ws.bucket_info = nullptr;
-        ws.bucket_offsets_b = nullptr;
-        ws.bucket_info_b = nullptr;
         ws.ckpt = nullptr;
         ws.rows = nullptr;
         ws.bwd_exec_rows = nullptr;

@@ -41,19 +41,15 @@ namespace {
 // (tile, first Gaussian of the bucket inside the tile's list, Gaussians in the bucket, start of the tile's list):
 // a bucket kernel's wave learns everything about its work item from ONE load instead of a binary search over the
 // offsets followed by three dependent loads
-// Round 5, `split` (rgb frames): TWO work lists.  List B takes the buckets of the tiles whose compositing stopped before the
-// end of their list -- every pixel saturated: from some bucket on whole pixel rows are dead, which the row-layout kernel
-// (raster_backward_rows_kernel) leaves out --, list A the buckets of the tiles composited to the end of their list, where
-// nothing can be left out and the pixel-parallel kernel is the faster one (same-box A/B, profiles/r05_b_*: 2.4 M
-// Gaussians, every tile saturates: 0.60 -> 0.50 ms with the row kernel; 376 k Gaussians, none does: 0.30 -> 0.32 ms).  The
-// decision costs nothing where it is taken: this kernel runs on the side stream underneath the caller's loss.
+// Round 5: with frame ranges the scan also counts the buckets of SATURATED tiles -- tiles whose compositing stopped before the
+// end of their list because every pixel had saturated -- and returns the count in the upper half of *n_buckets: the share of
+// such buckets is what decides between the two rgb backward kernels (GS_FRAME_BWD_ROWS, include/gs_abi.h), and the caller
+// reads the counter back with the frame's other counters anyway.
 __global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t *__restrict__ tile_nproc, int n_tiles,
                                                           uint32_t *__restrict__ bucket_offsets,
                                                           unsigned long long *__restrict__ n_buckets,
                                                           uint4 *__restrict__ bucket_info,
-                                                          const int32_t *__restrict__ ranges, int frame_ranges,
-                                                          uint32_t *__restrict__ bucket_offsets_b = nullptr,
-                                                          uint4 *__restrict__ bucket_info_b = nullptr, int split = 0) {
+                                                          const int32_t *__restrict__ ranges, int frame_ranges) {
     __shared__ uint32_t s_wave[2][16];
     __shared__ uint32_t s_carry[2];
     if (threadIdx.x < 2) s_carry[threadIdx.x] = 0;
@@ -63,44 +59,39 @@ __global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t *__res
         const int i = base + threadIdx.x;
         const uint32_t np = i < n_tiles ? tile_nproc[i] : 0;
         const uint32_t v = (np + GS_BUCKET - 1) / GS_BUCKET;
-        // (split needs the list's length: frame ranges only)
-        const bool to_b = split && i < n_tiles && np < (uint32_t)(ranges[2 * i + 1] - ranges[2 * i]);
-        const uint32_t va = to_b ? 0u : v, vb = to_b ? v : 0u;
-        const uint32_t incl_a = gs_wave_incl_scan_u32(va), incl_b = split ? gs_wave_incl_scan_u32(vb) : 0u;
+        const bool sat = frame_ranges && i < n_tiles && np < (uint32_t)(ranges[2 * i + 1] - ranges[2 * i]);
+        const uint32_t incl = gs_wave_incl_scan_u32(v), sat_sum = gs_wave_sum_u32(sat ? v : 0u);
         if (lane == 63) {
-            s_wave[0][wave] = incl_a;
-            s_wave[1][wave] = incl_b;
+            s_wave[0][wave] = incl;
+            s_wave[1][wave] = sat_sum;
         }
         __syncthreads();
-        uint32_t woff_a = 0, woff_b = 0;
+        uint32_t woff = 0, sat_all = 0;
 #pragma unroll
         for (int w = 0; w < 16; ++w) {
-            woff_a += w < wave ? s_wave[0][w] : 0;
-            woff_b += w < wave ? s_wave[1][w] : 0;
+            woff += w < wave ? s_wave[0][w] : 0;
+            sat_all += s_wave[1][w];
         }
-        const uint32_t carry_a = s_carry[0], carry_b = s_carry[1];
+        const uint32_t carry = s_carry[0];
         if (i < n_tiles) {
-            const uint32_t first_a = carry_a + woff_a + incl_a - va, first_b = carry_b + woff_b + incl_b - vb;
-            bucket_offsets[i] = first_a;
-            if (split) bucket_offsets_b[i] = first_b;
+            const uint32_t first = carry + woff + incl - v;
+            bucket_offsets[i] = first;
             const uint32_t st = (uint32_t)(frame_ranges ? ranges[2 * i] : ranges[i]);
-            uint4 *dst = to_b ? bucket_info_b + first_b : bucket_info + first_a;
             for (uint32_t b = 0; b < v; ++b) {
                 const uint32_t rem = np - b * GS_BUCKET;
-                dst[b] = make_uint4((uint32_t)i, b * GS_BUCKET, rem < GS_BUCKET ? rem : GS_BUCKET, st);
+                bucket_info[first + b] = make_uint4((uint32_t)i, b * GS_BUCKET, rem < GS_BUCKET ? rem : GS_BUCKET, st);
             }
         }
         __syncthreads();
         if (threadIdx.x == 1023) {
-            s_carry[0] = carry_a + woff_a + incl_a;
-            s_carry[1] = carry_b + woff_b + incl_b;
+            s_carry[0] = carry + woff + incl;
+            s_carry[1] += sat_all;
         }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
         bucket_offsets[n_tiles] = s_carry[0];
-        if (split) bucket_offsets_b[n_tiles] = s_carry[1];
-        *n_buckets = (unsigned long long)s_carry[0] + s_carry[1];
+        *n_buckets = (unsigned long long)s_carry[0] | ((unsigned long long)s_carry[1] << 32);
     }
 }
 
@@ -153,9 +144,7 @@ struct BwdIn {
     // Long lists (frames flagged GS_FRAME_LONG_LISTS): the per-tile SH kernel takes the first bucket_cap buckets of a tile
     // (0: all of them), the one-wave-per-bucket kernel the buckets from bucket_first on (see launch_bwd)
     uint32_t bucket_cap, bucket_first;
-    // rgb frames, GS_BWD_RGB_ROWS == 2: the second work list (the tiles whose pixels all saturated: bucket_scan_kernel)
-    const uint32_t *bucket_offsets_b;
-    const uint4 *bucket_info_b;
+    uint32_t use_rows;  // rgb frames: GS_FRAME_BWD_ROWS -- the row-layout kernel instead of the pixel-parallel one (launch_bwd)
 };
 
 // Inputs of one pixel for the backward kernels: final colour, and dL/dC -- for the frame path the gradient of
@@ -1801,9 +1790,12 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
 // Rows leave as one aligned 64-byte line each, sixteen rows per store instruction; no flags (stop keys).  No atomics; the
 // sums run in a fixed order: bitwise repeatable.
 #ifndef GS_BWD_RGB_ROWS
-// 2: this kernel for the buckets of the tiles whose pixels all saturated, raster_backward_pixel_sh_kernel<3> for the tiles
-//    composited to the end of their list (two work lists: bucket_scan_kernel); 1: this kernel for every bucket; 0: the
-//    pixel-parallel kernel for every bucket (A/B switch, tools/ab_variants.py)
+// 2: this kernel in frames flagged GS_FRAME_BWD_ROWS (include/gs_abi.h: the caller's statistic says most buckets belong to
+//    saturated tiles), raster_backward_pixel_sh_kernel<3> in the others; 1: this kernel always; 0: never (A/B switch).
+// Why not always: kernel traces on one box (profiles/r05_e_*) -- 2.4 M Gaussians, every tile saturates: 446 -> 408 us; 376 k
+// Gaussians, none does and no row is ever left out: 276 -> 305 us (the DPP scans cost more than the LDS reduction they
+// replace).  Why not per tile (built: two work lists, one kernel each): the second launch is serial behind the first on
+// the stream and costs the tail of its slowest lone wave (33 us at 376 k Gaussians for the ~100 tiles that do saturate).
 #define GS_BWD_RGB_ROWS 2
 #endif
 #ifndef GS_BWD_ROWS_PF
@@ -2121,18 +2113,11 @@ void launch_bwd(const RasterSrc &S, const RasterGeom &G, const BwdIn &I, const B
         }
         return;
     }
-    if constexpr (FRAME && CDIM == 3 && GS_BWD_RGB_ROWS == 1) {
-        hipLaunchKernelGGL(raster_backward_rows_kernel, dim3(fgrid), dim3(64), 0, stream, S, G, I, O);
-        return;
-    }
-    if constexpr (FRAME && CDIM == 3 && GS_BWD_RGB_ROWS == 2) {
-        // list A (I.bucket_info): tiles composited to the end of their list; list B: tiles whose pixels all saturated
-        BwdIn IB = I;
-        IB.bucket_offsets = I.bucket_offsets_b;
-        IB.bucket_info = I.bucket_info_b;
-        hipLaunchKernelGGL(raster_backward_rows_kernel, dim3(fgrid), dim3(64), 0, stream, S, G, IB, O);
-        hipLaunchKernelGGL((raster_backward_pixel_sh_kernel<3, true>), dim3(fgrid), dim3(64), 0, stream, S, G, I, O);
-        return;
+    if constexpr (FRAME && CDIM == 3 && GS_BWD_RGB_ROWS) {
+        if (GS_BWD_RGB_ROWS == 1 || I.use_rows) {
+            hipLaunchKernelGGL(raster_backward_rows_kernel, dim3(fgrid), dim3(64), 0, stream, S, G, I, O);
+            return;
+        }
     }
     if (CDIM == 3 && !GS_BWD_PACKED_RGB) {
         const int64_t blocks = gs_div_up(max_buckets > 0 ? max_buckets : 1, GS_PP_WPB);
@@ -2278,8 +2263,7 @@ int gs_stage_backward_prepare(const gs_frame *f, const gs_frame_ws &ws, const ui
                           !gs_frame_long_lists(f, FG.n_tiles);  // (flagged frames: the buckets beyond a tile's first 32)
     if (!per_tile)
         hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, ws.tile_nproc, FG.n_tiles,
-                           ws.bucket_offsets, ws.counters + GS_CNT_BUCKETS, ws.bucket_info, ws.tile_ranges, 1,
-                           ws.bucket_offsets_b, ws.bucket_info_b, (f->color_dim == 3 && GS_BWD_RGB_ROWS == 2) ? 1 : 0);
+                           ws.bucket_offsets, ws.counters + GS_CNT_BUCKETS, ws.bucket_info, ws.tile_ranges, 1);
     GS_CHECK_LAUNCH();
     return 0;
 }
@@ -2317,7 +2301,7 @@ int gs_stage_raster_backward(const gs_frame *f, const gs_frame_ws &ws, const uin
     }
     BwdIn I = {f->image_padded, grad_image, ws.ckpt, ws.tile_nproc, ws.bucket_offsets, ws.bucket_info, ws.tile_ranges,
                (gs_frame_uses_strips(f) && f->N > 0 && GS_BWD_MFMA_ORDER) ? ws.tile_order : nullptr, 0, 0,
-               ws.bucket_offsets_b, ws.bucket_info_b};
+               (f->flags & GS_FRAME_BWD_ROWS) ? 1u : 0u};
     if (f->color_dim != 3 && gs_frame_long_lists(f, FG.n_tiles)) I.bucket_cap = I.bucket_first = GS_LONG_MIN / GS_BUCKET;
     BwdOut O = {ws.rows, ws.bwd_exec_rows, ws.pair_offsets, ws.rects, (uint64_t)f->max_pairs, nullptr, nullptr, nullptr, nullptr};
     if (f->color_dim == 48)

@@ -50,6 +50,7 @@ GS_FRAME_TABLE_BIN = 4
 GS_FRAME_SERIAL_LONG_LISTS = 8
 GS_FRAME_LONG_LISTS = 16
 GS_FRAME_STRIP_BIN = 32
+GS_FRAME_BWD_ROWS = 64
 
 
 def _sig(name, restype, *argtypes):

@@ -34,8 +34,9 @@ class FrameStats:
     visible: int  # V: Gaussians surviving frustum culling
     pairs: int  # M: (tile, Gaussian) pairs after duplication (clamped to capacity)
     overflow: int  # 0, or the true M when it exceeded the workspace capacity
-    buckets: int  # 64-Gaussian buckets processed by the last backward
+    buckets: int  # 64-Gaussian buckets in the last backward's work list
     longest_list: int = 0  # longest tile list of the frame (lists of up to 1024 pairs are reported as 0)
+    saturated_buckets: int = 0  # ... of them in tiles whose compositing stopped before the end of their list
 
 
 class FrameRenderer:
@@ -45,7 +46,7 @@ class FrameRenderer:
                  thresh: float = 0.05, scale_activation: str = "abs", auto_grow: bool = True,
                  sort_mode: int = 2, tile_culling_method: str = "prob2", tile_culling_dist_thresh: float = 0.5,
                  emit_sorted_keys: bool = False, slice_sort: bool = False, table_bin: bool = False,
-                 serial_long_lists: bool = False, long_lists: Optional[bool] = None,
+                 serial_long_lists: bool = False, long_lists: Optional[bool] = None, bwd_rows: Optional[bool] = None,
                  force_strips: Optional[bool] = None):
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -72,6 +73,11 @@ class FrameRenderer:
         # back anyway carry the longest list).  The workspace capacity plays no part in it.
         self.long_lists = long_lists
         self._long_lists_seen = False
+        # rgb training frames: which kernel composites the backward (GS_FRAME_BWD_ROWS, include/gs_abi.h).  None: by the
+        # share of saturated buckets an earlier backward of this renderer reported (read back with the other counters:
+        # `stats()`, or the asynchronous copy of auto_grow="async"), with hysteresis; True / False: always / never.
+        self.bwd_rows = bwd_rows
+        self._bwd_rows_seen = False
         self.max_pairs = int(max_pairs)
         self.training = bool(training)
         self.thresh = float(thresh)
@@ -122,7 +128,8 @@ class FrameRenderer:
                pos.shape[0], rgb.shape[-1] if rgb.dim() == 2 else 1, bool(training), self.max_pairs, self.sort_mode,
                self.tile_culling_method, self.tile_culling_dist_thresh, self.thresh, self.scale_activation,
                self.emit_sorted_keys, self.slice_sort, self.table_bin, self.force_strips, self.serial_long_lists,
-               self.long_lists, self._long_lists_seen, self._ws.data_ptr() if self._ws is not None else 0)
+               self.long_lists, self._long_lists_seen, self.bwd_rows, self._bwd_rows_seen,
+               self._ws.data_ptr() if self._ws is not None else 0)
         cached = getattr(self, "_desc_cache", None)
         if cached is not None and cached[0] == key:
             f = _lib.GsFrame()
@@ -197,7 +204,8 @@ class FrameRenderer:
             (_lib.GS_FRAME_SLICE_SORT if self.slice_sort else 0) | (_lib.GS_FRAME_TABLE_BIN if self.table_bin else 0) | \
             (_lib.GS_FRAME_STRIP_BIN if (self.force_strips and not (self.slice_sort or self.table_bin)) else 0) | \
             (_lib.GS_FRAME_SERIAL_LONG_LISTS if self.serial_long_lists else 0) | \
-            (_lib.GS_FRAME_LONG_LISTS if (self.long_lists or (self.long_lists is None and self._long_lists_seen)) else 0)
+            (_lib.GS_FRAME_LONG_LISTS if (self.long_lists or (self.long_lists is None and self._long_lists_seen)) else 0) | \
+            (_lib.GS_FRAME_BWD_ROWS if (self.bwd_rows or (self.bwd_rows is None and self._bwd_rows_seen)) else 0)
         f.training = int(training)
         f.sort_mode = self.sort_mode
         f.tile_culling_method = self.tile_culling_method
@@ -252,12 +260,25 @@ class FrameRenderer:
             v, m, o, b, longest = (int(x) for x in self._async_host.tolist())
             self._async_event = None
             self._long_lists_seen = self._long_lists_seen or longest > 2048
+            self._note_buckets(b)
             if o:
                 self.overflowed_frames += 1
                 self._last_overflow_serial = self._async_serial
                 self.max_pairs = max(self.max_pairs, int(o * self.headroom) + 1024)
             elif m * self.headroom > self.max_pairs:  # close to the limit: grow before it overflows
                 self.max_pairs = int(m * self.headroom * self.headroom) + 1024
+
+    def _note_buckets(self, b: int):
+        """`b`: the `buckets` counter of a backward's preparation -- low half: buckets in the work list, high half: those of
+        saturated tiles.  The row-layout rgb backward pays when most buckets are of that kind (it leaves dead pixel rows
+        out) and costs ~10 % when none is: switch on above 60 %, off below 40 %."""
+        total, sat = b & 0xffffffff, b >> 32
+        if total > 0:
+            share = sat / total
+            if share > 0.6:
+                self._bwd_rows_seen = True
+            elif share < 0.4:
+                self._bwd_rows_seen = False
 
     def last_frame_overflowed(self, wait: bool = False) -> bool:
         """auto_grow="async": did the most recent forward overflow its workspace?  Without ``wait`` only what has
@@ -486,7 +507,8 @@ class FrameRenderer:
         stream.synchronize()
         v, m, o, b, longest = (int(x) for x in self._stats_host.tolist())
         self._long_lists_seen = self._long_lists_seen or longest > 2048
-        return FrameStats(v, m, o, b, longest)
+        self._note_buckets(b)
+        return FrameStats(v, m, o, b & 0xffffffff, longest, b >> 32)
 
     def binning_variant(self) -> str:
         """Which binning / sort path the last frame took: "radix64", "radix_tile_bits", "table", "slice", "strip"."""

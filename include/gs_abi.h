@@ -34,7 +34,8 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-/* 6 (round 5): gs_frame_debug_bwd_exec_rows; SH gradient rows in whole 64-byte lines without per-row flags (workspace
+/* 6 (round 5): gs_frame_debug_bwd_exec_rows; GS_FRAME_BWD_ROWS and the saturated-bucket count in the upper half of the
+ * `buckets` counter; SH gradient rows in whole 64-byte lines without per-row flags (workspace
  * layout only: no signature changed).
  * 5 (round 4): the frame in pieces -- gs_frame_forward_project + gs_frame_forward_rest == gs_frame_forward,
  * gs_frame_backward_slice (the per-Gaussian sums of a range of Gaussians), gs_frame_project_slices --, gs_adam_step_multi /
@@ -192,6 +193,16 @@ int gs_sort_pairs_bits(uint64_t *keys0, uint32_t *vals0, uint64_t *keys1, uint32
                                        by N: the table variant below GS_STRIP_AUTO_MIN_N (131,072) Gaussians, where its shorter
                                        chain of dependent kernels wins, the strip variant from there on.  Every variant
                                        produces the same lists. */
+#define GS_FRAME_BWD_ROWS 64         /* rgb training frames: composite the backward with the row-layout kernel (lanes = 16
+                                       Gaussians x 4 pixel quads, pixel rows whose pixels have all stopped are left out)
+                                       instead of the pixel-parallel one.  Worth it when most of the frame's buckets belong
+                                       to SATURATED tiles -- tiles whose compositing stopped before the end of their list --
+                                       and a loss otherwise (2.4 M Gaussians at 1080p: -9 %; 376 k Gaussians: +11 %, kernel
+                                       traces profiles/r05_e_*).  The library cannot know without a host synchronisation;
+                                       the caller can: the upper half of gs_frame_stats_async's `buckets` counter is the
+                                       number of buckets of saturated tiles in the last backward's work list.  Either
+                                       kernel is correct for any frame; the results differ in the last bits (another
+                                       summation order).  Ignored by SH frames. */
 
 /* Frame descriptor.  All scalars are per-camera constants computed on the host exactly as
  * splatter.py does (Tiles, RayInfo, frustum guard band); rot/tran are passed by value. */
@@ -289,7 +300,9 @@ int gs_frame_backward_profile(const gs_frame *f, const float *grad_image, float 
 
 /* Counters of the last forward on this workspace, copied device->host asynchronously into
  * `stats_host` (4 x int64: V visible, M pairs, overflow flag, processed buckets).  The
- * caller synchronises the stream before reading. */
+ * caller synchronises the stream before reading.  `processed buckets` (training frames; written by the backward's
+ * preparation, i.e. it may still be the previous frame's when read right behind a forward): low 32 bits = buckets of 64
+ * Gaussians in the backward's work list, high 32 bits = how many of them belong to saturated tiles (GS_FRAME_BWD_ROWS). */
 int gs_frame_stats_async(const gs_frame *f, int64_t *stats_host, gs_stream_t stream);
 
 /* Length of the longest tile list of the last forward on this workspace (sort_mode 2, strip variant; lists of up to

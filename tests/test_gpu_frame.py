@@ -531,18 +531,107 @@ def test_frame_repeatable_bitwise(gpu, sort_mode):
     assert torch.equal(a, b)  # forward is deterministic (no atomics on the data path)
 
 
-def test_frame_backward_repeatable_bitwise(gpu):
-    """No atomics anywhere on the gradient path: two backward passes give identical bits."""
+@pytest.mark.parametrize("bwd_rows", [False, True])
+def test_frame_backward_repeatable_bitwise(gpu, bwd_rows):
+    """No atomics anywhere on the gradient path: two backward passes give identical bits (both rgb kernels: the
+    pixel-parallel one and the row-layout one of GS_FRAME_BWD_ROWS)."""
     scene, cam = case(15_000, 160, 112, seed=21)
     gimg = torch.from_numpy(np.random.default_rng(6).normal(size=(112, 160, 3)).astype(np.float32)).to(gpu)
     grads = []
     for _ in range(2):
         params = to_torch(scene, gpu, requires_grad=True)
-        r = FrameRenderer(gpu, max_pairs=1 << 17, training=True, auto_grow=False)
+        r = FrameRenderer(gpu, max_pairs=1 << 17, training=True, auto_grow=False, bwd_rows=bwd_rows)
         r.render(*params, cam).backward(gimg)
+        assert bool(r._frame.flags & 64) == bwd_rows  # GS_FRAME_BWD_ROWS
         grads.append([t.grad.clone() for t in params])
     for a, b in zip(*grads):
         assert torch.equal(a, b)
+
+
+def _rows_scenes():
+    """(name, scene, camera) the row-layout rgb backward is checked on: deep tiles whose pixels stop inside the list (dead
+    pixel rows are left out, several buckets per tile, ragged groups of 16), Gaussian counts around the group / bucket
+    sizes, a nearly transparent scene (nothing stops: no row is ever left out), and screen-filling Gaussians next to
+    ordinary ones (hundreds of rows per Gaussian: the projection backward's cooperative sums downstream)."""
+    out = []
+    sc, cam = case(14_000, 96, 64, seed=5)
+    sc.opa += 1.5
+    out.append(("deep_saturating", sc, cam))
+    for n in (1, 15, 17, 63, 65, 1025):
+        sc, cam = case(n, 96, 80, seed=100 + n)
+        sc.pos[:, 2] = np.abs(sc.pos[:, 2]) + 1.0
+        out.append((f"n{n}", sc, cam))
+    sc, cam = case(20_000, 128, 96, seed=9)
+    sc.opa[:] = -4.0
+    out.append(("transparent", sc, cam))
+    sc, cam = case(3_000, 352, 272, seed=31)
+    big = [10, 11, 12, 700, 2999]
+    sc.scale[big] = np.float32(3.0) * np.abs(sc.pos[big, 2:3]) / cam.focal_x * 40 * np.array([1.0, 0.55, 0.8], np.float32)
+    sc.pos[big, :2] *= 0.05
+    sc.pos[big, 2] = np.linspace(3.0, 8.0, len(big), dtype=np.float32)
+    sc.opa[big] = -2.0
+    out.append(("screen_filling", sc, cam))
+    return out
+
+
+def test_rgb_backward_row_layout_matches_oracle(gpu):
+    """Round 5: raster_backward_rows_kernel (GS_FRAME_BWD_ROWS: lanes = 16 Gaussians x 4 pixel quads, transmittance and rho as
+    DPP row scans, the opacity in the exponent, dead pixel rows left out) against the oracle's draw_backward + index sum +
+    projection backward (gaussian.cu:440-803, splatter.py:604-613, gaussian.cu:1371-1576), element by element with the
+    standard tolerances; and against the pixel-parallel kernel of the same build (another summation order: rel. L2)."""
+    for name, scene, cam in _rows_scenes():
+        of = OracleFrame(scene, cam)
+        gimg = np.random.default_rng(8).normal(size=of.image.shape).astype(np.float32)
+        gimg, _ = of.robust_grad_image(gimg)
+        ref, scale = of.backward(gimg, with_scale=True)
+        got = {}
+        for rows in (True, False):
+            params = to_torch(scene, gpu, requires_grad=True)
+            r = FrameRenderer(gpu, max_pairs=max(len(of.ids) + 64, 256), training=True, auto_grow=False, bwd_rows=rows,
+                              force_strips=True)
+            img = r.render(*params, cam)
+            assert bool(r._frame.flags & 64) == rows
+            img.backward(torch.from_numpy(gimg).to(gpu))
+            got[rows] = [t.grad.cpu().numpy() for t in params]
+        assert_grads_close(got[True], ref, scale, f"row layout, {name}")
+        for a, b, t in zip(got[True], got[False], ("pos", "quat", "scale", "opa", "rgb")):
+            den = np.linalg.norm(b.astype(np.float64)) + 1e-300
+            assert np.linalg.norm(a.astype(np.float64) - b) / den < 2e-5, (name, t)
+            culled = of.mask == 0
+            assert np.abs(a[culled]).max(initial=0.0) == 0.0, (name, t)
+
+
+def test_row_layout_kernel_follows_the_saturated_bucket_statistic(gpu):
+    """Which rgb backward kernel runs is the caller's decision (GS_FRAME_BWD_ROWS); FrameRenderer takes it from the share of
+    the backward's buckets that belong to saturated tiles -- the upper half of the `buckets` counter, read back with the
+    frame's other counters: an opaque scene (every tile's pixels saturate long before its list ends) switches the row
+    layout on from the next frame, a transparent one (every list composited to its end) never does, bwd_rows=False
+    never switches, and a renderer that goes from the first scene to the second switches off again."""
+    dense, cam = case(60_000, 128, 96, seed=3)
+    dense.opa += 3.0
+    thin, _ = case(20_000, 128, 96, seed=9)
+    thin.opa[:] = -4.0
+    g = torch.from_numpy(np.random.default_rng(1).normal(size=(96, 128, 3)).astype(np.float32)).to(gpu)
+
+    def step(r, scene):
+        params = to_torch(scene, gpu, requires_grad=True)
+        img = r.render(*params, cam)
+        flag = bool(r._frame.flags & 64)
+        img.backward(g)
+        st = r.stats()  # (synchronises; the trainer reads the same counters asynchronously)
+        return flag, st
+
+    r = FrameRenderer(gpu, max_pairs=1 << 20, training=True, auto_grow=False)
+    flag, st = step(r, dense)
+    assert not flag and st.buckets > 0 and st.saturated_buckets > 0.9 * st.buckets and r._bwd_rows_seen
+    flag, st = step(r, dense)
+    assert flag  # from the second frame on
+    flag, st = step(r, thin)
+    assert flag and st.saturated_buckets < 0.1 * st.buckets and not r._bwd_rows_seen  # (this frame still ran flagged)
+    flag, _ = step(r, thin)
+    assert not flag
+    never = FrameRenderer(gpu, max_pairs=1 << 20, training=True, auto_grow=False, bwd_rows=False)
+    assert [step(never, dense)[0] for _ in range(3)] == [False, False, False]
 
 
 # ------------------------------------------------------------------ BASELINE.json full sizes
@@ -625,7 +714,7 @@ def test_full_size_backward_properties(gpu):
         assert float(a[vis].abs().max()) > 0.0
 
 
-@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg4", "cfg4_deg3", "cfg5_yaw35"])
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg4", "cfg4_deg3", "cfg5_yaw35", "cfg5_yaw35_rows"])
 def test_full_size_backward_matches_oracle(gpu, cfg):
     """BASELINE.json configs[1], [2] (376,467 / 506,627 Gaussians, 1080p, rgb logits), [3] (2.4 M Gaussians, 1080p,
     SH: the reference's degree 2, and "cfg4_deg3": the degree 3 -- 48 coefficients, 115 M of them -- that configs[3]
@@ -638,6 +727,8 @@ def test_full_size_backward_matches_oracle(gpu, cfg):
     from gs_scene import CONFIGS
 
     base, _, variant = cfg.partition("_")
+    rows = variant.endswith("_rows")  # "cfg5_yaw35_rows": the same view with the row-layout rgb kernel (GS_FRAME_BWD_ROWS)
+    variant = variant[:-5] if rows else variant
     n, W, H, use_sh = CONFIGS[base]
     deg = 3 if variant == "deg3" else 2
     scene = make_scene(n, W, H, seed=2023, use_sh=use_sh, sh_degree=deg)
@@ -649,10 +740,11 @@ def test_full_size_backward_matches_oracle(gpu, cfg):
     ref, scale = of.backward(gimg, with_scale=True)
     params = to_torch(scene, gpu, requires_grad=True)
     assert params[4].shape[1] == (3 * (deg + 1) ** 2 if use_sh else 3)
-    r = FrameRenderer(gpu, max_pairs=len(of.ids) + 64, training=True, auto_grow=False)
+    r = FrameRenderer(gpu, max_pairs=len(of.ids) + 64, training=True, auto_grow=False, bwd_rows=rows)
     img = r.render(*params, cam)
     assert r.stats().pairs == len(of.ids)
     assert np.abs(img.detach().cpu().numpy() - of.image).max() < IMG_ATOL
+    assert bool(r._frame.flags & 64) == rows
     img.backward(torch.from_numpy(gimg).to(gpu))
     report = assert_grads_close([t.grad.cpu().numpy() for t in params], ref, scale, cfg, rel_bounds=True)
     print(cfg, f"pixels with dL/dimage masked: {n_masked} ({100.0 * n_masked / (W * H):.3f} %);",

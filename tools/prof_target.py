@@ -26,26 +26,35 @@ ap.add_argument("--frames", type=int, default=60)
 ap.add_argument("--backward", action="store_true")
 ap.add_argument("--sh-degree", type=int, default=2)
 ap.add_argument("--no-stage-times", action="store_true", help="skip the hipEvent-bracketed frames (PMC passes)")
+ap.add_argument("--bwd-rows", type=int, default=-1,
+                help="rgb backward kernel: 1 = row layout (GS_FRAME_BWD_ROWS), 0 = pixel-parallel, -1 = the renderer's own "
+                     "choice from the saturated-bucket statistic (it needs a backward + stats() to have run: below)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 n, W, H, use_sh = CONFIGS[a.config]
 scene = make_scene(n, W, H, seed=2023, use_sh=use_sh, sh_degree=a.sh_degree)
 cam = make_camera(W, H)
 params = [torch.from_numpy(x).to(dev) for x in (scene.pos, scene.quat, scene.scale, scene.opa, scene.rgb)]
-r = FrameRenderer(dev, max_pairs=1 << 20, training=a.backward, auto_grow=True)
+r = FrameRenderer(dev, max_pairs=1 << 20, training=a.backward, auto_grow=True,
+                  bwd_rows=None if a.bwd_rows < 0 else bool(a.bwd_rows))
 img, _ = r.forward(*params, cam)
 st = r.stats()
 r.max_pairs = int(st.pairs * 1.1) + 4096
 r.auto_grow = False
 img, _ = r.forward(*params, cam)
 g = (torch.sign(img - 0.5) / img.numel()).contiguous()
+if a.backward:  # one backward + its counters: the renderer settles which rgb backward kernel this scene takes
+    r.backward(g)
+    r.stats()
+    img, _ = r.forward(*params, cam)
 for _ in range(a.frames):
     img, _ = r.forward(*params, cam)
     if a.backward:
         r.backward(g)
 torch.cuda.synchronize()
 out = {"config": a.config, "n": n, "visible": st.visible, "tile_pairs": st.pairs, "frames": a.frames,
-       "backward": a.backward, "sh_degree": a.sh_degree if use_sh else None}
+       "backward": a.backward, "sh_degree": a.sh_degree if use_sh else None,
+       "bwd_rows_flag": bool(r._frame.flags & 64)}
 if not a.no_stage_times:
     pf = [r.profile_forward(*params, cam) for _ in range(12)][4:]
     out["forward_stage_ms"] = {k: round(statistics.median(p[k] for p in pf), 4) for k in pf[0]}

@@ -3,7 +3,8 @@
 
 Suffixes: `_deg3` = degree-3 SH (48 coefficients), `_keys` = also write the sorted keys (GS_FRAME_EMIT_SORTED_KEYS),
 `_fwd` = inference forward only (no checkpoints, no backward), `_ss` = slice-sorted binning variant, `_tb` = table
-binning variant (default: the strip variant)."""
+binning variant (default: the strip variant), `_rows` / `_pix` = the row-layout / pixel-parallel rgb backward kernel
+(default: the renderer's choice from the saturated-bucket statistic of a first backward)."""
 import os
 import sys
 
@@ -19,7 +20,7 @@ dev = torch.device("cuda:0")
 for cfg in (sys.argv[1:] or ("cfg2", "cfg4", "cfg5")):
     base = cfg
     flags = set()
-    for suf in ("_deg3", "_keys", "_fwd", "_ss", "_tb"):
+    for suf in ("_deg3", "_keys", "_fwd", "_ss", "_tb", "_rows", "_pix"):
         if suf in base:
             base = base.replace(suf, "")
             flags.add(suf)
@@ -30,7 +31,8 @@ for cfg in (sys.argv[1:] or ("cfg2", "cfg4", "cfg5")):
     params = [torch.from_numpy(a).to(dev) for a in (scene.pos, scene.quat, scene.scale, scene.opa, scene.rgb)]
     training = "_fwd" not in flags
     r = FrameRenderer(dev, max_pairs=1 << 20, training=training, auto_grow=True, emit_sorted_keys="_keys" in flags,
-                      slice_sort="_ss" in flags, table_bin="_tb" in flags)
+                      slice_sort="_ss" in flags, table_bin="_tb" in flags,
+                      bwd_rows=True if "_rows" in flags else False if "_pix" in flags else None)
     r.forward(*params, cam)
     st = r.stats()
     r.max_pairs = int(st.pairs * 1.1) + 4096
@@ -43,8 +45,12 @@ for cfg in (sys.argv[1:] or ("cfg2", "cfg4", "cfg5")):
     bw = {}
     if training:
         g = torch.sign(img - 0.5) / img.numel()
+        r.backward(g)
+        r.stats()  # (the renderer settles which rgb backward kernel this scene takes)
+        r.forward(*params, cam)
         pb = [r.profile_backward(g) for _ in range(8)][3:]
         bw = {k: round(float(np.median([p[k] for p in pb])), 4) for k in pb[0]}
-    print(cfg, "V", st.visible, "M", st.pairs, "fwd", fw, "bwd", bw, flush=True)
+    print(cfg, "V", st.visible, "M", st.pairs, "fwd", fw, "bwd", bw,
+          "rows" if (training and r._frame.flags & 64) else "", flush=True)
     del r, params
     torch.cuda.empty_cache()
