@@ -74,8 +74,10 @@ class FrameRenderer:
         self.long_lists = long_lists
         self._long_lists_seen = False
         # rgb training frames: which kernel composites the backward (GS_FRAME_BWD_ROWS, include/gs_abi.h).  None: by the
-        # share of saturated buckets an earlier backward of this renderer reported (read back with the other counters:
-        # `stats()`, or the asynchronous copy of auto_grow="async"), with hysteresis; True / False: always / never.
+        # share of saturated buckets the last backward in front of a `stats()` call reported, with hysteresis -- the
+        # choice moves at those (synchronising, caller-placed) calls only, never from asynchronously arriving counters,
+        # so that a training run takes the same kernels -- the same bits -- every time (gs_train.Trainer asks once per
+        # Gaussian set, after its first step); True / False: always / never.
         self.bwd_rows = bwd_rows
         self._bwd_rows_seen = False
         self.max_pairs = int(max_pairs)
@@ -260,7 +262,8 @@ class FrameRenderer:
             v, m, o, b, longest = (int(x) for x in self._async_host.tolist())
             self._async_event = None
             self._long_lists_seen = self._long_lists_seen or longest > 2048
-            self._note_buckets(b)
+            # (NOT the backward-kernel choice: counters that arrive asynchronously would make it -- and with it the
+            # gradients' last bits -- depend on host timing; it moves at synchronous stats() calls only)
             if o:
                 self.overflowed_frames += 1
                 self._last_overflow_serial = self._async_serial
@@ -402,6 +405,10 @@ class FrameRenderer:
             if self.auto_grow == "async":
                 self._poll_async_counters()
             f = b["f"]
+            # the backward-kernel choice is a property of the BACKWARD: taken where the frame is completed, not where its
+            # project stage was issued (a choice that moved in between must not depend on whether the frame was begun ahead)
+            rows = self.bwd_rows or (self.bwd_rows is None and self._bwd_rows_seen)
+            f.flags = (f.flags & ~_lib.GS_FRAME_BWD_ROWS) | (_lib.GS_FRAME_BWD_ROWS if rows else 0)
             _lib.check(_lib.gs_frame_forward_rest(C.byref(f), stream), "gs_frame_forward_rest")
             self._frame = f
             self._frame_serial += 1

@@ -221,7 +221,8 @@ class Trainer:
     def __init__(self, params: Sequence[torch.Tensor], cameras, targets: Sequence[torch.Tensor],
                  opt: Optional[TrainOptions] = None, world_size: int = 1, max_pairs: int = 1 << 20,
                  scale_activation: str = "abs", densify: bool = False, generator: Optional[torch.Generator] = None,
-                 per_view_stat: Optional[bool] = None, exchange: str = "all_reduce", n_slices: Optional[int] = None):
+                 per_view_stat: Optional[bool] = None, exchange: str = "all_reduce", n_slices: Optional[int] = None,
+                 bwd_rows: Optional[bool] = None):
         self.opt = opt or TrainOptions()
         self.world_size = int(world_size)
         self.n_slices = n_slices  # exchange slices of the Gaussian array (gs_dp.py; None: by scene size)
@@ -250,8 +251,12 @@ class Trainer:
         # capacity was simply unknown; after that a view's pair count only drifts, and the workspace grows ahead of
         # it (25 % head room).  Should a frame overflow all the same, `renderer.overflowed_frames` counts it and
         # train_step warns once the late counters arrive.
+        # `bwd_rows`: which kernel composites the rgb backward (FrameRenderer; None: by the scene's share of saturated
+        # buckets, asked for ONCE per Gaussian set -- behind its first step -- so that a run takes the same kernels, the
+        # same bits, every time).
         self.renderer = FrameRenderer(dev, max_pairs=max_pairs, training=True, scale_activation=scale_activation,
-                                      auto_grow="async")
+                                      auto_grow="async", bwd_rows=bwd_rows)
+        self._backward_choice_due = True
         self._views_checked = set()
         self._overflow_warned = 0
         self._lambdas, self._base = lr_lambdas(self.opt), base_lrs(self.opt)
@@ -274,6 +279,7 @@ class Trainer:
                                                self.opt.grad_accum_method, self.world_size) if split_stat else None)
         self.grad_counter = None  # "mean" accumulation only: per-Gaussian count of views that saw it (train.py:150)
         self._views_checked = set()  # a new Gaussian set: every view's first frame is capacity-checked again
+        self._backward_choice_due = True  # ... and the rgb backward kernel is chosen again, behind its first step
 
     @property
     def n_gaussians(self) -> int:
@@ -389,6 +395,14 @@ class Trainer:
             self.optimizer.step()  # also: accum_max_grad = max(|pos.grad|, accum) or += |pos.grad| (train.py:144-153)
         if seen is not None and self.view_stat is None:
             self.grad_counter = seen if self.grad_counter is None else self.grad_counter + seen
+        if self._backward_choice_due:
+            # One host synchronisation per Gaussian set (the set's first frame was capacity-checked synchronously a moment
+            # ago anyway): the backward that has just been issued left the share of its buckets that belong to saturated
+            # tiles in the frame's counters; the renderer keeps the rgb backward kernel that share asks for until the next
+            # Gaussian set (after a densification the scene is a different one).
+            self._backward_choice_due = False
+            if r.bwd_rows is None and self.flat.params[4].dim() == 2 and self.flat.params[4].shape[1] == 3:
+                r.stats()
         if self.densify and (control or only_delete):
             self.adaptive_control(i_iter, densify=control and not in_reset)
         # train.py:184-185: the learning rates of the NEXT step
