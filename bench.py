@@ -456,7 +456,10 @@ def main():
                      world_size=world, max_pairs=int(pairs * 1.25) + 4096, exchange=exchange, n_slices=n_slices)
         tr.flat.force_collective = (use_dist or force) and dist.is_initialized()
         tr.flat.enable_collective = bool(collective)
-        dtt, blocks, k = time_training(tr, k, warm=30, repeats=repeats, barrier=barrier, max_over_ranks=max_over_ranks)
+        if args.quick:  # (test hook: a handful of steps -- under two gloo ranks on one GPU an exchange takes ~40 ms)
+            k = 3
+        dtt, blocks, k = time_training(tr, k, warm=10 if args.quick else 30, repeats=repeats, barrier=barrier,
+                                       max_over_ranks=max_over_ranks)
         assert tr.renderer.overflowed_frames == 0 and not tr.renderer.last_frame_overflowed(wait=True)
         detail = {}
         if rank == 0:

@@ -594,7 +594,8 @@ def test_bench_multi_gpu_leg_runs_under_two_ranks(gpu, tmp_path):
     scene = mg["scenes"]["cfg1"]
     for mode in ("all_reduce", "reduce_scatter"):
         m = scene["modes"][mode]
-        assert m["train_views_per_s"] > 0 and np.isfinite(m["exposed_ms"]) and m["exchange_ms"] > 0 and m["busbw_GBs"] > 0
+        # (busbw: half a megabyte through gloo and the host in ~40 ms rounds to 0.0 GB/s -- present and finite is the point)
+        assert m["train_views_per_s"] > 0 and np.isfinite(m["exposed_ms"]) and m["exchange_ms"] > 0 and m["busbw_GBs"] >= 0
     assert scene["two_slice_pipeline"]["n_slices"] == 2
     assert set(scene["slices_sweep_all_reduce"]) >= {"1"}
     # sharded optimizer: half the state per rank
