@@ -30,6 +30,7 @@ FETCH_FACTOR = {
                                              "pair offsets are gathered (x1); SH coefficients are contiguous 108 / 192-B "
                                              "runs per Gaussian (between the two)"),
     "raster_backward_pixel_kernel": (1.5, "as raster_backward_pixel_sh_kernel"),
+    "raster_backward_rows_kernel": (1.5, "as raster_backward_pixel_sh_kernel (round 5: the rgb backward in the row layout)"),
     "raster_backward_mfma_sh_kernel": (1.5, "as raster_backward_pixel_sh_kernel (round 4: the SH backward of the frame path)"),
     "raster_backward_kernel": (1.5, "as raster_backward_pixel_sh_kernel"),
     "frame_project_backward_kernel": (1.5, "mixed: rectangles, offsets and raw parameters stream (x2), gradient rows are "
@@ -75,7 +76,7 @@ for arg in sys.argv[1:]:
     data[cfg] = entry
 data["_note"] = (
     "HBM-side bytes per launch from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of "
-    "tools/prof_target.py <config>; current set: the `source` file of every config, profiles/r03_*). FETCH_SIZE / "
+    "tools/prof_target.py <config>; current set: the `source` file of every config). FETCH_SIZE / "
     "WRITE_SIZE are in KiB. FETCH_SIZE = 64 B x read requests: a coalesced stream asks for 128 B per request (x2, the "
     "correction of MI355X_MICROARCH.md), an isolated 64-byte line is one 64-B request (x1: exact) -- "
     "profiles/r04_fetch_calibration.json; every entry says which factor it used (`correction`) and gives the bounds. "
