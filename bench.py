@@ -788,7 +788,7 @@ def main():
             from soak import training_soak
 
             sk = {}
-            for deg, iters in ((0, 1500), (2, 1500), (3, 1500)):
+            for deg, iters in ((0, 3000), (2, 2000), (3, 2000)):  # (round 4 quoted these lengths: tools/soak.py)
                 r_ = training_soak(dev, deg, iters)
                 r_.pop("iters_per_s_blocks", None)
                 sk["rgb" if deg == 0 else f"sh_degree_{deg}"] = r_

@@ -195,11 +195,18 @@ GRAD_KAPPA = 3e-5
 GRAD_L2 = 2e-5  # ||got - ref||_2 / ||ref||_2 per tensor
 # Independent of the oracle-supplied scale: the PURE relative error |got - ref| / |ref|
 # over the elements above 1e-6 of the tensor's largest entry -- its 99.9th percentile, and its maximum (single elements
-# that are small differences of large terms: measured up to 7.6 % at full size, profiles/r03_b_full_size_gradient_parity.txt
-# and profiles/r04_*_gradient_parity.txt)
-GRAD_REL_P999 = 1e-2   # measured (round 4, profiles/r04_g_full_size_gradient_parity.txt): pos 1.7e-3 ... 5.4e-3 -- dL/dx =
-                       # ln2 (2 A' Sx - B' Sy) is a difference of two sums of like magnitude --, every other tensor far below
-GRAD_REL_MAX = 0.15
+# that are small differences of large terms).  Per tensor, at most 2 x the worst value measured over the six full-size
+# cases on the round's final tree (round 5, profiles/r05_h_full_size_gradient_parity.txt; VERDICT round 4, weak item 2:
+# one pair of constants for all tensors was 1.7 ... 700 x looser than measured):
+#            measured p99.9 / max        bound
+#   pos      5.4e-3 / 5.4e-2   (dL/dx = ln2 (2 A' Sx - B' Sy): a difference of two sums of like magnitude)
+#   quat     3.1e-3 / 2.9e-2
+#   scale    2.7e-3 / 1.1e-2
+#   opa      6.0e-3 / 7.6e-2   (T gc against rho / (1 - alpha) for a Gaussian deep in a tile's list)
+#   rgb      1.4e-5 / 1.2e-2   (colour logits / SH coefficients: sums of like-signed terms)
+# The kernels are bitwise repeatable, so the measured values are properties of the build, not of a run.
+GRAD_REL_P999 = {"pos": 1.0e-2, "quat": 6.0e-3, "scale": 5.0e-3, "opa": 1.2e-2, "rgb": 2.8e-5}
+GRAD_REL_MAX = {"pos": 0.10, "quat": 0.055, "scale": 0.022, "opa": 0.15, "rgb": 0.024}
 
 
 # Entries 14 orders of magnitude below the tensor's largest are compared up to this floor: they are sums of products
@@ -236,9 +243,10 @@ def assert_grads_close(grads, ref, scale, what="", rtol=GRAD_RTOL, kappa=GRAD_KA
         ok, worst, where, pure = grad_close(g, ref[name], scale[name], rtol, kappa)
         rl2 = float(np.linalg.norm(g.astype(np.float64) - ref[name]) / (np.linalg.norm(ref[name].astype(np.float64)) + 1e-300))
         # worst PURE relative error |got - ref| / |ref| over the elements above 1e-6 of the tensor's largest: a figure
-        # that does not involve the oracle-supplied conditioning scale at all (asserted since round 4: GRAD_REL_MAX and,
-        # for the bulk, GRAD_REL_P999; an element that is the small difference of large terms is legitimately off by
-        # many of its own ulp, which is why the maximum gets 15 % and the 99.9th percentile 0.1 %)
+        # that does not involve the oracle-supplied conditioning scale at all (asserted since round 4, per tensor since
+        # round 5: GRAD_REL_MAX and, for the bulk, GRAD_REL_P999 -- an element that is the small difference of large terms
+        # is legitimately off by many of its own ulp, which is why the maximum gets percents where the 99.9th percentile
+        # gets tenths of a percent)
         r64 = np.abs(np.asarray(ref[name], np.float64))
         big = r64 > 1e-6 * (r64.max() if r64.size else 0.0)
         rels = np.abs(g.astype(np.float64) - ref[name])[big] / r64[big] if big.any() else np.zeros(1)
@@ -249,7 +257,7 @@ def assert_grads_close(grads, ref, scale, what="", rtol=GRAD_RTOL, kappa=GRAD_KA
                     float(ref[name][where]), "scale", float(scale[name][where]))
         assert rl2 <= l2, (what, name, "relative L2 error", rl2)
     if rel_bounds:  # the full-size tests (>= 376 k Gaussians: the percentile means something there)
-        bad = {k: v[3:] for k, v in report.items() if v[4] > GRAD_REL_P999 or v[3] > GRAD_REL_MAX}
+        bad = {k: v[3:] for k, v in report.items() if v[4] > GRAD_REL_P999[k] or v[3] > GRAD_REL_MAX[k]}
         assert not bad, (what, "pure relative error (worst above 1e-6 of the maximum, 99.9th percentile)", bad, report)
     return report
 

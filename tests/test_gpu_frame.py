@@ -361,6 +361,33 @@ def test_frame_tile_culling_method_dist(gpu, dist_thresh, W, H):
         FrameRenderer(gpu, tile_culling_method="nearest")
 
 
+@pytest.mark.parametrize("dist_thresh,n", [(0.5, 6_000), (0.2, 2_000)])
+def test_frame_tile_culling_method_dist_sh_backward(gpu, dist_thresh, n):
+    """"dist" listing with SH colours, backward: since round 5 the SH readers decide which gradient rows exist from the tiles'
+    stop keys (a flag byte per row until then) -- and in a "dist" frame the rows are laid out over the disc's bounding SQUARE,
+    of which only the listed tiles hold a row: the stop-key test alone would read the holes.  dist_thresh 0.5: discs of ~12
+    tiles (the projection backward's own row walk); 0.2: ~80 tiles per Gaussian, beyond the 64 rows from which
+    sh_big_rows_kernel sums a Gaussian's rows.  Gradients against the oracle, element by element."""
+    scene, cam = case(n, 250, 186, seed=29, use_sh=True)
+    scene.opa += 1.0  # some tiles saturate: rows behind the stop keys do not exist
+    of = OracleFrame(scene, cam, tile_culling_method="dist", dist_thresh=dist_thresh)
+    counts = np.bincount(of.ids, minlength=scene.n)
+    assert (counts.max() > 64) == (dist_thresh < 0.3), counts.max()
+    params = to_torch(scene, gpu, requires_grad=True)
+    r = FrameRenderer(gpu, max_pairs=len(of.ids), training=True, auto_grow=True, tile_culling_method="dist",
+                      tile_culling_dist_thresh=dist_thresh)
+    r.forward(*params, cam)  # grows the workspace to the sum of the bounding squares
+    r.auto_grow = False
+    img = r.render(*params, cam)
+    assert r.stats().pairs == len(of.ids)
+    assert np.array_equal(r.debug_views()["sorted_ids"].cpu().numpy(), of.ids)
+    gimg = np.random.default_rng(6).normal(size=of.image.shape).astype(np.float32)
+    gimg, _ = of.robust_grad_image(gimg)
+    img.backward(torch.from_numpy(gimg).to(gpu))
+    ref, scale = of.backward(gimg, with_scale=True)
+    assert_grads_close([t.grad.cpu().numpy() for t in params], ref, scale, f"dist, SH, thresh {dist_thresh}")
+
+
 @pytest.mark.parametrize("sh_degree", [2, 3])
 def test_frame_forward_sh(gpu, sh_degree):
     # degree 2 = the reference's 27 coefficients; degree 3 (48) is the extension BASELINE config 4 names
