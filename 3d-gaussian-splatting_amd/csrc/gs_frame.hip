@@ -459,7 +459,7 @@ extern "C" int gs_frame_debug_tile_nproc(const gs_frame *f, const uint32_t **til
     return 0;
 }
 
-int gs_bwd_mfma_slots(int color_dim, int n_tiles);  // raster_bwd.hip: (workgroup, wave) slots of the SH backward on the matrix pipe
+int gs_bwd_mfma_slots(int color_dim, int n_tiles, int64_t max_buckets);  // raster_bwd.hip: (workgroup, wave) slots of the SH backward on the matrix pipe
 
 extern "C" int gs_frame_debug_bwd_exec_rows(const gs_frame *f, const uint32_t **exec_rows, int32_t *n_slots) {
     int rc = validate(f);
@@ -468,7 +468,7 @@ extern "C" int gs_frame_debug_bwd_exec_rows(const gs_frame *f, const uint32_t **
     GS_CHECK_ARG(f->training, "the executed-row counters are kept by training frames only");
     gs_frame_ws ws = gs_frame_carve(f->workspace, f->N, f->max_pairs, f->width, f->height, f->color_dim, 1);
     *exec_rows = ws.bwd_exec_rows;
-    *n_slots = gs_bwd_mfma_slots(f->color_dim, gs_frame_geometry(f).n_tiles);
+    *n_slots = gs_bwd_mfma_slots(f->color_dim, gs_frame_geometry(f).n_tiles, ws.max_buckets);
     return 0;
 }
 

@@ -173,6 +173,9 @@ static constexpr int gs_row_compact(int color_dim, int f) {
 // executed pixel-row steps of the SH backward on the matrix pipe, one counter per (workgroup, wave): what its MFMA flops
 // are counted from (bench.py); [GS_BWD_EXEC_SLOTS x T] u32
 #define GS_BWD_EXEC_SLOTS 8
+// SH backward on the matrix pipe: buckets per work item (raster_bwd.hip: mfma_items_kernel); the item list holds at most
+// T + max_buckets / GS_MFMA_ITEM_BUCKETS items
+#define GS_MFMA_ITEM_BUCKETS 8
 
 struct gs_frame_geom {
     int padW, padH, ntx, nty, n_tiles, crop_top, crop_left;
@@ -249,6 +252,8 @@ struct gs_frame_ws {
     uint4 *bucket_info;            // [max_buckets + 8] (tile, first Gaussian, count, list start) per bucket
     float4 *ckpt;                  // [max_buckets][256] (T, Cr, Cg, Cb) at bucket starts
     float *rows;                   // [max_pairs][GS_ROW(C)] per-pair gradient rows in EMISSION order
+    uint4 *mfma_items;             // SH frames: [T + max_buckets / 8 + 8] work items (tile, first bucket, buckets <= 8, -) of the SH
+    uint32_t *mfma_n_items;        //            backward on the matrix pipe, heavy tiles first, and their count (raster_bwd.hip)
     uint32_t *bwd_exec_rows;       // [GS_BWD_EXEC_SLOTS x T] SH backward on the matrix pipe: pixel-row steps (16 Gaussians x 16
                                    // pixels) every wave executed in the last backward (rows whose pixels had all stopped are
                                    // left out); slot = workgroup x waves + wave.  Diagnostic (bench.py's MFMA flop count).
@@ -346,6 +351,8 @@ static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pair
         ws.ckpt = (float4 *)take(sizeof(float4) * 256 * (size_t)ws.max_buckets);
         ws.rows = (float *)take(sizeof(float) * (size_t)gs_row_floats(color_dim) * max_pairs);
         ws.bwd_exec_rows = (uint32_t *)take(sizeof(uint32_t) * GS_BWD_EXEC_SLOTS * (size_t)G.n_tiles);
+        ws.mfma_items = (uint4 *)take(sizeof(uint4) * (color_dim == 3 ? 1 : (size_t)(G.n_tiles + ws.max_buckets / GS_MFMA_ITEM_BUCKETS + 8)));
+        ws.mfma_n_items = (uint32_t *)take(sizeof(uint32_t));
         ws.stop_keys = (uint64_t *)take(sizeof(uint64_t) * G.n_tiles);
     } else {
         ws.tile_nproc = nullptr;
@@ -354,6 +361,8 @@ static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pair
         ws.ckpt = nullptr;
         ws.rows = nullptr;
         ws.bwd_exec_rows = nullptr;
+        ws.mfma_items = nullptr;
+        ws.mfma_n_items = nullptr;
         ws.stop_keys = nullptr;
     }
     ws.total_bytes = off;

@@ -52,6 +52,8 @@ __global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t *__res
                                                           const int32_t *__restrict__ ranges, int frame_ranges) {
     __shared__ uint32_t s_wave[2][16];
     __shared__ uint32_t s_carry[2];
+    __shared__ uint32_t s_nheavy;
+    __shared__ uint4 s_heavy[1024];  // (tile, first record, Gaussians processed, list start) of the chunk's tiles beyond 8 buckets
     if (threadIdx.x < 2) s_carry[threadIdx.x] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -73,16 +75,34 @@ __global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t *__res
             sat_all += s_wave[1][w];
         }
         const uint32_t carry = s_carry[0];
+        if (threadIdx.x == 0) s_nheavy = 0;
+        __syncthreads();
         if (i < n_tiles) {
             const uint32_t first = carry + woff + incl - v;
             bucket_offsets[i] = first;
             const uint32_t st = (uint32_t)(frame_ranges ? ranges[2 * i] : ranges[i]);
-            for (uint32_t b = 0; b < v; ++b) {
-                const uint32_t rem = np - b * GS_BUCKET;
-                bucket_info[first + b] = make_uint4((uint32_t)i, b * GS_BUCKET, rem < GS_BUCKET ? rem : GS_BUCKET, st);
+            if (v <= 8) {
+                for (uint32_t b = 0; b < v; ++b) {
+                    const uint32_t rem = np - b * GS_BUCKET;
+                    bucket_info[first + b] = make_uint4((uint32_t)i, b * GS_BUCKET, rem < GS_BUCKET ? rem : GS_BUCKET, st);
+                }
+            } else {
+                // a tile with dozens of buckets (a pile of a densifying run: 100 and more) would keep ONE thread storing its
+                // records while 1,023 wait -- 88 us per call on average in the rgb soak (profiles/r05_j_*), as long as the
+                // loss kernel this scan is meant to hide under: such tiles are written by the whole workgroup below
+                const uint32_t h = atomicAdd(&s_nheavy, 1u);
+                s_heavy[h] = make_uint4((uint32_t)i, first, np, st);
             }
         }
         __syncthreads();
+        for (uint32_t h = 0; h < s_nheavy; ++h) {
+            const uint4 t = s_heavy[h];
+            const uint32_t vb = (t.z + GS_BUCKET - 1) / GS_BUCKET;
+            for (uint32_t b = threadIdx.x; b < vb; b += 1024) {
+                const uint32_t rem = t.z - b * GS_BUCKET;
+                bucket_info[t.y + b] = make_uint4(t.x, b * GS_BUCKET, rem < GS_BUCKET ? rem : GS_BUCKET, t.w);
+            }
+        }
         if (threadIdx.x == 1023) {
             s_carry[0] = carry + woff + incl;
             s_carry[1] += sat_all;
@@ -145,6 +165,9 @@ struct BwdIn {
     // (0: all of them), the one-wave-per-bucket kernel the buckets from bucket_first on (see launch_bwd)
     uint32_t bucket_cap, bucket_first;
     uint32_t use_rows;  // rgb frames: GS_FRAME_BWD_ROWS -- the row-layout kernel instead of the pixel-parallel one (launch_bwd)
+    // SH frames on the matrix pipe: the work items (tile, first bucket, buckets) of mfma_items_kernel and their count
+    const uint4 *mfma_items;
+    const uint32_t *mfma_n_items;
 };
 
 // Inputs of one pixel for the backward kernels: final colour, and dL/dC -- for the frame path the gradient of
@@ -1355,6 +1378,19 @@ __device__ __forceinline__ void gs_row_scan_mul4_excl(float p[4], float t[4]) {
 #ifndef GS_BWD_MFMA_TILES
 #define GS_BWD_MFMA_TILES 1  // tiles per workgroup (see the kernel's header: the waves of a workgroup share their buckets)
 #endif
+#ifndef GS_BWD_MFMA_CHUNK
+#define GS_BWD_MFMA_CHUNK GS_MFMA_ITEM_BUCKETS  // buckets per work item (gs_frame_layout.h; 0: one workgroup per tile, round 4)
+#endif
+static_assert(GS_BWD_MFMA_CHUNK == 0 || GS_BWD_MFMA_CHUNK >= GS_MFMA_ITEM_BUCKETS, "the item list is sized for GS_MFMA_ITEM_BUCKETS");
+constexpr bool GS_MFMA_ITEMS = GS_BWD_MFMA_CHUNK > 0 && GS_BWD_MFMA_TILES == 1 && GS_BWD_MFMA_SPLIT == 1;
+// workgroups of the matrix-pipe launch: one per work item up to 2 T (the kernel walks the items with the grid as the stride;
+// the executed-row counters have GS_BWD_EXEC_SLOTS x T = 8 T slots for grid x waves)
+static inline unsigned gs_bwd_mfma_grid(int n_tiles, int64_t max_buckets) {
+    if (!GS_MFMA_ITEMS)
+        return (unsigned)(gs_div_up(n_tiles, GS_BWD_MFMA_TILES) * (GS_BWD_MFMA_TILES == 1 ? GS_BWD_MFMA_SPLIT : 1));
+    const int64_t cap_items = n_tiles + max_buckets / (GS_BWD_MFMA_CHUNK ? GS_BWD_MFMA_CHUNK : 1);
+    return (unsigned)(cap_items < 2ll * n_tiles ? cap_items : 2ll * n_tiles);
+}
 template <int CDIM, int W, int TPW>
 __global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GS_BWD_MFMA_WPE)))
 raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
@@ -1380,29 +1416,46 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
         __builtin_amdgcn_wave_barrier();
     };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // One workgroup per tile walks the tile's buckets W at a time: a tile of 14 buckets holds its workgroup four times as
-    // long as the average one, so the workgroups are dealt in the forward's dispatch order -- the tiles in descending
-    // order of what they cost in the previous frame of this workspace (raster_fwd.hip) -- where the frame has one.
+    // Work items (round 5): (tile, first bucket, buckets) with at most GS_BWD_MFMA_CHUNK buckets, in the forward's dispatch
+    // order of the tiles (heavy tiles first), built by mfma_items_kernel underneath the caller's loss.  One workgroup per TILE
+    // (round 4) walks a tile's buckets W at a time, so the kernel lasts as long as its longest tile: on the 2.4 M scene
+    // (3.8 buckets per tile on average, 14 at most) that is harmless, in a densifying run it is not -- a few tiles with 30 - 100
+    // buckets kept one workgroup busy for milliseconds while the device idled (kernel trace of tools/soak.py, SH degree 2:
+    // 1.78 ms per call on average, 5.4 ms at worst, at 376 k - 556 k Gaussians; 1.27 ms at 2.4 M Gaussians, profiles/r05_j_*).
+    // A workgroup takes items blockIdx.x, + gridDim.x, ... and rebuilds the tile's tables per item (a few microseconds
+    // against >= 56 us per bucket).  Without an item list (GS_BWD_MFMA_CHUNK = 0): one item per tile / tile part, as before.
     const uint32_t n_tiles = (uint32_t)(G.ntx * G.nty);
     constexpr uint32_t SPLIT = TPW == 1 ? GS_BWD_MFMA_SPLIT : 1;
-    const uint32_t wg = blockIdx.x / SPLIT, part = blockIdx.x % SPLIT;  // workgroup `part` of SPLIT of this tile
-    const uint32_t tile0 = (TPW == 1 && I.tile_order) ? I.tile_order[wg] : wg * TPW;
+    const uint32_t n_items = I.mfma_items ? *I.mfma_n_items : gridDim.x;
+    uint32_t n_exec = 0;  // (wave-uniform) pixel-row steps this wave executed: what its MFMA flops are counted from
+    constexpr float KS = -GS_LOG2E;  // the table holds sh'_k = -log2(e) sh_k (raster_common.h)
+    const uint32_t gq = (uint32_t)lane & 15u, jq = (uint32_t)lane >> 4;  // Gaussian of the group, pixel quad
+    float *sT = s_T[wave], *sR = s_rho[wave];
+    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+    uint32_t tile0, bk0 = 0, part = 0;
     // the workgroup's TPW consecutive tiles: their buckets form ONE work list that the W waves share (a tile has 4.3
     // buckets on average at 2.4 M Gaussians: alone it keeps four waves busy 68 % of the time, two tiles together 85 %)
     uint32_t nbk[TPW], nproc_t[TPW], total_bk = 0;
+    if (TPW == 1 && I.mfma_items) {
+        const uint4 it = I.mfma_items[item];
+        tile0 = it.x;
+        bk0 = it.y;
+        nproc_t[0] = I.tile_nproc[tile0];
+        nbk[0] = total_bk = it.z;
+    } else {
+        const uint32_t wg = item / SPLIT;
+        part = item % SPLIT;  // workgroup `part` of SPLIT of this tile
+        tile0 = (TPW == 1 && I.tile_order) ? I.tile_order[wg] : wg * TPW;
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        nproc_t[t] = tile0 + t < n_tiles ? I.tile_nproc[tile0 + t] : 0;
-        nbk[t] = (nproc_t[t] + GS_BUCKET - 1) / GS_BUCKET;
-        if (I.bucket_cap && nbk[t] > I.bucket_cap) nbk[t] = I.bucket_cap;  // the rest: one wave per bucket (launch_bwd)
-        total_bk += nbk[t];
+        for (int t = 0; t < TPW; ++t) {
+            nproc_t[t] = tile0 + t < n_tiles ? I.tile_nproc[tile0 + t] : 0;
+            nbk[t] = (nproc_t[t] + GS_BUCKET - 1) / GS_BUCKET;
+            if (I.bucket_cap && nbk[t] > I.bucket_cap) nbk[t] = I.bucket_cap;  // the rest: one wave per bucket (launch_bwd)
+            total_bk += nbk[t];
+        }
     }
-    if (total_bk <= part * W) {  // uniform: nothing (left) of these tiles for this workgroup
-        if (tid < W) O.exec_rows[(size_t)blockIdx.x * W + tid] = 0;
-        return;
-    }
-    uint32_t n_exec = 0;  // (wave-uniform) pixel-row steps this wave executed: what its MFMA flops are counted from
-    constexpr float KS = -GS_LOG2E;  // the table holds sh'_k = -log2(e) sh_k (raster_common.h)
+    if (total_bk <= part * W) continue;  // uniform: nothing (left) of these tiles for this workgroup
+    __syncthreads();  // (a wave of this workgroup may still be reading the previous item's tables)
 
     // ---- per tile: SH table, dL/dC, pixel-row centres
     for (int q = tid; q < 256 * TPW; q += 64 * W) {
@@ -1426,11 +1479,9 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
     }
     __syncthreads();
 
-    const uint32_t gq = (uint32_t)lane & 15u, jq = (uint32_t)lane >> 4;  // Gaussian of the group, pixel quad
-    float *sT = s_T[wave], *sR = s_rho[wave];
     for (uint32_t u = part * W + wave; u < total_bk; u += W * SPLIT) {
         int t = 0;
-        uint32_t b = u;
+        uint32_t b = bk0 + u;
 #pragma unroll
         for (int k = 0; k + 1 < TPW; ++k)
             if (t == k && b >= nbk[k]) {
@@ -1766,7 +1817,42 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
         }
         lds_order();  // (the next bucket's states overwrite this wave's arrays)
     }
+    }  // work items
     if (lane == 0) O.exec_rows[(size_t)blockIdx.x * W + wave] = n_exec;
+}
+
+// The SH backward's work items: (tile, first bucket, buckets <= chunk) in the forward's dispatch order of the tiles (`order`:
+// heavy tiles first; NULL: raster order); `cap`: buckets per tile the matrix-pipe kernel takes at most (long-list frames).
+__global__ void __launch_bounds__(1024) mfma_items_kernel(const uint32_t *__restrict__ tile_nproc, int n_tiles,
+                                                         const uint32_t *__restrict__ order, uint32_t cap, uint32_t chunk,
+                                                         uint4 *__restrict__ items, uint32_t *__restrict__ n_items) {
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = 0; base < n_tiles; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t tile = i < n_tiles ? (order ? order[i] : (uint32_t)i) : 0u;
+        uint32_t nb = i < n_tiles ? (tile_nproc[tile] + GS_BUCKET - 1) / GS_BUCKET : 0u;
+        if (cap && nb > cap) nb = cap;
+        const uint32_t v = (nb + chunk - 1) / chunk;
+        const uint32_t incl = gs_wave_incl_scan_u32(v);
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) woff += w < wave ? s_wave[w] : 0;
+        const uint32_t carry = s_carry, first = carry + woff + incl - v;
+        for (uint32_t c = 0; c < v; ++c) {
+            const uint32_t b0 = c * chunk, left = nb - b0;
+            items[first + c] = make_uint4(tile, b0, left < chunk ? left : chunk, 0u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = carry + woff + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_items = s_carry;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2092,8 +2178,7 @@ void launch_bwd(const RasterSrc &S, const RasterGeom &G, const BwdIn &I, const B
     const unsigned fgrid = (unsigned)(max_buckets > 0 ? (max_buckets < GS_BWD_GRID_CAP ? max_buckets : GS_BWD_GRID_CAP) : 1);
     if constexpr (FRAME && ((CDIM == 48 && GS_BWD_SH_MFMA >= 1) || (CDIM == 27 && GS_BWD_SH_MFMA >= 2))) {
         // one workgroup per GS_BWD_MFMA_TILES tiles (tiles nothing was composited in leave at once)
-        const unsigned mgrid = (unsigned)(gs_div_up(G.ntx * G.nty, GS_BWD_MFMA_TILES) *
-                                          (GS_BWD_MFMA_TILES == 1 ? GS_BWD_MFMA_SPLIT : 1));
+        const unsigned mgrid = gs_bwd_mfma_grid(G.ntx * G.nty, max_buckets);
         const int mwaves = GS_BWD_MFMA_WAVES ? GS_BWD_MFMA_WAVES : (G.ntx * G.nty >= 1024 ? 2 : 4);
         static_assert((GS_BWD_MFMA_TILES == 1 ? GS_BWD_MFMA_SPLIT : 1) * 4 <= GS_BWD_EXEC_SLOTS, "executed-row counters");
         if (mwaves == 2)
@@ -2135,12 +2220,11 @@ void launch_bwd(const RasterSrc &S, const RasterGeom &G, const BwdIn &I, const B
 
 // (workgroup, wave) slots the SH backward on the matrix pipe writes its executed-row counters to (0: this colour model
 // takes another kernel): the launch geometry of launch_bwd above
-int gs_bwd_mfma_slots(int color_dim, int n_tiles) {
+int gs_bwd_mfma_slots(int color_dim, int n_tiles, int64_t max_buckets) {
     const bool mfma = (color_dim == 48 && GS_BWD_SH_MFMA >= 1) || (color_dim == 27 && GS_BWD_SH_MFMA >= 2);
     if (!mfma) return 0;
-    const int mgrid = (int)(gs_div_up(n_tiles, GS_BWD_MFMA_TILES) * (GS_BWD_MFMA_TILES == 1 ? GS_BWD_MFMA_SPLIT : 1));
     const int mwaves = GS_BWD_MFMA_WAVES ? GS_BWD_MFMA_WAVES : (n_tiles >= 1024 ? 2 : 4);
-    return mgrid * mwaves;
+    return (int)gs_bwd_mfma_grid(n_tiles, max_buckets) * mwaves;
 }
 
 namespace {
@@ -2264,6 +2348,13 @@ int gs_stage_backward_prepare(const gs_frame *f, const gs_frame_ws &ws, const ui
     if (!per_tile)
         hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, ws.tile_nproc, FG.n_tiles,
                            ws.bucket_offsets, ws.counters + GS_CNT_BUCKETS, ws.bucket_info, ws.tile_ranges, 1);
+    const bool mfma_frame = (f->color_dim == 48 && GS_BWD_SH_MFMA >= 1) || (f->color_dim == 27 && GS_BWD_SH_MFMA >= 2);
+    if (mfma_frame && GS_MFMA_ITEMS) {  // the matrix-pipe kernel's work items, heavy tiles first where the frame has an order
+        const uint32_t cap = gs_frame_long_lists(f, FG.n_tiles) ? (uint32_t)(GS_LONG_MIN / GS_BUCKET) : 0u;
+        hipLaunchKernelGGL(mfma_items_kernel, dim3(1), dim3(1024), 0, stream, ws.tile_nproc, FG.n_tiles,
+                           (gs_frame_uses_strips(f) && f->N > 0 && GS_BWD_MFMA_ORDER) ? ws.tile_order : nullptr, cap,
+                           (uint32_t)GS_BWD_MFMA_CHUNK, ws.mfma_items, ws.mfma_n_items);
+    }
     GS_CHECK_LAUNCH();
     return 0;
 }
@@ -2301,7 +2392,8 @@ int gs_stage_raster_backward(const gs_frame *f, const gs_frame_ws &ws, const uin
     }
     BwdIn I = {f->image_padded, grad_image, ws.ckpt, ws.tile_nproc, ws.bucket_offsets, ws.bucket_info, ws.tile_ranges,
                (gs_frame_uses_strips(f) && f->N > 0 && GS_BWD_MFMA_ORDER) ? ws.tile_order : nullptr, 0, 0,
-               (f->flags & GS_FRAME_BWD_ROWS) ? 1u : 0u};
+               (f->flags & GS_FRAME_BWD_ROWS) ? 1u : 0u, GS_MFMA_ITEMS ? ws.mfma_items : nullptr,
+               GS_MFMA_ITEMS ? ws.mfma_n_items : nullptr};
     if (f->color_dim != 3 && gs_frame_long_lists(f, FG.n_tiles)) I.bucket_cap = I.bucket_first = GS_LONG_MIN / GS_BUCKET;
     BwdOut O = {ws.rows, ws.bwd_exec_rows, ws.pair_offsets, ws.rects, (uint64_t)f->max_pairs, nullptr, nullptr, nullptr, nullptr};
     if (f->color_dim == 48)
