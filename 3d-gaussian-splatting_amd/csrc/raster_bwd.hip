@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t *__res
     __shared__ uint32_t s_wave[2][16];
     __shared__ uint32_t s_carry[2];
     __shared__ uint32_t s_nheavy;
-    __shared__ uint4 s_heavy[1024];  // (tile, first record, Gaussians processed, list start) of the chunk's tiles beyond 8 buckets
+    __shared__ uint4 s_heavy[1024];  // (tile, first record, Gaussians processed, list start) of the chunk's tiles beyond 48 buckets
     if (threadIdx.x < 2) s_carry[threadIdx.x] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -81,15 +81,16 @@ __global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t *__res
             const uint32_t first = carry + woff + incl - v;
             bucket_offsets[i] = first;
             const uint32_t st = (uint32_t)(frame_ranges ? ranges[2 * i] : ranges[i]);
-            if (v <= 8) {
+            if (v <= 48) {
                 for (uint32_t b = 0; b < v; ++b) {
                     const uint32_t rem = np - b * GS_BUCKET;
                     bucket_info[first + b] = make_uint4((uint32_t)i, b * GS_BUCKET, rem < GS_BUCKET ? rem : GS_BUCKET, st);
                 }
             } else {
-                // a tile with dozens of buckets (a pile of a densifying run: 100 and more) would keep ONE thread storing its
-                // records while 1,023 wait -- 88 us per call on average in the rgb soak (profiles/r05_j_*), as long as the
-                // loss kernel this scan is meant to hide under: such tiles are written by the whole workgroup below
+                // a tile with hundreds of buckets (a pile of a densifying run) would keep ONE thread storing its records
+                // while 1,023 wait: such tiles are written by the whole workgroup below.  (Threshold 48: with 8 the serial
+                // loop over the MANY moderately long tiles of the soak's end state cost more than it saved -- 453 against
+                // 117 us per call, profiles/r05_l_*.)
                 const uint32_t h = atomicAdd(&s_nheavy, 1u);
                 s_heavy[h] = make_uint4((uint32_t)i, first, np, st);
             }
@@ -2344,13 +2345,14 @@ int gs_stage_backward_prepare(const gs_frame *f, const gs_frame_ws &ws, const ui
     // the bucket work list is what the one-wave-per-bucket kernels read; the SH backward on the matrix pipe walks a
     // tile's buckets itself (one workgroup per tile) and needs none
     const bool per_tile = ((f->color_dim == 48 && GS_BWD_SH_MFMA >= 1) || (f->color_dim == 27 && GS_BWD_SH_MFMA >= 2)) &&
-                          !gs_frame_long_lists(f, FG.n_tiles);  // (flagged frames: the buckets beyond a tile's first 32)
+                          (GS_MFMA_ITEMS || !gs_frame_long_lists(f, FG.n_tiles));  // (no items + flagged frame: the buckets
+                                                                                    // beyond a tile's first 32: hand-over)
     if (!per_tile)
         hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, ws.tile_nproc, FG.n_tiles,
                            ws.bucket_offsets, ws.counters + GS_CNT_BUCKETS, ws.bucket_info, ws.tile_ranges, 1);
     const bool mfma_frame = (f->color_dim == 48 && GS_BWD_SH_MFMA >= 1) || (f->color_dim == 27 && GS_BWD_SH_MFMA >= 2);
     if (mfma_frame && GS_MFMA_ITEMS) {  // the matrix-pipe kernel's work items, heavy tiles first where the frame has an order
-        const uint32_t cap = gs_frame_long_lists(f, FG.n_tiles) ? (uint32_t)(GS_LONG_MIN / GS_BUCKET) : 0u;
+        const uint32_t cap = 0u;  // (work items spread a long list over the device: no hand-over, see gs_stage_raster_backward)
         hipLaunchKernelGGL(mfma_items_kernel, dim3(1), dim3(1024), 0, stream, ws.tile_nproc, FG.n_tiles,
                            (gs_frame_uses_strips(f) && f->N > 0 && GS_BWD_MFMA_ORDER) ? ws.tile_order : nullptr, cap,
                            (uint32_t)GS_BWD_MFMA_CHUNK, ws.mfma_items, ws.mfma_n_items);
@@ -2394,7 +2396,14 @@ int gs_stage_raster_backward(const gs_frame *f, const gs_frame_ws &ws, const uin
                (gs_frame_uses_strips(f) && f->N > 0 && GS_BWD_MFMA_ORDER) ? ws.tile_order : nullptr, 0, 0,
                (f->flags & GS_FRAME_BWD_ROWS) ? 1u : 0u, GS_MFMA_ITEMS ? ws.mfma_items : nullptr,
                GS_MFMA_ITEMS ? ws.mfma_n_items : nullptr};
-    if (f->color_dim != 3 && gs_frame_long_lists(f, FG.n_tiles)) I.bucket_cap = I.bucket_first = GS_LONG_MIN / GS_BUCKET;
+    // One workgroup per TILE (GS_BWD_MFMA_CHUNK = 0, round 4) walks a 100,000-Gaussian pile alone: frames flagged for long lists
+    // then leave a tile's buckets beyond the first GS_BWD_SH_HANDOVER to the one-wave-per-bucket kernel.  With work items
+    // (round 5) a long list is spread over the device anyway: no hand-over, the matrix-pipe kernel takes every bucket.
+#ifndef GS_BWD_SH_HANDOVER
+#define GS_BWD_SH_HANDOVER 32
+#endif
+    if (!GS_MFMA_ITEMS && f->color_dim != 3 && gs_frame_long_lists(f, FG.n_tiles))
+        I.bucket_cap = I.bucket_first = GS_BWD_SH_HANDOVER;
     BwdOut O = {ws.rows, ws.bwd_exec_rows, ws.pair_offsets, ws.rects, (uint64_t)f->max_pairs, nullptr, nullptr, nullptr, nullptr};
     if (f->color_dim == 48)
         launch_bwd<48, true>(S, G, I, O, ws.max_buckets, stream);

@@ -30,7 +30,7 @@ def soak_scene(dev, sh_degree):
     return params, cams
 
 
-def training_soak(dev, sh_degree, n_iters, params=None, cams=None, block=100, stats_every=500):
+def training_soak(dev, sh_degree, n_iters, params=None, cams=None, block=100, stats_every=500, keep=None):
     """Training with densification every 100 iterations (train.py's schedule) from a colour-perturbed copy of the 376,467-
     Gaussian scene against renders of the original from nine cameras, a random view per iteration.  The device is
     synchronised once per `block` iterations: `iters_per_s_blocks` = the rate of every block (the scene grows and its
@@ -66,6 +66,8 @@ def training_soak(dev, sh_degree, n_iters, params=None, cams=None, block=100, st
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     vals = v.cpu().numpy()
+    if keep is not None:  # (diagnostics: the trainer in its end state)
+        keep["trainer"], keep["cams"] = tr, cams
     return {"iters": n_iters, "iters_per_s": round(n_iters / dt, 1), "block": block, "repeats": len(rates),
             "iters_per_s_median_block": round(statistics.median(rates), 1) if rates else None,
             "iters_per_s_min_block": min(rates) if rates else None, "iters_per_s_max_block": max(rates) if rates else None,
