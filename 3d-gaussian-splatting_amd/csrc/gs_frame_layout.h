@@ -59,11 +59,19 @@ static inline gs_bin_plan gs_bin_plan_for(int64_t N, int64_t max_pairs, int n_ti
 // composites all of it), only slower on such lists.  The CAPACITY of the workspace plays no part: sizing it up never
 // changes the kernel path or the rounding.
 #define GS_LONGEST_MIN 1024   // the longest-list statistic only reports lists beyond this (shorter ones read as 0)
+// Where the serial walk of a FLAGGED frame's tile ends and how long a segment is.  Round 2 measured a single 100,000-Gaussian
+// pile (4096 / 2048: 1.02 ms, 2048 / 1024: 0.59 ms).  Round 5 looked at the end state of a densifying run instead
+// (profiles/r05_m_*: 724 k Gaussians, 3.96 M pairs, nothing saturates, 2,277 tiles beyond 512 Gaussians, 160 beyond 2,048): the
+// compositing kernel lasts as long as its longest serial walk -- 2,048 Gaussians x 0.25 us (rgb) / 0.8 us (SH) per step of a
+// lone wave -- while the device idles: 0.60 ms (rgb) / 1.82 ms (SH degree 2) where the work is worth 0.21 / 1.0 ms.  Same-box
+// A/B (profiles/r05_n_*), 2048 / 1024 -> 512 / 512: pile forward 0.56 -> 0.38 ms (rgb), 1.51 -> 0.86 ms (SH); the densifying
+// soak's last block +10 ... +15 %; 512 / 256 and 1024 / 512 measured within 5 % of it.  Only flagged frames are concerned
+// (GS_FRAME_LONG_LISTS: a list beyond 2,048 was seen); a tile that saturates before 512 Gaussians never continues.
 #ifndef GS_LONG_MIN
-#define GS_LONG_MIN 2048      // Gaussians a tile's own wave composites before the rest of its list is cut into segments
+#define GS_LONG_MIN 512       // Gaussians a tile's own wave composites before the rest of its list is cut into segments
 #endif
 #ifndef GS_SEG_LEN
-#define GS_SEG_LEN 1024       // Gaussians per segment (measured on a 100,000-Gaussian pile: 4096 / 2048: 1.02 ms, 2048 / 1024: 0.59 ms)
+#define GS_SEG_LEN 512        // Gaussians per segment
 #endif
 static inline bool gs_frame_long_lists(const gs_frame *f, int n_tiles) {
     (void)n_tiles;

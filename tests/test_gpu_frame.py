@@ -155,7 +155,8 @@ def test_small_scene_with_a_pile_switches_to_the_long_list_kernels(gpu):
 @pytest.mark.parametrize("use_sh", [False, True])
 def test_long_lists_composited_in_segments(gpu, use_sh):
     """Dense frame with low-opacity pile-ups: every tile's pixels are still alive after 4096 Gaussians, so the rest
-    of each list (up to ~12,000 here) is composited in segments of 2048 by separate waves (transmittance products ->
+    of each list (up to ~12,000 here; beyond the first GS_LONG_MIN = 512 since round 5) is composited in segments of
+    GS_SEG_LEN = 512 by separate waves (transmittance products ->
     incoming transmittance -> per-segment colours -> combine; raster_fwd.hip).  Against the one-wave-per-tile walk of
     the same build (GS_FRAME_SERIAL_LONG_LISTS): image, processed counts and all five parameter gradients must agree to
     the rounding of the transmittance that enters a segment; against the oracle: the list exactly, the image to 1e-3
@@ -193,25 +194,27 @@ LONG_L2 = 2e-5
 
 @pytest.mark.parametrize("sh_degree", [2, 3])
 def test_long_lists_sh_backward_hand_over_matches_oracle(gpu, sh_degree):
-    """in a frame flagged GS_FRAME_LONG_LISTS the SH backward on the matrix pipe takes a
-    tile's first 32 buckets and hands the rest of the list to raster_backward_pixel_sh_kernel, one wave per bucket
-    (raster_bwd.hip: launch_bwd, bucket_cap / bucket_first).  Until round 5 that seam was only compared with the serial
-    walk of the same build.  Here every tile's list is 40 - 80 buckets deep (2,600 - 5,000 Gaussians of opacity 0.0067:
-    pixels stop at T <= 1e-4 around the 4,600th layer, i.e. INSIDE the part the per-bucket kernel walks) and all five
-    gradients meet the oracle's draw_backward + index sum + projection backward (gaussian.cu:440-803, splatter.py:604-613,
+    """the SH backward of frames flagged GS_FRAME_LONG_LISTS was only compared with the serial walk
+    of the same build, never with the oracle.  Round 4 had the matrix-pipe kernel take a tile's first 32 buckets and hand the
+    rest to raster_backward_pixel_sh_kernel (one wave per bucket); since round 5 the matrix-pipe kernel takes work items of at
+    most 8 buckets, several workgroups per long tile, and there is no hand-over (raster_bwd.hip: mfma_items_kernel) -- either
+    way it is this test that puts the long-list backward against the oracle: every tile's list is 60 - 96 buckets deep (3,900 -
+    6,150 Gaussians of opacity 0.0067: pixels stop at T <= 1e-4 around the 4,600th layer, i.e. deep inside the list, in
+    another work item than the one that started the tile; the forward composites the lists in segments) and all five gradients
+    meet the oracle's draw_backward + index sum + projection backward (gaussian.cu:440-803, splatter.py:604-613,
     gaussian.cu:1371-1576) element by element."""
     scene, cam = case(30_000, 64, 64, seed=33, use_sh=True, sh_degree=sh_degree)
     scene.opa[:] = -5.0
     of = OracleFrame(scene, cam)
     lens = np.diff(of.accum)
-    assert lens.min() > 32 * 64 + 4 * 64 and lens.max() > 4096, (lens.min(), lens.max())  # every tile crosses the seam
+    assert lens.min() > 32 * 64 + 4 * 64 and lens.max() > 4096, (lens.min(), lens.max())  # every tile: several work items
     gimg = np.random.default_rng(12).normal(size=of.image.shape).astype(np.float32)
     gimg, n_masked = of.robust_grad_image(gimg)
     ref, scale = of.backward(gimg, with_scale=True)
     params = to_torch(scene, gpu, requires_grad=True)
     r = FrameRenderer(gpu, max_pairs=len(of.ids) + 64, training=True, auto_grow=False, long_lists=True)
     img = r.render(*params, cam)
-    assert r._frame.flags & 16  # GS_FRAME_LONG_LISTS: the hand-over is on
+    assert r._frame.flags & 16  # GS_FRAME_LONG_LISTS
     assert r.stats().pairs == len(of.ids)
     assert np.abs(img.detach().cpu().numpy() - of.image).max() < 1e-3
     img.backward(torch.from_numpy(gimg).to(gpu))
