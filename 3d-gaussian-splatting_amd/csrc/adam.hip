@@ -37,12 +37,10 @@ __device__ __forceinline__ float group_step(const AdamGroups &G, int64_t i) {
     return s;
 }
 
+// (the per-element arithmetic lives in gs_common.h: gs_adam_one -- shared with the fused backward + Adam kernel)
 __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float step_size, float one_m_b1,
                                          float b2, float one_m_b2, float inv_bc2_sqrt, float eps) {
-    m = m + (g - m) * one_m_b1;
-    v = v * b2 + one_m_b2 * (g * g);
-    const float denom = sqrtf(v) * inv_bc2_sqrt + eps;
-    p = p - step_size * (m / denom);
+    gs_adam_one(p, g, m, v, step_size, one_m_b1, b2, one_m_b2, inv_bc2_sqrt, eps);
 }
 
 template <bool NT>

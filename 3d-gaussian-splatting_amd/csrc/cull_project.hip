@@ -768,17 +768,33 @@ __global__ void __launch_bounds__(1024) sh_big_rows_kernel(const uint4 *__restri
 #ifndef GS_PB_SH_U
 #define GS_PB_SH_U 8  // A/B switch: row loads the SH walk keeps in flight
 #endif
-template <int CDIM, int PART = 0, int BLOCK = (CDIM == 3 ? 256 : 128)>
+// The optimizer step fused into the kernel's epilogue (gs_frame_backward_adam, include/gs_abi.h; rgb colours, PART 0): instead of
+// storing the Gaussian's 14 gradients the thread applies gs_adam_one to its 14 parameters -- the five raw parameter arrays
+// are then written through `p_*` (the same memory the kernel read them from: every thread reads its own Gaussian's parameters
+// before it overwrites them, nobody else's), the moments through m_* / v_*.  ADAM: 0 = off, 1 = plain accesses, 2 = moments
+// with non-temporal loads / stores (beyond the Infinity Cache they only evict each other on their way through: adam.hip).
+struct AdamFusedDev {
+    float *p_pos, *p_quat, *p_scale, *p_opa, *p_rgb;
+    float *m_pos, *m_quat, *m_scale, *m_opa, *m_rgb;
+    float *v_pos, *v_quat, *v_scale, *v_opa, *v_rgb;
+    float step_pos, step_quat, step_scale, step_opa, step_rgb;  // lr_k / (1 - b1^t)
+    float one_m_b1, b2, one_m_b2, inv_bc2_sqrt, eps;
+    float *stat;  // [N,3] or NULL
+    int stat_mode;
+    const unsigned long long *skip_if_nonzero;
+};
+template <int CDIM, int PART = 0, int BLOCK = (CDIM == 3 ? 256 : 128), int ADAM = 0>
 __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
-    const float *__restrict__ pos, const float4 *__restrict__ quat, const float *__restrict__ scale,
+    const float *pos, const float4 *quat, const float *scale,
     int64_t n, ProjectParams P, const float4 *__restrict__ rec_geom,
     const float4 *__restrict__ rec_color, const float4 *__restrict__ rows,
-    const unsigned long long *__restrict__ stop_keys, const float *__restrict__ opa_raw,
-    const float *__restrict__ rgb_raw, GsDistCull D,
+    const unsigned long long *__restrict__ stop_keys, const float *opa_raw,
+    const float *rgb_raw, GsDistCull D,
     const uint32_t *__restrict__ pair_offsets, const uint4 *__restrict__ rects, uint64_t max_pairs, int64_t g_first,
     float *__restrict__ grad_pos,
     float4 *__restrict__ grad_quat, float *__restrict__ grad_scale, float *__restrict__ grad_opa,
-    float *__restrict__ grad_rgb) {
+    float *__restrict__ grad_rgb, AdamFusedDev A = AdamFusedDev{}) {
+    static_assert(ADAM == 0 || (CDIM == 3 && PART == 0), "the fused optimizer step: rgb colours, everything in one kernel");
     // rgb rows (round 4): only rows that EXIST are fetched.  71 % of the pairs of the 2.4 M scene lie behind their
     // tile's stop point and their rows are uninitialised memory; round 3 streamed all of them through LDS and looked at
     // the flags afterwards (PMC: 916 MB of traffic against 316 MB algorithmic).  Whether the row of pair (tile, g) was
@@ -1272,6 +1288,69 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
             gopa = d1.z * g.w * (1.0f - g.w);
         }
     }
+    if constexpr (ADAM != 0) {
+        // ---- the optimizer step of this Gaussian's 14 parameters (gs_adam_one: torch's _single_tensor_adam); a culled
+        // Gaussian takes its zero-gradient step (momentum), as gs_adam_step gives it.  All loads first.
+        if (A.skip_if_nonzero && *A.skip_if_nonzero) return;  // the frame overflowed and was rendered empty: no step (uniform)
+        auto ld = [](const float *p) { return ADAM == 2 ? __builtin_nontemporal_load(p) : *p; };
+        auto st = [](float *p, float x) {
+            if (ADAM == 2)
+                __builtin_nontemporal_store(x, p);
+            else
+                *p = x;
+        };
+        float pp[3], pq[4], ps[3], po, pc[3], mp[3], mq[4], ms[3], mo, mc[3], vp[3], vq[4], vs[3], vo, vc[3], sg[3] = {0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            pp[k] = A.p_pos[pid * 3 + k];
+            ps[k] = A.p_scale[pid * 3 + k];
+            pc[k] = A.p_rgb[pid * 3 + k];
+            mp[k] = ld(A.m_pos + pid * 3 + k);
+            ms[k] = ld(A.m_scale + pid * 3 + k);
+            mc[k] = ld(A.m_rgb + pid * 3 + k);
+            vp[k] = ld(A.v_pos + pid * 3 + k);
+            vs[k] = ld(A.v_scale + pid * 3 + k);
+            vc[k] = ld(A.v_rgb + pid * 3 + k);
+            if (A.stat_mode) sg[k] = A.stat[pid * 3 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            pq[k] = A.p_quat[pid * 4 + k];
+            mq[k] = ld(A.m_quat + pid * 4 + k);
+            vq[k] = ld(A.v_quat + pid * 4 + k);
+        }
+        po = A.p_opa[pid];
+        mo = ld(A.m_opa + pid);
+        vo = ld(A.v_opa + pid);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            gs_adam_one(pp[k], gp[k], mp[k], vp[k], A.step_pos, A.one_m_b1, A.b2, A.one_m_b2, A.inv_bc2_sqrt, A.eps);
+            gs_adam_one(ps[k], gsr[k], ms[k], vs[k], A.step_scale, A.one_m_b1, A.b2, A.one_m_b2, A.inv_bc2_sqrt, A.eps);
+            gs_adam_one(pc[k], gcol[k], mc[k], vc[k], A.step_rgb, A.one_m_b1, A.b2, A.one_m_b2, A.inv_bc2_sqrt, A.eps);
+            A.p_pos[pid * 3 + k] = pp[k];
+            A.p_scale[pid * 3 + k] = ps[k];
+            A.p_rgb[pid * 3 + k] = pc[k];
+            st(A.m_pos + pid * 3 + k, mp[k]);
+            st(A.m_scale + pid * 3 + k, ms[k]);
+            st(A.m_rgb + pid * 3 + k, mc[k]);
+            st(A.v_pos + pid * 3 + k, vp[k]);
+            st(A.v_scale + pid * 3 + k, vs[k]);
+            st(A.v_rgb + pid * 3 + k, vc[k]);
+            if (A.stat_mode) A.stat[pid * 3 + k] = A.stat_mode == 1 ? fmaxf(sg[k], fabsf(gp[k])) : sg[k] + fabsf(gp[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            gs_adam_one(pq[k], gqr[k], mq[k], vq[k], A.step_quat, A.one_m_b1, A.b2, A.one_m_b2, A.inv_bc2_sqrt, A.eps);
+            A.p_quat[pid * 4 + k] = pq[k];
+            st(A.m_quat + pid * 4 + k, mq[k]);
+            st(A.v_quat + pid * 4 + k, vq[k]);
+        }
+        gs_adam_one(po, gopa, mo, vo, A.step_opa, A.one_m_b1, A.b2, A.one_m_b2, A.inv_bc2_sqrt, A.eps);
+        A.p_opa[pid] = po;
+        st(A.m_opa + pid, mo);
+        st(A.v_opa + pid, vo);
+        return;
+    }
     if (PART != 2) {
         grad_pos[pid * 3 + 0] = gp[0];
         grad_pos[pid * 3 + 1] = gp[1];
@@ -1490,6 +1569,58 @@ int gs_stage_sh_big_rows(const gs_frame *f, const gs_frame_ws &ws, hipStream_t s
     else
         GS_LAUNCH_BIG_ROWS(27);
 #undef GS_LAUNCH_BIG_ROWS
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+// The projection backward with the Adam step in its epilogue (gs_frame_backward_adam): rgb colours, all Gaussians, one launch
+int gs_stage_project_backward_adam(const gs_frame *f, const gs_frame_ws &ws, const gs_adam_fused *a, hipStream_t stream) {
+    GS_CHECK_ARG(f->color_dim == 3, "color_dim must be 3");
+    GS_CHECK_ARG(a->step >= 1, "step counts from 1 (torch.optim.Adam increments before the update)");
+    GS_CHECK_ARG(a->beta1 >= 0.f && a->beta1 < 1.f && a->beta2 >= 0.f && a->beta2 < 1.f && a->eps >= 0.f, "bad hyper-parameters");
+    GS_CHECK_ARG(a->stat_mode >= 0 && a->stat_mode <= 2 && (!a->stat_mode || a->grad_stat), "bad statistic");
+    for (int k = 0; k < 5; ++k) GS_CHECK_ARG(a->exp_avg[k] && a->exp_avg_sq[k], "null moment pointer");
+    if (f->N <= 0) return 0;
+    ProjectParams P = make_params(f);
+    gs_frame_geom Gf = gs_frame_geometry(f);
+    GsDistCull Dc = {(float)(Gf.padW / 2), (float)(Gf.padH / 2), f->focal_x, f->focal_y, f->thresh};
+    // bias corrections on the host in double, as torch does (adam.hip: adam_step_impl)
+    const double bc1 = 1.0 - pow((double)a->beta1, (double)a->step), bc2 = 1.0 - pow((double)a->beta2, (double)a->step);
+    AdamFusedDev A;
+    A.p_pos = const_cast<float *>(f->pos);
+    A.p_quat = const_cast<float *>(f->quat);
+    A.p_scale = const_cast<float *>(f->scale);
+    A.p_opa = const_cast<float *>(f->opa);
+    A.p_rgb = const_cast<float *>(f->rgb);
+    A.m_pos = a->exp_avg[0]; A.m_quat = a->exp_avg[1]; A.m_scale = a->exp_avg[2]; A.m_opa = a->exp_avg[3]; A.m_rgb = a->exp_avg[4];
+    A.v_pos = a->exp_avg_sq[0]; A.v_quat = a->exp_avg_sq[1]; A.v_scale = a->exp_avg_sq[2]; A.v_opa = a->exp_avg_sq[3]; A.v_rgb = a->exp_avg_sq[4];
+    A.step_pos = (float)((double)a->lr[0] / bc1);
+    A.step_quat = (float)((double)a->lr[1] / bc1);
+    A.step_scale = (float)((double)a->lr[2] / bc1);
+    A.step_opa = (float)((double)a->lr[3] / bc1);
+    A.step_rgb = (float)((double)a->lr[4] / bc1);
+    A.one_m_b1 = 1.0f - a->beta1;
+    A.b2 = a->beta2;
+    A.one_m_b2 = 1.0f - a->beta2;
+    A.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    A.eps = a->eps;
+    A.stat = a->grad_stat;
+    A.stat_mode = a->stat_mode;
+    A.skip_if_nonzero = (const unsigned long long *)a->skip_if_nonzero;
+    const unsigned grid = (unsigned)gs_div_up(f->N, 256);
+    // 14 parameters x 16 bytes of arrays: beyond the Infinity Cache the moments stream with non-temporal accesses (adam.hip)
+    const bool nt = (unsigned long long)f->N * 14ull * 16ull > (300ull << 20);
+#define GS_LAUNCH_PB_ADAM(MODE)                                                                                         \
+    hipLaunchKernelGGL((frame_project_backward_kernel<3, 0, 256, MODE>), dim3(grid), dim3(256), 0, stream, f->pos,      \
+                       (const float4 *)f->quat, f->scale, f->N, P, ws.rec_geom, ws.rec_color, (const float4 *)ws.rows, \
+                       (const unsigned long long *)ws.stop_keys, f->opa, f->rgb, Dc, ws.pair_offsets, ws.rects,        \
+                       (uint64_t)f->max_pairs, (int64_t)0, (float *)nullptr, (float4 *)nullptr, (float *)nullptr,      \
+                       (float *)nullptr, (float *)nullptr, A)
+    if (nt)
+        GS_LAUNCH_PB_ADAM(2);
+    else
+        GS_LAUNCH_PB_ADAM(1);
+#undef GS_LAUNCH_PB_ADAM
     GS_CHECK_LAUNCH();
     return 0;
 }

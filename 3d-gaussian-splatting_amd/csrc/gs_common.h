@@ -138,4 +138,16 @@ __device__ __forceinline__ void gs_conic(float a, float b, float c, float d, flo
     C = a * k;
 }
 
+// One element of torch's _single_tensor_adam (adam.hip; also the fused projection-backward + Adam kernel of cull_project.hip --
+// both translation units are compiled with -ffp-contract=off, so the two paths round alike):
+//   m <- m + (g - m)(1 - b1);  v <- v b2 + (1 - b2) g g;  p <- p - step_size m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+__device__ __forceinline__ void gs_adam_one(float &p, float g, float &m, float &v, float step_size, float one_m_b1,
+                                            float b2, float one_m_b2, float inv_bc2_sqrt, float eps) {
+#pragma clang fp contract(off)
+    m = m + (g - m) * one_m_b1;
+    v = v * b2 + one_m_b2 * (g * g);
+    const float denom = sqrtf(v) * inv_bc2_sqrt + eps;
+    p = p - step_size * (m / denom);
+}
+
 #endif  // __HIPCC__

@@ -387,6 +387,27 @@ extern "C" int gs_frame_backward(const gs_frame *f, const float *grad_image, flo
                                (hipStream_t)stream, nullptr);
 }
 
+extern "C" int gs_frame_backward_adam(const gs_frame *f, const float *grad_image, const gs_adam_fused *adam,
+                                      gs_stream_t stream) {
+    int rc = validate(f);
+    if (rc) return rc;
+    GS_CHECK_ARG(f->training && f->image_padded, "gs_frame_backward_adam needs a training forward (image_padded kept)");
+    GS_CHECK_ARG(grad_image && adam, "null pointer");
+    if (f->color_dim != 3) {
+        gs_set_error("gs_frame_backward_adam: rgb colours only (color_dim 3): SH coefficient gradients are written by whole waves");
+        return GS_E_UNSUPPORTED;
+    }
+    if (f->N == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    gs_frame_ws ws = gs_frame_carve(f->workspace, f->N, f->max_pairs, f->width, f->height, f->color_dim, 1);
+    uint64_t *skeys, *okeys;
+    uint32_t *sids;
+    sorted_buffers(f, ws, &skeys, &sids, &okeys);
+    const bool prepared = join_prepared(f, s);
+    if ((rc = gs_stage_raster_backward(f, ws, sids, grad_image, s, prepared))) return rc;
+    return gs_stage_project_backward_adam(f, ws, adam, s);
+}
+
 extern "C" int gs_frame_backward_part(const gs_frame *f, const float *grad_image, float *grad_pos, float *grad_quat,
                                       float *grad_scale, float *grad_opa, float *grad_rgb, int32_t part,
                                       gs_stream_t stream) {

@@ -98,6 +98,15 @@ gs_frame_debug_views = _sig("gs_frame_debug_views", ci, C.POINTER(GsFrame), C.PO
 
 gs_frame_binning_variant = _sig("gs_frame_binning_variant", ci, C.POINTER(GsFrame))
 gs_frame_debug_rects = _sig("gs_frame_debug_rects", ci, C.POINTER(GsFrame), C.POINTER(vp))
+class GsAdamFused(C.Structure):
+    """Mirror of ``struct gs_adam_fused`` (include/gs_abi.h): moments / learning rates in the order pos, quat, scale, opa, rgb."""
+
+    _fields_ = [("exp_avg", vp * 5), ("exp_avg_sq", vp * 5), ("lr", C.c_float * 5),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("step", i64),
+                ("grad_stat", vp), ("stat_mode", i32), ("skip_if_nonzero", vp)]
+
+
+gs_frame_backward_adam = _sig("gs_frame_backward_adam", ci, C.POINTER(GsFrame), vp, C.POINTER(GsAdamFused), vp)
 gs_frame_debug_tile_nproc = _sig("gs_frame_debug_tile_nproc", ci, C.POINTER(GsFrame), C.POINTER(vp))
 gs_frame_debug_bwd_exec_rows = _sig("gs_frame_debug_bwd_exec_rows", ci, C.POINTER(GsFrame), C.POINTER(vp), C.POINTER(C.c_int32))
 
@@ -139,7 +148,7 @@ EXPORTS = [
     "gs_jacobian", "gs_global_culling", "gs_global_culling_backward", "gs_calc_tile_list",
     "gs_gather_gaussians", "gs_draw", "gs_draw_backward_workspace_bytes", "gs_draw_backward",
     "gs_sort_pairs_tmp_bytes", "gs_sort_pairs", "gs_sort_pairs_bits", "gs_frame_workspace_bytes", "gs_frame_forward",
-    "gs_frame_stats_async", "gs_frame_longest_list_async", "gs_frame_debug_views", "gs_frame_debug_rects", "gs_frame_binning_variant", "gs_frame_debug_tile_nproc", "gs_frame_debug_bwd_exec_rows", "gs_frame_backward", "gs_frame_forward_profile",
+    "gs_frame_stats_async", "gs_frame_longest_list_async", "gs_frame_debug_views", "gs_frame_debug_rects", "gs_frame_binning_variant", "gs_frame_debug_tile_nproc", "gs_frame_debug_bwd_exec_rows", "gs_frame_backward", "gs_frame_backward_adam", "gs_frame_forward_profile",
     "gs_frame_backward_part", "gs_frame_async_create", "gs_frame_async_wait", "gs_frame_async_destroy",
     "gs_frame_backward_slice", "gs_frame_project_slices", "gs_frame_forward_project", "gs_frame_forward_rest",
     "gs_adam_step_multi",

@@ -437,6 +437,17 @@ class FrameRenderer:
                                                     int(g_end), self._stream().cuda_stream), "gs_frame_backward_slice")
         return out
 
+    def backward_adam(self, grad_image, adam):
+        """``backward`` with the optimizer step fused into its last kernel (rgb colours; gs_frame_backward_adam, include/
+        gs_abi.h): the frame's own parameter tensors are updated in place, no gradient is written.  ``adam``: a filled
+        ``gaussian._lib.GsAdamFused`` (gs_train.FusedAdam.fused_descriptor)."""
+        f = self._frame
+        if f is None or not f.training:
+            raise RuntimeError("backward_adam() needs a preceding forward(training=True)")
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.gs_frame_backward_adam(C.byref(f), grad_image.contiguous().data_ptr(), C.byref(adam),
+                                                   self._stream().cuda_stream), "gs_frame_backward_adam")
+
     def backward(self, grad_image, out=None, part: int = 0):
         """dL/d(image) -> (grad_pos, grad_quat, grad_scale, grad_opa, grad_rgb).  ``out`` may
         supply the five destination tensors (e.g. views of one flat all-reduce bucket).

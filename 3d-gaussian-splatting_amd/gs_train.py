@@ -18,6 +18,7 @@ schedule) is SURVEY 8f-2; data loading and the viewer stay out of scope (8f-3, 8
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Sequence
@@ -174,6 +175,27 @@ class FusedAdam:
             self.accum_grad.data_ptr() if self.accum_grad is not None else None, b, e, self.stat_mode, self.skip_flag,
             torch.cuda.current_stream().cuda_stream), "gs_adam_step")
 
+    def fused_descriptor(self, advance: bool = True):
+        """The ``gs_adam_fused`` argument of ``FrameRenderer.backward_adam`` for ONE optimizer step over everything
+        (replicated optimizer: the moments mirror the flat buffer).  Advances the step counter like ``step``."""
+        if self.sharded:
+            raise RuntimeError("the fused backward + Adam step needs a replicated optimizer")
+        if advance:
+            self.step_count += 1
+        f = self.flat
+        d = _lib.GsAdamFused()
+        lr_of = dict(zip(ORDER, self._lr))
+        for i, name in enumerate(("pos", "quat", "scale", "opa", "rgb")):
+            off = f.offsets[name][0] * 4
+            d.exp_avg[i] = self.exp_avg.data_ptr() + off
+            d.exp_avg_sq[i] = self.exp_avg_sq.data_ptr() + off
+            d.lr[i] = lr_of[name]
+        d.beta1, d.beta2, d.eps, d.step = self.betas[0], self.betas[1], self.eps, self.step_count
+        d.grad_stat = self.accum_grad.data_ptr() if self.accum_grad is not None else None
+        d.stat_mode = self.stat_mode
+        d.skip_if_nonzero = self.skip_flag
+        return d
+
     def step_slice(self, k: int, advance: bool = False, grad_scale: float = 1.0):
         """The same step for exchange slice ``k`` only (pass ``advance=True`` for the first slice of a step).
         ``grad_scale``: the gradient enters as grad * grad_scale (1 / world after a SUM exchange: gs_dp.py)."""
@@ -222,8 +244,15 @@ class Trainer:
                  opt: Optional[TrainOptions] = None, world_size: int = 1, max_pairs: int = 1 << 20,
                  scale_activation: str = "abs", densify: bool = False, generator: Optional[torch.Generator] = None,
                  per_view_stat: Optional[bool] = None, exchange: str = "all_reduce", n_slices: Optional[int] = None,
-                 bwd_rows: Optional[bool] = None):
+                 bwd_rows: Optional[bool] = None, fuse_adam: Optional[bool] = None):
         self.opt = opt or TrainOptions()
+        # `fuse_adam`: apply the Adam step inside the backward's last kernel (FrameRenderer.backward_adam: no gradient buffer
+        # is written, bit-identical parameters).  None: whenever the step allows it -- one rank (no exchange between the
+        # backward and the optimizer), rgb colours, no regulariser that edits the gradient, the densification statistic
+        # fused into the optimizer; False: never (a caller that wants to read flat.grads after a step).
+        if fuse_adam is None and os.environ.get("GS_TRAIN_FUSE_ADAM", "") == "0":  # (A/B measurements: bench.py unfused)
+            fuse_adam = False
+        self.fuse_adam = fuse_adam
         self.world_size = int(world_size)
         self.n_slices = n_slices  # exchange slices of the Gaussian array (gs_dp.py; None: by scene size)
         if exchange == "reduce_scatter" and self.world_size > 1:
@@ -290,6 +319,11 @@ class Trainer:
         if key not in self._loss:
             self._loss[key] = ImageLoss(h, w, self.opt.ssim_weight, self.flat.flat_param.device)
         return self._loss[key]
+
+    def _can_fuse_adam(self) -> bool:
+        o, rgb = self.opt, self.flat.params[4]
+        return (self.fuse_adam is not False and not self.flat.collective_active() and not self.optimizer.sharded
+                and self.view_stat is None and o.scale_reg == 0 and o.opa_reg == 0 and rgb.dim() == 2 and rgb.shape[1] == 3)
 
     def _is_control_iteration(self, i_iter: int) -> bool:
         """Does train_step(i_iter) run adaptive_control (prune, or prune + densify)?  train.py:86-91."""
@@ -387,6 +421,10 @@ class Trainer:
                     flat.finish_slice_gather(j)  # ... the next slice's reduce-scatter + Adam
                     ahead = self._project_ahead(j, next_camera_id)
             # (gathers nobody waited for are waited for where the parameters are read next: finish_gather)
+        elif self._can_fuse_adam():
+            # one kernel less and no gradient round trip through memory: the per-Gaussian sums, the projection / activation
+            # backward and the Adam update of the Gaussian's 14 parameters (+ the |pos.grad| statistic) in one launch
+            r.backward_adam(grad_image, self.optimizer.fused_descriptor())
         else:
             r.backward(grad_image, out=flat.grads)
             local_terms(0, flat.n)

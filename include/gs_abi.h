@@ -34,7 +34,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-/* 6 (round 5): gs_frame_debug_bwd_exec_rows; GS_FRAME_BWD_ROWS and the saturated-bucket count in the upper half of the
+/* 6 (round 5): gs_frame_backward_adam (the backward with the optimizer step fused in); gs_frame_debug_bwd_exec_rows; GS_FRAME_BWD_ROWS and the saturated-bucket count in the upper half of the
  * `buckets` counter; SH gradient rows in whole 64-byte lines without per-row flags (workspace
  * layout only: no signature changed).
  * 5 (round 4): the frame in pieces -- gs_frame_forward_project + gs_frame_forward_rest == gs_frame_forward,
@@ -441,6 +441,29 @@ int gs_adam_step_multi(float *param, const float *grad, float *exp_avg, float *e
                        int32_t n_groups, const int64_t *group_end, const float *lr, float beta1, float beta2, float eps,
                        int64_t step, float *grad_stat, int64_t stat_begin, int64_t stat_end, int32_t stat_mode,
                        const void *skip_if_nonzero, float grad_scale, gs_stream_t stream);
+
+/* Single-GPU training step, rgb colours (round 5): gs_frame_backward whose LAST kernel -- the per-Gaussian sum of the gradient
+ * rows + projection / activation backward -- applies the Adam update to the Gaussian's 14 parameters on the spot instead of
+ * writing their gradients.  The gradient never travels through memory (2 x 56 B per Gaussian) and the optimizer's stream of
+ * parameters and moments runs underneath the projection backward's arithmetic (that kernel is VALU-bound, gs_adam_step
+ * HBM-bound).  Every updated value is bit for bit what gs_frame_backward + gs_adam_step give (same expressions, same
+ * rounding); culled Gaussians take their zero-gradient step (momentum) as they do there.
+ *   The PARAMETERS updated in place are the frame's own f->pos, quat, scale, opa, rgb (the descriptor calls them const: they
+ * are not, here); exp_avg / exp_avg_sq: their moments, same shapes, in the order pos, quat, scale, opa, rgb; lr likewise;
+ * step counts from 1; grad_stat (may be NULL with stat_mode 0): [N,3], max (1) or sum (2) of |dL/dpos| folded in
+ * (train.py:145-154); skip_if_nonzero (may be NULL): device address of a 64-bit counter -- non-zero: the step is skipped (the
+ * frame's overflow counter, gs_frame_overflow_flag).  color_dim must be 3 (GS_E_UNSUPPORTED otherwise: SH coefficient
+ * gradients are written by whole waves).  No gradient buffer is written. */
+typedef struct gs_adam_fused {
+    float *exp_avg[5], *exp_avg_sq[5];
+    float lr[5];
+    float beta1, beta2, eps;
+    int64_t step;
+    float *grad_stat;
+    int32_t stat_mode;
+    const void *skip_if_nonzero;
+} gs_adam_fused;
+int gs_frame_backward_adam(const gs_frame *f, const float *grad_image, const gs_adam_fused *adam, gs_stream_t stream);
 
 /* Device address of the frame's overflow counter (inside the caller's workspace; 64-bit, 0 = the last forward of this
  * frame description fitted its pair capacity, else the pair count it would have needed).  No launch, no copy. */

@@ -246,7 +246,7 @@ def test_trainer_with_densification(gpu):
     opt = TrainOptions(n_iters=400, n_iters_warmup=5, adaptive_control_start_iter=20, n_adaptive_control=25,
                        grad_accum_iters=10, split_thresh=0.02, delete_thresh=1.5, grad_thresh=1e-7, use_clone=1)
     tr = Trainer(start, [cam], [target], opt, max_pairs=1 << 16, densify=True,
-                 generator=torch.Generator(gpu).manual_seed(1))
+                 generator=torch.Generator(gpu).manual_seed(1), fuse_adam=False)  # (the test reads flat.grads behind a step)
     sizes, losses = [], []
     for it in range(80):
         if it == 41:  # cleared at (it + 10 - 1) % 25 == 0, i.e. it = 41 (and 66)
@@ -601,3 +601,75 @@ def test_bench_multi_gpu_leg_runs_under_two_ranks(gpu, tmp_path):
     # sharded optimizer: half the state per rank
     assert scene["modes"]["reduce_scatter"]["optimizer_state_bytes_per_rank"] * 2 <= \
         scene["modes"]["all_reduce"]["optimizer_state_bytes_per_rank"] + 64
+
+
+@pytest.mark.parametrize("n,W,H,stat", [(6_000, 160, 112, "max"), (6_000, 160, 112, "mean"), (2_400_000, 1920, 1080, "max")])
+def test_fused_backward_adam_equals_backward_then_adam(gpu, n, W, H, stat):
+    """Round 5: gs_frame_backward_adam -- the Adam update applied inside the backward's last kernel, no gradient buffer -- against
+    gs_frame_backward followed by gs_adam_step: parameters, both moments and the |pos.grad| statistic BIT FOR BIT over several
+    steps of gs_train.Trainer (learning-rate warm-up included; Gaussians outside the frustum take their zero-gradient momentum
+    step on both paths).  2.4 M Gaussians: the moments stream with non-temporal accesses there (the third kernel variant)."""
+    from gs_scene import make_camera, make_scene
+    from gs_train import TrainOptions, Trainer
+
+    scene, cam = make_scene(n, W, H, seed=11), make_camera(W, H, yaw_deg=3.0)
+    gt = to_torch(scene, gpu)
+    r0 = FrameRenderer(gpu, max_pairs=1 << 20, auto_grow=True)
+    target = r0.forward(*gt, cam)[0].clone()
+    pairs = r0.stats().pairs
+    del r0
+    start = [t.clone() for t in gt]
+    start[4] = start[4] + 0.5 * torch.randn(start[4].shape, device=gpu, generator=torch.Generator(gpu).manual_seed(2))
+    start[3] = start[3] - 0.3
+    opt = TrainOptions(n_iters=100, n_iters_warmup=3, grad_accum_method=stat)
+    steps = 3 if n > 1_000_000 else 7
+    got = []
+    for fuse in (True, False):
+        tr = Trainer([t.clone() for t in start], [cam], [target], opt, max_pairs=int(pairs * 1.3) + 4096, fuse_adam=fuse)
+        assert tr._can_fuse_adam() == fuse
+        vals = [tr.train_step(i, 0).clone() for i in range(steps)]
+        assert tr.optimizer.step_count == steps
+        got.append((tr.flat.flat_param.clone(), tr.optimizer.exp_avg.clone(), tr.optimizer.exp_avg_sq.clone(),
+                    tr.optimizer.accum_grad.clone(), torch.stack(vals)))
+        if not fuse:
+            culled = ~tr.renderer.culling_mask()
+            assert int(culled.sum()) > 0  # (Gaussians outside the frustum: zero gradient, momentum step)
+        del tr
+        torch.cuda.empty_cache()
+    for a, b, name in zip(got[0], got[1], ("parameters", "exp_avg", "exp_avg_sq", "grad statistic", "loss values")):
+        assert torch.equal(a, b), name
+    assert float(got[0][1].abs().max()) > 0 and float(got[0][3].abs().max()) > 0
+
+
+def test_fused_backward_adam_refuses_sh_and_skips_overflowed_frames(gpu):
+    """gs_frame_backward_adam is for rgb colours (GS_E_UNSUPPORTED with SH: the Trainer then takes the two-kernel path by
+    itself), and with the frame's overflow counter as skip flag an overflowed -- empty -- frame moves nothing."""
+    from gaussian import _lib
+    from gs_scene import make_camera, make_scene
+    from gs_train import TrainOptions, Trainer
+
+    W, H = 128, 96
+    cam = make_camera(W, H)
+    sh = make_scene(1500, W, H, seed=3, use_sh=True)
+    gt = to_torch(sh, gpu)
+    target = FrameRenderer(gpu, max_pairs=1 << 16).forward(*gt, cam)[0].clone()
+    tr = Trainer([t.clone() for t in gt], [cam], [target], TrainOptions(n_iters_warmup=1), max_pairs=1 << 16)
+    assert not tr._can_fuse_adam()
+    tr.train_step(0, 0)
+    with pytest.raises(RuntimeError):
+        tr.renderer.backward_adam(torch.zeros(H, W, 3, device=gpu), tr.optimizer.fused_descriptor())
+    # rgb, a workspace that is too small: the frame overflows, the device-side flag skips the fused step
+    rgb = make_scene(4000, W, H, seed=4)
+    p = [t.clone() for t in to_torch(rgb, gpu)]
+    tr2 = Trainer(p, [cam], [target], TrainOptions(n_iters_warmup=1), max_pairs=1 << 16)
+    assert tr2._can_fuse_adam()
+    r = tr2.renderer
+    r.auto_grow = False
+    r.max_pairs = 64  # far too small
+    before = tr2.flat.flat_param.clone()
+    img, _ = r.forward(*tr2.flat.params, cam)
+    assert r.stats().overflow > 0
+    tr2.optimizer.skip_flag = r.overflow_flag()
+    tr2.optimizer.exp_avg.fill_(0.5)  # momentum that WOULD move the parameters
+    r.backward_adam(torch.ones(H, W, 3, device=gpu), tr2.optimizer.fused_descriptor())
+    assert torch.equal(tr2.flat.flat_param, before)
