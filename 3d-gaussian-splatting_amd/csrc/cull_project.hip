@@ -864,6 +864,8 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
     __shared__ uint64_t s_big_off[NBIG];
     __shared__ uint32_t s_big_cnt[NBIG];
     __shared__ float s_big_part[4][CDIM == 3 ? NA : 1];
+    __shared__ __attribute__((aligned(16))) float s_adam_tr[ADAM ? BLOCK * 3 : 1];  // the fused optimizer step's hand-over (below)
+    (void)s_adam_tr;
     const bool big = CDIM == 3 && cnt > BIG;
     if (threadIdx.x == 0) s_nbig = 0;
     __syncthreads();
@@ -1251,7 +1253,7 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
         wave_sync();  // (the next pass clears the sums)
         }
     }
-    if (!valid) return;
+    if (ADAM == 0 && !valid) return;  // (ADAM: the epilogue's LDS hand-over is the whole wave's; an invalid thread is culled: zeros)
     if (vis && PART != 2) {
         float p[3], sraw[3], q[4], s[3];
         load3(pos, pid, p);
@@ -1289,66 +1291,95 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
         }
     }
     if constexpr (ADAM != 0) {
-        // ---- the optimizer step of this Gaussian's 14 parameters (gs_adam_one: torch's _single_tensor_adam); a culled
-        // Gaussian takes its zero-gradient step (momentum), as gs_adam_step gives it.  All loads first.
+        // ---- the optimizer step of the wave's 64 x 14 parameters (gs_adam_one: torch's _single_tensor_adam); a culled
+        // Gaussian takes its zero-gradient step (momentum), as gs_adam_step gives it.  Every global access is a whole
+        // float4 per lane over a contiguous run of the wave: a thread owns a GAUSSIAN, but the three [N, 3] arrays (and
+        // their moments) are walked by ELEMENT -- the wave's 192 gradients go through LDS once ([Gaussian][3] in, float4
+        // by float4 out, 48 lanes) and lane l updates elements 4 l .. 4 l + 3 of the wave's run.  (First version, r05_q:
+        // every thread its own 14 parameters, 84 four-byte accesses at a 12-byte stride -- 0.19 ms SLOWER than
+        // backward + gs_adam_step at 2.4 M Gaussians.)  The lanes that write a Gaussian's parameters are lanes of the
+        // wave that read them (above, in program order): nobody else's.
         if (A.skip_if_nonzero && *A.skip_if_nonzero) return;  // the frame overflowed and was rendered empty: no step (uniform)
-        auto ld = [](const float *p) { return ADAM == 2 ? __builtin_nontemporal_load(p) : *p; };
-        auto st = [](float *p, float x) {
-            if (ADAM == 2)
-                __builtin_nontemporal_store(x, p);
-            else
-                *p = x;
+        typedef float nt4 __attribute__((ext_vector_type(4)));
+        auto ld4 = [](const float *q) {
+            if (ADAM == 2) {
+                const nt4 x = __builtin_nontemporal_load(reinterpret_cast<const nt4 *>(q));
+                return make_float4(x.x, x.y, x.z, x.w);
+            }
+            return *reinterpret_cast<const float4 *>(q);
         };
-        float pp[3], pq[4], ps[3], po, pc[3], mp[3], mq[4], ms[3], mo, mc[3], vp[3], vq[4], vs[3], vo, vc[3], sg[3] = {0, 0, 0};
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            pp[k] = A.p_pos[pid * 3 + k];
-            ps[k] = A.p_scale[pid * 3 + k];
-            pc[k] = A.p_rgb[pid * 3 + k];
-            mp[k] = ld(A.m_pos + pid * 3 + k);
-            ms[k] = ld(A.m_scale + pid * 3 + k);
-            mc[k] = ld(A.m_rgb + pid * 3 + k);
-            vp[k] = ld(A.v_pos + pid * 3 + k);
-            vs[k] = ld(A.v_scale + pid * 3 + k);
-            vc[k] = ld(A.v_rgb + pid * 3 + k);
-            if (A.stat_mode) sg[k] = A.stat[pid * 3 + k];
+        auto st4 = [](float *q, float4 x) {
+            if (ADAM == 2)
+                __builtin_nontemporal_store(nt4{x.x, x.y, x.z, x.w}, reinterpret_cast<nt4 *>(q));
+            else
+                *reinterpret_cast<float4 *>(q) = x;
+        };
+        auto one4 = [&](float4 &pv, float4 gv, float4 &mv, float4 &vv, float step) {
+            gs_adam_one(pv.x, gv.x, mv.x, vv.x, step, A.one_m_b1, A.b2, A.one_m_b2, A.inv_bc2_sqrt, A.eps);
+            gs_adam_one(pv.y, gv.y, mv.y, vv.y, step, A.one_m_b1, A.b2, A.one_m_b2, A.inv_bc2_sqrt, A.eps);
+            gs_adam_one(pv.z, gv.z, mv.z, vv.z, step, A.one_m_b1, A.b2, A.one_m_b2, A.inv_bc2_sqrt, A.eps);
+            gs_adam_one(pv.w, gv.w, mv.w, vv.w, step, A.one_m_b1, A.b2, A.one_m_b2, A.inv_bc2_sqrt, A.eps);
+        };
+        const int a_lane = threadIdx.x & 63, a_wv = threadIdx.x >> 6;
+        float *tr = s_adam_tr + a_wv * 192;
+        const int64_t wbase = pid0 + (int64_t)a_wv * 64, left = n - wbase;  // the wave's first Gaussian; how many lie inside
+        const int ne = left >= 64 ? 192 : (left > 0 ? (int)left * 3 : 0);  // elements of the wave's run of an [N, 3] array
+        const int e0 = a_lane * 4;
+        auto step3 = [&](float *P3, float *M3, float *V3, const float (&g3)[3], float step, float *stat) {
+            tr[a_lane * 3 + 0] = g3[0];
+            tr[a_lane * 3 + 1] = g3[1];
+            tr[a_lane * 3 + 2] = g3[2];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (e0 + 4 <= ne) {
+                const int64_t b = wbase * 3 + e0;
+                const float4 gv = *reinterpret_cast<const float4 *>(tr + e0);
+                float4 pv = *reinterpret_cast<const float4 *>(P3 + b), mv = ld4(M3 + b), vv = ld4(V3 + b);
+                one4(pv, gv, mv, vv, step);
+                *reinterpret_cast<float4 *>(P3 + b) = pv;
+                st4(M3 + b, mv);
+                st4(V3 + b, vv);
+                if (stat) {
+                    float4 sv = *reinterpret_cast<const float4 *>(stat + b);
+                    if (A.stat_mode == 1)
+                        sv = make_float4(fmaxf(sv.x, fabsf(gv.x)), fmaxf(sv.y, fabsf(gv.y)), fmaxf(sv.z, fabsf(gv.z)),
+                                         fmaxf(sv.w, fabsf(gv.w)));
+                    else
+                        sv = make_float4(sv.x + fabsf(gv.x), sv.y + fabsf(gv.y), sv.z + fabsf(gv.z), sv.w + fabsf(gv.w));
+                    *reinterpret_cast<float4 *>(stat + b) = sv;
+                }
+            } else {
+                for (int e = e0; e < ne; ++e) {  // the ragged end of the array (N not a multiple of 4): element by element
+                    const int64_t b = wbase * 3 + e;
+                    const float ge = tr[e];
+                    float pe = P3[b], me = M3[b], ve = V3[b];
+                    gs_adam_one(pe, ge, me, ve, step, A.one_m_b1, A.b2, A.one_m_b2, A.inv_bc2_sqrt, A.eps);
+                    P3[b] = pe;
+                    M3[b] = me;
+                    V3[b] = ve;
+                    if (stat) stat[b] = A.stat_mode == 1 ? fmaxf(stat[b], fabsf(ge)) : stat[b] + fabsf(ge);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // (the next array's gradients overwrite tr)
+        };
+        step3(A.p_pos, A.m_pos, A.v_pos, gp, A.step_pos, A.stat_mode ? A.stat : nullptr);
+        step3(A.p_scale, A.m_scale, A.v_scale, gsr, A.step_scale, nullptr);
+        step3(A.p_rgb, A.m_rgb, A.v_rgb, gcol, A.step_rgb, nullptr);
+        if (!valid) return;
+        {  // the quaternion: the thread's own float4s
+            float4 pv = *reinterpret_cast<const float4 *>(A.p_quat + pid * 4), mv = ld4(A.m_quat + pid * 4);
+            float4 vv = ld4(A.v_quat + pid * 4);
+            one4(pv, make_float4(gqr[0], gqr[1], gqr[2], gqr[3]), mv, vv, A.step_quat);
+            *reinterpret_cast<float4 *>(A.p_quat + pid * 4) = pv;
+            st4(A.m_quat + pid * 4, mv);
+            st4(A.v_quat + pid * 4, vv);
         }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            pq[k] = A.p_quat[pid * 4 + k];
-            mq[k] = ld(A.m_quat + pid * 4 + k);
-            vq[k] = ld(A.v_quat + pid * 4 + k);
-        }
-        po = A.p_opa[pid];
-        mo = ld(A.m_opa + pid);
-        vo = ld(A.v_opa + pid);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            gs_adam_one(pp[k], gp[k], mp[k], vp[k], A.step_pos, A.one_m_b1, A.b2, A.one_m_b2, A.inv_bc2_sqrt, A.eps);
-            gs_adam_one(ps[k], gsr[k], ms[k], vs[k], A.step_scale, A.one_m_b1, A.b2, A.one_m_b2, A.inv_bc2_sqrt, A.eps);
-            gs_adam_one(pc[k], gcol[k], mc[k], vc[k], A.step_rgb, A.one_m_b1, A.b2, A.one_m_b2, A.inv_bc2_sqrt, A.eps);
-            A.p_pos[pid * 3 + k] = pp[k];
-            A.p_scale[pid * 3 + k] = ps[k];
-            A.p_rgb[pid * 3 + k] = pc[k];
-            st(A.m_pos + pid * 3 + k, mp[k]);
-            st(A.m_scale + pid * 3 + k, ms[k]);
-            st(A.m_rgb + pid * 3 + k, mc[k]);
-            st(A.v_pos + pid * 3 + k, vp[k]);
-            st(A.v_scale + pid * 3 + k, vs[k]);
-            st(A.v_rgb + pid * 3 + k, vc[k]);
-            if (A.stat_mode) A.stat[pid * 3 + k] = A.stat_mode == 1 ? fmaxf(sg[k], fabsf(gp[k])) : sg[k] + fabsf(gp[k]);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            gs_adam_one(pq[k], gqr[k], mq[k], vq[k], A.step_quat, A.one_m_b1, A.b2, A.one_m_b2, A.inv_bc2_sqrt, A.eps);
-            A.p_quat[pid * 4 + k] = pq[k];
-            st(A.m_quat + pid * 4 + k, mq[k]);
-            st(A.v_quat + pid * 4 + k, vq[k]);
-        }
+        float po = A.p_opa[pid], mo = A.m_opa[pid], vo = A.v_opa[pid];
         gs_adam_one(po, gopa, mo, vo, A.step_opa, A.one_m_b1, A.b2, A.one_m_b2, A.inv_bc2_sqrt, A.eps);
         A.p_opa[pid] = po;
-        st(A.m_opa + pid, mo);
-        st(A.v_opa + pid, vo);
+        A.m_opa[pid] = mo;
+        A.v_opa[pid] = vo;
         return;
     }
     if (PART != 2) {
@@ -1580,6 +1611,11 @@ int gs_stage_project_backward_adam(const gs_frame *f, const gs_frame_ws &ws, con
     GS_CHECK_ARG(a->beta1 >= 0.f && a->beta1 < 1.f && a->beta2 >= 0.f && a->beta2 < 1.f && a->eps >= 0.f, "bad hyper-parameters");
     GS_CHECK_ARG(a->stat_mode >= 0 && a->stat_mode <= 2 && (!a->stat_mode || a->grad_stat), "bad statistic");
     for (int k = 0; k < 5; ++k) GS_CHECK_ARG(a->exp_avg[k] && a->exp_avg_sq[k], "null moment pointer");
+    {  // the kernel walks the arrays float4 by float4
+        const void *al[] = {f->pos, f->quat, f->scale, f->rgb, a->exp_avg[0], a->exp_avg[1], a->exp_avg[2], a->exp_avg[4],
+                            a->exp_avg_sq[0], a->exp_avg_sq[1], a->exp_avg_sq[2], a->exp_avg_sq[4], a->grad_stat};
+        for (const void *q : al) GS_CHECK_ARG(((uintptr_t)q & 15) == 0, "parameters, moments and statistic must be 16-byte aligned");
+    }
     if (f->N <= 0) return 0;
     ProjectParams P = make_params(f);
     gs_frame_geom Gf = gs_frame_geometry(f);

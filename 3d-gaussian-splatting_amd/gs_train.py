@@ -246,13 +246,17 @@ class Trainer:
                  per_view_stat: Optional[bool] = None, exchange: str = "all_reduce", n_slices: Optional[int] = None,
                  bwd_rows: Optional[bool] = None, fuse_adam: Optional[bool] = None):
         self.opt = opt or TrainOptions()
-        # `fuse_adam`: apply the Adam step inside the backward's last kernel (FrameRenderer.backward_adam: no gradient buffer
-        # is written, bit-identical parameters).  None: whenever the step allows it -- one rank (no exchange between the
-        # backward and the optimizer), rgb colours, no regulariser that edits the gradient, the densification statistic
-        # fused into the optimizer; False: never (a caller that wants to read flat.grads after a step).
-        if fuse_adam is None and os.environ.get("GS_TRAIN_FUSE_ADAM", "") == "0":  # (A/B measurements: bench.py unfused)
-            fuse_adam = False
-        self.fuse_adam = fuse_adam
+        # `fuse_adam`: apply the Adam step inside the backward's last kernel (FrameRenderer.backward_adam: no gradient buffer is
+        # written, bit-identical parameters) where the step allows it -- one rank, rgb colours, no regulariser that edits the
+        # gradient, the densification statistic fused into the optimizer.  None: on (GS_TRAIN_FUSE_ADAM=0 turns it off for
+        # A/B runs of bench.py); False: never (a caller that reads flat.grads behind a step).  Same-box A/B, round 5
+        # (profiles/r05_r_*): 775 against 745 it/s on the moving 2.4 M-Gaussian scene, 933 against 894 fixed, 1786 against
+        # 1738 at 376 k -- one 208 us kernel where the projection backward (113 us) and gs_adam_step (150 us) ran.  (The
+        # first version -- every thread its own 14 parameters, 84 four-byte accesses at a 12-byte stride -- was 15 % SLOWER
+        # than the two kernels, r05_q; the float4 walk through an LDS hand-over is what made it pay.)
+        if fuse_adam is None:
+            fuse_adam = os.environ.get("GS_TRAIN_FUSE_ADAM", "") != "0"
+        self.fuse_adam = bool(fuse_adam)
         self.world_size = int(world_size)
         self.n_slices = n_slices  # exchange slices of the Gaussian array (gs_dp.py; None: by scene size)
         if exchange == "reduce_scatter" and self.world_size > 1:
@@ -322,7 +326,7 @@ class Trainer:
 
     def _can_fuse_adam(self) -> bool:
         o, rgb = self.opt, self.flat.params[4]
-        return (self.fuse_adam is not False and not self.flat.collective_active() and not self.optimizer.sharded
+        return (self.fuse_adam and not self.flat.collective_active() and not self.optimizer.sharded
                 and self.view_stat is None and o.scale_reg == 0 and o.opa_reg == 0 and rgb.dim() == 2 and rgb.shape[1] == 3)
 
     def _is_control_iteration(self, i_iter: int) -> bool:
