@@ -1298,7 +1298,9 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
         // by float4 out, 48 lanes) and lane l updates elements 4 l .. 4 l + 3 of the wave's run.  (First version, r05_q:
         // every thread its own 14 parameters, 84 four-byte accesses at a 12-byte stride -- 0.19 ms SLOWER than
         // backward + gs_adam_step at 2.4 M Gaussians.)  The lanes that write a Gaussian's parameters are lanes of the
-        // wave that read them (above, in program order): nobody else's.
+        // wave that read them (above, in program order): nobody else's.  (Measured and dropped, r5s: every load of the step
+        // issued first -- one round trip per wave instead of five, 86 VGPRs and 9 KiB more LDS: 1,750 against 1,785 it/s
+        // at 376 k Gaussians, 942 against 950 at 2.4 M; the other waves of the CU already cover the round trips.)
         if (A.skip_if_nonzero && *A.skip_if_nonzero) return;  // the frame overflowed and was rendered empty: no step (uniform)
         typedef float nt4 __attribute__((ext_vector_type(4)));
         auto ld4 = [](const float *q) {
