@@ -1894,6 +1894,12 @@ __global__ void __launch_bounds__(1024) mfma_items_kernel(const uint32_t *__rest
 #ifndef GS_BWD_ROWS_WPE
 #define GS_BWD_ROWS_WPE 4  // waves per SIMD the register allocation aims at
 #endif
+#ifndef GS_BWD_ROWS_PK
+// 1: the per-pixel algebra of a row step on PAIRS of the lane's four pixels (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two
+// fp32 results per issue slot; the kernel sits at the VALU issue limit).  The DPP scans, the exponentials / reciprocals and
+// the stop-point selects stay per pixel.  0: one instruction per pixel (the first version; A/B switch)
+#define GS_BWD_ROWS_PK 1
+#endif
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GS_BWD_ROWS_WPE)))
 raster_backward_rows_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
     typedef float f4 __attribute__((ext_vector_type(4)));
@@ -2010,6 +2016,79 @@ raster_backward_rows_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
             d.G2 = *reinterpret_cast<const f4 *>(s_gr[2] + prow);
             d.py = s_py[s];
         };
+#if GS_BWD_ROWS_PK
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        auto sp = [](float v) { return f2{v, v}; };
+        auto pfma = [](f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); };
+        f2 Scp[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}, S1p[2] = {{0.f, 0.f}, {0.f, 0.f}}, Syp[2] = {{0.f, 0.f}, {0.f, 0.f}};
+        f2 Sqp = {0.f, 0.f};
+        const f2 nbdx2[2] = {{nbdx[0], nbdx[1]}, {nbdx[2], nbdx[3]}}, adx22[2] = {{adx2[0], adx2[1]}, {adx2[2], adx2[3]}};
+        auto row_step = [&](RowIn &cur, RowIn &nxt, int s) {  // pixel row s of the tile
+            if (!GS_BWD_ROWS_PF) row_loads(cur, s);
+            const bool any_live = __ballot(cur.T[0] > GS_T_STOP || cur.T[1] > GS_T_STOP || cur.T[2] > GS_T_STOP ||
+                                           cur.T[3] > GS_T_STOP) != 0ull;
+            if (GS_BWD_ROWS_PF && s + 1 < 16) row_loads(nxt, s + 1);
+            if (!any_live) return;  // (see the per-pixel version below)
+            const float dy = cur.py - gy;
+            const f2 dy2 = sp(dy);
+            f2 q2[2];
+            float araw[4], pin[4], Tb[4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                q2[h] = pfma(pfma(sp(cC), dy2, nbdx2[h]), dy2, adx22[h]);  // q' = q - log2 sigma(opa); the forward's evaluation order
+                araw[2 * h] = gs_exp2(-q2[h].x);
+                araw[2 * h + 1] = gs_exp2(-q2[h].y);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                pin[i] = fminf(fmaxf(1.0f - araw[i], 0.f), 1.0f);  // (the subtraction's clamp modifier)
+                Tb[i] = cur.T[i];
+            }
+            gs_row_scan_mul4_excl(pin, Tb);
+            float alpha[4], wg[4], ws[4];
+            f2 w2[2], al2[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) alpha[i] = Tb[i] > GS_T_STOP ? araw[i] : 0.f;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                al2[h] = f2{alpha[2 * h], alpha[2 * h + 1]};
+                w2[h] = al2[h] * f2{Tb[2 * h], Tb[2 * h + 1]};
+                const f2 g0 = h ? cur.G0.zw : cur.G0.xy, g1 = h ? cur.G1.zw : cur.G1.xy, g2 = h ? cur.G2.zw : cur.G2.xy;
+                const f2 wgh = w2[h] * pfma(g2, sp(c2), pfma(g1, sp(c1), g0 * sp(c0)));  // w (dL/dC . colour)
+                wg[2 * h] = wgh.x;
+                wg[2 * h + 1] = wgh.y;
+            }
+            gs_row_scan_add4_oop(ws, wg);
+            f2 rho2[2], svs[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f2 R2 = h ? cur.R.zw : cur.R.xy;
+                rho2[h] = R2 - f2{ws[2 * h], ws[2 * h + 1]};  // rho behind this Gaussian
+                const f2 den = sp(1.00000011920928955f) - f2{araw[2 * h], araw[2 * h + 1]};
+                const f2 beta = al2[h] * f2{gs_rcp(den.x), gs_rcp(den.y)};
+                const f2 sv = pfma(-rho2[h], beta, f2{wg[2 * h], wg[2 * h + 1]});  // s = w gc - rho beta (see below)
+                const f2 g0 = h ? cur.G0.zw : cur.G0.xy, g1 = h ? cur.G1.zw : cur.G1.xy, g2 = h ? cur.G2.zw : cur.G2.xy;
+                Scp[0] = pfma(g0, w2[h], Scp[0]);
+                Scp[1] = pfma(g1, w2[h], Scp[1]);
+                Scp[2] = pfma(g2, w2[h], Scp[2]);
+                S1p[h] += sv;
+                Syp[h] = pfma(sv, dy2, Syp[h]);
+                svs[h] = sv;
+                Sqp = pfma(sv, q2[h], Sqp);
+            }
+            const f2 ss = svs[0] + svs[1];
+            Syy = fmaf((ss.x + ss.y) * dy, dy, Syy);
+            if (gq == 15) {  // the row's pixel states in front of the next group: T behind the group's last Gaussian
+                f4 Tout, Rout;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Tout[i] = cur.T[i] * pin[i];
+                Rout.xy = rho2[0];
+                Rout.zw = rho2[1];
+                *reinterpret_cast<f4 *>(s_T + 16 * s + 4 * jq) = Tout;
+                *reinterpret_cast<f4 *>(s_rho + 16 * s + 4 * jq) = Rout;
+            }
+        };
+#else
         auto row_step = [&](RowIn &cur, RowIn &nxt, int s) {  // pixel row s of the tile
             if (!GS_BWD_ROWS_PF) row_loads(cur, s);
             // a pixel row whose 16 pixels have all stopped adds exact zeros to every sum of every Gaussian of the group and
@@ -2069,12 +2148,19 @@ raster_backward_rows_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
                 *reinterpret_cast<f4 *>(s_rho + 16 * s + 4 * jq) = Rout;
             }
         };
+#endif
         RowIn ra, rb;
         if (GS_BWD_ROWS_PF) row_loads(ra, 0);
         for (int s = 0; s < 16; s += 2) {
             row_step(ra, rb, s);
             row_step(rb, ra, s + 1);
         }
+#if GS_BWD_ROWS_PK
+        S1[0] = S1p[0].x, S1[1] = S1p[0].y, S1[2] = S1p[1].x, S1[3] = S1p[1].y;
+        Sy[0] = Syp[0].x, Sy[1] = Syp[0].y, Sy[2] = Syp[1].x, Sy[3] = Syp[1].y;
+        Sc0 = Scp[0].x + Scp[0].y, Sc1 = Scp[1].x + Scp[1].y, Sc2 = Scp[2].x + Scp[2].y;
+        Sq = Sqp.x + Sqp.y;
+#endif
         // ---- close the group: the lane's four pixel columns, then the four pixel quads of the Gaussian
         const float4 cv = rec[1];
         float Sx = 0.f, Sxx = 0.f, Sxy = 0.f, Syt = 0.f, Stot = (S1[0] + S1[1]) + (S1[2] + S1[3]);
