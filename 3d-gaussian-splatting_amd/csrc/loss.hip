@@ -87,8 +87,11 @@ __global__ void __launch_bounds__(FT) loss_fused_kernel(const float *__restrict_
     constexpr int LW = FT + 2 * FHALO;
     // every LDS row is double-buffered by the parity of the step, so that ONE barrier per step suffices: step n reads
     // the image row n and the adjoint row n - 1 and writes the image row n + 1 and the adjoint row n into the other halves
-    __shared__ float s_x[2][LW], s_y[2][LW];
-    __shared__ float s_d[2][3][LW];
+    // (round 5: x and y interleaved, and the first two adjoints: one 8-byte read per tap feeds a packed fp32 instruction)
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    __shared__ f2 s_xy[2][LW];
+    __shared__ f2 s_d01[2][LW];
+    __shared__ float s_d2[2][LW];
     __shared__ float s_red[FT / 64];
     const int t = threadIdx.x;
     const int F = 3 * L.W;
@@ -112,25 +115,25 @@ __global__ void __launch_bounds__(FT) loss_fused_kernel(const float *__restrict_
         }
     };
     auto stage = [&](int buf) {
-        s_x[buf][t] = xa;
-        s_y[buf][t] = ya;
-        if (t < 2 * FHALO) {
-            s_x[buf][FT + t] = xb;
-            s_y[buf][FT + t] = yb;
-        }
+        s_xy[buf][t] = f2{xa, ya};
+        if (t < 2 * FHALO) s_xy[buf][FT + t] = f2{xb, yb};
     };
     if (t < FHALO) {
 #pragma unroll
-        for (int q = 0; q < 6; ++q) (&s_d[0][0][0])[q * LW + t] = (&s_d[0][0][0])[q * LW + FT + FHALO + t] = 0.f;  // never written again, read by idle columns
+        for (int q = 0; q < 2; ++q) {  // never written again, read by idle columns
+            s_d01[q][t] = s_d01[q][FT + FHALO + t] = f2{0.f, 0.f};
+            s_d2[q][t] = s_d2[q][FT + FHALO + t] = 0.f;
+        }
     }
-    float a1[K][5], a2[K][3];
+    // the rings, in pairs for the packed instructions: (mu, nu), (Exx, Eyy), Exy; (D_mu, D_xx), D_xy
+    f2 a1p[K][2], a2p[K];
+    float a1s[K], a2s[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-#pragma unroll
-        for (int m = 0; m < 5; ++m) a1[k][m] = 0.f;
-#pragma unroll
-        for (int m = 0; m < 3; ++m) a2[k][m] = 0.f;
+        a1p[k][0] = a1p[k][1] = a2p[k] = f2{0.f, 0.f};
+        a1s[k] = a2s[k] = 0.f;
     }
+    auto pfma = [](f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); };
     float ssim_sum = 0.f, l1_sum = 0.f;
     const int rows = min(SH, L.H - r0), n_end = rows + 4 * R;
     fetch(r0 - 2 * R);
@@ -155,39 +158,42 @@ __global__ void __launch_bounds__(FT) loss_fused_kernel(const float *__restrict_
             stage(buf ^ 1);  // the image row of step n + 1 (fetched during step n - 1)
             fetch(i + 2);
         }
-        float h[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, g3[3] = {0.f, 0.f, 0.f};
+        f2 h01 = {0.f, 0.f}, h23 = {0.f, 0.f}, g01 = {0.f, 0.f};
+        float h4 = 0.f, g2 = 0.f;
         if (head) {  // H1
-            const float *sx = &s_x[buf][t], *sy = &s_y[buf][t];
+            const f2 *sxy = &s_xy[buf][t];
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                const float a = sx[3 * k], b = sy[3 * k];
-                const float wa = Wd.g[k] * a, wb = Wd.g[k] * b;
-                h[0] += wa;
-                h[1] += wb;
-                h[2] = fmaf(wa, a, h[2]);
-                h[3] = fmaf(wb, b, h[3]);
-                h[4] = fmaf(wa, b, h[4]);
+                const f2 ab = sxy[3 * k];
+                const f2 w = f2{Wd.g[k], Wd.g[k]} * ab;
+                h01 += w;
+                h23 = pfma(w, ab, h23);
+                h4 = fmaf(w.x, ab.y, h4);
             }
         }
         if (tail) {  // H2 of the adjoint row written by step n - 1
-            const float *sd = &s_d[buf ^ 1][0][t];
+            const f2 *sd01 = &s_d01[buf ^ 1][t];
+            const float *sd2 = &s_d2[buf ^ 1][t];
 #pragma unroll
-            for (int k = 0; k < K; ++k)
-#pragma unroll
-                for (int m = 0; m < 3; ++m) g3[m] = fmaf(Wd.g[k], sd[m * LW + 3 * k], g3[m]);
+            for (int k = 0; k < K; ++k) {
+                g01 = pfma(f2{Wd.g[k], Wd.g[k]}, sd01[3 * k], g01);
+                g2 = fmaf(Wd.g[k], sd2[3 * k], g2);
+            }
         }
         if (head) {
             // V1: image row n adds tap k to the partial sum of moment row n - k (slot (n - k) mod 11)
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const int slot = (P - k + K) % K;
-#pragma unroll
-                for (int m = 0; m < 5; ++m) a1[slot][m] = k == 0 ? Wd.g[0] * h[m] : fmaf(Wd.g[k], h[m], a1[slot][m]);
+                const f2 gk = {Wd.g[k], Wd.g[k]};
+                a1p[slot][0] = k == 0 ? gk * h01 : pfma(gk, h01, a1p[slot][0]);
+                a1p[slot][1] = k == 0 ? gk * h23 : pfma(gk, h23, a1p[slot][1]);
+                a1s[slot] = k == 0 ? Wd.g[0] * h4 : fmaf(Wd.g[k], h4, a1s[slot]);
             }
             if (n >= 2 * R) {  // uniform: moment row rho = i - 5 is complete
                 constexpr int E = (P + 1) % K;
                 const int rho = i - R;
-                const float mu = a1[E][0], nu = a1[E][1], exx = a1[E][2], eyy = a1[E][3], exy = a1[E][4];
+                const float mu = a1p[E][0].x, nu = a1p[E][0].y, exx = a1p[E][1].x, eyy = a1p[E][1].y, exy = a1s[E];
                 const float vx_raw = exx - mu * mu, vy_raw = eyy - nu * nu;
                 const float vx = fmaxf(vx_raw, 0.f), vy = fmaxf(vy_raw, 0.f);
                 const float A1 = 2.f * mu * nu + L.c1, A2 = 2.f * (exy - mu * nu) + L.c2;
@@ -205,9 +211,8 @@ __global__ void __launch_bounds__(FT) loss_fused_kernel(const float *__restrict_
                 const float dExy = 2.f * A1 * inv;
                 const bool valid = col_in && rho >= R && rho < L.H - R;  // the window lies inside the image
                 if (valid && out_col && rho >= r0 && rho < r0 + SH) ssim_sum += S;
-                s_d[buf][0][t + FHALO] = valid ? dmu : 0.f;
-                s_d[buf][1][t + FHALO] = valid ? dExx : 0.f;
-                s_d[buf][2][t + FHALO] = valid ? dExy : 0.f;
+                s_d01[buf][t + FHALO] = f2{valid ? dmu : 0.f, valid ? dExx : 0.f};
+                s_d2[buf][t + FHALO] = valid ? dExy : 0.f;
             }
         }
         if (tail) {
@@ -215,15 +220,16 @@ __global__ void __launch_bounds__(FT) loss_fused_kernel(const float *__restrict_
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const int slot = (P - k + K) % K;
-#pragma unroll
-                for (int m = 0; m < 3; ++m) a2[slot][m] = k == 0 ? Wd.g[0] * g3[m] : fmaf(Wd.g[k], g3[m], a2[slot][m]);
+                const f2 gk = {Wd.g[k], Wd.g[k]};
+                a2p[slot] = k == 0 ? gk * g01 : pfma(gk, g01, a2p[slot]);
+                a2s[slot] = k == 0 ? Wd.g[0] * g2 : fmaf(Wd.g[k], g2, a2s[slot]);
             }
             if (emit) {
                 constexpr int E2 = (P + 1) % K;
                 const float d = xo - yo;
                 l1_sum += fabsf(d);
                 float g = L.a * (d > 0.f ? 1.f : d < 0.f ? -1.f : 0.f);  // torch: sign(0) = 0
-                g -= L.b * (a2[E2][0] + 2.f * xo * a2[E2][1] + yo * a2[E2][2]);
+                g -= L.b * (a2p[E2].x + 2.f * xo * a2p[E2].y + yo * a2s[E2]);
                 grad[(size_t)o * F + cv] = g;
             }
         }
