@@ -1370,6 +1370,12 @@ __device__ __forceinline__ void gs_row_scan_mul4_excl(float p[4], float t[4]) {
 #ifndef GS_BWD_MFMA_PF
 #define GS_BWD_MFMA_PF 1
 #endif
+#ifndef GS_BWD_MFMA_PK
+// 1: the per-pixel algebra of a row step between the two matrix products on PAIRS of the lane's four pixels (packed fp32, as
+// raster_backward_rows_kernel's GS_BWD_ROWS_PK); the scans, the transcendentals and the stop-point selects stay per pixel
+#define GS_BWD_MFMA_PK 1
+#endif
+static_assert(!GS_BWD_MFMA_PK || GS_BWD_MFMA_DIET, "the packed row step is the diet's");
 #ifndef GS_BWD_MFMA_ORDER
 #define GS_BWD_MFMA_ORDER 1
 #endif
@@ -1591,6 +1597,11 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
             const float gy = g.y;
             f4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
             float S1[4] = {0.f, 0.f, 0.f, 0.f}, Sy[4] = {0.f, 0.f, 0.f, 0.f}, Syy = 0.f, Sq = 0.f;
+#if GS_BWD_MFMA_PK
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            auto pfma = [](f2 x, f2 y, f2 z) { return __builtin_elementwise_fma(x, y, z); };
+            f2 S1p[2] = {{0.f, 0.f}, {0.f, 0.f}}, Syp[2] = {{0.f, 0.f}, {0.f, 0.f}}, Sqp = {0.f, 0.f};
+#endif
             // The LDS operands of a pixel row -- the A operands of both products, the row's pixel states and dL/dC -- are
             // requested one row ahead, behind the row's arithmetic and in front of its twelve coefficient MFMAs (registers
             // are free there, and the ~100 cycles of LDS latency pass under the MFMAs; asked for where they are used,
@@ -1640,6 +1651,74 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
                 for (int kk = 0; kk < KQ; ++kk)
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch) lg[ch] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], cob[ch][kk], lg[ch], 0, 0, 0);
+#if GS_BWD_MFMA_PK
+                const float dy = pyt[s] - gy;
+                const f2 dy2 = {dy, dy};
+                f4 Tout, Rout;
+                float dv[3][4];
+                f2 q2[2];
+                float araw[4], pin[4], Tb[4];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    q2[h] = pfma(pfma(f2{cC, cC}, dy2, -f2{bdx[2 * h], bdx[2 * h + 1]}), dy2, f2{adx2[2 * h], adx2[2 * h + 1]});
+                    araw[2 * h] = gs_exp2(-q2[h].x);  // (q is q' = q - log2 sigma(opa): 2^-q' is alpha itself)
+                    araw[2 * h + 1] = gs_exp2(-q2[h].y);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    pin[i] = fminf(fmaxf(1.0f - araw[i], 0.f), 1.0f);  // (the subtraction's clamp modifier; see below)
+                    Tb[i] = Tin[i];
+                }
+                gs_row_scan_mul4_excl(pin, Tb);
+                float alpha[4], wg[4], wsum[4];
+                f2 w2[2], al2[2], cc2[3][2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) alpha[i] = Tb[i] > GS_T_STOP ? araw[i] : 0.f;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    al2[h] = f2{alpha[2 * h], alpha[2 * h + 1]};
+                    w2[h] = al2[h] * f2{Tb[2 * h], Tb[2 * h + 1]};
+                    // colours sigma(logit) = 1 / (1 + 2^(logit')) with the pre-scaled basis
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        const f2 den = f2{1.0f, 1.0f} + f2{gs_exp2(lg[ch][2 * h]), gs_exp2(lg[ch][2 * h + 1])};
+                        cc2[ch][h] = f2{gs_rcp(den.x), gs_rcp(den.y)};
+                    }
+                    const f2 g0 = h ? G0.zw : G0.xy, g1 = h ? G1.zw : G1.xy, g2 = h ? G2.zw : G2.xy;
+                    const f2 wgh = w2[h] * pfma(g2, cc2[2][h], pfma(g1, cc2[1][h], g0 * cc2[0][h]));
+                    wg[2 * h] = wgh.x;
+                    wg[2 * h + 1] = wgh.y;
+                    const f2 to = (h ? Tin.zw : Tin.xy) * f2{pin[2 * h], pin[2 * h + 1]};  // (lanes of Gaussian 15: the group's product)
+                    Tout[2 * h] = to.x;
+                    Tout[2 * h + 1] = to.y;
+                }
+                gs_row_scan_add4_oop(wsum, wg);  // rho behind this Gaussian: rho_in minus the inclusive prefix sum of w gc
+                f2 svs[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f2 rho = (h ? Rin.zw : Rin.xy) - f2{wsum[2 * h], wsum[2 * h + 1]};
+                    const f2 den = f2{1.00000011920928955f, 1.00000011920928955f} - f2{araw[2 * h], araw[2 * h + 1]};
+                    // s = dL/dalpha alpha = w gc - rho beta, beta = alpha / (1 - alpha + 1e-7): masked with alpha, like w
+                    const f2 sv = pfma(-rho, al2[h] * f2{gs_rcp(den.x), gs_rcp(den.y)}, f2{wg[2 * h], wg[2 * h + 1]});
+                    // D = dL/dC_ch w c (1 - c) [x -ln 2: D sh' = D' sh]
+                    const f2 wk = w2[h] * f2{-GS_LN2, -GS_LN2};
+                    const f2 g0 = h ? G0.zw : G0.xy, g1 = h ? G1.zw : G1.xy, g2 = h ? G2.zw : G2.xy;
+                    const f2 d0 = (g0 * wk) * pfma(-cc2[0][h], cc2[0][h], cc2[0][h]);
+                    const f2 d1 = (g1 * wk) * pfma(-cc2[1][h], cc2[1][h], cc2[1][h]);
+                    const f2 d2 = (g2 * wk) * pfma(-cc2[2][h], cc2[2][h], cc2[2][h]);
+                    dv[0][2 * h] = d0.x, dv[0][2 * h + 1] = d0.y;
+                    dv[1][2 * h] = d1.x, dv[1][2 * h + 1] = d1.y;
+                    dv[2][2 * h] = d2.x, dv[2][2 * h + 1] = d2.y;
+                    S1p[h] += sv;
+                    Syp[h] = pfma(sv, dy2, Syp[h]);
+                    Sqp = pfma(sv, q2[h], Sqp);
+                    svs[h] = sv;
+                    Rout[2 * h] = rho.x;
+                    Rout[2 * h + 1] = rho.y;
+                }
+                const f2 ss = svs[0] + svs[1];
+                Syy = fmaf((ss.x + ss.y) * dy, dy, Syy);
+#else
                 const float dy = pyt[s] - gy;
                 f4 Tout, Rout;
                 float dv[3][4];
@@ -1710,6 +1789,7 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
                     Rout[i] = rho;
                 }
                 Syy = fmaf(ssum * dy, dy, Syy);
+#endif
                 if (GS_BWD_MFMA_PF && s + 1 < 16) {
                     row_loads(s + 1);
                     __builtin_amdgcn_sched_barrier(0);  // (the requests stay in front of the MFMAs below)
@@ -1725,6 +1805,11 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
                 }
             }
             asm volatile("" ::"v"(warm));  // (the warming load must not be dropped; its value is not used)
+#if GS_BWD_MFMA_PK
+            S1[0] = S1p[0].x, S1[1] = S1p[0].y, S1[2] = S1p[1].x, S1[3] = S1p[1].y;
+            Sy[0] = Syp[0].x, Sy[1] = Syp[0].y, Sy[2] = Syp[1].x, Sy[3] = Syp[1].y;
+            Sq = Sqp.x + Sqp.y;
+#endif
             // ---- close the group: the lane's four pixel columns, then the four pixel quads of the Gaussian
             const uint32_t gid2 = (uint32_t)__shfl((int)id_lane, (int)(valid ? gi : r - 1), 64);
             const float4 ge2 = S.geom[(size_t)gid2 * GS_REC_STRIDE], cv2 = S.cov4[(size_t)gid2 * GS_REC_STRIDE];
