@@ -791,7 +791,7 @@ def main():
             sk = {}
             for deg, iters in ((0, 3000), (2, 2000), (3, 2000)):  # (round 4 quoted these lengths: tools/soak.py)
                 r_ = training_soak(dev, deg, iters)
-                r_.pop("iters_per_s_blocks", None)
+                r_["iters_per_s_blocks"] = [round(x) for x in r_.get("iters_per_s_blocks", [])]  # (a stalled block shows)
                 sk["rgb" if deg == 0 else f"sh_degree_{deg}"] = r_
                 torch.cuda.empty_cache()
             extra["soak_densifying"] = sk
