@@ -28,7 +28,8 @@ Rank 0 prints ONE JSON line (driver contract):
   cfg1                 BASELINE.json configs[0] (10 k Gaussians, 256 x 256, forward): GPU FPS next to the CPU oracle timed on
                        the SAME scene (BASELINE.md section 3 plans exactly this pair);
   cfg2                 BASELINE.json configs[1] (376,467 Gaussians, 1080p): FPS + the same roofline object;
-  extra                training step (forward + L1/SSIM loss + backward + fused Adam) at cfg2 and at 2.4 M Gaussians -- timed
+  extra                training step (forward + L1/SSIM loss + backward + fused Adam; on one rank with rgb colours the Adam
+                       step runs inside the backward's last kernel: `adam_fused_into_backward`) at cfg2 and at 2.4 M Gaussians -- timed
                        with tools/train_timing.py: the same iterations per block restored from a snapshot, 15 blocks.
                        `iters_per_s` is the MOVING scene (the reference's learning rates: what a training run sees; round 5,
                        ADVICE round 4), `fixed_scene` the same step with learning rate 0 (the full step runs, the parameters
@@ -492,7 +493,7 @@ def main():
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": round(28 * n_par / (adam_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                        "parameters": n_par}
-        detail["adam_fused_into_backward"] = bool(tr._can_fuse_adam())  # (opt-in: GS_TRAIN_FUSE_ADAM=1)
+        detail["adam_fused_into_backward"] = bool(tr._can_fuse_adam())  # (one rank, rgb: gs_frame_backward_adam; GS_TRAIN_FUSE_ADAM=0 for A/B)
         detail.update(repeats=len(blocks), ms_per_iter_min=round(min(blocks) / k * 1e3, 4),
                       ms_per_iter_max=round(max(blocks) / k * 1e3, 4), iters_per_block=k,
                       scene="fixed (learning rate 0: the full step runs, the parameters stay put)" if fixed_scene else
