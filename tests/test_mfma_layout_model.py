@@ -345,3 +345,42 @@ def test_rgb_row_layout_model_equals_the_sequential_recursion():
     live_end = T_ref > T_STOP
     assert np.allclose(sT[live_end], T_ref[live_end], rtol=1e-9, atol=0)
     assert np.allclose(np.delete(sR, 3, axis=0), np.delete(rho_ref, 3, axis=0), rtol=1e-9, atol=1e-12)
+
+
+def test_fused_adam_hand_over_covers_every_element_once():
+    """The optimizer step fused into the projection backward (cull_project.hip: frame_project_backward_kernel<3, 0, 256, ADAM>,
+    round 5): a thread owns a GAUSSIAN, but the [N, 3] arrays are walked by ELEMENT -- lane l of wave w writes its Gaussian's
+    three gradients to tr[3 l + k], then lanes with 4 l + 4 <= ne take elements 4 l .. 4 l + 3 of the wave's contiguous run
+    (base 3 (pid0 + 64 w)) as one float4, and the lane that straddles the array's end takes the rest one by one.  The model
+    walks every workgroup / wave / lane for array lengths around every boundary and checks that each element of the array
+    is updated exactly once, with the gradient of ITS Gaussian and component, by a lane whose own Gaussian lies inside the
+    array (the kernel's `valid` lanes are the only ones guaranteed to have live registers for the quaternion / opacity step,
+    and the early return of invalid threads must not take a needed lane away)."""
+    for n in (1, 2, 3, 5, 63, 64, 65, 127, 191, 255, 256, 257, 300, 511, 515, 1000, 1021):
+        grad = np.arange(3 * n, dtype=np.int64) + 7  # gradient of element e = e + 7
+        hits = np.zeros(3 * n, dtype=np.int64)
+        got = np.zeros(3 * n, dtype=np.int64)
+        for blk in range((n + 255) // 256):
+            pid0 = blk * 256
+            for wv in range(4):
+                wbase = pid0 + 64 * wv
+                left = n - wbase
+                ne = 192 if left >= 64 else (3 * left if left > 0 else 0)
+                tr = np.zeros(192, dtype=np.int64)
+                for lane in range(64):  # every lane of the wave, valid or not (an invalid lane offers zeros)
+                    pid = wbase + lane
+                    for k in range(3):
+                        tr[3 * lane + k] = grad[3 * pid + k] if pid < n else 0
+                for lane in range(64):
+                    e0 = 4 * lane
+                    if e0 + 4 <= ne:
+                        todo = range(e0, e0 + 4)
+                        assert (3 * wbase + e0) % 4 == 0  # the float4 is aligned when the arrays are (wbase is a multiple of 64)
+                    else:
+                        todo = range(e0, ne)
+                    for e in todo:
+                        assert wbase + lane < n, "an element is left to a lane the kernel may have retired"
+                        hits[3 * wbase + e] += 1
+                        got[3 * wbase + e] = tr[e]
+        assert (hits == 1).all(), n
+        assert (got == grad).all(), n
