@@ -1973,7 +1973,8 @@ __global__ void __launch_bounds__(1024) mfma_items_kernel(const uint32_t *__rest
 #ifndef GS_BWD_ROWS_PF
 // 1: LDS operands of a pixel row requested one row ahead.  Measured equal (same box, 2.4 M Gaussians: 0.497 / 0.514 ms
 // without against 0.508 / 0.498 ms with; profiles/r05_b_*): four resident waves per SIMD cover the LDS latency, and without
-// the second register set the kernel needs 105 VGPRs and no scratch (128 and three spilled registers with it)
+// the second register set the kernel needs 105 VGPRs and no scratch (128 and three spilled registers with it; with the
+// packed row step, GS_BWD_ROWS_PK: 126 and no scratch)
 #define GS_BWD_ROWS_PF 0
 #endif
 #ifndef GS_BWD_ROWS_WPE
