@@ -37,23 +37,24 @@ int gs_raster_forward_ref(const RasterSrc &S, const RasterGeom &G, const int32_t
 
 namespace {
 
-// exclusive scan of ceil(nproc/64) over tiles -> bucket_offsets[T+1], total -> *n_buckets, and one record per bucket
-// (tile, first Gaussian of the bucket inside the tile's list, Gaussians in the bucket, start of the tile's list):
-// a bucket kernel's wave learns everything about its work item from ONE load instead of a binary search over the
-// offsets followed by three dependent loads
+// exclusive scan of ceil(nproc/64) over tiles -> bucket_offsets[T+1], total -> *n_buckets (bucket_scan_kernel, one workgroup),
+// then one record per bucket (bucket_fill_kernel, a wave per tile): (tile, first Gaussian of the bucket inside the tile's
+// list, Gaussians in the bucket, start of the tile's list) -- a bucket kernel's wave learns everything about its work item
+// from ONE load instead of a binary search over the offsets followed by three dependent loads.
 // Round 5: with frame ranges the scan also counts the buckets of SATURATED tiles -- tiles whose compositing stopped before the
 // end of their list because every pixel had saturated -- and returns the count in the upper half of *n_buckets: the share of
 // such buckets is what decides between the two rgb backward kernels (GS_FRAME_BWD_ROWS, include/gs_abi.h), and the caller
 // reads the counter back with the frame's other counters anyway.
+// Two kernels since the end of round 5: until then the scan's ONE workgroup also stored the records -- 31 k x 16 bytes from one
+// CU at 2.4 M Gaussians: 28 us alone, and 91 us where it actually runs, on the side stream underneath the caller's loss kernel
+// (kernel trace of whole training steps, profiles/r05_z_*): longer than the loss it was meant to hide under; 62 k and more
+// records in a densified scene.
 __global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t *__restrict__ tile_nproc, int n_tiles,
                                                           uint32_t *__restrict__ bucket_offsets,
                                                           unsigned long long *__restrict__ n_buckets,
-                                                          uint4 *__restrict__ bucket_info,
                                                           const int32_t *__restrict__ ranges, int frame_ranges) {
     __shared__ uint32_t s_wave[2][16];
     __shared__ uint32_t s_carry[2];
-    __shared__ uint32_t s_nheavy;
-    __shared__ uint4 s_heavy[1024];  // (tile, first record, Gaussians processed, list start) of the chunk's tiles beyond 48 buckets
     if (threadIdx.x < 2) s_carry[threadIdx.x] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -75,35 +76,8 @@ __global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t *__res
             sat_all += s_wave[1][w];
         }
         const uint32_t carry = s_carry[0];
-        if (threadIdx.x == 0) s_nheavy = 0;
+        if (i < n_tiles) bucket_offsets[i] = carry + woff + incl - v;
         __syncthreads();
-        if (i < n_tiles) {
-            const uint32_t first = carry + woff + incl - v;
-            bucket_offsets[i] = first;
-            const uint32_t st = (uint32_t)(frame_ranges ? ranges[2 * i] : ranges[i]);
-            if (v <= 48) {
-                for (uint32_t b = 0; b < v; ++b) {
-                    const uint32_t rem = np - b * GS_BUCKET;
-                    bucket_info[first + b] = make_uint4((uint32_t)i, b * GS_BUCKET, rem < GS_BUCKET ? rem : GS_BUCKET, st);
-                }
-            } else {
-                // a tile with hundreds of buckets (a pile of a densifying run) would keep ONE thread storing its records
-                // while 1,023 wait: such tiles are written by the whole workgroup below.  (Threshold 48: with 8 the serial
-                // loop over the MANY moderately long tiles of the soak's end state cost more than it saved -- 453 against
-                // 117 us per call, profiles/r05_l_*.)
-                const uint32_t h = atomicAdd(&s_nheavy, 1u);
-                s_heavy[h] = make_uint4((uint32_t)i, first, np, st);
-            }
-        }
-        __syncthreads();
-        for (uint32_t h = 0; h < s_nheavy; ++h) {
-            const uint4 t = s_heavy[h];
-            const uint32_t vb = (t.z + GS_BUCKET - 1) / GS_BUCKET;
-            for (uint32_t b = threadIdx.x; b < vb; b += 1024) {
-                const uint32_t rem = t.z - b * GS_BUCKET;
-                bucket_info[t.y + b] = make_uint4(t.x, b * GS_BUCKET, rem < GS_BUCKET ? rem : GS_BUCKET, t.w);
-            }
-        }
         if (threadIdx.x == 1023) {
             s_carry[0] = carry + woff + incl;
             s_carry[1] += sat_all;
@@ -114,6 +88,29 @@ __global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t *__res
         bucket_offsets[n_tiles] = s_carry[0];
         *n_buckets = (unsigned long long)s_carry[0] | ((unsigned long long)s_carry[1] << 32);
     }
+}
+// the records: a wave per tile, lane b takes the tile's buckets b, b + 64, ... (a pile of a densifying run has hundreds)
+__global__ void __launch_bounds__(256) bucket_fill_kernel(const uint32_t *__restrict__ tile_nproc, int n_tiles,
+                                                         const uint32_t *__restrict__ bucket_offsets,
+                                                         uint4 *__restrict__ bucket_info,
+                                                         const int32_t *__restrict__ ranges, int frame_ranges) {
+    const int tile = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    if (tile >= n_tiles) return;
+    const uint32_t np = tile_nproc[tile], v = (np + GS_BUCKET - 1) / GS_BUCKET;
+    if (v == 0) return;
+    const uint32_t first = bucket_offsets[tile], st = (uint32_t)(frame_ranges ? ranges[2 * tile] : ranges[tile]);
+    for (uint32_t b = (uint32_t)lane; b < v; b += 64) {
+        const uint32_t rem = np - b * GS_BUCKET;
+        bucket_info[first + b] = make_uint4((uint32_t)tile, b * GS_BUCKET, rem < GS_BUCKET ? rem : GS_BUCKET, st);
+    }
+}
+static inline void gs_launch_bucket_list(const uint32_t *tile_nproc, int n_tiles, uint32_t *bucket_offsets,
+                                         unsigned long long *n_buckets, uint4 *bucket_info, const int32_t *ranges,
+                                         int frame_ranges, hipStream_t stream) {
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, tile_nproc, n_tiles, bucket_offsets, n_buckets,
+                       ranges, frame_ranges);
+    hipLaunchKernelGGL(bucket_fill_kernel, dim3((unsigned)gs_div_up(n_tiles, 4)), dim3(256), 0, stream, tile_nproc, n_tiles,
+                       bucket_offsets, bucket_info, ranges, frame_ranges);
 }
 
 // Frame path, rgb rows: the key (depth bits, Gaussian) of the last list entry the forward processed in every tile
@@ -2480,8 +2477,7 @@ extern "C" int gs_draw_backward(const float *pos, const float *rgb, const float 
                                    ws.tile_nproc, s, exact);
     if (rc) return rc;
     // 2. bucket work list
-    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, s, ws.tile_nproc, G.ntx * G.nty,
-                       ws.bucket_offsets, ws.n_buckets, ws.bucket_info, tile_n_point_accum, 0);
+    gs_launch_bucket_list(ws.tile_nproc, G.ntx * G.nty, ws.bucket_offsets, ws.n_buckets, ws.bucket_info, tile_n_point_accum, 0, s);
     // 3. one wave per bucket, one output row per pair
     BwdIn I = {output, grad_output, ws.ckpt, ws.tile_nproc, ws.bucket_offsets, ws.bucket_info, tile_n_point_accum};
     BwdOut O = {nullptr, nullptr, nullptr, nullptr, 0, grad_pos, grad_rgb, grad_opa, grad_cov};  // (reference API: no rows)
@@ -2520,8 +2516,8 @@ int gs_stage_backward_prepare(const gs_frame *f, const gs_frame_ws &ws, const ui
                           (GS_MFMA_ITEMS || !gs_frame_long_lists(f, FG.n_tiles));  // (no items + flagged frame: the buckets
                                                                                     // beyond a tile's first 32: hand-over)
     if (!per_tile)
-        hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, ws.tile_nproc, FG.n_tiles,
-                           ws.bucket_offsets, ws.counters + GS_CNT_BUCKETS, ws.bucket_info, ws.tile_ranges, 1);
+        gs_launch_bucket_list(ws.tile_nproc, FG.n_tiles, ws.bucket_offsets, ws.counters + GS_CNT_BUCKETS, ws.bucket_info,
+                              ws.tile_ranges, 1, stream);
     const bool mfma_frame = (f->color_dim == 48 && GS_BWD_SH_MFMA >= 1) || (f->color_dim == 27 && GS_BWD_SH_MFMA >= 2);
     if (mfma_frame && GS_MFMA_ITEMS) {  // the matrix-pipe kernel's work items, heavy tiles first where the frame has an order
         const uint32_t cap = 0u;  // (work items spread a long list over the device: no hand-over, see gs_stage_raster_backward)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One workload, nothing else: the process rocprofv3 is wrapped around for per-config kernel traces and PMC passes.
 
-    python tools/prof_target.py cfg5 [--frames 60] [--backward] [--sh-degree 3]
+    python tools/prof_target.py cfg5 [--frames 60] [--backward] [--sh-degree 3] [--train]
 
 Every kernel dispatched after the warm-up belongs to `frames` identical forward (and, with --backward, backward)
 frames of that BASELINE.json config, so per-kernel averages / counter sums in the rocprofv3 output are per-config
@@ -29,6 +29,9 @@ ap.add_argument("--no-stage-times", action="store_true", help="skip the hipEvent
 ap.add_argument("--bwd-rows", type=int, default=-1,
                 help="rgb backward kernel: 1 = row layout (GS_FRAME_BWD_ROWS), 0 = pixel-parallel, -1 = the renderer's own "
                      "choice from the saturated-bucket statistic (it needs a backward + stats() to have run: below)")
+ap.add_argument("--train", action="store_true",
+                help="whole training steps of gs_train.Trainer instead of bare frames (learning rate 0: the scene stays the "
+                     "config's): forward, loss, backward with the optimizer step fused in (rgb, one rank) or followed by it")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 n, W, H, use_sh = CONFIGS[a.config]
@@ -39,6 +42,19 @@ r = FrameRenderer(dev, max_pairs=1 << 20, training=a.backward, auto_grow=True,
                   bwd_rows=None if a.bwd_rows < 0 else bool(a.bwd_rows))
 img, _ = r.forward(*params, cam)
 st = r.stats()
+if a.train:
+    from gs_train import TrainOptions, Trainer
+
+    target = (img + 0.05 * torch.randn(H, W, 3, device=dev)).clamp_(0, 1).contiguous()
+    del r, img
+    tr = Trainer(params, [cam], [target], TrainOptions(lr=0.0), max_pairs=int(st.pairs * 1.25) + 4096)
+    for i in range(30 + a.frames):
+        tr.train_step(i, 0)
+    torch.cuda.synchronize()
+    print(json.dumps({"config": a.config, "n": n, "visible": st.visible, "tile_pairs": st.pairs, "train_steps": a.frames,
+                      "warm_up_steps": 30, "adam_fused_into_backward": bool(tr._can_fuse_adam()),
+                      "bwd_rows_flag": bool(tr.renderer._frame.flags & 64)}), flush=True)
+    sys.exit(0)
 r.max_pairs = int(st.pairs * 1.1) + 4096
 r.auto_grow = False
 img, _ = r.forward(*params, cam)

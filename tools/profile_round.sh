@@ -1,5 +1,6 @@
 #!/bin/bash
-# Collects one profiles/ set on the GPU box:  tools/profile_round.sh <tag> <config> [fwd|fwdbwd] [extra prof_target flags]
+# Collects one profiles/ set on the GPU box:  tools/profile_round.sh <tag> <config> [fwd|fwdbwd|train] [extra prof_target flags]
+#   (mode `train`: whole steps of gs_train.Trainer -- forward, loss, backward, optimizer -- instead of bare frames)
 #   1. rocprofv3 --kernel-trace --stats of tools/prof_target.py <config> (per-kernel averages of THAT workload)
 #      + the JSON line of the same run (N, V, M, hipEvent stage times)
 #   2. separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ instruction / busy counters, SQ active / wait counters);
@@ -11,7 +12,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BW=""; [ "$MODE" = "fwdbwd" ] && BW="--backward"
+BW=""; [ "$MODE" = "fwdbwd" ] && BW="--backward"; [ "$MODE" = "train" ] && BW="--train"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o s -- python "$R/tools/prof_target.py" $CFG $BW --frames 100 "$@" > "$OUT/target.json" 2> "$OUT/stats.err"
 i=0
 for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD"; do
