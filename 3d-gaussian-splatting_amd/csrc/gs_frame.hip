@@ -155,6 +155,11 @@ struct StageTimer {
 // keeps no state: the stream, the two events and the pending flag live in the handle (gs_frame_async_create /
 // _destroy), and PyTorch may call backward from its autograd thread -- hence the mutex inside the handle.
 // Skipped while the stream is being captured into a graph (the fork would never be joined inside the capture).
+#ifndef GS_ASYNC_EVENT_FLAGS
+// fork / join between two streams of ONE device: no system-scope release / acquire fence with the event (the host never waits on
+// these events, and what the two streams hand each other lives in device memory)
+#define GS_ASYNC_EVENT_FLAGS (hipEventDisableTiming | hipEventDisableSystemFence)
+#endif
 struct gs_frame_async {
     std::mutex mu;
     hipStream_t side = nullptr;
@@ -169,8 +174,8 @@ extern "C" int gs_frame_async_create(gs_frame_async **out) {
     GS_CHECK_ARG(a != nullptr, "out of memory");
     if (hipGetDevice(&a->device) != hipSuccess ||
         hipStreamCreateWithFlags(&a->side, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&a->fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&a->done, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&a->fork, GS_ASYNC_EVENT_FLAGS) != hipSuccess ||
+        hipEventCreateWithFlags(&a->done, GS_ASYNC_EVENT_FLAGS) != hipSuccess) {
         if (a->fork) (void)hipEventDestroy(a->fork);
         if (a->done) (void)hipEventDestroy(a->done);
         if (a->side) (void)hipStreamDestroy(a->side);
