@@ -1179,6 +1179,14 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
             }
         }
         static_assert(GS_PB_SH_BIG <= 64, "one 64-bit row mask per Gaussian");
+#ifndef GS_PB_SH_DIAG
+#define GS_PB_SH_DIAG 0  // timing-only builds (tools/ab_variants.py): 2 = the existence mask is built but no row is walked
+#endif
+        if (GS_PB_SH_DIAG == 2) {
+            asm volatile("" ::"v"((uint32_t)written_all), "v"((uint32_t)(written_all >> 32)));  // (the mask stays alive)
+            written_all = 0;
+            maxrows = 0;
+        }
         for (int pass = 0; pass < GS_PB_SH_PASSES; ++pass) {
         const int own0 = pass * OWN;
         const bool mine_pass = lane >= own0 && lane < own0 + OWN;
