@@ -16,6 +16,7 @@ reductions) are not reproduced.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -256,8 +257,21 @@ class FrameRenderer:
         with torch.cuda.device(self.device):
             return self._forward(pos, quat, scale, opa, rgb, camera, training)
 
+    # auto_grow="async": how many frames the host may issue beyond the frame whose counters are still on their way.  A
+    # Python loop issues a training step in ~0.1 ms and the device takes ~1 ms for it: unbounded, the host runs hundreds of
+    # frames ahead, the counters of frame k are looked at while frame k + 500 is being issued, and a scene whose pair count
+    # grows (training lowers opacities; views differ) overflows its workspace -- frames rendered empty, steps skipped on the
+    # device -- long before the growth that frame k asked for takes effect; with one copy in flight at a time most of those
+    # frames are never even looked at.  (Found at the end of round 5: two 7,001-iteration fits that are bit-identical step by
+    # step in lockstep ended 0.1 dB apart when run at their own pace, tools/fused_adam_bisect.py.)  Waiting for the copy of
+    # frame k before frame k + 8 is issued costs nothing -- seven frames are queued behind it -- and bounds the lag.
+    ASYNC_COUNTER_LAG = int(os.environ.get("GS_FRAME_COUNTER_LAG", "8"))  # (the variable: A/B measurements)
+
     def _poll_async_counters(self):
-        """Counters of an earlier frame that have landed in pinned memory (no waiting)."""
+        """Counters of an earlier frame that have landed in pinned memory (no waiting -- unless the host has run
+        ``ASYNC_COUNTER_LAG`` frames ahead of them)."""
+        if self._async_event is not None and self._frame_serial - self._async_serial >= self.ASYNC_COUNTER_LAG:
+            self._async_event.synchronize()
         if self._async_event is not None and self._async_event.query():
             v, m, o, b, longest = (int(x) for x in self._async_host.tolist())
             self._async_event = None

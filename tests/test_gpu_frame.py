@@ -961,6 +961,30 @@ def test_frame_async_growth(gpu):
     assert np.abs(img.cpu().numpy() - of.image).max() < IMG_ATOL and r.overflowed_frames == 1
 
 
+def test_async_counters_lag_is_bounded(gpu):
+    """auto_grow="async": the host never issues more than ASYNC_COUNTER_LAG frames beyond the frame whose counters are still on
+    their way (round 5: a Python loop runs hundreds of frames ahead of the device otherwise, the growth a frame asked for
+    arrives hundreds of frames late and frames overflow -- are rendered empty, their steps skipped -- without anybody looking;
+    tools/fused_adam_bisect.py).  A scene whose pair count doubles behind the renderer's back is picked up within that many
+    frames although nothing in the loop synchronises."""
+    scene, cam = case(10_000, 128, 128)
+    of = OracleFrame(scene, cam)
+    params = to_torch(scene, gpu)
+    r = FrameRenderer(gpu, max_pairs=len(of.ids) * 2, auto_grow="async", training=True)
+    r.forward(*params, cam)
+    lag = FrameRenderer.ASYNC_COUNTER_LAG
+    assert 1 <= lag <= 64
+    r.max_pairs = len(of.ids) // 2  # as if the scene had doubled: every frame overflows until the counters are looked at
+    frames = 0
+    while r.max_pairs < len(of.ids) and frames < 10 * lag:
+        r.forward(*params, cam)
+        frames += 1
+        assert r._async_event is None or r._frame_serial - r._async_serial <= lag
+    assert frames <= lag + 2 and r.max_pairs >= len(of.ids), (frames, r.max_pairs, len(of.ids))
+    img = r.forward(*params, cam)[0]
+    assert np.abs(img.cpu().numpy() - of.image).max() < IMG_ATOL
+
+
 def test_c_abi_client_without_torch(gpu, tmp_path):
     """examples/abi_demo.cpp links libgs_amd.so and the HIP runtime only (no torch, no Python): the same scene
     rendered through that client and through FrameRenderer gives bit-identical images and counters."""
