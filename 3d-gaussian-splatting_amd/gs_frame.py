@@ -70,7 +70,7 @@ class FrameRenderer:
         self.force_strips = FrameRenderer.default_force_strips if force_strips is None else bool(force_strips)
         self.serial_long_lists = bool(serial_long_lists)  # frames with long lists: no segmented compositing
         # GS_FRAME_LONG_LISTS (big-list sort + segmented compositing of long tile lists): True / False, or None = as soon
-        # as an earlier frame of this renderer reported a tile list beyond 2048 pairs (the counters that auto_grow reads
+        # as an earlier frame of this renderer reported a tile list beyond LONG_LIST_FLAG_AT = 6,144 pairs (the counters that auto_grow reads
         # back anyway carry the longest list).  The workspace capacity plays no part in it.
         self.long_lists = long_lists
         self._long_lists_seen = False
@@ -265,6 +265,13 @@ class FrameRenderer:
     # frames are never even looked at.  (Found at the end of round 5: two 7,001-iteration fits that are bit-identical step by
     # step in lockstep ended 0.1 dB apart when run at their own pace, tools/fused_adam_bisect.py.)  Waiting for the copy of
     # frame k before frame k + 8 is issued costs nothing -- seven frames are queued behind it -- and bounds the lag.
+    # The longest tile list beyond which following frames are flagged GS_FRAME_LONG_LISTS.  A flagged frame composites EVERY
+    # tile beyond 512 entries in segments (two passes in training) to cut the serial walk of the longest one: worth it for a
+    # pile (100,000 Gaussians in one tile: 26 -> 1.4 ms) and at the very end of the densifying rgb run (longest list beyond
+    # 6,000: 516 against 464 it/s, r5av), not in its middle (longest list 2,000 - 5,000, a thousand tiles beyond 512: flagged
+    # frames ran 15 - 17 % slower, r5as / r5at).  2,048 until the end of round 5 -- when the counters started to arrive on
+    # time (ASYNC_COUNTER_LAG) the flag came on a thousand iterations earlier and that run lost 13 %.
+    LONG_LIST_FLAG_AT = int(os.environ.get("GS_FRAME_LONG_LIST_FLAG_AT", "6144"))
     ASYNC_COUNTER_LAG = int(os.environ.get("GS_FRAME_COUNTER_LAG", "8"))  # (the variable: A/B measurements)
 
     def _poll_async_counters(self):
@@ -275,7 +282,7 @@ class FrameRenderer:
         if self._async_event is not None and self._async_event.query():
             v, m, o, b, longest = (int(x) for x in self._async_host.tolist())
             self._async_event = None
-            self._long_lists_seen = self._long_lists_seen or longest > 2048
+            self._long_lists_seen = self._long_lists_seen or longest > self.LONG_LIST_FLAG_AT
             # (NOT the backward-kernel choice: counters that arrive asynchronously would make it -- and with it the
             # gradients' last bits -- depend on host timing; it moves at synchronous stats() calls only)
             if o:
@@ -538,7 +545,7 @@ class FrameRenderer:
                                                     stream.cuda_stream), "gs_frame_longest_list_async")
         stream.synchronize()
         v, m, o, b, longest = (int(x) for x in self._stats_host.tolist())
-        self._long_lists_seen = self._long_lists_seen or longest > 2048
+        self._long_lists_seen = self._long_lists_seen or longest > self.LONG_LIST_FLAG_AT
         self._note_buckets(b)
         return FrameStats(v, m, o, b & 0xffffffff, longest, b >> 32)
 

@@ -307,7 +307,7 @@ int gs_frame_stats_async(const gs_frame *f, int64_t *stats_host, gs_stream_t str
 
 /* Length of the longest tile list of the last forward on this workspace (sort_mode 2, strip variant; lists of up to
  * 1024 pairs are reported as 0), copied device->host asynchronously into *longest_host.  A caller that sees a value
- * above ~2048 sets GS_FRAME_LONG_LISTS on the following frames. */
+ * above ~6144 sets GS_FRAME_LONG_LISTS on the following frames. */
 int gs_frame_longest_list_async(const gs_frame *f, int64_t *longest_host, gs_stream_t stream);
 
 /* (Validity, since ABI 4: `tiles_touched` is written by sort_modes 0 / 1 only -- sort_mode 2 keeps the count in
