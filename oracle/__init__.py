@@ -269,6 +269,23 @@ def draw_backward(pos, rgb, opa, cov, accum, output, grad_output, focal_x, focal
     return gp, gr, go, gc
 
 
+def draw_backward_f64(pos, rgb, opa, cov, accum, grad_output, focal_x, focal_y, use_sh=False, rays_o=None,
+                      lefttop=None, vdx=None, vdy=None):
+    """K8 evaluated in double on the fp32 inputs (gs_oracle.c, gso_draw_backward_f64): the yardstick the fp32
+    evaluations -- the reference's kernel, the oracle, the HIP kernels -- are measured against.  `fast` flavour,
+    sigmoid off; the stop decisions are those of the fp32 transmittance chain.  -> four float64 arrays."""
+    pos, rgb, opa, cov, grad_output = _f(pos), _f(rgb), _f(opa), _f(cov), _f(grad_output)
+    accum = np.ascontiguousarray(accum, np.int32)
+    h, w = grad_output.shape[0], grad_output.shape[1]
+    gp, gr, go, gc = (np.zeros(a.shape, np.float64) for a in (pos, rgb, opa, cov))
+    rv = [_f(v) if v is not None else _Z3 for v in (rays_o, lefttop, vdx, vdy)]
+    lib().gso_draw_backward_f64(_vp(pos), _vp(rgb), _vp(opa), _vp(cov), _vp(accum), _vp(grad_output), _vp(gp),
+                                _vp(gr), _vp(go), _vp(gc), C.c_int32(h), C.c_int32(w), C.c_float(focal_x),
+                                C.c_float(focal_y), _vp(rv[0]), _vp(rv[1]), _vp(rv[2]), _vp(rv[3]),
+                                C.c_int(_sh_code(use_sh, rgb)))
+    return gp, gr, go, gc
+
+
 def render_forward(pos, quat_raw, scale_raw, opa_raw, rgb_raw, rot, tran, near, W, H, fx, fy,
                    thresh, use_sh=False, rays_o=None, lefttop=None, vdx=None, vdy=None):
     """Whole forward frame (splatter.py:513-655, train.py defaults).  -> image[H,W,3], V, M."""

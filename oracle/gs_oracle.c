@@ -923,6 +923,153 @@ GSO_API void gso_draw_backward_scaled(const float *pos, const float *rgb, const 
 }
 
 /* ---------------------------------------------------------------------------------------
+ * K8 in DOUBLE: the yardstick the fp32 evaluations are measured against (tests/test_grad_calibration*.py,
+ * tools/grad_calibration.py).  The same formulas as draw_backward_impl above (gaussian.cu:574-775; `fast` flavour,
+ * sigmoid = 0), with every operation carried out in double on the fp32 inputs -- pixel coordinates, ray direction
+ * and SH basis, exp, the colour sigmoid, the running and the FINAL colour (recomputed here in double rather than
+ * taken from the fp32 forward), all sums.  The reference's constants 1e-14 (:591) and 1e-7 (:720) are part of the
+ * formula and stay.  The only fp32 quantity is the early-stop DECISION: a pixel stops where the fp32 transmittance
+ * chain of K7 / K8 (:906, :578) finds T < 1e-4, so that truth, oracle and kernels sum the same set of terms (the
+ * parity tests zero dL/dimage on the pixels where that decision is not robust, gso_draw_ambiguous).
+ * Outputs are double arrays laid out like the gradients: gp[M,3] (z untouched), gr[M,D], go[M], gc[M,4].
+ * ------------------------------------------------------------------------------------- */
+static void calc_sh_f64(int nb, const double *dir, double *out) {
+    const double x = dir[0], y = dir[1], z = dir[2];
+    const double xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    out[0] = (double)C0;
+    out[1] = -(double)C1 * y;
+    out[2] = (double)C1 * z;
+    out[3] = -(double)C1 * x;
+    out[4] = (double)C2[0] * xy;
+    out[5] = (double)C2[1] * yz;
+    out[6] = (double)C2[2] * (2.0 * zz - xx - yy);
+    out[7] = (double)C2[3] * xz;
+    out[8] = (double)C2[4] * (xx - yy);
+    if (nb == 16) {
+        out[9] = (double)C3[0] * y * (3.0 * xx - yy);
+        out[10] = (double)C3[1] * xy * z;
+        out[11] = (double)C3[2] * y * (4.0 * zz - xx - yy);
+        out[12] = (double)C3[3] * z * (2.0 * zz - 3.0 * xx - 3.0 * yy);
+        out[13] = (double)C3[4] * x * (4.0 * zz - xx - yy);
+        out[14] = (double)C3[5] * z * (xx - yy);
+        out[15] = (double)C3[6] * x * (xx - 3.0 * yy);
+    }
+}
+
+GSO_API void gso_draw_backward_f64(const float *pos, const float *rgb, const float *opa, const float *cov,
+                                   const int32_t *accum_idx, const float *grad_output, double *gp, double *gr,
+                                   double *go_, double *gc, int32_t h, int32_t w, float focal_x, float focal_y,
+                                   const float *rays_o, const float *lefttop, const float *vdx, const float *vdy,
+                                   int use_sh) {
+    const uint32_t ntx = (uint32_t)(w + 15) / 16, nty = (uint32_t)(h + 15) / 16;
+    const int nb = sh_nb(use_sh), D = use_sh ? 3 * nb : 3;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (uint32_t id_tile = 0; id_tile < ntx * nty; ++id_tile) {
+        const uint32_t tx = id_tile % ntx, ty = id_tile / ntx;
+        const uint32_t start = (uint32_t)accum_idx[id_tile], end = (uint32_t)accum_idx[id_tile + 1];
+        const uint32_t len = end - start;
+        if (len == 0) continue;
+        double *cpc = (double *)malloc(sizeof(double) * 3 * (size_t)len); /* colours of this pixel's Gaussians */
+        for (uint32_t ly = 0; ly < 16; ++ly)
+            for (uint32_t lx = 0; lx < 16; ++lx) {
+                const uint32_t id_x = tx * 16 + lx, id_y = ty * 16 + ly;
+                if (id_x >= (uint32_t)w || id_y >= (uint32_t)h) continue;
+                const double px = (id_x + 0.5 - (uint32_t)w / 2) / (double)focal_x;
+                const double py = (id_y + 0.5 - (uint32_t)h / 2) / (double)focal_y;
+                const float pxf = (float)px, pyf = (float)py; /* the fp32 chain that takes the stop decision */
+                double SH[16];
+                if (use_sh) {
+                    double dir[3], nrm = 0.0;
+                    for (int i = 0; i < 3; ++i) {
+                        dir[i] = (double)lefttop[i] + id_x * (double)vdx[i] + id_y * (double)vdy[i] - (double)rays_o[i];
+                        nrm += dir[i] * dir[i];
+                    }
+                    nrm = sqrt(nrm);
+                    for (int i = 0; i < 3; ++i) dir[i] = dir[i] / (nrm + 1e-7);
+                    calc_sh_f64(nb, dir, SH);
+                }
+                const float *g3 = grad_output + ((size_t)id_x + (size_t)id_y * w) * 3;
+                const double gO[3] = {g3[0], g3[1], g3[2]};
+                /* pass 1: how many Gaussians this pixel composites (fp32 decision) and its final colour in double */
+                uint32_t n_live = 0;
+                double Cf[3] = {0, 0, 0}, T = 1.0;
+                float accum = 1.0f;
+                for (uint32_t i = 0; i < len; ++i) {
+                    const uint32_t g = start + i;
+                    if (accum < 0.0001) break;
+                    const float af = cov[g * 4], bf = cov[g * 4 + 1], cf = cov[g * 4 + 2], df = cov[g * 4 + 3];
+                    { /* fp32 alpha exactly as K7 / K8's fast path (gso_draw above) */
+                        const float x = pxf - pos[g * 3], y = pyf - pos[g * 3 + 1];
+                        const float det = af * df - bf * cf;
+                        const double q = -(df * x * x - (bf + cf) * x * y + af * y * y) / (2 * det + 1e-14);
+                        const float alpha = expf((float)q) * opa[g];
+                        accum *= (1 - alpha);
+                    }
+                    const double a = af, b = bf, c = cf, d = df;
+                    const double x = px - (double)pos[g * 3], y = py - (double)pos[g * 3 + 1];
+                    const double det = a * d - b * c;
+                    const double alpha = exp(-(d * x * x - (b + c) * x * y + a * y * y) / (2 * det + 1e-14)) *
+                                         (double)opa[g];
+                    for (int ch = 0; ch < 3; ++ch) {
+                        double v;
+                        if (use_sh) {
+                            v = 0.0;
+                            for (int s = 0; s < nb; ++s) v += SH[s] * (double)rgb[(size_t)g * D + ch * nb + s];
+                            v = 1.0 / (1.0 + exp(-v));
+                        } else {
+                            v = (double)rgb[(size_t)g * 3 + ch];
+                        }
+                        cpc[3 * (size_t)i + ch] = v;
+                        Cf[ch] += v * alpha * T;
+                    }
+                    T *= (1.0 - alpha);
+                    n_live = i + 1;
+                }
+                /* pass 2: the terms */
+                double Crun[3] = {0, 0, 0};
+                T = 1.0;
+                for (uint32_t i = 0; i < n_live; ++i) {
+                    const uint32_t g = start + i;
+                    const double a = cov[g * 4], b = cov[g * 4 + 1], c = cov[g * 4 + 2], d = cov[g * 4 + 3];
+                    const double x = px - (double)pos[g * 3], y = py - (double)pos[g * 3 + 1];
+                    const double det = a * d - b * c;
+                    const double Pm = -(d * x * x - (b + c) * x * y + a * y * y), Pn = 2 * det + 1e-14;
+                    const double p1 = exp(Pm / Pn);
+                    const double o = (double)opa[g], alpha = p1 * o, weight = alpha * T;
+                    const double *cc = cpc + 3 * (size_t)i;
+                    double d_alpha = 0, dacc = 0;
+                    for (int m = 0; m < 3; ++m) {
+                        Crun[m] += cc[m] * weight;
+                        d_alpha += gO[m] * cc[m];
+                    }
+                    d_alpha *= T;
+                    for (int m = 0; m < 3; ++m) dacc += gO[m] * (Cf[m] - Crun[m]);
+                    d_alpha -= dacc / (1 - alpha + 1e-7);
+                    if (use_sh) {
+                        for (int ch = 0; ch < 3; ++ch) {
+                            const double Dk = gO[ch] * weight * (cc[ch] * (1 - cc[ch]));
+                            for (int s = 0; s < nb; ++s) gr[(size_t)g * D + ch * nb + s] += Dk * SH[s];
+                        }
+                    } else {
+                        for (int m = 0; m < 3; ++m) gr[(size_t)g * 3 + m] += gO[m] * weight;
+                    }
+                    go_[g] += d_alpha * p1;
+                    const double d_prob = d_alpha * o;
+                    gp[(size_t)g * 3 + 0] += d_prob * p1 / Pn * (2 * d * x - b * y - c * y);
+                    gp[(size_t)g * 3 + 1] += d_prob * p1 / Pn * (2 * a * y - b * x - c * x);
+                    const double k = d_prob * p1 / (Pn * Pn);
+                    gc[(size_t)g * 4 + 0] += k * (-(y * y) * Pn - 2 * d * Pm);
+                    gc[(size_t)g * 4 + 1] += k * ((x * y) * Pn + 2 * c * Pm);
+                    gc[(size_t)g * 4 + 2] += k * ((x * y) * Pn + 2 * b * Pm);
+                    gc[(size_t)g * 4 + 3] += k * (-(x * x) * Pn - 2 * a * Pm);
+                    T *= (1.0 - alpha);
+                }
+            }
+        free(cpc);
+    }
+}
+
+/* ---------------------------------------------------------------------------------------
  * Whole forward frame on raw parameters (splatter.py:513-655 with the train.py defaults:
  * cudaculling=1, scale_activation="abs", tile_culling_method="prob2", fast_drawing=1),
  * canonical order, no MAXP cap.  Used as bench.py's cpu_baseline ("port") and by smoke().

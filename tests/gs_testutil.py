@@ -111,7 +111,7 @@ class OracleFrame:
                                    rays_o=rays.rays_o, lefttop=rays.lefttop, vdx=rays.dx, vdy=rays.dy,
                                    with_scale=with_scale, scale_w=scale_w)
         (gp, gr, go, gc), cs = out if with_scale else (out, None)
-        self.pair_grads = (gp, gr, go, gc)
+        self.pair_grads, self.pair_scales = (gp, gr, go, gc), cs  # the (tile, Gaussian) rows, for the reference-API tests
         # index backward (index_put accumulate) in double
         d_pos_i, d_cov, d_opa, d_col = (_sum_by_id(self.ids, a, n) for a in (gp, gc, go, gr))
         grads = self._chain(d_pos_i, d_cov, d_opa, d_col)
@@ -119,6 +119,52 @@ class OracleFrame:
             return grads
         s_pos_i, s_cov, s_opa, s_col = (_sum_by_id(self.ids, a, n) for a in (cs[0], cs[3], cs[2], cs[1]))
         return grads, self._chain_scale(s_pos_i, s_cov, s_opa, s_col)
+
+    def backward_f64(self, grad_image):
+        """The same chain as ``backward`` evaluated in DOUBLE on the fp32 inputs: K8 by oracle.draw_backward_f64
+        (its own final colour, exp, sums -- only the stop decisions are the fp32 chain's), the index backward as a
+        double sum, the projection backward as torch.autograd (float64) on oracle/torch_ref.project -- A.4 with the
+        Jacobian detached, i.e. gaussian.cu:1371-1576 derived independently --, the activations in double.
+        The yardstick of tests/test_grad_calibration.py.  -> ((gp, gr, go, gc) rows, {name: parameter gradient})."""
+        import torch
+
+        from oracle import torch_ref
+
+        sc, cam, grid, rays = self.scene, self.cam, self.grid, self.rays
+        n = sc.n
+        top, left = grid.crop_offsets()
+        gpad = np.zeros_like(self.padded)
+        inside = ((self.padded >= 0) & (self.padded <= 1)).astype(np.float32)
+        gpad[top:top + grid.height, left:left + grid.width] = grad_image
+        gpad *= inside
+        rows = oracle.draw_backward_f64(self.s_pos, self.s_rgb, self.s_opa, self.s_cov, self.accum, gpad,
+                                        grid.focal_x, grid.focal_y, use_sh=sc.use_sh, rays_o=rays.rays_o,
+                                        lefttop=rays.lefttop, vdx=rays.dx, vdy=rays.dy)
+        gp, gr, go, gc = rows
+        d_pos_i, d_cov, d_opa, d_col = (_sum_by_id(self.ids, a, n) for a in (gp, gc, go, gr))
+        vis = np.nonzero(self.mask)[0]
+        f64 = lambda a: torch.from_numpy(np.asarray(a, np.float64))  # noqa: E731
+        q = sc.quat.astype(np.float64)
+        nr = np.linalg.norm(q, axis=1, keepdims=True)
+        qh = q / nr
+        # (the projection sees the fp32 activated values, like every fp32 evaluation: each stage's backward is taken
+        # at the forward's stored fp32 intermediates)
+        tp, tq, ts = (f64(a[vis]).requires_grad_(True) for a in (sc.pos, self.qn, self.sn))
+        pos_i, cov = torch_ref.project(tp, tq, ts, f64(cam.rot), f64(cam.tran), detach_jacobian=True)
+        obj = (pos_i * f64(d_pos_i[vis])).sum() + (cov.reshape(-1, 4) * f64(d_cov[vis])).sum()
+        gpv, gqv, gsv = torch.autograd.grad(obj, (tp, tq, ts))
+        g_pos, g_qn, g_sn = (np.zeros((n, k)) for k in (3, 4, 3))
+        g_pos[vis], g_qn[vis], g_sn[vis] = gpv.numpy(), gqv.numpy(), gsv.numpy()
+        g_q = (g_qn - qh * np.sum(qh * g_qn, axis=1, keepdims=True)) / nr
+        g_s = g_sn * np.sign(sc.scale) if self.scale_activation == "abs" else g_sn * np.exp(np.clip(sc.scale, -1, 1))
+        o = 1.0 / (1.0 + np.exp(-sc.opa.astype(np.float64)))
+        g_o = d_opa * o * (1 - o)
+        if sc.use_sh:
+            g_c = d_col
+        else:
+            c = 1.0 / (1.0 + np.exp(-sc.rgb.astype(np.float64)))
+            g_c = d_col * c * (1 - c)
+        return rows, {"pos": g_pos, "quat": g_q, "scale": g_s, "opa": g_o, "rgb": g_c}
 
     def _chain(self, d_pos_i, d_cov, d_opa, d_col):
         sc, cam = self.scene, self.cam
@@ -193,20 +239,57 @@ def _sum_by_id(ids, rows, n):
 GRAD_RTOL = 1e-4
 GRAD_KAPPA = 3e-5
 GRAD_L2 = 2e-5  # ||got - ref||_2 / ||ref||_2 per tensor
-# Independent of the oracle-supplied scale: the PURE relative error |got - ref| / |ref|
-# over the elements above 1e-6 of the tensor's largest entry -- its 99.9th percentile, and its maximum (single elements
-# that are small differences of large terms).  Per tensor, at most 2 x the worst value measured over the six full-size
-# cases on the round's final tree (round 5, profiles/r05_h_full_size_gradient_parity.txt; VERDICT round 4, weak item 2:
-# one pair of constants for all tensors was 1.7 ... 700 x looser than measured):
-#            measured p99.9 / max        bound
-#   pos      5.4e-3 / 5.4e-2   (dL/dx = ln2 (2 A' Sx - B' Sy): a difference of two sums of like magnitude)
-#   quat     3.1e-3 / 2.9e-2
-#   scale    2.7e-3 / 1.1e-2
-#   opa      6.0e-3 / 7.6e-2   (T gc against rho / (1 - alpha) for a Gaussian deep in a tile's list)
-#   rgb      1.4e-5 / 1.2e-2   (colour logits / SH coefficients: sums of like-signed terms)
-# The kernels are bitwise repeatable, so the measured values are properties of the build, not of a run.
-GRAD_REL_P999 = {"pos": 1.0e-2, "quat": 6.0e-3, "scale": 5.0e-3, "opa": 1.2e-2, "rgb": 2.8e-5}
-GRAD_REL_MAX = {"pos": 0.10, "quat": 0.055, "scale": 0.022, "opa": 0.15, "rgb": 0.024}
+# Independent of the oracle-supplied scale, and CALIBRATED rather than fitted: the PURE
+# relative error |got - truth| / |truth| against a DOUBLE-precision evaluation of the same formulas
+# (OracleFrame.backward_f64), over the elements above 1e-6 of the tensor's largest entry, compared quantile by quantile
+# with the error the REFERENCE's own fp32 arithmetic has against that same truth:
+#   * at the size where the reference's kernels are well defined, their outputs are committed
+#     (tests/golden/calib_*.npz) and the HIP kernels' error quantiles are bounded by CALIB_K x theirs
+#     (tests/test_grad_calibration.py) -- where the same file shows that the ORACLE's error distribution is the
+#     reference kernels' (same fp32 terms; quantiles within a factor 2, measured within 20 %);
+#   * at full size (tests/test_gpu_frame.py) the reference kernel is not defined (its chunk defect), and the oracle
+#     -- fp32 terms in the reference's expression order, accumulated in double: never WORSE than the reference's
+#     fp32 shuffles / atomics -- stands in for it: assert_error_no_worse_than.
+# What the reference's own arithmetic achieves (calib fixtures, lists <= 166): median ~1e-6, 99.9th percentile 1e-4 ...
+# 5e-4, maximum up to 1.8e-2 -- percent-level single elements are a property of fp32 on these sums, not of a kernel.
+CALIB_QS = (0.5, 0.9, 0.99, 0.999, 1.0)
+CALIB_K = 4.0  # error quantile of a HIP kernel <= CALIB_K x the same quantile of the reference arithmetic's error
+CALIB_K_ELEM = 4.0  # per element: e_hip <= CALIB_K_ELEM x max(e_ref, 1 fp32 ulp of the summed magnitudes) at p99.9; 2 x that at the maximum
+
+
+def rel_error_quantiles(got, truth, qs=CALIB_QS, floor=1e-6):
+    """Quantiles of |got - truth| / |truth| over the elements with |truth| > floor x max |truth|."""
+    got, truth = np.asarray(got, np.float64), np.asarray(truth, np.float64)
+    a = np.abs(truth)
+    big = a > floor * (a.max() if a.size else 0.0)
+    if not big.any():
+        return [0.0] * len(qs)
+    r = np.abs(got - truth)[big] / a[big]
+    return [float(np.quantile(r, q)) for q in qs]
+
+
+def elementwise_error_ratio(got, ref, truth, scale):
+    """e_got / max(e_ref, ulp floor) per element -> (99.9th percentile, maximum).  The floor is one fp32 ulp (2^-23)
+    of the element's term-magnitude sum (the oracle's conditioning scale with scale_w = 0): where the reference
+    evaluation happened to round luckily, the comparison is against what fp32 can resolve at all."""
+    got, ref, truth, scale = (np.asarray(a, np.float64) for a in (got, ref, truth, scale))
+    e_got, e_ref = np.abs(got - truth), np.abs(ref - truth)
+    ratio = e_got / np.maximum(np.maximum(e_ref, 2.0 ** -23 * scale), 1e-300)
+    return float(np.quantile(ratio, 0.999)), float(ratio.max())
+
+
+def assert_error_no_worse_than(grads, truth, ref, what="", k=CALIB_K):
+    """Five parameter gradients `grads` and the reference arithmetic's `ref` (the oracle's, fp32 terms) against the
+    double-precision `truth`: every quantile of CALIB_QS of the HIP error is within k x the reference arithmetic's.
+    -> {name: (hip quantiles, reference quantiles)}"""
+    report = {}
+    for g, name in zip(grads, ("pos", "quat", "scale", "opa", "rgb")):
+        qh = rel_error_quantiles(np.asarray(g), truth[name])
+        qr = rel_error_quantiles(ref[name], truth[name])
+        report[name] = (qh, qr)
+        for a, b, q in zip(qh, qr, CALIB_QS):
+            assert a <= k * b, (what, name, "quantile", q, "hip error", a, "reference arithmetic's error", b)
+    return report
 
 
 # Entries 14 orders of magnitude below the tensor's largest are compared up to this floor: they are sums of products
@@ -232,7 +315,7 @@ def grad_close(got, ref, scale, rtol=GRAD_RTOL, kappa=GRAD_KAPPA):
         np.unravel_index(worst, ratio.shape) if ratio.size else (), pure
 
 
-def assert_grads_close(grads, ref, scale, what="", rtol=GRAD_RTOL, kappa=GRAD_KAPPA, l2=GRAD_L2, rel_bounds=False):
+def assert_grads_close(grads, ref, scale, what="", rtol=GRAD_RTOL, kappa=GRAD_KAPPA, l2=GRAD_L2):
     """grads: five arrays (pos, quat, scale, opa, rgb) -> element-wise check of each against the oracle + a relative
     L2 bound per tensor + bounds on the pure relative error.  Returns {name: (worst err / tol, fraction of elements inside
     rtol |ref| alone, rel. L2, worst pure relative error over the elements above 1e-6 of the tensor's maximum, its 99.9th
@@ -242,11 +325,8 @@ def assert_grads_close(grads, ref, scale, what="", rtol=GRAD_RTOL, kappa=GRAD_KA
         g = np.asarray(g)
         ok, worst, where, pure = grad_close(g, ref[name], scale[name], rtol, kappa)
         rl2 = float(np.linalg.norm(g.astype(np.float64) - ref[name]) / (np.linalg.norm(ref[name].astype(np.float64)) + 1e-300))
-        # worst PURE relative error |got - ref| / |ref| over the elements above 1e-6 of the tensor's largest: a figure
-        # that does not involve the oracle-supplied conditioning scale at all (asserted since round 4, per tensor since
-        # round 5: GRAD_REL_MAX and, for the bulk, GRAD_REL_P999 -- an element that is the small difference of large terms
-        # is legitimately off by many of its own ulp, which is why the maximum gets percents where the 99.9th percentile
-        # gets tenths of a percent)
+        # worst PURE relative error |got - ref| / |ref| over the elements above 1e-6 of the tensor's largest (reported;
+        # the asserted oracle-independent statement is assert_error_no_worse_than, against a double-precision truth)
         r64 = np.abs(np.asarray(ref[name], np.float64))
         big = r64 > 1e-6 * (r64.max() if r64.size else 0.0)
         rels = np.abs(g.astype(np.float64) - ref[name])[big] / r64[big] if big.any() else np.zeros(1)
@@ -256,10 +336,37 @@ def assert_grads_close(grads, ref, scale, what="", rtol=GRAD_RTOL, kappa=GRAD_KA
         assert ok, (what, name, "worst err/tol", worst, "at", where, "got", float(g[where]), "ref",
                     float(ref[name][where]), "scale", float(scale[name][where]))
         assert rl2 <= l2, (what, name, "relative L2 error", rl2)
-    if rel_bounds:  # the full-size tests (>= 376 k Gaussians: the percentile means something there)
-        bad = {k: v[3:] for k, v in report.items() if v[4] > GRAD_REL_P999[k] or v[3] > GRAD_REL_MAX[k]}
-        assert not bad, (what, "pure relative error (worst above 1e-6 of the maximum, 99.9th percentile)", bad, report)
     return report
+
+
+ROW_NAMES = ("pos", "rgb", "opa", "cov")
+
+
+def assert_rows_close(got, ref, scale, what="", rtol=GRAD_RTOL, kappa=GRAD_KAPPA, l2=GRAD_L2):
+    """The four (tile, Gaussian)-row gradients of draw_backward (pos, rgb, opa, cov -- renderer.py:46-58) against the
+    oracle's, ELEMENT BY ELEMENT in units of each element's conditioning scale (oracle.draw_backward(with_scale=True)),
+    plus a relative L2 bound per tensor: the standard of the frame path's parameter gradients (assert_grads_close)
+    applied at the reference API's own boundary.  -> {name: (worst err / tol, fraction within rtol |ref| alone, rel. L2)}"""
+    report = {}
+    for g, r, sc, name in zip(got, ref, scale, ROW_NAMES):
+        g = np.asarray(g).reshape(np.asarray(r).shape)
+        ok, worst, where, pure = grad_close(g, r, sc, rtol, kappa)
+        rl2 = float(np.linalg.norm(g.astype(np.float64) - r) / (np.linalg.norm(np.asarray(r, np.float64)) + 1e-300))
+        report[name] = (round(worst, 3), round(pure, 5), rl2)
+        assert ok, (what, name, "worst err/tol", worst, "at", where, "got", float(g[where]), "ref", float(r[where]),
+                    "scale", float(sc[where]))
+        assert rl2 <= l2, (what, name, "relative L2 error", rl2)
+    return report
+
+
+def robust_padded_grad(of, gpad, band=2e-5):
+    """dL/d(padded image) zeroed on the pixels whose early-stop decision is not robust in fp32 (OracleFrame.robust_grad_image
+    for the padded image the reference API's draw works on).  -> (gpad, #pixels zeroed)"""
+    grid = of.grid
+    amb = oracle.draw_ambiguous(of.s_pos, of.s_opa, of.s_cov, of.accum, grid.padded_height, grid.padded_width,
+                                grid.focal_x, grid.focal_y, band)
+    keep = ~amb[:, :, None].astype(bool)
+    return np.ascontiguousarray(gpad * keep, np.float32), int(amb.sum())
 
 
 def rel_err(a, b):

@@ -14,7 +14,7 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
 
-from gs_testutil import OracleFrame, rel_err, to_torch
+from gs_testutil import OracleFrame, assert_grads_close, to_torch
 
 pytestmark = pytest.mark.gpu
 
@@ -46,8 +46,11 @@ def test_reference_call_sequence_matches_frame_path_and_oracle(gpu):
     fused = FrameRenderer(gpu, max_pairs=1 << 16).forward(*[p.detach() for p in params], cam)[0]
     assert float((fused - img.detach()).abs().max()) < 2e-4
     gimg = np.random.default_rng(2).normal(size=of.image.shape).astype(np.float32)
+    gimg, _ = of.robust_grad_image(gimg)
     img.backward(torch.from_numpy(gimg).to(gpu))
-    ref = of.backward(gimg)
+    ref, scale = of.backward(gimg, with_scale=True)
     for t, name in zip(params, ("pos", "quat", "scale", "opa", "rgb")):
         assert t.grad is not None and bool(torch.isfinite(t.grad).all()), name
-        assert rel_err(t.grad.cpu().numpy(), ref[name]) < 2e-3, (name, rel_err(t.grad.cpu().numpy(), ref[name]))
+    # element by element, the frame path's standard (the reference's torch.sort on the fp32 composite key may order
+    # equal-depth neighbours differently from the canonical order: the sums are the same terms in another order)
+    print(assert_grads_close([t.grad.cpu().numpy() for t in params], ref, scale, "zero-change sequence"))

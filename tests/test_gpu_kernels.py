@@ -3,7 +3,9 @@
 
 Tolerances: integer / index results bit-exact; cull+project forward bit-exact (both sides are
 IEEE fp32 in source order, no contraction); rasterizer images abs 5e-5 (v_exp_f32 vs expf and
-the hoisted conic division), gradients 2e-4 relative to the tensor's max magnitude.
+the hoisted conic division); the rasterizer's gradients ELEMENT BY ELEMENT in units of each element's conditioning
+scale plus a relative L2 bound per tensor (gs_testutil.assert_rows_close / assert_grads_close: the frame path's
+standard, at the reference API's own boundary -- no tensor-max criterion on any function of SURVEY.md section 8a).
 """
 import numpy as np
 import pytest
@@ -11,12 +13,12 @@ import torch
 
 import oracle
 from gs_scene import make_camera, make_scene
-from gs_testutil import OracleFrame, activate, frame_scalars, rel_err
+from gs_testutil import (OracleFrame, activate, assert_grads_close, assert_rows_close, frame_scalars, grad_close,
+                         robust_padded_grad, to_torch)
 
 pytestmark = pytest.mark.gpu
 
 IMG_ATOL = 5e-5
-GRAD_RTOL = 2e-4
 
 
 def dev(a, device, dtype=None):
@@ -67,10 +69,15 @@ def test_global_culling_backward(gpu):
     outs = [torch.zeros(scene.n, k, device=gpu) for k in (3, 4, 3)]
     gaussian.global_culling_backward(dev(scene.pos, gpu), dev(qn, gpu), dev(sn, gpu), dev(cam.rot, gpu),
                                      dev(cam.tran, gpu), dev(gop, gpu), dev(goc, gpu), dev(mk, gpu), *outs)
-    for o, r, name in zip(outs, ref, ("pos", "quat", "scale")):
+    # element by element: |got - ref| <= 1e-5 |ref| + 2e-6 x the element's magnitude sum (the backward with every
+    # product taken between magnitudes, oracle.global_culling_backward_scale) -- ~16 fp32 ulp of what is summed
+    S = oracle.global_culling_backward_scale(scene.pos, qn, sn, cam.rot, cam.tran, np.abs(gop),
+                                             np.abs(goc).reshape(-1, 4), mk)
+    for o, r, sc, name in zip(outs, ref, S, ("pos", "quat", "scale")):
         o = o.cpu().numpy()
         assert np.all(o[mk == 0] == 0), name
-        assert np.allclose(o, r, rtol=1e-5, atol=1e-6 * np.abs(r).max()), (name, rel_err(o, r))
+        ok, worst, where, _ = grad_close(o, r, sc, rtol=1e-5, kappa=2e-6)
+        assert ok, (name, "worst err/tol", worst, "at", where, float(o[where]), float(r[where]), float(sc[where]))
 
 
 def test_world2camera_and_jacobian(gpu):
@@ -203,15 +210,61 @@ def test_draw_forward_backward(gpu, use_sh):
     err = np.abs(img.detach().cpu().numpy() - of.padded)
     assert err.max() < IMG_ATOL, err.max()
     rng = np.random.default_rng(9)
-    gpad = rng.normal(size=of.padded.shape).astype(np.float32)
+    gpad, _ = robust_padded_grad(of, rng.normal(size=of.padded.shape).astype(np.float32))
     img.backward(dev(gpad, gpu))
-    ref = oracle.draw_backward(of.s_pos, of.s_rgb, of.s_opa, of.s_cov, of.accum, of.padded, gpad, grid.focal_x,
-                               grid.focal_y, use_sh=use_sh, fast=True, rays_o=rays.rays_o, lefttop=rays.lefttop,
-                               vdx=rays.dx, vdy=rays.dy)
+    ref, scale = oracle.draw_backward(of.s_pos, of.s_rgb, of.s_opa, of.s_cov, of.accum, of.padded, gpad, grid.focal_x,
+                                      grid.focal_y, use_sh=use_sh, fast=True, rays_o=rays.rays_o,
+                                      lefttop=rays.lefttop, vdx=rays.dx, vdy=rays.dy, with_scale=True)
     got = [x.grad.cpu().numpy() for x in t]
     assert np.all(got[0][:, 2] == 0)  # grad_pos z is never written
-    for g, r, name in zip(got, ref, ("pos", "rgb", "opa", "cov")):
-        assert rel_err(g.reshape(r.shape), r) < GRAD_RTOL, (name, rel_err(g.reshape(r.shape), r))
+    print("draw_backward rows", "sh" if use_sh else "rgb", assert_rows_close(got, ref, scale, f"use_sh={use_sh}"))
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg4"])
+def test_reference_api_full_size(gpu, cfg):
+    """The reference's OWN call sequence at BASELINE.json full size -- 376,467 Gaussians rgb (configs[1]) and 2.4 M
+    Gaussians SH degree 2 (configs[3]), 1080p: renderer.global_culling (renderer.py:116-158) -> the mask / sorted-id
+    gathers of splatter.py:536-541, 604-613 (the oracle's canonical order for the ids) -> renderer.draw
+    (renderer.py:8-87) -> backward through both autograd Functions.  Projection bit-exact; image 5e-5; the FOUR
+    (tile, Gaussian)-row gradient tensors of draw_backward element by element; and the five raw-parameter gradients
+    that come out of global_culling_backward + the torch activations, element by element too."""
+    from gs_scene import CONFIGS
+    from renderer import draw, global_culling
+
+    n, W, H, use_sh = CONFIGS[cfg]
+    scene, cam = make_scene(n, W, H, seed=2023, use_sh=use_sh), make_camera(W, H)
+    of = OracleFrame(scene, cam)
+    grid, rays = of.grid, of.rays
+    hw, hh = grid.frustum_half_extents()
+    params = to_torch(scene, gpu, requires_grad=True)
+    pos, quat, scale_raw, opa_raw, rgb_raw = params
+    qn = quat / torch.norm(quat, dim=1, keepdim=True)  # splatter.py:519-524 (train.py defaults)
+    sn = torch.abs(scale_raw) + 1e-4
+    pos_i, cov, mask = global_culling(pos, qn, sn, dev(cam.rot, gpu), dev(cam.tran, gpu), cam.near, hw, hh)
+    assert np.array_equal(mask.cpu().numpy(), of.mask)
+    assert np.array_equal(pos_i.detach().cpu().numpy().view(np.uint32), of.pos_i.view(np.uint32))
+    assert np.array_equal(cov.detach().cpu().numpy().view(np.uint32), of.cov.view(np.uint32))
+    ids = dev(of.ids, gpu, torch.long)
+    opa = torch.sigmoid(opa_raw)
+    col = rgb_raw if use_sh else torch.sigmoid(rgb_raw)
+    s = [pos_i[ids], col[ids], opa[ids], cov[ids]]
+    for t in s:
+        t.retain_grad()
+    img = draw(*s, dev(of.accum, gpu), grid.padded_height, grid.padded_width, grid.focal_x, grid.focal_y, False, False,
+               use_sh, True, dev(rays.rays_o, gpu), dev(rays.lefttop, gpu), dev(rays.dx, gpu), dev(rays.dy, gpu))
+    assert np.abs(img.detach().cpu().numpy() - of.padded).max() < IMG_ATOL
+    gimg = (np.sign(of.image - 0.5) / of.image.size).astype(np.float32)
+    gimg, n_masked = of.robust_grad_image(gimg)
+    assert n_masked < 0.002 * W * H
+    ref, scale = of.backward(gimg, with_scale=True)  # (also leaves the oracle's row gradients in of.pair_grads)
+    top, left = grid.crop_offsets()
+    gpad = np.zeros_like(of.padded)
+    gpad[top:top + H, left:left + W] = gimg
+    gpad *= ((of.padded >= 0) & (of.padded <= 1))
+    img.backward(dev(gpad, gpu))
+    print(cfg, "reference API rows:",
+          assert_rows_close([t.grad.cpu().numpy() for t in s], of.pair_grads, of.pair_scales, cfg))
+    print(cfg, "reference API parameters:", assert_grads_close([t.grad.cpu().numpy() for t in params], ref, scale, cfg))
 
 
 @pytest.mark.parametrize("use_sh", [False, True])
@@ -230,7 +283,7 @@ def test_draw_exact_exp_flavour(gpu, use_sh):
                           grid.focal_x, grid.focal_y, fast=f, **kw) for f in (False, True)}
     rb = [dev(a, gpu) for a in (rays.rays_o, rays.lefttop, rays.dx, rays.dy)]
     imgs, grads = {}, {}
-    gpad = np.random.default_rng(9).normal(size=ref[False].shape).astype(np.float32)
+    gpad, _ = robust_padded_grad(of, np.random.default_rng(9).normal(size=ref[False].shape).astype(np.float32))
     for fast in (False, True):
         t = [dev(a, gpu).requires_grad_(True) for a in (of.s_pos, of.s_rgb, of.s_opa, of.s_cov.reshape(-1, 2, 2))]
         img = draw(*t, dev(of.accum, gpu), grid.padded_height, grid.padded_width, grid.focal_x, grid.focal_y, False,
@@ -241,10 +294,9 @@ def test_draw_exact_exp_flavour(gpu, use_sh):
     assert np.abs(imgs[False] - ref[False]).max() < 2e-6, np.abs(imgs[False] - ref[False]).max()
     assert np.abs(imgs[True] - ref[True]).max() < IMG_ATOL
     assert np.abs(imgs[False] - imgs[True]).max() > 0
-    gref = oracle.draw_backward(of.s_pos, of.s_rgb, of.s_opa, of.s_cov, of.accum, ref[False], gpad, grid.focal_x,
-                                grid.focal_y, fast=False, **kw)
-    for g, r, name in zip(grads[False], gref, ("pos", "rgb", "opa", "cov")):
-        assert rel_err(g.reshape(r.shape), r) < GRAD_RTOL, (name, rel_err(g.reshape(r.shape), r))
+    gref, gscale = oracle.draw_backward(of.s_pos, of.s_rgb, of.s_opa, of.s_cov, of.accum, ref[False], gpad,
+                                        grid.focal_x, grid.focal_y, fast=False, with_scale=True, **kw)
+    assert_rows_close(grads[False], gref, gscale, f"fast=False use_sh={use_sh}")
 
 
 def test_draw_flags_weight_normalize_and_sigmoid(gpu):
@@ -293,12 +345,12 @@ def test_draw_backward_sigmoid_flag(gpu, use_sh, saturated):
     gpad = np.random.default_rng(10).normal(size=want.shape).astype(np.float32)
     img.backward(dev(gpad, gpu))
     # the backward replays the forward from ITS image argument: hand the oracle the same image the GPU produced
-    ref = oracle.draw_backward(of.s_pos, of.s_rgb, opa, of.s_cov, of.accum, img.detach().cpu().numpy(), gpad,
-                               grid.focal_x, grid.focal_y, **kw)
+    ref, scale = oracle.draw_backward(of.s_pos, of.s_rgb, opa, of.s_cov, of.accum, img.detach().cpu().numpy(), gpad,
+                                      grid.focal_x, grid.focal_y, with_scale=True, **kw)
     got = [x.grad.cpu().numpy() for x in t]
-    for g, r, name in zip(got, ref, ("pos", "rgb", "opa", "cov")):
+    for g, name in zip(got, ("pos", "rgb", "opa", "cov")):
         assert np.isfinite(g).all(), name
-        assert rel_err(g.reshape(r.shape), r) < (2e-3 if saturated else GRAD_RTOL), (name, rel_err(g.reshape(r.shape), r))
+    print("sigmoid flag", use_sh, saturated, assert_rows_close(got, ref, scale, f"sigmoid use_sh={use_sh} saturated={saturated}"))
 
 
 def test_draw_empty_and_errors(gpu):
