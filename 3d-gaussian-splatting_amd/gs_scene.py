@@ -87,6 +87,34 @@ def make_scene(n: int, width: int, height: int, seed: int = 2023, use_sh: bool =
                  rgb.astype(np.float32))
 
 
+def make_trained_like_scene(n: int = 724_312, width: int = 1920, height: int = 1080, seed: int = 7, use_sh: bool = False,
+                            sh_degree: int = 2, max_px_sigma: float = 26.0, clustered: float = 0.32, n_clusters: int = 30,
+                            opa_shift: float = -3.5) -> Scene:
+    """A deterministic scene in the STATE a trained / densified model is in (missing item 2): translucent
+    (opacity logits shifted by ``opa_shift``: no tile saturates, every pair of every list is composited), larger
+    footprints (pixel sigma up to ``max_px_sigma``: ~6.5 tiles per visible Gaussian) and a heavy tail of tile-list
+    lengths (a share ``clustered`` of the Gaussians sits in ``n_clusters`` screen-space clusters of 1 - 3 tiles' sigma).
+    The defaults reproduce the end state of the densifying SH run of tools/soak.py (profiles/r05_m_soak_end_state.jsonl:
+    724,312 Gaussians, 3.96 M pairs, list length mean 485 / median 317 / p99 2,391 / max 4,065, 2,277 tiles beyond 512):
+    this generator gives 619,582 visible, 3,925,915 pairs, mean 481, median 312, p99 2,696, max 5,361, 1,673 tiles beyond
+    512 at 1080p -- without 2,000 training iterations in front of the measurement."""
+    rng = np.random.default_rng(seed + 1_000_003)
+    sc = make_scene(n, width, height, seed=seed, use_sh=use_sh, max_px_sigma=max_px_sigma, sh_degree=sh_degree)
+    fx = 0.75 * width
+    m = int(clustered * n)
+    idx = rng.choice(n, m, replace=False)
+    cx = rng.uniform(-0.9, 0.9, n_clusters) * (width / 2 / fx)
+    cy = rng.uniform(-0.9, 0.9, n_clusters) * (height / 2 / fx)
+    cs = np.exp(rng.uniform(0.0, math.log(3.0), n_clusters)) * 16 / fx  # cluster sigma: 1 .. 3 tiles
+    which = rng.integers(0, n_clusters, m)
+    z = np.abs(sc.pos[idx, 2]) + 0.5
+    sc.pos[idx, 2] = z
+    sc.pos[idx, 0] = ((cx[which] + cs[which] * rng.normal(size=m)) * z).astype(np.float32)
+    sc.pos[idx, 1] = ((cy[which] + cs[which] * rng.normal(size=m)) * z).astype(np.float32)
+    sc.opa = (sc.opa + opa_shift).astype(np.float32)
+    return sc
+
+
 # BASELINE.json configs -> (n_gaussians, width, height, use_sh)
 CONFIGS = {
     "cfg1": (10_000, 256, 256, False),

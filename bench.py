@@ -20,7 +20,9 @@ Rank 0 prints ONE JSON line (driver contract):
                        synchronize on both sides, max over ranks) is repeated R times ("repeats": R >= 15 and >= 0.3 s
                        of GPU work, so that an external sampler can see the run); value / ms_per_step are the MEDIAN
                        block, "ms_per_step_min" / "_max" its spread;
-  roofline             dominant kernel of that workload (raster_forward_kernel), algorithmic bytes of SURVEY.md 8d S5
+  latency_fps          the reference's protocol (train.py:259-266): events around ONE frame, synchronise, repeat;
+  roofline             (`frac_executed`: the same fraction on the list steps the kernel executed)
+                       dominant kernel of that workload (raster_forward_kernel), algorithmic bytes of SURVEY.md 8d S5
                        / its hipEvent-timed duration (events on the launch stream, inside the library); `traffic` = HBM-side
                        bytes per launch from the committed PMC passes (profiles/traffic.json) with `correction` = how
                        FETCH_SIZE was turned into bytes for this kernel's access pattern and `traffic_bounds`;
@@ -40,7 +42,10 @@ Rank 0 prints ONE JSON line (driver contract):
                        the matrix pipe, counted from the pixel-row steps the kernel EXECUTED (a device counter: rows whose
                        pixels had all stopped are left out) / its time against the 157.3 TFLOP/s matrix peak --, `soak`:
                        the densifying training run of tools/soak.py (376 k Gaussians growing, rgb / SH degree 2 / 3), rate
-                       per block of 100 iterations --, three frames in flight;
+                       per block of 100 iterations --, `trained_state`: a deterministic translucent, heavy-tailed scene in the
+                       state a trained model is in (gs_scene.make_trained_like_scene), rgb and SH degree 2: FPS, forward +
+                       backward it/s, stage times, compositing against the roofline by EXECUTED steps, with the long-list
+                       flag auto / off / on --, three frames in flight;
   multi_gpu            (under torchrun, or with --force-collective on one rank) ranks seen, gradient buffer bytes, and per
                        scene (rgb, SH) and exchange mode: training views/s over all ranks, the exchange alone, bus
                        bandwidth, and exposed_ms = the step with its exchange minus the same step without it in the same
@@ -67,7 +72,7 @@ import torch.distributed as dist
 sys.path.insert(0, os.path.join(ROOT, "tools"))  # train_timing.py, compat_fps.py (measurement helpers, not product code)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-ALL_LEGS = ("headline", "cfg1", "cfg2", "train", "fit", "cfg4", "soak", "pipelined", "compat", "multi_gpu", "cpu")
+ALL_LEGS = ("headline", "cfg1", "cfg2", "train", "fit", "cfg4", "trained", "soak", "pipelined", "compat", "multi_gpu", "cpu")
 
 
 def log(*a):
@@ -233,6 +238,25 @@ def main():
                 fn()
             torch.cuda.synchronize()
 
+    def latency_fps(frame, frames=60):
+        """The reference's FPS protocol (train.py:259-266): an event in front of ONE frame, an event behind it, synchronise,
+        repeat -- frames/s = 1 / the median per-frame span.  Every frame starts on an idle device: no launch of frame k + 1
+        overlaps the tail of frame k, and the host's issue time of the first launch is inside the span."""
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        spans = []
+        for _ in range(frames + 5):
+            torch.cuda.synchronize()
+            e0.record()
+            frame()
+            e1.record()
+            e1.synchronize()
+            spans.append(e0.elapsed_time(e1))
+        spans = spans[5:]
+        med = statistics.median(spans)
+        return {"fps": round(1e3 / med, 1), "ms_per_frame": round(med, 4), "ms_min": round(min(spans), 4),
+                "ms_p90": round(sorted(spans)[int(0.9 * len(spans))], 4), "frames": len(spans),
+                "protocol": "hipEvent before / after ONE forward, synchronise, repeat (the span of train.py:259-266); median"}
+
     def render_leg(cfg, steps, warmup):
         """One workload, one frame in flight: FPS over `steps` timed frames + roofline objects (rank 0)."""
         scene, cam, params = load(cfg)
@@ -248,7 +272,8 @@ def main():
         host_us = (time.perf_counter() - t0) / 50 * 1e6  # host cost of issuing one frame, GPU free-running
         torch.cuda.synchronize()
         dt, blocks = time_frames(frame, steps, warmup)
-        res = {"fps": world * steps / dt, "ms": dt / steps * 1e3, "host_us": host_us, "stats": st,
+        lat = latency_fps(frame)
+        res = {"fps": world * steps / dt, "ms": dt / steps * 1e3, "host_us": host_us, "stats": st, "latency": lat,
                "scene": scene, "cam": cam, "params": params, "renderer": r, "repeats": len(blocks),
                "ms_min": min(blocks) / steps * 1e3, "ms_max": max(blocks) / steps * 1e3}
         if rank == 0:
@@ -283,15 +308,23 @@ def main():
                         traffic / (stage_ms["raster"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "correction": correction, "traffic_bounds": bounds,
                     "issue_busy": issue_busy, "kernel_ms": round(stage_ms["raster"], 4), "workload": cfg}
+            # the same fraction on the steps the kernel EXECUTED: `frac` credits every pair
+            # of every list, but a tile stops reading its list once all its pixels have saturated -- composited steps x
+            # the per-step bytes of SURVEY.md 8d S5 + the image written, over the same kernel time
+            rt = FrameRenderer(dev, max_pairs=r.max_pairs, training=True, auto_grow=False)
+            rt.forward(*params, cam)
+            steps_done = rt.composited_steps()
+            del rt
+            exec_bytes = (32 + 4 * C) * steps_done + 12 * P
+            roof["composited_steps"] = steps_done
+            roof["executed_bytes"] = int(exec_bytes)
+            roof["frac_executed"] = round(exec_bytes / (stage_ms["raster"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            roof["ns_per_executed_step"] = round(stage_ms["raster"] * 1e6 / max(steps_done, 1), 4)
             if not use_sh:
                 # the compositing kernel is fp32-VALU bound, not HBM bound: 73 flops per Gaussian
                 # per 4 pixels of a lane (5 shared + 34 per packed pixel pair) => 18.25 flops per (step, pixel), a step
                 # being one Gaussian composited by one tile; tiles stop when all their pixels have (composited steps
                 # <= pairs, counted by a training forward); peak = packed fp32 FMA, 256 CUs x 4 SIMD x 16 lanes, 2.4 GHz
-                rt = FrameRenderer(dev, max_pairs=r.max_pairs, training=True, auto_grow=False)
-                rt.forward(*params, cam)
-                steps_done = rt.composited_steps()
-                del rt
                 tf = 18.25 * 256 * steps_done / (stage_ms["raster"] * 1e-3) / 1e12
                 roof["valu"] = {"achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s fp32 vector",
                                 "frac": round(tf / 157.3, 3), "composited_steps": steps_done}
@@ -325,6 +358,9 @@ def main():
                    "tile_pairs": st.pairs, "width": W, "height": H,
                    "parallelism": f"view-sharded x{world} (no data-path collective)", "frames_in_flight": 1},
         "host_us_per_frame": round(head["host_us"], 1),
+        # the reference quotes FPS as one frame between two events with a synchronisation per frame (train.py:259-266);
+        # `value` is throughput (K frames queued, one synchronisation) -- both, side by side
+        "latency_fps": head["latency"]["fps"], "latency": head["latency"],
     }
     if rank == 0:
         out["roofline"], out["stages"] = head["roofline"], head["stages"]
@@ -389,7 +425,8 @@ def main():
                    "ms_per_frame": round(c1["ms"], 4), "repeats": c1["repeats"],
                    "ms_per_frame_min": round(c1["ms_min"], 4), "ms_per_frame_max": round(c1["ms_max"], 4),
                    "visible": c1["stats"].visible, "tile_pairs": c1["stats"].pairs,
-                   "host_us_per_frame": round(c1["host_us"], 1), "binning_variant": c1["renderer"].binning_variant(),
+                   "host_us_per_frame": round(c1["host_us"], 1), "latency_fps": c1["latency"]["fps"],
+                   "latency": c1["latency"], "binning_variant": c1["renderer"].binning_variant(),
                    "stages": c1["stages"], "roofline": c1["roofline"]}
             if "cpu" in legs:
                 import oracle  # the checker, timed as the "port" baseline -- never on the product path
@@ -422,7 +459,8 @@ def main():
                            "ms_per_frame": round(c2["ms"], 4), "repeats": c2["repeats"],
                            "ms_per_frame_min": round(c2["ms_min"], 4), "ms_per_frame_max": round(c2["ms_max"], 4),
                            "visible": c2["stats"].visible,
-                           "tile_pairs": c2["stats"].pairs, "host_us_per_frame": round(c2["host_us"], 1)}
+                           "tile_pairs": c2["stats"].pairs, "host_us_per_frame": round(c2["host_us"], 1),
+                           "latency_fps": c2["latency"]["fps"], "latency": c2["latency"]}
             if rank == 0:
                 out["cfg2"].update(roofline=c2["roofline"], stages=c2["stages"], frame_roofline=c2["frame_roofline"])
             del c2
@@ -779,6 +817,92 @@ def main():
             extra["cfg4_2p4M_sh_fwd_bwd"] = cfg4
 
         guarded("cfg4", _leg_cfg4)
+
+    # ---------------------------------------------------------------- the state a trained / densified model is in
+    if "trained" in legs and rank == 0 and world == 1:
+        def _leg_trained():
+            # gs_scene.make_trained_like_scene: 724,312 translucent Gaussians with larger footprints and a heavy tail of
+            # tile-list lengths (the end state of the densifying SH run of tools/soak.py, regenerated from a seed): every
+            # pair of every list is composited, the longest lists are ten times the mean.  The reference's published
+            # numbers are on trained models (README.md:34-48); the headline scene is the opaque generator of SURVEY.md 8d.
+            # Per colour model: render FPS (throughput and the reference's synchronised-per-frame protocol), forward +
+            # backward it/s (free running), stage times, and the compositing kernel against the HBM roofline on the steps it
+            # EXECUTED -- with the frame flagged GS_FRAME_LONG_LISTS by the renderer's own rule ("auto"), never, and always.
+            from gs_scene import make_trained_like_scene
+
+            Wt, Ht = 1920, 1080
+            Pt = (-(-Wt // 16) * 16) * (-(-Ht // 16) * 16)
+            ts = {}
+            for tag, sh_t in (("rgb", False), ("sh_degree_2", True)):
+                sc = make_trained_like_scene(width=Wt, height=Ht, use_sh=sh_t)
+                cam_t = make_camera(Wt, Ht)
+                p_t = [torch.from_numpy(a).to(dev) for a in (sc.pos, sc.quat, sc.scale, sc.opa, sc.rgb)]
+                Ct = 27 if sh_t else 3
+                res = {"n_gaussians": sc.n, "width": Wt, "height": Ht, "coefficients": Ct}
+                for mode, ll in (("auto", None), ("flag_off", False), ("flag_on", True)):
+                    r_i = FrameRenderer(dev, max_pairs=1 << 22, training=False, auto_grow=True, long_lists=ll)
+                    r_i.forward(*p_t, cam_t)
+                    st_i = r_i.stats()  # (auto: a longest list beyond LONG_LIST_FLAG_AT flags the following frames)
+                    r_i.max_pairs, r_i.auto_grow = int(st_i.pairs * 1.1) + 4096, False
+                    frame_i = lambda: r_i.forward(*p_t, cam_t)  # noqa: E731
+                    settle(frame_i, 0.3)
+                    dt_i, blocks_i = time_frames(frame_i, 20, 5)
+                    pf = [r_i.profile_forward(*p_t, cam_t) for _ in range(10)][3:]
+                    fwd = {k: round(statistics.median(x[k] for x in pf), 4) for k in pf[0]}
+                    del r_i
+                    # training renderer: checkpoints, forward + backward
+                    r_t = FrameRenderer(dev, max_pairs=int(st_i.pairs * 1.1) + 4096, training=True, auto_grow=False,
+                                        long_lists=ll)
+                    img_t, _ = r_t.forward(*p_t, cam_t)
+                    st_t = r_t.stats()
+                    g_t = (torch.sign(img_t - 0.5) / img_t.numel()).contiguous()
+
+                    def fwd_bwd_t():
+                        r_t.forward(*p_t, cam_t)
+                        r_t.backward(g_t)
+
+                    settle(fwd_bwd_t, 0.3)
+                    wall_dt, wall_blocks = time_frames(fwd_bwd_t, 10, 3, repeats=15)
+                    r_t.forward(*p_t, cam_t)
+                    steps_t = r_t.composited_steps()
+                    tf = [r_t.profile_forward(*p_t, cam_t) for _ in range(8)][2:]
+                    tb = [r_t.profile_backward(g_t) for _ in range(8)][2:]
+                    tfwd = {k: round(statistics.median(x[k] for x in tf), 4) for k in tf[0]}
+                    tbwd = {k: round(statistics.median(x[k] for x in tb), 4) for k in tb[0]}
+                    flagged = bool(r_t._frame.flags & 16)
+                    del r_t, img_t, g_t
+                    torch.cuda.empty_cache()
+                    exec_b = (32 + 4 * Ct) * steps_t + 12 * Pt
+                    res[mode] = {
+                        "flagged_long_lists": flagged, "visible": st_i.visible, "tile_pairs": st_i.pairs,
+                        "longest_list": st_t.longest_list, "composited_steps": steps_t,
+                        "render_fps": round(20 / dt_i, 1), "ms_per_frame": round(dt_i / 20 * 1e3, 4),
+                        "ms_per_frame_min": round(min(blocks_i) / 20 * 1e3, 4),
+                        "ms_per_frame_max": round(max(blocks_i) / 20 * 1e3, 4), "repeats": len(blocks_i),
+                        "forward_stage_ms": fwd,
+                        "fwd_bwd_iters_per_s": round(10 / wall_dt, 1), "fwd_bwd_ms_per_iter": round(wall_dt / 10 * 1e3, 4),
+                        "fwd_bwd_ms_per_iter_min": round(min(wall_blocks) / 10 * 1e3, 4),
+                        "fwd_bwd_ms_per_iter_max": round(max(wall_blocks) / 10 * 1e3, 4),
+                        "training_forward_stage_ms": tfwd, "backward_stage_ms": tbwd,
+                        # compositing on the executed steps: every list is walked to its end here, so this IS the
+                        # algorithmic figure; ns per step next to the headline scene's
+                        "raster_forward": {"bound": "hbm", "kernel_ms": fwd["raster"], "executed_bytes": int(exec_b),
+                                           "achieved": round(exec_b / (fwd["raster"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                           "unit": "GB/s", "frac_executed": round(exec_b / (fwd["raster"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                           "ns_per_executed_step": round(fwd["raster"] * 1e6 / max(steps_t, 1), 4),
+                                           "training_ns_per_executed_step": round(tfwd["raster"] * 1e6 / max(steps_t, 1), 4)}}
+                    if mode == "auto":
+                        r_l = FrameRenderer(dev, max_pairs=int(st_i.pairs * 1.1) + 4096, auto_grow=False, long_lists=ll)
+                        if flagged:
+                            r_l._long_lists_seen = True
+                        res[mode]["latency"] = latency_fps(lambda: r_l.forward(*p_t, cam_t), 30)
+                        del r_l
+                ts[tag] = res
+                del p_t
+                torch.cuda.empty_cache()
+            extra["trained_state"] = ts
+
+        guarded("trained", _leg_trained)
 
     # ---------------------------------------------------------------- training where it is slow: the densifying run
     if "soak" in legs and rank == 0 and world == 1:
