@@ -374,3 +374,89 @@ def test_view_parallel_densification_statistic_gloo(tmp_path, mode):
     red = [np.load(tmp_path / f"stat_red_{r}.npy") for r in range(world)]
     expect = np.maximum(local[0], local[1]) if mode == "max" else local[0] + local[1]
     assert np.array_equal(red[0], expect) and np.array_equal(red[1], expect)
+
+
+def _world8_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gs_dp import ORDER, FlatGaussianParams, ViewParallelGradStat, project_slice_size
+
+    n = 4099  # 17 project slices of 256; regions padded to 4,128 rows (a multiple of 4 x 8)
+    shapes = [(n, 3), (n, 4), (n, 3), (n,), (n, 27)]
+    params = [torch.from_numpy(np.random.default_rng(5).normal(size=s).astype(np.float32)) for s in shapes]  # replicas
+    out, apis = {}, {}
+    for exchange, n_slices in (("all_reduce", 1), ("all_reduce", 4), ("reduce_scatter", 4)):
+        flat = FlatGaussianParams(params, world_size=world, exchange=exchange, n_slices=n_slices)
+        assert flat.rank == rank and flat.n_pad == 4128 and project_slice_size(n) == 256
+        if n_slices == 4:
+            assert flat.n_slices == 4 and all(b % 32 == 0 and b % 256 == 0 for b in flat.slice_bounds[:-1])
+            apis[exchange] = flat.self_check()  # the closed-form pattern over eight ranks before the path is trusted
+        for step in range(2):
+            # integer-valued gradients: every order of adding eight of them is exact, so all paths must agree bit for bit
+            g = np.random.default_rng(1000 * step + rank).integers(-8, 9, flat.flat_grad.numel()).astype(np.float32)
+            flat.flat_grad.copy_(torch.from_numpy(g))
+            for t in ORDER:  # pad rows carry zero gradient
+                flat.flat_grad[flat.offsets[t][1]:flat.region[t] + flat.n_pad * flat.width[t]].zero_()
+            flat.finish_gather()
+            for k in range(flat.n_slices):
+                flat.begin_slice(k)
+            for k in range(flat.n_slices):
+                flat.finish_slice(k)
+                for (lo, hi), (slo, shi) in zip(flat.slice_ranges(k), flat.owned(flat.slice_ranges(k))):
+                    if exchange == "reduce_scatter":  # this rank's eighth of the range
+                        assert (shi - slo) * world == hi - lo and slo == lo + rank * (shi - slo) and slo % 4 == 0
+                    flat.flat_param[slo:shi].sub_(0.125 * flat.flat_grad[slo:shi])
+                flat.begin_slice_gather(k)
+                if k:
+                    flat.finish_slice_gather(k - 1)
+        flat.finish_gather()
+        out[(exchange, n_slices)] = flat.flat_param.numpy().copy()
+    stats = {}
+    for mode in ("max", "mean"):
+        st = ViewParallelGradStat(500, "cpu", mode, world_size=world)
+        rng = np.random.default_rng(7 + rank)
+        st.accum.copy_(torch.from_numpy(rng.integers(0, 64, (500, 3)).astype(np.float32)))
+        st.counter.copy_(torch.from_numpy(rng.integers(0, 5, 500).astype(np.float32)))
+        local = st._buf.numpy().copy()
+        st.reduce()
+        stats[mode] = (local, st._buf.numpy().copy())
+    np.savez(os.path.join(tmp, f"w8_{rank}.npz"), unsliced=out[("all_reduce", 1)], sliced=out[("all_reduce", 4)],
+             sharded=out[("reduce_scatter", 4)], max_local=stats["max"][0], max_red=stats["max"][1],
+             mean_local=stats["mean"][0], mean_red=stats["mean"][1],
+             apis=np.array([apis["all_reduce"], apis["reduce_scatter"]]))
+    dist.destroy_process_group()
+
+
+def test_world8_slice_pipeline_and_statistic_gloo(tmp_path):
+    """The rank count of the target node: EIGHT gloo ranks run the slice
+    pipeline -- Np = a multiple of 4 x 8 rows, four slices of whole project slices, eighth-shards of every range -- in
+    both exchange modes after the grouped-collective self-check, and ViewParallelGradStat.reduce in both modes.  With
+    integer-valued gradients every summation order is exact: sliced == unsliced == sharded bit for bit on every rank, all
+    replicas agree, and the update equals the closed form (parameters - 0.125 x the mean of the ranks' gradients)."""
+    world, port = 8, 41500 + (os.getpid() % 2000)
+    mp.spawn(_world8_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"w8_{k}.npz") for k in range(world)]
+    for k in range(world):
+        assert np.array_equal(r[k]["unsliced"], r[k]["sliced"]) and np.array_equal(r[k]["unsliced"], r[k]["sharded"])
+        assert np.array_equal(r[0]["unsliced"], r[k]["unsliced"])
+        assert list(r[k]["apis"]) == list(r[0]["apis"])  # every rank settled on the same API
+    assert set(r[0]["apis"]) <= {"grouped", "public"}
+    from gs_dp import FlatGaussianParams
+
+    n = 4099
+    shapes = [(n, 3), (n, 4), (n, 3), (n,), (n, 27)]
+    params = [torch.from_numpy(np.random.default_rng(5).normal(size=s).astype(np.float32)) for s in shapes]
+    flat = FlatGaussianParams(params, world_size=world, rank=0)
+    expect = flat.flat_param.numpy().copy()
+    for step in range(2):
+        tot = sum(np.random.default_rng(1000 * step + k).integers(-8, 9, expect.size).astype(np.float32) for k in range(world))
+        expect = (expect - np.float32(0.125) * (tot / np.float32(world))).astype(np.float32)  # the exchange leaves the MEAN
+    live = np.zeros(expect.size, bool)
+    for t, (lo, hi) in flat.offsets.items():
+        live[lo:hi] = True
+    assert np.array_equal(r[0]["unsliced"][live], expect[live])
+    assert np.array_equal(r[0]["unsliced"][~live], flat.flat_param.numpy()[~live])  # pad rows never move
+    want_max = np.maximum.reduce([r[k]["max_local"] for k in range(world)])
+    want_sum = np.add.reduce([r[k]["mean_local"] for k in range(world)])
+    for k in range(world):
+        assert np.array_equal(r[k]["max_red"], want_max) and np.array_equal(r[k]["mean_red"], want_sum)
