@@ -85,6 +85,12 @@ __device__ __forceinline__ float gs_wave_shr1(float old, float src) {
 }
 
 // 2^x on the transcendental unit (v_exp_f32)
+// The `sigmoid` flag's squashing of alpha (reference API only; gaussian.cu:930, :622): 2. / (exp(-alpha) + 1) - 1.  The
+// reference evaluates it in DOUBLE (its literals are doubles), and it has to: in float the result carries an ABSOLUTE error
+// of ~6e-8 whatever alpha is (2 / (2 - a) - 1 cancels), i.e. percents of a small alpha -- the row gradients of faint
+// Gaussians then come out with errors of 30 % of their term sum (round 6: the element-wise parity test of the flag
+// found it; a tensor-max criterion had hidden it).  The flag's kernels are no hot path.
+__device__ __forceinline__ float gs_squash_alpha(float a) { return (float)(2.0 / (exp(-(double)a) + 1.0) - 1.0); }
 __device__ __forceinline__ float gs_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float gs_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float gs_rsq(float x) { return __builtin_amdgcn_rsqf(x); }

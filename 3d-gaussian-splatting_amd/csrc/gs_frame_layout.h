@@ -77,6 +77,12 @@ static inline bool gs_frame_long_lists(const gs_frame *f, int n_tiles) {
     (void)n_tiles;
     return (f->flags & GS_FRAME_LONG_LISTS) != 0;
 }
+// the sort half alone (GS_FRAME_LONG_SORT, round 6): lists beyond the LDS window go to big_list_sort_kernel; the segmented
+// compositing -- which changes the rounding of the transmittance and only pays for lists several times longer -- follows
+// GS_FRAME_LONG_LISTS
+static inline bool gs_frame_long_sort(const gs_frame *f) {
+    return (f->flags & (GS_FRAME_LONG_LISTS | GS_FRAME_LONG_SORT)) != 0;
+}
 static inline int64_t gs_seg_items_cap(int64_t max_pairs, int n_tiles) { return max_pairs / GS_SEG_LEN + n_tiles; }
 static inline int64_t gs_group_queue_cap(int64_t max_pairs, int n_tiles) { return max_pairs / 256 + 4 * (int64_t)n_tiles; }
 #define GS_STRIP_SORT_CAP 2048  // pairs strip_sort_kernel's LDS window holds (a half strip's four lists, or one list at a time)
@@ -121,7 +127,7 @@ static inline bool gs_frame_uses_strips(const gs_frame *f) {
     if (f->flags & GS_FRAME_STRIP_BIN) return true;
     // the kernels for long tile lists (big-list sort, segmented compositing) belong to the strip variant: a frame that
     // asks for them gets it whatever its size (round 4: below GS_STRIP_AUTO_MIN_N the flag used to be ignored silently)
-    if (f->flags & GS_FRAME_LONG_LISTS) return true;
+    if (f->flags & (GS_FRAME_LONG_LISTS | GS_FRAME_LONG_SORT)) return true;
     // small scenes take the table variant where it exists (one LDS counter per tile)
     return f->N >= GS_STRIP_AUTO_MIN_N || ntx * nty > GS_BIN_MAX_TILES;
 }

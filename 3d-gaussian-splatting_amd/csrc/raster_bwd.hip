@@ -396,7 +396,7 @@ __global__ void __launch_bounds__(64 * BwdCfg<CDIM>::WPB) raster_backward_kernel
             const float Gv = EXACT ? (float)exp(-(double)(q * GS_LN2)) : gs_exp2(-q);
             const bool live = T > GS_T_STOP;
             const float araw = live ? Gv * opa : 0.f;  // before squashing
-            const float alpha = SIG ? 2.0f / (__expf(-araw) + 1.0f) - 1.0f : araw;
+            const float alpha = SIG ? gs_squash_alpha(araw) : araw;
             const float w = alpha * T;
             if (CDIM > 3) {
                 float v0 = 0.f, v1 = 0.f, v2 = 0.f;

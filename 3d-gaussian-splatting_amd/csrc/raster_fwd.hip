@@ -405,8 +405,8 @@ raster_forward_kernel(RasterSrc S, RasterGeom G,
                     }
                     if (!FRAME) al = al * splat(nlop);
                     if (SIG) {  // gaussian.cu:930
-                        al.x = 2.0f / (__expf(-al.x) + 1.0f) - 1.0f;
-                        al.y = 2.0f / (__expf(-al.y) + 1.0f) - 1.0f;
+                        al.x = gs_squash_alpha(al.x);
+                        al.y = gs_squash_alpha(al.y);
                     }
                     // w = alpha T with v_mul_legacy_f32 (0 x anything = 0): a finished pixel (T == 0) stays
                     // untouched whatever alpha is -- NaN, infinite --, like the reference, which `break`s before it

@@ -1287,10 +1287,10 @@ int gs_stage_strip_sort(const gs_frame *f, const gs_frame_ws &ws, const uint64_t
     const gs_strip_plan plan = gs_strip_plan_for(f->N, G.ntx, G.nty);
     GsDistCull D = {(float)(G.padW / 2), (float)(G.padH / 2), f->focal_x, f->focal_y, f->thresh};
     const unsigned grid = GS_STRIP_W == 8 ? (unsigned)gs_div_up(plan.geom.NS, 8) * 16 : plan.geom.NS;
-    // GS_FRAME_LONG_LISTS (the caller has seen a long list in an earlier frame): lists beyond the window are queued
+    // GS_FRAME_LONG_SORT / GS_FRAME_LONG_LISTS (the caller has seen a long list in an earlier frame): lists beyond the window are queued
     // for big_list_sort_kernel, one workgroup each; otherwise strip_sort_kernel sorts a long list itself and the
     // frame saves the launches
-    const bool dense = gs_frame_long_lists(f, G.n_tiles) && ws.big_tiles != nullptr;
+    const bool dense = gs_frame_long_sort(f) && ws.big_tiles != nullptr;
     uint32_t *queue = dense ? ws.big_tiles : nullptr;
     if (f->tile_culling_method == 0)
         hipLaunchKernelGGL((strip_sort_kernel<STRIP_SORT_CAP_, true>), dim3(grid), dim3(256), 0, stream, entries,

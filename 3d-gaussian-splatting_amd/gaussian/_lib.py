@@ -51,6 +51,7 @@ GS_FRAME_SERIAL_LONG_LISTS = 8
 GS_FRAME_LONG_LISTS = 16
 GS_FRAME_STRIP_BIN = 32
 GS_FRAME_BWD_ROWS = 64
+GS_FRAME_LONG_SORT = 128
 
 
 def _sig(name, restype, *argtypes):

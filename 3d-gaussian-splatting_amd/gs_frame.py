@@ -74,6 +74,7 @@ class FrameRenderer:
         # back anyway carry the longest list).  The workspace capacity plays no part in it.
         self.long_lists = long_lists
         self._long_lists_seen = False
+        self._long_sort_seen = False  # GS_FRAME_LONG_SORT: a list beyond the per-tile sort's LDS window was seen (see _note_lists)
         # rgb training frames: which kernel composites the backward (GS_FRAME_BWD_ROWS, include/gs_abi.h).  None: by the
         # share of saturated buckets the last backward in front of a `stats()` call reported, with hysteresis -- the
         # choice moves at those (synchronising, caller-placed) calls only, never from asynchronously arriving counters,
@@ -131,7 +132,7 @@ class FrameRenderer:
                pos.shape[0], rgb.shape[-1] if rgb.dim() == 2 else 1, bool(training), self.max_pairs, self.sort_mode,
                self.tile_culling_method, self.tile_culling_dist_thresh, self.thresh, self.scale_activation,
                self.emit_sorted_keys, self.slice_sort, self.table_bin, self.force_strips, self.serial_long_lists,
-               self.long_lists, self._long_lists_seen, self.bwd_rows, self._bwd_rows_seen,
+               self.long_lists, self._long_lists_seen, self._long_sort_seen, self.bwd_rows, self._bwd_rows_seen,
                self._ws.data_ptr() if self._ws is not None else 0)
         cached = getattr(self, "_desc_cache", None)
         if cached is not None and cached[0] == key:
@@ -208,6 +209,7 @@ class FrameRenderer:
             (_lib.GS_FRAME_STRIP_BIN if (self.force_strips and not (self.slice_sort or self.table_bin)) else 0) | \
             (_lib.GS_FRAME_SERIAL_LONG_LISTS if self.serial_long_lists else 0) | \
             (_lib.GS_FRAME_LONG_LISTS if (self.long_lists or (self.long_lists is None and self._long_lists_seen)) else 0) | \
+            (_lib.GS_FRAME_LONG_SORT if (self.long_lists is None and self._long_sort_seen) else 0) | \
             (_lib.GS_FRAME_BWD_ROWS if (self.bwd_rows or (self.bwd_rows is None and self._bwd_rows_seen)) else 0)
         f.training = int(training)
         f.sort_mode = self.sort_mode
@@ -265,13 +267,29 @@ class FrameRenderer:
     # frames are never even looked at.  (Found at the end of round 5: two 7,001-iteration fits that are bit-identical step by
     # step in lockstep ended 0.1 dB apart when run at their own pace, tools/fused_adam_bisect.py.)  Waiting for the copy of
     # frame k before frame k + 8 is issued costs nothing -- seven frames are queued behind it -- and bounds the lag.
-    # The longest tile list beyond which following frames are flagged GS_FRAME_LONG_LISTS.  A flagged frame composites EVERY
-    # tile beyond 512 entries in segments (two passes in training) to cut the serial walk of the longest one: worth it for a
-    # pile (100,000 Gaussians in one tile: 26 -> 1.4 ms) and at the very end of the densifying rgb run (longest list beyond
-    # 6,000: 516 against 464 it/s, r5av), not in its middle (longest list 2,000 - 5,000, a thousand tiles beyond 512: flagged
-    # frames ran 15 - 17 % slower, r5as / r5at).  2,048 until the end of round 5 -- when the counters started to arrive on
-    # time (ASYNC_COUNTER_LAG) the flag came on a thousand iterations earlier and that run lost 13 %.
+    # Long tile lists: what the following frames are flagged with, from the counters every frame carries (longest list, M).
+    #   GS_FRAME_LONG_SORT -- lists beyond the per-tile sort's LDS window go to big_list_sort_kernel -- as soon as a list beyond
+    #     LONG_SORT_FLAG_AT = 2,048 (that window) was seen: the sorted list is the same either way, and in a trained /
+    #     densified scene (3.9 M pairs, 165 lists beyond 2,048) the per-tile sort drops from 407 to 122 us whatever the
+    #     colour model (profiles/r06_a_trained_state_flag_ab.txt);
+    #   GS_FRAME_LONG_LISTS -- segmented compositing of every tile beyond 512 entries (two passes in training) -- only where
+    #     the serial walk of the longest list outlasts the whole frame's compositing: a wave that is alone on its SIMD
+    #     composites a Gaussian in ~48 ns (rgb) / ~190 ns (SH degree 2), the full device one in 0.066 / 0.26 ns -- the
+    #     same ratio, ~720, for every colour model --, and the segment path costs ~2 x the plain kernel on the same scene
+    #     (rgb 0.26 -> 0.51 ms, SH 1.04 -> 1.47 ms at 3.9 M pairs, longest list 5,361: r06_a), so it pays from
+    #     longest > ~2 M / 720 on: flagged when longest > max(LONG_LIST_FLAG_AT, M / LONG_LIST_PAIRS_PER_STEP).  A pile
+    #     (100,000 Gaussians in one tile on a 1.1 M-pair frame) is far beyond that; the densifying run's end states
+    #     (longest 4,000 - 6,000 at 3.4 - 4 M pairs) are not, for any colour model -- round 5 ran those flagged and lost
+    #     2 x in the forward's compositing.
+    LONG_SORT_FLAG_AT = int(os.environ.get("GS_FRAME_LONG_SORT_FLAG_AT", "2048"))
     LONG_LIST_FLAG_AT = int(os.environ.get("GS_FRAME_LONG_LIST_FLAG_AT", "6144"))
+    LONG_LIST_PAIRS_PER_STEP = int(os.environ.get("GS_FRAME_LONG_LIST_PAIRS_PER_STEP", "400"))
+
+    def _note_lists(self, longest: int, pairs: int):
+        self._long_sort_seen = self._long_sort_seen or longest > self.LONG_SORT_FLAG_AT
+        self._long_lists_seen = self._long_lists_seen or \
+            longest > max(self.LONG_LIST_FLAG_AT, pairs // self.LONG_LIST_PAIRS_PER_STEP)
+
     ASYNC_COUNTER_LAG = int(os.environ.get("GS_FRAME_COUNTER_LAG", "8"))  # (the variable: A/B measurements)
 
     def _poll_async_counters(self):
@@ -282,7 +300,7 @@ class FrameRenderer:
         if self._async_event is not None and self._async_event.query():
             v, m, o, b, longest = (int(x) for x in self._async_host.tolist())
             self._async_event = None
-            self._long_lists_seen = self._long_lists_seen or longest > self.LONG_LIST_FLAG_AT
+            self._note_lists(longest, m)
             # (NOT the backward-kernel choice: counters that arrive asynchronously would make it -- and with it the
             # gradients' last bits -- depend on host timing; it moves at synchronous stats() calls only)
             if o:
@@ -468,6 +486,7 @@ class FrameRenderer:
         with torch.cuda.device(self.device):
             _lib.check(_lib.gs_frame_backward_adam(C.byref(f), grad_image.contiguous().data_ptr(), C.byref(adam),
                                                    self._stream().cuda_stream), "gs_frame_backward_adam")
+        self._bwd_serial = self._frame_serial
 
     def backward(self, grad_image, out=None, part: int = 0):
         """dL/d(image) -> (grad_pos, grad_quat, grad_scale, grad_opa, grad_rgb).  ``out`` may
@@ -498,6 +517,8 @@ class FrameRenderer:
                 _lib.check(_lib.gs_frame_backward_part(C.byref(f), grad_image.data_ptr() if grad_image is not None
                                                        else None, *(t.data_ptr() for t in out), int(part),
                                                        self._stream().cuda_stream), "gs_frame_backward_part")
+        if part in (0, _lib.GS_BWD_RASTER):
+            self._bwd_serial = self._frame_serial  # this frame's bucket counter is final once the stream gets here
         return out
 
     def profile_forward(self, pos, quat, scale, opa, rgb, camera, training: Optional[bool] = None):
@@ -532,6 +553,7 @@ class FrameRenderer:
             _lib.check(_lib.gs_frame_backward_profile(C.byref(f), grad_image.contiguous().data_ptr(),
                                                       *(t.data_ptr() for t in out), ms, self._stream().cuda_stream),
                        "gs_frame_backward_profile")
+        self._bwd_serial = self._frame_serial
         return dict(zip(("raster_bwd", "project_bwd", "total"), (float(x) for x in ms)))
 
     def stats(self) -> FrameStats:
@@ -545,9 +567,16 @@ class FrameRenderer:
                                                     stream.cuda_stream), "gs_frame_longest_list_async")
         stream.synchronize()
         v, m, o, b, longest = (int(x) for x in self._stats_host.tolist())
-        self._long_lists_seen = self._long_lists_seen or longest > self.LONG_LIST_FLAG_AT
-        self._note_buckets(b)
-        return FrameStats(v, m, o, b & 0xffffffff, longest, b >> 32)
+        self._note_lists(longest, m)
+        # The bucket counter is written by the backward's preparation on the library's SIDE stream; the copy above is
+        # ordered behind it only once a backward of this frame has been issued on this stream (it waits for the side
+        # stream).  A stats() call between forward and backward may read 0, the previous frame's count or this one's:
+        # it reports what it read, but the backward-kernel choice -- and with it the gradients' last bits -- moves only
+        # on a count that is known to be this frame's.
+        bwd_done = getattr(self, "_bwd_serial", -1) == self._frame_serial
+        if bwd_done:
+            self._note_buckets(b)
+        return FrameStats(v, m, o, (b & 0xffffffff) if bwd_done else 0, longest, (b >> 32) if bwd_done else 0)
 
     def binning_variant(self) -> str:
         """Which binning / sort path the last frame took: "radix64", "radix_tile_bits", "table", "slice", "strip"."""

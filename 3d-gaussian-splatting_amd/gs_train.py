@@ -395,6 +395,18 @@ class Trainer:
                 sg = torch.sigmoid(flat.params[3][g0:g1])
                 flat.grads[3][g0:g1].add_(sg * (1 - sg) * (1 - 2 * sg), alpha=o.opa_reg / flat.params[3].numel())
 
+        def settle_backward_choice():
+            # One host synchronisation per Gaussian set (the set's first frame was capacity-checked synchronously a moment
+            # ago anyway): the backward that has just been issued left the share of its buckets that belong to saturated
+            # tiles in the frame's counters; the renderer keeps the rgb backward kernel that share asks for until the next
+            # Gaussian set (after a densification the scene is a different one).  Called while THIS frame's descriptor and
+            # counters are still the workspace's current ones -- in the view-parallel path that is before the next frame's
+            # project stage is issued ahead (behind it the counters may belong to the half-issued frame).
+            if self._backward_choice_due:
+                self._backward_choice_due = False
+                if r.bwd_rows is None and self.flat.params[4].dim() == 2 and self.flat.params[4].shape[1] == 3:
+                    r.stats()
+
         if flat.collective_active():
             # View parallelism.  Every gradient of the frame becomes final in the LAST kernel of the backward, the
             # per-Gaussian sum of the gradient rows; that kernel, the exchange, the optimizer and the NEXT frame's project
@@ -406,6 +418,7 @@ class Trainer:
             # the blocking path bit for bit (tests/test_host_logic.py, tests/test_gpu_train.py).
             K = flat.n_slices
             r.backward(grad_image, out=flat.grads, part=_lib.GS_BWD_RASTER)
+            settle_backward_choice()
             if self.view_stat is not None and seen is not None:
                 self.view_stat.add_seen(seen)
             for k in range(K):
@@ -437,14 +450,7 @@ class Trainer:
             self.optimizer.step()  # also: accum_max_grad = max(|pos.grad|, accum) or += |pos.grad| (train.py:144-153)
         if seen is not None and self.view_stat is None:
             self.grad_counter = seen if self.grad_counter is None else self.grad_counter + seen
-        if self._backward_choice_due:
-            # One host synchronisation per Gaussian set (the set's first frame was capacity-checked synchronously a moment
-            # ago anyway): the backward that has just been issued left the share of its buckets that belong to saturated
-            # tiles in the frame's counters; the renderer keeps the rgb backward kernel that share asks for until the next
-            # Gaussian set (after a densification the scene is a different one).
-            self._backward_choice_due = False
-            if r.bwd_rows is None and self.flat.params[4].dim() == 2 and self.flat.params[4].shape[1] == 3:
-                r.stats()
+        settle_backward_choice()
         if self.densify and (control or only_delete):
             self.adaptive_control(i_iter, densify=control and not in_reset)
         # train.py:184-185: the learning rates of the NEXT step

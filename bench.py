@@ -827,7 +827,8 @@ def main():
             # numbers are on trained models (README.md:34-48); the headline scene is the opaque generator of SURVEY.md 8d.
             # Per colour model: render FPS (throughput and the reference's synchronised-per-frame protocol), forward +
             # backward it/s (free running), stage times, and the compositing kernel against the HBM roofline on the steps it
-            # EXECUTED -- with the frame flagged GS_FRAME_LONG_LISTS by the renderer's own rule ("auto"), never, and always.
+            # EXECUTED -- with the long-list flags set by the renderer's own rule ("auto": GS_FRAME_LONG_SORT here), never, and
+            # with GS_FRAME_LONG_LISTS (segmented compositing + the sort) forced on.
             from gs_scene import make_trained_like_scene
 
             Wt, Ht = 1920, 1080
@@ -853,8 +854,9 @@ def main():
                     # training renderer: checkpoints, forward + backward
                     r_t = FrameRenderer(dev, max_pairs=int(st_i.pairs * 1.1) + 4096, training=True, auto_grow=False,
                                         long_lists=ll)
+                    r_t.forward(*p_t, cam_t)
+                    st_t = r_t.stats()  # (auto: the renderer's rule flags the following frames from these counters)
                     img_t, _ = r_t.forward(*p_t, cam_t)
-                    st_t = r_t.stats()
                     g_t = (torch.sign(img_t - 0.5) / img_t.numel()).contiguous()
 
                     def fwd_bwd_t():
@@ -869,12 +871,12 @@ def main():
                     tb = [r_t.profile_backward(g_t) for _ in range(8)][2:]
                     tfwd = {k: round(statistics.median(x[k] for x in tf), 4) for k in tf[0]}
                     tbwd = {k: round(statistics.median(x[k] for x in tb), 4) for k in tb[0]}
-                    flagged = bool(r_t._frame.flags & 16)
+                    flagged, flagged_sort = bool(r_t._frame.flags & 16), bool(r_t._frame.flags & (16 | 128))
                     del r_t, img_t, g_t
                     torch.cuda.empty_cache()
                     exec_b = (32 + 4 * Ct) * steps_t + 12 * Pt
                     res[mode] = {
-                        "flagged_long_lists": flagged, "visible": st_i.visible, "tile_pairs": st_i.pairs,
+                        "flagged_long_lists": flagged, "flagged_long_sort": flagged_sort, "visible": st_i.visible, "tile_pairs": st_i.pairs,
                         "longest_list": st_t.longest_list, "composited_steps": steps_t,
                         "render_fps": round(20 / dt_i, 1), "ms_per_frame": round(dt_i / 20 * 1e3, 4),
                         "ms_per_frame_min": round(min(blocks_i) / 20 * 1e3, 4),
@@ -893,8 +895,8 @@ def main():
                                            "training_ns_per_executed_step": round(tfwd["raster"] * 1e6 / max(steps_t, 1), 4)}}
                     if mode == "auto":
                         r_l = FrameRenderer(dev, max_pairs=int(st_i.pairs * 1.1) + 4096, auto_grow=False, long_lists=ll)
-                        if flagged:
-                            r_l._long_lists_seen = True
+                        r_l.forward(*p_t, cam_t)
+                        r_l.stats()  # (the renderer's own rule flags the following frames)
                         res[mode]["latency"] = latency_fps(lambda: r_l.forward(*p_t, cam_t), 30)
                         del r_l
                 ts[tag] = res

@@ -193,6 +193,14 @@ int gs_sort_pairs_bits(uint64_t *keys0, uint32_t *vals0, uint64_t *keys1, uint32
                                        by N: the table variant below GS_STRIP_AUTO_MIN_N (131,072) Gaussians, where its shorter
                                        chain of dependent kernels wins, the strip variant from there on.  Every variant
                                        produces the same lists. */
+#define GS_FRAME_LONG_SORT 128        /* the SORT half of GS_FRAME_LONG_LISTS alone (round 6): tile lists beyond strip_sort_kernel's LDS
+                                       window (2,048 pairs) are queued for big_list_sort_kernel, one workgroup per list, instead
+                                       of being sorted by their strip's workgroup with the chunked bitonic network -- the tail of
+                                       that kernel in a trained / densified scene (3.9 M pairs, 165 lists beyond 2,048: per-tile
+                                       sort 407 -> 122 us, profiles/r06_a_*).  The sorted list is the same either way (the order is
+                                       exact), so unlike the segmented compositing this half costs nothing but two launches in
+                                       frames without such lists.  The caller sets it once gs_frame_longest_list_async reported
+                                       a list beyond 2,048; GS_FRAME_LONG_LISTS implies it. */
 #define GS_FRAME_BWD_ROWS 64         /* rgb training frames: composite the backward with the row-layout kernel (lanes = 16
                                        Gaussians x 4 pixel quads, pixel rows whose pixels have all stopped are left out)
                                        instead of the pixel-parallel one.  Worth it when most of the frame's buckets belong

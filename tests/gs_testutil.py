@@ -36,13 +36,17 @@ class OracleFrame:
     """Oracle restatement of one forward frame on raw parameters, keeping every intermediate."""
 
     def __init__(self, scene: Scene, cam: Camera, thresh=0.05, scale_activation="abs", tile_culling_method="prob2",
-                 dist_thresh=0.5):
+                 dist_thresh=0.5, activated=None):
+        """``activated`` = (normalised quaternions, activated scales) computed by the CALLER (the reference's torch ops,
+        splatter.py:519-524, whose last bits differ from ``activate``'s expression order): the frame is then the oracle's
+        on exactly those inputs -- what the reference-API tests need to compare bit for bit behind torch activations."""
         self.scene, self.cam = scene, cam
         self.dist_thresh = dist_thresh
         self.scale_activation = scale_activation
         grid, hw, hh, rays = frame_scalars(cam)
         self.grid, self.rays = grid, rays
-        self.qn, self.sn = activate(scene, scale_activation)
+        self.qn, self.sn = activate(scene, scale_activation) if activated is None else \
+            tuple(np.ascontiguousarray(a, np.float32) for a in activated)
         self.pos_i, self.cov, self.mask = oracle.global_culling(scene.pos, self.qn, self.sn, cam.rot, cam.tran,
                                                                 cam.near, hw, hh)
         if tile_culling_method == "prob2":
@@ -254,7 +258,7 @@ GRAD_L2 = 2e-5  # ||got - ref||_2 / ||ref||_2 per tensor
 # 5e-4, maximum up to 1.8e-2 -- percent-level single elements are a property of fp32 on these sums, not of a kernel.
 CALIB_QS = (0.5, 0.9, 0.99, 0.999, 1.0)
 CALIB_K = 4.0  # error quantile of a HIP kernel <= CALIB_K x the same quantile of the reference arithmetic's error
-CALIB_K_ELEM = 4.0  # per element: e_hip <= CALIB_K_ELEM x max(e_ref, 1 fp32 ulp of the summed magnitudes) at p99.9; 2 x that at the maximum
+CALIB_K_ELEM = 4.0  # per element: e_hip <= CALIB_K_ELEM x max(e_ref, the reference's 99.9th-percentile error on sums of that magnitude)
 
 
 def rel_error_quantiles(got, truth, qs=CALIB_QS, floor=1e-6):
@@ -269,13 +273,20 @@ def rel_error_quantiles(got, truth, qs=CALIB_QS, floor=1e-6):
 
 
 def elementwise_error_ratio(got, ref, truth, scale):
-    """e_got / max(e_ref, ulp floor) per element -> (99.9th percentile, maximum).  The floor is one fp32 ulp (2^-23)
-    of the element's term-magnitude sum (the oracle's conditioning scale with scale_w = 0): where the reference
-    evaluation happened to round luckily, the comparison is against what fp32 can resolve at all."""
-    got, ref, truth, scale = (np.asarray(a, np.float64) for a in (got, ref, truth, scale))
+    """Element by element: e_got / max(e_ref, F x scale) -> (99.9th percentile, maximum, F, the same F for `got`).
+    `scale` is the element's term-magnitude sum (the oracle's conditioning scale with scale_w = 0) and F the REFERENCE
+    evaluation's own tail error per unit of scale, the 99.9th percentile of e_ref / scale over the tensor: where the
+    reference happened to round luckily, an element is held to what the reference's arithmetic delivers at its 99.9th
+    percentile on sums of that magnitude -- not to that luck.  (Errors of two independent fp32 evaluations are not
+    correlated element by element: against max(e_ref, one ulp of scale) the ORACLE passes with 1.5, because it shares
+    the reference's per-term arithmetic, while any kernel with another exp / rcp / summation order sits at 5 - 25.)"""
+    got, ref, truth, scale = (np.asarray(a, np.float64).ravel() for a in (got, ref, truth, scale))
     e_got, e_ref = np.abs(got - truth), np.abs(ref - truth)
-    ratio = e_got / np.maximum(np.maximum(e_ref, 2.0 ** -23 * scale), 1e-300)
-    return float(np.quantile(ratio, 0.999)), float(ratio.max())
+    pos = scale > 0
+    F = float(np.quantile(e_ref[pos] / scale[pos], 0.999)) if pos.any() else 0.0
+    F_got = float(np.quantile(e_got[pos] / scale[pos], 0.999)) if pos.any() else 0.0
+    ratio = e_got / np.maximum(np.maximum(e_ref, F * scale), 1e-300)
+    return float(np.quantile(ratio, 0.999)), float(ratio.max()), F, F_got
 
 
 def assert_error_no_worse_than(grads, truth, ref, what="", k=CALIB_K):

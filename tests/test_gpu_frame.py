@@ -123,6 +123,40 @@ def test_long_list_kernels_follow_the_longest_list_statistic(gpu):
     assert np.array_equal(v["sorted_ids"].cpu().numpy(), of.ids)
 
 
+def test_lists_beyond_the_sort_window_switch_the_sort_alone(gpu):
+    """Round 6: lists of 4,100 - 5,000 pairs (beyond the per-tile sort's 2,048-pair LDS window, below what the segmented
+    compositing pays for): the renderer sets GS_FRAME_LONG_SORT (128) from the second frame on and NOT
+    GS_FRAME_LONG_LISTS (16) -- the lists go to big_list_sort_kernel, the compositing keeps its one-wave walk.  The sort
+    is exact in every variant, so the flagged frame's list AND image equal the first frame's bit for bit."""
+    scene, cam = make_scene(14_000, 48, 32, seed=8), make_camera(48, 32)
+    of = OracleFrame(scene, cam)
+    lens = np.diff(of.accum)
+    assert 2048 < lens.min() and lens.max() <= FrameRenderer.LONG_LIST_FLAG_AT
+    params = to_torch(scene, gpu)
+    r = FrameRenderer(gpu, max_pairs=len(of.ids) + 64, auto_grow=True, force_strips=False, emit_sorted_keys=True)
+    first, _ = r.forward(*params, cam)
+    assert not (r._frame.flags & (16 | 128))
+    assert r.stats().longest_list == int(lens.max()) and r._long_sort_seen and not r._long_lists_seen
+    ids_first = r.debug_views()["sorted_ids"].clone()
+    second, _ = r.forward(*params, cam)
+    assert (r._frame.flags & 128) and not (r._frame.flags & 16) and r.binning_variant() == "strip"
+    v = r.debug_views()
+    assert np.array_equal(v["sorted_ids"].cpu().numpy(), of.ids) and torch.equal(v["sorted_ids"], ids_first)
+    assert np.array_equal(v["sorted_keys"].cpu().numpy().view(np.uint64), of.keys)
+    assert torch.equal(first, second)
+    assert np.abs(second.cpu().numpy() - of.image).max() < IMG_ATOL
+    # training frames too: same image, gradients bit-identical with and without the flag (the backward never looks at it)
+    g = torch.randn(32, 48, 3, device=gpu)
+    grads = []
+    for flagged in (False, True):
+        rt = FrameRenderer(gpu, max_pairs=len(of.ids) + 64, training=True, auto_grow=False)
+        rt._long_sort_seen = flagged
+        img, _ = rt.forward(*params, cam)
+        assert bool(rt._frame.flags & 128) == flagged and torch.equal(img, first)
+        grads.append([t.clone() for t in rt.backward(g)])
+    assert all(torch.equal(a, b) for a, b in zip(*grads))
+
+
 def test_small_scene_with_a_pile_switches_to_the_long_list_kernels(gpu):
     """below 131,072 Gaussians sort_mode 2 takes the TABLE variant, whose kernels used to report 0 for the
     longest list -- a small scene with a pile-up (the case the long-list kernels were built for) stayed on the serial path

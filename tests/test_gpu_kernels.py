@@ -233,13 +233,14 @@ def test_reference_api_full_size(gpu, cfg):
 
     n, W, H, use_sh = CONFIGS[cfg]
     scene, cam = make_scene(n, W, H, seed=2023, use_sh=use_sh), make_camera(W, H)
-    of = OracleFrame(scene, cam)
-    grid, rays = of.grid, of.rays
-    hw, hh = grid.frustum_half_extents()
     params = to_torch(scene, gpu, requires_grad=True)
     pos, quat, scale_raw, opa_raw, rgb_raw = params
     qn = quat / torch.norm(quat, dim=1, keepdim=True)  # splatter.py:519-524 (train.py defaults)
     sn = torch.abs(scale_raw) + 1e-4
+    # the oracle's frame on exactly the activated values torch produced (identical inputs for the bit-exact comparison)
+    of = OracleFrame(scene, cam, activated=(qn.detach().cpu().numpy(), sn.detach().cpu().numpy()))
+    grid, rays = of.grid, of.rays
+    hw, hh = grid.frustum_half_extents()
     pos_i, cov, mask = global_culling(pos, qn, sn, dev(cam.rot, gpu), dev(cam.tran, gpu), cam.near, hw, hh)
     assert np.array_equal(mask.cpu().numpy(), of.mask)
     assert np.array_equal(pos_i.detach().cpu().numpy().view(np.uint32), of.pos_i.view(np.uint32))
