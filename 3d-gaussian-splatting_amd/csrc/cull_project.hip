@@ -551,7 +551,7 @@ __global__ void __launch_bounds__(STRIP_THREADS) frame_project_count_kernel(
     float4 *__restrict__ rec_geom, uint32_t *__restrict__ tiles_touched, uint4 *__restrict__ rects, GsDistCull D,
     uint32_t per_slice, gs_strip_geom SG, uint32_t S, uint32_t slice0, unsigned long long *__restrict__ table,
     uint32_t *__restrict__ slice_pairs, uint32_t *__restrict__ slice_vis, const uint32_t *__restrict__ tile_cost,
-    uint32_t n_tiles, uint32_t *__restrict__ tile_order) {
+    uint32_t n_tiles, uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ cut) {
     extern __shared__ unsigned long long s_hist[];  // [NS] entries << 32 | pairs of this slice
     __shared__ uint32_t s_acc[2];
     if (blockIdx.x >= S) {  // the one extra workgroup of the launch (uniform)
@@ -581,7 +581,8 @@ __global__ void __launch_bounds__(STRIP_THREADS) frame_project_count_kernel(
         acc_cnt += rc.w;
         acc_vis += vis;
         walk_strips<DIST>(rc, g0 + i, SG, cxy, D,
-                          [&](uint32_t strip, uint32_t, uint32_t, uint32_t np) { atomicAdd(&s_hist[strip], (1ull << 32) | np); });
+                          [&](uint32_t strip, uint32_t, uint32_t, uint32_t np) { atomicAdd(&s_hist[strip], (1ull << 32) | np); },
+                          cut);
         cur = nxt;
     }
     // rectangle areas (= gradient-row slots; == pairs unless DIST) and visible Gaussians of this slice
@@ -1546,7 +1547,9 @@ int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t strea
     hipLaunchKernelGGL(frame_project_count_kernel<DIST>, dim3(nsl + extra), dim3(STRIP_THREADS), lds, stream,          \
                        f->pos, (const float4 *)f->quat, f->scale, f->opa, f->rgb, f->N, P, ws.rec_geom, touched,       \
                        ws.rects, D, plan.per_slice, SG, nsl, (uint32_t)slice_begin, table, ws.slice_pairs,             \
-                       ws.slice_vis, ws.tile_cost, (uint32_t)G.n_tiles, ws.tile_order)
+                       ws.slice_vis, ws.tile_cost, (uint32_t)G.n_tiles, ws.tile_order, cut)
+        // GS_FRAME_OCCLUSION_CULL: level-1 entries trimmed by the cut table the previous frame of this workspace left
+        const uint32_t *cut = gs_frame_occlusion_cull(f) ? ws.cut : nullptr;
         if (f->tile_culling_method == 0)
             GS_LAUNCH_PROJECT_COUNT(true);
         else

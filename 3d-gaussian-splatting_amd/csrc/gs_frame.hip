@@ -65,7 +65,7 @@ static int validate(const gs_frame *f) {
     }
     GS_CHECK_ARG((f->flags & ~(GS_FRAME_EMIT_SORTED_KEYS | GS_FRAME_SLICE_SORT | GS_FRAME_TABLE_BIN |
                                GS_FRAME_SERIAL_LONG_LISTS | GS_FRAME_LONG_LISTS | GS_FRAME_STRIP_BIN |
-                               GS_FRAME_BWD_ROWS | GS_FRAME_LONG_SORT)) == 0,
+                               GS_FRAME_BWD_ROWS | GS_FRAME_LONG_SORT | GS_FRAME_OCCLUSION_CULL)) == 0,
                  "unknown flag bits");
     GS_CHECK_ARG(f->sort_mode >= 0 && f->sort_mode <= 2,
                  "sort_mode must be 0 (full LSD radix), 1 (tile-bit radix + per-tile LDS sort) or 2 (LDS counting sort "
@@ -116,7 +116,7 @@ static void sorted_buffers(const gs_frame *f, const gs_frame_ws &ws, uint64_t **
 }
 
 struct StageTimer {
-    hipEvent_t ev[GS_N_STAGES + 1];
+    hipEvent_t ev[GS_N_STAGES + 2];  // (+1: the gated second pass of an occlusion-culled frame counts towards the total only)
     int n = 0;
     bool on;
     hipStream_t s;
@@ -131,7 +131,7 @@ struct StageTimer {
             if (e) (void)hipEventDestroy(e);
     }
     void mark() {
-        if (on && ok && n <= GS_N_STAGES) ok = hipEventRecord(ev[n++], s) == hipSuccess;
+        if (on && ok && n <= GS_N_STAGES + 1) ok = hipEventRecord(ev[n++], s) == hipSuccess;
     }
     // ms[i] = ev[i+1] - ev[i]; ms[last] = total
     int finish(float *ms, int n_stages) {
@@ -307,6 +307,17 @@ static int frame_forward_impl(const gs_frame *f, hipStream_t s, float *stage_ms,
     tm.mark();  // stage "ranges" = tile ranges (+ the per-tile depth sort in mode 1)
     if ((rc = gs_stage_raster_forward(f, ws, sids, s))) return rc;
     tm.mark();
+    if (mode == 2 && gs_frame_occlusion_cull(f)) {
+        // The lists of this frame were trimmed by the occlusion cuts of the previous one (gs_frame_layout.h).  If a tile ran
+        // past its cut, counters[GS_CNT_RANPAST] is set and the five launches below render the frame again from the full
+        // lists; otherwise each of them returns at its first instruction.  The project stage is not repeated: the
+        // rectangles are the same, only the level-1 entries are recounted from them.
+        if ((rc = gs_stage_strip_bin(f, ws, s, true))) return rc;
+        uint64_t *keys_out = nullptr;  // (frames that export their sorted keys are never culled)
+        if ((rc = gs_stage_strip_sort(f, ws, okeys, skeys, keys_out, sids, s, true))) return rc;
+        if ((rc = gs_stage_raster_forward(f, ws, sids, s, true))) return rc;
+        tm.mark();
+    }
     if (f->training && f->N > 0) prepare_on_side_stream(f, ws, sids, s);
     return tm.finish(stage_ms, GS_N_STAGES);
 }
@@ -471,6 +482,31 @@ extern "C" int gs_frame_longest_list_async(const gs_frame *f, int64_t *longest_h
     GS_CHECK_ARG(longest_host != nullptr, "longest_host is null");
     gs_frame_ws ws = gs_frame_carve(f->workspace, f->N, f->max_pairs, f->width, f->height, f->color_dim, f->training);
     GS_HIP(hipMemcpyAsync(longest_host, ws.counters + GS_CNT_MAXLIST, sizeof(int64_t), hipMemcpyDeviceToHost,
+                          (hipStream_t)stream));
+    return 0;
+}
+
+// The counters of the last forward (+ the last backward's preparation) on this workspace WITH the caller's tag behind them:
+// the tag is written into the counter block by a fill command on `stream` (no host memory involved) and travels in the
+// same device-to-host copy, so stats_host[11] == tag tells the host -- without any bookkeeping of its own -- that the
+// eleven values in front of it are those the stream held when it reached THIS call, i.e. of the frame issued just before.
+extern "C" int gs_frame_stats_tagged_async(const gs_frame *f, uint32_t tag, int64_t *stats_host, gs_stream_t stream) {
+    int rc = validate(f);
+    if (rc) return rc;
+    GS_CHECK_ARG(stats_host != nullptr, "stats_host is null");
+    gs_frame_ws ws = gs_frame_carve(f->workspace, f->N, f->max_pairs, f->width, f->height, f->color_dim, f->training);
+    GS_HIP(hipMemsetD32Async((hipDeviceptr_t)(ws.counters + GS_CNT_TAG), (int)tag, 2, (hipStream_t)stream));
+    GS_HIP(hipMemcpyAsync(stats_host, ws.counters, sizeof(int64_t) * GS_STATS_TAGGED_N, hipMemcpyDeviceToHost,
+                          (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int gs_frame_cull_fallback_async(const gs_frame *f, int64_t *ran_past_host, gs_stream_t stream) {
+    int rc = validate(f);
+    if (rc) return rc;
+    GS_CHECK_ARG(ran_past_host != nullptr, "ran_past_host is null");
+    gs_frame_ws ws = gs_frame_carve(f->workspace, f->N, f->max_pairs, f->width, f->height, f->color_dim, f->training);
+    GS_HIP(hipMemcpyAsync(ran_past_host, ws.counters + GS_CNT_RANPAST, sizeof(int64_t), hipMemcpyDeviceToHost,
                           (hipStream_t)stream));
     return 0;
 }

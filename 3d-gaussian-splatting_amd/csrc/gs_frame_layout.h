@@ -2,7 +2,7 @@
 #pragma once
 #include "gs_common.h"
 
-enum { GS_CNT_VISIBLE = 0, GS_CNT_PAIRS = 1, GS_CNT_OVERFLOW = 2, GS_CNT_BUCKETS = 3, GS_CNT_TICKET = 4, GS_CNT_ENTRIES = 5, GS_CNT_BIG = 6, GS_CNT_SEGS = 7, GS_CNT_GROUPS = 8, GS_CNT_MAXLIST = 9, GS_CNT_N = 16 };
+enum { GS_CNT_VISIBLE = 0, GS_CNT_PAIRS = 1, GS_CNT_OVERFLOW = 2, GS_CNT_BUCKETS = 3, GS_CNT_TICKET = 4, GS_CNT_ENTRIES = 5, GS_CNT_BIG = 6, GS_CNT_SEGS = 7, GS_CNT_GROUPS = 8, GS_CNT_MAXLIST = 9, GS_CNT_RANPAST = 10, GS_CNT_TAG = 11, GS_CNT_N = 16 };
 
 #define GS_BUCKET 64          // Gaussians per backward bucket (= wavefront size)
 #define GS_SORT_TILE 2048     // keys per radix-sort workgroup (256 threads x 8)
@@ -77,6 +77,25 @@ static inline bool gs_frame_long_lists(const gs_frame *f, int n_tiles) {
     (void)n_tiles;
     return (f->flags & GS_FRAME_LONG_LISTS) != 0;
 }
+// ---------------------------------------------------------------- temporal occlusion cull (round 6; GS_FRAME_OCCLUSION_CULL)
+// 71 % of the pairs of the 2.4 M-Gaussian scene lie behind the point where their tile's pixels have all stopped: they are
+// emitted, scattered and sorted (32 + 70 us of a 300-us frame) and never read.  The compositing kernel records, per tile,
+// the depth of the last Gaussian it composited when ALL the tile's pixels had stopped before the end of its list (x (1 +
+// GS_CUT_MARGIN); GS_NO_CUT otherwise), and the NEXT frame of the same workspace -- when the caller allows it with
+// GS_FRAME_OCCLUSION_CULL -- trims every level-1 entry at the ends whose tiles' cut lies in front of the Gaussian
+// (strip_common.h, walk_strips): those pairs are never emitted.  Exactness: a tile's list ascends in depth, the dropped
+// pairs are deeper than every kept one, so a tile whose pixels all stop inside its kept prefix composites exactly what it
+// would have composited from the full list -- bit for bit.  A tile that reaches the end of a trimmed list with a live pixel
+// "ran past the cut" (the camera moved, something in front went away): it raises counters[GS_CNT_RANPAST], and the same
+// launch sequence that follows the compositing -- count (from the rectangles, untrimmed), column scan, scatter, per-tile
+// sort, compositing, each gated on that counter (a few microseconds of empty grids otherwise) -- renders the frame again
+// from the full lists.  No host synchronisation, the image is exact either way.  Not for training frames (the backward
+// owns the full emission order), frames that export their sorted keys, the "dist" listing, segmented long lists, or
+// the table / radix variants.
+#define GS_NO_CUT 0xffffffffu
+#define GS_CUT_MARGIN 0.0625f
+static inline bool gs_frame_occlusion_cull(const gs_frame *f);
+
 // the sort half alone (GS_FRAME_LONG_SORT, round 6): lists beyond the LDS window go to big_list_sort_kernel; the segmented
 // compositing -- which changes the rounding of the transmittance and only pays for lists several times longer -- follows
 // GS_FRAME_LONG_LISTS
@@ -138,6 +157,11 @@ static inline bool gs_frame_uses_strips(const gs_frame *f) {
 #define GS_FUSED_PROJECT_COUNT 1  // A/B switch (tools/ab_variants.py)
 #endif
 static inline bool gs_frame_fused_count(const gs_frame *f) { return GS_FUSED_PROJECT_COUNT && gs_frame_uses_strips(f); }
+static inline bool gs_frame_occlusion_cull(const gs_frame *f) {
+    return (f->flags & GS_FRAME_OCCLUSION_CULL) && !f->training && f->N > 0 && f->tile_culling_method != 0 &&
+           !(f->flags & (GS_FRAME_EMIT_SORTED_KEYS | GS_FRAME_LONG_LISTS | GS_FRAME_SERIAL_LONG_LISTS)) &&
+           gs_frame_uses_strips(f) && GS_FUSED_PROJECT_COUNT;
+}
 // Table variant (small scenes: a frame is a chain of dependent launches of ~7 us each): the per-(slice, tile) count
 // (bin_count_kernel) is taken inside the project stage as well -- five launches per frame instead of six.
 static inline bool gs_frame_fused_table_count(const gs_frame *f) {
@@ -237,6 +261,9 @@ struct gs_frame_ws {
     void *sort_tmp;
     size_t sort_tmp_bytes;
     int32_t *tile_ranges;          // [T][2]
+    uint32_t *cut;                 // [T] occlusion cut of every tile (GS_FRAME_OCCLUSION_CULL, below): depth bits behind which the
+                                   // LAST forward of this workspace composited nothing in the tile, GS_NO_CUT if its pixels
+                                   // had not all stopped; written by every INFERENCE frame-path compositing launch
     // sort_mode 2 (tile_bin.hip)
     uint32_t *bin_table;           // table variant: [GS_BIN_SLICES][T] pairs of (slice, tile), scanned in place over
                                    // slices; slice-sorted variant: [S][T + 1] offsets of a tile's pairs inside the
@@ -302,6 +329,8 @@ static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pair
     ws.counters = (unsigned long long *)take(sizeof(unsigned long long) * GS_CNT_N);
     ws.tile_ranges = (int32_t *)take(sizeof(int32_t) * 2 * G.n_tiles);
     ws.zero_bytes = off;
+    // (in front of everything whose size depends on N: the table outlives a change of the Gaussian count)
+    ws.cut = (uint32_t *)take(sizeof(uint32_t) * G.n_tiles);
     ws.rec_geom = (float4 *)take(sizeof(float4) * GS_REC_STRIDE * N);
     ws.rec_cov = ws.rec_geom ? ws.rec_geom + 1 : nullptr;
     ws.rec_color = ws.rec_geom ? ws.rec_geom + 2 : nullptr;
@@ -393,15 +422,16 @@ int gs_stage_scan_emit(const gs_frame *f, const gs_frame_ws &ws, hipStream_t str
 int gs_stage_tile_sort(const gs_frame *f, const gs_frame_ws &ws, uint64_t *keys, uint32_t *ids, uint64_t *scratch,
                        hipStream_t stream);
 int gs_stage_tile_bin(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream);
-int gs_stage_strip_bin(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream);
+int gs_stage_strip_bin(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream, bool second_pass = false);
 int gs_stage_strip_sort(const gs_frame *f, const gs_frame_ws &ws, const uint64_t *entries, uint64_t *scratch,
-                        uint64_t *keys_out, uint32_t *ids_out, hipStream_t stream);
+                        uint64_t *keys_out, uint32_t *ids_out, hipStream_t stream, bool second_pass = false);
 int gs_stage_tile_sort_packed(const gs_frame *f, const gs_frame_ws &ws, uint64_t *packed, uint64_t *keys_out,
                               uint32_t *ids_out, hipStream_t stream);
 int gs_stage_tile_sort_gather(const gs_frame *f, const gs_frame_ws &ws, const uint64_t *slice_pairs_buf,
                               uint64_t *big_scratch, uint64_t *keys_out, uint32_t *ids_out, hipStream_t stream);
 int gs_stage_tile_ranges(const gs_frame *f, const gs_frame_ws &ws, const uint64_t *sorted_keys, hipStream_t stream);
-int gs_stage_raster_forward(const gs_frame *f, const gs_frame_ws &ws, const uint32_t *sorted_ids, hipStream_t stream);
+int gs_stage_raster_forward(const gs_frame *f, const gs_frame_ws &ws, const uint32_t *sorted_ids, hipStream_t stream,
+                            bool second_pass = false);
 int gs_stage_backward_prepare(const gs_frame *f, const gs_frame_ws &ws, const uint32_t *sorted_ids, hipStream_t stream);
 int gs_stage_sh_big_rows(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream);
 int gs_stage_raster_backward(const gs_frame *f, const gs_frame_ws &ws, const uint32_t *sorted_ids,

@@ -118,8 +118,16 @@ raster_forward_kernel(RasterSrc S, RasterGeom G,
                                                                     float4 *__restrict__ cont_state,
                                                                     uint32_t *__restrict__ cont_flag,
                                                                     const uint32_t *__restrict__ tile_order,
-                                                                    uint32_t *__restrict__ tile_cost) {
+                                                                    uint32_t *__restrict__ tile_cost,
+                                                                    const uint32_t *cut_in, uint32_t *cut_out,
+                                                                    unsigned long long *__restrict__ ranpast,
+                                                                    const unsigned long long *__restrict__ gate) {
     static_assert(!(EXACT && FRAME), "the exact-exp flavour belongs to the reference API (gs_draw, fast = 0)");
+    // frame path, temporal occlusion cull (gs_frame_layout.h): `cut_out` [T] receives, per tile, the depth behind which this
+    // launch composited nothing (all its pixels had stopped) or GS_NO_CUT; `cut_in` (the same table, set when this frame's
+    // lists were trimmed by it) makes a tile that reaches the end of its list with a live pixel raise *ranpast; `gate`: the
+    // untrimmed second pass, which only runs if some tile did
+    if (FRAME && gate && *gate == 0) return;
     using SM = FwdSmem<CDIM>;
     constexpr int CH = SM::CH;
 #ifndef GS_FWD_GROUP
@@ -450,6 +458,19 @@ raster_forward_kernel(RasterSrc S, RasterGeom G,
         nproc = base + cnt;
     }
     if (!staged_next) fetch(nstart, nn, 0);  // empty tile, or the wave stopped before its last chunk
+    if (FRAME && !CKPT && cut_out) {  // (uniform; inference frames only: the training variant sits at its 128-VGPR budget)
+        // all pixels stopped inside the list (or exactly at its end): nothing behind the last composited Gaussian matters
+        const bool sat = !continues && steps > 0 && (done || !any_live());
+        if (lane == 0) {
+            uint32_t c = GS_NO_CUT;
+            if (sat) {
+                const uint32_t last = S.ids[start + steps - 1];
+                c = __float_as_uint(S.geom[(size_t)last * GS_REC_STRIDE].z * (1.0f + GS_CUT_MARGIN));
+            }
+            if (cut_in && !sat && cut_in[tile] != GS_NO_CUT) *ranpast = 1ull;  // this tile's list had been trimmed
+            cut_out[tile] = c;
+        }
+    }
     if (tile_nproc && lane == 0) tile_nproc[tile] = nproc;
     if (FRAME && tile_cost && lane == 0) tile_cost[tile] = steps;
     if (FRAME && cont_flag && lane == 0) cont_flag[tile] = continues ? 1u : 0u;
@@ -815,17 +836,19 @@ static uint32_t fwd_grid(uint32_t n_tiles) {
 template <int CDIM, bool FRAME, bool CKPT, bool SIG, bool EXACT = false>
 void launch_fwd(const RasterSrc &S, const RasterGeom &G, const int32_t *ranges, float *out_padded, float *out_image,
                 float4 *ckpt, uint32_t *tile_nproc, int wn, hipStream_t stream, float4 *cont_state = nullptr,
-                uint32_t *cont_flag = nullptr, const uint32_t *tile_order = nullptr, uint32_t *tile_cost = nullptr) {
+                uint32_t *cont_flag = nullptr, const uint32_t *tile_order = nullptr, uint32_t *tile_cost = nullptr,
+                const uint32_t *cut_in = nullptr, uint32_t *cut_out = nullptr, unsigned long long *ranpast = nullptr,
+                const unsigned long long *gate = nullptr) {
     if (!fwd_plan().order) tile_order = nullptr;
     const uint32_t T = (uint32_t)(G.ntx * G.nty), grid = fwd_grid(T);
     if (wn)
         hipLaunchKernelGGL((raster_forward_kernel<CDIM, FRAME, CKPT, SIG, true, EXACT>), dim3(grid), dim3(FWD_THREADS),
                            0, stream, S, G, ranges, out_padded, out_image, ckpt, tile_nproc, T, cont_state, cont_flag,
-                           tile_order, tile_cost);
+                           tile_order, tile_cost, cut_in, cut_out, ranpast, gate);
     else
         hipLaunchKernelGGL((raster_forward_kernel<CDIM, FRAME, CKPT, SIG, false, EXACT>), dim3(grid), dim3(FWD_THREADS),
                            0, stream, S, G, ranges, out_padded, out_image, ckpt, tile_nproc, T, cont_state, cont_flag,
-                           tile_order, tile_cost);
+                           tile_order, tile_cost, cut_in, cut_out, ranpast, gate);
 }
 
 }  // namespace
@@ -906,7 +929,7 @@ extern "C" int gs_draw(const float *pos, const float *rgb, const float *opa, con
 }
 
 int gs_stage_raster_forward(const gs_frame *f, const gs_frame_ws &ws, const uint32_t *sorted_ids,
-                            hipStream_t stream) {
+                            hipStream_t stream, bool second_pass) {
     gs_frame_geom FG = gs_frame_geometry(f);
     RasterSrc S = {};
     S.ids = sorted_ids;
@@ -942,14 +965,21 @@ int gs_stage_raster_forward(const gs_frame *f, const gs_frame_ws &ws, const uint
     const bool ordered = gs_frame_uses_strips(f) && f->N > 0 && ws.tile_order != nullptr;
     const uint32_t *order = ordered ? ws.tile_order : nullptr;
     uint32_t *cost = ordered ? ws.tile_cost : nullptr;
+    // occlusion cut (gs_frame_layout.h): every INFERENCE frame-path launch leaves the table behind for the next frame of this
+    // workspace (a training forward leaves it untouched: the caller must not allow the cull right behind one); a frame
+    // whose lists were trimmed by it checks them, and its gated second pass composites the full lists
+    const bool culled = gs_frame_occlusion_cull(f);
+    const uint32_t *cut_in = culled && !second_pass ? ws.cut : nullptr;
+    unsigned long long *ranpast = ws.counters + GS_CNT_RANPAST;
+    const unsigned long long *gate = second_pass ? ranpast : nullptr;
 #define GS_LAUNCH_FRAME_FWD(CD)                                                                                        \
     do {                                                                                                               \
         if (f->training)                                                                                               \
             launch_fwd<CD, true, true, false>(S, G, ws.tile_ranges, f->image_padded, f->image, ws.ckpt, ws.tile_nproc, \
-                                              0, stream, cs, cf, order, cost);                                         \
+                                              0, stream, cs, cf, order, cost, nullptr, nullptr, ranpast, nullptr);     \
         else                                                                                                           \
             launch_fwd<CD, true, false, false>(S, G, ws.tile_ranges, f->image_padded, f->image, nullptr, nullptr, 0,   \
-                                               stream, cs, cf, order, cost);                                           \
+                                               stream, cs, cf, order, cost, cut_in, ws.cut, ranpast, gate);            \
     } while (0)
     if (f->color_dim == 48)
         GS_LAUNCH_FRAME_FWD(48);

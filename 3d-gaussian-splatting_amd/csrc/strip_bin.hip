@@ -57,9 +57,14 @@ __global__ void __launch_bounds__(STRIP_THREADS) strip_count_kernel(
     const uint4 *__restrict__ rects, const float4 *__restrict__ rec_geom, GsDistCull D, int64_t n, uint32_t per_slice,
     gs_strip_geom SG, uint32_t S, unsigned long long *__restrict__ table, const uint32_t *__restrict__ block_sums,
     const uint32_t *__restrict__ block_vis, uint32_t *__restrict__ slice_pairs, uint32_t *__restrict__ slice_vis,
-    const uint32_t *__restrict__ tile_cost, uint32_t n_tiles, uint32_t *__restrict__ tile_order) {
+    const uint32_t *__restrict__ tile_cost, uint32_t n_tiles, uint32_t *__restrict__ tile_order,
+    const unsigned long long *__restrict__ gate) {
     extern __shared__ unsigned long long s_hist[];  // [NS] entries << 32 | pairs of this slice
     __shared__ uint32_t s_acc[2];
+    // `gate` (the second, untrimmed pass of a GS_FRAME_OCCLUSION_CULL frame, gs_frame_layout.h): nothing to do unless a tile
+    // ran past its cut.  That pass recounts the entries only -- block_sums == NULL: the slices' rectangle areas and visible
+    // counts are the first pass's
+    if (gate && *gate == 0) return;
     if (blockIdx.x >= S) {  // the one extra workgroup of the launch (uniform)
         tile_order_workgroup(tile_cost, n_tiles, tile_order, SG.ntx, SG.nty);
         return;
@@ -92,7 +97,7 @@ __global__ void __launch_bounds__(STRIP_THREADS) strip_count_kernel(
     // rectangle areas (= gradient-row slots; == pairs unless DIST) and visible Gaussians of this slice, from the
     // project stage's per-block sums
     const int64_t nblk = (n + 255) / 256;
-    for (uint32_t k = threadIdx.x; k < per_slice / 256; k += STRIP_THREADS) {
+    for (uint32_t k = threadIdx.x; block_sums && k < per_slice / 256; k += STRIP_THREADS) {
         const int64_t pb = L.g0 / 256 + k;
         if (pb < nblk) {
             atomicAdd(&s_acc[0], block_sums[pb]);
@@ -102,7 +107,7 @@ __global__ void __launch_bounds__(STRIP_THREADS) strip_count_kernel(
     __syncthreads();
     unsigned long long *row = table + (size_t)slice * SG.NS;
     for (uint32_t t = threadIdx.x; t < SG.NS; t += STRIP_THREADS) row[t] = s_hist[t];
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && block_sums) {
         slice_pairs[slice] = s_acc[0];
         slice_vis[slice] = s_acc[1];
     }
@@ -114,8 +119,9 @@ __global__ void __launch_bounds__(STRIP_THREADS) strip_count_kernel(
 // (entries << 32 | pairs) sums never carry from the low half: a strip lists at most 8 N < 2^32 pairs.
 __global__ void __launch_bounds__(256) strip_colscan_kernel(
     const unsigned long long *__restrict__ table, unsigned long long *__restrict__ scan, uint32_t S, uint32_t NS,
-    unsigned long long *__restrict__ strip_tot) {
+    unsigned long long *__restrict__ strip_tot, const unsigned long long *__restrict__ gate) {
     static_assert(GS_BIN_SLICES == 256, "16 groups of 16 slices");
+    if (gate && *gate == 0) return;  // (see strip_count_kernel)
     __shared__ unsigned long long s_tot[16][17];
     const uint32_t col = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const uint32_t t = blockIdx.x * 16 + col;
@@ -178,8 +184,10 @@ __global__ void __launch_bounds__(STRIP_THREADS) strip_scatter_kernel(
     const unsigned long long *__restrict__ strip_tot, unsigned long long *__restrict__ strip_base,
     const uint32_t *__restrict__ slice_pairs, const uint32_t *__restrict__ slice_vis, uint64_t max_pairs,
     unsigned long long *__restrict__ out, uint32_t *__restrict__ pair_offsets,
-    unsigned long long *__restrict__ counters) {
+    unsigned long long *__restrict__ counters, const uint32_t *__restrict__ cut,
+    const unsigned long long *__restrict__ gate) {
     extern __shared__ unsigned long long s_dyn[];
+    if (gate && *gate == 0) return;  // (see strip_count_kernel)
     uint32_t *s_cur = reinterpret_cast<uint32_t *>(s_dyn), *s_gd = s_cur + SG.NS;
     unsigned long long *s_stage = s_dyn + SG.NS;  // 2 NS uint32 = NS uint64
     __shared__ uint32_t s_wave[STRIP_THREADS / 64];
@@ -265,6 +273,7 @@ __global__ void __launch_bounds__(STRIP_THREADS) strip_scatter_kernel(
             counters[GS_CNT_BIG] = 0;  // strip_sort_kernel queues the tiles whose list exceeds its LDS window
             counters[GS_CNT_GROUPS] = 0;  // big_list_sort_kernel queues the groups it cut for group_sort_kernel
             counters[GS_CNT_MAXLIST] = 0;  // strip_sort_kernel: longest list above GS_LONGEST_MIN pairs
+            if (!gate) counters[GS_CNT_RANPAST] = 0;  // raised by a tile that ran past its occlusion cut (raster_fwd.hip)
         }
     }
     if (overflow) return;  // uniform
@@ -324,7 +333,8 @@ __global__ void __launch_bounds__(STRIP_THREADS) strip_scatter_kernel(
                                       s_stage[slot] = e;
                                   else
                                       out[s_gd[strip] + slot] = e;
-                              });
+                              },
+                              cut);
         }
     }
     __syncthreads();
@@ -339,7 +349,8 @@ __global__ void __launch_bounds__(STRIP_THREADS) strip_scatter_kernel(
 }  // namespace
 
 // LDS of the count kernel: 8 B per strip; of the scatter kernel: 8 B per strip + the staging buffer
-int gs_stage_strip_bin(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream) {
+// `second_pass`: the untrimmed re-run of a GS_FRAME_OCCLUSION_CULL frame, every kernel gated on counters[GS_CNT_RANPAST]
+int gs_stage_strip_bin(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream, bool second_pass) {
     gs_frame_geom G = gs_frame_geometry(f);
     const gs_strip_plan plan = gs_strip_plan_for(f->N, G.ntx, G.nty);
     const gs_strip_geom SG = plan.geom;
@@ -360,23 +371,31 @@ int gs_stage_strip_bin(const gs_frame *f, const gs_frame_ws &ws, hipStream_t str
     unsigned long long *table = (unsigned long long *)ws.strip_table, *scan = table + (size_t)GS_BIN_SLICES * SG.NS;
     const size_t lds_count = sizeof(unsigned long long) * SG.NS;
     const size_t lds_scatter = sizeof(unsigned long long) * ((size_t)SG.NS + plan.cap);
+    const unsigned long long *gate = second_pass ? ws.counters + GS_CNT_RANPAST : nullptr;
+    const uint32_t *cut = (!second_pass && gs_frame_occlusion_cull(f)) ? ws.cut : nullptr;
 #define GS_LAUNCH_STRIP(DIST)                                                                                          \
     do {                                                                                                               \
-        if (!gs_frame_fused_count(f)) { /* else: counted by the project stage (frame_project_count_kernel) */            \
+        if (second_pass) { /* recount from the rectangles, untrimmed; no tile-order workgroup, no slice sums */          \
+            hipLaunchKernelGGL(strip_count_kernel<DIST>, dim3(plan.slices), dim3(STRIP_THREADS), lds_count, stream,    \
+                               ws.rects, ws.rec_geom, D, f->N, plan.per_slice, SG, plan.slices, table,                 \
+                               (const uint32_t *)nullptr, (const uint32_t *)nullptr, ws.slice_pairs, ws.slice_vis,     \
+                               ws.tile_cost, (uint32_t)G.n_tiles, ws.tile_order, gate);                                \
+            GS_CHECK_LAUNCH();                                                                                         \
+        } else if (!gs_frame_fused_count(f)) { /* else: counted by the project stage (frame_project_count_kernel) */   \
             hipLaunchKernelGGL(strip_count_kernel<DIST>, dim3(plan.slices + 1), dim3(STRIP_THREADS), lds_count, stream,\
                                ws.rects, ws.rec_geom, D, f->N, plan.per_slice, SG, plan.slices, table, ws.block_sums,  \
                                ws.block_vis, ws.slice_pairs, ws.slice_vis, ws.tile_cost, (uint32_t)G.n_tiles,          \
-                               ws.tile_order);                                                                         \
+                               ws.tile_order, (const unsigned long long *)nullptr);                                    \
             GS_CHECK_LAUNCH();                                                                                         \
         }                                                                                                              \
         hipLaunchKernelGGL(strip_colscan_kernel, dim3((unsigned)gs_div_up(SG.NS, 16)), dim3(256), 0, stream, table,    \
-                           scan, plan.slices, SG.NS, (unsigned long long *)ws.strip_tot);                              \
+                           scan, plan.slices, SG.NS, (unsigned long long *)ws.strip_tot, gate);                        \
         GS_CHECK_LAUNCH();                                                                                             \
         hipLaunchKernelGGL(strip_scatter_kernel<DIST>, dim3(plan.slices), dim3(STRIP_THREADS), lds_scatter, stream,    \
                            ws.rects, ws.rec_geom, D, f->N, plan.per_slice, SG, plan.slices, plan.cap, scan,            \
                            (const unsigned long long *)ws.strip_tot, (unsigned long long *)ws.strip_base,              \
                            ws.slice_pairs, ws.slice_vis, (uint64_t)f->max_pairs, (unsigned long long *)ws.keys_a,      \
-                           f->training ? ws.pair_offsets : nullptr, ws.counters);                                      \
+                           f->training ? ws.pair_offsets : nullptr, ws.counters, cut, gate);                           \
         GS_CHECK_LAUNCH();                                                                                             \
     } while (0)
     if (dist)

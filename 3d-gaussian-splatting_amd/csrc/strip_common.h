@@ -18,9 +18,13 @@ namespace {
 // the strip << 29 | last covered tile << 26 | gaussian; pairs = listed tiles of the run.  DIST: a tile of the
 // bounding square is listed iff gs_dist_listed says so; runs without a listed tile emit nothing (the same decision
 // in the count and in the scatter pass, and in strip_sort_kernel).
+// `cut` (GS_FRAME_OCCLUSION_CULL, gs_frame_layout.h; NULL: off): the run is trimmed at both ends by the tiles whose cut depth
+// lies in front of the Gaussian -- pairs the previous frame of this workspace proved to be behind the point where their
+// tile's pixels have all stopped; a run that loses all its tiles emits nothing.  The same table in the count and in the
+// scatter pass; strip_sort_kernel takes the run from the entry.
 template <bool DIST, typename Fn>
 __device__ __forceinline__ void walk_strips(const uint4 rc, int64_t g, const gs_strip_geom SG, float2 cxy,
-                                            const GsDistCull &D, Fn fn) {
+                                            const GsDistCull &D, Fn fn, const uint32_t *__restrict__ cut = nullptr) {
     const int lane = threadIdx.x & 63;
     const uint32_t y0 = rc.x & 0xffff, y1 = rc.x >> 16, x0 = rc.y & 0xffff, x1 = rc.y >> 16, dbits = rc.z;
     const bool vis = rc.w != 0;
@@ -28,7 +32,16 @@ __device__ __forceinline__ void walk_strips(const uint4 rc, int64_t g, const gs_
     const uint32_t ne = span * (y1 - y0);
     auto emit = [&](uint32_t sx, uint32_t iy, uint32_t ex0, uint32_t ex1, uint32_t id, uint32_t d, float px, float py) {
         const uint32_t t0 = sx * GS_STRIP_W;
-        const uint32_t lo = ex0 > t0 ? ex0 - t0 : 0, hi = (ex1 < t0 + GS_STRIP_W ? ex1 : t0 + GS_STRIP_W) - t0;  // [lo, hi)
+        uint32_t lo = ex0 > t0 ? ex0 - t0 : 0, hi = (ex1 < t0 + GS_STRIP_W ? ex1 : t0 + GS_STRIP_W) - t0;  // [lo, hi)
+        if (cut) {
+            const uint32_t *c = cut + iy * SG.ntx + t0;
+            uint32_t l = lo, h = hi;
+            while (l < h && d > c[l]) ++l;
+            while (h > l && d > c[h - 1]) --h;
+            if (l == h) return;
+            lo = l;
+            hi = h;
+        }
         uint32_t np = hi - lo;
         if (DIST) {
             np = 0;

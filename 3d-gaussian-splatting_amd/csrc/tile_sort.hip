@@ -660,8 +660,9 @@ __global__ void __launch_bounds__(256, STRIP_SORT_WPE) strip_sort_kernel(
     uint64_t *__restrict__ keys, uint32_t *__restrict__ ids, uint64_t *__restrict__ scratch,
     int32_t *__restrict__ ranges, gs_strip_geom SG, const float4 *__restrict__ rec_geom, GsDistCull D,
     uint32_t *__restrict__ big_queue, unsigned long long *__restrict__ big_count,
-    unsigned long long *__restrict__ longest) {
+    unsigned long long *__restrict__ longest, const unsigned long long *__restrict__ gate) {
     constexpr uint32_t W = GS_STRIP_W, WAVE_MAX = 512, ID_MASK = (1u << GS_STRIP_ID_BITS) - 1;
+    if (gate && *gate == 0) return;  // (see group_sort_kernel)
     static_assert(GS_STRIP_W == 8 || GS_STRIP_W == 4, "a workgroup owns four tiles: a strip or half a strip");
     __shared__ uint64_t s_a[CAP];
     __shared__ uint32_t s_scan[4];
@@ -1015,9 +1016,11 @@ __global__ void __launch_bounds__(256) group_sort_kernel(const uint4 *__restrict
                                                         const unsigned long long *__restrict__ counters,
                                                         uint32_t queue_cap, uint64_t *__restrict__ keys,
                                                         uint32_t *__restrict__ ids,
-                                                        const uint32_t *__restrict__ tmp_depth) {
+                                                        const uint32_t *__restrict__ tmp_depth,
+                                                        const unsigned long long *__restrict__ gate) {
     __shared__ uint64_t s_a[CAP];
     __shared__ uint32_t s_bcnt[256 * 8 + 4], s_wl[1 + 2 * 128], s_red[16];
+    if (gate && *gate == 0) return;  // second pass of a GS_FRAME_OCCLUSION_CULL frame: only if a tile ran past its cut
     const unsigned long long total = counters[GS_CNT_GROUPS];
     const uint32_t ng = total < queue_cap ? (uint32_t)total : queue_cap;
     for (uint32_t w = blockIdx.x; w < ng; w += gridDim.x) {
@@ -1045,8 +1048,10 @@ __global__ void __launch_bounds__(256) big_list_sort_kernel(const uint32_t *__re
                                                            uint64_t *__restrict__ scratch,
                                                            uint32_t *__restrict__ tmp_depth,
                                                            uint4 *__restrict__ group_queue, uint32_t queue_cap,
-                                                           unsigned long long *__restrict__ group_count) {
+                                                           unsigned long long *__restrict__ group_count,
+                                                           const unsigned long long *__restrict__ gate) {
     constexpr uint32_t NBIN = 1024, STACK = 192;
+    if (gate && *gate == 0) return;  // (see group_sort_kernel)
     static_assert(CAP == 2048, "groups are loaded eight keys per thread");
     __shared__ uint64_t s_a[CAP];
     __shared__ uint32_t s_scan[4];
@@ -1282,7 +1287,8 @@ int gs_stage_tile_sort_gather(const gs_frame *f, const gs_frame_ws &ws, const ui
 #endif
 // STRIP variant: entries (level 1, strip_bin.hip) -> tile ranges + sorted ids (+ sorted keys on request)
 int gs_stage_strip_sort(const gs_frame *f, const gs_frame_ws &ws, const uint64_t *entries, uint64_t *scratch,
-                        uint64_t *keys_out, uint32_t *ids_out, hipStream_t stream) {
+                        uint64_t *keys_out, uint32_t *ids_out, hipStream_t stream, bool second_pass) {
+    const unsigned long long *gate = second_pass ? ws.counters + GS_CNT_RANPAST : nullptr;
     gs_frame_geom G = gs_frame_geometry(f);
     const gs_strip_plan plan = gs_strip_plan_for(f->N, G.ntx, G.nty);
     GsDistCull D = {(float)(G.padW / 2), (float)(G.padH / 2), f->focal_x, f->focal_y, f->thresh};
@@ -1295,20 +1301,20 @@ int gs_stage_strip_sort(const gs_frame *f, const gs_frame_ws &ws, const uint64_t
     if (f->tile_culling_method == 0)
         hipLaunchKernelGGL((strip_sort_kernel<STRIP_SORT_CAP_, true>), dim3(grid), dim3(256), 0, stream, entries,
                            ws.strip_base, ws.strip_tot, ws.counters, keys_out, ids_out, scratch, ws.tile_ranges,
-                           plan.geom, ws.rec_geom, D, queue, ws.counters + GS_CNT_BIG, ws.counters + GS_CNT_MAXLIST);
+                           plan.geom, ws.rec_geom, D, queue, ws.counters + GS_CNT_BIG, ws.counters + GS_CNT_MAXLIST, gate);
     else
         hipLaunchKernelGGL((strip_sort_kernel<STRIP_SORT_CAP_, false>), dim3(grid), dim3(256), 0, stream, entries,
                            ws.strip_base, ws.strip_tot, ws.counters, keys_out, ids_out, scratch, ws.tile_ranges,
-                           plan.geom, ws.rec_geom, D, queue, ws.counters + GS_CNT_BIG, ws.counters + GS_CNT_MAXLIST);
+                           plan.geom, ws.rec_geom, D, queue, ws.counters + GS_CNT_BIG, ws.counters + GS_CNT_MAXLIST, gate);
     GS_CHECK_LAUNCH();
     if (dense) {
         const uint32_t qcap = (uint32_t)gs_group_queue_cap(f->max_pairs, G.n_tiles);
         hipLaunchKernelGGL((big_list_sort_kernel<STRIP_SORT_CAP_>), dim3((unsigned)G.n_tiles), dim3(256), 0, stream,
                            ws.big_tiles, ws.counters, ws.tile_ranges, keys_out, ids_out, scratch, ws.vals_b,
-                           ws.group_queue, qcap, ws.counters + GS_CNT_GROUPS);
+                           ws.group_queue, qcap, ws.counters + GS_CNT_GROUPS, gate);
         GS_CHECK_LAUNCH();
         hipLaunchKernelGGL((group_sort_kernel<STRIP_SORT_CAP_>), dim3(qcap < 8192u ? qcap : 8192u), dim3(256), 0, stream,
-                           ws.group_queue, ws.counters, qcap, keys_out, ids_out, ws.vals_b);
+                           ws.group_queue, ws.counters, qcap, keys_out, ids_out, ws.vals_b, gate);
     }
     GS_CHECK_LAUNCH();
     return 0;

@@ -38,6 +38,7 @@ class FrameStats:
     buckets: int  # 64-Gaussian buckets in the last backward's work list
     longest_list: int = 0  # longest tile list of the frame (lists of up to 1024 pairs are reported as 0)
     saturated_buckets: int = 0  # ... of them in tiles whose compositing stopped before the end of their list
+    cull_fallback: bool = False  # an occlusion-culled frame whose lists proved too short: rendered again from the full ones
 
 
 class FrameRenderer:
@@ -48,7 +49,7 @@ class FrameRenderer:
                  sort_mode: int = 2, tile_culling_method: str = "prob2", tile_culling_dist_thresh: float = 0.5,
                  emit_sorted_keys: bool = False, slice_sort: bool = False, table_bin: bool = False,
                  serial_long_lists: bool = False, long_lists: Optional[bool] = None, bwd_rows: Optional[bool] = None,
-                 force_strips: Optional[bool] = None):
+                 force_strips: Optional[bool] = None, occlusion_cull: Optional[bool] = None):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("FrameRenderer needs a HIP device; there is no CPU fallback")
@@ -72,6 +73,13 @@ class FrameRenderer:
         # GS_FRAME_LONG_LISTS (big-list sort + segmented compositing of long tile lists): True / False, or None = as soon
         # as an earlier frame of this renderer reported a tile list beyond LONG_LIST_FLAG_AT = 6,144 pairs (the counters that auto_grow reads
         # back anyway carry the longest list).  The workspace capacity plays no part in it.
+        # GS_FRAME_OCCLUSION_CULL (include/gs_abi.h): inference frames drop, at emission, the pairs behind the depth at which
+        # the PREVIOUS forward of this workspace saw all pixels of their tile stop -- exact (a frame whose trimmed lists
+        # prove too short is rendered again from the full ones on the device, inside the same call).  None / True: on for
+        # every frame that follows a forward of the same size in the same workspace; False: never.  `stats().pairs` of a
+        # culled frame counts the pairs that were emitted.
+        self.occlusion_cull = False if (occlusion_cull is None and os.environ.get("GS_NO_CULL", "") == "1") else occlusion_cull  # (GS_NO_CULL=1: A/B runs)
+        self._cut_key = None  # (workspace address, width, height) of the inference forward that left the current cut table behind
         self.long_lists = long_lists
         self._long_lists_seen = False
         self._long_sort_seen = False  # GS_FRAME_LONG_SORT: a list beyond the per-tile sort's LDS window was seen (see _note_lists)
@@ -92,14 +100,14 @@ class FrameRenderer:
         # head room as soon as the copy of an overflowed frame has landed (that one frame was rendered empty /
         # truncated); False: never check.
         self.auto_grow = auto_grow
-        self._async_host = torch.zeros(5, dtype=torch.int64).pin_memory()
+        self._async_host = torch.zeros(_lib.GS_STATS_TAGGED_N, dtype=torch.int64).pin_memory()
         self._async_event: Optional[torch.cuda.Event] = None
         self.headroom = 1.25
         # 0: LSD radix on 64-bit keys, 1: tile-bit radix + per-tile LDS sort, 2: LDS counting sort by tile
         # + per-tile LDS sort (all three give the same list)
         self.sort_mode = int(sort_mode)
         self._ws: Optional[torch.Tensor] = None
-        self._stats_host = torch.zeros(5, dtype=torch.int64).pin_memory()
+        self._stats_host = torch.zeros(_lib.GS_STATS_TAGGED_N, dtype=torch.int64).pin_memory()
         self._frame: Optional[_lib.GsFrame] = None
         self._frame_serial = 0  # counts forwards: autograd checks that backward() belongs to the latest one
         self._cam_cache = {}
@@ -133,6 +141,7 @@ class FrameRenderer:
                self.tile_culling_method, self.tile_culling_dist_thresh, self.thresh, self.scale_activation,
                self.emit_sorted_keys, self.slice_sort, self.table_bin, self.force_strips, self.serial_long_lists,
                self.long_lists, self._long_lists_seen, self._long_sort_seen, self.bwd_rows, self._bwd_rows_seen,
+               self.occlusion_cull, self._cut_key,
                self._ws.data_ptr() if self._ws is not None else 0)
         cached = getattr(self, "_desc_cache", None)
         if cached is not None and cached[0] == key:
@@ -218,9 +227,13 @@ class FrameRenderer:
         if self._ws is None or self._ws.numel() < need:
             self._release_workspace()  # side-stream work of an earlier training frame may still touch the old one
             self._ws = torch.empty(int(need) + 256, dtype=torch.uint8, device=self.device)
+            self._cut_key = None  # a fresh allocation: no cut table
         base = self._ws.data_ptr()
         f.workspace = (base + 255) // 256 * 256
         f.workspace_bytes = self._ws.numel() - (f.workspace - base)
+        if self.occlusion_cull is not False and not training and not self.emit_sorted_keys and \
+                self._cut_key == (base, grid.width, grid.height):
+            f.flags |= _lib.GS_FRAME_OCCLUSION_CULL  # (the library ignores it where the cull does not apply)
         self._grid = grid
         return f
 
@@ -233,6 +246,7 @@ class FrameRenderer:
         if self._ws is not None and self._async:
             _lib.check(_lib.gs_frame_async_wait(self._async, self._stream().cuda_stream), "gs_frame_async_wait")
             self._frame = None
+        self._cut_key = None
 
     def __del__(self):
         try:
@@ -285,6 +299,12 @@ class FrameRenderer:
     LONG_LIST_FLAG_AT = int(os.environ.get("GS_FRAME_LONG_LIST_FLAG_AT", "6144"))
     LONG_LIST_PAIRS_PER_STEP = int(os.environ.get("GS_FRAME_LONG_LIST_PAIRS_PER_STEP", "400"))
 
+    def _note_cut_table(self, f):
+        """Every inference frame's compositing launch leaves the per-tile occlusion cuts of ITS frame in the workspace: the
+        next forward of the same size may use them (GS_FRAME_OCCLUSION_CULL).  A training forward does not write the table
+        (and may use the workspace differently): no cull right behind one."""
+        self._cut_key = None if f.training else (self._ws.data_ptr(), int(f.width), int(f.height))
+
     def _note_lists(self, longest: int, pairs: int):
         self._long_sort_seen = self._long_sort_seen or longest > self.LONG_SORT_FLAG_AT
         self._long_lists_seen = self._long_lists_seen or \
@@ -298,8 +318,11 @@ class FrameRenderer:
         if self._async_event is not None and self._frame_serial - self._async_serial >= self.ASYNC_COUNTER_LAG:
             self._async_event.synchronize()
         if self._async_event is not None and self._async_event.query():
-            v, m, o, b, longest = (int(x) for x in self._async_host.tolist())
+            h = self._async_host.tolist()
+            v, m, o, b, longest, tag = (int(h[k]) for k in (0, 1, 2, 3, 9, 11))
             self._async_event = None
+            if (tag & 0xffffffff) != (self._async_serial & 0xffffffff):
+                return  # (cannot happen in stream order; counters without their frame's tag are not acted upon)
             self._note_lists(longest, m)
             # (NOT the backward-kernel choice: counters that arrive asynchronously would make it -- and with it the
             # gradients' last bits -- depend on host timing; it moves at synchronous stats() calls only)
@@ -347,6 +370,7 @@ class FrameRenderer:
             _lib.check(_lib.gs_frame_forward(C.byref(f), stream), "gs_frame_forward")
             self._frame = f
             self._frame_serial += 1
+            self._note_cut_table(f)
             self._keep = (pos, quat, scale, opa, rgb, image, padded)
             if sync_check:
                 st = self.stats()
@@ -358,10 +382,10 @@ class FrameRenderer:
                     self.max_pairs = int(st.pairs * self.headroom * self.headroom) + 1024  # takes effect next frame
                 break
             if self.auto_grow == "async" and self._async_event is None:  # one copy in flight at a time
-                _lib.check(_lib.gs_frame_stats_async(C.byref(f), self._async_host.data_ptr(), stream),
-                           "gs_frame_stats_async")
-                _lib.check(_lib.gs_frame_longest_list_async(C.byref(f), self._async_host.data_ptr() + 32, stream),
-                           "gs_frame_longest_list_async")
+                # tagged with the frame's serial number (include/gs_abi.h: the counters say which frame they belong to)
+                _lib.check(_lib.gs_frame_stats_tagged_async(C.byref(f), self._frame_serial & 0xffffffff,
+                                                            self._async_host.data_ptr(), stream),
+                           "gs_frame_stats_tagged_async")
                 self._async_event = torch.cuda.Event()
                 self._async_event.record(self._stream())
                 self._async_serial = self._frame_serial
@@ -452,11 +476,11 @@ class FrameRenderer:
             self._frame = f
             self._frame_serial += 1
             self._keep = (*b["keep"], b["image"], b["padded"])
+            self._note_cut_table(f)
             if self.auto_grow == "async" and self._async_event is None:  # one copy in flight at a time
-                _lib.check(_lib.gs_frame_stats_async(C.byref(f), self._async_host.data_ptr(), stream),
-                           "gs_frame_stats_async")
-                _lib.check(_lib.gs_frame_longest_list_async(C.byref(f), self._async_host.data_ptr() + 32, stream),
-                           "gs_frame_longest_list_async")
+                _lib.check(_lib.gs_frame_stats_tagged_async(C.byref(f), self._frame_serial & 0xffffffff,
+                                                            self._async_host.data_ptr(), stream),
+                           "gs_frame_stats_tagged_async")
                 self._async_event = torch.cuda.Event()
                 self._async_event.record(self._stream())
                 self._async_serial = self._frame_serial
@@ -539,6 +563,7 @@ class FrameRenderer:
                        "gs_frame_forward_profile")
         self._frame = f
         self._frame_serial += 1
+        self._note_cut_table(f)
         self._keep = (pos, quat, scale, opa, rgb, image, padded)
         return dict(zip(("project", "scan_emit", "sort", "ranges", "raster", "total"), (float(x) for x in ms)))
 
@@ -561,12 +586,13 @@ class FrameRenderer:
         if self._frame is None:
             raise RuntimeError("no frame rendered yet")
         stream = self._stream()
-        _lib.check(_lib.gs_frame_stats_async(C.byref(self._frame), self._stats_host.data_ptr(), stream.cuda_stream),
-                   "gs_frame_stats_async")
-        _lib.check(_lib.gs_frame_longest_list_async(C.byref(self._frame), self._stats_host.data_ptr() + 32,
-                                                    stream.cuda_stream), "gs_frame_longest_list_async")
+        tag = self._frame_serial & 0xffffffff
+        _lib.check(_lib.gs_frame_stats_tagged_async(C.byref(self._frame), tag, self._stats_host.data_ptr(),
+                                                    stream.cuda_stream), "gs_frame_stats_tagged_async")
         stream.synchronize()
-        v, m, o, b, longest = (int(x) for x in self._stats_host.tolist())
+        h = self._stats_host.tolist()
+        v, m, o, b, longest, ran_past = (int(h[k]) for k in (0, 1, 2, 3, 9, 10))
+        assert (int(h[11]) & 0xffffffff) == tag, "gs_frame_stats_tagged_async: the tag did not come back"
         self._note_lists(longest, m)
         # The bucket counter is written by the backward's preparation on the library's SIDE stream; the copy above is
         # ordered behind it only once a backward of this frame has been issued on this stream (it waits for the side
@@ -576,7 +602,9 @@ class FrameRenderer:
         bwd_done = getattr(self, "_bwd_serial", -1) == self._frame_serial
         if bwd_done:
             self._note_buckets(b)
-        return FrameStats(v, m, o, (b & 0xffffffff) if bwd_done else 0, longest, (b >> 32) if bwd_done else 0)
+        culled = bool(self._frame.flags & _lib.GS_FRAME_OCCLUSION_CULL)
+        return FrameStats(v, m, o, (b & 0xffffffff) if bwd_done else 0, longest, (b >> 32) if bwd_done else 0,
+                          bool(ran_past) and culled)
 
     def binning_variant(self) -> str:
         """Which binning / sort path the last frame took: "radix64", "radix_tile_bits", "table", "slice", "strip"."""

@@ -205,7 +205,9 @@ def main():
         r.max_pairs = int(st.pairs * 1.1) + 4096
         r.auto_grow = False  # from here on: no host synchronisation inside a frame
         r.forward(*params, cam)
-        return r, r.stats()
+        # (V, M of the FRAME: the first forward of a workspace lists every pair; the inference frames after it are
+        # occlusion-culled -- GS_FRAME_OCCLUSION_CULL -- and emit fewer: render_leg reports that count as well)
+        return r, st
 
     def time_block(fn, steps):
         """EXACTLY `steps` steps between barrier + synchronize on both sides; max over ranks (seconds)."""
@@ -273,8 +275,11 @@ def main():
         torch.cuda.synchronize()
         dt, blocks = time_frames(frame, steps, warmup)
         lat = latency_fps(frame)
+        st_run = r.stats()  # the steady-state frame: pairs EMITTED (after the occlusion cull), did it fall back
         res = {"fps": world * steps / dt, "ms": dt / steps * 1e3, "host_us": host_us, "stats": st, "latency": lat,
                "scene": scene, "cam": cam, "params": params, "renderer": r, "repeats": len(blocks),
+               "occlusion_cull": {"active": bool(r._frame.flags & 256), "pairs_emitted": st_run.pairs,
+                                  "pairs_of_the_frame": st.pairs, "fell_back": st_run.cull_fallback},
                "ms_min": min(blocks) / steps * 1e3, "ms_max": max(blocks) / steps * 1e3}
         if rank == 0:
             prof = [r.profile_forward(*params, cam) for _ in range(25)][5:]
@@ -358,6 +363,9 @@ def main():
                    "tile_pairs": st.pairs, "width": W, "height": H,
                    "parallelism": f"view-sharded x{world} (no data-path collective)", "frames_in_flight": 1},
         "host_us_per_frame": round(head["host_us"], 1),
+        # temporal occlusion cull (include/gs_abi.h, GS_FRAME_OCCLUSION_CULL): the steady-state frame emits / sorts only the
+        # pairs in front of the depth at which the previous frame's tiles stopped; the image is bit-identical
+        "occlusion_cull": head["occlusion_cull"],
         # the reference quotes FPS as one frame between two events with a synchronisation per frame (train.py:259-266);
         # `value` is throughput (K frames queued, one synchronisation) -- both, side by side
         "latency_fps": head["latency"]["fps"], "latency": head["latency"],
@@ -460,7 +468,8 @@ def main():
                            "ms_per_frame_min": round(c2["ms_min"], 4), "ms_per_frame_max": round(c2["ms_max"], 4),
                            "visible": c2["stats"].visible,
                            "tile_pairs": c2["stats"].pairs, "host_us_per_frame": round(c2["host_us"], 1),
-                           "latency_fps": c2["latency"]["fps"], "latency": c2["latency"]}
+                           "latency_fps": c2["latency"]["fps"], "latency": c2["latency"],
+                           "occlusion_cull": c2["occlusion_cull"]}
             if rank == 0:
                 out["cfg2"].update(roofline=c2["roofline"], stages=c2["stages"], frame_roofline=c2["frame_roofline"])
             del c2

@@ -34,7 +34,9 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-/* 6 (round 5): gs_frame_backward_adam (the backward with the optimizer step fused in); gs_frame_debug_bwd_exec_rows; GS_FRAME_BWD_ROWS and the saturated-bucket count in the upper half of the
+/* 7 (round 6): GS_FRAME_LONG_SORT, GS_FRAME_OCCLUSION_CULL + gs_frame_cull_fallback_async; gs_frame_stats_serial (the frame the
+ * counters belong to).
+ * 6 (round 5): gs_frame_backward_adam (the backward with the optimizer step fused in); gs_frame_debug_bwd_exec_rows; GS_FRAME_BWD_ROWS and the saturated-bucket count in the upper half of the
  * `buckets` counter; SH gradient rows in whole 64-byte lines without per-row flags (workspace
  * layout only: no signature changed).
  * 5 (round 4): the frame in pieces -- gs_frame_forward_project + gs_frame_forward_rest == gs_frame_forward,
@@ -44,7 +46,7 @@ extern "C" {
  * gs_frame_debug_rects (records of culled Gaussians are no longer written), gs_frame_overflow_flag,
  * gs_adam_step_sharded, `fast = 0` of gs_draw / gs_draw_backward honoured, the long-list kernels follow GS_FRAME_LONG_LISTS alone (not the
  * workspace capacity).  3: gs_frame.async / flags. */
-#define GS_ABI_VERSION 6
+#define GS_ABI_VERSION 7
 
 #define GS_E_INVALID (-1)   /* bad argument (null pointer, negative size, bad enum)   */
 #define GS_E_UNSUPPORTED (-2) /* valid in the reference but not implemented here (none at present) */
@@ -201,6 +203,20 @@ int gs_sort_pairs_bits(uint64_t *keys0, uint32_t *vals0, uint64_t *keys1, uint32
                                        exact), so unlike the segmented compositing this half costs nothing but two launches in
                                        frames without such lists.  The caller sets it once gs_frame_longest_list_async reported
                                        a list beyond 2,048; GS_FRAME_LONG_LISTS implies it. */
+#define GS_FRAME_OCCLUSION_CULL 256   /* temporal occlusion cull (round 6): allow the frame to drop, at emission, the (tile, Gaussian)
+                                       pairs that lie behind the depth at which the PREVIOUS forward of this workspace saw all
+                                       pixels of their tile stop -- 71 % of the pairs of the 2.4 M-Gaussian scene are emitted,
+                                       scattered and sorted and never composited.  The image is exact (bit-identical to the
+                                       unculled frame): the dropped pairs are deeper than every kept one, and a tile that
+                                       reaches the end of a trimmed list with a live pixel makes the library render the frame
+                                       again from the full lists, on the device, inside the same call (five gated launches:
+                                       a few microseconds when nothing ran past its cut).  The CALLER's promise: the previous
+                                       forward of this workspace was an inference frame (training = 0: training forwards do
+                                       not write the table) of the same width and height (the cut table is per tile).
+                                       Ignored by training frames, frames with GS_FRAME_EMIT_SORTED_KEYS / GS_FRAME_LONG_LISTS /
+                                       GS_FRAME_SERIAL_LONG_LISTS, the "dist" listing and the table / radix variants.
+                                       gs_frame_stats_async then reports the pairs that were emitted (fewer than the frame
+                                       lists); gs_frame_cull_fallback_async tells whether the frame was re-rendered. */
 #define GS_FRAME_BWD_ROWS 64         /* rgb training frames: composite the backward with the row-layout kernel (lanes = 16
                                        Gaussians x 4 pixel quads, pixel rows whose pixels have all stopped are left out)
                                        instead of the pixel-parallel one.  Worth it when most of the frame's buckets belong
@@ -317,6 +333,24 @@ int gs_frame_stats_async(const gs_frame *f, int64_t *stats_host, gs_stream_t str
  * 1024 pairs are reported as 0), copied device->host asynchronously into *longest_host.  A caller that sees a value
  * above ~6144 sets GS_FRAME_LONG_LISTS on the following frames. */
 int gs_frame_longest_list_async(const gs_frame *f, int64_t *longest_host, gs_stream_t stream);
+
+/* The ABI-level guard against LAGGING counters (round 6).  A client that copies the counters
+ * asynchronously and looks at them frames later -- to grow its workspace, to set GS_FRAME_LONG_SORT / GS_FRAME_LONG_LISTS /
+ * GS_FRAME_BWD_ROWS -- must know WHICH frame they belong to: flags latched from the counters of frame k while frame k + 500
+ * is being issued made a training run timing-dependent in round 5.  This call enqueues, on `stream`: a fill of the counter
+ * block's tag word with `tag` (the client's frame number), then ONE device-to-host copy of GS_STATS_TAGGED_N = 12 values:
+ *   [0] visible, [1] emitted pairs, [2] overflow (0, or the pairs the frame needed), [3] buckets (low 32 bits: in the
+ *   backward's work list, high: of saturated tiles), [4..8] internal, [9] longest tile list (0 up to 1,024), [10] non-zero iff
+ *   an occlusion-culled frame was rendered again from its full lists, [11] the tag (both 32-bit halves).
+ * stats_host[11] == tag (low half) <=> the copy has landed and the values are those of the frame issued just before this
+ * call on `stream`.  stats_host should be pinned memory (the copy is asynchronous only then).  Recommended policy
+ * (gs_frame.py): one copy in flight, and never issue frame k + 8 before the counters of frame k have been looked at. */
+#define GS_STATS_TAGGED_N 12
+int gs_frame_stats_tagged_async(const gs_frame *f, uint32_t tag, int64_t *stats_host, gs_stream_t stream);
+
+/* Non-zero in *ran_past_host (after `stream` has reached this copy) iff the frame's lists had been trimmed
+ * (GS_FRAME_OCCLUSION_CULL) and a tile ran past its cut, i.e. the frame was rendered a second time from the full lists. */
+int gs_frame_cull_fallback_async(const gs_frame *f, int64_t *ran_past_host, gs_stream_t stream);
 
 /* (Validity, since ABI 4: `tiles_touched` is written by sort_modes 0 / 1 only -- sort_mode 2 keeps the count in
  * rects[i].w, gs_frame_debug_rects -- and the rec_* records are written for VISIBLE Gaussians only: the record of a

@@ -157,6 +157,96 @@ def test_lists_beyond_the_sort_window_switch_the_sort_alone(gpu):
     assert all(torch.equal(a, b) for a, b in zip(*grads))
 
 
+# ------------------------------------------------------------------ temporal occlusion cull (GS_FRAME_OCCLUSION_CULL)
+def _dense_case(n=60_000, W=192, H=128, seed=3, yaw=0.0):
+    scene = make_scene(n, W, H, seed=seed)
+    scene.opa += 3.0  # opaque: every tile's pixels stop long before the end of its list
+    return scene, make_camera(W, H, yaw_deg=yaw)
+
+
+def test_occlusion_cull_static_camera_is_bit_exact(gpu):
+    """Round 6.  The second and later inference frames of a renderer drop, at emission, the pairs behind the depth at which
+    the previous frame saw all pixels of their tile stop: fewer pairs emitted and sorted, no fallback, and the image is
+    BIT-identical to the first (unculled) frame's and to a renderer with the cull off; it matches the oracle."""
+    scene, cam = _dense_case()
+    of = OracleFrame(scene, cam)
+    params = to_torch(scene, gpu)
+    r = FrameRenderer(gpu, max_pairs=len(of.ids) + 64, auto_grow=False)
+    off = FrameRenderer(gpu, max_pairs=len(of.ids) + 64, auto_grow=False, occlusion_cull=False)
+    first, _ = r.forward(*params, cam)
+    st1 = r.stats()
+    assert not (r._frame.flags & 256) and st1.pairs == len(of.ids) and not st1.cull_fallback
+    assert np.abs(first.cpu().numpy() - of.image).max() < IMG_ATOL
+    for _ in range(3):
+        img, _ = r.forward(*params, cam)
+        st = r.stats()
+        assert r._frame.flags & 256 and r.binning_variant() == "strip"
+        assert st.pairs < 0.6 * len(of.ids) and st.visible == st1.visible and st.overflow == 0 and not st.cull_fallback
+        assert torch.equal(img, first)
+        ref, _ = off.forward(*params, cam)
+        assert not (off._frame.flags & 256) and off.stats().pairs == len(of.ids) and torch.equal(ref, first)
+    # frames that must keep their full lists: training, exported sorted keys
+    rt = FrameRenderer(gpu, max_pairs=len(of.ids) + 64, auto_grow=False, training=True)
+    rk = FrameRenderer(gpu, max_pairs=len(of.ids) + 64, auto_grow=False, emit_sorted_keys=True)
+    for rr in (rt, rk):
+        for _ in range(2):
+            rr.forward(*params, cam)
+            assert rr.stats().pairs == len(of.ids)
+    assert np.array_equal(rk.debug_views()["sorted_ids"].cpu().numpy(), of.ids)
+
+
+def test_occlusion_cull_moving_camera_falls_back_and_stays_exact(gpu):
+    """A camera that yaws, jumps and comes back; then another scene (thin: nothing saturates) and another Gaussian count in
+    the same workspace.  Every frame equals, bit for bit, the frame of a renderer with the cull off -- whether its
+    trimmed lists sufficed (no fallback) or a tile ran past its cut and the library rendered the frame again from the
+    full lists.  Both happen in the sweep.  Spot checks against the oracle."""
+    scene, _ = _dense_case()
+    params = to_torch(scene, gpu)
+    r = FrameRenderer(gpu, max_pairs=1 << 21, auto_grow=False)
+    off = FrameRenderer(gpu, max_pairs=1 << 21, auto_grow=False, occlusion_cull=False)
+    yaws = [0.0, 0.0, 0.25, 0.5, 1.0, 2.0, 4.0, 8.0, 30.0, 30.0, -20.0, 0.0, 0.0]
+    fell, clean, culled_share = 0, 0, []
+    for k, yaw in enumerate(yaws):
+        cam = make_camera(192, 128, yaw_deg=yaw)
+        cam.tran = np.array([0.02 * k, -0.01 * k, 0.05 * (k % 3)], np.float32)
+        img, _ = r.forward(*params, cam)
+        st = r.stats()
+        ref, _ = off.forward(*params, cam)
+        full = off.stats().pairs
+        assert torch.equal(img, ref), (k, yaw, st)
+        if k:
+            assert r._frame.flags & 256
+            fell += int(st.cull_fallback)
+            clean += int(not st.cull_fallback)
+            if not st.cull_fallback:
+                culled_share.append(1.0 - st.pairs / full)
+            else:
+                assert st.pairs == full  # the counters are those of the second, untrimmed pass
+        if k in (1, 8, 12):
+            assert np.abs(img.cpu().numpy() - OracleFrame(scene, cam).image).max() < IMG_ATOL
+    assert fell >= 2 and clean >= 4, (fell, clean)
+    assert max(culled_share) > 0.4, culled_share
+    # another scene in the same workspace: thin (no tile saturates -> the cut table it leaves is all GS_NO_CUT) ...
+    cam = make_camera(192, 128, yaw_deg=1.0)
+    thin = make_scene(20_000, 192, 128, seed=9)
+    thin.opa[:] = -4.0
+    p_thin = to_torch(thin, gpu)
+    for k in range(3):
+        img, _ = r.forward(*p_thin, cam)
+        st = r.stats()
+        ref, _ = off.forward(*p_thin, cam)
+        assert torch.equal(img, ref) and (k == 0 or not st.cull_fallback)
+        assert k == 0 or st.pairs == off.stats().pairs  # nothing to cull
+    # ... and back to the dense one with another Gaussian count (the table's place in the workspace does not depend on N)
+    dense2, _ = _dense_case(n=45_000, seed=11)
+    p2 = to_torch(dense2, gpu)
+    for k in range(3):
+        img, _ = r.forward(*p2, cam)
+        ref, _ = off.forward(*p2, cam)
+        assert torch.equal(img, ref)
+    assert r.stats().pairs < off.stats().pairs and not r.stats().cull_fallback
+
+
 def test_small_scene_with_a_pile_switches_to_the_long_list_kernels(gpu):
     """below 131,072 Gaussians sort_mode 2 takes the TABLE variant, whose kernels used to report 0 for the
     longest list -- a small scene with a pile-up (the case the long-list kernels were built for) stayed on the serial path
@@ -891,6 +981,14 @@ def test_full_size_2p4M_forward_matches_oracle(gpu):
         assert np.array_equal(v["sorted_ids"].cpu().numpy(), of.ids)
         err = np.abs(img.cpu().numpy() - of.image)
         assert err.max() < IMG_ATOL, err.max()
+        if not variant:
+            # the next frame of the same renderer is occlusion-culled (strip variant): 71 % of this scene's pairs lie behind
+            # their tile's stop and are no longer emitted; the image is the same bit for bit
+            img2, _ = r.forward(*params, cam)
+            st2 = r.stats()
+            assert r._frame.flags & 256 and not st2.cull_fallback and st2.pairs < 0.45 * st.pairs, st2
+            assert torch.equal(img2, img)
+            print("cfg5 occlusion cull: pairs emitted", st2.pairs, "of", st.pairs)
         del r
 
 
