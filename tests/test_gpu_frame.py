@@ -77,15 +77,24 @@ def check_forward(gpu, scene, cam, training=False, sort_mode=2, emit_sorted_keys
     return of, r, params
 
 
-@pytest.mark.parametrize("sort_mode", [0, 1, 2, "2t", "2s"])
+@pytest.mark.parametrize("sort_mode", [2, "2t"])
 @pytest.mark.parametrize("n,W,H", [(10_000, 256, 256), (30_000, 333, 201), (2_000, 64, 48), (3_000, 40, 200)])
 def test_frame_forward_parity(gpu, n, W, H, sort_mode):
-    # 2: the strip variant (default); "2t": the table variant (GS_FRAME_TABLE_BIN); "2s": the slice-sorted variant
-    # (GS_FRAME_SLICE_SORT).  333 x 201 and 40 x 200: tile rows that end inside a strip / inside its first half
+    # 2: the strip variant (default); "2t": the table variant (GS_FRAME_TABLE_BIN, what small scenes take).
+    # 333 x 201 and 40 x 200: tile rows that end inside a strip / inside its first half
     check_forward(gpu, *case(n, W, H), sort_mode=sort_mode)
 
 
-@pytest.mark.parametrize("sort_mode", [1, 2, "2t", "2s"])
+@pytest.mark.parametrize("sort_mode", [0, 1, "2s"])
+def test_frame_forward_parity_fallback_variants(gpu, sort_mode):
+    """Round 6: the round-1 variants are no longer part of the frame path's test matrix -- sort_mode 0 / 1 (LSD radix on
+    the 64-bit key / on the tile bits; mode 1 is what grids beyond the LDS counters fall back to,
+    test_frame_forward_more_tiles_than_lds_counters) and the slice-sorted binning ("2s") are checked once here and at
+    full size in test_full_size_sortedness_and_mode_equivalence; gs_sort_pairs has its own test (test_gpu_kernels.py)."""
+    check_forward(gpu, *case(30_000, 333, 201), sort_mode=sort_mode)
+
+
+@pytest.mark.parametrize("sort_mode", [2, "2t"])
 def test_frame_forward_giant_bucket_sorted_in_chunks(gpu, sort_mode):
     # > 4096 pairs in one tile: the per-tile sort handles 2048-key chunks in LDS and the strides >= 2048 of the
     # last merge levels through global memory (the packed, the (key, id) and the gathered input variants)
@@ -347,7 +356,7 @@ def test_long_lists_sh_backward_hand_over_matches_oracle(gpu, sh_degree):
     print(f"long-list seam, degree {sh_degree}: lists {lens.min()} .. {lens.max()}, masked pixels {n_masked};", report)
 
 
-@pytest.mark.parametrize("sort_mode", [2, "2t", "2s"])
+@pytest.mark.parametrize("sort_mode", [2, "2t"])
 @pytest.mark.parametrize("n,W,H", [(10_000, 256, 256), (40_000, 32, 32)])
 def test_frame_forward_emitted_sorted_keys(gpu, n, W, H, sort_mode):
     """GS_FRAME_EMIT_SORTED_KEYS: the per-tile sort also writes the sorted (tile << 32 | depth bits) keys (the default
@@ -392,12 +401,9 @@ def test_frame_forward_depth_clusters(gpu, n_sites, jitter):
     assert np.diff(of.accum).max() > 500  # 3000 sites: lists of up to ~520 (one wave each); 40 sites: thousands
 
 
-@pytest.mark.parametrize("sort_mode,n_big", [("2s", 60), (2, 230)])
+@pytest.mark.parametrize("sort_mode,n_big", [(2, 230)])
 def test_frame_forward_slice_larger_than_the_lds_staging_buffer(gpu, sort_mode, n_big):
-    """The slice-sorted variant of sort_mode 2 counting-sorts every slice of the Gaussian array by tile inside LDS and
-    streams it out; a slice with more pairs than the staging buffer holds (here: 60 screen-filling Gaussians next to
-    each other in the array, ~60 k pairs in one 256-Gaussian slice against ~19 k slots) stores straight to its region
-    instead -- same list.  Likewise the strip variant's scatter stages the ENTRIES of a slice (one per strip of eight
+    """The strip variant's scatter stages the ENTRIES of a slice (one per strip of eight
     tiles a Gaussian crosses: 125 per screen-filling Gaussian here, 230 of them = ~29 k against ~19.9 k slots) and
     stores the ones that do not fit straight to their final place; the half strips then hold far more than the 4096
     pairs of the LDS sort window and take the global path."""
@@ -549,7 +555,7 @@ def test_frame_sh_degree3_with_zero_band3_is_degree2(gpu):
     assert float(b3[:, :, 9:].abs().max()) > 0  # the zero band still receives its gradient
 
 
-@pytest.mark.parametrize("sort_mode", [0, 1, 2])
+@pytest.mark.parametrize("sort_mode", [2])
 def test_frame_forward_dense_tiles_multi_chunk(gpu, sort_mode):
     # ~1.5k Gaussians per tile: several 256-Gaussian LDS chunks per tile + early termination
     scene, cam = case(60_000, 96, 64, seed=3)
@@ -675,7 +681,7 @@ def test_frame_capacity_overflow_grows(gpu):
     assert r2.stats().overflow == len(of.ids)  # reported, never silently dropped
 
 
-@pytest.mark.parametrize("sort_mode", [0, 1, 2])
+@pytest.mark.parametrize("sort_mode", [2])
 def test_frame_repeatable_bitwise(gpu, sort_mode):
     scene, cam = case(10_000, 128, 128)
     r = FrameRenderer(gpu, max_pairs=1 << 17, auto_grow=False, sort_mode=sort_mode)
@@ -972,7 +978,7 @@ def test_full_size_2p4M_forward_matches_oracle(gpu):
     scene, cam = make_scene(n, W, H, seed=2023, use_sh=use_sh), make_camera(W, H)
     params = to_torch(scene, gpu)
     of = OracleFrame(scene, cam)
-    for variant in ({}, dict(table_bin=True), dict(slice_sort=True)):  # the three binning variants of sort_mode 2
+    for variant in ({}, dict(table_bin=True)):  # the strip (default) and the table variant of the binning
         r = FrameRenderer(gpu, max_pairs=7_600_000, auto_grow=False, **variant)
         img, _ = r.forward(*params, cam)
         st, v = r.stats(), r.debug_views()
