@@ -567,6 +567,13 @@ __global__ void __launch_bounds__(STRIP_THREADS) frame_project_count_kernel(
     RawGaussian cur = {}, nxt = {};
     if (in_range(threadIdx.x)) cur = load_raw(pos, quat, scale, opa, rgb, g0 + threadIdx.x, P.color_dim);
     for (uint32_t t = threadIdx.x; t < SG.NS; t += STRIP_THREADS) s_hist[t] = 0;
+    // occlusion cuts (GS_FRAME_OCCLUSION_CULL): the per-tile table is staged in LDS behind the histogram -- looked up from
+    // global memory, two to eight dependent loads per Gaussian inside this latency-bound kernel cost 62 us at 2.4 M Gaussians
+    // (first version, profiles/r06_c_*)
+    uint32_t *s_cut = reinterpret_cast<uint32_t *>(s_hist + SG.NS);
+    if (cut)
+        for (uint32_t t = threadIdx.x; t < n_tiles; t += STRIP_THREADS) s_cut[t] = cut[t];
+    const uint32_t *cut_tab = cut ? s_cut : nullptr;
     if (threadIdx.x < 2) s_acc[threadIdx.x] = 0;
     __syncthreads();
     settle(cur);
@@ -582,7 +589,7 @@ __global__ void __launch_bounds__(STRIP_THREADS) frame_project_count_kernel(
         acc_vis += vis;
         walk_strips<DIST>(rc, g0 + i, SG, cxy, D,
                           [&](uint32_t strip, uint32_t, uint32_t, uint32_t np) { atomicAdd(&s_hist[strip], (1ull << 32) | np); },
-                          cut);
+                          cut_tab);
         cur = nxt;
     }
     // rectangle areas (= gradient-row slots; == pairs unless DIST) and visible Gaussians of this slice
@@ -1534,11 +1541,12 @@ int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t strea
         if (dev < 64 && !((attr_done.load(std::memory_order_acquire) >> dev) & 1)) {
             std::lock_guard<std::mutex> lock(attr_mu);
             for (const void *fn : {(const void *)frame_project_count_kernel<false>, (const void *)frame_project_count_kernel<true>})
-                GS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, GS_STRIP_MAX * 8));
+                GS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, GS_BIN_LDS_BYTES));
             attr_done.fetch_or(1ull << dev, std::memory_order_release);
         }
         unsigned long long *table = (unsigned long long *)ws.strip_table;
-        const size_t lds = sizeof(unsigned long long) * SG.NS;
+        // (+ the per-tile occlusion cuts behind the histogram when the frame is culled: gs_frame_occlusion_cull checks the room)
+        const size_t lds = sizeof(unsigned long long) * SG.NS + (gs_frame_occlusion_cull(f) ? sizeof(uint32_t) * (size_t)G.n_tiles : 0);
         if (slice_end < 0) slice_end = (int)plan.slices;
         GS_CHECK_ARG(slice_begin >= 0 && slice_begin < slice_end && slice_end <= (int)plan.slices, "bad slice range");
         const uint32_t nsl = (uint32_t)(slice_end - slice_begin);
@@ -1618,7 +1626,9 @@ int gs_stage_sh_big_rows(const gs_frame *f, const gs_frame_ws &ws, hipStream_t s
 }
 
 // The projection backward with the Adam step in its epilogue (gs_frame_backward_adam): rgb colours, all Gaussians, one launch
-int gs_stage_project_backward_adam(const gs_frame *f, const gs_frame_ws &ws, const gs_adam_fused *a, hipStream_t stream) {
+// Everything gs_frame_backward_adam can reject about its optimizer argument, checked BEFORE anything is enqueued (ADVICE
+// round 5: a call rejected behind the raster backward left the caller's step counter ahead of the moments).
+int gs_validate_adam_fused(const gs_frame *f, const gs_adam_fused *a) {
     GS_CHECK_ARG(f->color_dim == 3, "color_dim must be 3");
     GS_CHECK_ARG(a->step >= 1, "step counts from 1 (torch.optim.Adam increments before the update)");
     GS_CHECK_ARG(a->beta1 >= 0.f && a->beta1 < 1.f && a->beta2 >= 0.f && a->beta2 < 1.f && a->eps >= 0.f, "bad hyper-parameters");
@@ -1629,6 +1639,12 @@ int gs_stage_project_backward_adam(const gs_frame *f, const gs_frame_ws &ws, con
                             a->exp_avg_sq[0], a->exp_avg_sq[1], a->exp_avg_sq[2], a->exp_avg_sq[4], a->grad_stat};
         for (const void *q : al) GS_CHECK_ARG(((uintptr_t)q & 15) == 0, "parameters, moments and statistic must be 16-byte aligned");
     }
+    return 0;
+}
+
+int gs_stage_project_backward_adam(const gs_frame *f, const gs_frame_ws &ws, const gs_adam_fused *a, hipStream_t stream) {
+    int vrc = gs_validate_adam_fused(f, a);
+    if (vrc) return vrc;
     if (f->N <= 0) return 0;
     ProjectParams P = make_params(f);
     gs_frame_geom Gf = gs_frame_geometry(f);

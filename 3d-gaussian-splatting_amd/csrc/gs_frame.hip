@@ -158,7 +158,10 @@ struct StageTimer {
 #ifndef GS_ASYNC_EVENT_FLAGS
 // fork / join between two streams of ONE device: no system-scope release / acquire fence with the event (the host never waits on
 // these events, and what the two streams hand each other lives in device memory)
-#define GS_ASYNC_EVENT_FLAGS (hipEventDisableTiming | hipEventDisableSystemFence)
+// (hipEventDisableSystemFence is documented for timing-only events; relying on each kernel's own agent-scope
+// release for cross-XCD visibility of the preparation's outputs is an undocumented runtime detail, and its gain was never
+// measured above noise.  Default: the documented flag only; -DGS_ASYNC_EVENT_FLAGS=... to experiment.)
+#define GS_ASYNC_EVENT_FLAGS hipEventDisableTiming
 #endif
 struct gs_frame_async {
     std::mutex mu;
@@ -413,6 +416,7 @@ extern "C" int gs_frame_backward_adam(const gs_frame *f, const float *grad_image
         gs_set_error("gs_frame_backward_adam: rgb colours only (color_dim 3): SH coefficient gradients are written by whole waves");
         return GS_E_UNSUPPORTED;
     }
+    if ((rc = gs_validate_adam_fused(f, adam))) return rc;  // before anything is enqueued
     if (f->N == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     gs_frame_ws ws = gs_frame_carve(f->workspace, f->N, f->max_pairs, f->width, f->height, f->color_dim, 1);

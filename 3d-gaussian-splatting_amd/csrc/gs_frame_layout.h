@@ -66,7 +66,9 @@ static inline gs_bin_plan gs_bin_plan_for(int64_t N, int64_t max_pairs, int n_ti
 // lone wave -- while the device idles: 0.60 ms (rgb) / 1.82 ms (SH degree 2) where the work is worth 0.21 / 1.0 ms.  Same-box
 // A/B (profiles/r05_n_*), 2048 / 1024 -> 512 / 512: pile forward 0.56 -> 0.38 ms (rgb), 1.51 -> 0.86 ms (SH); the densifying
 // soak's last block +10 ... +15 %; 512 / 256 and 1024 / 512 measured within 5 % of it.  Only flagged frames are concerned
-// (GS_FRAME_LONG_LISTS: a list beyond 2,048 was seen); a tile that saturates before 512 Gaussians never continues.
+// (GS_FRAME_LONG_LISTS: the caller's rule -- gs_frame.py flags once the longest list exceeds max(6,144, pairs / 400), round 6;
+// unflagged frames walk lists of any length with one wave by design, and lists beyond 2,048 take the big-list SORT alone,
+// GS_FRAME_LONG_SORT); a tile that saturates before 512 Gaussians never continues.
 #ifndef GS_LONG_MIN
 #define GS_LONG_MIN 512       // Gaussians a tile's own wave composites before the rest of its list is cut into segments
 #endif
@@ -158,9 +160,15 @@ static inline bool gs_frame_uses_strips(const gs_frame *f) {
 #endif
 static inline bool gs_frame_fused_count(const gs_frame *f) { return GS_FUSED_PROJECT_COUNT && gs_frame_uses_strips(f); }
 static inline bool gs_frame_occlusion_cull(const gs_frame *f) {
-    return (f->flags & GS_FRAME_OCCLUSION_CULL) && !f->training && f->N > 0 && f->tile_culling_method != 0 &&
-           !(f->flags & (GS_FRAME_EMIT_SORTED_KEYS | GS_FRAME_LONG_LISTS | GS_FRAME_SERIAL_LONG_LISTS)) &&
-           gs_frame_uses_strips(f) && GS_FUSED_PROJECT_COUNT;
+    if (!((f->flags & GS_FRAME_OCCLUSION_CULL) && !f->training && f->N > 0 && f->tile_culling_method != 0 &&
+          !(f->flags & (GS_FRAME_EMIT_SORTED_KEYS | GS_FRAME_LONG_LISTS | GS_FRAME_SERIAL_LONG_LISTS)) &&
+          gs_frame_uses_strips(f) && GS_FUSED_PROJECT_COUNT))
+        return false;
+    // the level-1 kernels keep the per-tile cuts in LDS next to their strip tables: 8 B per strip + 4 B per tile, and the
+    // scatter still wants a staging buffer worth having (1080p: 8 + 32 KiB of 160; beyond ~25 k tiles the frame is not culled)
+    const int ntx = (f->width + GS_TILE - 1) / GS_TILE, nty = (f->height + GS_TILE - 1) / GS_TILE;
+    const int64_t ns = (int64_t)((ntx + GS_STRIP_W - 1) / GS_STRIP_W) * nty;
+    return 8 * ns + 4 * (int64_t)ntx * nty + 8 * 4096 <= (int64_t)GS_BIN_LDS_BYTES;
 }
 // Table variant (small scenes: a frame is a chain of dependent launches of ~7 us each): the per-(slice, tile) count
 // (bin_count_kernel) is taken inside the project stage as well -- five launches per frame instead of six.
@@ -418,6 +426,7 @@ int gs_stage_project_backward(const gs_frame *f, const gs_frame_ws &ws, float *g
                               float *grad_scale, float *grad_opa, float *grad_rgb, int part, int64_t g_begin,
                               int64_t g_end, hipStream_t stream);
 int gs_stage_project_backward_adam(const gs_frame *f, const gs_frame_ws &ws, const gs_adam_fused *a, hipStream_t stream);
+int gs_validate_adam_fused(const gs_frame *f, const gs_adam_fused *a);
 int gs_stage_scan_emit(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream);
 int gs_stage_tile_sort(const gs_frame *f, const gs_frame_ws &ws, uint64_t *keys, uint32_t *ids, uint64_t *scratch,
                        hipStream_t stream);

@@ -184,12 +184,17 @@ __global__ void __launch_bounds__(STRIP_THREADS) strip_scatter_kernel(
     const unsigned long long *__restrict__ strip_tot, unsigned long long *__restrict__ strip_base,
     const uint32_t *__restrict__ slice_pairs, const uint32_t *__restrict__ slice_vis, uint64_t max_pairs,
     unsigned long long *__restrict__ out, uint32_t *__restrict__ pair_offsets,
-    unsigned long long *__restrict__ counters, const uint32_t *__restrict__ cut,
+    unsigned long long *__restrict__ counters, const uint32_t *__restrict__ cut, uint32_t n_tiles,
     const unsigned long long *__restrict__ gate) {
     extern __shared__ unsigned long long s_dyn[];
     if (gate && *gate == 0) return;  // (see strip_count_kernel)
     uint32_t *s_cur = reinterpret_cast<uint32_t *>(s_dyn), *s_gd = s_cur + SG.NS;
     unsigned long long *s_stage = s_dyn + SG.NS;  // 2 NS uint32 = NS uint64
+    // occlusion cuts (the same table the count pass used): staged in LDS behind the `cap` staged entries
+    uint32_t *s_cut = reinterpret_cast<uint32_t *>(s_stage + cap);
+    if (cut)
+        for (uint32_t t = threadIdx.x; t < n_tiles; t += STRIP_THREADS) s_cut[t] = cut[t];  // (barriers follow below)
+    const uint32_t *cut_tab = cut ? s_cut : nullptr;
     __shared__ uint32_t s_wave[STRIP_THREADS / 64];
     __shared__ unsigned long long s_wave64[4 * (STRIP_THREADS / 64)];
     const uint32_t slice = strip_slice_of_block(blockIdx.x, gridDim.x);
@@ -334,7 +339,7 @@ __global__ void __launch_bounds__(STRIP_THREADS) strip_scatter_kernel(
                                   else
                                       out[s_gd[strip] + slot] = e;
                               },
-                              cut);
+                              cut_tab);
         }
     }
     __syncthreads();
@@ -370,9 +375,11 @@ int gs_stage_strip_bin(const gs_frame *f, const gs_frame_ws &ws, hipStream_t str
     }
     unsigned long long *table = (unsigned long long *)ws.strip_table, *scan = table + (size_t)GS_BIN_SLICES * SG.NS;
     const size_t lds_count = sizeof(unsigned long long) * SG.NS;
-    const size_t lds_scatter = sizeof(unsigned long long) * ((size_t)SG.NS + plan.cap);
     const unsigned long long *gate = second_pass ? ws.counters + GS_CNT_RANPAST : nullptr;
     const uint32_t *cut = (!second_pass && gs_frame_occlusion_cull(f)) ? ws.cut : nullptr;
+    // a culled frame's scatter gives T / 2 staged entries (4 B per tile) to the cut table
+    const uint32_t cap = cut ? plan.cap - ((uint32_t)G.n_tiles + 1) / 2 : plan.cap;
+    const size_t lds_scatter = sizeof(unsigned long long) * ((size_t)SG.NS + cap) + (cut ? sizeof(uint32_t) * (size_t)G.n_tiles : 0);
 #define GS_LAUNCH_STRIP(DIST)                                                                                          \
     do {                                                                                                               \
         if (second_pass) { /* recount from the rectangles, untrimmed; no tile-order workgroup, no slice sums */          \
@@ -392,10 +399,10 @@ int gs_stage_strip_bin(const gs_frame *f, const gs_frame_ws &ws, hipStream_t str
                            scan, plan.slices, SG.NS, (unsigned long long *)ws.strip_tot, gate);                        \
         GS_CHECK_LAUNCH();                                                                                             \
         hipLaunchKernelGGL(strip_scatter_kernel<DIST>, dim3(plan.slices), dim3(STRIP_THREADS), lds_scatter, stream,    \
-                           ws.rects, ws.rec_geom, D, f->N, plan.per_slice, SG, plan.slices, plan.cap, scan,            \
+                           ws.rects, ws.rec_geom, D, f->N, plan.per_slice, SG, plan.slices, cap, scan,                 \
                            (const unsigned long long *)ws.strip_tot, (unsigned long long *)ws.strip_base,              \
                            ws.slice_pairs, ws.slice_vis, (uint64_t)f->max_pairs, (unsigned long long *)ws.keys_a,      \
-                           f->training ? ws.pair_offsets : nullptr, ws.counters, cut, gate);                           \
+                           f->training ? ws.pair_offsets : nullptr, ws.counters, cut, (uint32_t)G.n_tiles, gate);      \
         GS_CHECK_LAUNCH();                                                                                             \
     } while (0)
     if (dist)

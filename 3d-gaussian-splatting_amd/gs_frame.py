@@ -507,6 +507,11 @@ class FrameRenderer:
         f = self._frame
         if f is None or not f.training:
             raise RuntimeError("backward_adam() needs a preceding forward(training=True)")
+        # the step is applied to whatever the frame's pointers address: they must be the caller's LIVE parameter tensors
+        # (a forward handed converted / non-contiguous tensors would step a temporary copy silently)
+        for ptr, t in zip((f.pos, f.quat, f.scale, f.opa, f.rgb), self._keep[:5]):
+            if int(ptr or 0) != t.data_ptr():
+                raise RuntimeError("backward_adam(): the frame was rendered from tensors that are no longer alive")
         with torch.cuda.device(self.device):
             _lib.check(_lib.gs_frame_backward_adam(C.byref(f), grad_image.contiguous().data_ptr(), C.byref(adam),
                                                    self._stream().cuda_stream), "gs_frame_backward_adam")

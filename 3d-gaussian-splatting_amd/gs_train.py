@@ -238,7 +238,11 @@ class ImageLoss:
 
 
 class Trainer:
-    """One view per step on this rank; gradients are averaged over ranks when torch.distributed is up."""
+    """One view per step on this rank; gradients are averaged over ranks when torch.distributed is up.
+
+    NOTE for callers that read gradients: with ``fuse_adam`` active (the default on one rank with rgb colours) the
+    optimizer step runs inside the backward's last kernel and ``flat.grads`` is NOT written -- it holds whatever an
+    earlier, unfused step left there.  Pass ``fuse_adam=False`` to get the gradients of every step."""
 
     def __init__(self, params: Sequence[torch.Tensor], cameras, targets: Sequence[torch.Tensor],
                  opt: Optional[TrainOptions] = None, world_size: int = 1, max_pairs: int = 1 << 20,

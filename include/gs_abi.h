@@ -331,7 +331,8 @@ int gs_frame_stats_async(const gs_frame *f, int64_t *stats_host, gs_stream_t str
 
 /* Length of the longest tile list of the last forward on this workspace (sort_mode 2, strip variant; lists of up to
  * 1024 pairs are reported as 0), copied device->host asynchronously into *longest_host.  A caller that sees a value
- * above ~6144 sets GS_FRAME_LONG_LISTS on the following frames. */
+ * above 2,048 sets GS_FRAME_LONG_SORT, one above max(6,144, pairs / 400) GS_FRAME_LONG_LISTS on the following frames
+ * (gs_frame.py, FrameRenderer._note_lists: where the segmented compositing starts to pay, for every colour model). */
 int gs_frame_longest_list_async(const gs_frame *f, int64_t *longest_host, gs_stream_t stream);
 
 /* The ABI-level guard against LAGGING counters (round 6).  A client that copies the counters

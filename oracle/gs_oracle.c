@@ -565,6 +565,34 @@ static void calc_sh(int nb, const float *dir, float *out) {
     }
 }
 
+/* Conditioning of the basis values (test infrastructure, for the gradient tolerance's scale): every monomial of calc_sh with
+ * its magnitude, every difference replaced by the sum of its operands' magnitudes.  b6 = C (2 zz - xx - yy), b8 = C (xx - yy)
+ * and the degree-3 functions cancel internally: along |x| = |y| b8 is a few ulp of xx + yy with either sign, whatever
+ * its own size (round 6: one SH-coefficient row element of 188 M, in a tile on that diagonal, sat at 2.4 x its tolerance
+ * while the scale only carried |b8|). */
+static void calc_sh_abs(int nb, const float *dir, double *out) {
+    const double x = fabs((double)dir[0]), y = fabs((double)dir[1]), z = fabs((double)dir[2]);
+    const double xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    out[0] = fabs((double)C0);
+    out[1] = fabs((double)C1) * y;
+    out[2] = fabs((double)C1) * z;
+    out[3] = fabs((double)C1) * x;
+    out[4] = fabs((double)C2[0]) * xy;
+    out[5] = fabs((double)C2[1]) * yz;
+    out[6] = fabs((double)C2[2]) * (2.0 * zz + xx + yy);
+    out[7] = fabs((double)C2[3]) * xz;
+    out[8] = fabs((double)C2[4]) * (xx + yy);
+    if (nb == 16) {
+        out[9] = fabs((double)C3[0]) * y * (3.0 * xx + yy);
+        out[10] = fabs((double)C3[1]) * xy * z;
+        out[11] = fabs((double)C3[2]) * y * (4.0 * zz + xx + yy);
+        out[12] = fabs((double)C3[3]) * z * (2.0 * zz + 3.0 * xx + 3.0 * yy);
+        out[13] = fabs((double)C3[4]) * x * (4.0 * zz + xx + yy);
+        out[14] = fabs((double)C3[5]) * z * (xx + yy);
+        out[15] = fabs((double)C3[6]) * x * (xx + 3.0 * yy);
+    }
+}
+
 static void pixel_sh(int nb, uint32_t id_x, uint32_t id_y, const float *rays_o, const float *lefttop,
                      const float *vdx, const float *vdy, float *SH) {
     /* gaussian.cu:849-860 */
@@ -576,6 +604,18 @@ static void pixel_sh(int nb, uint32_t id_x, uint32_t id_y, const float *rays_o, 
     nrm = sqrtf(nrm);
     for (int i = 0; i < 3; ++i) dir[i] = (float)(dir[i] / (nrm + 1e-7));
     calc_sh(nb, dir, SH);
+}
+
+static void pixel_sh_abs(int nb, uint32_t id_x, uint32_t id_y, const float *rays_o, const float *lefttop,
+                         const float *vdx, const float *vdy, double *SHabs) {
+    float dir[3], nrm = 0.0f;
+    for (int i = 0; i < 3; ++i) {
+        dir[i] = lefttop[i] + id_x * vdx[i] + id_y * vdy[i] - rays_o[i];
+        nrm += dir[i] * dir[i];
+    }
+    nrm = sqrtf(nrm);
+    for (int i = 0; i < 3; ++i) dir[i] = (float)(dir[i] / (nrm + 1e-7));
+    calc_sh_abs(nb, dir, SHabs);
 }
 
 GSO_API void gso_pixel_sh(uint32_t id_x, uint32_t id_y, const float *rays_o, const float *lefttop,
@@ -734,7 +774,9 @@ static void draw_backward_impl(const float *pos, const float *rgb, const float *
                     float pixel_x = (float)((id_x + 0.5 - (uint32_t)w / 2) / focal_x);
                     float pixel_y = (float)((id_y + 0.5 - (uint32_t)h / 2) / focal_y);
                     float SH[16];
+                    double SHabs[16];
                     if (use_sh) pixel_sh(nb, id_x, id_y, rays_o, lefttop, vdx, vdy, SH);
+                    if (use_sh && want_cs) pixel_sh_abs(nb, id_x, id_y, rays_o, lefttop, vdx, vdy, SHabs);
                     const float *go = grad_output + ((size_t)id_x + (size_t)id_y * w) * 3;
                     const float *co = output + ((size_t)id_x + (size_t)id_y * w) * 3;
                     float color[3] = {0, 0, 0}, accum = 1.0f;
@@ -849,7 +891,9 @@ static void draw_backward_impl(const float *pos, const float *rgb, const float *
                                     double Dk = fabs((double)go[ch] * weight * (cpc[ch] * (1 - cpc[ch]))) * rel +
                                                 W * fabs((double)go[ch] * weight) * fabs((double)cpc[ch]) *
                                                     (1.0 + fabs((double)cpc[ch]));
-                                    for (int s = 0; s < nb; ++s) cr[2 + ch * nb + s] += Dk * fabs((double)SH[s]);
+                                    /* ... times the basis value, whose own internal differences count like every other */
+                                    for (int s = 0; s < nb; ++s)
+                                        cr[2 + ch * nb + s] += Dk * (fabs((double)SH[s]) + W * SHabs[s]);
                                 }
                             } else {
                                 for (int m = 0; m < 3; ++m) cr[2 + m] += fabs((double)go[m] * weight) * rel;

@@ -213,11 +213,12 @@ def test_occlusion_cull_moving_camera_falls_back_and_stays_exact(gpu):
     params = to_torch(scene, gpu)
     r = FrameRenderer(gpu, max_pairs=1 << 21, auto_grow=False)
     off = FrameRenderer(gpu, max_pairs=1 << 21, auto_grow=False, occlusion_cull=False)
-    yaws = [0.0, 0.0, 0.25, 0.5, 1.0, 2.0, 4.0, 8.0, 30.0, 30.0, -20.0, 0.0, 0.0]
+    # a viewer's path: small steps (a fraction of a degree, millimetres) with a few jumps in between
+    yaws = [0.0, 0.0, 0.05, 0.1, 0.15, 0.2, 0.3, 0.4, 4.0, 4.05, 30.0, 30.0, -20.0, 0.0, 0.0]
     fell, clean, culled_share = 0, 0, []
     for k, yaw in enumerate(yaws):
         cam = make_camera(192, 128, yaw_deg=yaw)
-        cam.tran = np.array([0.02 * k, -0.01 * k, 0.05 * (k % 3)], np.float32)
+        cam.tran = np.array([0.002 * k, -0.001 * k, 0.003 * (k % 3)], np.float32)
         img, _ = r.forward(*params, cam)
         st = r.stats()
         ref, _ = off.forward(*params, cam)
@@ -231,8 +232,9 @@ def test_occlusion_cull_moving_camera_falls_back_and_stays_exact(gpu):
                 culled_share.append(1.0 - st.pairs / full)
             else:
                 assert st.pairs == full  # the counters are those of the second, untrimmed pass
-        if k in (1, 8, 12):
+        if k in (1, 8, 14):
             assert np.abs(img.cpu().numpy() - OracleFrame(scene, cam).image).max() < IMG_ATOL
+    print("occlusion cull over the camera path: fell back", fell, "clean", clean, "culled share", [round(c, 2) for c in culled_share])
     assert fell >= 2 and clean >= 4, (fell, clean)
     assert max(culled_share) > 0.4, culled_share
     # another scene in the same workspace: thin (no tile saturates -> the cut table it leaves is all GS_NO_CUT) ...
