@@ -1541,7 +1541,9 @@ int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t strea
         if (dev < 64 && !((attr_done.load(std::memory_order_acquire) >> dev) & 1)) {
             std::lock_guard<std::mutex> lock(attr_mu);
             for (const void *fn : {(const void *)frame_project_count_kernel<false>, (const void *)frame_project_count_kernel<true>})
-                GS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, GS_BIN_LDS_BYTES));
+                // (the kernel also holds ~17 KiB of static LDS -- the tile-order workgroup's bins --: the strip histogram, and the
+                // occlusion cuts behind it in a culled frame, get what gs_frame_occlusion_cull's room rule allows)
+                GS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, GS_BIN_LDS_BYTES - 8 * 4096));
             attr_done.fetch_or(1ull << dev, std::memory_order_release);
         }
         unsigned long long *table = (unsigned long long *)ws.strip_table;

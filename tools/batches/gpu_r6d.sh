@@ -9,7 +9,7 @@ timeout 900 python bench.py --legs headline,cfg2,cfg1 --steps 20 --warmup 5 > "$
 GS_NO_CULL=1 timeout 900 python bench.py --legs headline,cfg2,cfg1 --steps 20 --warmup 5 > "$OUT/bench_headline_nocull.json" 2> "$OUT/bench_nocull.err"; echo "bench nocull rc=$?" | tee -a "$OUT/steps.txt"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/st_cfg5" -o s -- python "$R/tools/prof_target.py" cfg5 --frames 100 > "$OUT/target_cfg5.json" 2> "$OUT/st_cfg5.err"
-cp $(find "$OUT/st_cfg5" -name '*kernel_stats.csv' | head -1) "$OUT/kernel_stats_cfg5_culled.csv"; rm -rf "$OUT/st_cfg5"
+F=$(find "$OUT/st_cfg5" -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp "$F" "$OUT/kernel_stats_cfg5_culled.csv"; rm -rf "$OUT/st_cfg5"
 cd "$R"
 cat "$OUT/steps.txt"; tail -8 "$OUT/cull_tests.txt"; grep "occlusion cull" "$OUT/cull_tests.txt"; tail -4 "$OUT/api_tests.txt"
 python - <<'PY'
