@@ -551,7 +551,8 @@ __global__ void __launch_bounds__(STRIP_THREADS) frame_project_count_kernel(
     float4 *__restrict__ rec_geom, uint32_t *__restrict__ tiles_touched, uint4 *__restrict__ rects, GsDistCull D,
     uint32_t per_slice, gs_strip_geom SG, uint32_t S, uint32_t slice0, unsigned long long *__restrict__ table,
     uint32_t *__restrict__ slice_pairs, uint32_t *__restrict__ slice_vis, const uint32_t *__restrict__ tile_cost,
-    uint32_t n_tiles, uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ cut) {
+    uint32_t n_tiles, uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ cut,
+    unsigned long long *__restrict__ table_full) {
     extern __shared__ unsigned long long s_hist[];  // [NS] entries << 32 | pairs of this slice
     __shared__ uint32_t s_acc[2];
     if (blockIdx.x >= S) {  // the one extra workgroup of the launch (uniform)
@@ -570,10 +571,19 @@ __global__ void __launch_bounds__(STRIP_THREADS) frame_project_count_kernel(
     // occlusion cuts (GS_FRAME_OCCLUSION_CULL): the per-tile table is staged in LDS behind the histogram -- looked up from
     // global memory, two to eight dependent loads per Gaussian inside this latency-bound kernel cost 62 us at 2.4 M Gaussians
     // (first version, profiles/r06_c_*)
-    uint32_t *s_cut = reinterpret_cast<uint32_t *>(s_hist + SG.NS);
-    if (cut)
-        for (uint32_t t = threadIdx.x; t < n_tiles; t += STRIP_THREADS) s_cut[t] = cut[t];
-    const uint32_t *cut_tab = cut ? s_cut : nullptr;
+    // A culled frame keeps TWO histograms: the trimmed entries (what this frame emits) and the full ones -- the table the
+    // gated second pass scans if a tile runs past its cut, so that pass needs no recount.  Layout: [NS] trimmed, [NS] full,
+    // then the cuts with every tile row padded to whole strips (walk_strips<.., true>).
+    unsigned long long *s_full = s_hist + SG.NS;
+    uint32_t *s_cut = reinterpret_cast<uint32_t *>(s_hist + 2 * SG.NS);
+    if (cut) {
+        for (uint32_t t = threadIdx.x; t < SG.NS; t += STRIP_THREADS) s_full[t] = 0;
+        const uint32_t stride = SG.nsx * GS_STRIP_W;
+        for (uint32_t t = threadIdx.x; t < stride * SG.nty; t += STRIP_THREADS) {
+            const uint32_t iy = t / stride, ix = t - iy * stride;
+            s_cut[t] = ix < SG.ntx ? cut[iy * SG.ntx + ix] : GS_NO_CUT;
+        }
+    }
     if (threadIdx.x < 2) s_acc[threadIdx.x] = 0;
     __syncthreads();
     settle(cur);
@@ -587,9 +597,16 @@ __global__ void __launch_bounds__(STRIP_THREADS) frame_project_count_kernel(
         if (in_range(i)) rc = project_one(cur, g0 + i, P, rec_geom, tiles_touched, rects, vis, cxy);
         acc_cnt += rc.w;
         acc_vis += vis;
-        walk_strips<DIST>(rc, g0 + i, SG, cxy, D,
-                          [&](uint32_t strip, uint32_t, uint32_t, uint32_t np) { atomicAdd(&s_hist[strip], (1ull << 32) | np); },
-                          cut_tab);
+        if (cut) {  // (uniform)
+            walk_strips<DIST, true>(rc, g0 + i, SG, cxy, D,
+                                    [&](uint32_t strip, uint32_t, uint32_t, uint32_t np) { atomicAdd(&s_hist[strip], (1ull << 32) | np); },
+                                    s_cut);
+            walk_strips<DIST>(rc, g0 + i, SG, cxy, D,
+                              [&](uint32_t strip, uint32_t, uint32_t, uint32_t np) { atomicAdd(&s_full[strip], (1ull << 32) | np); });
+        } else {
+            walk_strips<DIST>(rc, g0 + i, SG, cxy, D,
+                              [&](uint32_t strip, uint32_t, uint32_t, uint32_t np) { atomicAdd(&s_hist[strip], (1ull << 32) | np); });
+        }
         cur = nxt;
     }
     // rectangle areas (= gradient-row slots; == pairs unless DIST) and visible Gaussians of this slice
@@ -602,6 +619,10 @@ __global__ void __launch_bounds__(STRIP_THREADS) frame_project_count_kernel(
     __syncthreads();
     unsigned long long *row = table + (size_t)slice * SG.NS;
     for (uint32_t t = threadIdx.x; t < SG.NS; t += STRIP_THREADS) row[t] = s_hist[t];
+    if (cut) {
+        unsigned long long *rowf = table_full + (size_t)slice * SG.NS;
+        for (uint32_t t = threadIdx.x; t < SG.NS; t += STRIP_THREADS) rowf[t] = s_full[t];
+    }
     if (threadIdx.x == 0) {
         slice_pairs[slice] = s_acc[0];
         slice_vis[slice] = s_acc[1];
@@ -1548,7 +1569,8 @@ int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t strea
         }
         unsigned long long *table = (unsigned long long *)ws.strip_table;
         // (+ the per-tile occlusion cuts behind the histogram when the frame is culled: gs_frame_occlusion_cull checks the room)
-        const size_t lds = sizeof(unsigned long long) * SG.NS + (gs_frame_occlusion_cull(f) ? sizeof(uint32_t) * (size_t)G.n_tiles : 0);
+        const size_t lds = gs_frame_occlusion_cull(f) ? gs_cull_lds_bytes(SG.NS) + sizeof(unsigned long long) * SG.NS
+                                                      : sizeof(unsigned long long) * SG.NS;
         if (slice_end < 0) slice_end = (int)plan.slices;
         GS_CHECK_ARG(slice_begin >= 0 && slice_begin < slice_end && slice_end <= (int)plan.slices, "bad slice range");
         const uint32_t nsl = (uint32_t)(slice_end - slice_begin);
@@ -1557,7 +1579,8 @@ int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t strea
     hipLaunchKernelGGL(frame_project_count_kernel<DIST>, dim3(nsl + extra), dim3(STRIP_THREADS), lds, stream,          \
                        f->pos, (const float4 *)f->quat, f->scale, f->opa, f->rgb, f->N, P, ws.rec_geom, touched,       \
                        ws.rects, D, plan.per_slice, SG, nsl, (uint32_t)slice_begin, table, ws.slice_pairs,             \
-                       ws.slice_vis, ws.tile_cost, (uint32_t)G.n_tiles, ws.tile_order, cut)
+                       ws.slice_vis, ws.tile_cost, (uint32_t)G.n_tiles, ws.tile_order, cut,                            \
+                       (unsigned long long *)ws.strip_table_full)
         // GS_FRAME_OCCLUSION_CULL: level-1 entries trimmed by the cut table the previous frame of this workspace left
         const uint32_t *cut = gs_frame_occlusion_cull(f) ? ws.cut : nullptr;
         if (f->tile_culling_method == 0)

@@ -840,7 +840,10 @@ void launch_fwd(const RasterSrc &S, const RasterGeom &G, const int32_t *ranges, 
                 const uint32_t *cut_in = nullptr, uint32_t *cut_out = nullptr, unsigned long long *ranpast = nullptr,
                 const unsigned long long *gate = nullptr) {
     if (!fwd_plan().order) tile_order = nullptr;
-    const uint32_t T = (uint32_t)(G.ntx * G.nty), grid = fwd_grid(T);
+    const uint32_t T = (uint32_t)(G.ntx * G.nty);
+    // the gated second pass of a culled frame almost never runs: a small persistent grid (every wave walks several tiles)
+    // returns in ~2 us where T workgroups take ~8 us to be dispatched and retired
+    const uint32_t grid = gate ? (T < 1024u ? T : 1024u) : fwd_grid(T);
     if (wn)
         hipLaunchKernelGGL((raster_forward_kernel<CDIM, FRAME, CKPT, SIG, true, EXACT>), dim3(grid), dim3(FWD_THREADS),
                            0, stream, S, G, ranges, out_padded, out_image, ckpt, tile_nproc, T, cont_state, cont_flag,

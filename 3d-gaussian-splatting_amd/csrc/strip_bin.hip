@@ -190,11 +190,16 @@ __global__ void __launch_bounds__(STRIP_THREADS) strip_scatter_kernel(
     if (gate && *gate == 0) return;  // (see strip_count_kernel)
     uint32_t *s_cur = reinterpret_cast<uint32_t *>(s_dyn), *s_gd = s_cur + SG.NS;
     unsigned long long *s_stage = s_dyn + SG.NS;  // 2 NS uint32 = NS uint64
-    // occlusion cuts (the same table the count pass used): staged in LDS behind the `cap` staged entries
+    // occlusion cuts (the same table the count pass used): staged in LDS behind the `cap` staged entries, every tile row
+    // padded to whole strips (walk_strips<.., true>)
     uint32_t *s_cut = reinterpret_cast<uint32_t *>(s_stage + cap);
-    if (cut)
-        for (uint32_t t = threadIdx.x; t < n_tiles; t += STRIP_THREADS) s_cut[t] = cut[t];  // (barriers follow below)
-    const uint32_t *cut_tab = cut ? s_cut : nullptr;
+    if (cut) {
+        const uint32_t stride = SG.nsx * GS_STRIP_W;
+        for (uint32_t t = threadIdx.x; t < stride * SG.nty; t += STRIP_THREADS) {  // (barriers follow below)
+            const uint32_t iy = t / stride, ix = t - iy * stride;
+            s_cut[t] = ix < SG.ntx ? cut[iy * SG.ntx + ix] : GS_NO_CUT;
+        }
+    }
     __shared__ uint32_t s_wave[STRIP_THREADS / 64];
     __shared__ unsigned long long s_wave64[4 * (STRIP_THREADS / 64)];
     const uint32_t slice = strip_slice_of_block(blockIdx.x, gridDim.x);
@@ -330,16 +335,18 @@ __global__ void __launch_bounds__(STRIP_THREADS) strip_scatter_kernel(
                 if (i < per_slice && L.g0 + i < n) pair_offsets[L.g0 + i] = before + ex;
                 before += dummy;
             }
-            walk_strips<DIST>(cur[k], L.g0 + i, SG, L.xy<DIST>(b, cur[k]), D,
-                              [&](uint32_t strip, uint32_t lo32, uint32_t d, uint32_t) {
-                                  const uint32_t slot = atomicAdd(&s_cur[strip], 1u);
-                                  const unsigned long long e = ((unsigned long long)d << 32) | lo32;
-                                  if (slot < cap)
-                                      s_stage[slot] = e;
-                                  else
-                                      out[s_gd[strip] + slot] = e;
-                              },
-                              cut_tab);
+            auto place = [&](uint32_t strip, uint32_t lo32, uint32_t d, uint32_t) {
+                const uint32_t slot = atomicAdd(&s_cur[strip], 1u);
+                const unsigned long long e = ((unsigned long long)d << 32) | lo32;
+                if (slot < cap)
+                    s_stage[slot] = e;
+                else
+                    out[s_gd[strip] + slot] = e;
+            };
+            if (cut)  // (uniform)
+                walk_strips<DIST, true>(cur[k], L.g0 + i, SG, L.xy<DIST>(b, cur[k]), D, place, s_cut);
+            else
+                walk_strips<DIST>(cur[k], L.g0 + i, SG, L.xy<DIST>(b, cur[k]), D, place);
         }
     }
     __syncthreads();
@@ -377,25 +384,21 @@ int gs_stage_strip_bin(const gs_frame *f, const gs_frame_ws &ws, hipStream_t str
     const size_t lds_count = sizeof(unsigned long long) * SG.NS;
     const unsigned long long *gate = second_pass ? ws.counters + GS_CNT_RANPAST : nullptr;
     const uint32_t *cut = (!second_pass && gs_frame_occlusion_cull(f)) ? ws.cut : nullptr;
-    // a culled frame's scatter gives T / 2 staged entries (4 B per tile) to the cut table
-    const uint32_t cap = cut ? plan.cap - ((uint32_t)G.n_tiles + 1) / 2 : plan.cap;
-    const size_t lds_scatter = sizeof(unsigned long long) * ((size_t)SG.NS + cap) + (cut ? sizeof(uint32_t) * (size_t)G.n_tiles : 0);
+    // a culled frame's scatter gives 4 staged entries per strip (32 B: the strip's eight cuts) to the cut table
+    const uint32_t cap = cut ? plan.cap - 4 * SG.NS : plan.cap;
+    const size_t lds_scatter = sizeof(unsigned long long) * ((size_t)SG.NS + cap) + (cut ? (size_t)32 * SG.NS : 0);
+    // the second pass scans the UNTRIMMED table the culled frame's project + count launch wrote next to the trimmed one
+    const unsigned long long *raw = second_pass ? (const unsigned long long *)ws.strip_table_full : table;
 #define GS_LAUNCH_STRIP(DIST)                                                                                          \
     do {                                                                                                               \
-        if (second_pass) { /* recount from the rectangles, untrimmed; no tile-order workgroup, no slice sums */          \
-            hipLaunchKernelGGL(strip_count_kernel<DIST>, dim3(plan.slices), dim3(STRIP_THREADS), lds_count, stream,    \
-                               ws.rects, ws.rec_geom, D, f->N, plan.per_slice, SG, plan.slices, table,                 \
-                               (const uint32_t *)nullptr, (const uint32_t *)nullptr, ws.slice_pairs, ws.slice_vis,     \
-                               ws.tile_cost, (uint32_t)G.n_tiles, ws.tile_order, gate);                                \
-            GS_CHECK_LAUNCH();                                                                                         \
-        } else if (!gs_frame_fused_count(f)) { /* else: counted by the project stage (frame_project_count_kernel) */   \
+        if (!second_pass && !gs_frame_fused_count(f)) { /* else: counted by the project stage */                         \
             hipLaunchKernelGGL(strip_count_kernel<DIST>, dim3(plan.slices + 1), dim3(STRIP_THREADS), lds_count, stream,\
                                ws.rects, ws.rec_geom, D, f->N, plan.per_slice, SG, plan.slices, table, ws.block_sums,  \
                                ws.block_vis, ws.slice_pairs, ws.slice_vis, ws.tile_cost, (uint32_t)G.n_tiles,          \
                                ws.tile_order, (const unsigned long long *)nullptr);                                    \
             GS_CHECK_LAUNCH();                                                                                         \
         }                                                                                                              \
-        hipLaunchKernelGGL(strip_colscan_kernel, dim3((unsigned)gs_div_up(SG.NS, 16)), dim3(256), 0, stream, table,    \
+        hipLaunchKernelGGL(strip_colscan_kernel, dim3((unsigned)gs_div_up(SG.NS, 16)), dim3(256), 0, stream, raw,      \
                            scan, plan.slices, SG.NS, (unsigned long long *)ws.strip_tot, gate);                        \
         GS_CHECK_LAUNCH();                                                                                             \
         hipLaunchKernelGGL(strip_scatter_kernel<DIST>, dim3(plan.slices), dim3(STRIP_THREADS), lds_scatter, stream,    \
