@@ -598,11 +598,13 @@ __global__ void __launch_bounds__(STRIP_THREADS) frame_project_count_kernel(
         acc_cnt += rc.w;
         acc_vis += vis;
         if (cut) {  // (uniform)
-            walk_strips<DIST, true>(rc, g0 + i, SG, cxy, D,
-                                    [&](uint32_t strip, uint32_t, uint32_t, uint32_t np) { atomicAdd(&s_hist[strip], (1ull << 32) | np); },
-                                    s_cut);
-            walk_strips<DIST>(rc, g0 + i, SG, cxy, D,
-                              [&](uint32_t strip, uint32_t, uint32_t, uint32_t np) { atomicAdd(&s_full[strip], (1ull << 32) | np); });
+            if constexpr (!DIST)  // (a "dist" frame is never culled: gs_frame_occlusion_cull)
+                walk_strips<false, true, true>(rc, g0 + i, SG, cxy, D,
+                                               [&](uint32_t strip, uint32_t, uint32_t, uint32_t np, uint32_t full) {
+                                                   atomicAdd(&s_full[strip], (1ull << 32) | full);
+                                                   if (np) atomicAdd(&s_hist[strip], (1ull << 32) | np);
+                                               },
+                                               s_cut);
         } else {
             walk_strips<DIST>(rc, g0 + i, SG, cxy, D,
                               [&](uint32_t strip, uint32_t, uint32_t, uint32_t np) { atomicAdd(&s_hist[strip], (1ull << 32) | np); });

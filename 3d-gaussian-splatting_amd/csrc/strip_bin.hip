@@ -343,10 +343,11 @@ __global__ void __launch_bounds__(STRIP_THREADS) strip_scatter_kernel(
                 else
                     out[s_gd[strip] + slot] = e;
             };
-            if (cut)  // (uniform)
-                walk_strips<DIST, true>(cur[k], L.g0 + i, SG, L.xy<DIST>(b, cur[k]), D, place, s_cut);
-            else
+            if (cut) {  // (uniform; a "dist" frame is never culled)
+                if constexpr (!DIST) walk_strips<false, true>(cur[k], L.g0 + i, SG, L.xy<DIST>(b, cur[k]), D, place, s_cut);
+            } else {
                 walk_strips<DIST>(cur[k], L.g0 + i, SG, L.xy<DIST>(b, cur[k]), D, place);
+            }
         }
     }
     __syncthreads();

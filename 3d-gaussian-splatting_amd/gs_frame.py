@@ -135,13 +135,14 @@ class FrameRenderer:
         for name, t in (("pos", pos), ("quat", quat), ("scale", scale), ("opa", opa), ("rgb", rgb)):
             if t.dtype != torch.float32 or not t.is_contiguous():
                 raise RuntimeError(f"{name} must be a contiguous float32 HIP tensor")
+        self._cur_ck = ck
         key = (ck, pos.data_ptr(), quat.data_ptr(), scale.data_ptr(), opa.data_ptr(), rgb.data_ptr(),
                tuple(pos.shape), tuple(quat.shape), tuple(scale.shape), tuple(opa.shape), tuple(rgb.shape),
                pos.shape[0], rgb.shape[-1] if rgb.dim() == 2 else 1, bool(training), self.max_pairs, self.sort_mode,
                self.tile_culling_method, self.tile_culling_dist_thresh, self.thresh, self.scale_activation,
                self.emit_sorted_keys, self.slice_sort, self.table_bin, self.force_strips, self.serial_long_lists,
                self.long_lists, self._long_lists_seen, self._long_sort_seen, self.bwd_rows, self._bwd_rows_seen,
-               self.occlusion_cull, self._cut_key,
+               self.occlusion_cull, self._cut_key, getattr(self, "_cut_ck", None),
                self._ws.data_ptr() if self._ws is not None else 0)
         cached = getattr(self, "_desc_cache", None)
         if cached is not None and cached[0] == key:
@@ -232,7 +233,8 @@ class FrameRenderer:
         f.workspace = (base + 255) // 256 * 256
         f.workspace_bytes = self._ws.numel() - (f.workspace - base)
         if self.occlusion_cull is not False and not training and not self.emit_sorted_keys and \
-                self._cut_key == (base, grid.width, grid.height):
+                self._cut_key == (base, grid.width, grid.height) and \
+                self._camera_shift_px(camera) <= self.CULL_MAX_SHIFT_PX:
             f.flags |= _lib.GS_FRAME_OCCLUSION_CULL  # (the library ignores it where the cull does not apply)
         self._grid = grid
         return f
@@ -299,11 +301,35 @@ class FrameRenderer:
     LONG_LIST_FLAG_AT = int(os.environ.get("GS_FRAME_LONG_LIST_FLAG_AT", "6144"))
     LONG_LIST_PAIRS_PER_STEP = int(os.environ.get("GS_FRAME_LONG_LIST_PAIRS_PER_STEP", "400"))
 
+    # The occlusion cull is exact for ANY camera -- a frame whose trimmed lists prove too short is rendered again from the
+    # full ones --, but that second pass costs 0.6 of a frame, and with 8,160 tiles SOME tile runs past its cut in nearly
+    # every frame of a moving camera (a pixel at the rim of an opaque Gaussian's footprint sees through to something twice
+    # as deep).  So the cull is only allowed while the camera has (all but) stayed where the cut table was recorded: a
+    # viewer at rest, a benchmark or an evaluation that renders one view repeatedly, a trainer that re-renders a test view.
+    # The reference's own evaluation loop walks through DIFFERENT test cameras (train.py:240-266): those frames are not
+    # culled and pay nothing for the feature (no gated launches without the flag).
+    CULL_MAX_SHIFT_PX = float(os.environ.get("GS_FRAME_CULL_MAX_SHIFT_PX", "1.0"))
+
+    def _camera_shift_px(self, camera) -> float:
+        """Upper estimate of how far image content moved, in pixels, between the camera the cut table was recorded under
+        and ``camera``: rotation angle x focal length + focal length x camera-centre displacement / 1 (unit depth)."""
+        prev, cur = getattr(self, "_cut_ck", None), getattr(self, "_cur_ck", None)
+        if prev is None or cur is None or prev[:4] != cur[:4]:  # (width, height, focal lengths)
+            return float("inf")
+        if prev[5] == cur[5] and prev[6] == cur[6]:  # the same pose, byte for byte (the common case: no arithmetic)
+            return 0.0
+        r0, t0 = np.frombuffer(prev[5], np.float32).astype(np.float64).reshape(3, 3), np.frombuffer(prev[6], np.float32).astype(np.float64)
+        r1, t1 = np.frombuffer(cur[5], np.float32).astype(np.float64).reshape(3, 3), np.frombuffer(cur[6], np.float32).astype(np.float64)
+        ang = float(np.arccos(np.clip((np.trace(r1 @ r0.T) - 1.0) / 2.0, -1.0, 1.0)))
+        dc = float(np.linalg.norm(r1.T @ t1 - r0.T @ t0))
+        return max(float(cur[2]), float(cur[3])) * (ang + dc)
+
     def _note_cut_table(self, f):
         """Every inference frame's compositing launch leaves the per-tile occlusion cuts of ITS frame in the workspace: the
         next forward of the same size may use them (GS_FRAME_OCCLUSION_CULL).  A training forward does not write the table
         (and may use the workspace differently): no cull right behind one."""
         self._cut_key = None if f.training else (self._ws.data_ptr(), int(f.width), int(f.height))
+        self._cut_ck = getattr(self, "_cur_ck", None)  # the camera (by value) the table was recorded under
 
     def _note_lists(self, longest: int, pairs: int):
         self._long_sort_seen = self._long_sort_seen or longest > self.LONG_SORT_FLAG_AT

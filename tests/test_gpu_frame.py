@@ -205,40 +205,54 @@ def test_occlusion_cull_static_camera_is_bit_exact(gpu):
 
 
 def test_occlusion_cull_moving_camera_falls_back_and_stays_exact(gpu):
-    """A camera that yaws, jumps and comes back; then another scene (thin: nothing saturates) and another Gaussian count in
-    the same workspace.  Every frame equals, bit for bit, the frame of a renderer with the cull off -- whether its
-    trimmed lists sufficed (no fallback) or a tile ran past its cut and the library rendered the frame again from the
-    full lists.  Both happen in the sweep.  Spot checks against the oracle."""
+    """A camera that creeps, jumps and comes back; then another scene (thin: nothing saturates) and another Gaussian count in
+    the same workspace.  Every frame equals, bit for bit, the frame of a renderer with the cull off.
+    Default policy: a frame is only culled while the camera has stayed (within a pixel) where the cut table was recorded --
+    with thousands of tiles SOME tile runs past its cut in nearly every frame of a moving camera, and the second pass costs
+    0.6 of a frame.  With the policy lifted (CULL_MAX_SHIFT_PX = inf) moving frames are culled too: whether the trimmed lists
+    sufficed or a tile ran past its cut and the library rendered the frame again from the full lists, the image is exact;
+    both happen.  Spot checks against the oracle."""
     scene, _ = _dense_case()
     params = to_torch(scene, gpu)
-    r = FrameRenderer(gpu, max_pairs=1 << 21, auto_grow=False)
     off = FrameRenderer(gpu, max_pairs=1 << 21, auto_grow=False, occlusion_cull=False)
-    # a viewer's path: small steps (a fraction of a degree, millimetres) with a few jumps in between
-    yaws = [0.0, 0.0, 0.05, 0.1, 0.15, 0.2, 0.3, 0.4, 4.0, 4.05, 30.0, 30.0, -20.0, 0.0, 0.0]
-    fell, clean, culled_share = 0, 0, []
-    for k, yaw in enumerate(yaws):
-        cam = make_camera(192, 128, yaw_deg=yaw)
-        cam.tran = np.array([0.002 * k, -0.001 * k, 0.003 * (k % 3)], np.float32)
-        img, _ = r.forward(*params, cam)
-        st = r.stats()
-        ref, _ = off.forward(*params, cam)
-        full = off.stats().pairs
-        assert torch.equal(img, ref), (k, yaw, st)
-        if k:
-            assert r._frame.flags & 256
+    # a viewer's path: rests, small steps (a fraction of a degree, millimetres), a few jumps
+    yaws = [0.0, 0.0, 0.0, 0.002, 0.002, 0.1, 0.15, 0.2, 0.3, 4.0, 4.0, 30.0, 30.0, -20.0, 0.0, 0.0]
+    for lifted in (False, True):
+        r = FrameRenderer(gpu, max_pairs=1 << 21, auto_grow=False)
+        if lifted:
+            r.CULL_MAX_SHIFT_PX = float("inf")
+        fell, clean, not_culled, culled_share = 0, 0, 0, []
+        for k, yaw in enumerate(yaws):
+            cam = make_camera(192, 128, yaw_deg=yaw)
+            cam.tran = np.array([0.002 * (k // 2), -0.001 * (k // 2), 0.0], np.float32)
+            img, _ = r.forward(*params, cam)
+            st = r.stats()
+            ref, _ = off.forward(*params, cam)
+            full = off.stats().pairs
+            assert torch.equal(img, ref), (lifted, k, yaw, st)
+            if not (r._frame.flags & 256):
+                not_culled += 1
+                assert st.pairs == full and not st.cull_fallback
+                continue
             fell += int(st.cull_fallback)
             clean += int(not st.cull_fallback)
             if not st.cull_fallback:
                 culled_share.append(1.0 - st.pairs / full)
             else:
                 assert st.pairs == full  # the counters are those of the second, untrimmed pass
-        if k in (1, 8, 14):
-            assert np.abs(img.cpu().numpy() - OracleFrame(scene, cam).image).max() < IMG_ATOL
-    print("occlusion cull over the camera path: fell back", fell, "clean", clean, "culled share", [round(c, 2) for c in culled_share])
-    assert fell >= 2 and clean >= 4, (fell, clean)
-    assert max(culled_share) > 0.4, culled_share
-    # another scene in the same workspace: thin (no tile saturates -> the cut table it leaves is all GS_NO_CUT) ...
+            if k in (1, 10, 15):
+                assert np.abs(img.cpu().numpy() - OracleFrame(scene, cam).image).max() < IMG_ATOL
+        print("occlusion cull over the camera path, policy lifted:", lifted, "| fell back", fell, "clean", clean,
+              "not culled", not_culled, "culled share", [round(c, 2) for c in culled_share])
+        if lifted:
+            assert not_culled == 1 and fell >= 2 and clean >= 3, (fell, clean, not_culled)
+        else:
+            # left alone: the first frame and the four jumps (4, 26, 50, 20 degrees); culled: repeats of a pose and
+            # sub-pixel creep -- of which the identical poses (and the 0.005-pixel step) cannot run past their cuts
+            assert not_culled == 5 and clean >= 3, (fell, clean, not_culled)
+        assert max(culled_share) > 0.4, culled_share
     cam = make_camera(192, 128, yaw_deg=1.0)
+    # another scene in the same workspace: thin (no tile saturates -> the cut table it leaves is all GS_NO_CUT) ...
     thin = make_scene(20_000, 192, 128, seed=9)
     thin.opa[:] = -4.0
     p_thin = to_torch(thin, gpu)
