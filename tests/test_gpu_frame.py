@@ -272,6 +272,31 @@ def test_occlusion_cull_moving_camera_falls_back_and_stays_exact(gpu):
     assert r.stats().pairs < off.stats().pairs and not r.stats().cull_fallback
 
 
+def test_occlusion_cull_switches_itself_off_where_it_does_not_pay(gpu):
+    """A scene whose tiles do not saturate (nothing to cull): the renderer looks at the counters of its first unculled and
+    first culled frame (asynchronous, tagged copies), finds that the cull dropped less than a third of the pairs, and
+    switches it off for 256 frames -- those frames carry no flag, i.e. none of the gated launches.  On the opaque scene
+    it stays on.  Images identical throughout."""
+    thin = make_scene(30_000, 192, 128, seed=9)
+    thin.opa[:] = -4.0
+    cam = make_camera(192, 128)
+    for scene, stays_on in ((thin, False), (_dense_case()[0], True)):
+        params = to_torch(scene, gpu)
+        r = FrameRenderer(gpu, max_pairs=1 << 21, auto_grow=False)
+        first, _ = r.forward(*params, cam)
+        flags = []
+        for k in range(12):
+            img, _ = r.forward(*params, cam)
+            flags.append(bool(r._frame.flags & 256))
+            assert torch.equal(img, first)
+            torch.cuda.synchronize()  # (lets the probes land: a free-running loop decides a few frames later)
+        assert flags[0], flags  # the frame right behind the first one is culled: nothing is known yet
+        if stays_on:
+            assert all(flags) and r._cull_settled and r._cull_off_until == 0, flags
+        else:
+            assert not any(flags[4:]) and r._cull_off_until > r._frame_serial and not r._cull_settled, flags
+
+
 def test_small_scene_with_a_pile_switches_to_the_long_list_kernels(gpu):
     """below 131,072 Gaussians sort_mode 2 takes the TABLE variant, whose kernels used to report 0 for the
     longest list -- a small scene with a pile-up (the case the long-list kernels were built for) stayed on the serial path
