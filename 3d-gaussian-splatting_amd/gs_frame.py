@@ -345,7 +345,9 @@ class FrameRenderer:
             self._cull_probe = None
             if (int(h[11]) & 0xffffffff) == (p[2] & 0xffffffff):
                 pairs, ran_past = int(h[1]), int(h[10])
-                if not p[3]:
+                if int(h[2]) or pairs <= 0:
+                    pass  # an overflowed (empty) frame says nothing about the scene
+                elif not p[3]:
                     self._cull_full_pairs, self._cull_full_serial = pairs, p[2]
                 elif self._cull_full_pairs:
                     if ran_past or pairs > self.CULL_MIN_GAIN * self._cull_full_pairs:
@@ -361,6 +363,8 @@ class FrameRenderer:
         # count is unknown or older than 64 frames (a moving camera renders unculled frame after unculled frame)
         fresh = self._cull_full_pairs is not None and self._frame_serial - getattr(self, "_cull_full_serial", -10**9) <= 64
         want = (not self._cull_settled and self._cull_full_pairs is not None) if culled else not fresh
+        if culled and self._cull_full_pairs is None and self._cull_probe is None:
+            self._cull_off_until = self._frame_serial + 1  # nothing to compare with yet: one unculled frame, which is probed
         if self._cull_probe is None and want:
             host = getattr(self, "_cull_host", None)
             if host is None:

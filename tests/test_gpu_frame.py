@@ -249,7 +249,8 @@ def test_occlusion_cull_moving_camera_falls_back_and_stays_exact(gpu):
         else:
             # left alone: the first frame and the four jumps (4, 26, 50, 20 degrees); culled: repeats of a pose and
             # sub-pixel creep -- of which the identical poses (and the 0.005-pixel step) cannot run past their cuts
-            assert not_culled == 5 and clean >= 3, (fell, clean, not_culled)
+            # (a frame that fell back also switches the cull off for a while: the adaptive policy, next test)
+            assert not_culled >= 5 and clean >= 3, (fell, clean, not_culled)
         assert max(culled_share) > 0.4, culled_share
     cam = make_camera(192, 128, yaw_deg=1.0)
     # another scene in the same workspace: thin (no tile saturates -> the cut table it leaves is all GS_NO_CUT) ...
