@@ -460,74 +460,19 @@ __device__ __forceinline__ void settle(const RawGaussian &r) {
 #endif
 }
 
-// Occlusion test of one Gaussian BEFORE its covariance is projected (GS_FRAME_OCCLUSION_CULL, gs_frame_layout.h): is it
-// behind the occlusion cut of every tile its rectangle can reach?  Conservative by construction: the rectangle's half
-// extents are sqrt(tlog S00) and sqrt(tlog S11) (tile_rect; the +1e-14 only shrinks them), S00 = r0 (R S S R^T) r0^T with
-// r0 the first row of J W, so S00 <= s_max^2 |r0|^2 = s_max^2 (1 + (x/z)^2) / z^2 (W, R orthonormal), likewise S11; the
-// bound is inflated by 2 % (fp32 roundings are 1e-6) and the tile range by one tile on every side (any index arithmetic,
-// "prob" or "prob2").  `bmax` (LDS): per block of 4 x 4 tiles the LARGEST cut of its tiles (GS_NO_CUT if any tile has
-// none); a range of more than 3 x 3 blocks is not tested.  true => every pair of this Gaussian would be trimmed.
-__device__ __forceinline__ bool occluded_everywhere(const float pi[3], float z, const float s[3], uint32_t dbits,
-                                                    const ProjectParams &P, const uint32_t *bmax, uint32_t nbx) {
-    const float smax = fmaxf(s[0], fmaxf(s[1], s[2]));
-    const float k = 1.02f * sqrtf(P.tlog) * smax / z;
-    const float rx = k * sqrtf(1.0f + pi[0] * pi[0]), ry = k * sqrtf(1.0f + pi[1] * pi[1]);
-    const float fx0 = (pi[0] - rx - P.leftmost) / P.tlx - 1.0f, fx1 = (pi[0] + rx - P.leftmost) / P.tlx + 2.0f;
-    const float fy0 = (pi[1] - ry - P.topmost) / P.tly - 1.0f, fy1 = (pi[1] + ry - P.topmost) / P.tly + 2.0f;
-    if (!(fx1 - fx0 < 64.0f) || !(fy1 - fy0 < 64.0f)) return false;  // huge or not finite: keep
-    const uint32_t x0 = gs_f2u_sat(fmaxf(fx0, 0.f)), y0 = gs_f2u_sat(fmaxf(fy0, 0.f));
-    uint32_t x1 = gs_f2u_sat(fmaxf(fx1, 0.f)), y1 = gs_f2u_sat(fmaxf(fy1, 0.f));
-    if (x1 > P.ntx) x1 = P.ntx;
-    if (y1 > P.nty) y1 = P.nty;
-    if (x0 >= x1 || y0 >= y1) return false;  // (off the grid: nothing to emit anyway; left to the exact arithmetic)
-    const uint32_t bx0 = x0 >> 2, bx1 = (x1 - 1) >> 2, by0 = y0 >> 2, by1 = (y1 - 1) >> 2;
-    if (bx1 - bx0 > 2 || by1 - by0 > 2) return false;
-    uint32_t m = 0;
-    for (uint32_t by = by0; by <= by1; ++by)
-        for (uint32_t bx = bx0; bx <= bx1; ++bx) {
-            const uint32_t c = bmax[by * nbx + bx];
-            m = c > m ? c : m;
-        }
-    return dbits > m;
-}
-
 // S1 for one Gaussian: activations -> project -> tile rectangle -> 64-byte record (visible Gaussians only) + the
 // 16-byte rectangle record (every Gaussian).  Returns the rectangle record; `vis` = passed the frustum test; `cxy` = the
 // projected centre (the "dist" listing test of the binning needs it).
-// OCC (an occlusion-culled frame's first pass): a Gaussian that lies behind the cut of every tile it can reach leaves its
-// depth bits and an EMPTY rectangle (tiles touched = 0: no later stage of an inference frame looks at it again) and skips
-// the quaternion, the covariance, the rectangle, the activations and the record -- ~600 of this stage's ~820 instructions.
-template <bool OCC = false>
 __device__ __forceinline__ uint4 project_one(const RawGaussian &in, int64_t pid, const ProjectParams &P,
                                              float4 *__restrict__ rec_geom, uint32_t *__restrict__ tiles_touched,
-                                             uint4 *__restrict__ rects, uint32_t &vis, float2 &cxy,
-                                             const uint32_t *bmax = nullptr, uint32_t nbx = 0) {
+                                             uint4 *__restrict__ rects, uint32_t &vis, float2 &cxy) {
     float q[4], s[3], pi[3], cv[4];
+    activate(in.qraw, in.sraw, P.scale_act, q, s);
     uint32_t cnt = 0;
     vis = 0;
     cxy = make_float2(0.f, 0.f);
     uint2 rc = make_uint2(0, 0);
     float depth = 0.f;
-    if constexpr (OCC) {
-        float pc[3];
-        if (project_cull(in.p, P.cam, P.near_plane, P.half_w, P.half_h, pc, pi)) {
-            const float dep = sqrtf(pc[0] * pc[0] + pc[1] * pc[1] + pc[2] * pc[2]);  // == project_cov's pos_i[2]
-#pragma unroll
-            for (int k = 0; k < 3; ++k) s[k] = P.scale_act == 0 ? fabsf(in.sraw[k]) + 1e-4f : expf(in.sraw[k]);
-            pi[2] = dep;
-            if (occluded_everywhere(pi, pc[2], s, __float_as_uint(dep), P, bmax, nbx)) {
-                vis = 1;
-                const uint4 out = make_uint4(0, 0, __float_as_uint(dep), 0);
-                rects[pid] = out;
-                return out;
-            }
-        } else {
-            const uint4 out = make_uint4(0, 0, 0, 0);
-            rects[pid] = out;
-            return out;
-        }
-    }
-    activate(in.qraw, in.sraw, P.scale_act, q, s);
     // A culled Gaussian leaves 16 (20) bytes -- its all-zero rectangle, which is what every later stage looks at first
     // (rects[i].z, the depth bits, is 0 exactly for culled Gaussians: visible ones lie beyond the near plane) --
     // and NOT its 64-byte record: nothing reads the record of a Gaussian that is in no tile's list (21 % of the
@@ -599,7 +544,7 @@ __global__ void __launch_bounds__(256) frame_project_kernel(
 // long half (~750 instructions) on full waves of survivors only, so that the 21 % culled Gaussians of the 2.4 M scene
 // stop paying for it lane-masked.  Bit-identical outputs, 21 % fewer long-half wave passes -- and 89 - 92 us against
 // 81 - 82 us for the kernel below (parameters loaded by index in the long half instead of queued: 93 us).
-template <bool DIST, bool OCC = false>
+template <bool DIST>
 __global__ void __launch_bounds__(STRIP_THREADS) frame_project_count_kernel(
     const float *__restrict__ pos, const float4 *__restrict__ quat, const float *__restrict__ scale,
     const float *__restrict__ opa, const float *__restrict__ rgb, int64_t n, ProjectParams P,
@@ -607,12 +552,9 @@ __global__ void __launch_bounds__(STRIP_THREADS) frame_project_count_kernel(
     uint32_t per_slice, gs_strip_geom SG, uint32_t S, uint32_t slice0, unsigned long long *__restrict__ table,
     uint32_t *__restrict__ slice_pairs, uint32_t *__restrict__ slice_vis, const uint32_t *__restrict__ tile_cost,
     uint32_t n_tiles, uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ cut,
-    const unsigned long long *__restrict__ gate) {
-    static_assert(!(OCC && DIST), "the occlusion cull is not combined with the \"dist\" listing");
+    unsigned long long *__restrict__ table_full) {
     extern __shared__ unsigned long long s_hist[];  // [NS] entries << 32 | pairs of this slice
     __shared__ uint32_t s_acc[2];
-    // `gate`: the second, unculled pass of an occlusion-culled frame -- nothing to do unless a tile ran past its cut
-    if (gate && *gate == 0) return;
     if (blockIdx.x >= S) {  // the one extra workgroup of the launch (uniform)
         tile_order_workgroup(tile_cost, n_tiles, tile_order, SG.ntx, SG.nty);
         return;
@@ -626,31 +568,20 @@ __global__ void __launch_bounds__(STRIP_THREADS) frame_project_count_kernel(
     RawGaussian cur = {}, nxt = {};
     if (in_range(threadIdx.x)) cur = load_raw(pos, quat, scale, opa, rgb, g0 + threadIdx.x, P.color_dim);
     for (uint32_t t = threadIdx.x; t < SG.NS; t += STRIP_THREADS) s_hist[t] = 0;
-    // occlusion cuts (GS_FRAME_OCCLUSION_CULL): the per-tile table is staged in LDS behind the histogram, every tile row
-    // padded to whole strips (walk_strips<.., true>), and behind it the largest cut of every block of 4 x 4 tiles
-    // (occluded_everywhere).  Looked up from global memory, two to eight dependent loads per Gaussian inside this
-    // latency-bound kernel cost 62 us at 2.4 M Gaussians (first version, profiles/r06_c_*).
-    uint32_t *s_cut = reinterpret_cast<uint32_t *>(s_hist + SG.NS);
-    const uint32_t cut_stride = SG.nsx * GS_STRIP_W, nbx = (SG.ntx + 3) / 4, nby = (SG.nty + 3) / 4;
-    uint32_t *s_bmax = s_cut + cut_stride * SG.nty;
-    if constexpr (OCC) {
-        for (uint32_t t = threadIdx.x; t < cut_stride * SG.nty; t += STRIP_THREADS) {
-            const uint32_t iy = t / cut_stride, ix = t - iy * cut_stride;
+    // occlusion cuts (GS_FRAME_OCCLUSION_CULL): the per-tile table is staged in LDS behind the histogram -- looked up from
+    // global memory, two to eight dependent loads per Gaussian inside this latency-bound kernel cost 62 us at 2.4 M Gaussians
+    // (first version, profiles/r06_c_*)
+    // A culled frame keeps TWO histograms: the trimmed entries (what this frame emits) and the full ones -- the table the
+    // gated second pass scans if a tile runs past its cut, so that pass needs no recount.  Layout: [NS] trimmed, [NS] full,
+    // then the cuts with every tile row padded to whole strips (walk_strips<.., true>).
+    unsigned long long *s_full = s_hist + SG.NS;
+    uint32_t *s_cut = reinterpret_cast<uint32_t *>(s_hist + 2 * SG.NS);
+    if (cut) {
+        for (uint32_t t = threadIdx.x; t < SG.NS; t += STRIP_THREADS) s_full[t] = 0;
+        const uint32_t stride = SG.nsx * GS_STRIP_W;
+        for (uint32_t t = threadIdx.x; t < stride * SG.nty; t += STRIP_THREADS) {
+            const uint32_t iy = t / stride, ix = t - iy * stride;
             s_cut[t] = ix < SG.ntx ? cut[iy * SG.ntx + ix] : GS_NO_CUT;
-        }
-        __syncthreads();
-        for (uint32_t b = threadIdx.x; b < nbx * nby; b += STRIP_THREADS) {
-            const uint32_t bx = b % nbx, by = b / nbx;
-            uint32_t m = 0;
-            for (uint32_t dy = 0; dy < 4; ++dy)
-                for (uint32_t dx = 0; dx < 4; ++dx) {
-                    const uint32_t x = 4 * bx + dx, y = 4 * by + dy;
-                    if (x < SG.ntx && y < SG.nty) {
-                        const uint32_t c = s_cut[y * cut_stride + x];
-                        m = c > m ? c : m;
-                    }
-                }
-            s_bmax[b] = m;
         }
     }
     if (threadIdx.x < 2) s_acc[threadIdx.x] = 0;
@@ -663,14 +594,21 @@ __global__ void __launch_bounds__(STRIP_THREADS) frame_project_count_kernel(
         uint4 rc = make_uint4(0, 0, 0, 0);
         uint32_t vis = 0;
         float2 cxy = make_float2(0.f, 0.f);
-        if (in_range(i)) rc = project_one<OCC>(cur, g0 + i, P, rec_geom, tiles_touched, rects, vis, cxy, s_bmax, nbx);
+        if (in_range(i)) rc = project_one(cur, g0 + i, P, rec_geom, tiles_touched, rects, vis, cxy);
         acc_cnt += rc.w;
         acc_vis += vis;
-        auto count = [&](uint32_t strip, uint32_t, uint32_t, uint32_t np) { atomicAdd(&s_hist[strip], (1ull << 32) | np); };
-        if constexpr (OCC)
-            walk_strips<false, true>(rc, g0 + i, SG, cxy, D, count, s_cut);
-        else
-            walk_strips<DIST>(rc, g0 + i, SG, cxy, D, count);
+        if (cut) {  // (uniform)
+            if constexpr (!DIST)  // (a "dist" frame is never culled: gs_frame_occlusion_cull)
+                walk_strips<false, true, true>(rc, g0 + i, SG, cxy, D,
+                                               [&](uint32_t strip, uint32_t, uint32_t, uint32_t np, uint32_t full) {
+                                                   atomicAdd(&s_full[strip], (1ull << 32) | full);
+                                                   if (np) atomicAdd(&s_hist[strip], (1ull << 32) | np);
+                                               },
+                                               s_cut);
+        } else {
+            walk_strips<DIST>(rc, g0 + i, SG, cxy, D,
+                              [&](uint32_t strip, uint32_t, uint32_t, uint32_t np) { atomicAdd(&s_hist[strip], (1ull << 32) | np); });
+        }
         cur = nxt;
     }
     // rectangle areas (= gradient-row slots; == pairs unless DIST) and visible Gaussians of this slice
@@ -683,6 +621,10 @@ __global__ void __launch_bounds__(STRIP_THREADS) frame_project_count_kernel(
     __syncthreads();
     unsigned long long *row = table + (size_t)slice * SG.NS;
     for (uint32_t t = threadIdx.x; t < SG.NS; t += STRIP_THREADS) row[t] = s_hist[t];
+    if (cut) {
+        unsigned long long *rowf = table_full + (size_t)slice * SG.NS;
+        for (uint32_t t = threadIdx.x; t < SG.NS; t += STRIP_THREADS) rowf[t] = s_full[t];
+    }
     if (threadIdx.x == 0) {
         slice_pairs[slice] = s_acc[0];
         slice_vis[slice] = s_acc[1];
@@ -1605,9 +1547,7 @@ static ProjectParams make_params(const gs_frame *f) {
 
 // slice_begin / slice_end: the slices of the Gaussian array to project (strip variant with the fused count only:
 // gs_frame_project_slices; every other path projects everything at once: 0, -1)
-// `second_pass`: the unculled re-run of a GS_FRAME_OCCLUSION_CULL frame's project stage, gated on counters[GS_CNT_RANPAST]
-int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream, int slice_begin, int slice_end,
-                     bool second_pass) {
+int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream, int slice_begin, int slice_end) {
     ProjectParams P = make_params(f);
     // sort_modes 0 / 1 read tiles_touched (emit_pairs_kernel); sort_mode 2 reads the rectangle records only
     uint32_t *touched = f->sort_mode == 2 && gs_frame_geometry(f).n_tiles <= GS_BIN_MAX_TILES ? nullptr : ws.tiles_touched;
@@ -1623,8 +1563,7 @@ int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t strea
         GS_HIP(hipGetDevice(&dev));
         if (dev < 64 && !((attr_done.load(std::memory_order_acquire) >> dev) & 1)) {
             std::lock_guard<std::mutex> lock(attr_mu);
-            for (const void *fn : {(const void *)frame_project_count_kernel<false, false>, (const void *)frame_project_count_kernel<true, false>,
-                                   (const void *)frame_project_count_kernel<false, true>})
+            for (const void *fn : {(const void *)frame_project_count_kernel<false>, (const void *)frame_project_count_kernel<true>})
                 // (the kernel also holds ~17 KiB of static LDS -- the tile-order workgroup's bins --: the strip histogram, and the
                 // occlusion cuts behind it in a culled frame, get what gs_frame_occlusion_cull's room rule allows)
                 GS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, GS_BIN_LDS_BYTES - 8 * 4096));
@@ -1632,27 +1571,24 @@ int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t strea
         }
         unsigned long long *table = (unsigned long long *)ws.strip_table;
         // (+ the per-tile occlusion cuts behind the histogram when the frame is culled: gs_frame_occlusion_cull checks the room)
-        const bool occ = gs_frame_occlusion_cull(f) && !second_pass;
-        const size_t lds = sizeof(unsigned long long) * SG.NS + (occ ? gs_cull_lds_bytes(SG.NS, G.ntx, G.nty) : 0);
-        const unsigned long long *gate = second_pass ? ws.counters + GS_CNT_RANPAST : nullptr;
+        const size_t lds = gs_frame_occlusion_cull(f) ? gs_cull_lds_bytes(SG.NS) + sizeof(unsigned long long) * SG.NS
+                                                      : sizeof(unsigned long long) * SG.NS;
         if (slice_end < 0) slice_end = (int)plan.slices;
         GS_CHECK_ARG(slice_begin >= 0 && slice_begin < slice_end && slice_end <= (int)plan.slices, "bad slice range");
         const uint32_t nsl = (uint32_t)(slice_end - slice_begin);
-        const uint32_t extra = (slice_begin == 0 && !second_pass) ? 1u : 0u;  // the tile-order workgroup rides with the first range
-#define GS_LAUNCH_PROJECT_COUNT(DIST, OCC)                                                                             \
-    hipLaunchKernelGGL((frame_project_count_kernel<DIST, OCC>), dim3(nsl + extra), dim3(STRIP_THREADS), lds, stream,   \
+        const uint32_t extra = slice_begin == 0 ? 1u : 0u;  // the tile-order workgroup rides with the first range
+#define GS_LAUNCH_PROJECT_COUNT(DIST)                                                                                  \
+    hipLaunchKernelGGL(frame_project_count_kernel<DIST>, dim3(nsl + extra), dim3(STRIP_THREADS), lds, stream,          \
                        f->pos, (const float4 *)f->quat, f->scale, f->opa, f->rgb, f->N, P, ws.rec_geom, touched,       \
                        ws.rects, D, plan.per_slice, SG, nsl, (uint32_t)slice_begin, table, ws.slice_pairs,             \
-                       ws.slice_vis, ws.tile_cost, (uint32_t)G.n_tiles, ws.tile_order, cut, gate)
-        // GS_FRAME_OCCLUSION_CULL: Gaussians behind every cut they can reach skip their projection, level-1 entries are
-        // trimmed by the cut table the previous frame of this workspace left
-        const uint32_t *cut = occ ? ws.cut : nullptr;
+                       ws.slice_vis, ws.tile_cost, (uint32_t)G.n_tiles, ws.tile_order, cut,                            \
+                       (unsigned long long *)ws.strip_table_full)
+        // GS_FRAME_OCCLUSION_CULL: level-1 entries trimmed by the cut table the previous frame of this workspace left
+        const uint32_t *cut = gs_frame_occlusion_cull(f) ? ws.cut : nullptr;
         if (f->tile_culling_method == 0)
-            GS_LAUNCH_PROJECT_COUNT(true, false);
-        else if (occ)
-            GS_LAUNCH_PROJECT_COUNT(false, true);
+            GS_LAUNCH_PROJECT_COUNT(true);
         else
-            GS_LAUNCH_PROJECT_COUNT(false, false);
+            GS_LAUNCH_PROJECT_COUNT(false);
 #undef GS_LAUNCH_PROJECT_COUNT
         GS_CHECK_LAUNCH();
         return 0;

@@ -95,8 +95,7 @@ BUDGETS = [
     (("raster_backward_mfma_sh_kernelILi48ELi4E",), 168, True),
     (("frame_project_backward_kernelILi3ELi0ELi256ELi0E",), 80, False),  # rgb projection backward: six waves per SIMD
     (("frame_project_backward_kernelILi3ELi0ELi256ELi1E",), 104, False), # ... with the Adam step fused in (round 5): four
-    (("frame_project_count_kernelILb0ELb0E",), 128, False),               # 1024 threads per workgroup: 128 is the hard limit
-    (("frame_project_count_kernelILb0ELb1E",), 128, False),               # ... and its occlusion-culling flavour (round 6)
+    (("frame_project_count_kernelILb0E",), 128, False),                   # 1024 threads per workgroup: 128 is the hard limit
     (("frame_project_bin_count_kernelILb0E",), 128, False),
     (("strip_sort_kernelILi2048ELb0E",), 128, False),                    # four workgroups of 256 per CU
     (("loss_fused_kernel",), 256, False),                                # one workgroup of 512 per CU: two waves per SIMD
@@ -133,9 +132,7 @@ def test_lds_budgets(kernels):
     assert pick(kernels, "frame_project_backward_kernelILi27ELi0ELi128E")[".group_segment_fixed_size"] * 15 <= 160 * 1024
     sort = pick(kernels, "strip_sort_kernelILi2048ELb0E")
     assert sort[".group_segment_fixed_size"] * 4 <= 160 * 1024      # four workgroups per CU
-    assert pick(kernels, "frame_project_count_kernelILb0ELb0E")[".group_segment_fixed_size"] + 8192 * 8 <= 160 * 1024
-    # the occlusion-culling flavour adds the staged cut table: static + the dynamic limit set at launch (cull_project.hip)
-    assert pick(kernels, "frame_project_count_kernelILb0ELb1E")[".group_segment_fixed_size"] + (160000 - 8 * 4096) <= 160 * 1024
+    assert pick(kernels, "frame_project_count_kernelILb0E")[".group_segment_fixed_size"] + 8192 * 8 <= 160 * 1024
 
 
 # ---------------------------------------------------------------------------------------------------------------------
