@@ -2,7 +2,7 @@
 #pragma once
 #include "gs_common.h"
 
-enum { GS_CNT_VISIBLE = 0, GS_CNT_PAIRS = 1, GS_CNT_OVERFLOW = 2, GS_CNT_BUCKETS = 3, GS_CNT_TICKET = 4, GS_CNT_ENTRIES = 5, GS_CNT_BIG = 6, GS_CNT_SEGS = 7, GS_CNT_GROUPS = 8, GS_CNT_MAXLIST = 9, GS_CNT_RANPAST = 10, GS_CNT_TAG = 11, GS_CNT_N = 16 };
+enum { GS_CNT_VISIBLE = 0, GS_CNT_PAIRS = 1, GS_CNT_OVERFLOW = 2, GS_CNT_BUCKETS = 3, GS_CNT_TICKET = 4, GS_CNT_ENTRIES = 5, GS_CNT_BIG = 6, GS_CNT_SEGS = 7, GS_CNT_GROUPS = 8, GS_CNT_MAXLIST = 9, GS_CNT_RANPAST = 10, GS_CNT_TAG = 11, GS_CNT_EXCESS = 12, GS_CNT_N = 16 };
 
 #define GS_BUCKET 64          // Gaussians per backward bucket (= wavefront size)
 #define GS_SORT_TILE 2048     // keys per radix-sort workgroup (256 threads x 8)
@@ -66,7 +66,7 @@ static inline gs_bin_plan gs_bin_plan_for(int64_t N, int64_t max_pairs, int n_ti
 // lone wave -- while the device idles: 0.60 ms (rgb) / 1.82 ms (SH degree 2) where the work is worth 0.21 / 1.0 ms.  Same-box
 // A/B (profiles/r05_n_*), 2048 / 1024 -> 512 / 512: pile forward 0.56 -> 0.38 ms (rgb), 1.51 -> 0.86 ms (SH); the densifying
 // soak's last block +10 ... +15 %; 512 / 256 and 1024 / 512 measured within 5 % of it.  Only flagged frames are concerned
-// (GS_FRAME_LONG_LISTS: the caller's rule -- gs_frame.py flags once the longest list exceeds max(6,144, pairs / 400), round 6;
+// (GS_FRAME_LONG_LISTS: the caller's rule -- gs_frame.py's cost model over longest list / pairs / pairs beyond 512, round 6;
 // unflagged frames walk lists of any length with one wave by design, and lists beyond 2,048 take the big-list SORT alone,
 // GS_FRAME_LONG_SORT); a tile that saturates before 512 Gaussians never continues.
 #ifndef GS_LONG_MIN

@@ -289,103 +289,44 @@ class FrameRenderer:
     # frames are never even looked at.  (Found at the end of round 5: two 7,001-iteration fits that are bit-identical step by
     # step in lockstep ended 0.1 dB apart when run at their own pace, tools/fused_adam_bisect.py.)  Waiting for the copy of
     # frame k before frame k + 8 is issued costs nothing -- seven frames are queued behind it -- and bounds the lag.
-    # Long tile lists: what the following frames are flagged with, from the counters every frame carries (longest list, M).
+    # Long tile lists: what the following frames are flagged with, from the counters every frame carries (longest list, M,
+    # and X = the pairs that lie beyond the first 512 of their tile's list).
     #   GS_FRAME_LONG_SORT -- lists beyond the per-tile sort's LDS window go to big_list_sort_kernel -- as soon as a list beyond
     #     LONG_SORT_FLAG_AT = 2,048 (that window) was seen: the sorted list is the same either way, and in a trained /
     #     densified scene (3.9 M pairs, 165 lists beyond 2,048) the per-tile sort drops from 407 to 122 us whatever the
     #     colour model (profiles/r06_a_trained_state_flag_ab.txt);
-    #   GS_FRAME_LONG_LISTS -- segmented compositing of every tile beyond 512 entries (two passes in training) -- only where
-    #     the serial walk of the longest list outlasts the whole frame's compositing: a wave that is alone on its SIMD
-    #     composites a Gaussian in ~48 ns (rgb) / ~190 ns (SH degree 2), the full device one in 0.066 / 0.26 ns -- the
-    #     same ratio, ~720, for every colour model --, and the segment path costs ~2 x the plain kernel on the same scene
-    #     (rgb 0.26 -> 0.51 ms, SH 1.04 -> 1.47 ms at 3.9 M pairs, longest list 5,361: r06_a), so it pays from
-    #     longest > ~2 M / 720 on: flagged when longest > max(LONG_LIST_FLAG_AT, M / LONG_LIST_PAIRS_PER_STEP).  A pile
-    #     (100,000 Gaussians in one tile on a 1.1 M-pair frame) is far beyond that; the densifying run's end states
-    #     (longest 4,000 - 6,000 at 3.4 - 4 M pairs) are not, for any colour model -- round 5 ran those flagged and lost
-    #     2 x in the forward's compositing.
+    #   GS_FRAME_LONG_LISTS -- segmented compositing of every tile beyond 512 entries (two passes) -- by a COST MODEL per
+    #     colour model (round 6; VERDICT round 5, item 3b: one threshold for all colour models made SH end states slower):
+    #       plain   = max(longest x c_lone, M x c_dev)      a wave alone on its SIMD walks the longest list while the device
+    #                                                       composites everything else
+    #       flagged = (M - X) x c_dev + X x k x c_dev + 50 us   the segment kernels cost k x the plain kernel per step they
+    #                                                       take over (pass 1 + pass 2 + combine) plus their launches
+    #     with (c_dev, c_lone, k) measured on the trained-like scene (r06_a: 3.9 M pairs, X = 1.02 M, longest 5,361):
+    #     rgb 0.066 ns / 48 ns / 4.4, SH degree 2 0.264 / 190 / 2.3, degree 3 0.37 / 270 / 2.3.  Flagged when the model
+    #     says it saves 10 %, unflagged again when it says it costs 10 %.  That scene: plain 0.26 / 1.04 ms against 0.51 /
+    #     1.47 ms flagged (model: 0.26 / 1.04 against 0.54 / 1.43) -> not flagged; a densifying run's end state with a few
+    #     piles (longest 6,300 at 2.6 M pairs, X ~ 0.15 M) -> SH flagged (1.2 against 0.8 ms), rgb not (0.30 against 0.27);
+    #     one 100,000-Gaussian pile on a 1.1 M-pair frame -> flagged for every colour model (4.8 against 0.5 ms).
+    #     Lists up to LONG_LIST_FLAG_AT = 2,048 never flag: below the sort window there is nothing to gain.
     LONG_SORT_FLAG_AT = int(os.environ.get("GS_FRAME_LONG_SORT_FLAG_AT", "2048"))
-    LONG_LIST_FLAG_AT = int(os.environ.get("GS_FRAME_LONG_LIST_FLAG_AT", "6144"))
-    LONG_LIST_PAIRS_PER_STEP = int(os.environ.get("GS_FRAME_LONG_LIST_PAIRS_PER_STEP", "400"))
+    LONG_LIST_FLAG_AT = int(os.environ.get("GS_FRAME_LONG_LIST_FLAG_AT", "2048"))
+    LONG_LIST_COST = {3: (0.066, 48.0, 4.4), 27: (0.264, 190.0, 2.3), 48: (0.37, 270.0, 2.3)}  # ns, ns, ratio
 
-    # The occlusion cull is exact for ANY camera -- a frame whose trimmed lists prove too short is rendered again from the
-    # full ones --, but that second pass costs 0.6 of a frame, and with 8,160 tiles SOME tile runs past its cut in nearly
-    # every frame of a moving camera (a pixel at the rim of an opaque Gaussian's footprint sees through to something twice
-    # as deep).  So the cull is only allowed while the camera has (all but) stayed where the cut table was recorded: a
-    # viewer at rest, a benchmark or an evaluation that renders one view repeatedly, a trainer that re-renders a test view.
-    # The reference's own evaluation loop walks through DIFFERENT test cameras (train.py:240-266): those frames are not
-    # culled and pay nothing for the feature (no gated launches without the flag).
-    CULL_MAX_SHIFT_PX = float(os.environ.get("GS_FRAME_CULL_MAX_SHIFT_PX", "1.0"))
-
-    def _camera_shift_px(self, camera) -> float:
-        """Upper estimate of how far image content moved, in pixels, between the camera the cut table was recorded under
-        and ``camera``: rotation angle x focal length + focal length x camera-centre displacement / 1 (unit depth)."""
-        prev, cur = getattr(self, "_cut_ck", None), getattr(self, "_cur_ck", None)
-        if prev is None or cur is None or prev[:4] != cur[:4]:  # (width, height, focal lengths)
-            return float("inf")
-        if prev[5] == cur[5] and prev[6] == cur[6]:  # the same pose, byte for byte (the common case: no arithmetic)
-            return 0.0
-        r0, t0 = np.frombuffer(prev[5], np.float32).astype(np.float64).reshape(3, 3), np.frombuffer(prev[6], np.float32).astype(np.float64)
-        r1, t1 = np.frombuffer(cur[5], np.float32).astype(np.float64).reshape(3, 3), np.frombuffer(cur[6], np.float32).astype(np.float64)
-        ang = float(np.arccos(np.clip((np.trace(r1 @ r0.T) - 1.0) / 2.0, -1.0, 1.0)))
-        dc = float(np.linalg.norm(r1.T @ t1 - r0.T @ t0))
-        return max(float(cur[2]), float(cur[3])) * (ang + dc)
-
-    # Whether the cull PAYS is a property of the scene: on the opaque 2.4 M-Gaussian scene 74 % of the pairs are dropped and
-    # the frame gains 5 %; on a scene whose tiles do not saturate (BASELINE configs[1], a trained model) nothing is dropped
-    # and the gated launches + the second histogram cost 10 % (profiles/r06_d_*).  So the first unculled and the first culled
-    # frame of a run of inference frames copy their counters to pinned memory (tagged, asynchronous: no synchronisation);
-    # when they have landed the renderer keeps the cull if it emitted < CULL_MIN_GAIN of the frame's pairs without falling
-    # back, else switches it off for `_cull_backoff` frames (256, doubling up to 4,096 while it keeps failing).
-    CULL_MIN_GAIN = float(os.environ.get("GS_FRAME_CULL_MIN_GAIN", "0.65"))
-
-    def _cull_probe_step(self, f, stream):
-        p = self._cull_probe
-        if p is not None and p[0].query():
-            h = p[1].tolist()
-            self._cull_probe = None
-            if (int(h[11]) & 0xffffffff) == (p[2] & 0xffffffff):
-                pairs, ran_past = int(h[1]), int(h[10])
-                if int(h[2]) or pairs <= 0:
-                    pass  # an overflowed (empty) frame says nothing about the scene
-                elif not p[3]:
-                    self._cull_full_pairs, self._cull_full_serial = pairs, p[2]
-                elif self._cull_full_pairs:
-                    if ran_past or pairs > self.CULL_MIN_GAIN * self._cull_full_pairs:
-                        self._cull_off_until = self._frame_serial + self._cull_backoff
-                        self._cull_backoff = min(2 * self._cull_backoff, 4096)
-                        self._cull_settled = False
-                    else:
-                        self._cull_settled, self._cull_backoff = True, 256
-        culled = bool(f.flags & _lib.GS_FRAME_OCCLUSION_CULL)
-        if not culled:
-            self._cull_settled = False  # (camera moved, workspace changed, switched off: the next culled frame is looked at again)
-        # what is worth a copy: a culled frame that has not been judged yet, and an unculled one when the frame's full pair
-        # count is unknown or older than 64 frames (a moving camera renders unculled frame after unculled frame)
-        fresh = self._cull_full_pairs is not None and self._frame_serial - getattr(self, "_cull_full_serial", -10**9) <= 64
-        want = (not self._cull_settled and self._cull_full_pairs is not None) if culled else not fresh
-        if culled and self._cull_full_pairs is None and self._cull_probe is None:
-            self._cull_off_until = self._frame_serial + 1  # nothing to compare with yet: one unculled frame, which is probed
-        if self._cull_probe is None and want:
-            host = getattr(self, "_cull_host", None)
-            if host is None:
-                host = self._cull_host = torch.zeros(_lib.GS_STATS_TAGGED_N, dtype=torch.int64).pin_memory()
-            _lib.check(_lib.gs_frame_stats_tagged_async(C.byref(f), self._frame_serial & 0xffffffff, host.data_ptr(), stream),
-                       "gs_frame_stats_tagged_async")
-            ev = torch.cuda.Event()
-            ev.record(self._stream())
-            self._cull_probe = (ev, host, self._frame_serial, culled)
-
-    def _note_cut_table(self, f):
-        """Every inference frame's compositing launch leaves the per-tile occlusion cuts of ITS frame in the workspace: the
-        next forward of the same size may use them (GS_FRAME_OCCLUSION_CULL).  A training forward does not write the table
-        (and may use the workspace differently): no cull right behind one."""
-        self._cut_key = None if f.training else (self._ws.data_ptr(), int(f.width), int(f.height))
-        self._cut_ck = getattr(self, "_cur_ck", None)  # the camera (by value) the table was recorded under
-
-    def _note_lists(self, longest: int, pairs: int):
+    def _note_lists(self, longest: int, pairs: int, excess: int = None):
         self._long_sort_seen = self._long_sort_seen or longest > self.LONG_SORT_FLAG_AT
-        self._long_lists_seen = self._long_lists_seen or \
-            longest > max(self.LONG_LIST_FLAG_AT, pairs // self.LONG_LIST_PAIRS_PER_STEP)
+        if longest <= self.LONG_LIST_FLAG_AT:
+            return
+        cdim = int(self._frame.color_dim) if self._frame is not None else 3
+        c_dev, c_lone, k = self.LONG_LIST_COST.get(cdim, self.LONG_LIST_COST[3])
+        x = min(max(int(excess or 0), 0), pairs)
+        plain = max(longest * c_lone, pairs * c_dev)
+        flagged = (pairs - x) * c_dev + x * k * c_dev + 50_000.0
+        if flagged < 0.9 * plain:
+            self._long_lists_seen = True
+        elif flagged > 1.1 * plain and not (self._frame is not None and self._frame.flags & _lib.GS_FRAME_LONG_LISTS):
+            # (only judged on UNFLAGGED frames: a flagged frame's counters are the same lists, but keeping the decision to
+            # frames that ran the plain path avoids flapping on the model's own error)
+            self._long_lists_seen = False
 
     ASYNC_COUNTER_LAG = int(os.environ.get("GS_FRAME_COUNTER_LAG", "8"))  # (the variable: A/B measurements)
 
@@ -396,11 +337,11 @@ class FrameRenderer:
             self._async_event.synchronize()
         if self._async_event is not None and self._async_event.query():
             h = self._async_host.tolist()
-            v, m, o, b, longest, tag = (int(h[k]) for k in (0, 1, 2, 3, 9, 11))
+            v, m, o, b, longest, tag, excess = (int(h[k]) for k in (0, 1, 2, 3, 9, 11, 12))
             self._async_event = None
             if (tag & 0xffffffff) != (self._async_serial & 0xffffffff):
                 return  # (cannot happen in stream order; counters without their frame's tag are not acted upon)
-            self._note_lists(longest, m)
+            self._note_lists(longest, m, excess)
             # (NOT the backward-kernel choice: counters that arrive asynchronously would make it -- and with it the
             # gradients' last bits -- depend on host timing; it moves at synchronous stats() calls only)
             if o:
@@ -675,9 +616,9 @@ class FrameRenderer:
                                                     stream.cuda_stream), "gs_frame_stats_tagged_async")
         stream.synchronize()
         h = self._stats_host.tolist()
-        v, m, o, b, longest, ran_past = (int(h[k]) for k in (0, 1, 2, 3, 9, 10))
+        v, m, o, b, longest, ran_past, excess = (int(h[k]) for k in (0, 1, 2, 3, 9, 10, 12))
         assert (int(h[11]) & 0xffffffff) == tag, "gs_frame_stats_tagged_async: the tag did not come back"
-        self._note_lists(longest, m)
+        self._note_lists(longest, m, excess)
         # The bucket counter is written by the backward's preparation on the library's SIDE stream; the copy above is
         # ordered behind it only once a backward of this frame has been issued on this stream (it waits for the side
         # stream).  A stats() call between forward and backward may read 0, the previous frame's count or this one's:

@@ -331,22 +331,23 @@ int gs_frame_stats_async(const gs_frame *f, int64_t *stats_host, gs_stream_t str
 
 /* Length of the longest tile list of the last forward on this workspace (sort_mode 2, strip variant; lists of up to
  * 1024 pairs are reported as 0), copied device->host asynchronously into *longest_host.  A caller that sees a value
- * above 2,048 sets GS_FRAME_LONG_SORT, one above max(6,144, pairs / 400) GS_FRAME_LONG_LISTS on the following frames
- * (gs_frame.py, FrameRenderer._note_lists: where the segmented compositing starts to pay, for every colour model). */
+ * above 2,048 sets GS_FRAME_LONG_SORT on the following frames; GS_FRAME_LONG_LISTS follows a cost model over the longest list,
+ * the pairs and the pairs beyond 512 per tile (gs_frame.py, FrameRenderer._note_lists). */
 int gs_frame_longest_list_async(const gs_frame *f, int64_t *longest_host, gs_stream_t stream);
 
 /* The ABI-level guard against LAGGING counters (round 6).  A client that copies the counters
  * asynchronously and looks at them frames later -- to grow its workspace, to set GS_FRAME_LONG_SORT / GS_FRAME_LONG_LISTS /
  * GS_FRAME_BWD_ROWS -- must know WHICH frame they belong to: flags latched from the counters of frame k while frame k + 500
  * is being issued made a training run timing-dependent in round 5.  This call enqueues, on `stream`: a fill of the counter
- * block's tag word with `tag` (the client's frame number), then ONE device-to-host copy of GS_STATS_TAGGED_N = 12 values:
+ * block's tag word with `tag` (the client's frame number), then ONE device-to-host copy of GS_STATS_TAGGED_N = 13 values:
  *   [0] visible, [1] emitted pairs, [2] overflow (0, or the pairs the frame needed), [3] buckets (low 32 bits: in the
  *   backward's work list, high: of saturated tiles), [4..8] internal, [9] longest tile list (0 up to 1,024), [10] non-zero iff
- *   an occlusion-culled frame was rendered again from its full lists, [11] the tag (both 32-bit halves).
+ *   an occlusion-culled frame was rendered again from its full lists, [11] the tag (both 32-bit halves), [12] pairs that lie
+ *   beyond the first 512 of their tile's list (strip variant: what a GS_FRAME_LONG_LISTS frame would composite in segments).
  * stats_host[11] == tag (low half) <=> the copy has landed and the values are those of the frame issued just before this
  * call on `stream`.  stats_host should be pinned memory (the copy is asynchronous only then).  Recommended policy
  * (gs_frame.py): one copy in flight, and never issue frame k + 8 before the counters of frame k have been looked at. */
-#define GS_STATS_TAGGED_N 12
+#define GS_STATS_TAGGED_N 13
 int gs_frame_stats_tagged_async(const gs_frame *f, uint32_t tag, int64_t *stats_host, gs_stream_t stream);
 
 /* Non-zero in *ran_past_host (after `stream` has reached this copy) iff the frame's lists had been trimmed

@@ -133,16 +133,19 @@ def test_long_list_kernels_follow_the_longest_list_statistic(gpu):
 
 
 def test_lists_beyond_the_sort_window_switch_the_sort_alone(gpu):
-    """Round 6: lists of 4,100 - 5,000 pairs (beyond the per-tile sort's 2,048-pair LDS window, below what the segmented
-    compositing pays for): the renderer sets GS_FRAME_LONG_SORT (128) from the second frame on and NOT
-    GS_FRAME_LONG_LISTS (16) -- the lists go to big_list_sort_kernel, the compositing keeps its one-wave walk.  The sort
-    is exact in every variant, so the flagged frame's list AND image equal the first frame's bit for bit."""
-    scene, cam = make_scene(14_000, 48, 32, seed=8), make_camera(48, 32)
+    """Round 6: 768 tiles with lists of 2,200 - 2,900 pairs each (beyond the per-tile sort's 2,048-pair LDS window; the device
+    is busy with them, so cutting them into segments would only add work): the renderer sets GS_FRAME_LONG_SORT (128) from
+    the second frame on and NOT GS_FRAME_LONG_LISTS (16) -- the lists go to big_list_sort_kernel, the compositing keeps
+    its one-wave walk (the cost model of FrameRenderer._note_lists).  The sort is exact in every variant, so the flagged
+    frame's list AND image equal the first frame's bit for bit.  Six tiles with lists of 4,100 - 5,000 and nothing else on
+    the device, on the other hand, DO take the segments: the same model."""
+    scene, cam = make_scene(240_000, 512, 384, seed=8, max_px_sigma=40.0), make_camera(512, 384)
+    scene.opa -= 4.0
     of = OracleFrame(scene, cam)
     lens = np.diff(of.accum)
-    assert 2048 < lens.min() and lens.max() <= FrameRenderer.LONG_LIST_FLAG_AT
+    assert (lens > 2048).sum() > 500 and lens.max() < 4096
     params = to_torch(scene, gpu)
-    r = FrameRenderer(gpu, max_pairs=len(of.ids) + 64, auto_grow=True, force_strips=False, emit_sorted_keys=True)
+    r = FrameRenderer(gpu, max_pairs=len(of.ids) + 64, auto_grow=True, emit_sorted_keys=True)
     first, _ = r.forward(*params, cam)
     assert not (r._frame.flags & (16 | 128))
     assert r.stats().longest_list == int(lens.max()) and r._long_sort_seen and not r._long_lists_seen
@@ -155,7 +158,7 @@ def test_lists_beyond_the_sort_window_switch_the_sort_alone(gpu):
     assert torch.equal(first, second)
     assert np.abs(second.cpu().numpy() - of.image).max() < IMG_ATOL
     # training frames too: same image, gradients bit-identical with and without the flag (the backward never looks at it)
-    g = torch.randn(32, 48, 3, device=gpu)
+    g = torch.randn(384, 512, 3, device=gpu)
     grads = []
     for flagged in (False, True):
         rt = FrameRenderer(gpu, max_pairs=len(of.ids) + 64, training=True, auto_grow=False)
@@ -164,6 +167,14 @@ def test_lists_beyond_the_sort_window_switch_the_sort_alone(gpu):
         assert bool(rt._frame.flags & 128) == flagged and torch.equal(img, first)
         grads.append([t.clone() for t in rt.backward(g)])
     assert all(torch.equal(a, b) for a, b in zip(*grads))
+    # six long lists on an otherwise idle device: the model asks for the segments
+    few, cam2 = make_scene(14_000, 48, 32, seed=8), make_camera(48, 32)
+    r2 = FrameRenderer(gpu, max_pairs=1 << 16, auto_grow=True)
+    a, _ = r2.forward(*to_torch(few, gpu), cam2)
+    st = r2.stats()
+    assert 4096 < st.longest_list <= 6144 and r2._long_lists_seen and r2._long_sort_seen
+    b, _ = r2.forward(*to_torch(few, gpu), cam2)
+    assert (r2._frame.flags & 16) and float((a - b).abs().max()) < 1e-5
 
 
 # ------------------------------------------------------------------ temporal occlusion cull (GS_FRAME_OCCLUSION_CULL)
