@@ -312,6 +312,83 @@ class FrameRenderer:
     LONG_LIST_FLAG_AT = int(os.environ.get("GS_FRAME_LONG_LIST_FLAG_AT", "2048"))
     LONG_LIST_COST = {3: (0.066, 48.0, 4.4), 27: (0.264, 190.0, 2.3), 48: (0.37, 270.0, 2.3)}  # ns, ns, ratio
 
+    # The occlusion cull is exact for ANY camera -- a frame whose trimmed lists prove too short is rendered again from the
+    # full ones --, but that second pass costs 0.6 of a frame, and with 8,160 tiles SOME tile runs past its cut in nearly
+    # every frame of a moving camera (a pixel at the rim of an opaque Gaussian's footprint sees through to something twice
+    # as deep).  So the cull is only allowed while the camera has (all but) stayed where the cut table was recorded: a
+    # viewer at rest, a benchmark or an evaluation that renders one view repeatedly, a trainer that re-renders a test view.
+    # The reference's own evaluation loop walks through DIFFERENT test cameras (train.py:240-266): those frames are not
+    # culled and pay nothing for the feature (no gated launches without the flag).
+    CULL_MAX_SHIFT_PX = float(os.environ.get("GS_FRAME_CULL_MAX_SHIFT_PX", "1.0"))
+
+    def _camera_shift_px(self, camera) -> float:
+        """Upper estimate of how far image content moved, in pixels, between the camera the cut table was recorded under
+        and ``camera``: rotation angle x focal length + focal length x camera-centre displacement / 1 (unit depth)."""
+        prev, cur = getattr(self, "_cut_ck", None), getattr(self, "_cur_ck", None)
+        if prev is None or cur is None or prev[:4] != cur[:4]:  # (width, height, focal lengths)
+            return float("inf")
+        if prev[5] == cur[5] and prev[6] == cur[6]:  # the same pose, byte for byte (the common case: no arithmetic)
+            return 0.0
+        r0, t0 = np.frombuffer(prev[5], np.float32).astype(np.float64).reshape(3, 3), np.frombuffer(prev[6], np.float32).astype(np.float64)
+        r1, t1 = np.frombuffer(cur[5], np.float32).astype(np.float64).reshape(3, 3), np.frombuffer(cur[6], np.float32).astype(np.float64)
+        ang = float(np.arccos(np.clip((np.trace(r1 @ r0.T) - 1.0) / 2.0, -1.0, 1.0)))
+        dc = float(np.linalg.norm(r1.T @ t1 - r0.T @ t0))
+        return max(float(cur[2]), float(cur[3])) * (ang + dc)
+
+    # Whether the cull PAYS is a property of the scene: on the opaque 2.4 M-Gaussian scene 74 % of the pairs are dropped and
+    # the frame gains 5 %; on a scene whose tiles do not saturate (BASELINE configs[1], a trained model) nothing is dropped
+    # and the gated launches + the second histogram cost 10 % (profiles/r06_d_*).  So the first unculled and the first culled
+    # frame of a run of inference frames copy their counters to pinned memory (tagged, asynchronous: no synchronisation);
+    # when they have landed the renderer keeps the cull if it emitted < CULL_MIN_GAIN of the frame's pairs without falling
+    # back, else switches it off for `_cull_backoff` frames (256, doubling up to 4,096 while it keeps failing).
+    CULL_MIN_GAIN = float(os.environ.get("GS_FRAME_CULL_MIN_GAIN", "0.65"))
+
+    def _cull_probe_step(self, f, stream):
+        if torch.cuda.is_current_stream_capturing():
+            return  # (a frame being captured into a graph: no event queries, no copies to the host)
+        p = self._cull_probe
+        if p is not None and p[0].query():
+            h = p[1].tolist()
+            self._cull_probe = None
+            if (int(h[11]) & 0xffffffff) == (p[2] & 0xffffffff):
+                pairs, ran_past = int(h[1]), int(h[10])
+                if int(h[2]) or pairs <= 0:
+                    pass  # an overflowed (empty) frame says nothing about the scene
+                elif not p[3]:
+                    self._cull_full_pairs, self._cull_full_serial = pairs, p[2]
+                elif self._cull_full_pairs:
+                    if ran_past or pairs > self.CULL_MIN_GAIN * self._cull_full_pairs:
+                        self._cull_off_until = self._frame_serial + self._cull_backoff
+                        self._cull_backoff = min(2 * self._cull_backoff, 4096)
+                        self._cull_settled = False
+                    else:
+                        self._cull_settled, self._cull_backoff = True, 256
+        culled = bool(f.flags & _lib.GS_FRAME_OCCLUSION_CULL)
+        if not culled:
+            self._cull_settled = False  # (camera moved, workspace changed, switched off: the next culled frame is looked at again)
+        # what is worth a copy: a culled frame that has not been judged yet, and an unculled one when the frame's full pair
+        # count is unknown or older than 64 frames (a moving camera renders unculled frame after unculled frame)
+        fresh = self._cull_full_pairs is not None and self._frame_serial - getattr(self, "_cull_full_serial", -10**9) <= 64
+        want = (not self._cull_settled and self._cull_full_pairs is not None) if culled else not fresh
+        if culled and self._cull_full_pairs is None and self._cull_probe is None:
+            self._cull_off_until = self._frame_serial + 1  # nothing to compare with yet: one unculled frame, which is probed
+        if self._cull_probe is None and want:
+            host = getattr(self, "_cull_host", None)
+            if host is None:
+                host = self._cull_host = torch.zeros(_lib.GS_STATS_TAGGED_N, dtype=torch.int64).pin_memory()
+            _lib.check(_lib.gs_frame_stats_tagged_async(C.byref(f), self._frame_serial & 0xffffffff, host.data_ptr(), stream),
+                       "gs_frame_stats_tagged_async")
+            ev = torch.cuda.Event()
+            ev.record(self._stream())
+            self._cull_probe = (ev, host, self._frame_serial, culled)
+
+    def _note_cut_table(self, f):
+        """Every inference frame's compositing launch leaves the per-tile occlusion cuts of ITS frame in the workspace: the
+        next forward of the same size may use them (GS_FRAME_OCCLUSION_CULL).  A training forward does not write the table
+        (and may use the workspace differently): no cull right behind one."""
+        self._cut_key = None if f.training else (self._ws.data_ptr(), int(f.width), int(f.height))
+        self._cut_ck = getattr(self, "_cur_ck", None)  # the camera (by value) the table was recorded under
+
     def _note_lists(self, longest: int, pairs: int, excess: int = None):
         self._long_sort_seen = self._long_sort_seen or longest > self.LONG_SORT_FLAG_AT
         if longest <= self.LONG_LIST_FLAG_AT:

@@ -276,10 +276,29 @@ def main():
         dt, blocks = time_frames(frame, steps, warmup)
         lat = latency_fps(frame)
         st_run = r.stats()  # the steady-state frame: pairs EMITTED (after the occlusion cull), did it fall back
+        st_run_culled = bool(r._frame.flags & 256)
+        # the same workload with a camera that MOVES every frame (a viewer's pan: 0.01 degree per frame, 1.4 px): the
+        # occlusion cull is not applied (its host-side rule: only while the camera has stayed within a pixel), the host
+        # rebuilds the frame descriptor every frame -- what `value` was measured like up to round 5, pose changes included
+        W_, H_ = CONFIGS[cfg][1], CONFIGS[cfg][2]
+        pan = [make_camera(W_, H_, yaw_deg=5.0 * rank + 0.01 * i) for i in range(40)]
+        mv = [0]
+
+        def moving_frame():
+            mv[0] += 1
+            r.forward(*params, pan[mv[0] % len(pan)] if (mv[0] // len(pan)) % 2 == 0 else pan[-1 - mv[0] % len(pan)])
+
+        dt_mv, _ = time_frames(moving_frame, steps, warmup, repeats=15)
+        moving_culled = bool(r._frame.flags & 256)
+        r.forward(*params, cam)
         res = {"fps": world * steps / dt, "ms": dt / steps * 1e3, "host_us": host_us, "stats": st, "latency": lat,
                "scene": scene, "cam": cam, "params": params, "renderer": r, "repeats": len(blocks),
-               "occlusion_cull": {"active": bool(r._frame.flags & 256), "pairs_emitted": st_run.pairs,
+               "occlusion_cull": {"active": st_run_culled, "pairs_emitted": st_run.pairs,
                                   "pairs_of_the_frame": st.pairs, "fell_back": st_run.cull_fallback},
+               "moving_camera": {"fps": round(world * steps / dt_mv, 2), "ms_per_frame": round(dt_mv / steps * 1e3, 4),
+                                 "culled": moving_culled,
+                                 "what": "the camera yaws 0.01 degree (1.4 px) per frame: no occlusion cull, a new frame "
+                                         "descriptor per frame"},
                "ms_min": min(blocks) / steps * 1e3, "ms_max": max(blocks) / steps * 1e3}
         if rank == 0:
             prof = [r.profile_forward(*params, cam) for _ in range(25)][5:]
@@ -366,6 +385,7 @@ def main():
         # temporal occlusion cull (include/gs_abi.h, GS_FRAME_OCCLUSION_CULL): the steady-state frame emits / sorts only the
         # pairs in front of the depth at which the previous frame's tiles stopped; the image is bit-identical
         "occlusion_cull": head["occlusion_cull"],
+        "moving_camera": head["moving_camera"],
         # the reference quotes FPS as one frame between two events with a synchronisation per frame (train.py:259-266);
         # `value` is throughput (K frames queued, one synchronisation) -- both, side by side
         "latency_fps": head["latency"]["fps"], "latency": head["latency"],
@@ -469,7 +489,7 @@ def main():
                            "visible": c2["stats"].visible,
                            "tile_pairs": c2["stats"].pairs, "host_us_per_frame": round(c2["host_us"], 1),
                            "latency_fps": c2["latency"]["fps"], "latency": c2["latency"],
-                           "occlusion_cull": c2["occlusion_cull"]}
+                           "occlusion_cull": c2["occlusion_cull"], "moving_camera": c2["moving_camera"]}
             if rank == 0:
                 out["cfg2"].update(roofline=c2["roofline"], stages=c2["stages"], frame_roofline=c2["frame_roofline"])
             del c2
