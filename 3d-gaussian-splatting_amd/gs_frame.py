@@ -238,6 +238,9 @@ class FrameRenderer:
         base = self._ws.data_ptr()
         f.workspace = (base + 255) // 256 * 256
         f.workspace_bytes = self._ws.numel() - (f.workspace - base)
+        if getattr(self, "_cull_scene_key", None) != (pos.data_ptr(), n):
+            # other tensors / another Gaussian count: what the cull was judged against no longer applies
+            self._cull_scene_key, self._cull_full_pairs, self._cull_settled = (pos.data_ptr(), n), None, False
         if self.occlusion_cull is not False and not training and not self.emit_sorted_keys and \
                 self._cut_key == (base, grid.width, grid.height) and self._frame_serial >= self._cull_off_until and \
                 self._camera_shift_px(camera) <= self.CULL_MAX_SHIFT_PX:
@@ -364,12 +367,15 @@ class FrameRenderer:
                     else:
                         self._cull_settled, self._cull_backoff = True, 256
         culled = bool(f.flags & _lib.GS_FRAME_OCCLUSION_CULL)
+        # (judged from the SECOND culled frame of a run on: the first one may have been trimmed by a cut table that another
+        # scene or another set of parameters left in the workspace -- all GS_NO_CUT, or cuts that make it fall back)
+        self._cull_run = getattr(self, "_cull_run", 0) + 1 if culled else 0
         if not culled:
-            self._cull_settled = False  # (camera moved, workspace changed, switched off: the next culled frame is looked at again)
+            self._cull_settled = False  # (camera moved, workspace changed, switched off: the next culled frames are looked at again)
         # what is worth a copy: a culled frame that has not been judged yet, and an unculled one when the frame's full pair
         # count is unknown or older than 64 frames (a moving camera renders unculled frame after unculled frame)
         fresh = self._cull_full_pairs is not None and self._frame_serial - getattr(self, "_cull_full_serial", -10**9) <= 64
-        want = (not self._cull_settled and self._cull_full_pairs is not None) if culled else not fresh
+        want = (not self._cull_settled and self._cull_full_pairs is not None and self._cull_run >= 2) if culled else not fresh
         if culled and self._cull_full_pairs is None and self._cull_probe is None:
             self._cull_off_until = self._frame_serial + 1  # nothing to compare with yet: one unculled frame, which is probed
         if self._cull_probe is None and want:
