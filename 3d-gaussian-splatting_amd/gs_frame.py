@@ -241,9 +241,12 @@ class FrameRenderer:
         if getattr(self, "_cull_scene_key", None) != (pos.data_ptr(), n):
             # other tensors / another Gaussian count: what the cull was judged against no longer applies
             self._cull_scene_key, self._cull_full_pairs, self._cull_settled = (pos.data_ptr(), n), None, False
+        shift = self._camera_shift_px(camera)
+        if shift > 0.0:
+            self._cull_settled = False  # another pose: whether the cull still pays is looked at again
         if self.occlusion_cull is not False and not training and not self.emit_sorted_keys and \
                 self._cut_key == (base, grid.width, grid.height) and self._frame_serial >= self._cull_off_until and \
-                self._camera_shift_px(camera) <= self.CULL_MAX_SHIFT_PX:
+                shift <= self.CULL_MAX_SHIFT_PX:
             f.flags |= _lib.GS_FRAME_OCCLUSION_CULL  # (the library ignores it where the cull does not apply)
         self._grid = grid
         return f
@@ -318,11 +321,13 @@ class FrameRenderer:
     # The occlusion cull is exact for ANY camera -- a frame whose trimmed lists prove too short is rendered again from the
     # full ones --, but that second pass costs 0.6 of a frame, and with 8,160 tiles SOME tile runs past its cut in nearly
     # every frame of a moving camera (a pixel at the rim of an opaque Gaussian's footprint sees through to something twice
-    # as deep).  So the cull is only allowed while the camera has (all but) stayed where the cut table was recorded: a
+    # as deep).  So the cull is only allowed while the camera has stayed where the cut table was recorded: a
     # viewer at rest, a benchmark or an evaluation that renders one view repeatedly, a trainer that re-renders a test view.
     # The reference's own evaluation loop walks through DIFFERENT test cameras (train.py:240-266): those frames are not
     # culled and pay nothing for the feature (no gated launches without the flag).
-    CULL_MAX_SHIFT_PX = float(os.environ.get("GS_FRAME_CULL_MAX_SHIFT_PX", "1.0"))
+    # (round 6, measured: at 1080p even a 0.25-pixel pan makes SOME tile of 8,160 run past its cut in nearly every frame
+    # -- 1,535 instead of 3,300 FPS with the cull on, profiles/r06_g_*: the default is the identical pose only)
+    CULL_MAX_SHIFT_PX = float(os.environ.get("GS_FRAME_CULL_MAX_SHIFT_PX", "0.0"))
 
     def _camera_shift_px(self, camera) -> float:
         """Upper estimate of how far image content moved, in pixels, between the camera the cut table was recorded under

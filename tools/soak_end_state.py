@@ -62,4 +62,24 @@ pf = [r.profile_forward(*flat.params, cam) for _ in range(6)][2:]
 out["forward_stage_ms"] = {k: round(statistics.median(p[k] for p in pf), 4) for k in pf[0]}
 pb = [r.profile_backward(g) for _ in range(6)][2:]
 out["backward_stage_ms"] = {k: round(statistics.median(p[k] for p in pb), 4) for k in pb[0]}
+# the same end state with the long-list flags forced: none / the sort alone / sort + segmented compositing (round 6: what the
+# cost model of FrameRenderer._note_lists has to reproduce), forward and backward stage times, and the list statistics it sees
+h = r._stats_host.tolist()
+out["pairs_beyond_512_per_tile"] = int(h[12])
+keep = (r.long_lists, r._long_sort_seen, r._long_lists_seen)
+r.auto_grow = False  # (no asynchronous counters: nothing re-latches a flag underneath the forced modes)
+for mode, (ll, srt) in (("none", (False, False)), ("sort_only", (None, True)), ("sort_and_segments", (True, True))):
+    r.long_lists, r._long_sort_seen, r._long_lists_seen = ll, srt, False
+    for _ in range(3):
+        img, _ = r.forward(*flat.params, cam)
+        r.backward(g)
+    pf = [r.profile_forward(*flat.params, cam) for _ in range(6)][2:]
+    pb = [r.profile_backward(g) for _ in range(6)][2:]
+    out["mode_" + mode] = {"flags": int(r._frame.flags),
+                           "forward_stage_ms": {k: round(statistics.median(p[k] for p in pf), 4) for k in pf[0]},
+                           "backward_stage_ms": {k: round(statistics.median(p[k] for p in pb), 4) for k in pb[0]}}
+r.long_lists, r._long_sort_seen, r._long_lists_seen = keep
+lens_sorted = np.sort(lens)[::-1]
+out["list_len"]["top10"] = lens_sorted[:10].tolist()
+out["list_len"]["sum_of_top_64"] = int(lens_sorted[:64].sum())
 print(json.dumps(out))
