@@ -2,7 +2,7 @@
 #pragma once
 #include "gs_common.h"
 
-enum { GS_CNT_VISIBLE = 0, GS_CNT_PAIRS = 1, GS_CNT_OVERFLOW = 2, GS_CNT_BUCKETS = 3, GS_CNT_TICKET = 4, GS_CNT_ENTRIES = 5, GS_CNT_BIG = 6, GS_CNT_SEGS = 7, GS_CNT_GROUPS = 8, GS_CNT_MAXLIST = 9, GS_CNT_RANPAST = 10, GS_CNT_TAG = 11, GS_CNT_EXCESS = 12, GS_CNT_N = 16 };
+enum { GS_CNT_VISIBLE = 0, GS_CNT_PAIRS = 1, GS_CNT_OVERFLOW = 2, GS_CNT_BUCKETS = 3, GS_CNT_TICKET = 4, GS_CNT_ENTRIES = 5, GS_CNT_BIG = 6, GS_CNT_SEGS = 7, GS_CNT_GROUPS = 8, GS_CNT_MAXLIST = 9, GS_CNT_RANPAST = 10, GS_CNT_TAG = 11, GS_CNT_EXCESS = 12, GS_CNT_MAXWALK = 13, GS_CNT_EXCESS_WALK = 14, GS_CNT_N = 16 };
 
 #define GS_BUCKET 64          // Gaussians per backward bucket (= wavefront size)
 #define GS_SORT_TILE 2048     // keys per radix-sort workgroup (256 threads x 8)

@@ -473,6 +473,13 @@ raster_forward_kernel(RasterSrc S, RasterGeom G,
     }
     if (tile_nproc && lane == 0) tile_nproc[tile] = nproc;
     if (FRAME && tile_cost && lane == 0) tile_cost[tile] = steps;
+    // statistics for the caller's long-list cost model (gs_frame.py): the longest walk a wave actually made -- a list's
+    // LENGTH says nothing about a tile whose pixels stop early -- and the steps beyond the first GS_LONG_MIN of every walk
+    // (what the segmented compositing would take over).  Rare (tiles beyond 512 / 1,024 steps), so the atomics cost nothing.
+    if (FRAME && ranpast && lane == 0 && steps > (uint32_t)GS_LONG_MIN) {
+        atomicAdd(ranpast + (GS_CNT_EXCESS_WALK - GS_CNT_RANPAST), (unsigned long long)(steps - (uint32_t)GS_LONG_MIN));
+        if (steps > (uint32_t)GS_LONGEST_MIN) atomicMax(ranpast + (GS_CNT_MAXWALK - GS_CNT_RANPAST), (unsigned long long)steps);
+    }
     if (FRAME && cont_flag && lane == 0) cont_flag[tile] = continues ? 1u : 0u;
 
 #pragma unroll

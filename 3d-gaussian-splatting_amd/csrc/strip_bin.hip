@@ -284,6 +284,8 @@ __global__ void __launch_bounds__(STRIP_THREADS) strip_scatter_kernel(
             counters[GS_CNT_GROUPS] = 0;  // big_list_sort_kernel queues the groups it cut for group_sort_kernel
             counters[GS_CNT_MAXLIST] = 0;  // strip_sort_kernel: longest list above GS_LONGEST_MIN pairs
             counters[GS_CNT_EXCESS] = 0;   // ... and the pairs beyond the first GS_LONG_MIN of their tile's list
+            counters[GS_CNT_MAXWALK] = 0;  // raster_forward_kernel: longest walk a tile's wave made, steps beyond GS_LONG_MIN
+            counters[GS_CNT_EXCESS_WALK] = 0;
             if (!gate) counters[GS_CNT_RANPAST] = 0;  // raised by a tile that ran past its occlusion cut (raster_fwd.hip)
         }
     }

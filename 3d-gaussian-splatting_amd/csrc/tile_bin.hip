@@ -400,6 +400,8 @@ __global__ void __launch_bounds__(BIN_THREADS) slice_sort_kernel(
         counters[GS_CNT_OVERFLOW] = R > max_pairs ? R : 0;
         counters[GS_CNT_TICKET] = 0;  // bin_totals_kernel counts its finished workgroups here
         counters[GS_CNT_EXCESS] = 0;  // (the table variant does not count the pairs beyond GS_LONG_MIN per tile)
+        counters[GS_CNT_MAXWALK] = 0;  // raster_forward_kernel's walk statistics
+        counters[GS_CNT_EXCESS_WALK] = 0;
         counters[GS_CNT_BIG] = counters[GS_CNT_GROUPS] = counters[GS_CNT_MAXLIST] = 0;  // strip variant only
     }
     if (R > max_pairs) {  // not enough room: an all-zero table = an empty frame, the true count is reported

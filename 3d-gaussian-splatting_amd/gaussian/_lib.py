@@ -97,7 +97,7 @@ gs_frame_stats_async = _sig("gs_frame_stats_async", ci, C.POINTER(GsFrame), vp, 
 gs_frame_longest_list_async = _sig("gs_frame_longest_list_async", ci, C.POINTER(GsFrame), vp, vp)
 gs_frame_stats_tagged_async = _sig("gs_frame_stats_tagged_async", ci, C.POINTER(GsFrame), C.c_uint32, vp, vp)
 gs_frame_cull_fallback_async = _sig("gs_frame_cull_fallback_async", ci, C.POINTER(GsFrame), vp, vp)
-GS_STATS_TAGGED_N = 13
+GS_STATS_TAGGED_N = 15
 gs_frame_debug_views = _sig("gs_frame_debug_views", ci, C.POINTER(GsFrame), C.POINTER(vp), C.POINTER(vp),
                             C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp))
 

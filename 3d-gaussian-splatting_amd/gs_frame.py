@@ -241,6 +241,8 @@ class FrameRenderer:
         if getattr(self, "_cull_scene_key", None) != (pos.data_ptr(), n):
             # other tensors / another Gaussian count: what the cull was judged against no longer applies
             self._cull_scene_key, self._cull_full_pairs, self._cull_settled = (pos.data_ptr(), n), None, False
+            if self.long_lists is None:
+                self._long_lists_seen = False  # (the segment decision holds for one Gaussian set: _note_lists)
         shift = self._camera_shift_px(camera)
         if shift > 0.0:
             self._cull_settled = False  # another pose: whether the cull still pays is looked at again
@@ -302,21 +304,23 @@ class FrameRenderer:
     #     densified scene (3.9 M pairs, 165 lists beyond 2,048) the per-tile sort drops from 407 to 122 us whatever the
     #     colour model (profiles/r06_a_trained_state_flag_ab.txt);
     #   GS_FRAME_LONG_LISTS -- segmented compositing of every tile beyond 512 entries (two passes) -- by a COST MODEL per
-    #     colour model (round 6; VERDICT round 5, item 3b: one threshold for all colour models made SH end states slower):
-    #       plain   = max(longest x c_lone, M x c_dev)      a wave alone on its SIMD walks the longest list while the device
-    #                                                       composites everything else
+    #     colour model (round 6; VERDICT round 5, item 3b: one threshold for all colour models made SH end states slower),
+    #     from what the compositing kernel of an UNFLAGGED frame reports about itself: W = the longest walk a tile's wave made
+    #     (not the longest LIST: a tile whose pixels stop early walks a fraction of it), X = the steps beyond the first 512 of
+    #     every walk, and M = the frame's pairs:
+    #       plain   = max(W x c_wave, M x c_dev)            the longest walk at the pace of a wave that shares its SIMD,
+    #                                                       against the whole device's pace on all the work
     #       flagged = (M - X) x c_dev + X x k x c_dev + 50 us   the segment kernels cost k x the plain kernel per step they
     #                                                       take over (pass 1 + pass 2 + combine) plus their launches
-    #     with (c_dev, c_lone, k) measured on the trained-like scene (r06_a: 3.9 M pairs, X = 1.02 M, longest 5,361):
-    #     rgb 0.066 ns / 48 ns / 4.4, SH degree 2 0.264 / 190 / 2.3, degree 3 0.37 / 270 / 2.3.  Flagged when the model
-    #     says it saves 10 %, unflagged again when it says it costs 10 %.  That scene: plain 0.26 / 1.04 ms against 0.51 /
-    #     1.47 ms flagged (model: 0.26 / 1.04 against 0.54 / 1.43) -> not flagged; a densifying run's end state with a few
-    #     piles (longest 6,300 at 2.6 M pairs, X ~ 0.15 M) -> SH flagged (1.2 against 0.8 ms), rgb not (0.30 against 0.27);
-    #     one 100,000-Gaussian pile on a 1.1 M-pair frame -> flagged for every colour model (4.8 against 0.5 ms).
-    #     Lists up to LONG_LIST_FLAG_AT = 2,048 never flag: below the sort window there is nothing to gain.
+    #     (c_dev, c_wave, k) measured on the end states of the densifying runs (tools/soak_end_state.py, profiles/r06_g_*:
+    #     SH degree 2: 4.54 M pairs, W = 6,616, X = 1.66 M: plain 2.73 ms, flagged 1.75 ms; rgb: 3.48 M, 4,959, 0.70 M: 0.52
+    #     against 0.48 ms) and on the trained-like scene (r06_a): rgb 0.066 ns / 105 ns / 5.0, SH degree 2 0.264 / 413 / 2.2,
+    #     degree 3 0.37 / 580 / 2.2.  Flagged when the model says the segments save 10 %; the decision is taken on unflagged
+    #     frames only and holds until the Gaussian set changes (a flagged frame's waves stop at 512 and report nothing).
+    #     Walks up to LONG_LIST_FLAG_AT = 2,048 steps never flag.
     LONG_SORT_FLAG_AT = int(os.environ.get("GS_FRAME_LONG_SORT_FLAG_AT", "2048"))
     LONG_LIST_FLAG_AT = int(os.environ.get("GS_FRAME_LONG_LIST_FLAG_AT", "2048"))
-    LONG_LIST_COST = {3: (0.066, 48.0, 4.4), 27: (0.264, 190.0, 2.3), 48: (0.37, 270.0, 2.3)}  # ns, ns, ratio
+    LONG_LIST_COST = {3: (0.066, 105.0, 5.0), 27: (0.264, 413.0, 2.2), 48: (0.37, 580.0, 2.2)}  # ns, ns, ratio
 
     # The occlusion cull is exact for ANY camera -- a frame whose trimmed lists prove too short is rendered again from the
     # full ones --, but that second pass costs 0.6 of a frame, and with 8,160 tiles SOME tile runs past its cut in nearly
@@ -400,21 +404,16 @@ class FrameRenderer:
         self._cut_key = None if f.training else (self._ws.data_ptr(), int(f.width), int(f.height))
         self._cut_ck = getattr(self, "_cur_ck", None)  # the camera (by value) the table was recorded under
 
-    def _note_lists(self, longest: int, pairs: int, excess: int = None):
+    def _note_lists(self, longest: int, pairs: int, max_walk: int = 0, excess_walk: int = 0):
         self._long_sort_seen = self._long_sort_seen or longest > self.LONG_SORT_FLAG_AT
-        if longest <= self.LONG_LIST_FLAG_AT:
+        if self._frame is None or (self._frame.flags & _lib.GS_FRAME_LONG_LISTS) or max_walk <= self.LONG_LIST_FLAG_AT:
             return
-        cdim = int(self._frame.color_dim) if self._frame is not None else 3
-        c_dev, c_lone, k = self.LONG_LIST_COST.get(cdim, self.LONG_LIST_COST[3])
-        x = min(max(int(excess or 0), 0), pairs)
-        plain = max(longest * c_lone, pairs * c_dev)
+        c_dev, c_wave, k = self.LONG_LIST_COST.get(int(self._frame.color_dim), self.LONG_LIST_COST[3])
+        x = min(max(int(excess_walk), 0), pairs)
+        plain = max(max_walk * c_wave, pairs * c_dev)
         flagged = (pairs - x) * c_dev + x * k * c_dev + 50_000.0
         if flagged < 0.9 * plain:
             self._long_lists_seen = True
-        elif flagged > 1.1 * plain and not (self._frame is not None and self._frame.flags & _lib.GS_FRAME_LONG_LISTS):
-            # (only judged on UNFLAGGED frames: a flagged frame's counters are the same lists, but keeping the decision to
-            # frames that ran the plain path avoids flapping on the model's own error)
-            self._long_lists_seen = False
 
     ASYNC_COUNTER_LAG = int(os.environ.get("GS_FRAME_COUNTER_LAG", "8"))  # (the variable: A/B measurements)
 
@@ -425,11 +424,11 @@ class FrameRenderer:
             self._async_event.synchronize()
         if self._async_event is not None and self._async_event.query():
             h = self._async_host.tolist()
-            v, m, o, b, longest, tag, excess = (int(h[k]) for k in (0, 1, 2, 3, 9, 11, 12))
+            v, m, o, b, longest, tag, walk, xwalk = (int(h[k]) for k in (0, 1, 2, 3, 9, 11, 13, 14))
             self._async_event = None
             if (tag & 0xffffffff) != (self._async_serial & 0xffffffff):
                 return  # (cannot happen in stream order; counters without their frame's tag are not acted upon)
-            self._note_lists(longest, m, excess)
+            self._note_lists(longest, m, walk, xwalk)
             # (NOT the backward-kernel choice: counters that arrive asynchronously would make it -- and with it the
             # gradients' last bits -- depend on host timing; it moves at synchronous stats() calls only)
             if o:
@@ -704,9 +703,9 @@ class FrameRenderer:
                                                     stream.cuda_stream), "gs_frame_stats_tagged_async")
         stream.synchronize()
         h = self._stats_host.tolist()
-        v, m, o, b, longest, ran_past, excess = (int(h[k]) for k in (0, 1, 2, 3, 9, 10, 12))
+        v, m, o, b, longest, ran_past, walk, xwalk = (int(h[k]) for k in (0, 1, 2, 3, 9, 10, 13, 14))
         assert (int(h[11]) & 0xffffffff) == tag, "gs_frame_stats_tagged_async: the tag did not come back"
-        self._note_lists(longest, m, excess)
+        self._note_lists(longest, m, walk, xwalk)
         # The bucket counter is written by the backward's preparation on the library's SIDE stream; the copy above is
         # ordered behind it only once a backward of this frame has been issued on this stream (it waits for the side
         # stream).  A stats() call between forward and backward may read 0, the previous frame's count or this one's:

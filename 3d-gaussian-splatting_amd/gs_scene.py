@@ -89,7 +89,7 @@ def make_scene(n: int, width: int, height: int, seed: int = 2023, use_sh: bool =
 
 def make_trained_like_scene(n: int = 724_312, width: int = 1920, height: int = 1080, seed: int = 7, use_sh: bool = False,
                             sh_degree: int = 2, max_px_sigma: float = 26.0, clustered: float = 0.32, n_clusters: int = 30,
-                            opa_shift: float = -3.5) -> Scene:
+                            opa_shift: float = -3.5, cluster_opa_shift: float = -3.0) -> Scene:
     """A deterministic scene in the STATE a trained / densified model is in (missing item 2): translucent
     (opacity logits shifted by ``opa_shift``: no tile saturates, every pair of every list is composited), larger
     footprints (pixel sigma up to ``max_px_sigma``: ~6.5 tiles per visible Gaussian) and a heavy tail of tile-list
@@ -112,6 +112,10 @@ def make_trained_like_scene(n: int = 724_312, width: int = 1920, height: int = 1
     sc.pos[idx, 0] = ((cx[which] + cs[which] * rng.normal(size=m)) * z).astype(np.float32)
     sc.pos[idx, 1] = ((cy[which] + cs[which] * rng.normal(size=m)) * z).astype(np.float32)
     sc.opa = (sc.opa + opa_shift).astype(np.float32)
+    # the Gaussians of a cluster are fainter still: a trained model's long lists are walked to their end (the end states of
+    # the densifying runs composite every pair: profiles/r06_g_*), whereas thousands of opa_shift Gaussians on top of each
+    # other would stop the cluster tiles' pixels half-way -- and a walk that stops early hides the long-list problem
+    sc.opa[idx] = (sc.opa[idx] + cluster_opa_shift).astype(np.float32)
     return sc
 
 

@@ -339,15 +339,17 @@ int gs_frame_longest_list_async(const gs_frame *f, int64_t *longest_host, gs_str
  * asynchronously and looks at them frames later -- to grow its workspace, to set GS_FRAME_LONG_SORT / GS_FRAME_LONG_LISTS /
  * GS_FRAME_BWD_ROWS -- must know WHICH frame they belong to: flags latched from the counters of frame k while frame k + 500
  * is being issued made a training run timing-dependent in round 5.  This call enqueues, on `stream`: a fill of the counter
- * block's tag word with `tag` (the client's frame number), then ONE device-to-host copy of GS_STATS_TAGGED_N = 13 values:
+ * block's tag word with `tag` (the client's frame number), then ONE device-to-host copy of GS_STATS_TAGGED_N = 15 values:
  *   [0] visible, [1] emitted pairs, [2] overflow (0, or the pairs the frame needed), [3] buckets (low 32 bits: in the
  *   backward's work list, high: of saturated tiles), [4..8] internal, [9] longest tile list (0 up to 1,024), [10] non-zero iff
  *   an occlusion-culled frame was rendered again from its full lists, [11] the tag (both 32-bit halves), [12] pairs that lie
- *   beyond the first 512 of their tile's list (strip variant: what a GS_FRAME_LONG_LISTS frame would composite in segments).
+ *   beyond the first 512 of their tile's list (strip variant), [13] the longest walk a tile's wave actually made in the compositing
+ *   (0 up to 1,024; a tile whose pixels stop early walks less than its list), [14] the steps beyond the first 512 of every walk
+ *   (what a GS_FRAME_LONG_LISTS frame would composite in segments; both from UNFLAGGED frames: a flagged frame's waves stop at 512).
  * stats_host[11] == tag (low half) <=> the copy has landed and the values are those of the frame issued just before this
  * call on `stream`.  stats_host should be pinned memory (the copy is asynchronous only then).  Recommended policy
  * (gs_frame.py): one copy in flight, and never issue frame k + 8 before the counters of frame k have been looked at. */
-#define GS_STATS_TAGGED_N 13
+#define GS_STATS_TAGGED_N 15
 int gs_frame_stats_tagged_async(const gs_frame *f, uint32_t tag, int64_t *stats_host, gs_stream_t stream);
 
 /* Non-zero in *ran_past_host (after `stream` has reached this copy) iff the frame's lists had been trimmed
