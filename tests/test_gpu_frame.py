@@ -265,9 +265,9 @@ def test_occlusion_cull_moving_camera_falls_back_and_stays_exact(gpu):
         if lifted:
             assert not_culled == 1 and fell >= 2 and clean >= 3, (fell, clean, not_culled)
         else:
-            # culled: the repeats of a pose (k = 1, 10, 12, 15: they cannot run past their cuts); every frame whose pose
-            # differs from the previous one's is left alone
-            assert fell == 0 and clean == 4 and not_culled == 12, (fell, clean, not_culled)
+            # culled: the exact repeats of a pose (k = 1 and k = 15: they cannot run past their cuts); every frame whose
+            # pose differs from the previous one's, by however little, is left alone
+            assert fell == 0 and clean == 2 and not_culled == 14, (fell, clean, not_culled)
         assert max(culled_share) > 0.4, culled_share
     cam = make_camera(192, 128, yaw_deg=1.0)
     # another scene in the same workspace: thin (no tile saturates -> the cut table it leaves is all GS_NO_CUT) ...
