@@ -343,7 +343,9 @@ class FrameRenderer:
             return 0.0
         r0, t0 = np.frombuffer(prev[5], np.float32).astype(np.float64).reshape(3, 3), np.frombuffer(prev[6], np.float32).astype(np.float64)
         r1, t1 = np.frombuffer(cur[5], np.float32).astype(np.float64).reshape(3, 3), np.frombuffer(cur[6], np.float32).astype(np.float64)
-        ang = float(np.arccos(np.clip((np.trace(r1 @ r0.T) - 1.0) / 2.0, -1.0, 1.0)))
+        # (|R1 - R0|_F / sqrt 2 = 2 sin(angle / 2): exact for small angles, where arccos((trace - 1) / 2) returns 0 for
+        # anything below 0.03 degree -- cos rounds to 1 in fp32; first version of round 6, profiles/r06_h_cull_flag_trace.txt)
+        ang = float(np.linalg.norm(r1 - r0) / np.sqrt(2.0))
         dc = float(np.linalg.norm(r1.T @ t1 - r0.T @ t0))
         return max(float(cur[2]), float(cur[3])) * (ang + dc)
 

@@ -302,6 +302,7 @@ def main():
                "ms_min": min(blocks) / steps * 1e3, "ms_max": max(blocks) / steps * 1e3}
         if rank == 0:
             prof = [r.profile_forward(*params, cam) for _ in range(25)][5:]
+            res["occlusion_cull"]["stage_times_of_culled_frames"] = bool(r._frame.flags & 256)
             med = {k: statistics.median(p[k] for p in prof) for k in prof[0]}
             # sort_mode 2: "scan_emit" = count + column scan + scatter (the tile binning), "ranges" = per-tile sort
             stage_ms = {"project": med["project"], "bin": med["scan_emit"] + med["sort"], "tile_sort": med["ranges"],
