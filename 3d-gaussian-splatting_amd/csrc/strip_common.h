@@ -42,22 +42,21 @@ __device__ __forceinline__ void walk_strips(const uint4 rc, int64_t g, const gs_
         const uint32_t t0 = sx * GS_STRIP_W;
         uint32_t lo = ex0 > t0 ? ex0 - t0 : 0, hi = (ex1 < t0 + GS_STRIP_W ? ex1 : t0 + GS_STRIP_W) - t0;  // [lo, hi)
         if (CUT) {
-            // trim the run at both ends by the tiles whose cut lies in front of the Gaussian.  Runs are 1 - 3 tiles long and
-            // most ends are decided by their first comparison: two short loops of 4-byte LDS reads (the first version built
-            // the whole 8-tile keep mask from two 16-byte reads: ~30 VALU instructions per entry, and an entry's cost is
-            // paid by every lane of the wave that walks the longest rectangle -- +7 M wave-instructions in each of the two
-            // level-1 kernels at 2.4 M Gaussians, profiles/r06_h_cfg5_forward_culled_pmc_summary.csv)
-            const uint32_t *c = cut8 + (size_t)(iy * SG.nsx + sx) * GS_STRIP_W;
-            uint32_t l = lo, h = hi;
-            while (l < h && d > c[l]) ++l;
-            while (h > l && d > c[h - 1]) --h;
+            const uint4 *c = reinterpret_cast<const uint4 *>(cut8 + (size_t)(iy * SG.nsx + sx) * GS_STRIP_W);
+            const uint4 c0 = c[0], c1 = c[1];
+            // bit j: tile j of the strip keeps the Gaussian (its depth does not lie behind the tile's cut)
+            uint32_t keep = (d <= c0.x ? 1u : 0u) | (d <= c0.y ? 2u : 0u) | (d <= c0.z ? 4u : 0u) | (d <= c0.w ? 8u : 0u) |
+                            (d <= c1.x ? 16u : 0u) | (d <= c1.y ? 32u : 0u) | (d <= c1.z ? 64u : 0u) | (d <= c1.w ? 128u : 0u);
+            keep &= ((1u << hi) - 1u) & ~((1u << lo) - 1u);
             if constexpr (BOTH) {
-                fn(iy * SG.nsx + sx, (l << 29) | ((h > l ? h - 1 : 0u) << 26) | id, d, h - l, hi - lo);
+                const uint32_t full = hi - lo;
+                const uint32_t l = keep ? (uint32_t)__ffs((int)keep) - 1u : 0u, h = keep ? 32u - (uint32_t)__clz((int)keep) : 0u;
+                fn(iy * SG.nsx + sx, (l << 29) | ((h ? h - 1 : 0u) << 26) | id, d, h - l, full);
                 return;
             }
-            if (l == h) return;
-            lo = l;
-            hi = h;
+            if (!keep) return;
+            lo = (uint32_t)__ffs((int)keep) - 1u;
+            hi = 32u - (uint32_t)__clz((int)keep);
         }
         uint32_t np = hi - lo;
         if (DIST) {
