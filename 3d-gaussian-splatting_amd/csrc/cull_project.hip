@@ -825,7 +825,7 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
     float *__restrict__ grad_pos,
     float4 *__restrict__ grad_quat, float *__restrict__ grad_scale, float *__restrict__ grad_opa,
     float *__restrict__ grad_rgb, AdamFusedDev A = AdamFusedDev{}) {
-    static_assert(ADAM == 0 || (CDIM == 3 && PART == 0), "the fused optimizer step: rgb colours, everything in one kernel");
+    static_assert(ADAM == 0 || PART == 0, "the fused optimizer step: everything in one kernel");
     // rgb rows (round 4): only rows that EXIST are fetched.  71 % of the pairs of the 2.4 M scene lie behind their
     // tile's stop point and their rows are uninitialised memory; round 3 streamed all of them through LDS and looked at
     // the flags afterwards (PMC: 916 MB of traffic against 316 MB algorithmic).  Whether the row of pair (tile, g) was
@@ -1283,10 +1283,57 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
             // by the wave as one contiguous run (a culled Gaussian's sums are the zeros the array started with)
             const int64_t g0w = pid0 + (int64_t)wv * 64 + own0;
             const int ng = n - g0w < OWN ? (int)(n - g0w) : OWN;  // Gaussians of this pass inside the array (may be <= 0)
-            float *dst = grad_rgb + g0w * CDIM;
-            for (int e = lane; e < ng * CDIM; e += 64) {
-                const int gl = e / CDIM, c = e - gl * CDIM;
-                dst[e] = wsum[gl * RS + 7 + c];
+            if constexpr (ADAM != 0) {
+                // the fused optimizer step of the run's coefficients (round 6: SH colours too): the wave walks its contiguous
+                // run of the coefficient array and of the two moments -- a kilobyte per instruction -- and applies gs_adam_one
+                // with the gradients it would have stored.  Nothing else reads the raw coefficients
+                // in this kernel, and a Gaussian's coefficients belong to this wave alone.
+                if (!(A.skip_if_nonzero && *A.skip_if_nonzero)) {  // (uniform: an overflowed frame takes no step)
+                    float *pp = A.p_rgb + g0w * CDIM, *mm = A.m_rgb + g0w * CDIM, *vv = A.v_rgb + g0w * CDIM;
+                    const int ne = ng > 0 ? ng * CDIM : 0, ne4 = ne & ~3;
+                    auto one = [&](float &pe, float &me, float &ve, int e) {
+                        const int gl = e / CDIM, c = e - gl * CDIM;
+                        gs_adam_one(pe, wsum[gl * RS + 7 + c], me, ve, A.step_rgb, A.one_m_b1, A.b2, A.one_m_b2, A.inv_bc2_sqrt,
+                                    A.eps);
+                    };
+                    // float4 by float4 (the run starts at a multiple of 32 Gaussians: 16-byte aligned with the arrays) ...
+                    for (int e = lane * 4; e < ne4; e += 256) {
+                        typedef float nt4v __attribute__((ext_vector_type(4)));
+                        float4 pv = *reinterpret_cast<const float4 *>(pp + e), mv, vw;
+                        if (ADAM == 2) {
+                            const nt4v a = __builtin_nontemporal_load(reinterpret_cast<const nt4v *>(mm + e));
+                            const nt4v b = __builtin_nontemporal_load(reinterpret_cast<const nt4v *>(vv + e));
+                            mv = make_float4(a.x, a.y, a.z, a.w), vw = make_float4(b.x, b.y, b.z, b.w);
+                        } else {
+                            mv = *reinterpret_cast<const float4 *>(mm + e);
+                            vw = *reinterpret_cast<const float4 *>(vv + e);
+                        }
+                        one(pv.x, mv.x, vw.x, e);
+                        one(pv.y, mv.y, vw.y, e + 1);
+                        one(pv.z, mv.z, vw.z, e + 2);
+                        one(pv.w, mv.w, vw.w, e + 3);
+                        *reinterpret_cast<float4 *>(pp + e) = pv;
+                        if (ADAM == 2) {
+                            __builtin_nontemporal_store(nt4v{mv.x, mv.y, mv.z, mv.w}, reinterpret_cast<nt4v *>(mm + e));
+                            __builtin_nontemporal_store(nt4v{vw.x, vw.y, vw.z, vw.w}, reinterpret_cast<nt4v *>(vv + e));
+                        } else {
+                            *reinterpret_cast<float4 *>(mm + e) = mv;
+                            *reinterpret_cast<float4 *>(vv + e) = vw;
+                        }
+                    }
+                    // ... and the up to three elements an array that ends inside the run leaves over
+                    if (const int e = ne4 + lane; e < ne) {
+                        float pe = pp[e], me = mm[e], ve = vv[e];
+                        one(pe, me, ve, e);
+                        pp[e] = pe, mm[e] = me, vv[e] = ve;
+                    }
+                }
+            } else {
+                float *dst = grad_rgb + g0w * CDIM;
+                for (int e = lane; e < ng * CDIM; e += 64) {
+                    const int gl = e / CDIM, c = e - gl * CDIM;
+                    dst[e] = wsum[gl * RS + 7 + c];
+                }
             }
         }
         wave_sync();  // (the next pass clears the sums)
@@ -1406,7 +1453,7 @@ __global__ void __launch_bounds__(BLOCK) frame_project_backward_kernel(
         };
         step3(A.p_pos, A.m_pos, A.v_pos, gp, A.step_pos, A.stat_mode ? A.stat : nullptr);
         step3(A.p_scale, A.m_scale, A.v_scale, gsr, A.step_scale, nullptr);
-        step3(A.p_rgb, A.m_rgb, A.v_rgb, gcol, A.step_rgb, nullptr);
+        if constexpr (CDIM == 3) step3(A.p_rgb, A.m_rgb, A.v_rgb, gcol, A.step_rgb, nullptr);  // (SH: stepped by the wave, above)
         if (!valid) return;
         {  // the quaternion: the thread's own float4s
             float4 pv = *reinterpret_cast<const float4 *>(A.p_quat + pid * 4), mv = ld4(A.m_quat + pid * 4);
@@ -1656,7 +1703,7 @@ int gs_stage_sh_big_rows(const gs_frame *f, const gs_frame_ws &ws, hipStream_t s
 // Everything gs_frame_backward_adam can reject about its optimizer argument, checked BEFORE anything is enqueued (ADVICE
 // round 5: a call rejected behind the raster backward left the caller's step counter ahead of the moments).
 int gs_validate_adam_fused(const gs_frame *f, const gs_adam_fused *a) {
-    GS_CHECK_ARG(f->color_dim == 3, "color_dim must be 3");
+    GS_CHECK_ARG(f->color_dim == 3 || f->color_dim == 27 || f->color_dim == 48, "color_dim must be 3, 27 or 48");
     GS_CHECK_ARG(a->step >= 1, "step counts from 1 (torch.optim.Adam increments before the update)");
     GS_CHECK_ARG(a->beta1 >= 0.f && a->beta1 < 1.f && a->beta2 >= 0.f && a->beta2 < 1.f && a->eps >= 0.f, "bad hyper-parameters");
     GS_CHECK_ARG(a->stat_mode >= 0 && a->stat_mode <= 2 && (!a->stat_mode || a->grad_stat), "bad statistic");
@@ -1699,19 +1746,22 @@ int gs_stage_project_backward_adam(const gs_frame *f, const gs_frame_ws &ws, con
     A.stat = a->grad_stat;
     A.stat_mode = a->stat_mode;
     A.skip_if_nonzero = (const unsigned long long *)a->skip_if_nonzero;
-    const unsigned grid = (unsigned)gs_div_up(f->N, 256);
-    // 14 parameters x 16 bytes of arrays: beyond the Infinity Cache the moments stream with non-temporal accesses (adam.hip)
-    const bool nt = (unsigned long long)f->N * 14ull * 16ull > (300ull << 20);
-#define GS_LAUNCH_PB_ADAM(MODE)                                                                                         \
-    hipLaunchKernelGGL((frame_project_backward_kernel<3, 0, 256, MODE>), dim3(grid), dim3(256), 0, stream, f->pos,      \
+    // (11 + C) parameters x 16 bytes of arrays: beyond the Infinity Cache the moments stream with non-temporal accesses (adam.hip)
+    const bool nt = (unsigned long long)f->N * (unsigned long long)(11 + f->color_dim) * 16ull > (300ull << 20);
+#define GS_LAUNCH_PB_ADAM(CD, BLK, MODE)                                                                                \
+    hipLaunchKernelGGL((frame_project_backward_kernel<CD, 0, BLK, MODE>), dim3((unsigned)gs_div_up(f->N, BLK)),         \
+                       dim3(BLK), 0, stream, f->pos,                                                                   \
                        (const float4 *)f->quat, f->scale, f->N, P, ws.rec_geom, ws.rec_color, (const float4 *)ws.rows, \
                        (const unsigned long long *)ws.stop_keys, f->opa, f->rgb, Dc, ws.pair_offsets, ws.rects,        \
                        (uint64_t)f->max_pairs, (int64_t)0, (float *)nullptr, (float4 *)nullptr, (float *)nullptr,      \
                        (float *)nullptr, (float *)nullptr, A)
-    if (nt)
-        GS_LAUNCH_PB_ADAM(2);
-    else
-        GS_LAUNCH_PB_ADAM(1);
+    if (f->color_dim == 48) {
+        if (nt) GS_LAUNCH_PB_ADAM(48, 128, 2); else GS_LAUNCH_PB_ADAM(48, 128, 1);
+    } else if (f->color_dim == 27) {
+        if (nt) GS_LAUNCH_PB_ADAM(27, 128, 2); else GS_LAUNCH_PB_ADAM(27, 128, 1);
+    } else {
+        if (nt) GS_LAUNCH_PB_ADAM(3, 256, 2); else GS_LAUNCH_PB_ADAM(3, 256, 1);
+    }
 #undef GS_LAUNCH_PB_ADAM
     GS_CHECK_LAUNCH();
     return 0;

@@ -412,10 +412,6 @@ extern "C" int gs_frame_backward_adam(const gs_frame *f, const float *grad_image
     if (rc) return rc;
     GS_CHECK_ARG(f->training && f->image_padded, "gs_frame_backward_adam needs a training forward (image_padded kept)");
     GS_CHECK_ARG(grad_image && adam, "null pointer");
-    if (f->color_dim != 3) {
-        gs_set_error("gs_frame_backward_adam: rgb colours only (color_dim 3): SH coefficient gradients are written by whole waves");
-        return GS_E_UNSUPPORTED;
-    }
     if ((rc = gs_validate_adam_fused(f, adam))) return rc;  // before anything is enqueued
     if (f->N == 0) return 0;
     hipStream_t s = (hipStream_t)stream;

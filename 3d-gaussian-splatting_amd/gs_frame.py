@@ -610,7 +610,7 @@ class FrameRenderer:
         return out
 
     def backward_adam(self, grad_image, adam):
-        """``backward`` with the optimizer step fused into its last kernel (rgb colours; gs_frame_backward_adam, include/
+        """``backward`` with the optimizer step fused into its last kernel (gs_frame_backward_adam, include/
         gs_abi.h): the frame's own parameter tensors are updated in place, no gradient is written.  ``adam``: a filled
         ``gaussian._lib.GsAdamFused`` (gs_train.FusedAdam.fused_descriptor)."""
         f = self._frame

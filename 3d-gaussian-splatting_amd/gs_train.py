@@ -240,7 +240,7 @@ class ImageLoss:
 class Trainer:
     """One view per step on this rank; gradients are averaged over ranks when torch.distributed is up.
 
-    NOTE for callers that read gradients: with ``fuse_adam`` active (the default on one rank with rgb colours) the
+    NOTE for callers that read gradients: with ``fuse_adam`` active (the default on one rank, rgb or SH colours) the
     optimizer step runs inside the backward's last kernel and ``flat.grads`` is NOT written -- it holds whatever an
     earlier, unfused step left there.  Pass ``fuse_adam=False`` to get the gradients of every step."""
 
@@ -251,7 +251,7 @@ class Trainer:
                  bwd_rows: Optional[bool] = None, fuse_adam: Optional[bool] = None):
         self.opt = opt or TrainOptions()
         # `fuse_adam`: apply the Adam step inside the backward's last kernel (FrameRenderer.backward_adam: no gradient buffer is
-        # written, bit-identical parameters) where the step allows it -- one rank, rgb colours, no regulariser that edits the
+        # written, bit-identical parameters) where the step allows it -- one rank, no regulariser that edits the
         # gradient, the densification statistic fused into the optimizer.  None: on (GS_TRAIN_FUSE_ADAM=0 turns it off for
         # A/B runs of bench.py); False: never (a caller that reads flat.grads behind a step).  Same-box A/B, round 5
         # (profiles/r05_r_*): 775 against 745 it/s on the moving 2.4 M-Gaussian scene, 933 against 894 fixed, 1786 against
@@ -331,7 +331,8 @@ class Trainer:
     def _can_fuse_adam(self) -> bool:
         o, rgb = self.opt, self.flat.params[4]
         return (self.fuse_adam and not self.flat.collective_active() and not self.optimizer.sharded
-                and self.view_stat is None and o.scale_reg == 0 and o.opa_reg == 0 and rgb.dim() == 2 and rgb.shape[1] == 3)
+                and self.view_stat is None and o.scale_reg == 0 and o.opa_reg == 0 and rgb.dim() == 2
+                and rgb.shape[1] in (3, 27, 48))
 
     def _is_control_iteration(self, i_iter: int) -> bool:
         """Does train_step(i_iter) run adaptive_control (prune, or prune + densify)?  train.py:86-91."""

@@ -561,7 +561,7 @@ def main():
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": round(28 * n_par / (adam_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                        "parameters": n_par}
-        detail["adam_fused_into_backward"] = bool(tr._can_fuse_adam())  # (one rank, rgb: gs_frame_backward_adam; GS_TRAIN_FUSE_ADAM=0 for A/B)
+        detail["adam_fused_into_backward"] = bool(tr._can_fuse_adam())  # (one rank: gs_frame_backward_adam; GS_TRAIN_FUSE_ADAM=0 for A/B)
         detail.update(repeats=len(blocks), ms_per_iter_min=round(min(blocks) / k * 1e3, 4),
                       ms_per_iter_max=round(max(blocks) / k * 1e3, 4), iters_per_block=k,
                       scene="fixed (learning rate 0: the full step runs, the parameters stay put)" if fixed_scene else

@@ -489,7 +489,7 @@ int gs_adam_step_multi(float *param, const float *grad, float *exp_avg, float *e
                        int64_t step, float *grad_stat, int64_t stat_begin, int64_t stat_end, int32_t stat_mode,
                        const void *skip_if_nonzero, float grad_scale, gs_stream_t stream);
 
-/* Single-GPU training step, rgb colours (round 5): gs_frame_backward whose LAST kernel -- the per-Gaussian sum of the gradient
+/* Single-GPU training step (round 5: rgb colours; round 6: SH colours too): gs_frame_backward whose LAST kernel -- the per-Gaussian sum of the gradient
  * rows + projection / activation backward -- applies the Adam update to the Gaussian's 14 parameters on the spot instead of
  * writing their gradients.  The gradient never travels through memory (2 x 56 B per Gaussian) and the optimizer's stream of
  * parameters and moments runs underneath the projection backward's arithmetic (that kernel is VALU-bound, gs_adam_step
@@ -499,8 +499,9 @@ int gs_adam_step_multi(float *param, const float *grad, float *exp_avg, float *e
  * are not, here); exp_avg / exp_avg_sq: their moments, same shapes, in the order pos, quat, scale, opa, rgb; lr likewise;
  * step counts from 1; grad_stat (may be NULL with stat_mode 0): [N,3], max (1) or sum (2) of |dL/dpos| folded in
  * (train.py:145-154); skip_if_nonzero (may be NULL): device address of a 64-bit counter -- non-zero: the step is skipped (the
- * frame's overflow counter, gs_frame_overflow_flag).  color_dim must be 3 (GS_E_UNSUPPORTED otherwise: SH coefficient
- * gradients are written by whole waves).  No gradient buffer is written. */
+ * frame's overflow counter, gs_frame_overflow_flag).  SH frames (color_dim 27 / 48): the wave that sums a Gaussian's
+ * coefficient gradients steps the coefficients where it would have stored the gradients (+1 % on the SH training step: the
+ * coefficient gradients' round trip and one launch; the optimizer's own stream stays).  No gradient buffer is written. */
 typedef struct gs_adam_fused {
     float *exp_avg[5], *exp_avg_sq[5];
     float lr[5];

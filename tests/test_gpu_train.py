@@ -646,20 +646,24 @@ def test_bench_multi_gpu_leg_runs_under_two_ranks(gpu, tmp_path):
         scene["modes"]["all_reduce"]["optimizer_state_bytes_per_rank"] + 64
 
 
-@pytest.mark.parametrize("n,W,H,stat", [(6_000, 160, 112, "max"), (6_000, 160, 112, "mean"), (6_001, 160, 112, "max"),
-                                        (2_400_000, 1920, 1080, "max")])
-def test_fused_backward_adam_equals_backward_then_adam(gpu, n, W, H, stat):
-    """Round 5: gs_frame_backward_adam (what a single-rank rgb Trainer step uses unless fuse_adam=False)
+@pytest.mark.parametrize("n,W,H,stat,sh", [(6_000, 160, 112, "max", 0), (6_000, 160, 112, "mean", 0), (6_001, 160, 112, "max", 0),
+                                           (2_400_000, 1920, 1080, "max", 0), (6_000, 160, 112, "max", 2),
+                                           (6_001, 160, 112, "mean", 3), (724_312, 1920, 1080, "max", 2)])
+def test_fused_backward_adam_equals_backward_then_adam(gpu, n, W, H, stat, sh):
+    """Round 5: gs_frame_backward_adam (what a single-rank Trainer step uses unless fuse_adam=False)
     -- the Adam update applied inside the backward's last kernel, no gradient buffer -- against
     gs_frame_backward followed by gs_adam_step: parameters, both moments and the |pos.grad| statistic BIT FOR BIT over several
     steps of gs_train.Trainer (learning-rate warm-up included; Gaussians outside the frustum take their zero-gradient momentum
     step on both paths).  2.4 M Gaussians: the moments stream with non-temporal accesses there (the third kernel variant);
-    6,001: the [N, 3] arrays end inside a float4 of the kernel's walk (its element-by-element tail)."""
+    6,001: the [N, 3] arrays end inside a float4 of the kernel's walk (its element-by-element tail).  Round 6: SH colours
+    (``sh`` = the degree) -- the wave that sums a Gaussian's coefficient gradients steps its 27 / 48 coefficients in place;
+    724,312 x SH2 is beyond the cache (the non-temporal variant), 6,001 ends inside a wave's run of Gaussians."""
     from gs_frame import FrameRenderer
     from gs_scene import make_camera, make_scene
     from gs_train import TrainOptions, Trainer
 
-    scene, cam = make_scene(n, W, H, seed=11), make_camera(W, H, yaw_deg=3.0)
+    scene = make_scene(n, W, H, seed=11, use_sh=bool(sh), sh_degree=sh) if sh else make_scene(n, W, H, seed=11)
+    cam = make_camera(W, H, yaw_deg=3.0)
     gt = to_torch(scene, gpu)
     r0 = FrameRenderer(gpu, max_pairs=1 << 20, auto_grow=True)
     target = r0.forward(*gt, cam)[0].clone()
@@ -688,25 +692,21 @@ def test_fused_backward_adam_equals_backward_then_adam(gpu, n, W, H, stat):
     assert float(got[0][1].abs().max()) > 0 and float(got[0][3].abs().max()) > 0
 
 
-def test_fused_backward_adam_refuses_sh_and_skips_overflowed_frames(gpu):
-    """gs_frame_backward_adam is for rgb colours (GS_E_UNSUPPORTED with SH: the Trainer then takes the two-kernel path by
-    itself), and with the frame's overflow counter as skip flag an overflowed -- empty -- frame moves nothing."""
+@pytest.mark.parametrize("use_sh", [False, True])
+def test_fused_backward_adam_skips_overflowed_frames(gpu, use_sh):
+    """With the frame's overflow counter as skip flag an overflowed -- empty -- frame moves nothing: rgb logits and (round 6)
+    SH coefficients alike, although momentum is there that WOULD move them."""
     from gs_frame import FrameRenderer
     from gs_scene import make_camera, make_scene
     from gs_train import TrainOptions, Trainer
 
     W, H = 128, 96
     cam = make_camera(W, H)
-    sh = make_scene(1500, W, H, seed=3, use_sh=True)
+    sh = make_scene(1500, W, H, seed=3, use_sh=use_sh)
     gt = to_torch(sh, gpu)
     target = FrameRenderer(gpu, max_pairs=1 << 16).forward(*gt, cam)[0].clone()
-    tr = Trainer([t.clone() for t in gt], [cam], [target], TrainOptions(n_iters_warmup=1), max_pairs=1 << 16, fuse_adam=True)
-    assert not tr._can_fuse_adam()  # (asked for, but SH colours: the two-kernel path)
-    tr.train_step(0, 0)
-    with pytest.raises(RuntimeError):
-        tr.renderer.backward_adam(torch.zeros(H, W, 3, device=gpu), tr.optimizer.fused_descriptor())
-    # rgb, a workspace that is too small: the frame overflows, the device-side flag skips the fused step
-    rgb = make_scene(4000, W, H, seed=4)
+    # a workspace that is too small: the frame overflows, the device-side flag skips the fused step
+    rgb = make_scene(4000, W, H, seed=4, use_sh=use_sh)
     p = [t.clone() for t in to_torch(rgb, gpu)]
     tr2 = Trainer(p, [cam], [target], TrainOptions(n_iters_warmup=1), max_pairs=1 << 16, fuse_adam=True)
     assert tr2._can_fuse_adam()
