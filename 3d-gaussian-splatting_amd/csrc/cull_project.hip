@@ -333,6 +333,9 @@ struct ProjectParams {
     float dist_thresh, dist_radius;  // "dist": squared distance threshold (splatter.py:577) and its square root
     float half_padw, half_padh;  // padded size / 2, in pixels (exact in fp32)
     float fx, fy;
+    // occlusion test of frame_project_cull_count_kernel (conservative, never compared bit for bit): 1 / tlx, 1 / tly and
+    // 1.02 x sqrt(tlog) x the largest singular value of the camera rotation (1 for a rotation; the caller's matrix is not trusted)
+    float inv_tlx, inv_tly, occ_k;
 };
 
 // sigmoid on the transcendental unit (v_exp_f32 + v_rcp_f32, ~2 ulp): the opacity / colour activations feed the
@@ -551,10 +554,11 @@ __global__ void __launch_bounds__(STRIP_THREADS) frame_project_count_kernel(
     float4 *__restrict__ rec_geom, uint32_t *__restrict__ tiles_touched, uint4 *__restrict__ rects, GsDistCull D,
     uint32_t per_slice, gs_strip_geom SG, uint32_t S, uint32_t slice0, unsigned long long *__restrict__ table,
     uint32_t *__restrict__ slice_pairs, uint32_t *__restrict__ slice_vis, const uint32_t *__restrict__ tile_cost,
-    uint32_t n_tiles, uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ cut,
-    unsigned long long *__restrict__ table_full) {
+    uint32_t n_tiles, uint32_t *__restrict__ tile_order, const unsigned long long *__restrict__ gate) {
     extern __shared__ unsigned long long s_hist[];  // [NS] entries << 32 | pairs of this slice
     __shared__ uint32_t s_acc[2];
+    // `gate`: the second, unculled pass of a GS_FRAME_OCCLUSION_CULL frame -- nothing to do unless a tile ran past its cut
+    if (gate && *gate == 0) return;
     if (blockIdx.x >= S) {  // the one extra workgroup of the launch (uniform)
         tile_order_workgroup(tile_cost, n_tiles, tile_order, SG.ntx, SG.nty);
         return;
@@ -568,22 +572,6 @@ __global__ void __launch_bounds__(STRIP_THREADS) frame_project_count_kernel(
     RawGaussian cur = {}, nxt = {};
     if (in_range(threadIdx.x)) cur = load_raw(pos, quat, scale, opa, rgb, g0 + threadIdx.x, P.color_dim);
     for (uint32_t t = threadIdx.x; t < SG.NS; t += STRIP_THREADS) s_hist[t] = 0;
-    // occlusion cuts (GS_FRAME_OCCLUSION_CULL): the per-tile table is staged in LDS behind the histogram -- looked up from
-    // global memory, two to eight dependent loads per Gaussian inside this latency-bound kernel cost 62 us at 2.4 M Gaussians
-    // (first version, profiles/r06_c_*)
-    // A culled frame keeps TWO histograms: the trimmed entries (what this frame emits) and the full ones -- the table the
-    // gated second pass scans if a tile runs past its cut, so that pass needs no recount.  Layout: [NS] trimmed, [NS] full,
-    // then the cuts with every tile row padded to whole strips (walk_strips<.., true>).
-    unsigned long long *s_full = s_hist + SG.NS;
-    uint32_t *s_cut = reinterpret_cast<uint32_t *>(s_hist + 2 * SG.NS);
-    if (cut) {
-        for (uint32_t t = threadIdx.x; t < SG.NS; t += STRIP_THREADS) s_full[t] = 0;
-        const uint32_t stride = SG.nsx * GS_STRIP_W;
-        for (uint32_t t = threadIdx.x; t < stride * SG.nty; t += STRIP_THREADS) {
-            const uint32_t iy = t / stride, ix = t - iy * stride;
-            s_cut[t] = ix < SG.ntx ? cut[iy * SG.ntx + ix] : GS_NO_CUT;
-        }
-    }
     if (threadIdx.x < 2) s_acc[threadIdx.x] = 0;
     __syncthreads();
     settle(cur);
@@ -597,18 +585,8 @@ __global__ void __launch_bounds__(STRIP_THREADS) frame_project_count_kernel(
         if (in_range(i)) rc = project_one(cur, g0 + i, P, rec_geom, tiles_touched, rects, vis, cxy);
         acc_cnt += rc.w;
         acc_vis += vis;
-        if (cut) {  // (uniform)
-            if constexpr (!DIST)  // (a "dist" frame is never culled: gs_frame_occlusion_cull)
-                walk_strips<false, true, true>(rc, g0 + i, SG, cxy, D,
-                                               [&](uint32_t strip, uint32_t, uint32_t, uint32_t np, uint32_t full) {
-                                                   atomicAdd(&s_full[strip], (1ull << 32) | full);
-                                                   if (np) atomicAdd(&s_hist[strip], (1ull << 32) | np);
-                                               },
-                                               s_cut);
-        } else {
-            walk_strips<DIST>(rc, g0 + i, SG, cxy, D,
-                              [&](uint32_t strip, uint32_t, uint32_t, uint32_t np) { atomicAdd(&s_hist[strip], (1ull << 32) | np); });
-        }
+        walk_strips<DIST>(rc, g0 + i, SG, cxy, D,
+                          [&](uint32_t strip, uint32_t, uint32_t, uint32_t np) { atomicAdd(&s_hist[strip], (1ull << 32) | np); });
         cur = nxt;
     }
     // rectangle areas (= gradient-row slots; == pairs unless DIST) and visible Gaussians of this slice
@@ -621,10 +599,241 @@ __global__ void __launch_bounds__(STRIP_THREADS) frame_project_count_kernel(
     __syncthreads();
     unsigned long long *row = table + (size_t)slice * SG.NS;
     for (uint32_t t = threadIdx.x; t < SG.NS; t += STRIP_THREADS) row[t] = s_hist[t];
-    if (cut) {
-        unsigned long long *rowf = table_full + (size_t)slice * SG.NS;
-        for (uint32_t t = threadIdx.x; t < SG.NS; t += STRIP_THREADS) rowf[t] = s_full[t];
+    if (threadIdx.x == 0) {
+        slice_pairs[slice] = s_acc[0];
+        slice_vis[slice] = s_acc[1];
     }
+}
+
+// ---------------------------------------------------------------- S1 + L1a of an occlusion-culled frame (first pass)
+// GS_FRAME_OCCLUSION_CULL (gs_frame_layout.h): the previous frame of this workspace left, per tile, the depth behind which
+// nothing was composited (`cut`).  74 % of the pairs of the opaque 2.4 M-Gaussian scene lie behind their tile's cut, and
+// more than half of the visible Gaussians have NO pair in front of one -- yet every one of them paid the ~750 instructions
+// of the projection.  Lane-masking them out gains nothing (a wave skips only what all of its 64 lanes skip, and Gaussians
+// arrive in no spatial order: measured, 92.7 against 79 us), so this kernel COMPACTS:
+//   phase A, every Gaussian of the slice: position and scale only (24 of 56 bytes), the exact frustum test, and a
+//     conservative occlusion test (occluded_everywhere) -- ~120 instructions; the survivors' indices are queued in LDS;
+//   phase B, full waves of survivors: the unchanged project_one + the trimmed strip count of the culled frame.
+// A Gaussian that fails the occlusion test would have lost every pair to the trimming of walk_strips<.., true>: the
+// emitted lists are exactly those of the lane-masked kernel, and the frame's second pass (a tile ran past its cut) starts
+// from a gated re-run of frame_project_count_kernel, which rewrites records, rectangles and the strip table untrimmed.
+// The cut pyramid: level 0 = the per-tile cuts (rows padded to whole strips, what walk_strips reads), level l = the LARGEST
+// cut of each block of 2^l x 2^l tiles (GS_NO_CUT -- a tile that did not saturate -- is the largest value there is).
+#define GS_OCC_QCAP 16384u   // Gaussians per chunk of a slice: their in-chunk indices are queued as 16-bit words
+#define GS_OCC_LEVELS 4      // pyramid levels 0..3: rectangles of up to 16 x 16 tiles are tested with <= 3 x 3 look-ups
+struct OccPyramid {
+    const uint32_t *t0;           // level 0
+    uint32_t o1, o2, o3;          // words from level l - 1's table to level l's
+    uint32_t st0, d1, d2, d3;     // row stride of level 0; stride of level l minus stride of level l - 1 (mod 2^32)
+};
+// Is the Gaussian behind the cut of every tile its rectangle can reach?  Conservative by construction: the rectangle's
+// half extents are sqrt(tlog S00) and sqrt(tlog S11) (tile_rect; its +1e-14 only shrinks them), S00 = r0 (R S S R^T) r0^T
+// with r0 the first row of J W, so S00 <= s_max^2 |r0|^2 = s_max^2 (1 + (x/z)^2) / z^2 (W and R orthonormal: P.occ_k
+// carries W's largest singular value, sqrt(tlog) and 2 % for the roundings -- fp32's are 1e-6), likewise S11; the tile
+// range follows tile_rect's "prob2" arithmetic, monotone in the extents, with 1e-3 tile of slack.  Anything not finite,
+// larger than 16 tiles, or another listing method: not tested (false).
+__device__ __forceinline__ bool occluded_everywhere(const float pi[3], float z, float smax, uint32_t dbits,
+                                                    const ProjectParams &P, const OccPyramid &Y) {
+    if (P.cull_method != 2) return false;
+    const float k = P.occ_k * smax * gs_rcp(z);
+    const float ax = 1.0f + pi[0] * pi[0], ay = 1.0f + pi[1] * pi[1];
+    const float rx = k * (ax * gs_rsq(ax)) * 1.0001f, ry = k * (ay * gs_rsq(ay)) * 1.0001f;
+    const float fx0 = (pi[0] - rx - P.leftmost) * P.inv_tlx - 1e-3f, fx1 = (pi[0] + rx - P.leftmost) * P.inv_tlx + 1e-3f;
+    const float fy0 = (pi[1] - ry - P.topmost) * P.inv_tly - 1e-3f, fy1 = (pi[1] + ry - P.topmost) * P.inv_tly + 1e-3f;
+    if (!(fx1 - fx0 < 16.0f) || !(fy1 - fy0 < 16.0f)) return false;  // large or not finite: projected
+    // beside the grid (23 % of the Gaussians inside the frustum test of the 2.4 M scene: its margin is wider than the image):
+    // tile_rect's range is empty -- x1 = floor(v + 1) = 0 for v < 0, x0 >= ntx >= x1 on the other side -- no tile, skipped
+    if (fx1 < 0.f || fy1 < 0.f) return true;
+    uint32_t x0 = gs_f2u_sat(fx0), y0 = gs_f2u_sat(fy0), x1 = gs_f2u_sat(fx1), y1 = gs_f2u_sat(fy1);  // tiles [x0, x1] x [y0, y1]
+    if (x0 >= P.ntx || y0 >= P.nty) return true;
+    x1 = x1 < P.ntx ? x1 : P.ntx - 1;
+    y1 = y1 < P.nty ? y1 : P.nty - 1;
+    const uint32_t e = (x1 - x0) > (y1 - y0) ? (x1 - x0) : (y1 - y0);
+    const uint32_t L = e <= 1 ? 0u : (e <= 3 ? 1u : (e <= 7 ? 2u : 3u));  // (x1 >> L) - (x0 >> L) <= 2 then
+    // (level L's table starts off[L] words behind level 0's; selected arithmetically: a select between the struct's fields
+    // became a load from a scratch copy of it)
+    const uint32_t m1 = L >= 1 ? ~0u : 0u, m2 = L >= 2 ? ~0u : 0u, m3 = L >= 3 ? ~0u : 0u;
+    const uint32_t *tab = Y.t0 + ((Y.o1 & m1) + (Y.o2 & m2) + (Y.o3 & m3));
+    const uint32_t st = Y.st0 + ((Y.d1 & m1) + (Y.d2 & m2) + (Y.d3 & m3));
+    const uint32_t cx0 = x0 >> L, cy0 = y0 >> L, w = (x1 >> L) - cx0, h = (y1 >> L) - cy0;  // w, h in 0..2
+    uint32_t m = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 3; ++j)
+#pragma unroll
+        for (uint32_t i = 0; i < 3; ++i) {
+            const uint32_t c = tab[(cy0 + (j < h ? j : h)) * st + cx0 + (i < w ? i : w)];
+            m = c > m ? c : m;
+        }
+    return dbits > m;
+}
+
+__global__ void __launch_bounds__(STRIP_THREADS) frame_project_cull_count_kernel(
+    const float *__restrict__ pos, const float4 *__restrict__ quat, const float *__restrict__ scale,
+    const float *__restrict__ opa, const float *__restrict__ rgb, int64_t n, ProjectParams P,
+    float4 *__restrict__ rec_geom, uint4 *__restrict__ rects, uint32_t per_slice, gs_strip_geom SG, uint32_t S,
+    unsigned long long *__restrict__ table, uint32_t *__restrict__ slice_pairs, uint32_t *__restrict__ slice_vis,
+    const uint32_t *__restrict__ tile_cost, uint32_t n_tiles, uint32_t *__restrict__ tile_order,
+    const uint32_t *__restrict__ cut, uint32_t qcap, uint32_t diag) {
+    extern __shared__ unsigned long long s_hist[];  // [NS] entries << 32 | pairs of this slice, then the pyramid, then the queue
+    __shared__ uint32_t s_acc[2], s_qn;
+    if (blockIdx.x >= S) {  // the one extra workgroup of the launch (uniform)
+        if (diag & 16) return;
+        tile_order_workgroup(tile_cost, n_tiles, tile_order, SG.ntx, SG.nty);
+        return;
+    }
+    const uint32_t slice = strip_slice_of_block(blockIdx.x, S);
+    const int64_t g0 = (int64_t)slice * per_slice;
+    const int lane = threadIdx.x & 63;
+    // ---- LDS: histogram | cut pyramid | survivor queue
+    uint32_t *s_cut = reinterpret_cast<uint32_t *>(s_hist + SG.NS);
+    const uint32_t st0 = SG.nsx * GS_STRIP_W;
+    const uint32_t w1 = (SG.ntx + 1) / 2, h1 = (SG.nty + 1) / 2, w2 = (w1 + 1) / 2, h2 = (h1 + 1) / 2, w3 = (w2 + 1) / 2,
+                   h3 = (h2 + 1) / 2;
+    uint32_t *s_l1 = s_cut + st0 * SG.nty, *s_l2 = s_l1 + w1 * h1, *s_l3 = s_l2 + w2 * h2;
+    uint16_t *s_q = reinterpret_cast<uint16_t *>(s_l3 + w3 * h3);
+    const OccPyramid Y = {s_cut, st0 * SG.nty, w1 * h1, w2 * h2, st0, w1 - st0, w2 - w1, w3 - w2};
+    for (uint32_t t = threadIdx.x; t < SG.NS; t += STRIP_THREADS) s_hist[t] = 0;
+    // (eight loads of the cut table in flight per thread: one at a time, each waited for, was 8 x the latency of a load)
+    for (uint32_t t0 = threadIdx.x; t0 < st0 * SG.nty; t0 += 8 * STRIP_THREADS) {
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {
+            const uint32_t t = t0 + k * STRIP_THREADS, iy = t / st0, ix = t - iy * st0;
+            const bool in = iy < SG.nty && ix < SG.ntx;
+            v[k] = cut[in ? iy * SG.ntx + ix : 0u];
+            v[k] = in ? v[k] : GS_NO_CUT;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k)
+            if (t0 + k * STRIP_THREADS < st0 * SG.nty) s_cut[t0 + k * STRIP_THREADS] = v[k];
+    }
+    if (threadIdx.x < 2) s_acc[threadIdx.x] = 0;
+    auto build = [&](uint32_t *dst, uint32_t dw, uint32_t dh, const uint32_t *src, uint32_t sst, uint32_t sw, uint32_t sh) {
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < dw * dh; t += STRIP_THREADS) {
+            const uint32_t cy = t / dw, cx = t - cy * dw, x = 2 * cx, y = 2 * cy;
+            uint32_t m = src[y * sst + x];
+            if (x + 1 < sw) m = max(m, src[y * sst + x + 1]);
+            if (y + 1 < sh) {
+                m = max(m, src[(y + 1) * sst + x]);
+                if (x + 1 < sw) m = max(m, src[(y + 1) * sst + x + 1]);
+            }
+            dst[t] = m;
+        }
+    };
+    build(s_l1, w1, h1, s_cut, st0, SG.ntx, SG.nty);
+    build(s_l2, w2, h2, s_l1, w1, w1, h1);
+    build(s_l3, w3, h3, s_l2, w2, w2, h2);
+    uint32_t acc_cnt = 0, acc_vis = 0;
+    for (uint32_t c0 = 0; c0 < per_slice; c0 += qcap) {  // uniform: chunks of the slice (one, unless the scene is huge)
+        const uint32_t cn = (diag & 8) ? 0u : (per_slice - c0 < qcap ? per_slice - c0 : qcap);
+        if (threadIdx.x == 0) s_qn = 0;
+        __syncthreads();  // (also: the pyramid is complete; the previous chunk's queue has been drained)
+        // ---- phase A: frustum + occlusion test of every Gaussian of the chunk; survivors are queued
+        // The phase is a 96 MB stream (24 B in, 16 B out per Gaussian) at one workgroup per CU: three rounds of positions
+        // and scales are kept in flight.  That takes THREE NAMED register sets and a loop unrolled by three -- rotating one
+        // set into the next at the end of a round (`cur = nxt`) makes the move wait for the newest load (first version:
+        // s_waitcnt vmcnt(0) in every round, 30 us for the bare stream) -- and loads whose control flow is uniform (a lane
+        // beyond the chunk loads the array's last Gaussian and drops it), so that the waitcnt pass counts them exactly.
+        auto in_chunk = [&](uint32_t i) { return i < cn && g0 + c0 + i < n; };
+        auto fetch = [&](float (&pp)[3], float (&ss)[3], uint32_t i) {
+            int64_t g = g0 + c0 + i;
+            g = g < n ? g : n - 1;
+            load3(pos, g, pp);
+            load3(scale, g, ss);
+        };
+        auto test = [&](const float (&pp)[3], const float (&ss)[3], uint32_t i) {
+            bool surv = false;
+            if (in_chunk(i)) {
+                const int64_t pid = g0 + c0 + i;
+                float pc[3], pi[3];
+                if (project_cull(pp, P.cam, P.near_plane, P.half_w, P.half_h, pc, pi)) {
+                    const float dep = sqrtf(pc[0] * pc[0] + pc[1] * pc[1] + pc[2] * pc[2]);  // == project_cov's pos_i[2]
+                    float s[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) s[k] = P.scale_act == 0 ? fabsf(ss[k]) + 1e-4f : gs_exp2(GS_LOG2E * ss[k]);
+                    const float smax = fmaxf(s[0], fmaxf(s[1], s[2]));
+                    // (a NaN scale slips through fmaxf: s0 + s1 + s2 is NaN then, and the Gaussian is projected)
+                    // (`diag`, GS_OCC_DIAG: TIMING-ONLY switches, the frames they render are wrong -- 1: nobody is tested, 2: nobody is
+                    // projected, 4: everybody is skipped, 8: no phase A either, 16: no tile order, 32: phase B loads contiguous
+                    // Gaussians instead of the queued ones, 64: no strip count; tools/batches/gpu_r6n.sh, profiles/r06_n_*)
+                    if ((diag & 4) || (!(diag & 1) && (s[0] + s[1] + s[2] < 3.0e38f) &&
+                                       occluded_everywhere(pi, pc[2], smax, __float_as_uint(dep), P, Y))) {
+                        // behind every cut it can reach: visible, no tile (no later stage of an inference frame looks at it)
+                        rects[pid] = make_uint4(0, 0, __float_as_uint(dep), 0);
+                        acc_vis += 1;
+                    } else {
+                        surv = true;
+                    }
+                } else {
+                    rects[pid] = make_uint4(0, 0, 0, 0);
+                }
+            }
+            const unsigned long long b = __ballot(surv);
+            if (b) {  // (uniform per wave)
+                uint32_t wbase = 0;
+                if (lane == 0) wbase = atomicAdd(&s_qn, (uint32_t)__popcll(b));
+                wbase = __shfl(wbase, 0, 64);
+                if (surv) s_q[wbase + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)i;
+            }
+        };
+        float pa[3], sa[3], pb[3], sb[3], pq[3], sq[3];
+        fetch(pa, sa, threadIdx.x);
+        fetch(pb, sb, threadIdx.x + STRIP_THREADS);
+        for (uint32_t base = 0; base < cn; base += 3 * STRIP_THREADS) {  // uniform trip count, uniform exits
+            const uint32_t i = base + threadIdx.x;
+            fetch(pq, sq, i + 2 * STRIP_THREADS);
+            test(pa, sa, i);
+            if (base + STRIP_THREADS >= cn) break;
+            fetch(pa, sa, i + 3 * STRIP_THREADS);
+            test(pb, sb, i + STRIP_THREADS);
+            if (base + 2 * STRIP_THREADS >= cn) break;
+            fetch(pb, sb, i + 4 * STRIP_THREADS);
+            test(pq, sq, i + 2 * STRIP_THREADS);
+        }
+        __syncthreads();
+        // ---- phase B: the survivors, 1,024 at a time on full waves
+        const uint32_t nq = (diag & 2) ? 0u : s_qn;
+        RawGaussian cur = {}, nxt = {};
+        uint32_t qi = 0, qn_ = 0;
+        if (threadIdx.x < nq) {
+            qi = (diag & 32) ? threadIdx.x : s_q[threadIdx.x];
+            cur = load_raw(pos, quat, scale, opa, rgb, g0 + c0 + qi, P.color_dim);
+        }
+        settle(cur);
+        for (uint32_t base = 0; base < nq; base += STRIP_THREADS) {  // uniform trip count
+            const uint32_t k = base + threadIdx.x;
+            if (k + STRIP_THREADS < nq) {
+                qn_ = (diag & 32) ? k + STRIP_THREADS : s_q[k + STRIP_THREADS];
+                nxt = load_raw(pos, quat, scale, opa, rgb, g0 + c0 + qn_, P.color_dim);
+            }
+            uint4 rc = make_uint4(0, 0, 0, 0);
+            uint32_t vis = 0;
+            float2 cxy = make_float2(0.f, 0.f);
+            const int64_t pid = g0 + c0 + qi;
+            if (k < nq) rc = project_one(cur, pid, P, rec_geom, nullptr, rects, vis, cxy);
+            acc_cnt += rc.w;
+            acc_vis += vis;
+            // (count only: the id walk_strips derives for ANOTHER lane's Gaussian, g - lane + src, is wrong here -- the queue
+            // is not in index order -- and not looked at)
+            if (!(diag & 64)) walk_strips<false, true>(rc, pid, SG, cxy, GsDistCull{},
+                                           [&](uint32_t strip, uint32_t, uint32_t, uint32_t np) {
+                                               atomicAdd(&s_hist[strip], (1ull << 32) | np);
+                                           },
+                                           s_cut);
+            cur = nxt;
+            qi = qn_;
+        }
+    }
+    acc_cnt = gs_wave_sum_u32(acc_cnt);
+    acc_vis = gs_wave_sum_u32(acc_vis);
+    if (lane == 0) {
+        atomicAdd(&s_acc[0], acc_cnt);
+        atomicAdd(&s_acc[1], acc_vis);
+    }
+    __syncthreads();
+    unsigned long long *row = table + (size_t)slice * SG.NS;
+    for (uint32_t t = threadIdx.x; t < SG.NS; t += STRIP_THREADS) row[t] = s_hist[t];
     if (threadIdx.x == 0) {
         slice_pairs[slice] = s_acc[0];
         slice_vis[slice] = s_acc[1];
@@ -1589,12 +1798,36 @@ static ProjectParams make_params(const gs_frame *f) {
     P.half_padh = (float)(G.padH / 2);
     P.fx = f->focal_x;
     P.fy = f->focal_y;
+    P.inv_tlx = 1.0f / G.tlx;
+    P.inv_tly = 1.0f / G.tly;
+    {   // largest singular value of the camera rotation as given (power iteration on W^T W; 1 for a rotation)
+        double A[9], v[3] = {0.6, 0.5, 0.62}, lam = 1.0;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                A[i * 3 + j] = 0;
+                for (int k = 0; k < 3; ++k) A[i * 3 + j] += (double)f->rot[k * 3 + i] * (double)f->rot[k * 3 + j];
+            }
+        for (int it = 0; it < 48; ++it) {
+            double w[3];
+            for (int i = 0; i < 3; ++i) w[i] = A[i * 3] * v[0] + A[i * 3 + 1] * v[1] + A[i * 3 + 2] * v[2];
+            lam = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+            if (!(lam > 0)) break;
+            for (int i = 0; i < 3; ++i) v[i] = w[i] / lam;
+        }
+        // (power iteration approaches the largest eigenvalue from below: 1 % on top; trace as the fail-safe upper bound)
+        const double tr = A[0] + A[4] + A[8];
+        double sig = sqrt(lam) * 1.01;
+        if (!(sig > 0) || !(sig <= sqrt(tr) * 1.01)) sig = sqrt(tr) * 1.01;
+        P.occ_k = (float)(1.02 * sqrt((double)P.tlog) * sig);
+    }
     return P;
 }
 
 // slice_begin / slice_end: the slices of the Gaussian array to project (strip variant with the fused count only:
 // gs_frame_project_slices; every other path projects everything at once: 0, -1)
-int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream, int slice_begin, int slice_end) {
+// `second_pass`: the unculled re-run of a GS_FRAME_OCCLUSION_CULL frame's project stage, gated on counters[GS_CNT_RANPAST]
+int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream, int slice_begin, int slice_end,
+                     bool second_pass) {
     ProjectParams P = make_params(f);
     // sort_modes 0 / 1 read tiles_touched (emit_pairs_kernel); sort_mode 2 reads the rectangle records only
     uint32_t *touched = f->sort_mode == 2 && gs_frame_geometry(f).n_tiles <= GS_BIN_MAX_TILES ? nullptr : ws.tiles_touched;
@@ -1610,28 +1843,39 @@ int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t strea
         GS_HIP(hipGetDevice(&dev));
         if (dev < 64 && !((attr_done.load(std::memory_order_acquire) >> dev) & 1)) {
             std::lock_guard<std::mutex> lock(attr_mu);
-            for (const void *fn : {(const void *)frame_project_count_kernel<false>, (const void *)frame_project_count_kernel<true>})
-                // (the kernel also holds ~17 KiB of static LDS -- the tile-order workgroup's bins --: the strip histogram, and the
-                // occlusion cuts behind it in a culled frame, get what gs_frame_occlusion_cull's room rule allows)
+            for (const void *fn : {(const void *)frame_project_count_kernel<false>, (const void *)frame_project_count_kernel<true>,
+                                   (const void *)frame_project_cull_count_kernel})
+                // (the kernels also hold ~17 KiB of static LDS -- the tile-order workgroup's bins --: the strip histogram, and the
+                // cut pyramid + survivor queue behind it in a culled frame, get what gs_frame_occlusion_cull's room rule allows)
                 GS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, GS_BIN_LDS_BYTES - 8 * 4096));
             attr_done.fetch_or(1ull << dev, std::memory_order_release);
         }
         unsigned long long *table = (unsigned long long *)ws.strip_table;
-        // (+ the per-tile occlusion cuts behind the histogram when the frame is culled: gs_frame_occlusion_cull checks the room)
-        const size_t lds = gs_frame_occlusion_cull(f) ? gs_cull_lds_bytes(SG.NS) + sizeof(unsigned long long) * SG.NS
-                                                      : sizeof(unsigned long long) * SG.NS;
         if (slice_end < 0) slice_end = (int)plan.slices;
         GS_CHECK_ARG(slice_begin >= 0 && slice_begin < slice_end && slice_end <= (int)plan.slices, "bad slice range");
         const uint32_t nsl = (uint32_t)(slice_end - slice_begin);
-        const uint32_t extra = slice_begin == 0 ? 1u : 0u;  // the tile-order workgroup rides with the first range
+        if (gs_frame_occlusion_cull(f) && !second_pass) {
+            // GS_FRAME_OCCLUSION_CULL, first pass: Gaussians behind every cut they can reach are not projected, the level-1
+            // entries of the others are trimmed by the cut table the previous frame of this workspace left
+            GS_CHECK_ARG(slice_begin == 0 && nsl == plan.slices, "an occlusion-culled frame is projected in one piece");
+            const uint32_t qcap = plan.per_slice < GS_OCC_QCAP ? plan.per_slice : GS_OCC_QCAP;
+            static const uint32_t diag = getenv("GS_OCC_DIAG") ? (uint32_t)atoi(getenv("GS_OCC_DIAG")) : 0u;  // timing-only builds of the kernel's phases
+            const size_t lds = sizeof(unsigned long long) * SG.NS + gs_cull_pyramid_bytes(G.ntx, G.nty) + 2 * (size_t)qcap + 16;
+            hipLaunchKernelGGL(frame_project_cull_count_kernel, dim3(nsl + 1), dim3(STRIP_THREADS), lds, stream, f->pos,
+                               (const float4 *)f->quat, f->scale, f->opa, f->rgb, f->N, P, ws.rec_geom, ws.rects,
+                               plan.per_slice, SG, nsl, table, ws.slice_pairs, ws.slice_vis, ws.tile_cost,
+                               (uint32_t)G.n_tiles, ws.tile_order, ws.cut, qcap, diag);
+            GS_CHECK_LAUNCH();
+            return 0;
+        }
+        const size_t lds = sizeof(unsigned long long) * SG.NS;
+        const uint32_t extra = (slice_begin == 0 && !second_pass) ? 1u : 0u;  // the tile-order workgroup rides with the first range
+        const unsigned long long *gate = second_pass ? ws.counters + GS_CNT_RANPAST : nullptr;
 #define GS_LAUNCH_PROJECT_COUNT(DIST)                                                                                  \
     hipLaunchKernelGGL(frame_project_count_kernel<DIST>, dim3(nsl + extra), dim3(STRIP_THREADS), lds, stream,          \
                        f->pos, (const float4 *)f->quat, f->scale, f->opa, f->rgb, f->N, P, ws.rec_geom, touched,       \
                        ws.rects, D, plan.per_slice, SG, nsl, (uint32_t)slice_begin, table, ws.slice_pairs,             \
-                       ws.slice_vis, ws.tile_cost, (uint32_t)G.n_tiles, ws.tile_order, cut,                            \
-                       (unsigned long long *)ws.strip_table_full)
-        // GS_FRAME_OCCLUSION_CULL: level-1 entries trimmed by the cut table the previous frame of this workspace left
-        const uint32_t *cut = gs_frame_occlusion_cull(f) ? ws.cut : nullptr;
+                       ws.slice_vis, ws.tile_cost, (uint32_t)G.n_tiles, ws.tile_order, gate)
         if (f->tile_culling_method == 0)
             GS_LAUNCH_PROJECT_COUNT(true);
         else
@@ -1640,6 +1884,7 @@ int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t strea
         GS_CHECK_LAUNCH();
         return 0;
     }
+    GS_CHECK_ARG(!second_pass, "the second pass of an occlusion-culled frame belongs to the fused project + count stage");
     GS_CHECK_ARG(slice_begin == 0 && slice_end < 0, "this frame's project stage cannot be issued in ranges");
     if (gs_frame_fused_table_count(f)) {
         gs_frame_geom G = gs_frame_geometry(f);

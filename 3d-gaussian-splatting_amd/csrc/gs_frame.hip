@@ -313,8 +313,10 @@ static int frame_forward_impl(const gs_frame *f, hipStream_t s, float *stage_ms,
     if (mode == 2 && gs_frame_occlusion_cull(f)) {
         // The lists of this frame were trimmed by the occlusion cuts of the previous one (gs_frame_layout.h).  If a tile ran
         // past its cut, counters[GS_CNT_RANPAST] is set and the launches below render the frame again from the full
-        // lists; otherwise each of them returns at its first instruction.  The project stage is not repeated: it wrote the
-        // untrimmed strip table next to the trimmed one (four gated launches: column scan, scatter, per-tile sort, compositing).
+        // lists; otherwise each of them returns at its first instruction (five gated launches: project + count -- the
+        // first pass did not project the Gaussians behind every cut they could reach --, column scan, scatter, per-tile
+        // sort, compositing).
+        if ((rc = gs_stage_project(f, ws, s, 0, -1, true))) return rc;
         if ((rc = gs_stage_strip_bin(f, ws, s, true))) return rc;
         uint64_t *keys_out = nullptr;  // (frames that export their sorted keys are never culled)
         if ((rc = gs_stage_strip_sort(f, ws, okeys, skeys, keys_out, sids, s, true))) return rc;

@@ -94,8 +94,19 @@ static inline bool gs_frame_long_lists(const gs_frame *f, int n_tiles) {
 // from the full lists.  No host synchronisation, the image is exact either way.  Not for training frames (the backward
 // owns the full emission order), frames that export their sorted keys, the "dist" listing, segmented long lists, or
 // the table / radix variants.
-// LDS a culled frame's level-1 kernels add to their strip tables: a second (full) histogram + the cuts, padded to strips
-static inline size_t gs_cull_lds_bytes(int64_t ns) { return (size_t)ns * 8 + (size_t)ns * 4 * 8; }
+// LDS a culled frame's level-1 kernels add to their strip tables: the cuts, every tile row padded to whole strips --
+static inline size_t gs_cull_lds_bytes(int64_t ns) { return (size_t)ns * 4 * 8; }
+// -- and, in the project stage (frame_project_cull_count_kernel), three more levels of the cut pyramid behind them
+static inline size_t gs_cull_pyramid_bytes(int ntx, int nty) {
+    const int nsx = (ntx + 7) / 8;  // (GS_STRIP_W, defined below)
+    size_t b = (size_t)nsx * 8 * nty * 4;
+    int w = ntx, h = nty;
+    for (int l = 1; l < 4; ++l) {
+        w = (w + 1) / 2, h = (h + 1) / 2;
+        b += (size_t)w * h * 4;
+    }
+    return b;
+}
 #define GS_NO_CUT 0xffffffffu
 #define GS_CUT_MARGIN 0.0625f
 static inline bool gs_frame_occlusion_cull(const gs_frame *f);
@@ -166,12 +177,14 @@ static inline bool gs_frame_occlusion_cull(const gs_frame *f) {
           !(f->flags & (GS_FRAME_EMIT_SORTED_KEYS | GS_FRAME_LONG_LISTS | GS_FRAME_SERIAL_LONG_LISTS)) &&
           gs_frame_uses_strips(f) && GS_FUSED_PROJECT_COUNT))
         return false;
-    // the level-1 kernels keep the per-tile cuts in LDS next to their strip tables (count: two histograms + the cuts =
-    // 48 B per strip; scatter: cursors + cuts + a staging buffer worth having): 1080p = 49 KiB of 160; beyond ~1,950
-    // strips (~15 k tiles: 4K images) the frame is not culled
+    // the level-1 kernels keep the per-tile cuts in LDS next to their strip tables (project + count: histogram, cut pyramid
+    // and a queue of up to 16,384 survivors; scatter: cursors + cuts + a staging buffer worth having): 1080p = 70 KiB of
+    // 160; beyond ~1,900 strips (~15 k tiles: 4K images) the frame is not culled
     const int ntx = (f->width + GS_TILE - 1) / GS_TILE, nty = (f->height + GS_TILE - 1) / GS_TILE;
     const int64_t ns = (int64_t)((ntx + GS_STRIP_W - 1) / GS_STRIP_W) * nty;
-    return 8 * ns + (int64_t)gs_cull_lds_bytes(ns) + 8 * 4096 <= (int64_t)GS_BIN_LDS_BYTES - 8 * 4096;
+    const int64_t room = (int64_t)GS_BIN_LDS_BYTES - 8 * 4096;
+    return 8 * ns + (int64_t)gs_cull_pyramid_bytes(ntx, nty) + 2 * 16384 + 16 <= room &&
+           8 * ns + (int64_t)gs_cull_lds_bytes(ns) + 8 * 4096 <= room;
 }
 // Table variant (small scenes: a frame is a chain of dependent launches of ~7 us each): the per-(slice, tile) count
 // (bin_count_kernel) is taken inside the project stage as well -- five launches per frame instead of six.
@@ -284,7 +297,6 @@ struct gs_frame_ws {
                                         // slice's region in keys_a
     // sort_mode 2, strip variant (strip_bin.hip): packed (entries << 32 | pairs) per (slice, strip)
     uint64_t *strip_table;         // [2][GS_BIN_SLICES][NS]: raw counts, then their exclusive scan over the slices
-    uint64_t *strip_table_full;    // [GS_BIN_SLICES][NS] occlusion-culled frames: the UNTRIMMED counts, for the gated second pass
     uint64_t *strip_tot;           // [NS] totals per strip
     uint64_t *strip_base;          // [NS] (first entry << 32 | first pair) of every strip
     uint32_t *big_tiles;           // [T] queue of the tiles whose list exceeds strip_sort_kernel's LDS window
@@ -372,7 +384,6 @@ static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pair
         const gs_strip_plan sp = gs_strip_plan_for(N, G.ntx, G.nty);
         const size_t ns = sp.ok ? sp.geom.NS : 1;
         ws.strip_table = (uint64_t *)take(sizeof(uint64_t) * 2 * GS_BIN_SLICES * ns);
-        ws.strip_table_full = (uint64_t *)take(sizeof(uint64_t) * GS_BIN_SLICES * ns);
         ws.strip_tot = (uint64_t *)take(sizeof(uint64_t) * ns);
         ws.strip_base = (uint64_t *)take(sizeof(uint64_t) * ns);
         ws.big_tiles = (uint32_t *)take(sizeof(uint32_t) * (sp.ok ? (size_t)G.n_tiles : 1));
@@ -426,7 +437,8 @@ static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pair
 }
 
 // stage entry points (defined across the .hip files)
-int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream, int slice_begin = 0, int slice_end = -1);
+int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream, int slice_begin = 0, int slice_end = -1,
+                     bool second_pass = false);
 int gs_stage_project_backward(const gs_frame *f, const gs_frame_ws &ws, float *grad_pos, float *grad_quat,
                               float *grad_scale, float *grad_opa, float *grad_rgb, int part, int64_t g_begin,
                               int64_t g_end, hipStream_t stream);

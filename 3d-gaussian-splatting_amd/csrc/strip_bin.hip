@@ -391,8 +391,8 @@ int gs_stage_strip_bin(const gs_frame *f, const gs_frame_ws &ws, hipStream_t str
     // a culled frame's scatter gives 4 staged entries per strip (32 B: the strip's eight cuts) to the cut table
     const uint32_t cap = cut ? plan.cap - 4 * SG.NS : plan.cap;
     const size_t lds_scatter = sizeof(unsigned long long) * ((size_t)SG.NS + cap) + (cut ? (size_t)32 * SG.NS : 0);
-    // the second pass scans the UNTRIMMED table the culled frame's project + count launch wrote next to the trimmed one
-    const unsigned long long *raw = second_pass ? (const unsigned long long *)ws.strip_table_full : table;
+    // (second pass: the table has been rewritten, untrimmed, by the gated re-run of the project stage)
+    const unsigned long long *raw = table;
 #define GS_LAUNCH_STRIP(DIST)                                                                                          \
     do {                                                                                                               \
         if (!second_pass && !gs_frame_fused_count(f)) { /* else: counted by the project stage */                         \

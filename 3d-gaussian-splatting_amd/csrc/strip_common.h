@@ -24,15 +24,11 @@ namespace {
 // workspace proved to be behind the point where their tile's pixels have all stopped; a run that loses all its tiles emits
 // nothing.  The same table in the count and in the scatter pass; strip_sort_kernel takes the run from the entry.
 // (First version: a generic pointer and a data-dependent loop per end -- flat loads, +45 us in the scatter at 2.4 M Gaussians.)
-// BOTH (count pass of a culled frame): fn is also told the run's UNTRIMMED pair count, fn(strip, lo32, depth, pairs, pairs of
-// the full run) -- called for every run of the rectangle, `pairs` = 0 for a run the cuts removed --, so that one walk
-// fills the trimmed and the full histogram.
-template <bool DIST, bool CUT = false, bool BOTH = false, typename Fn>
+template <bool DIST, bool CUT = false, typename Fn>
 __device__ __forceinline__ void walk_strips(const uint4 rc, int64_t g, const gs_strip_geom SG, float2 cxy,
                                             const GsDistCull &D, Fn fn, const uint32_t *cut8 = nullptr) {
     static_assert(!CUT || GS_STRIP_W == 8, "the cut table is read eight tiles at a time");
     static_assert(!CUT || !DIST, "the occlusion cull is not combined with the \"dist\" listing");
-    static_assert(!BOTH || CUT, "BOTH is a flavour of CUT");
     const int lane = threadIdx.x & 63;
     const uint32_t y0 = rc.x & 0xffff, y1 = rc.x >> 16, x0 = rc.y & 0xffff, x1 = rc.y >> 16, dbits = rc.z;
     const bool vis = rc.w != 0;
@@ -48,12 +44,6 @@ __device__ __forceinline__ void walk_strips(const uint4 rc, int64_t g, const gs_
             uint32_t keep = (d <= c0.x ? 1u : 0u) | (d <= c0.y ? 2u : 0u) | (d <= c0.z ? 4u : 0u) | (d <= c0.w ? 8u : 0u) |
                             (d <= c1.x ? 16u : 0u) | (d <= c1.y ? 32u : 0u) | (d <= c1.z ? 64u : 0u) | (d <= c1.w ? 128u : 0u);
             keep &= ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-            if constexpr (BOTH) {
-                const uint32_t full = hi - lo;
-                const uint32_t l = keep ? (uint32_t)__ffs((int)keep) - 1u : 0u, h = keep ? 32u - (uint32_t)__clz((int)keep) : 0u;
-                fn(iy * SG.nsx + sx, (l << 29) | ((h ? h - 1 : 0u) << 26) | id, d, h - l, full);
-                return;
-            }
             if (!keep) return;
             lo = (uint32_t)__ffs((int)keep) - 1u;
             hi = 32u - (uint32_t)__clz((int)keep);
@@ -64,7 +54,7 @@ __device__ __forceinline__ void walk_strips(const uint4 rc, int64_t g, const gs_
             for (uint32_t x = lo; x < hi; ++x) np += gs_dist_listed(px, py, t0 + x, iy, D) ? 1u : 0u;
             if (!np) return;
         }
-        if constexpr (!BOTH) fn(iy * SG.nsx + sx, (lo << 29) | ((hi - 1) << 26) | id, d, np);
+        fn(iy * SG.nsx + sx, (lo << 29) | ((hi - 1) << 26) | id, d, np);
     };
     if (ne && ne <= STRIP_SOLO) {
         uint32_t sx = sx0, iy = y0;

@@ -96,6 +96,7 @@ BUDGETS = [
     (("frame_project_backward_kernelILi3ELi0ELi256ELi0E",), 80, False),  # rgb projection backward: six waves per SIMD
     (("frame_project_backward_kernelILi3ELi0ELi256ELi1E",), 104, False), # ... with the Adam step fused in (round 5): four
     (("frame_project_count_kernelILb0E",), 128, False),                   # 1024 threads per workgroup: 128 is the hard limit
+    (("frame_project_cull_count_kernel",), 128, False),                   # ... of an occlusion-culled frame (round 6): compacting
     (("frame_project_bin_count_kernelILb0E",), 128, False),
     (("strip_sort_kernelILi2048ELb0E",), 128, False),                    # four workgroups of 256 per CU
     (("loss_fused_kernel",), 256, False),                                # one workgroup of 512 per CU: two waves per SIMD
