@@ -673,9 +673,10 @@ __global__ void __launch_bounds__(STRIP_THREADS) frame_project_cull_count_kernel
     float4 *__restrict__ rec_geom, uint4 *__restrict__ rects, uint32_t per_slice, gs_strip_geom SG, uint32_t S,
     unsigned long long *__restrict__ table, uint32_t *__restrict__ slice_pairs, uint32_t *__restrict__ slice_vis,
     const uint32_t *__restrict__ tile_cost, uint32_t n_tiles, uint32_t *__restrict__ tile_order,
-    const uint32_t *__restrict__ cut, uint32_t qcap, uint32_t diag) {
+    const uint32_t *__restrict__ cut, uint32_t qcap, uint4 *__restrict__ surv, uint32_t *__restrict__ slice_nsurv,
+    uint32_t diag) {
     extern __shared__ unsigned long long s_hist[];  // [NS] entries << 32 | pairs of this slice, then the pyramid, then the queue
-    __shared__ uint32_t s_acc[2], s_qn;
+    __shared__ uint32_t s_acc[2], s_qn, s_ns;
     if (blockIdx.x >= S) {  // the one extra workgroup of the launch (uniform)
         if (diag & 16) return;
         tile_order_workgroup(tile_cost, n_tiles, tile_order, SG.ntx, SG.nty);
@@ -708,6 +709,7 @@ __global__ void __launch_bounds__(STRIP_THREADS) frame_project_cull_count_kernel
             if (t0 + k * STRIP_THREADS < st0 * SG.nty) s_cut[t0 + k * STRIP_THREADS] = v[k];
     }
     if (threadIdx.x < 2) s_acc[threadIdx.x] = 0;
+    if (threadIdx.x == 2) s_ns = 0;
     auto build = [&](uint32_t *dst, uint32_t dw, uint32_t dh, const uint32_t *src, uint32_t sst, uint32_t sw, uint32_t sh) {
         __syncthreads();
         for (uint32_t t = threadIdx.x; t < dw * dh; t += STRIP_THREADS) {
@@ -745,7 +747,6 @@ __global__ void __launch_bounds__(STRIP_THREADS) frame_project_cull_count_kernel
         auto test = [&](const float (&pp)[3], const float (&ss)[3], uint32_t i) {
             bool surv = false;
             if (in_chunk(i)) {
-                const int64_t pid = g0 + c0 + i;
                 float pc[3], pi[3];
                 if (project_cull(pp, P.cam, P.near_plane, P.half_w, P.half_h, pc, pi)) {
                     const float dep = sqrtf(pc[0] * pc[0] + pc[1] * pc[1] + pc[2] * pc[2]);  // == project_cov's pos_i[2]
@@ -759,14 +760,13 @@ __global__ void __launch_bounds__(STRIP_THREADS) frame_project_cull_count_kernel
                     // Gaussians instead of the queued ones, 64: no strip count; tools/batches/gpu_r6n.sh, profiles/r06_n_*)
                     if ((diag & 4) || (!(diag & 1) && (s[0] + s[1] + s[2] < 3.0e38f) &&
                                        occluded_everywhere(pi, pc[2], smax, __float_as_uint(dep), P, Y))) {
-                        // behind every cut it can reach: visible, no tile (no later stage of an inference frame looks at it)
-                        rects[pid] = make_uint4(0, 0, __float_as_uint(dep), 0);
+                        // behind every cut it can reach, or beside the grid: visible, no tile.  NOTHING is written for it (nor
+                        // for a Gaussian outside the frustum): the scatter of this pass reads the survivor list, the second
+                        // pass re-projects everything -- rects[] of a culled frame is only fresh for the survivors
                         acc_vis += 1;
                     } else {
                         surv = true;
                     }
-                } else {
-                    rects[pid] = make_uint4(0, 0, 0, 0);
                 }
             }
             const unsigned long long b = __ballot(surv);
@@ -814,8 +814,18 @@ __global__ void __launch_bounds__(STRIP_THREADS) frame_project_cull_count_kernel
             if (k < nq) rc = project_one(cur, pid, P, rec_geom, nullptr, rects, vis, cxy);
             acc_cnt += rc.w;
             acc_vis += vis;
-            // (count only: the id walk_strips derives for ANOTHER lane's Gaussian, g - lane + src, is wrong here -- the queue
-            // is not in index order -- and not looked at)
+            {   // survivors that touch a tile: (rectangle, depth, Gaussian) appended to the slice's compact list
+                const bool has = rc.w != 0;
+                const unsigned long long hb = __ballot(has);
+                if (hb) {  // (uniform per wave)
+                    uint32_t wbase = 0;
+                    if (lane == 0) wbase = atomicAdd(&s_ns, (uint32_t)__popcll(hb));
+                    wbase = __shfl(wbase, 0, 64);
+                    if (has)
+                        surv[g0 + wbase + (uint32_t)__popcll(hb & ((1ull << lane) - 1ull))] =
+                            make_uint4(rc.x, rc.y, rc.z, (uint32_t)pid);
+                }
+            }
             if (!(diag & 64)) walk_strips<false, true>(rc, pid, SG, cxy, GsDistCull{},
                                            [&](uint32_t strip, uint32_t, uint32_t, uint32_t np) {
                                                atomicAdd(&s_hist[strip], (1ull << 32) | np);
@@ -837,6 +847,7 @@ __global__ void __launch_bounds__(STRIP_THREADS) frame_project_cull_count_kernel
     if (threadIdx.x == 0) {
         slice_pairs[slice] = s_acc[0];
         slice_vis[slice] = s_acc[1];
+        slice_nsurv[slice] = s_ns;
     }
 }
 
@@ -1864,7 +1875,7 @@ int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t strea
             hipLaunchKernelGGL(frame_project_cull_count_kernel, dim3(nsl + 1), dim3(STRIP_THREADS), lds, stream, f->pos,
                                (const float4 *)f->quat, f->scale, f->opa, f->rgb, f->N, P, ws.rec_geom, ws.rects,
                                plan.per_slice, SG, nsl, table, ws.slice_pairs, ws.slice_vis, ws.tile_cost,
-                               (uint32_t)G.n_tiles, ws.tile_order, ws.cut, qcap, diag);
+                               (uint32_t)G.n_tiles, ws.tile_order, ws.cut, qcap, ws.surv, ws.slice_nsurv, diag);
             GS_CHECK_LAUNCH();
             return 0;
         }

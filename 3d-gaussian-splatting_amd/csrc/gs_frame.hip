@@ -513,6 +513,12 @@ extern "C" int gs_frame_cull_fallback_async(const gs_frame *f, int64_t *ran_past
     return 0;
 }
 
+extern "C" int gs_frame_is_occlusion_culled(const gs_frame *f, int32_t *culled) {
+    GS_CHECK_ARG(f && culled, "null argument");
+    *culled = (effective_sort_mode(f) == 2 && gs_frame_occlusion_cull(f)) ? 1 : 0;
+    return 0;
+}
+
 extern "C" int gs_frame_debug_tile_nproc(const gs_frame *f, const uint32_t **tile_nproc) {
     int rc = validate(f);
     if (rc) return rc;

@@ -276,6 +276,8 @@ struct gs_frame_ws {
     float4 *rec_conic;             // (A, B, C, -)
     uint32_t *tiles_touched;       // [N]
     uint4 *rects;                  // [N] (y0 | y1 << 16, x0 | x1 << 16, depth bits, tiles touched): all the binning needs
+    uint4 *surv;                   // [N] inference workspaces: compacted survivor rectangles of an occlusion-culled frame
+    uint32_t *slice_nsurv;         // [slices] their count per slice
     uint32_t *block_sums;          // [ceil(N/256)] pairs emitted by each 256-Gaussian block
     uint32_t *block_vis;           // [ceil(N/256)] visible Gaussians of each block
     uint32_t *block_offsets;       // [ceil(N/256)]
@@ -361,6 +363,11 @@ static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pair
     ws.rec_conic = ws.rec_geom ? ws.rec_geom + 3 : nullptr;
     ws.tiles_touched = (uint32_t *)take(sizeof(uint32_t) * N);
     ws.rects = (uint4 *)take(sizeof(uint4) * N);
+    // occlusion-culled inference frames (first pass): the rectangles of the Gaussians that were projected AND touch a tile,
+    // compacted per slice of the Gaussian array -- (y range, x range, depth bits, Gaussian) at [slice x per_slice, +
+    // slice_nsurv[slice]) -- what the level-1 scatter of such a frame reads instead of all N rectangle records
+    ws.surv = (uint4 *)take(training ? 0 : sizeof(uint4) * N);
+    ws.slice_nsurv = (uint32_t *)take(sizeof(uint32_t) * GS_BIN_MAX_SLICES);
     ws.block_sums = (uint32_t *)take(sizeof(uint32_t) * nblk);
     ws.block_vis = (uint32_t *)take(sizeof(uint32_t) * nblk);
     ws.block_offsets = (uint32_t *)take(sizeof(uint32_t) * nblk);

@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(STRIP_THREADS) strip_scatter_kernel(
     const uint32_t *__restrict__ slice_pairs, const uint32_t *__restrict__ slice_vis, uint64_t max_pairs,
     unsigned long long *__restrict__ out, uint32_t *__restrict__ pair_offsets,
     unsigned long long *__restrict__ counters, const uint32_t *__restrict__ cut, uint32_t n_tiles,
-    const unsigned long long *__restrict__ gate) {
+    const unsigned long long *__restrict__ gate, const uint4 *__restrict__ surv, const uint32_t *__restrict__ slice_nsurv) {
     extern __shared__ unsigned long long s_dyn[];
     if (gate && *gate == 0) return;  // (see strip_count_kernel)
     uint32_t *s_cur = reinterpret_cast<uint32_t *>(s_dyn), *s_gd = s_cur + SG.NS;
@@ -203,7 +203,11 @@ __global__ void __launch_bounds__(STRIP_THREADS) strip_scatter_kernel(
     __shared__ uint32_t s_wave[STRIP_THREADS / 64];
     __shared__ unsigned long long s_wave64[4 * (STRIP_THREADS / 64)];
     const uint32_t slice = strip_slice_of_block(blockIdx.x, gridDim.x);
-    const SliceLoader L = {rects, rec_geom, n, (int64_t)slice * per_slice, per_slice};
+    // `surv` (first pass of an occlusion-culled frame): the slice's rectangles come from the compact list the project stage
+    // left -- (y range, x range, depth, Gaussian) of the Gaussians it projected that touch a tile, slice_nsurv[slice] of them
+    // at the slice's own offset -- instead of from all per_slice rectangle records, most of which were not even written
+    const uint32_t count = surv ? slice_nsurv[slice] : per_slice;
+    const SliceLoader L = {surv ? surv : rects, rec_geom, n, (int64_t)slice * per_slice, count};
     uint4 rc[STRIP_PF];
 #pragma unroll
     for (int k = 0; k < STRIP_PF; ++k) rc[k] = L.rect(k * STRIP_THREADS);  // in flight during the set-up below
@@ -321,7 +325,7 @@ __global__ void __launch_bounds__(STRIP_THREADS) strip_scatter_kernel(
     }
     __syncthreads();
     // ---- place
-    for (uint32_t base = 0; base < per_slice; base += STRIP_PF * STRIP_THREADS) {  // uniform trip counts (barriers inside)
+    for (uint32_t base = 0; base < count; base += STRIP_PF * STRIP_THREADS) {  // uniform trip counts (barriers inside)
         uint4 cur[STRIP_PF];
 #pragma unroll
         for (int k = 0; k < STRIP_PF; ++k) {
@@ -331,7 +335,7 @@ __global__ void __launch_bounds__(STRIP_THREADS) strip_scatter_kernel(
 #pragma unroll
         for (int k = 0; k < STRIP_PF; ++k) {
             const uint32_t b = base + k * STRIP_THREADS;
-            if (b >= per_slice) break;  // uniform
+            if (b >= count) break;  // uniform
             const uint32_t i = b + threadIdx.x;
             if (pair_offsets) {  // uniform: prefix sum of the rectangle areas in Gaussian order
                 const uint32_t ex = strip_block_excl_scan(cur[k].w, s_wave, dummy);
@@ -347,7 +351,15 @@ __global__ void __launch_bounds__(STRIP_THREADS) strip_scatter_kernel(
                     out[s_gd[strip] + slot] = e;
             };
             if (cut) {  // (uniform; a "dist" frame is never culled)
-                if constexpr (!DIST) walk_strips<false, true>(cur[k], L.g0 + i, SG, L.xy<DIST>(b, cur[k]), D, place, s_cut);
+                if constexpr (!DIST) {
+                    uint4 e = cur[k];
+                    int64_t gid = L.g0 + i;
+                    if (surv) {  // (uniform) a list entry: the Gaussian rides in .w, the area follows from the ranges
+                        gid = e.w;
+                        e.w = ((e.x >> 16) - (e.x & 0xffff)) * ((e.y >> 16) - (e.y & 0xffff));
+                    }
+                    walk_strips<false, true>(e, gid, SG, make_float2(0.f, 0.f), D, place, s_cut);
+                }
             } else {
                 walk_strips<DIST>(cur[k], L.g0 + i, SG, L.xy<DIST>(b, cur[k]), D, place);
             }
@@ -409,7 +421,8 @@ int gs_stage_strip_bin(const gs_frame *f, const gs_frame_ws &ws, hipStream_t str
                            ws.rects, ws.rec_geom, D, f->N, plan.per_slice, SG, plan.slices, cap, scan,                 \
                            (const unsigned long long *)ws.strip_tot, (unsigned long long *)ws.strip_base,              \
                            ws.slice_pairs, ws.slice_vis, (uint64_t)f->max_pairs, (unsigned long long *)ws.keys_a,      \
-                           f->training ? ws.pair_offsets : nullptr, ws.counters, cut, (uint32_t)G.n_tiles, gate);      \
+                           f->training ? ws.pair_offsets : nullptr, ws.counters, cut, (uint32_t)G.n_tiles, gate,       \
+                           cut ? (const uint4 *)ws.surv : (const uint4 *)nullptr, (const uint32_t *)ws.slice_nsurv);    \
         GS_CHECK_LAUNCH();                                                                                             \
     } while (0)
     if (dist)

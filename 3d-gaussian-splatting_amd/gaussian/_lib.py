@@ -97,6 +97,7 @@ gs_frame_stats_async = _sig("gs_frame_stats_async", ci, C.POINTER(GsFrame), vp, 
 gs_frame_longest_list_async = _sig("gs_frame_longest_list_async", ci, C.POINTER(GsFrame), vp, vp)
 gs_frame_stats_tagged_async = _sig("gs_frame_stats_tagged_async", ci, C.POINTER(GsFrame), C.c_uint32, vp, vp)
 gs_frame_cull_fallback_async = _sig("gs_frame_cull_fallback_async", ci, C.POINTER(GsFrame), vp, vp)
+gs_frame_is_occlusion_culled = _sig("gs_frame_is_occlusion_culled", ci, C.POINTER(GsFrame), C.POINTER(C.c_int32))
 GS_STATS_TAGGED_N = 15
 gs_frame_debug_views = _sig("gs_frame_debug_views", ci, C.POINTER(GsFrame), C.POINTER(vp), C.POINTER(vp),
                             C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp))
@@ -153,7 +154,7 @@ EXPORTS = [
     "gs_jacobian", "gs_global_culling", "gs_global_culling_backward", "gs_calc_tile_list",
     "gs_gather_gaussians", "gs_draw", "gs_draw_backward_workspace_bytes", "gs_draw_backward",
     "gs_sort_pairs_tmp_bytes", "gs_sort_pairs", "gs_sort_pairs_bits", "gs_frame_workspace_bytes", "gs_frame_forward",
-    "gs_frame_stats_async", "gs_frame_longest_list_async", "gs_frame_stats_tagged_async", "gs_frame_cull_fallback_async", "gs_frame_debug_views", "gs_frame_debug_rects", "gs_frame_binning_variant", "gs_frame_debug_tile_nproc", "gs_frame_debug_bwd_exec_rows", "gs_frame_backward", "gs_frame_backward_adam", "gs_frame_forward_profile",
+    "gs_frame_stats_async", "gs_frame_longest_list_async", "gs_frame_stats_tagged_async", "gs_frame_cull_fallback_async", "gs_frame_is_occlusion_culled", "gs_frame_debug_views", "gs_frame_debug_rects", "gs_frame_binning_variant", "gs_frame_debug_tile_nproc", "gs_frame_debug_bwd_exec_rows", "gs_frame_backward", "gs_frame_backward_adam", "gs_frame_forward_profile",
     "gs_frame_backward_part", "gs_frame_async_create", "gs_frame_async_wait", "gs_frame_async_destroy",
     "gs_frame_backward_slice", "gs_frame_project_slices", "gs_frame_forward_project", "gs_frame_forward_rest",
     "gs_adam_step_multi",

@@ -738,11 +738,20 @@ class FrameRenderer:
         _lib.check(_lib.gs_frame_overflow_flag(C.byref(self._frame), C.byref(ptr)), "gs_frame_overflow_flag")
         return ptr.value
 
-    def _rects(self) -> torch.Tensor:
-        """[N,4] int32 view of the workspace: (y0 | y1 << 16, x0 | x1 << 16, depth bits, tiles touched) per Gaussian."""
+    def _rects(self, allow_culled: bool = False) -> torch.Tensor:
+        """[N,4] int32 view of the workspace: (y0 | y1 << 16, x0 | x1 << 16, depth bits, tiles touched) per Gaussian.
+
+        An occlusion-culled inference frame writes the records of the Gaussians it PROJECTED only (frustum-culled and
+        occluded ones leave whatever an earlier frame wrote): ``culling_mask`` / ``debug_views`` refuse such a frame --
+        render with ``occlusion_cull=False`` where they are wanted."""
         f = self._frame
         if f is None:
             raise RuntimeError("no frame rendered yet")
+        culled = C.c_int32(0)
+        _lib.check(_lib.gs_frame_is_occlusion_culled(C.byref(f), C.byref(culled)), "gs_frame_is_occlusion_culled")
+        if culled.value and not allow_culled:
+            raise RuntimeError("the rectangle records of an occlusion-culled frame cover its projected Gaussians only: "
+                               "render with FrameRenderer(occlusion_cull=False) for culling_mask() / debug_views()")
         ptr = C.c_void_p()
         _lib.check(_lib.gs_frame_debug_rects(C.byref(f), C.byref(ptr)), "gs_frame_debug_rects")
         off = ptr.value - self._ws.data_ptr()

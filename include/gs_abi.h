@@ -34,7 +34,9 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-/* 7 (round 6): GS_FRAME_LONG_SORT, GS_FRAME_OCCLUSION_CULL + gs_frame_cull_fallback_async; gs_frame_stats_serial (the frame the
+/* 8 (round 6): gs_frame_is_occlusion_culled; an occlusion-culled frame's first pass projects only the Gaussians that are not
+ * behind every cut they can reach and writes rectangle records for those only (workspace layout: + the survivor list).
+ * 7 (round 6): GS_FRAME_LONG_SORT, GS_FRAME_OCCLUSION_CULL + gs_frame_cull_fallback_async; gs_frame_stats_serial (the frame the
  * counters belong to).
  * 6 (round 5): gs_frame_backward_adam (the backward with the optimizer step fused in); gs_frame_debug_bwd_exec_rows; GS_FRAME_BWD_ROWS and the saturated-bucket count in the upper half of the
  * `buckets` counter; SH gradient rows in whole 64-byte lines without per-row flags (workspace
@@ -46,7 +48,7 @@ extern "C" {
  * gs_frame_debug_rects (records of culled Gaussians are no longer written), gs_frame_overflow_flag,
  * gs_adam_step_sharded, `fast = 0` of gs_draw / gs_draw_backward honoured, the long-list kernels follow GS_FRAME_LONG_LISTS alone (not the
  * workspace capacity).  3: gs_frame.async / flags. */
-#define GS_ABI_VERSION 7
+#define GS_ABI_VERSION 8
 
 #define GS_E_INVALID (-1)   /* bad argument (null pointer, negative size, bad enum)   */
 #define GS_E_UNSUPPORTED (-2) /* valid in the reference but not implemented here (none at present) */
@@ -356,6 +358,13 @@ int gs_frame_stats_tagged_async(const gs_frame *f, uint32_t tag, int64_t *stats_
 /* Non-zero in *ran_past_host (after `stream` has reached this copy) iff the frame's lists had been trimmed
  * (GS_FRAME_OCCLUSION_CULL) and a tile ran past its cut, i.e. the frame was rendered a second time from the full lists. */
 int gs_frame_cull_fallback_async(const gs_frame *f, int64_t *ran_past_host, gs_stream_t stream);
+
+/* *culled = 1 iff the library renders this frame description with the occlusion cull (the flag is set AND none of the
+ * conditions under which it is ignored holds); host-side, no launch.  Such a frame's first pass tests every Gaussian
+ * against the frustum and the cut pyramid on its position and scale alone and projects the survivors only: the rectangle
+ * records (gs_frame_debug_rects) and the 64-byte records are then fresh for the PROJECTED Gaussians only -- the others keep
+ * what an earlier frame left -- unless the frame fell back (second pass: everything is projected again). */
+int gs_frame_is_occlusion_culled(const gs_frame *f, int32_t *culled);
 
 /* (Validity, since ABI 4: `tiles_touched` is written by sort_modes 0 / 1 only -- sort_mode 2 keeps the count in
  * rects[i].w, gs_frame_debug_rects -- and the rec_* records are written for VISIBLE Gaussians only: the record of a

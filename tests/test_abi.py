@@ -30,7 +30,7 @@ def test_header_functions_are_all_exported():
 def test_version_and_error_string():
     from gaussian import _lib
 
-    assert _lib.gs_abi_version() == 7  # GS_ABI_VERSION of include/gs_abi.h (7: GS_FRAME_LONG_SORT, GS_FRAME_OCCLUSION_CULL, tagged stats)
+    assert _lib.gs_abi_version() == 8  # GS_ABI_VERSION of include/gs_abi.h (8: gs_frame_is_occlusion_culled, survivor-only records in culled frames)
     assert _lib.gs_culling() == 0
     assert isinstance(_lib.gs_last_error(), bytes)
 

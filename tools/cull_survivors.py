@@ -24,7 +24,7 @@ for cull in (False, True):
     for _ in range(8):
         r.forward(*params, cam)
     torch.cuda.synchronize()
-    rc = r._rects().cpu().numpy()
+    rc = r._rects(allow_culled=True).cpu().numpy()  # (culled frame: fresh for the projected Gaussians only)
     st = r.stats()
     prof = [r.profile_forward(*params, cam) for _ in range(8)][3:]
     key = "culled" if cull else "plain"
