@@ -194,10 +194,20 @@ __global__ void __launch_bounds__(STRIP_THREADS) strip_scatter_kernel(
     // padded to whole strips (walk_strips<.., true>)
     uint32_t *s_cut = reinterpret_cast<uint32_t *>(s_stage + cap);
     if (cut) {
+        // (eight loads in flight per thread -- one at a time, each waited for, cost eight load latencies; barriers follow below)
         const uint32_t stride = SG.nsx * GS_STRIP_W;
-        for (uint32_t t = threadIdx.x; t < stride * SG.nty; t += STRIP_THREADS) {  // (barriers follow below)
-            const uint32_t iy = t / stride, ix = t - iy * stride;
-            s_cut[t] = ix < SG.ntx ? cut[iy * SG.ntx + ix] : GS_NO_CUT;
+        for (uint32_t t0 = threadIdx.x; t0 < stride * SG.nty; t0 += 8 * STRIP_THREADS) {
+            uint32_t v[8];
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) {
+                const uint32_t t = t0 + k * STRIP_THREADS, iy = t / stride, ix = t - iy * stride;
+                const bool in = iy < SG.nty && ix < SG.ntx;
+                v[k] = cut[in ? iy * SG.ntx + ix : 0u];
+                v[k] = in ? v[k] : GS_NO_CUT;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k)
+                if (t0 + k * STRIP_THREADS < stride * SG.nty) s_cut[t0 + k * STRIP_THREADS] = v[k];
         }
     }
     __shared__ uint32_t s_wave[STRIP_THREADS / 64];

@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from dataclasses import dataclass
 from typing import Optional
 
@@ -39,6 +40,9 @@ class FrameStats:
     longest_list: int = 0  # longest tile list of the frame (lists of up to 1024 pairs are reported as 0)
     saturated_buckets: int = 0  # ... of them in tiles whose compositing stopped before the end of their list
     cull_fallback: bool = False  # an occlusion-culled frame whose lists proved too short: rendered again from the full ones
+
+
+_LOG_FLAGS = os.environ.get("GS_LOG_FLAGS", "") == "1"
 
 
 class FrameRenderer:
@@ -227,6 +231,11 @@ class FrameRenderer:
             (_lib.GS_FRAME_LONG_LISTS if (self.long_lists or (self.long_lists is None and self._long_lists_seen)) else 0) | \
             (_lib.GS_FRAME_LONG_SORT if (self.long_lists is None and self._long_sort_seen) else 0) | \
             (_lib.GS_FRAME_BWD_ROWS if (self.bwd_rows or (self.bwd_rows is None and self._bwd_rows_seen)) else 0)
+        if _LOG_FLAGS and (f.flags, self.max_pairs) != getattr(self, "_logged_flags", None):
+            # GS_LOG_FLAGS=1: every change of the latched flags / the capacity, with the frame it happens at (diagnostic)
+            print(f"[gs_frame {id(self) & 0xffff:04x}] frame {self._frame_serial} N={n} training={int(training)} "
+                  f"flags={int(f.flags)} max_pairs={self.max_pairs}", file=sys.stderr, flush=True)
+            self._logged_flags = (f.flags, self.max_pairs)
         f.training = int(training)
         f.sort_mode = self.sort_mode
         f.tile_culling_method = self.tile_culling_method

@@ -49,7 +49,7 @@ def training_soak(dev, sh_degree, n_iters, params=None, cams=None, block=100, st
     opt = TrainOptions(n_iters=n_iters, use_clone=1, delete_thresh=1.5, grad_thresh=2e-4)
     tr = Trainer(start, cams, targets, opt, max_pairs=1 << 21, densify=True, generator=g)
     rng = np.random.default_rng(0)
-    sizes, pairs, rates = [tr.n_gaussians], [], []
+    sizes, pairs, rates, flags = [tr.n_gaussians], [], [], []
     torch.cuda.synchronize()
     t0 = t_win = time.perf_counter()
     v = None
@@ -60,6 +60,10 @@ def training_soak(dev, sh_degree, n_iters, params=None, cams=None, block=100, st
             now = time.perf_counter()
             rates.append(round(block / (now - t_win), 1))
             t_win = now
+            # what the renderer has latched at the end of the block (host-side state, no synchronisation): frame flags
+            # (16 segments, 64 row-layout rgb backward, 128 big-list sort), capacity, frames found overflowed
+            f = tr.renderer._frame
+            flags.append([int(f.flags) if f is not None else 0, int(tr.renderer.max_pairs), int(tr.renderer.overflowed_frames)])
         if i % stats_every == 0:
             sizes.append(tr.n_gaussians)
             pairs.append(tr.renderer.stats().pairs)  # synchronises: once per `stats_every` iterations
@@ -71,7 +75,7 @@ def training_soak(dev, sh_degree, n_iters, params=None, cams=None, block=100, st
     return {"iters": n_iters, "iters_per_s": round(n_iters / dt, 1), "block": block, "repeats": len(rates),
             "iters_per_s_median_block": round(statistics.median(rates), 1) if rates else None,
             "iters_per_s_min_block": min(rates) if rates else None, "iters_per_s_max_block": max(rates) if rates else None,
-            "iters_per_s_blocks": rates, f"n_gaussians_every_{stats_every}": sizes, f"tile_pairs_every_{stats_every}": pairs,
+            "iters_per_s_blocks": rates, "flags_capacity_overflows_per_block": flags, f"n_gaussians_every_{stats_every}": sizes, f"tile_pairs_every_{stats_every}": pairs,
             "final_loss": round(float(vals[0]), 5), "finite": bool(np.isfinite(vals).all()),
             "peak_memory_GiB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}
 
