@@ -673,8 +673,8 @@ __global__ void __launch_bounds__(STRIP_THREADS) frame_project_cull_count_kernel
     float4 *__restrict__ rec_geom, uint4 *__restrict__ rects, uint32_t per_slice, gs_strip_geom SG, uint32_t S,
     unsigned long long *__restrict__ table, uint32_t *__restrict__ slice_pairs, uint32_t *__restrict__ slice_vis,
     const uint32_t *__restrict__ tile_cost, uint32_t n_tiles, uint32_t *__restrict__ tile_order,
-    const uint32_t *__restrict__ cut, uint32_t qcap, uint4 *__restrict__ surv, uint32_t *__restrict__ slice_nsurv,
-    uint32_t diag) {
+    const uint32_t *__restrict__ cut, uint32_t qcap, uint32_t stash_cap, uint4 *__restrict__ surv,
+    uint32_t *__restrict__ slice_nsurv, uint32_t diag) {
     extern __shared__ unsigned long long s_hist[];  // [NS] entries << 32 | pairs of this slice, then the pyramid, then the queue
     __shared__ uint32_t s_acc[2], s_qn, s_ns;
     if (blockIdx.x >= S) {  // the one extra workgroup of the launch (uniform)
@@ -692,7 +692,20 @@ __global__ void __launch_bounds__(STRIP_THREADS) frame_project_cull_count_kernel
                    h3 = (h2 + 1) / 2;
     uint32_t *s_l1 = s_cut + st0 * SG.nty, *s_l2 = s_l1 + w1 * h1, *s_l3 = s_l2 + w2 * h2;
     uint16_t *s_q = reinterpret_cast<uint16_t *>(s_l3 + w3 * h3);
+    // the first `stash_cap` survivors of a chunk keep their position and scale in LDS (six planes of stash_cap floats): phase B
+    // then gathers only the 32 bytes phase A did not read -- 17 % of the array still touches 62 % of its 64-byte lines
+    float *s_stash = reinterpret_cast<float *>(s_q + ((qcap + 1) & ~1u));
     const OccPyramid Y = {s_cut, st0 * SG.nty, w1 * h1, w2 * h2, st0, w1 - st0, w2 - w1, w3 - w2};
+    // the first two rounds of positions and scales are requested before the set-up (their latency runs underneath it)
+    auto fetch_at = [&](float (&pp)[3], float (&ss)[3], uint32_t i) {
+        int64_t g = g0 + i;
+        g = g < n ? g : n - 1;
+        load3(pos, g, pp);
+        load3(scale, g, ss);
+    };
+    float pa[3], sa[3], pb[3], sb[3];
+    fetch_at(pa, sa, threadIdx.x);
+    fetch_at(pb, sb, threadIdx.x + STRIP_THREADS);
     for (uint32_t t = threadIdx.x; t < SG.NS; t += STRIP_THREADS) s_hist[t] = 0;
     // (eight loads of the cut table in flight per thread: one at a time, each waited for, was 8 x the latency of a load)
     for (uint32_t t0 = threadIdx.x; t0 < st0 * SG.nty; t0 += 8 * STRIP_THREADS) {
@@ -738,12 +751,7 @@ __global__ void __launch_bounds__(STRIP_THREADS) frame_project_cull_count_kernel
         // s_waitcnt vmcnt(0) in every round, 30 us for the bare stream) -- and loads whose control flow is uniform (a lane
         // beyond the chunk loads the array's last Gaussian and drops it), so that the waitcnt pass counts them exactly.
         auto in_chunk = [&](uint32_t i) { return i < cn && g0 + c0 + i < n; };
-        auto fetch = [&](float (&pp)[3], float (&ss)[3], uint32_t i) {
-            int64_t g = g0 + c0 + i;
-            g = g < n ? g : n - 1;
-            load3(pos, g, pp);
-            load3(scale, g, ss);
-        };
+        auto fetch = [&](float (&pp)[3], float (&ss)[3], uint32_t i) { fetch_at(pp, ss, c0 + i); };
         auto test = [&](const float (&pp)[3], const float (&ss)[3], uint32_t i) {
             bool surv = false;
             if (in_chunk(i)) {
@@ -774,12 +782,24 @@ __global__ void __launch_bounds__(STRIP_THREADS) frame_project_cull_count_kernel
                 uint32_t wbase = 0;
                 if (lane == 0) wbase = atomicAdd(&s_qn, (uint32_t)__popcll(b));
                 wbase = __shfl(wbase, 0, 64);
-                if (surv) s_q[wbase + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)i;
+                if (surv) {
+                    const uint32_t slot = wbase + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+                    s_q[slot] = (uint16_t)i;
+                    if (slot < stash_cap) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            s_stash[c * stash_cap + slot] = pp[c];
+                            s_stash[(3 + c) * stash_cap + slot] = ss[c];
+                        }
+                    }
+                }
             }
         };
-        float pa[3], sa[3], pb[3], sb[3], pq[3], sq[3];
-        fetch(pa, sa, threadIdx.x);
-        fetch(pb, sb, threadIdx.x + STRIP_THREADS);
+        float pq[3], sq[3];
+        if (c0 != 0) {  // (the first chunk's were requested in front of the set-up)
+            fetch(pa, sa, threadIdx.x);
+            fetch(pb, sb, threadIdx.x + STRIP_THREADS);
+        }
         for (uint32_t base = 0; base < cn; base += 3 * STRIP_THREADS) {  // uniform trip count, uniform exits
             const uint32_t i = base + threadIdx.x;
             fetch(pq, sq, i + 2 * STRIP_THREADS);
@@ -796,16 +816,36 @@ __global__ void __launch_bounds__(STRIP_THREADS) frame_project_cull_count_kernel
         const uint32_t nq = (diag & 2) ? 0u : s_qn;
         RawGaussian cur = {}, nxt = {};
         uint32_t qi = 0, qn_ = 0;
+        auto load_survivor = [&](uint32_t k, uint32_t q) {
+            RawGaussian r;
+            const int64_t pid = g0 + c0 + q;
+            if (k < stash_cap) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    r.p[c] = s_stash[c * stash_cap + k];
+                    r.sraw[c] = s_stash[(3 + c) * stash_cap + k];
+                }
+            } else {
+                load3(pos, pid, r.p);
+                load3(scale, pid, r.sraw);
+            }
+            const float4 q4 = quat[pid];
+            r.qraw[0] = q4.x; r.qraw[1] = q4.y; r.qraw[2] = q4.z; r.qraw[3] = q4.w;
+            r.opa = opa[pid];
+            r.rgb[0] = r.rgb[1] = r.rgb[2] = 0.f;
+            if (P.color_dim == 3) load3(rgb, pid, r.rgb);
+            return r;
+        };
         if (threadIdx.x < nq) {
             qi = (diag & 32) ? threadIdx.x : s_q[threadIdx.x];
-            cur = load_raw(pos, quat, scale, opa, rgb, g0 + c0 + qi, P.color_dim);
+            cur = load_survivor(threadIdx.x, qi);
         }
         settle(cur);
         for (uint32_t base = 0; base < nq; base += STRIP_THREADS) {  // uniform trip count
             const uint32_t k = base + threadIdx.x;
             if (k + STRIP_THREADS < nq) {
                 qn_ = (diag & 32) ? k + STRIP_THREADS : s_q[k + STRIP_THREADS];
-                nxt = load_raw(pos, quat, scale, opa, rgb, g0 + c0 + qn_, P.color_dim);
+                nxt = load_survivor(k + STRIP_THREADS, qn_);
             }
             uint4 rc = make_uint4(0, 0, 0, 0);
             uint32_t vis = 0;
@@ -1871,11 +1911,16 @@ int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t strea
             GS_CHECK_ARG(slice_begin == 0 && nsl == plan.slices, "an occlusion-culled frame is projected in one piece");
             const uint32_t qcap = plan.per_slice < GS_OCC_QCAP ? plan.per_slice : GS_OCC_QCAP;
             static const uint32_t diag = getenv("GS_OCC_DIAG") ? (uint32_t)atoi(getenv("GS_OCC_DIAG")) : 0u;  // timing-only builds of the kernel's phases
-            const size_t lds = sizeof(unsigned long long) * SG.NS + gs_cull_pyramid_bytes(G.ntx, G.nty) + 2 * (size_t)qcap + 16;
+            size_t lds = sizeof(unsigned long long) * SG.NS + gs_cull_pyramid_bytes(G.ntx, G.nty) + 2 * (size_t)qcap + 16;
+            // what is left of the kernel's LDS room holds positions and scales of the chunk's first survivors (24 B each)
+            const size_t room = (size_t)GS_BIN_LDS_BYTES - 8 * 4096;
+            uint32_t stash_cap = room > lds ? (uint32_t)((room - lds) / 24) & ~63u : 0u;
+            if (stash_cap > qcap) stash_cap = (qcap + 63u) & ~63u;
+            lds += (size_t)stash_cap * 24;
             hipLaunchKernelGGL(frame_project_cull_count_kernel, dim3(nsl + 1), dim3(STRIP_THREADS), lds, stream, f->pos,
                                (const float4 *)f->quat, f->scale, f->opa, f->rgb, f->N, P, ws.rec_geom, ws.rects,
                                plan.per_slice, SG, nsl, table, ws.slice_pairs, ws.slice_vis, ws.tile_cost,
-                               (uint32_t)G.n_tiles, ws.tile_order, ws.cut, qcap, ws.surv, ws.slice_nsurv, diag);
+                               (uint32_t)G.n_tiles, ws.tile_order, ws.cut, qcap, stash_cap, ws.surv, ws.slice_nsurv, diag);
             GS_CHECK_LAUNCH();
             return 0;
         }
