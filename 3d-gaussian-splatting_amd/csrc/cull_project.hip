@@ -1920,7 +1920,8 @@ int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t strea
             hipLaunchKernelGGL(frame_project_cull_count_kernel, dim3(nsl + 1), dim3(STRIP_THREADS), lds, stream, f->pos,
                                (const float4 *)f->quat, f->scale, f->opa, f->rgb, f->N, P, ws.rec_geom, ws.rects,
                                plan.per_slice, SG, nsl, table, ws.slice_pairs, ws.slice_vis, ws.tile_cost,
-                               (uint32_t)G.n_tiles, ws.tile_order, ws.cut, qcap, stash_cap, ws.surv, ws.slice_nsurv, diag);
+                               (uint32_t)G.n_tiles, ws.tile_order, gs_frame_cut_table(f, ws), qcap, stash_cap, ws.surv,
+                               ws.slice_nsurv, diag);
             GS_CHECK_LAUNCH();
             return 0;
         }

@@ -65,7 +65,7 @@ static int validate(const gs_frame *f) {
     }
     GS_CHECK_ARG((f->flags & ~(GS_FRAME_EMIT_SORTED_KEYS | GS_FRAME_SLICE_SORT | GS_FRAME_TABLE_BIN |
                                GS_FRAME_SERIAL_LONG_LISTS | GS_FRAME_LONG_LISTS | GS_FRAME_STRIP_BIN |
-                               GS_FRAME_BWD_ROWS | GS_FRAME_LONG_SORT | GS_FRAME_OCCLUSION_CULL)) == 0,
+                               GS_FRAME_BWD_ROWS | GS_FRAME_LONG_SORT | GS_FRAME_OCCLUSION_CULL | GS_FRAME_CULL_DILATE)) == 0,
                  "unknown flag bits");
     GS_CHECK_ARG(f->sort_mode >= 0 && f->sort_mode <= 2,
                  "sort_mode must be 0 (full LSD radix), 1 (tile-bit radix + per-tile LDS sort) or 2 (LDS counting sort "
@@ -260,6 +260,7 @@ static int frame_forward_impl(const gs_frame *f, hipStream_t s, float *stage_ms,
         // sort_mode 2 writes every counter and every tile range itself (tile_bin.hip, workgroup 0)
         if ((effective_sort_mode(f) != 2 || f->N == 0) && slice_begin == 0)
             GS_HIP(hipMemsetAsync(ws.counters, 0, ws.zero_bytes, s));
+        if (gs_frame_occlusion_cull(f) && (f->flags & GS_FRAME_CULL_DILATE) && (rc = gs_stage_cut_dilate(f, ws, s))) return rc;
         if (f->N > 0 && (rc = gs_stage_project(f, ws, s, slice_begin, slice_end))) return rc;
         if (!(phases & 2)) return 0;
     } else {

@@ -109,6 +109,12 @@ static inline size_t gs_cull_pyramid_bytes(int ntx, int nty) {
 }
 #define GS_NO_CUT 0xffffffffu
 #define GS_CUT_MARGIN 0.0625f
+// GS_FRAME_CULL_DILATE (a camera that moved a little since the table was recorded): a tile's cut is the deepest cut of its
+// 3 x 3 neighbourhood x 1.375.  A tile's stop depth is set by its deepest-seeing pixel (a ray through a gap between opaque
+// Gaussians) and jumps when content shifts by a pixel; measured on the 2.4 M scene, 119-frame pans (profiles/r06_x_*):
+// neighbourhood alone: 45 frames of a 1.25-px/frame pan fall back; x 1.25: 1; x 1.375: 0 (5 px/frame: 3, 12 px/frame: 4),
+// with 3.1 M instead of 1.8 M of 6.95 M pairs emitted.
+#define GS_CUT_DILATE_SCALE 1.375f
 static inline bool gs_frame_occlusion_cull(const gs_frame *f);
 
 // the sort half alone (GS_FRAME_LONG_SORT, round 6): lists beyond the LDS window go to big_list_sort_kernel; the segmented
@@ -288,6 +294,7 @@ struct gs_frame_ws {
     size_t sort_tmp_bytes;
     int32_t *tile_ranges;          // [T][2]
     uint32_t *cut;                 // [T] occlusion cut of every tile (GS_FRAME_OCCLUSION_CULL, below): depth bits behind which the
+    uint32_t *cut_dilated;         // [T] GS_FRAME_CULL_DILATE: the largest cut of every tile's 3 x 3 neighbourhood (written per frame)
                                    // LAST forward of this workspace composited nothing in the tile, GS_NO_CUT if its pixels
                                    // had not all stopped; written by every INFERENCE frame-path compositing launch
     // sort_mode 2 (tile_bin.hip)
@@ -357,6 +364,7 @@ static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pair
     ws.zero_bytes = off;
     // (in front of everything whose size depends on N: the table outlives a change of the Gaussian count)
     ws.cut = (uint32_t *)take(sizeof(uint32_t) * G.n_tiles);
+    ws.cut_dilated = (uint32_t *)take(sizeof(uint32_t) * G.n_tiles);
     ws.rec_geom = (float4 *)take(sizeof(float4) * GS_REC_STRIDE * N);
     ws.rec_cov = ws.rec_geom ? ws.rec_geom + 1 : nullptr;
     ws.rec_color = ws.rec_geom ? ws.rec_geom + 2 : nullptr;
@@ -444,6 +452,11 @@ static inline gs_frame_ws gs_frame_carve(void *base, int64_t N, int64_t max_pair
 }
 
 // stage entry points (defined across the .hip files)
+// the cut table a culled frame trims its lists by: the tiles' own cuts, or (GS_FRAME_CULL_DILATE) their neighbourhood maxima
+static inline const uint32_t *gs_frame_cut_table(const gs_frame *f, const gs_frame_ws &ws) {
+    return (f->flags & GS_FRAME_CULL_DILATE) ? ws.cut_dilated : ws.cut;
+}
+int gs_stage_cut_dilate(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream);
 int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream, int slice_begin = 0, int slice_end = -1,
                      bool second_pass = false);
 int gs_stage_project_backward(const gs_frame *f, const gs_frame_ws &ws, float *grad_pos, float *grad_quat,

@@ -979,7 +979,7 @@ int gs_stage_raster_forward(const gs_frame *f, const gs_frame_ws &ws, const uint
     // workspace (a training forward leaves it untouched: the caller must not allow the cull right behind one); a frame
     // whose lists were trimmed by it checks them, and its gated second pass composites the full lists
     const bool culled = gs_frame_occlusion_cull(f);
-    const uint32_t *cut_in = culled && !second_pass ? ws.cut : nullptr;
+    const uint32_t *cut_in = culled && !second_pass ? gs_frame_cut_table(f, ws) : nullptr;
     unsigned long long *ranpast = ws.counters + GS_CNT_RANPAST;
     const unsigned long long *gate = second_pass ? ranpast : nullptr;
 #define GS_LAUNCH_FRAME_FWD(CD)                                                                                        \

@@ -384,7 +384,37 @@ __global__ void __launch_bounds__(STRIP_THREADS) strip_scatter_kernel(
     }
 }
 
+__global__ void __launch_bounds__(256) cut_dilate_kernel(const uint32_t *__restrict__ cut, uint32_t *__restrict__ out,
+                                                         uint32_t ntx, uint32_t nty, float scale, uint32_t radius) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= ntx * nty) return;
+    const uint32_t y = t / ntx, x = t - y * ntx;
+    const uint32_t x0 = x > radius ? x - radius : 0, x1 = x + radius < ntx ? x + radius : ntx - 1;
+    const uint32_t y0 = y > radius ? y - radius : 0, y1 = y + radius < nty ? y + radius : nty - 1;
+    uint32_t m = 0;
+    for (uint32_t j = y0; j <= y1; ++j)
+        for (uint32_t i = x0; i <= x1; ++i) {
+            const uint32_t c = cut[j * ntx + i];
+            m = c > m ? c : m;
+        }
+    // (depth bits of positive floats order like the floats; GS_NO_CUT stays GS_NO_CUT)
+    out[t] = m == GS_NO_CUT ? m : __float_as_uint(__uint_as_float(m) * scale);
+}
+
 }  // namespace
+
+// GS_FRAME_CULL_DILATE: out[tile] = the largest cut of the tile's 3 x 3 neighbourhood (GS_NO_CUT is the largest value there
+// is), pushed back by GS_CUT_DILATE_SCALE in depth
+int gs_stage_cut_dilate(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stream) {
+    gs_frame_geom G = gs_frame_geometry(f);
+    // (the environment variables: A/B sweeps, tools/batches/gpu_r6w.sh / gpu_r6x.sh -> profiles/r06_x_cull_moving_camera.txt)
+    static const float scale = getenv("GS_CULL_DILATE_SCALE") ? (float)atof(getenv("GS_CULL_DILATE_SCALE")) : GS_CUT_DILATE_SCALE;
+    static const uint32_t radius = getenv("GS_CULL_DILATE_RADIUS") ? (uint32_t)atoi(getenv("GS_CULL_DILATE_RADIUS")) : 1u;
+    hipLaunchKernelGGL(cut_dilate_kernel, dim3((unsigned)gs_div_up(G.n_tiles, 256)), dim3(256), 0, stream,
+                       (const uint32_t *)ws.cut, ws.cut_dilated, (uint32_t)G.ntx, (uint32_t)G.nty, scale, radius);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
 
 // LDS of the count kernel: 8 B per strip; of the scatter kernel: 8 B per strip + the staging buffer
 // `second_pass`: the untrimmed re-run of a GS_FRAME_OCCLUSION_CULL frame, every kernel gated on counters[GS_CNT_RANPAST]
@@ -409,7 +439,7 @@ int gs_stage_strip_bin(const gs_frame *f, const gs_frame_ws &ws, hipStream_t str
     unsigned long long *table = (unsigned long long *)ws.strip_table, *scan = table + (size_t)GS_BIN_SLICES * SG.NS;
     const size_t lds_count = sizeof(unsigned long long) * SG.NS;
     const unsigned long long *gate = second_pass ? ws.counters + GS_CNT_RANPAST : nullptr;
-    const uint32_t *cut = (!second_pass && gs_frame_occlusion_cull(f)) ? ws.cut : nullptr;
+    const uint32_t *cut = (!second_pass && gs_frame_occlusion_cull(f)) ? gs_frame_cut_table(f, ws) : nullptr;
     // a culled frame's scatter gives 4 staged entries per strip (32 B: the strip's eight cuts) to the cut table
     const uint32_t cap = cut ? plan.cap - 4 * SG.NS : plan.cap;
     const size_t lds_scatter = sizeof(unsigned long long) * ((size_t)SG.NS + cap) + (cut ? (size_t)32 * SG.NS : 0);

@@ -53,6 +53,7 @@ GS_FRAME_STRIP_BIN = 32
 GS_FRAME_BWD_ROWS = 64
 GS_FRAME_LONG_SORT = 128
 GS_FRAME_OCCLUSION_CULL = 256
+GS_FRAME_CULL_DILATE = 512
 
 
 def _sig(name, restype, *argtypes):

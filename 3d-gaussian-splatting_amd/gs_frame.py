@@ -259,6 +259,8 @@ class FrameRenderer:
                 self._cut_key == (base, grid.width, grid.height) and self._frame_serial >= self._cull_off_until and \
                 shift <= self.CULL_MAX_SHIFT_PX:
             f.flags |= _lib.GS_FRAME_OCCLUSION_CULL  # (the library ignores it where the cull does not apply)
+            if shift > 0.0:
+                f.flags |= _lib.GS_FRAME_CULL_DILATE  # a pose near the recorded one: every tile's cut from its 3 x 3 neighbourhood
         self._grid = grid
         return f
 
@@ -332,15 +334,18 @@ class FrameRenderer:
     LONG_LIST_COST = {3: (0.066, 105.0, 5.0), 27: (0.264, 413.0, 2.2), 48: (0.37, 580.0, 2.2)}  # ns, ns, ratio
 
     # The occlusion cull is exact for ANY camera -- a frame whose trimmed lists prove too short is rendered again from the
-    # full ones --, but that second pass costs 0.6 of a frame, and with 8,160 tiles SOME tile runs past its cut in nearly
+    # full ones --, but that second pass costs 0.6 of a frame, and with 8,160 tiles SOME tile runs past its OWN cut in nearly
     # every frame of a moving camera (a pixel at the rim of an opaque Gaussian's footprint sees through to something twice
-    # as deep).  So the cull is only allowed while the camera has stayed where the cut table was recorded: a
-    # viewer at rest, a benchmark or an evaluation that renders one view repeatedly, a trainer that re-renders a test view.
-    # The reference's own evaluation loop walks through DIFFERENT test cameras (train.py:240-266): those frames are not
-    # culled and pay nothing for the feature (no gated launches without the flag).
-    # (round 6, measured: at 1080p even a 0.25-pixel pan makes SOME tile of 8,160 run past its cut in nearly every frame
-    # -- 1,535 instead of 3,300 FPS with the cull on, profiles/r06_g_*: the default is the identical pose only)
-    CULL_MAX_SHIFT_PX = float(os.environ.get("GS_FRAME_CULL_MAX_SHIFT_PX", "0.0"))
+    # as deep: even a 0.25-pixel pan, 1,535 instead of 3,300 FPS, profiles/r06_g_*).  So:
+    #   identical pose (a viewer at rest, a benchmark or an evaluation that renders one view repeatedly): the tiles' own cuts;
+    #   a pose within CULL_MAX_SHIFT_PX of the recorded one (a viewer in motion): GS_FRAME_CULL_DILATE -- every tile's cut is
+    #     the deepest of its 3 x 3 neighbourhood x 1.375 in depth.  Measured (tools/cull_moving.py, profiles/r06_x_*): no
+    #     fallback over 119 frames of a 1.25-px/frame pan, 3 at 5 px/frame, 4 at 12 px/frame; 3,760 / 3,620 / 3,470 FPS
+    #     against 3,090 / 3,060 / 3,270 unculled;
+    #   beyond (a jump, another test camera: the reference's evaluation loop walks through DIFFERENT cameras, train.py:240-
+    #     266): no cull, and nothing paid for the feature (no gated launches without the flag).
+    # A frame that does fall back switches the cull off for a while through the probes below.
+    CULL_MAX_SHIFT_PX = float(os.environ.get("GS_FRAME_CULL_MAX_SHIFT_PX", "8.0"))
 
     def _camera_shift_px(self, camera) -> float:
         """Upper estimate of how far image content moved, in pixels, between the camera the cut table was recorded under

@@ -277,9 +277,9 @@ def main():
         lat = latency_fps(frame)
         st_run = r.stats()  # the steady-state frame: pairs EMITTED (after the occlusion cull), did it fall back
         st_run_culled = bool(r._frame.flags & 256)
-        # the same workload with a camera that MOVES every frame (a viewer's pan: 0.01 degree per frame, 1.4 px): the
-        # occlusion cull is not applied (its host-side rule: only while the camera has stayed within a pixel), the host
-        # rebuilds the frame descriptor every frame -- what `value` was measured like up to round 5, pose changes included
+        # the same workload with a camera that MOVES every frame (a viewer's pan: 0.01 degree per frame, a quarter pixel):
+        # the host rebuilds the frame descriptor every frame, the occlusion cull works from the cuts of every tile's 3 x 3
+        # neighbourhood (GS_FRAME_CULL_DILATE, the host-side rule for poses within 8 px of the recorded one)
         W_, H_ = CONFIGS[cfg][1], CONFIGS[cfg][2]
         pan = [make_camera(W_, H_, yaw_deg=5.0 * rank + 0.01 * i) for i in range(40)]
         mv = [0]
@@ -289,16 +289,16 @@ def main():
             r.forward(*params, pan[mv[0] % len(pan)] if (mv[0] // len(pan)) % 2 == 0 else pan[-1 - mv[0] % len(pan)])
 
         dt_mv, _ = time_frames(moving_frame, steps, warmup, repeats=15)
-        moving_culled = bool(r._frame.flags & 256)
+        moving_culled, moving_dilated = bool(r._frame.flags & 256), bool(r._frame.flags & 512)
         r.forward(*params, cam)
         res = {"fps": world * steps / dt, "ms": dt / steps * 1e3, "host_us": host_us, "stats": st, "latency": lat,
                "scene": scene, "cam": cam, "params": params, "renderer": r, "repeats": len(blocks),
                "occlusion_cull": {"active": st_run_culled, "pairs_emitted": st_run.pairs,
                                   "pairs_of_the_frame": st.pairs, "fell_back": st_run.cull_fallback},
                "moving_camera": {"fps": round(world * steps / dt_mv, 2), "ms_per_frame": round(dt_mv / steps * 1e3, 4),
-                                 "culled": moving_culled,
-                                 "what": "the camera yaws 0.01 degree (1.4 px) per frame: no occlusion cull, a new frame "
-                                         "descriptor per frame"},
+                                 "culled": moving_culled, "dilated_cuts": moving_dilated,
+                                 "what": "the camera yaws 0.01 degree (0.25 px) per frame: a new frame descriptor per frame; "
+                                         "occlusion cull from the cuts of every tile's 3 x 3 neighbourhood x 1.375 in depth"},
                "ms_min": min(blocks) / steps * 1e3, "ms_max": max(blocks) / steps * 1e3}
         if rank == 0:
             prof = [r.profile_forward(*params, cam) for _ in range(25)][5:]
