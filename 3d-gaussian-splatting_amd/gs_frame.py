@@ -756,8 +756,8 @@ class FrameRenderer:
         """[N,4] int32 view of the workspace: (y0 | y1 << 16, x0 | x1 << 16, depth bits, tiles touched) per Gaussian.
 
         An occlusion-culled inference frame writes the records of the Gaussians it PROJECTED only (frustum-culled and
-        occluded ones leave whatever an earlier frame wrote): ``culling_mask`` / ``debug_views`` refuse such a frame --
-        render with ``occlusion_cull=False`` where they are wanted."""
+        occluded ones leave whatever an earlier frame wrote): ``debug_views`` refuses such a frame (render with
+        ``occlusion_cull=False`` where it is wanted), ``culling_mask`` recomputes the frustum test."""
         f = self._frame
         if f is None:
             raise RuntimeError("no frame rendered yet")
@@ -765,7 +765,7 @@ class FrameRenderer:
         _lib.check(_lib.gs_frame_is_occlusion_culled(C.byref(f), C.byref(culled)), "gs_frame_is_occlusion_culled")
         if culled.value and not allow_culled:
             raise RuntimeError("the rectangle records of an occlusion-culled frame cover its projected Gaussians only: "
-                               "render with FrameRenderer(occlusion_cull=False) for culling_mask() / debug_views()")
+                               "render with FrameRenderer(occlusion_cull=False) for debug_views()")
         ptr = C.c_void_p()
         _lib.check(_lib.gs_frame_debug_rects(C.byref(f), C.byref(ptr)), "gs_frame_debug_rects")
         off = ptr.value - self._ws.data_ptr()
@@ -773,7 +773,27 @@ class FrameRenderer:
 
     def culling_mask(self) -> torch.Tensor:
         """[N] bool: the Gaussians of the last forward that passed the frustum test (the reference's
-        ``culling_mask``, renderer.py:123-132).  Computed from the workspace; no host synchronisation."""
+        ``culling_mask``, renderer.py:123-132).  Computed from the workspace; no host synchronisation.
+
+        An occlusion-culled inference frame wrote the records of its projected Gaussians only: for such a frame the
+        reference's own ``global_culling`` operator (the same frustum test) is run on the frame's positions and pose."""
+        f = self._frame
+        if f is None:
+            raise RuntimeError("no frame rendered yet")
+        culled = C.c_int32(0)
+        _lib.check(_lib.gs_frame_is_occlusion_culled(C.byref(f), C.byref(culled)), "gs_frame_is_occlusion_culled")
+        if culled.value:
+            import gaussian  # (the reference-API operators: gaussian/__init__.py)
+            pos, quat, scale = self._keep[:3]
+            n = pos.shape[0]
+            rot = torch.tensor(list(f.rot), dtype=torch.float32, device=self.device).reshape(3, 3)
+            tran = torch.tensor(list(f.tran), dtype=torch.float32, device=self.device)
+            mask = torch.zeros(n, dtype=torch.int64, device=self.device)
+            with torch.cuda.device(self.device):
+                gaussian.global_culling(pos, quat, scale, rot, tran, torch.empty_like(pos),
+                                        torch.empty((n, 2, 2), dtype=torch.float32, device=self.device), mask,
+                                        float(f.near_plane), float(f.half_width), float(f.half_height))
+            return mask != 0
         return self._rects()[:, 2] != 0  # depth bits: |p_c| > near > 0 for visible Gaussians, 0 for culled ones
 
     def composited_steps(self) -> int:

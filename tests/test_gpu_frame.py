@@ -302,6 +302,24 @@ def test_occlusion_cull_moving_camera_falls_back_and_stays_exact(gpu):
     assert r.stats().pairs < off.stats().pairs and not r.stats().cull_fallback
 
 
+def test_culling_mask_of_an_occlusion_culled_frame(gpu):
+    """A culled frame writes the records of its projected Gaussians only: ``culling_mask()`` of such a frame re-runs the
+    frustum test (the reference's global_culling operator) and equals the mask of the unculled frame; ``debug_views()``
+    refuses."""
+    scene, cam = _dense_case()
+    params = to_torch(scene, gpu)
+    off = FrameRenderer(gpu, max_pairs=1 << 21, auto_grow=False, occlusion_cull=False)
+    off.forward(*params, cam)
+    want = off.culling_mask()
+    r = FrameRenderer(gpu, max_pairs=1 << 21, auto_grow=False)
+    for k in range(3):
+        r.forward(*params, cam)
+        assert torch.equal(r.culling_mask(), want), k
+    assert r._frame.flags & 256 and r.stats().pairs < off.stats().pairs
+    with pytest.raises(RuntimeError):
+        r.debug_views()
+
+
 def test_occlusion_cull_switches_itself_off_where_it_does_not_pay(gpu):
     """A scene whose tiles do not saturate (nothing to cull): the renderer looks at the counters of its first unculled and
     first culled frame (asynchronous, tagged copies), finds that the cull dropped less than a third of the pairs, and
