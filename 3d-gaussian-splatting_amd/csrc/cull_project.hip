@@ -1909,13 +1909,24 @@ int gs_stage_project(const gs_frame *f, const gs_frame_ws &ws, hipStream_t strea
             // GS_FRAME_OCCLUSION_CULL, first pass: Gaussians behind every cut they can reach are not projected, the level-1
             // entries of the others are trimmed by the cut table the previous frame of this workspace left
             GS_CHECK_ARG(slice_begin == 0 && nsl == plan.slices, "an occlusion-culled frame is projected in one piece");
-            const uint32_t qcap = plan.per_slice < GS_OCC_QCAP ? plan.per_slice : GS_OCC_QCAP;
+            // (GS_OCC_QCAP / GS_OCC_STASH: smaller chunks / stash, read per frame -- the parity tests walk the several-chunks and
+            // beyond-the-stash paths at sizes a test can afford; a slice has more than 16,384 Gaussians only beyond 4.2 M)
+            uint32_t qcap_max = GS_OCC_QCAP;
+            if (const char *e = getenv("GS_OCC_QCAP")) {
+                const long v = atol(e);
+                if (v >= 64 && v <= (long)GS_OCC_QCAP) qcap_max = (uint32_t)v;
+            }
+            const uint32_t qcap = plan.per_slice < qcap_max ? plan.per_slice : qcap_max;
             static const uint32_t diag = getenv("GS_OCC_DIAG") ? (uint32_t)atoi(getenv("GS_OCC_DIAG")) : 0u;  // timing-only builds of the kernel's phases
             size_t lds = sizeof(unsigned long long) * SG.NS + gs_cull_pyramid_bytes(G.ntx, G.nty) + 2 * (size_t)qcap + 16;
             // what is left of the kernel's LDS room holds positions and scales of the chunk's first survivors (24 B each)
             const size_t room = (size_t)GS_BIN_LDS_BYTES - 8 * 4096;
             uint32_t stash_cap = room > lds ? (uint32_t)((room - lds) / 24) & ~63u : 0u;
             if (stash_cap > qcap) stash_cap = (qcap + 63u) & ~63u;
+            if (const char *e = getenv("GS_OCC_STASH")) {
+                const long v = atol(e);
+                if (v >= 0 && (uint32_t)v < stash_cap) stash_cap = (uint32_t)v & ~63u;
+            }
             lds += (size_t)stash_cap * 24;
             hipLaunchKernelGGL(frame_project_cull_count_kernel, dim3(nsl + 1), dim3(STRIP_THREADS), lds, stream, f->pos,
                                (const float4 *)f->quat, f->scale, f->opa, f->rgb, f->N, P, ws.rec_geom, ws.rects,

@@ -302,6 +302,71 @@ def test_occlusion_cull_moving_camera_falls_back_and_stays_exact(gpu):
     assert r.stats().pairs < off.stats().pairs and not r.stats().cull_fallback
 
 
+@pytest.mark.parametrize("qcap,stash,method", [(None, None, "prob2"), (2048, 256, "prob2"), (512, 0, "prob2"), (None, None, "prob")])
+def test_occlusion_cull_compacting_project_paths(gpu, monkeypatch, qcap, stash, method):
+    """The compacting project kernel of a culled frame at a size where a slice takes several rounds (1.2 M Gaussians: 4,864
+    per slice) -- and, with the chunk and stash capacities shrunk through the environment, several CHUNKS per slice (a slice
+    has more than 16,384 Gaussians only beyond 4.2 M) and survivors beyond the LDS stash (their positions gathered from
+    memory again).  Static pose (the tiles' own cuts), a creeping pose (dilated cuts), a jump with the policy lifted
+    (fallback): every image bit-identical to the unculled renderer's.  "prob" listing: no Gaussian-level test, lists
+    trimmed all the same."""
+    if qcap is not None:
+        monkeypatch.setenv("GS_OCC_QCAP", str(qcap))
+        monkeypatch.setenv("GS_OCC_STASH", str(stash))
+    W, H, n = 640, 384, 1_200_000
+    scene = make_scene(n, W, H, seed=5)
+    scene.opa += 3.0
+    params = to_torch(scene, gpu)
+    kw = dict(max_pairs=6_000_000, auto_grow=False, tile_culling_method=method)
+    r, off = FrameRenderer(gpu, **kw), FrameRenderer(gpu, occlusion_cull=False, **kw)
+    r.CULL_MAX_SHIFT_PX = float("inf")
+    yaws = [0.0, 0.0, 0.0, 0.01, 0.02, 0.03, 25.0, 25.0, 25.01]
+    culled = fell = dilated = 0
+    emitted = []
+    for k, yaw in enumerate(yaws):
+        cam = make_camera(W, H, yaw_deg=yaw)
+        r._cull_off_until = 0
+        img, _ = r.forward(*params, cam)
+        st = r.stats()
+        ref, _ = off.forward(*params, cam)
+        assert torch.equal(img, ref), (k, yaw, st)
+        full = off.stats().pairs
+        assert full <= 6_000_000 and st.overflow == 0
+        culled += int(bool(r._frame.flags & 256))
+        dilated += int(bool(r._frame.flags & 512))
+        fell += int(st.cull_fallback)
+        if (r._frame.flags & 256) and not st.cull_fallback:
+            emitted.append(st.pairs / full)
+    print("compacting project paths:", qcap, stash, method, "| culled", culled, "dilated", dilated, "fell back", fell,
+          "emitted share", [round(e, 3) for e in emitted])
+    assert culled == len(yaws) - 1 and dilated >= 4 and min(emitted) < 0.6, (culled, dilated, fell, emitted)
+
+
+@pytest.mark.parametrize("deg", [2, 3])
+def test_occlusion_cull_sh_frames_are_bit_exact(gpu, deg):
+    """SH colours (inference): the same front end, the SH compositing kernel writes the cut table.  Static and creeping pose,
+    bit-identical to the unculled renderer's images; against the oracle at degree 2."""
+    W, H = 192, 128
+    scene = make_scene(60_000, W, H, seed=3, use_sh=True, sh_degree=deg)
+    scene.opa += 3.0
+    params = to_torch(scene, gpu)
+    r = FrameRenderer(gpu, max_pairs=1 << 21, auto_grow=False)
+    off = FrameRenderer(gpu, max_pairs=1 << 21, auto_grow=False, occlusion_cull=False)
+    culled = 0
+    for k, yaw in enumerate([0.0, 0.0, 0.0, 0.01, 0.02]):
+        cam = make_camera(W, H, yaw_deg=yaw)
+        img, _ = r.forward(*params, cam)
+        st = r.stats()
+        ref, _ = off.forward(*params, cam)
+        assert torch.equal(img, ref), (k, st)
+        if r._frame.flags & 256:
+            culled += 1
+            assert st.pairs < 0.6 * off.stats().pairs and not st.cull_fallback
+        if deg == 2 and k == 2:
+            assert np.abs(img.cpu().numpy() - OracleFrame(scene, cam).image).max() < IMG_ATOL
+    assert culled >= 2
+
+
 def test_culling_mask_of_an_occlusion_culled_frame(gpu):
     """A culled frame writes the records of its projected Gaussians only: ``culling_mask()`` of such a frame re-runs the
     frustum test (the reference's global_culling operator) and equals the mask of the unculled frame; ``debug_views()``
