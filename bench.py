@@ -357,7 +357,10 @@ def main():
             res.update(roofline=roof, stages=stages, stage_total_ms=round(med["total"], 4),
                        frame_roofline={"algorithmic_bytes": int(b_fwd),
                                        "achieved_GBs": round(b_fwd / (res["ms"] * 1e-3) / 1e9, 1),
-                                       "frac_of_hbm_peak": round(b_fwd / (res["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+                                       "frac_of_hbm_peak": round(b_fwd / (res["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                       "note": "SURVEY.md 8d bytes of the WHOLE frame (all N Gaussians, all M pairs) over the "
+                                               "measured frame time: an occlusion-culled frame moves fewer (pairs_emitted of M; "
+                                               "only the projected Gaussians' records) -- an equivalent rate, not traffic"})
         return res
 
     def workload_name(cfg, st):
