@@ -65,7 +65,7 @@ static int validate(const gs_frame *f) {
     }
     GS_CHECK_ARG((f->flags & ~(GS_FRAME_EMIT_SORTED_KEYS | GS_FRAME_SLICE_SORT | GS_FRAME_TABLE_BIN |
                                GS_FRAME_SERIAL_LONG_LISTS | GS_FRAME_LONG_LISTS | GS_FRAME_STRIP_BIN |
-                               GS_FRAME_BWD_ROWS | GS_FRAME_LONG_SORT | GS_FRAME_OCCLUSION_CULL | GS_FRAME_CULL_DILATE)) == 0,
+                               GS_FRAME_BWD_ROWS | GS_FRAME_LONG_SORT | GS_FRAME_OCCLUSION_CULL | GS_FRAME_CULL_DILATE | GS_FRAME_CULL_DILATE_NEAR)) == 0,
                  "unknown flag bits");
     GS_CHECK_ARG(f->sort_mode >= 0 && f->sort_mode <= 2,
                  "sort_mode must be 0 (full LSD radix), 1 (tile-bit radix + per-tile LDS sort) or 2 (LDS counting sort "

@@ -115,6 +115,8 @@ static inline size_t gs_cull_pyramid_bytes(int ntx, int nty) {
 // neighbourhood alone: 45 frames of a 1.25-px/frame pan fall back; x 1.25: 1; x 1.375: 0 (5 px/frame: 3, 12 px/frame: 4),
 // with 3.1 M instead of 1.8 M of 6.95 M pairs emitted.
 #define GS_CUT_DILATE_SCALE 1.375f
+// GS_FRAME_CULL_DILATE_NEAR (within half a pixel): x 1.125 -- no fallback over a 0.25-px/frame pan, 2 in 119 frames at 1.25 px
+#define GS_CUT_DILATE_SCALE_NEAR 1.125f
 static inline bool gs_frame_occlusion_cull(const gs_frame *f);
 
 // the sort half alone (GS_FRAME_LONG_SORT, round 6): lists beyond the LDS window go to big_list_sort_kernel; the segmented

@@ -409,9 +409,11 @@ int gs_stage_cut_dilate(const gs_frame *f, const gs_frame_ws &ws, hipStream_t st
     gs_frame_geom G = gs_frame_geometry(f);
     // (the environment variables: A/B sweeps, tools/batches/gpu_r6w.sh / gpu_r6x.sh -> profiles/r06_x_cull_moving_camera.txt)
     static const float scale = getenv("GS_CULL_DILATE_SCALE") ? (float)atof(getenv("GS_CULL_DILATE_SCALE")) : GS_CUT_DILATE_SCALE;
+    static const float scale_near = getenv("GS_CULL_DILATE_SCALE") ? scale : GS_CUT_DILATE_SCALE_NEAR;
     static const uint32_t radius = getenv("GS_CULL_DILATE_RADIUS") ? (uint32_t)atoi(getenv("GS_CULL_DILATE_RADIUS")) : 1u;
     hipLaunchKernelGGL(cut_dilate_kernel, dim3((unsigned)gs_div_up(G.n_tiles, 256)), dim3(256), 0, stream,
-                       (const uint32_t *)ws.cut, ws.cut_dilated, (uint32_t)G.ntx, (uint32_t)G.nty, scale, radius);
+                       (const uint32_t *)ws.cut, ws.cut_dilated, (uint32_t)G.ntx, (uint32_t)G.nty,
+                       (f->flags & GS_FRAME_CULL_DILATE_NEAR) ? scale_near : scale, radius);
     GS_CHECK_LAUNCH();
     return 0;
 }

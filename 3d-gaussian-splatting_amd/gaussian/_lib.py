@@ -54,6 +54,7 @@ GS_FRAME_BWD_ROWS = 64
 GS_FRAME_LONG_SORT = 128
 GS_FRAME_OCCLUSION_CULL = 256
 GS_FRAME_CULL_DILATE = 512
+GS_FRAME_CULL_DILATE_NEAR = 1024
 
 
 def _sig(name, restype, *argtypes):
