@@ -311,7 +311,8 @@ static int frame_forward_impl(const gs_frame *f, hipStream_t s, float *stage_ms,
     tm.mark();  // stage "ranges" = tile ranges (+ the per-tile depth sort in mode 1)
     if ((rc = gs_stage_raster_forward(f, ws, sids, s))) return rc;
     tm.mark();
-    if (mode == 2 && gs_frame_occlusion_cull(f)) {
+    static const bool no_second_pass = getenv("GS_CULL_NO_SECOND_PASS") != nullptr;  // TIMING ONLY: a frame that ran past a cut stays wrong
+    if (mode == 2 && gs_frame_occlusion_cull(f) && !no_second_pass) {
         // The lists of this frame were trimmed by the occlusion cuts of the previous one (gs_frame_layout.h).  If a tile ran
         // past its cut, counters[GS_CNT_RANPAST] is set and the launches below render the frame again from the full
         // lists; otherwise each of them returns at its first instruction (five gated launches: project + count -- the
