@@ -145,6 +145,9 @@ __global__ void __launch_bounds__(1024) scan_block_sums_kernel(const uint32_t *_
         counters[GS_CNT_PAIRS] = total < max_pairs ? total : max_pairs;
         counters[GS_CNT_OVERFLOW] = total > max_pairs ? total : 0ull;
         counters[GS_CNT_VISIBLE] = s_vis;
+        // (the compositing kernel's walk statistics and the strip variant's counters: never stale for a reader)
+        counters[GS_CNT_EXCESS] = counters[GS_CNT_MAXWALK] = counters[GS_CNT_EXCESS_WALK] = 0;
+        counters[GS_CNT_RANPAST] = counters[GS_CNT_BIG] = counters[GS_CNT_GROUPS] = counters[GS_CNT_MAXLIST] = 0;
     }
 }
 

@@ -261,6 +261,8 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_scatter_kernel(
                 counters[GS_CNT_VISIBLE] = V;
                 // only the strip variant's kernels maintain these; whoever reads them back must not see stale values
                 counters[GS_CNT_BIG] = counters[GS_CNT_GROUPS] = counters[GS_CNT_MAXLIST] = 0;
+                counters[GS_CNT_EXCESS] = counters[GS_CNT_MAXWALK] = counters[GS_CNT_EXCESS_WALK] = 0;
+                counters[GS_CNT_RANPAST] = 0;
             }
         }
         return;
@@ -299,6 +301,10 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_scatter_kernel(
         counters[GS_CNT_OVERFLOW] = 0;
         counters[GS_CNT_VISIBLE] = V;
         counters[GS_CNT_BIG] = counters[GS_CNT_GROUPS] = 0;  // strip variant only
+        // raster_forward_kernel's walk statistics (atomicMax / atomicAdd onto these): a workspace fresh from the allocator holds
+        // whatever was there -- round 6 found the long-list flag of a small scene depending on which tests had run before it
+        counters[GS_CNT_EXCESS] = counters[GS_CNT_MAXWALK] = counters[GS_CNT_EXCESS_WALK] = 0;
+        counters[GS_CNT_RANPAST] = 0;
     }
     __syncthreads();
     if (slice == 0 && threadIdx.x == 0) counters[GS_CNT_MAXLIST] = s_longest;

@@ -428,7 +428,8 @@ def test_small_scene_with_a_pile_switches_to_the_long_list_kernels(gpu):
     r = FrameRenderer(gpu, max_pairs=len(of.ids) + 64, auto_grow=True, force_strips=False)  # the library's own choice
     first, _ = r.forward(*params, cam)
     assert r.binning_variant() == "table" and not (r._frame.flags & 16)
-    assert r.stats().longest_list == longest and r._long_lists_seen
+    st = r.stats()
+    assert st.longest_list == longest and r._long_lists_seen, (st, r._stats_host.tolist(), int(r._frame.flags))
     second, _ = r.forward(*params, cam)
     assert r._frame.flags & 16 and r.binning_variant() == "strip"  # GS_FRAME_LONG_LISTS => strips + long-list kernels
     assert float((second - first).abs().max()) < 1e-5
@@ -437,6 +438,30 @@ def test_small_scene_with_a_pile_switches_to_the_long_list_kernels(gpu):
     r2 = FrameRenderer(gpu, max_pairs=len(of.ids) + 64, auto_grow=False, force_strips=False, long_lists=True)
     third, _ = r2.forward(*params, cam)
     assert r2.binning_variant() == "strip" and torch.equal(third, second)
+
+
+@pytest.mark.parametrize("kw", [dict(force_strips=False), dict(force_strips=True), dict(sort_mode=0), dict(sort_mode=1)],
+                         ids=["table", "strip", "radix64", "radix_tile_bits"])
+def test_counters_do_not_depend_on_what_the_workspace_held_before(gpu, kw):
+    """Round 6: the compositing kernel adds its walk statistics onto counters that only the strip variant reset -- in the
+    table variant a workspace fresh from the allocator kept whatever was there (a value with the top bit set reads as a
+    negative walk: a small scene with a pile-up never got its long-list flag; a positive one flags a harmless scene).  Here
+    the workspace is handed over filled with 0xFF: every counter the host acts upon is the frame's own."""
+    scene, cam = case(10_000, 256, 256, seed=37)
+    params = to_torch(scene, gpu)
+    ref = FrameRenderer(gpu, max_pairs=1 << 20, auto_grow=False, **kw)
+    ref.forward(*params, cam)
+    want = ref.stats()
+    r = FrameRenderer(gpu, max_pairs=1 << 20, auto_grow=False, **kw)
+    r._ws = torch.full((ref._ws.numel() + (1 << 20),), 0xFF, dtype=torch.uint8, device=gpu)
+    img, _ = r.forward(*params, cam)
+    st = r.stats()
+    h = r._stats_host.tolist()
+    assert (st.visible, st.pairs, st.overflow, st.longest_list) == (want.visible, want.pairs, 0, want.longest_list)
+    # [9] longest list, [10] ran past a cut, [12] pairs beyond 512 per tile, [13] longest walk, [14] steps beyond 512
+    assert h[9] == want.longest_list and h[10] == 0 and h[12] == 0 and h[13] == 0 and h[14] == 0, h
+    assert not r._long_lists_seen and not r._long_sort_seen and not st.cull_fallback
+    assert torch.equal(img, ref.forward(*params, cam)[0])
 
 
 @pytest.mark.parametrize("use_sh", [False, True])
