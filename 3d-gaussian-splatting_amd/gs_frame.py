@@ -732,7 +732,9 @@ class FrameRenderer:
         # stream).  A stats() call between forward and backward may read 0, the previous frame's count or this one's:
         # it reports what it read, but the backward-kernel choice -- and with it the gradients' last bits -- moves only
         # on a count that is known to be this frame's.
-        bwd_done = getattr(self, "_bwd_serial", -1) == self._frame_serial
+        # (rgb frames only: the SH backward builds its own work list and leaves this counter alone -- whatever the
+        # workspace memory held)
+        bwd_done = getattr(self, "_bwd_serial", -1) == self._frame_serial and int(self._frame.color_dim) == 3
         if bwd_done:
             self._note_buckets(b)
         culled = bool(self._frame.flags & _lib.GS_FRAME_OCCLUSION_CULL)

@@ -465,6 +465,34 @@ def test_counters_do_not_depend_on_what_the_workspace_held_before(gpu, kw):
 
 
 @pytest.mark.parametrize("use_sh", [False, True])
+@pytest.mark.parametrize("strips", [False, True], ids=["table", "strip"])
+def test_training_frame_does_not_depend_on_what_the_workspace_held_before(gpu, strips, use_sh):
+    """The backward reads only what the forward and its own kernels wrote (gradient rows are never zero-filled: unwritten
+    ones must never be read; checkpoints, work lists, stop keys likewise): a forward + backward in a workspace handed over
+    filled with 0xFF gives the image and all five gradients of a clean renderer, bit for bit."""
+    W, H = 192, 128
+    scene = make_scene(20_000, W, H, seed=21, use_sh=use_sh)
+    cam = make_camera(W, H, yaw_deg=2.0)
+    params = to_torch(scene, gpu)
+    g = torch.Generator(device=gpu).manual_seed(4)
+    grad = torch.randn(H, W, 3, device=gpu, generator=g) / (H * W)
+    kw = dict(max_pairs=1 << 20, auto_grow=False, training=True, force_strips=strips)
+    ref = FrameRenderer(gpu, **kw)
+    img0, _ = ref.forward(*params, cam)
+    g0 = [t.clone() for t in ref.backward(grad)]
+    r = FrameRenderer(gpu, **kw)
+    r._ws = torch.full((ref._ws.numel() + (1 << 20),), 0xFF, dtype=torch.uint8, device=gpu)
+    img1, _ = r.forward(*params, cam)
+    g1 = r.backward(grad)
+    assert r.binning_variant() == ("strip" if strips else "table")
+    assert torch.equal(img0, img1)
+    for a, b, name in zip(g0, g1, ("pos", "quat", "scale", "opa", "rgb")):
+        assert torch.equal(a, b), name
+    st0, st1 = ref.stats(), r.stats()
+    assert (st0.visible, st0.pairs, st0.buckets, st0.saturated_buckets) == (st1.visible, st1.pairs, st1.buckets, st1.saturated_buckets)
+
+
+@pytest.mark.parametrize("use_sh", [False, True])
 def test_long_lists_composited_in_segments(gpu, use_sh):
     """Dense frame with low-opacity pile-ups: every tile's pixels are still alive after 4096 Gaussians, so the rest
     of each list (up to ~12,000 here; beyond the first GS_LONG_MIN = 512 since round 5) is composited in segments of
