@@ -745,7 +745,7 @@ __global__ void __launch_bounds__(STRIP_THREADS) frame_project_cull_count_kernel
         if (threadIdx.x == 0) s_qn = 0;
         __syncthreads();  // (also: the pyramid is complete; the previous chunk's queue has been drained)
         // ---- phase A: frustum + occlusion test of every Gaussian of the chunk; survivors are queued
-        // The phase is a 96 MB stream (24 B in, 16 B out per Gaussian) at one workgroup per CU: three rounds of positions
+        // The phase is a 58 MB stream (24 B in per Gaussian, nothing out) at one workgroup per CU: three rounds of positions
         // and scales are kept in flight.  That takes THREE NAMED register sets and a loop unrolled by three -- rotating one
         // set into the next at the end of a round (`cur = nxt`) makes the move wait for the newest load (first version:
         // s_waitcnt vmcnt(0) in every round, 30 us for the bare stream) -- and loads whose control flow is uniform (a lane
