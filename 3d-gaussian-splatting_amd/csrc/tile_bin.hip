@@ -212,10 +212,30 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_scatter_kernel(
     uint32_t T, uint32_t ntx, const uint32_t *__restrict__ table, const uint32_t *__restrict__ tile_count,
     const uint32_t *__restrict__ slice_pairs, const uint32_t *__restrict__ slice_vis, uint32_t B,
     uint64_t *__restrict__ out, uint64_t max_pairs, uint32_t *__restrict__ pair_offsets,
-    int32_t *__restrict__ tile_ranges, unsigned long long *__restrict__ counters, uint32_t n_bands) {
+    int32_t *__restrict__ tile_ranges, unsigned long long *__restrict__ counters, uint32_t n_bands, uint32_t fused) {
     extern __shared__ uint32_t s_slot[];
     __shared__ uint32_t s_wave[BIN_THREADS / 64];
     const uint32_t slice = slice_of_block(blockIdx.x, gridDim.x);
+    // `fused` (small scenes: B x T <= 65,536, round 6): `table` is the RAW count table and there was no column-scan launch --
+    // every workgroup adds up the B rows itself (tile totals and the prefix of the slices in front of its own: B coalesced
+    // loads per tile, 40 KB per workgroup at 10,000 Gaussians) into LDS behind s_slot.  A frame of 10,000 Gaussians is a
+    // chain of dependent launches of ~7 us each: one launch fewer.
+    uint32_t *s_tot = s_slot + T, *s_pre = s_tot + T;
+    if (fused) {
+        for (uint32_t t = threadIdx.x; t < T; t += BIN_THREADS) {
+            uint32_t pre = 0, tot = 0;
+#pragma unroll 8
+            for (uint32_t b = 0; b < B; ++b) {
+                const uint32_t v = table[(size_t)b * T + t];
+                pre += b < slice ? v : 0u;
+                tot += v;
+            }
+            s_tot[t] = tot;
+            s_pre[t] = pre;
+        }
+        __syncthreads();
+    }
+    auto count_of = [&](uint32_t t) { return fused ? s_tot[t] : tile_count[t]; };
     const int64_t g0 = (int64_t)slice * per_block;
     auto load_rect = [&](uint32_t base) {
         const uint32_t i = base + threadIdx.x;
@@ -238,7 +258,7 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_scatter_kernel(
     unsigned long long mine = 0;
     uint32_t longest = 0;  // the frame's longest tile list (slice 0 reports it: GS_CNT_MAXLIST)
     for (uint32_t t = t0; t < t1; ++t) {
-        const uint32_t c = tile_count[t];
+        const uint32_t c = count_of(t);
         mine += c;
         longest = c > longest ? c : longest;
     }
@@ -271,13 +291,13 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_scatter_kernel(
     uint32_t run = (uint32_t)run64;  // the frame fits: every prefix is below max_pairs < 2^30
     for (uint32_t t = t0; t < t1; ++t) {
         s_slot[t] = run;
-        run += tile_count[t];
+        run += count_of(t);
     }
     __syncthreads();
-    const uint32_t *row = table + (size_t)slice * T;
+    const uint32_t *row = fused ? s_pre : table + (size_t)slice * T;
     if (slice == 0)
         for (uint32_t t = threadIdx.x; t < T; t += BIN_THREADS) {
-            const uint32_t s = s_slot[t], c = tile_count[t];  // row 0 of the scanned table is all zeros
+            const uint32_t s = s_slot[t], c = count_of(t);  // row 0 of the scanned table is all zeros
             // every tile is written (empty ones as (0, 0)): this path needs no memset of the ranges
             reinterpret_cast<int2 *>(tile_ranges)[t] = c ? make_int2((int)s, (int)(s + c)) : make_int2(0, 0);
         }
@@ -609,7 +629,9 @@ int gs_stage_tile_bin(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stre
     }
     const uint32_t per_block = bin_per_block(f->N);
     const uint32_t B = (uint32_t)gs_div_up(f->N, per_block);
-    const size_t lds = sizeof(uint32_t) * T;
+    // small scenes: the scatter adds up the raw count table itself, no column-scan launch (bin_scatter_kernel)
+    const bool fused_scan = (uint64_t)B * T <= 65536 && T <= GS_BIN_MAX_TILES / 3;
+    const size_t lds = sizeof(uint32_t) * T, lds_scatter = fused_scan ? 3 * lds : lds;
     // scatter bands: the pairs of one band (8 B each, capacity as the estimate) should stay within ~2.5 MB per XCD
     uint32_t n_bands = (uint32_t)gs_div_up(f->max_pairs * 8, (int64_t)8 * 2560 * 1024);
 #ifdef BIN_BANDS
@@ -626,13 +648,16 @@ int gs_stage_tile_bin(const gs_frame *f, const gs_frame_ws &ws, hipStream_t stre
                                ws.slice_pairs, ws.slice_vis);                                                          \
             GS_CHECK_LAUNCH();                                                                                         \
         }                                                                                                              \
-        hipLaunchKernelGGL(bin_colscan_kernel, dim3((unsigned)gs_div_up(T, 64)), dim3(256), 0, stream, ws.bin_table,   \
-                           B, T, ws.tile_count);                                                                       \
-        GS_CHECK_LAUNCH();                                                                                             \
-        hipLaunchKernelGGL(bin_scatter_kernel<DIST>, dim3(B), dim3(BIN_THREADS), lds, stream, ws.rects, ws.rec_geom,   \
-                           D, f->N, per_block, T, (uint32_t)G.ntx, ws.bin_table, ws.tile_count, ws.slice_pairs,        \
-                           ws.slice_vis, B, ws.keys_a, (uint64_t)f->max_pairs,                                         \
-                           f->training ? ws.pair_offsets : nullptr, ws.tile_ranges, ws.counters, n_bands);             \
+        if (!fused_scan) {                                                                                             \
+            hipLaunchKernelGGL(bin_colscan_kernel, dim3((unsigned)gs_div_up(T, 64)), dim3(256), 0, stream,             \
+                               ws.bin_table, B, T, ws.tile_count);                                                     \
+            GS_CHECK_LAUNCH();                                                                                         \
+        }                                                                                                              \
+        hipLaunchKernelGGL(bin_scatter_kernel<DIST>, dim3(B), dim3(BIN_THREADS), lds_scatter, stream, ws.rects,        \
+                           ws.rec_geom, D, f->N, per_block, T, (uint32_t)G.ntx, ws.bin_table, ws.tile_count,           \
+                           ws.slice_pairs, ws.slice_vis, B, ws.keys_a, (uint64_t)f->max_pairs,                         \
+                           f->training ? ws.pair_offsets : nullptr, ws.tile_ranges, ws.counters, n_bands,              \
+                           fused_scan ? 1u : 0u);                                                                      \
         GS_CHECK_LAUNCH();                                                                                             \
     } while (0)
     if (dist)
