@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 6, call z: one-pass segmented compositing -- long-list parity tests, then the trained-state leg with the one-pass and the
+# NOTE: the experiment was dropped: GS_SEG_TWO_PASS no longer exists in the library; kept as the record of what was run
 # two-pass scheme (GS_SEG_TWO_PASS=1)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$R/gpurun_out/r6z; rm -rf "$OUT"; mkdir -p "$OUT"
