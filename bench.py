@@ -858,7 +858,20 @@ def main():
                               "frac": round(mfma_flops / (rb_ms * 1e-3) / 1e12 / 157.3, 4),
                               "what": "fp32 MFMA flops of the kernel / its time; MFMAs and VALU instructions of a SIMD "
                                       "do not overlap on gfx950, so this fraction and issue_busy share the same cycles"})}
-                del r4, p4, img4, g4
+                # inference render of the same SH scene, camera at rest: with the occlusion cull and without (same renderer)
+                del r4
+                ri, _ = sized_renderer(p4, cam4, training=False)
+                fi = lambda: ri.forward(*p4, cam4)  # noqa: E731
+                settle(fi, 0.3)
+                dt_c, _ = time_frames(fi, 20, 5, repeats=10)
+                culled4 = bool(ri._frame.flags & 256)
+                ri.occlusion_cull = False
+                settle(fi, 0.2)
+                dt_n, _ = time_frames(fi, 20, 5, repeats=10)
+                cfg4[f"sh_degree_{deg}"]["render"] = {"fps": round(20 / dt_c, 1), "occlusion_culled": culled4,
+                                                      "fps_without_the_cull": round(20 / dt_n, 1),
+                                                      "what": "inference frames of the SH scene, one in flight, camera at rest"}
+                del ri, p4, img4, g4
                 torch.cuda.empty_cache()
             extra["cfg4_2p4M_sh_fwd_bwd"] = cfg4
 
