@@ -460,3 +460,39 @@ def test_world8_slice_pipeline_and_statistic_gloo(tmp_path):
     want_sum = np.add.reduce([r[k]["mean_local"] for k in range(world)])
     for k in range(world):
         assert np.array_equal(r[k]["max_red"], want_max) and np.array_equal(r[k]["mean_red"], want_sum)
+
+
+def test_camera_shift_estimate_of_the_cull_policy():
+    """FrameRenderer._camera_shift_px (host arithmetic only): how far image content moved, in pixels, between the pose the
+    occlusion cuts were recorded under and the current one -- 0 for the identical pose, rotation angle x focal length for a
+    small yaw (the first version's arccos returned 0 below 0.03 degree), + translation at unit depth, infinite when the image
+    geometry differs.  The cull policy's thresholds (0.5 px: near factor; 8 px: no cull beyond) are in these units."""
+    import numpy as np
+
+    from gs_frame import FrameRenderer
+    from gs_scene import make_camera
+
+    def key(cam):
+        return (int(cam.width), int(cam.height), float(cam.focal_x), float(cam.focal_y), float(cam.near),
+                np.asarray(cam.rot, np.float32).tobytes(), np.asarray(cam.tran, np.float32).tobytes())
+
+    r = object.__new__(FrameRenderer)  # (no device: only the two keys the method reads)
+    base = make_camera(1920, 1080)
+    f = float(base.focal_x)
+    r._cut_ck = key(base)
+    r._cur_ck = key(make_camera(1920, 1080))
+    assert r._camera_shift_px(base) == 0.0
+    for deg in (0.001, 0.01, 0.05, 0.2, 2.0):
+        r._cur_ck = key(make_camera(1920, 1080, yaw_deg=deg))
+        want = f * np.deg2rad(deg)
+        got = r._camera_shift_px(base)
+        assert abs(got - want) <= 0.02 * want + 1e-3, (deg, got, want)
+    moved = make_camera(1920, 1080)
+    moved.tran = np.asarray(moved.tran, np.float32) + np.array([0.002, 0.0, 0.0], np.float32)
+    r._cur_ck = key(moved)
+    assert abs(r._camera_shift_px(base) - 0.002 * f) < 0.05
+    r._cur_ck = key(make_camera(1280, 720))
+    assert r._camera_shift_px(base) == float("inf")
+    r._cut_ck = None
+    assert r._camera_shift_px(base) == float("inf")
+    assert FrameRenderer.CULL_NEAR_SHIFT_PX < FrameRenderer.CULL_MAX_SHIFT_PX
