@@ -302,8 +302,10 @@ def test_occlusion_cull_moving_camera_falls_back_and_stays_exact(gpu):
     assert r.stats().pairs < off.stats().pairs and not r.stats().cull_fallback
 
 
-@pytest.mark.parametrize("qcap,stash,method", [(None, None, "prob2"), (2048, 256, "prob2"), (512, 0, "prob2"), (None, None, "prob")])
-def test_occlusion_cull_compacting_project_paths(gpu, monkeypatch, qcap, stash, method):
+@pytest.mark.parametrize("qcap,stash,method,act", [(None, None, "prob2", "abs"), (2048, 256, "prob2", "abs"),
+                                                   (512, 0, "prob2", "abs"), (None, None, "prob", "abs"),
+                                                   (None, None, "prob2", "exp")])
+def test_occlusion_cull_compacting_project_paths(gpu, monkeypatch, qcap, stash, method, act):
     """The compacting project kernel of a culled frame at a size where a slice takes several rounds (1.2 M Gaussians: 4,864
     per slice) -- and, with the chunk and stash capacities shrunk through the environment, several CHUNKS per slice (a slice
     has more than 16,384 Gaussians only beyond 4.2 M) and survivors beyond the LDS stash (their positions gathered from
@@ -316,8 +318,10 @@ def test_occlusion_cull_compacting_project_paths(gpu, monkeypatch, qcap, stash, 
     W, H, n = 640, 384, 1_200_000
     scene = make_scene(n, W, H, seed=5)
     scene.opa += 3.0
+    if act == "exp":  # (the occlusion test bounds the footprint by the largest ACTIVATED scale: exp through v_exp_f32)
+        scene.scale[:] = np.log(scene.scale)
     params = to_torch(scene, gpu)
-    kw = dict(max_pairs=6_000_000, auto_grow=False, tile_culling_method=method)
+    kw = dict(max_pairs=6_000_000, auto_grow=False, tile_culling_method=method, scale_activation=act)
     r, off = FrameRenderer(gpu, **kw), FrameRenderer(gpu, occlusion_cull=False, **kw)
     r.CULL_MAX_SHIFT_PX = float("inf")
     yaws = [0.0, 0.0, 0.0, 0.01, 0.02, 0.03, 25.0, 25.0, 25.01]
@@ -337,7 +341,7 @@ def test_occlusion_cull_compacting_project_paths(gpu, monkeypatch, qcap, stash, 
         fell += int(st.cull_fallback)
         if (r._frame.flags & 256) and not st.cull_fallback:
             emitted.append(st.pairs / full)
-    print("compacting project paths:", qcap, stash, method, "| culled", culled, "dilated", dilated, "fell back", fell,
+    print("compacting project paths:", qcap, stash, method, act, "| culled", culled, "dilated", dilated, "fell back", fell,
           "emitted share", [round(e, 3) for e in emitted])
     assert culled == len(yaws) - 1 and dilated >= 4 and min(emitted) < 0.6, (culled, dilated, fell, emitted)
 
