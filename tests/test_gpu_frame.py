@@ -371,6 +371,42 @@ def test_occlusion_cull_sh_frames_are_bit_exact(gpu, deg):
     assert culled >= 2
 
 
+def test_occlusion_cull_with_degenerate_gaussians(gpu):
+    """Gaussians nobody should train towards -- NaN / infinite positions, zero, huge, NaN and infinite scales, a zero quaternion,
+    infinite opacities -- mixed into the dense scene: the occlusion test leaves everything it cannot bound to the exact
+    arithmetic (a NaN scale slips through fmaxf, a huge one fails the 16-tile limit, a NaN position fails every comparison), so
+    the culled frames equal the unculled renderer's bit for bit, NaN pixels included."""
+    scene, cam = _dense_case()
+    rng = np.random.default_rng(9)
+    k = 40
+    idx = rng.choice(len(scene.pos), size=8 * k, replace=False).reshape(8, k)
+    scene.pos[idx[0]] = np.nan
+    scene.pos[idx[1], 2] = np.inf
+    scene.scale[idx[2]] = 0.0
+    scene.scale[idx[3]] = 1e30
+    scene.scale[idx[4], 1] = np.nan
+    scene.scale[idx[5], 0] = np.inf
+    scene.quat[idx[6]] = 0.0
+    scene.opa[idx[7][: k // 2]] = np.inf
+    scene.opa[idx[7][k // 2:]] = -np.inf
+    params = to_torch(scene, gpu)
+    r = FrameRenderer(gpu, max_pairs=1 << 22, auto_grow=False)
+    off = FrameRenderer(gpu, max_pairs=1 << 22, auto_grow=False, occlusion_cull=False)
+    r.CULL_MAX_SHIFT_PX = float("inf")
+    culled = 0
+    for yaw in (0.0, 0.0, 0.0, 0.02, 0.05, 3.0, 3.0):
+        c = make_camera(192, 128, yaw_deg=yaw)
+        r._cull_off_until = 0
+        img, _ = r.forward(*params, c)
+        st = r.stats()
+        ref, _ = off.forward(*params, c)
+        assert st.overflow == 0 and off.stats().overflow == 0
+        assert torch.equal(torch.isnan(img), torch.isnan(ref)), (yaw, st)
+        assert torch.equal(torch.nan_to_num(img), torch.nan_to_num(ref)), (yaw, st)
+        culled += int(bool(r._frame.flags & 256))
+    assert culled == 6
+
+
 def test_culling_mask_of_an_occlusion_culled_frame(gpu):
     """A culled frame writes the records of its projected Gaussians only: ``culling_mask()`` of such a frame re-runs the
     frustum test (the reference's global_culling operator) and equals the mask of the unculled frame; ``debug_views()``
