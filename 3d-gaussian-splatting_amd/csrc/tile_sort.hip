@@ -796,10 +796,10 @@ __global__ void __launch_bounds__(256, STRIP_SORT_WPE) strip_sort_kernel(
         s_n[q] = valid ? nq : 0;
         // statistic for the caller (gs_frame_longest_list_async): rare, so the atomic costs nothing
         if (valid && nq > (uint32_t)GS_LONGEST_MIN) atomicMax(longest, (unsigned long long)nq);
-        // ... and the pairs that lie beyond the first GS_LONG_MIN of their tile's list: what the segmented compositing
-        // of a GS_FRAME_LONG_LISTS frame would have to take over (the caller's cost model, gs_frame.py)
-        if (valid && nq > (uint32_t)GS_LONG_MIN)
-            atomicAdd(longest + (GS_CNT_EXCESS - GS_CNT_MAXLIST), (unsigned long long)(nq - (uint32_t)GS_LONG_MIN));
+        // (Round 6 also summed the pairs beyond the first GS_LONG_MIN of every list here, for a first version of the caller's
+        // cost model: one 64-bit atomic per tile beyond 512 pairs onto ONE address -- 6,000 of them on the 2.4 M scene, and
+        // this kernel went from 69.5 to 84 us.  The model reads the compositing kernel's walk statistics instead; counter
+        // GS_CNT_EXCESS stays 0.)
     }
     if (total4 == 0) return;  // uniform
 #ifdef GS_DIAG_STRIP_NO_PLACE  // timing experiments only (tools/ab_variants.py): wrong results

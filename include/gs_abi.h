@@ -356,8 +356,8 @@ int gs_frame_longest_list_async(const gs_frame *f, int64_t *longest_host, gs_str
  * block's tag word with `tag` (the client's frame number), then ONE device-to-host copy of GS_STATS_TAGGED_N = 15 values:
  *   [0] visible, [1] emitted pairs, [2] overflow (0, or the pairs the frame needed), [3] buckets (low 32 bits: in the
  *   backward's work list, high: of saturated tiles), [4..8] internal, [9] longest tile list (0 up to 1,024), [10] non-zero iff
- *   an occlusion-culled frame was rendered again from its full lists, [11] the tag (both 32-bit halves), [12] pairs that lie
- *   beyond the first 512 of their tile's list (strip variant), [13] the longest walk a tile's wave actually made in the compositing
+ *   an occlusion-culled frame was rendered again from its full lists, [11] the tag (both 32-bit halves), [12] 0 (retired in ABI 8: the pairs beyond
+ *   the first 512 of every list, summed with one atomic per long tile -- 14 us on the 2.4 M scene; see [14]), [13] the longest walk a tile's wave actually made in the compositing
  *   (0 up to 1,024; a tile whose pixels stop early walks less than its list), [14] the steps beyond the first 512 of every walk
  *   (what a GS_FRAME_LONG_LISTS frame would composite in segments; both from UNFLAGGED frames: a flagged frame's waves stop at 512).
  * stats_host[11] == tag (low half) <=> the copy has landed and the values are those of the frame issued just before this

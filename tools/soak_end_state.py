@@ -65,7 +65,8 @@ out["backward_stage_ms"] = {k: round(statistics.median(p[k] for p in pb), 4) for
 # the same end state with the long-list flags forced: none / the sort alone / sort + segmented compositing (round 6: what the
 # cost model of FrameRenderer._note_lists has to reproduce), forward and backward stage times, and the list statistics it sees
 h = r._stats_host.tolist()
-out["pairs_beyond_512_per_tile"] = int(h[12])
+out["pairs_beyond_512_per_tile"] = int(np.clip(lens - 512, 0, None).sum())  # (the device counter [12] is retired: from the ranges)
+out["steps_beyond_512_per_walk"] = int(h[14])
 keep = (r.long_lists, r._long_sort_seen, r._long_lists_seen)
 r.auto_grow = False  # (no asynchronous counters: nothing re-latches a flag underneath the forced modes)
 for mode, (ll, srt) in (("none", (False, False)), ("sort_only", (None, True)), ("sort_and_segments", (True, True))):
