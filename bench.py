@@ -293,13 +293,19 @@ def main():
         r.forward(*params, cam)
         # ... and the camera at rest WITHOUT the occlusion cull (the same renderer, the feature switched off): what `value`
         # measured up to round 5 -- reported next to it so that nobody has to take the cull's share on trust
-        fps_no_cull = None
+        fps_no_cull = stages_no_cull = None
         if st_run_culled:
             keep_cull = r.occlusion_cull
             r.occlusion_cull = False
             settle(frame, 0.2)
             dt_nc, _ = time_frames(frame, steps, warmup, repeats=15)
             fps_no_cull = round(world * steps / dt_nc, 2)
+            if rank == 0:  # ... with its stage times (hipEvents, as `stages`): what every unculled and every training frame pays
+                pnc = [r.profile_forward(*params, cam) for _ in range(12)][4:]
+                stages_no_cull = {"project": round(statistics.median(x["project"] for x in pnc), 4),
+                                  "bin": round(statistics.median(x["scan_emit"] + x["sort"] for x in pnc), 4),
+                                  "tile_sort": round(statistics.median(x["ranges"] for x in pnc), 4),
+                                  "raster": round(statistics.median(x["raster"] for x in pnc), 4)}
             r.occlusion_cull = keep_cull
             for _ in range(3):
                 r.forward(*params, cam)
@@ -307,7 +313,7 @@ def main():
                "scene": scene, "cam": cam, "params": params, "renderer": r, "repeats": len(blocks),
                "occlusion_cull": {"active": st_run_culled, "pairs_emitted": st_run.pairs,
                                   "pairs_of_the_frame": st.pairs, "fell_back": st_run.cull_fallback,
-                                  "fps_without_the_cull": fps_no_cull},
+                                  "fps_without_the_cull": fps_no_cull, "stage_ms_without_the_cull": stages_no_cull},
                "moving_camera": {"fps": round(world * steps / dt_mv, 2), "ms_per_frame": round(dt_mv / steps * 1e3, 4),
                                  "culled": moving_culled, "dilated_cuts": moving_dilated,
                                  "what": "the camera yaws 0.01 degree (0.25 px) per frame: a new frame descriptor per frame; "
