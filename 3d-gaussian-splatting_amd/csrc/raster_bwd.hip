@@ -1566,9 +1566,7 @@ raster_backward_mfma_sh_kernel(RasterSrc S, RasterGeom G, BwdIn I, BwdOut O) {
             }
             float cA, cB, cC;
             raster_conic(g, cA, cB, cC);
-            const float opa = valid ? g.opa : 0.f;
             const float lopa = fmaxf(__log2f(g.opa), -200.0f);
-            (void)lopa;
             uint32_t slot = GS_NO_SLOT;
             if (valid) {
                 const uint4 rc = O.rects[gid];
