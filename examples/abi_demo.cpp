@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <cstring>
 #include <vector>
 
 #include "gs_abi.h"
@@ -109,6 +110,30 @@ int main(int argc, char **argv) {
     }
     std::vector<float> img((size_t)W * H * 3);
     HIP_OK(hipMemcpy(img.data(), d_img, img.size() * 4, hipMemcpyDeviceToHost));
+    // The same pose once more with GS_FRAME_OCCLUSION_CULL (include/gs_abi.h): the forward above left, per tile, the depth
+    // behind which nothing was composited; this frame drops the pairs (and skips the projection of the Gaussians) behind it.
+    // The image must be the first one's bit for bit -- a frame whose trimmed lists prove too short is rendered again from
+    // the full ones inside the call.  (The library ignores the flag where the cull does not apply: small scenes.)
+    {
+        gs_frame fc = fr;
+        fc.flags |= GS_FRAME_OCCLUSION_CULL;
+        int32_t culled = 0;
+        rc = gs_frame_is_occlusion_culled(&fc, &culled);
+        if (!rc) rc = gs_frame_forward(&fc, s);
+        int64_t st2[4] = {0, 0, 0, 0}, fell = 0;
+        if (!rc) rc = gs_frame_stats_async(&fc, st2, s);
+        if (!rc) rc = gs_frame_cull_fallback_async(&fc, &fell, s);
+        HIP_OK(hipStreamSynchronize(s));
+        std::vector<float> img2(img.size());
+        HIP_OK(hipMemcpy(img2.data(), d_img, img2.size() * 4, hipMemcpyDeviceToHost));
+        if (rc || memcmp(img.data(), img2.data(), img.size() * 4) != 0) {
+            fprintf(stderr, "occlusion-culled frame: rc %d (%s), image %s\n", rc, gs_last_error(),
+                    rc ? "-" : "differs from the unculled frame");
+            return 4;
+        }
+        printf("abi_demo: second frame with GS_FRAME_OCCLUSION_CULL: culled by the library %d, pairs emitted %lld of %lld, "
+               "fell back %lld, image identical\n", (int)culled, (long long)st2[1], (long long)stats[1], (long long)fell);
+    }
     FILE *o = fopen(argv[2], "wb");
     if (!o) return 1;
     fwrite(stats, sizeof(int64_t), 2, o);

@@ -1410,6 +1410,22 @@ def test_c_abi_client_without_torch(gpu, tmp_path):
     st = r.stats()
     assert (visible, pairs) == (st.visible, st.pairs)
     assert np.array_equal(image, ref.cpu().numpy())
+    assert "culled by the library 0" in p.stdout and "image identical" in p.stdout  # (9,000 Gaussians: the flag is ignored)
+    # the client's second frame carries GS_FRAME_OCCLUSION_CULL: on a scene of the strip variant's size, opaque, the library
+    # culls it (fewer pairs emitted), and the client itself checks that the image is the first frame's bit for bit
+    scene2, cam2 = case(150_000, W, H, seed=29)
+    scene2.opa += 3.0
+    with open(scene_file, "wb") as f:
+        f.write(struct.pack("<3i3f", scene2.n, W, H, cam2.focal_x, cam2.focal_y, cam2.near))
+        f.write(np.asarray(cam2.rot, np.float32).tobytes() + np.asarray(cam2.tran, np.float32).tobytes())
+        for a in (scene2.pos, scene2.quat, scene2.scale, scene2.opa, scene2.rgb):
+            f.write(np.ascontiguousarray(a, np.float32).tobytes())
+    p2 = subprocess.run([exe, str(scene_file), str(out_file)], capture_output=True, text=True, timeout=120)
+    assert p2.returncode == 0, p2.stderr
+    assert "culled by the library 1" in p2.stdout and "fell back 0, image identical" in p2.stdout, p2.stdout
+    import re
+    emitted, full = map(int, re.search(r"pairs emitted (\d+) of (\d+)", p2.stdout).groups())
+    assert 0 < emitted < 0.7 * full
 
 
 def test_frame_forward_is_graph_capturable(gpu):
