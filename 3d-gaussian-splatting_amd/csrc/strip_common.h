@@ -74,7 +74,9 @@ __device__ __forceinline__ void walk_strips(const uint4 rc, int64_t g, const gs_
         const uint32_t bsx0 = __shfl(sx0, src, 64), by0 = __shfl(y0, src, 64);
         const uint32_t bx0 = __shfl(x0, src, 64), bx1 = __shfl(x1, src, 64);
         const float spx = DIST ? __shfl(cxy.x, src, 64) : 0.f, spy = DIST ? __shfl(cxy.y, src, 64) : 0.f;
-        const uint32_t id = (uint32_t)__shfl((int)(uint32_t)g, src, 64);  // (not g - lane + src: a culled frame's survivors are not consecutive)
+        // (a culled frame's survivors are not consecutive Gaussians: their ids are shuffled; everybody else's follow from the lane
+        // -- one ds_bpermute less per wave-walked Gaussian: the scatter of an unculled 2.4 M frame measured 43.2 against 41.6 us)
+        const uint32_t id = CUT ? (uint32_t)__shfl((int)(uint32_t)g, src, 64) : (uint32_t)(g - lane + src);
         for (uint32_t k = lane; k < c; k += 64) emit(bsx0 + k % sp, by0 + k / sp, bx0, bx1, id, d, spx, spy);
     }
 }
