@@ -407,6 +407,34 @@ def test_occlusion_cull_with_degenerate_gaussians(gpu):
     assert culled == 6
 
 
+@pytest.mark.parametrize("seed", [1, 2])
+def test_occlusion_cull_random_walk_is_bit_exact(gpu, seed):
+    """tools/cull_fuzz.py in small: 160 frames of a random camera walk (rests, yaw steps between 0.001 and 3 degrees, small
+    translations) under the renderer's own policy -- own cuts at rest, dilated cuts near the recorded pose, none beyond,
+    adaptive back-off -- against a renderer with the cull off, bit for bit."""
+    scene, _ = _dense_case(n=150_000, W=320, H=208, seed=17)
+    params = to_torch(scene, gpu)
+    r = FrameRenderer(gpu, max_pairs=1 << 22, auto_grow=False)
+    off = FrameRenderer(gpu, max_pairs=1 << 22, auto_grow=False, occlusion_cull=False)
+    rng = np.random.default_rng(seed)
+    yaw = tx = 0.0
+    culled = dilated = 0
+    for k in range(160):
+        u = rng.random()
+        if 0.25 <= u < 0.9:
+            yaw = float(np.clip(yaw + np.exp(rng.uniform(np.log(0.001), np.log(3.0))) * (1 if rng.random() < 0.5 else -1), -20, 20))
+        elif u >= 0.9:
+            tx += float(rng.normal(0.0, 0.003))
+        cam = make_camera(320, 208, yaw_deg=yaw)
+        cam.tran = np.asarray(cam.tran, np.float32) + np.array([tx, 0.0, 0.0], np.float32)
+        img, _ = r.forward(*params, cam)
+        ref, _ = off.forward(*params, cam)
+        assert torch.equal(img, ref), (k, yaw, int(r._frame.flags), r.stats())
+        culled += int(bool(r._frame.flags & 256))
+        dilated += int(bool(r._frame.flags & 512))
+    assert culled >= 20 and dilated >= 5, (culled, dilated)
+
+
 def test_culling_mask_of_an_occlusion_culled_frame(gpu):
     """A culled frame writes the records of its projected Gaussians only: ``culling_mask()`` of such a frame re-runs the
     frustum test (the reference's global_culling operator) and equals the mask of the unculled frame; ``debug_views()``
